@@ -1,0 +1,178 @@
+/*
+ * swem_hip.h -- C ABI of libswem_hip.so: the MI355X (gfx950) implementation of the
+ * SWEM inference hot path (sequential weighted EM memory matching + the ResNet
+ * key/value encoders and mask decoder around it).
+ *
+ * The reference (lmm077/SWEM) is pure Python/PyTorch; it has no FFI.  The entry
+ * points below are what a Python binding (ctypes) of the
+ * reference's own call sites binds instead of the ATen ops those call sites launch.
+ * Every function cites the reference file:line whose arithmetic it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless stated; the library allocates nothing,
+ *     frees nothing and keeps no pointer after it returns;
+ *   - `stream` is a hipStream_t passed as void*; kernels are only enqueued, never
+ *     synchronised; the library holds no mutable global state besides the
+ *     thread-local error string;
+ *   - return value 0 = ok, <0 = error (SWEM_E_*); text via swem_last_error();
+ *   - activations are NHWC fp32 ("hwc"): [B][H][W][C], C contiguous.  The reference
+ *     tensors are NCHW; the Python side exposes NHWC memory as NCHW-shaped
+ *     channels_last views, so no copy happens at the module boundary;
+ *   - EM state uses the reference's own layouts: kappa [N][2][C][L], nu [N][2][V][L],
+ *     zita [N][2][L] (reference (B,N,2,C,L) with B folded into N).
+ */
+#ifndef SWEM_HIP_H
+#define SWEM_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWEM_ABI_VERSION 1
+
+enum {
+  SWEM_OK = 0,
+  SWEM_E_SHAPE = -1,     /* unsupported / inconsistent sizes */
+  SWEM_E_WORKSPACE = -2, /* workspace too small */
+  SWEM_E_HIP = -3,       /* a HIP call failed */
+  SWEM_E_ARG = -4        /* null pointer / bad flag */
+};
+
+/* conv flags */
+enum {
+  SWEM_CONV_RELU_IN = 1,  /* relu applied to the input while loading (ResBlock, networks.py:26-27) */
+  SWEM_CONV_RELU_OUT = 2, /* relu after scale/shift/residual */
+  SWEM_CONV_GLU = 4       /* two filter banks f,a: y = f * sigmoid(a) (modules.py:25-26) */
+};
+
+int swem_version(void);
+const char *swem_last_error(void);
+/* number of compute units of the current device (for launch heuristics / reports) */
+int swem_device_cus(void);
+
+/* ------------------------------------------------------------------------------------
+ * Dense convolution as implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ * Replaces every nn.Conv2d (+ frozen BatchNorm2d, + ReLU, + residual add) call on the
+ * path: networks.py:22-32,139-170,176-216; mod_resnet.py:58-113; modules.py:16-26;
+ * swem.py:33.
+ *   input   : up to three NHWC sources concatenated on the channel axis (x1/x2 may be
+ *             NULL); bsK = elements between consecutive batch items of source K,
+ *             0 = the same image for every batch item (replaces .expand(), swem.py:52-53,94-95)
+ *   w       : [Cout'][KH][KW][Cin], Cin = c0+c1+c2 (must be a multiple of 4);
+ *             Cout' = Cout, or 2*Cout grouped [Cout/32][2][32] when SWEM_CONV_GLU
+ *   scale   : [Cout'] or NULL (=1)     -- folded BatchNorm  gamma/sqrt(var+eps)
+ *   shift   : [Cout'] or NULL (=0)     -- conv bias and folded BatchNorm shift
+ *   res     : NHWC [B][Ho][Wo][Cout] added after scale/shift, or NULL; res_bs as bsK
+ *   y       : NHWC [B][Ho][Wo][Cout],  Ho = (H + 2*pad - KH)/stride + 1
+ *   ws      : workspace for split-K partial sums (swem_conv2d_workspace bytes)
+ */
+size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                             int flags);
+int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
+                         long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
+                         const float *w, const float *scale, const float *shift, const float *res,
+                         long long res_bs, float *y, int Cout, int KH, int KW, int stride, int pad, int flags,
+                         void *ws, size_t ws_bytes);
+
+/* ------------------------------------------------------------------------------------
+ * Pointwise / pooling / resampling kernels.
+ */
+/* (f - mean)/std, NCHW [B][3][H][W] -> NHWC [B][H][W][4] (4th channel 0).  networks.py:161
+ * mean3/std3 are HOST pointers to 3 floats (the module's registered buffers, networks.py:157-158). */
+int swem_prep_key_input_f32(void *stream, const float *frames, const float *mean3, const float *std3, float *out,
+                            int B, int H, int W);
+/* swem.py:48-53 + networks.py:115-117: per object n: [ (f-mean)/std, m[n+1], 1-m[n+1]-m[0], 0,0,0 ]
+ * (single_obj: the "others" channel is 0 and the packed weight ignores it).
+ * frame NCHW [B][3][H][W], masks [B][N+1][H][W] -> NHWC [B*N][H][W][8] */
+int swem_prep_value_input_f32(void *stream, const float *frame, const float *masks, const float *mean3,
+                              const float *std3, float *out, int B, int N, int H, int W, int single_obj);
+/* nn.MaxPool2d(3, 2, 1): mod_resnet.py:123.  NHWC, C % 4 == 0 */
+int swem_maxpool3x3s2_nhwc_f32(void *stream, const float *x, float *y, int B, int H, int W, int C);
+/* y = skip + bilinear(low -> Ho x Wo, align_corners=False): networks.py:193-194.  skip_bs 0 = shared skip */
+int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long long skip_bs, const float *low, float *y,
+                               int B, int Hl, int Wl, int Ho, int Wo, int C);
+/* F.interpolate on NCHW planes; mode 0 = nearest (legacy), 1 = bilinear align_corners=False.
+ * swem_evaluator.py:67,91 */
+int swem_resize_planes_f32(void *stream, const float *x, float *y, int planes, int Hi, int Wi, int Ho, int Wo,
+                           int mode);
+/* swem.py:79-84: hard masks (int64 or float planes, channel 0 = background skipped) nearest ->
+ * (h,w); soft masks bilinear -> (h,w); out [B*N][2][h*w] = {(1-h)(1-s), h*s} */
+int swem_mask_prep_f32(void *stream, const void *hard, int hard_is_i64, int Hh, int Wh, const float *soft, int Hs,
+                       int Ws, float *out, int B, int N, int h, int w);
+
+/* CBAM (attentions.py:22-84) on NHWC x [B][H][W][C], fused with the residual use at networks.py:46-47:
+ *   cscale[b][c] = sigmoid(mlp(avgpool(x)) + mlp(maxpool(x)))          ChannelGate
+ *   sgate[b][p]  = sigmoid(conv7x7([max_c, mean_c](x*cscale)) + b7)    SpatialGate
+ *   y = x + x * cscale * sgate                                         (block2 input = x + CBAM(x))
+ * w1 [hid][C], b1 [hid], w2 [C][hid], b2 [C], w7 [2][7][7], b7 [1]; cscale [B][C] is also returned. */
+size_t swem_cbam_workspace(int B, int H, int W, int C);
+int swem_cbam_f32(void *stream, const float *x, const float *w1, const float *b1, const float *w2, const float *b2,
+                  const float *w7, const float *b7, float *cscale, float *y, int B, int H, int W, int C, int hid,
+                  void *ws, size_t ws_bytes);
+
+/* decoder.pred: conv3x3(relu(x)) -> 1 channel (networks.py:213).  x NHWC, w [3][3][C], logit [B][H][W] */
+int swem_pred_head_f32(void *stream, const float *x, const float *w, const float *bias, float *logit, int B, int H,
+                       int W, int C);
+/* networks.py:215 + swem.py:99-106,110-116: bilinear -> (Ho,Wo), sigmoid, [prod(1-p), p] clamp, logit,
+ * softmax over N+1, argmax.  logit4 [B*N][h4][w4]; valid [B][N+1] or NULL;
+ * logits/prob [B][N+1][Ho][Wo]; argmax int64 [B][Ho][Wo] or NULL */
+int swem_decode_head_f32(void *stream, const float *logit4, const float *valid, float *logits, float *prob,
+                         long long *argmax, int B, int N, int h4, int w4, int Ho, int Wo);
+/* swem_evaluator.py:83-87: argmax over N1 planes and its one-hot, both int64 */
+int swem_argmax_onehot_i64(void *stream, const float *prob /*[B][N1][HW]*/, long long *argmax /*[B][HW]*/,
+                           long long *onehot /*[B][N1][HW] or NULL*/, int B, int N1, long long HW);
+/* batched 2-D transpose: in [batch][R][Cc] -> out [batch][Cc][ld] (ld >= R, pad columns zeroed) */
+int swem_transpose_f32(void *stream, const float *in, float *out, int batch, int R, int Cc, int ld);
+
+/* ------------------------------------------------------------------------------------
+ * Sequential weighted EM (methods/SWEM/modules.py).  NK = 2*N (object-major, class minor).
+ * Pp = P rounded up to a multiple of 8 (swem_em_pad(P)).
+ *   x     [P][C]      raw key of the frame, one row per pixel (reference x_t)
+ *   xT    [C][Pp]     the same transposed (reference x), pad columns 0
+ *   kn    [NK][L][C]  l2-normalised bases, one row per base (modules.py:115)
+ *   zT    [NK][L][Pp] responsibilities, one row per base, pad columns 0
+ */
+int swem_em_pad(int P);
+/* kn[nk][l][:] = kappa[nk][:][l] / (||kappa[nk][:][l]|| + 1e-6)   modules.py:7-9,115 */
+int swem_em_norm_bases_f32(void *stream, const float *kappa /*[NK][C][L]*/, float *kn, int NK, int C, int L);
+/* E and/or W step on one GEMM (they share x_t . l2norm(kappa)):
+ *   do_w: weights = masks * (1 - p_own)          modules.py:93-110  -> w_out [NK][P]
+ *   do_e: z = softmax((s - rowmax)/tau) * weights modules.py:112-120 -> zT
+ *         (weights = result of do_w when set, else w_in [NK][P]) */
+int swem_em_ew_f32(void *stream, const float *x, const float *kn, const float *masks /*[NK][P]*/,
+                   const float *w_in, float *w_out, float *zT, int N, int C, int P, int L, float tau, int do_w,
+                   int do_e);
+/* M step, modules.py:122-127 (rows = C, A = xT, a_batch_div = 0) and the value update
+ * modules.py:164-165 (rows = V, A = vT [N][V][Pp], a_batch_div = 2):
+ *   zita = zita_prev + sum_p z ;  out = (zita_prev * prev + A . z) / zita
+ * prev/out [NK][R][L]; zita_prev/zita_out [NK][L]; kn_out (optional, rows == C only) [NK][L][R] */
+size_t swem_em_mstep_workspace(int NK, int R, int P, int L);
+int swem_em_mstep_f32(void *stream, const float *A, int a_batch_div, const float *zT, const float *prev,
+                      const float *zita_prev, float *out, float *zita_out, float *kn_out, int NK, int R, int P,
+                      int L, void *ws, size_t ws_bytes);
+/* whole SWEMCore.swem() for one frame (modules.py:129-168): T x (E, M, W) + value update.
+ *   v [N][P][V] NHWC value map; masks [N][2][P]; *_prev = prior bases (random_init output on frame 0) */
+size_t swem_memorize_workspace(int N, int C, int V, int P, int L);
+int swem_memorize_f32(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
+                      const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out,
+                      float *zita_out, int N, int C, int V, int P, int L, int T, float tau, void *ws,
+                      size_t ws_bytes);
+
+/* ------------------------------------------------------------------------------------
+ * Matching (modules.py:198-208, 232-289): l2norm, affinity, joint {bg,fg} softmax, value
+ * readout and the top-l prefix-sum features, for all objects of one frame.
+ *   qk [P][C] raw query key; banks: kappa_k [N][2][C][L], nu_k [N][2][V][L], k = first / update
+ *   (update may be NULL on the first matched frame: Lm = L, else Lm = 2L)
+ *   mem_out [N][P][V], S [N][P][2*topl]  (NHWC sources of the fusion conv, modules.py:291)
+ */
+size_t swem_match_workspace(int N, int C, int V, int P, int L, int nbanks);
+int swem_match_f32(void *stream, const float *qk, const float *kappa_first, const float *nu_first,
+                   const float *kappa_update, const float *nu_update, float *mem_out, float *S, int N, int C,
+                   int V, int P, int L, int topl, float tau, void *ws, size_t ws_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWEM_HIP_H */

@@ -1,0 +1,398 @@
+"""CPU oracle for the SWEM hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (torch CPU ops, fp32) of the reference algorithm
+for the path BASELINE.json names.  It exists so that the HIP path can be checked
+against something that is *not* the HIP path.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it; the product package ``swem_amd`` never does.
+
+Parity status: PINNED for everything except the torchvision trunk.
+  * EM / matching / mask prep / value encoder / decoder / frame loop are checked
+    against the reference's own Python (imported from /root/reference with the
+    shims in ``tests/golden/make_golden.py``); the resulting vectors are
+    committed under ``tests/golden/`` and re-checked by ``tests/test_oracle_golden.py``.
+  * key-encoder trunk: the reference takes it from ``torchvision.models.resnet18/50``
+    (requirements.txt:10, unpinned, not vendored, not installed here).  The
+    topology below restates the published torchvision v1.5 ResNet
+    (stride on the 3x3 of the bottleneck, bias-free convs, BN after every conv);
+    it is checked against the reference's ``mod_resnet`` trunk with zero conv
+    biases (same topology), which is as far as this container allows:
+    "parity unpinned" for torchvision itself.
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference).  State dict keys are the reference's.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+EPS_L2 = 1e-6
+BN_EPS = 1e-5
+
+
+# --------------------------------------------------------------------------- #
+# EM core (methods/SWEM/modules.py)
+# --------------------------------------------------------------------------- #
+def l2norm(t, dim):
+    """modules.py:7-9 -- eps is added AFTER the sqrt."""
+    return t / (torch.linalg.norm(t, dim=dim, keepdim=True) + EPS_L2)
+
+
+def random_init(size, valdim, dtype=torch.float32):
+    """modules.py:170-178.  Draws from the global torch CPU generator, like the
+    reference does for CPU tensors, so a shared manual_seed gives equal bases."""
+    b, n, _, _, nb = size
+    kappa = torch.zeros(size, dtype=dtype)
+    kappa.normal_(0, math.sqrt(2.0 / nb))
+    kappa = l2norm(kappa, dim=-2)
+    nu = torch.zeros(b, n, 2, valdim, nb, dtype=dtype)
+    zita = torch.zeros(b, n, 2, 1, nb, dtype=dtype) + 1e-6
+    return kappa, nu, zita
+
+
+def e_step(x_t, kappa, weights, tau):
+    """modules.py:112-120.  x_t (B,1,1,P,C) is the RAW key; kappa (B,N,2,C,L)."""
+    s = torch.matmul(x_t, l2norm(kappa, dim=-2))
+    s = (s - s.max(dim=-1, keepdim=True)[0]) / tau
+    return F.softmax(s, dim=-1) * weights
+
+
+def m_step(z, x, kappa_prev, zita_prev):
+    """modules.py:122-127.  The prior is the previous FRAME's (kappa_, zita_)."""
+    zita = zita_prev + z.sum(dim=-2, keepdim=True)
+    kappa = (zita_prev * kappa_prev + torch.matmul(x, z)) / zita
+    return kappa, zita
+
+
+def w_step(kappa, x_t, masks, tau):
+    """modules.py:93-110.  Joint {bg,fg} max, literal ``1 - p``."""
+    c = torch.matmul(l2norm(x_t, dim=-1), l2norm(kappa, dim=-2))
+    m = c.max(dim=-1, keepdim=True)[0].max(dim=2, keepdim=True)[0]
+    se = torch.exp((c - m) / tau).sum(dim=-1, keepdim=True)
+    p = se / se.sum(dim=2, keepdim=True)
+    return masks * (1 - p)
+
+
+def swem(x, v, masks, bases_prev, n_bases, n_iters, tau, valdim):
+    """modules.py:129-168.  x (B,C,h,w), v (B,N,V,h,w), masks (B,N,2,h,w)."""
+    b, ck, _, _ = x.shape
+    n = masks.shape[1]
+    if bases_prev is None:
+        kappa_, nu_, zita_ = random_init((b, n, 2, ck, n_bases), valdim, x.dtype)
+    else:
+        kappa_, nu_, zita_ = bases_prev['kappa'], bases_prev['nu'], bases_prev['zita']
+    n_new = n - kappa_.shape[1]
+    if n_new > 0:  # modules.py:140-146 (objects that appear later)
+        k2, n2, z2 = random_init((b, n_new, 2, ck, n_bases), valdim, x.dtype)
+        kappa_ = torch.cat([kappa_, k2], 1)
+        nu_ = torch.cat([nu_, n2], 1)
+        zita_ = torch.cat([zita_, z2], 1)
+
+    xf = x.flatten(2)[:, None, None]            # B,1,1,C,P
+    x_t = xf.transpose(-2, -1)                   # B,1,1,P,C
+    mk = masks.flatten(3).unsqueeze(-1)          # B,N,2,P,1
+    weights = mk.clone()
+    kappa = kappa_.clone()
+    z = zita = None
+    for it in range(n_iters):
+        z = e_step(x_t, kappa, weights, tau)
+        kappa, zita = m_step(z, xf, kappa_, zita_)
+        if it < n_iters - 1:
+            weights = w_step(kappa, x_t, mk, tau)
+    mv = v.flatten(3).unsqueeze(2)               # B,N,1,V,P
+    nu = (zita_ * nu_ + torch.matmul(mv, z)) / zita   # modules.py:164-165
+    return {'kappa': kappa, 'nu': nu, 'zita': zita}
+
+
+def perm_inv_feat(e, topl):
+    """modules.py:198-208.  e (BN,2,Lm,h,w) after exp.  The prefix sums are added
+    strictly left to right like the reference's Python loop (torch.cumsum rounds
+    differently by ~2e-7, checked in make_golden.py), so this stays bit-exact."""
+    top = torch.topk(e, k=topl, dim=2)[0]
+    planes = [top[:, :, 0]]
+    for i in range(1, topl):
+        planes.append(planes[-1] + top[:, :, i])
+    c = torch.stack(planes, dim=2)
+    f = c[:, 0] / (c[:, 0] + c[:, 1])
+    return torch.cat([f, 1 - f], dim=1)
+
+
+def get_affinity(qk, mk, mv, tau, topl):
+    """modules.py:232-276, default branch (:264-266).  qk and mk already l2-normed."""
+    b, _, h, w = qk.shape
+    n = mk.shape[1]
+    q = qk.flatten(2)[:, None, None]                           # B,1,1,C,P
+    aff = torch.matmul(mk.transpose(-2, -1), q)                # B,N,2,Lm,P
+    m = aff.max(dim=2, keepdim=True)[0].max(dim=3, keepdim=True)[0]
+    e = torch.exp((aff - m) / tau)
+    p = (e / e.sum(dim=[2, 3], keepdim=True)).flatten(2, 3)    # B,N,2Lm,P
+    s_feat = perm_inv_feat(e.view(b * n, 2, -1, h, w), topl)
+    mvf = mv.transpose(2, 3).flatten(-2)                       # B,N,V,2Lm
+    mem_out = torch.matmul(mvf, p).view(b, n, -1, h, w)
+    return s_feat, mem_out
+
+
+class MemoryBank:
+    """modules.py:29-60."""
+
+    def __init__(self, fixed):
+        self.fixed = fixed
+        self.bases = None
+        self.n_objs = 0
+
+    def reset(self):
+        self.bases, self.n_objs = None, 0
+
+    def update(self, bases):
+        if not self.fixed:
+            self.bases = bases
+            return
+        if self.bases is None:
+            self.bases = bases
+        else:
+            n = bases['kappa'].shape[1]
+            if n > self.n_objs:
+                self.bases = {k: torch.cat([self.bases[k], bases[k][:, self.n_objs:]], 1)
+                              for k in bases}
+        self.n_objs = bases['kappa'].shape[1]
+
+
+class Core:
+    """SWEMCore bank policy: modules.py:63-88, 183-193, 278-306."""
+
+    def __init__(self, n_bases=256, valdim=512, n_iters=4, tau=0.05, topl=64):
+        self.n_bases, self.valdim, self.n_iters, self.tau = n_bases, valdim, n_iters, tau
+        self.topl = int(min(n_bases, topl))
+        self.first = MemoryBank(fixed=True)
+        self.upd = MemoryBank(fixed=False)
+
+    def empty(self):
+        self.first.reset()
+        self.upd.reset()
+
+    def memorize(self, qk, qv, masks):
+        prior = self.first.bases if self.upd.bases is None else self.upd.bases
+        bases = swem(qk, qv, masks, prior, self.n_bases, self.n_iters, self.tau, self.valdim)
+        had_first = self.first.bases is not None
+        self.first.update(bases)
+        if had_first:
+            self.upd.update(bases)
+        return bases
+
+    def get_mem(self):
+        banks = [b.bases for b in (self.first, self.upd) if b.bases is not None]
+        return (torch.cat([b['kappa'] for b in banks], -1),
+                torch.cat([b['nu'] for b in banks], -1))
+
+    def match_features(self, qk, qv):
+        """modules.py:278-289 up to (not including) the fusion conv."""
+        mk, mv = self.get_mem()
+        s_feat, mem_out = get_affinity(l2norm(qk, 1), l2norm(mk, -2), mv, self.tau, self.topl)
+        qv_e = qv.unsqueeze(1).expand_as(mem_out).flatten(0, 1)
+        return mem_out.flatten(0, 1), qv_e, s_feat, mk.shape[1]
+
+
+# --------------------------------------------------------------------------- #
+# Networks (methods/basic_modules/{networks,mod_resnet,attentions}.py)
+# --------------------------------------------------------------------------- #
+def conv(sd, name, x, stride=1, pad=None):
+    w = sd[name + '.weight']
+    if pad is None:
+        pad = w.shape[-1] // 2
+    return F.conv2d(x, w, sd.get(name + '.bias'), stride=stride, padding=pad)
+
+
+def bn(sd, name, x):
+    """Frozen (eval-mode) BatchNorm2d; the trainer also forces eval (swem_trainer.py:39)."""
+    return F.batch_norm(x, sd[name + '.running_mean'], sd[name + '.running_var'],
+                        sd[name + '.weight'], sd[name + '.bias'], False, 0.0, BN_EPS)
+
+
+def basic_block(sd, p, x, stride):
+    """mod_resnet.py:45-74 / torchvision BasicBlock."""
+    out = F.relu(bn(sd, p + '.bn1', conv(sd, p + '.conv1', x, stride)))
+    out = bn(sd, p + '.bn2', conv(sd, p + '.conv2', out))
+    if (p + '.downsample.0.weight') in sd:
+        x = bn(sd, p + '.downsample.1', conv(sd, p + '.downsample.0', x, stride, 0))
+    return F.relu(out + x)
+
+
+def bottleneck(sd, p, x, stride):
+    """mod_resnet.py:77-113 / torchvision v1.5 Bottleneck (stride on the 3x3)."""
+    out = F.relu(bn(sd, p + '.bn1', conv(sd, p + '.conv1', x, 1, 0)))
+    out = F.relu(bn(sd, p + '.bn2', conv(sd, p + '.conv2', out, stride)))
+    out = bn(sd, p + '.bn3', conv(sd, p + '.conv3', out, 1, 0))
+    if (p + '.downsample.0.weight') in sd:
+        x = bn(sd, p + '.downsample.1', conv(sd, p + '.downsample.0', x, stride, 0))
+    return F.relu(out + x)
+
+
+RESNET_LAYERS = {'resnet18': (basic_block, (2, 2, 2)), 'resnet50': (bottleneck, (3, 4, 6))}
+
+
+def resnet_stage(sd, p, x, block, nblocks, stride):
+    for i in range(nblocks):
+        x = block(sd, f'{p}.{i}', x, stride if i == 0 else 1)
+    return x
+
+
+def trunk(sd, p, x, backbone, layer_names):
+    """stem + three stages: networks.py:160-170 (key) and :119-125 (value)."""
+    block, nb = RESNET_LAYERS[backbone]
+    x = F.relu(bn(sd, p + '.bn1', conv(sd, p + '.conv1', x, 2, 3)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    f4 = resnet_stage(sd, f'{p}.{layer_names[0]}', x, block, nb[0], 1)
+    f8 = resnet_stage(sd, f'{p}.{layer_names[1]}', f4, block, nb[1], 2)
+    f16 = resnet_stage(sd, f'{p}.{layer_names[2]}', f8, block, nb[2], 2)
+    return f16, f8, f4
+
+
+def res_block(sd, p, x):
+    """networks.py:12-32 (pre-activation residual block, optional 3x3 downsample)."""
+    r = conv(sd, p + '.conv1', F.relu(x))
+    r = conv(sd, p + '.conv2', F.relu(r))
+    if (p + '.downsample.weight') in sd:
+        x = conv(sd, p + '.downsample', x)
+    return x + r
+
+
+def cbam(sd, p, x):
+    """attentions.py:22-84."""
+    def mlp(t):
+        t = F.linear(t.flatten(1), sd[p + '.ChannelGate.mlp.1.weight'], sd[p + '.ChannelGate.mlp.1.bias'])
+        return F.linear(F.relu(t), sd[p + '.ChannelGate.mlp.3.weight'], sd[p + '.ChannelGate.mlp.3.bias'])
+    hw = x.shape[-2:]
+    att = mlp(F.avg_pool2d(x, hw, stride=hw)) + mlp(F.max_pool2d(x, hw, stride=hw))
+    x = x * torch.sigmoid(att)[:, :, None, None]
+    comp = torch.cat([x.max(1, keepdim=True)[0], x.mean(1, keepdim=True)], 1)
+    return x * torch.sigmoid(conv(sd, p + '.SpatialGate.spatial.conv', comp, 1, 3))
+
+
+def encode_key(sd, cfg, frames):
+    """swem.py:39-43 + networks.py:160-182."""
+    f = (frames - sd['key_encoder.mean']) / sd['key_encoder.std']
+    s16, s8, s4 = trunk(sd, 'key_encoder', f, cfg.BACKBONE, ('res2', 'layer2', 'layer3'))
+    return conv(sd, 'key_proj.key_proj', s16), conv(sd, 'key_comp', s16), s16, s8, s4
+
+
+def encode_value(sd, cfg, frame, masks, s16):
+    """swem.py:45-62 + networks.py:56-129 + :35-50."""
+    n = masks.shape[1] - 1
+    others = 1 - masks - masks[:, 0:1]
+    m_fg = masks[:, 1:].flatten(0, 1).unsqueeze(1)
+    m_ot = others[:, 1:].flatten(0, 1).unsqueeze(1)
+    fr = frame.unsqueeze(1).expand(-1, n, -1, -1, -1).flatten(0, 1)
+    s16e = s16.unsqueeze(1).expand(-1, n, -1, -1, -1).flatten(0, 1)
+    img = (fr - sd['value_encoder.mean']) / sd['value_encoder.std']
+    f = torch.cat([img, m_fg] if cfg.SINGLE_OBJ else [img, m_fg, m_ot], 1)
+    x, _, _ = trunk(sd, 'value_encoder', f, 'resnet18', ('layer1', 'layer2', 'layer3'))
+    x = res_block(sd, 'value_encoder.fuser.block1', torch.cat([x, s16e], 1))
+    x = res_block(sd, 'value_encoder.fuser.block2', x + cbam(sd, 'value_encoder.fuser.attention', x))
+    return x.view(-1, n, *x.shape[1:])
+
+
+def mask_prep(masks_hard, masks_soft, h16, w16):
+    """swem.py:77-84."""
+    mh = F.interpolate(masks_hard[:, 1:].float(), size=(h16, w16), mode='nearest')
+    ms = F.interpolate(masks_soft[:, 1:], size=(h16, w16), mode='bilinear')
+    return torch.stack([(1 - mh) * (1 - ms), mh * ms], dim=2)
+
+
+def fusion_layer(sd, x):
+    """modules.py:13-26 (GLU)."""
+    return conv(sd, 'swem_core.fusion_layer.layer_f', x) * torch.sigmoid(conv(sd, 'swem_core.fusion_layer.layer_a', x))
+
+
+def aggregate(prob):
+    """swem.py:110-116."""
+    p = torch.cat([torch.prod(1 - prob, dim=1, keepdim=True), prob], 1).clamp(1e-7, 1 - 1e-7)
+    return torch.log(p / (1 - p))
+
+
+def decoder_logit(sd, context, s8e, s4e):
+    """networks.py:199-213, up to the single-channel 1/4-scale logit."""
+    x = res_block(sd, 'decoder.compress', context)
+    sk = conv(sd, 'decoder.up_16_8.skip_conv', s8e)
+    x = res_block(sd, 'decoder.up_16_8.out_conv',
+                  sk + F.interpolate(x, size=sk.shape[-2:], mode='bilinear', align_corners=False))
+    sk = conv(sd, 'decoder.up_8_4.skip_conv', s4e)
+    x = res_block(sd, 'decoder.up_8_4.out_conv',
+                  sk + F.interpolate(x, size=sk.shape[-2:], mode='bilinear', align_corners=False))
+    return conv(sd, 'decoder.pred', F.relu(x))
+
+
+def decode(sd, n, context, s8, s4, valid_obj, out_size):
+    """swem.py:92-108."""
+    s8e = s8.unsqueeze(1).expand(-1, n, -1, -1, -1).flatten(0, 1)
+    s4e = s4.unsqueeze(1).expand(-1, n, -1, -1, -1).flatten(0, 1)
+    lg = decoder_logit(sd, context, s8e, s4e)
+    lg = F.interpolate(lg, size=out_size, mode='bilinear', align_corners=False)
+    preds = torch.sigmoid(lg).view(-1, n, *lg.shape[-2:])
+    if valid_obj is not None:
+        preds = preds * valid_obj[:, 1:, None, None]
+    logits = aggregate(preds)
+    return logits, F.softmax(logits, dim=1)
+
+
+class Model:
+    """Functional counterpart of SWEM(nn.Module) (swem.py:9-133) over a plain state dict."""
+
+    def __init__(self, sd, cfg):
+        self.sd, self.cfg = sd, cfg
+        self.core = Core(cfg.NUM_BASES, cfg.VALDIM, cfg.NUM_EM_ITERS, cfg.EM_TAU, cfg.TOPL)
+
+    def __call__(self, mode, *a):
+        sd, cfg = self.sd, self.cfg
+        if mode == 'encode_key':
+            return encode_key(sd, cfg, *a)
+        if mode == 'encode_value':
+            return encode_value(sd, cfg, *a)
+        if mode == 'init':
+            qk, mv, mask = a
+            self.core.empty()
+            return self('memorize', qk, mv, mask, mask.float())
+        if mode == 'memorize':
+            qk, mv, mh, ms = a
+            return self.core.memorize(qk, mv, mask_prep(mh, ms, qk.shape[-2], qk.shape[-1]))
+        if mode == 'match':
+            mem_out, qv_e, s_feat, n = self.core.match_features(*a)
+            return fusion_layer(sd, torch.cat([mem_out, qv_e, s_feat], 1)), n
+        if mode == 'segment':
+            return decode(sd, *a)
+        raise NotImplementedError(mode)
+
+
+def evaluate_seq(model, frames, init_masks, out_size, trace=None):
+    """swem_evaluator.py:59-102: encode_key -> match -> segment -> argmax/one-hot ->
+    [bilinear -> encode_value -> memorize] for every frame but the last."""
+    b, t, _, h, w = frames.shape
+    preds, scores = [], []
+    mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+    m0 = F.interpolate(init_masks[0], size=(h, w), mode='nearest')
+    mv16 = model('encode_value', frames[:, 0], m0.float(), s16)
+    model('init', mk16, mv16, init_masks[0])
+    for i in range(1, t):
+        qk16, qv16, s16, s8, s4 = model('encode_key', frames[:, i])
+        context, n = model('match', qk16, qv16)
+        logits, pred_mask = model('segment', n, context, s8, s4, None, out_size)
+        scores.append(pred_mask.clone())
+        pred = torch.argmax(pred_mask, dim=1, keepdim=True)
+        hard = (pred.expand(-1, n + 1, -1, -1) ==
+                torch.arange(n + 1).view(1, -1, 1, 1)).type_as(pred)
+        if trace is not None:
+            trace.append({'qk16': qk16, 'context': context, 'logits': logits})
+        if i < t - 1:
+            pm = F.interpolate(pred_mask, size=(h, w), mode='bilinear', align_corners=False)
+            mv16 = model('encode_value', frames[:, i], pm, s16)
+            model('memorize', qk16, mv16, hard, pm)
+        preds.append(pred[:, 0])
+    return preds, scores
+
+
+def make_cfg(**kw):
+    base = dict(KEYDIM=128, VALDIM=512, NUM_BASES=256, NUM_EM_ITERS=4, EM_TAU=0.05, TOPL=64,
+                SINGLE_OBJ=False, BACKBONE='resnet50')
+    base.update(kw)
+    return SimpleNamespace(**base)

@@ -1,0 +1,78 @@
+"""ctypes binding of libswem_hip.so (C ABI: include/swem_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this module raises.
+Build the library with ``python -m swem_amd.build`` (or ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libswem_hip.so')
+
+_p, _i, _ll, _f, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol include/swem_hip.h declares
+# (tests/test_abi.py cross-checks against the header).
+SIGNATURES = {
+    'swem_version': (_i, []),
+    'swem_last_error': (C.c_char_p, []),
+    'swem_device_cus': (_i, []),
+    'swem_conv2d_workspace': (_sz, [_i] * 10),
+    'swem_conv2d_nhwc_f32': (_i, [_p, _p, _i, _ll, _p, _i, _ll, _p, _i, _ll, _i, _i, _i, _p, _p, _p, _p, _ll, _p,
+                                  _i, _i, _i, _i, _i, _i, _p, _sz]),
+    'swem_prep_key_input_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i]),
+    'swem_prep_value_input_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i]),
+    'swem_maxpool3x3s2_nhwc_f32': (_i, [_p, _p, _p, _i, _i, _i, _i]),
+    'swem_upsample_add_nhwc_f32': (_i, [_p, _p, _ll, _p, _p, _i, _i, _i, _i, _i, _i]),
+    'swem_resize_planes_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i]),
+    'swem_mask_prep_f32': (_i, [_p, _p, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i]),
+    'swem_cbam_workspace': (_sz, [_i, _i, _i, _i]),
+    'swem_cbam_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz]),
+    'swem_pred_head_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i]),
+    'swem_decode_head_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
+    'swem_argmax_onehot_i64': (_i, [_p, _p, _p, _p, _i, _i, _ll]),
+    'swem_transpose_f32': (_i, [_p, _p, _p, _i, _i, _i, _i]),
+    'swem_em_pad': (_i, [_i]),
+    'swem_em_norm_bases_f32': (_i, [_p, _p, _p, _i, _i, _i]),
+    'swem_em_ew_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i]),
+    'swem_em_mstep_workspace': (_sz, [_i, _i, _i, _i]),
+    'swem_em_mstep_f32': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz]),
+    'swem_memorize_workspace': (_sz, [_i, _i, _i, _i, _i]),
+    'swem_memorize_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _sz]),
+    'swem_match_workspace': (_sz, [_i, _i, _i, _i, _i, _i]),
+    'swem_match_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _sz]),
+}
+
+_lib = None
+
+
+class SwemHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise (never fall back) if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SwemHipError('%s not found: build it with `python -m swem_amd.build`; '
+                               'swem_amd has no CPU fallback' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on a negative status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise SwemHipError('%s failed (%d): %s' % (name, rc, lib.swem_last_error().decode()))
+
+
+def query(name, *args):
+    """Call a size/int query (no status convention)."""
+    return getattr(load(), name)(*args)

@@ -1,0 +1,69 @@
+// Shared helpers for libswem_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/swem_hip.h"
+
+void swem_set_error(const char *fmt, ...);
+// em.hip: l2-normalise + transpose one bank of key bases into rows [out_off, out_off+L) of [NK][out_rows][C]
+int swem_norm_bases_into(void *stream, const float *kappa, float *kn, int NK, int C, int L, int out_rows,
+                         int out_off);
+// raise the dynamic-LDS limit of a kernel once (needed above 64 KiB)
+#define SWEM_ALLOW_LDS(kernel, bytes)                                                                   \
+  do {                                                                                                  \
+    static bool done_ = false;                                                                          \
+    if (!done_) {                                                                                       \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),                       \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));    \
+      if (e_ != hipSuccess) {                                                                           \
+        swem_set_error("hipFuncSetAttribute(%s): %s", #kernel, hipGetErrorString(e_));                  \
+        return SWEM_E_HIP;                                                                              \
+      }                                                                                                 \
+      done_ = true;                                                                                     \
+    }                                                                                                   \
+  } while (0)
+
+#define SWEM_REQUIRE(cond, code, ...)  \
+  do {                                 \
+    if (!(cond)) {                     \
+      swem_set_error(__VA_ARGS__);     \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+#define SWEM_CHECK_LAUNCH(name)                                    \
+  do {                                                             \
+    hipError_t e_ = hipGetLastError();                             \
+    if (e_ != hipSuccess) {                                        \
+      swem_set_error("%s: %s", (name), hipGetErrorString(e_));     \
+      return SWEM_E_HIP;                                           \
+    }                                                              \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SWEM_L2_EPS 1e-6f
+
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
+// D[i][j] lives in lane (j + 32*hi), register r with i = (r & 3) + 8 * (r >> 2) + 4 * hi.
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// Four k-steps from one float4 per operand.  Lane half h holds k = 4*(2j+h) + e, e = 0..3: the k order is a
+// permutation of 0..7 that A and B share, so the sum is the same set of products.
+__device__ __forceinline__ f32x16 mfma32x4(float4 a, float4 b, f32x16 c) {
+  c = mfma32(a.x, b.x, c);
+  c = mfma32(a.y, b.y, c);
+  c = mfma32(a.z, b.z, c);
+  c = mfma32(a.w, b.w, c);
+  return c;
+}
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -1,0 +1,388 @@
+// Implicit-GEMM convolution on the gfx950 fp32 matrix cores.
+//
+//   GEMM view:  Y[m][n] = sum_k A[m][k] * Wt[n][k]
+//     m = output pixel (b, oy, ox)            M = B*Ho*Wo
+//     n = output filter                       Ncols = Cout (2*Cout for the GLU pair)
+//     k = (ky, kx, ci), ci fastest            K = KH*KW*Cin
+//   A is never materialised: each thread gathers 16-byte channel groups of the NHWC input
+//   (up to three concatenated sources, optional broadcast over the batch, optional input ReLU).
+//
+// Block = 256 threads = 4 waves in a 2x2 grid; wave tile = (32*WM) x (32*WN) outputs built from
+// v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).  K is walked in 32-wide blocks that
+// are register-staged (global -> VGPR while the previous block is multiplied, then VGPR -> LDS)
+// into a double-buffered LDS image  [k/4][row][4 floats], row stride padded by one 16-byte slot:
+//   - the 8 lanes that write one row hit 8 different slots (stride BM+1 is odd),
+//   - a ds_read_b128 of 16 consecutive rows is conflict free,
+//   - one float4 per operand feeds 4 MFMAs (lane half h owns k = 4*(2j+h)..+3).
+// The epilogue applies scale/shift (bias + folded frozen BatchNorm), the residual, ReLU or the GLU gate
+// and stores NHWC: 32 consecutive channels per half wave = one 128-byte segment.
+//
+// Layers whose grid would not fill the 256 CUs split K over blockIdx.z; the partial sums go to a
+// workspace and a second kernel reduces them in a fixed order (deterministic) and runs the epilogue.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int KQ = BK / 4;  // float4 slots per row per k-block
+
+struct ConvP {
+  const float *x[3];
+  int c[3];
+  long long bs[3];
+  int B, H, W, Ho, Wo, Cin, K, M;
+  const float *w, *scale, *shift, *res;
+  long long res_bs;
+  float *y;
+  int Cout, Ncols, KH, KW, stride, pad, flags;
+  int nkb, kb_per_split;
+  float *partial;
+};
+
+__device__ __forceinline__ float4 relu4(float4 v) {
+  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int SA = BM + 1, SB = BN + 1;  // row strides in float4 slots
+  constexpr int RA = BM / 32, RB = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *As = reinterpret_cast<float4 *>(smem);  // [2][KQ][SA]
+  float4 *Bs = As + 2 * KQ * SA;                  // [2][KQ][SB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  // ---- per-thread gather coordinates (fixed over the K loop) ----
+  const int kq = tid & 7, rbase = tid >> 3;
+  int iy0[RA], ix0[RA], bidx[RA];
+  bool rowok[RA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    int m = m0 + rbase + 32 * i;
+    rowok[i] = m < p.M;
+    int b = m / HoWo;
+    int rem = m - b * HoWo;
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    iy0[i] = oy * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.pad;
+    bidx[i] = b;
+  }
+  const float *wrow[RB];
+  bool colok[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    int n = n0 + rbase + 32 * i;
+    colok[i] = n < p.Ncols;
+    wrow[i] = p.w + (long long)(colok[i] ? n : 0) * p.K;
+  }
+  const bool relu_in = p.flags & SWEM_CONV_RELU_IN;
+
+  float4 ga[RA], gb[RB];
+  auto gload = [&](int kb) {
+    const int k = kb * BK + kq * 4;
+    const bool kok = k < p.K;
+    int tap = k / p.Cin;
+    int ci = k - tap * p.Cin;
+    int ky = tap / p.KW, kx = tap - ky * p.KW;
+    // channel -> (source, local channel) by selects: no runtime-indexed arrays (they would go to scratch)
+    const float *src = p.x[0];
+    int cs = p.c[0];
+    long long sbs = p.bs[0];
+    if (ci >= p.c[0]) {
+      ci -= p.c[0];
+      src = p.x[1];
+      cs = p.c[1];
+      sbs = p.bs[1];
+      if (ci >= p.c[1]) {
+        ci -= p.c[1];
+        src = p.x[2];
+        cs = p.c[2];
+        sbs = p.bs[2];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int iy = iy0[i] + ky, ix = ix0[i] + kx;
+      bool ok = kok && rowok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4 *>(src + bidx[i] * sbs + ((long long)iy * p.W + ix) * cs + ci);
+      ga[i] = relu_in ? relu4(v) : v;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kok && colok[i]) v = *reinterpret_cast<const float4 *>(wrow[i] + k);
+      gb[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) As[(buf * KQ + kq) * SA + rbase + 32 * i] = ga[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) Bs[(buf * KQ + kq) * SB + rbase + 32 * i] = gb[i];
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int kb_begin = blockIdx.z * p.kb_per_split;
+  const int kb_end = min(p.nkb, kb_begin + p.kb_per_split);
+
+  gload(kb_begin);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kb = kb_begin; kb < kb_end; ++kb) {
+    const bool more = kb + 1 < kb_end;
+    if (more) gload(kb + 1);
+    const float4 *Ab = As + buf * KQ * SA + wm * 32 * WM + r;
+    const float4 *Bb = Bs + buf * KQ * SB + wn * 32 * WN + r;
+#pragma unroll
+    for (int j = 0; j < KQ / 2; ++j) {
+      float4 a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = Ab[(2 * j + h) * SA + 32 * i];
+#pragma unroll
+      for (int i = 0; i < WN; ++i) b[i] = Bb[(2 * j + h) * SB + 32 * i];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < WN; ++jn) acc[i][jn] = mfma32x4(a[i], b[jn], acc[i][jn]);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue ----
+  const int mrow0 = m0 + wm * 32 * WM;
+  const int ncol0 = n0 + wn * 32 * WN;
+  if (p.partial) {  // split-K: raw partial sums, [z][M][Ncols]
+    float *dst = p.partial + (long long)blockIdx.z * p.M * p.Ncols;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < WN; ++jn) {
+        int n = ncol0 + 32 * jn + r;
+        if (n >= p.Ncols) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int m = mrow0 + 32 * i + acc_row(e, h);
+          if (m < p.M) dst[(long long)m * p.Ncols + n] = acc[i][jn][e];
+        }
+      }
+    return;
+  }
+  const bool relu_out = p.flags & SWEM_CONV_RELU_OUT;
+  if constexpr (WN == 2) {
+    if (p.flags & SWEM_CONV_GLU) {
+      // packed columns [group][f|a][32]: this wave's two N tiles are the f and a banks of one group
+      const int nf = ncol0 + r, na = ncol0 + 32 + r;
+      if (na >= p.Ncols) return;
+      const int co = (ncol0 >> 1) + r;
+      const float scf = p.scale ? p.scale[nf] : 1.f, sca = p.scale ? p.scale[na] : 1.f;
+      const float shf = p.shift ? p.shift[nf] : 0.f, sha = p.shift ? p.shift[na] : 0.f;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int m = mrow0 + 32 * i + acc_row(e, h);
+          if (m < p.M) {
+            float f = acc[i][0][e] * scf + shf, a = acc[i][1][e] * sca + sha;
+            p.y[(long long)m * p.Cout + co] = f * sigmoidf_(a);
+          }
+        }
+      return;
+    }
+  }
+#pragma unroll
+  for (int jn = 0; jn < WN; ++jn) {
+    const int n = ncol0 + 32 * jn + r;
+    if (n >= p.Ncols) continue;
+    const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int m = mrow0 + 32 * i + acc_row(e, h);
+        if (m < p.M) {
+          float v = acc[i][jn][e] * sc + sh;
+          if (p.res) {
+            int b = m / HoWo;
+            v += p.res[(long long)b * p.res_bs + (long long)(m - b * HoWo) * p.Cout + n];
+          }
+          if (relu_out) v = fmaxf(v, 0.f);
+          p.y[(long long)m * p.Cout + n] = v;
+        }
+      }
+  }
+}
+
+// Reduce split-K partials in z order and apply the same epilogue.  One thread per 4 output channels.
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int nsplit) {
+  const bool glu = p.flags & SWEM_CONV_GLU;
+  const int cq = p.Cout / 4;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)p.M * cq) return;
+  const int m = (int)(idx / cq);
+  const int co = (int)(idx - (long long)m * cq) * 4;
+  const long long MN = (long long)p.M * p.Ncols;
+  auto sum4 = [&](int col) {
+    const float *src = p.partial + (long long)m * p.Ncols + col;
+    float4 s = *reinterpret_cast<const float4 *>(src);
+    for (int z = 1; z < nsplit; ++z) {
+      float4 t = *reinterpret_cast<const float4 *>(src + z * MN);
+      s.x += t.x;
+      s.y += t.y;
+      s.z += t.z;
+      s.w += t.w;
+    }
+    return s;
+  };
+  auto affine4 = [&](float4 s, int col) {
+    float4 sc = p.scale ? *reinterpret_cast<const float4 *>(p.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 sh = p.shift ? *reinterpret_cast<const float4 *>(p.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return make_float4(s.x * sc.x + sh.x, s.y * sc.y + sh.y, s.z * sc.z + sh.z, s.w * sc.w + sh.w);
+  };
+  float4 v;
+  if (glu) {
+    const int g = co >> 5, rr = co & 31;
+    float4 f = affine4(sum4(g * 64 + rr), g * 64 + rr);
+    float4 a = affine4(sum4(g * 64 + 32 + rr), g * 64 + 32 + rr);
+    v = make_float4(f.x * sigmoidf_(a.x), f.y * sigmoidf_(a.y), f.z * sigmoidf_(a.z), f.w * sigmoidf_(a.w));
+  } else {
+    v = affine4(sum4(co), co);
+    if (p.res) {
+      const int HoWo = p.Ho * p.Wo;
+      int b = m / HoWo;
+      float4 rv = *reinterpret_cast<const float4 *>(p.res + (long long)b * p.res_bs +
+                                                    (long long)(m - b * HoWo) * p.Cout + co);
+      v.x += rv.x;
+      v.y += rv.y;
+      v.z += rv.z;
+      v.w += rv.w;
+    }
+    if (p.flags & SWEM_CONV_RELU_OUT) v = relu4(v);
+  }
+  *reinterpret_cast<float4 *>(p.y + (long long)m * p.Cout + co) = v;
+}
+
+struct Plan {
+  int wm, wn, nsplit, kb_per_split;
+};
+
+Plan make_plan(int M, int Ncols, int nkb, bool glu) {
+  // Candidate wave tiles, largest first.  Take the largest whose grid gives every CU about two blocks
+  // (the LDS image allows two resident blocks); if none does, take the smallest and split K until it does.
+  static const int cand[3][2] = {{2, 2}, {1, 2}, {1, 1}};
+  const long long target = 2 * 256;
+  Plan best{1, glu ? 2 : 1, 1, nkb};
+  for (int c = 0; c < 3; ++c) {
+    const int wm = cand[c][0], wn = cand[c][1];
+    if (glu && wn != 2) continue;
+    if (!glu && Ncols < 64 * wn && wn > 1) continue;
+    best = Plan{wm, wn, 1, nkb};
+    if ((long long)cdiv(M, 64 * wm) * cdiv(Ncols, 64 * wn) >= target) return best;
+  }
+  const long long blocks = (long long)cdiv(M, 64 * best.wm) * cdiv(Ncols, 64 * best.wn);
+  int ns = (int)((target + blocks - 1) / blocks);
+  const int maxsplit = nkb / 4;  // keep at least 4 k-blocks (128 k) per split
+  if (ns > maxsplit) ns = maxsplit;
+  if (ns > 16) ns = 16;
+  if (ns < 1) ns = 1;
+  const int per = cdiv(nkb, ns);
+  best.nsplit = cdiv(nkb, per);
+  best.kb_per_split = per;
+  return best;
+}
+
+template <int WM, int WN>
+int launch(const ConvP &p, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = 2 * KQ * (64 * WM + 1 + 64 * WN + 1) * sizeof(float4);
+  SWEM_ALLOW_LDS((conv_igemm_kernel<WM, WN>), lds);
+  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN>), grid, dim3(256), lds, st, p);
+  return SWEM_OK;
+}
+
+}  // namespace
+
+extern "C" size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                        int flags) {
+  if (stride <= 0) return 0;
+  int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  long long M = (long long)B * Ho * Wo;
+  int Ncols = (flags & SWEM_CONV_GLU) ? 2 * Cout : Cout;
+  int nkb = cdiv((long long)KH * KW * Cin, BK);
+  Plan pl = make_plan((int)M, Ncols, nkb, flags & SWEM_CONV_GLU);
+  if (pl.nsplit <= 1) return 0;
+  return (size_t)pl.nsplit * M * Ncols * sizeof(float);
+}
+
+extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
+                                    long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
+                                    const float *w, const float *scale, const float *shift, const float *res,
+                                    long long res_bs, float *y, int Cout, int KH, int KW, int stride, int pad,
+                                    int flags, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(x0 && w && y, SWEM_E_ARG, "conv2d: null pointer");
+  if (!x1) c1 = 0;
+  if (!x2) c2 = 0;
+  SWEM_REQUIRE(!(x2 && !x1), SWEM_E_ARG, "conv2d: source 2 without source 1");
+  SWEM_REQUIRE(c0 > 0 && c0 % 4 == 0 && c1 % 4 == 0 && c2 % 4 == 0, SWEM_E_SHAPE,
+               "conv2d: every source needs a channel count that is a multiple of 4 (got %d,%d,%d)", c0, c1, c2);
+  SWEM_REQUIRE(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, SWEM_E_SHAPE,
+               "conv2d: bad geometry");
+  SWEM_REQUIRE(Cout > 0 && Cout % 4 == 0, SWEM_E_SHAPE, "conv2d: Cout must be a multiple of 4 (got %d)", Cout);
+  const bool glu = flags & SWEM_CONV_GLU;
+  SWEM_REQUIRE(!glu || (Cout % 32 == 0 && !res), SWEM_E_SHAPE, "conv2d: GLU needs Cout %% 32 == 0 and no residual");
+  ConvP p;
+  p.x[0] = x0; p.x[1] = x1 ? x1 : x0; p.x[2] = x2 ? x2 : x0;
+  p.c[0] = c0; p.c[1] = c1; p.c[2] = c2;
+  p.bs[0] = bs0; p.bs[1] = bs1; p.bs[2] = bs2;
+  p.B = B; p.H = H; p.W = W;
+  p.Ho = (H + 2 * pad - KH) / stride + 1;
+  p.Wo = (W + 2 * pad - KW) / stride + 1;
+  SWEM_REQUIRE(p.Ho > 0 && p.Wo > 0, SWEM_E_SHAPE, "conv2d: empty output");
+  p.Cin = c0 + c1 + c2;
+  p.K = KH * KW * p.Cin;
+  long long M = (long long)B * p.Ho * p.Wo;
+  SWEM_REQUIRE(M < (1ll << 31) && M * (glu ? 2 * Cout : Cout) < (1ll << 40), SWEM_E_SHAPE, "conv2d: too large");
+  p.M = (int)M;
+  p.w = w; p.scale = scale; p.shift = shift; p.res = res; p.res_bs = res_bs; p.y = y;
+  p.Cout = Cout; p.Ncols = glu ? 2 * Cout : Cout;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.flags = flags;
+  p.nkb = cdiv(p.K, BK);
+  Plan pl = make_plan(p.M, p.Ncols, p.nkb, glu);
+  p.kb_per_split = pl.kb_per_split;
+  p.partial = nullptr;
+  if (pl.nsplit > 1) {
+    size_t need = (size_t)pl.nsplit * M * p.Ncols * sizeof(float);
+    SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d: workspace %zu < %zu bytes", ws_bytes, need);
+    p.partial = static_cast<float *>(ws);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 grid(cdiv(p.M, 64 * pl.wm), cdiv(p.Ncols, 64 * pl.wn), pl.nsplit);
+  int rc;
+  if (pl.wm == 2 && pl.wn == 2) rc = launch<2, 2>(p, grid, st);
+  else if (pl.wm == 1 && pl.wn == 2) rc = launch<1, 2>(p, grid, st);
+  else rc = launch<1, 1>(p, grid, st);
+  if (rc) return rc;
+  SWEM_CHECK_LAUNCH("conv_igemm_kernel");
+  if (pl.nsplit > 1) {
+    long long work = M * (Cout / 4);
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(cdiv(work, 256)), dim3(256), 0, st, p, pl.nsplit);
+    SWEM_CHECK_LAUNCH("conv_splitk_epilogue_kernel");
+  }
+  return SWEM_OK;
+}

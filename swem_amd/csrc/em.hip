@@ -1,0 +1,426 @@
+// Sequential weighted EM (reference methods/SWEM/modules.py:93-168) on the gfx950 fp32 matrix cores.
+//
+// Data layout (device, fp32; NK = 2*N, class minor; Pp = P rounded up to 8):
+//   x  [P][C]       raw key, one row per pixel          (reference x_t)
+//   xT [C][Pp]      transposed copy, zero padded        (reference x)
+//   kn [NK][L][C]   l2-normalised bases, row per base   (l2norm(kappa, dim=-2), modules.py:115)
+//   zT [NK][L][Pp]  responsibilities, row per base, pad columns zero
+// With the K dimension contiguous in every operand, each lane loads 16 bytes and feeds four
+// v_mfma_f32_32x32x2_f32 steps (common.h: mfma32x4).
+//
+// Kernels per EM iteration (3 launches):
+//   em_ew      : one GEMM  s = x_t . kn  per 32-pixel tile serves BOTH the W step of the previous iteration
+//                (cosine = s / (|x|+eps), joint {bg,fg} max, exp-sums, weights = mask * (1 - p)) and the E step
+//                (row softmax of s/tau, times weights).  The pixel sits on the MFMA lane, the base index in the
+//                accumulator registers, so the row reductions are in-register + one cross-half shuffle + one LDS
+//                exchange between the 4 waves (2 classes x 2 halves of L).
+//   em_mgemm   : split-P partial products  xT . z  (or vT . z for the value update) into a slab workspace.
+//   em_finalize: fixed-order slab reduction (deterministic), zita = zita_ + sum_p z, the prior blend
+//                (zita_*kappa_ + S)/zita, and the next iteration's normalised transposed bases.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// kn[nk][l][:] = kappa[nk][:][l] / (||kappa[nk][:][l]|| + eps).  Block: 32 bases x all channels.
+__global__ __launch_bounds__(256) void em_norm_bases_kernel(const float *__restrict__ kappa, float *__restrict__ kn,
+                                                            int C, int L, int out_rows, int out_off) {
+  extern __shared__ float sm[];  // tile[C][33], part[8][32], nrm[32]
+  float *tile = sm, *part = sm + C * 33, *nrm = part + 256;
+  const int nk = blockIdx.y, l0 = blockIdx.x * 32;
+  const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const float *src = kappa + (long long)nk * C * L + l0 + l;
+  float ss = 0.f;
+  for (int c = g; c < C; c += 8) {
+    float v = (l0 + l < L) ? src[(long long)c * L] : 0.f;
+    tile[c * 33 + l] = v;
+    ss += v * v;
+  }
+  part[g * 32 + l] = ss;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += part[i * 32 + threadIdx.x];
+    nrm[threadIdx.x] = sqrtf(s) + SWEM_L2_EPS;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 32 * C; idx += 256) {
+    int ll = idx / C, c = idx - ll * C;
+    if (l0 + ll < L) kn[((long long)nk * out_rows + out_off + l0 + ll) * C + c] = tile[c * 33 + ll] / nrm[ll];
+  }
+}
+
+template <int LT>
+__global__ __launch_bounds__(256) void em_ew_kernel(const float *__restrict__ x, const float *__restrict__ kn,
+                                                    const float *__restrict__ masks, const float *__restrict__ w_in,
+                                                    float *__restrict__ w_out, float *__restrict__ zT, int C, int P,
+                                                    int Pp, int L, float tau, int do_w, int do_e) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int XS = C + 4;
+  float *xs = sm;             // [32][C+4]
+  float *xn = xs + 32 * XS;   // [32]
+  float *red = xn + 32;       // [3][4][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int cls = wave >> 1, lh = wave & 1;
+  const int n = blockIdx.y, p0 = blockIdx.x * 32;
+  const int nk = n * 2 + cls;
+  const int cq = C / 4;
+  for (int idx = tid; idx < 32 * cq; idx += 256) {
+    int row = idx / cq, c4 = idx - row * cq;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p0 + row < P) v = ld4(x + (long long)(p0 + row) * C + c4 * 4);
+    *reinterpret_cast<float4 *>(xs + row * XS + c4 * 4) = v;
+  }
+  __syncthreads();
+  for (int rr = 0; rr < 8; ++rr) {
+    int row = wave * 8 + rr;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      float v = xs[row * XS + c];
+      s += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) xn[row] = sqrtf(s) + SWEM_L2_EPS;
+  }
+
+  f32x16 acc[LT];
+#pragma unroll
+  for (int t = 0; t < LT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  const int lbase = lh * 32 * LT;
+  const float *krow = kn + ((long long)nk * L + lbase + r) * C + 4 * h;
+  const float *xrow = xs + r * XS + 4 * h;
+  for (int j = 0; j < C / 8; ++j) {
+    float4 b4 = *reinterpret_cast<const float4 *>(xrow + 8 * j);
+#pragma unroll
+    for (int t = 0; t < LT; ++t) {
+      float4 a4 = ld4(krow + (long long)t * 32 * C + 8 * j);
+      acc[t] = mfma32x4(a4, b4, acc[t]);
+    }
+  }
+  __syncthreads();  // xn visible
+
+  const int p = p0 + r;
+  const bool pin = p < P;
+  float wgt;
+  if (do_w) {
+    // W step (modules.py:98-108): cosine, joint max over L and {bg,fg}, exp sums, 1 - p literally
+    const float den = xn[r];
+    float m = -__builtin_huge_valf();
+#pragma unroll
+    for (int t = 0; t < LT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m = fmaxf(m, acc[t][e] / den);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (h == 0) red[wave * 32 + r] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[r], red[32 + r]), fmaxf(red[64 + r], red[96 + r]));
+    float se = 0.f;
+#pragma unroll
+    for (int t = 0; t < LT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) se += expf((acc[t][e] / den - m) / tau);
+    se += __shfl_xor(se, 32);
+    if (h == 0) red[128 + wave * 32 + r] = se;
+    __syncthreads();
+    const float s_bg = red[128 + r] + red[128 + 32 + r], s_fg = red[128 + 64 + r] + red[128 + 96 + r];
+    const float prop = (cls ? s_fg : s_bg) / (s_bg + s_fg);
+    const float mk = pin ? masks[(long long)nk * P + p] : 0.f;
+    wgt = mk * (1.f - prop);
+    if (lh == 0 && h == 0 && pin && w_out) w_out[(long long)nk * P + p] = wgt;
+  } else {
+    wgt = pin ? w_in[(long long)nk * P + p] : 0.f;
+  }
+  if (!do_e) return;
+  // E step (modules.py:116-119)
+  float m = -__builtin_huge_valf();
+#pragma unroll
+  for (int t = 0; t < LT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m = fmaxf(m, acc[t][e]);
+  m = fmaxf(m, __shfl_xor(m, 32));
+  if (h == 0) red[256 + wave * 32 + r] = m;
+  __syncthreads();
+  m = fmaxf(red[256 + cls * 64 + r], red[256 + cls * 64 + 32 + r]);
+  float se = 0.f;
+#pragma unroll
+  for (int t = 0; t < LT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = expf((acc[t][e] - m) / tau);
+      acc[t][e] = v;
+      se += v;
+    }
+  se += __shfl_xor(se, 32);
+  __syncthreads();  // everyone has read red[256..] (max) before it is reused for the sums
+  if (h == 0) red[256 + wave * 32 + r] = se;
+  __syncthreads();
+  se = red[256 + cls * 64 + r] + red[256 + cls * 64 + 32 + r];
+  if (p < Pp) {
+    float *dst = zT + ((long long)nk * L + lbase) * Pp + p;
+#pragma unroll
+    for (int t = 0; t < LT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int l = 32 * t + acc_row(e, h);
+        dst[(long long)l * Pp] = pin ? (acc[t][e] / se) * wgt : 0.f;
+      }
+  }
+}
+
+// partial[sp][nk][row][l] = sum_{p in split sp} A[row][p] * zT[nk][l][p]
+template <int NT>
+__global__ __launch_bounds__(256) void em_mgemm_kernel(const float *__restrict__ A, long long a_bs, int a_div,
+                                                       const float *__restrict__ zT, float *__restrict__ part, int R,
+                                                       int Pp, int L, int kchunk, int nsplit, int NK) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nk = blockIdx.z / nsplit, sp = blockIdx.z - nk * nsplit;
+  const int k0 = sp * kchunk, k1 = min(Pp, k0 + kchunk);
+  const int row = blockIdx.x * 128 + wave * 32 + r;
+  const int col0 = blockIdx.y * 32 * NT;
+  const bool rok = row < R;
+  const float *Arow = A + (a_div ? (long long)(nk / a_div) * a_bs : 0) + (long long)(rok ? row : 0) * Pp + 4 * h;
+  const float *Brow = zT + ((long long)nk * L + col0 + r) * Pp + 4 * h;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  for (int k = k0; k < k1; k += 8) {
+    float4 a4 = rok ? ld4(Arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float4 b4 = ld4(Brow + (long long)t * 32 * Pp + k);
+      acc[t] = mfma32x4(a4, b4, acc[t]);
+    }
+  }
+  float *dst = part + (((long long)sp * NK + nk) * R) * L;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int rr = blockIdx.x * 128 + wave * 32 + acc_row(e, h);
+      if (rr < R) dst[(long long)rr * L + col0 + 32 * t + r] = acc[t][e];
+    }
+}
+
+// Block: 32 bases (columns l) of one nk.  zsum over pixels, slab reduction, prior blend, optional kn.
+__global__ __launch_bounds__(256) void em_finalize_kernel(const float *__restrict__ part, int nsplit,
+                                                          const float *__restrict__ zT,
+                                                          const float *__restrict__ prev,
+                                                          const float *__restrict__ zita_prev,
+                                                          float *__restrict__ out, float *__restrict__ zita_out,
+                                                          float *__restrict__ kn_out, int NK, int R, int P, int Pp,
+                                                          int L) {
+  extern __shared__ float sm[];  // red[8][32], zp[32], zt[32], nrm[32], tile[R][33] (kn only)
+  float *red = sm, *zp = sm + 256, *zt = zp + 32, *nrm = zt + 32, *tile = nrm + 32;
+  const int nk = blockIdx.y, l0 = blockIdx.x * 32;
+  const int tid = threadIdx.x;
+  {
+    // zsum: 8 threads per base row, float4 strided over the row
+    const int ll = tid >> 3, g = tid & 7;
+    const float *zr = zT + ((long long)nk * L + l0 + ll) * Pp;
+    float s = 0.f;
+    for (int k = g * 4; k < Pp; k += 32) {
+      float4 v = ld4(zr + k);
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (g == 0) {
+      float zprev = zita_prev[(long long)nk * L + l0 + ll];
+      zp[ll] = zprev;
+      zt[ll] = zprev + s;
+      if (zita_out) zita_out[(long long)nk * L + l0 + ll] = zprev + s;
+    }
+  }
+  __syncthreads();
+  const int l = tid & 31, g = tid >> 5;
+  const long long slab = (long long)NK * R * L;
+  float ss = 0.f;
+  for (int row = g; row < R; row += 8) {
+    const long long o = ((long long)nk * R + row) * L + l0 + l;
+    float s = part[o];
+    for (int sp = 1; sp < nsplit; ++sp) s += part[o + sp * slab];
+    float v = (zp[l] * prev[o] + s) / zt[l];
+    out[o] = v;
+    if (kn_out) {
+      tile[row * 33 + l] = v;
+      ss += v * v;
+    }
+  }
+  if (!kn_out) return;
+  red[g * 32 + l] = ss;
+  __syncthreads();
+  if (tid < 32) {
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += red[i * 32 + tid];
+    nrm[tid] = sqrtf(s) + SWEM_L2_EPS;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 32 * R; idx += 256) {
+    int ll = idx / R, c = idx - ll * R;
+    kn_out[((long long)nk * L + l0 + ll) * R + c] = tile[c * 33 + ll] / nrm[ll];
+  }
+}
+
+struct MPlan {
+  int nt, nsplit, kchunk;
+};
+MPlan mstep_plan(int NK, int R, int Pp, int L) {
+  MPlan pl;
+  pl.nt = (L % 64 == 0) ? 2 : 1;
+  long long blocks = (long long)cdiv(R, 128) * (L / (32 * pl.nt)) * NK;
+  int ns = (int)((384 + blocks - 1) / blocks);
+  int maxs = Pp / 64;  // at least 64 pixels per split
+  if (ns > maxs) ns = maxs;
+  if (ns < 1) ns = 1;
+  if (ns > 32) ns = 32;
+  pl.kchunk = (cdiv(Pp, ns) + 7) / 8 * 8;
+  pl.nsplit = cdiv(Pp, pl.kchunk);
+  return pl;
+}
+
+}  // namespace
+
+#define ST static_cast<hipStream_t>(stream)
+
+extern "C" int swem_em_pad(int P) { return (P + 7) / 8 * 8; }
+
+// kn rows of bank `kappa` land at row out_off + l of an [NK][out_rows][C] image (matching concatenates banks)
+int swem_norm_bases_into(void *stream, const float *kappa, float *kn, int NK, int C, int L, int out_rows,
+                         int out_off) {
+  SWEM_REQUIRE(kappa && kn && NK > 0 && C > 0 && L > 0, SWEM_E_ARG, "em_norm_bases: bad argument");
+  SWEM_REQUIRE(C <= 1024, SWEM_E_SHAPE, "em_norm_bases: C > 1024");
+  size_t lds = ((size_t)C * 33 + 256 + 32) * sizeof(float);
+  hipLaunchKernelGGL(em_norm_bases_kernel, dim3(cdiv(L, 32), NK), dim3(256), lds, ST, kappa, kn, C, L, out_rows,
+                     out_off);
+  SWEM_CHECK_LAUNCH("em_norm_bases");
+  return SWEM_OK;
+}
+
+extern "C" int swem_em_norm_bases_f32(void *stream, const float *kappa, float *kn, int NK, int C, int L) {
+  return swem_norm_bases_into(stream, kappa, kn, NK, C, L, L, 0);
+}
+
+extern "C" int swem_em_ew_f32(void *stream, const float *x, const float *kn, const float *masks, const float *w_in,
+                              float *w_out, float *zT, int N, int C, int P, int L, float tau, int do_w, int do_e) {
+  SWEM_REQUIRE(x && kn && N > 0 && P > 0, SWEM_E_ARG, "em_ew: bad argument");
+  SWEM_REQUIRE(C % 8 == 0 && C <= 512, SWEM_E_SHAPE, "em_ew: C must be a multiple of 8 and <= 512 (got %d)", C);
+  SWEM_REQUIRE(L == 64 || L == 128 || L == 256, SWEM_E_SHAPE, "em_ew: L must be 64, 128 or 256 (got %d)", L);
+  SWEM_REQUIRE(!do_w || masks, SWEM_E_ARG, "em_ew: W step needs masks");
+  SWEM_REQUIRE(do_w || !do_e || w_in, SWEM_E_ARG, "em_ew: E step without W step needs w_in");
+  SWEM_REQUIRE(!do_e || zT, SWEM_E_ARG, "em_ew: E step needs zT");
+  SWEM_REQUIRE(tau > 0.f, SWEM_E_ARG, "em_ew: tau must be positive");
+  const int Pp = swem_em_pad(P);
+  dim3 grid(cdiv(P, 32), N);
+  size_t lds = ((size_t)32 * (C + 4) + 32 + 3 * 128) * sizeof(float);
+#define EW(LT_) \
+  hipLaunchKernelGGL((em_ew_kernel<LT_>), grid, dim3(256), lds, ST, x, kn, masks, w_in, w_out, zT, C, P, Pp, L, tau, \
+                     do_w, do_e)
+  if (L == 64) EW(1);
+  else if (L == 128) EW(2);
+  else EW(4);
+#undef EW
+  SWEM_CHECK_LAUNCH("em_ew");
+  return SWEM_OK;
+}
+
+extern "C" size_t swem_em_mstep_workspace(int NK, int R, int P, int L) {
+  MPlan pl = mstep_plan(NK, R, swem_em_pad(P), L);
+  return (size_t)pl.nsplit * NK * R * L * sizeof(float);
+}
+
+extern "C" int swem_em_mstep_f32(void *stream, const float *A, int a_batch_div, const float *zT, const float *prev,
+                                 const float *zita_prev, float *out, float *zita_out, float *kn_out, int NK, int R,
+                                 int P, int L, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(A && zT && prev && zita_prev && out, SWEM_E_ARG, "em_mstep: null pointer");
+  SWEM_REQUIRE(L % 32 == 0 && R % 32 == 0, SWEM_E_SHAPE, "em_mstep: L and R must be multiples of 32");
+  SWEM_REQUIRE(!kn_out || R <= 1024, SWEM_E_SHAPE, "em_mstep: kn_out needs R <= 1024");
+  const int Pp = swem_em_pad(P);
+  MPlan pl = mstep_plan(NK, R, Pp, L);
+  size_t need = (size_t)pl.nsplit * NK * R * L * sizeof(float);
+  SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "em_mstep: workspace %zu < %zu", ws_bytes, need);
+  float *part = static_cast<float *>(ws);
+  dim3 grid(cdiv(R, 128), L / (32 * pl.nt), NK * pl.nsplit);
+  const long long a_bs = (long long)R * Pp;
+  if (pl.nt == 2)
+    hipLaunchKernelGGL((em_mgemm_kernel<2>), grid, dim3(256), 0, ST, A, a_bs, a_batch_div, zT, part, R, Pp, L,
+                       pl.kchunk, pl.nsplit, NK);
+  else
+    hipLaunchKernelGGL((em_mgemm_kernel<1>), grid, dim3(256), 0, ST, A, a_bs, a_batch_div, zT, part, R, Pp, L,
+                       pl.kchunk, pl.nsplit, NK);
+  SWEM_CHECK_LAUNCH("em_mgemm");
+  size_t lds = (256 + 96 + (kn_out ? (size_t)R * 33 : 0)) * sizeof(float);
+  hipLaunchKernelGGL(em_finalize_kernel, dim3(L / 32, NK), dim3(256), lds, ST, part, pl.nsplit, zT, prev, zita_prev,
+                     out, zita_out, kn_out, NK, R, P, Pp, L);
+  SWEM_CHECK_LAUNCH("em_finalize");
+  return SWEM_OK;
+}
+
+namespace {
+struct MemWs {
+  size_t xT, vT, kn, zT, wb, part, total;
+};
+MemWs memorize_ws(int N, int C, int V, int P, int L) {
+  const int Pp = swem_em_pad(P), NK = 2 * N;
+  MemWs w;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = align_up(o + bytes, 256);
+    return at;
+  };
+  w.xT = take((size_t)C * Pp * 4);
+  w.vT = take((size_t)N * V * Pp * 4);
+  w.kn = take((size_t)NK * L * C * 4);
+  w.zT = take((size_t)NK * L * Pp * 4);
+  w.wb = take((size_t)NK * P * 4);
+  size_t p1 = swem_em_mstep_workspace(NK, C, P, L), p2 = swem_em_mstep_workspace(NK, V, P, L);
+  w.part = take(p1 > p2 ? p1 : p2);
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t swem_memorize_workspace(int N, int C, int V, int P, int L) {
+  return memorize_ws(N, C, V, P, L).total;
+}
+
+extern "C" int swem_memorize_f32(void *stream, const float *x, const float *v, const float *masks,
+                                 const float *kappa_prev, const float *nu_prev, const float *zita_prev,
+                                 float *kappa_out, float *nu_out, float *zita_out, int N, int C, int V, int P, int L,
+                                 int T, float tau, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(x && v && masks && kappa_prev && nu_prev && zita_prev && kappa_out && nu_out && zita_out, SWEM_E_ARG,
+               "memorize: null pointer");
+  SWEM_REQUIRE(T >= 1, SWEM_E_ARG, "memorize: T < 1");
+  SWEM_REQUIRE(kappa_out != kappa_prev && nu_out != nu_prev && zita_out != zita_prev, SWEM_E_ARG,
+               "memorize: outputs must not alias the prior bases (the prior is read by every iteration)");
+  MemWs w = memorize_ws(N, C, V, P, L);
+  SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "memorize: workspace %zu < %zu", ws_bytes, w.total);
+  char *base = static_cast<char *>(ws);
+  float *xT = (float *)(base + w.xT), *vT = (float *)(base + w.vT), *kn = (float *)(base + w.kn);
+  float *zT = (float *)(base + w.zT), *wb = (float *)(base + w.wb);
+  void *part = base + w.part;
+  const size_t part_bytes = w.total - w.part;
+  const int Pp = swem_em_pad(P), NK = 2 * N;
+  int rc;
+  if ((rc = swem_transpose_f32(stream, x, xT, 1, P, C, Pp))) return rc;
+  if ((rc = swem_transpose_f32(stream, v, vT, N, P, V, Pp))) return rc;
+  if ((rc = swem_em_norm_bases_f32(stream, kappa_prev, kn, NK, C, L))) return rc;
+  for (int it = 0; it < T; ++it) {
+    // W step of iteration it-1 (modules.py:161-162) and E step of iteration it share one GEMM
+    if ((rc = swem_em_ew_f32(stream, x, kn, masks, masks, wb, zT, N, C, P, L, tau, it > 0, 1))) return rc;
+    if ((rc = swem_em_mstep_f32(stream, xT, 0, zT, kappa_prev, zita_prev, kappa_out, zita_out,
+                                it + 1 < T ? kn : nullptr, NK, C, P, L, part, part_bytes)))
+      return rc;
+  }
+  // value bases from the last z (modules.py:164-165); zita is the one just written
+  return swem_em_mstep_f32(stream, vT, 2, zT, nu_prev, zita_prev, nu_out, nullptr, nullptr, NK, V, P, L, part,
+                           part_bytes);
+}

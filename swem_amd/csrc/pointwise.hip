@@ -1,0 +1,529 @@
+// Memory-bound kernels of the SWEM frame pipeline: input packing, pooling, resampling, CBAM gates,
+// the single-channel prediction head and the mask aggregation head.  All activations are NHWC fp32
+// with C % 4 == 0 so every lane moves 16 bytes; index arithmetic mirrors ATen's so index maps match.
+#include "common.h"
+
+namespace {
+
+// ATen area_pixel_compute_source_index (align_corners=False, not cubic) + guard_index_and_lambda.
+struct Lerp {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lerp lerp_coord(int dst, float scale, int in) {
+  float src = scale * (dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  int i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  float l1 = src - (float)i0;
+  l1 = fminf(fmaxf(l1, 0.f), 1.f);
+  Lerp r;
+  r.i0 = i0;
+  r.i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  r.l1 = l1;
+  r.l0 = 1.f - l1;
+  return r;
+}
+// ATen nearest_neighbor_compute_source_index (legacy 'nearest')
+__device__ __forceinline__ int nearest_coord(int dst, float scale, int in) {
+  int s = (int)floorf((float)dst * scale);
+  return s < in - 1 ? s : in - 1;
+}
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float4 f4max(float4 a, float4 b) {
+  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 f4lerp2(float l0, float4 a, float l1, float4 b) {
+  return make_float4(l0 * a.x + l1 * b.x, l0 * a.y + l1 * b.y, l0 * a.z + l1 * b.z, l0 * a.w + l1 * b.w);
+}
+
+__global__ void prep_key_input_kernel(const float *__restrict__ f, float3 mean, float3 stdv, float *__restrict__ out,
+                                      int B, long long HW) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HW) return;
+  long long b = i / HW, p = i - b * HW;
+  const float *src = f + b * 3 * HW + p;
+  st4(out + i * 4, make_float4((src[0] - mean.x) / stdv.x, (src[HW] - mean.y) / stdv.y,
+                               (src[2 * HW] - mean.z) / stdv.z, 0.f));
+}
+
+__global__ void prep_value_input_kernel(const float *__restrict__ f, const float *__restrict__ masks, float3 mean,
+                                        float3 stdv, float *__restrict__ out, int B, int N, long long HW,
+                                        int single_obj) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * N * HW) return;
+  long long bn = i / HW, p = i - bn * HW;
+  int b = (int)(bn / N), n = (int)(bn - (long long)b * N);
+  const float *src = f + (long long)b * 3 * HW + p;
+  const float *mb = masks + (long long)b * (N + 1) * HW + p;
+  float m = mb[(long long)(n + 1) * HW];
+  float other = single_obj ? 0.f : (1.f - m - mb[0]);
+  st4(out + i * 8, make_float4((src[0] - mean.x) / stdv.x, (src[HW] - mean.y) / stdv.y,
+                               (src[2 * HW] - mean.z) / stdv.z, m));
+  st4(out + i * 8 + 4, make_float4(other, 0.f, 0.f, 0.f));
+}
+
+__global__ void maxpool_kernel(const float *__restrict__ x, float *__restrict__ y, int B, int H, int W, int C, int Ho,
+                               int Wo) {
+  const int cq = C / 4;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * Ho * Wo * cq) return;
+  int c4 = (int)(i % cq);
+  long long t = i / cq;
+  int ox = (int)(t % Wo);
+  t /= Wo;
+  int oy = (int)(t % Ho);
+  int b = (int)(t / Ho);
+  const float ninf = -__builtin_huge_valf();
+  float4 m = make_float4(ninf, ninf, ninf, ninf);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    int iy = oy * 2 - 1 + ky;
+    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      int ix = ox * 2 - 1 + kx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      m = f4max(m, ld4(x + (((long long)b * H + iy) * W + ix) * C + c4 * 4));
+    }
+  }
+  st4(y + i * 4, m);
+}
+
+__global__ void upsample_add_kernel(const float *__restrict__ skip, long long skip_bs, const float *__restrict__ low,
+                                    float *__restrict__ y, int B, int Hl, int Wl, int Ho, int Wo, int C) {
+  const int cq = C / 4;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * Ho * Wo * cq) return;
+  int c4 = (int)(i % cq);
+  long long t = i / cq;
+  int ox = (int)(t % Wo);
+  t /= Wo;
+  int oy = (int)(t % Ho);
+  int b = (int)(t / Ho);
+  Lerp ly = lerp_coord(oy, (float)Hl / (float)Ho, Hl), lx = lerp_coord(ox, (float)Wl / (float)Wo, Wl);
+  const float *base = low + (long long)b * Hl * Wl * C + c4 * 4;
+  float4 r0 = f4lerp2(lx.l0, ld4(base + ((long long)ly.i0 * Wl + lx.i0) * C), lx.l1,
+                      ld4(base + ((long long)ly.i0 * Wl + lx.i1) * C));
+  float4 r1 = f4lerp2(lx.l0, ld4(base + ((long long)ly.i1 * Wl + lx.i0) * C), lx.l1,
+                      ld4(base + ((long long)ly.i1 * Wl + lx.i1) * C));
+  float4 up = f4lerp2(ly.l0, r0, ly.l1, r1);
+  float4 s = ld4(skip + (long long)b * skip_bs + ((long long)oy * Wo + ox) * C + c4 * 4);
+  st4(y + i * 4, f4add(s, up));
+}
+
+__global__ void resize_planes_kernel(const float *__restrict__ x, float *__restrict__ y, int planes, int Hi, int Wi,
+                                     int Ho, int Wo, int mode) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)planes * Ho * Wo) return;
+  int ox = (int)(i % Wo);
+  long long t = i / Wo;
+  int oy = (int)(t % Ho);
+  long long pl = t / Ho;
+  const float *src = x + pl * Hi * Wi;
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  if (mode == 0) {
+    int iy = (Ho == Hi) ? oy : nearest_coord(oy, sh, Hi);
+    int ix = (Wo == Wi) ? ox : nearest_coord(ox, sw, Wi);
+    y[i] = src[(long long)iy * Wi + ix];
+  } else {
+    Lerp ly = lerp_coord(oy, sh, Hi), lx = lerp_coord(ox, sw, Wi);
+    float r0 = lx.l0 * src[(long long)ly.i0 * Wi + lx.i0] + lx.l1 * src[(long long)ly.i0 * Wi + lx.i1];
+    float r1 = lx.l0 * src[(long long)ly.i1 * Wi + lx.i0] + lx.l1 * src[(long long)ly.i1 * Wi + lx.i1];
+    y[i] = ly.l0 * r0 + ly.l1 * r1;
+  }
+}
+
+template <typename HT>
+__global__ void mask_prep_kernel(const HT *__restrict__ hard, int Hh, int Wh, const float *__restrict__ soft, int Hs,
+                                 int Ws, float *__restrict__ out, int B, int N, int h, int w) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int P = h * w;
+  if (i >= (long long)B * N * P) return;
+  int p = (int)(i % P);
+  long long bn = i / P;
+  int b = (int)(bn / N), n = (int)(bn - (long long)b * N);
+  int oy = p / w, ox = p - oy * w;
+  const HT *hp = hard + ((long long)b * (N + 1) + n + 1) * Hh * Wh;
+  int iy = (Hh == h) ? oy : nearest_coord(oy, (float)Hh / (float)h, Hh);
+  int ix = (Wh == w) ? ox : nearest_coord(ox, (float)Wh / (float)w, Wh);
+  float mh = (float)hp[(long long)iy * Wh + ix];
+  const float *sp = soft + ((long long)b * (N + 1) + n + 1) * Hs * Ws;
+  Lerp ly = lerp_coord(oy, (float)Hs / (float)h, Hs), lx = lerp_coord(ox, (float)Ws / (float)w, Ws);
+  float r0 = lx.l0 * sp[(long long)ly.i0 * Ws + lx.i0] + lx.l1 * sp[(long long)ly.i0 * Ws + lx.i1];
+  float r1 = lx.l0 * sp[(long long)ly.i1 * Ws + lx.i0] + lx.l1 * sp[(long long)ly.i1 * Ws + lx.i1];
+  float ms = ly.l0 * r0 + ly.l1 * r1;
+  out[(bn * 2 + 0) * P + p] = (1.f - mh) * (1.f - ms);
+  out[(bn * 2 + 1) * P + p] = mh * ms;
+}
+
+// ---------------------------------------------------------------- CBAM
+constexpr int CBAM_CHUNKS = 32;
+// stage 1: per (b, chunk): partial sum and max over the chunk's pixels for every channel
+__global__ void cbam_pool_partial_kernel(const float *__restrict__ x, float *__restrict__ part, int P, int C) {
+  const int cq = C / 4;
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int per = (P + CBAM_CHUNKS - 1) / CBAM_CHUNKS;
+  const int p0 = ch * per, p1 = min(P, p0 + per);
+  const float ninf = -__builtin_huge_valf();
+  for (int c4 = threadIdx.x; c4 < cq; c4 += blockDim.x) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), m = make_float4(ninf, ninf, ninf, ninf);
+    for (int p = p0; p < p1; ++p) {
+      float4 v = ld4(x + ((long long)b * P + p) * C + c4 * 4);
+      s = f4add(s, v);
+      m = f4max(m, v);
+    }
+    float *dst = part + (((long long)b * CBAM_CHUNKS + ch) * 2) * C + c4 * 4;
+    st4(dst, s);
+    st4(dst + C, m);
+  }
+}
+// stage 2 + MLP (attentions.py:26-50): one block per batch item
+__global__ void cbam_mlp_kernel(const float *__restrict__ part, const float *__restrict__ w1,
+                                const float *__restrict__ b1, const float *__restrict__ w2,
+                                const float *__restrict__ b2, float *__restrict__ cscale, int P, int C, int hid) {
+  extern __shared__ float sm[];  // avg[C], max[C], hidden[2][hid]
+  float *avg = sm, *mx = sm + C, *hd = sm + 2 * C;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f, m = -__builtin_huge_valf();
+    for (int ch = 0; ch < CBAM_CHUNKS; ++ch) {
+      const float *src = part + (((long long)b * CBAM_CHUNKS + ch) * 2) * C + c;
+      s += src[0];
+      m = fmaxf(m, src[C]);
+    }
+    avg[c] = s / (float)P;
+    mx[c] = m;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int j = wave; j < 2 * hid; j += nw) {  // one wave per (pool type, hidden unit)
+    const float *v = j < hid ? avg : mx;
+    const float *wr = w1 + (long long)(j % hid) * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += wr[c] * v[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) hd[j] = fmaxf(s + b1[j % hid], 0.f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float sa = b2[c], sm_ = b2[c];
+    for (int j = 0; j < hid; ++j) {
+      float wv = w2[(long long)c * hid + j];
+      sa += wv * hd[j];
+      sm_ += wv * hd[hid + j];
+    }
+    cscale[(long long)b * C + c] = sigmoidf_(sa + sm_);
+  }
+}
+// channel max / mean of x*cscale per pixel: one wave per pixel (attentions.py:53-55)
+__global__ void cbam_spatial_pool_kernel(const float *__restrict__ x, const float *__restrict__ cscale,
+                                         float *__restrict__ comp, int B, int P, int C) {
+  const int lane = threadIdx.x & 63;
+  long long pix = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pix >= (long long)B * P) return;
+  int b = (int)(pix / P);
+  float m = -__builtin_huge_valf(), s = 0.f;
+  for (int c4 = lane; c4 < C / 4; c4 += 64) {
+    float4 v = ld4(x + pix * C + c4 * 4), g = ld4(cscale + (long long)b * C + c4 * 4);
+    float a0 = v.x * g.x, a1 = v.y * g.y, a2 = v.z * g.z, a3 = v.w * g.w;
+    m = fmaxf(fmaxf(m, fmaxf(a0, a1)), fmaxf(a2, a3));
+    s += (a0 + a1) + (a2 + a3);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, o));
+    s += __shfl_xor(s, o);
+  }
+  if (lane == 0) {
+    comp[pix * 2] = m;
+    comp[pix * 2 + 1] = s / (float)C;
+  }
+}
+__global__ void cbam_sgate_kernel(const float *__restrict__ comp, const float *__restrict__ w7,
+                                  const float *__restrict__ b7, float *__restrict__ sg, int B, int H, int W) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * H * W) return;
+  int ox = (int)(i % W);
+  long long t = i / W;
+  int oy = (int)(t % H);
+  int b = (int)(t / H);
+  float acc = b7[0];
+  for (int ky = 0; ky < 7; ++ky) {
+    int iy = oy - 3 + ky;
+    if ((unsigned)iy >= (unsigned)H) continue;
+    for (int kx = 0; kx < 7; ++kx) {
+      int ix = ox - 3 + kx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const float *cp = comp + (((long long)b * H + iy) * W + ix) * 2;
+      acc += w7[ky * 7 + kx] * cp[0] + w7[49 + ky * 7 + kx] * cp[1];
+    }
+  }
+  sg[i] = sigmoidf_(acc);
+}
+__global__ void cbam_apply_kernel(const float *__restrict__ x, const float *__restrict__ cscale,
+                                  const float *__restrict__ sg, float *__restrict__ y, int B, int P, int C) {
+  const int cq = C / 4;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * P * cq) return;
+  int c4 = (int)(i % cq);
+  long long pix = i / cq;
+  int b = (int)(pix / P);
+  float4 v = ld4(x + i * 4), g = ld4(cscale + (long long)b * C + c4 * 4);
+  float s = sg[pix];
+  st4(y + i * 4, make_float4(v.x + v.x * g.x * s, v.y + v.y * g.y * s, v.z + v.z * g.z * s, v.w + v.w * g.w * s));
+}
+
+// ---------------------------------------------------------------- decoder heads
+// conv3x3(relu(x)) -> 1 channel: one wave per output pixel, lanes over channel groups
+__global__ void pred_head_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                 const float *__restrict__ bias, float *__restrict__ logit, int B, int H, int W,
+                                 int C) {
+  const int lane = threadIdx.x & 63;
+  long long pix = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pix >= (long long)B * H * W) return;
+  int ox = (int)(pix % W);
+  long long t = pix / W;
+  int oy = (int)(t % H);
+  int b = (int)(t / H);
+  float s = 0.f;
+  for (int ky = 0; ky < 3; ++ky) {
+    int iy = oy - 1 + ky;
+    if ((unsigned)iy >= (unsigned)H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      int ix = ox - 1 + kx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const float *xp = x + (((long long)b * H + iy) * W + ix) * C;
+      const float *wp = w + (ky * 3 + kx) * C;
+      for (int c4 = lane; c4 < C / 4; c4 += 64) {
+        float4 v = ld4(xp + c4 * 4), q = ld4(wp + c4 * 4);
+        s += fmaxf(v.x, 0.f) * q.x + fmaxf(v.y, 0.f) * q.y + fmaxf(v.z, 0.f) * q.z + fmaxf(v.w, 0.f) * q.w;
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) logit[pix] = s + bias[0];
+}
+
+__global__ void decode_head_kernel(const float *__restrict__ logit4, const float *__restrict__ valid,
+                                   float *__restrict__ logits, float *__restrict__ prob,
+                                   long long *__restrict__ amax, int B, int N, int h4, int w4, int Ho, int Wo) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long HW = (long long)Ho * Wo;
+  if (i >= B * HW) return;
+  int b = (int)(i / HW);
+  long long pix = i - b * HW;
+  int oy = (int)(pix / Wo), ox = (int)(pix - (long long)oy * Wo);
+  Lerp ly = lerp_coord(oy, (float)h4 / (float)Ho, h4), lx = lerp_coord(ox, (float)w4 / (float)Wo, w4);
+  float *lg = logits + (long long)b * (N + 1) * HW + pix;
+  float *pr = prob + (long long)b * (N + 1) * HW + pix;
+  float bg = 1.f, mx = -__builtin_huge_valf();
+  for (int n = 0; n < N; ++n) {
+    const float *src = logit4 + ((long long)b * N + n) * h4 * w4;
+    float r0 = lx.l0 * src[ly.i0 * w4 + lx.i0] + lx.l1 * src[ly.i0 * w4 + lx.i1];
+    float r1 = lx.l0 * src[ly.i1 * w4 + lx.i0] + lx.l1 * src[ly.i1 * w4 + lx.i1];
+    float p = sigmoidf_(ly.l0 * r0 + ly.l1 * r1);
+    if (valid) p *= valid[(long long)b * (N + 1) + n + 1];
+    bg *= 1.f - p;
+    float pc = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+    float l = logf(pc / (1.f - pc));
+    lg[(long long)(n + 1) * HW] = l;
+    mx = fmaxf(mx, l);
+  }
+  {
+    float pc = fminf(fmaxf(bg, 1e-7f), 1.f - 1e-7f);
+    float l = logf(pc / (1.f - pc));
+    lg[0] = l;
+    mx = fmaxf(mx, l);
+  }
+  float sum = 0.f;
+  for (int n = 0; n <= N; ++n) sum += expf(lg[(long long)n * HW] - mx);
+  float best = -1.f;
+  int bi = 0;
+  for (int n = 0; n <= N; ++n) {
+    float v = expf(lg[(long long)n * HW] - mx) / sum;
+    pr[(long long)n * HW] = v;
+    if (v > best) {
+      best = v;
+      bi = n;
+    }
+  }
+  if (amax) amax[i] = bi;
+}
+
+__global__ void argmax_onehot_kernel(const float *__restrict__ prob, long long *__restrict__ amax,
+                                     long long *__restrict__ onehot, int B, int N1, long long HW) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HW) return;
+  int b = (int)(i / HW);
+  long long pix = i - b * HW;
+  const float *src = prob + (long long)b * N1 * HW + pix;
+  float best = src[0];
+  int bi = 0;
+  for (int n = 1; n < N1; ++n) {
+    float v = src[(long long)n * HW];
+    if (v > best) {
+      best = v;
+      bi = n;
+    }
+  }
+  if (amax) amax[i] = bi;
+  if (onehot)
+    for (int n = 0; n < N1; ++n) onehot[((long long)b * N1 + n) * HW + pix] = (n == bi) ? 1 : 0;
+}
+
+__global__ void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int Cc, int ld) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const float *src = in + (long long)b * R * Cc;
+  float *dst = out + (long long)b * Cc * ld;
+  int c = blockIdx.x * 32 + threadIdx.x;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    int r = blockIdx.y * 32 + j;
+    tile[j][threadIdx.x] = (r < R && c < Cc) ? src[(long long)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  int r = blockIdx.y * 32 + threadIdx.x;  // output column (may be padding: r in [R, ld))
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    int cc = blockIdx.x * 32 + j;
+    if (cc < Cc && r < ld) dst[(long long)cc * ld + r] = tile[threadIdx.x][j];
+  }
+}
+
+inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+}  // namespace
+
+#define ST static_cast<hipStream_t>(stream)
+
+extern "C" int swem_prep_key_input_f32(void *stream, const float *frames, const float *mean3, const float *std3,
+                                       float *out, int B, int H, int W) {
+  SWEM_REQUIRE(frames && mean3 && std3 && out, SWEM_E_ARG, "prep_key_input: null pointer");
+  // mean/std are HOST pointers to 3 floats each (module buffers, networks.py:157-158)
+  float3 m = make_float3(mean3[0], mean3[1], mean3[2]), s = make_float3(std3[0], std3[1], std3[2]);
+  long long n = (long long)B * H * W;
+  hipLaunchKernelGGL(prep_key_input_kernel, grid1(n), dim3(256), 0, ST, frames, m, s, out, B, (long long)H * W);
+  SWEM_CHECK_LAUNCH("prep_key_input");
+  return SWEM_OK;
+}
+
+extern "C" int swem_prep_value_input_f32(void *stream, const float *frame, const float *masks, const float *mean3,
+                                         const float *std3, float *out, int B, int N, int H, int W,
+                                         int single_obj) {
+  SWEM_REQUIRE(frame && masks && mean3 && std3 && out && N > 0, SWEM_E_ARG, "prep_value_input: bad argument");
+  float3 m = make_float3(mean3[0], mean3[1], mean3[2]), s = make_float3(std3[0], std3[1], std3[2]);
+  long long n = (long long)B * N * H * W;
+  hipLaunchKernelGGL(prep_value_input_kernel, grid1(n), dim3(256), 0, ST, frame, masks, m, s, out, B, N,
+                     (long long)H * W, single_obj);
+  SWEM_CHECK_LAUNCH("prep_value_input");
+  return SWEM_OK;
+}
+
+extern "C" int swem_maxpool3x3s2_nhwc_f32(void *stream, const float *x, float *y, int B, int H, int W, int C) {
+  SWEM_REQUIRE(x && y && C % 4 == 0, SWEM_E_SHAPE, "maxpool: C %% 4 != 0");
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_kernel, grid1((long long)B * Ho * Wo * (C / 4)), dim3(256), 0, ST, x, y, B, H, W, C, Ho,
+                     Wo);
+  SWEM_CHECK_LAUNCH("maxpool");
+  return SWEM_OK;
+}
+
+extern "C" int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long long skip_bs, const float *low,
+                                          float *y, int B, int Hl, int Wl, int Ho, int Wo, int C) {
+  SWEM_REQUIRE(skip && low && y && C % 4 == 0, SWEM_E_SHAPE, "upsample_add: bad argument");
+  hipLaunchKernelGGL(upsample_add_kernel, grid1((long long)B * Ho * Wo * (C / 4)), dim3(256), 0, ST, skip, skip_bs,
+                     low, y, B, Hl, Wl, Ho, Wo, C);
+  SWEM_CHECK_LAUNCH("upsample_add");
+  return SWEM_OK;
+}
+
+extern "C" int swem_resize_planes_f32(void *stream, const float *x, float *y, int planes, int Hi, int Wi, int Ho,
+                                      int Wo, int mode) {
+  SWEM_REQUIRE(x && y && (mode == 0 || mode == 1), SWEM_E_ARG, "resize_planes: bad argument");
+  hipLaunchKernelGGL(resize_planes_kernel, grid1((long long)planes * Ho * Wo), dim3(256), 0, ST, x, y, planes, Hi, Wi,
+                     Ho, Wo, mode);
+  SWEM_CHECK_LAUNCH("resize_planes");
+  return SWEM_OK;
+}
+
+extern "C" int swem_mask_prep_f32(void *stream, const void *hard, int hard_is_i64, int Hh, int Wh, const float *soft,
+                                  int Hs, int Ws, float *out, int B, int N, int h, int w) {
+  SWEM_REQUIRE(hard && soft && out && N > 0, SWEM_E_ARG, "mask_prep: bad argument");
+  long long n = (long long)B * N * h * w;
+  if (hard_is_i64)
+    hipLaunchKernelGGL(mask_prep_kernel<long long>, grid1(n), dim3(256), 0, ST, static_cast<const long long *>(hard),
+                       Hh, Wh, soft, Hs, Ws, out, B, N, h, w);
+  else
+    hipLaunchKernelGGL(mask_prep_kernel<float>, grid1(n), dim3(256), 0, ST, static_cast<const float *>(hard), Hh, Wh,
+                       soft, Hs, Ws, out, B, N, h, w);
+  SWEM_CHECK_LAUNCH("mask_prep");
+  return SWEM_OK;
+}
+
+extern "C" size_t swem_cbam_workspace(int B, int H, int W, int C) {
+  return ((size_t)B * CBAM_CHUNKS * 2 * C + (size_t)B * H * W * 3) * sizeof(float);
+}
+
+extern "C" int swem_cbam_f32(void *stream, const float *x, const float *w1, const float *b1, const float *w2,
+                             const float *b2, const float *w7, const float *b7, float *cscale, float *y, int B, int H,
+                             int W, int C, int hid, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(x && w1 && b1 && w2 && b2 && w7 && b7 && cscale && y, SWEM_E_ARG, "cbam: null pointer");
+  SWEM_REQUIRE(C % 4 == 0 && C <= 4096 && hid > 0 && hid <= 256, SWEM_E_SHAPE, "cbam: unsupported C/hid");
+  SWEM_REQUIRE(ws && ws_bytes >= swem_cbam_workspace(B, H, W, C), SWEM_E_WORKSPACE, "cbam: workspace too small");
+  const int P = H * W;
+  float *part = static_cast<float *>(ws);
+  float *comp = part + (size_t)B * CBAM_CHUNKS * 2 * C;
+  float *sg = comp + (size_t)B * P * 2;
+  hipLaunchKernelGGL(cbam_pool_partial_kernel, dim3(CBAM_CHUNKS, B), dim3(256), 0, ST, x, part, P, C);
+  SWEM_CHECK_LAUNCH("cbam_pool_partial");
+  hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(256), (2 * C + 2 * hid) * sizeof(float), ST, part, w1, b1, w2, b2,
+                     cscale, P, C, hid);
+  SWEM_CHECK_LAUNCH("cbam_mlp");
+  hipLaunchKernelGGL(cbam_spatial_pool_kernel, grid1((long long)B * P * 64), dim3(256), 0, ST, x, cscale, comp, B, P,
+                     C);
+  SWEM_CHECK_LAUNCH("cbam_spatial_pool");
+  hipLaunchKernelGGL(cbam_sgate_kernel, grid1((long long)B * P), dim3(256), 0, ST, comp, w7, b7, sg, B, H, W);
+  SWEM_CHECK_LAUNCH("cbam_sgate");
+  hipLaunchKernelGGL(cbam_apply_kernel, grid1((long long)B * P * (C / 4)), dim3(256), 0, ST, x, cscale, sg, y, B, P,
+                     C);
+  SWEM_CHECK_LAUNCH("cbam_apply");
+  return SWEM_OK;
+}
+
+extern "C" int swem_pred_head_f32(void *stream, const float *x, const float *w, const float *bias, float *logit,
+                                  int B, int H, int W, int C) {
+  SWEM_REQUIRE(x && w && bias && logit && C % 4 == 0, SWEM_E_SHAPE, "pred_head: bad argument");
+  hipLaunchKernelGGL(pred_head_kernel, grid1((long long)B * H * W * 64), dim3(256), 0, ST, x, w, bias, logit, B, H, W,
+                     C);
+  SWEM_CHECK_LAUNCH("pred_head");
+  return SWEM_OK;
+}
+
+extern "C" int swem_decode_head_f32(void *stream, const float *logit4, const float *valid, float *logits, float *prob,
+                                    long long *argmax, int B, int N, int h4, int w4, int Ho, int Wo) {
+  SWEM_REQUIRE(logit4 && logits && prob && N > 0, SWEM_E_ARG, "decode_head: bad argument");
+  hipLaunchKernelGGL(decode_head_kernel, grid1((long long)B * Ho * Wo), dim3(256), 0, ST, logit4, valid, logits, prob,
+                     argmax, B, N, h4, w4, Ho, Wo);
+  SWEM_CHECK_LAUNCH("decode_head");
+  return SWEM_OK;
+}
+
+extern "C" int swem_argmax_onehot_i64(void *stream, const float *prob, long long *argmax, long long *onehot, int B,
+                                      int N1, long long HW) {
+  SWEM_REQUIRE(prob && N1 > 0, SWEM_E_ARG, "argmax_onehot: bad argument");
+  hipLaunchKernelGGL(argmax_onehot_kernel, grid1((long long)B * HW), dim3(256), 0, ST, prob, argmax, onehot, B, N1,
+                     HW);
+  SWEM_CHECK_LAUNCH("argmax_onehot");
+  return SWEM_OK;
+}
+
+extern "C" int swem_transpose_f32(void *stream, const float *in, float *out, int batch, int R, int Cc, int ld) {
+  SWEM_REQUIRE(in && out && ld >= R, SWEM_E_SHAPE, "transpose: ld < R");
+  dim3 grid(cdiv(Cc, 32), cdiv(ld, 32), batch);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, ST, in, out, R, Cc, ld);
+  SWEM_CHECK_LAUNCH("transpose");
+  return SWEM_OK;
+}

@@ -1,0 +1,49 @@
+"""Multi-GPU inference: one process per GPU, sequences sharded across ranks, no data-path collective.
+
+Within a sequence frame t needs frame t-1's bases (reference modules.py:183-193), so the time axis does not
+shard; sequences are independent.  Rank r takes sequences r, r+W, r+2W, ... (round
+robin; the reference's dormant ``val_loader`` uses contiguous ranges, datasets/dataloader.py:39-51 -- either is
+a pure partition).  The only communication is one all-reduce of the (frames, seconds) counters at the end
+(RCCL on GPUs -- torch backend "nccl" -- or gloo in the CPU tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment (no-op for a single process)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        dist.init_process_group(backend=backend, init_method='env://', rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard(items, rank, world):
+    """Round-robin partition: every item goes to exactly one rank."""
+    return [it for i, it in enumerate(items) if i % world == rank]
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def reduce_counters(frames, seconds, device='cpu'):
+    """Whole-job totals: SUM of frames over ranks, MAX of the elapsed time over ranks."""
+    if not dist.is_initialized():
+        return int(frames), float(seconds)
+    f = torch.tensor([float(frames)], dtype=torch.float64, device=device)
+    s = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    dist.all_reduce(f, op=dist.ReduceOp.SUM)
+    dist.all_reduce(s, op=dist.ReduceOp.MAX)
+    return int(round(f.item())), float(s.item())

@@ -1,0 +1,146 @@
+"""Runs the SWEM encoders / decoder on the HIP kernels.
+
+``Engine`` walks the parameter containers of ``swem_amd.networks`` once, packs every conv into the
+kernel layout (OHWI weights, frozen BatchNorm folded into a per-filter scale/shift) and then executes
+the reference's forward graphs (citations per method) as a sequence of C-ABI calls.  Activations are
+NHWC fp32 tensors; nothing here computes with torch.
+"""
+import ctypes as C
+
+import torch
+
+from . import ops
+from .networks import BasicBlock, Bottleneck
+
+
+def _bn(m):
+    return (m.weight, m.bias, m.running_mean, m.running_var)
+
+
+class _Block:
+    """One ResNet block (mod_resnet.py:58-113) as packed convs."""
+
+    def __init__(self, blk):
+        s = blk.stride
+        self.bottleneck = isinstance(blk, Bottleneck)
+        if self.bottleneck:
+            self.c1 = ops.pack_conv(blk.conv1.weight, blk.conv1.bias, _bn(blk.bn1), 1, 0)
+            self.c2 = ops.pack_conv(blk.conv2.weight, blk.conv2.bias, _bn(blk.bn2), s, 1)
+            self.c3 = ops.pack_conv(blk.conv3.weight, blk.conv3.bias, _bn(blk.bn3), 1, 0)
+        else:
+            assert isinstance(blk, BasicBlock)
+            self.c1 = ops.pack_conv(blk.conv1.weight, blk.conv1.bias, _bn(blk.bn1), s, 1)
+            self.c2 = ops.pack_conv(blk.conv2.weight, blk.conv2.bias, _bn(blk.bn2), 1, 1)
+        self.down = None
+        if blk.downsample is not None:
+            d = blk.downsample
+            self.down = ops.pack_conv(d[0].weight, d[0].bias, _bn(d[1]), s, 0)
+
+    def __call__(self, x):
+        res = x if self.down is None else ops.conv2d([x], self.down)
+        if self.bottleneck:
+            y = ops.conv2d([x], self.c1, relu_out=True)
+            y = ops.conv2d([y], self.c2, relu_out=True)
+            return ops.conv2d([y], self.c3, relu_out=True, residual=res)
+        y = ops.conv2d([x], self.c1, relu_out=True)
+        return ops.conv2d([y], self.c2, relu_out=True, residual=res)
+
+
+class _ResBlock:
+    """networks.py:12-32: r = conv2(relu(conv1(relu(x)))); out = downsample(x) + r."""
+
+    def __init__(self, rb):
+        self.c1 = ops.pack_conv(rb.conv1.weight, rb.conv1.bias)
+        self.c2 = ops.pack_conv(rb.conv2.weight, rb.conv2.bias)
+        self.down = None if rb.downsample is None else ops.pack_conv(rb.downsample.weight, rb.downsample.bias)
+
+    def __call__(self, srcs, batch=None):
+        r = ops.conv2d(srcs, self.c1, relu_in=True, batch=batch)
+        if self.down is None:
+            assert len(srcs) == 1
+            res = srcs[0]
+        else:
+            res = ops.conv2d(srcs, self.down, batch=batch)
+        return ops.conv2d([r], self.c2, relu_in=True, residual=res)
+
+
+class Engine:
+    def __init__(self, model):
+        dev = next(model.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('swem_amd runs on a HIP device only (model is on %s); there is no CPU path' % dev)
+        self.device = dev
+        self.single_obj = model.single_object
+        ke, ve, dec = model.key_encoder, model.value_encoder, model.decoder
+        # --- key encoder (networks.py:132-170)
+        self.k_mean, self.k_std = ops._f3(ke.mean), ops._f3(ke.std)
+        self.k_stem = ops.pack_conv(ke.conv1.weight, None, _bn(ke.bn1), 2, 3, cin_pad=4)
+        self.k_stages = [[_Block(b) for b in st] for st in (ke.res2, ke.layer2, ke.layer3)]
+        self.key_proj = ops.pack_conv(model.key_proj.key_proj.weight, model.key_proj.key_proj.bias)
+        self.key_comp = ops.pack_conv(model.key_comp.weight, model.key_comp.bias)
+        # --- value encoder (networks.py:94-129)
+        self.v_mean, self.v_std = ops._f3(ve.mean), ops._f3(ve.std)
+        self.v_stem = ops.pack_conv(ve.conv1.weight, ve.conv1.bias, _bn(ve.bn1), 2, 3, cin_pad=8)
+        self.v_stages = [[_Block(b) for b in st] for st in (ve.layer1, ve.layer2, ve.layer3)]
+        self.fuse1 = _ResBlock(ve.fuser.block1)
+        self.fuse2 = _ResBlock(ve.fuser.block2)
+        att = ve.fuser.attention
+        f32 = lambda t: t.detach().float().contiguous()
+        self.cbam = [f32(att.ChannelGate.mlp[1].weight), f32(att.ChannelGate.mlp[1].bias),
+                     f32(att.ChannelGate.mlp[3].weight), f32(att.ChannelGate.mlp[3].bias),
+                     f32(att.SpatialGate.spatial.conv.weight), f32(att.SpatialGate.spatial.conv.bias)]
+        # --- fusion layer (modules.py:13-26)
+        fl = model.swem_core.fusion_layer
+        self.glu = ops.pack_glu(fl.layer_f.weight, fl.layer_f.bias, fl.layer_a.weight, fl.layer_a.bias)
+        # --- decoder (networks.py:199-216)
+        self.compress = _ResBlock(dec.compress)
+        self.skip8 = ops.pack_conv(dec.up_16_8.skip_conv.weight, dec.up_16_8.skip_conv.bias)
+        self.out8 = _ResBlock(dec.up_16_8.out_conv)
+        self.skip4 = ops.pack_conv(dec.up_8_4.skip_conv.weight, dec.up_8_4.skip_conv.bias)
+        self.out4 = _ResBlock(dec.up_8_4.out_conv)
+        self.pred_w = f32(dec.pred.weight.permute(0, 2, 3, 1))  # [1][3][3][C]
+        self.pred_b = f32(dec.pred.bias)
+
+    # swem.py:39-43 + networks.py:160-182
+    def encode_key(self, frames):
+        x = ops.prep_key_input(frames, self.k_mean, self.k_std)
+        x = ops.maxpool(ops.conv2d([x], self.k_stem, relu_out=True))
+        feats = []
+        for st in self.k_stages:
+            for blk in st:
+                x = blk(x)
+            feats.append(x)
+        s4, s8, s16 = feats
+        qk16 = ops.conv2d([s16], self.key_proj)
+        qv16 = ops.conv2d([s16], self.key_comp)
+        return qk16, qv16, s16, s8, s4
+
+    # swem.py:45-62 + networks.py:113-129, 43-50
+    def encode_value(self, frame, masks, s16):
+        """frame NCHW (B,3,H,W), masks NCHW (B,N+1,H,W), s16 NHWC (B,h,w,Cs) -> NHWC (B*N,h,w,512)."""
+        B = frame.shape[0]
+        N = masks.shape[1] - 1
+        if B != 1 and N != 1:
+            # s16 must repeat per object inside each batch item; the conv broadcast covers B == 1 or N == 1 only
+            raise NotImplementedError('encode_value: batch > 1 with several objects needs an expanded s16')
+        x = ops.prep_value_input(frame, masks, self.v_mean, self.v_std, self.single_obj)
+        x = ops.maxpool(ops.conv2d([x], self.v_stem, relu_out=True))
+        for st in self.v_stages:
+            for blk in st:
+                x = blk(x)
+        x = self.fuse1([x, s16], batch=B * N)              # cat([x, f16]) never materialised
+        x = ops.cbam_residual(x, *self.cbam)                # x + CBAM(x)
+        return self.fuse2([x])
+
+    # modules.py:286-291
+    def fuse_context(self, mem_out, qv16, s_feat):
+        return ops.conv2d([mem_out, qv16, s_feat], self.glu, batch=mem_out.shape[0])
+
+    # networks.py:208-213 ; the skip convs see the same s8/s4 for every object (swem.py:94-95): computed once
+    def decoder_logit(self, context, s8, s4):
+        x = self.compress([context])
+        sk = ops.conv2d([s8], self.skip8)
+        x = self.out8([ops.upsample_add(sk, x)])
+        sk = ops.conv2d([s4], self.skip4)
+        x = self.out4([ops.upsample_add(sk, x)])
+        return ops.pred_head(x, self.pred_w, self.pred_b)

@@ -1,0 +1,236 @@
+"""SWEMCore: the sequential weighted EM memory, HIP-backed.
+
+Mirror of the reference's ``methods/SWEM/modules.py`` (same class / method / attribute names, same
+argument meaning, same bank policy) so callers written against the reference
+(``swem_evaluator.py:66-93``, ``swem_trainer.py:64-90``) work unchanged.  The arithmetic runs in
+``libswem_hip.so``; there is no torch fallback.
+
+Tensors cross this boundary in the reference's shapes: ``qk (B,Ck,h,w)``, ``qv (B,N,Cv,h,w)`` /
+``(B,Cv,h,w)``, ``masks (B,N,2,h,w)``, bases ``kappa (B,N,2,Ck,L)``, ``nu (B,N,2,Cv,L)``,
+``zita (B,N,2,1,L)``.  Feature maps produced by this package are channels-last in memory, so the
+``(P,C)`` pixel-major views the kernels want are free; foreign NCHW inputs are repacked by the
+transpose kernel.  B must be 1 (the reference evaluator's case; objects of one frame are batched as N).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+def l2norm(inp, dim):
+    """modules.py:7-9 (host-side helper for random_init only)."""
+    norm = torch.linalg.norm(inp, dim=dim, keepdim=True) + 1e-6
+    return inp / norm
+
+
+def to_pixel_major(t):
+    """(B,C,h,w) -> contiguous (B,h,w,C) memory; free for channels-last input."""
+    v = t.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v
+    B, Cc, h, w = t.shape
+    return ops.transpose(t.contiguous().view(B, Cc, h * w)).view(B, h, w, Cc)
+
+
+class FeatureFusionLayer(nn.Module):
+    """modules.py:13-26: parameters of the GLU fusion conv pair (executed by Engine.fuse_context)."""
+
+    def __init__(self, indim, outdim):
+        super().__init__()
+        self.layer_f = nn.Conv2d(indim, outdim, kernel_size=3, stride=1, padding=1)
+        self.layer_a = nn.Conv2d(indim, outdim, kernel_size=3, stride=1, padding=1)
+        nn.init.orthogonal_(self.layer_f.weight.data)
+        nn.init.zeros_(self.layer_f.bias.data)
+        nn.init.orthogonal_(self.layer_a.weight.data)
+        nn.init.zeros_(self.layer_a.bias.data)
+
+
+class MemoryBank:
+    """modules.py:29-60."""
+
+    def __init__(self, mode='updated'):
+        self.mode = mode
+        assert (self.mode in ['fixed', 'updated'])
+        self.bases = None
+        self.n_objs = 0
+
+    def initial_memory(self):
+        self.bases = None
+        self.n_objs = 0
+
+    def add_new(self, bases):
+        if self.bases is None:
+            self.bases = bases
+            self.n_objs = bases['kappa'].shape[1]
+        else:
+            N = bases['kappa'].shape[1]
+            if N > self.n_objs:
+                for key in bases.keys():
+                    self.bases[key] = torch.cat([self.bases[key], bases[key][:, self.n_objs:]], dim=1)
+            self.n_objs = N
+
+    def update(self, bases):
+        if self.mode == 'fixed':
+            self.add_new(bases)
+        else:
+            self.bases = bases
+
+
+class SWEMCore(nn.Module):
+    """modules.py:63-310."""
+
+    def __init__(self, n_bases=256, valdim=512, n_iters=4, tau=0.05, topl=64):
+        super().__init__()
+        self.n_bases = n_bases
+        self.n_iters = n_iters
+        self.tau = tau
+        assert (self.tau > 0)
+        self.valdim = valdim
+        self.memories = dict()
+        self.memories['first'] = MemoryBank(mode='fixed')
+        self.memories['update'] = MemoryBank(mode='updated')
+        self.p_drop = 0.0
+        self.topl = int(min(self.n_bases, topl))
+        self.fusion_layer = FeatureFusionLayer(valdim * 2 + self.topl * 2, valdim)
+        self.init_on_host = False
+        self._engine = None  # set by SWEM (the fusion conv needs the packed GLU weights)
+
+    def empty(self):
+        for key in self.memories.keys():
+            self.memories[key].initial_memory()
+
+    # ------------------------------------------------------------------ single EM steps (modules.py:93-127)
+    def sww_step(self, kappa, x_t, masks):
+        """kappa (B,N,2,Ck,L), x_t (B,1,1,P,Ck), masks (B,N,2,P,1) -> weights (B,N,2,P,1)."""
+        B, N = kappa.shape[:2]
+        assert B == 1
+        kn = ops.em_norm_bases(kappa.reshape(N * 2, *kappa.shape[-2:]).contiguous())
+        x = x_t.reshape(x_t.shape[-2], x_t.shape[-1]).contiguous()
+        w, _ = ops.em_ew(x, kn, masks.reshape(N * 2, -1).contiguous(), None, self.tau, True, False)
+        return w.view(B, N, 2, -1, 1)
+
+    def swe_step(self, x_t, kappa, weights):
+        """-> z (B,N,2,P,L)."""
+        B, N = kappa.shape[:2]
+        assert B == 1
+        L = kappa.shape[-1]
+        kn = ops.em_norm_bases(kappa.reshape(N * 2, *kappa.shape[-2:]).contiguous())
+        x = x_t.reshape(x_t.shape[-2], x_t.shape[-1]).contiguous()
+        P = x.shape[0]
+        _, zT = ops.em_ew(x, kn, None, weights.reshape(N * 2, -1).contiguous(), self.tau, False, True)
+        return zT[:, :, :P].transpose(1, 2).reshape(B, N, 2, P, L)
+
+    def swm_step(self, z, x, kappa_, zita_):
+        """z (B,N,2,P,L), x (B,1,1,Ck,P) -> kappa (B,N,2,Ck,L), zita (B,N,2,1,L)."""
+        B, N, _, P, L = z.shape
+        assert B == 1
+        Pp = ops.em_pad(P)
+        zT = ops.transpose(z.reshape(N * 2, P, L).contiguous())          # (NK, L, P)
+        if Pp != P:
+            zT = torch.nn.functional.pad(zT, (0, Pp - P)).contiguous()
+        xT = x.reshape(x.shape[-2], P)
+        xT = torch.nn.functional.pad(xT, (0, Pp - P)).contiguous()
+        kappa, zita, _ = ops.em_mstep(xT, 0, zT, kappa_.reshape(N * 2, -1, L).contiguous(),
+                                      zita_.reshape(N * 2, L).contiguous(), P)
+        return kappa.view(B, N, 2, -1, L), zita.view(B, N, 2, 1, L)
+
+    # ------------------------------------------------------------------ modules.py:129-168
+    def swem(self, x, v, masks, bases_=None):
+        B, Ck, H, W = x.shape
+        N = masks.shape[1]
+        if B != 1:
+            raise NotImplementedError('swem_amd.SWEMCore: batch > 1 is not built yet (inference uses B = 1)')
+        if bases_ is None:
+            kappa_, nu_, zita_ = self.random_init(size=(B, N, 2, Ck, self.n_bases), dtype=x.dtype, device=x.device)
+        else:
+            kappa_, nu_, zita_ = bases_['kappa'], bases_['nu'], bases_['zita']
+        N_new = N - kappa_.shape[1]
+        if N_new > 0:
+            new_kappa, new_nu, new_zita = self.random_init(size=(B, N_new, 2, Ck, self.n_bases), dtype=x.dtype,
+                                                           device=x.device)
+            kappa_ = torch.cat([kappa_, new_kappa], dim=1)
+            nu_ = torch.cat([nu_, new_nu], dim=1)
+            zita_ = torch.cat([zita_, new_zita], dim=1)
+        L = self.n_bases
+        xp = to_pixel_major(x).view(H * W, Ck)                       # (P, C)
+        if v.dim() == 5:                                             # (B,N,V,h,w) reference layout
+            vp = to_pixel_major(v.flatten(0, 1)).view(N, H * W, -1)
+        else:                                                        # engine output (B*N,h,w,V) NHWC
+            vp = v.view(N, H * W, -1)
+        mk = masks.reshape(N, 2, H * W).contiguous()
+        kappa, nu, zita = ops.memorize(xp, vp, mk, kappa_.reshape(N, 2, Ck, L).contiguous(),
+                                       nu_.reshape(N, 2, -1, L).contiguous(), zita_.reshape(N, 2, L).contiguous(),
+                                       self.n_iters, self.tau)
+        return {'kappa': kappa.view(B, N, 2, Ck, L), 'nu': nu.view(B, N, 2, -1, L),
+                'zita': zita.view(B, N, 2, 1, L)}
+
+    def random_init(self, size, norm_dim=-2, dtype=None, device=None):
+        """modules.py:170-178.  Host-side on purpose: the bases are drawn from the torch
+        generator of the tensor's device exactly like the reference does, so equal seeds give equal bases."""
+        B, N, _, _, L = size
+        if self.init_on_host:      # parity aid: same numbers as a CPU run of the reference with the same seed
+            kappa = torch.zeros(size=size, dtype=dtype)
+            kappa.normal_(0, math.sqrt(2. / size[-1]))
+            kappa = l2norm(kappa, dim=norm_dim).to(device)
+        else:
+            kappa = torch.zeros(size=size, dtype=dtype, device=device)
+            kappa.normal_(0, math.sqrt(2. / size[-1]))
+            kappa = l2norm(kappa, dim=norm_dim)
+        nu = torch.zeros(B, N, 2, self.valdim, L, dtype=dtype, device=device)
+        zita = torch.zeros(B, N, 2, 1, L, dtype=dtype, device=device) + 1e-6
+        return kappa, nu, zita
+
+    # ------------------------------------------------------------------ modules.py:183-193
+    def memorize(self, qk, qv, masks):
+        if self.memories['update'].bases is None:
+            bases = self.swem(qk, qv, masks, self.memories['first'].bases)
+        else:
+            bases = self.swem(qk, qv, masks, self.memories['update'].bases)
+        if self.memories['first'].bases is None:
+            self.memories['first'].update(bases)
+        else:
+            self.memories['first'].update(bases)
+            self.memories['update'].update(bases)
+
+    # ------------------------------------------------------------------ modules.py:232-293
+    def _affinity_readout(self, qk, first, update):
+        """get_affinity + perm_inv_feat in one kernel.  qk (1,Ck,h,w) RAW (normalised in-kernel, modules.py:282-283) -> S (N,h,w,2l) and mem_out (N,h,w,V), NHWC."""
+        B, Ck, H, W = qk.shape
+        assert B == 1
+        xp = to_pixel_major(qk).view(H * W, Ck)
+        N, L = first['kappa'].shape[1], first['kappa'].shape[-1]
+        kf = first['kappa'].reshape(N, 2, Ck, L).contiguous()
+        nf = first['nu'].reshape(N, 2, -1, L).contiguous()
+        ku = nu = None
+        if update is not None:
+            ku = update['kappa'].reshape(N, 2, Ck, L).contiguous()
+            nu = update['nu'].reshape(N, 2, -1, L).contiguous()
+        mem_out, S = ops.match(xp, kf, nf, ku, nu, self.topl, self.tau)
+        return S.view(N, H, W, -1), mem_out.view(N, H, W, -1)
+
+    def matching(self, qk, qv):
+        first, update = self.memories['first'].bases, self.memories['update'].bases
+        if first is None:
+            raise RuntimeError('matching before the memory was initialised')
+        if update is not None and update['kappa'].shape[1] != first['kappa'].shape[1]:
+            raise RuntimeError('memory banks disagree on the number of objects')
+        S, mem_out = self._affinity_readout(qk, first, update)
+        qvp = to_pixel_major(qv)                                      # (1,h,w,V), shared by all objects
+        if self._engine is None:
+            raise RuntimeError('SWEMCore.matching needs the owning SWEM model (packed fusion weights)')
+        ctx = self._engine().fuse_context(mem_out, qvp, S)           # (N,h,w,V) NHWC
+        return ctx.permute(0, 3, 1, 2), mem_out.shape[0]
+
+    def get_mem(self):
+        """modules.py:295-306 (inspection only: matching reads the banks directly)."""
+        kappas, nus = [], []
+        for key, mem in self.memories.items():
+            if mem.bases is not None:
+                kappas.append(mem.bases['kappa'])
+                nus.append(mem.bases['nu'])
+        return torch.cat(kappas, dim=-1), torch.cat(nus, dim=-1)
+
+    def forward(self, qk, qv):
+        pass

@@ -1,0 +1,328 @@
+"""Thin Python wrappers over the C ABI (include/swem_hip.h).
+
+torch is used for device memory and the current HIP stream only; every value is computed by
+a kernel of libswem_hip.so.  All activations are NHWC fp32 tensors ``(B, H, W, C)``.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+RELU_IN, RELU_OUT, GLU = 1, 2, 4
+
+_ws = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, name='tensor'):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise _lib.SwemHipError('%s must be a contiguous fp32 device tensor (got %s %s contiguous=%s)'
+                                % (name, t.device, t.dtype, t.is_contiguous()))
+    return t
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device (the library never allocates)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+class ConvPack:
+    """Weights of one conv in kernel layout: w [Cout'][KH][KW][Cin_pad] plus per-filter scale / shift."""
+
+    def __init__(self, w, scale, shift, cout, kh, kw, stride, pad, glu=False):
+        self.w, self.scale, self.shift = w, scale, shift
+        self.cout, self.kh, self.kw, self.stride, self.pad, self.glu = cout, kh, kw, stride, pad, glu
+        self.cin = w.shape[-1]
+
+
+def pack_conv(weight, bias=None, bn=None, stride=1, pad=None, cin_pad=None, eps=1e-5):
+    """OIHW weight (+bias, + frozen BatchNorm (gamma, beta, mean, var)) -> ConvPack.
+    BN folding follows ATen's eval-mode batch_norm: alpha = gamma/sqrt(var+eps), y = x*alpha + (beta - mean*alpha)."""
+    co, ci, kh, kw = weight.shape
+    w = weight.detach().float().permute(0, 2, 3, 1)
+    cp = cin_pad if cin_pad is not None else (ci + 3) // 4 * 4
+    if cp != ci:
+        w = torch.nn.functional.pad(w, (0, cp - ci))
+    w = w.contiguous()
+    dev = weight.device
+    scale = shift = None
+    if bn is not None:
+        g, b, m, v = [t.detach().float() for t in bn]
+        alpha = g / torch.sqrt(v + eps)
+        scale = alpha.contiguous()
+        shift = b - m * alpha
+        if bias is not None:
+            shift = shift + bias.detach().float() * alpha
+        shift = shift.contiguous()
+    elif bias is not None:
+        shift = bias.detach().float().contiguous()
+    return ConvPack(w.to(dev), scale, shift, co, kh, kw, stride, kh // 2 if pad is None else pad)
+
+
+def pack_glu(wf, bf, wa, ba):
+    """Two 3x3 convs (f, a) -> one GLU pack with filters grouped [Cout/32][f|a][32] (modules.py:13-26)."""
+    co, ci, kh, kw = wf.shape
+    assert co % 32 == 0 and ci % 4 == 0
+    f = wf.detach().float().permute(0, 2, 3, 1).reshape(co // 32, 1, 32, kh, kw, ci)
+    a = wa.detach().float().permute(0, 2, 3, 1).reshape(co // 32, 1, 32, kh, kw, ci)
+    w = torch.cat([f, a], 1).reshape(2 * co, kh, kw, ci).contiguous()
+    shift = torch.cat([bf.detach().float().reshape(co // 32, 1, 32), ba.detach().float().reshape(co // 32, 1, 32)],
+                      1).reshape(2 * co).contiguous()
+    return ConvPack(w, None, shift, co, kh, kw, 1, kh // 2, glu=True)
+
+
+def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadcast=False, batch=None, out=None):
+    """srcs: list of up to three NHWC tensors concatenated on C; a source with batch 1 is broadcast over `batch`."""
+    x0 = _chk(srcs[0], 'conv input')
+    B = batch if batch is not None else max(s.shape[0] for s in srcs)
+    _, H, W, _ = x0.shape
+    args = []
+    cin = 0
+    for s in srcs:
+        _chk(s, 'conv input')
+        if s.shape[1] != H or s.shape[2] != W:
+            raise _lib.SwemHipError('conv2d: sources differ in spatial size')
+        bs = 0 if (s.shape[0] == 1 and B > 1) else H * W * s.shape[3]
+        args += [s.data_ptr(), s.shape[3], bs]
+        cin += s.shape[3]
+    for _ in range(3 - len(srcs)):
+        args += [0, 0, 0]
+    if cin != pack.cin:
+        raise _lib.SwemHipError('conv2d: input has %d channels, pack expects %d' % (cin, pack.cin))
+    Ho = (H + 2 * pack.pad - pack.kh) // pack.stride + 1
+    Wo = (W + 2 * pack.pad - pack.kw) // pack.stride + 1
+    flags = (RELU_IN if relu_in else 0) | (RELU_OUT if relu_out else 0) | (GLU if pack.glu else 0)
+    y = out if out is not None else torch.empty((B, Ho, Wo, pack.cout), dtype=torch.float32, device=x0.device)
+    wsb = _lib.query('swem_conv2d_workspace', B, H, W, cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags)
+    ws = workspace(wsb, x0.device) if wsb else None
+    res_bs = 0
+    if residual is not None:
+        _chk(residual, 'conv residual')
+        res_bs = 0 if (res_broadcast or (residual.shape[0] == 1 and B > 1)) else Ho * Wo * pack.cout
+    _lib.call('swem_conv2d_nhwc_f32', _stream(), *args, B, H, W, pack.w.data_ptr(), _ptr(pack.scale),
+              _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw, pack.stride,
+              pack.pad, flags, _ptr(ws), wsb)
+    return y
+
+
+def _f3(t):
+    v = [float(x) for x in t.detach().flatten().cpu().tolist()]
+    return (C.c_float * 3)(*v)
+
+
+def prep_key_input(frames, mean3, std3):
+    """frames NCHW (B,3,H,W) -> normalised NHWC (B,H,W,4); mean3/std3 are ctypes float[3]."""
+    _chk(frames, 'frames')
+    B, _, H, W = frames.shape
+    out = torch.empty((B, H, W, 4), dtype=torch.float32, device=frames.device)
+    _lib.call('swem_prep_key_input_f32', _stream(), frames.data_ptr(), C.addressof(mean3), C.addressof(std3),
+              out.data_ptr(), B, H, W)
+    return out
+
+
+def prep_value_input(frame, masks, mean3, std3, single_obj):
+    _chk(frame, 'frame')
+    _chk(masks, 'masks')
+    B, _, H, W = frame.shape
+    N = masks.shape[1] - 1
+    out = torch.empty((B * N, H, W, 8), dtype=torch.float32, device=frame.device)
+    _lib.call('swem_prep_value_input_f32', _stream(), frame.data_ptr(), masks.data_ptr(), C.addressof(mean3),
+              C.addressof(std3), out.data_ptr(), B, N, H, W, int(single_obj))
+    return out
+
+
+def maxpool(x):
+    _chk(x)
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.float32, device=x.device)
+    _lib.call('swem_maxpool3x3s2_nhwc_f32', _stream(), x.data_ptr(), y.data_ptr(), B, H, W, Cc)
+    return y
+
+
+def upsample_add(skip, low, batch=None):
+    """skip (B or 1, Ho, Wo, C) + bilinear(low (B, Hl, Wl, C))."""
+    _chk(skip)
+    _chk(low)
+    B = low.shape[0]
+    _, Ho, Wo, Cc = skip.shape
+    y = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=low.device)
+    sbs = 0 if (skip.shape[0] == 1 and B > 1) else Ho * Wo * Cc
+    _lib.call('swem_upsample_add_nhwc_f32', _stream(), skip.data_ptr(), sbs, low.data_ptr(), y.data_ptr(), B,
+              low.shape[1], low.shape[2], Ho, Wo, Cc)
+    return y
+
+
+def resize_planes(x, size, mode):
+    """F.interpolate on the last two dims; mode 'nearest' or 'bilinear' (align_corners=False)."""
+    _chk(x)
+    Hi, Wi = x.shape[-2:]
+    planes = x.numel() // (Hi * Wi)
+    y = torch.empty(tuple(x.shape[:-2]) + tuple(size), dtype=torch.float32, device=x.device)
+    _lib.call('swem_resize_planes_f32', _stream(), x.data_ptr(), y.data_ptr(), planes, Hi, Wi, size[0], size[1],
+              {'nearest': 0, 'bilinear': 1}[mode])
+    return y
+
+
+def mask_prep(hard, soft, h, w):
+    """swem.py:79-84 -> (B*N, 2, h*w)."""
+    if hard.dtype not in (torch.int64, torch.float32):
+        hard = hard.float()
+    if not (hard.is_cuda and hard.is_contiguous()):
+        raise _lib.SwemHipError('mask_prep: hard mask must be a contiguous device tensor')
+    _chk(soft, 'soft mask')
+    B, N1 = hard.shape[:2]
+    N = N1 - 1
+    out = torch.empty((B * N, 2, h * w), dtype=torch.float32, device=soft.device)
+    _lib.call('swem_mask_prep_f32', _stream(), hard.data_ptr(), int(hard.dtype == torch.int64), hard.shape[2],
+              hard.shape[3], soft.data_ptr(), soft.shape[2], soft.shape[3], out.data_ptr(), B, N, h, w)
+    return out
+
+
+def cbam_residual(x, w1, b1, w2, b2, w7, b7):
+    """x + CBAM(x) (networks.py:46-47)."""
+    _chk(x)
+    B, H, W, Cc = x.shape
+    hid = w1.shape[0]
+    y = torch.empty_like(x)
+    cscale = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    wsb = _lib.query('swem_cbam_workspace', B, H, W, Cc)
+    ws = workspace(wsb, x.device)
+    _lib.call('swem_cbam_f32', _stream(), x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+              w7.data_ptr(), b7.data_ptr(), cscale.data_ptr(), y.data_ptr(), B, H, W, Cc, hid, ws.data_ptr(), wsb)
+    return y
+
+
+def pred_head(x, w, bias):
+    _chk(x)
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
+    _lib.call('swem_pred_head_f32', _stream(), x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W,
+              Cc)
+    return out
+
+
+def decode_head(logit4, B, N, out_size, valid=None, want_argmax=False):
+    _chk(logit4)
+    h4, w4 = logit4.shape[-2:]
+    Ho, Wo = out_size
+    dev = logit4.device
+    logits = torch.empty((B, N + 1, Ho, Wo), dtype=torch.float32, device=dev)
+    prob = torch.empty_like(logits)
+    amax = torch.empty((B, Ho, Wo), dtype=torch.int64, device=dev) if want_argmax else None
+    if valid is not None:
+        valid = _chk(valid.float().contiguous(), 'valid_obj')
+    _lib.call('swem_decode_head_f32', _stream(), logit4.data_ptr(), _ptr(valid), logits.data_ptr(), prob.data_ptr(),
+              _ptr(amax), B, N, h4, w4, Ho, Wo)
+    return logits, prob, amax
+
+
+def argmax_onehot(prob, want_onehot=True):
+    _chk(prob)
+    B, N1, H, W = prob.shape
+    amax = torch.empty((B, H, W), dtype=torch.int64, device=prob.device)
+    onehot = torch.empty((B, N1, H, W), dtype=torch.int64, device=prob.device) if want_onehot else None
+    _lib.call('swem_argmax_onehot_i64', _stream(), prob.data_ptr(), amax.data_ptr(), _ptr(onehot), B, N1, H * W)
+    return amax, onehot
+
+
+def transpose(x, ld=None):
+    """(batch, R, Cc) -> (batch, Cc, ld) with zero padded columns."""
+    _chk(x)
+    b, R, Cc = x.shape
+    ld = R if ld is None else ld
+    out = torch.empty((b, Cc, ld), dtype=torch.float32, device=x.device)
+    _lib.call('swem_transpose_f32', _stream(), x.data_ptr(), out.data_ptr(), b, R, Cc, ld)
+    return out
+
+
+# ------------------------------------------------------------------ EM / matching
+def em_pad(P):
+    return _lib.query('swem_em_pad', P)
+
+
+def em_norm_bases(kappa):
+    """kappa (NK, C, L) -> kn (NK, L, C)."""
+    _chk(kappa)
+    NK, Cc, L = kappa.shape
+    kn = torch.empty((NK, L, Cc), dtype=torch.float32, device=kappa.device)
+    _lib.call('swem_em_norm_bases_f32', _stream(), kappa.data_ptr(), kn.data_ptr(), NK, Cc, L)
+    return kn
+
+
+def em_ew(x, kn, masks, w_in, tau, do_w, do_e):
+    """x (P,C), kn (NK,L,C), masks/w_in (NK,P) -> (weights (NK,P) or None, zT (NK,L,Pp) or None)."""
+    _chk(x)
+    _chk(kn)
+    P, Cc = x.shape
+    NK, L, _ = kn.shape
+    Pp = em_pad(P)
+    w_out = torch.empty((NK, P), dtype=torch.float32, device=x.device) if do_w else None
+    zT = torch.empty((NK, L, Pp), dtype=torch.float32, device=x.device) if do_e else None
+    _lib.call('swem_em_ew_f32', _stream(), x.data_ptr(), kn.data_ptr(), _ptr(masks), _ptr(w_in), _ptr(w_out),
+              _ptr(zT), NK // 2, Cc, P, L, float(tau), int(do_w), int(do_e))
+    return w_out, zT
+
+
+def em_mstep(A, a_div, zT, prev, zita_prev, P, want_kn=False):
+    """A (.., R, Pp); zT (NK, L, Pp); prev (NK, R, L); zita_prev (NK, L) -> out, zita, kn."""
+    NK, L, Pp = zT.shape
+    R = prev.shape[1]
+    out = torch.empty_like(prev)
+    zita = torch.empty_like(zita_prev)
+    kn = torch.empty((NK, L, R), dtype=torch.float32, device=prev.device) if want_kn else None
+    wsb = _lib.query('swem_em_mstep_workspace', NK, R, P, L)
+    ws = workspace(wsb, prev.device)
+    _lib.call('swem_em_mstep_f32', _stream(), A.data_ptr(), a_div, zT.data_ptr(), prev.data_ptr(),
+              zita_prev.data_ptr(), out.data_ptr(), zita.data_ptr(), _ptr(kn), NK, R, P, L, ws.data_ptr(), wsb)
+    return out, zita, kn
+
+
+def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau):
+    """x (P,C); v (N,P,V); masks (N,2,P); bases (N,2,C,L)/(N,2,V,L)/(N,2,L) -> new bases."""
+    for t in (x, v, masks, kappa_prev, nu_prev, zita_prev):
+        _chk(t)
+    P, Cc = x.shape
+    N, _, V = v.shape
+    L = kappa_prev.shape[-1]
+    kappa, nu, zita = torch.empty_like(kappa_prev), torch.empty_like(nu_prev), torch.empty_like(zita_prev)
+    wsb = _lib.query('swem_memorize_workspace', N, Cc, V, P, L)
+    ws = workspace(wsb, x.device)
+    _lib.call('swem_memorize_f32', _stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(), kappa_prev.data_ptr(),
+              nu_prev.data_ptr(), zita_prev.data_ptr(), kappa.data_ptr(), nu.data_ptr(), zita.data_ptr(), N, Cc, V,
+              P, L, int(T), float(tau), ws.data_ptr(), wsb)
+    return kappa, nu, zita
+
+
+def match(qk, kappa_first, nu_first, kappa_update, nu_update, topl, tau):
+    """qk (P,C); banks (N,2,C,L)/(N,2,V,L) -> mem_out (N,P,V), S (N,P,2*topl)."""
+    _chk(qk)
+    _chk(kappa_first)
+    _chk(nu_first)
+    P, Cc = qk.shape
+    N, _, V, L = nu_first.shape
+    nb = 1
+    if kappa_update is not None:
+        _chk(kappa_update)
+        _chk(nu_update)
+        nb = 2
+    mem_out = torch.empty((N, P, V), dtype=torch.float32, device=qk.device)
+    S = torch.empty((N, P, 2 * topl), dtype=torch.float32, device=qk.device)
+    wsb = _lib.query('swem_match_workspace', N, Cc, V, P, L, nb)
+    ws = workspace(wsb, qk.device)
+    _lib.call('swem_match_f32', _stream(), qk.data_ptr(), kappa_first.data_ptr(), nu_first.data_ptr(),
+              _ptr(kappa_update), _ptr(nu_update), mem_out.data_ptr(), S.data_ptr(), N, Cc, V, P, L, int(topl),
+              float(tau), ws.data_ptr(), wsb)
+    return mem_out, S

@@ -1,0 +1,109 @@
+"""SWEM: the drop-in model module (reference methods/SWEM/swem.py:9-133).
+
+Same constructor argument (``config_model`` with KEYDIM, VALDIM, NUM_BASES, NUM_EM_ITERS, EM_TAU, TOPL,
+SINGLE_OBJ, BACKBONE), same ``forward(mode, *args)`` dispatcher and mode signatures, same child module
+names and therefore the same ``state_dict`` keys, so the reference's evaluator / trainer loops and
+checkpoints work against it.  All arithmetic is executed by libswem_hip.so through ``Engine``; the model
+must live on a HIP device and fails loudly otherwise.
+
+Feature maps returned by the modes are NCHW-shaped views of channels-last (NHWC) memory.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .engine import Engine
+from .modules import SWEMCore, to_pixel_major
+from .networks import Decoder, KeyEncoder, KeyProjection, ValueEncoder, ValueEncoderSO
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2)
+
+
+class SWEM(nn.Module):
+    def __init__(self, config_model):
+        super().__init__()
+        keydim = config_model.KEYDIM
+        valdim = config_model.VALDIM
+        self.single_object = config_model.SINGLE_OBJ
+        self.key_encoder = KeyEncoder(config_model.BACKBONE)
+        nf = self.key_encoder.num_features
+        self.value_encoder = ValueEncoderSO(nf[0]) if self.single_object else ValueEncoder(nf[0])
+        self.key_proj = KeyProjection(nf[0], keydim=keydim)
+        self.key_comp = nn.Conv2d(nf[0], valdim, kernel_size=(3, 3), padding=(1, 1))
+        self.swem_core = SWEMCore(n_bases=config_model.NUM_BASES, valdim=valdim, n_iters=config_model.NUM_EM_ITERS,
+                                  tau=config_model.EM_TAU, topl=config_model.TOPL)
+        self.decoder = Decoder([valdim, nf[1], nf[2]], 256)
+        self._eng = None
+        self.swem_core._engine = self.engine
+
+    # -- packed-weight cache: rebuilt after load_state_dict / .to() / .cuda()
+    def engine(self):
+        if self._eng is None:
+            self._eng = Engine(self)
+        return self._eng
+
+    def invalidate(self):
+        self._eng = None
+
+    def load_state_dict(self, *a, **k):
+        self._eng = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._eng = None
+        return super()._apply(fn, *a, **k)
+
+    # ------------------------------------------------------------------ swem.py:39-43
+    def encode_key(self, frames):
+        qk16, qv16, s16, s8, s4 = self.engine().encode_key(frames.float().contiguous())
+        return _nchw(qk16), _nchw(qv16), _nchw(s16), _nchw(s8), _nchw(s4)
+
+    # ------------------------------------------------------------------ swem.py:45-62
+    def encode_value(self, frame, masks, s16):
+        B = frame.shape[0]
+        N = masks.shape[1] - 1
+        mv = self.engine().encode_value(frame.float().contiguous(), masks.float().contiguous(), to_pixel_major(s16))
+        mv = _nchw(mv)                                    # (B*N, V, h, w)
+        return mv.view(B, N, *mv.shape[1:])
+
+    # ------------------------------------------------------------------ swem.py:64-86
+    def init_mem(self, qk16, mv16, mask):
+        self.swem_core.empty()
+        return self.memorize(qk16, mv16, mask, mask.float())
+
+    def memorize(self, qk16, mv16, masks_hard, masks_soft):
+        b, _, h_16, w_16 = qk16.shape
+        n = masks_hard.shape[1] - 1
+        masks = ops.mask_prep(masks_hard.contiguous(), masks_soft.float().contiguous(), h_16, w_16)
+        self.swem_core.memorize(qk16, mv16, masks.view(b, n, 2, h_16, w_16))
+
+    # ------------------------------------------------------------------ swem.py:88-90
+    def match(self, qk16, qv16):
+        return self.swem_core.matching(qk16, qv16)
+
+    # ------------------------------------------------------------------ swem.py:92-116
+    def decode(self, n, context, s8, s4, valid_obj, out_size):
+        B = s8.shape[0]
+        if B != 1 and n != 1:
+            raise NotImplementedError('decode: batch > 1 with several objects is not built yet')
+        logit4 = self.engine().decoder_logit(to_pixel_major(context), to_pixel_major(s8), to_pixel_major(s4))
+        logits, pred_mask, _ = ops.decode_head(logit4, B, n, tuple(int(v) for v in out_size), valid=valid_obj)
+        return logits, pred_mask
+
+    def forward(self, mode, *args, **kwargs):
+        if mode == 'encode_key':
+            return self.encode_key(*args, **kwargs)
+        elif mode == 'encode_value':
+            return self.encode_value(*args, **kwargs)
+        elif mode == 'init':
+            return self.init_mem(*args, **kwargs)
+        elif mode == 'memorize':
+            return self.memorize(*args, **kwargs)
+        elif mode == 'match':
+            return self.match(*args, **kwargs)
+        elif mode == 'segment':
+            return self.decode(*args, **kwargs)
+        else:
+            raise NotImplementedError

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    import numpy as np
+    import torch
+
+    def load(name):
+        with np.load(os.path.join(GOLDEN, name)) as z:
+            return {k: (torch.from_numpy(z[k]) if z[k].ndim else z[k].item()) for k in z.files}
+    return load
+
+
+@pytest.fixture(scope='session')
+def lib():
+    """Build (if stale) and load libswem_hip.so."""
+    from swem_amd import build, _lib
+    build.build()
+    return _lib.load()

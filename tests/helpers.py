@@ -1,0 +1,51 @@
+"""Shared helpers for the parity tests (oracle side + clip / weight regeneration)."""
+import torch
+
+from oracle import swem_oracle as O
+from swem_amd import synth, weights
+from swem_amd.swem import SWEM
+
+
+def make_model_and_sd(cfg, wseed, device=None):
+    """Product model with seeded weights (+ the same state dict on CPU for the oracle)."""
+    model = SWEM(cfg)
+    sd = weights.fill_state_dict(model.state_dict(), seed=wseed, backbone=cfg.BACKBONE)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    if device is not None:
+        model = model.to(device)
+        model.swem_core.init_on_host = True    # same random bases as a CPU run with the same seed
+    return model, sd
+
+
+def clip_from_fixture(fx):
+    frames, m0 = synth.make_clip(t=int(fx['t']), h=int(fx['h']), w=int(fx['w']), n_obj=int(fx['n_obj']),
+                                 out_hw=(int(fx['out_h']), int(fx['out_w'])), seed=int(fx['seed']))
+    return frames, m0
+
+
+def checksum(t):
+    return float(t.double().abs().sum())
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def structured_keys(P, C, n_clusters, g, noise=0.15):
+    centres = torch.randn(n_clusters, C, generator=g)
+    assign = (torch.arange(P) * n_clusters // P + torch.randint(0, 2, (P,), generator=g)) % n_clusters
+    return centres[assign] + noise * torch.randn(P, C, generator=g), assign
+
+
+def em_inputs(h, w, C, V, N, g):
+    """Structured (clustered) keys, random values, soft fg/bg masks for N objects."""
+    P = h * w
+    xk, assign = structured_keys(P, C, 6, g)
+    x = xk.t().reshape(1, C, h, w).contiguous()
+    v = torch.randn(1, N, V, h, w, generator=g)
+    fg = torch.stack([((assign >= 2 * n) & (assign < 2 * n + 2)).float() for n in range(N)])
+    sf = (fg * 0.9 + 0.05 * torch.rand(N, P, generator=g)).clamp(0, 1)
+    m = torch.stack([(1 - fg) * (1 - sf), fg * sf], 1).view(1, N, 2, h, w)
+    return x, v, m

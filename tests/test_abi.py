@@ -1,0 +1,53 @@
+"""CPU: libswem_hip.so builds for gfx950, loads, and exports exactly what include/swem_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from swem_amd import _lib
+
+HEADER = os.path.join(os.path.dirname(__file__), '..', 'include', 'swem_hip.h')
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(swem_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), 'library does not export %s' % s
+        assert s in _lib.SIGNATURES, 'ctypes binding lacks %s' % s
+    assert sorted(_lib.SIGNATURES) == syms, 'binding lists symbols the header does not declare'
+
+
+def test_version_and_error_channel(lib):
+    assert lib.swem_version() == 1
+    # argument validation happens before any HIP call, so it can be exercised without a GPU
+    rc = lib.swem_conv2d_nhwc_f32(None, None, 4, 0, None, 0, 0, None, 0, 0, 1, 8, 8, None, None, None, None, 0, None,
+                                  32, 3, 3, 1, 1, 0, None, 0)
+    assert rc == -4 and b'null pointer' in lib.swem_last_error()
+    rc = lib.swem_match_f32(None, 1, 1, 1, None, None, 1, 1, 1, 128, 512, 100, 100, 64, ctypes.c_float(0.05), None, 0)
+    assert rc == -1 and b'bases per class' in lib.swem_last_error()
+    with pytest.raises(_lib.SwemHipError):
+        _lib.call('swem_em_ew_f32', None, 1, 1, None, None, None, None, 1, 100, 10, 64, 0.05, 1, 0)
+
+
+def test_size_queries(lib):
+    assert lib.swem_em_pad(1620) == 1624 and lib.swem_em_pad(1624) == 1624
+    assert lib.swem_match_workspace(2, 128, 512, 1620, 256, 2) >= 2 * 1024 * (128 + 512) * 4
+    assert lib.swem_memorize_workspace(2, 128, 512, 1620, 256) > 0
+    # a 1/16-scale 3x3 conv (13 x 4 tiles of 128x128) is split over K; a full-resolution one is not
+    assert lib.swem_conv2d_workspace(1, 30, 54, 1024, 512, 3, 3, 1, 1, 0) > 0
+    assert lib.swem_conv2d_workspace(2, 120, 216, 256, 256, 3, 3, 1, 1, 0) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.SwemHipError, match='no CPU fallback'):
+        _lib.load()

@@ -1,0 +1,48 @@
+"""CPU, world_size 2 over gloo: the multi-GPU path (sequence sharding + counter reduction) of bench.py / dist.py."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from swem_amd import dist as sdist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    r, lr, w = sdist.init(backend='gloo')
+    seqs = list(range(7))
+    mine = sdist.shard(seqs, r, w)
+    sdist.barrier()
+    frames, secs = sdist.reduce_counters(10 * len(mine), 1.0 + r)
+    q.put((r, mine, frames, secs))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_reduction():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, m0, f0, s0), (r1, m1, f1, s1) = out
+    assert sorted(m0 + m1) == list(range(7)) and not set(m0) & set(m1)   # a partition: no sequence twice, none lost
+    assert f0 == f1 == 70 and s0 == s1 == 2.0                            # SUM of frames, MAX of seconds
+
+
+def test_single_process_is_a_no_op():
+    assert sdist.shard([1, 2, 3], 0, 1) == [1, 2, 3]
+    assert sdist.reduce_counters(5, 0.5) == (5, 0.5)

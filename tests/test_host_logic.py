@@ -1,0 +1,93 @@
+"""CPU: host-side logic of the drop-in boundary (state dict, bank policy, determinism, loud failure)."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import swem_oracle as O
+from swem_amd import synth, weights
+from swem_amd.modules import MemoryBank, SWEMCore
+from swem_amd.swem import SWEM
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.mark.parametrize('tag,kw', [('resnet50_mo', dict(BACKBONE='resnet50')),
+                                    ('resnet18_so', dict(BACKBONE='resnet18', SINGLE_OBJ=True, NUM_BASES=64))])
+def test_state_dict_keys_match_reference(tag, kw):
+    ref = json.load(open(os.path.join(GOLDEN, 'g0_state_dict_keys.json')))[tag]
+    sd = SWEM(O.make_cfg(**kw)).state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == ref
+
+
+def test_weights_and_clip_are_deterministic():
+    m = SWEM(O.make_cfg(BACKBONE='resnet18', NUM_BASES=64))
+    a = weights.fill_state_dict(m.state_dict(), seed=3, backbone='resnet18')
+    b = weights.fill_state_dict(dict(reversed(list(m.state_dict().items()))), seed=3, backbone='resnet18')
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    f1, m1 = synth.make_clip(t=2, h=64, w=96, n_obj=2, seed=5)
+    f2, m2 = synth.make_clip(t=2, h=64, w=96, n_obj=2, seed=5)
+    assert torch.equal(f1, f2) and torch.equal(m1, m2)
+    assert m1.sum(1).eq(1).all() and f1.min() >= 0 and f1.max() <= 1
+
+
+def _bases(n, tag):
+    return {'kappa': torch.full((1, n, 2, 4, 8), tag), 'nu': torch.full((1, n, 2, 6, 8), tag),
+            'zita': torch.full((1, n, 2, 1, 8), tag)}
+
+
+def test_memory_bank_policy_matches_oracle():
+    """modules.py:29-60,183-193: 'first' only appends unseen object ids, 'update' is replaced."""
+    first, upd = MemoryBank('fixed'), MemoryBank('updated')
+    ofirst, oupd = O.MemoryBank(True), O.MemoryBank(False)
+    for step, (n, tag) in enumerate([(2, 1.0), (2, 2.0), (3, 3.0), (3, 4.0)]):
+        b = _bases(n, tag)
+        had = first.bases is not None
+        first.update(b)
+        ofirst.update(_bases(n, tag))
+        if had:
+            upd.update(b)
+            oupd.update(_bases(n, tag))
+        for k in b:
+            assert torch.equal(first.bases[k], ofirst.bases[k])
+            if had:
+                assert torch.equal(upd.bases[k], oupd.bases[k])
+    assert first.bases['kappa'].shape[1] == 3 and first.n_objs == 3
+    assert first.bases['kappa'][0, 0, 0, 0, 0] == 1.0 and first.bases['kappa'][0, 2, 0, 0, 0] == 3.0
+    with pytest.raises(AssertionError):
+        MemoryBank('slow')
+
+
+def test_core_attributes_and_get_mem():
+    core = SWEMCore(n_bases=32, valdim=64, n_iters=3, tau=0.1, topl=64)
+    assert (core.n_bases, core.n_iters, core.tau, core.topl, core.p_drop) == (32, 3, 0.1, 32, 0.0)
+    assert core.fusion_layer.layer_f.weight.shape == (64, 2 * 64 + 2 * 32, 3, 3)
+    assert set(core.memories) == {'first', 'update'}
+    core.memories['first'].update(_bases(2, 1.0))
+    core.memories['update'].update(_bases(2, 2.0))
+    k, v = core.get_mem()
+    assert k.shape == (1, 2, 2, 4, 16) and v.shape == (1, 2, 2, 6, 16)
+    core.empty()
+    assert core.memories['first'].bases is None and core.memories['update'].bases is None
+
+
+def test_random_init_matches_reference_stream():
+    """modules.py:170-178: same seed -> same bases as the oracle's restatement (host generator)."""
+    core = SWEMCore(n_bases=16, valdim=8)
+    core.init_on_host = True
+    torch.manual_seed(9)
+    k, nu, z = core.random_init(size=(1, 2, 2, 12, 16), dtype=torch.float32, device=torch.device('cpu'))
+    torch.manual_seed(9)
+    ok, onu, oz = O.random_init((1, 2, 2, 12, 16), 8)
+    assert torch.equal(k, ok) and torch.equal(nu, onu) and torch.equal(z, oz)
+
+
+def test_cpu_model_fails_loudly():
+    m = SWEM(O.make_cfg(BACKBONE='resnet18', NUM_BASES=64)).eval()
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        m('encode_key', torch.zeros(1, 3, 32, 32))
+    with pytest.raises(NotImplementedError):
+        m('nonsense')
+    with pytest.raises(KeyError):
+        SWEM(O.make_cfg(BACKBONE='resnet101'))

@@ -1,0 +1,81 @@
+"""CPU: the oracle (oracle/swem_oracle.py) against the golden vectors generated from the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle; the GPU tests then pin the HIP path to the oracle."""
+import os
+
+import pytest
+import torch
+
+from oracle import swem_oracle as O
+from tests import helpers as H
+
+
+def test_single_steps_bit_exact(golden):
+    g = golden('g1_steps.npz')
+    x = g['x']
+    xf = x.flatten(2)[:, None, None]
+    x_t = xf.transpose(-2, -1)
+    assert torch.equal(O.e_step(x_t, g['kappa'], g['masks'], g['tau']), g['z'])
+    k, z = O.m_step(g['z'], xf, g['kappa_prev'], g['zita_prev'])
+    assert torch.equal(k, g['kappa_m']) and torch.equal(z, g['zita_m'])
+    assert torch.equal(O.w_step(g['kappa'], x_t, g['masks'], g['tau']), g['weights'])
+    nu = (g['zita_prev'] * g['nu_prev'] + torch.matmul(g['v'].flatten(3).unsqueeze(2), g['z'])) / g['zita_m']
+    assert torch.equal(nu, g['nu'])
+
+
+def test_two_frame_memorize_and_matching_bit_exact(golden):
+    g, m = golden('g2_memorize.npz'), golden('g3_matching.npz')
+    core = O.Core(64, 128, 4, 0.05, 64)
+    init = {'kappa': g['init_kappa'], 'nu': g['init_nu'], 'zita': g['init_zita']}
+    b0 = O.swem(g['x0'], g['v0'], g['m0'], init, 64, 4, 0.05, 128)
+    for k in ('kappa', 'nu', 'zita'):
+        assert torch.equal(b0[k], g[k + '0']), k
+    core.first.update(b0)
+    qv = torch.zeros(1, 128, *m['qk'].shape[-2:])
+    mem, _, S, n = core.match_features(m['qk'], qv)
+    assert n == 2 and torch.equal(S, m['S1']) and torch.equal(mem, m['mem1'].flatten(0, 1))
+    b1 = core.memorize(g['x1'], g['v1'], g['m1'])
+    for k in ('kappa', 'nu', 'zita'):
+        assert torch.equal(b1[k], g[k + '1']), k
+    mem, _, S, _ = core.match_features(m['qk'], qv)
+    assert torch.equal(S, m['S2']) and torch.equal(mem, m['mem2'].flatten(0, 1))
+
+
+def _run_clip(fx, cfg):
+    frames, m0 = H.clip_from_fixture(fx)
+    assert H.checksum(frames) == pytest.approx(fx['frames_sum'], rel=1e-12)
+    assert H.checksum(m0) == pytest.approx(fx['mask_sum'], rel=1e-12)
+    _, sd = H.make_model_and_sd(cfg, int(fx['wseed']))
+    wsum = sum(H.checksum(v) for v in sd.values() if v.dtype.is_floating_point)
+    assert wsum == pytest.approx(fx['w_sum'], rel=1e-12)
+    t = frames.shape[1]
+    trace = []
+    with torch.no_grad():
+        torch.manual_seed(77)
+        preds, _ = O.evaluate_seq(O.Model(sd, cfg), frames, [m0] + [None] * (t - 1),
+                                  (int(fx['out_h']), int(fx['out_w'])), trace)
+    return preds, trace
+
+
+@pytest.mark.parametrize('name,kw,sub', [
+    ('g6_configA.npz', dict(BACKBONE='resnet18', NUM_BASES=64, NUM_EM_ITERS=4, SINGLE_OBJ=True), 2),
+    ('g6_configA_mo.npz', dict(BACKBONE='resnet18', NUM_BASES=64, NUM_EM_ITERS=4, SINGLE_OBJ=False), 2),
+])
+def test_full_clip_config_a(golden, name, kw, sub):
+    fx = golden(name)
+    preds, trace = _run_clip(fx, O.make_cfg(**kw))
+    for i, tr in enumerate(trace):
+        assert torch.equal(tr['logits'][:, :, ::sub, ::sub], fx['logits%d' % i])
+        assert torch.equal(preds[i].to(torch.uint8), fx['pred%d' % i])
+        assert torch.equal(tr['context'][:, ::8], fx['ctx%d' % i])
+    assert torch.equal(trace[0]['qk16'], fx['qk16_0'])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(__file__), 'golden', 'g7_configB.npz')),
+                    reason='config-B fixture not generated')
+def test_full_clip_config_b(golden):
+    fx = golden('g7_configB.npz')
+    cfg = O.make_cfg(BACKBONE='resnet50', NUM_BASES=256, NUM_EM_ITERS=5, SINGLE_OBJ=False)
+    preds, trace = _run_clip(fx, cfg)
+    for i, tr in enumerate(trace):
+        assert torch.equal(tr['logits'][:, :, ::8, ::8], fx['logits%d' % i])
+        assert torch.equal(preds[i].to(torch.uint8), fx['pred%d' % i])
