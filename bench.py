@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- SWEM 480p multi-object inference throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic structured 480x864 clip, ResNet-50 key encoder, ResNet-18 value
+encoder, K=256 bases, 5 EM iterations, 2 objects, output 480x854, random weights of the reference architecture.
+A "step" is one steady-state frame of the reference's per-sequence loop (swem_evaluator.py:72-97):
+encode_key -> match -> segment -> argmax/one-hot -> bilinear -> encode_value -> memorize.  Frames are resident in
+HBM before the timed region (the reference also excludes the H2D copy, basic_evaluator.py:157-176).
+Every rank runs its own clip (sequences are independent: weak scaling, no data-path collective);
+value = frames of all ranks / max-over-ranks time.
+
+Extra objects in the JSON line:
+  roofline     -- dominant kernel = the implicit-GEMM conv (fp32 MFMA): useful conv FLOPs of the timed frames
+                  / summed launch durations (HIP events on the launch stream), vs 157.3 TFLOP/s fp32-matrix peak.
+  em_matching  -- the same for the EM/matching kernels (algorithmic FLOPs of SURVEY.md section 8d).
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's PyTorch path) on the same clip, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+H, W, OUT_HW, N_OBJ = 480, 864, (480, 854), 2
+CFG = dict(BACKBONE='resnet50', NUM_BASES=256, NUM_EM_ITERS=5, SINGLE_OBJ=False, KEYDIM=128, VALDIM=512,
+           EM_TAU=0.05, TOPL=64)
+FP32_MATRIX_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+
+
+def algorithmic_flops_per_frame(n):
+    """SURVEY.md section 8d / BASELINE.md section 3."""
+    return (73.3 + n * 301.9) * 1e9
+
+
+def em_flops_per_frame(n, P=1620, L=256, C=128, V=512, T=5, Lm=512):
+    return n * (4.0 * P * L * (C * (3 * T - 1) + V) + 4.0 * Lm * P * (C + V))
+
+
+class FrameRunner:
+    """Steady-state frame loop over a pre-staged clip (frames cycle; the memory keeps evolving)."""
+
+    def __init__(self, model, frames, m0):
+        from swem_amd import ops
+        self.model, self.frames, self.ops = model, frames, ops
+        self.t = frames.shape[1]
+        self.i = 0
+        h, w = frames.shape[-2:]
+        with torch.no_grad():
+            mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+            init_mask = ops.resize_planes(m0, (h, w), 'nearest')
+            mv16 = model('encode_value', frames[:, 0], init_mask, s16)
+            model('init', mk16, mv16, m0)
+
+    def step(self):
+        ops, model = self.ops, self.model
+        self.i = self.i % (self.t - 1) + 1
+        f = self.frames[:, self.i]
+        h, w = f.shape[-2:]
+        with torch.no_grad():
+            qk16, qv16, s16, s8, s4 = model('encode_key', f)
+            context, n = model('match', qk16, qv16)
+            logits, pred_mask = model('segment', n, context, s8, s4, None, OUT_HW)
+            pred, hard = ops.argmax_onehot(pred_mask)
+            pm = ops.resize_planes(pred_mask, (h, w), 'bilinear')
+            mv16 = model('encode_value', f, pm, s16)
+            model('memorize', qk16, mv16, hard, pm)
+        return pred
+
+
+def cpu_baseline(frames, m0, sd, n_frames=3):
+    """The CPU oracle (a port of the reference's PyTorch path) on the same clip: frame 0 + n_frames frames."""
+    from oracle import swem_oracle as O
+    cfg = O.make_cfg(**CFG)
+    threads = torch.get_num_threads()
+    fr = frames[:, :n_frames + 1].cpu()
+    with torch.no_grad():
+        torch.manual_seed(0)
+        t0 = time.time()
+        O.evaluate_seq(O.Model(sd, cfg), fr, [m0.cpu()] + [None] * n_frames, OUT_HW)
+        dt = time.time() - t0
+    return {'value': round((n_frames + 1) / dt, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            'sample': 'oracle/swem_oracle.py evaluate_seq on frame 0 + %d frames of the same 480x864 clip '
+                      '(all frames counted, as basic_evaluator.py:171-176), %d torch CPU threads, %.1f s'
+                      % (n_frames, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--objects', type=int, default=N_OBJ)
+    args = ap.parse_args()
+
+    from swem_amd import dist as sdist
+    rank, local_rank, world = sdist.init()
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: swem_amd has no CPU path')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    sdist.barrier()
+    from oracle import swem_oracle as O
+    from swem_amd import ops, synth, weights
+    from swem_amd.swem import SWEM
+
+    cfg = O.make_cfg(**CFG)
+    model = SWEM(cfg)
+    sd = weights.fill_state_dict(model.state_dict(), seed=3, backbone='resnet50')
+    model.load_state_dict(sd)
+    model = model.eval().to(dev)
+    n_obj = args.objects
+    frames_cpu, m0_cpu = synth.make_clip(t=8, h=H, w=W, n_obj=n_obj, out_hw=OUT_HW, seed=123 + rank)
+    frames, m0 = frames_cpu.to(dev), m0_cpu.to(dev)
+    torch.manual_seed(1234 + rank)
+    runner = FrameRunner(model, frames, m0)
+    for _ in range(args.warmup):
+        runner.step()
+
+    # ---------------- timed region: exactly K steps between barrier + synchronize
+    sdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sdist.barrier()
+    total_frames, max_t = sdist.reduce_counters(args.steps, elapsed, device=dev)
+
+    out = None
+    if rank == 0:
+        fps = total_frames / max_t
+        out = {
+            'metric': 'frames/sec (480p, K=256 bases, multi-object SWEM inference)', 'value': round(fps, 3),
+            'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * max_t / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'DAVIS17-val-shaped synthetic 480x864 clip (out 480x854), ResNet-50 key encoder, '
+                                   'K=256, 5 EM iters, %d objects, memorise every frame, 1 sequence per GPU' % n_obj,
+                       'objects': n_obj, 'frames_per_step': 1, 'parallelism': 'seq-sharded x%d (no collective)' % world,
+                       'weights': 'random init of the reference architecture (seeded)'},
+            'fps_per_gpu': round(fps / world, 3),
+            'frame_algorithmic_tflops': round(algorithmic_flops_per_frame(n_obj) * fps / world / 1e12, 2),
+        }
+
+    if world == 1:
+        # ---------------- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream
+        nprof = min(args.steps, 5)
+        ops.CONV_TRACE = []
+        for _ in range(nprof):
+            runner.step()
+        torch.cuda.synchronize()
+        tr, ops.CONV_TRACE = ops.CONV_TRACE, None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in tr)
+        flops = sum(f for _, _, f, _ in tr)
+        ach = flops / (ms * 1e-3) / 1e12
+        out['roofline'] = {
+            'bound': 'mfma', 'kernel': 'conv_igemm_kernel (+ split-K epilogue)', 'achieved': round(ach, 2),
+            'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
+            'traffic': None, 'launches_per_frame': len(tr) // nprof,
+            'avg_launch_us': round(1e3 * ms / len(tr), 2), 'gflop_per_launch': round(flops / len(tr) / 1e9, 3),
+            'conv_ms_per_frame': round(ms / nprof, 3),
+            'note': 'useful conv FLOPs (2*M*Cout*KH*KW*Cin, unpadded) of %d frames / summed per-launch HIP-event '
+                    'durations; peak = fp32 matrix (v_mfma_f32_32x32x2_f32)' % nprof}
+        # EM / matching share (whole memorize + match calls, algorithmic FLOPs of SURVEY 8d)
+        from swem_amd import modules as M
+        ev = []
+        orig_mem, orig_match = ops.memorize, ops.match
+
+        def timed(fn):
+            def wrap(*a, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = fn(*a, **k)
+                e1.record()
+                ev.append((e0, e1))
+                return r
+            return wrap
+        ops.memorize, ops.match = timed(orig_mem), timed(orig_match)
+        for _ in range(nprof):
+            runner.step()
+        torch.cuda.synchronize()
+        ops.memorize, ops.match = orig_mem, orig_match
+        em_ms = sum(a.elapsed_time(b) for a, b in ev) / nprof
+        em_tf = em_flops_per_frame(n_obj) / (em_ms * 1e-3) / 1e12
+        out['em_matching'] = {'ms_per_frame': round(em_ms, 3), 'achieved': round(em_tf, 2), 'unit': 'TFLOP/s',
+                              'peak': FP32_MATRIX_PEAK_TFLOPS, 'frac': round(em_tf / FP32_MATRIX_PEAK_TFLOPS, 4),
+                              'note': 'memorize + match calls, algorithmic FLOPs 4PL(C(3T-1)+V) + 4LmP(C+V) per object'}
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(frames_cpu, m0_cpu, sd)
+    if rank == 0:
+        print(json.dumps(out))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

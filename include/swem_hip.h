@@ -123,6 +123,11 @@ int swem_decode_head_f32(void *stream, const float *logit4, const float *valid, 
 /* swem_evaluator.py:83-87: argmax over N1 planes and its one-hot, both int64 */
 int swem_argmax_onehot_i64(void *stream, const float *prob /*[B][N1][HW]*/, long long *argmax /*[B][HW]*/,
                            long long *onehot /*[B][N1][HW] or NULL*/, int B, int N1, long long HW);
+/* torch.cat([x0, x1], dim=C) for NHWC x0 [B|1][P][c0], x1 [B|1][P][c1] (bs = 0: shared by the batch).
+ * Only needed where a concatenated tensor is itself a residual (networks.py:44-45 with a ResNet-18 key
+ * encoder); everywhere else the conv reads the sources directly. */
+int swem_concat2_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
+                          long long bs1, float *y, int B, long long P);
 /* batched 2-D transpose: in [batch][R][Cc] -> out [batch][Cc][ld] (ld >= R, pad columns zeroed) */
 int swem_transpose_f32(void *stream, const float *in, float *out, int batch, int R, int Cc, int ld);
 

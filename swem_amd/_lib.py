@@ -31,6 +31,7 @@ SIGNATURES = {
     'swem_pred_head_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i]),
     'swem_decode_head_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_argmax_onehot_i64': (_i, [_p, _p, _p, _p, _i, _i, _ll]),
+    'swem_concat2_nhwc_f32': (_i, [_p, _p, _i, _ll, _p, _i, _ll, _p, _i, _ll]),
     'swem_transpose_f32': (_i, [_p, _p, _p, _i, _i, _i, _i]),
     'swem_em_pad': (_i, [_i]),
     'swem_em_norm_bases_f32': (_i, [_p, _p, _p, _i, _i, _i]),

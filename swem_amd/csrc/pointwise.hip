@@ -393,6 +393,20 @@ __global__ void transpose_kernel(const float *__restrict__ in, float *__restrict
   }
 }
 
+// channel concat of two NHWC sources (either may be shared by all batch items: bs = 0)
+__global__ void concat2_kernel(const float *__restrict__ x0, int c0, long long bs0, const float *__restrict__ x1,
+                               int c1, long long bs1, float *__restrict__ y, int B, long long P) {
+  const int cq = (c0 + c1) / 4;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * P * cq) return;
+  int c = (int)(i % cq) * 4;
+  long long t = i / cq;
+  long long p = t % P;
+  int b = (int)(t / P);
+  float4 v = c < c0 ? ld4(x0 + b * bs0 + p * c0 + c) : ld4(x1 + b * bs1 + p * c1 + (c - c0));
+  st4(y + i * 4, v);
+}
+
 inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -517,6 +531,16 @@ extern "C" int swem_argmax_onehot_i64(void *stream, const float *prob, long long
   hipLaunchKernelGGL(argmax_onehot_kernel, grid1((long long)B * HW), dim3(256), 0, ST, prob, argmax, onehot, B, N1,
                      HW);
   SWEM_CHECK_LAUNCH("argmax_onehot");
+  return SWEM_OK;
+}
+
+extern "C" int swem_concat2_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
+                                     long long bs1, float *y, int B, long long P) {
+  SWEM_REQUIRE(x0 && x1 && y && c0 % 4 == 0 && c1 % 4 == 0 && c0 > 0 && c1 > 0, SWEM_E_SHAPE,
+               "concat2: channel counts must be positive multiples of 4");
+  hipLaunchKernelGGL(concat2_kernel, grid1((long long)B * P * ((c0 + c1) / 4)), dim3(256), 0, ST, x0, c0, bs0, x1, c1,
+                     bs1, y, B, P);
+  SWEM_CHECK_LAUNCH("concat2");
   return SWEM_OK;
 }
 

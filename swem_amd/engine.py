@@ -57,8 +57,8 @@ class _ResBlock:
     def __call__(self, srcs, batch=None):
         r = ops.conv2d(srcs, self.c1, relu_in=True, batch=batch)
         if self.down is None:
-            assert len(srcs) == 1
-            res = srcs[0]
+            # identity shortcut: with two sources the concatenated tensor itself is the residual
+            res = srcs[0] if len(srcs) == 1 else ops.concat2(srcs[0], srcs[1], batch or srcs[0].shape[0])
         else:
             res = ops.conv2d(srcs, self.down, batch=batch)
         return ops.conv2d([r], self.c2, relu_in=True, residual=res)

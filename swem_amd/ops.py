@@ -12,6 +12,9 @@ from . import _lib
 RELU_IN, RELU_OUT, GLU = 1, 2, 4
 
 _ws = {}
+# bench.py sets this to a list to time every conv launch with HIP events on the launch stream:
+# entries are (start_event, end_event, flops, description)
+CONV_TRACE = None
 
 
 def _stream():
@@ -46,6 +49,7 @@ class ConvPack:
         self.w, self.scale, self.shift = w, scale, shift
         self.cout, self.kh, self.kw, self.stride, self.pad, self.glu = cout, kh, kw, stride, pad, glu
         self.cin = w.shape[-1]
+        self.cin_true = self.cin          # channels of the reference conv (without layout padding)
 
 
 def pack_conv(weight, bias=None, bn=None, stride=1, pad=None, cin_pad=None, eps=1e-5):
@@ -69,7 +73,9 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=None, cin_pad=None, eps=
         shift = shift.contiguous()
     elif bias is not None:
         shift = bias.detach().float().contiguous()
-    return ConvPack(w.to(dev), scale, shift, co, kh, kw, stride, kh // 2 if pad is None else pad)
+    pk = ConvPack(w.to(dev), scale, shift, co, kh, kw, stride, kh // 2 if pad is None else pad)
+    pk.cin_true = ci
+    return pk
 
 
 def pack_glu(wf, bf, wa, ba):
@@ -112,9 +118,17 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     if residual is not None:
         _chk(residual, 'conv residual')
         res_bs = 0 if (res_broadcast or (residual.shape[0] == 1 and B > 1)) else Ho * Wo * pack.cout
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call('swem_conv2d_nhwc_f32', _stream(), *args, B, H, W, pack.w.data_ptr(), _ptr(pack.scale),
               _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw, pack.stride,
               pack.pad, flags, _ptr(ws), wsb)
+    if CONV_TRACE is not None:
+        e1.record()
+        ncols = pack.cout * (2 if pack.glu else 1)
+        CONV_TRACE.append((e0, e1, 2.0 * B * Ho * Wo * ncols * pack.kh * pack.kw * pack.cin_true,
+                           '%dx%dx%d k%d s%d %d->%d' % (B, H, W, pack.kh, pack.stride, pack.cin_true, ncols)))
     return y
 
 
@@ -236,6 +250,20 @@ def argmax_onehot(prob, want_onehot=True):
     onehot = torch.empty((B, N1, H, W), dtype=torch.int64, device=prob.device) if want_onehot else None
     _lib.call('swem_argmax_onehot_i64', _stream(), prob.data_ptr(), amax.data_ptr(), _ptr(onehot), B, N1, H * W)
     return amax, onehot
+
+
+def concat2(x0, x1, batch):
+    """NHWC channel concat; a source with batch 1 is shared by all `batch` items."""
+    _chk(x0)
+    _chk(x1)
+    _, H, W, c0 = x0.shape
+    c1 = x1.shape[3]
+    y = torch.empty((batch, H, W, c0 + c1), dtype=torch.float32, device=x0.device)
+    bs0 = 0 if (x0.shape[0] == 1 and batch > 1) else H * W * c0
+    bs1 = 0 if (x1.shape[0] == 1 and batch > 1) else H * W * c1
+    _lib.call('swem_concat2_nhwc_f32', _stream(), x0.data_ptr(), c0, bs0, x1.data_ptr(), c1, bs1, y.data_ptr(), batch,
+              H * W)
+    return y
 
 
 def transpose(x, ld=None):

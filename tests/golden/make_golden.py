@@ -99,10 +99,21 @@ def ref_evaluate_seq(model, frames, init_masks, out_size, trace=None):
 
 
 def structured_keys(P, C, n_clusters, g, noise=0.15, scale=1.0):
-    """Keys that look like encoder output: a few cluster centres + noise (iid noise makes EM chaotic)."""
+    """Keys that look like encoder output: a few cluster centres + noise (iid noise makes EM chaotic).  The
+    cluster of a pixel is independent of its position, so foreground and background share appearance and the
+    W step's  1 - p_own  stays O(0.1..1) instead of collapsing to rounding noise."""
     centres = torch.randn(n_clusters, C, generator=g)
-    assign = (torch.arange(P) * n_clusters // P + torch.randint(0, 2, (P,), generator=g)) % n_clusters
+    assign = torch.randint(0, n_clusters, (P,), generator=g)
     return (centres[assign] + noise * torch.randn(P, C, generator=g)) * scale, assign
+
+
+def blob_masks(N, h, w, g):
+    """Soft fg/bg masks of N objects: rectangles with soft values, independent of the key clusters."""
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    fg = torch.stack([((xx >= (n * w) // (N + 1)) & (xx < ((n + 1) * w) // (N + 1)) & (yy >= h // 5)).float().flatten()
+                      for n in range(N)])
+    soft = (fg * 0.9 + 0.1 * torch.rand(N, h * w, generator=g)).clamp(0, 1)
+    return fg, soft
 
 
 def maxdiff(a, b):
@@ -156,8 +167,7 @@ def main():
     xf = x.flatten(2)[:, None, None]
     x_t = xf.transpose(-2, -1)
     kappa = O.l2norm(torch.randn(1, N, 2, C, K, generator=g) * 0.2 + xk[torch.randint(0, P, (K,), generator=g)].t(), -2)
-    fg = torch.stack([(assign < 2).float(), ((assign >= 2) & (assign < 4)).float()])           # N,P
-    soft = (fg * 0.9 + 0.05 * torch.rand(N, P, generator=g)).clamp(0, 1)
+    fg, soft = blob_masks(N, h, w, g)                                                           # N,P
     masks = torch.stack([(1 - fg) * (1 - soft), fg * soft], 1)[None].unsqueeze(-1)                # 1,N,2,P,1
     zita_prev = torch.rand(1, N, 2, 1, K, generator=g) * 5 + 1e-6
     kappa_prev = O.l2norm(torch.randn(1, N, 2, C, K, generator=g), -2)
@@ -192,8 +202,7 @@ def main():
         xk, assign = structured_keys(P, C, 6, g)
         xx = xk.t().reshape(1, C, h, w).contiguous()
         vv = torch.randn(1, N, V, h, w, generator=g)
-        fg = torch.stack([(assign < 2).float(), ((assign >= 2) & (assign < 4)).float()])
-        sf = (fg * 0.9 + 0.05 * torch.rand(N, P, generator=g)).clamp(0, 1)
+        fg, sf = blob_masks(N, h, w, g)
         mm = torch.stack([(1 - fg) * (1 - sf), fg * sf], 1).view(1, N, 2, h, w)
         frames_in.append((xx, vv, mm))
     qx, _ = structured_keys(P, C, 6, g)
@@ -215,6 +224,9 @@ def main():
         om1, oq1, os1, _ = ocore.match_features(qk, qv)
         ob1 = ocore.memorize(*frames_in[1])
         om2, oq2, os2, _ = ocore.match_features(qk, qv)
+    print('   zita frame0: max %.3g, live fraction %.3f; frame1: max %.3g, live %.3f' % (
+        float(b0['zita'].max()), float((b0['zita'] >= 1e-3).float().mean()), float(b1['zita'].max()),
+        float((b1['zita'] >= 1e-3).float().mean())))
     for k in b0:
         assert maxdiff(ob0[k], b0[k]) == 0, k
         assert maxdiff(ob1[k], b1[k]) == 0, k
@@ -301,7 +313,7 @@ def main():
 
     print('G6 config A (240x432, R18, K=64, single object, 2 frames)')
     run_clip(dict(BACKBONE='resnet18', NUM_BASES=64, NUM_EM_ITERS=4, SINGLE_OBJ=True), 2, 240, 432, 1, (240, 432),
-             seed=123, wseed=1, tag='g6_configA', sub=2)
+             seed=123, wseed=1, tag='g6_configA', sub=2, double_floor=True)
     print('G6b config A multi-object variant (3 frames, 2 objects)')
     run_clip(dict(BACKBONE='resnet18', NUM_BASES=64, NUM_EM_ITERS=4, SINGLE_OBJ=False), 3, 240, 432, 2, (240, 427),
              seed=124, wseed=2, tag='g6_configA_mo', sub=2, double_floor=True)

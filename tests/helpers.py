@@ -34,18 +34,21 @@ def rel_err(a, b):
 
 
 def structured_keys(P, C, n_clusters, g, noise=0.15):
+    """Clustered keys whose cluster is independent of the pixel position (see tests/golden/make_golden.py)."""
     centres = torch.randn(n_clusters, C, generator=g)
-    assign = (torch.arange(P) * n_clusters // P + torch.randint(0, 2, (P,), generator=g)) % n_clusters
+    assign = torch.randint(0, n_clusters, (P,), generator=g)
     return centres[assign] + noise * torch.randn(P, C, generator=g), assign
 
 
 def em_inputs(h, w, C, V, N, g):
-    """Structured (clustered) keys, random values, soft fg/bg masks for N objects."""
+    """Clustered keys, random values, soft rectangular fg/bg masks for N objects."""
     P = h * w
-    xk, assign = structured_keys(P, C, 6, g)
+    xk, _ = structured_keys(P, C, 6, g)
     x = xk.t().reshape(1, C, h, w).contiguous()
     v = torch.randn(1, N, V, h, w, generator=g)
-    fg = torch.stack([((assign >= 2 * n) & (assign < 2 * n + 2)).float() for n in range(N)])
-    sf = (fg * 0.9 + 0.05 * torch.rand(N, P, generator=g)).clamp(0, 1)
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    fg = torch.stack([((xx >= (n * w) // (N + 1)) & (xx < ((n + 1) * w) // (N + 1)) & (yy >= h // 5)).float().flatten()
+                      for n in range(N)])
+    sf = (fg * 0.9 + 0.1 * torch.rand(N, P, generator=g)).clamp(0, 1)
     m = torch.stack([(1 - fg) * (1 - sf), fg * sf], 1).view(1, N, 2, h, w)
     return x, v, m

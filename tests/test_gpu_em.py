@@ -1,0 +1,186 @@
+"""GPU: the EM / matching kernels through the C ABI against (a) the golden vectors generated from the reference
+and (b) the CPU oracle on fresh seeded inputs, per step (parity is asserted per step,
+on live bases and on mass-weighted quantities, because low-mass bases are ratios of rounding noise in the
+reference itself).  Full-size (config B) cases use size-independent properties of the algorithm.
+
+Tolerances: 1e-4 relative per step for anything behind an exp((s - max)/tau): the logits s = x.kn are fp32 dot
+products of magnitude |x| ~ 11 whose summation order differs between MKL and the MFMA chain (abs error ~1e-6),
+and 1/tau = 20 turns that into ~3e-5 relative on z (measured 3.1e-5); 1e-5/1e-6 for the steps without an exp
+(M step, zita, l2norm); matching <= 1e-4 absolute."""
+import pytest
+import torch
+
+from oracle import swem_oracle as O
+from swem_amd import ops
+from swem_amd.modules import SWEMCore
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def d(t):
+    return t.to(DEV).contiguous()
+
+
+def relmax(a, b):
+    return float((a.cpu() - b).abs().max() / b.abs().max())
+
+
+def test_norm_bases(lib):
+    k = torch.randn(4, 128, 64)
+    kn = ops.em_norm_bases(d(k)).cpu()
+    assert relmax(kn, O.l2norm(k, 1).transpose(1, 2)) < 1e-6
+
+
+def test_single_steps_vs_golden(lib, golden):
+    """swe_step / swm_step / sww_step (modules.py:93-127) with the reference's own inputs and outputs."""
+    g = golden('g1_steps.npz')
+    core = SWEMCore(n_bases=64, valdim=128, n_iters=4, tau=g['tau'], topl=64)
+    x = g['x']
+    xf = x.flatten(2)[:, None, None]
+    x_t = xf.transpose(-2, -1).contiguous()
+    z = core.swe_step(d(x_t), d(g['kappa']), d(g['masks']))
+    assert relmax(z, g['z']) < 1e-4, 'E step'
+    w = core.sww_step(d(g['kappa']), d(x_t), d(g['masks']))
+    assert relmax(w, g['weights']) < 1e-4, 'W step'
+    kap, zita = core.swm_step(d(g['z']), d(xf), d(g['kappa_prev']), d(g['zita_prev']))
+    assert relmax(zita, g['zita_m']) < 1e-6, 'M step zita'
+    assert relmax(kap, g['kappa_m']) < 1e-5, 'M step kappa'
+    # value update (modules.py:164-165) = the same M kernel with the value map as A
+    P = x_t.shape[-2]
+    Pp = ops.em_pad(P)
+    zT = torch.nn.functional.pad(g['z'].reshape(4, P, 64).transpose(1, 2), (0, Pp - P))
+    vT = torch.nn.functional.pad(g['v'].flatten(3)[0], (0, Pp - P))                # (N, V, Pp)
+    nu, _, _ = ops.em_mstep(d(vT), 2, d(zT), d(g['nu_prev'].reshape(4, 128, 64)), d(g['zita_prev'].reshape(4, 64)), P)
+    assert relmax(nu.view(1, 2, 2, 128, 64), g['nu']) < 1e-5, 'nu update'
+
+
+def _check_bases(got, ref, zita_ref, tag, tol=1e-4):
+    """live bases (zita >= 1e-3) element-wise, every base mass-weighted."""
+    zr = zita_ref.squeeze(-2)                                  # (1,N,2,L)
+    live = (zr >= 1e-3)
+    for name in ('kappa', 'nu'):
+        a, b = got[name].cpu(), ref[name]
+        mass_err = ((a - b) * zr.unsqueeze(-2)).abs().max() / (b * zr.unsqueeze(-2)).abs().max()
+        assert mass_err < tol, '%s %s mass-weighted rel err %.3g' % (tag, name, mass_err)
+        lm = live.unsqueeze(-2).expand_as(b)
+        live_err = (a - b)[lm].abs().max() / b[lm].abs().max()
+        assert live_err < 5 * tol, '%s %s live-base rel err %.3g' % (tag, name, live_err)
+    assert relmax(got['zita'], ref['zita']) < tol, tag + ' zita'
+    return float(live.float().mean())
+
+
+def test_memorize_two_frames_vs_golden(lib, golden):
+    """SWEMCore.memorize (modules.py:183-193) over two frames from the reference's captured random init."""
+    g = golden('g2_memorize.npz')
+    core = SWEMCore(n_bases=64, valdim=128, n_iters=4, tau=0.05, topl=64)
+    init = {'kappa': d(g['init_kappa']), 'nu': d(g['init_nu']), 'zita': d(g['init_zita'])}
+    b0 = core.swem(d(g['x0']), d(g['v0']), d(g['m0']), init)
+    frac = _check_bases(b0, {k: g[k + '0'] for k in ('kappa', 'nu', 'zita')}, g['zita0'], 'frame 0')
+    # frame 1 from the REFERENCE's frame-0 bases (per-step parity: identical inputs)
+    ref0 = {k: d(g[k + '0']) for k in ('kappa', 'nu', 'zita')}
+    b1 = core.swem(d(g['x1']), d(g['v1']), d(g['m1']), ref0)
+    _check_bases(b1, {k: g[k + '1'] for k in ('kappa', 'nu', 'zita')}, g['zita1'], 'frame 1')
+    assert 0.05 < frac <= 1.0
+
+
+def test_matching_vs_golden(lib, golden):
+    """get_affinity + perm_inv_feat (modules.py:198-208,232-276) from the reference's bases, Lm = 64 and 128."""
+    g, m = golden('g2_memorize.npz'), golden('g3_matching.npz')
+    first = [d(g['kappa0'][0]), d(g['nu0'][0])]
+    upd = [d(g['kappa1'][0]), d(g['nu1'][0])]
+    qk = m['qk']
+    xp = d(qk[0].flatten(1).t())                                      # (P, C)
+    h, w = qk.shape[-2:]
+    for tag, banks, Sref, memref in (('Lm=64', (first[0], first[1], None, None), m['S1'], m['mem1']),
+                                     ('Lm=128', (first[0], first[1], upd[0], upd[1]), m['S2'], m['mem2'])):
+        mem, S = ops.match(xp, *banks, 64, 0.05)
+        mem = mem.view(2, h, w, -1).permute(0, 3, 1, 2).cpu()
+        S = S.view(2, h, w, -1).permute(0, 3, 1, 2).cpu()
+        e_mem = float((mem - memref[0]).abs().max())
+        e_S = float((S - Sref).abs().max())
+        assert e_mem < 1e-4 * max(1.0, float(memref.abs().max())), '%s mem_out abs err %.3g' % (tag, e_mem)
+        assert e_S < 1e-4, '%s S abs err %.3g' % (tag, e_S)
+
+
+@pytest.mark.parametrize('L,T', [(64, 4), (128, 3), (256, 5)])
+def test_memorize_and_match_vs_oracle(lib, L, T):
+    """Fresh seeded inputs, oracle computed on the CPU at test time; covers every template instance (L = 64/128/256)."""
+    g = torch.Generator().manual_seed(100 + L)
+    h, w, C, V, N = 12, 20, 128, 128, 2
+    x0, v0, m0 = H.em_inputs(h, w, C, V, N, g)
+    x1, v1, m1 = H.em_inputs(h, w, C, V, N, g)
+    torch.manual_seed(L)
+    init = dict(zip(('kappa', 'nu', 'zita'), O.random_init((1, N, 2, C, L), V)))
+    o0 = O.swem(x0, v0, m0, init, L, T, 0.05, V)
+    o1 = O.swem(x1, v1, m1, o0, L, T, 0.05, V)
+    core = SWEMCore(n_bases=L, valdim=V, n_iters=T, tau=0.05, topl=64)
+    b0 = core.swem(d(x0), d(v0), d(m0), {k: d(t) for k, t in init.items()})
+    _check_bases(b0, o0, o0['zita'], 'L=%d frame 0' % L)
+    b1 = core.swem(d(x1), d(v1), d(m1), {k: d(t) for k, t in o0.items()})
+    _check_bases(b1, o1, o1['zita'], 'L=%d frame 1' % L)
+    # matching on the ORACLE's banks
+    ocore = O.Core(L, V, T, 0.05, 64)
+    ocore.first.update(o0)
+    ocore.upd.update(o1)
+    qx, _ = H.structured_keys(h * w, C, 6, g)
+    qk = qx.t().reshape(1, C, h, w).contiguous()
+    omem, _, oS, _ = ocore.match_features(qk, torch.zeros(1, V, h, w))
+    mem, S = ops.match(d(qx), d(o0['kappa'][0]), d(o0['nu'][0]), d(o1['kappa'][0]), d(o1['nu'][0]), 64, 0.05)
+    mem = mem.view(N, h, w, V).permute(0, 3, 1, 2).cpu()
+    S = S.view(N, h, w, -1).permute(0, 3, 1, 2).cpu()
+    assert float((mem - omem).abs().max()) < 1e-4 * max(1.0, float(omem.abs().max())), 'mem_out'
+    assert float((S - oS).abs().max()) < 1e-4, 'S'
+
+
+def test_config_b_size_properties(lib):
+    """BASELINE config B sizes (P = 30*54, C = 128, V = 512, K = 256, T = 5, N = 3): properties that hold for any
+    input.  (1) responsibility mass is conserved: sum_l (zita - zita_prev) = sum_p weights of the last iteration,
+    where weights <= masks; (2) kappa and nu are convex combinations of the prior and the data;
+    (3) S features lie in [0,1] with feat + complement = 1, non-negative exp-sums; (4) mem_out lies in the
+    convex hull of the value bases; (5) the fused memorize equals the step-by-step composition on the device."""
+    g = torch.Generator().manual_seed(7)
+    h, w, C, V, N, L, T = 30, 54, 128, 512, 3, 256, 5
+    P = h * w
+    x, v, m = H.em_inputs(h, w, C, V, N, g)
+    torch.manual_seed(1)
+    kap0, nu0, z0 = O.random_init((1, N, 2, C, L), V)
+    core = SWEMCore(n_bases=L, valdim=V, n_iters=T, tau=0.05, topl=64)
+    init = {'kappa': d(kap0), 'nu': d(nu0), 'zita': d(z0)}
+    b = core.swem(d(x), d(v), d(m), init)
+    zita = b['zita'].cpu()
+    gained = (zita - z0).sum(-1).flatten()                                  # per (n, class)
+    msum = m.flatten(3).sum(-1).flatten()
+    assert (gained <= msum * (1 + 1e-5) + 1e-3).all() and (gained >= 0).all()
+    assert torch.isfinite(b['kappa']).all() and torch.isfinite(b['nu']).all()
+    # (2) with zita_prev = 1e-6 the new bases are (almost) weighted means of the pixels: inside the data range
+    kap = b['kappa'].cpu()
+    xmin, xmax = x.flatten(2).min(-1)[0].view(1, 1, 1, C, 1), x.flatten(2).max(-1)[0].view(1, 1, 1, C, 1)
+    live = (zita > 1e-3).expand_as(kap)
+    assert ((kap >= xmin - 1e-3) & (kap <= xmax + 1e-3))[live].all()
+    # (5) composition of the single-step kernels reproduces the fused driver bit for bit (same kernels, same order)
+    xf = d(x.flatten(2)[:, None, None])
+    x_t = xf.transpose(-2, -1).contiguous()
+    mk = d(m.flatten(3).unsqueeze(-1))
+    kappa, weights = init['kappa'], mk
+    for it in range(T):
+        z = core.swe_step(x_t, kappa, weights)
+        kappa, zt = core.swm_step(z, xf, init['kappa'], init['zita'])
+        if it < T - 1:
+            weights = core.sww_step(kappa, x_t, mk)
+    assert torch.equal(kappa, b['kappa']) and torch.equal(zt, b['zita'])
+    # frame 2 + matching at Lm = 512
+    x2, v2, m2 = H.em_inputs(h, w, C, V, N, g)
+    b2 = core.swem(d(x2), d(v2), d(m2), b)
+    qx, _ = H.structured_keys(P, C, 6, g)
+    mem, S = ops.match(d(qx), b['kappa'][0], b['nu'][0], b2['kappa'][0], b2['nu'][0], 64, 0.05)
+    S = S.cpu()
+    assert torch.isfinite(S).all() and (S >= 0).all() and (S <= 1).all()
+    assert float((S[..., :64] + S[..., 64:] - 1).abs().max()) < 1e-6
+    allnu = torch.cat([b['nu'][0], b2['nu'][0]], -1).cpu()                  # (N,2,V,2L)
+    lo = allnu.permute(0, 2, 1, 3).flatten(2).min(-1)[0]                    # (N,V)
+    hi = allnu.permute(0, 2, 1, 3).flatten(2).max(-1)[0]
+    mem = mem.cpu()                                                         # (N,P,V)
+    tol = 1e-4 * float(allnu.abs().max())
+    assert (mem >= lo[:, None] - tol).all() and (mem <= hi[:, None] + tol).all()

@@ -1,0 +1,196 @@
+"""GPU: every conv / pointwise kernel of libswem_hip.so, through the C ABI, against the same op in torch on the
+CPU (fp32) with identical seeded inputs.  Tolerances are stated per test; index outputs must be exact."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from swem_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def back(t):
+    return t.permute(0, 3, 1, 2).cpu()
+
+
+def close(a, b, rtol, what=''):
+    err = float((a - b).abs().max())
+    ref = float(b.abs().max())
+    assert err <= rtol * max(ref, 1e-6), '%s: max abs err %.3g vs max |ref| %.3g (rtol %.1g)' % (what, err, ref, rtol)
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, bias, bn, relu_in, relu_out, residual
+    (1, 64, 30, 54, 64, 1, 1, False, True, False, True, False),      # bottleneck 1x1 + bn + relu
+    (1, 64, 30, 54, 256, 1, 1, False, True, False, True, True),      # 1x1 + bn + residual + relu
+    (2, 64, 33, 47, 128, 3, 2, True, True, False, True, False),      # strided 3x3, ragged size
+    (1, 128, 60, 108, 128, 3, 1, True, False, True, False, True),    # ResBlock conv: relu on input + residual
+    (1, 256, 15, 27, 512, 3, 1, True, False, False, False, False),   # tiny grid -> split-K path
+    (1, 1024, 15, 27, 128, 3, 1, True, False, False, False, False),  # key_proj shape (config A size) split-K
+    (3, 256, 60, 108, 256, 3, 1, True, False, True, False, False),   # big grid -> 128x128 tiles
+    (1, 8, 64, 96, 64, 7, 2, True, True, False, True, False),        # stem 7x7/2, padded Cin
+    (1, 4, 31, 45, 64, 7, 2, False, True, False, True, False),       # key stem (3+1 pad channels), odd size
+    (1, 256, 30, 54, 128, 1, 2, False, True, False, False, False),   # downsample 1x1 stride 2
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'B%d_ci%d_%dx%d_co%d_k%d_s%d' % c[:7])
+def test_conv2d_matches_torch(lib, case):
+    B, Cin, H, W, Cout, k, stride, bias, bn, relu_in, relu_out, residual = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1 if bias else None
+    bnp = None
+    if bn:
+        bnp = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1,
+               torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5)
+    ref = F.conv2d(F.relu(x) if relu_in else x, w, b, stride=stride, padding=k // 2)
+    if bn:
+        ref = F.batch_norm(ref, bnp[2], bnp[3], bnp[0], bnp[1], False, 0.0, 1e-5)
+    res = torch.randn(ref.shape, generator=g) if residual else None
+    if residual:
+        ref = ref + res
+    if relu_out:
+        ref = F.relu(ref)
+    pack = ops.pack_conv(w.to(DEV), None if b is None else b.to(DEV), None if bnp is None else [t.to(DEV) for t in bnp],
+                         stride, k // 2)
+    y = ops.conv2d([nhwc(x)], pack, relu_in=relu_in, relu_out=relu_out, residual=None if res is None else nhwc(res))
+    torch.cuda.synchronize()
+    close(back(y), ref, 2e-5, 'conv2d')
+
+
+def test_conv2d_three_sources_broadcast_and_glu(lib):
+    """The fusion layer call (modules.py:291): cat[mem_out, qv (shared by all objects), S] -> f * sigmoid(a)."""
+    g = torch.Generator().manual_seed(3)
+    N, H, W, V, S2 = 3, 15, 27, 128, 64
+    mem, qv, s = torch.randn(N, V, H, W, generator=g), torch.randn(1, V, H, W, generator=g), torch.rand(N, S2, H, W, generator=g)
+    cin = 2 * V + S2
+    wf, wa = torch.randn(V, cin, 3, 3, generator=g) * 0.03, torch.randn(V, cin, 3, 3, generator=g) * 0.03
+    bf, ba = torch.randn(V, generator=g) * 0.1, torch.randn(V, generator=g) * 0.1
+    xin = torch.cat([mem, qv.expand(N, -1, -1, -1), s], 1)
+    ref = F.conv2d(xin, wf, bf, padding=1) * torch.sigmoid(F.conv2d(xin, wa, ba, padding=1))
+    pack = ops.pack_glu(wf.to(DEV), bf.to(DEV), wa.to(DEV), ba.to(DEV))
+    y = ops.conv2d([nhwc(mem), nhwc(qv), nhwc(s)], pack, batch=N)
+    close(back(y), ref, 2e-5, 'glu conv')
+    # plain conv over two sources with a broadcast residual (decoder skip shared by all objects)
+    w = torch.randn(64, 2 * V, 3, 3, generator=g) * 0.03
+    res = torch.randn(1, 64, H, W, generator=g)
+    ref2 = F.conv2d(torch.cat([mem, qv.expand(N, -1, -1, -1)], 1), w, None, padding=1) + res
+    y2 = ops.conv2d([nhwc(mem), nhwc(qv)], ops.pack_conv(w.to(DEV)), residual=nhwc(res), batch=N)
+    close(back(y2), ref2, 2e-5, 'two-source conv + broadcast residual')
+
+
+def test_conv2d_rejects_bad_shapes(lib):
+    from swem_amd._lib import SwemHipError
+    pack = ops.pack_conv(torch.randn(32, 8, 3, 3, device=DEV))
+    with pytest.raises(SwemHipError, match='channels'):
+        ops.conv2d([torch.zeros(1, 8, 8, 12, device=DEV)], pack)
+
+
+def test_prep_inputs_and_maxpool(lib):
+    g = torch.Generator().manual_seed(5)
+    B, N, H, W = 1, 3, 37, 52
+    frames = torch.rand(B, 3, H, W, generator=g)
+    masks = torch.rand(B, N + 1, H, W, generator=g)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    m3, s3 = ops._f3(mean), ops._f3(std)
+    k = ops.prep_key_input(frames.to(DEV), m3, s3).cpu()
+    img = (frames - mean) / std
+    assert torch.allclose(k[..., :3].permute(0, 3, 1, 2), img, rtol=1e-6, atol=1e-6) and (k[..., 3] == 0).all()
+    v = ops.prep_value_input(frames.to(DEV), masks.to(DEV), m3, s3, False).cpu()
+    others = 1 - masks - masks[:, 0:1]
+    for n in range(N):
+        assert torch.allclose(v[n, ..., :3].permute(2, 0, 1), img[0], rtol=1e-6, atol=1e-6)
+        assert torch.equal(v[n, ..., 3], masks[0, n + 1]) and torch.equal(v[n, ..., 4], others[0, n + 1])
+        assert (v[n, ..., 5:] == 0).all()
+    x = torch.randn(2, 64, 37, 51, generator=g)
+    assert torch.equal(back(ops.maxpool(nhwc(x))), F.max_pool2d(x, 3, 2, 1))
+
+
+def test_resampling_matches_torch(lib):
+    g = torch.Generator().manual_seed(6)
+    skip, low = torch.randn(2, 32, 30, 54, generator=g), torch.randn(2, 32, 15, 27, generator=g)
+    ref = skip + F.interpolate(low, size=(30, 54), mode='bilinear', align_corners=False)
+    close(back(ops.upsample_add(nhwc(skip), nhwc(low))), ref, 1e-6, 'upsample_add')
+    ref = skip[:1] + F.interpolate(low, size=(30, 54), mode='bilinear', align_corners=False)
+    close(back(ops.upsample_add(nhwc(skip[:1]), nhwc(low))), ref, 1e-6, 'upsample_add shared skip')
+    m = torch.rand(1, 3, 48, 85, generator=g)
+    for size in ((48, 86), (30, 54), (96, 170), (48, 85)):
+        assert torch.equal(ops.resize_planes(m.to(DEV), size, 'nearest').cpu(), F.interpolate(m, size=size, mode='nearest'))
+        close(ops.resize_planes(m.to(DEV), size, 'bilinear').cpu(),
+              F.interpolate(m, size=size, mode='bilinear', align_corners=False), 1e-6, 'bilinear %s' % (size,))
+
+
+@pytest.mark.parametrize('hard_dtype', [torch.int64, torch.float32])
+def test_mask_prep(lib, hard_dtype):
+    """swem.py:79-84 at the DAVIS sizes: masks at 480x854, memory at 30x54."""
+    g = torch.Generator().manual_seed(7)
+    B, N, Ho, Wo, h, w = 1, 2, 480, 854, 30, 54
+    idx = torch.randint(0, N + 1, (B, Ho, Wo), generator=g)
+    hard = F.one_hot(idx, N + 1).permute(0, 3, 1, 2).contiguous().to(hard_dtype)
+    soft = torch.rand(B, N + 1, 480, 864, generator=g)
+    mh = F.interpolate(hard[:, 1:].float(), size=(h, w), mode='nearest')
+    ms = F.interpolate(soft[:, 1:], size=(h, w), mode='bilinear')
+    ref = torch.stack([(1 - mh) * (1 - ms), mh * ms], dim=2).view(B * N, 2, h * w)
+    out = ops.mask_prep(hard.to(DEV), soft.to(DEV), h, w).cpu()
+    close(out, ref, 1e-6, 'mask_prep')
+
+
+def test_cbam_residual(lib):
+    g = torch.Generator().manual_seed(8)
+    B, Cc, H, W, hid = 2, 512, 15, 27, 32
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w1, b1 = torch.randn(hid, Cc, generator=g) * 0.05, torch.randn(hid, generator=g) * 0.1
+    w2, b2 = torch.randn(Cc, hid, generator=g) * 0.2, torch.randn(Cc, generator=g) * 0.1
+    w7, b7 = torch.randn(1, 2, 7, 7, generator=g) * 0.1, torch.randn(1, generator=g) * 0.1
+
+    def mlp(t):
+        return F.linear(F.relu(F.linear(t.flatten(1), w1, b1)), w2, b2)
+    att = mlp(F.avg_pool2d(x, (H, W))) + mlp(F.max_pool2d(x, (H, W)))
+    xc = x * torch.sigmoid(att)[:, :, None, None]
+    comp = torch.cat([xc.max(1, keepdim=True)[0], xc.mean(1, keepdim=True)], 1)
+    ref = x + xc * torch.sigmoid(F.conv2d(comp, w7, b7, padding=3))
+    y = ops.cbam_residual(nhwc(x), *[t.to(DEV).contiguous() for t in (w1, b1, w2, b2, w7, b7)])
+    close(back(y), ref, 1e-5, 'x + CBAM(x)')
+
+
+def test_decoder_heads(lib):
+    g = torch.Generator().manual_seed(9)
+    B, N, Cc, h4, w4, Ho, Wo = 1, 3, 256, 60, 108, 240, 427
+    x = torch.randn(B * N, Cc, h4, w4, generator=g)
+    w, b = torch.randn(1, Cc, 3, 3, generator=g) * 0.03, torch.randn(1, generator=g)
+    ref_l = F.conv2d(F.relu(x), w, b, padding=1)
+    lg = ops.pred_head(nhwc(x), w.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV))
+    close(lg.cpu(), ref_l[:, 0], 2e-5, 'pred head')
+    for valid in (None, torch.tensor([[1.0, 1.0, 0.0, 1.0]])):
+        up = F.interpolate(ref_l, size=(Ho, Wo), mode='bilinear', align_corners=False)
+        p = torch.sigmoid(up).view(B, N, Ho, Wo)
+        if valid is not None:
+            p = p * valid[:, 1:, None, None]
+        newp = torch.cat([torch.prod(1 - p, dim=1, keepdim=True), p], 1).clamp(1e-7, 1 - 1e-7)
+        ref_logits = torch.log(newp / (1 - newp))
+        ref_prob = F.softmax(ref_logits, dim=1)
+        logits, prob, amax = ops.decode_head(ref_l[:, 0].contiguous().to(DEV), B, N, (Ho, Wo),
+                                             valid=None if valid is None else valid.to(DEV), want_argmax=True)
+        close(logits.cpu(), ref_logits, 2e-5, 'aggregate logits')
+        close(prob.cpu(), ref_prob, 2e-5, 'softmax')
+        # the index map must be the argmax of the probabilities the kernel itself produced (bit exact)
+        assert torch.equal(amax.cpu(), prob.cpu().argmax(1))
+        am2, onehot = ops.argmax_onehot(prob)
+        assert torch.equal(am2, amax)
+        assert torch.equal(onehot.cpu(), F.one_hot(amax.cpu(), N + 1).permute(0, 3, 1, 2))
+        agree = (amax.cpu() == ref_prob.argmax(1)).float().mean()
+        assert agree > 0.9999, 'argmax agreement with the CPU reference %.6f' % agree
+
+
+def test_transpose(lib):
+    x = torch.randn(3, 405, 128)
+    y = ops.transpose(x.to(DEV), ld=408).cpu()
+    assert torch.equal(y[:, :, :405], x.transpose(1, 2)) and (y[:, :, 405:] == 0).all()
