@@ -101,6 +101,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--objects', type=int, default=N_OBJ)
+    ap.add_argument('--no-autotune', action='store_true')
+    ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
     args = ap.parse_args()
 
     from swem_amd import dist as sdist
@@ -129,10 +131,12 @@ def main():
     frames_cpu, m0_cpu = synth.make_clip(t=8, h=H, w=W, n_obj=n_obj, out_hw=OUT_HW, seed=123 + rank)
     frames, m0 = frames_cpu.to(dev), m0_cpu.to(dev)
     torch.manual_seed(1234 + rank)
+    ops.AUTOTUNE = not args.no_autotune     # per-layer tiling / K-split chosen by timing, during warm-up only
     runner = FrameRunner(model, frames, m0)
     for _ in range(args.warmup):
         runner.step()
 
+    ops.AUTOTUNE = False
     # ---------------- timed region: exactly K steps between barrier + synchronize
     sdist.barrier()
     torch.cuda.synchronize()
@@ -169,6 +173,18 @@ def main():
         torch.cuda.synchronize()
         tr, ops.CONV_TRACE = ops.CONV_TRACE, None
         ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in tr)
+        if args.conv_report:
+            agg = {}
+            for e0, e1, f, d in tr:
+                a = agg.setdefault(d, [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += e0.elapsed_time(e1)
+                a[2] += f
+            print('%-34s %5s %9s %9s %8s' % ('conv shape (BxHxW k s cin->ncols)', 'n/frm', 'us/call', 'ms/frame', 'TFLOP/s'),
+                  file=sys.stderr)
+            for d, (c, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print('%-34s %5.1f %9.1f %9.3f %8.1f' % (d, c / nprof, 1e3 * t / c, t / nprof, f / (t * 1e-3) / 1e12),
+                      file=sys.stderr)
         flops = sum(f for _, _, f, _ in tr)
         ach = flops / (ms * 1e-3) / 1e12
         out['roofline'] = {

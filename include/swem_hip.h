@@ -66,15 +66,18 @@ int swem_device_cus(void);
  *   shift   : [Cout'] or NULL (=0)     -- conv bias and folded BatchNorm shift
  *   res     : NHWC [B][Ho][Wo][Cout] added after scale/shift, or NULL; res_bs as bsK
  *   y       : NHWC [B][Ho][Wo][Cout],  Ho = (H + 2*pad - KH)/stride + 1
- *   ws      : workspace for split-K partial sums (swem_conv2d_workspace bytes)
+ *   plan    : tiling hint, 0 = built-in heuristic; else  wm | wn << 4 | nsplit << 8  with wave tile
+ *             (32*wm) x (32*wn) in {1x1, 1x2, 2x2} and nsplit K-splits (results are identical up to fp32
+ *             summation order; callers may time candidates once per layer shape and pass the fastest)
+ *   ws      : workspace for split-K partial sums (swem_conv2d_workspace bytes for the same plan)
  */
 size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                             int flags);
+                             int flags, int plan);
 int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
                          long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
                          const float *w, const float *scale, const float *shift, const float *res,
                          long long res_bs, float *y, int Cout, int KH, int KW, int stride, int pad, int flags,
-                         void *ws, size_t ws_bytes);
+                         int plan, void *ws, size_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------
  * Pointwise / pooling / resampling kernels.

@@ -19,6 +19,9 @@
 //
 // Layers whose grid would not fill the 256 CUs split K over blockIdx.z; the partial sums go to a
 // workspace and a second kernel reduces them in a fixed order (deterministic) and runs the epilogue.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -43,130 +46,18 @@ __device__ __forceinline__ float4 relu4(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
 }
 
+// zero a loaded vector with a bit mask: the value is used unconditionally, so the load itself stays unconditional
+__device__ __forceinline__ float4 mask4(float4 v, bool keep) {
+  const unsigned m = keep ? 0xffffffffu : 0u;
+  return make_float4(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m),
+                     __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
+}
+
+// Epilogue shared by both kernels: raw split-K partials, or scale/shift (+residual, ReLU) / GLU gate, NHWC stores.
 template <int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
-  constexpr int SA = BM + 1, SB = BN + 1;  // row strides in float4 slots
-  constexpr int RA = BM / 32, RB = BN / 32;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float4 *As = reinterpret_cast<float4 *>(smem);  // [2][KQ][SA]
-  float4 *Bs = As + 2 * KQ * SA;                  // [2][KQ][SB]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-
-  // ---- per-thread gather coordinates (fixed over the K loop) ----
-  const int kq = tid & 7, rbase = tid >> 3;
-  int iy0[RA], ix0[RA], bidx[RA];
-  bool rowok[RA];
+__device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][WN], int m0, int n0, int wm, int wn,
+                                              int r, int h) {
   const int HoWo = p.Ho * p.Wo;
-#pragma unroll
-  for (int i = 0; i < RA; ++i) {
-    int m = m0 + rbase + 32 * i;
-    rowok[i] = m < p.M;
-    int b = m / HoWo;
-    int rem = m - b * HoWo;
-    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    iy0[i] = oy * p.stride - p.pad;
-    ix0[i] = ox * p.stride - p.pad;
-    bidx[i] = b;
-  }
-  const float *wrow[RB];
-  bool colok[RB];
-#pragma unroll
-  for (int i = 0; i < RB; ++i) {
-    int n = n0 + rbase + 32 * i;
-    colok[i] = n < p.Ncols;
-    wrow[i] = p.w + (long long)(colok[i] ? n : 0) * p.K;
-  }
-  const bool relu_in = p.flags & SWEM_CONV_RELU_IN;
-
-  float4 ga[RA], gb[RB];
-  auto gload = [&](int kb) {
-    const int k = kb * BK + kq * 4;
-    const bool kok = k < p.K;
-    int tap = k / p.Cin;
-    int ci = k - tap * p.Cin;
-    int ky = tap / p.KW, kx = tap - ky * p.KW;
-    // channel -> (source, local channel) by selects: no runtime-indexed arrays (they would go to scratch)
-    const float *src = p.x[0];
-    int cs = p.c[0];
-    long long sbs = p.bs[0];
-    if (ci >= p.c[0]) {
-      ci -= p.c[0];
-      src = p.x[1];
-      cs = p.c[1];
-      sbs = p.bs[1];
-      if (ci >= p.c[1]) {
-        ci -= p.c[1];
-        src = p.x[2];
-        cs = p.c[2];
-        sbs = p.bs[2];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      int iy = iy0[i] + ky, ix = ix0[i] + kx;
-      bool ok = kok && rowok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = *reinterpret_cast<const float4 *>(src + bidx[i] * sbs + ((long long)iy * p.W + ix) * cs + ci);
-      ga[i] = relu_in ? relu4(v) : v;
-    }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kok && colok[i]) v = *reinterpret_cast<const float4 *>(wrow[i] + k);
-      gb[i] = v;
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < RA; ++i) As[(buf * KQ + kq) * SA + rbase + 32 * i] = ga[i];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) Bs[(buf * KQ + kq) * SB + rbase + 32 * i] = gb[i];
-  };
-
-  f32x16 acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int kb_begin = blockIdx.z * p.kb_per_split;
-  const int kb_end = min(p.nkb, kb_begin + p.kb_per_split);
-
-  gload(kb_begin);
-  lstore(0);
-  __syncthreads();
-  int buf = 0;
-  for (int kb = kb_begin; kb < kb_end; ++kb) {
-    const bool more = kb + 1 < kb_end;
-    if (more) gload(kb + 1);
-    const float4 *Ab = As + buf * KQ * SA + wm * 32 * WM + r;
-    const float4 *Bb = Bs + buf * KQ * SB + wn * 32 * WN + r;
-#pragma unroll
-    for (int j = 0; j < KQ / 2; ++j) {
-      float4 a[WM], b[WN];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = Ab[(2 * j + h) * SA + 32 * i];
-#pragma unroll
-      for (int i = 0; i < WN; ++i) b[i] = Bb[(2 * j + h) * SB + 32 * i];
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < WN; ++jn) acc[i][jn] = mfma32x4(a[i], b[jn], acc[i][jn]);
-    }
-    if (more) lstore(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-
-  // ---- epilogue ----
   const int mrow0 = m0 + wm * 32 * WM;
   const int ncol0 = n0 + wn * 32 * WN;
   if (p.partial) {  // split-K: raw partial sums, [z][M][Ncols]
@@ -230,6 +121,364 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   }
 }
 
+template <int WM, int WN, bool DB>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int SA = BM + 1, SB = BN + 1;  // row strides in float4 slots
+  constexpr int RA = BM / 32, RB = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *As = reinterpret_cast<float4 *>(smem);  // [2][KQ][SA]
+  constexpr int NBUF = DB ? 2 : 1;
+  float4 *Bs = As + NBUF * KQ * SA;               // [NBUF][KQ][SB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  // ---- per-thread gather coordinates (fixed over the K loop) ----
+  const int kq = tid & 7, rbase = tid >> 3;
+  int iy0[RA], ix0[RA], bidx[RA];
+  bool rowok[RA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    int m = m0 + rbase + 32 * i;
+    rowok[i] = m < p.M;
+    int b = m / HoWo;
+    int rem = m - b * HoWo;
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    iy0[i] = oy * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.pad;
+    bidx[i] = b;
+  }
+  const float *wrow[RB];
+  bool colok[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    int n = n0 + rbase + 32 * i;
+    colok[i] = n < p.Ncols;
+    wrow[i] = p.w + (long long)(colok[i] ? n : 0) * p.K;
+  }
+  const bool relu_in = p.flags & SWEM_CONV_RELU_IN;
+
+  float4 ga[RA], gb[RB];
+  unsigned okbits = 0;  // validity of the staged vectors: bit i = A row i, bit 8+i = B row i (applied at the LDS store)
+  // Loads are unconditional (out-of-image taps read a clamped in-bounds address and are zeroed by a select) so the
+  // compiler issues all of them back to back with ONE wait before the LDS stores; the input ReLU is applied at the
+  // store, not at the load (a use right behind each load would serialise the L2 round trips).
+  const bool dbg_simple = p.flags & 1024;  // timing experiment: trivial addresses (wrong results)
+  auto gload = [&](int kb) {
+    if (dbg_simple) {
+      unsigned bits = 0xffffu;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) ga[i] = *reinterpret_cast<const float4 *>(p.x[0] + (long long)(m0 + rbase + 32 * i) * p.c[0] + (kb & 7) * 32 + kq * 4);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) gb[i] = *reinterpret_cast<const float4 *>(wrow[i] + kb * BK + kq * 4);
+      okbits = bits;
+      return;
+    }
+    const int k = kb * BK + kq * 4;
+    const bool kok = k < p.K;
+    const int kc = kok ? k : 0;
+    unsigned bits = 0;
+    int tap = kc / p.Cin;
+    int ci = kc - tap * p.Cin;
+    int ky = tap / p.KW, kx = tap - ky * p.KW;
+    // channel -> (source, local channel) by selects: no runtime-indexed arrays (they would go to scratch)
+    const float *src = p.x[0];
+    int cs = p.c[0];
+    long long sbs = p.bs[0];
+    if (ci >= p.c[0]) {
+      ci -= p.c[0];
+      src = p.x[1];
+      cs = p.c[1];
+      sbs = p.bs[1];
+      if (ci >= p.c[1]) {
+        ci -= p.c[1];
+        src = p.x[2];
+        cs = p.c[2];
+        sbs = p.bs[2];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int iy = iy0[i] + ky, ix = ix0[i] + kx;
+      bool ok = kok && rowok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      long long off = ok ? bidx[i] * sbs + ((long long)iy * p.W + ix) * cs + ci : 0;
+      ga[i] = *reinterpret_cast<const float4 *>(src + off);
+      bits |= ok ? (1u << i) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      gb[i] = *reinterpret_cast<const float4 *>(wrow[i] + kc);
+      bits |= (kok && colok[i]) ? (1u << (8 + i)) : 0u;
+    }
+    okbits = bits;
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      float4 v = mask4(ga[i], (okbits >> i) & 1u);
+      As[(buf * KQ + kq) * SA + rbase + 32 * i] = relu_in ? relu4(v) : v;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) Bs[(buf * KQ + kq) * SB + rbase + 32 * i] = mask4(gb[i], (okbits >> (8 + i)) & 1u);
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int kb_begin = blockIdx.z * p.kb_per_split;
+  const int kb_end = min(p.nkb, kb_begin + p.kb_per_split);
+
+  if ((p.flags & 2048) && (((blockIdx.x + blockIdx.y * gridDim.x) >> 8) & 1)) {  // experiment: stagger co-resident blocks
+    __builtin_amdgcn_s_sleep(32);
+  }
+  gload(kb_begin);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  const bool dbg_noload = p.flags & 256, dbg_nostore = p.flags & 512;  // timing experiments only (wrong results)
+  for (int kb = kb_begin; kb < kb_end; ++kb) {
+    const bool more = kb + 1 < kb_end;
+    if (more && !dbg_noload) gload(kb + 1);
+    const float4 *Ab = As + buf * KQ * SA + wm * 32 * WM + r + h * SA;
+    const float4 *Bb = Bs + buf * KQ * SB + wn * 32 * WN + r + h * SB;
+    // operand fragments are fetched one k-group ahead of the MFMAs that use them
+    float4 a[2][WM], b[2][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a[0][i] = Ab[32 * i];
+#pragma unroll
+    for (int i = 0; i < WN; ++i) b[0][i] = Bb[32 * i];
+#pragma unroll
+    for (int j = 0; j < KQ / 2; ++j) {
+      if (j + 1 < KQ / 2) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[(j + 1) & 1][i] = Ab[2 * (j + 1) * SA + 32 * i];
+#pragma unroll
+        for (int i = 0; i < WN; ++i) b[(j + 1) & 1][i] = Bb[2 * (j + 1) * SB + 32 * i];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < WN; ++jn) acc[i][jn] = mfma32x4(a[j & 1][i], b[j & 1][jn], acc[i][jn]);
+      // keep the LDS reads of group j+1 ahead of the MFMAs of group j (the scheduler otherwise sinks them behind and
+      // reuses the fragment registers, exposing the LDS latency: 124 vs 155 TFLOP/s in tools/mfma_lds.hip)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (dbg_nostore) continue;
+    if constexpr (DB) {
+      if (more) lstore(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    } else {
+      // single LDS image: half the LDS, twice the resident blocks; other blocks' MFMAs cover this block's refill
+      __syncthreads();
+      if (more) lstore(0);
+      __syncthreads();
+    }
+  }
+
+  conv_epilogue<WM, WN>(p, acc, m0, n0, wm, wn, r, h);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fast variant for the common case (every source width, hence Cin, a multiple of 32).
+//
+// Measured on gfx950 (profiles/r01_conv_pmc.txt): while v_mfma_f32_32x32x2_f32 runs, NO vector-ALU instruction
+// co-executes (SQ_VALU_MFMA_COEXEC_CYCLES = 0: the fp32 MFMA runs at the fp32 vector rate on the same datapath), so
+// every VALU instruction in the k-loop is time taken from the matrix pipe.  This kernel therefore keeps the loop free
+// of vector arithmetic:
+//   - a 32-wide k-block lies inside one tap of one source, so its position (source, tap, channel) is block-uniform
+//     and advances with scalar instructions;
+//   - operands are fetched with raw buffer loads: per-lane byte offsets are recomputed only when the tap or source
+//     changes (every Cin/32 k-blocks), the channel offset travels in the scalar offset, and out-of-image taps /
+//     out-of-range rows use an out-of-range offset, which the buffer unit returns as zeros (no masks, no branches);
+//   - the only vector op left is the optional input ReLU on the staged values.
+struct KPos {
+  int src, ci0, ky, kx;
+};
+__device__ __forceinline__ void kpos_init(KPos &q, const ConvP &p, int kb) {
+  int k = kb * BK;
+  int tap = k / p.Cin;
+  int ci = k - tap * p.Cin;
+  q.ky = tap / p.KW;
+  q.kx = tap - q.ky * p.KW;
+  q.src = 0;
+  if (ci >= p.c[0]) {
+    ci -= p.c[0];
+    q.src = 1;
+    if (ci >= p.c[1]) {
+      ci -= p.c[1];
+      q.src = 2;
+    }
+  }
+  q.ci0 = ci;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 bufload4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+constexpr unsigned OOB = 0xfffffff0u;  // >= any num_records: the load returns 0 and touches no memory
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvP p) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int SA = BM + 1, SB = BN + 1;
+  constexpr int RA = BM / 32, RB = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *As = reinterpret_cast<float4 *>(smem);  // [2][KQ][SA]
+  float4 *Bs = As + 2 * KQ * SA;                  // [2][KQ][SB]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kq = tid & 7, rbase = tid >> 3;
+
+  // buffer descriptors (wave-uniform: built from kernel arguments and block-uniform scalars only)
+  const long long HWin = (long long)p.H * p.W;
+  auto src_rsrc = [&](int sidx) {
+    const float *base = sidx == 0 ? p.x[0] : (sidx == 1 ? p.x[1] : p.x[2]);
+    const int cs = sidx == 0 ? p.c[0] : (sidx == 1 ? p.c[1] : p.c[2]);
+    const long long bs = sidx == 0 ? p.bs[0] : (sidx == 1 ? p.bs[1] : p.bs[2]);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0,
+                                             (int)((bs ? (long long)p.B * bs : HWin * cs) * 4), 0x00020000);
+  };
+  __amdgpu_buffer_rsrc_t rsw =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, (int)((long long)p.Ncols * p.K * 4), 0x00020000);
+
+  int iy0[RA], ix0[RA], bidx[RA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    int m = m0 + rbase + 32 * i;
+    int b = m / HoWo;
+    int rem = m - b * HoWo;
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    iy0[i] = oy * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.pad;
+    bidx[i] = m < p.M ? b : -1;
+  }
+  unsigned wvoff[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    int n = n0 + rbase + 32 * i;
+    wvoff[i] = n < p.Ncols ? (unsigned)(((long long)n * p.K + kq * 4) * 4) : OOB;
+  }
+  const bool relu_in = p.flags & SWEM_CONV_RELU_IN;
+
+  // per-lane byte offsets of the A rows for the current (source, tap); recomputed only when that changes
+  unsigned avoff[RA];
+  auto set_tap = [&](const KPos &q) {
+    const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
+    const long long bs = q.src == 0 ? p.bs[0] : (q.src == 1 ? p.bs[1] : p.bs[2]);
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int iy = iy0[i] + q.ky, ix = ix0[i] + q.kx;
+      const bool ok = bidx[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const long long e = bidx[i] * bs + ((long long)iy * p.W + ix) * cs + kq * 4;
+      avoff[i] = ok ? (unsigned)(e * 4) : OOB;
+    }
+  };
+
+  float4 ga[RA], gb[RB];
+  __amdgpu_buffer_rsrc_t rsa;
+  auto gload = [&](const KPos &q, int kb) {
+    const unsigned soff = (unsigned)q.ci0 * 4u;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) ga[i] = bufload4(rsa, avoff[i], soff);
+    const unsigned wsoff = (unsigned)kb * (BK * 4u);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) gb[i] = bufload4(rsw, wvoff[i], wsoff);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) As[(buf * KQ + kq) * SA + rbase + 32 * i] = relu_in ? relu4(ga[i]) : ga[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) Bs[(buf * KQ + kq) * SB + rbase + 32 * i] = gb[i];
+  };
+  // advance to the next k-block (scalar); refresh the lane offsets when the tap or the source changes
+  auto advance = [&](KPos &q) {
+    q.ci0 += BK;
+    const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
+    if (q.ci0 >= cs) {
+      q.ci0 = 0;
+      ++q.src;
+      const int cn = q.src == 1 ? p.c[1] : (q.src == 2 ? p.c[2] : 0);
+      if (cn == 0) {
+        q.src = 0;
+        if (++q.kx == p.KW) {
+          q.kx = 0;
+          ++q.ky;
+        }
+      }
+      set_tap(q);
+      rsa = src_rsrc(q.src);
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int kb_begin = blockIdx.z * p.kb_per_split;
+  const int kb_end = min(p.nkb, kb_begin + p.kb_per_split);
+  KPos q;
+  kpos_init(q, p, kb_begin);
+  set_tap(q);
+  rsa = src_rsrc(q.src);
+  gload(q, kb_begin);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kb = kb_begin; kb < kb_end; ++kb) {
+    // the gathers for the next k-block are issued unconditionally (the last iteration re-reads its own block into the
+    // idle buffer): a conditional definition of the staging registers costs register copies + early waits here
+    const bool more = kb + 1 < kb_end;
+    if (more) advance(q);
+    gload(q, more ? kb + 1 : kb);
+    const float4 *Ab = As + buf * KQ * SA + wm * 32 * WM + r + h * SA;
+    const float4 *Bb = Bs + buf * KQ * SB + wn * 32 * WN + r + h * SB;
+    float4 a[2][WM], b[2][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a[0][i] = Ab[32 * i];
+#pragma unroll
+    for (int i = 0; i < WN; ++i) b[0][i] = Bb[32 * i];
+#pragma unroll
+    for (int j = 0; j < KQ / 2; ++j) {
+      if (j + 1 < KQ / 2) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[(j + 1) & 1][i] = Ab[2 * (j + 1) * SA + 32 * i];
+#pragma unroll
+        for (int i = 0; i < WN; ++i) b[(j + 1) & 1][i] = Bb[2 * (j + 1) * SB + 32 * i];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < WN; ++jn) acc[i][jn] = mfma32x4(a[j & 1][i], b[j & 1][jn], acc[i][jn]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  conv_epilogue<WM, WN>(p, acc, m0, n0, wm, wn, r, h);
+}
+
 // Reduce split-K partials in z order and apply the same epilogue.  One thread per 4 output channels.
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int nsplit) {
   const bool glu = p.flags & SWEM_CONV_GLU;
@@ -283,7 +532,26 @@ struct Plan {
   int wm, wn, nsplit, kb_per_split;
 };
 
+// Tuning hook (tools/conv_bench.py): SWEM_CONV_PLAN="wm,wn,nsplit" forces one plan for every launch.
+bool forced_plan(Plan &pl, int nkb, bool glu) {
+  static int state = 0, fwm = 0, fwn = 0, fns = 0;
+  if (state == 0) {
+    const char *e = getenv("SWEM_CONV_PLAN");
+    state = (e && sscanf(e, "%d,%d,%d", &fwm, &fwn, &fns) == 3) ? 1 : -1;
+  }
+  if (state < 0) return false;
+  if (glu && fwn != 2) return false;
+  int ns = fns < 1 ? 1 : (fns > nkb ? nkb : fns);
+  int per = cdiv(nkb, ns);
+  pl = Plan{fwm, fwn, cdiv(nkb, per), per};
+  return true;
+}
+
 Plan make_plan(int M, int Ncols, int nkb, bool glu) {
+  {
+    Plan f;
+    if (forced_plan(f, nkb, glu)) return f;
+  }
   // Candidate wave tiles, largest first.  Take the largest whose grid gives every CU about two blocks
   // (the LDS image allows two resident blocks); if none does, take the smallest and split K until it does.
   static const int cand[3][2] = {{2, 2}, {1, 2}, {1, 1}};
@@ -309,23 +577,45 @@ Plan make_plan(int M, int Ncols, int nkb, bool glu) {
 }
 
 template <int WM, int WN>
-int launch(const ConvP &p, dim3 grid, hipStream_t st) {
+int launch_pipe(const ConvP &p, dim3 grid, hipStream_t st) {
   constexpr size_t lds = 2 * KQ * (64 * WM + 1 + 64 * WN + 1) * sizeof(float4);
-  SWEM_ALLOW_LDS((conv_igemm_kernel<WM, WN>), lds);
-  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN>), grid, dim3(256), lds, st, p);
+  SWEM_ALLOW_LDS((conv_igemm_pipe_kernel<WM, WN>), lds);
+  hipLaunchKernelGGL((conv_igemm_pipe_kernel<WM, WN>), grid, dim3(256), lds, st, p);
+  return SWEM_OK;
+}
+
+template <int WM, int WN, bool DB>
+int launch(const ConvP &p, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = (DB ? 2 : 1) * KQ * (64 * WM + 1 + 64 * WN + 1) * sizeof(float4);
+  SWEM_ALLOW_LDS((conv_igemm_kernel<WM, WN, DB>), lds);
+  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, DB>), grid, dim3(256), lds, st, p);
   return SWEM_OK;
 }
 
 }  // namespace
 
+// plan hint: 0 = heuristic; else wm | wn << 4 | nsplit << 8 (swem_hip.h)
+Plan resolve_plan(int plan, int M, int Ncols, int nkb, bool glu) {
+  if (plan > 0) {
+    int wm = plan & 15, wn = (plan >> 4) & 15, ns = plan >> 8;
+    bool ok = (wm == 1 || wm == 2) && (wn == 1 || wn == 2) && !(wm == 2 && wn == 1) && !(glu && wn != 2);
+    if (ok) {
+      ns = ns < 1 ? 1 : (ns > nkb ? nkb : ns);
+      int per = cdiv(nkb, ns);
+      return Plan{wm, wn, cdiv(nkb, per), per};
+    }
+  }
+  return make_plan(M, Ncols, nkb, glu);
+}
+
 extern "C" size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                        int flags) {
+                                        int flags, int plan) {
   if (stride <= 0) return 0;
   int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   long long M = (long long)B * Ho * Wo;
   int Ncols = (flags & SWEM_CONV_GLU) ? 2 * Cout : Cout;
   int nkb = cdiv((long long)KH * KW * Cin, BK);
-  Plan pl = make_plan((int)M, Ncols, nkb, flags & SWEM_CONV_GLU);
+  Plan pl = resolve_plan(plan, (int)M, Ncols, nkb, flags & SWEM_CONV_GLU);
   if (pl.nsplit <= 1) return 0;
   return (size_t)pl.nsplit * M * Ncols * sizeof(float);
 }
@@ -334,7 +624,7 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
                                     long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
                                     const float *w, const float *scale, const float *shift, const float *res,
                                     long long res_bs, float *y, int Cout, int KH, int KW, int stride, int pad,
-                                    int flags, void *ws, size_t ws_bytes) {
+                                    int flags, int plan, void *ws, size_t ws_bytes) {
   SWEM_REQUIRE(x0 && w && y, SWEM_E_ARG, "conv2d: null pointer");
   if (!x1) c1 = 0;
   if (!x2) c2 = 0;
@@ -362,8 +652,16 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
   p.w = w; p.scale = scale; p.shift = shift; p.res = res; p.res_bs = res_bs; p.y = y;
   p.Cout = Cout; p.Ncols = glu ? 2 * Cout : Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.flags = flags;
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char *e = getenv("SWEM_CONV_DEBUG");
+      dbg = e ? atoi(e) : 0;
+    }
+    p.flags |= dbg;
+  }
   p.nkb = cdiv(p.K, BK);
-  Plan pl = make_plan(p.M, p.Ncols, p.nkb, glu);
+  Plan pl = resolve_plan(plan, p.M, p.Ncols, p.nkb, glu);
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;
   if (pl.nsplit > 1) {
@@ -374,9 +672,27 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(cdiv(p.M, 64 * pl.wm), cdiv(p.Ncols, 64 * pl.wn), pl.nsplit);
   int rc;
-  if (pl.wm == 2 && pl.wn == 2) rc = launch<2, 2>(p, grid, st);
-  else if (pl.wm == 1 && pl.wn == 2) rc = launch<1, 2>(p, grid, st);
-  else rc = launch<1, 1>(p, grid, st);
+  static int single = -1;
+  if (single < 0) {
+    const char *e = getenv("SWEM_CONV_SINGLE");
+    single = e ? atoi(e) : 0;
+  }
+  static int nopipe = -1;
+  if (nopipe < 0) {
+    const char *e = getenv("SWEM_CONV_NOPIPE");
+    nopipe = e ? atoi(e) : 0;
+  }
+  const bool pipe_ok = !nopipe && c0 % 32 == 0 && c1 % 32 == 0 && c2 % 32 == 0;
+  if (pipe_ok && pl.wm == 2 && pl.wn == 2) rc = launch_pipe<2, 2>(p, grid, st);
+  else if (pipe_ok && pl.wm == 1 && pl.wn == 2) rc = launch_pipe<1, 2>(p, grid, st);
+  else if (pipe_ok && pl.wm == 1 && pl.wn == 1) rc = launch_pipe<1, 1>(p, grid, st);
+  else if (pl.wm == 2 && pl.wn == 2) rc = single ? launch<2, 2, false>(p, grid, st) : launch<2, 2, true>(p, grid, st);
+  else if (pl.wm == 1 && pl.wn == 2) rc = single ? launch<1, 2, false>(p, grid, st) : launch<1, 2, true>(p, grid, st);
+  else if (pl.wm == 1 && pl.wn == 1) rc = single ? launch<1, 1, false>(p, grid, st) : launch<1, 1, true>(p, grid, st);
+  else {
+    swem_set_error("conv2d: unsupported tile plan %dx%d", pl.wm, pl.wn);
+    return SWEM_E_ARG;
+  }
   if (rc) return rc;
   SWEM_CHECK_LAUNCH("conv_igemm_kernel");
   if (pl.nsplit > 1) {

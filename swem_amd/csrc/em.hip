@@ -8,15 +8,16 @@
 // With the K dimension contiguous in every operand, each lane loads 16 bytes and feeds four
 // v_mfma_f32_32x32x2_f32 steps (common.h: mfma32x4).
 //
-// Kernels per EM iteration (3 launches):
+// Kernels per EM iteration (5 small launches):
 //   em_ew      : one GEMM  s = x_t . kn  per 32-pixel tile serves BOTH the W step of the previous iteration
 //                (cosine = s / (|x|+eps), joint {bg,fg} max, exp-sums, weights = mask * (1 - p)) and the E step
 //                (row softmax of s/tau, times weights).  The pixel sits on the MFMA lane, the base index in the
 //                accumulator registers, so the row reductions are in-register + one cross-half shuffle + one LDS
 //                exchange between the 4 waves (2 classes x 2 halves of L).
 //   em_mgemm   : split-P partial products  xT . z  (or vT . z for the value update) into a slab workspace.
-//   em_finalize: fixed-order slab reduction (deterministic), zita = zita_ + sum_p z, the prior blend
-//                (zita_*kappa_ + S)/zita, and the next iteration's normalised transposed bases.
+//   em_zsum    : zita = zita_ + sum_p z (one wave per base row).
+//   em_finalize: fixed-order slab reduction (deterministic) and the prior blend (zita_*kappa_ + S)/zita;
+//                em_norm_bases then produces the next iteration's normalised transposed bases.
 #include "common.h"
 
 namespace {
@@ -208,64 +209,46 @@ __global__ __launch_bounds__(256) void em_mgemm_kernel(const float *__restrict__
     }
 }
 
-// Block: 32 bases (columns l) of one nk.  zsum over pixels, slab reduction, prior blend, optional kn.
+// zita[nk][l] = zita_prev[nk][l] + sum_p zT[nk][l][p]: one wave per base row, 16-byte coalesced reads, fixed order
+__global__ __launch_bounds__(256) void em_zsum_kernel(const float *__restrict__ zT, const float *__restrict__ zita_prev,
+                                                      float *__restrict__ zt, float *__restrict__ zita_out, int rows,
+                                                      int Pp) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *zr = zT + (long long)row * Pp;
+  float s = 0.f;
+  for (int k = lane * 4; k < Pp; k += 256) {
+    float4 v = ld4(zr + k);
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) {
+    float z = zita_prev[row] + s;
+    zt[row] = z;
+    if (zita_out) zita_out[row] = z;
+  }
+}
+
+// out[nk][row][l] = (zita_prev[l] * prev[row][l] + sum_sp part[sp][nk][row][l]) / zita[l]
+// Block: 32 bases x 32 rows; slabs are summed in split order (deterministic).
 __global__ __launch_bounds__(256) void em_finalize_kernel(const float *__restrict__ part, int nsplit,
-                                                          const float *__restrict__ zT,
                                                           const float *__restrict__ prev,
                                                           const float *__restrict__ zita_prev,
-                                                          float *__restrict__ out, float *__restrict__ zita_out,
-                                                          float *__restrict__ kn_out, int NK, int R, int P, int Pp,
-                                                          int L) {
-  extern __shared__ float sm[];  // red[8][32], zp[32], zt[32], nrm[32], tile[R][33] (kn only)
-  float *red = sm, *zp = sm + 256, *zt = zp + 32, *nrm = zt + 32, *tile = nrm + 32;
-  const int nk = blockIdx.y, l0 = blockIdx.x * 32;
-  const int tid = threadIdx.x;
-  {
-    // zsum: 8 threads per base row, float4 strided over the row
-    const int ll = tid >> 3, g = tid & 7;
-    const float *zr = zT + ((long long)nk * L + l0 + ll) * Pp;
-    float s = 0.f;
-    for (int k = g * 4; k < Pp; k += 32) {
-      float4 v = ld4(zr + k);
-      s += (v.x + v.y) + (v.z + v.w);
-    }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);
-    if (g == 0) {
-      float zprev = zita_prev[(long long)nk * L + l0 + ll];
-      zp[ll] = zprev;
-      zt[ll] = zprev + s;
-      if (zita_out) zita_out[(long long)nk * L + l0 + ll] = zprev + s;
-    }
-  }
-  __syncthreads();
-  const int l = tid & 31, g = tid >> 5;
+                                                          const float *__restrict__ zt, float *__restrict__ out, int NK,
+                                                          int R, int L) {
+  const int nk = blockIdx.y, l = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int row0 = blockIdx.z * 32 + (threadIdx.x >> 5);
+  const float zp = zita_prev[(long long)nk * L + l], z = zt[(long long)nk * L + l];
   const long long slab = (long long)NK * R * L;
-  float ss = 0.f;
-  for (int row = g; row < R; row += 8) {
-    const long long o = ((long long)nk * R + row) * L + l0 + l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = row0 + 8 * i;
+    if (row >= R) break;
+    const long long o = ((long long)nk * R + row) * L + l;
     float s = part[o];
     for (int sp = 1; sp < nsplit; ++sp) s += part[o + sp * slab];
-    float v = (zp[l] * prev[o] + s) / zt[l];
-    out[o] = v;
-    if (kn_out) {
-      tile[row * 33 + l] = v;
-      ss += v * v;
-    }
-  }
-  if (!kn_out) return;
-  red[g * 32 + l] = ss;
-  __syncthreads();
-  if (tid < 32) {
-    float s = 0.f;
-    for (int i = 0; i < 8; ++i) s += red[i * 32 + tid];
-    nrm[tid] = sqrtf(s) + SWEM_L2_EPS;
-  }
-  __syncthreads();
-  for (int idx = tid; idx < 32 * R; idx += 256) {
-    int ll = idx / R, c = idx - ll * R;
-    kn_out[((long long)nk * L + l0 + ll) * R + c] = tile[c * 33 + ll] / nrm[ll];
+    out[o] = (zp * prev[o] + s) / z;
   }
 }
 
@@ -276,11 +259,11 @@ MPlan mstep_plan(int NK, int R, int Pp, int L) {
   MPlan pl;
   pl.nt = (L % 64 == 0) ? 2 : 1;
   long long blocks = (long long)cdiv(R, 128) * (L / (32 * pl.nt)) * NK;
-  int ns = (int)((384 + blocks - 1) / blocks);
+  int ns = (int)((256 + blocks - 1) / blocks);
   int maxs = Pp / 64;  // at least 64 pixels per split
   if (ns > maxs) ns = maxs;
+  if (ns > 8) ns = 8;  // every slab is read back once: keep the partial-sum traffic a few MB
   if (ns < 1) ns = 1;
-  if (ns > 32) ns = 32;
   pl.kchunk = (cdiv(Pp, ns) + 7) / 8 * 8;
   pl.nsplit = cdiv(Pp, pl.kchunk);
   return pl;
@@ -333,7 +316,7 @@ extern "C" int swem_em_ew_f32(void *stream, const float *x, const float *kn, con
 
 extern "C" size_t swem_em_mstep_workspace(int NK, int R, int P, int L) {
   MPlan pl = mstep_plan(NK, R, swem_em_pad(P), L);
-  return (size_t)pl.nsplit * NK * R * L * sizeof(float);
+  return align_up((size_t)pl.nsplit * NK * R * L * sizeof(float), 256) + align_up((size_t)NK * L * sizeof(float), 256);
 }
 
 extern "C" int swem_em_mstep_f32(void *stream, const float *A, int a_batch_div, const float *zT, const float *prev,
@@ -344,9 +327,11 @@ extern "C" int swem_em_mstep_f32(void *stream, const float *A, int a_batch_div, 
   SWEM_REQUIRE(!kn_out || R <= 1024, SWEM_E_SHAPE, "em_mstep: kn_out needs R <= 1024");
   const int Pp = swem_em_pad(P);
   MPlan pl = mstep_plan(NK, R, Pp, L);
-  size_t need = (size_t)pl.nsplit * NK * R * L * sizeof(float);
+  const size_t slab_bytes = align_up((size_t)pl.nsplit * NK * R * L * sizeof(float), 256);
+  const size_t need = slab_bytes + align_up((size_t)NK * L * sizeof(float), 256);
   SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "em_mstep: workspace %zu < %zu", ws_bytes, need);
   float *part = static_cast<float *>(ws);
+  float *zt = reinterpret_cast<float *>(static_cast<char *>(ws) + slab_bytes);
   dim3 grid(cdiv(R, 128), L / (32 * pl.nt), NK * pl.nsplit);
   const long long a_bs = (long long)R * Pp;
   if (pl.nt == 2)
@@ -356,10 +341,12 @@ extern "C" int swem_em_mstep_f32(void *stream, const float *A, int a_batch_div, 
     hipLaunchKernelGGL((em_mgemm_kernel<1>), grid, dim3(256), 0, ST, A, a_bs, a_batch_div, zT, part, R, Pp, L,
                        pl.kchunk, pl.nsplit, NK);
   SWEM_CHECK_LAUNCH("em_mgemm");
-  size_t lds = (256 + 96 + (kn_out ? (size_t)R * 33 : 0)) * sizeof(float);
-  hipLaunchKernelGGL(em_finalize_kernel, dim3(L / 32, NK), dim3(256), lds, ST, part, pl.nsplit, zT, prev, zita_prev,
-                     out, zita_out, kn_out, NK, R, P, Pp, L);
+  hipLaunchKernelGGL(em_zsum_kernel, dim3(cdiv(NK * L, 4)), dim3(256), 0, ST, zT, zita_prev, zt, zita_out, NK * L, Pp);
+  SWEM_CHECK_LAUNCH("em_zsum");
+  hipLaunchKernelGGL(em_finalize_kernel, dim3(L / 32, NK, cdiv(R, 32)), dim3(256), 0, ST, part, pl.nsplit, prev,
+                     zita_prev, zt, out, NK, R, L);
   SWEM_CHECK_LAUNCH("em_finalize");
+  if (kn_out) return swem_norm_bases_into(stream, out, kn_out, NK, R, L, L, 0);
   return SWEM_OK;
 }
 

@@ -15,6 +15,12 @@ _ws = {}
 # bench.py sets this to a list to time every conv launch with HIP events on the launch stream:
 # entries are (start_event, end_event, flops, description)
 CONV_TRACE = None
+# When True, the first call of a conv layer at a new input shape times a few tilings / K-splits on the device and
+# keeps the fastest (passed to the library as the `plan` hint).  Off by default: results never depend on it beyond
+# fp32 summation order, but tuning costs a few milliseconds per layer shape.
+AUTOTUNE = False
+_TUNE_TILES = ((2, 2), (1, 2), (1, 1))
+_TUNE_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
 
 
 def _stream():
@@ -50,6 +56,7 @@ class ConvPack:
         self.cout, self.kh, self.kw, self.stride, self.pad, self.glu = cout, kh, kw, stride, pad, glu
         self.cin = w.shape[-1]
         self.cin_true = self.cin          # channels of the reference conv (without layout padding)
+        self.plans = {}                   # (B, H, W) -> plan hint chosen by the autotuner
 
 
 def pack_conv(weight, bias=None, bn=None, stride=1, pad=None, cin_pad=None, eps=1e-5):
@@ -112,24 +119,59 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     Wo = (W + 2 * pack.pad - pack.kw) // pack.stride + 1
     flags = (RELU_IN if relu_in else 0) | (RELU_OUT if relu_out else 0) | (GLU if pack.glu else 0)
     y = out if out is not None else torch.empty((B, Ho, Wo, pack.cout), dtype=torch.float32, device=x0.device)
-    wsb = _lib.query('swem_conv2d_workspace', B, H, W, cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags)
-    ws = workspace(wsb, x0.device) if wsb else None
     res_bs = 0
     if residual is not None:
         _chk(residual, 'conv residual')
         res_bs = 0 if (res_broadcast or (residual.shape[0] == 1 and B > 1)) else Ho * Wo * pack.cout
+
+    def launch(plan):
+        wsb = _lib.query('swem_conv2d_workspace', B, H, W, cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad,
+                         flags, plan)
+        ws = workspace(wsb, x0.device) if wsb else None
+        _lib.call('swem_conv2d_nhwc_f32', _stream(), *args, B, H, W, pack.w.data_ptr(), _ptr(pack.scale),
+                  _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw, pack.stride,
+                  pack.pad, flags, plan, _ptr(ws), wsb)
+
+    plan = pack.plans.get((B, H, W), 0)
+    if AUTOTUNE and plan == 0 and not torch.cuda.is_current_stream_capturing():
+        plan = pack.plans[(B, H, W)] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
+                                                 -(-pack.kh * pack.kw * cin // 32), pack.glu)
     if CONV_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call('swem_conv2d_nhwc_f32', _stream(), *args, B, H, W, pack.w.data_ptr(), _ptr(pack.scale),
-              _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw, pack.stride,
-              pack.pad, flags, _ptr(ws), wsb)
+    launch(plan)
     if CONV_TRACE is not None:
         e1.record()
         ncols = pack.cout * (2 if pack.glu else 1)
         CONV_TRACE.append((e0, e1, 2.0 * B * Ho * Wo * ncols * pack.kh * pack.kw * pack.cin_true,
                            '%dx%dx%d k%d s%d %d->%d' % (B, H, W, pack.kh, pack.stride, pack.cin_true, ncols)))
     return y
+
+
+def _autotune(launch, M, ncols, nkb, glu, reps=3):
+    """Time candidate (wave tile, K-split) plans for one layer shape; return the fastest as a plan hint."""
+    cands = [0]
+    for wm, wn in _TUNE_TILES:
+        if (glu and wn != 2) or (wn == 2 and ncols < 128):
+            continue
+        blocks = -(-M // (64 * wm)) * -(-ncols // (64 * wn))
+        for ns in _TUNE_SPLITS:
+            if ns > 1 and (nkb // ns < 2 or blocks * ns > 4096):
+                continue
+            cands.append(wm | wn << 4 | ns << 8)
+    best, best_t = 0, float('inf')
+    for plan in cands:
+        launch(plan)                               # warm (also grows the workspace)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            launch(plan)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t:
+            best, best_t = plan, t
+    return best
 
 
 def _f3(t):

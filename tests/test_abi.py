@@ -29,7 +29,7 @@ def test_version_and_error_channel(lib):
     assert lib.swem_version() == 1
     # argument validation happens before any HIP call, so it can be exercised without a GPU
     rc = lib.swem_conv2d_nhwc_f32(None, None, 4, 0, None, 0, 0, None, 0, 0, 1, 8, 8, None, None, None, None, 0, None,
-                                  32, 3, 3, 1, 1, 0, None, 0)
+                                  32, 3, 3, 1, 1, 0, 0, None, 0)
     assert rc == -4 and b'null pointer' in lib.swem_last_error()
     rc = lib.swem_match_f32(None, 1, 1, 1, None, None, 1, 1, 1, 128, 512, 100, 100, 64, ctypes.c_float(0.05), None, 0)
     assert rc == -1 and b'bases per class' in lib.swem_last_error()
@@ -42,8 +42,8 @@ def test_size_queries(lib):
     assert lib.swem_match_workspace(2, 128, 512, 1620, 256, 2) >= 2 * 1024 * (128 + 512) * 4
     assert lib.swem_memorize_workspace(2, 128, 512, 1620, 256) > 0
     # a 1/16-scale 3x3 conv (13 x 4 tiles of 128x128) is split over K; a full-resolution one is not
-    assert lib.swem_conv2d_workspace(1, 30, 54, 1024, 512, 3, 3, 1, 1, 0) > 0
-    assert lib.swem_conv2d_workspace(2, 120, 216, 256, 256, 3, 3, 1, 1, 0) == 0
+    assert lib.swem_conv2d_workspace(1, 30, 54, 1024, 512, 3, 3, 1, 1, 0, 0) > 0
+    assert lib.swem_conv2d_workspace(2, 120, 216, 256, 256, 3, 3, 1, 1, 0, 0) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

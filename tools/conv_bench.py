@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the implicit-GEMM conv on the shapes of one config-B frame (GPU box only).
+   python tools/conv_bench.py [--reps 20] [--shapes big|all]      (SWEM_CONV_PLAN=wm,wn,ns forces a plan)"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch  # noqa: E402
+from swem_amd import ops  # noqa: E402
+
+SHAPES = [  # B, H, W, Cin, Cout, k, stride, relu_in
+    (2, 120, 216, 256, 256, 3, 1, True),
+    (2, 30, 54, 512, 512, 3, 1, True),
+    (2, 30, 54, 1280, 512, 3, 1, True),
+    (2, 60, 108, 512, 256, 3, 1, True),
+    (1, 60, 108, 512, 512, 3, 1, False),
+    (1, 120, 216, 256, 256, 3, 1, False),
+    (2, 120, 216, 64, 64, 3, 1, False),
+    (1, 30, 54, 256, 256, 3, 1, False),
+    (1, 30, 54, 1024, 256, 1, 1, False),
+    (1, 30, 54, 256, 1024, 1, 1, False),
+    (1, 120, 216, 64, 256, 1, 1, False),
+    (1, 30, 54, 1024, 512, 3, 1, False),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--only', type=int, default=-1)
+    a = ap.parse_args()
+    dev = 'cuda:0'
+    print('plan=%s' % os.environ.get('SWEM_CONV_PLAN', 'auto'))
+    for idx, (B, H, W, ci, co, k, s, relu) in enumerate(SHAPES):
+        if a.only >= 0 and idx != a.only:
+            continue
+        x = torch.randn(B, H, W, ci, device=dev)
+        pack = ops.pack_conv(torch.randn(co, ci, k, k, device=dev) * 0.02, torch.zeros(co, device=dev), None, s, k // 2)
+        for _ in range(3):
+            y = ops.conv2d([x], pack, relu_in=relu)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            y = ops.conv2d([x], pack, relu_in=relu)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / a.reps
+        fl = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * co * k * k * ci
+        print('%dx%dx%d k%d s%d %4d->%4d  %8.1f us  %6.1f TFLOP/s' % (B, H, W, k, s, ci, co, us, fl / us / 1e6))
+
+
+if __name__ == '__main__':
+    main()
