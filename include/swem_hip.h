@@ -62,6 +62,9 @@ int swem_device_cus(void);
  *             0 = the same image for every batch item (replaces .expand(), swem.py:52-53,94-95)
  *   w       : [Cout'][KH][KW][Cin], Cin = c0+c1+c2 (must be a multiple of 4);
  *             Cout' = Cout, or 2*Cout grouped [Cout/32][2][32] when SWEM_CONV_GLU
+ *   w_bs    : 0 = one filter bank for the whole batch (every nn.Conv2d); else elements between the banks of
+ *             consecutive batch items (a batched GEMM: the value readout of matching, modules.py:272-273);
+ *             then Ho*Wo must be a multiple of the row tile (128 is always safe)
  *   scale   : [Cout'] or NULL (=1)     -- folded BatchNorm  gamma/sqrt(var+eps)
  *   shift   : [Cout'] or NULL (=0)     -- conv bias and folded BatchNorm shift
  *   res     : NHWC [B][Ho][Wo][Cout] added after scale/shift, or NULL; res_bs as bsK
@@ -75,7 +78,7 @@ size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, int KH, int
                              int flags, int plan);
 int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
                          long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
-                         const float *w, const float *scale, const float *shift, const float *res,
+                         const float *w, long long w_bs, const float *scale, const float *shift, const float *res,
                          long long res_bs, float *y, int Cout, int KH, int KW, int stride, int pad, int flags,
                          int plan, void *ws, size_t ws_bytes);
 
@@ -173,12 +176,15 @@ int swem_memorize_f32(void *stream, const float *x, const float *v, const float 
  * readout and the top-l prefix-sum features, for all objects of one frame.
  *   qk [P][C] raw query key; banks: kappa_k [N][2][C][L], nu_k [N][2][V][L], k = first / update
  *   (update may be NULL on the first matched frame: Lm = L, else Lm = 2L)
- *   mem_out [N][P][V], S [N][P][2*topl]  (NHWC sources of the fusion conv, modules.py:291)
+ *   mem_out [N][Pm][V] with Pm = swem_match_pad(P) rows per object (rows >= P are zero),
+ *   S [N][P][2*topl]  -- the NHWC sources of the fusion conv (modules.py:291)
+ *   readout_plan: conv plan hint for the readout GEMM (0 = heuristic), see swem_conv2d_nhwc_f32
  */
-size_t swem_match_workspace(int N, int C, int V, int P, int L, int nbanks);
+int swem_match_pad(int P);
+size_t swem_match_workspace(int N, int C, int V, int P, int L, int nbanks, int readout_plan);
 int swem_match_f32(void *stream, const float *qk, const float *kappa_first, const float *nu_first,
                    const float *kappa_update, const float *nu_update, float *mem_out, float *S, int N, int C,
-                   int V, int P, int L, int topl, float tau, void *ws, size_t ws_bytes);
+                   int V, int P, int L, int topl, float tau, int readout_plan, void *ws, size_t ws_bytes);
 
 #ifdef __cplusplus
 }

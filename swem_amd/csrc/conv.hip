@@ -35,16 +35,22 @@ struct ConvP {
   long long bs[3];
   int B, H, W, Ho, Wo, Cin, K, M;
   const float *w, *scale, *shift, *res;
-  long long res_bs;
+  long long res_bs, w_bs;  // w_bs: elements between the filter banks of consecutive batch items (0 = shared)
   float *y;
   int Cout, Ncols, KH, KW, stride, pad, flags;
   int nkb, kb_per_split;
   float *partial;
 };
 
-__device__ __forceinline__ float4 relu4(float4 v) {
-  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+// One v_max_f32 per element.  fmaxf() costs two (hipcc first canonicalises the operand with v_max x,x), and in the fp32
+// MFMA k-loop every vector instruction is time taken from the matrix pipe.  NaN inputs map to 0 (IEEE maxNum),
+// like ATen's clamp-based ReLU on this path's finite activations.
+__device__ __forceinline__ float relu1(float x) {
+  float y;
+  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
 }
+__device__ __forceinline__ float4 relu4(float4 v) { return make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)); }
 
 // zero a loaded vector with a bit mask: the value is used unconditionally, so the load itself stays unconditional
 __device__ __forceinline__ float4 mask4(float4 v, bool keep) {
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   for (int i = 0; i < RB; ++i) {
     int n = n0 + rbase + 32 * i;
     colok[i] = n < p.Ncols;
-    wrow[i] = p.w + (long long)(colok[i] ? n : 0) * p.K;
+    wrow[i] = p.w + (long long)(m0 / (p.Ho * p.Wo)) * p.w_bs + (long long)(colok[i] ? n : 0) * p.K;
   }
   const bool relu_in = p.flags & SWEM_CONV_RELU_IN;
 
@@ -354,8 +360,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvP p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0,
                                              (int)((bs ? (long long)p.B * bs : HWin * cs) * 4), 0x00020000);
   };
-  __amdgpu_buffer_rsrc_t rsw =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, (int)((long long)p.Ncols * p.K * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.w + (long long)(m0 / (p.Ho * p.Wo)) * p.w_bs), 0, (int)((long long)p.Ncols * p.K * 4),
+      0x00020000);
 
   int iy0[RA], ix0[RA], bidx[RA];
   const int HoWo = p.Ho * p.Wo;
@@ -622,9 +629,9 @@ extern "C" size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, 
 
 extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
                                     long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
-                                    const float *w, const float *scale, const float *shift, const float *res,
-                                    long long res_bs, float *y, int Cout, int KH, int KW, int stride, int pad,
-                                    int flags, int plan, void *ws, size_t ws_bytes) {
+                                    const float *w, long long w_bs, const float *scale, const float *shift,
+                                    const float *res, long long res_bs, float *y, int Cout, int KH, int KW, int stride,
+                                    int pad, int flags, int plan, void *ws, size_t ws_bytes) {
   SWEM_REQUIRE(x0 && w && y, SWEM_E_ARG, "conv2d: null pointer");
   if (!x1) c1 = 0;
   if (!x2) c2 = 0;
@@ -649,7 +656,7 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
   long long M = (long long)B * p.Ho * p.Wo;
   SWEM_REQUIRE(M < (1ll << 31) && M * (glu ? 2 * Cout : Cout) < (1ll << 40), SWEM_E_SHAPE, "conv2d: too large");
   p.M = (int)M;
-  p.w = w; p.scale = scale; p.shift = shift; p.res = res; p.res_bs = res_bs; p.y = y;
+  p.w = w; p.scale = scale; p.shift = shift; p.res = res; p.res_bs = res_bs; p.w_bs = w_bs; p.y = y;
   p.Cout = Cout; p.Ncols = glu ? 2 * Cout : Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.flags = flags;
   {
@@ -669,6 +676,8 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
     SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d: workspace %zu < %zu bytes", ws_bytes, need);
     p.partial = static_cast<float *>(ws);
   }
+  SWEM_REQUIRE(w_bs == 0 || (p.Ho * p.Wo) % (64 * pl.wm) == 0, SWEM_E_SHAPE,
+               "conv2d: per-batch filters need Ho*Wo (%d) to be a multiple of the %d-row tile", p.Ho * p.Wo, 64 * pl.wm);
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(cdiv(p.M, 64 * pl.wm), cdiv(p.Ncols, 64 * pl.wn), pl.nsplit);
   int rc;

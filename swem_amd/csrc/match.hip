@@ -1,19 +1,18 @@
-// Matching (reference methods/SWEM/modules.py:198-208, 232-289) as ONE kernel per frame plus a small
-// memory-packing step.  Nothing of size (bases x pixels) ever reaches HBM.
+// Matching (reference methods/SWEM/modules.py:198-208, 232-289): three high-occupancy kernels + one batched GEMM.
 //
-// prep   : the two banks ('first', 'update') of each object are l2-normalised over C and packed as
-//          mkn [N][Ltot][C] (row = class*Lm + bank*L + l, the order of get_mem + flatten, modules.py:266,304),
-//          and the value bases as mvp [N][V][Ltot] (modules.py:272).
-// match  : block = (object, 32-pixel tile), 4 waves, the whole exp-affinity tile e[Ltot][32] in LDS (132 KiB at
-//          Ltot = 1024, row stride 33 floats so column AND row walks are conflict free):
-//   1. stage the raw query keys, l2-normalise each pixel in LDS (modules.py:282);
-//   2. affinity  mkn . q  on v_mfma_f32_32x32x2_f32 with the pixel on the lane and the base in the accumulator
-//      registers, so the joint {bg,fg} max and the exp-sum are in-register + one LDS exchange (modules.py:247-250);
-//   3. readout  mvp . e  (second MFMA chain, B operand read from the LDS tile), divided by the exp-sum in the
-//      epilogue (modules.py:265-266, 272-274) and stored NHWC;
-//   4. top-l features: each wave takes 8 pixels; per (pixel, class) the Lm exp values are sorted across the wave
-//      (64-lane bitonic network on J = Lm/64 registers, pairwise top-64 merges), a wave scan gives the prefix sums,
-//      feat = c_bg / (c_bg + c_fg) and its complement are stored as 2*topl channels (modules.py:198-208).
+// prep     : the two banks ('first', 'update') of each object are l2-normalised over C and packed as
+//            mkn [N][Ltot][C] (row = class*Lm + bank*L + l, the order of get_mem + flatten, modules.py:266,304),
+//            and the value bases as mvp [N][V][Ltot] (modules.py:272).
+// affinity : block = (object, 32-pixel tile): l2-normalise the query pixels in LDS (modules.py:282), affinity
+//            mkn . q on v_mfma_f32_32x32x2_f32 with the pixel on the MFMA lane and the base in the accumulator registers,
+//            so the joint {bg,fg} max and exp-sum are in-register + one LDS exchange (modules.py:247-250, 265-266);
+//            writes the probabilities pixel-major  pT [N][Pm][Ltot]  (13 MB at config B: L2 / Infinity-Cache resident).
+// top-l    : one wave per (object, pixel): 64-lane bitonic sort of each class's Lm values, pairwise top-64 merges,
+//            wave scan, feat = c_bg/(c_bg+c_fg) and its complement -> S [N][P][2*topl] (modules.py:198-208).
+// readout  : mem_out[n] = pT[n] . mvp[n]^T (modules.py:272-274) is a batched GEMM run by the implicit-GEMM conv kernel
+//            (1x1 "conv" over a Pm x 1 image with Ltot channels and per-object filters), output NHWC [N][Pm][V].
+// (The first version kept the whole exp tile in 132 KiB of LDS inside one kernel; at one block per CU and one wave
+//  per SIMD every global and LDS latency was exposed: 209 us per frame.  This split runs in a fraction of that.)
 #include "common.h"
 
 namespace {
@@ -60,22 +59,21 @@ __device__ __forceinline__ float merge_top64(float a, float b, int lane) {
   return v;
 }
 
+// K1: affinity + joint softmax.  Block = (object, 32-pixel tile); wave w owns bases [w*32J, +32J).
+// pT[n][p][l] = exp((aff - max)/tau) / sum   (pixel-major, one row of Ltot probabilities per pixel; rows >= P are 0)
 template <int J>  // Lm = 64*J bases per class; Ltot = 128*J
-__global__ __launch_bounds__(256) void match_kernel(const float *__restrict__ qk, const float *__restrict__ mkn,
-                                                    const float *__restrict__ mvp, float *__restrict__ mem_out,
-                                                    float *__restrict__ S, int C, int V, int P, int topl, float tau) {
-  constexpr int Ltot = 128 * J, Lm = 64 * J;
-  constexpr int ES = 33;
+__global__ __launch_bounds__(256) void match_affinity_kernel(const float *__restrict__ qk,
+                                                             const float *__restrict__ mkn, float *__restrict__ pT,
+                                                             int C, int P, int Pm, float tau) {
+  constexpr int Ltot = 128 * J;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int QS = C + 4;
-  float *et = sm;                 // [Ltot][33]
-  float *qs = et + Ltot * ES;     // [32][C+4]
-  float *red = qs + 32 * QS;      // [2][4][32]
+  float *qs = sm;             // [32][C+4]
+  float *red = qs + 32 * QS;  // [2][4][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int n = blockIdx.y, p0 = blockIdx.x * 32;
   const int cq = C / 4;
-  // 1. stage + normalise the query tile
   for (int idx = tid; idx < 32 * cq; idx += 256) {
     int row = idx / cq, c4 = idx - row * cq;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -83,7 +81,7 @@ __global__ __launch_bounds__(256) void match_kernel(const float *__restrict__ qk
     *reinterpret_cast<float4 *>(qs + row * QS + c4 * 4) = v;
   }
   __syncthreads();
-  for (int rr = 0; rr < 8; ++rr) {
+  for (int rr = 0; rr < 8; ++rr) {  // l2norm of the query pixels (modules.py:282)
     int row = wave * 8 + rr;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) {
@@ -95,7 +93,6 @@ __global__ __launch_bounds__(256) void match_kernel(const float *__restrict__ qk
     for (int c = lane; c < C; c += 64) qs[row * QS + c] /= den;
   }
   __syncthreads();
-  // 2. affinity: this wave owns bases [wave*32J, +32J)
   f32x16 acc[J];
 #pragma unroll
   for (int t = 0; t < J; ++t)
@@ -104,10 +101,19 @@ __global__ __launch_bounds__(256) void match_kernel(const float *__restrict__ qk
   {
     const float *krow = mkn + ((long long)n * Ltot + wave * 32 * J + r) * C + 4 * h;
     const float *qrow = qs + r * QS + 4 * h;
+    // operands of step j+1 are requested before the MFMAs of step j (one wave per SIMD: nothing else hides the latency)
+    float4 a4[J], an[J];
+#pragma unroll
+    for (int t = 0; t < J; ++t) a4[t] = ld4(krow + (long long)t * 32 * C);
     for (int j = 0; j < C / 8; ++j) {
+      const int jn = j + 1 < C / 8 ? j + 1 : j;
+#pragma unroll
+      for (int t = 0; t < J; ++t) an[t] = ld4(krow + (long long)t * 32 * C + 8 * jn);
       float4 b4 = *reinterpret_cast<const float4 *>(qrow + 8 * j);
 #pragma unroll
-      for (int t = 0; t < J; ++t) acc[t] = mfma32x4(ld4(krow + (long long)t * 32 * C + 8 * j), b4, acc[t]);
+      for (int t = 0; t < J; ++t) acc[t] = mfma32x4(a4[t], b4, acc[t]);
+#pragma unroll
+      for (int t = 0; t < J; ++t) a4[t] = an[t];
     }
   }
   float m = -__builtin_huge_valf();
@@ -125,74 +131,83 @@ __global__ __launch_bounds__(256) void match_kernel(const float *__restrict__ qk
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       float v = expf((acc[t][e] - m) / tau);
+      acc[t][e] = v;
       se += v;
-      et[(wave * 32 * J + 32 * t + acc_row(e, h)) * ES + r] = v;
     }
   se += __shfl_xor(se, 32);
   if (h == 0) red[128 + wave * 32 + r] = se;
   __syncthreads();
   const float esum = (red[128 + r] + red[128 + 32 + r]) + (red[128 + 64 + r] + red[128 + 96 + r]);
-  // 3. readout: 128 value rows per pass, one 32x32 tile per wave
-  const bool pin = p0 + r < P;
-  for (int vc = 0; vc < V; vc += 128) {
-    f32x16 o;
+  const float inv = (p0 + r < P) ? 1.0f / esum : 0.f;  // padded rows are written as zeros
+  if (p0 + r < Pm) {
+    float *dst = pT + ((long long)n * Pm + p0 + r) * Ltot + wave * 32 * J + 4 * h;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) o[e] = 0.f;
-    const float *vrow = mvp + ((long long)n * V + vc + wave * 32 + r) * Ltot + 4 * h;
-    const float *ecol = et + (4 * h) * ES + r;
-    for (int j = 0; j < Ltot / 8; ++j) {
-      float4 a4 = ld4(vrow + 8 * j);
-      const float *ep = ecol + (8 * j) * ES;
-      float4 b4 = make_float4(ep[0], ep[ES], ep[2 * ES], ep[3 * ES]);
-      o = mfma32x4(a4, b4, o);
-    }
-    if (pin) {
-      float *dst = mem_out + ((long long)n * P + p0 + r) * V + vc + wave * 32 + 4 * h;
+    for (int t = 0; t < J; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4 *>(dst + 8 * g) =
-            make_float4(o[4 * g] / esum, o[4 * g + 1] / esum, o[4 * g + 2] / esum, o[4 * g + 3] / esum);
-    }
+        *reinterpret_cast<float4 *>(dst + 32 * t + 8 * g) = make_float4(
+            acc[t][4 * g] * inv, acc[t][4 * g + 1] * inv, acc[t][4 * g + 2] * inv, acc[t][4 * g + 3] * inv);
   }
-  // 4. top-l prefix features: wave -> pixels [wave*8, +8)
-  for (int pi = 0; pi < 8; ++pi) {
-    const int pix = wave * 8 + pi;
-    float cum[2];
+}
+
+// K3: top-l prefix features (modules.py:198-208).  One wave per (object, pixel): the Lm probabilities of each class are
+// sorted across the wave (bitonic network on J registers per lane + pairwise top-64 merges), a wave scan gives the
+// prefix sums and feat = c_bg / (c_bg + c_fg) (invariant to the common 1/sum factor of the row).
+template <int J>
+__global__ __launch_bounds__(256) void match_topl_kernel(const float *__restrict__ pT, float *__restrict__ S, int N,
+                                                         int P, int Pm, int topl) {
+  constexpr int Ltot = 128 * J, Lm = 64 * J;
+  const int lane = threadIdx.x & 63;
+  const long long idx = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= (long long)N * P) return;
+  const int n = (int)(idx / P), pix = (int)(idx - (long long)n * P);
+  const float *row = pT + ((long long)n * Pm + pix) * Ltot;
+  float cum[2];
 #pragma unroll
-    for (int cls = 0; cls < 2; ++cls) {
-      float v[J];
+  for (int cls = 0; cls < 2; ++cls) {
+    float v[J];
 #pragma unroll
-      for (int j = 0; j < J; ++j) v[j] = sort64_desc(et[(cls * Lm + lane + 64 * j) * ES + pix], lane);
+    for (int j = 0; j < J; ++j) v[j] = row[cls * Lm + lane + 64 * j];
 #pragma unroll
-      for (int w = 1; w < J; w <<= 1)
+    for (int j = 0; j < J; ++j) v[j] = sort64_desc(v[j], lane);
 #pragma unroll
-        for (int j = 0; j + w < J; j += 2 * w) v[j] = merge_top64(v[j], v[j + w], lane);
-      float c = v[0];
+    for (int w = 1; w < J; w <<= 1)
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        float t = __shfl_up(c, d);
-        if (lane >= d) c += t;
-      }
-      cum[cls] = c;
+      for (int j = 0; j + w < J; j += 2 * w) v[j] = merge_top64(v[j], v[j + w], lane);
+    float c = v[0];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      float t = __shfl_up(c, d);
+      if (lane >= d) c += t;
     }
-    if (p0 + pix < P && lane < topl) {
-      float f = cum[0] / (cum[0] + cum[1]);
-      float *dst = S + ((long long)n * P + p0 + pix) * (2 * topl);
-      dst[lane] = f;
-      dst[topl + lane] = 1.f - f;
-    }
+    cum[cls] = c;
+  }
+  if (lane < topl) {
+    float f = cum[0] / (cum[0] + cum[1]);
+    float *dst = S + idx * (2 * topl);
+    dst[lane] = f;
+    dst[topl + lane] = 1.f - f;
   }
 }
 
 struct MatchWs {
-  size_t mkn, mvp, total;
+  size_t mkn, mvp, pT, conv, total;
 };
-MatchWs match_ws(int N, int C, int V, int L, int nbanks) {
+MatchWs match_ws(int N, int C, int V, int P, int L, int nbanks, int plan) {
   MatchWs w;
   const size_t Ltot = (size_t)2 * nbanks * L;
-  w.mkn = 0;
-  w.mvp = align_up((size_t)N * Ltot * C * 4, 256);
-  w.total = w.mvp + align_up((size_t)N * V * Ltot * 4, 256);
+  const int Pm = swem_match_pad(P);
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = align_up(o + bytes, 256);
+    return at;
+  };
+  w.mkn = take((size_t)N * Ltot * C * 4);
+  w.mvp = take((size_t)N * V * Ltot * 4);
+  w.pT = take((size_t)N * Pm * Ltot * 4);
+  w.conv = take(swem_conv2d_workspace(N, Pm, 1, (int)Ltot, V, 1, 1, 1, 0, 0, plan));
+  w.total = o;
   return w;
 }
 
@@ -200,28 +215,31 @@ MatchWs match_ws(int N, int C, int V, int L, int nbanks) {
 
 #define ST static_cast<hipStream_t>(stream)
 
-extern "C" size_t swem_match_workspace(int N, int C, int V, int P, int L, int nbanks) {
-  (void)P;
-  return match_ws(N, C, V, L, nbanks).total;
+extern "C" int swem_match_pad(int P) { return (P + 127) / 128 * 128; }
+
+extern "C" size_t swem_match_workspace(int N, int C, int V, int P, int L, int nbanks, int readout_plan) {
+  return match_ws(N, C, V, P, L, nbanks, readout_plan).total;
 }
 
 extern "C" int swem_match_f32(void *stream, const float *qk, const float *kappa_first, const float *nu_first,
                               const float *kappa_update, const float *nu_update, float *mem_out, float *S, int N,
-                              int C, int V, int P, int L, int topl, float tau, void *ws, size_t ws_bytes) {
+                              int C, int V, int P, int L, int topl, float tau, int readout_plan, void *ws,
+                              size_t ws_bytes) {
   SWEM_REQUIRE(qk && kappa_first && nu_first && mem_out && S, SWEM_E_ARG, "match: null pointer");
   SWEM_REQUIRE((kappa_update == nullptr) == (nu_update == nullptr), SWEM_E_ARG, "match: update bank half given");
   const int nbanks = kappa_update ? 2 : 1;
   const int Lm = nbanks * L, Ltot = 2 * Lm;
   SWEM_REQUIRE(Lm == 64 || Lm == 128 || Lm == 256 || Lm == 512, SWEM_E_SHAPE,
                "match: bases per class must be 64, 128, 256 or 512 (got %d)", Lm);
-  SWEM_REQUIRE(C % 8 == 0 && V % 128 == 0 && L % 4 == 0, SWEM_E_SHAPE, "match: need C %% 8 == 0, V %% 128 == 0");
+  SWEM_REQUIRE(C % 8 == 0 && C <= 1024 && V % 4 == 0 && L % 4 == 0, SWEM_E_SHAPE,
+               "match: need C %% 8 == 0, C <= 1024, V %% 4 == 0");
   SWEM_REQUIRE(topl >= 1 && topl <= 64 && topl <= Lm, SWEM_E_SHAPE, "match: topl must be in [1, 64] (got %d)", topl);
   SWEM_REQUIRE(tau > 0.f, SWEM_E_ARG, "match: tau must be positive");
-  const size_t lds = ((size_t)Ltot * 33 + 32 * (C + 4) + 256) * sizeof(float);
-  SWEM_REQUIRE(lds <= 160 * 1024, SWEM_E_SHAPE, "match: tile needs %zu bytes of LDS (> 160 KiB); reduce C", lds);
-  MatchWs w = match_ws(N, C, V, L, nbanks);
+  const int Pm = swem_match_pad(P);
+  MatchWs w = match_ws(N, C, V, P, L, nbanks, readout_plan);
   SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "match: workspace %zu < %zu", ws_bytes, w.total);
-  float *mkn = (float *)((char *)ws + w.mkn), *mvp = (float *)((char *)ws + w.mvp);
+  char *base = static_cast<char *>(ws);
+  float *mkn = (float *)(base + w.mkn), *mvp = (float *)(base + w.mvp), *pT = (float *)(base + w.pT);
   int rc;
   if ((rc = swem_norm_bases_into(stream, kappa_first, mkn, 2 * N, C, L, Lm, 0))) return rc;
   if (nbanks == 2 && (rc = swem_norm_bases_into(stream, kappa_update, mkn, 2 * N, C, L, Lm, L))) return rc;
@@ -232,17 +250,22 @@ extern "C" int swem_match_f32(void *stream, const float *qk, const float *kappa_
       hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu_update, mvp, N, V, L, Lm, L);
     SWEM_CHECK_LAUNCH("pack_values");
   }
-  dim3 grid(cdiv(P, 32), N);
-#define MATCH(J_)                                                                                                   \
-  do {                                                                                                              \
-    SWEM_ALLOW_LDS((match_kernel<J_>), 160 * 1024);                                                                 \
-    hipLaunchKernelGGL((match_kernel<J_>), grid, dim3(256), lds, ST, qk, mkn, mvp, mem_out, S, C, V, P, topl, tau); \
+  const size_t lds = ((size_t)32 * (C + 4) + 256) * sizeof(float);
+  dim3 grid(Pm / 32, N), gridt(cdiv((long long)N * P, 4));
+#define MATCH(J_)                                                                                                     \
+  do {                                                                                                                \
+    hipLaunchKernelGGL((match_affinity_kernel<J_>), grid, dim3(256), lds, ST, qk, mkn, pT, C, P, Pm, tau);            \
+    hipLaunchKernelGGL((match_topl_kernel<J_>), gridt, dim3(256), 0, ST, pT, S, N, P, Pm, topl);                      \
   } while (0)
   if (Lm == 64) MATCH(1);
   else if (Lm == 128) MATCH(2);
   else if (Lm == 256) MATCH(4);
   else MATCH(8);
 #undef MATCH
-  SWEM_CHECK_LAUNCH("match_kernel");
-  return SWEM_OK;
+  SWEM_CHECK_LAUNCH("match_affinity / match_topl");
+  // value readout (modules.py:272-273) = batched GEMM  mem_out[n] = pT[n] . mvp[n]^T  on the conv kernel:
+  // "image" of Pm x 1 pixels with Ltot channels, 1x1 filters = the V value rows of object n (w_bs = V*Ltot)
+  return swem_conv2d_nhwc_f32(stream, pT, Ltot, (long long)Pm * Ltot, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, mvp,
+                              (long long)V * Ltot, nullptr, nullptr, nullptr, 0, mem_out, V, 1, 1, 1, 0, 0,
+                              readout_plan, base + w.conv, w.total - w.conv);
 }

@@ -208,7 +208,8 @@ class SWEMCore(nn.Module):
             ku = update['kappa'].reshape(N, 2, Ck, L).contiguous()
             nu = update['nu'].reshape(N, 2, -1, L).contiguous()
         mem_out, S = ops.match(xp, kf, nf, ku, nu, self.topl, self.tau)
-        return S.view(N, H, W, -1), mem_out.view(N, H, W, -1)
+        # mem_out keeps a row pitch per object (ops.match): NHWC images, free batch stride
+        return S.view(N, H, W, -1), mem_out.unflatten(1, (H, W))
 
     def matching(self, qk, qv):
         first, update = self.memories['first'].bases, self.memories['update'].bases

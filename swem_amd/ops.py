@@ -97,18 +97,26 @@ def pack_glu(wf, bf, wa, ba):
     return ConvPack(w, None, shift, co, kh, kw, 1, kh // 2, glu=True)
 
 
+def _chk_src(t):
+    """A conv source: fp32 device tensor (B,H,W,C) whose images are contiguous; the batch stride is free
+    (match's mem_out keeps a row pitch per object)."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t[0].is_contiguous()):
+        raise _lib.SwemHipError('conv input must be an fp32 device tensor (B,H,W,C) with contiguous images')
+    return t
+
+
 def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadcast=False, batch=None, out=None):
     """srcs: list of up to three NHWC tensors concatenated on C; a source with batch 1 is broadcast over `batch`."""
-    x0 = _chk(srcs[0], 'conv input')
+    x0 = _chk_src(srcs[0])
     B = batch if batch is not None else max(s.shape[0] for s in srcs)
     _, H, W, _ = x0.shape
     args = []
     cin = 0
     for s in srcs:
-        _chk(s, 'conv input')
+        _chk_src(s)
         if s.shape[1] != H or s.shape[2] != W:
             raise _lib.SwemHipError('conv2d: sources differ in spatial size')
-        bs = 0 if (s.shape[0] == 1 and B > 1) else H * W * s.shape[3]
+        bs = 0 if (s.shape[0] == 1 and B > 1) else (s.stride(0) if s.shape[0] > 1 else H * W * s.shape[3])
         args += [s.data_ptr(), s.shape[3], bs]
         cin += s.shape[3]
     for _ in range(3 - len(srcs)):
@@ -128,7 +136,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         wsb = _lib.query('swem_conv2d_workspace', B, H, W, cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad,
                          flags, plan)
         ws = workspace(wsb, x0.device) if wsb else None
-        _lib.call('swem_conv2d_nhwc_f32', _stream(), *args, B, H, W, pack.w.data_ptr(), _ptr(pack.scale),
+        _lib.call('swem_conv2d_nhwc_f32', _stream(), *args, B, H, W, pack.w.data_ptr(), 0, _ptr(pack.scale),
                   _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw, pack.stride,
                   pack.pad, flags, plan, _ptr(ws), wsb)
 
@@ -376,8 +384,12 @@ def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau):
     return kappa, nu, zita
 
 
+_MATCH_PLANS = {}
+
+
 def match(qk, kappa_first, nu_first, kappa_update, nu_update, topl, tau):
-    """qk (P,C); banks (N,2,C,L)/(N,2,V,L) -> mem_out (N,P,V), S (N,P,2*topl)."""
+    """qk (P,C); banks (N,2,C,L)/(N,2,V,L) -> mem_out (N,P,V) (a view of a buffer with Pm >= P rows per object),
+    S (N,P,2*topl)."""
     _chk(qk)
     _chk(kappa_first)
     _chk(nu_first)
@@ -388,11 +400,20 @@ def match(qk, kappa_first, nu_first, kappa_update, nu_update, topl, tau):
         _chk(kappa_update)
         _chk(nu_update)
         nb = 2
-    mem_out = torch.empty((N, P, V), dtype=torch.float32, device=qk.device)
+    Pm = _lib.query('swem_match_pad', P)
+    mem_out = torch.empty((N, Pm, V), dtype=torch.float32, device=qk.device)
     S = torch.empty((N, P, 2 * topl), dtype=torch.float32, device=qk.device)
-    wsb = _lib.query('swem_match_workspace', N, Cc, V, P, L, nb)
-    ws = workspace(wsb, qk.device)
-    _lib.call('swem_match_f32', _stream(), qk.data_ptr(), kappa_first.data_ptr(), nu_first.data_ptr(),
-              _ptr(kappa_update), _ptr(nu_update), mem_out.data_ptr(), S.data_ptr(), N, Cc, V, P, L, int(topl),
-              float(tau), ws.data_ptr(), wsb)
-    return mem_out, S
+
+    def launch(plan):
+        wsb = _lib.query('swem_match_workspace', N, Cc, V, P, L, nb, plan)
+        ws = workspace(wsb, qk.device)
+        _lib.call('swem_match_f32', _stream(), qk.data_ptr(), kappa_first.data_ptr(), nu_first.data_ptr(),
+                  _ptr(kappa_update), _ptr(nu_update), mem_out.data_ptr(), S.data_ptr(), N, Cc, V, P, L, int(topl),
+                  float(tau), plan, ws.data_ptr(), wsb)
+
+    key = (N, Cc, V, P, L, nb)
+    plan = _MATCH_PLANS.get(key, 0)
+    if AUTOTUNE and plan == 0 and not torch.cuda.is_current_stream_capturing():
+        plan = _MATCH_PLANS[key] = _autotune(launch, N * Pm, V, 2 * nb * L // 32, False)
+    launch(plan)
+    return mem_out[:, :P], S

@@ -28,10 +28,10 @@ def test_header_symbols_are_exported_and_bound(lib):
 def test_version_and_error_channel(lib):
     assert lib.swem_version() == 1
     # argument validation happens before any HIP call, so it can be exercised without a GPU
-    rc = lib.swem_conv2d_nhwc_f32(None, None, 4, 0, None, 0, 0, None, 0, 0, 1, 8, 8, None, None, None, None, 0, None,
+    rc = lib.swem_conv2d_nhwc_f32(None, None, 4, 0, None, 0, 0, None, 0, 0, 1, 8, 8, None, 0, None, None, None, 0, None,
                                   32, 3, 3, 1, 1, 0, 0, None, 0)
     assert rc == -4 and b'null pointer' in lib.swem_last_error()
-    rc = lib.swem_match_f32(None, 1, 1, 1, None, None, 1, 1, 1, 128, 512, 100, 100, 64, ctypes.c_float(0.05), None, 0)
+    rc = lib.swem_match_f32(None, 1, 1, 1, None, None, 1, 1, 1, 128, 512, 100, 100, 64, ctypes.c_float(0.05), 0, None, 0)
     assert rc == -1 and b'bases per class' in lib.swem_last_error()
     with pytest.raises(_lib.SwemHipError):
         _lib.call('swem_em_ew_f32', None, 1, 1, None, None, None, None, 1, 100, 10, 64, 0.05, 1, 0)
@@ -39,7 +39,8 @@ def test_version_and_error_channel(lib):
 
 def test_size_queries(lib):
     assert lib.swem_em_pad(1620) == 1624 and lib.swem_em_pad(1624) == 1624
-    assert lib.swem_match_workspace(2, 128, 512, 1620, 256, 2) >= 2 * 1024 * (128 + 512) * 4
+    assert lib.swem_match_pad(1620) == 1664
+    assert lib.swem_match_workspace(2, 128, 512, 1620, 256, 2, 0) >= 2 * 1024 * (128 + 512 + 1664) * 4
     assert lib.swem_memorize_workspace(2, 128, 512, 1620, 256) > 0
     # a 1/16-scale 3x3 conv (13 x 4 tiles of 128x128) is split over K; a full-resolution one is not
     assert lib.swem_conv2d_workspace(1, 30, 54, 1024, 512, 3, 3, 1, 1, 0, 0) > 0

@@ -96,7 +96,7 @@ def test_matching_vs_golden(lib, golden):
     for tag, banks, Sref, memref in (('Lm=64', (first[0], first[1], None, None), m['S1'], m['mem1']),
                                      ('Lm=128', (first[0], first[1], upd[0], upd[1]), m['S2'], m['mem2'])):
         mem, S = ops.match(xp, *banks, 64, 0.05)
-        mem = mem.view(2, h, w, -1).permute(0, 3, 1, 2).cpu()
+        mem = mem.reshape(2, h, w, -1).permute(0, 3, 1, 2).cpu()
         S = S.view(2, h, w, -1).permute(0, 3, 1, 2).cpu()
         e_mem = float((mem - memref[0]).abs().max())
         e_S = float((S - Sref).abs().max())
@@ -128,7 +128,7 @@ def test_memorize_and_match_vs_oracle(lib, L, T):
     qk = qx.t().reshape(1, C, h, w).contiguous()
     omem, _, oS, _ = ocore.match_features(qk, torch.zeros(1, V, h, w))
     mem, S = ops.match(d(qx), d(o0['kappa'][0]), d(o0['nu'][0]), d(o1['kappa'][0]), d(o1['nu'][0]), 64, 0.05)
-    mem = mem.view(N, h, w, V).permute(0, 3, 1, 2).cpu()
+    mem = mem.reshape(N, h, w, V).permute(0, 3, 1, 2).cpu()
     S = S.view(N, h, w, -1).permute(0, 3, 1, 2).cpu()
     assert float((mem - omem).abs().max()) < 1e-4 * max(1.0, float(omem.abs().max())), 'mem_out'
     assert float((S - oS).abs().max()) < 1e-4, 'S'

@@ -163,3 +163,35 @@ def test_fps_meter_and_sequences(lib):
     res, meter = evaluator.run_sequences(model, [(frames.to(DEV), m0.to(DEV), (128, 192))] * 2)
     assert meter.frame_n == 6 and meter.total_time > 0 and len(res) == 2 and len(res[0]) == 2
     assert res[0][0].dtype == torch.int64 and res[0][0].shape == (1, 128, 192)
+
+
+def test_frame_graph_matches_eager(lib):
+    """The HIP-graph replay of the steady-state frame (evaluator.FrameGraph) is bit-identical to eager launches,
+    including the recurrent memory state, over several frames."""
+    from swem_amd import synth
+    cfg = O.make_cfg(**CFG_A)
+    frames, m0 = synth.make_clip(t=6, h=128, w=192, n_obj=2, seed=9)
+    frames, m0 = frames.to(DEV), m0.to(DEV)
+
+    def run(use_graph):
+        model, _ = H.make_model_and_sd(cfg, wseed=4, device=DEV)
+        with torch.no_grad():
+            torch.manual_seed(11)
+            mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+            mv16 = model('encode_value', frames[:, 0], m0, s16)
+            model('init', mk16, mv16, m0)
+            preds = [evaluator.frame_step(model, frames[:, i], (128, 192)).clone() for i in (1, 2)]
+            g = evaluator.FrameGraph(model, frames[:, 1].shape, (128, 192)).capture(frames[:, 1]) if use_graph else None
+            for i in (3, 4, 5, 3, 4):
+                p = g.run(frames[:, i]) if use_graph else evaluator.frame_step(model, frames[:, i], (128, 192))
+                preds.append(p.clone())
+            bases = {k: v.clone() for k, v in model.swem_core.memories['update'].bases.items()}
+        torch.cuda.synchronize()
+        return preds, bases
+
+    pe, be = run(False)
+    pg, bg = run(True)
+    for a, b in zip(pe, pg):
+        assert torch.equal(a, b)
+    for k in be:
+        assert torch.equal(be[k], bg[k]), k
