@@ -8,7 +8,9 @@
 Workload (BASELINE.json configs[1]): synthetic structured 480x864 clip, ResNet-50 key encoder, ResNet-18 value
 encoder, K=256 bases, 5 EM iterations, 2 objects, output 480x854, random weights of the reference architecture.
 A "step" is one steady-state frame of the reference's per-sequence loop (swem_evaluator.py:72-97):
-encode_key -> match -> segment -> argmax/one-hot -> bilinear -> encode_value -> memorize.  Frames are resident in
+encode_key -> match -> segment -> argmax/one-hot -> bilinear -> encode_value -> memorize, for each of the --seqs
+independent sequences a GPU works on concurrently (default 2, one HIP stream + one HIP graph each: the second
+sequence fills the CUs the first leaves idle in small layers and kernel tails; --seqs 1 = strictly one at a time).  Frames are resident in
 HBM before the timed region (the reference also excludes the H2D copy, basic_evaluator.py:157-176).
 Every rank runs its own clip (sequences are independent: weak scaling, no data-path collective);
 value = frames of all ranks / max-over-ranks time.
@@ -107,6 +109,8 @@ def main():
     ap.add_argument('--objects', type=int, default=N_OBJ)
     ap.add_argument('--no-autotune', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay')
+    ap.add_argument('--seqs', type=int, default=2,
+                    help='independent sequences processed concurrently per GPU, each on its own HIP stream')
     ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
     args = ap.parse_args()
 
@@ -128,34 +132,57 @@ def main():
     from swem_amd.swem import SWEM
 
     cfg = O.make_cfg(**CFG)
-    model = SWEM(cfg)
-    sd = weights.fill_state_dict(model.state_dict(), seed=3, backbone='resnet50')
-    model.load_state_dict(sd)
-    model = model.eval().to(dev)
     n_obj = args.objects
-    frames_cpu, m0_cpu = synth.make_clip(t=8, h=H, w=W, n_obj=n_obj, out_hw=OUT_HW, seed=123 + rank)
-    frames, m0 = frames_cpu.to(dev), m0_cpu.to(dev)
-    torch.manual_seed(1234 + rank)
+    nseq = max(1, args.seqs)
     ops.AUTOTUNE = not args.no_autotune     # per-layer tiling / K-split chosen by timing, during warm-up only
-    runner = FrameRunner(model, frames, m0)
-    for _ in range(max(args.warmup, 2)):
-        runner.step()
-    ops.AUTOTUNE = False
-    if not args.no_graph:
-        runner.enable_graph()
-        runner.step()
+    runners, streams = [], []
+    sd = None
+    for si in range(nseq):
+        model = SWEM(cfg)
+        if sd is None:
+            sd = weights.fill_state_dict(model.state_dict(), seed=3, backbone='resnet50')
+        model.load_state_dict(sd)
+        model = model.eval().to(dev)
+        frames_cpu, m0_cpu = synth.make_clip(t=8, h=H, w=W, n_obj=n_obj, out_hw=OUT_HW, seed=123 + rank * 16 + si)
+        frames, m0 = frames_cpu.to(dev), m0_cpu.to(dev)
+        st = torch.cuda.Stream() if nseq > 1 else torch.cuda.current_stream()
+        if si == 0:
+            frames0_cpu, m0_0_cpu = frames_cpu, m0_cpu
+        with torch.cuda.stream(st):
+            torch.manual_seed(1234 + rank * 16 + si)
+            runner = FrameRunner(model, frames, m0)
+            for _ in range(max(args.warmup, 2)):
+                runner.step()
+            if si > 0 and runners:          # reuse the plans tuned on the first sequence
+                pass
+            ops.AUTOTUNE = False
+            if not args.no_graph:
+                runner.enable_graph()
+                runner.step()
+        torch.cuda.synchronize()
+        runners.append(runner)
+        streams.append(st)
+    runner = runners[0]
+    frames_cpu, m0_cpu = frames0_cpu, m0_0_cpu
 
-    ops.AUTOTUNE = False
+    def step_all():
+        if nseq == 1:
+            runners[0].step()
+            return
+        for rn, st in zip(runners, streams):
+            with torch.cuda.stream(st):
+                rn.step()
+
     # ---------------- timed region: exactly K steps between barrier + synchronize
     sdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        runner.step()
+        step_all()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     sdist.barrier()
-    total_frames, max_t = sdist.reduce_counters(args.steps, elapsed, device=dev)
+    total_frames, max_t = sdist.reduce_counters(args.steps * nseq, elapsed, device=dev)
 
     out = None
     if rank == 0:
@@ -163,11 +190,12 @@ def main():
         out = {
             'metric': 'frames/sec (480p, K=256 bases, multi-object SWEM inference)', 'value': round(fps, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * max_t / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(1e3 * max_t / args.steps, 3), 'ms_per_frame': round(1e3 * max_t / total_frames * world, 3),
+            'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'DAVIS17-val-shaped synthetic 480x864 clip (out 480x854), ResNet-50 key encoder, '
-                                   'K=256, 5 EM iters, %d objects, memorise every frame, 1 sequence per GPU' % n_obj,
-                       'objects': n_obj, 'frames_per_step': 1, 'parallelism': 'seq-sharded x%d (no collective)' % world,
+                                   'K=256, 5 EM iters, %d objects, memorise every frame, %d sequence(s) per GPU' % (n_obj, nseq),
+                       'objects': n_obj, 'frames_per_step': nseq, 'sequences_per_gpu': nseq, 'parallelism': 'seq-sharded x%d (no collective)' % world,
                        'weights': 'random init of the reference architecture (seeded)',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay of the steady-state frame'},
             'fps_per_gpu': round(fps / world, 3),

@@ -19,6 +19,7 @@ CONV_TRACE = None
 # keeps the fastest (passed to the library as the `plan` hint).  Off by default: results never depend on it beyond
 # fp32 summation order, but tuning costs a few milliseconds per layer shape.
 AUTOTUNE = False
+_CONV_PLANS = {}      # layer signature + input shape -> plan hint (shared by every model instance in the process)
 _TUNE_TILES = ((2, 2), (1, 2), (1, 1))
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
 
@@ -39,8 +40,10 @@ def _chk(t, name='tensor'):
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer per device (the library never allocates)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only scratch buffer per (device, stream): the library never allocates, and sequences that run
+    concurrently on different streams must not share scratch."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -56,7 +59,6 @@ class ConvPack:
         self.cout, self.kh, self.kw, self.stride, self.pad, self.glu = cout, kh, kw, stride, pad, glu
         self.cin = w.shape[-1]
         self.cin_true = self.cin          # channels of the reference conv (without layout padding)
-        self.plans = {}                   # (B, H, W) -> plan hint chosen by the autotuner
 
 
 def pack_conv(weight, bias=None, bn=None, stride=1, pad=None, cin_pad=None, eps=1e-5):
@@ -140,9 +142,10 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
                   _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw, pack.stride,
                   pack.pad, flags, plan, _ptr(ws), wsb)
 
-    plan = pack.plans.get((B, H, W), 0)
+    sig = (cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags, B, H, W)
+    plan = _CONV_PLANS.get(sig, 0)
     if AUTOTUNE and plan == 0 and not torch.cuda.is_current_stream_capturing():
-        plan = pack.plans[(B, H, W)] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
+        plan = _CONV_PLANS[sig] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
                                                  -(-pack.kh * pack.kw * cin // 32), pack.glu)
     if CONV_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
