@@ -115,13 +115,14 @@ def main():
     args = ap.parse_args()
 
     from swem_amd import dist as sdist
-    rank, local_rank, world = sdist.init()
+    rank, local_rank, world = sdist.env_world()
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: swem_amd has no CPU path')
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)        # before the RCCL communicator is created
     dev = torch.device('cuda', local_rank)
+    sdist.init()
 
     import __graft_entry__
     if rank == 0:
@@ -226,14 +227,23 @@ def main():
                       file=sys.stderr)
         flops = sum(f for _, _, f, _ in tr)
         ach = flops / (ms * 1e-3) / 1e12
+        traffic, tnote = None, ''
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_conv_traffic.json')) as f:
+                tj = json.load(f)
+            traffic = tj['hbm_bytes_per_launch']
+            tnote = ('; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from the separate rocprofv3 --pmc passes in '
+                     'profiles/r01_conv_traffic.json (not re-measured in this run)')
+        except (OSError, KeyError, ValueError):
+            pass
         out['roofline'] = {
             'bound': 'mfma', 'kernel': 'conv_igemm_kernel (+ split-K epilogue)', 'achieved': round(ach, 2),
             'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
-            'traffic': None, 'launches_per_frame': len(tr) // nprof,
+            'traffic': traffic, 'launches_per_frame': len(tr) // nprof,
             'avg_launch_us': round(1e3 * ms / len(tr), 2), 'gflop_per_launch': round(flops / len(tr) / 1e9, 3),
             'conv_ms_per_frame': round(ms / nprof, 3),
             'note': 'useful conv FLOPs (2*M*Cout*KH*KW*Cin, unpadded) of %d frames / summed per-launch HIP-event '
-                    'durations; peak = fp32 matrix (v_mfma_f32_32x32x2_f32)' % nprof}
+                    'durations; peak = fp32 matrix (v_mfma_f32_32x32x2_f32)' % nprof + tnote}
         # EM / matching share (whole memorize + match calls, algorithmic FLOPs of SURVEY 8d)
         from swem_amd import modules as M
         ev = []

@@ -50,6 +50,18 @@ __device__ __forceinline__ float relu1(float x) {
   asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
   return y;
 }
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so the
+// linear id is remapped to give every XCD one contiguous range of tiles, with the N tiles of one M tile adjacent:
+// the tiles that share activation rows (same M tile, neighbouring M tiles' 3x3 halo) then hit the same L2.
+// Placement only changes speed, never results.
+__device__ __forceinline__ void tile_coords(int &mt, int &nt) {
+  const int nwg = gridDim.x * gridDim.y, id = blockIdx.x + blockIdx.y * gridDim.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, local = id >> 3;
+  const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  mt = nid / (int)gridDim.y;
+  nt = nid - mt * (int)gridDim.y;
+}
+
 __device__ __forceinline__ float4 relu4(float4 v) { return make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)); }
 
 // zero a loaded vector with a bit mask: the value is used unconditionally, so the load itself stays unconditional
@@ -141,7 +153,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int tm, tn;
+  tile_coords(tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- per-thread gather coordinates (fixed over the K loop) ----
   const int kq = tid & 7, rbase = tid >> 3;
@@ -348,7 +362,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvP p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int tm, tn;
+  tile_coords(tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
   const int kq = tid & 7, rbase = tid >> 3;
 
   // buffer descriptors (wave-uniform: built from kernel arguments and block-uniform scalars only)

@@ -35,7 +35,10 @@ def shard(items, rank, world):
 
 def barrier():
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == 'nccl':
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def reduce_counters(frames, seconds, device='cpu'):
