@@ -139,7 +139,7 @@ int swem_transpose_f32(void *stream, const float *in, float *out, int batch, int
 
 /* ------------------------------------------------------------------------------------
  * Sequential weighted EM (methods/SWEM/modules.py).  NK = 2*N (object-major, class minor).
- * Pp = P rounded up to a multiple of 8 (swem_em_pad(P)).
+ * Pp = P rounded up to a multiple of 32 (swem_em_pad(P)).
  *   x     [P][C]      raw key of the frame, one row per pixel (reference x_t)
  *   xT    [C][Pp]     the same transposed (reference x), pad columns 0
  *   kn    [NK][L][C]  l2-normalised bases, one row per base (modules.py:115)

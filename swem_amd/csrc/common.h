@@ -63,6 +63,14 @@ __device__ __forceinline__ f32x16 mfma32x4(float4 a, float4 b, f32x16 c) {
 }
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// exp(x * inv_tau) for the softmax kernels as ONE transcendental: v_exp_f32 on x * (log2(e)/tau).
+// The reference computes exp((a - m) / tau); the two differ by ~2 ulp (2e-7 relative), far inside the 1e-4 per-step
+// tolerance, and the ~30-instruction libm expf would dominate the EM / matching epilogues (64-128 values per lane).
+__device__ __forceinline__ float exp_scaled(float x, float log2e_over_tau) {
+  return __builtin_amdgcn_exp2f(x * log2e_over_tau);
+}
+#define SWEM_LOG2E 1.4426950408889634f
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,23 +1,24 @@
 // Sequential weighted EM (reference methods/SWEM/modules.py:93-168) on the gfx950 fp32 matrix cores.
 //
-// Data layout (device, fp32; NK = 2*N, class minor; Pp = P rounded up to 8):
+// Data layout (device, fp32; NK = 2*N, class minor; Pp = P rounded up to 32):
 //   x  [P][C]       raw key, one row per pixel          (reference x_t)
 //   xT [C][Pp]      transposed copy, zero padded        (reference x)
 //   kn [NK][L][C]   l2-normalised bases, row per base   (l2norm(kappa, dim=-2), modules.py:115)
-//   zT [NK][L][Pp]  responsibilities, row per base, pad columns zero
+//   zT [NK][L][Pp]  responsibilities, row per base, pad columns zero  (Pp = P rounded up to 32)
 // With the K dimension contiguous in every operand, each lane loads 16 bytes and feeds four
 // v_mfma_f32_32x32x2_f32 steps (common.h: mfma32x4).
 //
-// Kernels per EM iteration (5 small launches):
+// Kernels per EM iteration (4 small launches):
 //   em_ew      : one GEMM  s = x_t . kn  per 32-pixel tile serves BOTH the W step of the previous iteration
 //                (cosine = s / (|x|+eps), joint {bg,fg} max, exp-sums, weights = mask * (1 - p)) and the E step
 //                (row softmax of s/tau, times weights).  The pixel sits on the MFMA lane, the base index in the
 //                accumulator registers, so the row reductions are in-register + one cross-half shuffle + one LDS
 //                exchange between the 4 waves (2 classes x 2 halves of L).
-//   em_mgemm   : split-P partial products  xT . z  (or vT . z for the value update) into a slab workspace.
+//   M GEMM     : xT . z (or vT . z for the value update) for both classes of an object side by side, run by the
+//                implicit-GEMM conv kernel as a batched 1x1 "conv" (LDS-staged, split over P, deterministic).
 //   em_zsum    : zita = zita_ + sum_p z (one wave per base row).
-//   em_finalize: fixed-order slab reduction (deterministic) and the prior blend (zita_*kappa_ + S)/zita;
-//                em_norm_bases then produces the next iteration's normalised transposed bases.
+//   em_finalize: fixed-order slab reduction (deterministic) and the prior blend (zita_*kappa_ + S)/zita; the key-base
+//                variant also emits the next iteration's normalised transposed bases (block-local column norms).
 #include "common.h"
 
 namespace {
@@ -94,27 +95,36 @@ __global__ __launch_bounds__(256) void em_ew_kernel(const float *__restrict__ x,
   const int lbase = lh * 32 * LT;
   const float *krow = kn + ((long long)nk * L + lbase + r) * C + 4 * h;
   const float *xrow = xs + r * XS + 4 * h;
-  for (int j = 0; j < C / 8; ++j) {
-    float4 b4 = *reinterpret_cast<const float4 *>(xrow + 8 * j);
+  {
+    // base rows of step j+1 are requested before the MFMAs of step j (one wave per SIMD: nothing else hides the latency)
+    float4 a4[LT], an[LT];
 #pragma unroll
-    for (int t = 0; t < LT; ++t) {
-      float4 a4 = ld4(krow + (long long)t * 32 * C + 8 * j);
-      acc[t] = mfma32x4(a4, b4, acc[t]);
+    for (int t = 0; t < LT; ++t) a4[t] = ld4(krow + (long long)t * 32 * C);
+    for (int j = 0; j < C / 8; ++j) {
+      const int jn = j + 1 < C / 8 ? j + 1 : j;
+#pragma unroll
+      for (int t = 0; t < LT; ++t) an[t] = ld4(krow + (long long)t * 32 * C + 8 * jn);
+      float4 b4 = *reinterpret_cast<const float4 *>(xrow + 8 * j);
+#pragma unroll
+      for (int t = 0; t < LT; ++t) acc[t] = mfma32x4(a4[t], b4, acc[t]);
+#pragma unroll
+      for (int t = 0; t < LT; ++t) a4[t] = an[t];
     }
   }
   __syncthreads();  // xn visible
 
   const int p = p0 + r;
   const bool pin = p < P;
+  const float k2 = SWEM_LOG2E / tau;
   float wgt;
   if (do_w) {
     // W step (modules.py:98-108): cosine, joint max over L and {bg,fg}, exp sums, 1 - p literally
-    const float den = xn[r];
+    const float rden = 1.0f / xn[r];  // cosine = s / (|x| + eps): one reciprocal per pixel instead of a division per base
     float m = -__builtin_huge_valf();
 #pragma unroll
     for (int t = 0; t < LT; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) m = fmaxf(m, acc[t][e] / den);
+      for (int e = 0; e < 16; ++e) m = fmaxf(m, acc[t][e] * rden);
     m = fmaxf(m, __shfl_xor(m, 32));
     if (h == 0) red[wave * 32 + r] = m;
     __syncthreads();
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(256) void em_ew_kernel(const float *__restrict__ x,
 #pragma unroll
     for (int t = 0; t < LT; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) se += expf((acc[t][e] / den - m) / tau);
+      for (int e = 0; e < 16; ++e) se += exp_scaled(acc[t][e] * rden - m, k2);
     se += __shfl_xor(se, 32);
     if (h == 0) red[128 + wave * 32 + r] = se;
     __syncthreads();
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(256) void em_ew_kernel(const float *__restrict__ x,
   for (int t = 0; t < LT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      float v = expf((acc[t][e] - m) / tau);
+      float v = exp_scaled(acc[t][e] - m, k2);
       acc[t][e] = v;
       se += v;
     }
@@ -160,6 +170,7 @@ __global__ __launch_bounds__(256) void em_ew_kernel(const float *__restrict__ x,
   if (h == 0) red[256 + wave * 32 + r] = se;
   __syncthreads();
   se = red[256 + cls * 64 + r] + red[256 + cls * 64 + 32 + r];
+  const float zscale = wgt / se;  // softmax normalisation and the pixel weight in one factor
   if (p < Pp) {
     float *dst = zT + ((long long)nk * L + lbase) * Pp + p;
 #pragma unroll
@@ -167,46 +178,9 @@ __global__ __launch_bounds__(256) void em_ew_kernel(const float *__restrict__ x,
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         int l = 32 * t + acc_row(e, h);
-        dst[(long long)l * Pp] = pin ? (acc[t][e] / se) * wgt : 0.f;
+        dst[(long long)l * Pp] = pin ? acc[t][e] * zscale : 0.f;
       }
   }
-}
-
-// partial[sp][nk][row][l] = sum_{p in split sp} A[row][p] * zT[nk][l][p]
-template <int NT>
-__global__ __launch_bounds__(256) void em_mgemm_kernel(const float *__restrict__ A, long long a_bs, int a_div,
-                                                       const float *__restrict__ zT, float *__restrict__ part, int R,
-                                                       int Pp, int L, int kchunk, int nsplit, int NK) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int nk = blockIdx.z / nsplit, sp = blockIdx.z - nk * nsplit;
-  const int k0 = sp * kchunk, k1 = min(Pp, k0 + kchunk);
-  const int row = blockIdx.x * 128 + wave * 32 + r;
-  const int col0 = blockIdx.y * 32 * NT;
-  const bool rok = row < R;
-  const float *Arow = A + (a_div ? (long long)(nk / a_div) * a_bs : 0) + (long long)(rok ? row : 0) * Pp + 4 * h;
-  const float *Brow = zT + ((long long)nk * L + col0 + r) * Pp + 4 * h;
-  f32x16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-  for (int k = k0; k < k1; k += 8) {
-    float4 a4 = rok ? ld4(Arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float4 b4 = ld4(Brow + (long long)t * 32 * Pp + k);
-      acc[t] = mfma32x4(a4, b4, acc[t]);
-    }
-  }
-  float *dst = part + (((long long)sp * NK + nk) * R) * L;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      int rr = blockIdx.x * 128 + wave * 32 + acc_row(e, h);
-      if (rr < R) dst[(long long)rr * L + col0 + 32 * t + r] = acc[t][e];
-    }
 }
 
 // zita[nk][l] = zita_prev[nk][l] + sum_p zT[nk][l][p]: one wave per base row, 16-byte coalesced reads, fixed order
@@ -230,50 +204,91 @@ __global__ __launch_bounds__(256) void em_zsum_kernel(const float *__restrict__ 
   }
 }
 
-// out[nk][row][l] = (zita_prev[l] * prev[row][l] + sum_sp part[sp][nk][row][l]) / zita[l]
-// Block: 32 bases x 32 rows; slabs are summed in split order (deterministic).
-__global__ __launch_bounds__(256) void em_finalize_kernel(const float *__restrict__ part, int nsplit,
-                                                          const float *__restrict__ prev,
+// out[nk][row][l] = (zita_prev[l] * prev[row][l] + S[n][row][cls*L + l]) / zita[l],  nk = 2n + cls
+// (S = A . z for both classes of an object, produced by the GEMM with the classes side by side).  Block: 32 bases x 32 rows.
+__global__ __launch_bounds__(256) void em_finalize_kernel(const float *__restrict__ S, const float *__restrict__ prev,
                                                           const float *__restrict__ zita_prev,
                                                           const float *__restrict__ zt, float *__restrict__ out, int NK,
                                                           int R, int L) {
   const int nk = blockIdx.y, l = blockIdx.x * 32 + (threadIdx.x & 31);
   const int row0 = blockIdx.z * 32 + (threadIdx.x >> 5);
   const float zp = zita_prev[(long long)nk * L + l], z = zt[(long long)nk * L + l];
-  const long long slab = (long long)NK * R * L;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = row0 + 8 * i;
     if (row >= R) break;
     const long long o = ((long long)nk * R + row) * L + l;
-    float s = part[o];
-    for (int sp = 1; sp < nsplit; ++sp) s += part[o + sp * slab];
+    const float s = S[((long long)(nk >> 1) * R + row) * (2 * L) + (nk & 1) * L + l];
     out[o] = (zp * prev[o] + s) / z;
   }
 }
 
-struct MPlan {
-  int nt, nsplit, kchunk;
+// Same blend for the key bases (R = C rows), fused with the l2-normalised transposed copy the next E/W step reads:
+// block = 32 bases x all C rows, so the column norms are block-local.
+__global__ __launch_bounds__(1024) void em_finalize_norm_kernel(const float *__restrict__ S,
+                                                                const float *__restrict__ prev,
+                                                                const float *__restrict__ zita_prev,
+                                                                const float *__restrict__ zt, float *__restrict__ out,
+                                                                float *__restrict__ kn_out, int NK, int R, int L) {
+  extern __shared__ float sm[];  // tile[R][33], red[32][32], nrm[32]
+  float *tile = sm, *red = sm + R * 33, *nrm = red + 1024;
+  const int nk = blockIdx.y, l0 = blockIdx.x * 32;
+  const int l = threadIdx.x & 31, g = threadIdx.x >> 5;  // 32 row groups: enough loads in flight to hide the slab reads
+  const float zp = zita_prev[(long long)nk * L + l0 + l], z = zt[(long long)nk * L + l0 + l];
+  for (int row = g; row < R; row += 32) {
+    const long long o = ((long long)nk * R + row) * L + l0 + l;
+    const float s = S[((long long)(nk >> 1) * R + row) * (2 * L) + (nk & 1) * L + l0 + l];
+    const float v = (zp * prev[o] + s) / z;
+    out[o] = v;
+    tile[row * 33 + l] = v;
+  }
+  __syncthreads();
+  if (g < 8) {  // column norms from the tile, in the association of em_norm_bases_kernel (bit-identical kn)
+    float ss = 0.f;
+    for (int c = g; c < R; c += 8) {
+      const float v = tile[c * 33 + l];
+      ss += v * v;
+    }
+    red[g * 32 + l] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += red[i * 32 + threadIdx.x];
+    nrm[threadIdx.x] = sqrtf(s) + SWEM_L2_EPS;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 32 * R; idx += 1024) {
+    int ll = idx / R, c = idx - ll * R;
+    kn_out[((long long)nk * L + l0 + ll) * R + c] = tile[c * 33 + ll] / nrm[ll];
+  }
+}
+
+struct MWs {
+  size_t S, conv, zt, total;
 };
-MPlan mstep_plan(int NK, int R, int Pp, int L) {
-  MPlan pl;
-  pl.nt = (L % 64 == 0) ? 2 : 1;
-  long long blocks = (long long)cdiv(R, 128) * (L / (32 * pl.nt)) * NK;
-  int ns = (int)((256 + blocks - 1) / blocks);
-  int maxs = Pp / 64;  // at least 64 pixels per split
-  if (ns > maxs) ns = maxs;
-  if (ns > 8) ns = 8;  // every slab is read back once: keep the partial-sum traffic a few MB
-  if (ns < 1) ns = 1;
-  pl.kchunk = (cdiv(Pp, ns) + 7) / 8 * 8;
-  pl.nsplit = cdiv(Pp, pl.kchunk);
-  return pl;
+// workspace of one M step: S [N][R][2L], the GEMM's split-K scratch, zita scratch
+MWs mstep_ws(int NK, int R, int P, int L) {
+  MWs w;
+  const int N = NK / 2, Pp = swem_em_pad(P);
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = align_up(o + bytes, 256);
+    return at;
+  };
+  w.S = take((size_t)N * R * 2 * L * sizeof(float));
+  w.conv = take(swem_conv2d_workspace(N, R, 1, Pp, 2 * L, 1, 1, 1, 0, 0, 0));
+  w.zt = take((size_t)NK * L * sizeof(float));
+  w.total = o;
+  return w;
 }
 
 }  // namespace
 
 #define ST static_cast<hipStream_t>(stream)
 
-extern "C" int swem_em_pad(int P) { return (P + 7) / 8 * 8; }
+extern "C" int swem_em_pad(int P) { return (P + 31) / 32 * 32; }
 
 // kn rows of bank `kappa` land at row out_off + l of an [NK][out_rows][C] image (matching concatenates banks)
 int swem_norm_bases_into(void *stream, const float *kappa, float *kn, int NK, int C, int L, int out_rows,
@@ -314,39 +329,38 @@ extern "C" int swem_em_ew_f32(void *stream, const float *x, const float *kn, con
   return SWEM_OK;
 }
 
-extern "C" size_t swem_em_mstep_workspace(int NK, int R, int P, int L) {
-  MPlan pl = mstep_plan(NK, R, swem_em_pad(P), L);
-  return align_up((size_t)pl.nsplit * NK * R * L * sizeof(float), 256) + align_up((size_t)NK * L * sizeof(float), 256);
-}
+extern "C" size_t swem_em_mstep_workspace(int NK, int R, int P, int L) { return mstep_ws(NK, R, P, L).total; }
 
 extern "C" int swem_em_mstep_f32(void *stream, const float *A, int a_batch_div, const float *zT, const float *prev,
                                  const float *zita_prev, float *out, float *zita_out, float *kn_out, int NK, int R,
                                  int P, int L, void *ws, size_t ws_bytes) {
   SWEM_REQUIRE(A && zT && prev && zita_prev && out, SWEM_E_ARG, "em_mstep: null pointer");
-  SWEM_REQUIRE(L % 32 == 0 && R % 32 == 0, SWEM_E_SHAPE, "em_mstep: L and R must be multiples of 32");
+  SWEM_REQUIRE(NK % 2 == 0 && L % 32 == 0 && R % 128 == 0, SWEM_E_SHAPE,
+               "em_mstep: need NK even, L %% 32 == 0 and R %% 128 == 0 (got %d, %d, %d)", NK, L, R);
+  SWEM_REQUIRE(a_batch_div == 0 || a_batch_div == 2, SWEM_E_ARG, "em_mstep: a_batch_div must be 0 (shared A) or 2");
   SWEM_REQUIRE(!kn_out || R <= 1024, SWEM_E_SHAPE, "em_mstep: kn_out needs R <= 1024");
-  const int Pp = swem_em_pad(P);
-  MPlan pl = mstep_plan(NK, R, Pp, L);
-  const size_t slab_bytes = align_up((size_t)pl.nsplit * NK * R * L * sizeof(float), 256);
-  const size_t need = slab_bytes + align_up((size_t)NK * L * sizeof(float), 256);
-  SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "em_mstep: workspace %zu < %zu", ws_bytes, need);
-  float *part = static_cast<float *>(ws);
-  float *zt = reinterpret_cast<float *>(static_cast<char *>(ws) + slab_bytes);
-  dim3 grid(cdiv(R, 128), L / (32 * pl.nt), NK * pl.nsplit);
-  const long long a_bs = (long long)R * Pp;
-  if (pl.nt == 2)
-    hipLaunchKernelGGL((em_mgemm_kernel<2>), grid, dim3(256), 0, ST, A, a_bs, a_batch_div, zT, part, R, Pp, L,
-                       pl.kchunk, pl.nsplit, NK);
-  else
-    hipLaunchKernelGGL((em_mgemm_kernel<1>), grid, dim3(256), 0, ST, A, a_bs, a_batch_div, zT, part, R, Pp, L,
-                       pl.kchunk, pl.nsplit, NK);
-  SWEM_CHECK_LAUNCH("em_mgemm");
+  const int Pp = swem_em_pad(P), N = NK / 2;
+  MWs w = mstep_ws(NK, R, P, L);
+  SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "em_mstep: workspace %zu < %zu", ws_bytes, w.total);
+  char *base = static_cast<char *>(ws);
+  float *S = reinterpret_cast<float *>(base + w.S), *zt = reinterpret_cast<float *>(base + w.zt);
+  // S[n] = A[n] . [z_bg | z_fg]^T : a batched GEMM on the conv kernel: an R x 1 "image" with Pp channels per object
+  // (A shared by all objects when a_batch_div == 0), 2L 1x1 filters per object = its two classes' rows of zT
+  int rc = swem_conv2d_nhwc_f32(stream, A, Pp, a_batch_div ? (long long)R * Pp : 0, nullptr, 0, 0, nullptr, 0, 0, N, R, 1,
+                                zT, (long long)2 * L * Pp, nullptr, nullptr, nullptr, 0, S, 2 * L, 1, 1, 1, 0, 0, 0,
+                                base + w.conv, w.zt - w.conv);
+  if (rc) return rc;
   hipLaunchKernelGGL(em_zsum_kernel, dim3(cdiv(NK * L, 4)), dim3(256), 0, ST, zT, zita_prev, zt, zita_out, NK * L, Pp);
   SWEM_CHECK_LAUNCH("em_zsum");
-  hipLaunchKernelGGL(em_finalize_kernel, dim3(L / 32, NK, cdiv(R, 32)), dim3(256), 0, ST, part, pl.nsplit, prev,
-                     zita_prev, zt, out, NK, R, L);
+  if (kn_out) {
+    size_t lds = ((size_t)R * 33 + 1024 + 32) * sizeof(float);
+    hipLaunchKernelGGL(em_finalize_norm_kernel, dim3(L / 32, NK), dim3(1024), lds, ST, S, prev, zita_prev, zt, out,
+                       kn_out, NK, R, L);
+  } else {
+    hipLaunchKernelGGL(em_finalize_kernel, dim3(L / 32, NK, cdiv(R, 32)), dim3(256), 0, ST, S, prev, zita_prev, zt, out,
+                       NK, R, L);
+  }
   SWEM_CHECK_LAUNCH("em_finalize");
-  if (kn_out) return swem_norm_bases_into(stream, out, kn_out, NK, R, L, L, 0);
   return SWEM_OK;
 }
 

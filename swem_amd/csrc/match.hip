@@ -126,11 +126,12 @@ __global__ __launch_bounds__(256) void match_affinity_kernel(const float *__rest
   __syncthreads();
   m = fmaxf(fmaxf(red[r], red[32 + r]), fmaxf(red[64 + r], red[96 + r]));
   float se = 0.f;
+  const float k2 = SWEM_LOG2E / tau;
 #pragma unroll
   for (int t = 0; t < J; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      float v = expf((acc[t][e] - m) / tau);
+      float v = exp_scaled(acc[t][e] - m, k2);
       acc[t][e] = v;
       se += v;
     }
