@@ -99,8 +99,9 @@ int swem_maxpool3x3s2_nhwc_f32(void *stream, const float *x, float *y, int B, in
 /* y = skip + bilinear(low -> Ho x Wo, align_corners=False): networks.py:193-194.  skip_bs 0 = shared skip */
 int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long long skip_bs, const float *low, float *y,
                                int B, int Hl, int Wl, int Ho, int Wo, int C);
-/* F.interpolate on NCHW planes; mode 0 = nearest (legacy), 1 = bilinear align_corners=False.
- * swem_evaluator.py:67,91 */
+/* F.interpolate / flip on NCHW planes; mode 0 = nearest (legacy), 1 = bilinear align_corners=False
+ * (swem_evaluator.py:67,91), 2 = bicubic align_corners=False (swem_evaluator.py:43, basic_evaluator.py:160),
+ * 3 = horizontal flip, same size (torch.flip(dims=[-1]), swem_evaluator.py:46-49) */
 int swem_resize_planes_f32(void *stream, const float *x, float *y, int planes, int Hi, int Wi, int Ho, int Wo,
                            int mode);
 /* swem.py:79-84: hard masks (int64 or float planes, channel 0 = background skipped) nearest ->
@@ -134,6 +135,13 @@ int swem_argmax_onehot_i64(void *stream, const float *prob /*[B][N1][HW]*/, long
  * encoder); everywhere else the conv reads the sources directly. */
 int swem_concat2_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
                           long long bs1, float *y, int B, long long P);
+/* y = alpha*a + beta*b (b may be NULL): test-time-augmentation score averaging, swem_evaluator.py:49-53 */
+int swem_lincomb_f32(void *stream, const float *a, float alpha, const float *b, float beta, float *y, long long n);
+/* swem_evaluator.py:124-130 (YouTube-VOS: objects annotated from a later frame on): prob [B][N1][HW] scores,
+ * new_masks [B][Nn1][HW] (channel 0 unused) -> out [B][N1+Nn1-1][HW]: scores zeroed where a new object is
+ * annotated, new objects' masks appended as extra channels */
+int swem_inject_objects_f32(void *stream, const float *prob, const float *new_masks, float *out, int B, int N1,
+                            int Nn1, long long HW);
 /* batched 2-D transpose: in [batch][R][Cc] -> out [batch][Cc][ld] (ld >= R, pad columns zeroed) */
 int swem_transpose_f32(void *stream, const float *in, float *out, int batch, int R, int Cc, int ld);
 

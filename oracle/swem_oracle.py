@@ -391,6 +391,49 @@ def evaluate_seq(model, frames, init_masks, out_size, trace=None):
     return preds, scores
 
 
+def evaluate_ytvos_seq(model, frames, init_masks, out_size):
+    """swem_evaluator.py:104-148 (new objects injected from init_masks[i], i > 0)."""
+    b, t, _, h, w = frames.shape
+    preds = []
+    mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+    m0 = F.interpolate(init_masks[0], size=(h, w), mode='nearest')
+    mv16 = model('encode_value', frames[:, 0], m0.float(), s16)
+    model('init', mk16, mv16, init_masks[0])
+    for i in range(1, t):
+        qk16, qv16, s16, s8, s4 = model('encode_key', frames[:, i])
+        context, n = model('match', qk16, qv16)
+        logits, pred_mask = model('segment', n, context, s8, s4, None, out_size)
+        if init_masks[i] is not None:
+            new_objects = init_masks[i][:, 1:].sum(dim=1, keepdim=True).expand_as(pred_mask)
+            pred_mask[new_objects > 0] = 0
+            pred_mask = torch.cat([pred_mask, init_masks[i][:, 1:]], dim=1)
+            n = pred_mask.shape[1] - 1
+        pred = torch.argmax(pred_mask, dim=1, keepdim=True)
+        hard = (pred.expand(-1, n + 1, -1, -1) == torch.arange(n + 1).view(1, -1, 1, 1)).type_as(pred)
+        if i < t - 1:
+            pm = F.interpolate(pred_mask, size=(h, w), mode='bilinear', align_corners=False)
+            mv16 = model('encode_value', frames[:, i], pm, s16)
+            model('memorize', qk16, mv16, hard, pm)
+        preds.append(pred[:, 0])
+    return preds
+
+
+def evaluate_seq_ms(model, frames, init_masks, out_size, scales=(480,), is_flip=False):
+    """swem_evaluator.py:34-57 (multi-scale / flip averaging of the probability maps)."""
+    final = [0 for _ in range(frames.shape[1] - 1)]
+    for scale in scales:
+        h, w = scale, int((scale / 480) * 864)
+        fr = F.interpolate(frames[0], size=(h, w), mode='bicubic', align_corners=False).unsqueeze(0)
+        _, scores = evaluate_seq(model, fr, init_masks, out_size)
+        if is_flip:
+            ff = torch.flip(fr, dims=[-1])
+            fm = [torch.flip(m, dims=[-1]) for m in init_masks if m is not None]
+            _, fs = evaluate_seq(model, ff, fm + [None] * (frames.shape[1] - len(fm)), out_size)
+            scores = [(a + torch.flip(b, dims=[-1])) / 2 for a, b in zip(scores, fs)]
+        final = [f + s_ / len(scales) for f, s_ in zip(final, scores)]
+    return [torch.argmax(f, dim=1) for f in final]
+
+
 def make_cfg(**kw):
     base = dict(KEYDIM=128, VALDIM=512, NUM_BASES=256, NUM_EM_ITERS=4, EM_TAU=0.05, TOPL=64,
                 SINGLE_OBJ=False, BACKBONE='resnet50')

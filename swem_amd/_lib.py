@@ -32,6 +32,8 @@ SIGNATURES = {
     'swem_decode_head_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_argmax_onehot_i64': (_i, [_p, _p, _p, _p, _i, _i, _ll]),
     'swem_concat2_nhwc_f32': (_i, [_p, _p, _i, _ll, _p, _i, _ll, _p, _i, _ll]),
+    'swem_lincomb_f32': (_i, [_p, _p, _f, _p, _f, _p, _ll]),
+    'swem_inject_objects_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _ll]),
     'swem_transpose_f32': (_i, [_p, _p, _p, _i, _i, _i, _i]),
     'swem_em_pad': (_i, [_i]),
     'swem_em_norm_bases_f32': (_i, [_p, _p, _p, _i, _i, _i]),

@@ -138,6 +138,72 @@ __global__ void resize_planes_kernel(const float *__restrict__ x, float *__restr
   }
 }
 
+// ATen upsample_bicubic2d (align_corners=False, A = -0.75): unclamped source coordinate, 4x4 taps clamped to the image
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__global__ void resize_bicubic_kernel(const float *__restrict__ x, float *__restrict__ y, int planes, int Hi, int Wi,
+                                      int Ho, int Wo) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)planes * Ho * Wo) return;
+  int ox = (int)(i % Wo);
+  long long t = i / Wo;
+  int oy = (int)(t % Ho);
+  long long pl = t / Ho;
+  const float *src = x + pl * Hi * Wi;
+  const float A = -0.75f;
+  const float sy = (float)Hi / (float)Ho * (oy + 0.5f) - 0.5f, sx = (float)Wi / (float)Wo * (ox + 0.5f) - 0.5f;
+  const float fy = floorf(sy), fx = floorf(sx);
+  const int iy = (int)fy, ix = (int)fx;
+  const float ty = sy - fy, tx = sx - fx;
+  const float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+  const float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int yy = min(max(iy - 1 + a, 0), Hi - 1);
+    float row = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int xx = min(max(ix - 1 + b, 0), Wi - 1);
+      row += wx[b] * src[(long long)yy * Wi + xx];
+    }
+    acc += wy[a] * row;
+  }
+  y[i] = acc;
+}
+// horizontal flip of planes (torch.flip(dims=[-1]), swem_evaluator.py:46-49)
+__global__ void flip_w_kernel(const float *__restrict__ x, float *__restrict__ y, long long rows, int W) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * W) return;
+  long long r = i / W;
+  int c = (int)(i - r * W);
+  y[i] = x[r * W + (W - 1 - c)];
+}
+// y = alpha * a + beta * b   (b may be NULL: y = alpha * a); TTA score averaging, swem_evaluator.py:49-53
+__global__ void lincomb_kernel(const float *__restrict__ a, float alpha, const float *__restrict__ b, float beta,
+                               float *__restrict__ y, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  y[i] = b ? alpha * a[i] + beta * b[i] : alpha * a[i];
+}
+// swem_evaluator.py:124-130: objects that first appear at this frame: zero the predicted scores where a new object is
+// annotated, then append the new objects' masks as extra channels
+__global__ void inject_objects_kernel(const float *__restrict__ prob, const float *__restrict__ newm,
+                                      float *__restrict__ out, int B, int N1, int Nn1, long long HW) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * HW) return;
+  int b = (int)(i / HW);
+  long long pix = i - b * HW;
+  const float *nm = newm + (long long)b * Nn1 * HW + pix;
+  float cover = 0.f;
+  for (int n = 1; n < Nn1; ++n) cover += nm[(long long)n * HW];
+  const int Nout = N1 + Nn1 - 1;
+  float *o = out + (long long)b * Nout * HW + pix;
+  const float *pp = prob + (long long)b * N1 * HW + pix;
+  for (int n = 0; n < N1; ++n) o[(long long)n * HW] = cover > 0.f ? 0.f : pp[(long long)n * HW];
+  for (int n = 1; n < Nn1; ++n) o[(long long)(N1 + n - 1) * HW] = nm[(long long)n * HW];
+}
+
 template <typename HT>
 __global__ void mask_prep_kernel(const HT *__restrict__ hard, int Hh, int Wh, const float *__restrict__ soft, int Hs,
                                  int Ws, float *__restrict__ out, int B, int N, int h, int w) {
@@ -456,9 +522,17 @@ extern "C" int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long 
 
 extern "C" int swem_resize_planes_f32(void *stream, const float *x, float *y, int planes, int Hi, int Wi, int Ho,
                                       int Wo, int mode) {
-  SWEM_REQUIRE(x && y && (mode == 0 || mode == 1), SWEM_E_ARG, "resize_planes: bad argument");
-  hipLaunchKernelGGL(resize_planes_kernel, grid1((long long)planes * Ho * Wo), dim3(256), 0, ST, x, y, planes, Hi, Wi,
-                     Ho, Wo, mode);
+  SWEM_REQUIRE(x && y && mode >= 0 && mode <= 3, SWEM_E_ARG, "resize_planes: bad argument");
+  if (mode == 2)
+    hipLaunchKernelGGL(resize_bicubic_kernel, grid1((long long)planes * Ho * Wo), dim3(256), 0, ST, x, y, planes, Hi, Wi,
+                       Ho, Wo);
+  else if (mode == 3) {
+    SWEM_REQUIRE(Hi == Ho && Wi == Wo, SWEM_E_SHAPE, "resize_planes: flip keeps the size");
+    hipLaunchKernelGGL(flip_w_kernel, grid1((long long)planes * Ho * Wo), dim3(256), 0, ST, x, y,
+                       (long long)planes * Ho, Wo);
+  } else
+    hipLaunchKernelGGL(resize_planes_kernel, grid1((long long)planes * Ho * Wo), dim3(256), 0, ST, x, y, planes, Hi, Wi,
+                       Ho, Wo, mode);
   SWEM_CHECK_LAUNCH("resize_planes");
   return SWEM_OK;
 }
@@ -541,6 +615,23 @@ extern "C" int swem_concat2_nhwc_f32(void *stream, const float *x0, int c0, long
   hipLaunchKernelGGL(concat2_kernel, grid1((long long)B * P * ((c0 + c1) / 4)), dim3(256), 0, ST, x0, c0, bs0, x1, c1,
                      bs1, y, B, P);
   SWEM_CHECK_LAUNCH("concat2");
+  return SWEM_OK;
+}
+
+extern "C" int swem_lincomb_f32(void *stream, const float *a, float alpha, const float *b, float beta, float *y,
+                                long long n) {
+  SWEM_REQUIRE(a && y && n >= 0, SWEM_E_ARG, "lincomb: bad argument");
+  hipLaunchKernelGGL(lincomb_kernel, grid1(n), dim3(256), 0, ST, a, alpha, b, beta, y, n);
+  SWEM_CHECK_LAUNCH("lincomb");
+  return SWEM_OK;
+}
+
+extern "C" int swem_inject_objects_f32(void *stream, const float *prob, const float *new_masks, float *out, int B,
+                                       int N1, int Nn1, long long HW) {
+  SWEM_REQUIRE(prob && new_masks && out && N1 >= 1 && Nn1 >= 2, SWEM_E_ARG, "inject_objects: bad argument");
+  hipLaunchKernelGGL(inject_objects_kernel, grid1((long long)B * HW), dim3(256), 0, ST, prob, new_masks, out, B, N1, Nn1,
+                     HW);
+  SWEM_CHECK_LAUNCH("inject_objects");
   return SWEM_OK;
 }
 

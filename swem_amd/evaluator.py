@@ -60,6 +60,54 @@ def evaluate_davis_seq(model, frames, init_masks, out_size, trace=None):
     return preds, pred_scores
 
 
+def evaluate_ytvos_seq(model, frames, init_masks, out_size):
+    """swem_evaluator.py:104-148: like the DAVIS loop, but objects may be annotated from a later frame on:
+    ``init_masks[i]`` (1,N'+1,Ho,Wo) then zeroes the predicted scores where a new object sits and appends the new
+    masks as extra channels; the memory grows by random-initialised bases for the new ids (modules.py:140-146)."""
+    preds = []
+    b, t, c, h, w = frames.shape
+    out_size = (int(out_size[0]), int(out_size[1]))
+    mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+    init_mask = ops.resize_planes(init_masks[0].float().contiguous(), (h, w), 'nearest')
+    mv16 = model('encode_value', frames[:, 0], init_mask, s16)
+    model('init', mk16, mv16, init_masks[0])
+    for i in range(1, t):
+        qk16, qv16, s16, s8, s4 = model('encode_key', frames[:, i])
+        context, n = model('match', qk16, qv16)
+        logits, pred_mask = model('segment', n, context, s8, s4, None, out_size)
+        if init_masks[i] is not None:
+            pred_mask = ops.inject_objects(pred_mask, init_masks[i])
+            n = pred_mask.shape[1] - 1
+        pred, hard_pred_mask = ops.argmax_onehot(pred_mask, want_onehot=i < t - 1)
+        if i < t - 1:
+            pm = ops.resize_planes(pred_mask, (h, w), 'bilinear')
+            mv16 = model('encode_value', frames[:, i], pm, s16)
+            model('memorize', qk16, mv16, hard_pred_mask, pm)
+        preds.append(pred)
+    return preds
+
+
+def evaluate_davis_seq_ms(model, frames, init_masks, out_size, scales=(480,), is_flip=False):
+    """swem_evaluator.py:34-57: multi-scale / flip test-time augmentation: the probability maps of every pass are
+    averaged, the index map is their argmax.  frames (1,T,C,H,W)."""
+    assert len(scales) > 0
+    final = None
+    masks = [m for m in init_masks if m is not None]
+    for scale in scales:
+        h, w = scale, int((scale / 480) * 864)
+        in_frames = ops.resize_planes(frames[0].contiguous(), (h, w), 'bicubic').unsqueeze(0)
+        _, scores = evaluate_davis_seq(model, in_frames, init_masks, out_size)
+        if is_flip:
+            flipped = ops.flip_w(in_frames)
+            fmasks = [ops.flip_w(m.float().contiguous()) for m in masks]
+            _, fscores = evaluate_davis_seq(model, flipped, fmasks + [None] * (frames.shape[1] - len(fmasks)), out_size)
+            scores = [ops.lincomb(a, 0.5, ops.flip_w(bf), 0.5) for a, bf in zip(scores, fscores)]
+        k = 1.0 / len(scales)
+        final = [ops.lincomb(sc, k) for sc in scores] if final is None else \
+            [ops.lincomb(f, 1.0, sc, k) for f, sc in zip(final, scores)]
+    return [ops.argmax_onehot(f, want_onehot=False)[0] for f in final]
+
+
 def frame_step(model, frame, out_size, memorize=True):
     """One steady-state frame (swem_evaluator.py:72-97) for a (1,3,H,W) device tensor; returns the index map."""
     h, w = frame.shape[-2:]

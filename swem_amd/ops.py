@@ -233,14 +233,40 @@ def upsample_add(skip, low, batch=None):
 
 
 def resize_planes(x, size, mode):
-    """F.interpolate on the last two dims; mode 'nearest' or 'bilinear' (align_corners=False)."""
+    """F.interpolate on the last two dims; mode 'nearest', 'bilinear' or 'bicubic' (align_corners=False), or 'flip'
+    (horizontal flip, size unchanged)."""
     _chk(x)
     Hi, Wi = x.shape[-2:]
     planes = x.numel() // (Hi * Wi)
     y = torch.empty(tuple(x.shape[:-2]) + tuple(size), dtype=torch.float32, device=x.device)
     _lib.call('swem_resize_planes_f32', _stream(), x.data_ptr(), y.data_ptr(), planes, Hi, Wi, size[0], size[1],
-              {'nearest': 0, 'bilinear': 1}[mode])
+              {'nearest': 0, 'bilinear': 1, 'bicubic': 2, 'flip': 3}[mode])
     return y
+
+
+def flip_w(x):
+    return resize_planes(x, tuple(x.shape[-2:]), 'flip')
+
+
+def lincomb(a, alpha, b=None, beta=0.0):
+    """alpha*a + beta*b on the device (TTA averaging)."""
+    _chk(a)
+    y = torch.empty_like(a)
+    _lib.call('swem_lincomb_f32', _stream(), a.data_ptr(), float(alpha), _ptr(None if b is None else _chk(b)),
+              float(beta), y.data_ptr(), a.numel())
+    return y
+
+
+def inject_objects(prob, new_masks):
+    """swem_evaluator.py:124-130 -> (B, N1 + Nn1 - 1, H, W)."""
+    _chk(prob)
+    new_masks = _chk(new_masks.float().contiguous())
+    B, N1, H, W = prob.shape
+    Nn1 = new_masks.shape[1]
+    out = torch.empty((B, N1 + Nn1 - 1, H, W), dtype=torch.float32, device=prob.device)
+    _lib.call('swem_inject_objects_f32', _stream(), prob.data_ptr(), new_masks.data_ptr(), out.data_ptr(), B, N1, Nn1,
+              H * W)
+    return out
 
 
 def mask_prep(hard, soft, h, w):

@@ -9,8 +9,9 @@ import torch
 import torch.nn.functional as F
 
 
-def make_clip(t=4, h=480, w=864, n_obj=2, out_hw=None, seed=123):
-    """Returns frames (1,T,3,h,w) in [0,1] and init_mask (1,N+1,Ho,Wo) one-hot float."""
+def make_clip(t=4, h=480, w=864, n_obj=2, out_hw=None, seed=123, all_masks=False):
+    """Returns frames (1,T,3,h,w) in [0,1] and init_mask (1,N+1,Ho,Wo) one-hot float
+    (all_masks=True: the list of one-hot masks of every frame instead)."""
     g = torch.Generator(device='cpu')
     g.manual_seed(seed)
     ho, wo = out_hw if out_hw is not None else (h, w)
@@ -20,6 +21,7 @@ def make_clip(t=4, h=480, w=864, n_obj=2, out_hw=None, seed=123):
                             torch.arange(w, dtype=torch.float32), indexing='ij')
     frames = []
     masks0 = None
+    per_frame = []
     col = torch.rand(n_obj, 3, generator=g) * 0.6 + 0.2
     cx0 = (torch.rand(n_obj, generator=g) * 0.5 + 0.25) * w
     cy0 = (torch.rand(n_obj, generator=g) * 0.5 + 0.25) * h
@@ -37,8 +39,11 @@ def make_clip(t=4, h=480, w=864, n_obj=2, out_hw=None, seed=123):
                 img[c] = torch.where(inside, (0.5 * col[o, c] + 0.5 * tex).clamp(0, 1), img[c])
             occ = torch.where(inside, torch.full_like(occ, o + 1), occ)
         frames.append(img)
-        if ti == 0:
+        if ti == 0 or all_masks:
             oh = F.one_hot(occ, n_obj + 1).permute(2, 0, 1).float()[None]
-            masks0 = F.interpolate(oh, size=(ho, wo), mode='nearest') if (ho, wo) != (h, w) else oh
+            mk = (F.interpolate(oh, size=(ho, wo), mode='nearest') if (ho, wo) != (h, w) else oh).contiguous()
+            if ti == 0:
+                masks0 = mk
+            per_frame.append(mk)
     frames = torch.stack(frames)[None].contiguous()
-    return frames, masks0.contiguous()
+    return frames, (per_frame if all_masks else masks0)

@@ -98,6 +98,47 @@ def ref_evaluate_seq(model, frames, init_masks, out_size, trace=None):
     return preds, scores
 
 
+def ref_evaluate_ytvos(model, frames, init_masks, out_size):
+    """The frame loop of swem_evaluator.py:104-148 driven through the REFERENCE model (see ref_evaluate_seq)."""
+    import torch.nn.functional as F
+    b, t, c, h, w = frames.shape
+    preds = []
+    mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+    init_mask = F.interpolate(init_masks[0], size=(h, w), mode='nearest')
+    mv16 = model('encode_value', frames[:, 0], init_mask.float(), s16)
+    model('init', mk16, mv16, init_masks[0])
+    for i in range(1, t):
+        qk16, qv16, s16, s8, s4 = model('encode_key', frames[:, i])
+        context, n = model('match', qk16, qv16)
+        logits, pred_mask = model('segment', n, context, s8, s4, None, out_size)
+        if init_masks[i] is not None:
+            new_objects = torch.sum(init_masks[i][:, 1:], dim=1, keepdim=True)
+            new_objects = new_objects.expand_as(pred_mask)
+            pred_mask[new_objects > 0] = 0
+            pred_mask = torch.cat([pred_mask, init_masks[i][:, 1:]], dim=1)
+            n = pred_mask.shape[1] - 1
+        pred = torch.argmax(pred_mask, dim=1, keepdim=True)
+        pred_expand = pred.expand(-1, n + 1, -1, -1)
+        obj_idx = torch.arange(n + 1).type(pred.dtype).view(1, -1, 1, 1).expand(b, -1, out_size[0], out_size[1])
+        hard = (pred_expand == obj_idx).type_as(pred)
+        if i < t - 1:
+            pm = F.interpolate(pred_mask, size=(h, w), mode='bilinear', align_corners=False)
+            mv16 = model('encode_value', frames[:, i], pm, s16)
+            model('memorize', qk16, mv16, hard, pm)
+        preds.append(pred[:, 0])
+    return preds
+
+
+def ytvos_masks(per_frame, appear_at):
+    """Object 1 is annotated at frame 0, object 2 only from frame `appear_at` on (YouTube-VOS style)."""
+    m0 = per_frame[0]
+    first = torch.stack([1 - m0[:, 1], m0[:, 1]], 1)                 # (1,2,H,W): bg, obj1
+    late = torch.stack([torch.zeros_like(per_frame[appear_at][:, 2]), per_frame[appear_at][:, 2]], 1)   # (1,2,H,W): -, obj2
+    masks = [first] + [None] * (len(per_frame) - 1)
+    masks[appear_at] = late
+    return masks
+
+
 def structured_keys(P, C, n_clusters, g, noise=0.15, scale=1.0):
     """Keys that look like encoder output: a few cluster centres + noise (iid noise makes EM chaotic).  The
     cluster of a pixel is independent of its position, so foreground and background share appearance and the
@@ -310,6 +351,69 @@ def main():
                 if tr_ref[0]['mv16'] is not None:
                     out['mv16'] = tr_ref[0]['mv16'][:, :, ::8]
         save(tag + '.npz', **out)
+
+    print('G8 YouTube-VOS loop: object 2 appears at frame 2 (config A sizes), + multi-scale/flip TTA')
+    cfg = O.make_cfg(BACKBONE='resnet18', NUM_BASES=64, NUM_EM_ITERS=4, SINGLE_OBJ=False)
+    ref = Rswem.SWEM(cfg)
+    ref.eval()
+    sd = weights.fill_state_dict(HipSWEM(cfg).state_dict(), seed=5, backbone='resnet18')
+    ref.load_state_dict(sd, strict=False)
+    frames, per_frame = synth.make_clip(t=5, h=240, w=432, n_obj=2, out_hw=(240, 432), seed=31, all_masks=True)
+    ymasks = ytvos_masks(per_frame, 2)
+    with torch.no_grad():
+        torch.manual_seed(78)
+        rp = ref_evaluate_ytvos(ref, frames, ymasks, (240, 432))
+        torch.manual_seed(78)
+        op = O.evaluate_ytvos_seq(O.Model(sd, cfg), frames, ymasks, (240, 432))
+        ref64 = Rswem.SWEM(cfg).double()
+        ref64.eval()
+        ref64.load_state_dict({k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}, strict=False)
+        init64 = ref64.swem_core.random_init
+        ref64.swem_core.random_init = lambda size, **k: tuple(
+            t_.double() for t_ in init64(size, **dict(k, dtype=torch.FloatTensor().type())))
+        torch.manual_seed(78)
+        rp64 = ref_evaluate_ytvos(ref64, frames.double(), [None if m is None else m.double() for m in ymasks], (240, 432))
+    for a, b_ in zip(rp, op):
+        assert torch.equal(a, b_)
+    agree64 = [float((a == b_).float().mean()) for a, b_ in zip(rp, rp64)]
+    print('   ytvos: oracle == reference (bit exact); reference fp32-vs-fp64 index agreement per frame', agree64,
+          ' objects in last frame', int(rp[-1].max()))
+    out = {'seed': 31, 'wseed': 5, 'agree64': np.array(agree64)}
+    for i, pr in enumerate(rp):
+        out['pred%d' % i] = pr.to(torch.uint8)
+    # test-time augmentation (swem_evaluator.py:34-57) on the 2-object DAVIS-style clip: reference evaluator body restated
+    import torch.nn.functional as F
+    m0 = per_frame[0]
+    tfr = frames[:, :3]
+    with torch.no_grad():
+        final = [0, 0]
+        for scale in (240, 288):
+            hh, ww = scale, int((scale / 480) * 864)
+            fr = F.interpolate(tfr[0], size=(hh, ww), mode='bicubic', align_corners=False).unsqueeze(0)
+            torch.manual_seed(79)
+            _, sc = ref_evaluate_seq(ref, fr, [m0, None, None], (240, 432))
+            ff = torch.flip(fr, dims=[-1])
+            torch.manual_seed(79)
+            _, fs = ref_evaluate_seq(ref, ff, [torch.flip(m0, dims=[-1])], (240, 432))
+            sc = [(a + torch.flip(b_, dims=[-1])) / 2 for a, b_ in zip(sc, fs)]
+            final = [f + s_ / 2 for f, s_ in zip(final, sc)]
+        tta_ref = [torch.argmax(f, dim=1) for f in final]
+
+        class _Seeded:      # the oracle's evaluate_seq_ms runs 4 passes: reseed before each like the reference run above
+            def __init__(self, m):
+                self.m = m
+
+            def __call__(self, mode, *a):
+                if mode == 'init':
+                    torch.manual_seed(79)
+                return self.m(mode, *a)
+        tta_orc = O.evaluate_seq_ms(_Seeded(O.Model(sd, cfg)), tfr, [m0, None, None], (240, 432), scales=(240, 288),
+                                    is_flip=True)
+    for a, b_ in zip(tta_ref, tta_orc):
+        assert torch.equal(a, b_)
+    for i, pr in enumerate(tta_ref):
+        out['tta%d' % i] = pr.to(torch.uint8)
+    save('g8_ytvos_tta.npz', **out)
 
     print('G6 config A (240x432, R18, K=64, single object, 2 frames)')
     run_clip(dict(BACKBONE='resnet18', NUM_BASES=64, NUM_EM_ITERS=4, SINGLE_OBJ=True), 2, 240, 432, 1, (240, 432),

@@ -52,3 +52,25 @@ def em_inputs(h, w, C, V, N, g):
     sf = (fg * 0.9 + 0.1 * torch.rand(N, P, generator=g)).clamp(0, 1)
     m = torch.stack([(1 - fg) * (1 - sf), fg * sf], 1).view(1, N, 2, h, w)
     return x, v, m
+
+
+def ytvos_masks(per_frame, appear_at):
+    """Object 1 annotated at frame 0, object 2 only from frame `appear_at` on (same construction as make_golden.py)."""
+    m0 = per_frame[0]
+    first = torch.stack([1 - m0[:, 1], m0[:, 1]], 1)
+    late = torch.stack([torch.zeros_like(per_frame[appear_at][:, 2]), per_frame[appear_at][:, 2]], 1)
+    masks = [first] + [None] * (len(per_frame) - 1)
+    masks[appear_at] = late
+    return masks
+
+
+class SeededInit:
+    """Re-seeds the torch generator before every 'init' (each TTA pass of the fixture run was seeded the same way)."""
+
+    def __init__(self, model, seed, gpu_core=None):
+        self.model, self.seed = model, seed
+
+    def __call__(self, mode, *a):
+        if mode == 'init':
+            torch.manual_seed(self.seed)
+        return self.model(mode, *a)

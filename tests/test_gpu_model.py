@@ -195,3 +195,31 @@ def test_frame_graph_matches_eager(lib):
         assert torch.equal(a, b)
     for k in be:
         assert torch.equal(be[k], bg[k]), k
+
+
+def test_ytvos_loop_and_tta_vs_golden(lib, golden):
+    """f1 rows: evaluate_ytvos_seq with an object that appears at frame 2 (exercises N_new > 0 in swem() and
+    MemoryBank.add_new) and the multi-scale + flip TTA, against the reference's index maps."""
+    from swem_amd import synth
+    fx = golden('g8_ytvos_tta.npz')
+    cfg = O.make_cfg(**CFG_A)
+    model, _ = H.make_model_and_sd(cfg, int(fx['wseed']), device=DEV)
+    frames, per_frame = synth.make_clip(t=5, h=240, w=432, n_obj=2, out_hw=(240, 432), seed=int(fx['seed']), all_masks=True)
+    masks = [None if m is None else m.to(DEV) for m in H.ytvos_masks(per_frame, 2)]
+    with torch.no_grad():
+        torch.manual_seed(78)
+        preds = evaluator.evaluate_ytvos_seq(model, frames.to(DEV), masks, (240, 432))
+    core = model.swem_core
+    assert core.memories['first'].bases['kappa'].shape[1] == 2 and core.memories['update'].bases['kappa'].shape[1] == 2
+    for i, p in enumerate(preds):
+        agree = float((p.cpu().to(torch.uint8) == fx['pred%d' % i]).float().mean())
+        print('ytvos frame %d: index agreement %.6f (reference fp32-vs-fp64 %.6f)' % (i + 1, agree, float(fx['agree64'][i])))
+        assert agree >= min(0.9995, float(fx['agree64'][i]) - 0.01)
+    assert int(preds[0].max()) <= 1 and int(preds[-1].max()) == 2
+    with torch.no_grad():
+        tta = evaluator.evaluate_davis_seq_ms(H.SeededInit(model, 79), frames[:, :3].to(DEV),
+                                              [per_frame[0].to(DEV), None, None], (240, 432), scales=(240, 288), is_flip=True)
+    for i, p in enumerate(tta):
+        agree = float((p.cpu().to(torch.uint8) == fx['tta%d' % i]).float().mean())
+        print('tta frame %d: index agreement %.6f' % (i + 1, agree))
+        assert agree >= 0.97

@@ -194,3 +194,24 @@ def test_transpose(lib):
     x = torch.randn(3, 405, 128)
     y = ops.transpose(x.to(DEV), ld=408).cpu()
     assert torch.equal(y[:, :, :405], x.transpose(1, 2)) and (y[:, :, 405:] == 0).all()
+
+
+def test_bicubic_flip_lincomb_inject(lib):
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(1, 3, 48, 85, generator=g)
+    for size in ((48, 86), (96, 172), (30, 54)):
+        ref = F.interpolate(x, size=size, mode='bicubic', align_corners=False)
+        close(ops.resize_planes(x.to(DEV), size, 'bicubic').cpu(), ref, 2e-6, 'bicubic %s' % (size,))
+    assert torch.equal(ops.flip_w(x.to(DEV)).cpu(), torch.flip(x, dims=[-1]))
+    a, b = torch.rand(2, 3, 40, 50, generator=g), torch.rand(2, 3, 40, 50, generator=g)
+    assert torch.allclose(ops.lincomb(a.to(DEV), 0.5, b.to(DEV), 0.25).cpu(), 0.5 * a + 0.25 * b, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(ops.lincomb(a.to(DEV), 0.5).cpu(), 0.5 * a)
+    # swem_evaluator.py:124-130
+    prob = torch.rand(1, 3, 40, 50, generator=g)
+    newm = torch.zeros(1, 3, 40, 50)
+    newm[0, 1, 5:15, 5:20] = 1
+    newm[0, 2, 20:30, 30:45] = 1
+    ref = prob.clone()
+    ref[newm[:, 1:].sum(1, keepdim=True).expand_as(ref) > 0] = 0
+    ref = torch.cat([ref, newm[:, 1:]], 1)
+    assert torch.equal(ops.inject_objects(prob.to(DEV), newm.to(DEV)).cpu(), ref)

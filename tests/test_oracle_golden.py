@@ -79,3 +79,23 @@ def test_full_clip_config_b(golden):
     for i, tr in enumerate(trace):
         assert torch.equal(tr['logits'][:, :, ::8, ::8], fx['logits%d' % i])
         assert torch.equal(preds[i].to(torch.uint8), fx['pred%d' % i])
+
+
+def test_ytvos_loop_and_tta(golden):
+    """swem_evaluator.py:104-148 (objects appearing later -> MemoryBank.add_new / random_init for new ids) and
+    :34-57 (multi-scale + flip averaging) against the reference's index maps."""
+    from swem_amd import synth
+    fx = golden('g8_ytvos_tta.npz')
+    cfg = O.make_cfg(BACKBONE='resnet18', NUM_BASES=64, NUM_EM_ITERS=4, SINGLE_OBJ=False)
+    _, sd = H.make_model_and_sd(cfg, int(fx['wseed']))
+    frames, per_frame = synth.make_clip(t=5, h=240, w=432, n_obj=2, out_hw=(240, 432), seed=int(fx['seed']), all_masks=True)
+    with torch.no_grad():
+        torch.manual_seed(78)
+        preds = O.evaluate_ytvos_seq(O.Model(sd, cfg), frames, H.ytvos_masks(per_frame, 2), (240, 432))
+        tta = O.evaluate_seq_ms(H.SeededInit(O.Model(sd, cfg), 79), frames[:, :3], [per_frame[0], None, None],
+                                (240, 432), scales=(240, 288), is_flip=True)
+    for i, p in enumerate(preds):
+        assert torch.equal(p.to(torch.uint8), fx['pred%d' % i])
+    assert int(preds[-1].max()) == 2 and int(preds[0].max()) == 1      # the second object exists only after frame 2
+    for i, p in enumerate(tta):
+        assert torch.equal(p.to(torch.uint8), fx['tta%d' % i])
