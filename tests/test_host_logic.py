@@ -91,3 +91,20 @@ def test_cpu_model_fails_loudly():
         m('nonsense')
     with pytest.raises(KeyError):
         SWEM(O.make_cfg(BACKBONE='resnet101'))
+
+
+def test_checkpoint_so_to_mo_surgery(tmp_path):
+    """basic_evaluator.py:104-124: a 4-channel (single-object) value-encoder stem loads into the 5-channel model."""
+    from swem_amd import checkpoint
+    so = SWEM(O.make_cfg(BACKBONE='resnet18', NUM_BASES=64, SINGLE_OBJ=True))
+    mo = SWEM(O.make_cfg(BACKBONE='resnet18', NUM_BASES=64, SINGLE_OBJ=False))
+    sd = weights.fill_state_dict(so.state_dict(), seed=8, backbone='resnet18')
+    assert sd['value_encoder.conv1.weight'].shape[1] == 4
+    path = str(tmp_path / 'SWEM.pth')
+    torch.save(sd, path)
+    res = checkpoint.load_model(mo, path, strict=True, cpu=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    w = mo.state_dict()['value_encoder.conv1.weight']
+    assert w.shape[1] == 5 and torch.equal(w[:, :4], sd['value_encoder.conv1.weight']) and w[:, 4].abs().sum() > 0
+    checkpoint.load_model(so, sd)          # same-arity checkpoints load untouched
+    assert torch.equal(so.state_dict()['key_comp.weight'], sd['key_comp.weight'])
