@@ -223,3 +223,56 @@ def test_ytvos_loop_and_tta_vs_golden(lib, golden):
         agree = float((p.cpu().to(torch.uint8) == fx['tta%d' % i]).float().mean())
         print('tta frame %d: index agreement %.6f' % (i + 1, agree))
         assert agree >= 0.97
+
+
+@pytest.mark.parametrize('n_obj,h,w,bases,topl', [(1, 96, 160, 64, 64), (5, 112, 176, 64, 32), (3, 80, 144, 128, 64)],
+                         ids=['one_object', 'five_objects_topl32', 'three_objects_k128'])
+def test_edge_shapes_free_running(lib, n_obj, h, w, bases, topl):
+    """Edge cases of the frame loop: a single object, the reference's maximum of five objects, a top-l smaller than the
+    bank, sizes whose 1/16 grid is not a multiple of the 32-pixel tile, an EMPTY initial mask for one object and an
+    object that leaves the frame.  Free-running against the CPU oracle (index agreement; logits on frame 1)."""
+    from swem_amd import synth
+    cfg = O.make_cfg(BACKBONE='resnet18', NUM_BASES=bases, NUM_EM_ITERS=3, TOPL=topl)
+    model, sd = H.make_model_and_sd(cfg, wseed=21 + n_obj, device=DEV)
+    frames, m0 = synth.make_clip(t=3, h=h, w=w, n_obj=n_obj, seed=40 + n_obj)
+    if n_obj >= 3:                       # object n_obj has no pixels at all in the first frame (empty mask)
+        m0[:, 0] += m0[:, n_obj]
+        m0[:, n_obj] = 0
+    with torch.no_grad():
+        torch.manual_seed(3)
+        otr = []
+        opreds, _ = O.evaluate_seq(O.Model(sd, cfg), frames, [m0, None, None], (h, w), otr)
+        torch.manual_seed(3)
+        tr = []
+        preds, scores = evaluator.evaluate_davis_seq(model, frames.to(DEV), [m0.to(DEV), None, None], (h, w), tr)
+    assert scores[0].shape == (1, n_obj + 1, h, w) and torch.isfinite(scores[-1]).all()
+    assert float((scores[0].sum(1) - 1).abs().max()) < 1e-5
+    assert relmax(tr[0]['qk16'], otr[0]['qk16']) < 1e-4
+    for i in range(2):
+        agree = float((preds[i].cpu() == opreds[i]).float().mean())
+        assert agree > 0.97, 'frame %d index agreement %.4f' % (i + 1, agree)
+    bases_ = model.swem_core.memories['update'].bases
+    assert bases_['kappa'].shape == (1, n_obj, 2, 128, bases) and torch.isfinite(bases_['nu']).all()
+
+
+def test_memory_is_constant_size_over_a_long_clip(lib):
+    """BASELINE config E in miniature: memorise every frame of a longer clip; the state never grows (two banks of
+    K bases per object and class) and stays finite."""
+    from swem_amd import synth
+    cfg = O.make_cfg(**CFG_A)
+    model, _ = H.make_model_and_sd(cfg, wseed=6, device=DEV)
+    frames, m0 = synth.make_clip(t=6, h=96, w=160, n_obj=2, seed=77)
+    frames, m0 = frames.to(DEV), m0.to(DEV)
+    with torch.no_grad():
+        mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+        model('init', mk16, model('encode_value', frames[:, 0], m0, s16), m0)
+        shapes = None
+        for rep in range(25):
+            evaluator.frame_step(model, frames[:, 1 + rep % 5], (96, 160))
+            mem = model.swem_core.memories
+            cur = {k: tuple(v.shape) for k, v in mem['update'].bases.items()}
+            assert shapes is None or cur == shapes
+            shapes = cur
+            zsum = float(mem['update'].bases['zita'].sum())
+        assert mem['first'].bases['kappa'].shape == mem['update'].bases['kappa'].shape == (1, 2, 2, 128, 64)
+        assert all(torch.isfinite(v).all() for v in mem['update'].bases.values()) and zsum > 0
