@@ -65,20 +65,26 @@ int swem_device_cus(void);
  *   w_bs    : 0 = one filter bank for the whole batch (every nn.Conv2d); else elements between the banks of
  *             consecutive batch items (a batched GEMM: the value readout of matching, modules.py:272-273);
  *             then Ho*Wo must be a multiple of the row tile (128 is always safe)
+ *   w_bf16x3: NULL, or the same filters split into three bf16 planes [3][Cout'][KH*KW*Cin] with
+ *             w = hi + mid + lo (round-to-nearest residuals); used by the bf16x6 math mode (plan bit 16), which
+ *             otherwise splits the filters on the fly; ignored when w_bs != 0
  *   scale   : [Cout'] or NULL (=1)     -- folded BatchNorm  gamma/sqrt(var+eps)
  *   shift   : [Cout'] or NULL (=0)     -- conv bias and folded BatchNorm shift
  *   res     : NHWC [B][Ho][Wo][Cout] added after scale/shift, or NULL; res_bs as bsK
  *   y       : NHWC [B][Ho][Wo][Cout],  Ho = (H + 2*pad - KH)/stride + 1
- *   plan    : tiling hint, 0 = built-in heuristic; else  wm | wn << 4 | nsplit << 8  with wave tile
- *             (32*wm) x (32*wn) in {1x1, 1x2, 2x2} and nsplit K-splits (results are identical up to fp32
- *             summation order; callers may time candidates once per layer shape and pass the fastest)
+ *   plan    : tiling hint, 0 = built-in heuristic; else  wm | wn << 4 | nsplit << 8 | math << 16  with wave tile
+ *             (32*wm) x (32*wn) in {1x1, 1x2, 2x2}, nsplit K-splits, math 0 = fp32 MFMA, 1 = "bf16x6": operands
+ *             split exactly into three bf16 terms, six bf16 MFMA products, fp32 accumulation (fp32-level error,
+ *             2.7x the fp32-MFMA rate).  Results are identical up to fp32 rounding; callers may time candidates once
+ *             per layer shape and pass the fastest
  *   ws      : workspace for split-K partial sums (swem_conv2d_workspace bytes for the same plan)
  */
 size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                              int flags, int plan);
 int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
                          long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
-                         const float *w, long long w_bs, const float *scale, const float *shift, const float *res,
+                         const float *w, long long w_bs, const void *w_bf16x3, const float *scale, const float *shift,
+                         const float *res,
                          long long res_bs, float *y, int Cout, int KH, int KW, int stride, int pad, int flags,
                          int plan, void *ws, size_t ws_bytes);
 

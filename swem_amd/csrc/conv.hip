@@ -21,6 +21,7 @@
 // workspace and a second kernel reduces them in a fixed order (deterministic) and runs the epilogue.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -36,6 +37,7 @@ struct ConvP {
   int B, H, W, Ho, Wo, Cin, K, M;
   const float *w, *scale, *shift, *res;
   long long res_bs, w_bs;  // w_bs: elements between the filter banks of consecutive batch items (0 = shared)
+  const unsigned short *wsplit;  // optional [3][Ncols][K] bf16: the filters pre-split into hi/mid/lo planes
   float *y;
   int Cout, Ncols, KH, KW, stride, pad, flags;
   int nkb, kb_per_split;
@@ -502,6 +504,231 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvP p) {
   conv_epilogue<WM, WN>(p, acc, m0, n0, wm, wn, r, h);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// fp32-accurate convolution on the bf16 matrix cores ("bf16x6"): every fp32 operand is split exactly into three bf16
+// terms  x = hi + mid + lo  (8 + 8 + 8 significant bits, round-to-nearest residuals) while it is staged into LDS, and
+// the product is rebuilt from the six term pairs above 2^-24:  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid,
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (each bf16 x bf16 product is exact).  The dropped pairs are <= 2^-24
+// relative, i.e. the result carries fp32-level error, at 16/6 = 2.7x the fp32-MFMA rate -- and, unlike the fp32 MFMA,
+// the bf16 MFMA co-executes with the vector ALU, so the splitting arithmetic of one wave hides behind another's MFMAs.
+// Same tiling, loads, k-block bookkeeping and epilogue as conv_igemm_pipe_kernel; LDS holds three bf16 planes per
+// operand,  [plane][k/8][row][8 bf16], one 16-byte MFMA fragment per (row, k/8), plane stride padded by 16 bytes.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32, a in the low half
+}
+__device__ __forceinline__ float lo_f32(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi_f32(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+// x = hi + mid + lo per element; returns the three planes' 8-byte pieces (4 consecutive k each)
+__device__ __forceinline__ void split3(float4 v, uint2 &h, uint2 &m, uint2 &l) {
+  h.x = pack_bf16(v.x, v.y);
+  h.y = pack_bf16(v.z, v.w);
+  const float rx = v.x - lo_f32(h.x), ry = v.y - hi_f32(h.x), rz = v.z - lo_f32(h.y), rw = v.w - hi_f32(h.y);
+  m.x = pack_bf16(rx, ry);
+  m.y = pack_bf16(rz, rw);
+  l.x = pack_bf16(rx - lo_f32(m.x), ry - hi_f32(m.x));
+  l.y = pack_bf16(rz - lo_f32(m.y), rw - hi_f32(m.y));
+}
+__device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 bufload2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+  return make_uint2(v.x, v.y);
+}
+
+// PS: the filters arrive pre-split (three bf16 planes packed once per model), so only the activations are split here
+template <int WM, int WN, bool PS>
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(ConvP p) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int SA = BM + 1, SB = BN + 1;          // k/8-group strides in 16-byte slots (+1: conflict-free stores)
+  constexpr int PA = 4 * SA, PB = 4 * SB;         // plane strides
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4 *As = reinterpret_cast<uint4 *>(smem);  // [2 buffers][3 planes][PA]
+  uint4 *Bs = As + 2 * 3 * PA;                  // [2][3][PB]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int tm, tn;
+  tile_coords(tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kq = tid & 7, rbase = tid >> 3;
+
+  const long long HWin = (long long)p.H * p.W;
+  auto src_rsrc = [&](int sidx) {
+    const float *base = sidx == 0 ? p.x[0] : (sidx == 1 ? p.x[1] : p.x[2]);
+    const int cs = sidx == 0 ? p.c[0] : (sidx == 1 ? p.c[1] : p.c[2]);
+    const long long bs = sidx == 0 ? p.bs[0] : (sidx == 1 ? p.bs[1] : p.bs[2]);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0,
+                                             (int)((bs ? (long long)p.B * bs : HWin * cs) * 4), 0x00020000);
+  };
+  __amdgpu_buffer_rsrc_t rsw =
+      PS ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.wsplit), 0,
+                                             (int)((long long)3 * p.Ncols * p.K * 2), 0x00020000)
+         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w + (long long)(m0 / (p.Ho * p.Wo)) * p.w_bs), 0,
+                                             (int)((long long)p.Ncols * p.K * 4), 0x00020000);
+  const unsigned wplane = (unsigned)((long long)p.Ncols * p.K * 2);  // bytes per pre-split plane
+
+  int iy0[RA], ix0[RA], bidx[RA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    int m = m0 + rbase + 32 * i;
+    int b = m / HoWo;
+    int rem = m - b * HoWo;
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    iy0[i] = oy * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.pad;
+    bidx[i] = m < p.M ? b : -1;
+  }
+  unsigned wvoff[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    int n = n0 + rbase + 32 * i;
+    wvoff[i] = n < p.Ncols ? (unsigned)(((long long)n * p.K + kq * 4) * (PS ? 2 : 4)) : OOB;
+  }
+  const bool relu_in = p.flags & SWEM_CONV_RELU_IN;
+  unsigned avoff[RA];
+  auto set_tap = [&](const KPos &q) {
+    const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
+    const long long bs = q.src == 0 ? p.bs[0] : (q.src == 1 ? p.bs[1] : p.bs[2]);
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int iy = iy0[i] + q.ky, ix = ix0[i] + q.kx;
+      const bool ok = bidx[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const long long e = bidx[i] * bs + ((long long)iy * p.W + ix) * cs + kq * 4;
+      avoff[i] = ok ? (unsigned)(e * 4) : OOB;
+    }
+  };
+  float4 ga[RA], gb[PS ? 1 : RB];
+  uint2 gs[PS ? 3 : 1][RB];
+  __amdgpu_buffer_rsrc_t rsa;
+  auto gload = [&](const KPos &q, int kb) {
+    const unsigned soff = (unsigned)q.ci0 * 4u;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) ga[i] = bufload4(rsa, avoff[i], soff);
+    if constexpr (PS) {
+      const unsigned wsoff = (unsigned)kb * (BK * 2u);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int i = 0; i < RB; ++i) gs[pl][i] = bufload2(rsw, wvoff[i], wsoff + pl * wplane);
+    } else {
+      const unsigned wsoff = (unsigned)kb * (BK * 4u);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) gb[i] = bufload4(rsw, wvoff[i], wsoff);
+    }
+  };
+  // split + store: 8 bytes per plane at [plane][k8 = kq/2][row] + (kq & 1) * 8
+  auto lstore = [&](int buf) {
+    char *abase = reinterpret_cast<char *>(As + buf * 3 * PA) + ((kq >> 1) * SA + rbase) * 16 + (kq & 1) * 8;
+    char *bbase = reinterpret_cast<char *>(Bs + buf * 3 * PB) + ((kq >> 1) * SB + rbase) * 16 + (kq & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      uint2 hh, mm, ll;
+      split3(relu_in ? relu4(ga[i]) : ga[i], hh, mm, ll);
+      *reinterpret_cast<uint2 *>(abase + 32 * i * 16) = hh;
+      *reinterpret_cast<uint2 *>(abase + PA * 16 + 32 * i * 16) = mm;
+      *reinterpret_cast<uint2 *>(abase + 2 * PA * 16 + 32 * i * 16) = ll;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      uint2 hh, mm, ll;
+      if constexpr (PS) {
+        hh = gs[0][i];
+        mm = gs[1][i];
+        ll = gs[2][i];
+      } else {
+        split3(gb[i], hh, mm, ll);
+      }
+      *reinterpret_cast<uint2 *>(bbase + 32 * i * 16) = hh;
+      *reinterpret_cast<uint2 *>(bbase + PB * 16 + 32 * i * 16) = mm;
+      *reinterpret_cast<uint2 *>(bbase + 2 * PB * 16 + 32 * i * 16) = ll;
+    }
+  };
+  auto advance = [&](KPos &q) {
+    q.ci0 += BK;
+    const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
+    if (q.ci0 >= cs) {
+      q.ci0 = 0;
+      ++q.src;
+      const int cn = q.src == 1 ? p.c[1] : (q.src == 2 ? p.c[2] : 0);
+      if (cn == 0) {
+        q.src = 0;
+        if (++q.kx == p.KW) {
+          q.kx = 0;
+          ++q.ky;
+        }
+      }
+      set_tap(q);
+      rsa = src_rsrc(q.src);
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int kb_begin = blockIdx.z * p.kb_per_split;
+  const int kb_end = min(p.nkb, kb_begin + p.kb_per_split);
+  KPos q;
+  kpos_init(q, p, kb_begin);
+  set_tap(q);
+  rsa = src_rsrc(q.src);
+  gload(q, kb_begin);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kb = kb_begin; kb < kb_end; ++kb) {
+    const bool more = kb + 1 < kb_end;
+    if (more) advance(q);
+    gload(q, more ? kb + 1 : kb);
+    const uint4 *Ab = As + buf * 3 * PA + wm * 32 * WM + r;
+    const uint4 *Bb = Bs + buf * 3 * PB + wn * 32 * WN + r;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {  // two 16-wide k-steps; lane half h holds k = 8h..8h+7 of the step
+      const int k8 = 2 * s2 + h;
+      uint4 a[3][WM], b[3][WN];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[pl][i] = Ab[pl * PA + k8 * SA + 32 * i];
+#pragma unroll
+        for (int i = 0; i < WN; ++i) b[pl][i] = Bb[pl * PB + k8 * SB + 32 * i];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < WN; ++jn) {
+          f32x16 c = acc[i][jn];
+          c = mfma_bf16(a[0][i], b[2][jn], c);  // small terms first
+          c = mfma_bf16(a[2][i], b[0][jn], c);
+          c = mfma_bf16(a[1][i], b[1][jn], c);
+          c = mfma_bf16(a[0][i], b[1][jn], c);
+          c = mfma_bf16(a[1][i], b[0][jn], c);
+          c = mfma_bf16(a[0][i], b[0][jn], c);
+          acc[i][jn] = c;
+        }
+    }
+    lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  conv_epilogue<WM, WN>(p, acc, m0, n0, wm, wn, r, h);
+}
+
 // Reduce split-K partials in z order and apply the same epilogue.  One thread per 4 output channels.
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int nsplit) {
   const bool glu = p.flags & SWEM_CONV_GLU;
@@ -607,6 +834,19 @@ int launch_pipe(const ConvP &p, dim3 grid, hipStream_t st) {
   return SWEM_OK;
 }
 
+template <int WM, int WN>
+int launch_bf3(const ConvP &p, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = 2 * 3 * 4 * (64 * WM + 1 + 64 * WN + 1) * 16;
+  if (p.wsplit) {
+    SWEM_ALLOW_LDS((conv_igemm_bf3_kernel<WM, WN, true>), lds);
+    hipLaunchKernelGGL((conv_igemm_bf3_kernel<WM, WN, true>), grid, dim3(256), lds, st, p);
+  } else {
+    SWEM_ALLOW_LDS((conv_igemm_bf3_kernel<WM, WN, false>), lds);
+    hipLaunchKernelGGL((conv_igemm_bf3_kernel<WM, WN, false>), grid, dim3(256), lds, st, p);
+  }
+  return SWEM_OK;
+}
+
 template <int WM, int WN, bool DB>
 int launch(const ConvP &p, dim3 grid, hipStream_t st) {
   constexpr size_t lds = (DB ? 2 : 1) * KQ * (64 * WM + 1 + 64 * WN + 1) * sizeof(float4);
@@ -617,8 +857,9 @@ int launch(const ConvP &p, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
-// plan hint: 0 = heuristic; else wm | wn << 4 | nsplit << 8 (swem_hip.h)
+// plan hint: 0 = heuristic; else wm | wn << 4 | nsplit << 8 | math << 16 (swem_hip.h)
 Plan resolve_plan(int plan, int M, int Ncols, int nkb, bool glu) {
+  plan &= 0xffff;
   if (plan > 0) {
     int wm = plan & 15, wn = (plan >> 4) & 15, ns = plan >> 8;
     bool ok = (wm == 1 || wm == 2) && (wn == 1 || wn == 2) && !(wm == 2 && wn == 1) && !(glu && wn != 2);
@@ -645,7 +886,8 @@ extern "C" size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, 
 
 extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
                                     long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
-                                    const float *w, long long w_bs, const float *scale, const float *shift,
+                                    const float *w, long long w_bs, const void *w_bf16x3, const float *scale,
+                                    const float *shift,
                                     const float *res, long long res_bs, float *y, int Cout, int KH, int KW, int stride,
                                     int pad, int flags, int plan, void *ws, size_t ws_bytes) {
   SWEM_REQUIRE(x0 && w && y, SWEM_E_ARG, "conv2d: null pointer");
@@ -673,6 +915,7 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
   SWEM_REQUIRE(M < (1ll << 31) && M * (glu ? 2 * Cout : Cout) < (1ll << 40), SWEM_E_SHAPE, "conv2d: too large");
   p.M = (int)M;
   p.w = w; p.scale = scale; p.shift = shift; p.res = res; p.res_bs = res_bs; p.w_bs = w_bs; p.y = y;
+  p.wsplit = w_bs == 0 ? static_cast<const unsigned short *>(w_bf16x3) : nullptr;
   p.Cout = Cout; p.Ncols = glu ? 2 * Cout : Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.flags = flags;
   {
@@ -708,7 +951,16 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
     nopipe = e ? atoi(e) : 0;
   }
   const bool pipe_ok = !nopipe && c0 % 32 == 0 && c1 % 32 == 0 && c2 % 32 == 0;
-  if (pipe_ok && pl.wm == 2 && pl.wn == 2) rc = launch_pipe<2, 2>(p, grid, st);
+  static int math_env = -1;
+  if (math_env < 0) {
+    const char *e = getenv("SWEM_CONV_MATH");  // tuning/debug override: "bf16x6" or "f32"
+    math_env = !e ? 0 : (strcmp(e, "bf16x6") == 0 ? 1 : 2);
+  }
+  const bool emulate = pipe_ok && (math_env == 1 || (math_env == 0 && ((plan >> 16) & 1)));
+  if (emulate && pl.wm == 2 && pl.wn == 2) rc = launch_bf3<2, 2>(p, grid, st);
+  else if (emulate && pl.wm == 1 && pl.wn == 2) rc = launch_bf3<1, 2>(p, grid, st);
+  else if (emulate && pl.wm == 1 && pl.wn == 1) rc = launch_bf3<1, 1>(p, grid, st);
+  else if (pipe_ok && pl.wm == 2 && pl.wn == 2) rc = launch_pipe<2, 2>(p, grid, st);
   else if (pipe_ok && pl.wm == 1 && pl.wn == 2) rc = launch_pipe<1, 2>(p, grid, st);
   else if (pipe_ok && pl.wm == 1 && pl.wn == 1) rc = launch_pipe<1, 1>(p, grid, st);
   else if (pl.wm == 2 && pl.wn == 2) rc = single ? launch<2, 2, false>(p, grid, st) : launch<2, 2, true>(p, grid, st);

@@ -20,6 +20,7 @@ CONV_TRACE = None
 # fp32 summation order, but tuning costs a few milliseconds per layer shape.
 AUTOTUNE = False
 _CONV_PLANS = {}      # layer signature + input shape -> plan hint (shared by every model instance in the process)
+CONV_MATH_MODES = (0, 1)   # 0 = fp32 MFMA, 1 = bf16x6 (exact 3-way bf16 split, fp32-level error); both are tuned over
 _TUNE_TILES = ((2, 2), (1, 2), (1, 1))
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
 
@@ -59,6 +60,16 @@ class ConvPack:
         self.cout, self.kh, self.kw, self.stride, self.pad, self.glu = cout, kh, kw, stride, pad, glu
         self.cin = w.shape[-1]
         self.cin_true = self.cin          # channels of the reference conv (without layout padding)
+        self.w3 = split_bf16x3(w)         # the same filters as three bf16 planes (bf16x6 math mode)
+
+
+def split_bf16x3(w):
+    """w (fp32) -> (3, ...) bf16 with w = hi + mid + lo, round-to-nearest residuals (one-time weight packing)."""
+    hi = w.to(torch.bfloat16)
+    r1 = w - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return torch.stack([hi, mid, lo]).contiguous()
 
 
 def pack_conv(weight, bias=None, bn=None, stride=1, pad=None, cin_pad=None, eps=1e-5):
@@ -107,8 +118,10 @@ def _chk_src(t):
     return t
 
 
-def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadcast=False, batch=None, out=None):
-    """srcs: list of up to three NHWC tensors concatenated on C; a source with batch 1 is broadcast over `batch`."""
+def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadcast=False, batch=None, out=None,
+           plan=None):
+    """srcs: list of up to three NHWC tensors concatenated on C; a source with batch 1 is broadcast over `batch`.
+    plan: explicit plan hint (include/swem_hip.h); default = tuned plan of this layer shape, else the heuristic."""
     x0 = _chk_src(srcs[0])
     B = batch if batch is not None else max(s.shape[0] for s in srcs)
     _, H, W, _ = x0.shape
@@ -138,13 +151,15 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         wsb = _lib.query('swem_conv2d_workspace', B, H, W, cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad,
                          flags, plan)
         ws = workspace(wsb, x0.device) if wsb else None
-        _lib.call('swem_conv2d_nhwc_f32', _stream(), *args, B, H, W, pack.w.data_ptr(), 0, _ptr(pack.scale),
+        _lib.call('swem_conv2d_nhwc_f32', _stream(), *args, B, H, W, pack.w.data_ptr(), 0, pack.w3.data_ptr(),
+                  _ptr(pack.scale),
                   _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw, pack.stride,
                   pack.pad, flags, plan, _ptr(ws), wsb)
 
     sig = (cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags, B, H, W)
-    plan = _CONV_PLANS.get(sig, 0)
-    if AUTOTUNE and plan == 0 and not torch.cuda.is_current_stream_capturing():
+    explicit = plan is not None
+    plan = plan if explicit else _CONV_PLANS.get(sig, 0)
+    if AUTOTUNE and not explicit and plan == 0 and not torch.cuda.is_current_stream_capturing():
         plan = _CONV_PLANS[sig] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
                                                  -(-pack.kh * pack.kw * cin // 32), pack.glu)
     if CONV_TRACE is not None:
@@ -169,7 +184,8 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3):
         for ns in _TUNE_SPLITS:
             if ns > 1 and (nkb // ns < 2 or blocks * ns > 4096):
                 continue
-            cands.append(wm | wn << 4 | ns << 8)
+            for math in CONV_MATH_MODES:
+                cands.append(wm | wn << 4 | ns << 8 | math << 16)
     best, best_t = 0, float('inf')
     for plan in cands:
         launch(plan)                               # warm (also grows the workspace)

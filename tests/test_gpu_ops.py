@@ -215,3 +215,30 @@ def test_bicubic_flip_lincomb_inject(lib):
     ref[newm[:, 1:].sum(1, keepdim=True).expand_as(ref) > 0] = 0
     ref = torch.cat([ref, newm[:, 1:]], 1)
     assert torch.equal(ops.inject_objects(prob.to(DEV), newm.to(DEV)).cpu(), ref)
+
+
+@pytest.mark.parametrize('plan', [0x00011, 0x00021, 0x00022, 0x00211, 0x10011, 0x10021, 0x10022, 0x10321],
+                         ids=lambda p: 'math%d_wm%d_wn%d_ns%d' % (p >> 16, p & 15, (p >> 4) & 15, (p >> 8) & 255))
+def test_conv2d_plans_and_math_modes(lib, plan):
+    """Every tiling / K-split / math mode of the fast conv kernel gives the same convolution: fp32 MFMA and the
+    bf16x6 mode (exact three-way bf16 split of both operands, six products, fp32 accumulate) to the same 2e-5."""
+    g = torch.Generator().manual_seed(77)
+    B, Cin, H, W, Cout = 2, 160, 21, 37, 192
+    x = torch.randn(B, Cin, H, W, generator=g) * 3
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.03
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(B, Cout, H, W, generator=g)
+    ref = F.relu(F.conv2d(F.relu(x), w, b, padding=1) + res)
+    pack = ops.pack_conv(w.to(DEV), b.to(DEV))
+    y = ops.conv2d([nhwc(x)], pack, relu_in=True, relu_out=True, residual=nhwc(res), plan=plan)
+    close(back(y), ref, 2e-5, 'conv2d plan %#x' % plan)
+    # three sources + GLU through the same plan (wn must be 2 for the gate pairing)
+    if (plan >> 4) & 15 == 2:
+        a, q, s = torch.randn(2, 64, 9, 14, generator=g), torch.randn(1, 64, 9, 14, generator=g), torch.rand(2, 32, 9, 14, generator=g)
+        wf, wa = torch.randn(64, 160, 3, 3, generator=g) * 0.05, torch.randn(64, 160, 3, 3, generator=g) * 0.05
+        bf, ba = torch.randn(64, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1
+        xin = torch.cat([a, q.expand(2, -1, -1, -1), s], 1)
+        ref = F.conv2d(xin, wf, bf, padding=1) * torch.sigmoid(F.conv2d(xin, wa, ba, padding=1))
+        y = ops.conv2d([nhwc(a), nhwc(q), nhwc(s)], ops.pack_glu(wf.to(DEV), bf.to(DEV), wa.to(DEV), ba.to(DEV)),
+                       batch=2, plan=plan)
+        close(back(y), ref, 2e-5, 'glu plan %#x' % plan)
