@@ -65,17 +65,14 @@ int swem_device_cus(void);
  *   w_bs    : 0 = one filter bank for the whole batch (every nn.Conv2d); else elements between the banks of
  *             consecutive batch items (a batched GEMM: the value readout of matching, modules.py:272-273);
  *             then Ho*Wo must be a multiple of the row tile (128 is always safe)
- *   w_bf16x3: NULL, or the same filters split into three bf16 planes [3][Cout'][KH*KW*Cin] with
- *             w = hi + mid + lo (round-to-nearest residuals); used by the bf16x6 math mode (plan bit 16), which
- *             otherwise splits the filters on the fly; ignored when w_bs != 0
  *   scale   : [Cout'] or NULL (=1)     -- folded BatchNorm  gamma/sqrt(var+eps)
  *   shift   : [Cout'] or NULL (=0)     -- conv bias and folded BatchNorm shift
  *   res     : NHWC [B][Ho][Wo][Cout] added after scale/shift, or NULL; res_bs as bsK
  *   y       : NHWC [B][Ho][Wo][Cout],  Ho = (H + 2*pad - KH)/stride + 1
  *   plan    : tiling hint, 0 = built-in heuristic; else  wm | wn << 4 | nsplit << 8 | math << 16  with wave tile
  *             (32*wm) x (32*wn) in {1x1, 1x2, 2x2}, nsplit K-splits, math 0 = fp32 MFMA, 1 = "bf16x6": operands
- *             split exactly into three bf16 terms, six bf16 MFMA products, fp32 accumulation (fp32-level error,
- *             2.7x the fp32-MFMA rate).  Results are identical up to fp32 rounding; callers may time candidates once
+ *             split exactly into three bf16 terms while they are staged, six bf16 MFMA products, fp32 accumulation
+ *             (fp32-level error, 2.7x the fp32-MFMA rate; swem_conv2d_nhwc_bf16x3 is the pre-split form).  Results are identical up to fp32 rounding; callers may time candidates once
  *             per layer shape and pass the fastest
  *   ws      : workspace for split-K partial sums (swem_conv2d_workspace bytes for the same plan)
  */
@@ -83,10 +80,25 @@ size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, int KH, int
                              int flags, int plan);
 int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
                          long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
-                         const float *w, long long w_bs, const void *w_bf16x3, const float *scale, const float *shift,
-                         const float *res,
+                         const float *w, long long w_bs, const float *scale, const float *shift, const float *res,
                          long long res_bs, float *y, int Cout, int KH, int KW, int stride, int pad, int flags,
                          int plan, void *ws, size_t ws_bytes);
+
+/* Pre-split operands for the bf16x6 math mode: x [npix][C] fp32 (C % 8 == 0) -> out: three bf16 planes, each
+ * channel-group major [C/8][npix][8], with x = hi + mid + lo exactly (three round-to-nearest bf16 terms = 24
+ * significant bits); relu != 0 splits relu(x) (the input ReLU of networks.py:26-27 then costs nothing in the conv). */
+int swem_split_bf16x3_f32(void *stream, const float *x, void *out, long long npix, int C, int relu);
+/* The same convolution as swem_conv2d_nhwc_f32 in bf16x6 math with PRE-SPLIT sources and filters: xK = plane 0 of
+ * source K in the layout above (npix = all pixels of its storage; bsK = fp32-element batch stride as before, a
+ * multiple of cK), psK = elements between its three planes (npix * cK), cK % 32 == 0;
+ * w_bf16x3 = three planes [K/8][Cout'][8], K = KH*KW*Cin ordered (ky, kx, ci).
+ * Every fragment goes HBM/L2 -> LDS by buffer-load-to-LDS (no register staging, no vector arithmetic in the k-loop).
+ * Output, scale/shift/residual/ReLU-out/GLU, plan and workspace as swem_conv2d_nhwc_f32 (math bit ignored). */
+int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1, int c1,
+                            long long bs1, long long ps1, const void *x2, int c2, long long bs2, long long ps2, int B,
+                            int H, int W, const void *w_bf16x3, const float *scale, const float *shift,
+                            const float *res, long long res_bs, float *y, int Cout, int KH, int KW, int stride,
+                            int pad, int flags, int plan, void *ws, size_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------
  * Pointwise / pooling / resampling kernels.

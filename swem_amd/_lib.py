@@ -18,8 +18,11 @@ SIGNATURES = {
     'swem_last_error': (C.c_char_p, []),
     'swem_device_cus': (_i, []),
     'swem_conv2d_workspace': (_sz, [_i] * 11),
-    'swem_conv2d_nhwc_f32': (_i, [_p, _p, _i, _ll, _p, _i, _ll, _p, _i, _ll, _i, _i, _i, _p, _ll, _p, _p, _p, _p, _ll, _p,
+    'swem_conv2d_nhwc_f32': (_i, [_p, _p, _i, _ll, _p, _i, _ll, _p, _i, _ll, _i, _i, _i, _p, _ll, _p, _p, _p, _ll, _p,
                                   _i, _i, _i, _i, _i, _i, _i, _p, _sz]),
+    'swem_split_bf16x3_f32': (_i, [_p, _p, _p, _ll, _i, _i]),
+    'swem_conv2d_nhwc_bf16x3': (_i, [_p, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _i, _i, _i, _p, _p, _p, _p, _ll,
+                                     _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz]),
     'swem_prep_key_input_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i]),
     'swem_prep_value_input_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i]),
     'swem_maxpool3x3s2_nhwc_f32': (_i, [_p, _p, _p, _i, _i, _i, _i]),

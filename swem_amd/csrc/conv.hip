@@ -38,6 +38,8 @@ struct ConvP {
   const float *w, *scale, *shift, *res;
   long long res_bs, w_bs;  // w_bs: elements between the filter banks of consecutive batch items (0 = shared)
   const unsigned short *wsplit;  // optional [3][Ncols][K] bf16: the filters pre-split into hi/mid/lo planes
+  const unsigned short *xs[3];   // pre-split activations (conv_igemm_bf3s_kernel): plane 0 of each source
+  long long ps[3];               // ... and the element stride between a source's three planes
   float *y;
   int Cout, Ncols, KH, KW, stride, pad, flags;
   int nkb, kb_per_split;
@@ -543,9 +545,9 @@ __device__ __forceinline__ uint2 bufload2(__amdgpu_buffer_rsrc_t rs, unsigned vo
   return make_uint2(v.x, v.y);
 }
 
-// PS: the filters arrive pre-split (three bf16 planes packed once per model), so only the activations are split here
-template <int WM, int WN, bool PS>
+template <int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(ConvP p) {
+  constexpr bool PS = false;  // (pre-split filters in this register-staged variant were measured slower: more loads)
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int RA = BM / 32, RB = BN / 32;
   constexpr int SA = BM + 1, SB = BN + 1;          // k/8-group strides in 16-byte slots (+1: conflict-free stores)
@@ -729,6 +731,183 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(ConvP p) {
   conv_epilogue<WM, WN>(p, acc, m0, n0, wm, wn, r, h);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// bf16x6 with PRE-SPLIT operands: activations and filters arrive as three bf16 planes each (swem_split_bf16x3_f32 /
+// weight packing), so one input element is split once per tensor instead of once per (tap, N tile) use.  The k-loop
+// then holds no vector arithmetic and no register staging at all: every 16-byte MFMA fragment row-run is moved
+// HBM/L2 -> LDS by the buffer unit itself (buffer_load_dwordx4 ... lds: 64 lanes x 16 B = 64 consecutive rows of one
+// [plane][k/8] image; padding taps use an out-of-range offset and land as zeros) while the waves read fragments and
+// issue MFMAs.  The planes are CHANNEL-GROUP MAJOR, [plane][C/8][pixel][8 bf16] (filters [plane][K/8][Cout][8]), so the
+// 64 lanes of one transfer read 64 consecutive 16-byte chunks = full cache lines (with NHWC planes each lane would
+// touch its own line: measured 80-100 instead of 115-125 TFLOP/s for the register-staged kernel).
+// 16 bytes per lane, global/L2 -> LDS without a register stop (buffer_load_dwordx4 ... lds): the 64 lanes of a wave land
+// in 64 consecutive 16-byte slots starting at the wave-uniform LDS address; out-of-range offsets land as zeros.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char *lds_dst, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the kernel's launch stub
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_dst, 16, voff, soff, 0, 0);
+#endif
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf3s_kernel(ConvP p) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int SA = BM + 1, SB = BN + 1;
+  constexpr int PA = 4 * SA, PB = 4 * SB;
+  constexpr int NA = 3 * 4 * WM, NB = 3 * 4 * WN;  // 64-row fragment runs per k-block
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4 *As = reinterpret_cast<uint4 *>(smem);  // [2][3][PA]
+  uint4 *Bs = As + 2 * 3 * PA;                  // [2][3][PB]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int tm, tn;
+  tile_coords(tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  auto src_rsrc = [&](int sidx) {
+    const unsigned short *base = sidx == 0 ? p.xs[0] : (sidx == 1 ? p.xs[1] : p.xs[2]);
+    const long long ps = sidx == 0 ? p.ps[0] : (sidx == 1 ? p.ps[1] : p.ps[2]);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(base), 0, (int)(3 * ps * 2), 0x00020000);
+  };
+  __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.wsplit), 0,
+                                                                 (int)((long long)3 * p.Ncols * p.K * 2), 0x00020000);
+  const unsigned wplane = (unsigned)((long long)p.Ncols * p.K * 2);
+  const unsigned wgroup = (unsigned)p.Ncols * 16u;  // bytes per k/8 group of the filter planes
+
+  // rows served by this lane: run j covers rows j*64 + lane of the A (pixels) and B (filters) tiles
+  int iy0[WM], ix0[WM], bidx[WM];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int j = 0; j < WM; ++j) {
+    int m = m0 + j * 64 + lane;
+    int b = m / HoWo;
+    int rem = m - b * HoWo;
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    iy0[j] = oy * p.stride - p.pad;
+    ix0[j] = ox * p.stride - p.pad;
+    bidx[j] = m < p.M ? b : -1;
+  }
+  unsigned bvoff[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    int n = n0 + j * 64 + lane;
+    bvoff[j] = n < p.Ncols ? (unsigned)n * 16u : OOB;
+  }
+  unsigned avoff[WM];
+  unsigned aplane = 0, agroup = 0;  // byte strides between the planes / the 8-channel groups of the current source
+  __amdgpu_buffer_rsrc_t rsa;
+  auto set_tap = [&](const KPos &q) {
+    const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
+    const long long bs = q.src == 0 ? p.bs[0] : (q.src == 1 ? p.bs[1] : p.bs[2]);
+#pragma unroll
+    for (int j = 0; j < WM; ++j) {
+      const int iy = iy0[j] + q.ky, ix = ix0[j] + q.kx;
+      const bool ok = bidx[j] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const long long pix = bidx[j] * (bs / cs) + (long long)iy * p.W + ix;  // pixel index in the source's storage
+      avoff[j] = ok ? (unsigned)(pix * 16) : OOB;
+    }
+    const long long ps = q.src == 0 ? p.ps[0] : (q.src == 1 ? p.ps[1] : p.ps[2]);
+    aplane = (unsigned)(ps * 2);
+    agroup = (unsigned)(ps / cs * 16);  // pixels in the plane * 16 bytes
+    rsa = src_rsrc(q.src);
+  };
+  auto advance = [&](KPos &q) {
+    q.ci0 += BK;
+    const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
+    if (q.ci0 >= cs) {
+      q.ci0 = 0;
+      ++q.src;
+      const int cn = q.src == 1 ? p.c[1] : (q.src == 2 ? p.c[2] : 0);
+      if (cn == 0) {
+        q.src = 0;
+        if (++q.kx == p.KW) {
+          q.kx = 0;
+          ++q.ky;
+        }
+      }
+      set_tap(q);
+    }
+  };
+  // each wave moves every 4th fragment run of the k-block: f -> (operand, plane, k/8 group, 64-row run)
+  auto issue = [&](const KPos &q, int kb, int buf) {
+#pragma unroll
+    for (int f0 = 0; f0 < NA + NB; f0 += 4) {
+      const int f = f0 + wave;
+      if (f < NA) {
+        const int j = f % WM, g = (f / WM) & 3, pl = f / (4 * WM);
+        const unsigned dst = ((buf * 3 + pl) * PA + g * SA + j * 64) * 16;
+        const unsigned soff = pl * aplane + (unsigned)(q.ci0 / 8 + g) * agroup;
+#pragma unroll
+        for (int jj = 0; jj < WM; ++jj)
+          if (jj == j) dma16(rsa, smem + dst, avoff[jj], soff);
+      } else if (f < NA + NB) {
+        const int fb = f - NA;
+        const int j = fb % WN, g = (fb / WN) & 3, pl = fb / (4 * WN);
+        const unsigned dst = (2 * 3 * PA + (buf * 3 + pl) * PB + g * SB + j * 64) * 16;
+        const unsigned soff = pl * wplane + (unsigned)(kb * (BK / 8) + g) * wgroup;
+#pragma unroll
+        for (int jj = 0; jj < WN; ++jj)
+          if (jj == j) dma16(rsw, smem + dst, bvoff[jj], soff);
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int kb_begin = blockIdx.z * p.kb_per_split;
+  const int kb_end = min(p.nkb, kb_begin + p.kb_per_split);
+  KPos q;
+  kpos_init(q, p, kb_begin);
+  set_tap(q);
+  issue(q, kb_begin, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int kb = kb_begin; kb < kb_end; ++kb) {
+    if (kb + 1 < kb_end) {
+      advance(q);
+      issue(q, kb + 1, buf ^ 1);
+    }
+    const uint4 *Ab = As + buf * 3 * PA + wm * 32 * WM + r;
+    const uint4 *Bb = Bs + buf * 3 * PB + wn * 32 * WN + r;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int k8 = 2 * s2 + h;
+      uint4 a[3][WM], b[3][WN];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[pl][i] = Ab[pl * PA + k8 * SA + 32 * i];
+#pragma unroll
+        for (int i = 0; i < WN; ++i) b[pl][i] = Bb[pl * PB + k8 * SB + 32 * i];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < WN; ++jn) {
+          f32x16 c = acc[i][jn];
+          c = mfma_bf16(a[0][i], b[2][jn], c);
+          c = mfma_bf16(a[2][i], b[0][jn], c);
+          c = mfma_bf16(a[1][i], b[1][jn], c);
+          c = mfma_bf16(a[0][i], b[1][jn], c);
+          c = mfma_bf16(a[1][i], b[0][jn], c);
+          c = mfma_bf16(a[0][i], b[0][jn], c);
+          acc[i][jn] = c;
+        }
+    }
+    __syncthreads();  // drains this wave's LDS-DMA (vmcnt) and orders it against every wave's fragment reads
+    buf ^= 1;
+  }
+  conv_epilogue<WM, WN>(p, acc, m0, n0, wm, wn, r, h);
+}
+
 // Reduce split-K partials in z order and apply the same epilogue.  One thread per 4 output channels.
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int nsplit) {
   const bool glu = p.flags & SWEM_CONV_GLU;
@@ -837,13 +1016,16 @@ int launch_pipe(const ConvP &p, dim3 grid, hipStream_t st) {
 template <int WM, int WN>
 int launch_bf3(const ConvP &p, dim3 grid, hipStream_t st) {
   constexpr size_t lds = 2 * 3 * 4 * (64 * WM + 1 + 64 * WN + 1) * 16;
-  if (p.wsplit) {
-    SWEM_ALLOW_LDS((conv_igemm_bf3_kernel<WM, WN, true>), lds);
-    hipLaunchKernelGGL((conv_igemm_bf3_kernel<WM, WN, true>), grid, dim3(256), lds, st, p);
-  } else {
-    SWEM_ALLOW_LDS((conv_igemm_bf3_kernel<WM, WN, false>), lds);
-    hipLaunchKernelGGL((conv_igemm_bf3_kernel<WM, WN, false>), grid, dim3(256), lds, st, p);
-  }
+  SWEM_ALLOW_LDS((conv_igemm_bf3_kernel<WM, WN>), lds);
+  hipLaunchKernelGGL((conv_igemm_bf3_kernel<WM, WN>), grid, dim3(256), lds, st, p);
+  return SWEM_OK;
+}
+
+template <int WM, int WN>
+int launch_bf3s(const ConvP &p, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = 2 * 3 * 4 * (64 * WM + 1 + 64 * WN + 1) * 16;
+  SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN>), lds);
+  hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN>), grid, dim3(256), lds, st, p);
   return SWEM_OK;
 }
 
@@ -886,8 +1068,7 @@ extern "C" size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, 
 
 extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
                                     long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
-                                    const float *w, long long w_bs, const void *w_bf16x3, const float *scale,
-                                    const float *shift,
+                                    const float *w, long long w_bs, const float *scale, const float *shift,
                                     const float *res, long long res_bs, float *y, int Cout, int KH, int KW, int stride,
                                     int pad, int flags, int plan, void *ws, size_t ws_bytes) {
   SWEM_REQUIRE(x0 && w && y, SWEM_E_ARG, "conv2d: null pointer");
@@ -915,7 +1096,7 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
   SWEM_REQUIRE(M < (1ll << 31) && M * (glu ? 2 * Cout : Cout) < (1ll << 40), SWEM_E_SHAPE, "conv2d: too large");
   p.M = (int)M;
   p.w = w; p.scale = scale; p.shift = shift; p.res = res; p.res_bs = res_bs; p.w_bs = w_bs; p.y = y;
-  p.wsplit = w_bs == 0 ? static_cast<const unsigned short *>(w_bf16x3) : nullptr;
+  p.wsplit = nullptr;
   p.Cout = Cout; p.Ncols = glu ? 2 * Cout : Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.flags = flags;
   {
@@ -972,6 +1153,106 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
   }
   if (rc) return rc;
   SWEM_CHECK_LAUNCH("conv_igemm_kernel");
+  if (pl.nsplit > 1) {
+    long long work = M * (Cout / 4);
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(cdiv(work, 256)), dim3(256), 0, st, p, pl.nsplit);
+    SWEM_CHECK_LAUNCH("conv_splitk_epilogue_kernel");
+  }
+  return SWEM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+// x [npix][C] fp32 -> three bf16 planes [C/8][npix][8] with x = hi + mid + lo (optionally of relu(x)).
+// One thread per (channel group, pixel), pixel fastest: every store is a coalesced 16-byte chunk of the plane.
+__global__ void split_bf16x3_kernel(const float *__restrict__ x, unsigned short *__restrict__ out, long long npix, int C,
+                                    int relu) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = npix * (C / 8);
+  if (i >= total) return;
+  const long long cg = i / npix, pix = i - cg * npix;
+  const float *src = x + pix * C + cg * 8;
+  float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 4);
+  if (relu) {
+    v0 = relu4(v0);
+    v1 = relu4(v1);
+  }
+  uint2 h0, m0, l0, h1, m1, l1;
+  split3(v0, h0, m0, l0);
+  split3(v1, h1, m1, l1);
+  const long long plane = npix * C;
+  *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+  *reinterpret_cast<uint4 *>(out + 2 * plane + i * 8) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+}  // namespace
+
+extern "C" int swem_split_bf16x3_f32(void *stream, const float *x, void *out, long long npix, int C, int relu) {
+  SWEM_REQUIRE(x && out && npix > 0 && C > 0 && C % 8 == 0, SWEM_E_ARG, "split_bf16x3: need C %% 8 == 0");
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)cdiv(npix * (C / 8), 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, static_cast<unsigned short *>(out), npix, C, relu);
+  SWEM_CHECK_LAUNCH("split_bf16x3");
+  return SWEM_OK;
+}
+
+extern "C" int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0, long long ps0,
+                                       const void *x1, int c1, long long bs1, long long ps1, const void *x2, int c2,
+                                       long long bs2, long long ps2, int B, int H, int W, const void *w_bf16x3,
+                                       const float *scale, const float *shift, const float *res, long long res_bs,
+                                       float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan,
+                                       void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(x0 && w_bf16x3 && y, SWEM_E_ARG, "conv2d_bf16x3: null pointer");
+  if (!x1) c1 = 0;
+  if (!x2) c2 = 0;
+  SWEM_REQUIRE(!(x2 && !x1), SWEM_E_ARG, "conv2d_bf16x3: source 2 without source 1");
+  SWEM_REQUIRE(c0 > 0 && c0 % 32 == 0 && c1 % 32 == 0 && c2 % 32 == 0, SWEM_E_SHAPE,
+               "conv2d_bf16x3: every source needs a channel count that is a multiple of 32 (got %d,%d,%d)", c0, c1, c2);
+  SWEM_REQUIRE(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, SWEM_E_SHAPE,
+               "conv2d_bf16x3: bad geometry");
+  SWEM_REQUIRE(Cout > 0 && Cout % 4 == 0 && !(flags & SWEM_CONV_RELU_IN), SWEM_E_SHAPE,
+               "conv2d_bf16x3: Cout %% 4 != 0, or RELU_IN (apply the ReLU when splitting the input)");
+  const bool glu = flags & SWEM_CONV_GLU;
+  SWEM_REQUIRE(!glu || (Cout % 32 == 0 && !res), SWEM_E_SHAPE, "conv2d_bf16x3: GLU needs Cout %% 32 == 0, no residual");
+  ConvP p;
+  p.x[0] = p.x[1] = p.x[2] = nullptr;
+  p.xs[0] = static_cast<const unsigned short *>(x0);
+  p.xs[1] = static_cast<const unsigned short *>(x1 ? x1 : x0);
+  p.xs[2] = static_cast<const unsigned short *>(x2 ? x2 : x0);
+  p.ps[0] = ps0; p.ps[1] = x1 ? ps1 : ps0; p.ps[2] = x2 ? ps2 : ps0;
+  p.c[0] = c0; p.c[1] = c1; p.c[2] = c2;
+  p.bs[0] = bs0; p.bs[1] = bs1; p.bs[2] = bs2;
+  SWEM_REQUIRE(ps0 * 6 < (1ll << 31) && p.ps[1] * 6 < (1ll << 31) && p.ps[2] * 6 < (1ll << 31), SWEM_E_SHAPE,
+               "conv2d_bf16x3: a source exceeds the 2 GiB buffer-descriptor range");
+  p.B = B; p.H = H; p.W = W;
+  p.Ho = (H + 2 * pad - KH) / stride + 1;
+  p.Wo = (W + 2 * pad - KW) / stride + 1;
+  SWEM_REQUIRE(p.Ho > 0 && p.Wo > 0, SWEM_E_SHAPE, "conv2d_bf16x3: empty output");
+  p.Cin = c0 + c1 + c2;
+  p.K = KH * KW * p.Cin;
+  long long M = (long long)B * p.Ho * p.Wo;
+  SWEM_REQUIRE(M < (1ll << 31), SWEM_E_SHAPE, "conv2d_bf16x3: too large");
+  p.M = (int)M;
+  p.w = nullptr; p.wsplit = static_cast<const unsigned short *>(w_bf16x3);
+  p.scale = scale; p.shift = shift; p.res = res; p.res_bs = res_bs; p.w_bs = 0; p.y = y;
+  p.Cout = Cout; p.Ncols = glu ? 2 * Cout : Cout;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.flags = flags;
+  p.nkb = cdiv(p.K, BK);
+  Plan pl = resolve_plan(plan, p.M, p.Ncols, p.nkb, glu);
+  p.kb_per_split = pl.kb_per_split;
+  p.partial = nullptr;
+  if (pl.nsplit > 1) {
+    size_t need = (size_t)pl.nsplit * M * p.Ncols * sizeof(float);
+    SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_bf16x3: workspace %zu < %zu bytes", ws_bytes, need);
+    p.partial = static_cast<float *>(ws);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 grid(cdiv(p.M, 64 * pl.wm), cdiv(p.Ncols, 64 * pl.wn), pl.nsplit);
+  int rc;
+  if (pl.wm == 2 && pl.wn == 2) rc = launch_bf3s<2, 2>(p, grid, st);
+  else if (pl.wm == 1 && pl.wn == 2) rc = launch_bf3s<1, 2>(p, grid, st);
+  else rc = launch_bf3s<1, 1>(p, grid, st);
+  if (rc) return rc;
+  SWEM_CHECK_LAUNCH("conv_igemm_bf3s_kernel");
   if (pl.nsplit > 1) {
     long long work = M * (Cout / 4);
     hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(cdiv(work, 256)), dim3(256), 0, st, p, pl.nsplit);

@@ -347,7 +347,7 @@ extern "C" int swem_em_mstep_f32(void *stream, const float *A, int a_batch_div, 
   // S[n] = A[n] . [z_bg | z_fg]^T : a batched GEMM on the conv kernel: an R x 1 "image" with Pp channels per object
   // (A shared by all objects when a_batch_div == 0), 2L 1x1 filters per object = its two classes' rows of zT
   int rc = swem_conv2d_nhwc_f32(stream, A, Pp, a_batch_div ? (long long)R * Pp : 0, nullptr, 0, 0, nullptr, 0, 0, N, R, 1,
-                                zT, (long long)2 * L * Pp, nullptr, nullptr, nullptr, nullptr, 0, S, 2 * L, 1, 1, 1, 0, 0, 0,
+                                zT, (long long)2 * L * Pp, nullptr, nullptr, nullptr, 0, S, 2 * L, 1, 1, 1, 0, 0, 0,
                                 base + w.conv, w.zt - w.conv);
   if (rc) return rc;
   hipLaunchKernelGGL(em_zsum_kernel, dim3(cdiv(NK * L, 4)), dim3(256), 0, ST, zT, zita_prev, zt, zita_out, NK * L, Pp);

@@ -267,6 +267,6 @@ extern "C" int swem_match_f32(void *stream, const float *qk, const float *kappa_
   // value readout (modules.py:272-273) = batched GEMM  mem_out[n] = pT[n] . mvp[n]^T  on the conv kernel:
   // "image" of Pm x 1 pixels with Ltot channels, 1x1 filters = the V value rows of object n (w_bs = V*Ltot)
   return swem_conv2d_nhwc_f32(stream, pT, Ltot, (long long)Pm * Ltot, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, mvp,
-                              (long long)V * Ltot, nullptr, nullptr, nullptr, nullptr, 0, mem_out, V, 1, 1, 1, 0, 0,
+                              (long long)V * Ltot, nullptr, nullptr, nullptr, 0, mem_out, V, 1, 1, 1, 0, 0,
                               readout_plan, base + w.conv, w.total - w.conv);
 }

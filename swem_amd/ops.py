@@ -60,7 +60,9 @@ class ConvPack:
         self.cout, self.kh, self.kw, self.stride, self.pad, self.glu = cout, kh, kw, stride, pad, glu
         self.cin = w.shape[-1]
         self.cin_true = self.cin          # channels of the reference conv (without layout padding)
-        self.w3 = split_bf16x3(w)         # the same filters as three bf16 planes (bf16x6 math mode)
+        co, kk = w.shape[0], w.shape[1] * w.shape[2] * w.shape[3]
+        # the same filters as three bf16 planes, k/8-group major [K/8][Cout'][8] (bf16x6 math mode, pre-split form)
+        self.w3 = split_bf16x3(w.reshape(co, kk // 8, 8).permute(1, 0, 2).contiguous()) if kk % 8 == 0 else None
 
 
 def split_bf16x3(w):
@@ -118,6 +120,23 @@ def _chk_src(t):
     return t
 
 
+def presplit(t, relu=False):
+    """Three bf16 planes, each [C/8][npix][8], of an NHWC fp32 activation with t = hi + mid + lo (of relu(t) if asked),
+    computed once per tensor and cached on it: conv inputs are never modified after they are produced.  npix covers the
+    tensor's storage range (a batch stride larger than one image, as match's mem_out has, is kept)."""
+    cache = t.__dict__.setdefault('_swem_split', {})
+    sp = cache.get(relu)
+    if sp is None:
+        B, H, W, Cc = t.shape
+        if B > 1 and t.stride(0) % Cc:
+            raise _lib.SwemHipError('presplit: batch stride must be a multiple of the channel count')
+        npix = (B - 1) * (t.stride(0) // Cc) + H * W if B > 1 else H * W
+        sp = torch.empty((3, npix * Cc), dtype=torch.bfloat16, device=t.device)
+        _lib.call('swem_split_bf16x3_f32', _stream(), t.data_ptr(), sp.data_ptr(), npix, Cc, int(relu))
+        cache[relu] = sp
+    return sp
+
+
 def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadcast=False, batch=None, out=None,
            plan=None):
     """srcs: list of up to three NHWC tensors concatenated on C; a source with batch 1 is broadcast over `batch`.
@@ -147,12 +166,27 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         _chk(residual, 'conv residual')
         res_bs = 0 if (res_broadcast or (residual.shape[0] == 1 and B > 1)) else Ho * Wo * pack.cout
 
-    def launch(plan):
+    presplit_ok = pack.w3 is not None and all(s_.shape[3] % 32 == 0 for s_ in srcs)
+
+    def launch(plan, fresh=False):
         wsb = _lib.query('swem_conv2d_workspace', B, H, W, cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad,
                          flags, plan)
         ws = workspace(wsb, x0.device) if wsb else None
-        _lib.call('swem_conv2d_nhwc_f32', _stream(), *args, B, H, W, pack.w.data_ptr(), 0, pack.w3.data_ptr(),
-                  _ptr(pack.scale),
+        if (plan >> 16) & 1 and presplit_ok:
+            # bf16x6 math: sources split once per tensor (input ReLU folded into the split), filters split at pack time
+            sargs = []
+            for i, s_ in enumerate(srcs):
+                if fresh:
+                    s_.__dict__.pop('_swem_split', None)
+                sp = presplit(s_, relu_in)
+                sargs += [sp.data_ptr(), s_.shape[3], args[3 * i + 2], sp.stride(0)]
+            for _ in range(3 - len(srcs)):
+                sargs += [0, 0, 0, 0]
+            _lib.call('swem_conv2d_nhwc_bf16x3', _stream(), *sargs, B, H, W, pack.w3.data_ptr(), _ptr(pack.scale),
+                      _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw,
+                      pack.stride, pack.pad, flags & ~RELU_IN, plan, _ptr(ws), wsb)
+            return
+        _lib.call('swem_conv2d_nhwc_f32', _stream(), *args, B, H, W, pack.w.data_ptr(), 0, _ptr(pack.scale),
                   _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw, pack.stride,
                   pack.pad, flags, plan, _ptr(ws), wsb)
 
@@ -161,7 +195,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     plan = plan if explicit else _CONV_PLANS.get(sig, 0)
     if AUTOTUNE and not explicit and plan == 0 and not torch.cuda.is_current_stream_capturing():
         plan = _CONV_PLANS[sig] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
-                                                 -(-pack.kh * pack.kw * cin // 32), pack.glu)
+                                            -(-pack.kh * pack.kw * cin // 32), pack.glu, fresh_kw=True)
     if CONV_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -174,8 +208,10 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     return y
 
 
-def _autotune(launch, M, ncols, nkb, glu, reps=3):
-    """Time candidate (wave tile, K-split) plans for one layer shape; return the fastest as a plan hint."""
+def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
+    """Time candidate (wave tile, K-split, math mode) plans for one layer shape; return the fastest as a plan hint.
+    fresh_kw: the launcher takes fresh=True to re-split its inputs every time (the split cost is then part of the
+    bf16x6 candidates' time, as if no other layer shared the input)."""
     cands = [0]
     for wm, wn in _TUNE_TILES:
         if (glu and wn != 2) or (wn == 2 and ncols < 128):
@@ -192,7 +228,7 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            launch(plan)
+            launch(plan, True) if fresh_kw else launch(plan)
         e1.record()
         e1.synchronize()
         t = e0.elapsed_time(e1)

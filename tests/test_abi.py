@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 def test_version_and_error_channel(lib):
     assert lib.swem_version() == 1
     # argument validation happens before any HIP call, so it can be exercised without a GPU
-    rc = lib.swem_conv2d_nhwc_f32(None, None, 4, 0, None, 0, 0, None, 0, 0, 1, 8, 8, None, 0, None, None, None, None, 0, None,
+    rc = lib.swem_conv2d_nhwc_f32(None, None, 4, 0, None, 0, 0, None, 0, 0, 1, 8, 8, None, 0, None, None, None, 0, None,
                                   32, 3, 3, 1, 1, 0, 0, None, 0)
     assert rc == -4 and b'null pointer' in lib.swem_last_error()
     rc = lib.swem_match_f32(None, 1, 1, 1, None, None, 1, 1, 1, 128, 512, 100, 100, 64, ctypes.c_float(0.05), 0, None, 0)

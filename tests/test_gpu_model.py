@@ -116,6 +116,17 @@ def test_stages_vs_oracle(lib, kw, h, w, n_obj):
         assert logits_close(l2, ol2, tol)
 
 
+def test_stages_vs_oracle_with_tuned_plans(lib):
+    """The bench configuration: per-layer plans chosen by the on-device autotuner, which mixes the fp32-MFMA kernel and
+    the bf16x6 mode (exact 3-way bf16 split, pre-split operands moved by LDS-DMA).  Same stage-by-stage bars as above."""
+    ops.AUTOTUNE = True
+    try:
+        test_stages_vs_oracle(lib, CFG_B, 480, 864, 2)
+    finally:
+        ops.AUTOTUNE = False
+    assert any((p >> 16) & 1 for p in ops._CONV_PLANS.values()), 'the tuner never picked the bf16x6 mode'
+
+
 def _run_fixture(golden, name, kw, sub):
     fx = golden(name)
     cfg = O.make_cfg(**kw)

@@ -29,6 +29,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--only', type=int, default=-1)
+    ap.add_argument('--plan', type=lambda v: int(v, 0), default=None, help='explicit plan hint, e.g. 0x10021')
+    ap.add_argument('--fresh', action='store_true', help='re-split the input every launch (bf16x6 plans)')
     a = ap.parse_args()
     dev = 'cuda:0'
     print('plan=%s' % os.environ.get('SWEM_CONV_PLAN', 'auto'))
@@ -37,13 +39,17 @@ def main():
             continue
         x = torch.randn(B, H, W, ci, device=dev)
         pack = ops.pack_conv(torch.randn(co, ci, k, k, device=dev) * 0.02, torch.zeros(co, device=dev), None, s, k // 2)
+        def run():
+            if a.fresh:
+                x.__dict__.pop('_swem_split', None)
+            return ops.conv2d([x], pack, relu_in=relu, plan=a.plan)
         for _ in range(3):
-            y = ops.conv2d([x], pack, relu_in=relu)
+            y = run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.reps):
-            y = ops.conv2d([x], pack, relu_in=relu)
+            y = run()
         e1.record()
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / a.reps
