@@ -108,6 +108,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--objects', type=int, default=N_OBJ)
     ap.add_argument('--no-autotune', action='store_true')
+    ap.add_argument('--save-plans', default=None, help='write the tuned per-layer plans to this JSON file')
+    ap.add_argument('--load-plans', default=None, help='reuse plans from this file (no tuning; for profiler runs)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--seqs', type=int, default=2,
                     help='independent sequences processed concurrently per GPU, each on its own HIP stream')
@@ -135,7 +137,9 @@ def main():
     cfg = O.make_cfg(**CFG)
     n_obj = args.objects
     nseq = max(1, args.seqs)
-    ops.AUTOTUNE = not args.no_autotune     # per-layer tiling / K-split chosen by timing, during warm-up only
+    if args.load_plans:
+        ops.load_plans(args.load_plans)
+    ops.AUTOTUNE = not args.no_autotune and not args.load_plans   # per-layer plan chosen by timing, during warm-up only
     runners, streams = [], []
     sd = None
     for si in range(nseq):
@@ -165,6 +169,8 @@ def main():
         streams.append(st)
     runner = runners[0]
     frames_cpu, m0_cpu = frames0_cpu, m0_0_cpu
+    if args.save_plans and rank == 0:
+        ops.save_plans(args.save_plans)
 
     def step_all():
         if nseq == 1:
@@ -237,13 +243,15 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         out['roofline'] = {
-            'bound': 'mfma', 'kernel': 'conv_igemm_kernel (+ split-K epilogue)', 'achieved': round(ach, 2),
+            'bound': 'mfma', 'kernel': 'implicit-GEMM conv family: conv_igemm_bf3s (bf16x6, pre-split, LDS-DMA) / conv_igemm_pipe (fp32 MFMA) / stems, + operand split and split-K reduce kernels', 'achieved': round(ach, 2),
             'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
             'traffic': traffic, 'launches_per_frame': len(tr) // nprof,
             'avg_launch_us': round(1e3 * ms / len(tr), 2), 'gflop_per_launch': round(flops / len(tr) / 1e9, 3),
             'conv_ms_per_frame': round(ms / nprof, 3),
             'note': 'useful conv FLOPs (2*M*Cout*KH*KW*Cin, unpadded) of %d frames / summed per-launch HIP-event '
-                    'durations; peak = fp32 matrix (v_mfma_f32_32x32x2_f32)' % nprof + tnote}
+                    'durations (operand-split and split-K reduce launches included); peak = fp32 matrix rate (the arithmetic is fp32-accurate); '
+                    'layers the tuner runs in bf16x6 mode execute 6 bf16-MFMA products per fp32 product, their own ceiling is 2500/6 = 417 TFLOP/s' % nprof + tnote,
+            'plans_bf16x6': sum(1 for v in ops._CONV_PLANS.values() if (v >> 16) & 1), 'plans_total': len(ops._CONV_PLANS)}
         # EM / matching: capture the arguments of one real memorize + match call, then time 20 back-to-back
         # repetitions of each with HIP events (queue kept full, so this is device time, not host launch time)
         orig_mem, orig_match = ops.memorize, ops.match

@@ -208,6 +208,22 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     return y
 
 
+def save_plans(path):
+    """Persist the tuned plans (profiling runs reload them instead of re-tuning under the profiler)."""
+    import json
+    with open(path, 'w') as f:
+        json.dump({'conv': [[list(k), v] for k, v in _CONV_PLANS.items()],
+                   'match': [[list(k), v] for k, v in _MATCH_PLANS.items()]}, f)
+
+
+def load_plans(path):
+    import json
+    with open(path) as f:
+        d = json.load(f)
+    _CONV_PLANS.update({tuple(k): v for k, v in d.get('conv', [])})
+    _MATCH_PLANS.update({tuple(k): v for k, v in d.get('match', [])})
+
+
 def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
     """Time candidate (wave tile, K-split, math mode) plans for one layer shape; return the fastest as a plan hint.
     fresh_kw: the launcher takes fresh=True to re-split its inputs every time (the split cost is then part of the
