@@ -741,22 +741,49 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(ConvP p) {
 // 64 lanes of one transfer read 64 consecutive 16-byte chunks = full cache lines (with NHWC planes each lane would
 // touch its own line: measured 80-100 instead of 115-125 TFLOP/s for the register-staged kernel).
 // 16 bytes per lane, global/L2 -> LDS without a register stop (buffer_load_dwordx4 ... lds): the 64 lanes of a wave land
-// in 64 consecutive 16-byte slots starting at the wave-uniform LDS address; out-of-range offsets land as zeros.
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char *lds_dst, unsigned voff, unsigned soff) {
+// in 64 consecutive 16-byte slots starting at the wave-uniform LDS address in M0; out-of-range offsets land as zeros.
+// Inline asm on purpose: with the builtin, hipcc counts the transfer as an LDS write of unknown address and puts
+// s_waitcnt vmcnt(0) in front of the next ds_read, which drains the ring every k-block; here the only waits are the
+// counted ones in the kernel.  M0 is saved and restored (compiler-reserved); s_nop 4 covers a descriptor or offset SGPR
+// written just before.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// raw buffer descriptor: base, stride 0, byte range, raw 32-bit data format
+__device__ __forceinline__ i32x4 raw_rsrc(const void *base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4 r;
+  r[0] = (int)(unsigned)a;
+  r[1] = (int)(unsigned)((a >> 32) & 0xffffu);
+  r[2] = (int)bytes;
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void dma16(i32x4 r4, char *lds_dst, unsigned voff, unsigned soff) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the kernel's launch stub
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_dst, 16, voff, soff, 0, 0);
+  const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds_dst;
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(lds_addr), "s"(r4), "s"(soff)
+      : "memory");
 #endif
 }
 
-template <int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_bf3s_kernel(ConvP p) {
+template <int WM, int WN, int NST, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kernel(ConvP p) {
+  // block tile 64WM x 64WN, NW waves as an (NW/2) x 2 grid, each owning TM x TN 32x32 accumulator tiles
   constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int TM = 4 * WM / NW, TN = WN;
+  static_assert(TM >= 1 && TM * (NW / 2) * 32 == BM, "wave grid must tile the block");
   constexpr int SA = BM + 1, SB = BN + 1;
   constexpr int PA = 4 * SA, PB = 4 * SB;
   constexpr int NA = 3 * 4 * WM, NB = 3 * 4 * WN;  // 64-row fragment runs per k-block
+  // NST LDS stages: the transfers run NST-1 k-blocks ahead of the MFMAs
+  constexpr int NDMA = (NA + NB) / NW;             // transfers per wave per k-block
+  static_assert((NA + NB) % NW == 0, "every wave must issue the same number of transfers (counted vmcnt)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint4 *As = reinterpret_cast<uint4 *>(smem);  // [2][3][PA]
-  uint4 *Bs = As + 2 * 3 * PA;                  // [2][3][PB]
+  uint4 *As = reinterpret_cast<uint4 *>(smem);  // [NST][3][PA]
+  uint4 *Bs = As + NST * 3 * PA;                // [NST][3][PB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -769,10 +796,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3s_kernel(ConvP p) {
   auto src_rsrc = [&](int sidx) {
     const unsigned short *base = sidx == 0 ? p.xs[0] : (sidx == 1 ? p.xs[1] : p.xs[2]);
     const long long ps = sidx == 0 ? p.ps[0] : (sidx == 1 ? p.ps[1] : p.ps[2]);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(base), 0, (int)(3 * ps * 2), 0x00020000);
+    return raw_rsrc(base, (unsigned)(3 * ps * 2));
   };
-  __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.wsplit), 0,
-                                                                 (int)((long long)3 * p.Ncols * p.K * 2), 0x00020000);
+  const i32x4 rsw = raw_rsrc(p.wsplit, (unsigned)((long long)3 * p.Ncols * p.K * 2));
   const unsigned wplane = (unsigned)((long long)p.Ncols * p.K * 2);
   const unsigned wgroup = (unsigned)p.Ncols * 16u;  // bytes per k/8 group of the filter planes
 
@@ -797,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3s_kernel(ConvP p) {
   }
   unsigned avoff[WM];
   unsigned aplane = 0, agroup = 0;  // byte strides between the planes / the 8-channel groups of the current source
-  __amdgpu_buffer_rsrc_t rsa;
+  i32x4 rsa;
   auto set_tap = [&](const KPos &q) {
     const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
     const long long bs = q.src == 0 ? p.bs[0] : (q.src == 1 ? p.bs[1] : p.bs[2]);
@@ -833,7 +859,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3s_kernel(ConvP p) {
   // each wave moves every 4th fragment run of the k-block: f -> (operand, plane, k/8 group, 64-row run)
   auto issue = [&](const KPos &q, int kb, int buf) {
 #pragma unroll
-    for (int f0 = 0; f0 < NA + NB; f0 += 4) {
+    for (int f0 = 0; f0 < NA + NB; f0 += NW) {
       const int f = f0 + wave;
       if (f < NA) {
         const int j = f % WM, g = (f / WM) & 3, pl = f / (4 * WM);
@@ -845,7 +871,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3s_kernel(ConvP p) {
       } else if (f < NA + NB) {
         const int fb = f - NA;
         const int j = fb % WN, g = (fb / WN) & 3, pl = fb / (4 * WN);
-        const unsigned dst = (2 * 3 * PA + (buf * 3 + pl) * PB + g * SB + j * 64) * 16;
+        const unsigned dst = (NST * 3 * PA + (buf * 3 + pl) * PB + g * SB + j * 64) * 16;
         const unsigned soff = pl * wplane + (unsigned)(kb * (BK / 8) + g) * wgroup;
 #pragma unroll
         for (int jj = 0; jj < WN; ++jj)
@@ -854,44 +880,60 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3s_kernel(ConvP p) {
     }
   };
 
-  f32x16 acc[WM][WN];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < WM; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < WN; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int kb_begin = blockIdx.z * p.kb_per_split;
   const int kb_end = min(p.nkb, kb_begin + p.kb_per_split);
+  // Ring of NST stages.  In iteration kb the transfers of block kb+NST-1 are issued into the stage that was read in
+  // iteration kb-1, the MFMAs run on stage kb%NST, then a COUNTED wait (all but the newest (NST-2)*NDMA transfers of
+  // this wave, i.e. everything up to block kb+1) and a raw s_barrier publish stage (kb+1)%NST.  __syncthreads() would
+  // drain vmcnt(0) and serialise the ~1-2 us L2/MALL -> LDS latency with every 0.3 us of MFMA work.
   KPos q;
   kpos_init(q, p, kb_begin);
   set_tap(q);
   issue(q, kb_begin, 0);
-  __syncthreads();
-  int buf = 0;
-  for (int kb = kb_begin; kb < kb_end; ++kb) {
-    if (kb + 1 < kb_end) {
+  if (NST == 3) {
+    if (kb_begin + 1 < kb_end) {
       advance(q);
-      issue(q, kb + 1, buf ^ 1);
+      issue(q, kb_begin + 1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    const uint4 *Ab = As + buf * 3 * PA + wm * 32 * WM + r;
-    const uint4 *Bb = Bs + buf * 3 * PB + wn * 32 * WN + r;
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  int st = 0;
+  for (int kb = kb_begin; kb < kb_end; ++kb) {
+    const bool ahead = kb + NST - 1 < kb_end;
+    if (ahead) {
+      advance(q);
+      issue(q, kb + NST - 1, st == 0 ? NST - 1 : st - 1);  // stage (kb+NST-1) % NST
+    }
+    const uint4 *Ab = As + st * 3 * PA + wm * 32 * TM + r;
+    const uint4 *Bb = Bs + st * 3 * PB + wn * 32 * TN + r;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int k8 = 2 * s2 + h;
-      uint4 a[3][WM], b[3][WN];
+      uint4 a[3][TM], b[3][TN];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) a[pl][i] = Ab[pl * PA + k8 * SA + 32 * i];
+        for (int i = 0; i < TM; ++i) a[pl][i] = Ab[pl * PA + k8 * SA + 32 * i];
 #pragma unroll
-        for (int i = 0; i < WN; ++i) b[pl][i] = Bb[pl * PB + k8 * SB + 32 * i];
+        for (int i = 0; i < TN; ++i) b[pl][i] = Bb[pl * PB + k8 * SB + 32 * i];
       }
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int jn = 0; jn < WN; ++jn) {
+        for (int jn = 0; jn < TN; ++jn) {
           f32x16 c = acc[i][jn];
           c = mfma_bf16(a[0][i], b[2][jn], c);
           c = mfma_bf16(a[2][i], b[0][jn], c);
@@ -902,10 +944,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3s_kernel(ConvP p) {
           acc[i][jn] = c;
         }
     }
-    __syncthreads();  // drains this wave's LDS-DMA (vmcnt) and orders it against every wave's fragment reads
-    buf ^= 1;
+    // block kb+1 must have landed (this wave's share); with three stages block kb+2 may stay in flight
+    if (NST == 3 && ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of stage st are done
+    __builtin_amdgcn_s_barrier();
+    st = st == NST - 1 ? 0 : st + 1;
   }
-  conv_epilogue<WM, WN>(p, acc, m0, n0, wm, wn, r, h);
+  conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, r, h);
 }
 
 // Reduce split-K partials in z order and apply the same epilogue.  One thread per 4 output channels.
@@ -1021,12 +1067,24 @@ int launch_bf3(const ConvP &p, dim3 grid, hipStream_t st) {
   return SWEM_OK;
 }
 
-template <int WM, int WN>
-int launch_bf3s(const ConvP &p, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = 2 * 3 * 4 * (64 * WM + 1 + 64 * WN + 1) * 16;
-  SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN>), lds);
-  hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN>), grid, dim3(256), lds, st, p);
+template <int WM, int WN, int NST, int NW>
+int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = NST * 3 * 4 * (64 * WM + 1 + 64 * WN + 1) * 16;  // NST stages x 3 planes
+  SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW>), lds);
+  hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW>), grid, dim3(64 * NW), lds, st, p);
   return SWEM_OK;
+}
+
+// variant (plan bits 20-23): 0 = the tile's default; 1 = three LDS stages instead of two (or two instead of three);
+// 2 = eight waves on the 128x128 tile (two stages), 3 = eight waves, three stages
+template <int WM, int WN>
+int launch_bf3s(const ConvP &p, dim3 grid, hipStream_t st, int variant) {
+  if constexpr (WM == 2 && WN == 2) {
+    if (variant == 2) return launch_bf3s_n<2, 2, 2, 8>(p, grid, st);
+    if (variant == 3) return launch_bf3s_n<2, 2, 3, 8>(p, grid, st);
+  }
+  const bool three = (WM * WN == 1) != (variant == 1);
+  return three ? launch_bf3s_n<WM, WN, 3, 4>(p, grid, st) : launch_bf3s_n<WM, WN, 2, 4>(p, grid, st);
 }
 
 template <int WM, int WN, bool DB>
@@ -1039,7 +1097,7 @@ int launch(const ConvP &p, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
-// plan hint: 0 = heuristic; else wm | wn << 4 | nsplit << 8 | math << 16 (swem_hip.h)
+// plan hint: 0 = heuristic; else wm | wn << 4 | nsplit << 8 | math << 16 | variant << 20 (swem_hip.h)
 Plan resolve_plan(int plan, int M, int Ncols, int nkb, bool glu) {
   plan &= 0xffff;
   if (plan > 0) {
@@ -1248,9 +1306,10 @@ extern "C" int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, lon
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(cdiv(p.M, 64 * pl.wm), cdiv(p.Ncols, 64 * pl.wn), pl.nsplit);
   int rc;
-  if (pl.wm == 2 && pl.wn == 2) rc = launch_bf3s<2, 2>(p, grid, st);
-  else if (pl.wm == 1 && pl.wn == 2) rc = launch_bf3s<1, 2>(p, grid, st);
-  else rc = launch_bf3s<1, 1>(p, grid, st);
+  const int variant = (plan >> 20) & 15;
+  if (pl.wm == 2 && pl.wn == 2) rc = launch_bf3s<2, 2>(p, grid, st, variant);
+  else if (pl.wm == 1 && pl.wn == 2) rc = launch_bf3s<1, 2>(p, grid, st, variant);
+  else rc = launch_bf3s<1, 1>(p, grid, st, variant);
   if (rc) return rc;
   SWEM_CHECK_LAUNCH("conv_igemm_bf3s_kernel");
   if (pl.nsplit > 1) {
