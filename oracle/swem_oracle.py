@@ -52,13 +52,16 @@ def random_init(size, valdim, dtype=torch.float32):
     return kappa, nu, zita
 
 
+@torch.no_grad()
 def e_step(x_t, kappa, weights, tau):
-    """modules.py:112-120.  x_t (B,1,1,P,C) is the RAW key; kappa (B,N,2,C,L)."""
+    """modules.py:112-120.  x_t (B,1,1,P,C) is the RAW key; kappa (B,N,2,C,L).  Like the M and W steps it runs under
+    no_grad in the reference (decorators at :93,:112,:122): in training only the value update carries gradient."""
     s = torch.matmul(x_t, l2norm(kappa, dim=-2))
     s = (s - s.max(dim=-1, keepdim=True)[0]) / tau
     return F.softmax(s, dim=-1) * weights
 
 
+@torch.no_grad()
 def m_step(z, x, kappa_prev, zita_prev):
     """modules.py:122-127.  The prior is the previous FRAME's (kappa_, zita_)."""
     zita = zita_prev + z.sum(dim=-2, keepdim=True)
@@ -66,6 +69,7 @@ def m_step(z, x, kappa_prev, zita_prev):
     return kappa, zita
 
 
+@torch.no_grad()
 def w_step(kappa, x_t, masks, tau):
     """modules.py:93-110.  Joint {bg,fg} max, literal ``1 - p``."""
     c = torch.matmul(l2norm(x_t, dim=-1), l2norm(kappa, dim=-2))
@@ -432,6 +436,111 @@ def evaluate_seq_ms(model, frames, init_masks, out_size, scales=(480,), is_flip=
             scores = [(a + torch.flip(b, dims=[-1])) / 2 for a, b in zip(scores, fs)]
         final = [f + s_ / len(scales) for f, s_ in zip(final, scores)]
     return [torch.argmax(f, dim=1) for f in final]
+
+
+# --------------------------------------------------------------------------- #
+# Training step (methods/SWEM/swem_trainer.py:59-108, losses/, solver/solver.py)
+# --------------------------------------------------------------------------- #
+def bootstrapped_ce(scores, target, it, valid_obj, start_warm, end_warm, top_p):
+    """losses/bce_losses.py:7-51.  scores (B,N+1,T,H,W) logits, target (B,T,H,W) int64, valid_obj (B,N+1) or None."""
+    b, t, h, w = target.shape
+    if valid_obj is not None:
+        if it < start_warm:
+            tot = 0.0
+            for i in range(b):
+                tot = tot + F.cross_entropy(scores[i][valid_obj[i] > 0.5].unsqueeze(0), target[i].unsqueeze(0))
+            return tot / b, 1.0
+        raw = torch.cat([F.cross_entropy(scores[i][valid_obj[i] > 0.5].unsqueeze(0), target[i].unsqueeze(0),
+                                         reduction='none').view(1, t, -1) for i in range(b)], 0)
+    else:
+        if it < start_warm:
+            return F.cross_entropy(scores, target), 1.0
+        raw = F.cross_entropy(scores, target, reduction='none').view(b, t, -1)
+    if it > end_warm:
+        this_p = top_p
+    else:
+        this_p = top_p + (1 - top_p) * ((end_warm - it) / (end_warm - start_warm))
+    loss, _ = torch.topk(raw, k=int(h * w * this_p), dim=-1, sorted=False)
+    return loss.mean(), this_p
+
+
+def mask_iou_loss(pred, label):
+    """losses/bce_losses.py:109-141.  pred (B,N,H,W) probabilities, label (B,H,W) indices."""
+    b, n = pred.shape[:2]
+    target = torch.stack([(label == i).type(pred.dtype) for i in range(n)], 1)
+    inter = torch.min(pred, target).sum(dim=(-1, -2))
+    union = torch.max(pred, target).sum(dim=(-1, -2)) + 1e-6
+    return 1.0 - torch.sum(inter / union) / (b * n)
+
+
+def vos_loss(scores, target, it, valid_obj, loss_cfg):
+    """losses/__init__.py:15-63 with NAME='boots_ce', AUX='iou' (configs/config.py:83-89)."""
+    main, p = bootstrapped_ce(scores, target, it, valid_obj, loss_cfg['BS_PERIOD'][0], loss_cfg['BS_PERIOD'][1],
+                              loss_cfg['BS_RATIO'])
+    b, n, t, h, w = scores.shape
+    if valid_obj is None:
+        aux = mask_iou_loss(F.softmax(scores.transpose(1, 2), dim=2).reshape(b * t, n, h, w),
+                            target.contiguous().view(b * t, h, w))
+    else:
+        aux = 0.0
+        for i in range(b):
+            cur = F.softmax(scores[i][valid_obj[i] > 0.5].transpose(0, 1), dim=1)
+            aux = aux + mask_iou_loss(cur, target[i])
+        aux = aux / b
+    return {'total_loss': main + loss_cfg['AUX_RATIO'] * aux, 'main_loss': main, 'aux_loss': aux, 'p': p}
+
+
+def train_forward(model, frames, init_mask, valid_obj):
+    """swem_trainer.py:59-90: the clip loop with gradients (bases restart from random_init every step)."""
+    b, t, _, h, w = frames.shape
+    out_size = tuple(init_mask.shape[-2:])
+    mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+    mv16 = model('encode_value', frames[:, 0], init_mask.float(), s16)
+    model('init', mk16, mv16, init_mask)
+    logits_list, results = [], []
+    for i in range(1, t):
+        qk16, qv16, s16, s8, s4 = model('encode_key', frames[:, i])
+        context, n = model('match', qk16, qv16)
+        logits, pred_mask = model('segment', n, context, s8, s4, valid_obj, out_size)
+        logits_list.append(logits)
+        pred = torch.argmax(pred_mask, dim=1, keepdim=True)
+        results.append(pred)
+        hard = (pred.expand(-1, n + 1, -1, -1) == torch.arange(n + 1).view(1, -1, 1, 1)).type_as(pred)
+        if i < t - 1:
+            mv16 = model('encode_value', frames[:, i], pred_mask, s16)
+            model('memorize', qk16, mv16, hard, pred_mask)
+    return torch.stack(logits_list, dim=2), torch.cat(results, dim=1)
+
+
+def adamw_step(params, grads, state, lr, weight_decay, step, betas=(0.9, 0.999), eps=1e-8):
+    """torch.optim.AdamW (solver/solver.py:38-41) for one step, single-tensor form:
+    p *= 1 - lr*wd;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)."""
+    b1, b2 = betas
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    for k, p in params.items():
+        g = grads[k]
+        m, v = state.setdefault(k, (torch.zeros_like(p), torch.zeros_like(p)))
+        p.mul_(1 - lr * weight_decay)
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def multistep_lr(base_lr, milestones, gamma, it):
+    """optim.lr_scheduler.MultiStepLR (solver/solver.py:62-70): lr during iteration ``it`` (0-based)."""
+    return base_lr * gamma ** sum(1 for m in milestones if it >= m)
+
+
+def train_one_step(sd, cfg, frames, init_mask, valid_obj, label, cur_iter, loss_cfg):
+    """swem_trainer.py:59-108 up to (not including) the optimizer step.  sd: name -> tensor; parameters that train
+    carry requires_grad (frozen-BN running stats do not).  Returns losses, results, {name: grad}."""
+    model = Model(sd, cfg)
+    logits, results = train_forward(model, frames, init_mask, valid_obj)
+    losses = vos_loss(logits, label[:, 1:], cur_iter, valid_obj, loss_cfg)
+    names = [k for k, v in sd.items() if v.requires_grad]
+    grads = torch.autograd.grad(losses['total_loss'], [sd[k] for k in names], allow_unused=True)
+    return losses, results, {k: g for k, g in zip(names, grads)}, logits
 
 
 def make_cfg(**kw):

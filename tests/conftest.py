@@ -20,7 +20,8 @@ def golden():
 
     def load(name):
         with np.load(os.path.join(GOLDEN, name)) as z:
-            return {k: (torch.from_numpy(z[k]) if z[k].ndim else z[k].item()) for k in z.files}
+            return {k: ([str(x) for x in z[k].tolist()] if z[k].dtype.kind in 'US' and z[k].ndim else
+                        torch.from_numpy(z[k]) if z[k].ndim else z[k].item()) for k in z.files}
     return load
 
 

@@ -74,3 +74,43 @@ class SeededInit:
         if mode == 'init':
             torch.manual_seed(self.seed)
         return self.model(mode, *a)
+
+
+def train_cases():
+    """Training-step cases and configs recorded by tests/golden/make_golden_train.py."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g9_train_cases.json')) as f:
+        return json.load(f)
+
+
+def train_batch(case):
+    """Same construction as make_golden_train.make_batch: frames (B,T,3,H,W), init one-hot mask (B,N+1,H,W),
+    labels (B,T,H,W) int64, valid_obj (B,N+1)."""
+    h, w = case['hw']
+    fr, im, lb = [], [], []
+    for i in range(case['b']):
+        frames, per = synth.make_clip(t=case['t'], h=h, w=w, n_obj=case['n'], out_hw=(h, w), seed=case['seed'] + i,
+                                      all_masks=True)
+        valid = torch.tensor(case['valid'][i], dtype=torch.float32)
+        lab = torch.stack([m[0].argmax(0) for m in per])
+        for o in range(1, case['n'] + 1):
+            if valid[o] < 0.5:
+                lab[lab == o] = 0
+        m0 = torch.stack([(lab[0] == o).float() for o in range(case['n'] + 1)])
+        fr.append(frames[0])
+        im.append(m0)
+        lb.append(lab)
+    return torch.stack(fr), torch.stack(im), torch.stack(lb), torch.tensor(case['valid'], dtype=torch.float32)
+
+
+def trainable_sd(sd, model):
+    """Oracle-side state dict whose parameters (not the frozen-BN running statistics) require grad."""
+    names = {k for k, _ in model.named_parameters()}
+    out = {}
+    for k, v in sd.items():
+        t = v.clone()
+        if k in names and t.dtype.is_floating_point:
+            t.requires_grad_(True)
+        out[k] = t
+    return out

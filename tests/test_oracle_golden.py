@@ -99,3 +99,35 @@ def test_ytvos_loop_and_tta(golden):
     assert int(preds[-1].max()) == 2 and int(preds[0].max()) == 1      # the second object exists only after frame 2
     for i, p in enumerate(tta):
         assert torch.equal(p.to(torch.uint8), fx['tta%d' % i])
+
+
+@pytest.mark.parametrize('tag,it', [('r18', 5), ('r18', 45), ('r50', 45)])
+def test_train_step_matches_reference_trainer(golden, tag, it):
+    """a18 / f3: the oracle's training step (forward with gradients, BootstrappedCE + IoU loss, autograd) against the
+    losses, index maps and per-parameter gradient norms recorded from the reference's SWEMTrainer.one_step."""
+    tc = H.train_cases()
+    case = tc['cases'][tag]
+    fx = golden('g9_train_%s_it%d.npz' % (tag, it))
+    cfg = O.make_cfg(**case['cfg'])
+    model, sd = H.make_model_and_sd(cfg, case['wseed'])
+    frames, init_mask, label, valid = H.train_batch(case)
+    assert H.checksum(frames) == pytest.approx(float(fx['frames_sum']), rel=1e-12)
+    torch.manual_seed(91)
+    losses, results, grads, logits = O.train_one_step(H.trainable_sd(sd, model), cfg, frames, init_mask, valid, label,
+                                                      it, tc['loss_cfg'])
+    assert float(losses['total_loss']) == pytest.approx(float(fx['total_loss']), abs=1e-6)
+    assert float(losses['main_loss']) == pytest.approx(float(fx['main_loss']), abs=1e-6)
+    assert float(losses['aux_loss']) == pytest.approx(float(fx['aux_loss']), abs=1e-6)
+    assert float(losses['p']) == pytest.approx(float(fx['p']), abs=1e-12)
+    assert torch.equal(results.to(torch.uint8), fx['results'])
+    names = fx['grad_names']
+    assert names == sorted(k for k, g in grads.items() if g is not None)
+    for n, ref_norm in zip(names, fx['grad_norms'].tolist()):
+        assert float(grads[n].double().norm()) == pytest.approx(ref_norm, rel=1e-5, abs=1e-12), n
+    assert torch.allclose(grads['decoder.pred.weight'], fx['g_pred_weight'], rtol=1e-5, atol=1e-9)
+    # AdamW (solver/solver.py:38-41) on these gradients reproduces the reference optimizer's parameters
+    sc = tc['solver_cfg']
+    p = {'decoder.pred.weight': sd['decoder.pred.weight'].clone()}
+    O.adamw_step(p, {'decoder.pred.weight': grads['decoder.pred.weight']}, {},
+                 O.multistep_lr(sc['BASE_LR'], sc['PRETRAIN_ITERS'], sc['GAMMA'], 0), sc['WEIGHT_DECAY'], 1)
+    assert torch.allclose(p['decoder.pred.weight'], fx['w_after_pred_weight'], rtol=0, atol=1e-8)
