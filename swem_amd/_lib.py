@@ -48,6 +48,12 @@ SIGNATURES = {
     'swem_match_pad': (_i, [_i]),
     'swem_match_workspace': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'swem_match_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _sz]),
+    # ---- include/swem_hip_train.h
+    'swem_vos_loss_workspace': (_sz, [_i, _i, _ll]),
+    'swem_vos_loss_frame_fwd_f32': (_i, [_p, _p, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _ll, _ll, _p, _sz]),
+    'swem_vos_loss_reduce_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _ll, _ll, _f]),
+    'swem_vos_loss_frame_bwd_f32': (_i, [_p, _p, _p, _p, _ll, _p, _p, _p, _p, _i, _i, _i, _ll, _ll, _f, _p]),
+    'swem_adamw_f32': (_i, [_p, _p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i]),
 }
 
 _lib = None

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libswem_hip.so')
-SOURCES = ['api.hip', 'conv.hip', 'pointwise.hip', 'em.hip', 'match.hip']
+SOURCES = ['api.hip', 'conv.hip', 'pointwise.hip', 'em.hip', 'match.hip', 'train.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
@@ -19,7 +19,8 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'swem_hip.h')]
+    hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'swem_hip.h'),
+            os.path.join(HERE, '..', 'include', 'swem_hip_train.h')]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -1,4 +1,4 @@
-"""CPU: libswem_hip.so builds for gfx950, loads, and exports exactly what include/swem_hip.h declares."""
+"""CPU: libswem_hip.so builds for gfx950, loads, and exports exactly what include/*.h declare."""
 import ctypes
 import os
 import re
@@ -7,11 +7,11 @@ import pytest
 
 from swem_amd import _lib
 
-HEADER = os.path.join(os.path.dirname(__file__), '..', 'include', 'swem_hip.h')
+INCLUDE = os.path.join(os.path.dirname(__file__), '..', 'include')
 
 
 def declared_symbols():
-    src = open(HEADER).read()
+    src = ''.join(open(os.path.join(INCLUDE, h)).read() for h in sorted(os.listdir(INCLUDE)) if h.endswith('.h'))
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(swem_[a-z0-9_]+)\s*\(', src)))
 
