@@ -44,7 +44,14 @@ enum {
 enum {
   SWEM_CONV_RELU_IN = 1,  /* relu applied to the input while loading (ResBlock, networks.py:26-27) */
   SWEM_CONV_RELU_OUT = 2, /* relu after scale/shift/residual */
-  SWEM_CONV_GLU = 4       /* two filter banks f,a: y = f * sigmoid(a) (modules.py:25-26) */
+  SWEM_CONV_GLU = 4,      /* two filter banks f,a: y = f * sigmoid(a) (modules.py:25-26) */
+  /* training (swem_hip_train.h): the same kernels compute the DATA GRADIENT of a convolution.  x = dY [B][H][W][c],
+   * w = the filters transposed to [Cin][KH][KW][Cout], Cout(arg) = Cin; the output is dX with the forward input's size
+   * (H-1)*stride + KH - 2*pad (+1 row / column with EH / EW when the strided filter left one uncovered); stride 1|2 */
+  SWEM_CONV_DGRAD = 8,
+  SWEM_CONV_DGRAD_EH = 16,
+  SWEM_CONV_DGRAD_EW = 32,
+  SWEM_CONV_MASK_POS = 64 /* res is a mask source, not an addend: y = res > 0 ? y : 0 (gradient of an input ReLU) */
 };
 
 int swem_version(void);

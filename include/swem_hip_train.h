@@ -46,6 +46,97 @@ int swem_vos_loss_frame_bwd_f32(void *stream, const float *prob, const float *ra
 int swem_adamw_f32(void *stream, float *p, const float *g, float *m, float *v, long long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step);
 
+/* ------------------------------------------------------------------------------------
+ * Convolution backward.  The DATA gradient is swem_conv2d_nhwc_f32 / _bf16x3 themselves with SWEM_CONV_DGRAD
+ * (swem_hip.h): x = dY, filters transposed to [Cin][KH][KW][Cout]; SWEM_CONV_MASK_POS applies the input-ReLU mask.
+ * The WEIGHT gradient:  dw[co][ci][ky][kx] (+)= sum_pixels dY[b][oy][ox][co] * act(x[b][oy*s-p+ky][ox*s-p+kx][ci])
+ *   dy [B][Ho][Wo][Cout]; up to three concatenated NHWC sources as in swem_conv2d_nhwc_f32 (bsK = 0: shared map);
+ *   act = ReLU when relu_in; dw in the reference's OIHW layout with cin_store input channels (< c0+c1+c2 only for the
+ *   zero-padded stems); accumulate != 0 adds to dw (the gradient buffer of the optimizer). */
+size_t swem_conv2d_wgrad_workspace(int B, int H, int W, int c0, int c1, int c2, int Cout, int KH, int KW, int stride,
+                                   int pad);
+int swem_conv2d_wgrad_f32(void *stream, const float *dy, const float *x0, int c0, long long bs0, const float *x1,
+                          int c1, long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W, int Cout,
+                          int KH, int KW, int stride, int pad, int relu_in, float *dw, int cin_store, int accumulate,
+                          void *ws, size_t ws_bytes);
+/* column sums of a [M][C] matrix: out1[c] (+)= sum_m a[m][c], out2[c] (+)= sum_m a[m][c]*b[m][c]  (bias and frozen
+ * BatchNorm parameter gradients); either output may be NULL */
+size_t swem_colsum_workspace(long long M, int C);
+int swem_colsum_f32(void *stream, const float *a, const float *b, float *out1, float *out2, long long M, int C,
+                    int accumulate, void *ws, size_t ws_bytes);
+/* y[i] (+)= sum_b x[b][i], i < n: gradient of a map shared by the B objects of a frame */
+int swem_sum_batch_f32(void *stream, const float *x, float *y, int B, long long n, int accumulate);
+
+/* ------------------------------------------------------------------------------------
+ * Frozen BatchNorm (+ residual, ReLU) as a stage of its own: training keeps the raw convolution output c for the
+ * BatchNorm parameter gradients (mod_resnet.py:58-113 with the trainer's set_bn_eval, swem_trainer.py:37-39).
+ *   y = act(c * alpha + shift + res),  alpha = gamma / sqrt(var + eps),  shift = beta - mean * alpha
+ *   bwd: dz = dy * (y > 0) (also the residual's gradient, optional), dc = dz * alpha
+ *   parameters: dgamma += invstd * (s2 - mean * s1), dbeta += s1, dbias += alpha * s1 with s1 = colsum(dz),
+ *   s2 = colsum(dz * c) (swem_colsum_f32) */
+int swem_bn_act_f32(void *stream, const float *c, const float *alpha, const float *shift, const float *res, float *y,
+                    long long M, int C, int relu);
+int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y, const float *alpha, float *dz, float *dc,
+                        long long M, int C, int relu);
+int swem_bn_param_grad_f32(void *stream, const float *s1, const float *s2, const float *mean, const float *invstd,
+                           const float *alpha, float *dgamma, float *dbeta, float *dbias, int C);
+/* backward of swem_cbam_f32 (y = x + CBAM(x), attentions.py:22-84): dx [B][H][W][C]; the gradients of the six
+ * parameters (mlp.1 / mlp.3 weight+bias, spatial conv weight [1][2][7][7] + bias) are ACCUMULATED.  Ties of the two
+ * max-pools send the gradient to the first maximum. */
+size_t swem_cbam_bwd_workspace(int B, int H, int W, int C);
+int swem_cbam_bwd_f32(void *stream, const float *x, const float *w1, const float *b1, const float *w2, const float *b2,
+                      const float *w7, const float *b7, const float *dy, float *dx, float *dw1, float *db1, float *dw2,
+                      float *db2, float *dw7, float *db7, int B, int H, int W, int C, int hid, void *ws,
+                      size_t ws_bytes);
+/* alpha = gamma / sqrt(var + eps), shift = beta - mean * alpha, invstd = 1 / sqrt(var + eps) (frozen BatchNorm) */
+int swem_bn_fold_f32(void *stream, const float *gamma, const float *beta, const float *mean, const float *var, float eps,
+                     float *alpha, float *shift, float *invstd, int C);
+/* modules.py:25-26 as two convolutions + a gate: y = f * sigmoid(a) and its gradients; n elements */
+int swem_glu_f32(void *stream, const float *f, const float *a, float *y, long long n);
+int swem_glu_bwd_f32(void *stream, const float *dy, const float *f, const float *a, float *df, float *da, long long n);
+int swem_add_f32(void *stream, const float *a, const float *b, float *y, long long n);
+/* backward of swem_maxpool3x3s2_nhwc_f32 (first maximum of a window takes the gradient, as ATen) */
+int swem_maxpool3x3s2_bwd_f32(void *stream, const float *x, const float *dy, float *dx, int B, int H, int W, int C);
+/* adjoint of the bilinear upsampling of swem_upsample_add_nhwc_f32 (the skip branch's gradient is dy itself) and of
+ * swem_resize_planes_f32 mode 1 for upsampling (planes) */
+int swem_upsample_bwd_nhwc_f32(void *stream, const float *dy, float *dlow, int B, int Hl, int Wl, int Ho, int Wo,
+                               int C);
+int swem_resize_bilinear_bwd_f32(void *stream, const float *dy, float *dx, int planes, int Hi, int Wi, int Ho, int Wo);
+/* backward of swem_decode_head_f32: dlogits / dprob (either may be NULL) [B][N+1][Ho*Wo] -> dlogit4 [B*N][h4][w4];
+ * workspace B*N*Ho*Wo floats */
+int swem_decode_head_bwd_f32(void *stream, const float *logit4, const float *valid, const float *dlogits,
+                             const float *dprob, float *dlogit4, int B, int N, int h4, int w4, int Ho, int Wo, void *ws,
+                             size_t ws_bytes);
+/* backward of swem_pred_head_f32: dx [B][H][W][C]; dw (OIHW [1][C][3][3]) and db are ACCUMULATED */
+size_t swem_pred_head_bwd_workspace(int B, int H, int W, int C);
+int swem_pred_head_bwd_f32(void *stream, const float *x, const float *w, const float *dlogit, float *dx, float *dw,
+                           float *db, int B, int H, int W, int C, void *ws, size_t ws_bytes);
+/* backward of swem_prep_value_input_f32 w.r.t. the masks: dxin [B*N][H][W][8] -> dmasks [B][N+1][H][W] */
+int swem_prep_value_input_bwd_f32(void *stream, const float *dxin, float *dmasks, int B, int N, int H, int W,
+                                  int single_obj);
+
+/* ------------------------------------------------------------------------------------
+ * EM / matching in the training step.  The E, M and W steps run under no_grad in the reference (modules.py:93,112,122):
+ * only the value update nu = (zita_prev*nu_prev + v.z)/zita (:164-165) and the matching carry gradient.
+ * swem_memorize_train_f32 = swem_memorize_f32 that also returns the last responsibilities zT [2N][L][Pp]
+ * (Pp = swem_em_pad(P)) for swem_nu_update_bwd_f32:
+ *   dv [N][P][V] (the NHWC value map's gradient), dnu_prev [2N][V][L] (may be NULL) from dnu [2N][V][L] */
+int swem_memorize_train_f32(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
+                            const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out,
+                            float *zita_out, float *zT_out, int N, int C, int V, int P, int L, int T, float tau,
+                            void *ws, size_t ws_bytes);
+size_t swem_nu_update_bwd_workspace(int N, int V, int P, int L);
+int swem_nu_update_bwd_f32(void *stream, const float *zT, const float *zita_prev, const float *zita, const float *dnu,
+                           float *dv, float *dnu_prev, int N, int V, int P, int L, void *ws, size_t ws_bytes);
+/* backward of swem_match_f32 for the N <= 3 objects of one clip: dmem [N][Pm][V] and dS [N][P][2*topl] (dS may be NULL)
+ * -> dqk [P][C] (summed over objects; through the query's l2norm), dnu_first / dnu_update [N][2][V][L].
+ * Ties among the top-l values take the gradient jointly (measure zero). */
+size_t swem_match_bwd_workspace(int N, int C, int V, int P, int L, int nbanks);
+int swem_match_bwd_f32(void *stream, const float *qk, const float *kappa_first, const float *nu_first,
+                       const float *kappa_update, const float *nu_update, const float *dmem, const float *dS,
+                       float *dqk, float *dnu_first, float *dnu_update, int N, int C, int V, int P, int L, int topl,
+                       float tau, void *ws, size_t ws_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,33 @@ SIGNATURES = {
     'swem_vos_loss_reduce_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _ll, _ll, _f]),
     'swem_vos_loss_frame_bwd_f32': (_i, [_p, _p, _p, _p, _ll, _p, _p, _p, _p, _i, _i, _i, _ll, _ll, _f, _p]),
     'swem_adamw_f32': (_i, [_p, _p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i]),
+    'swem_memorize_train_f32': (_i, [_p] * 11 + [_i] * 6 + [_f, _p, _sz]),
+    'swem_nu_update_bwd_workspace': (_sz, [_i, _i, _i, _i]),
+    'swem_nu_update_bwd_f32': (_i, [_p] * 7 + [_i] * 4 + [_p, _sz]),
+    'swem_match_bwd_workspace': (_sz, [_i] * 6),
+    'swem_match_bwd_f32': (_i, [_p] * 11 + [_i] * 6 + [_f, _p, _sz]),
+    'swem_conv2d_wgrad_workspace': (_sz, [_i] * 11),
+    'swem_conv2d_wgrad_f32': (_i, [_p, _p, _p, _i, _ll, _p, _i, _ll, _p, _i, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                   _p, _i, _i, _p, _sz]),
+    'swem_colsum_workspace': (_sz, [_ll, _i]),
+    'swem_colsum_f32': (_i, [_p, _p, _p, _p, _p, _ll, _i, _i, _p, _sz]),
+    'swem_sum_batch_f32': (_i, [_p, _p, _p, _i, _ll, _i]),
+    'swem_bn_act_f32': (_i, [_p, _p, _p, _p, _p, _p, _ll, _i, _i]),
+    'swem_bn_act_bwd_f32': (_i, [_p, _p, _p, _p, _p, _p, _ll, _i, _i]),
+    'swem_bn_param_grad_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i]),
+    'swem_cbam_bwd_workspace': (_sz, [_i, _i, _i, _i]),
+    'swem_cbam_bwd_f32': (_i, [_p] * 16 + [_i] * 5 + [_p, _sz]),
+    'swem_bn_fold_f32': (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _i]),
+    'swem_glu_f32': (_i, [_p, _p, _p, _p, _ll]),
+    'swem_glu_bwd_f32': (_i, [_p, _p, _p, _p, _p, _p, _ll]),
+    'swem_add_f32': (_i, [_p, _p, _p, _p, _ll]),
+    'swem_maxpool3x3s2_bwd_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i]),
+    'swem_upsample_bwd_nhwc_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i]),
+    'swem_resize_bilinear_bwd_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _i]),
+    'swem_decode_head_bwd_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz]),
+    'swem_pred_head_bwd_workspace': (_sz, [_i, _i, _i, _i]),
+    'swem_pred_head_bwd_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz]),
+    'swem_prep_value_input_bwd_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _i]),
 }
 
 _lib = None

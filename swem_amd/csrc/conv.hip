@@ -75,6 +75,23 @@ __device__ __forceinline__ float4 mask4(float4 v, bool keep) {
                      __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
 }
 
+// Source pixel coordinate of output coordinate o (carried as o0) under tap k.
+//   forward:  o0 = o*stride - pad,  i = o0 + k
+//   data gradient (SWEM_CONV_DGRAD: x is dY, the output is dX): o0 = o + pad, t = o0 - k must be a multiple of the
+//   stride, i = t / stride  (stride 1 or 2).  Evaluated only when the tap changes, never inside the k-loop.
+__device__ __forceinline__ bool tap_coord(const ConvP &p, int o0, int k, int lim, int &i) {
+  if (p.flags & SWEM_CONV_DGRAD) {
+    const int t = o0 - k;
+    i = t >> (p.stride - 1);
+    return t >= 0 && (t & (p.stride - 1)) == 0 && i < lim;
+  }
+  i = o0 + k;
+  return (unsigned)i < (unsigned)lim;
+}
+__device__ __forceinline__ int tap_origin(const ConvP &p, int o) {
+  return (p.flags & SWEM_CONV_DGRAD) ? o + p.pad : o * p.stride - p.pad;
+}
+
 // Epilogue shared by both kernels: raw split-K partials, or scale/shift (+residual, ReLU) / GLU gate, NHWC stores.
 template <int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][WN], int m0, int n0, int wm, int wn,
@@ -134,7 +151,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][
           float v = acc[i][jn][e] * sc + sh;
           if (p.res) {
             int b = m / HoWo;
-            v += p.res[(long long)b * p.res_bs + (long long)(m - b * HoWo) * p.Cout + n];
+            const float rv = p.res[(long long)b * p.res_bs + (long long)(m - b * HoWo) * p.Cout + n];
+            v = (p.flags & SWEM_CONV_MASK_POS) ? (rv > 0.f ? v : 0.f) : v + rv;
           }
           if (relu_out) v = fmaxf(v, 0.f);
           p.y[(long long)m * p.Cout + n] = v;
@@ -173,8 +191,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     int b = m / HoWo;
     int rem = m - b * HoWo;
     int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    iy0[i] = oy * p.stride - p.pad;
-    ix0[i] = ox * p.stride - p.pad;
+    iy0[i] = tap_origin(p, oy);
+    ix0[i] = tap_origin(p, ox);
     bidx[i] = b;
   }
   const float *wrow[RB];
@@ -392,8 +410,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvP p) {
     int b = m / HoWo;
     int rem = m - b * HoWo;
     int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    iy0[i] = oy * p.stride - p.pad;
-    ix0[i] = ox * p.stride - p.pad;
+    iy0[i] = tap_origin(p, oy);
+    ix0[i] = tap_origin(p, ox);
     bidx[i] = m < p.M ? b : -1;
   }
   unsigned wvoff[RB];
@@ -411,8 +429,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvP p) {
     const long long bs = q.src == 0 ? p.bs[0] : (q.src == 1 ? p.bs[1] : p.bs[2]);
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int iy = iy0[i] + q.ky, ix = ix0[i] + q.kx;
-      const bool ok = bidx[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      int iy, ix;
+      const bool oky = tap_coord(p, iy0[i], q.ky, p.H, iy), okx = tap_coord(p, ix0[i], q.kx, p.W, ix);
+      const bool ok = bidx[i] >= 0 && oky && okx;
       const long long e = bidx[i] * bs + ((long long)iy * p.W + ix) * cs + kq * 4;
       avoff[i] = ok ? (unsigned)(e * 4) : OOB;
     }
@@ -587,8 +606,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(ConvP p) {
     int b = m / HoWo;
     int rem = m - b * HoWo;
     int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    iy0[i] = oy * p.stride - p.pad;
-    ix0[i] = ox * p.stride - p.pad;
+    iy0[i] = tap_origin(p, oy);
+    ix0[i] = tap_origin(p, ox);
     bidx[i] = m < p.M ? b : -1;
   }
   unsigned wvoff[RB];
@@ -604,8 +623,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(ConvP p) {
     const long long bs = q.src == 0 ? p.bs[0] : (q.src == 1 ? p.bs[1] : p.bs[2]);
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int iy = iy0[i] + q.ky, ix = ix0[i] + q.kx;
-      const bool ok = bidx[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      int iy, ix;
+      const bool oky = tap_coord(p, iy0[i], q.ky, p.H, iy), okx = tap_coord(p, ix0[i], q.kx, p.W, ix);
+      const bool ok = bidx[i] >= 0 && oky && okx;
       const long long e = bidx[i] * bs + ((long long)iy * p.W + ix) * cs + kq * 4;
       avoff[i] = ok ? (unsigned)(e * 4) : OOB;
     }
@@ -811,8 +831,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
     int b = m / HoWo;
     int rem = m - b * HoWo;
     int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    iy0[j] = oy * p.stride - p.pad;
-    ix0[j] = ox * p.stride - p.pad;
+    iy0[j] = tap_origin(p, oy);
+    ix0[j] = tap_origin(p, ox);
     bidx[j] = m < p.M ? b : -1;
   }
   unsigned bvoff[WN];
@@ -829,8 +849,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
     const long long bs = q.src == 0 ? p.bs[0] : (q.src == 1 ? p.bs[1] : p.bs[2]);
 #pragma unroll
     for (int j = 0; j < WM; ++j) {
-      const int iy = iy0[j] + q.ky, ix = ix0[j] + q.kx;
-      const bool ok = bidx[j] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      int iy, ix;
+      const bool oky = tap_coord(p, iy0[j], q.ky, p.H, iy), okx = tap_coord(p, ix0[j], q.kx, p.W, ix);
+      const bool ok = bidx[j] >= 0 && oky && okx;
       const long long pix = bidx[j] * (bs / cs) + (long long)iy * p.W + ix;  // pixel index in the source's storage
       avoff[j] = ok ? (unsigned)(pix * 16) : OOB;
     }
@@ -993,10 +1014,14 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
       int b = m / HoWo;
       float4 rv = *reinterpret_cast<const float4 *>(p.res + (long long)b * p.res_bs +
                                                     (long long)(m - b * HoWo) * p.Cout + co);
-      v.x += rv.x;
-      v.y += rv.y;
-      v.z += rv.z;
-      v.w += rv.w;
+      if (p.flags & SWEM_CONV_MASK_POS) {
+        v = make_float4(rv.x > 0.f ? v.x : 0.f, rv.y > 0.f ? v.y : 0.f, rv.z > 0.f ? v.z : 0.f, rv.w > 0.f ? v.w : 0.f);
+      } else {
+        v.x += rv.x;
+        v.y += rv.y;
+        v.z += rv.z;
+        v.w += rv.w;
+      }
     }
     if (p.flags & SWEM_CONV_RELU_OUT) v = relu4(v);
   }
@@ -1112,10 +1137,23 @@ Plan resolve_plan(int plan, int M, int Ncols, int nkb, bool glu) {
   return make_plan(M, Ncols, nkb, glu);
 }
 
+// output size: forward floor((H + 2p - K)/s) + 1; data gradient: the forward INPUT size (H-1)*s + K - 2p + e, where
+// e = rows/cols of the forward input the strided filter never reached (flag bits EH / EW)
+static inline void conv_out_dims(int H, int W, int KH, int KW, int stride, int pad, int flags, int &Ho, int &Wo) {
+  if (flags & SWEM_CONV_DGRAD) {
+    Ho = (H - 1) * stride + KH - 2 * pad + ((flags & SWEM_CONV_DGRAD_EH) ? 1 : 0);
+    Wo = (W - 1) * stride + KW - 2 * pad + ((flags & SWEM_CONV_DGRAD_EW) ? 1 : 0);
+  } else {
+    Ho = (H + 2 * pad - KH) / stride + 1;
+    Wo = (W + 2 * pad - KW) / stride + 1;
+  }
+}
+
 extern "C" size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                         int flags, int plan) {
   if (stride <= 0) return 0;
-  int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  int Ho, Wo;
+  conv_out_dims(H, W, KH, KW, stride, pad, flags, Ho, Wo);
   long long M = (long long)B * Ho * Wo;
   int Ncols = (flags & SWEM_CONV_GLU) ? 2 * Cout : Cout;
   int nkb = cdiv((long long)KH * KW * Cin, BK);
@@ -1145,9 +1183,11 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
   p.c[0] = c0; p.c[1] = c1; p.c[2] = c2;
   p.bs[0] = bs0; p.bs[1] = bs1; p.bs[2] = bs2;
   p.B = B; p.H = H; p.W = W;
-  p.Ho = (H + 2 * pad - KH) / stride + 1;
-  p.Wo = (W + 2 * pad - KW) / stride + 1;
+  conv_out_dims(H, W, KH, KW, stride, pad, flags, p.Ho, p.Wo);
   SWEM_REQUIRE(p.Ho > 0 && p.Wo > 0, SWEM_E_SHAPE, "conv2d: empty output");
+  SWEM_REQUIRE(!(flags & SWEM_CONV_DGRAD) || ((stride == 1 || stride == 2) && c0 % 32 == 0 && c1 % 32 == 0 && c2 % 32 == 0),
+               SWEM_E_SHAPE, "conv2d: the data-gradient mode needs stride 1 or 2 and sources that are multiples of 32 channels");
+  SWEM_REQUIRE(!(flags & SWEM_CONV_MASK_POS) || res, SWEM_E_ARG, "conv2d: SWEM_CONV_MASK_POS needs the mask in res");
   p.Cin = c0 + c1 + c2;
   p.K = KH * KW * p.Cin;
   long long M = (long long)B * p.Ho * p.Wo;
@@ -1282,9 +1322,10 @@ extern "C" int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, lon
   SWEM_REQUIRE(ps0 * 6 < (1ll << 31) && p.ps[1] * 6 < (1ll << 31) && p.ps[2] * 6 < (1ll << 31), SWEM_E_SHAPE,
                "conv2d_bf16x3: a source exceeds the 2 GiB buffer-descriptor range");
   p.B = B; p.H = H; p.W = W;
-  p.Ho = (H + 2 * pad - KH) / stride + 1;
-  p.Wo = (W + 2 * pad - KW) / stride + 1;
+  conv_out_dims(H, W, KH, KW, stride, pad, flags, p.Ho, p.Wo);
   SWEM_REQUIRE(p.Ho > 0 && p.Wo > 0, SWEM_E_SHAPE, "conv2d_bf16x3: empty output");
+  SWEM_REQUIRE(!(flags & SWEM_CONV_DGRAD) || stride == 1 || stride == 2, SWEM_E_SHAPE,
+               "conv2d_bf16x3: the data-gradient mode needs stride 1 or 2");
   p.Cin = c0 + c1 + c2;
   p.K = KH * KW * p.Cin;
   long long M = (long long)B * p.Ho * p.Wo;

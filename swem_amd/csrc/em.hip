@@ -19,6 +19,7 @@
 //   em_zsum    : zita = zita_ + sum_p z (one wave per base row).
 //   em_finalize: fixed-order slab reduction (deterministic) and the prior blend (zita_*kappa_ + S)/zita; the key-base
 //                variant also emits the next iteration's normalised transposed bases (block-local column norms).
+#include "../../include/swem_hip_train.h"
 #include "common.h"
 
 namespace {
@@ -393,10 +394,31 @@ extern "C" size_t swem_memorize_workspace(int N, int C, int V, int P, int L) {
   return memorize_ws(N, C, V, P, L).total;
 }
 
+namespace {
+int memorize_impl(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
+                  const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out, int N,
+                  int C, int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes, float *zT_ext);
+}
 extern "C" int swem_memorize_f32(void *stream, const float *x, const float *v, const float *masks,
                                  const float *kappa_prev, const float *nu_prev, const float *zita_prev,
                                  float *kappa_out, float *nu_out, float *zita_out, int N, int C, int V, int P, int L,
                                  int T, float tau, void *ws, size_t ws_bytes) {
+  return memorize_impl(stream, x, v, masks, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out, N, C, V, P, L, T,
+                       tau, ws, ws_bytes, nullptr);
+}
+// training: the same, and the last E step's responsibilities zT [2N][L][Pp] are kept for the value update's backward
+extern "C" int swem_memorize_train_f32(void *stream, const float *x, const float *v, const float *masks,
+                                       const float *kappa_prev, const float *nu_prev, const float *zita_prev,
+                                       float *kappa_out, float *nu_out, float *zita_out, float *zT_out, int N, int C,
+                                       int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(zT_out, SWEM_E_ARG, "memorize_train: zT_out is null");
+  return memorize_impl(stream, x, v, masks, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out, N, C, V, P, L, T,
+                       tau, ws, ws_bytes, zT_out);
+}
+namespace {
+int memorize_impl(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
+                  const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out, int N,
+                  int C, int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes, float *zT_ext) {
   SWEM_REQUIRE(x && v && masks && kappa_prev && nu_prev && zita_prev && kappa_out && nu_out && zita_out, SWEM_E_ARG,
                "memorize: null pointer");
   SWEM_REQUIRE(T >= 1, SWEM_E_ARG, "memorize: T < 1");
@@ -406,7 +428,7 @@ extern "C" int swem_memorize_f32(void *stream, const float *x, const float *v, c
   SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "memorize: workspace %zu < %zu", ws_bytes, w.total);
   char *base = static_cast<char *>(ws);
   float *xT = (float *)(base + w.xT), *vT = (float *)(base + w.vT), *kn = (float *)(base + w.kn);
-  float *zT = (float *)(base + w.zT), *wb = (float *)(base + w.wb);
+  float *zT = zT_ext ? zT_ext : (float *)(base + w.zT), *wb = (float *)(base + w.wb);
   void *part = base + w.part;
   const size_t part_bytes = w.total - w.part;
   const int Pp = swem_em_pad(P), NK = 2 * N;
@@ -424,4 +446,83 @@ extern "C" int swem_memorize_f32(void *stream, const float *x, const float *v, c
   // value bases from the last z (modules.py:164-165); zita is the one just written
   return swem_em_mstep_f32(stream, vT, 2, zT, nu_prev, zita_prev, nu_out, nullptr, nullptr, NK, V, P, L, part,
                            part_bytes);
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ backward (training)
+// nu = (zita_prev * nu_prev + v . z) / zita  (modules.py:164-165) is the only part of swem() that carries gradient
+// (E/M/W run under no_grad): d v = z . (dnu / zita),  d nu_prev = dnu * zita_prev / zita.
+namespace {
+// Gp[n][v][cls*L + l] = dnu[nk][v][l] / zita[nk][l];  dnu_prev[nk][v][l] = Gp * zita_prev[nk][l]
+__global__ void nu_bwd_prep_kernel(const float *__restrict__ dnu, const float *__restrict__ zita,
+                                   const float *__restrict__ zita_prev, float *__restrict__ Gp,
+                                   float *__restrict__ dnu_prev, int N, int V, int L) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)N * 2 * V * L) return;
+  const int l = (int)(i % L);
+  long long t = i / L;
+  const int v = (int)(t % V);
+  t /= V;  // nk
+  const int cls = (int)(t & 1), n = (int)(t >> 1);
+  const float g = dnu[i] / zita[t * L + l];
+  Gp[((long long)n * V + v) * (2 * L) + cls * L + l] = g;
+  if (dnu_prev) dnu_prev[i] = g * zita_prev[t * L + l];
+}
+struct NuBwdWs {
+  size_t Gp, zTt, dvp, conv, total;
+};
+NuBwdWs nu_bwd_ws(int N, int V, int P, int L) {
+  NuBwdWs w;
+  const int Pm = swem_match_pad(P);
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = align_up(o + bytes, 256);
+    return at;
+  };
+  w.Gp = take((size_t)N * V * 2 * L * 4);
+  w.zTt = take((size_t)N * Pm * 2 * L * 4);
+  w.dvp = take((size_t)N * Pm * V * 4);
+  w.conv = take(swem_conv2d_workspace(N, Pm, 1, 2 * L, V, 1, 1, 1, 0, 0, 0));
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t swem_nu_update_bwd_workspace(int N, int V, int P, int L) { return nu_bwd_ws(N, V, P, L).total; }
+
+extern "C" int swem_nu_update_bwd_f32(void *stream, const float *zT, const float *zita_prev, const float *zita,
+                                      const float *dnu, float *dv, float *dnu_prev, int N, int V, int P, int L, void *ws,
+                                      size_t ws_bytes) {
+  SWEM_REQUIRE(zT && zita_prev && zita && dnu && dv, SWEM_E_ARG, "nu_update_bwd: null pointer");
+  SWEM_REQUIRE(N > 0 && V % 4 == 0 && L % 32 == 0, SWEM_E_SHAPE, "nu_update_bwd: need V %% 4 == 0 and L %% 32 == 0");
+  NuBwdWs w = nu_bwd_ws(N, V, P, L);
+  SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "nu_update_bwd: workspace %zu < %zu", ws_bytes, w.total);
+  char *base = static_cast<char *>(ws);
+  float *Gp = (float *)(base + w.Gp), *zTt = (float *)(base + w.zTt), *dvp = (float *)(base + w.dvp);
+  const int Pp = swem_em_pad(P), Pm = swem_match_pad(P);
+  hipLaunchKernelGGL(nu_bwd_prep_kernel, dim3(cdiv((long long)N * 2 * V * L, 256)), dim3(256), 0, ST, dnu, zita,
+                     zita_prev, Gp, dnu_prev, N, V, L);
+  SWEM_CHECK_LAUNCH("nu_bwd_prep");
+  // z pixel-major per object: zT[n] is [2L][Pp] -> [Pp][2L], rows padded with zeros to the GEMM tile (Pm)
+  if (hipMemsetAsync(zTt, 0, (size_t)N * Pm * 2 * L * 4, ST) != hipSuccess) {
+    swem_set_error("nu_update_bwd: memset failed");
+    return SWEM_E_HIP;
+  }
+  int rc;
+  for (int n = 0; n < N; ++n)
+    if ((rc = swem_transpose_f32(stream, zT + (long long)n * 2 * L * Pp, zTt + (long long)n * Pm * 2 * L, 1, 2 * L, Pp,
+                                 2 * L)))
+      return rc;
+  // dv[n] = z[n] . Gp[n]^T : batched GEMM on the conv kernel (a Pm x 1 image with 2L channels, V filters per object)
+  if ((rc = swem_conv2d_nhwc_f32(stream, zTt, 2 * L, (long long)Pm * 2 * L, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, Gp,
+                                 (long long)V * 2 * L, nullptr, nullptr, nullptr, 0, dvp, V, 1, 1, 1, 0, 0, 0,
+                                 base + w.conv, w.total - w.conv)))
+    return rc;
+  if (hipMemcpy2DAsync(dv, (size_t)P * V * 4, dvp, (size_t)Pm * V * 4, (size_t)P * V * 4, N, hipMemcpyDeviceToDevice,
+                       ST) != hipSuccess) {
+    swem_set_error("nu_update_bwd: copy failed");
+    return SWEM_E_HIP;
+  }
+  return SWEM_OK;
 }

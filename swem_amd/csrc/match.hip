@@ -13,6 +13,7 @@
 //            (1x1 "conv" over a Pm x 1 image with Ltot channels and per-object filters), output NHWC [N][Pm][V].
 // (The first version kept the whole exp tile in 132 KiB of LDS inside one kernel; at one block per CU and one wave
 //  per SIMD every global and LDS latency was exposed: 209 us per frame.  This split runs in a fraction of that.)
+#include "../../include/swem_hip_train.h"
 #include "common.h"
 
 namespace {
@@ -212,6 +213,150 @@ MatchWs match_ws(int N, int C, int V, int P, int L, int nbanks, int plan) {
   return w;
 }
 
+// ------------------------------------------------------------------------------------------------ backward (training)
+// dnu[n][cls][v][l] = dmvp[n][v][cls*Lm + off + l]   (inverse of pack_values_kernel)
+__global__ void unpack_values_kernel(const float *__restrict__ dmvp, float *__restrict__ dnu, int N, int V, int L,
+                                     int Lm, int off) {
+  const int lq = L / 4;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)N * 2 * V * lq) return;
+  int l4 = (int)(i % lq);
+  long long t = i / lq;
+  int v = (int)(t % V);
+  t /= V;
+  int cls = (int)(t & 1);
+  int n = (int)(t >> 1);
+  *reinterpret_cast<float4 *>(dnu + i * 4) = ld4(dmvp + ((long long)n * V + v) * (2 * Lm) + cls * Lm + off + l4 * 4);
+}
+
+// Per (object, pixel), one wave: gradient at the affinities from (a) the readout path (dP = dmem . mv, computed by a
+// GEMM before this kernel) and (b) the top-l prefix features: the class's values are sorted as in the forward kernel,
+// d f_i -> d c_i -> suffix sums R_j = sum_{i >= j} d c_i, and every element takes R at its rank (found by a binary
+// search in the sorted top-64 list; elements below the list get none).  Then the joint-softmax Jacobian:
+// da_l = p_l * (g_l - sum_j p_j g_j) / tau.  The result overwrites dP.
+template <int J>
+__global__ __launch_bounds__(256) void match_bwd_pixel_kernel(const float *__restrict__ pT, float *__restrict__ dP,
+                                                              const float *__restrict__ dS, int N, int P, int Pm,
+                                                              int topl, float inv_tau) {
+  constexpr int Ltot = 128 * J, Lm = 64 * J;
+  __shared__ float sv[4][2][64], sr[4][2][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long idx = (long long)blockIdx.x * 4 + w;
+  if (idx >= (long long)N * P) return;
+  const int n = (int)(idx / P), pix = (int)(idx - (long long)n * P);
+  const float *row = pT + ((long long)n * Pm + pix) * Ltot;
+  float *drow = dP + ((long long)n * Pm + pix) * Ltot;
+  float pv[2][J], cum[2];
+#pragma unroll
+  for (int cls = 0; cls < 2; ++cls) {
+    float v[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) pv[cls][j] = v[j] = row[cls * Lm + lane + 64 * j];
+#pragma unroll
+    for (int j = 0; j < J; ++j) v[j] = sort64_desc(v[j], lane);
+#pragma unroll
+    for (int ww = 1; ww < J; ww <<= 1)
+#pragma unroll
+      for (int j = 0; j + ww < J; j += 2 * ww) v[j] = merge_top64(v[j], v[j + ww], lane);
+    float c = v[0];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      float t = __shfl_up(c, d);
+      if (lane >= d) c += t;
+    }
+    cum[cls] = c;
+    sv[w][cls][lane] = v[0];
+  }
+  const float df = (dS && lane < topl) ? dS[idx * (2 * topl) + lane] - dS[idx * (2 * topl) + topl + lane] : 0.f;
+  const float den = cum[0] + cum[1];
+  float rb = lane < topl ? df * cum[1] / (den * den) : 0.f;
+  float rf = lane < topl ? -df * cum[0] / (den * den) : 0.f;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float tb = __shfl_down(rb, d), tf = __shfl_down(rf, d);
+    if (lane + d < 64) {
+      rb += tb;
+      rf += tf;
+    }
+  }
+  sr[w][0][lane] = rb;
+  sr[w][1][lane] = rf;
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed before it reads them back
+  float g[2][J];
+  float dot = 0.f;
+#pragma unroll
+  for (int cls = 0; cls < 2; ++cls)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const float x = pv[cls][j];
+      int lo = 0, hi = 64;
+#pragma unroll
+      for (int it = 0; it < 7; ++it) {   // [0, 64) halves to empty in 7 steps; entries [0, lo) are > x
+        if (lo >= hi) break;
+        const int mid = (lo + hi) >> 1;
+        if (sv[w][cls][mid] > x) lo = mid + 1;
+        else hi = mid;
+      }
+      const float gs = lo < topl ? sr[w][cls][lo] : 0.f;
+      const float gg = gs + drow[cls * Lm + lane + 64 * j];
+      g[cls][j] = gg;
+      dot += x * gg;
+    }
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+#pragma unroll
+  for (int cls = 0; cls < 2; ++cls)
+#pragma unroll
+    for (int j = 0; j < J; ++j) drow[cls * Lm + lane + 64 * j] = pv[cls][j] * (g[cls][j] - dot) * inv_tau;
+}
+
+// l2norm backward (modules.py:7-9,282): qn = q / (|q| + eps);  dq = g / (|q| + eps) - q (q.g) / (|q| (|q| + eps)^2)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *__restrict__ q, const float *__restrict__ g,
+                                                         float *__restrict__ dq, int P, int C) {
+  const int lane = threadIdx.x & 63;
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= P) return;
+  float s = 0.f, d = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float a = q[pix * C + c], b = g[pix * C + c];
+    s += a * a;
+    d += a * b;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    d += __shfl_xor(d, o);
+  }
+  const float nrm = sqrtf(s), den = nrm + SWEM_L2_EPS;
+  const float k = nrm > 0.f ? d / (nrm * den * den) : 0.f;
+  for (int c = lane; c < C; c += 64) dq[pix * C + c] = g[pix * C + c] / den - q[pix * C + c] * k;
+}
+
+struct MatchBwdWs {
+  size_t fwd, mvpT, dP, mknT, dmvp, dqn, conv, wgrad, total;
+};
+MatchBwdWs match_bwd_ws(int N, int C, int V, int P, int L, int nbanks) {
+  MatchBwdWs w;
+  const size_t Ltot = (size_t)2 * nbanks * L;
+  const int Pm = swem_match_pad(P);
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = align_up(o + bytes, 256);
+    return at;
+  };
+  w.fwd = take(match_ws(N, C, V, P, L, nbanks, 0).total);
+  w.mvpT = take((size_t)N * Ltot * V * 4);
+  w.dP = take((size_t)N * Pm * Ltot * 4);
+  w.mknT = take((size_t)C * N * Ltot * 4);
+  w.dmvp = take((size_t)N * V * Ltot * 4);
+  w.dqn = take((size_t)Pm * C * 4);
+  size_t c1 = swem_conv2d_workspace(N, Pm, 1, V, (int)Ltot, 1, 1, 1, 0, 0, 0);
+  size_t c2 = swem_conv2d_workspace(1, Pm, 1, (int)(N * Ltot), C, 1, 1, 1, 0, 0, 0);
+  w.conv = take(c1 > c2 ? c1 : c2);
+  w.wgrad = take(swem_conv2d_wgrad_workspace(1, Pm, 1, (int)Ltot, 0, 0, V, 1, 1, 1, 0));
+  w.total = o;
+  return w;
+}
+
 }  // namespace
 
 #define ST static_cast<hipStream_t>(stream)
@@ -269,4 +414,88 @@ extern "C" int swem_match_f32(void *stream, const float *qk, const float *kappa_
   return swem_conv2d_nhwc_f32(stream, pT, Ltot, (long long)Pm * Ltot, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, mvp,
                               (long long)V * Ltot, nullptr, nullptr, nullptr, 0, mem_out, V, 1, 1, 1, 0, 0,
                               readout_plan, base + w.conv, w.total - w.conv);
+}
+
+// backward of swem_match_f32 for one clip: d mem_out [N][Pm][V] and dS [N][P][2*topl] (either may be NULL) ->
+// dqk [P][C] (summed over the objects) and the value bases' gradients dnu_* [N][2][V][L]; the key bases carry none
+// (the EM runs under no_grad, modules.py:93,112,122).
+extern "C" size_t swem_match_bwd_workspace(int N, int C, int V, int P, int L, int nbanks) {
+  return match_bwd_ws(N, C, V, P, L, nbanks).total;
+}
+
+extern "C" int swem_match_bwd_f32(void *stream, const float *qk, const float *kappa_first, const float *nu_first,
+                                  const float *kappa_update, const float *nu_update, const float *dmem,
+                                  const float *dS, float *dqk, float *dnu_first, float *dnu_update, int N, int C, int V,
+                                  int P, int L, int topl, float tau, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(qk && kappa_first && nu_first && dmem && dqk && dnu_first, SWEM_E_ARG, "match_bwd: null pointer");
+  SWEM_REQUIRE((kappa_update == nullptr) == (nu_update == nullptr) && (nu_update == nullptr) == (dnu_update == nullptr),
+               SWEM_E_ARG, "match_bwd: update bank half given");
+  SWEM_REQUIRE(N >= 1 && N <= 3, SWEM_E_SHAPE, "match_bwd: 1..3 objects per clip (got %d)", N);
+  const int nbanks = kappa_update ? 2 : 1;
+  const int Lm = nbanks * L, Ltot = 2 * Lm, Pm = swem_match_pad(P);
+  MatchBwdWs w = match_bwd_ws(N, C, V, P, L, nbanks);
+  SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "match_bwd: workspace %zu < %zu", ws_bytes, w.total);
+  char *base = static_cast<char *>(ws);
+  // forward intermediates again: mkn, mvp, pT (the readout GEMM's output lands in the dP slot and is overwritten)
+  MatchWs fw = match_ws(N, C, V, P, L, nbanks, 0);
+  char *fb = base + w.fwd;
+  float *mkn = (float *)(fb + fw.mkn), *mvp = (float *)(fb + fw.mvp), *pT = (float *)(fb + fw.pT);
+  float *mvpT = (float *)(base + w.mvpT), *dP = (float *)(base + w.dP), *mknT = (float *)(base + w.mknT);
+  float *dmvp = (float *)(base + w.dmvp), *dqn = (float *)(base + w.dqn);
+  int rc;
+  if ((rc = swem_norm_bases_into(stream, kappa_first, mkn, 2 * N, C, L, Lm, 0))) return rc;
+  if (nbanks == 2 && (rc = swem_norm_bases_into(stream, kappa_update, mkn, 2 * N, C, L, Lm, L))) return rc;
+  const long long work = (long long)N * 2 * V * (L / 4);
+  hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu_first, mvp, N, V, L, Lm, 0);
+  if (nbanks == 2)
+    hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu_update, mvp, N, V, L, Lm, L);
+  const size_t lds = ((size_t)32 * (C + 4) + 256) * sizeof(float);
+  dim3 grid(Pm / 32, N), gridt(cdiv((long long)N * P, 4));
+#define AFF(J_) hipLaunchKernelGGL((match_affinity_kernel<J_>), grid, dim3(256), lds, ST, qk, mkn, pT, C, P, Pm, tau)
+  if (Lm == 64) AFF(1);
+  else if (Lm == 128) AFF(2);
+  else if (Lm == 256) AFF(4);
+  else if (Lm == 512) AFF(8);
+  else {
+    swem_set_error("match_bwd: bases per class must be 64, 128, 256 or 512 (got %d)", Lm);
+    return SWEM_E_SHAPE;
+  }
+#undef AFF
+  SWEM_CHECK_LAUNCH("match_bwd (forward recompute)");
+  // (1) dP[n] = dmem[n] . mvp[n]   (batched GEMM on the conv kernel; filters = mvp[n]^T [Ltot][V])
+  if ((rc = swem_transpose_f32(stream, mvp, mvpT, N, V, Ltot, V))) return rc;
+  if ((rc = swem_conv2d_nhwc_f32(stream, dmem, V, (long long)Pm * V, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, mvpT,
+                                 (long long)Ltot * V, nullptr, nullptr, nullptr, 0, dP, Ltot, 1, 1, 1, 0, 0, 0,
+                                 base + w.conv, w.wgrad - w.conv)))
+    return rc;
+  // (2) dmvp[n] = dmem[n]^T . pT[n]  (the weight-gradient GEMM), unpacked into the banks' layout
+  for (int n = 0; n < N; ++n)
+    if ((rc = swem_conv2d_wgrad_f32(stream, dmem + (long long)n * Pm * V, pT + (long long)n * Pm * Ltot, Ltot, 0, nullptr,
+                                    0, 0, nullptr, 0, 0, 1, Pm, 1, V, 1, 1, 1, 0, 0, dmvp + (long long)n * V * Ltot,
+                                    Ltot, 0, base + w.wgrad, w.total - w.wgrad)))
+      return rc;
+  hipLaunchKernelGGL(unpack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, dmvp, dnu_first, N, V, L, Lm, 0);
+  if (nbanks == 2)
+    hipLaunchKernelGGL(unpack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, dmvp, dnu_update, N, V, L, Lm, L);
+  SWEM_CHECK_LAUNCH("unpack_values");
+  // (3) per pixel: top-l feature gradient + softmax Jacobian -> da (in place of dP)
+#define PIX(J_)                                                                                                 \
+  hipLaunchKernelGGL((match_bwd_pixel_kernel<J_>), gridt, dim3(256), 0, ST, pT, dP, dS, N, P, Pm, topl, 1.0f / tau)
+  if (Lm == 64) PIX(1);
+  else if (Lm == 128) PIX(2);
+  else if (Lm == 256) PIX(4);
+  else PIX(8);
+#undef PIX
+  SWEM_CHECK_LAUNCH("match_bwd_pixel");
+  // (4) d qn = sum_n da[n] . mkn[n]: one GEMM with the objects as concatenated sources (filters [C][N*Ltot])
+  if ((rc = swem_transpose_f32(stream, mkn, mknT, 1, N * Ltot, C, N * Ltot))) return rc;
+  const float *d0 = dP, *d1 = N > 1 ? dP + (long long)Pm * Ltot : nullptr, *d2 = N > 2 ? dP + 2ll * Pm * Ltot : nullptr;
+  if ((rc = swem_conv2d_nhwc_f32(stream, d0, Ltot, 0, d1, N > 1 ? Ltot : 0, 0, d2, N > 2 ? Ltot : 0, 0, 1, Pm, 1, mknT,
+                                 0, nullptr, nullptr, nullptr, 0, dqn, C, 1, 1, 1, 0, 0, 0, base + w.conv,
+                                 w.wgrad - w.conv)))
+    return rc;
+  // (5) through the query's l2norm
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(P, 4)), dim3(256), 0, ST, qk, dqn, dqk, P, C);
+  SWEM_CHECK_LAUNCH("l2norm_bwd");
+  return SWEM_OK;
 }

@@ -1,6 +1,7 @@
 // Memory-bound kernels of the SWEM frame pipeline: input packing, pooling, resampling, CBAM gates,
 // the single-channel prediction head and the mask aggregation head.  All activations are NHWC fp32
 // with C % 4 == 0 so every lane moves 16 bytes; index arithmetic mirrors ATen's so index maps match.
+#include "../../include/swem_hip_train.h"
 #include "common.h"
 
 namespace {
@@ -343,6 +344,222 @@ __global__ void cbam_apply_kernel(const float *__restrict__ x, const float *__re
   st4(y + i * 4, make_float4(v.x + v.x * g.x * s, v.y + v.y * g.y * s, v.z + v.z * g.z * s, v.w + v.w * g.w * s));
 }
 
+// ---------------------------------------------------------------- CBAM backward (training; attentions.py:22-84)
+// y = x + u * s,  u = x * g (channel gate g = sigmoid(mlp(avg) + mlp(max))),  s = sigmoid(conv7([max_c u, mean_c u]))
+__global__ void cbam_stats_kernel(const float *__restrict__ part, float *__restrict__ avg, float *__restrict__ mx,
+                                  int P, int C) {
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f, m = -__builtin_huge_valf();
+  for (int ch = 0; ch < CBAM_CHUNKS; ++ch) {
+    const float *src = part + (((long long)b * CBAM_CHUNKS + ch) * 2) * C + c;
+    s += src[0];
+    m = fmaxf(m, src[C]);
+  }
+  avg[(long long)b * C + c] = s / (float)P;
+  mx[(long long)b * C + c] = m;
+}
+// first pixel attaining the channel maximum (torch's max-pool gradient goes to one position)
+__global__ void cbam_argmax_pix_kernel(const float *__restrict__ x, const float *__restrict__ mx,
+                                       int *__restrict__ amax, int P, int C) {
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float m = mx[(long long)b * C + c];
+  int idx = 0;
+  for (int p = 0; p < P; ++p)
+    if (x[((long long)b * P + p) * C + c] == m) {
+      idx = p;
+      break;
+    }
+  amax[(long long)b * C + c] = idx;
+}
+// da[p] = (sum_c dy * x * g) * s * (1 - s): gradient at the spatial gate's pre-activation.  One wave per pixel.
+__global__ void cbam_bwd_pix1_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                     const float *__restrict__ cscale, const float *__restrict__ sg,
+                                     float *__restrict__ da, int B, int P, int C) {
+  const int lane = threadIdx.x & 63;
+  const long long pix = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pix >= (long long)B * P) return;
+  const int b = (int)(pix / P);
+  float s = 0.f;
+  for (int c4 = lane; c4 < C / 4; c4 += 64) {
+    const float4 v = ld4(x + pix * C + c4 * 4), g = ld4(cscale + (long long)b * C + c4 * 4), d = ld4(dy + pix * C + c4 * 4);
+    s += d.x * v.x * g.x + d.y * v.y * g.y + d.z * v.z * g.z + d.w * v.w * g.w;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) {
+    const float q = sg[pix];
+    da[pix] = s * q * (1.f - q);
+  }
+}
+// transposed 7x7 conv: dcomp[p][k] = sum_taps w7[k][ky][kx] * da[p + 3 - tap]
+__global__ void cbam_bwd_sconv_kernel(const float *__restrict__ da, const float *__restrict__ w7,
+                                      float *__restrict__ dcomp, int B, int H, int W) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * H * W) return;
+  const int ix = (int)(i % W);
+  long long t = i / W;
+  const int iy = (int)(t % H);
+  const int b = (int)(t / H);
+  float a0 = 0.f, a1 = 0.f;
+  for (int ky = 0; ky < 7; ++ky) {
+    const int oy = iy + 3 - ky;
+    if ((unsigned)oy >= (unsigned)H) continue;
+    for (int kx = 0; kx < 7; ++kx) {
+      const int ox = ix + 3 - kx;
+      if ((unsigned)ox >= (unsigned)W) continue;
+      const float d = da[((long long)b * H + oy) * W + ox];
+      a0 += w7[ky * 7 + kx] * d;
+      a1 += w7[49 + ky * 7 + kx] * d;
+    }
+  }
+  dcomp[i * 2] = a0;
+  dcomp[i * 2 + 1] = a1;
+}
+// dw7[k][tap] += sum_p da[p] * comp[p + tap - 3][k];  db7 += sum da.  One block per (k, tap); block 98 = bias.
+__global__ __launch_bounds__(256) void cbam_bwd_w7_kernel(const float *__restrict__ da, const float *__restrict__ comp,
+                                                          float *__restrict__ dw7, float *__restrict__ db7, int B,
+                                                          int H, int W) {
+  __shared__ float sh[256];
+  const int item = blockIdx.x;
+  const int k = item / 49, tap = item - k * 49, ky = tap / 7, kx = tap - ky * 7;
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < (long long)B * H * W; i += 256) {
+    if (item == 98) {
+      s += da[i];
+      continue;
+    }
+    const int ox = (int)(i % W);
+    long long t = i / W;
+    const int oy = (int)(t % H);
+    const int b = (int)(t / H);
+    const int iy = oy - 3 + ky, ix = ox - 3 + kx;
+    if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+    s += da[i] * comp[(((long long)b * H + iy) * W + ix) * 2 + k];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (item == 98) db7[0] += sh[0];
+    else dw7[item] += sh[0];
+  }
+}
+// du = dy * s + dcomp1 / C + [c == argmax_c u] * dcomp0;  dxp = dy + du * g.  One wave per pixel.
+__global__ void cbam_bwd_pix2_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                     const float *__restrict__ cscale, const float *__restrict__ sg,
+                                     const float *__restrict__ comp, const float *__restrict__ dcomp,
+                                     float *__restrict__ du, float *__restrict__ dxp, int B, int P, int C) {
+  const int lane = threadIdx.x & 63;
+  const long long pix = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pix >= (long long)B * P) return;
+  const int b = (int)(pix / P);
+  const float m = comp[pix * 2], d0 = dcomp[pix * 2], d1 = dcomp[pix * 2 + 1] / (float)C, q = sg[pix];
+  int first = 1 << 30;  // first channel whose gated value equals the maximum
+  for (int c4 = lane; c4 < C / 4; c4 += 64) {
+    const float4 v = ld4(x + pix * C + c4 * 4), g = ld4(cscale + (long long)b * C + c4 * 4);
+    const float u[4] = {v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w};
+#pragma unroll
+    for (int e = 3; e >= 0; --e)
+      if (u[e] == m) first = min(first, c4 * 4 + e);
+  }
+  for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+  for (int c4 = lane; c4 < C / 4; c4 += 64) {
+    const float4 g = ld4(cscale + (long long)b * C + c4 * 4), d = ld4(dy + pix * C + c4 * 4);
+    float r[4] = {d.x * q + d1, d.y * q + d1, d.z * q + d1, d.w * q + d1};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c4 * 4 + e == first) r[e] += d0;
+    st4(du + pix * C + c4 * 4, make_float4(r[0], r[1], r[2], r[3]));
+    st4(dxp + pix * C + c4 * 4, make_float4(d.x + r[0] * g.x, d.y + r[1] * g.y, d.z + r[2] * g.z, d.w + r[3] * g.w));
+  }
+}
+// channel-gate MLP backward, one block, batch items in sequence (the parameter gradients accumulate)
+__global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float *__restrict__ avg, const float *__restrict__ mx,
+                                                           const float *__restrict__ cscale,
+                                                           const float *__restrict__ dg, const float *__restrict__ w1,
+                                                           const float *__restrict__ b1, const float *__restrict__ w2,
+                                                           float *__restrict__ dw1, float *__restrict__ db1,
+                                                           float *__restrict__ dw2, float *__restrict__ db2,
+                                                           float *__restrict__ davg, float *__restrict__ dmx, int B,
+                                                           int C, int hid) {
+  extern __shared__ float sm[];  // dA[C], h[2][hid], dh[2][hid]
+  float *dA = sm, *hd = sm + C, *dh = hd + 2 * hid;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int b = 0; b < B; ++b) {
+    const float *av = avg + (long long)b * C, *mv = mx + (long long)b * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const float g = cscale[(long long)b * C + c];
+      dA[c] = dg[(long long)b * C + c] * g * (1.f - g);
+    }
+    for (int j = wave; j < 2 * hid; j += nw) {
+      const float *v = j < hid ? av : mv;
+      const float *wr = w1 + (long long)(j % hid) * C;
+      float s = 0.f;
+      for (int c = lane; c < C; c += 64) s += wr[c] * v[c];
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (lane == 0) hd[j] = fmaxf(s + b1[j % hid], 0.f);
+    }
+    __syncthreads();
+    for (int j = wave; j < hid; j += nw) {  // dh = (h > 0) * W2^T dA  (the same W2 for both pools)
+      float s = 0.f;
+      for (int c = lane; c < C; c += 64) s += w2[(long long)c * hid + j] * dA[c];
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (lane == 0) {
+        dh[j] = hd[j] > 0.f ? s : 0.f;
+        dh[hid + j] = hd[hid + j] > 0.f ? s : 0.f;
+        db1[j] += dh[j] + dh[hid + j];
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float da_ = 0.f, dm_ = 0.f;
+      for (int j = 0; j < hid; ++j) {
+        dw2[(long long)c * hid + j] += dA[c] * (hd[j] + hd[hid + j]);
+        dw1[(long long)j * C + c] += dh[j] * av[c] + dh[hid + j] * mv[c];
+        da_ += w1[(long long)j * C + c] * dh[j];
+        dm_ += w1[(long long)j * C + c] * dh[hid + j];
+      }
+      db2[c] += 2.f * dA[c];
+      davg[(long long)b * C + c] = da_;
+      dmx[(long long)b * C + c] = dm_;
+    }
+    __syncthreads();
+  }
+}
+// dx = dxp + davg / P + [p == argmax_p x] * dmax
+__global__ void cbam_bwd_pix3_kernel(const float *__restrict__ dxp, const float *__restrict__ davg,
+                                     const float *__restrict__ dmx, const int *__restrict__ amax,
+                                     float *__restrict__ dx, int B, int P, int C) {
+  const int cq = C / 4;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * P * cq) return;
+  const int c4 = (int)(i % cq);
+  const long long pix = i / cq;
+  const int b = (int)(pix / P), p = (int)(pix - (long long)b * P);
+  const float4 v = ld4(dxp + i * 4), a = ld4(davg + (long long)b * C + c4 * 4), m = ld4(dmx + (long long)b * C + c4 * 4);
+  const int4 am = *reinterpret_cast<const int4 *>(amax + (long long)b * C + c4 * 4);
+  const float ip = 1.f / (float)P;
+  st4(dx + i * 4, make_float4(v.x + a.x * ip + (am.x == p ? m.x : 0.f), v.y + a.y * ip + (am.y == p ? m.y : 0.f),
+                              v.z + a.z * ip + (am.z == p ? m.z : 0.f), v.w + a.w * ip + (am.w == p ? m.w : 0.f)));
+}
+// dg[b][c] = sum_p du[b][p][c] * x[b][p][c]   (P is small: one thread per 4 channels walks the pixels)
+__global__ void cbam_bwd_dg_kernel(const float *__restrict__ du, const float *__restrict__ x, float *__restrict__ dg,
+                                   int P, int C) {
+  const int cq = C / 4;
+  const int b = blockIdx.y, c4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c4 >= cq) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < P; ++p) {
+    const float4 a = ld4(du + ((long long)b * P + p) * C + c4 * 4), v = ld4(x + ((long long)b * P + p) * C + c4 * 4);
+    s.x += a.x * v.x; s.y += a.y * v.y; s.z += a.z * v.z; s.w += a.w * v.w;
+  }
+  st4(dg + (long long)b * C + c4 * 4, s);
+}
+
 // ---------------------------------------------------------------- decoder heads
 // conv3x3(relu(x)) -> 1 channel: one wave per output pixel, lanes over channel groups
 __global__ void pred_head_kernel(const float *__restrict__ x, const float *__restrict__ w,
@@ -578,6 +795,58 @@ extern "C" int swem_cbam_f32(void *stream, const float *x, const float *w1, cons
   hipLaunchKernelGGL(cbam_apply_kernel, grid1((long long)B * P * (C / 4)), dim3(256), 0, ST, x, cscale, sg, y, B, P,
                      C);
   SWEM_CHECK_LAUNCH("cbam_apply");
+  return SWEM_OK;
+}
+
+// backward of y = x + CBAM(x) (swem_cbam_f32): dx; the six parameter gradients are ACCUMULATED.
+extern "C" size_t swem_cbam_bwd_workspace(int B, int H, int W, int C) {
+  const size_t P = (size_t)H * W;
+  // part, comp, sg, da, dcomp | cscale, avg, max, dg, davg, dmax, amax | du, dxp
+  return ((size_t)B * CBAM_CHUNKS * 2 * C + (size_t)B * P * (2 + 1 + 1 + 2) + (size_t)B * C * 7 + 2 * (size_t)B * P * C) *
+         sizeof(float);
+}
+extern "C" int swem_cbam_bwd_f32(void *stream, const float *x, const float *w1, const float *b1, const float *w2,
+                                 const float *b2, const float *w7, const float *b7, const float *dy, float *dx,
+                                 float *dw1, float *db1, float *dw2, float *db2, float *dw7, float *db7, int B, int H,
+                                 int W, int C, int hid, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(x && w1 && b1 && w2 && b2 && w7 && b7 && dy && dx && dw1 && db1 && dw2 && db2 && dw7 && db7, SWEM_E_ARG,
+               "cbam_bwd: null pointer");
+  SWEM_REQUIRE(C % 4 == 0 && C <= 4096 && hid > 0 && hid <= 256, SWEM_E_SHAPE, "cbam_bwd: unsupported C/hid");
+  SWEM_REQUIRE(ws && ws_bytes >= swem_cbam_bwd_workspace(B, H, W, C), SWEM_E_WORKSPACE, "cbam_bwd: workspace too small");
+  const int P = H * W;
+  float *part = static_cast<float *>(ws);
+  float *comp = part + (size_t)B * CBAM_CHUNKS * 2 * C;
+  float *sg = comp + (size_t)B * P * 2;
+  float *da = sg + (size_t)B * P;
+  float *dcomp = da + (size_t)B * P;
+  float *cscale = dcomp + (size_t)B * P * 2;
+  float *avg = cscale + (size_t)B * C, *mx = avg + (size_t)B * C, *dg = mx + (size_t)B * C;
+  float *davg = dg + (size_t)B * C, *dmx = davg + (size_t)B * C;
+  int *amax = reinterpret_cast<int *>(dmx + (size_t)B * C);
+  float *du = reinterpret_cast<float *>(amax + (size_t)B * C);
+  float *dxp = du + (size_t)B * P * C;
+  // forward intermediates again (cheap next to keeping them alive across the whole clip)
+  hipLaunchKernelGGL(cbam_pool_partial_kernel, dim3(CBAM_CHUNKS, B), dim3(256), 0, ST, x, part, P, C);
+  hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(256), (2 * C + 2 * hid) * sizeof(float), ST, part, w1, b1, w2, b2,
+                     cscale, P, C, hid);
+  hipLaunchKernelGGL(cbam_stats_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, ST, part, avg, mx, P, C);
+  hipLaunchKernelGGL(cbam_argmax_pix_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, ST, x, mx, amax, P, C);
+  hipLaunchKernelGGL(cbam_spatial_pool_kernel, grid1((long long)B * P * 64), dim3(256), 0, ST, x, cscale, comp, B, P,
+                     C);
+  hipLaunchKernelGGL(cbam_sgate_kernel, grid1((long long)B * P), dim3(256), 0, ST, comp, w7, b7, sg, B, H, W);
+  SWEM_CHECK_LAUNCH("cbam_bwd (forward recompute)");
+  hipLaunchKernelGGL(cbam_bwd_pix1_kernel, grid1((long long)B * P * 64), dim3(256), 0, ST, x, dy, cscale, sg, da, B, P,
+                     C);
+  hipLaunchKernelGGL(cbam_bwd_sconv_kernel, grid1((long long)B * P), dim3(256), 0, ST, da, w7, dcomp, B, H, W);
+  hipLaunchKernelGGL(cbam_bwd_w7_kernel, dim3(99), dim3(256), 0, ST, da, comp, dw7, db7, B, H, W);
+  hipLaunchKernelGGL(cbam_bwd_pix2_kernel, grid1((long long)B * P * 64), dim3(256), 0, ST, x, dy, cscale, sg, comp,
+                     dcomp, du, dxp, B, P, C);
+  hipLaunchKernelGGL(cbam_bwd_dg_kernel, dim3(cdiv(C / 4, 64), B), dim3(64), 0, ST, du, x, dg, P, C);
+  hipLaunchKernelGGL(cbam_bwd_mlp_kernel, dim3(1), dim3(256), (C + 4 * hid) * sizeof(float), ST, avg, mx, cscale, dg, w1,
+                     b1, w2, dw1, db1, dw2, db2, davg, dmx, B, C, hid);
+  hipLaunchKernelGGL(cbam_bwd_pix3_kernel, grid1((long long)B * P * (C / 4)), dim3(256), 0, ST, dxp, davg, dmx, amax, dx,
+                     B, P, C);
+  SWEM_CHECK_LAUNCH("cbam_bwd");
   return SWEM_OK;
 }
 

@@ -348,3 +348,507 @@ extern "C" int swem_adamw_f32(void *stream, float *p, const float *g, float *m, 
   SWEM_CHECK_LAUNCH("adamw_kernel");
   return SWEM_OK;
 }
+
+// =====================================================================================================================
+// Backward kernels of the pointwise stages (forward: pointwise.hip).  Gather form throughout: every output element is
+// written by exactly one thread, sums run in a fixed order (deterministic, no atomics).
+// =====================================================================================================================
+namespace {
+
+__device__ __forceinline__ float4 ld4t(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4t(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+inline dim3 grid1t(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// same source-index rule as pointwise.hip (ATen area_pixel_compute_source_index, align_corners=False)
+struct LerpT {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ LerpT lerp_coord_t(int dst, float scale, int in) {
+  float src = scale * (dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  int i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  float l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+  LerpT r;
+  r.i0 = i0;
+  r.i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  r.l1 = l1;
+  r.l0 = 1.f - l1;
+  return r;
+}
+// weight with which destination coordinate d reads source coordinate s (0 if it does not)
+__device__ __forceinline__ float lerp_weight(int d, float scale, int in, int s) {
+  const LerpT l = lerp_coord_t(d, scale, in);
+  return (l.i0 == s ? l.l0 : 0.f) + (l.i1 == s ? l.l1 : 0.f);
+}
+// destination range that can read source coordinate s
+__device__ __forceinline__ void lerp_span(int s, float scale, int out, int &d0, int &d1) {
+  const float inv = 1.f / scale;
+  d0 = max(0, (int)floorf(((float)s - 1.f + 0.5f) * inv - 0.5f) - 1);
+  d1 = min(out - 1, (int)ceilf(((float)s + 1.f + 0.5f) * inv - 0.5f) + 1);
+}
+
+// ---- frozen BatchNorm + residual + ReLU as its own stage (training keeps the raw conv output for the BN gradients)
+__global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ c, const float *__restrict__ alpha,
+                                                     const float *__restrict__ shift, const float *__restrict__ res,
+                                                     float *__restrict__ y, long long M, int C, int relu) {
+  const int cq = C / 4;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * cq) return;
+  const int c4 = (int)(i % cq);
+  const float4 v = ld4t(c + i * 4), a = ld4t(alpha + c4 * 4), s = ld4t(shift + c4 * 4);
+  float4 o = make_float4(v.x * a.x + s.x, v.y * a.y + s.y, v.z * a.z + s.z, v.w * a.w + s.w);
+  if (res) {
+    const float4 rv = ld4t(res + i * 4);
+    o = make_float4(o.x + rv.x, o.y + rv.y, o.z + rv.z, o.w + rv.w);
+  }
+  if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+  st4t(y + i * 4, o);
+}
+// dz = dy * (y > 0) (the residual's gradient), dc = dz * alpha (the conv output's gradient)
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                         const float *__restrict__ alpha, float *__restrict__ dz,
+                                                         float *__restrict__ dc, long long M, int C, int relu) {
+  const int cq = C / 4;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * cq) return;
+  const int c4 = (int)(i % cq);
+  float4 g = ld4t(dy + i * 4);
+  if (relu) {
+    const float4 o = ld4t(y + i * 4);
+    g = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+  }
+  if (dz) st4t(dz + i * 4, g);
+  const float4 a = ld4t(alpha + c4 * 4);
+  st4t(dc + i * 4, make_float4(g.x * a.x, g.y * a.y, g.z * a.z, g.w * a.w));
+}
+// dgamma += invstd * (s2 - mean * s1); dbeta += s1; dbias += alpha * s1   (s1 = sum dz, s2 = sum dz * c)
+__global__ void bn_param_grad_kernel(const float *__restrict__ s1, const float *__restrict__ s2,
+                                     const float *__restrict__ mean, const float *__restrict__ invstd,
+                                     const float *__restrict__ alpha, float *__restrict__ dgamma,
+                                     float *__restrict__ dbeta, float *__restrict__ dbias, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dgamma) dgamma[c] += invstd[c] * (s2[c] - mean[c] * s1[c]);
+  if (dbeta) dbeta[c] += s1[c];
+  if (dbias) dbias[c] += alpha[c] * s1[c];
+}
+
+__global__ void bn_fold_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
+                               const float *__restrict__ mean, const float *__restrict__ var, float eps,
+                               float *__restrict__ alpha, float *__restrict__ shift, float *__restrict__ invstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(var[c] + eps);
+  const float a = gamma[c] / sqrtf(var[c] + eps);
+  alpha[c] = a;
+  shift[c] = beta[c] - mean[c] * a;
+  invstd[c] = is;
+}
+
+// ---- y = f * sigmoid(a) on two [M][C] maps (training runs layer_f / layer_a as two convolutions)
+__global__ __launch_bounds__(256) void glu_kernel(const float *__restrict__ f, const float *__restrict__ a,
+                                                  float *__restrict__ y, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 vf = ld4t(f + i * 4), va = ld4t(a + i * 4);
+  st4t(y + i * 4, make_float4(vf.x * sigmoidf_(va.x), vf.y * sigmoidf_(va.y), vf.z * sigmoidf_(va.z),
+                              vf.w * sigmoidf_(va.w)));
+}
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ f,
+                                                      const float *__restrict__ a, float *__restrict__ df,
+                                                      float *__restrict__ da, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 g = ld4t(dy + i * 4), vf = ld4t(f + i * 4), va = ld4t(a + i * 4);
+  const float s0 = sigmoidf_(va.x), s1 = sigmoidf_(va.y), s2 = sigmoidf_(va.z), s3 = sigmoidf_(va.w);
+  st4t(df + i * 4, make_float4(g.x * s0, g.y * s1, g.z * s2, g.w * s3));
+  st4t(da + i * 4, make_float4(g.x * vf.x * s0 * (1.f - s0), g.y * vf.y * s1 * (1.f - s1), g.z * vf.z * s2 * (1.f - s2),
+                               g.w * vf.w * s3 * (1.f - s3)));
+}
+// y = a + b (identity shortcut of a residual block when the kernel cannot fuse it)
+__global__ __launch_bounds__(256) void add_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                  float *__restrict__ y, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 va = ld4t(a + i * 4), vb = ld4t(b + i * 4);
+  st4t(y + i * 4, make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w));
+}
+
+// ---- max_pool2d(3, 2, 1) backward: the gradient goes to the first maximum of each window (ATen scan order ky, kx)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                          float *__restrict__ dx, int B, int H, int W, int C, int Ho,
+                                                          int Wo) {
+  const int cq = C / 4;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * H * W * cq) return;
+  const int c4 = (int)(i % cq);
+  long long t = i / cq;
+  const int ix = (int)(t % W);
+  t /= W;
+  const int iy = (int)(t % H);
+  const int b = (int)(t / H);
+  const float4 me = ld4t(x + i * 4);
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  const float mv[4] = {me.x, me.y, me.z, me.w};
+  // windows (oy, ox) containing (iy, ix): oy*2-1 <= iy <= oy*2+1
+  for (int oy = max(0, (iy - 1 + 1) / 2); oy <= min(Ho - 1, (iy + 1) / 2); ++oy)
+    for (int ox = max(0, (ix - 1 + 1) / 2); ox <= min(Wo - 1, (ix + 1) / 2); ++ox) {
+      // position of this pixel in the window's scan order, and whether an earlier position holds a value >= ours
+      bool win[4] = {true, true, true, true};
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = oy * 2 - 1 + ky;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = ox * 2 - 1 + kx;
+          if ((unsigned)xx >= (unsigned)W) continue;
+          if (yy == iy && xx == ix) continue;
+          const float4 o = ld4t(x + (((long long)b * H + yy) * W + xx) * C + c4 * 4);
+          const float ov[4] = {o.x, o.y, o.z, o.w};
+          const bool earlier = yy < iy || (yy == iy && xx < ix);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (earlier ? ov[e] >= mv[e] : ov[e] > mv[e]) win[e] = false;
+        }
+      }
+      const float4 d = ld4t(dy + (((long long)b * Ho + oy) * Wo + ox) * C + c4 * 4);
+      const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (win[e]) g[e] += dv[e];
+    }
+  st4t(dx + i * 4, make_float4(g[0], g[1], g[2], g[3]));
+}
+
+// ---- adjoint of the bilinear upsampling inside upsample_add: dlow[b][ly][lx][c] = sum_o w(o->l) dy[b][oy][ox][c]
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dlow, int B,
+                                                           int Hl, int Wl, int Ho, int Wo, int C) {
+  const int cq = C / 4;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * Hl * Wl * cq) return;
+  const int c4 = (int)(i % cq);
+  long long t = i / cq;
+  const int lx = (int)(t % Wl);
+  t /= Wl;
+  const int ly = (int)(t % Hl);
+  const int b = (int)(t / Hl);
+  const float sy = (float)Hl / (float)Ho, sx = (float)Wl / (float)Wo;
+  int y0, y1, x0, x1;
+  lerp_span(ly, sy, Ho, y0, y1);
+  lerp_span(lx, sx, Wo, x0, x1);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int oy = y0; oy <= y1; ++oy) {
+    const float wy = lerp_weight(oy, sy, Hl, ly);
+    if (wy == 0.f) continue;
+    for (int ox = x0; ox <= x1; ++ox) {
+      const float w = wy * lerp_weight(ox, sx, Wl, lx);
+      if (w == 0.f) continue;
+      const float4 d = ld4t(dy + (((long long)b * Ho + oy) * Wo + ox) * C + c4 * 4);
+      acc.x += w * d.x; acc.y += w * d.y; acc.z += w * d.z; acc.w += w * d.w;
+    }
+  }
+  st4t(dlow + i * 4, acc);
+}
+// the same adjoint on NCHW planes (decode head: 1/4-scale logit -> output size)
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx,
+                                                                  int planes, int Hi, int Wi, int Ho, int Wo) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)planes * Hi * Wi) return;
+  const int lx = (int)(i % Wi);
+  long long t = i / Wi;
+  const int ly = (int)(t % Hi);
+  const long long pl = t / Hi;
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  int y0, y1, x0, x1;
+  lerp_span(ly, sy, Ho, y0, y1);
+  lerp_span(lx, sx, Wo, x0, x1);
+  const float *src = dy + pl * Ho * Wo;
+  float acc = 0.f;
+  for (int oy = y0; oy <= y1; ++oy) {
+    const float wy = lerp_weight(oy, sy, Hi, ly);
+    if (wy == 0.f) continue;
+    for (int ox = x0; ox <= x1; ++ox) acc += wy * lerp_weight(ox, sx, Wi, lx) * src[(long long)oy * Wo + ox];
+  }
+  dx[i] = acc;
+}
+
+// ---- decode head backward (swem.py:92-116): softmax -> aggregate (clamp, logit) -> valid -> sigmoid, per output pixel
+// d_up[b][n][pix] = gradient at the bilinearly upsampled single-channel logit (resize_bilinear_bwd brings it to 1/4)
+__global__ __launch_bounds__(256) void decode_head_bwd_kernel(const float *__restrict__ logit4,
+                                                              const float *__restrict__ valid,
+                                                              const float *__restrict__ dlogits,
+                                                              const float *__restrict__ dprob, float *__restrict__ dup,
+                                                              int B, int N, int h4, int w4, int Ho, int Wo) {
+  constexpr int MAXN = 7;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long HW = (long long)Ho * Wo;
+  if (i >= B * HW) return;
+  const int b = (int)(i / HW);
+  const long long pix = i - b * HW;
+  const int oy = (int)(pix / Wo), ox = (int)(pix - (long long)oy * Wo);
+  const LerpT ly = lerp_coord_t(oy, (float)h4 / (float)Ho, h4), lx = lerp_coord_t(ox, (float)w4 / (float)Wo, w4);
+  float sg[MAXN], p[MAXN], lg[MAXN + 1];
+  float bg = 1.f, mx = -INFINITY;
+  for (int n = 0; n < N; ++n) {
+    const float *src = logit4 + ((long long)b * N + n) * h4 * w4;
+    const float r0 = lx.l0 * src[ly.i0 * w4 + lx.i0] + lx.l1 * src[ly.i0 * w4 + lx.i1];
+    const float r1 = lx.l0 * src[ly.i1 * w4 + lx.i0] + lx.l1 * src[ly.i1 * w4 + lx.i1];
+    sg[n] = sigmoidf_(ly.l0 * r0 + ly.l1 * r1);
+    p[n] = valid ? sg[n] * valid[(long long)b * (N + 1) + n + 1] : sg[n];
+    bg *= 1.f - p[n];
+    const float pc = fminf(fmaxf(p[n], 1e-7f), 1.f - 1e-7f);
+    lg[n + 1] = logf(pc / (1.f - pc));
+    mx = fmaxf(mx, lg[n + 1]);
+  }
+  const float bgc = fminf(fmaxf(bg, 1e-7f), 1.f - 1e-7f);
+  lg[0] = logf(bgc / (1.f - bgc));
+  mx = fmaxf(mx, lg[0]);
+  // total gradient at the aggregated logits: the loss's plus the softmax Jacobian applied to d prob
+  float dl[MAXN + 1];
+  float sum = 0.f;
+  for (int n = 0; n <= N; ++n) sum += expf(lg[n] - mx);
+  float dot = 0.f;
+  for (int n = 0; n <= N; ++n) {
+    const float q = expf(lg[n] - mx) / sum;
+    const float dq = dprob ? dprob[((long long)b * (N + 1) + n) * HW + pix] : 0.f;
+    dl[n] = q;           // stash the probability
+    dot += q * dq;
+  }
+  for (int n = 0; n <= N; ++n) {
+    const float q = dl[n];
+    const float dq = dprob ? dprob[((long long)b * (N + 1) + n) * HW + pix] : 0.f;
+    dl[n] = (dlogits ? dlogits[((long long)b * (N + 1) + n) * HW + pix] : 0.f) + q * (dq - dot);
+  }
+  // background: lg0 = logit(clamp(prod(1 - p)));  clamp passes the gradient inside [1e-7, 1 - 1e-7] (inclusive)
+  const float dbg = (bg >= 1e-7f && bg <= 1.f - 1e-7f) ? dl[0] / (bgc * (1.f - bgc)) : 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float pc = fminf(fmaxf(p[n], 1e-7f), 1.f - 1e-7f);
+    float dp = (p[n] >= 1e-7f && p[n] <= 1.f - 1e-7f) ? dl[n + 1] / (pc * (1.f - pc)) : 0.f;
+    float others = 1.f;
+    for (int j = 0; j < N; ++j)
+      if (j != n) others *= 1.f - p[j];
+    dp -= dbg * others;
+    const float v = valid ? valid[(long long)b * (N + 1) + n + 1] : 1.f;
+    dup[((long long)b * N + n) * HW + pix] = dp * v * sg[n] * (1.f - sg[n]);
+  }
+}
+
+// ---- prediction head backward: logit = conv3x3(relu(x)) -> 1 channel
+// dx[pix][c] = (x > 0) * sum_taps dlogit[pix - tap] * w[tap][c]
+__global__ __launch_bounds__(256) void pred_head_bwd_x_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                              const float *__restrict__ dlogit, float *__restrict__ dx,
+                                                              int B, int H, int W, int C) {
+  const int cq = C / 4;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * H * W * cq) return;
+  const int c4 = (int)(i % cq);
+  long long t = i / cq;
+  const int ix = (int)(t % W);
+  t /= W;
+  const int iy = (int)(t % H);
+  const int b = (int)(t / H);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int ky = 0; ky < 3; ++ky) {
+    const int oy = iy + 1 - ky;
+    if ((unsigned)oy >= (unsigned)H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ox = ix + 1 - kx;
+      if ((unsigned)ox >= (unsigned)W) continue;
+      const float d = dlogit[((long long)b * H + oy) * W + ox];
+      const float4 q = ld4t(w + (ky * 3 + kx) * C + c4 * 4);
+      acc.x += d * q.x; acc.y += d * q.y; acc.z += d * q.z; acc.w += d * q.w;
+    }
+  }
+  const float4 v = ld4t(x + i * 4);
+  st4t(dx + i * 4, make_float4(v.x > 0.f ? acc.x : 0.f, v.y > 0.f ? acc.y : 0.f, v.z > 0.f ? acc.z : 0.f,
+                               v.w > 0.f ? acc.w : 0.f));
+}
+// dw[tap][c] partial sums over a chunk of pixels; part [chunks][9][C]
+constexpr int PH_CHUNK = 256;
+__global__ __launch_bounds__(256) void pred_head_bwd_w_kernel(const float *__restrict__ x,
+                                                              const float *__restrict__ dlogit,
+                                                              float *__restrict__ part, int B, int H, int W, int C) {
+  const int cq = C / 4;
+  const long long npix = (long long)B * H * W;
+  const long long p0 = (long long)blockIdx.x * PH_CHUNK, p1 = min(npix, p0 + PH_CHUNK);
+  for (int item = threadIdx.x; item < 9 * cq; item += 256) {
+    const int tap = item / cq, c4 = item - tap * cq;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long pix = p0; pix < p1; ++pix) {
+      const int ox = (int)(pix % W);
+      long long t = pix / W;
+      const int oy = (int)(t % H);
+      const int b = (int)(t / H);
+      const int iy = oy - 1 + ky, ixx = ox - 1 + kx;
+      if ((unsigned)iy >= (unsigned)H || (unsigned)ixx >= (unsigned)W) continue;
+      const float d = dlogit[pix];
+      const float4 v = ld4t(x + (((long long)b * H + iy) * W + ixx) * C + c4 * 4);
+      acc.x += d * fmaxf(v.x, 0.f); acc.y += d * fmaxf(v.y, 0.f); acc.z += d * fmaxf(v.z, 0.f); acc.w += d * fmaxf(v.w, 0.f);
+    }
+    st4t(part + ((long long)blockIdx.x * 9 + tap) * C + c4 * 4, acc);
+  }
+}
+// dw (OIHW [1][C][3][3]) += sum of the chunk partials; db += sum dlogit
+__global__ __launch_bounds__(256) void pred_head_bwd_reduce_kernel(const float *__restrict__ part,
+                                                                   const float *__restrict__ dlogit,
+                                                                   float *__restrict__ dw, float *__restrict__ db,
+                                                                   int nchunk, long long npix, int C) {
+  __shared__ double sh[4];
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x < (unsigned)((9 * C + 255) / 256)) {
+    if (item < 9 * C) {
+      const int tap = item / C, c = item - tap * C;
+      float s = 0.f;
+      for (int j = 0; j < nchunk; ++j) s += part[((long long)j * 9 + tap) * C + c];
+      dw[(long long)c * 9 + tap] += s;
+    }
+    return;
+  }
+  double s = 0.0;   // last block: the bias
+  for (long long i = threadIdx.x; i < npix; i += 256) s += dlogit[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) db[0] += (float)s;
+}
+
+// ---- value-encoder input packing backward: channels [img(3), m, other = 1 - m - m_bg] of the padded 8
+__global__ __launch_bounds__(256) void prep_value_bwd_kernel(const float *__restrict__ dxin, float *__restrict__ dmasks,
+                                                             int B, int N, long long HW, int single_obj) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * HW) return;
+  const int b = (int)(i / HW);
+  const long long p = i - b * HW;
+  float dbg = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float *g = dxin + (((long long)b * N + n) * HW + p) * 8;
+    const float dm = g[3], dother = single_obj ? 0.f : g[4];
+    dmasks[((long long)b * (N + 1) + n + 1) * HW + p] = dm - dother;
+    dbg -= dother;
+  }
+  dmasks[((long long)b * (N + 1)) * HW + p] = dbg;
+}
+
+}  // namespace
+
+#define STT static_cast<hipStream_t>(stream)
+
+extern "C" int swem_bn_act_f32(void *stream, const float *c, const float *alpha, const float *shift, const float *res,
+                               float *y, long long M, int C, int relu) {
+  SWEM_REQUIRE(c && alpha && shift && y && C % 4 == 0 && M > 0, SWEM_E_ARG, "bn_act: bad argument");
+  hipLaunchKernelGGL(bn_act_kernel, grid1t(M * (C / 4)), dim3(256), 0, STT, c, alpha, shift, res, y, M, C, relu);
+  SWEM_CHECK_LAUNCH("bn_act_kernel");
+  return SWEM_OK;
+}
+extern "C" int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y, const float *alpha, float *dz,
+                                   float *dc, long long M, int C, int relu) {
+  SWEM_REQUIRE(dy && alpha && dc && (y || !relu) && C % 4 == 0 && M > 0, SWEM_E_ARG, "bn_act_bwd: bad argument");
+  hipLaunchKernelGGL(bn_act_bwd_kernel, grid1t(M * (C / 4)), dim3(256), 0, STT, dy, y, alpha, dz, dc, M, C, relu);
+  SWEM_CHECK_LAUNCH("bn_act_bwd_kernel");
+  return SWEM_OK;
+}
+extern "C" int swem_bn_param_grad_f32(void *stream, const float *s1, const float *s2, const float *mean,
+                                      const float *invstd, const float *alpha, float *dgamma, float *dbeta,
+                                      float *dbias, int C) {
+  SWEM_REQUIRE(s1 && s2 && mean && invstd && alpha && C > 0, SWEM_E_ARG, "bn_param_grad: bad argument");
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, STT, s1, s2, mean, invstd, alpha, dgamma,
+                     dbeta, dbias, C);
+  SWEM_CHECK_LAUNCH("bn_param_grad_kernel");
+  return SWEM_OK;
+}
+extern "C" int swem_bn_fold_f32(void *stream, const float *gamma, const float *beta, const float *mean,
+                                const float *var, float eps, float *alpha, float *shift, float *invstd, int C) {
+  SWEM_REQUIRE(gamma && beta && mean && var && alpha && shift && invstd && C > 0, SWEM_E_ARG, "bn_fold: bad argument");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, STT, gamma, beta, mean, var, eps, alpha, shift,
+                     invstd, C);
+  SWEM_CHECK_LAUNCH("bn_fold_kernel");
+  return SWEM_OK;
+}
+extern "C" int swem_glu_f32(void *stream, const float *f, const float *a, float *y, long long n) {
+  SWEM_REQUIRE(f && a && y && n > 0 && n % 4 == 0, SWEM_E_ARG, "glu: bad argument");
+  hipLaunchKernelGGL(glu_kernel, grid1t(n / 4), dim3(256), 0, STT, f, a, y, n / 4);
+  SWEM_CHECK_LAUNCH("glu_kernel");
+  return SWEM_OK;
+}
+extern "C" int swem_glu_bwd_f32(void *stream, const float *dy, const float *f, const float *a, float *df, float *da,
+                                long long n) {
+  SWEM_REQUIRE(dy && f && a && df && da && n > 0 && n % 4 == 0, SWEM_E_ARG, "glu_bwd: bad argument");
+  hipLaunchKernelGGL(glu_bwd_kernel, grid1t(n / 4), dim3(256), 0, STT, dy, f, a, df, da, n / 4);
+  SWEM_CHECK_LAUNCH("glu_bwd_kernel");
+  return SWEM_OK;
+}
+extern "C" int swem_add_f32(void *stream, const float *a, const float *b, float *y, long long n) {
+  SWEM_REQUIRE(a && b && y && n > 0 && n % 4 == 0, SWEM_E_ARG, "add: bad argument");
+  hipLaunchKernelGGL(add_kernel, grid1t(n / 4), dim3(256), 0, STT, a, b, y, n / 4);
+  SWEM_CHECK_LAUNCH("add_kernel");
+  return SWEM_OK;
+}
+extern "C" int swem_maxpool3x3s2_bwd_f32(void *stream, const float *x, const float *dy, float *dx, int B, int H, int W,
+                                         int C) {
+  SWEM_REQUIRE(x && dy && dx && C % 4 == 0, SWEM_E_ARG, "maxpool_bwd: bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, grid1t((long long)B * H * W * (C / 4)), dim3(256), 0, STT, x, dy, dx, B, H, W,
+                     C, Ho, Wo);
+  SWEM_CHECK_LAUNCH("maxpool_bwd_kernel");
+  return SWEM_OK;
+}
+extern "C" int swem_upsample_bwd_nhwc_f32(void *stream, const float *dy, float *dlow, int B, int Hl, int Wl, int Ho,
+                                          int Wo, int C) {
+  SWEM_REQUIRE(dy && dlow && C % 4 == 0 && Ho >= Hl && Wo >= Wl, SWEM_E_ARG, "upsample_bwd: bad argument");
+  hipLaunchKernelGGL(upsample_bwd_kernel, grid1t((long long)B * Hl * Wl * (C / 4)), dim3(256), 0, STT, dy, dlow, B, Hl,
+                     Wl, Ho, Wo, C);
+  SWEM_CHECK_LAUNCH("upsample_bwd_kernel");
+  return SWEM_OK;
+}
+extern "C" int swem_resize_bilinear_bwd_f32(void *stream, const float *dy, float *dx, int planes, int Hi, int Wi,
+                                            int Ho, int Wo) {
+  SWEM_REQUIRE(dy && dx && planes > 0 && Ho >= Hi && Wo >= Wi, SWEM_E_ARG,
+               "resize_bilinear_bwd: bad argument (upsampling only)");
+  hipLaunchKernelGGL(resize_bilinear_bwd_kernel, grid1t((long long)planes * Hi * Wi), dim3(256), 0, STT, dy, dx, planes,
+                     Hi, Wi, Ho, Wo);
+  SWEM_CHECK_LAUNCH("resize_bilinear_bwd_kernel");
+  return SWEM_OK;
+}
+extern "C" int swem_decode_head_bwd_f32(void *stream, const float *logit4, const float *valid, const float *dlogits,
+                                        const float *dprob, float *dlogit4, int B, int N, int h4, int w4, int Ho,
+                                        int Wo, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(logit4 && dlogit4 && (dlogits || dprob) && N > 0 && N <= 7, SWEM_E_ARG, "decode_head_bwd: bad argument");
+  const size_t need = (size_t)B * N * Ho * Wo * sizeof(float);
+  SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "decode_head_bwd: workspace %zu < %zu bytes", ws_bytes, need);
+  float *dup = static_cast<float *>(ws);
+  hipLaunchKernelGGL(decode_head_bwd_kernel, grid1t((long long)B * Ho * Wo), dim3(256), 0, STT, logit4, valid, dlogits,
+                     dprob, dup, B, N, h4, w4, Ho, Wo);
+  SWEM_CHECK_LAUNCH("decode_head_bwd_kernel");
+  hipLaunchKernelGGL(resize_bilinear_bwd_kernel, grid1t((long long)B * N * h4 * w4), dim3(256), 0, STT, dup, dlogit4,
+                     B * N, h4, w4, Ho, Wo);
+  SWEM_CHECK_LAUNCH("resize_bilinear_bwd_kernel");
+  return SWEM_OK;
+}
+extern "C" size_t swem_pred_head_bwd_workspace(int B, int H, int W, int C) {
+  return (size_t)cdiv((long long)B * H * W, PH_CHUNK) * 9 * C * sizeof(float);
+}
+extern "C" int swem_pred_head_bwd_f32(void *stream, const float *x, const float *w, const float *dlogit, float *dx,
+                                      float *dw, float *db, int B, int H, int W, int C, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(x && w && dlogit && dx && dw && db && C % 4 == 0, SWEM_E_ARG, "pred_head_bwd: bad argument");
+  const size_t need = swem_pred_head_bwd_workspace(B, H, W, C);
+  SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "pred_head_bwd: workspace %zu < %zu bytes", ws_bytes, need);
+  const long long npix = (long long)B * H * W;
+  const int nchunk = cdiv(npix, PH_CHUNK);
+  float *part = static_cast<float *>(ws);
+  hipLaunchKernelGGL(pred_head_bwd_x_kernel, grid1t(npix * (C / 4)), dim3(256), 0, STT, x, w, dlogit, dx, B, H, W, C);
+  SWEM_CHECK_LAUNCH("pred_head_bwd_x_kernel");
+  hipLaunchKernelGGL(pred_head_bwd_w_kernel, dim3(nchunk), dim3(256), 0, STT, x, dlogit, part, B, H, W, C);
+  SWEM_CHECK_LAUNCH("pred_head_bwd_w_kernel");
+  hipLaunchKernelGGL(pred_head_bwd_reduce_kernel, dim3(cdiv(9 * C, 256) + 1), dim3(256), 0, STT, part, dlogit, dw, db,
+                     nchunk, npix, C);
+  SWEM_CHECK_LAUNCH("pred_head_bwd_reduce_kernel");
+  return SWEM_OK;
+}
+extern "C" int swem_prep_value_input_bwd_f32(void *stream, const float *dxin, float *dmasks, int B, int N, int H, int W,
+                                             int single_obj) {
+  SWEM_REQUIRE(dxin && dmasks && N > 0, SWEM_E_ARG, "prep_value_input_bwd: bad argument");
+  hipLaunchKernelGGL(prep_value_bwd_kernel, grid1t((long long)B * H * W), dim3(256), 0, STT, dxin, dmasks, B, N,
+                     (long long)H * W, single_obj);
+  SWEM_CHECK_LAUNCH("prep_value_bwd_kernel");
+  return SWEM_OK;
+}

@@ -1,0 +1,309 @@
+// Weight gradient of the implicit-GEMM convolution and the column reductions of the backward pass (gfx950).
+//
+//   dW[n][k] = sum_m dY[m][n] * A[m][k]        n = filter, k = (ky, kx, ci), m = output pixel (the reduction axis)
+//
+// A "TN" GEMM: both operands are read pixel-major ([m][channel], channels contiguous), so a 32-pixel slab of each is
+// staged in LDS as it lies in memory and the MFMA operands are read down the pixel axis: lane (i, h) of
+// v_mfma_f32_32x32x2_f32 takes dY[m = 2kk + h][n = i] and A[m = 2kk + h][k = i] -- consecutive lanes read consecutive
+// floats of one LDS row (conflict free).  Block = 2x2 waves, wave tile (32 WT) x (32 WT); one block owns one
+// (filter tile, tap, channel tile) and a slice of the pixels (grid.z); the slices are summed in a fixed order by the
+// reduce kernel, which also writes the reference's OIHW layout and accumulates into the gradient buffer.
+#include "../../include/swem_hip_train.h"
+#include "common.h"
+
+namespace {
+
+struct WgradP {
+  const float *dy;
+  const float *x;
+  long long bs;       // batch stride of x in elements (0 = one map shared by every batch item)
+  int cs, c_off;      // channels of this source, its offset inside the concatenated Cin
+  int B, H, W, Ho, Wo, Cout, Cin, KH, KW, stride, pad, relu_in;
+  int M, m_per_split, ctiles, K;
+  float *partial;     // [zsplit][Cout][K]
+};
+
+__device__ __forceinline__ float4 ld4g(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+template <int WT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
+  constexpr int BT = 64 * WT;        // tile edge (filters and channels)
+  constexpr int LD = BT + 4;         // LDS row stride in floats (keeps 16-byte alignment, shifts the second half-wave)
+  constexpr int NL = BT / 32;        // float4 loads per thread per operand per 32-pixel slab
+  __shared__ __attribute__((aligned(16))) float Ds[32 * LD];
+  __shared__ __attribute__((aligned(16))) float Xs[32 * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * BT;
+  const int tap = blockIdx.y / p.ctiles, ci0 = (blockIdx.y - tap * p.ctiles) * BT;
+  const int ky = tap / p.KW, kx = tap - ky * p.KW;
+  const int m_begin = blockIdx.z * p.m_per_split, m_end = min(p.M, m_begin + p.m_per_split);
+  const int HoWo = p.Ho * p.Wo;
+  constexpr int C4 = BT / 4;         // float4 per slab row
+  int lrow[NL], lc4[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int f = tid + 256 * i;
+    lrow[i] = f / C4;
+    lc4[i] = f - lrow[i] * C4;
+  }
+  float4 gd[NL], gx[NL];
+  auto gload = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int m = mb + lrow[i];
+      const bool mok = m < m_end;
+      const int n = n0 + lc4[i] * 4;
+      gd[i] = (mok && n < p.Cout) ? ld4g(p.dy + (long long)m * p.Cout + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int b = m / HoWo, rem = m - b * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+      const int c = ci0 + lc4[i] * 4;
+      const bool ok = mok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cs;
+      float4 v = ok ? ld4g(p.x + (long long)b * p.bs + ((long long)iy * p.W + ix) * p.cs + c)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.relu_in) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      gx[i] = v;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      *reinterpret_cast<float4 *>(&Ds[lrow[i] * LD + lc4[i] * 4]) = gd[i];
+      *reinterpret_cast<float4 *>(&Xs[lrow[i] * LD + lc4[i] * 4]) = gx[i];
+    }
+  };
+  f32x16 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  gload(m_begin);
+  for (int mb = m_begin; mb < m_end; mb += 32) {
+    __syncthreads();   // the previous slab has been consumed
+    lstore();
+    __syncthreads();
+    if (mb + 32 < m_end) gload(mb + 32);
+    const float *Db = Ds + h * LD + wn * 32 * WT + r;
+    const float *Xb = Xs + h * LD + wc * 32 * WT + r;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[WT], b[WT];
+#pragma unroll
+      for (int i = 0; i < WT; ++i) a[i] = Db[2 * kk * LD + 32 * i];
+#pragma unroll
+      for (int j = 0; j < WT; ++j) b[j] = Xb[2 * kk * LD + 32 * j];
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    }
+  }
+  float *dst = p.partial + (long long)blockIdx.z * p.Cout * p.K + (long long)tap * p.Cin + p.c_off;
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const int c = ci0 + wc * 32 * WT + 32 * j + r;
+      if (c >= p.cs) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wn * 32 * WT + 32 * i + acc_row(e, h);
+        if (n < p.Cout) dst[(long long)n * p.K + c] = acc[i][j][e];
+      }
+    }
+}
+
+// sum the pixel slices in order, write OIHW (the reference's parameter layout), optionally accumulate
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial,
+                                                                float *__restrict__ dw, int Cout, int Cin, int taps,
+                                                                int Cin_store, int zsplit, int accumulate) {
+  const long long K = (long long)taps * Cin;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)Cout * K) return;
+  const int n = (int)(i / K);
+  const long long k = i - (long long)n * K;
+  const int tap = (int)(k / Cin), ci = (int)(k - (long long)tap * Cin);
+  if (ci >= Cin_store) return;       // zero-padded input channels of the stems have no parameter
+  float s = 0.f;
+  for (int z = 0; z < zsplit; ++z) s += partial[(long long)z * Cout * K + i];
+  float *o = dw + ((long long)n * Cin_store + ci) * taps + tap;
+  *o = accumulate ? *o + s : s;
+}
+
+// per-column sums of a [M][C] matrix (optionally of the product with a second one): stage 1 = one partial row per
+// block row, stage 2 = fixed-order sum.  Serves the bias / frozen-BatchNorm parameter gradients.
+constexpr int CS_ROWS = 512;  // rows per stage-1 block
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                             float *__restrict__ part, long long M, int C) {
+  __shared__ float4 sh1[256], sh2[256];
+  const int cq = C / 4;
+  const int c4 = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int rsub = threadIdx.x >> 4;  // 16 row lanes
+  const long long m0 = (long long)blockIdx.y * CS_ROWS, m1 = min(M, m0 + CS_ROWS);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (c4 < cq)
+    for (long long m = m0 + rsub; m < m1; m += 16) {
+      const float4 va = ld4g(a + m * C + c4 * 4);
+      s1.x += va.x; s1.y += va.y; s1.z += va.z; s1.w += va.w;
+      if (b) {
+        const float4 vb = ld4g(b + m * C + c4 * 4);
+        s2.x += va.x * vb.x; s2.y += va.y * vb.y; s2.z += va.z * vb.z; s2.w += va.w * vb.w;
+      }
+    }
+  sh1[threadIdx.x] = s1;
+  sh2[threadIdx.x] = s2;
+  __syncthreads();
+  if (rsub == 0 && c4 < cq) {
+    for (int j = 1; j < 16; ++j) {
+      const float4 t1 = sh1[threadIdx.x + 16 * j], t2 = sh2[threadIdx.x + 16 * j];
+      s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
+      s2.x += t2.x; s2.y += t2.y; s2.z += t2.z; s2.w += t2.w;
+    }
+    float *dst = part + ((long long)blockIdx.y * 2) * C + c4 * 4;
+    *reinterpret_cast<float4 *>(dst) = s1;
+    *reinterpret_cast<float4 *>(dst + C) = s2;
+  }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, float *__restrict__ out1,
+                                                           float *__restrict__ out2, int nrow, int C,
+                                                           int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int j = 0; j < nrow; ++j) {
+    s1 += part[((long long)j * 2) * C + c];
+    s2 += part[((long long)j * 2 + 1) * C + c];
+  }
+  if (out1) out1[c] = accumulate ? out1[c] + s1 : s1;
+  if (out2) out2[c] = accumulate ? out2[c] + s2 : s2;
+}
+
+// y[i] (+)= sum_b x[b][i]: gradient of a tensor that was broadcast over the objects of a frame
+__global__ __launch_bounds__(256) void sum_batch_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
+                                                        long long n4, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = ld4g(x + i * 4);
+  for (int b = 1; b < B; ++b) {
+    const float4 v = ld4g(x + ((long long)b * n4 + i) * 4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (accumulate) {
+    const float4 o = ld4g(y + i * 4);
+    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+  }
+  *reinterpret_cast<float4 *>(y + i * 4) = s;
+}
+
+struct WgradPlan {
+  int wt, zsplit, m_per_split;
+};
+WgradPlan wgrad_plan(long long M, int Cout, int KH, int KW, int c0, int c1, int c2) {
+  WgradPlan pl;
+  const bool big = Cout >= 128 && c0 >= 128 && (c1 == 0 || c1 >= 128) && (c2 == 0 || c2 >= 128);
+  pl.wt = big ? 2 : 1;
+  const int bt = 64 * pl.wt;
+  long long tiles = (long long)cdiv(Cout, bt) * KH * KW * (cdiv(c0, bt) + (c1 ? cdiv(c1, bt) : 0) + (c2 ? cdiv(c2, bt) : 0));
+  long long zs = 2048 / (tiles > 0 ? tiles : 1);
+  const long long zmax = (M + 255) / 256;
+  if (zs > zmax) zs = zmax;
+  if (zs < 1) zs = 1;
+  long long per = ((M + zs - 1) / zs + 31) / 32 * 32;
+  pl.m_per_split = (int)per;
+  pl.zsplit = (int)((M + per - 1) / per);
+  return pl;
+}
+
+}  // namespace
+
+extern "C" size_t swem_conv2d_wgrad_workspace(int B, int H, int W, int c0, int c1, int c2, int Cout, int KH, int KW,
+                                              int stride, int pad) {
+  if (stride <= 0) return 0;
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const long long M = (long long)B * Ho * Wo;
+  WgradPlan pl = wgrad_plan(M, Cout, KH, KW, c0, c1, c2);
+  return (size_t)pl.zsplit * Cout * KH * KW * (c0 + c1 + c2) * sizeof(float);
+}
+
+extern "C" int swem_conv2d_wgrad_f32(void *stream, const float *dy, const float *x0, int c0, long long bs0,
+                                     const float *x1, int c1, long long bs1, const float *x2, int c2, long long bs2,
+                                     int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu_in,
+                                     float *dw, int cin_store, int accumulate, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(dy && x0 && dw, SWEM_E_ARG, "conv2d_wgrad: null pointer");
+  SWEM_REQUIRE((c1 == 0 || x1) && (c2 == 0 || x2) && c0 > 0 && c0 % 4 == 0 && c1 % 4 == 0 && c2 % 4 == 0 &&
+                   Cout % 4 == 0 && Cout > 0,
+               SWEM_E_SHAPE, "conv2d_wgrad: channel counts must be multiples of 4");
+  SWEM_REQUIRE(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, SWEM_E_SHAPE,
+               "conv2d_wgrad: bad geometry");
+  const int Cin = c0 + c1 + c2;
+  SWEM_REQUIRE(cin_store > 0 && cin_store <= Cin, SWEM_E_SHAPE, "conv2d_wgrad: cin_store out of range");
+  WgradP p;
+  p.dy = dy;
+  p.B = B; p.H = H; p.W = W;
+  p.Ho = (H + 2 * pad - KH) / stride + 1;
+  p.Wo = (W + 2 * pad - KW) / stride + 1;
+  SWEM_REQUIRE(p.Ho > 0 && p.Wo > 0, SWEM_E_SHAPE, "conv2d_wgrad: empty output");
+  const long long M = (long long)B * p.Ho * p.Wo;
+  SWEM_REQUIRE(M < (1ll << 31), SWEM_E_SHAPE, "conv2d_wgrad: too large");
+  p.M = (int)M;
+  p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.relu_in = relu_in;
+  p.K = KH * KW * Cin;
+  WgradPlan pl = wgrad_plan(M, Cout, KH, KW, c0, c1, c2);
+  const size_t need = (size_t)pl.zsplit * Cout * p.K * sizeof(float);
+  SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+  p.partial = static_cast<float *>(ws);
+  p.m_per_split = pl.m_per_split;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float *xs[3] = {x0, x1, x2};
+  const int cs[3] = {c0, c1, c2};
+  const long long bss[3] = {bs0, bs1, bs2};
+  const int bt = 64 * pl.wt;
+  int off = 0;
+  for (int s = 0; s < 3; ++s) {
+    if (cs[s] == 0) continue;
+    p.x = xs[s]; p.cs = cs[s]; p.bs = bss[s]; p.c_off = off;
+    p.ctiles = cdiv(cs[s], bt);
+    dim3 grid(cdiv(Cout, bt), KH * KW * p.ctiles, pl.zsplit);
+    if (pl.wt == 2) hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, st, p);
+    SWEM_CHECK_LAUNCH("conv_wgrad_kernel");
+    off += cs[s];
+  }
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((long long)Cout * p.K, 256)), dim3(256), 0, st, p.partial, dw,
+                     Cout, Cin, KH * KW, cin_store, pl.zsplit, accumulate);
+  SWEM_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
+  return SWEM_OK;
+}
+
+extern "C" size_t swem_colsum_workspace(long long M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  return (size_t)cdiv(M, CS_ROWS) * 2 * C * sizeof(float);
+}
+
+extern "C" int swem_colsum_f32(void *stream, const float *a, const float *b, float *out1, float *out2, long long M,
+                               int C, int accumulate, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(a && (out1 || out2) && M > 0 && C > 0 && C % 4 == 0, SWEM_E_ARG, "colsum: bad argument");
+  SWEM_REQUIRE(!out2 || b, SWEM_E_ARG, "colsum: the product sum needs the second matrix");
+  const size_t need = swem_colsum_workspace(M, C);
+  SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "colsum: workspace %zu < %zu bytes", ws_bytes, need);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nrow = cdiv(M, CS_ROWS);
+  float *part = static_cast<float *>(ws);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C / 4, 16), nrow), dim3(256), 0, st, a, b, part, M, C);
+  SWEM_CHECK_LAUNCH("colsum_partial_kernel");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, out1, out2, nrow, C, accumulate);
+  SWEM_CHECK_LAUNCH("colsum_final_kernel");
+  return SWEM_OK;
+}
+
+extern "C" int swem_sum_batch_f32(void *stream, const float *x, float *y, int B, long long n, int accumulate) {
+  SWEM_REQUIRE(x && y && B > 0 && n > 0 && n % 4 == 0, SWEM_E_ARG, "sum_batch: bad argument");
+  hipLaunchKernelGGL(sum_batch_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, B,
+                     n / 4, accumulate);
+  SWEM_CHECK_LAUNCH("sum_batch_kernel");
+  return SWEM_OK;
+}

@@ -137,10 +137,15 @@ def presplit(t, relu=False):
     return sp
 
 
+DGRAD, DGRAD_EH, DGRAD_EW, MASK_POS = 8, 16, 32, 64
+
+
 def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadcast=False, batch=None, out=None,
-           plan=None):
+           plan=None, dgrad=None, mask=None):
     """srcs: list of up to three NHWC tensors concatenated on C; a source with batch 1 is broadcast over `batch`.
-    plan: explicit plan hint (include/swem_hip.h); default = tuned plan of this layer shape, else the heuristic."""
+    plan: explicit plan hint (include/swem_hip.h); default = tuned plan of this layer shape, else the heuristic.
+    dgrad=(H, W): data-gradient mode (SWEM_CONV_DGRAD): srcs = [dY], pack = the transposed filters, the result has the
+    forward input's size H x W.  mask: tensor of the output's shape; the result is zeroed where mask <= 0."""
     x0 = _chk_src(srcs[0])
     B = batch if batch is not None else max(s.shape[0] for s in srcs)
     _, H, W, _ = x0.shape
@@ -160,6 +165,17 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     Ho = (H + 2 * pack.pad - pack.kh) // pack.stride + 1
     Wo = (W + 2 * pack.pad - pack.kw) // pack.stride + 1
     flags = (RELU_IN if relu_in else 0) | (RELU_OUT if relu_out else 0) | (GLU if pack.glu else 0)
+    if dgrad is not None:
+        Ho, Wo = dgrad
+        eh = Ho - ((H - 1) * pack.stride + pack.kh - 2 * pack.pad)
+        ew = Wo - ((W - 1) * pack.stride + pack.kw - 2 * pack.pad)
+        if eh not in (0, 1) or ew not in (0, 1):
+            raise _lib.SwemHipError('conv2d dgrad: %dx%d is not an input size of this %dx%d output' % (Ho, Wo, H, W))
+        flags |= DGRAD | (DGRAD_EH if eh else 0) | (DGRAD_EW if ew else 0)
+    if mask is not None:
+        if residual is not None:
+            raise _lib.SwemHipError('conv2d: mask and residual share the res operand')
+        residual, flags = mask, flags | MASK_POS
     y = out if out is not None else torch.empty((B, Ho, Wo, pack.cout), dtype=torch.float32, device=x0.device)
     res_bs = 0
     if residual is not None:
