@@ -1,0 +1,489 @@
+"""Differentiable stages of the SWEM training step: ``torch.autograd.Function`` wrappers whose forward AND backward are
+HIP kernels (C ABI: include/swem_hip.h, include/swem_hip_train.h).
+
+torch's autograd engine is used for what it is here -- the tape: it records which stage produced which tensor and calls
+the ``backward`` below in reverse order on the forward stream.  No arithmetic is done by torch.  Activations are NHWC
+fp32 tensors (B, H, W, C) as in the inference engine.
+
+Parameter gradients are ACCUMULATED IN-KERNEL into ``param.grad`` (views of the optimizer's flat gradient buffer,
+``optim.make_optimizer``): the ``backward`` functions return ``None`` for parameters.  ``param.grad`` must exist and be
+zeroed before the step (``optimizer.zero_grad()``); ``ensure_grads`` creates missing ones.
+
+Reference graph: methods/SWEM/swem_trainer.py:59-108 through swem.py / networks.py / modules.py (cited per stage).
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import _lib, ops
+
+_PACKS = {}      # (id(weight), tag) -> packed operand; parameters change every optimizer step: new_step() clears it
+
+
+def new_step():
+    _PACKS.clear()
+
+
+def ensure_grads(params):
+    for p in params:
+        if p.requires_grad and p.grad is None:
+            p.grad = torch.zeros_like(p)
+
+
+def _grad(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    if not p.grad.is_contiguous():
+        raise _lib.SwemHipError('parameter gradient buffers must be contiguous')
+    return p.grad
+
+
+def _ws(nbytes, dev):
+    return ops.workspace(nbytes, dev)
+
+
+def colsum(a, b=None, out1=None, out2=None, accumulate=True):
+    """out1[c] (+)= sum_m a[m][c]; out2[c] (+)= sum_m a[m][c]*b[m][c] over all leading dimensions."""
+    Cc = a.shape[-1]
+    M = a.numel() // Cc
+    wsb = _lib.query('swem_colsum_workspace', M, Cc)
+    ws = _ws(wsb, a.device)
+    _lib.call('swem_colsum_f32', ops._stream(), a.data_ptr(), ops._ptr(b), ops._ptr(out1), ops._ptr(out2), M, Cc,
+              int(accumulate), ws.data_ptr(), wsb)
+
+
+def sum_batch(x, out=None, accumulate=False):
+    """(B, ...) -> (1, ...): gradient of a map shared by the objects of a frame."""
+    B = x.shape[0]
+    n = x.numel() // B
+    y = out if out is not None else torch.empty((1,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    _lib.call('swem_sum_batch_f32', ops._stream(), x.data_ptr(), y.data_ptr(), B, n, int(accumulate))
+    return y
+
+
+# --------------------------------------------------------------------------------------------- convolution
+def _fwd_pack(weight, bias, stride, pad, cin_pad):
+    key = (id(weight), 'fwd', cin_pad)
+    pk = _PACKS.get(key)
+    if pk is None:
+        pk = _PACKS[key] = ops.pack_conv(weight, bias, None, stride, pad, cin_pad=cin_pad)
+    return pk
+
+
+def _dgrad_pack(weight, off, c, stride, pad, cin_pad):
+    """Filters of the data-gradient GEMM for the source that owns input channels [off, off+c): [c][KH][KW][Cout]."""
+    key = (id(weight), 'dgrad', off, c, cin_pad)
+    pk = _PACKS.get(key)
+    if pk is None:
+        co, ci, kh, kw = weight.shape
+        w = weight.detach()
+        if cin_pad is not None and cin_pad != ci:
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_pad - ci))
+        wt = w[:, off:off + c].permute(1, 2, 3, 0).contiguous()        # [c][KH][KW][Cout]
+        pk = _PACKS[key] = ops.ConvPack(wt, None, None, c, kh, kw, stride, pad)
+    return pk
+
+
+class _Conv(Function):
+    """y = conv(act(cat(srcs)), W) + b (+ residual); act = ReLU when relu_in (networks.py:22-32 pre-activation blocks,
+    mod_resnet convs, modules.py:25-26, swem.py:33).  A source with batch 1 is shared by all `batch` items."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, residual, meta, *srcs):
+        stride, pad, relu_in, batch, cin_pad = meta
+        pk = _fwd_pack(weight, bias, stride, pad, cin_pad)
+        y = ops.conv2d(list(srcs), pk, relu_in=relu_in, residual=residual, batch=batch)
+        ctx.meta = meta
+        ctx.weight, ctx.bias, ctx.srcs = weight, bias, srcs
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, pad, relu_in, batch, cin_pad = ctx.meta
+        weight, bias, srcs = ctx.weight, ctx.bias, ctx.srcs
+        dy = dy.contiguous()
+        B, Ho, Wo, Cout = dy.shape
+        dev = dy.device
+        if bias is not None and bias.requires_grad:
+            colsum(dy, out1=_grad(bias))
+        H, W = srcs[0].shape[1:3]
+        if weight.requires_grad:
+            cs = [s.shape[3] for s in srcs] + [0, 0]
+            args = []
+            for s in srcs:
+                bs = 0 if (s.shape[0] == 1 and B > 1) else (s.stride(0) if s.shape[0] > 1 else H * W * s.shape[3])
+                args += [s.data_ptr(), s.shape[3], bs]
+            for _ in range(3 - len(srcs)):
+                args += [0, 0, 0]
+            kh, kw = weight.shape[2:]
+            wsb = _lib.query('swem_conv2d_wgrad_workspace', B, H, W, cs[0], cs[1], cs[2], Cout, kh, kw, stride, pad)
+            ws = _ws(wsb, dev)
+            _lib.call('swem_conv2d_wgrad_f32', ops._stream(), dy.data_ptr(), *args, B, H, W, Cout, kh, kw, stride, pad,
+                      int(relu_in), _grad(weight).data_ptr(), weight.shape[1], 1, ws.data_ptr(), wsb)
+        grads = []
+        off = 0
+        for i, s in enumerate(srcs):
+            c = s.shape[3]
+            g = None
+            if ctx.needs_input_grad[4 + i]:
+                pk = _dgrad_pack(weight, off, c, stride, pad, cin_pad)
+                g = ops.conv2d([dy], pk, dgrad=(H, W), mask=s if relu_in else None, batch=B)
+                if s.shape[0] == 1 and B > 1:
+                    g = sum_batch(g)
+            grads.append(g)
+            off += c
+        return (None, None, dy if ctx.has_res else None, None, *grads)
+
+
+def conv2d(srcs, weight, bias=None, stride=1, pad=None, relu_in=False, residual=None, batch=None, cin_pad=None):
+    pad = weight.shape[-1] // 2 if pad is None else pad
+    return _Conv.apply(weight, bias, residual, (stride, pad, relu_in, batch, cin_pad), *srcs)
+
+
+# --------------------------------------------------------------------------------------------- frozen BatchNorm (+res, ReLU)
+class _BNAct(Function):
+    """y = act(bn_eval(c) + res): mod_resnet.py:58-113 with BatchNorm in eval mode (swem_trainer.py:37-39); gamma and
+    beta still train."""
+
+    @staticmethod
+    def forward(ctx, c, gamma, beta, mean, var, res, relu, eps):
+        Cc = c.shape[-1]
+        M = c.numel() // Cc
+        fold = torch.empty((3, Cc), dtype=torch.float32, device=c.device)     # alpha, shift, invstd
+        _lib.call('swem_bn_fold_f32', ops._stream(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                  eps, fold[0].data_ptr(), fold[1].data_ptr(), fold[2].data_ptr(), Cc)
+        y = torch.empty_like(c)
+        _lib.call('swem_bn_act_f32', ops._stream(), c.data_ptr(), fold[0].data_ptr(), fold[1].data_ptr(), ops._ptr(res),
+                  y.data_ptr(), M, Cc, int(relu))
+        ctx.saved = (c, y, fold, gamma, beta, mean, relu, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        c, y, fold, gamma, beta, mean, relu, has_res = ctx.saved
+        dy = dy.contiguous()
+        Cc = c.shape[-1]
+        M = c.numel() // Cc
+        dz = torch.empty_like(c)
+        dc = torch.empty_like(c)
+        _lib.call('swem_bn_act_bwd_f32', ops._stream(), dy.data_ptr(), y.data_ptr(), fold[0].data_ptr(), dz.data_ptr(),
+                  dc.data_ptr(), M, Cc, int(relu))
+        if gamma.requires_grad or beta.requires_grad:
+            s = torch.empty((2, Cc), dtype=torch.float32, device=c.device)
+            colsum(dz, c, out1=s[0], out2=s[1], accumulate=False)
+            _lib.call('swem_bn_param_grad_f32', ops._stream(), s[0].data_ptr(), s[1].data_ptr(), mean.data_ptr(),
+                      fold[2].data_ptr(), fold[0].data_ptr(), _grad(gamma).data_ptr() if gamma.requires_grad else 0,
+                      _grad(beta).data_ptr() if beta.requires_grad else 0, 0, Cc)
+        return dc, None, None, None, None, (dz if has_res else None), None, None
+
+
+def bn_act(c, bn, res=None, relu=True, eps=1e-5):
+    """bn = (weight, bias, running_mean, running_var) of the frozen BatchNorm2d."""
+    return _BNAct.apply(c, bn[0], bn[1], bn[2], bn[3], res, relu, eps)
+
+
+# --------------------------------------------------------------------------------------------- small stages
+class _MaxPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.x = x
+        return ops.maxpool(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x = ctx.x
+        B, H, W, Cc = x.shape
+        dx = torch.empty_like(x)
+        _lib.call('swem_maxpool3x3s2_bwd_f32', ops._stream(), x.data_ptr(), dy.contiguous().data_ptr(), dx.data_ptr(), B,
+                  H, W, Cc)
+        return dx
+
+
+def maxpool(x):
+    return _MaxPool.apply(x)
+
+
+class _UpsampleAdd(Function):
+    """networks.py:193-194: skip + bilinear x2 of the low-resolution map (skip may be shared by the objects)."""
+
+    @staticmethod
+    def forward(ctx, skip, low, batch):
+        ctx.shapes = (skip.shape, low.shape)
+        return ops.upsample_add(skip, low, batch=batch)
+
+    @staticmethod
+    def backward(ctx, dy):
+        sshape, lshape = ctx.shapes
+        dy = dy.contiguous()
+        B, Ho, Wo, Cc = dy.shape
+        dlow = torch.empty(lshape, dtype=torch.float32, device=dy.device)
+        _lib.call('swem_upsample_bwd_nhwc_f32', ops._stream(), dy.data_ptr(), dlow.data_ptr(), B, lshape[1], lshape[2],
+                  Ho, Wo, Cc)
+        dskip = sum_batch(dy) if (sshape[0] == 1 and B > 1) else dy
+        return dskip, dlow, None
+
+
+def upsample_add(skip, low, batch=None):
+    return _UpsampleAdd.apply(skip, low, batch)
+
+
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        y = torch.empty_like(a)
+        _lib.call('swem_add_f32', ops._stream(), a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _Concat2(Function):
+    """torch.cat([x0, x1], C) where the concatenation itself is a residual (networks.py:44-45 with ResNet-18)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, batch):
+        ctx.meta = (x0.shape, x1.shape)
+        return ops.concat2(x0, x1, batch)
+
+    @staticmethod
+    def backward(ctx, dy):
+        s0, s1 = ctx.meta
+        dy = dy.contiguous()
+        B = dy.shape[0]
+        g0 = dy[..., :s0[3]].contiguous()
+        g1 = dy[..., s0[3]:].contiguous()
+        if s0[0] == 1 and B > 1:
+            g0 = sum_batch(g0)
+        if s1[0] == 1 and B > 1:
+            g1 = sum_batch(g1)
+        return g0, g1, None
+
+
+def concat2(x0, x1, batch):
+    return _Concat2.apply(x0, x1, batch)
+
+
+class _GLU(Function):
+    """modules.py:25-26: layer_f(x) * sigmoid(layer_a(x)) on the two convolutions' outputs."""
+
+    @staticmethod
+    def forward(ctx, f, a):
+        y = torch.empty_like(f)
+        _lib.call('swem_glu_f32', ops._stream(), f.data_ptr(), a.data_ptr(), y.data_ptr(), f.numel())
+        ctx.saved = (f, a)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        f, a = ctx.saved
+        df, da = torch.empty_like(f), torch.empty_like(a)
+        _lib.call('swem_glu_bwd_f32', ops._stream(), dy.contiguous().data_ptr(), f.data_ptr(), a.data_ptr(),
+                  df.data_ptr(), da.data_ptr(), f.numel())
+        return df, da
+
+
+def glu(f, a):
+    return _GLU.apply(f, a)
+
+
+class _CBAM(Function):
+    """x + CBAM(x) (attentions.py:22-84, networks.py:46-47)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w7, b7):
+        ctx.saved = (x, w1, b1, w2, b2, w7, b7)
+        return ops.cbam_residual(x, w1.detach(), b1.detach(), w2.detach(), b2.detach(), w7.detach(), b7.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2, b2, w7, b7 = ctx.saved
+        B, H, W, Cc = x.shape
+        dx = torch.empty_like(x)
+        wsb = _lib.query('swem_cbam_bwd_workspace', B, H, W, Cc)
+        ws = _ws(wsb, x.device)
+        _lib.call('swem_cbam_bwd_f32', ops._stream(), x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                  b2.data_ptr(), w7.data_ptr(), b7.data_ptr(), dy.contiguous().data_ptr(), dx.data_ptr(),
+                  _grad(w1).data_ptr(), _grad(b1).data_ptr(), _grad(w2).data_ptr(), _grad(b2).data_ptr(),
+                  _grad(w7).data_ptr(), _grad(b7).data_ptr(), B, H, W, Cc, w1.shape[0], ws.data_ptr(), wsb)
+        return dx, None, None, None, None, None, None
+
+
+def cbam_residual(x, w1, b1, w2, b2, w7, b7):
+    return _CBAM.apply(x, w1, b1, w2, b2, w7, b7)
+
+
+class _PredHead(Function):
+    """networks.py:213: conv3x3(relu(x)) -> one channel; returns (B, H, W) logits at 1/4 scale."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        key = (id(weight), 'pred')
+        w = _PACKS.get(key)
+        if w is None:
+            w = _PACKS[key] = weight.detach().permute(0, 2, 3, 1).contiguous()   # [1][3][3][C]
+        ctx.saved = (x, weight, bias, w)
+        return ops.pred_head(x, w, bias.detach())
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, weight, bias, w = ctx.saved
+        B, H, W, Cc = x.shape
+        dx = torch.empty_like(x)
+        wsb = _lib.query('swem_pred_head_bwd_workspace', B, H, W, Cc)
+        ws = _ws(wsb, x.device)
+        _lib.call('swem_pred_head_bwd_f32', ops._stream(), x.data_ptr(), w.data_ptr(), dl.contiguous().data_ptr(),
+                  dx.data_ptr(), _grad(weight).data_ptr(), _grad(bias).data_ptr(), B, H, W, Cc, ws.data_ptr(), wsb)
+        return dx, None, None
+
+
+def pred_head(x, weight, bias):
+    return _PredHead.apply(x, weight, bias)
+
+
+class _DecodeHead(Function):
+    """swem.py:99-108 + aggregate :110-116: bilinear to out_size, sigmoid, valid_obj, soft aggregation, softmax.
+    logit4 (B*N, h4, w4) -> logits, prob (B, N+1, Ho, Wo)."""
+
+    @staticmethod
+    def forward(ctx, logit4, valid, B, N, out_size):
+        logits, prob, _ = ops.decode_head(logit4, B, N, out_size, valid=valid)
+        ctx.saved = (logit4, valid, B, N, out_size)
+        return logits, prob
+
+    @staticmethod
+    def backward(ctx, dlogits, dprob):
+        logit4, valid, B, N, (Ho, Wo) = ctx.saved
+        h4, w4 = logit4.shape[-2:]
+        d4 = torch.empty_like(logit4)
+        wsb = B * N * Ho * Wo * 4
+        ws = _ws(wsb, logit4.device)
+        _lib.call('swem_decode_head_bwd_f32', ops._stream(), logit4.data_ptr(), ops._ptr(valid),
+                  ops._ptr(None if dlogits is None else dlogits.contiguous()),
+                  ops._ptr(None if dprob is None else dprob.contiguous()), d4.data_ptr(), B, N, h4, w4, Ho, Wo,
+                  ws.data_ptr(), wsb)
+        return d4, None, None, None, None
+
+
+def decode_head(logit4, valid, B, N, out_size):
+    return _DecodeHead.apply(logit4, valid, B, N, (int(out_size[0]), int(out_size[1])))
+
+
+class _PrepValueInput(Function):
+    """swem.py:48-53 + networks.py:115-117: [normalised image, object mask, other objects' mask] per object (padded
+    to 8 channels); the masks carry gradient (the predicted soft masks feed the value encoder, swem_trainer.py:88)."""
+
+    @staticmethod
+    def forward(ctx, frame, masks, mean3, std3, single_obj):
+        ctx.meta = (masks.shape, single_obj)
+        return ops.prep_value_input(frame, masks, mean3, std3, single_obj)
+
+    @staticmethod
+    def backward(ctx, dx):
+        (B, N1, H, W), single_obj = ctx.meta
+        dm = torch.empty((B, N1, H, W), dtype=torch.float32, device=dx.device)
+        _lib.call('swem_prep_value_input_bwd_f32', ops._stream(), dx.contiguous().data_ptr(), dm.data_ptr(), B, N1 - 1, H,
+                  W, int(single_obj))
+        return None, dm, None, None, None
+
+
+def prep_value_input(frame, masks, mean3, std3, single_obj):
+    return _PrepValueInput.apply(frame, masks, mean3, std3, single_obj)
+
+
+# --------------------------------------------------------------------------------------------- EM value update, matching
+class _Memorize(Function):
+    """SWEMCore.swem (modules.py:129-168) for the N objects of one clip.  x (P,C) raw key (no gradient: the E/M/W steps
+    run under no_grad), v (N,P,V) value map, masks (N,2,P), prior bases.  Gradient flows v -> nu and nu_prev -> nu."""
+
+    @staticmethod
+    def forward(ctx, v, nu_prev, x, masks, kappa_prev, zita_prev, T, tau):
+        N, P, V = v.shape
+        Cc = x.shape[1]
+        L = kappa_prev.shape[-1]
+        dev = v.device
+        kappa = torch.empty_like(kappa_prev)
+        nu = torch.empty_like(nu_prev)
+        zita = torch.empty_like(zita_prev)
+        Pp = _lib.query('swem_em_pad', P)
+        zT = torch.empty((2 * N, L, Pp), dtype=torch.float32, device=dev)
+        wsb = _lib.query('swem_memorize_workspace', N, Cc, V, P, L)
+        ws = _ws(wsb, dev)
+        _lib.call('swem_memorize_train_f32', ops._stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(),
+                  kappa_prev.data_ptr(), nu_prev.data_ptr(), zita_prev.data_ptr(), kappa.data_ptr(), nu.data_ptr(),
+                  zita.data_ptr(), zT.data_ptr(), N, Cc, V, P, L, T, tau, ws.data_ptr(), wsb)
+        ctx.saved = (zT, zita_prev, zita, (N, P, V, L))
+        ctx.mark_non_differentiable(kappa, zita)
+        return kappa, nu, zita
+
+    @staticmethod
+    def backward(ctx, dkappa, dnu, dzita):
+        zT, zita_prev, zita, (N, P, V, L) = ctx.saved
+        dev = zT.device
+        dv = torch.empty((N, P, V), dtype=torch.float32, device=dev)
+        want_prev = ctx.needs_input_grad[1]
+        dnu_prev = torch.empty_like(dnu) if want_prev else None
+        wsb = _lib.query('swem_nu_update_bwd_workspace', N, V, P, L)
+        ws = _ws(wsb, dev)
+        _lib.call('swem_nu_update_bwd_f32', ops._stream(), zT.data_ptr(), zita_prev.data_ptr(), zita.data_ptr(),
+                  dnu.contiguous().data_ptr(), dv.data_ptr(), ops._ptr(dnu_prev), N, V, P, L, ws.data_ptr(), wsb)
+        return dv, dnu_prev, None, None, None, None, None, None
+
+
+def memorize(v, nu_prev, x, masks, kappa_prev, zita_prev, T, tau):
+    return _Memorize.apply(v, nu_prev, x, masks, kappa_prev, zita_prev, T, tau)
+
+
+class _Match(Function):
+    """get_affinity + perm_inv_feat (modules.py:198-208, 232-276) for the N objects of one clip.
+    qk (P,C) raw query key; banks: kappa (N,2,C,L) no gradient, nu (N,2,V,L) with gradient.
+    -> mem_out (N,Pm,V) (rows >= P zero), S (N,P,2*topl)."""
+
+    @staticmethod
+    def forward(ctx, qk, nu_first, nu_update, kappa_first, kappa_update, topl, tau):
+        P, Cc = qk.shape
+        N, _, V, L = nu_first.shape
+        dev = qk.device
+        nb = 1 if kappa_update is None else 2
+        Pm = _lib.query('swem_match_pad', P)
+        mem = torch.empty((N, Pm, V), dtype=torch.float32, device=dev)
+        S = torch.empty((N, P, 2 * topl), dtype=torch.float32, device=dev)
+        wsb = _lib.query('swem_match_workspace', N, Cc, V, P, L, nb, 0)
+        ws = _ws(wsb, dev)
+        _lib.call('swem_match_f32', ops._stream(), qk.data_ptr(), kappa_first.data_ptr(), nu_first.data_ptr(),
+                  ops._ptr(kappa_update), ops._ptr(nu_update), mem.data_ptr(), S.data_ptr(), N, Cc, V, P, L, topl, tau, 0,
+                  ws.data_ptr(), wsb)
+        ctx.saved = (qk, nu_first, nu_update, kappa_first, kappa_update, topl, tau)
+        return mem, S
+
+    @staticmethod
+    def backward(ctx, dmem, dS):
+        qk, nu_first, nu_update, kappa_first, kappa_update, topl, tau = ctx.saved
+        P, Cc = qk.shape
+        N, _, V, L = nu_first.shape
+        dev = qk.device
+        nb = 1 if kappa_update is None else 2
+        Pm = _lib.query('swem_match_pad', P)
+        if dmem is None:
+            dmem = torch.zeros((N, Pm, V), dtype=torch.float32, device=dev)
+        dqk = torch.empty_like(qk)
+        dn1 = torch.empty_like(nu_first)
+        dn2 = torch.empty_like(nu_update) if nu_update is not None else None
+        wsb = _lib.query('swem_match_bwd_workspace', N, Cc, V, P, L, nb)
+        ws = _ws(wsb, dev)
+        _lib.call('swem_match_bwd_f32', ops._stream(), qk.data_ptr(), kappa_first.data_ptr(), nu_first.data_ptr(),
+                  ops._ptr(kappa_update), ops._ptr(nu_update), dmem.contiguous().data_ptr(),
+                  ops._ptr(None if dS is None else dS.contiguous()), dqk.data_ptr(), dn1.data_ptr(), ops._ptr(dn2), N, Cc,
+                  V, P, L, topl, tau, ws.data_ptr(), wsb)
+        return dqk, dn1, dn2, None, None, None, None
+
+
+def match(qk, nu_first, nu_update, kappa_first, kappa_update, topl, tau):
+    return _Match.apply(qk, nu_first, nu_update, kappa_first, kappa_update, topl, tau)

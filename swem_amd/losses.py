@@ -88,7 +88,7 @@ class VOSLoss:
             target = target.long().contiguous()
         out = _ClipLoss.apply(target, valid_obj, k, self.aux_alpha, *logits_list)
         det = out.detach()
-        return {'total_loss': out[0], 'main_loss': det[1], 'aux_loss': det[2], 'p': 1.0 if p is None else p}
+        return {'total_loss': out[0], 'main_loss': det[1], 'aux_loss': det[2], 'p': 1.0 if p is None else p, '_vec': out}
 
     def __call__(self, scores, target, it, valid_obj=None):
         """scores (B,N+1,T,H,W) as in the reference (losses/__init__.py:34-41)."""

@@ -1,0 +1,219 @@
+"""Training step of SWEM on HIP kernels: the counterpart of ``SWEMTrainer.one_step``
+(reference methods/SWEM/swem_trainer.py:59-108).
+
+``SWEMTrainer(config, model)`` keeps the reference's ``one_step(frames, init_mask, valid_obj, label, cur_iter)``
+signature and return value ``(losses, results)``.  The clip loop, the loss (``losses.VOSLoss``) and the optimizer
+(``optim.FlatAdamW`` + ``MultiStepLR``) run through ``swem_amd.autograd`` / ``libswem_hip.so``; the model's parameters
+live in one flat buffer and their gradients are accumulated in-kernel.
+
+How the batch is run: clips are independent (frozen BatchNorm, per-clip memory), so the step walks the B clips one
+after another -- forward, per-clip loss with weight 1/B, backward -- and the parameter gradients add up in the flat
+gradient buffer.  That equals the reference's batched step (``total = mean_b``) and frees a clip's activations before
+the next one starts.  Mixed precision (config.AMP) is not built: the step runs in fp32 (bf16x6 / fp32 MFMA).
+"""
+import math
+
+import torch
+
+from . import _lib, autograd as A, losses as L, ops, optim
+from .networks import BasicBlock, Bottleneck
+
+
+def _bn(m):
+    return (m.weight, m.bias, m.running_mean, m.running_var)
+
+
+def _get(cfg, k):
+    return cfg[k] if isinstance(cfg, dict) else getattr(cfg, k)
+
+
+class TrainGraph:
+    """The forward graphs of swem.py / networks.py on differentiable HIP stages, for ONE clip (batch 1, N objects)."""
+
+    def __init__(self, model):
+        dev = next(model.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('swem_amd trains on a HIP device only (model is on %s); there is no CPU path' % dev)
+        self.m = model
+        self.single_obj = model.single_object
+        self.k_mean, self.k_std = ops._f3(model.key_encoder.mean), ops._f3(model.key_encoder.std)
+        self.v_mean, self.v_std = ops._f3(model.value_encoder.mean), ops._f3(model.value_encoder.std)
+
+    # mod_resnet.py:58-113 / torchvision blocks with BatchNorm frozen (swem_trainer.py:37-39)
+    @staticmethod
+    def _block(blk, x):
+        s = blk.stride
+        if blk.downsample is not None:
+            d = blk.downsample
+            res = A.bn_act(A.conv2d([x], d[0].weight, d[0].bias, stride=s, pad=0), _bn(d[1]), relu=False)
+        else:
+            res = x
+        if isinstance(blk, Bottleneck):
+            y = A.bn_act(A.conv2d([x], blk.conv1.weight, blk.conv1.bias, pad=0), _bn(blk.bn1))
+            y = A.bn_act(A.conv2d([y], blk.conv2.weight, blk.conv2.bias, stride=s, pad=1), _bn(blk.bn2))
+            return A.bn_act(A.conv2d([y], blk.conv3.weight, blk.conv3.bias, pad=0), _bn(blk.bn3), res=res)
+        assert isinstance(blk, BasicBlock)
+        y = A.bn_act(A.conv2d([x], blk.conv1.weight, blk.conv1.bias, stride=s, pad=1), _bn(blk.bn1))
+        return A.bn_act(A.conv2d([y], blk.conv2.weight, blk.conv2.bias, pad=1), _bn(blk.bn2), res=res)
+
+    # networks.py:12-32
+    @staticmethod
+    def _res_block(rb, srcs, batch=None):
+        r = A.conv2d(srcs, rb.conv1.weight, rb.conv1.bias, relu_in=True, batch=batch)
+        if rb.downsample is None:
+            res = srcs[0] if len(srcs) == 1 else A.concat2(srcs[0], srcs[1], batch or srcs[0].shape[0])
+        else:
+            res = A.conv2d(srcs, rb.downsample.weight, rb.downsample.bias, batch=batch)
+        return A.conv2d([r], rb.conv2.weight, rb.conv2.bias, relu_in=True, residual=res)
+
+    # swem.py:39-43 + networks.py:160-182
+    def encode_key(self, frame):
+        m, ke = self.m, self.m.key_encoder
+        x = ops.prep_key_input(frame, self.k_mean, self.k_std)
+        x = A.maxpool(A.bn_act(A.conv2d([x], ke.conv1.weight, None, stride=2, pad=3, cin_pad=4), _bn(ke.bn1)))
+        feats = []
+        for st in (ke.res2, ke.layer2, ke.layer3):
+            for blk in st:
+                x = self._block(blk, x)
+            feats.append(x)
+        s4, s8, s16 = feats
+        qk16 = A.conv2d([s16], m.key_proj.key_proj.weight, m.key_proj.key_proj.bias)
+        qv16 = A.conv2d([s16], m.key_comp.weight, m.key_comp.bias)
+        return qk16, qv16, s16, s8, s4
+
+    # swem.py:45-62 + networks.py:113-129, 43-50
+    def encode_value(self, frame, masks, s16):
+        ve = self.m.value_encoder
+        N = masks.shape[1] - 1
+        x = A.prep_value_input(frame, masks, self.v_mean, self.v_std, self.single_obj)
+        x = A.maxpool(A.bn_act(A.conv2d([x], ve.conv1.weight, ve.conv1.bias, stride=2, pad=3, cin_pad=8), _bn(ve.bn1)))
+        for st in (ve.layer1, ve.layer2, ve.layer3):
+            for blk in st:
+                x = self._block(blk, x)
+        x = self._res_block(ve.fuser.block1, [x, s16], batch=N)
+        att = ve.fuser.attention
+        x = A.cbam_residual(x, att.ChannelGate.mlp[1].weight, att.ChannelGate.mlp[1].bias, att.ChannelGate.mlp[3].weight,
+                            att.ChannelGate.mlp[3].bias, att.SpatialGate.spatial.conv.weight,
+                            att.SpatialGate.spatial.conv.bias)
+        return self._res_block(ve.fuser.block2, [x])                      # (N, h, w, V)
+
+    # modules.py:278-293
+    def match(self, qk16, qv16, first, update):
+        core = self.m.swem_core
+        _, h, w, Cc = qk16.shape
+        P = h * w
+        mem, S = A.match(qk16.view(P, Cc), first['nu'], None if update is None else update['nu'], first['kappa'],
+                         None if update is None else update['kappa'], core.topl, core.tau)
+        N = mem.shape[0]
+        mem = mem[:, :P].view(N, h, w, -1)
+        S = S.view(N, h, w, -1)
+        fl = core.fusion_layer
+        f = A.conv2d([mem, qv16, S], fl.layer_f.weight, fl.layer_f.bias, batch=N)
+        a = A.conv2d([mem, qv16, S], fl.layer_a.weight, fl.layer_a.bias, batch=N)
+        return A.glu(f, a), N
+
+    # swem.py:92-116 + networks.py:199-216
+    def segment(self, n, context, s8, s4, valid_obj, out_size):
+        dec = self.m.decoder
+        x = self._res_block(dec.compress, [context])
+        sk = A.conv2d([s8], dec.up_16_8.skip_conv.weight, dec.up_16_8.skip_conv.bias)
+        x = self._res_block(dec.up_16_8.out_conv, [A.upsample_add(sk, x, batch=n)])
+        sk = A.conv2d([s4], dec.up_8_4.skip_conv.weight, dec.up_8_4.skip_conv.bias)
+        x = self._res_block(dec.up_8_4.out_conv, [A.upsample_add(sk, x, batch=n)])
+        logit4 = A.pred_head(x, dec.pred.weight, dec.pred.bias)
+        return A.decode_head(logit4, valid_obj, 1, n, out_size)
+
+    # swem.py:64-86 + modules.py:129-168, 183-193
+    def memorize(self, qk16, mv16, masks_hard, masks_soft, prior):
+        core = self.m.swem_core
+        _, h, w, Cc = qk16.shape
+        N = mv16.shape[0]
+        masks = ops.mask_prep(masks_hard.contiguous(), masks_soft.detach().float().contiguous(), h, w)   # (N,2,P)
+        kappa, nu, zita = A.memorize(mv16.view(N, h * w, -1), prior['nu'], qk16.detach().view(h * w, Cc), masks,
+                                     prior['kappa'], prior['zita'], core.n_iters, core.tau)
+        return {'kappa': kappa, 'nu': nu, 'zita': zita}
+
+
+def random_init_host(B, N, Cc, V, Lb, device):
+    """modules.py:170-178 drawn from the global torch CPU generator (the reference draws one tensor for the whole batch):
+    kappa ~ N(0, sqrt(2/L)) l2-normalised over C, nu = 0, zita = 1e-6.  Per-clip slices, kernels' layouts."""
+    kappa = torch.zeros(B, N, 2, Cc, Lb)
+    kappa.normal_(0, math.sqrt(2.0 / Lb))
+    kappa = kappa / (torch.linalg.norm(kappa, dim=-2, keepdim=True) + 1e-6)
+    out = []
+    for b in range(B):
+        out.append({'kappa': kappa[b].contiguous().to(device),
+                    'nu': torch.zeros(N, 2, V, Lb, device=device),
+                    'zita': torch.full((N, 2, Lb), 1e-6, device=device)})
+    return out
+
+
+class SWEMTrainer:
+    """swem_trainer.py:19-108 without the dataset / logging plumbing: model, criterion, optimizer, scheduler, one_step."""
+
+    def __init__(self, config, model, num_gpu=None):
+        self.config = config
+        self.model = model
+        if _get(config, 'AMP'):
+            raise NotImplementedError('AMP training is not built on the HIP path (fp32-accurate step only)')
+        dev = next(model.parameters()).device
+        model.train()
+        for mod in model.modules():                    # BasicTrainer.set_bn_eval (swem_trainer.py:37-39)
+            if mod.__class__.__name__.find('BatchNorm') != -1:
+                mod.eval()
+        self.optimizer = optim.make_optimizer(_get(config, 'SOLVER'), model, num_gpu)
+        self.lr_scheduler = optim.make_lr_scheduler(_get(config, 'SOLVER'), self.optimizer)
+        self.criterion = L.get_criterion(_get(config, 'LOSS'), None, 1, 1, dev)
+        self.graph = TrainGraph(model)
+        self.device = dev
+
+    def clip_forward(self, frames, init_mask, valid_obj, prior0):
+        """swem_trainer.py:63-90 for one clip: frames (1,T,3,H,W), init_mask (1,N+1,H,W), valid_obj (1,N+1)."""
+        g = self.graph
+        t = frames.shape[1]
+        out_size = tuple(init_mask.shape[-2:])
+        mk16, _, s16, _, _ = g.encode_key(frames[:, 0])
+        mv16 = g.encode_value(frames[:, 0], init_mask.float(), s16)
+        first = g.memorize(mk16, mv16, init_mask, init_mask.float(), prior0)
+        update = None
+        logits_list, results = [], []
+        for i in range(1, t):
+            qk16, qv16, s16, s8, s4 = g.encode_key(frames[:, i])
+            context, n = g.match(qk16, qv16, first, update)
+            logits, pred_mask = g.segment(n, context, s8, s4, valid_obj, out_size)
+            logits_list.append(logits)
+            pred, hard = ops.argmax_onehot(pred_mask.detach(), want_onehot=i < t - 1)
+            results.append(pred)
+            if i < t - 1:
+                mv16 = g.encode_value(frames[:, i], pred_mask, s16)
+                update = g.memorize(qk16, mv16, hard, pred_mask, first if update is None else update)
+        return logits_list, results
+
+    def one_step(self, frames, init_mask, valid_obj, label, cur_iter):
+        B = frames.shape[0]
+        core = self.model.swem_core
+        frames = frames.float().contiguous()
+        init_mask = init_mask.contiguous()
+        N = init_mask.shape[1] - 1
+        self.optimizer.zero_grad()
+        A.new_step()
+        h16, w16 = frames.shape[-2] // 16, frames.shape[-1] // 16
+        priors = random_init_host(B, N, self.model.key_proj.key_proj.weight.shape[0], core.valdim, core.n_bases,
+                                  self.device)
+        label = label.long().contiguous()
+        sums = torch.zeros(3, dtype=torch.float32, device=self.device)
+        gout = torch.tensor([1.0 / B, 0.0, 0.0], dtype=torch.float32, device=self.device)
+        results, p = [], 1.0
+        for b in range(B):
+            vo = None if valid_obj is None else valid_obj[b:b + 1].float().contiguous()
+            logits_list, res = self.clip_forward(frames[b:b + 1], init_mask[b:b + 1], vo, priors[b])
+            out = self.criterion.clip_loss(logits_list, label[b:b + 1, 1:], cur_iter, vo)
+            vec = out['_vec']                                          # (total, main, aux) of this clip
+            vec.backward(gout)
+            sums = ops.lincomb(sums, 1.0, vec.detach(), 1.0 / B)
+            results.append(torch.stack(res, dim=1))                    # (1, T-1, H, W)
+            p = out['p']
+        self.optimizer.step()
+        self.lr_scheduler.step()
+        losses = {'total_loss': sums[0], 'main_loss': sums[1], 'aux_loss': sums[2], 'p': p}
+        return losses, torch.cat(results, dim=0)

@@ -71,3 +71,298 @@ def test_adamw_matches_torch_optimizer(lib):
     assert float((opt.param.cpu() - pr.detach()).abs().max()) <= 2.5e-7
     close(opt.param.cpu() - p0, pr.detach() - p0, 5e-3, 'AdamW parameter update')
     assert opt.step_count == 3
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# backward kernels, one stage at a time, against torch's CPU autograd of the same stage with identical inputs
+# ----------------------------------------------------------------------------------------------------------------
+import torch.nn.functional as F  # noqa: E402
+
+
+def nhwc(t):
+    return t.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def back(t):
+    return t.detach().permute(0, 3, 1, 2).cpu()
+
+
+def leaf(t):
+    return t.detach().clone().requires_grad_(True)
+
+
+def param(t):
+    p = torch.nn.Parameter(t.detach().clone().to(DEV))
+    p.grad = torch.zeros_like(p)
+    return p
+
+
+@pytest.mark.parametrize('case', [
+    dict(cins=[(64, 2)], cout=64, k=3, s=1, hw=(12, 20), relu_in=True, res=True),
+    dict(cins=[(128, 2)], cout=128, k=3, s=2, hw=(17, 24), relu_in=False, res=False),
+    dict(cins=[(64, 1)], cout=128, k=1, s=2, hw=(16, 15), relu_in=False, res=False, pad=0),
+    dict(cins=[(64, 3), (128, 1)], cout=64, k=3, s=1, hw=(9, 11), relu_in=True, res=False),
+    dict(cins=[(256, 2), (128, 1), (64, 2)], cout=96, k=3, s=1, hw=(8, 8), relu_in=False, res=False),
+    dict(cins=[(5, 2)], cout=64, k=7, s=2, hw=(32, 40), relu_in=False, res=False, cin_pad=8, pad=3),
+], ids=['3x3_relu_res', '3x3_s2_odd', '1x1_s2', 'two_src_broadcast', 'three_src', 'stem7x7'])
+def test_conv_backward(lib, case):
+    """Data gradient (SWEM_CONV_DGRAD on the forward kernels, input-ReLU mask, shared sources summed over the batch),
+    weight gradient (swem_conv2d_wgrad_f32, accumulated into .grad) and bias gradient against F.conv2d's autograd."""
+    from swem_amd import autograd as A
+    A.new_step()
+    g = torch.Generator().manual_seed(7)
+    k, s = case['k'], case['s']
+    pad = case.get('pad', k // 2)
+    H, W = case['hw']
+    B = max(b for _, b in case['cins'])
+    xs = [leaf(torch.randn(b, c, H, W, generator=g)) for c, b in case['cins']]
+    cin = sum(c for c, _ in case['cins'])
+    w = leaf(torch.randn(case['cout'], cin, k, k, generator=g) * 0.05)
+    bias = leaf(torch.randn(case['cout'], generator=g))
+    xcat = torch.cat([x.expand(B, -1, -1, -1) for x in xs], 1)
+    y = F.conv2d(F.relu(xcat) if case['relu_in'] else xcat, w, bias, stride=s, padding=pad)
+    res = leaf(torch.randn(*y.shape, generator=g)) if case['res'] else None
+    if res is not None:
+        y = y + res
+    dy = torch.randn(*y.shape, generator=g)
+    y.backward(dy)
+    # HIP
+    cin_pad = case.get('cin_pad')
+    srcs = []
+    for x in xs:
+        t = x.detach()
+        if cin_pad:
+            t = F.pad(t, (0, 0, 0, 0, 0, cin_pad - t.shape[1]))
+        srcs.append(nhwc(t).requires_grad_(True))
+    wp, bp = param(w), param(bias)
+    rs = nhwc(res).requires_grad_(True) if res is not None else None
+    out = A.conv2d(srcs, wp, bp, stride=s, pad=pad, relu_in=case['relu_in'], residual=rs, batch=B, cin_pad=cin_pad)
+    close(back(out), y, 2e-5, 'conv forward')
+    out.backward(nhwc(dy))
+    close(wp.grad, w.grad, 3e-5, 'dW')
+    close(bp.grad, bias.grad, 3e-5, 'dbias')
+    for x, sx in zip(xs, srcs):
+        gx = back(sx.grad)[:, :x.shape[1]]
+        close(gx, x.grad, 3e-5, 'dX (%d ch, batch %d)' % (x.shape[1], x.shape[0]))
+    if res is not None:
+        close(back(rs.grad), res.grad, 1e-6, 'dres')
+    # a second backward accumulates into .grad (the optimizer's flat buffer is zeroed once per step)
+    out2 = A.conv2d([t_.detach().requires_grad_(True) for t_ in srcs], wp, bp, stride=s, pad=pad,
+                    relu_in=case['relu_in'], residual=None, batch=B, cin_pad=cin_pad)
+    out2.backward(nhwc(dy))
+    close(wp.grad, 2 * w.grad, 3e-5, 'dW accumulated')
+
+
+@pytest.mark.parametrize('relu,with_res', [(True, True), (True, False), (False, False)])
+def test_bn_act_backward(lib, relu, with_res):
+    """Frozen BatchNorm (+residual, ReLU) as a stage: dc, dres, dgamma, dbeta vs F.batch_norm(eval) autograd."""
+    from swem_amd import autograd as A
+    g = torch.Generator().manual_seed(8)
+    B, Cc, H, W = 2, 64, 9, 13
+    c = leaf(torch.randn(B, Cc, H, W, generator=g))
+    gamma, beta = leaf(torch.rand(Cc, generator=g) + 0.5), leaf(torch.randn(Cc, generator=g))
+    mean, var = torch.randn(Cc, generator=g), torch.rand(Cc, generator=g) + 0.5
+    res = leaf(torch.randn(B, Cc, H, W, generator=g)) if with_res else None
+    y = F.batch_norm(c, mean, var, gamma, beta, False, 0.0, 1e-5)
+    if res is not None:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    dy = torch.randn(*y.shape, generator=g)
+    y.backward(dy)
+    cx = nhwc(c).requires_grad_(True)
+    rx = nhwc(res).requires_grad_(True) if with_res else None
+    gp, bp = param(gamma), param(beta)
+    out = A.bn_act(cx, (gp, bp, mean.to(DEV), var.to(DEV)), res=rx, relu=relu)
+    close(back(out), y, 1e-5, 'bn_act forward')
+    out.backward(nhwc(dy))
+    close(back(cx.grad), c.grad, 1e-5, 'dc')
+    close(gp.grad, gamma.grad, 3e-5, 'dgamma')
+    close(bp.grad, beta.grad, 3e-5, 'dbeta')
+    if with_res:
+        close(back(rx.grad), res.grad, 1e-6, 'dres')
+
+
+def test_maxpool_upsample_glu_backward(lib):
+    from swem_amd import autograd as A
+    g = torch.Generator().manual_seed(9)
+    x = leaf(torch.randn(2, 64, 15, 18, generator=g))
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(*y.shape, generator=g)
+    y.backward(dy)
+    hx = nhwc(x).requires_grad_(True)
+    out = A.maxpool(hx)
+    assert torch.equal(back(out), y)
+    out.backward(nhwc(dy))
+    close(back(hx.grad), x.grad, 1e-6, 'maxpool dx')
+    # ties: a constant map sends each window's gradient to its first element, like ATen
+    xc = leaf(torch.zeros(1, 4, 6, 6))
+    F.max_pool2d(xc, 3, 2, 1).sum().backward()
+    hc = nhwc(xc).requires_grad_(True)
+    A.maxpool(hc).sum().backward()
+    assert torch.equal(back(hc.grad), xc.grad)
+    # skip (shared by the 3 objects) + bilinear x2 of the low map
+    skip, low = leaf(torch.randn(1, 32, 12, 16, generator=g)), leaf(torch.randn(3, 32, 6, 8, generator=g))
+    y = skip + F.interpolate(low, size=(12, 16), mode='bilinear', align_corners=False)
+    dy = torch.randn(*y.shape, generator=g)
+    y.backward(dy)
+    hs, hl = nhwc(skip).requires_grad_(True), nhwc(low).requires_grad_(True)
+    out = A.upsample_add(hs, hl, batch=3)
+    close(back(out), y, 1e-6, 'upsample_add forward')
+    out.backward(nhwc(dy))
+    close(back(hl.grad), low.grad, 2e-6, 'dlow')
+    close(back(hs.grad), skip.grad, 2e-6, 'dskip (summed over objects)')
+    # odd -> even sizes (7 -> 13 is not x2: the adjoint is generic)
+    low2 = leaf(torch.randn(1, 8, 7, 5, generator=g))
+    sk2 = leaf(torch.randn(1, 8, 13, 10, generator=g))
+    y = sk2 + F.interpolate(low2, size=(13, 10), mode='bilinear', align_corners=False)
+    dy = torch.randn(*y.shape, generator=g)
+    y.backward(dy)
+    hl2 = nhwc(low2).requires_grad_(True)
+    A.upsample_add(nhwc(sk2), hl2).backward(nhwc(dy))
+    close(back(hl2.grad), low2.grad, 2e-6, 'dlow generic scale')
+    # GLU gate
+    f, a = leaf(torch.randn(2, 32, 5, 7, generator=g)), leaf(torch.randn(2, 32, 5, 7, generator=g))
+    y = f * torch.sigmoid(a)
+    dy = torch.randn(*y.shape, generator=g)
+    y.backward(dy)
+    hf, ha = nhwc(f).requires_grad_(True), nhwc(a).requires_grad_(True)
+    out = A.glu(hf, ha)
+    close(back(out), y, 1e-6, 'glu forward')
+    out.backward(nhwc(dy))
+    close(back(hf.grad), f.grad, 2e-6, 'glu df')
+    close(back(ha.grad), a.grad, 2e-6, 'glu da')
+
+
+def test_cbam_backward(lib):
+    """x + CBAM(x): dx and the six parameter gradients vs the oracle's cbam (attentions.py:22-84) under autograd."""
+    from swem_amd import autograd as A
+    g = torch.Generator().manual_seed(10)
+    B, Cc, H, W, hid = 2, 64, 6, 9, 4
+    x = leaf(torch.randn(B, Cc, H, W, generator=g))
+    names = ['ChannelGate.mlp.1.weight', 'ChannelGate.mlp.1.bias', 'ChannelGate.mlp.3.weight', 'ChannelGate.mlp.3.bias',
+             'SpatialGate.spatial.conv.weight', 'SpatialGate.spatial.conv.bias']
+    shapes = [(hid, Cc), (hid,), (Cc, hid), (Cc,), (1, 2, 7, 7), (1,)]
+    sd = {'a.' + n: leaf(torch.randn(*s, generator=g) * 0.3) for n, s in zip(names, shapes)}
+    y = x + O.cbam(sd, 'a', x)
+    dy = torch.randn(*y.shape, generator=g)
+    y.backward(dy)
+    hx = nhwc(x).requires_grad_(True)
+    ps = [param(sd['a.' + n]) for n in names]
+    out = A.cbam_residual(hx, *ps)
+    close(back(out), y, 1e-5, 'cbam forward')
+    out.backward(nhwc(dy))
+    close(back(hx.grad), x.grad, 5e-5, 'cbam dx')
+    for n, p_ in zip(names, ps):
+        close(p_.grad, sd['a.' + n].grad, 1e-4, 'cbam d' + n)
+
+
+def test_heads_backward(lib):
+    """pred head, decode head (bilinear -> sigmoid -> valid -> aggregate -> softmax; gradient through logits AND the
+    probabilities), value-encoder input packing."""
+    from swem_amd import autograd as A
+    A.new_step()
+    g = torch.Generator().manual_seed(11)
+    N, Cc, h4, w4 = 2, 64, 10, 12
+    x = leaf(torch.randn(N, Cc, h4, w4, generator=g))
+    w, b = leaf(torch.randn(1, Cc, 3, 3, generator=g) * 0.1), leaf(torch.randn(1, generator=g))
+    valid = torch.tensor([[1., 1., 0.]])
+    lg4 = F.conv2d(F.relu(x), w, b, padding=1)                                     # (N,1,h4,w4)
+    Ho, Wo = 40, 48
+    up = F.interpolate(lg4, size=(Ho, Wo), mode='bilinear', align_corners=False)
+    preds = torch.sigmoid(up).view(1, N, Ho, Wo) * valid[:, 1:, None, None]
+    logits = O.aggregate(preds)
+    prob = F.softmax(logits, dim=1)
+    dl, dp = torch.randn(1, N + 1, Ho, Wo, generator=g), torch.randn(1, N + 1, Ho, Wo, generator=g)
+    ((logits * dl).sum() + (prob * dp).sum()).backward()
+    hx = nhwc(x).requires_grad_(True)
+    wp, bp = param(w), param(b)
+    l4 = A.pred_head(hx, wp, bp)
+    hl, hp = A.decode_head(l4, valid.to(DEV), 1, N, (Ho, Wo))
+    close(hl.cpu(), logits, 1e-4, 'logits')
+    ((hl * dl.to(DEV)).sum() + (hp * dp.to(DEV)).sum()).backward()
+    close(back(hx.grad), x.grad, 1e-4, 'pred/decode dx')
+    close(wp.grad, w.grad, 1e-4, 'pred dw')
+    close(bp.grad, b.grad, 1e-4, 'pred db')
+    # value-encoder input: channels [img, m, 1 - m - m_bg]
+    frame = torch.rand(1, 3, 16, 20, generator=g)
+    masks = leaf(torch.rand(1, 3, 16, 20, generator=g))
+    others = 1 - masks - masks[:, 0:1]
+    f = torch.cat([masks[:, 1:].flatten(0, 1).unsqueeze(1), others[:, 1:].flatten(0, 1).unsqueeze(1)], 1)   # (N,2,H,W)
+    dy = torch.randn(2, 8, 16, 20, generator=g)
+    (f * dy[:, 3:5]).sum().backward()
+    hm = masks.detach().to(DEV).requires_grad_(True)
+    import ctypes as C
+    z3, o3 = (C.c_float * 3)(0, 0, 0), (C.c_float * 3)(1, 1, 1)
+    out = A.prep_value_input(frame.to(DEV), hm, z3, o3, False)
+    out.backward(nhwc(dy))
+    close(hm.grad.cpu(), masks.grad, 1e-6, 'd masks')
+
+
+@pytest.mark.parametrize('L,banks,topl', [(64, 1, 32), (64, 2, 64), (128, 2, 64)])
+def test_match_backward(lib, L, banks, topl):
+    """get_affinity + perm_inv_feat: d qk (through the l2norm, the joint softmax and the top-l prefix features) and
+    d nu for both banks, against the oracle under autograd."""
+    from swem_amd import autograd as A
+    g = torch.Generator().manual_seed(12 + L + banks)
+    N, Cc, V, h, w = 2, 128, 64, 6, 9
+    P = h * w
+    xk, _ = H.structured_keys(P, Cc, 5, g)
+    qk = leaf(xk.t().reshape(1, Cc, h, w).contiguous())
+    kap = [O.l2norm(torch.randn(1, N, 2, Cc, L, generator=g) * 0.3 + xk[torch.randint(0, P, (L,), generator=g)].t(), -2)
+           for _ in range(banks)]
+    nus = [leaf(torch.randn(1, N, 2, V, L, generator=g)) for _ in range(banks)]
+    mk, mv = torch.cat(kap, -1), torch.cat(nus, -1)
+    S, mem = O.get_affinity(O.l2norm(qk, 1), O.l2norm(mk, -2), mv, 0.05, topl)
+    dS, dmem = torch.randn(*S.shape, generator=g), torch.randn(*mem.shape, generator=g)
+    ((S * dS).sum() + (mem * dmem).sum()).backward()
+    hq = qk.detach().permute(0, 2, 3, 1).reshape(P, Cc).contiguous().to(DEV).requires_grad_(True)
+    hn = [n_.detach()[0].contiguous().to(DEV).requires_grad_(True) for n_ in nus]
+    hk = [k_[0].contiguous().to(DEV) for k_ in kap]
+    m_, s_ = A.match(hq, hn[0], hn[1] if banks == 2 else None, hk[0], hk[1] if banks == 2 else None, topl, 0.05)
+    close(s_.cpu(), S.view(N, 2 * topl, P).permute(0, 2, 1), 1e-4, 'S')
+    close(m_[:, :P].cpu(), mem[0].flatten(2).permute(0, 2, 1), 1e-4, 'mem_out')
+    dm = torch.zeros_like(m_)
+    dm[:, :P] = dmem[0].flatten(2).permute(0, 2, 1).to(DEV)
+    ds = dS.view(N, 2 * topl, P).permute(0, 2, 1).contiguous().to(DEV)
+    ((m_ * dm).sum() + (s_ * ds).sum()).backward()
+    # d qk passes through p (g - sum p g) / tau with strong cancellation: judge it against an fp64 evaluation, with
+    # the fp32 CPU oracle's own distance to fp64 as the yardstick
+    q64 = qk.detach().double().requires_grad_(True)
+    S64, mem64 = O.get_affinity(O.l2norm(q64, 1), O.l2norm(mk.double(), -2), mv.detach().double(), 0.05, topl)
+    ((S64 * dS.double()).sum() + (mem64 * dmem.double()).sum()).backward()
+    ref64 = q64.grad[0].flatten(1).t()
+    scale = float(ref64.abs().max())
+    err_cpu = float((qk.grad[0].flatten(1).t().double() - ref64).abs().max())
+    err_hip = float((hq.grad.cpu().double() - ref64).abs().max())
+    assert err_hip <= max(3 * err_cpu, 2e-4 * scale), 'd qk: HIP %.3e vs fp64, CPU fp32 %.3e, scale %.3e' % (
+        err_hip, err_cpu, scale)
+    for i in range(banks):
+        close(hn[i].grad.cpu(), nus[i].grad[0], 1e-4, 'd nu bank %d' % i)
+
+
+def test_memorize_backward(lib):
+    """swem(): bases as the inference kernel gives them, and the value update's gradient (d v, d nu_prev)."""
+    from swem_amd import autograd as A
+    g = torch.Generator().manual_seed(13)
+    N, Cc, V, h, w, L, T = 2, 128, 128, 6, 9, 64, 4
+    P = h * w
+    x, v, m = H.em_inputs(h, w, Cc, V, N, g)
+    v = leaf(v)
+    prior = {'kappa': O.l2norm(torch.randn(1, N, 2, Cc, L, generator=g), -2),
+             'nu': leaf(torch.randn(1, N, 2, V, L, generator=g)), 'zita': torch.rand(1, N, 2, 1, L, generator=g) * 3 + 1e-6}
+    ref = O.swem(x, v, m, prior, L, T, 0.05, V)
+    dnu = torch.randn(*ref['nu'].shape, generator=g)
+    (ref['nu'] * dnu).sum().backward()
+    hv = v.detach()[0].flatten(2).permute(0, 2, 1).contiguous().to(DEV).requires_grad_(True)       # (N,P,V)
+    hnu = prior['nu'].detach()[0].contiguous().to(DEV).requires_grad_(True)
+    hx = x[0].flatten(1).t().contiguous().to(DEV)
+    kap, nu, zita = A.memorize(hv, hnu, hx, m[0].flatten(2).contiguous().to(DEV), prior['kappa'][0].contiguous().to(DEV),
+                               prior['zita'][0, :, :, 0].contiguous().to(DEV), T, 0.05)
+    close(zita.cpu(), ref['zita'][0, :, :, 0], 1e-4, 'zita')
+    mass = ref['zita'][0]
+    close((nu.cpu() * mass), (ref['nu'][0] * mass).detach(), 1e-4, 'nu * zita')
+    (nu * dnu[0].to(DEV)).sum().backward()
+    # identical z would make these exact; the fp32 EM differs by rounding, so compare mass-weighted like the forward
+    close(hnu.grad.cpu(), prior['nu'].grad[0], 1e-3, 'd nu_prev')
+    close(hv.grad.cpu(), v.grad[0].flatten(2).permute(0, 2, 1), 1e-3, 'd v')
