@@ -6,10 +6,14 @@ from swem_amd import synth, weights
 from swem_amd.swem import SWEM
 
 
-def make_model_and_sd(cfg, wseed, device=None):
-    """Product model with seeded weights (+ the same state dict on CPU for the oracle)."""
+def make_model_and_sd(cfg, wseed, device=None, pred_scale=None):
+    """Product model with seeded weights (+ the same state dict on CPU for the oracle).  pred_scale: the training
+    fixtures shrink the prediction head (tests/golden/make_golden_train.py)."""
     model = SWEM(cfg)
     sd = weights.fill_state_dict(model.state_dict(), seed=wseed, backbone=cfg.BACKBONE)
+    if pred_scale is not None:
+        sd['decoder.pred.weight'] = sd['decoder.pred.weight'] * pred_scale
+        sd['decoder.pred.bias'] = sd['decoder.pred.bias'] * 0
     model.load_state_dict(sd, strict=True)
     model.eval()
     if device is not None:

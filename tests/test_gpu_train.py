@@ -366,3 +366,59 @@ def test_memorize_backward(lib):
     # identical z would make these exact; the fp32 EM differs by rounding, so compare mass-weighted like the forward
     close(hnu.grad.cpu(), prior['nu'].grad[0], 1e-3, 'd nu_prev')
     close(hv.grad.cpu(), v.grad[0].flatten(2).permute(0, 2, 1), 1e-3, 'd v')
+
+
+@pytest.mark.parametrize('tag,it', [('r18', 5), ('r18', 45), ('r50', 45)])
+def test_one_step_matches_reference_trainer(golden, lib, tag, it):
+    """a18: SWEMTrainer.one_step on HIP against the losses, index maps, per-parameter gradient norms and the AdamW
+    update recorded from the REFERENCE trainer (tests/golden/make_golden_train.py)."""
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    case = tc['cases'][tag]
+    fx = golden('g9_train_%s_it%d.npz' % (tag, it))
+    cfg = O.make_cfg(**case['cfg'])
+    model, sd = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+    trainer = SWEMTrainer(dict(SOLVER=tc['solver_cfg'], LOSS=tc['loss_cfg'], AMP=False), model)
+    frames, init_mask, label, valid = H.train_batch(case)
+    assert H.checksum(frames) == pytest.approx(float(fx['frames_sum']), rel=1e-12)
+    torch.manual_seed(91)
+    losses, results = trainer.one_step(frames.to(DEV), init_mask.to(DEV), valid.to(DEV), label.to(DEV), it)
+    got = {k: float(losses[k]) for k in ('total_loss', 'main_loss', 'aux_loss')}
+    print(tag, it, 'losses', got, 'ref', {k: float(fx[k]) for k in got})
+    agree = float((results.cpu().to(torch.uint8) == fx['results']).float().mean())
+    print('   index maps agree %.5f' % agree)
+    # yardstick: the reference's own fp32-vs-fp64 distance on this step (floor64_*, measured when the fixture was made):
+    # the EM amplifies rounding (SURVEY.md section 7.2), so two correct fp32 implementations differ by about that much
+    names = fx['grad_names']
+    params = dict(model.named_parameters())
+    floors = fx['floor64_norm'].tolist()
+    rels, bad = [], []
+    for n, ref_norm, fl in zip(names, fx['grad_norms'].tolist(), floors):
+        gn = float(params[n].grad.double().norm())
+        rel = abs(gn - ref_norm) / (ref_norm + 1e-12)
+        rels.append(rel)
+        if rel > max(5e-3, 5 * fl):
+            bad.append((n, rel, fl))
+    srt = sorted(rels)
+    print('   grad norms: median rel err %.2e (floor %.2e), 90%% %.2e, worst %.2e (floor max %.2e); outside the bound: %s'
+          % (srt[len(srt) // 2], sorted(floors)[len(floors) // 2], srt[int(len(srt) * 0.9)], srt[-1], max(floors), bad))
+    errs = []
+    for key, fxk in (('decoder.pred.weight', 'g_pred_weight'), ('key_proj.key_proj.bias', 'g_key_proj_bias'),
+                     ('value_encoder.conv1.weight', 'g_v_conv1_weight')):
+        errs.append(float((params[key].grad.cpu() - fx[fxk]).abs().max() / fx[fxk].abs().max()))
+    fe = fx['floor64_elem'].tolist()
+    print('   elementwise rel err: pred.weight %.2e (floor %.1e), key_proj.bias %.2e (%.1e), value conv1.weight %.2e (%.1e)'
+          % (errs[0], fe[0], errs[1], fe[1], errs[2], fe[2]))
+    for k in got:
+        assert got[k] == pytest.approx(float(fx[k]), rel=max(1e-4, 5 * float(fx['floor64_loss']))), k
+    assert losses['p'] == pytest.approx(float(fx['p']))
+    assert agree >= min(0.9995, 1 - 3 * (1 - float(fx['agree64'])))
+    assert not bad, bad
+    assert srt[len(srt) // 2] < max(2e-4, 5 * sorted(floors)[len(floors) // 2])
+    for e, f in zip(errs, fe):
+        assert e < max(2e-3, 5 * f)
+    # optimizer: the parameter moved exactly like the reference's (lr 2e-5: the update is lr-sized whatever the gradient)
+    dw = (params['decoder.pred.weight'].detach().cpu() - fx['w_after_pred_weight']).abs().max()
+    assert float(dw) < 2e-6
+    for n in fx['unused']:
+        assert float(params[n].grad.abs().max()) == 0.0, n

@@ -109,7 +109,7 @@ def test_train_step_matches_reference_trainer(golden, tag, it):
     case = tc['cases'][tag]
     fx = golden('g9_train_%s_it%d.npz' % (tag, it))
     cfg = O.make_cfg(**case['cfg'])
-    model, sd = H.make_model_and_sd(cfg, case['wseed'])
+    model, sd = H.make_model_and_sd(cfg, case['wseed'], pred_scale=tc['pred_scale'])
     frames, init_mask, label, valid = H.train_batch(case)
     assert H.checksum(frames) == pytest.approx(float(fx['frames_sum']), rel=1e-12)
     torch.manual_seed(91)
