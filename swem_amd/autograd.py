@@ -95,14 +95,14 @@ class _Conv(Function):
         pk = _fwd_pack(weight, bias, stride, pad, cin_pad)
         y = ops.conv2d(list(srcs), pk, relu_in=relu_in, residual=residual, batch=batch)
         ctx.meta = meta
-        ctx.weight, ctx.bias, ctx.srcs = weight, bias, srcs
+        ctx.save_for_backward(weight, bias, *srcs)
         ctx.has_res = residual is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         stride, pad, relu_in, batch, cin_pad = ctx.meta
-        weight, bias, srcs = ctx.weight, ctx.bias, ctx.srcs
+        weight, bias, *srcs = ctx.saved_tensors
         dy = dy.contiguous()
         B, Ho, Wo, Cout = dy.shape
         dev = dy.device
@@ -157,12 +157,14 @@ class _BNAct(Function):
         y = torch.empty_like(c)
         _lib.call('swem_bn_act_f32', ops._stream(), c.data_ptr(), fold[0].data_ptr(), fold[1].data_ptr(), ops._ptr(res),
                   y.data_ptr(), M, Cc, int(relu))
-        ctx.saved = (c, y, fold, gamma, beta, mean, relu, res is not None)
+        ctx.save_for_backward(c, y, fold, gamma, beta, mean)     # (saved_tensors keeps the output without a cycle)
+        ctx.flags = (relu, res is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        c, y, fold, gamma, beta, mean, relu, has_res = ctx.saved
+        c, y, fold, gamma, beta, mean = ctx.saved_tensors
+        relu, has_res = ctx.flags
         dy = dy.contiguous()
         Cc = c.shape[-1]
         M = c.numel() // Cc
@@ -419,13 +421,15 @@ class _Memorize(Function):
         _lib.call('swem_memorize_train_f32', ops._stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(),
                   kappa_prev.data_ptr(), nu_prev.data_ptr(), zita_prev.data_ptr(), kappa.data_ptr(), nu.data_ptr(),
                   zita.data_ptr(), zT.data_ptr(), N, Cc, V, P, L, T, tau, ws.data_ptr(), wsb)
-        ctx.saved = (zT, zita_prev, zita, (N, P, V, L))
+        ctx.save_for_backward(zT, zita_prev, zita)
+        ctx.dims = (N, P, V, L)
         ctx.mark_non_differentiable(kappa, zita)
         return kappa, nu, zita
 
     @staticmethod
     def backward(ctx, dkappa, dnu, dzita):
-        zT, zita_prev, zita, (N, P, V, L) = ctx.saved
+        zT, zita_prev, zita = ctx.saved_tensors
+        N, P, V, L = ctx.dims
         dev = zT.device
         dv = torch.empty((N, P, V), dtype=torch.float32, device=dev)
         want_prev = ctx.needs_input_grad[1]

@@ -1,4 +1,5 @@
-"""Multi-GPU inference: one process per GPU, sequences sharded across ranks, no data-path collective.
+"""Multi-GPU: one process per GPU.  Inference: sequences sharded across ranks, no data-path collective.
+Training (data parallel over clips, train.py): one bucketed gradient all-reduce per step over the flat gradient buffer.
 
 Within a sequence frame t needs frame t-1's bases (reference modules.py:183-193), so the time axis does not
 shard; sequences are independent.  Rank r takes sequences r, r+W, r+2W, ... (round
@@ -50,3 +51,18 @@ def reduce_counters(frames, seconds, device='cpu'):
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     dist.all_reduce(s, op=dist.ReduceOp.MAX)
     return int(round(f.item())), float(s.item())
+
+
+def allreduce_sum_(flat, bucket_bytes=64 << 20):
+    """In-place SUM all-reduce of a flat gradient buffer in buckets (training: the reference wraps the model in
+    DistributedDataParallel, swem_trainer.py:41-43; here the parameters' gradients already live in ONE buffer, so the
+    'buckets' are plain slices).  All buckets are launched asynchronously and waited for together: on xGMI the ring is
+    per-link bound, 64 MB slices keep every link busy without serialising the launch latency (58.6 M fp32 gradients =
+    4 slices).  The mean over ranks is folded into the loss gradient by the caller (1 / (clips * world))."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return flat
+    n = max(1, bucket_bytes // flat.element_size())
+    works = [dist.all_reduce(flat[i:i + n], op=dist.ReduceOp.SUM, async_op=True) for i in range(0, flat.numel(), n)]
+    for w in works:
+        w.wait()
+    return flat

@@ -6,6 +6,10 @@ signature and return value ``(losses, results)``.  The clip loop, the loss (``lo
 (``optim.FlatAdamW`` + ``MultiStepLR``) run through ``swem_amd.autograd`` / ``libswem_hip.so``; the model's parameters
 live in one flat buffer and their gradients are accumulated in-kernel.
 
+Data parallel: every rank steps its own clips; one bucketed all-reduce of the flat gradient buffer (dist.py) precedes the
+optimizer step, the 1/world factor is folded into the loss gradient.  The reference scales the learning rate by the
+number of GPUs only if asked (solver.py:31-34, ``num_gpu``), so does ``SWEMTrainer(num_gpu=...)``.
+
 How the batch is run: clips are independent (frozen BatchNorm, per-clip memory), so the step walks the B clips one
 after another -- forward, per-clip loss with weight 1/B, backward -- and the parameter gradients add up in the flat
 gradient buffer.  That equals the reference's batched step (``total = mean_b``) and frees a clip's activations before
@@ -15,7 +19,7 @@ import math
 
 import torch
 
-from . import _lib, autograd as A, losses as L, ops, optim
+from . import _lib, autograd as A, dist as sdist, losses as L, ops, optim
 from .networks import BasicBlock, Bottleneck
 
 
@@ -202,7 +206,9 @@ class SWEMTrainer:
                                   self.device)
         label = label.long().contiguous()
         sums = torch.zeros(3, dtype=torch.float32, device=self.device)
-        gout = torch.tensor([1.0 / B, 0.0, 0.0], dtype=torch.float32, device=self.device)
+        # mean over the clips of this rank and over the ranks (DistributedDataParallel averages, swem_trainer.py:41-43)
+        world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        gout = torch.tensor([1.0 / (B * world), 0.0, 0.0], dtype=torch.float32, device=self.device)
         results, p = [], 1.0
         for b in range(B):
             vo = None if valid_obj is None else valid_obj[b:b + 1].float().contiguous()
@@ -213,6 +219,7 @@ class SWEMTrainer:
             sums = ops.lincomb(sums, 1.0, vec.detach(), 1.0 / B)
             results.append(torch.stack(res, dim=1))                    # (1, T-1, H, W)
             p = out['p']
+        sdist.allreduce_sum_(self.optimizer.grad)                      # RCCL over xGMI; no-op for one process
         self.optimizer.step()
         self.lr_scheduler.step()
         losses = {'total_loss': sums[0], 'main_loss': sums[1], 'aux_loss': sums[2], 'p': p}

@@ -23,6 +23,10 @@ def _worker(rank, world, port, q):
     mine = sdist.shard(seqs, r, w)
     sdist.barrier()
     frames, secs = sdist.reduce_counters(10 * len(mine), 1.0 + r)
+    # training: bucketed all-reduce of a flat gradient buffer (several buckets, ragged tail)
+    flat = torch.full((1000003,), float(r + 1))
+    sdist.allreduce_sum_(flat, bucket_bytes=1 << 20)
+    assert float(flat.min()) == float(flat.max()) == 3.0
     q.put((r, mine, frames, secs))
     dist.destroy_process_group()
 
@@ -46,3 +50,5 @@ def test_two_rank_sharding_and_reduction():
 def test_single_process_is_a_no_op():
     assert sdist.shard([1, 2, 3], 0, 1) == [1, 2, 3]
     assert sdist.reduce_counters(5, 0.5) == (5, 0.5)
+    t = torch.ones(10)
+    assert sdist.allreduce_sum_(t) is t and float(t.sum()) == 10.0

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Times SWEMTrainer.one_step (reference swem_trainer.py:59-108) on the reference's training shapes
+(configs/config.py: 3 frames of 384x384 per clip, MAX_NUM_OBJS = 2, ResNet-50, K = 256, 4 EM iterations).
+   python tools/train_bench.py [--clips 4] [--steps 5] [--warmup 2] [--size 384] [--no-autotune]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch  # noqa: E402
+from swem_amd import ops, synth, weights  # noqa: E402
+from swem_amd.swem import SWEM  # noqa: E402
+from swem_amd.train import SWEMTrainer  # noqa: E402
+from types import SimpleNamespace  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--clips', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--size', type=int, default=384)
+    ap.add_argument('--objects', type=int, default=2)
+    ap.add_argument('--backbone', default='resnet50')
+    ap.add_argument('--no-autotune', action='store_true')
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    cfg = SimpleNamespace(KEYDIM=128, VALDIM=512, NUM_BASES=256, NUM_EM_ITERS=4, EM_TAU=0.05, TOPL=64, SINGLE_OBJ=False,
+                          BACKBONE=a.backbone)
+    model = SWEM(cfg)
+    sd = weights.fill_state_dict(model.state_dict(), seed=1, backbone=a.backbone)
+    sd['decoder.pred.weight'] = sd['decoder.pred.weight'] * 0.02
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    ops.AUTOTUNE = not a.no_autotune
+    tr = SWEMTrainer(dict(SOLVER=dict(STAGE=0, BASE_LR=2e-5, PRETRAIN_ITERS=[150000, 300000], GAMMA=0.1,
+                                      OPTIMIZER='AdamW', WEIGHT_DECAY=5e-4),
+                          LOSS=dict(NAME='boots_ce', BS_RATIO=0.3, BS_PERIOD=[20000, 70000], AUX='iou', AUX_RATIO=1.0),
+                          AMP=False), model)
+    fr, im, lb = [], [], []
+    for i in range(a.clips):
+        frames, per = synth.make_clip(t=3, h=a.size, w=a.size, n_obj=a.objects, out_hw=(a.size, a.size), seed=50 + i,
+                                      all_masks=True)
+        lab = torch.stack([m[0].argmax(0) for m in per])
+        fr.append(frames[0])
+        im.append(per[0][0])
+        lb.append(lab)
+    frames, init_mask, label = torch.stack(fr).to(dev), torch.stack(im).to(dev), torch.stack(lb).to(dev)
+    valid = torch.ones(a.clips, a.objects + 1, device=dev)
+    for it in range(a.warmup):
+        losses, _ = tr.one_step(frames, init_mask, valid, label, 30000 + it)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for it in range(a.steps):
+        losses, _ = tr.one_step(frames, init_mask, valid, label, 30000 + it)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / a.steps
+    print(json.dumps({'metric': 'training clips/s (3 x %dx%d frames, %d objects, %s, fp32-accurate)' % (
+        a.size, a.size, a.objects, a.backbone), 'value': a.clips / dt, 'ms_per_step': dt * 1e3, 'clips_per_step': a.clips,
+        'total_loss': float(losses['total_loss']), 'peak_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30}))
+
+
+if __name__ == '__main__':
+    main()
