@@ -108,3 +108,46 @@ def test_checkpoint_so_to_mo_surgery(tmp_path):
     assert w.shape[1] == 5 and torch.equal(w[:, :4], sd['value_encoder.conv1.weight']) and w[:, 4].abs().sum() > 0
     checkpoint.load_model(so, sd)          # same-arity checkpoints load untouched
     assert torch.equal(so.state_dict()['key_comp.weight'], sd['key_comp.weight'])
+
+
+def test_training_host_logic_matches_reference_semantics():
+    """CPU-side pieces of the training step: bootstrap ratio schedule (bce_losses.py:44-48), MultiStepLR, the flat
+    parameter buffer and the host-drawn random bases (modules.py:170-178)."""
+    import math
+    import torch
+    from oracle import swem_oracle as O
+    from swem_amd import losses, optim, train
+    assert losses.this_p(5, 20, 70, 0.3) is None
+    assert losses.this_p(45, 20, 70, 0.3) == pytest.approx(0.3 + 0.7 * 0.5)
+    assert losses.this_p(71, 20, 70, 0.3) == 0.3
+
+    class Opt:
+        lr = 2e-5
+    o = Opt()
+    sch = optim.MultiStepLR(o, [3, 6], 0.1)
+    ref_p = torch.nn.Parameter(torch.zeros(1))
+    ropt = torch.optim.SGD([ref_p], lr=2e-5)
+    rs = torch.optim.lr_scheduler.MultiStepLR(ropt, milestones=[3, 6], gamma=0.1)
+    for it in range(8):
+        assert o.lr == pytest.approx(ropt.param_groups[0]['lr'])
+        assert o.lr == pytest.approx(O.multistep_lr(2e-5, [3, 6], 0.1, it))
+        ropt.step()
+        rs.step()
+        sch.step()
+    # parameters become views of one buffer (16-byte aligned slots), values kept
+    ps = [torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2, 2))]
+    before = [p.detach().clone() for p in ps]
+    flat, table = optim.flatten_parameters(ps)
+    assert flat.numel() == 16 + 8 + 8
+    for p, b in zip(ps, before):
+        off, n = table[id(p)]
+        assert off % 4 == 0 and torch.equal(p.detach(), b) and p.data_ptr() == flat[off:].data_ptr()
+    flat.mul_(2)
+    assert torch.equal(ps[1].detach(), before[1] * 2)
+    # one draw for the whole batch, like the reference: clip b gets slice b
+    torch.manual_seed(3)
+    pri = train.random_init_host(2, 2, 8, 4, 64, 'cpu')
+    torch.manual_seed(3)
+    k, n, z = O.random_init((2, 2, 2, 8, 64), 4)
+    assert torch.equal(pri[1]['kappa'], k[1]) and float(pri[0]['zita'].max()) == pytest.approx(1e-6)
+    assert pri[0]['nu'].shape == (2, 2, 4, 64)
