@@ -169,6 +169,8 @@ int swem_lincomb_f32(void *stream, const float *a, float alpha, const float *b, 
  * annotated, new objects' masks appended as extra channels */
 int swem_inject_objects_f32(void *stream, const float *prob, const float *new_masks, float *out, int B, int N1,
                             int Nn1, long long HW);
+/* int64 index maps -> uint8 on the device, before the copy to the host (basic_evaluator.py:176) */
+int swem_pack_u8_i64(void *stream, const long long *x, unsigned char *y, long long n);
 /* batched 2-D transpose: in [batch][R][Cc] -> out [batch][Cc][ld] (ld >= R, pad columns zeroed) */
 int swem_transpose_f32(void *stream, const float *in, float *out, int batch, int R, int Cc, int ld);
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     'swem_concat2_nhwc_f32': (_i, [_p, _p, _i, _ll, _p, _i, _ll, _p, _i, _ll]),
     'swem_lincomb_f32': (_i, [_p, _p, _f, _p, _f, _p, _ll]),
     'swem_inject_objects_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _ll]),
+    'swem_pack_u8_i64': (_i, [_p, _p, _p, _ll]),
     'swem_transpose_f32': (_i, [_p, _p, _p, _i, _i, _i, _i]),
     'swem_em_pad': (_i, [_i]),
     'swem_em_norm_bases_f32': (_i, [_p, _p, _p, _i, _i, _i]),

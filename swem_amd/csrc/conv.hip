@@ -210,17 +210,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   // Loads are unconditional (out-of-image taps read a clamped in-bounds address and are zeroed by a select) so the
   // compiler issues all of them back to back with ONE wait before the LDS stores; the input ReLU is applied at the
   // store, not at the load (a use right behind each load would serialise the L2 round trips).
-  const bool dbg_simple = p.flags & 1024;  // timing experiment: trivial addresses (wrong results)
   auto gload = [&](int kb) {
-    if (dbg_simple) {
-      unsigned bits = 0xffffu;
-#pragma unroll
-      for (int i = 0; i < RA; ++i) ga[i] = *reinterpret_cast<const float4 *>(p.x[0] + (long long)(m0 + rbase + 32 * i) * p.c[0] + (kb & 7) * 32 + kq * 4);
-#pragma unroll
-      for (int i = 0; i < RB; ++i) gb[i] = *reinterpret_cast<const float4 *>(wrow[i] + kb * BK + kq * 4);
-      okbits = bits;
-      return;
-    }
     const int k = kb * BK + kq * 4;
     const bool kok = k < p.K;
     const int kc = kok ? k : 0;
@@ -280,17 +270,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int kb_begin = blockIdx.z * p.kb_per_split;
   const int kb_end = min(p.nkb, kb_begin + p.kb_per_split);
 
-  if ((p.flags & 2048) && (((blockIdx.x + blockIdx.y * gridDim.x) >> 8) & 1)) {  // experiment: stagger co-resident blocks
-    __builtin_amdgcn_s_sleep(32);
-  }
   gload(kb_begin);
   lstore(0);
   __syncthreads();
   int buf = 0;
-  const bool dbg_noload = p.flags & 256, dbg_nostore = p.flags & 512;  // timing experiments only (wrong results)
   for (int kb = kb_begin; kb < kb_end; ++kb) {
     const bool more = kb + 1 < kb_end;
-    if (more && !dbg_noload) gload(kb + 1);
+    if (more) gload(kb + 1);
     const float4 *Ab = As + buf * KQ * SA + wm * 32 * WM + r + h * SA;
     const float4 *Bb = Bs + buf * KQ * SB + wn * 32 * WN + r + h * SB;
     // operand fragments are fetched one k-group ahead of the MFMAs that use them
@@ -315,7 +301,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       // reuses the fragment registers, exposing the LDS latency: 124 vs 155 TFLOP/s in tools/mfma_lds.hip)
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (dbg_nostore) continue;
     if constexpr (DB) {
       if (more) lstore(buf ^ 1);
       __syncthreads();
@@ -1197,14 +1182,6 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
   p.wsplit = nullptr;
   p.Cout = Cout; p.Ncols = glu ? 2 * Cout : Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.flags = flags;
-  {
-    static int dbg = -1;
-    if (dbg < 0) {
-      const char *e = getenv("SWEM_CONV_DEBUG");
-      dbg = e ? atoi(e) : 0;
-    }
-    p.flags |= dbg;
-  }
   p.nkb = cdiv(p.K, BK);
   Plan pl = resolve_plan(plan, p.M, p.Ncols, p.nkb, glu);
   p.kb_per_split = pl.kb_per_split;

@@ -433,6 +433,15 @@ def concat2(x0, x1, batch):
     return y
 
 
+def pack_u8(idx):
+    """int64 index maps -> uint8 on the device (basic_evaluator.py:176)."""
+    if not (idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous()):
+        raise _lib.SwemHipError('pack_u8: need a contiguous int64 device tensor')
+    out = torch.empty(idx.shape, dtype=torch.uint8, device=idx.device)
+    _lib.call('swem_pack_u8_i64', _stream(), idx.data_ptr(), out.data_ptr(), idx.numel())
+    return out
+
+
 def transpose(x, ld=None):
     """(batch, R, Cc) -> (batch, Cc, ld) with zero padded columns."""
     _chk(x)

@@ -287,3 +287,27 @@ def test_memory_is_constant_size_over_a_long_clip(lib):
             zsum = float(mem['update'].bases['zita'].sum())
         assert mem['first'].bases['kappa'].shape == mem['update'].bases['kappa'].shape == (1, 2, 2, 128, 64)
         assert all(torch.isfinite(v).all() for v in mem['update'].bases.values()) and zsum > 0
+
+
+def test_output_staging_pack_and_png_writer(lib, tmp_path):
+    """f4 (basic_evaluator.py:176-190): int64 maps -> uint8 on the device, async copy, palette PNGs."""
+    import numpy as np
+    from PIL import Image
+    from swem_amd import io, ops
+    g = torch.Generator().manual_seed(4)
+    preds = [torch.randint(0, 4, (1, 37, 53), generator=g).to(DEV) for _ in range(3)]
+    assert torch.equal(ops.pack_u8(preds[0]).cpu(), preds[0].cpu().to(torch.uint8))
+    w = io.IndexMapWriter(str(tmp_path))
+    w.submit('seq', preds)
+    onehot = torch.nn.functional.one_hot(preds[0][0].cpu(), 4).permute(2, 0, 1)[None].float().to(DEV)
+    w.save_first('seq', onehot)
+    assert w.close() == 3
+    for t in range(3):
+        back = np.array(Image.open(str(tmp_path / 'seq' / ('%05d.png' % (t + 1)))))
+        assert np.array_equal(back, preds[t][0].cpu().numpy().astype(np.uint8))
+    assert np.array_equal(np.array(Image.open(str(tmp_path / 'seq' / '00000.png'))), preds[0][0].cpu().numpy())
+    fr = torch.rand(1, 2, 3, 100, 180, generator=g).to(DEV)
+    m = torch.zeros(1, 1, 3, 100, 180, device=DEV)
+    inf, inm = io.stage_sequence(fr, m)
+    ref = torch.nn.functional.interpolate(fr[0].cpu(), size=(480, 864), mode='bicubic', align_corners=False)
+    assert inf.shape == (1, 2, 3, 480, 864) and float((inf[0].cpu() - ref).abs().max()) < 2e-5 and inm[1] is None
