@@ -71,15 +71,15 @@ int swem_sum_batch_f32(void *stream, const float *x, float *y, int B, long long 
  * Frozen BatchNorm (+ residual, ReLU) as a stage of its own: training keeps the raw convolution output c for the
  * BatchNorm parameter gradients (mod_resnet.py:58-113 with the trainer's set_bn_eval, swem_trainer.py:37-39).
  *   y = act(c * alpha + shift + res),  alpha = gamma / sqrt(var + eps),  shift = beta - mean * alpha
- *   bwd: dz = dy * (y > 0) (also the residual's gradient, optional), dc = dz * alpha
- *   parameters: dgamma += invstd * (s2 - mean * s1), dbeta += s1, dbias += alpha * s1 with s1 = colsum(dz),
- *   s2 = colsum(dz * c) (swem_colsum_f32) */
+ *   bwd (one pass + a per-channel finish): dz = dy * (y > 0) (also the residual's gradient, optional), dc = dz * alpha,
+ *   dgamma += invstd * (sum dz*c - mean * sum dz), dbeta += sum dz  (either may be NULL; the conv bias's gradient is the
+ *   column sum of dc, taken by the convolution's own backward) */
 int swem_bn_act_f32(void *stream, const float *c, const float *alpha, const float *shift, const float *res, float *y,
                     long long M, int C, int relu);
-int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y, const float *alpha, float *dz, float *dc,
-                        long long M, int C, int relu);
-int swem_bn_param_grad_f32(void *stream, const float *s1, const float *s2, const float *mean, const float *invstd,
-                           const float *alpha, float *dgamma, float *dbeta, float *dbias, int C);
+size_t swem_bn_act_bwd_workspace(long long M, int C);
+int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y, const float *c, const float *alpha,
+                        const float *mean, const float *invstd, float *dz, float *dc, float *dgamma, float *dbeta,
+                        long long M, int C, int relu, void *ws, size_t ws_bytes);
 /* backward of swem_cbam_f32 (y = x + CBAM(x), attentions.py:22-84): dx [B][H][W][C]; the gradients of the six
  * parameters (mlp.1 / mlp.3 weight+bias, spatial conv weight [1][2][7][7] + bias) are ACCUMULATED.  Ties of the two
  * max-pools send the gradient to the first maximum. */

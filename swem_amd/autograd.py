@@ -168,16 +168,15 @@ class _BNAct(Function):
         dy = dy.contiguous()
         Cc = c.shape[-1]
         M = c.numel() // Cc
-        dz = torch.empty_like(c)
+        dz = torch.empty_like(c) if has_res else None
         dc = torch.empty_like(c)
-        _lib.call('swem_bn_act_bwd_f32', ops._stream(), dy.data_ptr(), y.data_ptr(), fold[0].data_ptr(), dz.data_ptr(),
-                  dc.data_ptr(), M, Cc, int(relu))
-        if gamma.requires_grad or beta.requires_grad:
-            s = torch.empty((2, Cc), dtype=torch.float32, device=c.device)
-            colsum(dz, c, out1=s[0], out2=s[1], accumulate=False)
-            _lib.call('swem_bn_param_grad_f32', ops._stream(), s[0].data_ptr(), s[1].data_ptr(), mean.data_ptr(),
-                      fold[2].data_ptr(), fold[0].data_ptr(), _grad(gamma).data_ptr() if gamma.requires_grad else 0,
-                      _grad(beta).data_ptr() if beta.requires_grad else 0, 0, Cc)
+        want = gamma.requires_grad or beta.requires_grad
+        wsb = _lib.query('swem_bn_act_bwd_workspace', M, Cc) if want else 0
+        ws = _ws(wsb, c.device) if want else None
+        _lib.call('swem_bn_act_bwd_f32', ops._stream(), dy.data_ptr(), y.data_ptr(), c.data_ptr(), fold[0].data_ptr(),
+                  mean.data_ptr(), fold[2].data_ptr(), ops._ptr(dz), dc.data_ptr(),
+                  _grad(gamma).data_ptr() if gamma.requires_grad else 0, _grad(beta).data_ptr() if beta.requires_grad else 0,
+                  M, Cc, int(relu), ops._ptr(ws), wsb)
         return dc, None, None, None, None, (dz if has_res else None), None, None
 
 

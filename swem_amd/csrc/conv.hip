@@ -762,15 +762,15 @@ __device__ __forceinline__ i32x4 raw_rsrc(const void *base, unsigned bytes) {
   r[3] = 0x00020000;
   return r;
 }
-__device__ __forceinline__ void dma16(i32x4 r4, char *lds_dst, unsigned voff, unsigned soff) {
+__device__ __forceinline__ void dma16(i32x4 r4, unsigned lds_addr, unsigned voff, unsigned soff) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the kernel's launch stub
-  const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds_dst;
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(lds_addr), "s"(r4), "s"(soff)
-      : "memory");
+  // M0 is written in the statement that consumes it and is not kept live by hipcc anywhere in these kernels (no other
+  // M0 user: checked in the ISA), so it is not saved; the one wait state between the M0 write and the transfer is the
+  // s_nop.  Descriptor and offset SGPRs are written by scalar instructions only (no VALU->SGPR hazard).
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+               :
+               : "v"(voff), "s"(lds_addr), "s"(r4), "s"(soff)
+               : "memory");
 #endif
 }
 
@@ -785,6 +785,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   constexpr int NA = 3 * 4 * WM, NB = 3 * 4 * WN;  // 64-row fragment runs per k-block
   // NST LDS stages: the transfers run NST-1 k-blocks ahead of the MFMAs
   constexpr int NDMA = (NA + NB) / NW;             // transfers per wave per k-block
+  static_assert(NW == 4 || WM == WN, "eight waves: four move the A image, four the B image, the same count each");
   static_assert((NA + NB) % NW == 0, "every wave must issue the same number of transfers (counted vmcnt)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4 *As = reinterpret_cast<uint4 *>(smem);  // [NST][3][PA]
@@ -826,8 +827,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
     int n = n0 + j * 64 + lane;
     bvoff[j] = n < p.Ncols ? (unsigned)n * 16u : OOB;
   }
+  // Each wave moves ONE k/8 group (g = wave & 3) of every plane: the slot -> (operand, plane, row run) map is then a
+  // compile-time constant and the wave only adds its group's offsets, kept in scalars that advance by one add per k-block.
+  // (With eight waves, waves 0-3 move the A image and 4-7 the B image.)  Scalar instructions share the wave's issue
+  // slot with the MFMAs: the first version of this loop spent 24 % of its wave cycles on ~190 of them per k-block.
+  const int g = wave & 3, half = wave >> 2;
   unsigned avoff[WM];
   unsigned aplane = 0, agroup = 0;  // byte strides between the planes / the 8-channel groups of the current source
+  unsigned a_base = 0;              // scalar offset of (current k-block, group g) in plane 0 of the current source
+  unsigned w_base = 0;              // ... of the filter planes
   i32x4 rsa;
   auto set_tap = [&](const KPos &q) {
     const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
@@ -843,10 +851,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
     const long long ps = q.src == 0 ? p.ps[0] : (q.src == 1 ? p.ps[1] : p.ps[2]);
     aplane = (unsigned)(ps * 2);
     agroup = (unsigned)(ps / cs * 16);  // pixels in the plane * 16 bytes
+    a_base = (unsigned)(q.ci0 / 8 + g) * agroup;
     rsa = src_rsrc(q.src);
   };
   auto advance = [&](KPos &q) {
     q.ci0 += BK;
+    a_base += (BK / 8) * agroup;
+    w_base += (BK / 8) * wgroup;
     const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
     if (q.ci0 >= cs) {
       q.ci0 = 0;
@@ -862,27 +873,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
       set_tap(q);
     }
   };
-  // each wave moves every 4th fragment run of the k-block: f -> (operand, plane, k/8 group, 64-row run)
-  auto issue = [&](const KPos &q, int kb, int buf) {
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const unsigned lds_a = lds0 + (unsigned)g * (SA * 16), lds_b = lds0 + NST * 3 * PA * 16 + (unsigned)g * (SB * 16);
+  auto issue = [&](int stage) {
+    const unsigned sa = lds_a + (unsigned)stage * (3 * PA * 16), sb = lds_b + (unsigned)stage * (3 * PB * 16);
+    if (NW == 4 || half == 0) {
 #pragma unroll
-    for (int f0 = 0; f0 < NA + NB; f0 += NW) {
-      const int f = f0 + wave;
-      if (f < NA) {
-        const int j = f % WM, g = (f / WM) & 3, pl = f / (4 * WM);
-        const unsigned dst = ((buf * 3 + pl) * PA + g * SA + j * 64) * 16;
-        const unsigned soff = pl * aplane + (unsigned)(q.ci0 / 8 + g) * agroup;
+      for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int jj = 0; jj < WM; ++jj)
-          if (jj == j) dma16(rsa, smem + dst, avoff[jj], soff);
-      } else if (f < NA + NB) {
-        const int fb = f - NA;
-        const int j = fb % WN, g = (fb / WN) & 3, pl = fb / (4 * WN);
-        const unsigned dst = (NST * 3 * PA + (buf * 3 + pl) * PB + g * SB + j * 64) * 16;
-        const unsigned soff = pl * wplane + (unsigned)(kb * (BK / 8) + g) * wgroup;
+        for (int j = 0; j < WM; ++j) dma16(rsa, sa + (pl * PA + j * 64) * 16, avoff[j], a_base + pl * aplane);
+    }
+    if (NW == 4 || half == 1) {
 #pragma unroll
-        for (int jj = 0; jj < WN; ++jj)
-          if (jj == j) dma16(rsw, smem + dst, bvoff[jj], soff);
-      }
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) dma16(rsw, sb + (pl * PB + j * 64) * 16, bvoff[j], w_base + pl * wplane);
     }
   };
 
@@ -902,12 +907,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   // drain vmcnt(0) and serialise the ~1-2 us L2/MALL -> LDS latency with every 0.3 us of MFMA work.
   KPos q;
   kpos_init(q, p, kb_begin);
+  w_base = (unsigned)(kb_begin * (BK / 8) + g) * wgroup;
   set_tap(q);
-  issue(q, kb_begin, 0);
+  issue(0);
   if (NST == 3) {
     if (kb_begin + 1 < kb_end) {
       advance(q);
-      issue(q, kb_begin + 1, 1);
+      issue(1);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
     const bool ahead = kb + NST - 1 < kb_end;
     if (ahead) {
       advance(q);
-      issue(q, kb + NST - 1, st == 0 ? NST - 1 : st - 1);  // stage (kb+NST-1) % NST
+      issue(st == 0 ? NST - 1 : st - 1);  // stage (kb+NST-1) % NST
     }
     const uint4 *Ab = As + st * 3 * PA + wm * 32 * TM + r;
     const uint4 *Bb = Bs + st * 3 * PB + wn * 32 * TN + r;

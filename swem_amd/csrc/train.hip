@@ -406,33 +406,66 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ c
   if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
   st4t(y + i * 4, o);
 }
-// dz = dy * (y > 0) (the residual's gradient), dc = dz * alpha (the conv output's gradient)
+// Backward of bn_act in one pass: dz = dy * (y > 0) (also the residual's gradient), dc = dz * alpha (the conv output's
+// gradient), and per block the column partials s1 = sum dz, s2 = sum dz * c for the BatchNorm parameters.
+// Block = 16 channel quads x 16 row lanes over BN_ROWS rows.
+constexpr int BN_ROWS = 512;
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
-                                                         const float *__restrict__ alpha, float *__restrict__ dz,
-                                                         float *__restrict__ dc, long long M, int C, int relu) {
+                                                         const float *__restrict__ c, const float *__restrict__ alpha,
+                                                         float *__restrict__ dz, float *__restrict__ dc,
+                                                         float *__restrict__ part, long long M, int C, int relu) {
+  __shared__ float4 sh1[256], sh2[256];
   const int cq = C / 4;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= M * cq) return;
-  const int c4 = (int)(i % cq);
-  float4 g = ld4t(dy + i * 4);
-  if (relu) {
-    const float4 o = ld4t(y + i * 4);
-    g = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+  const int c4 = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int rsub = threadIdx.x >> 4;
+  const long long m0 = (long long)blockIdx.y * BN_ROWS, m1 = min(M, m0 + BN_ROWS);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (c4 < cq) {
+    const float4 a = ld4t(alpha + c4 * 4);
+    for (long long m = m0 + rsub; m < m1; m += 16) {
+      const long long i = m * C + c4 * 4;
+      float4 g = ld4t(dy + i);
+      if (relu) {
+        const float4 o = ld4t(y + i);
+        g = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+      }
+      if (dz) st4t(dz + i, g);
+      st4t(dc + i, make_float4(g.x * a.x, g.y * a.y, g.z * a.z, g.w * a.w));
+      if (part) {
+        const float4 v = ld4t(c + i);
+        s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+        s2.x += g.x * v.x; s2.y += g.y * v.y; s2.z += g.z * v.z; s2.w += g.w * v.w;
+      }
+    }
   }
-  if (dz) st4t(dz + i * 4, g);
-  const float4 a = ld4t(alpha + c4 * 4);
-  st4t(dc + i * 4, make_float4(g.x * a.x, g.y * a.y, g.z * a.z, g.w * a.w));
+  if (!part) return;
+  sh1[threadIdx.x] = s1;
+  sh2[threadIdx.x] = s2;
+  __syncthreads();
+  if (rsub == 0 && c4 < cq) {
+    for (int j = 1; j < 16; ++j) {
+      const float4 t1 = sh1[threadIdx.x + 16 * j], t2 = sh2[threadIdx.x + 16 * j];
+      s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
+      s2.x += t2.x; s2.y += t2.y; s2.z += t2.z; s2.w += t2.w;
+    }
+    float *dst = part + ((long long)blockIdx.y * 2) * C + c4 * 4;
+    st4t(dst, s1);
+    st4t(dst + C, s2);
+  }
 }
-// dgamma += invstd * (s2 - mean * s1); dbeta += s1; dbias += alpha * s1   (s1 = sum dz, s2 = sum dz * c)
-__global__ void bn_param_grad_kernel(const float *__restrict__ s1, const float *__restrict__ s2,
-                                     const float *__restrict__ mean, const float *__restrict__ invstd,
-                                     const float *__restrict__ alpha, float *__restrict__ dgamma,
-                                     float *__restrict__ dbeta, float *__restrict__ dbias, int C) {
+// dgamma += invstd * (s2 - mean * s1); dbeta += s1, with s1 / s2 summed over the row blocks in order
+__global__ void bn_param_grad_kernel(const float *__restrict__ part, int nrow, const float *__restrict__ mean,
+                                     const float *__restrict__ invstd, float *__restrict__ dgamma,
+                                     float *__restrict__ dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  if (dgamma) dgamma[c] += invstd[c] * (s2[c] - mean[c] * s1[c]);
-  if (dbeta) dbeta[c] += s1[c];
-  if (dbias) dbias[c] += alpha[c] * s1[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int j = 0; j < nrow; ++j) {
+    s1 += part[((long long)j * 2) * C + c];
+    s2 += part[((long long)j * 2 + 1) * C + c];
+  }
+  if (dgamma) dgamma[c] += invstd[c] * (s2 - mean[c] * s1);
+  if (dbeta) dbeta[c] += s1;
 }
 
 __global__ void bn_fold_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -740,20 +773,31 @@ extern "C" int swem_bn_act_f32(void *stream, const float *c, const float *alpha,
   SWEM_CHECK_LAUNCH("bn_act_kernel");
   return SWEM_OK;
 }
-extern "C" int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y, const float *alpha, float *dz,
-                                   float *dc, long long M, int C, int relu) {
-  SWEM_REQUIRE(dy && alpha && dc && (y || !relu) && C % 4 == 0 && M > 0, SWEM_E_ARG, "bn_act_bwd: bad argument");
-  hipLaunchKernelGGL(bn_act_bwd_kernel, grid1t(M * (C / 4)), dim3(256), 0, STT, dy, y, alpha, dz, dc, M, C, relu);
-  SWEM_CHECK_LAUNCH("bn_act_bwd_kernel");
-  return SWEM_OK;
+extern "C" size_t swem_bn_act_bwd_workspace(long long M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  return (size_t)cdiv(M, BN_ROWS) * 2 * C * sizeof(float);
 }
-extern "C" int swem_bn_param_grad_f32(void *stream, const float *s1, const float *s2, const float *mean,
-                                      const float *invstd, const float *alpha, float *dgamma, float *dbeta,
-                                      float *dbias, int C) {
-  SWEM_REQUIRE(s1 && s2 && mean && invstd && alpha && C > 0, SWEM_E_ARG, "bn_param_grad: bad argument");
-  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, STT, s1, s2, mean, invstd, alpha, dgamma,
-                     dbeta, dbias, C);
-  SWEM_CHECK_LAUNCH("bn_param_grad_kernel");
+extern "C" int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y, const float *c, const float *alpha,
+                                   const float *mean, const float *invstd, float *dz, float *dc, float *dgamma,
+                                   float *dbeta, long long M, int C, int relu, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(dy && alpha && dc && (y || !relu) && C % 4 == 0 && M > 0, SWEM_E_ARG, "bn_act_bwd: bad argument");
+  const bool params = dgamma || dbeta;
+  SWEM_REQUIRE(!params || (c && mean && invstd), SWEM_E_ARG, "bn_act_bwd: parameter gradients need c, mean, invstd");
+  const int nrow = cdiv(M, BN_ROWS);
+  float *part = nullptr;
+  if (params) {
+    const size_t need = swem_bn_act_bwd_workspace(M, C);
+    SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "bn_act_bwd: workspace %zu < %zu bytes", ws_bytes, need);
+    part = static_cast<float *>(ws);
+  }
+  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(cdiv(C / 4, 16), nrow), dim3(256), 0, STT, dy, y, c, alpha, dz, dc, part, M,
+                     C, relu);
+  SWEM_CHECK_LAUNCH("bn_act_bwd_kernel");
+  if (params) {
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, STT, part, nrow, mean, invstd, dgamma,
+                       dbeta, C);
+    SWEM_CHECK_LAUNCH("bn_param_grad_kernel");
+  }
   return SWEM_OK;
 }
 extern "C" int swem_bn_fold_f32(void *stream, const float *gamma, const float *beta, const float *mean,

@@ -39,29 +39,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const int ky = tap / p.KW, kx = tap - ky * p.KW;
   const int m_begin = blockIdx.z * p.m_per_split, m_end = min(p.M, m_begin + p.m_per_split);
   const int HoWo = p.Ho * p.Wo;
-  constexpr int C4 = BT / 4;         // float4 per slab row
-  int lrow[NL], lc4[NL];
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    const int f = tid + 256 * i;
-    lrow[i] = f / C4;
-    lc4[i] = f - lrow[i] * C4;
-  }
+  // one slab row (pixel) per 8 threads, NL consecutive float4 each: the pixel -> (b, oy, ox) decode (two integer
+  // divisions; vector instructions do not overlap the fp32 MFMA) is done once per thread and slab
+  const int lrow = tid >> 3, lc4 = (tid & 7) * NL;
   float4 gd[NL], gx[NL];
   auto gload = [&](int mb) {
+    const int m = mb + lrow;
+    const bool mok = m < m_end;
+    const int b = m / HoWo, rem = m - b * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+    const bool pok = mok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const float *drow = p.dy + (long long)m * p.Cout + n0;
+    const float *xrow = p.x + (long long)b * p.bs + ((long long)iy * p.W + ix) * p.cs + ci0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int m = mb + lrow[i];
-      const bool mok = m < m_end;
-      const int n = n0 + lc4[i] * 4;
-      gd[i] = (mok && n < p.Cout) ? ld4g(p.dy + (long long)m * p.Cout + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const int b = m / HoWo, rem = m - b * HoWo;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
-      const int c = ci0 + lc4[i] * 4;
-      const bool ok = mok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cs;
-      float4 v = ok ? ld4g(p.x + (long long)b * p.bs + ((long long)iy * p.W + ix) * p.cs + c)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int cc = (lc4 + i) * 4;
+      gd[i] = (mok && n0 + cc < p.Cout) ? ld4g(drow + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = (pok && ci0 + cc < p.cs) ? ld4g(xrow + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (p.relu_in) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
       gx[i] = v;
     }
@@ -69,8 +64,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   auto lstore = [&]() {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      *reinterpret_cast<float4 *>(&Ds[lrow[i] * LD + lc4[i] * 4]) = gd[i];
-      *reinterpret_cast<float4 *>(&Xs[lrow[i] * LD + lc4[i] * 4]) = gx[i];
+      *reinterpret_cast<float4 *>(&Ds[lrow * LD + (lc4 + i) * 4]) = gd[i];
+      *reinterpret_cast<float4 *>(&Xs[lrow * LD + (lc4 + i) * 4]) = gx[i];
     }
   };
   f32x16 acc[WT][WT];
@@ -208,7 +203,7 @@ WgradPlan wgrad_plan(long long M, int Cout, int KH, int KW, int c0, int c1, int 
   pl.wt = big ? 2 : 1;
   const int bt = 64 * pl.wt;
   long long tiles = (long long)cdiv(Cout, bt) * KH * KW * (cdiv(c0, bt) + (c1 ? cdiv(c1, bt) : 0) + (c2 ? cdiv(c2, bt) : 0));
-  long long zs = 2048 / (tiles > 0 ? tiles : 1);
+  long long zs = 1024 / (tiles > 0 ? tiles : 1);
   const long long zmax = (M + 255) / 256;
   if (zs > zmax) zs = zmax;
   if (zs < 1) zs = 1;

@@ -25,6 +25,8 @@ def main():
     ap.add_argument('--objects', type=int, default=2)
     ap.add_argument('--backbone', default='resnet50')
     ap.add_argument('--no-autotune', action='store_true')
+    ap.add_argument('--save-plans', default=None)
+    ap.add_argument('--load-plans', default=None, help='reuse tuned conv plans (profiler runs)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     cfg = SimpleNamespace(KEYDIM=128, VALDIM=512, NUM_BASES=256, NUM_EM_ITERS=4, EM_TAU=0.05, TOPL=64, SINGLE_OBJ=False,
@@ -34,7 +36,9 @@ def main():
     sd['decoder.pred.weight'] = sd['decoder.pred.weight'] * 0.02
     model.load_state_dict(sd)
     model = model.to(dev)
-    ops.AUTOTUNE = not a.no_autotune
+    if a.load_plans:
+        ops.load_plans(a.load_plans)
+    ops.AUTOTUNE = not a.no_autotune and not a.load_plans
     tr = SWEMTrainer(dict(SOLVER=dict(STAGE=0, BASE_LR=2e-5, PRETRAIN_ITERS=[150000, 300000], GAMMA=0.1,
                                       OPTIMIZER='AdamW', WEIGHT_DECAY=5e-4),
                           LOSS=dict(NAME='boots_ce', BS_RATIO=0.3, BS_PERIOD=[20000, 70000], AUX='iou', AUX_RATIO=1.0),
@@ -51,6 +55,9 @@ def main():
     valid = torch.ones(a.clips, a.objects + 1, device=dev)
     for it in range(a.warmup):
         losses, _ = tr.one_step(frames, init_mask, valid, label, 30000 + it)
+    if a.save_plans:
+        ops.save_plans(a.save_plans)
+    ops.AUTOTUNE = False
     torch.cuda.synchronize()
     t0 = time.time()
     for it in range(a.steps):
