@@ -122,6 +122,8 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: swem_amd has no CPU path')
+    # one rank per GPU; (ranks wrap around only when a multi-rank run is rehearsed on a smaller box, SWEM_DIST_BACKEND=gloo)
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)        # before the RCCL communicator is created
     dev = torch.device('cuda', local_rank)
     sdist.init()

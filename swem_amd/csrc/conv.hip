@@ -44,6 +44,8 @@ struct ConvP {
   int Cout, Ncols, KH, KW, stride, pad, flags;
   int nkb, kb_per_split;
   float *partial;
+  int mt0;      // first M tile of this launch (the tail launch of a tail-split layer starts further down)
+  int part_m0;  // first output row held by `partial` (rows are stored relative to it)
 };
 
 // One v_max_f32 per element.  fmaxf() costs two (hipcc first canonicalises the operand with v_max x,x), and in the fp32
@@ -100,7 +102,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][
   const int mrow0 = m0 + wm * 32 * WM;
   const int ncol0 = n0 + wn * 32 * WN;
   if (p.partial) {  // split-K: raw partial sums, [z][M][Ncols]
-    float *dst = p.partial + (long long)blockIdx.z * p.M * p.Ncols;
+    float *dst = p.partial + (long long)blockIdx.z * (p.M - p.part_m0) * p.Ncols - (long long)p.part_m0 * p.Ncols;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int r = lane & 31, h = lane >> 5;
   int tm, tn;
   tile_coords(tm, tn);
+  tm += p.mt0;
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- per-thread gather coordinates (fixed over the K loop) ----
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvP p) {
   const int r = lane & 31, h = lane >> 5;
   int tm, tn;
   tile_coords(tm, tn);
+  tm += p.mt0;
   const int m0 = tm * BM, n0 = tn * BN;
   const int kq = tid & 7, rbase = tid >> 3;
 
@@ -565,6 +569,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(ConvP p) {
   const int r = lane & 31, h = lane >> 5;
   int tm, tn;
   tile_coords(tm, tn);
+  tm += p.mt0;
   const int m0 = tm * BM, n0 = tn * BN;
   const int kq = tid & 7, rbase = tid >> 3;
 
@@ -797,6 +802,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   const int r = lane & 31, h = lane >> 5;
   int tm, tn;
   tile_coords(tm, tn);
+  tm += p.mt0;
   const int m0 = tm * BM, n0 = tn * BN;
 
   auto src_rsrc = [&](int sidx) {
@@ -971,12 +977,13 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
   const bool glu = p.flags & SWEM_CONV_GLU;
   const int cq = p.Cout / 4;
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)p.M * cq) return;
-  const int m = (int)(idx / cq);
-  const int co = (int)(idx - (long long)m * cq) * 4;
-  const long long MN = (long long)p.M * p.Ncols;
+  if (idx >= (long long)(p.M - p.part_m0) * cq) return;
+  const int mrel = (int)(idx / cq);
+  const int m = p.part_m0 + mrel;
+  const int co = (int)(idx - (long long)mrel * cq) * 4;
+  const long long MN = (long long)(p.M - p.part_m0) * p.Ncols;
   auto sum4 = [&](int col) {
-    const float *src = p.partial + (long long)m * p.Ncols + col;
+    const float *src = p.partial + (long long)mrel * p.Ncols + col;
     float4 s = *reinterpret_cast<const float4 *>(src);
     for (int z = 1; z < nsplit; ++z) {
       float4 t = *reinterpret_cast<const float4 *>(src + z * MN);
@@ -1128,6 +1135,32 @@ Plan resolve_plan(int plan, int M, int Ncols, int nkb, bool glu) {
   return make_plan(M, Ncols, nkb, glu);
 }
 
+// Tail split (plan bits 24-27 = K-split factor ts of the LAST, partly filled round of tiles): a grid of T tiles on S
+// resident-block slots runs ceil(T/S) rounds however few tiles the last one holds (2x120x216x256->256: 1620 tiles on 512
+// slots = 3.16 -> 4 rounds).  The whole rounds are launched as they are; the M-tile rows of the remainder are launched a
+// second time split ts ways over K (so they fill the chip) and reduced by the split-K epilogue over those rows only.
+struct TailSplit {
+  int main_mt, nsplit, kb_per_split;
+};
+static TailSplit tail_split(int plan, const Plan &pl, int M, int Ncols, int nkb) {
+  TailSplit t{cdiv(M, 64 * pl.wm), 1, nkb};
+  const int ts = (plan >> 24) & 15;
+  if (ts <= 1 || pl.nsplit != 1 || nkb < 2 * ts) return t;
+  const int bpc = (pl.wm == 2 && pl.wn == 2) ? 1 : 2;  // resident blocks per CU (LDS: 98 KB for the 128x128 tile, 74 KB else)
+  const long long slots = (long long)swem_device_cus() * bpc;
+  const int mt = cdiv(M, 64 * pl.wm), nt = cdiv(Ncols, 64 * pl.wn);
+  const long long tiles = (long long)mt * nt, full = tiles / slots * slots;
+  if (full == 0 || full == tiles) return t;
+  t.main_mt = (int)(full / nt);
+  if (t.main_mt >= mt) {
+    t.main_mt = mt;
+    return t;
+  }
+  t.kb_per_split = cdiv(nkb, ts);
+  t.nsplit = cdiv(nkb, t.kb_per_split);
+  return t;
+}
+
 // output size: forward floor((H + 2p - K)/s) + 1; data gradient: the forward INPUT size (H-1)*s + K - 2p + e, where
 // e = rows/cols of the forward input the strided filter never reached (flag bits EH / EW)
 static inline void conv_out_dims(int H, int W, int KH, int KW, int stride, int pad, int flags, int &Ho, int &Wo) {
@@ -1149,7 +1182,10 @@ extern "C" size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, 
   int Ncols = (flags & SWEM_CONV_GLU) ? 2 * Cout : Cout;
   int nkb = cdiv((long long)KH * KW * Cin, BK);
   Plan pl = resolve_plan(plan, (int)M, Ncols, nkb, flags & SWEM_CONV_GLU);
-  if (pl.nsplit <= 1) return 0;
+  if (pl.nsplit <= 1) {
+    TailSplit t = tail_split(plan, pl, (int)M, Ncols, nkb);
+    return t.nsplit > 1 ? (size_t)t.nsplit * (M - (long long)t.main_mt * 64 * pl.wm) * Ncols * sizeof(float) : 0;
+  }
   return (size_t)pl.nsplit * M * Ncols * sizeof(float);
 }
 
@@ -1192,6 +1228,7 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
   Plan pl = resolve_plan(plan, p.M, p.Ncols, p.nkb, glu);
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;
+  p.mt0 = 0; p.part_m0 = 0;
   if (pl.nsplit > 1) {
     size_t need = (size_t)pl.nsplit * M * p.Ncols * sizeof(float);
     SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d: workspace %zu < %zu bytes", ws_bytes, need);
@@ -1322,19 +1359,39 @@ extern "C" int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, lon
   Plan pl = resolve_plan(plan, p.M, p.Ncols, p.nkb, glu);
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;
+  p.mt0 = 0; p.part_m0 = 0;
   if (pl.nsplit > 1) {
     size_t need = (size_t)pl.nsplit * M * p.Ncols * sizeof(float);
     SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_bf16x3: workspace %zu < %zu bytes", ws_bytes, need);
     p.partial = static_cast<float *>(ws);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  dim3 grid(cdiv(p.M, 64 * pl.wm), cdiv(p.Ncols, 64 * pl.wn), pl.nsplit);
-  int rc;
   const int variant = (plan >> 20) & 15;
-  if (pl.wm == 2 && pl.wn == 2) rc = launch_bf3s<2, 2>(p, grid, st, variant);
-  else if (pl.wm == 1 && pl.wn == 2) rc = launch_bf3s<1, 2>(p, grid, st, variant);
-  else rc = launch_bf3s<1, 1>(p, grid, st, variant);
-  if (rc) return rc;
+  const int mtiles = cdiv(p.M, 64 * pl.wm), ntiles = cdiv(p.Ncols, 64 * pl.wn);
+  auto run = [&](const ConvP &q, dim3 grid) {
+    if (pl.wm == 2 && pl.wn == 2) return launch_bf3s<2, 2>(q, grid, st, variant);
+    if (pl.wm == 1 && pl.wn == 2) return launch_bf3s<1, 2>(q, grid, st, variant);
+    return launch_bf3s<1, 1>(q, grid, st, variant);
+  };
+  const TailSplit tl = tail_split(plan, pl, p.M, p.Ncols, p.nkb);
+  int rc;
+  if (tl.nsplit > 1) {
+    if ((rc = run(p, dim3(tl.main_mt, ntiles, 1)))) return rc;      // the whole rounds
+    ConvP t = p;                                                    // the last round's tile rows, split over K
+    t.mt0 = tl.main_mt;
+    t.part_m0 = tl.main_mt * 64 * pl.wm;
+    t.kb_per_split = tl.kb_per_split;
+    const size_t need = (size_t)tl.nsplit * (M - t.part_m0) * p.Ncols * sizeof(float);
+    SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_bf16x3: workspace %zu < %zu bytes", ws_bytes, need);
+    t.partial = static_cast<float *>(ws);
+    if ((rc = run(t, dim3(mtiles - tl.main_mt, ntiles, tl.nsplit)))) return rc;
+    SWEM_CHECK_LAUNCH("conv_igemm_bf3s_kernel");
+    const long long work = (M - t.part_m0) * (Cout / 4);
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(cdiv(work, 256)), dim3(256), 0, st, t, tl.nsplit);
+    SWEM_CHECK_LAUNCH("conv_splitk_epilogue_kernel");
+    return SWEM_OK;
+  }
+  if ((rc = run(p, dim3(mtiles, ntiles, pl.nsplit)))) return rc;
   SWEM_CHECK_LAUNCH("conv_igemm_bf3s_kernel");
   if (pl.nsplit > 1) {
     long long work = M * (Cout / 4);

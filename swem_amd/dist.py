@@ -24,7 +24,7 @@ def init(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('SWEM_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         dist.init_process_group(backend=backend, init_method='env://', rank=rank, world_size=world)
     return rank, local_rank, world
 

@@ -255,9 +255,15 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
             for math in CONV_MATH_MODES:
                 cands.append(wm | wn << 4 | ns << 8 | math << 16)
                 if math == 1:                      # pre-split kernel variants: other stage count, 8-wave 128x128 tile
-                    cands.append(wm | wn << 4 | ns << 8 | math << 16 | 1 << 20)
+                    base = wm | wn << 4 | ns << 8 | math << 16
+                    cands.append(base | 1 << 20)
                     if wm == 2 and wn == 2:
-                        cands.append(wm | wn << 4 | ns << 8 | math << 16 | 2 << 20)
+                        cands.append(base | 2 << 20)
+                    if ns == 1 and blocks > 256 and nkb >= 16:   # tail split: the last, partly filled round over K
+                        for ts in (4, 8):
+                            cands.append(base | ts << 24)
+                            if wm == 2 and wn == 2:
+                                cands.append(base | 2 << 20 | ts << 24)
     best, best_t = 0, float('inf')
     for plan in cands:
         launch(plan)                               # warm (also grows the workspace)

@@ -243,3 +243,22 @@ def test_conv2d_plans_and_math_modes(lib, plan):
         y = ops.conv2d([nhwc(a), nhwc(q), nhwc(s)], ops.pack_glu(wf.to(DEV), bf.to(DEV), wa.to(DEV), ba.to(DEV)),
                        batch=2, plan=plan)
         close(back(y), ref, 2e-5, 'glu plan %#x' % plan)
+
+
+@pytest.mark.parametrize('plan', [0x4010021, 0x8010011, 0x4210022, 0x4010022], ids=lambda p: '%#x' % p)
+def test_conv2d_tail_split(lib, plan):
+    """Plan bits 24-27: the last, partly filled round of tiles is launched a second time split over K and reduced over
+    its rows only; the result equals the plain launch's up to fp32 summation order."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 120, 216, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) * 0.05
+    b = torch.randn(128, generator=g)
+    pack = ops.pack_conv(w.to(DEV), b.to(DEV))
+    xs = nhwc(x)
+    base = ops.conv2d([xs], pack, relu_in=True, plan=plan & 0xffffff)
+    y = ops.conv2d([xs], pack, relu_in=True, plan=plan)
+    ref = F.conv2d(F.relu(x), w, b, padding=1)
+    close(back(y), ref, 2e-5, 'tail-split conv')
+    assert float((y - base).abs().max()) < 1e-4
+    # the workspace query covers the tail's partial sums
+    assert ops._lib.query('swem_conv2d_workspace', 2, 120, 216, 64, 128, 3, 3, 1, 1, 1, plan) > 0
