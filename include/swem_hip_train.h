@@ -27,19 +27,21 @@ extern "C" {
  *   rowstat[B][4]        k-th largest value of raw (threshold), #values above it, their sum, #values equal to it
  *                        (k = 0: plain mean -- {0, HW, sum, 0})
  *   iou    [B][N1][2]    sum min(prob, onehot), sum max(prob, onehot) + 1e-6 per valid channel
- *   k = int(HW * p) of bce_losses.py:49 (0 below start_warm) */
+ *   k = int(HW * p) of bce_losses.py:49 (0 below start_warm); k_dev != NULL: read from device memory instead (the value
+ *   changes every iteration, a captured HIP graph must not bake it in) */
 size_t swem_vos_loss_workspace(int B, int N1, long long HW);
 int swem_vos_loss_frame_fwd_f32(void *stream, const float *logits, const long long *label, long long label_bs,
                                 const float *valid,
                                 float *prob, float *raw, float *rowstat, float *iou, int B, int N1, long long HW,
-                                long long k, void *ws, size_t ws_bytes);
+                                long long k, const long long *k_dev, void *ws, size_t ws_bytes);
 /* losses = {total, main, aux} from the per-frame statistics of T frames (rowstat [T][B][4], iou [T][B][N1][2]) */
 int swem_vos_loss_reduce_f32(void *stream, const float *rowstat, const float *iou, const float *valid, float *losses,
-                             int B, int N1, int T, long long HW, long long k, float aux_ratio);
+                             int B, int N1, int T, long long HW, long long k, const long long *k_dev, float aux_ratio);
 /* d total_loss / d logits of one frame, times the device scalar gout[0] (NULL = 1); T = frames in the clip loss */
 int swem_vos_loss_frame_bwd_f32(void *stream, const float *prob, const float *raw, const long long *label,
                                 long long label_bs, const float *valid, const float *rowstat, const float *iou, float *dlogits, int B,
-                                int N1, int T, long long HW, long long k, float aux_ratio, const float *gout);
+                                int N1, int T, long long HW, long long k, const long long *k_dev, float aux_ratio,
+                                const float *gout);
 
 /* torch.optim.AdamW, one step over a flat parameter buffer (solver/solver.py:38-41):
  *   p *= 1 - lr*wd;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps) */

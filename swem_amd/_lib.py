@@ -51,9 +51,9 @@ SIGNATURES = {
     'swem_match_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _sz]),
     # ---- include/swem_hip_train.h
     'swem_vos_loss_workspace': (_sz, [_i, _i, _ll]),
-    'swem_vos_loss_frame_fwd_f32': (_i, [_p, _p, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _ll, _ll, _p, _sz]),
-    'swem_vos_loss_reduce_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _ll, _ll, _f]),
-    'swem_vos_loss_frame_bwd_f32': (_i, [_p, _p, _p, _p, _ll, _p, _p, _p, _p, _i, _i, _i, _ll, _ll, _f, _p]),
+    'swem_vos_loss_frame_fwd_f32': (_i, [_p, _p, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _ll, _ll, _p, _p, _sz]),
+    'swem_vos_loss_reduce_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _ll, _ll, _p, _f]),
+    'swem_vos_loss_frame_bwd_f32': (_i, [_p, _p, _p, _p, _ll, _p, _p, _p, _p, _i, _i, _i, _ll, _ll, _p, _f, _p]),
     'swem_adamw_f32': (_i, [_p, _p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i]),
     'swem_memorize_train_f32': (_i, [_p] * 11 + [_i] * 6 + [_f, _p, _sz]),
     'swem_nu_update_bwd_workspace': (_sz, [_i, _i, _i, _i]),

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void loss_iou_reduce_kernel(const float *__res
 // the row with an 8-bit histogram each, then one pass for the count / sum above the threshold.  One block per row.
 __global__ __launch_bounds__(1024) void loss_row_select_kernel(const float *__restrict__ raw,
                                                                float *__restrict__ rowstat, long long HW,
-                                                               long long k) {
+                                                               long long k_arg, const long long *__restrict__ k_dev) {
+  const long long k = k_dev ? *k_dev : k_arg;   // device-resident when the step is replayed from a HIP graph
   __shared__ unsigned hist[256];
   __shared__ unsigned sel_digit, sel_remain;
   __shared__ double sh[16];
@@ -168,8 +169,10 @@ __global__ __launch_bounds__(1024) void loss_row_select_kernel(const float *__re
 // losses/__init__.py:57-61: means over rows / planes.  One small block.
 __global__ void loss_reduce_kernel(const float *__restrict__ rowstat, const float *__restrict__ iou,
                                    const float *__restrict__ valid, float *__restrict__ losses, int B, int N1, int T,
-                                   long long HW, long long k, float aux_ratio) {
+                                   long long HW, long long k_arg, const long long *__restrict__ k_dev,
+                                   float aux_ratio) {
   if (threadIdx.x != 0) return;
+  const long long k = k_dev ? *k_dev : k_arg;
   const double keff = k > 0 ? (double)k : (double)HW;
   double main = 0.0;
   for (int r = 0; r < T * B; ++r) {
@@ -206,9 +209,10 @@ __global__ __launch_bounds__(256) void loss_pixel_bwd_kernel(const float *__rest
                                                              const float *__restrict__ valid,
                                                              const float *__restrict__ rowstat,
                                                              const float *__restrict__ iou, float *__restrict__ dlogits,
-                                                             int B, int N1, int T, long long HW, long long k,
+                                                             int B, int N1, int T, long long HW, long long k_arg,
                                                              float aux_ratio, const float *__restrict__ gout,
-                                                             long long label_bs) {
+                                                             long long label_bs, const long long *__restrict__ k_dev) {
+  const long long k = k_dev ? *k_dev : k_arg;
   const float gscale = gout ? gout[0] : 1.f;
   const int b = blockIdx.y;
   const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -292,7 +296,8 @@ extern "C" size_t swem_vos_loss_workspace(int B, int N1, long long HW) {
 
 extern "C" int swem_vos_loss_frame_fwd_f32(void *stream, const float *logits, const long long *label,
                                            long long label_bs, const float *valid, float *prob, float *raw, float *rowstat, float *iou,
-                                           int B, int N1, long long HW, long long k, void *ws, size_t ws_bytes) {
+                                           int B, int N1, long long HW, long long k, const long long *k_dev, void *ws,
+                                           size_t ws_bytes) {
   SWEM_REQUIRE(logits && label && prob && raw && rowstat && iou, SWEM_E_ARG, "vos_loss_fwd: null pointer");
   SWEM_REQUIRE(B > 0 && N1 >= 2 && N1 <= LOSS_MAXC && HW > 0 && HW < (1ll << 31) && k >= 0 && k <= HW, SWEM_E_SHAPE,
                "vos_loss_fwd: B=%d N1=%d (2..%d) HW=%lld k=%lld", B, N1, LOSS_MAXC, HW, k);
@@ -306,31 +311,31 @@ extern "C" int swem_vos_loss_frame_fwd_f32(void *stream, const float *logits, co
   SWEM_CHECK_LAUNCH("loss_pixel_fwd_kernel");
   hipLaunchKernelGGL(loss_iou_reduce_kernel, dim3(B * N1), dim3(256), 0, st, part, iou, nblk);
   SWEM_CHECK_LAUNCH("loss_iou_reduce_kernel");
-  hipLaunchKernelGGL(loss_row_select_kernel, dim3(B), dim3(1024), 0, st, raw, rowstat, HW, k);
+  hipLaunchKernelGGL(loss_row_select_kernel, dim3(B), dim3(1024), 0, st, raw, rowstat, HW, k, k_dev);
   SWEM_CHECK_LAUNCH("loss_row_select_kernel");
   return SWEM_OK;
 }
 
 extern "C" int swem_vos_loss_reduce_f32(void *stream, const float *rowstat, const float *iou, const float *valid,
                                         float *losses, int B, int N1, int T, long long HW, long long k,
-                                        float aux_ratio) {
+                                        const long long *k_dev, float aux_ratio) {
   SWEM_REQUIRE(rowstat && iou && losses, SWEM_E_ARG, "vos_loss_reduce: null pointer");
   SWEM_REQUIRE(B > 0 && N1 >= 2 && N1 <= LOSS_MAXC && T > 0 && HW > 0, SWEM_E_SHAPE, "vos_loss_reduce: bad shape");
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), rowstat, iou, valid,
-                     losses, B, N1, T, HW, k, aux_ratio);
+                     losses, B, N1, T, HW, k, k_dev, aux_ratio);
   SWEM_CHECK_LAUNCH("loss_reduce_kernel");
   return SWEM_OK;
 }
 
 extern "C" int swem_vos_loss_frame_bwd_f32(void *stream, const float *prob, const float *raw, const long long *label,
                                            long long label_bs, const float *valid, const float *rowstat, const float *iou, float *dlogits,
-                                           int B, int N1, int T, long long HW, long long k, float aux_ratio,
-                                           const float *gout) {
+                                           int B, int N1, int T, long long HW, long long k, const long long *k_dev,
+                                           float aux_ratio, const float *gout) {
   SWEM_REQUIRE(prob && raw && label && rowstat && iou && dlogits, SWEM_E_ARG, "vos_loss_bwd: null pointer");
   SWEM_REQUIRE(B > 0 && N1 >= 2 && N1 <= LOSS_MAXC && T > 0 && HW > 0 && HW < (1ll << 31), SWEM_E_SHAPE,
                "vos_loss_bwd: bad shape");
   hipLaunchKernelGGL(loss_pixel_bwd_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, static_cast<hipStream_t>(stream), prob,
-                     raw, label, valid, rowstat, iou, dlogits, B, N1, T, HW, k, aux_ratio, gout, label_bs);
+                     raw, label, valid, rowstat, iou, dlogits, B, N1, T, HW, k, aux_ratio, gout, label_bs, k_dev);
   SWEM_CHECK_LAUNCH("loss_pixel_bwd_kernel");
   return SWEM_OK;
 }

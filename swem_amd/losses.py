@@ -24,7 +24,7 @@ class _ClipLoss(torch.autograd.Function):
     """total_loss of a clip from its per-frame logits (B,N+1,H,W); label (B,T,H,W) int64; valid (B,N+1) or None."""
 
     @staticmethod
-    def forward(ctx, label, valid, k, aux_ratio, *logits):
+    def forward(ctx, label, valid, k, k_dev, aux_ratio, *logits):
         T = len(logits)
         B, N1, H, W = logits[0].shape
         HW = H * W
@@ -41,15 +41,15 @@ class _ClipLoss(torch.autograd.Function):
             ops._chk(lg, 'logits')
             _lib.call('swem_vos_loss_frame_fwd_f32', ops._stream(), lg.data_ptr(), label[:, t].data_ptr(),
                       label.stride(0), vp, prob[t].data_ptr(), raw[t].data_ptr(), rowstat[t].data_ptr(), iou[t].data_ptr(),
-                      B, N1, HW, k, ws.data_ptr(), wsb)
+                      B, N1, HW, k, ops._ptr(k_dev), ws.data_ptr(), wsb)
         _lib.call('swem_vos_loss_reduce_f32', ops._stream(), rowstat.data_ptr(), iou.data_ptr(), vp, out.data_ptr(), B, N1,
-                  T, HW, k, aux_ratio)
-        ctx.saved = (label, valid, prob, raw, rowstat, iou, k, aux_ratio, (B, N1, T, H, W))
+                  T, HW, k, ops._ptr(k_dev), aux_ratio)
+        ctx.saved = (label, valid, prob, raw, rowstat, iou, k, k_dev, aux_ratio, (B, N1, T, H, W))
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        label, valid, prob, raw, rowstat, iou, k, aux_ratio, (B, N1, T, H, W) = ctx.saved
+        label, valid, prob, raw, rowstat, iou, k, k_dev, aux_ratio, (B, N1, T, H, W) = ctx.saved
         grads = []
         gout = gout.contiguous()               # (3,): d/d total first (1 for total.backward(); a loss scale otherwise)
         for t in range(T):
@@ -57,9 +57,9 @@ class _ClipLoss(torch.autograd.Function):
             _lib.call('swem_vos_loss_frame_bwd_f32', ops._stream(), prob[t].data_ptr(), raw[t].data_ptr(),
                       label[:, t].data_ptr(), label.stride(0), ops._ptr(valid), rowstat[t].data_ptr(),
                       iou[t].data_ptr(),
-                      d.data_ptr(), B, N1, T, H * W, k, aux_ratio, gout.data_ptr())
+                      d.data_ptr(), B, N1, T, H * W, k, ops._ptr(k_dev), aux_ratio, gout.data_ptr())
             grads.append(d)
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 class VOSLoss:
@@ -78,15 +78,19 @@ class VOSLoss:
         self.top_p = get('BS_RATIO')
         self.aux_alpha = float(get('AUX_RATIO')) if aux is not None else 0.0
 
-    def clip_loss(self, logits_list, target, it, valid_obj=None):
-        """logits_list: T tensors (B,N+1,H,W); target (B,T,H,W) int64.  Returns the reference's losses dict; total_loss
-        carries the gradient, the others are device scalars."""
-        H, W = logits_list[0].shape[-2:]
+    def top_k(self, it, hw):
+        """(p, k) of bce_losses.py:44-49 for iteration `it` and hw pixels (k = 0: plain cross entropy)."""
         p = this_p(it, self.start_warm, self.end_warm, self.top_p) if self.bootstrap else None
-        k = 0 if p is None else int(H * W * p)
+        return p, (0 if p is None else int(hw * p))
+
+    def clip_loss(self, logits_list, target, it, valid_obj=None, k_dev=None):
+        """logits_list: T tensors (B,N+1,H,W); target (B,T,H,W) int64.  Returns the reference's losses dict; total_loss
+        carries the gradient, the others are device scalars.  k_dev: int64 device scalar holding k (graph replay)."""
+        H, W = logits_list[0].shape[-2:]
+        p, k = self.top_k(it, H * W)
         if target.dtype != torch.int64 or not target.is_contiguous():
             target = target.long().contiguous()
-        out = _ClipLoss.apply(target, valid_obj, k, self.aux_alpha, *logits_list)
+        out = _ClipLoss.apply(target, valid_obj, k, k_dev, self.aux_alpha, *logits_list)
         det = out.detach()
         return {'total_loss': out[0], 'main_loss': det[1], 'aux_loss': det[2], 'p': 1.0 if p is None else p, '_vec': out}
 

@@ -224,6 +224,11 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     return y
 
 
+def AUTOTUNE_PENDING():
+    """True while the on-device tuner may still run (it must not run inside a graph capture)."""
+    return bool(AUTOTUNE)
+
+
 def save_plans(path):
     """Persist the tuned plans (profiling runs reload them instead of re-tuning under the profiler)."""
     import json

@@ -138,24 +138,18 @@ class TrainGraph:
         return {'kappa': kappa, 'nu': nu, 'zita': zita}
 
 
-def random_init_host(B, N, Cc, V, Lb, device):
-    """modules.py:170-178 drawn from the global torch CPU generator (the reference draws one tensor for the whole batch):
-    kappa ~ N(0, sqrt(2/L)) l2-normalised over C, nu = 0, zita = 1e-6.  Per-clip slices, kernels' layouts."""
+def random_init_host(B, N, Cc, Lb):
+    """kappa of modules.py:170-178 drawn from the global torch CPU generator (the reference draws one tensor for the whole
+    batch): N(0, sqrt(2/L)) l2-normalised over C.  (nu = 0 and zita = 1e-6 are constants.)"""
     kappa = torch.zeros(B, N, 2, Cc, Lb)
     kappa.normal_(0, math.sqrt(2.0 / Lb))
-    kappa = kappa / (torch.linalg.norm(kappa, dim=-2, keepdim=True) + 1e-6)
-    out = []
-    for b in range(B):
-        out.append({'kappa': kappa[b].contiguous().to(device),
-                    'nu': torch.zeros(N, 2, V, Lb, device=device),
-                    'zita': torch.full((N, 2, Lb), 1e-6, device=device)})
-    return out
+    return kappa / (torch.linalg.norm(kappa, dim=-2, keepdim=True) + 1e-6)
 
 
 class SWEMTrainer:
     """swem_trainer.py:19-108 without the dataset / logging plumbing: model, criterion, optimizer, scheduler, one_step."""
 
-    def __init__(self, config, model, num_gpu=None):
+    def __init__(self, config, model, num_gpu=None, use_graph=True):
         self.config = config
         self.model = model
         if _get(config, 'AMP'):
@@ -170,6 +164,7 @@ class SWEMTrainer:
         self.criterion = L.get_criterion(_get(config, 'LOSS'), None, 1, 1, dev)
         self.graph = TrainGraph(model)
         self.device = dev
+        self.use_graph = use_graph
 
     def clip_forward(self, frames, init_mask, valid_obj, prior0):
         """swem_trainer.py:63-90 for one clip: frames (1,T,3,H,W), init_mask (1,N+1,H,W), valid_obj (1,N+1)."""
@@ -193,34 +188,88 @@ class SWEMTrainer:
                 update = g.memorize(qk16, mv16, hard, pred_mask, first if update is None else update)
         return logits_list, results
 
-    def one_step(self, frames, init_mask, valid_obj, label, cur_iter):
-        B = frames.shape[0]
-        core = self.model.swem_core
-        frames = frames.float().contiguous()
-        init_mask = init_mask.contiguous()
-        N = init_mask.shape[1] - 1
+    # ------------------------------------------------------------------ the step
+    def _static(self, frames, init_mask, valid_obj, label):
+        """Device buffers with fixed addresses for the step's inputs (a captured HIP graph replays on them)."""
+        key = (tuple(frames.shape), tuple(init_mask.shape), valid_obj is not None)
+        if getattr(self, '_static_key', None) != key:
+            core = self.model.swem_core
+            B, N = frames.shape[0], init_mask.shape[1] - 1
+            Ck = self.model.key_proj.key_proj.weight.shape[0]
+            dev = self.device
+            self.buf = {
+                'frames': torch.empty(frames.shape, dtype=torch.float32, device=dev),
+                'init_mask': torch.empty(init_mask.shape, dtype=torch.float32, device=dev),
+                'label': torch.empty(label.shape, dtype=torch.int64, device=dev),
+                'valid': None if valid_obj is None else torch.empty(valid_obj.shape, dtype=torch.float32, device=dev),
+                'kappa0': torch.empty((B, N, 2, Ck, core.n_bases), dtype=torch.float32, device=dev),
+                'nu0': torch.zeros((N, 2, core.valdim, core.n_bases), dtype=torch.float32, device=dev),
+                'zita0': torch.full((N, 2, core.n_bases), 1e-6, dtype=torch.float32, device=dev),
+                'gout': torch.zeros(3, dtype=torch.float32, device=dev),
+                'k': torch.zeros(1, dtype=torch.int64, device=dev),
+                'sums': torch.zeros(3, dtype=torch.float32, device=dev),
+            }
+            self._static_key, self._graph, self._eager_steps = key, None, 0
+        return self.buf
+
+    def _clips(self, cur_iter):
+        """zero_grad + forward / loss / backward of every clip on the static buffers; returns (results, p)."""
+        bf = self.buf
+        B = bf['frames'].shape[0]
         self.optimizer.zero_grad()
         A.new_step()
-        h16, w16 = frames.shape[-2] // 16, frames.shape[-1] // 16
-        priors = random_init_host(B, N, self.model.key_proj.key_proj.weight.shape[0], core.valdim, core.n_bases,
-                                  self.device)
-        label = label.long().contiguous()
-        sums = torch.zeros(3, dtype=torch.float32, device=self.device)
-        # mean over the clips of this rank and over the ranks (DistributedDataParallel averages, swem_trainer.py:41-43)
-        world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-        gout = torch.tensor([1.0 / (B * world), 0.0, 0.0], dtype=torch.float32, device=self.device)
+        bf['sums'].zero_()
         results, p = [], 1.0
         for b in range(B):
-            vo = None if valid_obj is None else valid_obj[b:b + 1].float().contiguous()
-            logits_list, res = self.clip_forward(frames[b:b + 1], init_mask[b:b + 1], vo, priors[b])
-            out = self.criterion.clip_loss(logits_list, label[b:b + 1, 1:], cur_iter, vo)
+            vo = None if bf['valid'] is None else bf['valid'][b:b + 1]
+            prior = {'kappa': bf['kappa0'][b], 'nu': bf['nu0'], 'zita': bf['zita0']}
+            logits_list, res = self.clip_forward(bf['frames'][b:b + 1], bf['init_mask'][b:b + 1], vo, prior)
+            out = self.criterion.clip_loss(logits_list, bf['label'][b:b + 1, 1:], cur_iter, vo, k_dev=bf['k'])
             vec = out['_vec']                                          # (total, main, aux) of this clip
-            vec.backward(gout)
-            sums = ops.lincomb(sums, 1.0, vec.detach(), 1.0 / B)
+            vec.backward(bf['gout'])
+            bf['sums'].copy_(ops.lincomb(bf['sums'], 1.0, vec.detach(), 1.0 / B))
             results.append(torch.stack(res, dim=1))                    # (1, T-1, H, W)
             p = out['p']
+        return torch.cat(results, dim=0), p
+
+    def one_step(self, frames, init_mask, valid_obj, label, cur_iter):
+        """swem_trainer.py:59-108.  With ``use_graph`` (default) the clips' forward/backward is captured into a HIP graph
+        after two eager steps (which also tune the conv plans) and replayed afterwards: ~3000 launches per clip otherwise
+        leave the GPU waiting for the host.  Everything that changes between steps enters through device buffers (inputs,
+        random bases, the bootstrap k, the loss weight); the optimizer update stays outside the graph (lr, step count)."""
+        bf = self._static(frames, init_mask, valid_obj, label)
+        B, N = frames.shape[0], init_mask.shape[1] - 1
+        core = self.model.swem_core
+        bf['frames'].copy_(frames)
+        bf['init_mask'].copy_(init_mask)
+        bf['label'].copy_(label)
+        if valid_obj is not None:
+            bf['valid'].copy_(valid_obj)
+        bf['kappa0'].copy_(random_init_host(B, N, bf['kappa0'].shape[3], core.n_bases))
+        # mean over the clips of this rank and over the ranks (DistributedDataParallel averages, swem_trainer.py:41-43)
+        world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        bf['gout'].copy_(torch.tensor([1.0 / (B * world), 0.0, 0.0]))
+        H, W = init_mask.shape[-2:]
+        p, k = self.criterion.top_k(cur_iter, H * W)
+        bf['k'].fill_(k)
+        if self.use_graph and self._eager_steps >= 2 and self._graph is None and not ops.AUTOTUNE_PENDING():
+            self._capture(cur_iter)
+        if self._graph is not None:
+            self._graph.replay()
+            results, p = self._graph_out, (1.0 if p is None else p)
+        else:
+            results, p = self._clips(cur_iter)
+            self._eager_steps += 1
         sdist.allreduce_sum_(self.optimizer.grad)                      # RCCL over xGMI; no-op for one process
         self.optimizer.step()
         self.lr_scheduler.step()
+        sums = bf['sums']
         losses = {'total_loss': sums[0], 'main_loss': sums[1], 'aux_loss': sums[2], 'p': p}
-        return losses, torch.cat(results, dim=0)
+        return losses, results
+
+    def _capture(self, cur_iter):
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out, _ = self._clips(cur_iter)
+        self._graph, self._graph_out = g, out

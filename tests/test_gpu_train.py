@@ -422,3 +422,30 @@ def test_one_step_matches_reference_trainer(golden, lib, tag, it):
     assert float(dw) < 2e-6
     for n in fx['unused']:
         assert float(params[n].grad.abs().max()) == 0.0, n
+
+
+def test_graph_replay_equals_eager_steps(lib):
+    """The captured step (HIP graph of all clips' forward/backward, replayed on static buffers with the bootstrap k, the
+    random bases and the loss weight entering through device memory) gives the same losses and the same parameters as
+    eager steps, iteration after iteration (the kernels are deterministic: no atomics)."""
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    case = dict(tc['cases']['r18'], hw=[128, 128])
+    cfg = O.make_cfg(**case['cfg'])
+    frames, init_mask, label, valid = [t.to(DEV) for t in H.train_batch(case)]
+    out = {}
+    for mode in (False, True):
+        model, _ = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+        solver = dict(tc['solver_cfg'], BASE_LR=1e-4)        # a visible update per step
+        tr = SWEMTrainer(dict(SOLVER=solver, LOSS=tc['loss_cfg'], AMP=False), model, use_graph=mode)
+        torch.manual_seed(5)
+        hist = []
+        for it in (18, 19, 20, 45, 71, 5):                   # plain CE, annealed top-k, final top-k, plain again
+            losses, results = tr.one_step(frames, init_mask, valid, label, it)
+            hist.append((float(losses['total_loss']), float(losses['main_loss']), losses['p'], int(results.sum())))
+        assert (tr._graph is not None) == mode
+        out[mode] = (hist, tr.optimizer.param.detach().clone())
+    for a, b in zip(out[False][0], out[True][0]):
+        assert a == b, (a, b)
+    assert torch.equal(out[False][1], out[True][1])
+    assert len({h[0] for h in out[True][0]}) == 6 and out[True][0][-1][3] > 0   # the loss moves, the masks are alive
