@@ -52,3 +52,22 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_lib.SwemHipError, match='no CPU fallback'):
         _lib.load()
+
+
+def test_lds_dma_kernels_are_the_only_m0_users():
+    """conv.hip issues buffer_load ... lds from inline asm and writes M0 itself, without saving it (csrc/conv.hip, dma16).
+    That is only sound while hipcc keeps nothing of its own in M0 inside those kernels: check the generated ISA."""
+    import subprocess
+    src = os.path.join(os.path.dirname(__file__), '..', 'swem_amd', 'csrc', 'conv.hip')
+    asm = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',
+                          src, '-o', '-'], check=True, capture_output=True, text=True, timeout=600).stdout
+    checked = 0
+    for m in re.finditer(r'^(_ZN\S*conv_igemm_bf3s_kernel\S*):', asm, flags=re.M):
+        name = m.group(1)
+        body = asm[m.end():asm.index('s_endpgm', m.end())]
+        uses = [ln.strip() for ln in body.splitlines() if re.search(r'\bm0\b', ln) and not ln.strip().startswith(';')]
+        assert uses, name
+        assert all(re.fullmatch(r's_mov_b32 m0, s\d+', u) for u in uses), (name, uses[:5])
+        assert body.count('offen lds') == len(uses)            # one M0 write per transfer, nothing else
+        checked += 1
+    assert checked >= 6
