@@ -311,3 +311,48 @@ def test_output_staging_pack_and_png_writer(lib, tmp_path):
     inf, inm = io.stage_sequence(fr, m)
     ref = torch.nn.functional.interpolate(fr[0].cpu(), size=(480, 864), mode='bicubic', align_corners=False)
     assert inf.shape == (1, 2, 3, 480, 864) and float((inf[0].cpu() - ref).abs().max()) < 2e-5 and inm[1] is None
+
+
+def test_module_level_vectors_vs_reference(lib, golden):
+    """G4 / G5 on the HIP path: ResBlock (identity and 3x3 shortcut), UpsampleBlock, FeatureFusionBlock with CBAM, the GLU
+    fusion layer, Decoder + decode/aggregate with valid_obj, against outputs recorded from the reference's own classes."""
+    from swem_amd import engine as E, networks as Nw, weights
+    from swem_amd.swem import SWEM
+    fx = golden('g45_modules.npz')
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    back = lambda t: t.permute(0, 3, 1, 2).cpu()
+
+    def load(mod, tag):
+        sd = {k[len(tag) + 3:]: v for k, v in fx.items() if k.startswith(tag + '_m.')}
+        mod.load_state_dict(sd, strict=True)
+        return mod.to(DEV)
+    for tag, (ci, co) in (('rb_same', (32, 32)), ('rb_down', (64, 32))):
+        rb = E._ResBlock(load(Nw.ResBlock(ci, co), tag))
+        assert relmax(back(rb([nhwc(fx[tag + '_x'])])), fx[tag + '_y']) < 2e-5
+    ub = load(Nw.UpsampleBlock(32, 64, 32), 'up')
+    sk = ops.conv2d([nhwc(fx['up_skip'])], ops.pack_conv(ub.skip_conv.weight, ub.skip_conv.bias))
+    y = E._ResBlock(ub.out_conv)([ops.upsample_add(sk, nhwc(fx['up_low']))])
+    assert relmax(back(y), fx['up_y']) < 2e-5
+    fb = load(Nw.FeatureFusionBlock(64, 64), 'ffb')
+    x = E._ResBlock(fb.block1)([nhwc(fx['ffb_x']), nhwc(fx['ffb_f16'])])
+    att = fb.attention
+    x = ops.cbam_residual(x, att.ChannelGate.mlp[1].weight.detach(), att.ChannelGate.mlp[1].bias.detach(),
+                          att.ChannelGate.mlp[3].weight.detach(), att.ChannelGate.mlp[3].bias.detach(),
+                          att.SpatialGate.spatial.conv.weight.detach(), att.SpatialGate.spatial.conv.bias.detach())
+    assert relmax(back(E._ResBlock(fb.block2)([x])), fx['ffb_y']) < 5e-5
+    glu = ops.pack_glu(fx['ffl_layer_f.weight'].to(DEV), fx['ffl_layer_f.bias'].to(DEV), fx['ffl_layer_a.weight'].to(DEV),
+                       fx['ffl_layer_a.bias'].to(DEV))
+    assert relmax(back(ops.conv2d([nhwc(fx['ffl_x'])], glu)), fx['ffl_y']) < 2e-5
+    cfg = O.make_cfg(BACKBONE='resnet18', NUM_BASES=64)
+    model = SWEM(cfg)
+    full = weights.fill_state_dict(model.state_dict(), seed=int(fx['dec_wseed']), backbone='resnet18')
+    full['decoder.pred.weight'] = full['decoder.pred.weight'] * float(fx['dec_pred_scale'])
+    model.load_state_dict(full)
+    model = model.eval().to(DEV)
+    with torch.no_grad():
+        lg, pr = model('segment', 2, fx['dec_ctx'].to(DEV), fx['dec_s8'].to(DEV), fx['dec_s4'].to(DEV),
+                       fx['dec_valid'].to(DEV), (61, 90))
+        lg2, _ = model('segment', 2, fx['dec_ctx'].to(DEV), fx['dec_s8'].to(DEV), fx['dec_s4'].to(DEV), None, (64, 96))
+    assert logits_close(lg.cpu(), fx['dec_logits'])
+    assert probs_close(pr.cpu(), fx['dec_prob'], fx['dec_logits'])
+    assert logits_close(lg2.cpu(), fx['dec_logits_novalid'])

@@ -131,3 +131,36 @@ def test_train_step_matches_reference_trainer(golden, tag, it):
     O.adamw_step(p, {'decoder.pred.weight': grads['decoder.pred.weight']}, {},
                  O.multistep_lr(sc['BASE_LR'], sc['PRETRAIN_ITERS'], sc['GAMMA'], 0), sc['WEIGHT_DECAY'], 1)
     assert torch.allclose(p['decoder.pred.weight'], fx['w_after_pred_weight'], rtol=0, atol=1e-8)
+
+
+def _module_sd(fx, tag, prefix):
+    return {prefix + k[len(tag) + 1:]: v for k, v in fx.items()
+            if k.startswith(tag + '_') and torch.is_tensor(v) and ('weight' in k or 'bias' in k)}
+
+
+def test_module_level_vectors_bit_exact(golden):
+    """G4 / G5: the oracle against outputs of the reference's own ResBlock, UpsampleBlock, FeatureFusionBlock(+CBAM),
+    FeatureFusionLayer, Decoder + decode/aggregate (tests/golden/make_golden_modules.py)."""
+    from swem_amd import weights
+    from swem_amd.swem import SWEM
+    fx = golden('g45_modules.npz')
+    for tag in ('rb_same', 'rb_down'):
+        assert torch.equal(O.res_block(_module_sd(fx, tag, ''), 'm', fx[tag + '_x']), fx[tag + '_y'])
+    sd = _module_sd(fx, 'up', '')
+    sk = O.conv(sd, 'm.skip_conv', fx['up_skip'])
+    y = O.res_block(sd, 'm.out_conv', sk + torch.nn.functional.interpolate(fx['up_low'], size=sk.shape[-2:],
+                                                                            mode='bilinear', align_corners=False))
+    assert torch.equal(y, fx['up_y'])
+    sd = _module_sd(fx, 'ffb', '')
+    x = O.res_block(sd, 'm.block1', torch.cat([fx['ffb_x'], fx['ffb_f16']], 1))
+    assert torch.equal(O.res_block(sd, 'm.block2', x + O.cbam(sd, 'm.attention', x)), fx['ffb_y'])
+    sd = {'swem_core.fusion_layer.' + k[4:]: v for k, v in fx.items() if k.startswith('ffl_layer')}
+    assert torch.equal(O.fusion_layer(sd, fx['ffl_x']), fx['ffl_y'])
+    cfg = O.make_cfg(BACKBONE='resnet18', NUM_BASES=64)
+    full = weights.fill_state_dict(SWEM(cfg).state_dict(), seed=int(fx['dec_wseed']), backbone='resnet18')
+    full['decoder.pred.weight'] = full['decoder.pred.weight'] * float(fx['dec_pred_scale'])
+    lg, pr = O.decode(full, 2, fx['dec_ctx'], fx['dec_s8'], fx['dec_s4'], fx['dec_valid'], (61, 90))
+    assert torch.equal(lg, fx['dec_logits']) and torch.equal(pr, fx['dec_prob'])
+    lg2, _ = O.decode(full, 2, fx['dec_ctx'], fx['dec_s8'], fx['dec_s4'], None, (64, 96))
+    assert torch.equal(lg2, fx['dec_logits_novalid'])
+    assert torch.equal(O.aggregate(fx['agg_in']), fx['agg_out'])
