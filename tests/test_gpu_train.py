@@ -449,3 +449,27 @@ def test_graph_replay_equals_eager_steps(lib):
         assert a == b, (a, b)
     assert torch.equal(out[False][1], out[True][1])
     assert len({h[0] for h in out[True][0]}) == 6 and out[True][0][-1][3] > 0   # the loss moves, the masks are alive
+
+
+def test_one_step_single_object_vs_oracle(lib):
+    """Stage-0 style step (SINGLE_OBJ model, one object, valid_obj=None, plain CE below start_warm) against the oracle's
+    autograd run in the test itself: exercises ValueEncoderSO, the 4-channel stem and the valid_obj=None branches."""
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    cfg = O.make_cfg(BACKBONE='resnet18', NUM_BASES=64, TOPL=32, NUM_EM_ITERS=4, SINGLE_OBJ=True)
+    model, sd = H.make_model_and_sd(cfg, 6, DEV, pred_scale=tc['pred_scale'])
+    case = dict(b=1, t=3, hw=(128, 160), n=1, seed=77, valid=[[1, 1]])
+    frames, init_mask, label, _ = H.train_batch(case)
+    torch.manual_seed(17)
+    ref_l, ref_res, ref_g, _ = O.train_one_step(H.trainable_sd(sd, model), cfg, frames, init_mask, None, label, 3,
+                                                tc['loss_cfg'])
+    tr = SWEMTrainer(dict(SOLVER=tc['solver_cfg'], LOSS=tc['loss_cfg'], AMP=False), model, use_graph=False)
+    torch.manual_seed(17)
+    losses, results = tr.one_step(frames.to(DEV), init_mask.to(DEV), None, label.to(DEV), 3)
+    assert float(losses['total_loss']) == pytest.approx(float(ref_l['total_loss']), rel=2e-4)
+    assert float((results.cpu() == ref_res).float().mean()) > 0.998
+    params = dict(model.named_parameters())
+    rels = sorted(abs(float(params[k].grad.double().norm()) - float(g.double().norm())) / (float(g.double().norm()) + 1e-12)
+                  for k, g in ref_g.items() if g is not None)
+    assert rels[len(rels) // 2] < 1e-3 and rels[int(len(rels) * 0.9)] < 2e-2, (rels[len(rels) // 2], rels[-5:])
+    assert params['value_encoder.conv1.weight'].shape[1] == 4
