@@ -179,11 +179,12 @@ int swem_transpose_f32(void *stream, const float *in, float *out, int batch, int
  * Pp = P rounded up to a multiple of 32 (swem_em_pad(P)).
  *   x     [P][C]      raw key of the frame, one row per pixel (reference x_t)
  *   xT    [C][Pp]     the same transposed (reference x), pad columns 0
- *   kn    [NK][L][C]  l2-normalised bases, one row per base (modules.py:115)
+ *   kn    [NK][C/4][L][4]  l2-normalised bases, channel-group major: kn[nk][c/4][l][c%4] = kappa[nk][c][l]/(|.|+eps)
+ *                      (modules.py:115; the GEMM kernels put one base on every lane: this keeps their loads coalesced)
  *   zT    [NK][L][Pp] responsibilities, one row per base, pad columns 0
  */
 int swem_em_pad(int P);
-/* kn[nk][l][:] = kappa[nk][:][l] / (||kappa[nk][:][l]|| + 1e-6)   modules.py:7-9,115 */
+/* kn = l2-normalised bases in the layout above   modules.py:7-9,115 */
 int swem_em_norm_bases_f32(void *stream, const float *kappa /*[NK][C][L]*/, float *kn, int NK, int C, int L);
 /* E and/or W step on one GEMM (they share x_t . l2norm(kappa)):
  *   do_w: weights = masks * (1 - p_own)          modules.py:93-110  -> w_out [NK][P]

@@ -26,7 +26,7 @@ namespace {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-// kn[nk][l][:] = kappa[nk][:][l] / (||kappa[nk][:][l]|| + eps).  Block: 32 bases x all channels.
+// kn[nk][c/4][l][c%4] = kappa[nk][c][l] / (||kappa[nk][:][l]|| + eps).  Block: 32 bases x all channels.
 __global__ __launch_bounds__(256) void em_norm_bases_kernel(const float *__restrict__ kappa, float *__restrict__ kn,
                                                             int C, int L, int out_rows, int out_off) {
   extern __shared__ float sm[];  // tile[C][33], part[8][32], nrm[32]
@@ -48,37 +48,45 @@ __global__ __launch_bounds__(256) void em_norm_bases_kernel(const float *__restr
     nrm[threadIdx.x] = sqrtf(s) + SWEM_L2_EPS;
   }
   __syncthreads();
+  // kn is channel-group major, [nk][C/4][row][4]: the E/W and affinity kernels put one base row on every lane, and with
+  // row-major [row][C] every lane of a load touched its own cache line (32 lines per instruction, the blocks' GEMMs were
+  // bound by that: 15 of em_ew's 19 us); here the 32 rows' 16-byte chunks of one k-step are contiguous.
   for (int idx = threadIdx.x; idx < 32 * C; idx += 256) {
-    int ll = idx / C, c = idx - ll * C;
-    if (l0 + ll < L) kn[((long long)nk * out_rows + out_off + l0 + ll) * C + c] = tile[c * 33 + ll] / nrm[ll];
+    const int e = idx & 3, ll = (idx >> 2) & 31, c4 = idx >> 7;
+    if (l0 + ll < L)
+      kn[(((long long)nk * (C / 4) + c4) * out_rows + out_off + l0 + ll) * 4 + e] = tile[(c4 * 4 + e) * 33 + ll] / nrm[ll];
   }
 }
 
-template <int LT>
-__global__ __launch_bounds__(256) void em_ew_kernel(const float *__restrict__ x, const float *__restrict__ kn,
+// L = 32 * LT * WPC bases per class: WPC waves per class, LT 32-base tiles per wave.  The block is 2*WPC waves; more waves
+// per block shorten every wave's MFMA chain and epilogue (there are only P/32 x N blocks: 102 at config B, well under the
+// 256 CUs, so the kernel's time is one block's latency).
+template <int LT, int WPC>
+__global__ __launch_bounds__(128 * WPC) void em_ew_kernel(const float *__restrict__ x, const float *__restrict__ kn,
                                                     const float *__restrict__ masks, const float *__restrict__ w_in,
                                                     float *__restrict__ w_out, float *__restrict__ zT, int C, int P,
                                                     int Pp, int L, float tau, int do_w, int do_e) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int XS = C + 4;
   float *xs = sm;             // [32][C+4]
+  constexpr int NW = 2 * WPC;
   float *xn = xs + 32 * XS;   // [32]
-  float *red = xn + 32;       // [3][4][32]
+  float *red = xn + 32;       // [3][NW][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int cls = wave >> 1, lh = wave & 1;
+  const int cls = wave / WPC, lh = wave % WPC;
   const int n = blockIdx.y, p0 = blockIdx.x * 32;
   const int nk = n * 2 + cls;
   const int cq = C / 4;
-  for (int idx = tid; idx < 32 * cq; idx += 256) {
+  for (int idx = tid; idx < 32 * cq; idx += 64 * NW) {
     int row = idx / cq, c4 = idx - row * cq;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p0 + row < P) v = ld4(x + (long long)(p0 + row) * C + c4 * 4);
     *reinterpret_cast<float4 *>(xs + row * XS + c4 * 4) = v;
   }
   __syncthreads();
-  for (int rr = 0; rr < 8; ++rr) {
-    int row = wave * 8 + rr;
+  for (int rr = 0; rr < 32 / NW; ++rr) {
+    int row = wave * (32 / NW) + rr;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) {
       float v = xs[row * XS + c];
@@ -94,22 +102,35 @@ __global__ __launch_bounds__(256) void em_ew_kernel(const float *__restrict__ x,
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
   const int lbase = lh * 32 * LT;
-  const float *krow = kn + ((long long)nk * L + lbase + r) * C + 4 * h;
+  const float *krow = kn + (((long long)nk * (C / 4) + h) * L + lbase + r) * 4;  // chunk (2j + h) of row lbase + r
   const float *xrow = xs + r * XS + 4 * h;
   {
-    // base rows of step j+1 are requested before the MFMAs of step j (one wave per SIMD: nothing else hides the latency)
-    float4 a4[LT], an[LT];
+    // The base rows stream from L2 (every lane its own row: 32 cache lines per load instruction) with one wave per SIMD,
+    // so nothing but the wave's own prefetch hides the ~1 us round trip: a register ring keeps PF k-steps in flight
+    // (with one step ahead the 16-step loop was latency bound: 24 us for 7 us of MFMA work).
+    constexpr int PF = 4;
+    float4 ring[PF][LT];
+    const int steps = C / 8;
 #pragma unroll
-    for (int t = 0; t < LT; ++t) a4[t] = ld4(krow + (long long)t * 32 * C);
-    for (int j = 0; j < C / 8; ++j) {
-      const int jn = j + 1 < C / 8 ? j + 1 : j;
+    for (int d = 0; d < PF; ++d)
 #pragma unroll
-      for (int t = 0; t < LT; ++t) an[t] = ld4(krow + (long long)t * 32 * C + 8 * jn);
-      float4 b4 = *reinterpret_cast<const float4 *>(xrow + 8 * j);
+      for (int t = 0; t < LT; ++t) ring[d][t] = ld4(krow + ((long long)2 * min(d, steps - 1) * L + t * 32) * 4);
+    for (int j0 = 0; j0 < steps; j0 += PF) {
 #pragma unroll
-      for (int t = 0; t < LT; ++t) acc[t] = mfma32x4(a4[t], b4, acc[t]);
+      for (int d = 0; d < PF; ++d) {
+        const int j = j0 + d;
+        if (j < steps) {
+          float4 b4 = *reinterpret_cast<const float4 *>(xrow + 8 * j);
+          float4 a4[LT];
 #pragma unroll
-      for (int t = 0; t < LT; ++t) a4[t] = an[t];
+          for (int t = 0; t < LT; ++t) a4[t] = ring[d][t];
+          const int jn = min(j + PF, steps - 1);
+#pragma unroll
+          for (int t = 0; t < LT; ++t) ring[d][t] = ld4(krow + ((long long)2 * jn * L + t * 32) * 4);
+#pragma unroll
+          for (int t = 0; t < LT; ++t) acc[t] = mfma32x4(a4[t], b4, acc[t]);
+        }
+      }
     }
   }
   __syncthreads();  // xn visible
@@ -129,16 +150,23 @@ __global__ __launch_bounds__(256) void em_ew_kernel(const float *__restrict__ x,
     m = fmaxf(m, __shfl_xor(m, 32));
     if (h == 0) red[wave * 32 + r] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[r], red[32 + r]), fmaxf(red[64 + r], red[96 + r]));
+    m = red[r];
+#pragma unroll
+    for (int q = 1; q < NW; ++q) m = fmaxf(m, red[q * 32 + r]);
     float se = 0.f;
 #pragma unroll
     for (int t = 0; t < LT; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) se += exp_scaled(acc[t][e] * rden - m, k2);
     se += __shfl_xor(se, 32);
-    if (h == 0) red[128 + wave * 32 + r] = se;
+    if (h == 0) red[NW * 32 + wave * 32 + r] = se;
     __syncthreads();
-    const float s_bg = red[128 + r] + red[128 + 32 + r], s_fg = red[128 + 64 + r] + red[128 + 96 + r];
+    float s_bg = 0.f, s_fg = 0.f;
+#pragma unroll
+    for (int q = 0; q < WPC; ++q) {
+      s_bg += red[NW * 32 + q * 32 + r];
+      s_fg += red[NW * 32 + (WPC + q) * 32 + r];
+    }
     const float prop = (cls ? s_fg : s_bg) / (s_bg + s_fg);
     const float mk = pin ? masks[(long long)nk * P + p] : 0.f;
     wgt = mk * (1.f - prop);
@@ -154,9 +182,11 @@ __global__ __launch_bounds__(256) void em_ew_kernel(const float *__restrict__ x,
 #pragma unroll
     for (int e = 0; e < 16; ++e) m = fmaxf(m, acc[t][e]);
   m = fmaxf(m, __shfl_xor(m, 32));
-  if (h == 0) red[256 + wave * 32 + r] = m;
+  if (h == 0) red[2 * NW * 32 + wave * 32 + r] = m;
   __syncthreads();
-  m = fmaxf(red[256 + cls * 64 + r], red[256 + cls * 64 + 32 + r]);
+  m = red[2 * NW * 32 + cls * WPC * 32 + r];
+#pragma unroll
+  for (int q = 1; q < WPC; ++q) m = fmaxf(m, red[2 * NW * 32 + (cls * WPC + q) * 32 + r]);
   float se = 0.f;
 #pragma unroll
   for (int t = 0; t < LT; ++t)
@@ -167,10 +197,12 @@ __global__ __launch_bounds__(256) void em_ew_kernel(const float *__restrict__ x,
       se += v;
     }
   se += __shfl_xor(se, 32);
-  __syncthreads();  // everyone has read red[256..] (max) before it is reused for the sums
-  if (h == 0) red[256 + wave * 32 + r] = se;
+  __syncthreads();  // everyone has read the maxima before the slots are reused for the sums
+  if (h == 0) red[2 * NW * 32 + wave * 32 + r] = se;
   __syncthreads();
-  se = red[256 + cls * 64 + r] + red[256 + cls * 64 + 32 + r];
+  se = 0.f;
+#pragma unroll
+  for (int q = 0; q < WPC; ++q) se += red[2 * NW * 32 + (cls * WPC + q) * 32 + r];
   const float zscale = wgt / se;  // softmax normalisation and the pixel weight in one factor
   if (p < Pp) {
     float *dst = zT + ((long long)nk * L + lbase) * Pp + p;
@@ -229,13 +261,37 @@ __global__ __launch_bounds__(256) void em_finalize_kernel(const float *__restric
 __global__ __launch_bounds__(1024) void em_finalize_norm_kernel(const float *__restrict__ S,
                                                                 const float *__restrict__ prev,
                                                                 const float *__restrict__ zita_prev,
-                                                                const float *__restrict__ zt, float *__restrict__ out,
-                                                                float *__restrict__ kn_out, int NK, int R, int L) {
+                                                                float *__restrict__ zt, float *__restrict__ out,
+                                                                float *__restrict__ kn_out, int NK, int R, int L,
+                                                                const float *__restrict__ zT, float *__restrict__ zita_out,
+                                                                int Pp) {
   extern __shared__ float sm[];  // tile[R][33], red[32][32], nrm[32]
   float *tile = sm, *red = sm + R * 33, *nrm = red + 1024;
   const int nk = blockIdx.y, l0 = blockIdx.x * 32;
   const int l = threadIdx.x & 31, g = threadIdx.x >> 5;  // 32 row groups: enough loads in flight to hide the slab reads
-  const float zp = zita_prev[(long long)nk * L + l0 + l], z = zt[(long long)nk * L + l0 + l];
+  if (zT) {
+    // zita = zita_prev + sum_p z for this block's 32 bases (em_zsum_kernel's order: one wave per row, the same partial
+    // sums), fused here to save a launch per EM iteration; published through zt for the value update
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // 16 waves, 2 rows each
+    for (int rr = w; rr < 32; rr += 16) {
+      const float *zr = zT + ((long long)nk * L + l0 + rr) * Pp;
+      float s = 0.f;
+      for (int k = lane * 4; k < Pp; k += 256) {
+        float4 v = ld4(zr + k);
+        s += (v.x + v.y) + (v.z + v.w);
+      }
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (lane == 0) {
+        const float zv = zita_prev[(long long)nk * L + l0 + rr] + s;
+        nrm[rr] = zv;
+        zt[(long long)nk * L + l0 + rr] = zv;
+        if (zita_out) zita_out[(long long)nk * L + l0 + rr] = zv;
+      }
+    }
+    __syncthreads();
+  }
+  const float zp = zita_prev[(long long)nk * L + l0 + l], z = zT ? nrm[l] : zt[(long long)nk * L + l0 + l];
+  __syncthreads();  // nrm is reused for the column norms below
   for (int row = g; row < R; row += 32) {
     const long long o = ((long long)nk * R + row) * L + l0 + l;
     const float s = S[((long long)(nk >> 1) * R + row) * (2 * L) + (nk & 1) * L + l0 + l];
@@ -259,9 +315,9 @@ __global__ __launch_bounds__(1024) void em_finalize_norm_kernel(const float *__r
     nrm[threadIdx.x] = sqrtf(s) + SWEM_L2_EPS;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 32 * R; idx += 1024) {
-    int ll = idx / R, c = idx - ll * R;
-    kn_out[((long long)nk * L + l0 + ll) * R + c] = tile[c * 33 + ll] / nrm[ll];
+  for (int idx = threadIdx.x; idx < 32 * R; idx += 1024) {  // [nk][R/4][l][4], as em_norm_bases_kernel
+    const int e = idx & 3, ll = (idx >> 2) & 31, c4 = idx >> 7;
+    kn_out[(((long long)nk * (R / 4) + c4) * L + l0 + ll) * 4 + e] = tile[(c4 * 4 + e) * 33 + ll] / nrm[ll];
   }
 }
 
@@ -318,19 +374,50 @@ extern "C" int swem_em_ew_f32(void *stream, const float *x, const float *kn, con
   SWEM_REQUIRE(tau > 0.f, SWEM_E_ARG, "em_ew: tau must be positive");
   const int Pp = swem_em_pad(P);
   dim3 grid(cdiv(P, 32), N);
-  size_t lds = ((size_t)32 * (C + 4) + 32 + 3 * 128) * sizeof(float);
-#define EW(LT_) \
-  hipLaunchKernelGGL((em_ew_kernel<LT_>), grid, dim3(256), lds, ST, x, kn, masks, w_in, w_out, zT, C, P, Pp, L, tau, \
-                     do_w, do_e)
-  if (L == 64) EW(1);
-  else if (L == 128) EW(2);
-  else EW(4);
+  // 64 bases per class: 2 waves per class; 128: 4 waves x 1 tile; 256: 4 waves x 2 tiles (8-wave blocks)
+#define EW(LT_, WPC_)                                                                                               \
+  hipLaunchKernelGGL((em_ew_kernel<LT_, WPC_>), grid, dim3(128 * WPC_),                                              \
+                     ((size_t)32 * (C + 4) + 32 + 3 * 2 * WPC_ * 32) * sizeof(float), ST, x, kn, masks, w_in, w_out, zT, \
+                     C, P, Pp, L, tau, do_w, do_e)
+  if (L == 64) EW(1, 2);
+  else if (L == 128) EW(1, 4);
+  else EW(2, 4);
 #undef EW
   SWEM_CHECK_LAUNCH("em_ew");
   return SWEM_OK;
 }
 
 extern "C" size_t swem_em_mstep_workspace(int NK, int R, int P, int L) { return mstep_ws(NK, R, P, L).total; }
+
+namespace {
+// zsum_mode: 0 = separate em_zsum launch (the step-level entry point), 1 = fused into the finalize+norm kernel (key bases
+// inside memorize), 2 = zt already holds zita (the value update reuses the last key step's)
+int mstep_impl(void *stream, const float *A, int a_batch_div, const float *zT, const float *prev, const float *zita_prev,
+               float *out, float *zita_out, float *kn_out, int NK, int R, int P, int L, float *S, void *conv_ws,
+               size_t conv_bytes, float *zt, int zsum_mode) {
+  const int Pp = swem_em_pad(P), N = NK / 2;
+  // S[n] = A[n] . [z_bg | z_fg]^T : a batched GEMM on the conv kernel: an R x 1 "image" with Pp channels per object
+  // (A shared by all objects when a_batch_div == 0), 2L 1x1 filters per object = its two classes' rows of zT
+  int rc = swem_conv2d_nhwc_f32(stream, A, Pp, a_batch_div ? (long long)R * Pp : 0, nullptr, 0, 0, nullptr, 0, 0, N, R, 1,
+                                zT, (long long)2 * L * Pp, nullptr, nullptr, nullptr, 0, S, 2 * L, 1, 1, 1, 0, 0, 0, conv_ws,
+                                conv_bytes);
+  if (rc) return rc;
+  if (zsum_mode == 0) {
+    hipLaunchKernelGGL(em_zsum_kernel, dim3(cdiv(NK * L, 4)), dim3(256), 0, ST, zT, zita_prev, zt, zita_out, NK * L, Pp);
+    SWEM_CHECK_LAUNCH("em_zsum");
+  }
+  if (kn_out) {
+    size_t lds = ((size_t)R * 33 + 1024 + 32) * sizeof(float);
+    hipLaunchKernelGGL(em_finalize_norm_kernel, dim3(L / 32, NK), dim3(1024), lds, ST, S, prev, zita_prev, zt, out,
+                       kn_out, NK, R, L, zsum_mode == 1 ? zT : nullptr, zita_out, Pp);
+  } else {
+    hipLaunchKernelGGL(em_finalize_kernel, dim3(L / 32, NK, cdiv(R, 32)), dim3(256), 0, ST, S, prev, zita_prev, zt, out,
+                       NK, R, L);
+  }
+  SWEM_CHECK_LAUNCH("em_finalize");
+  return SWEM_OK;
+}
+}  // namespace
 
 extern "C" int swem_em_mstep_f32(void *stream, const float *A, int a_batch_div, const float *zT, const float *prev,
                                  const float *zita_prev, float *out, float *zita_out, float *kn_out, int NK, int R,
@@ -340,34 +427,17 @@ extern "C" int swem_em_mstep_f32(void *stream, const float *A, int a_batch_div, 
                "em_mstep: need NK even, L %% 32 == 0 and R %% 128 == 0 (got %d, %d, %d)", NK, L, R);
   SWEM_REQUIRE(a_batch_div == 0 || a_batch_div == 2, SWEM_E_ARG, "em_mstep: a_batch_div must be 0 (shared A) or 2");
   SWEM_REQUIRE(!kn_out || R <= 1024, SWEM_E_SHAPE, "em_mstep: kn_out needs R <= 1024");
-  const int Pp = swem_em_pad(P), N = NK / 2;
   MWs w = mstep_ws(NK, R, P, L);
   SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "em_mstep: workspace %zu < %zu", ws_bytes, w.total);
   char *base = static_cast<char *>(ws);
-  float *S = reinterpret_cast<float *>(base + w.S), *zt = reinterpret_cast<float *>(base + w.zt);
-  // S[n] = A[n] . [z_bg | z_fg]^T : a batched GEMM on the conv kernel: an R x 1 "image" with Pp channels per object
-  // (A shared by all objects when a_batch_div == 0), 2L 1x1 filters per object = its two classes' rows of zT
-  int rc = swem_conv2d_nhwc_f32(stream, A, Pp, a_batch_div ? (long long)R * Pp : 0, nullptr, 0, 0, nullptr, 0, 0, N, R, 1,
-                                zT, (long long)2 * L * Pp, nullptr, nullptr, nullptr, 0, S, 2 * L, 1, 1, 1, 0, 0, 0,
-                                base + w.conv, w.zt - w.conv);
-  if (rc) return rc;
-  hipLaunchKernelGGL(em_zsum_kernel, dim3(cdiv(NK * L, 4)), dim3(256), 0, ST, zT, zita_prev, zt, zita_out, NK * L, Pp);
-  SWEM_CHECK_LAUNCH("em_zsum");
-  if (kn_out) {
-    size_t lds = ((size_t)R * 33 + 1024 + 32) * sizeof(float);
-    hipLaunchKernelGGL(em_finalize_norm_kernel, dim3(L / 32, NK), dim3(1024), lds, ST, S, prev, zita_prev, zt, out,
-                       kn_out, NK, R, L);
-  } else {
-    hipLaunchKernelGGL(em_finalize_kernel, dim3(L / 32, NK, cdiv(R, 32)), dim3(256), 0, ST, S, prev, zita_prev, zt, out,
-                       NK, R, L);
-  }
-  SWEM_CHECK_LAUNCH("em_finalize");
-  return SWEM_OK;
+  return mstep_impl(stream, A, a_batch_div, zT, prev, zita_prev, out, zita_out, kn_out, NK, R, P, L,
+                    reinterpret_cast<float *>(base + w.S), base + w.conv, w.zt - w.conv,
+                    reinterpret_cast<float *>(base + w.zt), 0);
 }
 
 namespace {
 struct MemWs {
-  size_t xT, vT, kn, zT, wb, part, total;
+  size_t xT, vT, kn, zT, wb, ztb, part, total;
 };
 MemWs memorize_ws(int N, int C, int V, int P, int L) {
   const int Pp = swem_em_pad(P), NK = 2 * N;
@@ -383,6 +453,7 @@ MemWs memorize_ws(int N, int C, int V, int P, int L) {
   w.kn = take((size_t)NK * L * C * 4);
   w.zT = take((size_t)NK * L * Pp * 4);
   w.wb = take((size_t)NK * P * 4);
+  w.ztb = take((size_t)NK * L * 4);
   size_t p1 = swem_em_mstep_workspace(NK, C, P, L), p2 = swem_em_mstep_workspace(NK, V, P, L);
   w.part = take(p1 > p2 ? p1 : p2);
   w.total = o;
@@ -429,8 +500,13 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
   char *base = static_cast<char *>(ws);
   float *xT = (float *)(base + w.xT), *vT = (float *)(base + w.vT), *kn = (float *)(base + w.kn);
   float *zT = zT_ext ? zT_ext : (float *)(base + w.zT), *wb = (float *)(base + w.wb);
-  void *part = base + w.part;
-  const size_t part_bytes = w.total - w.part;
+  // the two M steps' scratch (S, split-K partials, zita) carved from the shared slot
+  MWs wk = mstep_ws(2 * N, C, P, L), wv = mstep_ws(2 * N, V, P, L);
+  char *part = base + w.part;
+  float *Sk = (float *)(part + wk.S), *Sv = (float *)(part + wv.S);
+  void *convk = part + wk.conv, *convv = part + wv.conv;
+  const size_t convk_bytes = wk.zt - wk.conv, convv_bytes = wv.zt - wv.conv;
+  float *ztb = (float *)(base + w.ztb);
   const int Pp = swem_em_pad(P), NK = 2 * N;
   int rc;
   if ((rc = swem_transpose_f32(stream, x, xT, 1, P, C, Pp))) return rc;
@@ -439,13 +515,15 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
   for (int it = 0; it < T; ++it) {
     // W step of iteration it-1 (modules.py:161-162) and E step of iteration it share one GEMM
     if ((rc = swem_em_ew_f32(stream, x, kn, masks, masks, wb, zT, N, C, P, L, tau, it > 0, 1))) return rc;
-    if ((rc = swem_em_mstep_f32(stream, xT, 0, zT, kappa_prev, zita_prev, kappa_out, zita_out,
-                                it + 1 < T ? kn : nullptr, NK, C, P, L, part, part_bytes)))
+    // key bases: GEMM + one kernel for zita, the prior blend and the next iteration's normalised bases (the last
+    // iteration's kn lands in the same scratch and is simply not used)
+    if ((rc = mstep_impl(stream, xT, 0, zT, kappa_prev, zita_prev, kappa_out, zita_out, kn, NK, C, P, L, Sk, convk,
+                         convk_bytes, ztb, 1)))
       return rc;
   }
-  // value bases from the last z (modules.py:164-165); zita is the one just written
-  return swem_em_mstep_f32(stream, vT, 2, zT, nu_prev, zita_prev, nu_out, nullptr, nullptr, NK, V, P, L, part,
-                           part_bytes);
+  // value bases from the last z (modules.py:164-165); zita is the one just written (ztb)
+  return mstep_impl(stream, vT, 2, zT, nu_prev, zita_prev, nu_out, nullptr, nullptr, NK, V, P, L, Sv, convv, convv_bytes,
+                    ztb, 2);
 }
 }  // namespace
 

@@ -62,28 +62,28 @@ __device__ __forceinline__ float merge_top64(float a, float b, int lane) {
 
 // K1: affinity + joint softmax.  Block = (object, 32-pixel tile); wave w owns bases [w*32J, +32J).
 // pT[n][p][l] = exp((aff - max)/tau) / sum   (pixel-major, one row of Ltot probabilities per pixel; rows >= P are 0)
-template <int J>  // Lm = 64*J bases per class; Ltot = 128*J
-__global__ __launch_bounds__(256) void match_affinity_kernel(const float *__restrict__ qk,
+template <int J, int NW>  // NW waves x J 32-base tiles: Ltot = 32 * J * NW = 2 Lm
+__global__ __launch_bounds__(64 * NW) void match_affinity_kernel(const float *__restrict__ qk,
                                                              const float *__restrict__ mkn, float *__restrict__ pT,
                                                              int C, int P, int Pm, float tau) {
-  constexpr int Ltot = 128 * J;
+  constexpr int Ltot = 32 * J * NW;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int QS = C + 4;
   float *qs = sm;             // [32][C+4]
-  float *red = qs + 32 * QS;  // [2][4][32]
+  float *red = qs + 32 * QS;  // [2][NW][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int n = blockIdx.y, p0 = blockIdx.x * 32;
   const int cq = C / 4;
-  for (int idx = tid; idx < 32 * cq; idx += 256) {
+  for (int idx = tid; idx < 32 * cq; idx += 64 * NW) {
     int row = idx / cq, c4 = idx - row * cq;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p0 + row < P) v = ld4(qk + (long long)(p0 + row) * C + c4 * 4);
     *reinterpret_cast<float4 *>(qs + row * QS + c4 * 4) = v;
   }
   __syncthreads();
-  for (int rr = 0; rr < 8; ++rr) {  // l2norm of the query pixels (modules.py:282)
-    int row = wave * 8 + rr;
+  for (int rr = 0; rr < 32 / NW; ++rr) {  // l2norm of the query pixels (modules.py:282)
+    int row = wave * (32 / NW) + rr;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) {
       float v = qs[row * QS + c];
@@ -100,21 +100,34 @@ __global__ __launch_bounds__(256) void match_affinity_kernel(const float *__rest
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
   {
-    const float *krow = mkn + ((long long)n * Ltot + wave * 32 * J + r) * C + 4 * h;
+    // mkn is [2n + cls][C/4][Lm][4] (em_norm_bases_kernel); a wave's 32 J rows lie inside one class
+    constexpr int Lm = Ltot / 2, WPC = NW / 2;
+    const float *krow = mkn + (((long long)(2 * n + wave / WPC) * (C / 4) + h) * Lm + (wave % WPC) * 32 * J + r) * 4;
     const float *qrow = qs + r * QS + 4 * h;
-    // operands of step j+1 are requested before the MFMAs of step j (one wave per SIMD: nothing else hides the latency)
-    float4 a4[J], an[J];
+    // operands stream from L2 with one wave per SIMD: a register ring keeps PF k-steps in flight (see em_ew_kernel)
+    constexpr int PF = J <= 4 ? 4 : 2;   // J float4 per step; the accumulators already take 16 J registers
+    float4 ring[PF][J];
+    const int steps = C / 8;
 #pragma unroll
-    for (int t = 0; t < J; ++t) a4[t] = ld4(krow + (long long)t * 32 * C);
-    for (int j = 0; j < C / 8; ++j) {
-      const int jn = j + 1 < C / 8 ? j + 1 : j;
+    for (int d = 0; d < PF; ++d)
 #pragma unroll
-      for (int t = 0; t < J; ++t) an[t] = ld4(krow + (long long)t * 32 * C + 8 * jn);
-      float4 b4 = *reinterpret_cast<const float4 *>(qrow + 8 * j);
+      for (int t = 0; t < J; ++t) ring[d][t] = ld4(krow + ((long long)2 * min(d, steps - 1) * Lm + t * 32) * 4);
+    for (int j0 = 0; j0 < steps; j0 += PF) {
 #pragma unroll
-      for (int t = 0; t < J; ++t) acc[t] = mfma32x4(a4[t], b4, acc[t]);
+      for (int d = 0; d < PF; ++d) {
+        const int j = j0 + d;
+        if (j < steps) {
+          float4 b4 = *reinterpret_cast<const float4 *>(qrow + 8 * j);
+          float4 a4[J];
 #pragma unroll
-      for (int t = 0; t < J; ++t) a4[t] = an[t];
+          for (int t = 0; t < J; ++t) a4[t] = ring[d][t];
+          const int jn = min(j + PF, steps - 1);
+#pragma unroll
+          for (int t = 0; t < J; ++t) ring[d][t] = ld4(krow + ((long long)2 * jn * Lm + t * 32) * 4);
+#pragma unroll
+          for (int t = 0; t < J; ++t) acc[t] = mfma32x4(a4[t], b4, acc[t]);
+        }
+      }
     }
   }
   float m = -__builtin_huge_valf();
@@ -125,7 +138,9 @@ __global__ __launch_bounds__(256) void match_affinity_kernel(const float *__rest
   m = fmaxf(m, __shfl_xor(m, 32));
   if (h == 0) red[wave * 32 + r] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red[r], red[32 + r]), fmaxf(red[64 + r], red[96 + r]));
+  m = red[r];
+#pragma unroll
+  for (int q = 1; q < NW; ++q) m = fmaxf(m, red[q * 32 + r]);
   float se = 0.f;
   const float k2 = SWEM_LOG2E / tau;
 #pragma unroll
@@ -137,9 +152,11 @@ __global__ __launch_bounds__(256) void match_affinity_kernel(const float *__rest
       se += v;
     }
   se += __shfl_xor(se, 32);
-  if (h == 0) red[128 + wave * 32 + r] = se;
+  if (h == 0) red[NW * 32 + wave * 32 + r] = se;
   __syncthreads();
-  const float esum = (red[128 + r] + red[128 + 32 + r]) + (red[128 + 64 + r] + red[128 + 96 + r]);
+  float esum = 0.f;
+#pragma unroll
+  for (int q = 0; q < NW; ++q) esum += red[NW * 32 + q * 32 + r];
   const float inv = (p0 + r < P) ? 1.0f / esum : 0.f;  // padded rows are written as zeros
   if (p0 + r < Pm) {
     float *dst = pT + ((long long)n * Pm + p0 + r) * Ltot + wave * 32 * J + 4 * h;
@@ -190,6 +207,26 @@ __global__ __launch_bounds__(256) void match_topl_kernel(const float *__restrict
     dst[lane] = f;
     dst[topl + lane] = 1.f - f;
   }
+}
+
+// Lm bases per class -> (tiles per wave J, waves NW) of the affinity kernel: blocks of 8 waves from 256 bases per class on
+// (there are only Pm/32 x N blocks, so a block's latency is the kernel's time)
+static int launch_affinity(hipStream_t st, const float *qk, const float *mkn, float *pT, int N, int C, int P, int Pm, int Lm,
+                           float tau) {
+  dim3 grid(Pm / 32, N);
+#define AFF(J_, NW_)                                                                                          \
+  hipLaunchKernelGGL((match_affinity_kernel<J_, NW_>), grid, dim3(64 * NW_),                                   \
+                     ((size_t)32 * (C + 4) + 2 * NW_ * 32) * sizeof(float), st, qk, mkn, pT, C, P, Pm, tau)
+  if (Lm == 64) AFF(1, 4);
+  else if (Lm == 128) AFF(2, 4);
+  else if (Lm == 256) AFF(2, 8);
+  else if (Lm == 512) AFF(4, 8);
+  else {
+    swem_set_error("match: bases per class must be 64, 128, 256 or 512 (got %d)", Lm);
+    return SWEM_E_SHAPE;
+  }
+#undef AFF
+  return SWEM_OK;
 }
 
 struct MatchWs {
@@ -309,6 +346,17 @@ __global__ __launch_bounds__(256) void match_bwd_pixel_kernel(const float *__res
     for (int j = 0; j < J; ++j) drow[cls * Lm + lane + 64 * j] = pv[cls][j] * (g[cls][j] - dot) * inv_tau;
 }
 
+// mknT[c][n*Ltot + cls*Lm + l] = mkn[2n + cls][c/4][l][c%4]: the filters of the d qn GEMM (reduction axis contiguous)
+__global__ void kn_cmajor_kernel(const float *__restrict__ mkn, float *__restrict__ mknT, int N, int C, int Lm) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per = (long long)2 * N * Lm;
+  if (i >= per * C) return;
+  const int c = (int)(i / per);
+  const long long rowg = i - (long long)c * per;          // n*Ltot + cls*Lm + l = nk*Lm + l
+  const int nk = (int)(rowg / Lm), l = (int)(rowg - (long long)nk * Lm);
+  mknT[i] = mkn[(((long long)nk * (C / 4) + c / 4) * Lm + l) * 4 + (c & 3)];
+}
+
 // l2norm backward (modules.py:7-9,282): qn = q / (|q| + eps);  dq = g / (|q| + eps) - q (q.g) / (|q| (|q| + eps)^2)
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *__restrict__ q, const float *__restrict__ g,
                                                          float *__restrict__ dq, int P, int C) {
@@ -396,18 +444,14 @@ extern "C" int swem_match_f32(void *stream, const float *qk, const float *kappa_
       hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu_update, mvp, N, V, L, Lm, L);
     SWEM_CHECK_LAUNCH("pack_values");
   }
-  const size_t lds = ((size_t)32 * (C + 4) + 256) * sizeof(float);
-  dim3 grid(Pm / 32, N), gridt(cdiv((long long)N * P, 4));
-#define MATCH(J_)                                                                                                     \
-  do {                                                                                                                \
-    hipLaunchKernelGGL((match_affinity_kernel<J_>), grid, dim3(256), lds, ST, qk, mkn, pT, C, P, Pm, tau);            \
-    hipLaunchKernelGGL((match_topl_kernel<J_>), gridt, dim3(256), 0, ST, pT, S, N, P, Pm, topl);                      \
-  } while (0)
-  if (Lm == 64) MATCH(1);
-  else if (Lm == 128) MATCH(2);
-  else if (Lm == 256) MATCH(4);
-  else MATCH(8);
-#undef MATCH
+  dim3 gridt(cdiv((long long)N * P, 4));
+  if ((rc = launch_affinity(ST, qk, mkn, pT, N, C, P, Pm, Lm, tau))) return rc;
+#define TOPL(J_) hipLaunchKernelGGL((match_topl_kernel<J_>), gridt, dim3(256), 0, ST, pT, S, N, P, Pm, topl)
+  if (Lm == 64) TOPL(1);
+  else if (Lm == 128) TOPL(2);
+  else if (Lm == 256) TOPL(4);
+  else TOPL(8);
+#undef TOPL
   SWEM_CHECK_LAUNCH("match_affinity / match_topl");
   // value readout (modules.py:272-273) = batched GEMM  mem_out[n] = pT[n] . mvp[n]^T  on the conv kernel:
   // "image" of Pm x 1 pixels with Ltot channels, 1x1 filters = the V value rows of object n (w_bs = V*Ltot)
@@ -449,18 +493,8 @@ extern "C" int swem_match_bwd_f32(void *stream, const float *qk, const float *ka
   hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu_first, mvp, N, V, L, Lm, 0);
   if (nbanks == 2)
     hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu_update, mvp, N, V, L, Lm, L);
-  const size_t lds = ((size_t)32 * (C + 4) + 256) * sizeof(float);
-  dim3 grid(Pm / 32, N), gridt(cdiv((long long)N * P, 4));
-#define AFF(J_) hipLaunchKernelGGL((match_affinity_kernel<J_>), grid, dim3(256), lds, ST, qk, mkn, pT, C, P, Pm, tau)
-  if (Lm == 64) AFF(1);
-  else if (Lm == 128) AFF(2);
-  else if (Lm == 256) AFF(4);
-  else if (Lm == 512) AFF(8);
-  else {
-    swem_set_error("match_bwd: bases per class must be 64, 128, 256 or 512 (got %d)", Lm);
-    return SWEM_E_SHAPE;
-  }
-#undef AFF
+  dim3 gridt(cdiv((long long)N * P, 4));
+  if ((rc = launch_affinity(ST, qk, mkn, pT, N, C, P, Pm, Lm, tau))) return rc;
   SWEM_CHECK_LAUNCH("match_bwd (forward recompute)");
   // (1) dP[n] = dmem[n] . mvp[n]   (batched GEMM on the conv kernel; filters = mvp[n]^T [Ltot][V])
   if ((rc = swem_transpose_f32(stream, mvp, mvpT, N, V, Ltot, V))) return rc;
@@ -488,7 +522,8 @@ extern "C" int swem_match_bwd_f32(void *stream, const float *qk, const float *ka
 #undef PIX
   SWEM_CHECK_LAUNCH("match_bwd_pixel");
   // (4) d qn = sum_n da[n] . mkn[n]: one GEMM with the objects as concatenated sources (filters [C][N*Ltot])
-  if ((rc = swem_transpose_f32(stream, mkn, mknT, 1, N * Ltot, C, N * Ltot))) return rc;
+  hipLaunchKernelGGL(kn_cmajor_kernel, dim3(cdiv((long long)C * N * Ltot, 256)), dim3(256), 0, ST, mkn, mknT, N, C, Lm);
+  SWEM_CHECK_LAUNCH("kn_cmajor");
   const float *d0 = dP, *d1 = N > 1 ? dP + (long long)Pm * Ltot : nullptr, *d2 = N > 2 ? dP + 2ll * Pm * Ltot : nullptr;
   if ((rc = swem_conv2d_nhwc_f32(stream, d0, Ltot, 0, d1, N > 1 ? Ltot : 0, 0, d2, N > 2 ? Ltot : 0, 0, 1, Pm, 1, mknT,
                                  0, nullptr, nullptr, nullptr, 0, dqn, C, 1, 1, 1, 0, 0, 0, base + w.conv,

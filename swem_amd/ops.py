@@ -469,10 +469,10 @@ def em_pad(P):
 
 
 def em_norm_bases(kappa):
-    """kappa (NK, C, L) -> kn (NK, L, C)."""
+    """kappa (NK, C, L) -> kn (NK, C/4, L, 4): l2-normalised bases, channel-group major (include/swem_hip.h)."""
     _chk(kappa)
     NK, Cc, L = kappa.shape
-    kn = torch.empty((NK, L, Cc), dtype=torch.float32, device=kappa.device)
+    kn = torch.empty((NK, Cc // 4, L, 4), dtype=torch.float32, device=kappa.device)
     _lib.call('swem_em_norm_bases_f32', _stream(), kappa.data_ptr(), kn.data_ptr(), NK, Cc, L)
     return kn
 
@@ -482,7 +482,7 @@ def em_ew(x, kn, masks, w_in, tau, do_w, do_e):
     _chk(x)
     _chk(kn)
     P, Cc = x.shape
-    NK, L, _ = kn.shape
+    NK, _, L, _ = kn.shape
     Pp = em_pad(P)
     w_out = torch.empty((NK, P), dtype=torch.float32, device=x.device) if do_w else None
     zT = torch.empty((NK, L, Pp), dtype=torch.float32, device=x.device) if do_e else None
@@ -497,7 +497,7 @@ def em_mstep(A, a_div, zT, prev, zita_prev, P, want_kn=False):
     R = prev.shape[1]
     out = torch.empty_like(prev)
     zita = torch.empty_like(zita_prev)
-    kn = torch.empty((NK, L, R), dtype=torch.float32, device=prev.device) if want_kn else None
+    kn = torch.empty((NK, R // 4, L, 4), dtype=torch.float32, device=prev.device) if want_kn else None
     wsb = _lib.query('swem_em_mstep_workspace', NK, R, P, L)
     ws = workspace(wsb, prev.device)
     _lib.call('swem_em_mstep_f32', _stream(), A.data_ptr(), a_div, zT.data_ptr(), prev.data_ptr(),

@@ -30,6 +30,7 @@ def relmax(a, b):
 def test_norm_bases(lib):
     k = torch.randn(4, 128, 64)
     kn = ops.em_norm_bases(d(k)).cpu()
+    kn = kn.permute(0, 2, 1, 3).reshape(kn.shape[0], kn.shape[2], -1)      # (NK, C/4, L, 4) -> (NK, L, C)
     assert relmax(kn, O.l2norm(k, 1).transpose(1, 2)) < 1e-6
 
 
