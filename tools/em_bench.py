@@ -67,5 +67,51 @@ def main():
                                                                  100 * tot_f / tot_t / 1e6 / 157.3))
 
 
+def concurrent(n_streams, objects=2, reps=30, prio=False):
+    """memorize + match of n_streams independent sequences, one HIP graph per stream, replayed together (how the product
+    runs: bench.py --seqs): aggregate algorithmic TFLOP/s of the EM/matching phase when the GPU is shared."""
+    dev = 'cuda:0'
+    N, P, C, V, L, T, tau, topl = objects, 1620, 128, 512, 256, 5, 0.05, 64
+    graphs, streams = [], []
+    for si in range(n_streams):
+        g = torch.Generator().manual_seed(10 + si)
+        x = torch.randn(P, C, generator=g).to(dev)
+        v = torch.randn(N, P, V, generator=g).to(dev)
+        masks = torch.rand(N, 2, P, generator=g).to(dev)
+        kappa = torch.nn.functional.normalize(torch.randn(N, 2, C, L, generator=g), dim=2).to(dev)
+        nu = torch.randn(N, 2, V, L, generator=g).to(dev)
+        zita = (torch.rand(N, 2, L, generator=g) * 3 + 0.1).to(dev)
+        st = torch.cuda.Stream(priority=-(si % 2)) if prio else torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            def fn():
+                k2, n2, z2 = ops.memorize(x, v, masks, kappa, nu, zita, T, tau)
+                ops.match(x, kappa, nu, k2, n2, topl, tau)
+            for _ in range(2):
+                fn()
+            st.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                for _ in range(reps):
+                    fn()
+        graphs.append(gr)
+        streams.append(st)
+    torch.cuda.synchronize()
+    import time
+    for _ in range(2):
+        t0 = time.perf_counter()
+        for gr, st in zip(graphs, streams):
+            with torch.cuda.stream(st):
+                gr.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    fl = (4.0 * P * L * (C * (3 * T - 1) + V) + 4.0 * 2 * L * P * (C + V)) * N * n_streams * reps
+    print('%d concurrent sequence(s)%s: %7.1f us per memorize+match round, %6.1f TFLOP/s = %.1f %% of 157.3'
+          % (n_streams, ' (alternating stream priorities)' if prio else '', 1e6 * dt / reps, fl / dt / 1e12, 100 * fl / dt / 1e12 / 157.3))
+
+
 if __name__ == '__main__':
     main()
+    for ns in (1, 2, 2, 3, 4):
+        concurrent(ns)
+    for ns in (2, 2, 4):
+        concurrent(ns, prio=True)
