@@ -141,6 +141,7 @@ class FrameGraph:
         self.frame = torch.empty(frame_shape, dtype=torch.float32, device=dev)
         self.state = {k: v.clone() for k, v in upd.items()}
         core.memories['update'].bases = self.state
+        self.first = core.memories['first'].bases           # the captured kernels read these tensors in place
         self.graph = torch.cuda.CUDAGraph()
         self.pred = None
 
@@ -158,13 +159,32 @@ class FrameGraph:
             for k in self.state:
                 self.state[k].copy_(saved[k])
             core.memories['update'].bases = self.state
-            with torch.cuda.graph(self.graph):
+            # capture on a stream of this graph's own: scratch buffers are per stream (ops.workspace), and graphs that are
+            # replayed concurrently must not share one (torch's default capture stream is one object for all captures)
+            self.capture_stream = torch.cuda.Stream()
+            with torch.cuda.graph(self.graph, stream=self.capture_stream):
                 self.pred = frame_step(self.model, self.frame, self.out_size)
                 new = core.memories['update'].bases
                 for k in self.state:
                     self.state[k].copy_(new[k])
             core.memories['update'].bases = self.state
         return self
+
+    def rebind(self):
+        """Adopt the model's CURRENT memory (a new sequence initialised eagerly, same shapes) into the captured graph's
+        static buffers, so one capture serves every sequence of that shape."""
+        core = self.model.swem_core
+        cur_first, cur_upd = core.memories['first'].bases, core.memories['update'].bases
+        if cur_first is None or cur_upd is None or cur_first['kappa'].shape != self.first['kappa'].shape:
+            return False
+        for k in self.first:
+            if cur_first[k] is not self.first[k]:
+                self.first[k].copy_(cur_first[k])
+            if cur_upd[k] is not self.state[k]:
+                self.state[k].copy_(cur_upd[k])
+        core.memories['first'].bases = self.first
+        core.memories['update'].bases = self.state
+        return True
 
     def run(self, frame):
         """Stage the frame into the static input buffer and replay; returns the (static) int64 index map."""
@@ -186,3 +206,68 @@ def run_sequences(model, sequences, meter=None):
             meter.toc(frames.shape[1])
         results.append(preds)
     return results, meter
+
+
+class SequencePool:
+    """Several sequences in flight on one GPU, each on its own stream with its own model instance (memory banks):
+    sequences are independent and one sequence alone leaves the GPU under-filled (102 blocks in the
+    EM kernels, ~300 short launches per frame), so a second one's kernels fill the gaps (+18..25 % frames/s, bench.py).
+    Two lanes use streams of different priority: two pool streams can share a hardware queue and then never overlap.
+    After a sequence's first two frames (eager: they build the two banks) the steady-state frame is replayed from a HIP
+    graph that is captured once per lane and re-bound to each new sequence of the same shape."""
+
+    def __init__(self, models, use_graph=True):
+        self.models = list(models)
+        n = len(self.models)
+        self.streams = [torch.cuda.Stream(priority=-(i % 2) if n == 2 else 0) for i in range(n)]
+        self.graphs = [None] * n
+        self.use_graph = use_graph
+
+    def run(self, sequences, seeds=None):
+        """sequences: list of (frames (1,T,3,H,W), init_mask (1,N+1,Ho,Wo), out_size); returns one list of (1,Ho,Wo)
+        int64 index maps per sequence (frames 1..T-1), in input order.  seeds: optional torch seed per sequence, set
+        right before its memory is initialised (reproducible random bases whatever the interleaving)."""
+        todo = list(enumerate(sequences))
+        results = [None] * len(sequences)
+        lanes = [None] * len(self.models)          # per lane: [seq index, frames, out_size, next frame, preds]
+        main = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(main)
+        with torch.no_grad():
+            while todo or any(l is not None for l in lanes):
+                for li, (model, st) in enumerate(zip(self.models, self.streams)):
+                    with torch.cuda.stream(st):
+                        if lanes[li] is None:
+                            if not todo:
+                                continue
+                            si, (frames, init_mask, out_size) = todo.pop(0)
+                            if seeds is not None:
+                                torch.manual_seed(seeds[si])
+                            h, w = frames.shape[-2:]
+                            mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+                            m0 = ops.resize_planes(init_mask.float().contiguous(), (h, w), 'nearest')
+                            model('init', mk16, model('encode_value', frames[:, 0], m0, s16), init_mask)
+                            lanes[li] = [si, frames, (int(out_size[0]), int(out_size[1])), 1, []]
+                            continue
+                        si, frames, out_size, i, preds = lanes[li]
+                        g = self.graphs[li]
+                        bound = False
+                        if self.use_graph and i >= 2:
+                            if g is not None and g.frame.shape == frames[:, i].shape and g.out_size == out_size:
+                                bound = getattr(g, '_bound_to', None) == si or g.rebind()
+                            if not bound and model.swem_core.memories['update'].bases is not None:
+                                g = self.graphs[li] = FrameGraph(model, frames[:, i].shape, out_size).capture(frames[:, i])
+                                bound = True
+                            if bound:
+                                g._bound_to = si
+                        if bound:
+                            preds.append(g.run(frames[:, i]).clone())
+                        else:
+                            preds.append(frame_step(model, frames[:, i], out_size, memorize=i < frames.shape[1] - 1))
+                        lanes[li][3] = i + 1
+                        if i + 1 >= frames.shape[1]:
+                            results[si] = preds
+                            lanes[li] = None
+        for st in self.streams:
+            main.wait_stream(st)
+        return results

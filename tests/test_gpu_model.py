@@ -356,3 +356,33 @@ def test_module_level_vectors_vs_reference(lib, golden):
     assert logits_close(lg.cpu(), fx['dec_logits'])
     assert probs_close(pr.cpu(), fx['dec_prob'], fx['dec_logits'])
     assert logits_close(lg2.cpu(), fx['dec_logits_novalid'])
+
+
+def test_sequence_pool_equals_sequential_evaluation(lib):
+    """Two sequences in flight per GPU (two streams, HIP-graph replay re-bound from sequence to sequence) give the same
+    index maps as evaluating the sequences one after another with the plain loop."""
+    cfg = O.make_cfg(**CFG_A)
+    models = [H.make_model_and_sd(cfg, 5, DEV)[0] for _ in range(2)]
+    seqs, seeds = [], [11, 12, 13]
+    for k, t in enumerate((5, 4, 6)):
+        frames, m0 = synth_clip(t, 240, 432, 2, 40 + k)
+        seqs.append((frames.to(DEV), m0.to(DEV), (240, 432)))
+    ref = []
+    for (frames, m0, out), sd_ in zip(seqs, seeds):
+        torch.manual_seed(sd_)
+        with torch.no_grad():
+            preds, _ = evaluator.evaluate_davis_seq(models[0], frames, [m0] + [None] * (frames.shape[1] - 1), out)
+        ref.append([p.clone() for p in preds])
+    pool = evaluator.SequencePool(models, use_graph=True)
+    got = pool.run(seqs, seeds=seeds)
+    torch.cuda.synchronize()
+    assert pool.graphs[0] is not None
+    for r, g_ in zip(ref, got):
+        assert len(r) == len(g_)
+        for a, b in zip(r, g_):
+            assert torch.equal(a, b)
+
+
+def synth_clip(t, h, w, n, seed):
+    from swem_amd import synth
+    return synth.make_clip(t=t, h=h, w=w, n_obj=n, out_hw=(h, w), seed=seed)
