@@ -154,9 +154,14 @@ __global__ __launch_bounds__(64 * NW) void match_affinity_kernel(const float *__
   se += __shfl_xor(se, 32);
   if (h == 0) red[NW * 32 + wave * 32 + r] = se;
   __syncthreads();
-  float esum = 0.f;
+  float part4[NW / 4];   // pairwise tree, (a+b)+(c+d) per four waves: the association the 4-wave kernel always had
 #pragma unroll
-  for (int q = 0; q < NW; ++q) esum += red[NW * 32 + q * 32 + r];
+  for (int q = 0; q < NW / 4; ++q)
+    part4[q] = (red[NW * 32 + (4 * q) * 32 + r] + red[NW * 32 + (4 * q + 1) * 32 + r]) +
+               (red[NW * 32 + (4 * q + 2) * 32 + r] + red[NW * 32 + (4 * q + 3) * 32 + r]);
+  float esum = part4[0];
+#pragma unroll
+  for (int q = 1; q < NW / 4; ++q) esum += part4[q];
   const float inv = (p0 + r < P) ? 1.0f / esum : 0.f;  // padded rows are written as zeros
   if (p0 + r < Pm) {
     float *dst = pT + ((long long)n * Pm + p0 + r) * Ltot + wave * 32 * J + 4 * h;
