@@ -144,6 +144,9 @@ def main():
     ops.AUTOTUNE = not args.no_autotune and not args.load_plans   # per-layer plan chosen by timing, during warm-up only
     runners, streams = [], []
     sd = None
+    from swem_amd import evaluator
+    # streams that really overlap (two HIP streams can share a hardware queue and then serialise: evaluator.overlapping_streams)
+    seq_streams = evaluator.overlapping_streams(nseq) if nseq > 1 else [torch.cuda.current_stream()]
     for si in range(nseq):
         model = SWEM(cfg)
         if sd is None:
@@ -152,9 +155,7 @@ def main():
         model = model.eval().to(dev)
         frames_cpu, m0_cpu = synth.make_clip(t=8, h=H, w=W, n_obj=n_obj, out_hw=OUT_HW, seed=123 + rank * 16 + si)
         frames, m0 = frames_cpu.to(dev), m0_cpu.to(dev)
-        # two sequences: streams of different priority, so they are sure to sit on different hardware queues (two
-        # pool streams can share one, and then the sequences do not overlap at all: tools/em_bench.py)
-        st = torch.cuda.Stream(priority=-(si % 2) if nseq == 2 else 0) if nseq > 1 else torch.cuda.current_stream()
+        st = seq_streams[si]
         if si == 0:
             frames0_cpu, m0_0_cpu = frames_cpu, m0_cpu
         with torch.cuda.stream(st):
@@ -294,10 +295,11 @@ def main():
             a_mem, k_mem = cap['mem']
             a_mat, k_mat = cap['match']
             graphs, sts = [], []
+            em_streams = evaluator.overlapping_streams(n_streams)
             for si in range(n_streams):
                 am = [t.clone() if torch.is_tensor(t) else t for t in a_mem]
                 aq = [t.clone() if torch.is_tensor(t) else t for t in a_mat]
-                st_ = torch.cuda.Stream(priority=-(si % 2) if n_streams == 2 else 0)
+                st_ = em_streams[si]
                 st_.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st_):
                     def fn():

@@ -208,18 +208,67 @@ def run_sequences(model, sequences, meter=None):
     return results, meter
 
 
+def overlapping_streams(n, device=None, tries=12):
+    """n HIP streams that really run concurrently.  HIP multiplexes streams onto a few hardware queues, and two streams on
+    one queue execute strictly one after the other (measured: two sequences on two such streams took exactly twice the time
+    of one).  There is no query for the queue of a stream, so candidates are probed: a short chain of small kernels is
+    replayed on a pair, and a candidate is kept if the pair finishes in well under twice the single-stream time."""
+    import time
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+    buf = [torch.zeros(1 << 18, dtype=torch.float32, device=dev) for _ in range(tries + n)]
+
+    def chain(st, k):
+        g = torch.cuda.CUDAGraph()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            ops.lincomb(buf[k], 1.0)
+            st.synchronize()
+            with torch.cuda.graph(g, stream=st):
+                for _ in range(60):
+                    ops.lincomb(buf[k], 1.0)
+        return g
+
+    def run(pairs):
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for st, g in pairs:
+                with torch.cuda.stream(st):
+                    g.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best
+    chosen = []
+    first = torch.cuda.Stream()
+    chosen.append((first, chain(first, 0)))
+    t1 = run(chosen)
+    k = 1
+    while len(chosen) < n and k < tries + n:
+        cand = torch.cuda.Stream()
+        pair = (cand, chain(cand, k))
+        k += 1
+        # (measured with this probe: pairs on different queues 1.3-1.5 x the single-stream time, pairs on one queue 1.8-1.9 x)
+        if all(run([c, pair]) < 1.65 * t1 for c in chosen):
+            chosen.append(pair)
+    while len(chosen) < n:                     # no further overlapping candidate found: fall back to plain streams
+        chosen.append((torch.cuda.Stream(), None))
+    return [st for st, _ in chosen]
+
+
 class SequencePool:
     """Several sequences in flight on one GPU, each on its own stream with its own model instance (memory banks):
     sequences are independent and one sequence alone leaves the GPU under-filled (102 blocks in the
     EM kernels, ~300 short launches per frame), so a second one's kernels fill the gaps (+18..25 % frames/s, bench.py).
-    Two lanes use streams of different priority: two pool streams can share a hardware queue and then never overlap.
+    The lanes' streams are probed for real concurrency (`overlapping_streams`): two streams can share a hardware queue.
     After a sequence's first two frames (eager: they build the two banks) the steady-state frame is replayed from a HIP
     graph that is captured once per lane and re-bound to each new sequence of the same shape."""
 
     def __init__(self, models, use_graph=True):
         self.models = list(models)
         n = len(self.models)
-        self.streams = [torch.cuda.Stream(priority=-(i % 2) if n == 2 else 0) for i in range(n)]
+        self.streams = overlapping_streams(n) if n > 1 else [torch.cuda.current_stream()]
         self.graphs = [None] * n
         self.use_graph = use_graph
 
