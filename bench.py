@@ -111,7 +111,7 @@ def main():
     ap.add_argument('--save-plans', default=None, help='write the tuned per-layer plans to this JSON file')
     ap.add_argument('--load-plans', default=None, help='reuse plans from this file (no tuning; for profiler runs)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay')
-    ap.add_argument('--seqs', type=int, default=2,
+    ap.add_argument('--seqs', type=int, default=4,
                     help='independent sequences processed concurrently per GPU, each on its own HIP stream')
     ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
     args = ap.parse_args()
@@ -326,7 +326,18 @@ def main():
             tf = em_flops_per_frame(n_obj) * n_streams * reps / best / 1e12
             return {'sequences': n_streams, 'us_per_round': round(1e6 * best / reps, 1), 'achieved': round(tf, 2),
                     'frac': round(tf / FP32_MATRIX_PEAK_TFLOPS, 4)}
-        out['em_matching']['concurrent'] = [em_concurrent(n) for n in sorted({nseq, 4})]
+        conc = [em_concurrent(n) for n in sorted({2, nseq, 4}) if n > 1]
+        em = out['em_matching']
+        em['concurrent'] = conc
+        mine = [c for c in conc if c['sequences'] == nseq]
+        if mine:       # the number for THIS run's configuration first; the single-sequence figure stays as `isolated`
+            em['isolated'] = {'ms_per_frame': em['ms_per_frame'], 'achieved': em['achieved'], 'frac': em['frac']}
+            em['achieved'], em['frac'] = mine[0]['achieved'], mine[0]['frac']
+            em['ms_per_frame'] = round(mine[0]['us_per_round'] / nseq / 1e3, 3)
+            em['note'] = ('memorize + match of the %d sequences this configuration keeps in flight per GPU, one HIP graph per '
+                          'stream replayed together (device time per frame = round time / sequences); `isolated` = one '
+                          'sequence alone (20 back-to-back calls on one frame\'s real arguments); algorithmic FLOPs '
+                          '4PL(C(3T-1)+V) + 4LmP(C+V) per object' % nseq)
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(frames_cpu, m0_cpu, sd)
     if rank == 0:
