@@ -114,6 +114,7 @@ def main():
     ap.add_argument('--seqs', type=int, default=4,
                     help='independent sequences processed concurrently per GPU, each on its own HIP stream')
     ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
+    ap.add_argument('--max-split', type=int, default=0, help='cap the K-split factors the conv tuner may choose (0 = all)')
     args = ap.parse_args()
 
     from swem_amd import dist as sdist
@@ -142,6 +143,8 @@ def main():
     if args.load_plans:
         ops.load_plans(args.load_plans)
     ops.AUTOTUNE = not args.no_autotune and not args.load_plans   # per-layer plan chosen by timing, during warm-up only
+    if args.max_split:
+        ops._TUNE_SPLITS = tuple(v for v in ops._TUNE_SPLITS if v <= args.max_split)
     runners, streams = [], []
     sd = None
     from swem_amd import evaluator
