@@ -31,7 +31,20 @@ def ensure_grads(params):
             p.grad = torch.zeros_like(p)
 
 
+_LANE = 0          # clips of a batch may run on several streams at once (train.py): each lane accumulates into its own
+_LANE_GRADS = None  # gradient buffer ({id(param): tensor view}), and packs its own copies of the filters
+
+
+def use_lane(lane, grads=None):
+    """Route the in-kernel parameter-gradient accumulation of the following backward calls to `grads` ({id(param):
+    view of that lane's flat buffer}); None = the parameters' own .grad."""
+    global _LANE, _LANE_GRADS
+    _LANE, _LANE_GRADS = lane, grads
+
+
 def _grad(p):
+    if _LANE_GRADS is not None:
+        return _LANE_GRADS[id(p)]
     if p.grad is None:
         p.grad = torch.zeros_like(p)
     if not p.grad.is_contiguous():
@@ -64,7 +77,7 @@ def sum_batch(x, out=None, accumulate=False):
 
 # --------------------------------------------------------------------------------------------- convolution
 def _fwd_pack(weight, bias, stride, pad, cin_pad):
-    key = (id(weight), 'fwd', cin_pad)
+    key = (id(weight), 'fwd', cin_pad, _LANE)
     pk = _PACKS.get(key)
     if pk is None:
         pk = _PACKS[key] = ops.pack_conv(weight, bias, None, stride, pad, cin_pad=cin_pad)
@@ -73,7 +86,7 @@ def _fwd_pack(weight, bias, stride, pad, cin_pad):
 
 def _dgrad_pack(weight, off, c, stride, pad, cin_pad):
     """Filters of the data-gradient GEMM for the source that owns input channels [off, off+c): [c][KH][KW][Cout]."""
-    key = (id(weight), 'dgrad', off, c, cin_pad)
+    key = (id(weight), 'dgrad', off, c, cin_pad, _LANE)
     pk = _PACKS.get(key)
     if pk is None:
         co, ci, kh, kw = weight.shape
@@ -326,7 +339,7 @@ class _PredHead(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        key = (id(weight), 'pred')
+        key = (id(weight), 'pred', _LANE)
         w = _PACKS.get(key)
         if w is None:
             w = _PACKS[key] = weight.detach().permute(0, 2, 3, 1).contiguous()   # [1][3][3][C]

@@ -10,10 +10,10 @@ Data parallel: every rank steps its own clips; one bucketed all-reduce of the fl
 optimizer step, the 1/world factor is folded into the loss gradient.  The reference scales the learning rate by the
 number of GPUs only if asked (solver.py:31-34, ``num_gpu``), so does ``SWEMTrainer(num_gpu=...)``.
 
-How the batch is run: clips are independent (frozen BatchNorm, per-clip memory), so the step walks the B clips one
-after another -- forward, per-clip loss with weight 1/B, backward -- and the parameter gradients add up in the flat
-gradient buffer.  That equals the reference's batched step (``total = mean_b``) and frees a clip's activations before
-the next one starts.  Mixed precision (config.AMP) is not built: the step runs in fp32 (bf16x6 / fp32 MFMA).
+How the batch is run: clips are independent (frozen BatchNorm, per-clip memory), so every clip is its own forward /
+per-clip loss with weight 1/B / backward.  Up to ``lanes`` clips are in flight at once, each on its own stream with its
+own flat gradient buffer (the in-kernel accumulation is a plain read-modify-write); the lanes' buffers are summed into
+the optimizer's.  That equals the reference's batched step (``total = mean_b``).  Mixed precision (config.AMP) is not built: the step runs in fp32 (bf16x6 / fp32 MFMA).
 """
 import math
 
@@ -149,7 +149,7 @@ def random_init_host(B, N, Cc, Lb):
 class SWEMTrainer:
     """swem_trainer.py:19-108 without the dataset / logging plumbing: model, criterion, optimizer, scheduler, one_step."""
 
-    def __init__(self, config, model, num_gpu=None, use_graph=True):
+    def __init__(self, config, model, num_gpu=None, use_graph=True, lanes=4):
         self.config = config
         self.model = model
         if _get(config, 'AMP'):
@@ -165,6 +165,8 @@ class SWEMTrainer:
         self.graph = TrainGraph(model)
         self.device = dev
         self.use_graph = use_graph
+        self.lanes = max(1, int(lanes))      # clips of a batch in flight at once, each on its own stream
+        self._lane_state = None
 
     def clip_forward(self, frames, init_mask, valid_obj, prior0):
         """swem_trainer.py:63-90 for one clip: frames (1,T,3,H,W), init_mask (1,N+1,H,W), valid_obj (1,N+1)."""
@@ -212,24 +214,63 @@ class SWEMTrainer:
             self._static_key, self._graph, self._eager_steps = key, None, 0
         return self.buf
 
+    def _lanes(self, B):
+        """Streams, per-lane flat gradient buffers and loss accumulators for the clips in flight.  A clip's ~3000 launches are
+        short and dependent, so a second clip's kernels fill the gaps; the in-kernel gradient accumulation is a plain
+        read-modify-write, hence one gradient buffer per lane, summed into the optimizer's buffer at the end."""
+        n = min(self.lanes, B)
+        if self._lane_state is None or len(self._lane_state['streams']) != n:
+            from . import evaluator
+            opt = self.optimizer
+            flat = torch.zeros((n, opt.grad.numel()), dtype=torch.float32, device=self.device)
+            views = []
+            for l in range(n):
+                d = {}
+                for prm in opt.params:
+                    off = prm.grad.data_ptr() - opt.grad.data_ptr()
+                    d[id(prm)] = flat[l, off // 4: off // 4 + prm.numel()].view(prm.shape)
+                views.append(d)
+            self._lane_state = {'streams': evaluator.overlapping_streams(n) if n > 1 else [None], 'flat': flat,
+                                'views': views, 'sums': torch.zeros((n, 3), dtype=torch.float32, device=self.device)}
+        return self._lane_state
+
     def _clips(self, cur_iter):
         """zero_grad + forward / loss / backward of every clip on the static buffers; returns (results, p)."""
         bf = self.buf
         B = bf['frames'].shape[0]
-        self.optimizer.zero_grad()
+        ls = self._lanes(B)
+        n = len(ls['streams'])
         A.new_step()
-        bf['sums'].zero_()
-        results, p = [], 1.0
+        ls['flat'].zero_()
+        ls['sums'].zero_()
+        main = torch.cuda.current_stream()
+        results, p = [None] * B, 1.0
+        for st in ls['streams']:
+            if st is not None:
+                st.wait_stream(main)                                   # fork (also inside a graph capture)
         for b in range(B):
-            vo = None if bf['valid'] is None else bf['valid'][b:b + 1]
-            prior = {'kappa': bf['kappa0'][b], 'nu': bf['nu0'], 'zita': bf['zita0']}
-            logits_list, res = self.clip_forward(bf['frames'][b:b + 1], bf['init_mask'][b:b + 1], vo, prior)
-            out = self.criterion.clip_loss(logits_list, bf['label'][b:b + 1, 1:], cur_iter, vo, k_dev=bf['k'])
-            vec = out['_vec']                                          # (total, main, aux) of this clip
-            vec.backward(bf['gout'])
-            bf['sums'].copy_(ops.lincomb(bf['sums'], 1.0, vec.detach(), 1.0 / B))
-            results.append(torch.stack(res, dim=1))                    # (1, T-1, H, W)
-            p = out['p']
+            l = b % n
+            st = ls['streams'][l]
+            with torch.cuda.stream(st if st is not None else main):
+                A.use_lane(l, ls['views'][l])
+                vo = None if bf['valid'] is None else bf['valid'][b:b + 1]
+                prior = {'kappa': bf['kappa0'][b], 'nu': bf['nu0'], 'zita': bf['zita0']}
+                logits_list, res = self.clip_forward(bf['frames'][b:b + 1], bf['init_mask'][b:b + 1], vo, prior)
+                out = self.criterion.clip_loss(logits_list, bf['label'][b:b + 1, 1:], cur_iter, vo, k_dev=bf['k'])
+                vec = out['_vec']                                      # (total, main, aux) of this clip
+                vec.backward(bf['gout'])
+                ls['sums'][l].copy_(ops.lincomb(ls['sums'][l], 1.0, vec.detach(), 1.0 / B))
+                results[b] = torch.stack(res, dim=1)                   # (1, T-1, H, W)
+                p = out['p']
+        A.use_lane(0, None)
+        for st in ls['streams']:
+            if st is not None:
+                main.wait_stream(st)                                   # join
+        A.sum_batch(ls['flat'], out=self.optimizer.grad.view(1, -1))   # lanes' gradients -> the optimizer's buffer
+        tot = ls['sums'][0]
+        for l in range(1, n):
+            tot = ops.lincomb(tot, 1.0, ls['sums'][l], 1.0)
+        bf['sums'].copy_(tot)
         return torch.cat(results, dim=0), p
 
     def one_step(self, frames, init_mask, valid_obj, label, cur_iter):
