@@ -804,7 +804,8 @@ extern "C" int swem_cbam_f32(void *stream, const float *x, const float *w1, cons
   float *sg = comp + (size_t)B * P * 2;
   hipLaunchKernelGGL(cbam_pool_partial_kernel, dim3(CBAM_CHUNKS, B), dim3(256), 0, ST, x, part, P, C);
   SWEM_CHECK_LAUNCH("cbam_pool_partial");
-  hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(256), (2 * C + 2 * hid) * sizeof(float), ST, part, w1, b1, w2, b2,
+  // one block per batch item, 16 waves: the 2*hid hidden units are a wave each (4 waves took 48 us for this tiny MLP)
+  hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(1024), (2 * C + 2 * hid) * sizeof(float), ST, part, w1, b1, w2, b2,
                      cscale, P, C, hid);
   SWEM_CHECK_LAUNCH("cbam_mlp");
   hipLaunchKernelGGL(cbam_spatial_pool_kernel, grid1((long long)B * P * 64), dim3(256), 0, ST, x, cscale, comp, B, P,
