@@ -1282,13 +1282,14 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 // x [npix][C] fp32 -> three bf16 planes [C/8][npix][8] with x = hi + mid + lo (optionally of relu(x)).
-// One thread per (channel group, pixel), pixel fastest: every store is a coalesced 16-byte chunk of the plane.
-__global__ void split_bf16x3_kernel(const float *__restrict__ x, unsigned short *__restrict__ out, long long npix, int C,
-                                    int relu) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = npix * (C / 8);
-  if (i >= total) return;
-  const long long cg = i / npix, pix = i - cg * npix;
+// Block = 32 pixels x 8 channel groups; thread (pixel p, group g) = (tid / 8, tid % 8): the 8 threads of a pixel read 256
+// contiguous bytes of its row (full cache lines; with the pixel on the fast thread index every thread read 32 bytes of
+// its own line), and per channel group 8 consecutive pixels store one 128-byte run of every plane.
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ x, unsigned short *__restrict__ out,
+                                                           long long npix, int C, int relu) {
+  const long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int cg = blockIdx.y * 8 + (threadIdx.x & 7);
+  if (pix >= npix || cg >= C / 8) return;
   const float *src = x + pix * C + cg * 8;
   float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 4);
   if (relu) {
@@ -1298,7 +1299,7 @@ __global__ void split_bf16x3_kernel(const float *__restrict__ x, unsigned short 
   uint2 h0, m0, l0, h1, m1, l1;
   split3(v0, h0, m0, l0);
   split3(v1, h1, m1, l1);
-  const long long plane = npix * C;
+  const long long plane = npix * C, i = (long long)cg * npix + pix;
   *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
   *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
   *reinterpret_cast<uint4 *>(out + 2 * plane + i * 8) = make_uint4(l0.x, l0.y, l1.x, l1.y);
@@ -1307,7 +1308,7 @@ __global__ void split_bf16x3_kernel(const float *__restrict__ x, unsigned short 
 
 extern "C" int swem_split_bf16x3_f32(void *stream, const float *x, void *out, long long npix, int C, int relu) {
   SWEM_REQUIRE(x && out && npix > 0 && C > 0 && C % 8 == 0, SWEM_E_ARG, "split_bf16x3: need C %% 8 == 0");
-  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)cdiv(npix * (C / 8), 256)), dim3(256), 0,
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)cdiv(npix, 32), (unsigned)cdiv(C / 8, 8)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, static_cast<unsigned short *>(out), npix, C, relu);
   SWEM_CHECK_LAUNCH("split_bf16x3");
   return SWEM_OK;
