@@ -130,7 +130,7 @@ int swem_memorize_train_f32(void *stream, const float *x, const float *v, const 
 size_t swem_nu_update_bwd_workspace(int N, int V, int P, int L);
 int swem_nu_update_bwd_f32(void *stream, const float *zT, const float *zita_prev, const float *zita, const float *dnu,
                            float *dv, float *dnu_prev, int N, int V, int P, int L, void *ws, size_t ws_bytes);
-/* backward of swem_match_f32 for the N <= 3 objects of one clip: dmem [N][Pm][V] and dS [N][P][2*topl] (dS may be NULL)
+/* backward of swem_match_f32 for the N <= 7 objects of one clip: dmem [N][Pm][V] and dS [N][P][2*topl] (dS may be NULL)
  * -> dqk [P][C] (summed over objects; through the query's l2norm), dnu_first / dnu_update [N][2][V][L].
  * Ties among the top-l values take the gradient jointly (measure zero). */
 size_t swem_match_bwd_workspace(int N, int C, int V, int P, int L, int nbanks);

@@ -399,11 +399,11 @@ MatchBwdWs match_bwd_ws(int N, int C, int V, int P, int L, int nbanks) {
   w.fwd = take(match_ws(N, C, V, P, L, nbanks, 0).total);
   w.mvpT = take((size_t)N * Ltot * V * 4);
   w.dP = take((size_t)N * Pm * Ltot * 4);
-  w.mknT = take((size_t)C * N * Ltot * 4);
+  w.mknT = take((size_t)2 * C * N * Ltot * 4);   // + room for one group's packed filters when N > 3
   w.dmvp = take((size_t)N * V * Ltot * 4);
   w.dqn = take((size_t)Pm * C * 4);
   size_t c1 = swem_conv2d_workspace(N, Pm, 1, V, (int)Ltot, 1, 1, 1, 0, 0, 0);
-  size_t c2 = swem_conv2d_workspace(1, Pm, 1, (int)(N * Ltot), C, 1, 1, 1, 0, 0, 0);
+  size_t c2 = swem_conv2d_workspace(1, Pm, 1, (int)((N < 3 ? N : 3) * Ltot), C, 1, 1, 1, 0, 0, 0);
   w.conv = take(c1 > c2 ? c1 : c2);
   w.wgrad = take(swem_conv2d_wgrad_workspace(1, Pm, 1, (int)Ltot, 0, 0, V, 1, 1, 1, 0));
   w.total = o;
@@ -479,7 +479,7 @@ extern "C" int swem_match_bwd_f32(void *stream, const float *qk, const float *ka
   SWEM_REQUIRE(qk && kappa_first && nu_first && dmem && dqk && dnu_first, SWEM_E_ARG, "match_bwd: null pointer");
   SWEM_REQUIRE((kappa_update == nullptr) == (nu_update == nullptr) && (nu_update == nullptr) == (dnu_update == nullptr),
                SWEM_E_ARG, "match_bwd: update bank half given");
-  SWEM_REQUIRE(N >= 1 && N <= 3, SWEM_E_SHAPE, "match_bwd: 1..3 objects per clip (got %d)", N);
+  SWEM_REQUIRE(N >= 1 && N <= 7, SWEM_E_SHAPE, "match_bwd: 1..7 objects per clip (got %d)", N);
   const int nbanks = kappa_update ? 2 : 1;
   const int Lm = nbanks * L, Ltot = 2 * Lm, Pm = swem_match_pad(P);
   MatchBwdWs w = match_bwd_ws(N, C, V, P, L, nbanks);
@@ -529,11 +529,26 @@ extern "C" int swem_match_bwd_f32(void *stream, const float *qk, const float *ka
   // (4) d qn = sum_n da[n] . mkn[n]: one GEMM with the objects as concatenated sources (filters [C][N*Ltot])
   hipLaunchKernelGGL(kn_cmajor_kernel, dim3(cdiv((long long)C * N * Ltot, 256)), dim3(256), 0, ST, mkn, mknT, N, C, Lm);
   SWEM_CHECK_LAUNCH("kn_cmajor");
-  const float *d0 = dP, *d1 = N > 1 ? dP + (long long)Pm * Ltot : nullptr, *d2 = N > 2 ? dP + 2ll * Pm * Ltot : nullptr;
-  if ((rc = swem_conv2d_nhwc_f32(stream, d0, Ltot, 0, d1, N > 1 ? Ltot : 0, 0, d2, N > 2 ? Ltot : 0, 0, 1, Pm, 1, mknT,
-                                 0, nullptr, nullptr, nullptr, 0, dqn, C, 1, 1, 1, 0, 0, 0, base + w.conv,
-                                 w.wgrad - w.conv)))
-    return rc;
+  // (the conv kernel concatenates up to three sources: objects go in groups of three, later groups add onto the result)
+  for (int n0 = 0; n0 < N; n0 += 3) {
+    const int g = N - n0 < 3 ? N - n0 : 3;
+    const float *d0 = dP + (long long)n0 * Pm * Ltot, *d1 = g > 1 ? d0 + (long long)Pm * Ltot : nullptr,
+                *d2 = g > 2 ? d0 + 2ll * Pm * Ltot : nullptr;
+    // filters of this group: columns [n0*Ltot, (n0+g)*Ltot) of every row of mknT -> packed [C][g*Ltot]
+    float *wg = mknT;
+    if (N > 3) {
+      wg = mknT + (long long)C * N * Ltot;   // second half of the slot (sized for it below)
+      if (hipMemcpy2DAsync(wg, (size_t)g * Ltot * 4, mknT + (long long)n0 * Ltot, (size_t)N * Ltot * 4, (size_t)g * Ltot * 4, C,
+                           hipMemcpyDeviceToDevice, ST) != hipSuccess) {
+        swem_set_error("match_bwd: copy failed");
+        return SWEM_E_HIP;
+      }
+    }
+    if ((rc = swem_conv2d_nhwc_f32(stream, d0, Ltot, 0, d1, g > 1 ? Ltot : 0, 0, d2, g > 2 ? Ltot : 0, 0, 1, Pm, 1, wg, 0,
+                                   nullptr, nullptr, n0 ? dqn : nullptr, 0, dqn, C, 1, 1, 1, 0, 0, 0, base + w.conv,
+                                   w.wgrad - w.conv)))
+      return rc;
+  }
   // (5) through the query's l2norm
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(P, 4)), dim3(256), 0, ST, qk, dqn, dqk, P, C);
   SWEM_CHECK_LAUNCH("l2norm_bwd");

@@ -299,13 +299,13 @@ def test_heads_backward(lib):
     close(hm.grad.cpu(), masks.grad, 1e-6, 'd masks')
 
 
-@pytest.mark.parametrize('L,banks,topl', [(64, 1, 32), (64, 2, 64), (128, 2, 64)])
-def test_match_backward(lib, L, banks, topl):
+@pytest.mark.parametrize('L,banks,topl,N', [(64, 1, 32, 2), (64, 2, 64, 2), (128, 2, 64, 2), (64, 2, 32, 5)])
+def test_match_backward(lib, L, banks, topl, N):
     """get_affinity + perm_inv_feat: d qk (through the l2norm, the joint softmax and the top-l prefix features) and
     d nu for both banks, against the oracle under autograd."""
     from swem_amd import autograd as A
     g = torch.Generator().manual_seed(12 + L + banks)
-    N, Cc, V, h, w = 2, 128, 64, 6, 9
+    Cc, V, h, w = 128, 64, 6, 9
     P = h * w
     xk, _ = H.structured_keys(P, Cc, 5, g)
     qk = leaf(xk.t().reshape(1, Cc, h, w).contiguous())
@@ -473,3 +473,27 @@ def test_one_step_single_object_vs_oracle(lib):
                   for k, g in ref_g.items() if g is not None)
     assert rels[len(rels) // 2] < 1e-3 and rels[int(len(rels) * 0.9)] < 2e-2, (rels[len(rels) // 2], rels[-5:])
     assert params['value_encoder.conv1.weight'].shape[1] == 4
+
+
+def test_one_step_five_objects_vs_oracle(lib):
+    """YouTube-VOS main-training style step: five object slots, two of them invalid in this clip (valid_obj), against the
+    oracle's autograd run in the test."""
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    cfg = O.make_cfg(BACKBONE='resnet18', NUM_BASES=64, TOPL=32, NUM_EM_ITERS=4)
+    model, sd = H.make_model_and_sd(cfg, 8, DEV, pred_scale=tc['pred_scale'])
+    case = dict(b=1, t=3, hw=(128, 160), n=5, seed=91, valid=[[1, 1, 1, 1, 0, 0]])
+    frames, init_mask, label, valid = H.train_batch(case)
+    torch.manual_seed(19)
+    ref_l, ref_res, ref_g, _ = O.train_one_step(H.trainable_sd(sd, model), cfg, frames, init_mask, valid, label, 45,
+                                                tc['loss_cfg'])
+    tr = SWEMTrainer(dict(SOLVER=tc['solver_cfg'], LOSS=tc['loss_cfg'], AMP=False), model, use_graph=False)
+    torch.manual_seed(19)
+    losses, results = tr.one_step(frames.to(DEV), init_mask.to(DEV), valid.to(DEV), label.to(DEV), 45)
+    assert float(losses['total_loss'].detach()) == pytest.approx(float(ref_l['total_loss'].detach()), rel=5e-4)
+    # (the shrunken prediction head leaves the five slots' probabilities nearly equal: the argmax itself is noise-level)
+    assert float((results.cpu() == ref_res).float().mean()) > 0.97
+    params = dict(model.named_parameters())
+    rels = sorted(abs(float(params[k].grad.double().norm()) - float(g.double().norm())) / (float(g.double().norm()) + 1e-12)
+                  for k, g in ref_g.items() if g is not None)
+    assert rels[len(rels) // 2] < 2e-3 and rels[int(len(rels) * 0.9)] < 5e-2, (rels[len(rels) // 2], rels[-5:])
