@@ -226,10 +226,10 @@ def main():
             runner.step()
         torch.cuda.synchronize()
         tr, ops.CONV_TRACE = ops.CONV_TRACE, None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in tr)
+        ms = sum(t_[0].elapsed_time(t_[1]) for t_ in tr)
         if args.conv_report:
             agg = {}
-            for e0, e1, f, d in tr:
+            for e0, e1, f, d, _ in tr:
                 a = agg.setdefault(d, [0, 0.0, 0.0])
                 a[0] += 1
                 a[1] += e0.elapsed_time(e1)
@@ -239,7 +239,8 @@ def main():
             for d, (c, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print('%-34s %5.1f %9.1f %9.3f %8.1f' % (d, c / nprof, 1e3 * t / c, t / nprof, f / (t * 1e-3) / 1e12),
                       file=sys.stderr)
-        flops = sum(f for _, _, f, _ in tr)
+        flops = sum(t_[2] for t_ in tr)
+        alg_bytes = sum(t_[4] for t_ in tr) / len(tr)
         ach = flops / (ms * 1e-3) / 1e12
         traffic, tnote = None, ''
         try:
@@ -253,12 +254,12 @@ def main():
         out['roofline'] = {
             'bound': 'mfma', 'kernel': 'implicit-GEMM conv family: conv_igemm_bf3s (bf16x6, pre-split, LDS-DMA) / conv_igemm_pipe (fp32 MFMA) / stems, + operand split and split-K reduce kernels', 'achieved': round(ach, 2),
             'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
-            'traffic': traffic, 'launches_per_frame': len(tr) // nprof,
+            'traffic': traffic, 'algorithmic_bytes_per_launch': int(alg_bytes), 'launches_per_frame': len(tr) // nprof,
             'avg_launch_us': round(1e3 * ms / len(tr), 2), 'gflop_per_launch': round(flops / len(tr) / 1e9, 3),
             'conv_ms_per_frame': round(ms / nprof, 3),
             'note': 'useful conv FLOPs (2*M*Cout*KH*KW*Cin, unpadded) of %d frames / summed per-launch HIP-event '
                     'durations (operand-split and split-K reduce launches included); peak = fp32 matrix rate (the arithmetic is fp32-accurate); '
-                    'layers the tuner runs in bf16x6 mode execute 6 bf16-MFMA products per fp32 product, their own ceiling is 2500/6 = 417 TFLOP/s' % nprof + tnote,
+                    'layers the tuner runs in bf16x6 mode execute 6 bf16-MFMA products per fp32 product, their own ceiling is 2500/6 = 417 TFLOP/s; algorithmic bytes = every input map once + filters + output in fp32, the measured traffic adds the bf16x3 planes (1.5x an fp32 map, written by the split and read by the conv) and the Infinity-Cache-served halo re-reads that FETCH_SIZE counts' % nprof + tnote,
             'plans_bf16x6': sum(1 for v in ops._CONV_PLANS.values() if (v >> 16) & 1), 'plans_total': len(ops._CONV_PLANS)}
         # EM / matching: capture the arguments of one real memorize + match call, then time 20 back-to-back
         # repetitions of each with HIP events (queue kept full, so this is device time, not host launch time)

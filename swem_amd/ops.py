@@ -219,8 +219,11 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     if CONV_TRACE is not None:
         e1.record()
         ncols = pack.cout * (2 if pack.glu else 1)
+        # (events, useful FLOPs, label, algorithmic bytes: every input map once + filters + output, fp32)
+        in_bytes = 4.0 * sum(s_.shape[0] * H * W * s_.shape[3] for s_ in srcs)
         CONV_TRACE.append((e0, e1, 2.0 * B * Ho * Wo * ncols * pack.kh * pack.kw * pack.cin_true,
-                           '%dx%dx%d k%d s%d %d->%d' % (B, H, W, pack.kh, pack.stride, pack.cin_true, ncols)))
+                           '%dx%dx%d k%d s%d %d->%d' % (B, H, W, pack.kh, pack.stride, pack.cin_true, ncols),
+                           in_bytes + 4.0 * ncols * pack.kh * pack.kw * pack.cin_true + 4.0 * B * Ho * Wo * pack.cout))
     return y
 
 
