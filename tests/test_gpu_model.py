@@ -363,10 +363,12 @@ def test_sequence_pool_equals_sequential_evaluation(lib):
     index maps as evaluating the sequences one after another with the plain loop."""
     cfg = O.make_cfg(**CFG_A)
     models = [H.make_model_and_sd(cfg, 5, DEV)[0] for _ in range(2)]
-    seqs, seeds = [], [11, 12, 13]
-    for k, t in enumerate((5, 4, 6)):
-        frames, m0 = synth_clip(t, 240, 432, 2, 40 + k)
-        seqs.append((frames.to(DEV), m0.to(DEV), (240, 432)))
+    seqs, seeds = [], [11, 12, 13, 14, 15]
+    # same shape three times (the lane's graph is re-bound), then one object (re-captured), then another frame size
+    for k, (t, hh, ww, n) in enumerate(((5, 240, 432, 2), (4, 240, 432, 2), (6, 240, 432, 2), (5, 240, 432, 1),
+                                        (4, 192, 320, 2))):
+        frames, m0 = synth_clip(t, hh, ww, n, 40 + k)
+        seqs.append((frames.to(DEV), m0.to(DEV), (hh, ww)))
     ref = []
     for (frames, m0, out), sd_ in zip(seqs, seeds):
         torch.manual_seed(sd_)
