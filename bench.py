@@ -114,6 +114,7 @@ def main():
     ap.add_argument('--seqs', type=int, default=4,
                     help='independent sequences processed concurrently per GPU, each on its own HIP stream')
     ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
+    ap.add_argument('--no-em', action='store_true', help='skip the EM/matching timing legs (profiler runs)')
     ap.add_argument('--max-split', type=int, default=0, help='cap the K-split factors the conv tuner may choose (0 = all)')
     args = ap.parse_args()
 
@@ -261,6 +262,13 @@ def main():
                     'durations (operand-split and split-K reduce launches included); peak = fp32 matrix rate (the arithmetic is fp32-accurate); '
                     'layers the tuner runs in bf16x6 mode execute 6 bf16-MFMA products per fp32 product, their own ceiling is 2500/6 = 417 TFLOP/s; algorithmic bytes = every input map once + filters + output in fp32, the measured traffic adds the bf16x3 planes (1.5x an fp32 map, written by the split and read by the conv) and the Infinity-Cache-served halo re-reads that FETCH_SIZE counts' % nprof + tnote,
             'plans_bf16x6': sum(1 for v in ops._CONV_PLANS.values() if (v >> 16) & 1), 'plans_total': len(ops._CONV_PLANS)}
+        if args.no_em:
+            if not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline(frames_cpu, m0_cpu, sd)
+            print(json.dumps(out))
+            if torch.distributed.is_initialized():
+                torch.distributed.destroy_process_group()
+            return
         # EM / matching: capture the arguments of one real memorize + match call, then time 20 back-to-back
         # repetitions of each with HIP events (queue kept full, so this is device time, not host launch time)
         orig_mem, orig_match = ops.memorize, ops.match
