@@ -231,7 +231,7 @@ def overlapping_streams(n, device=None, tries=12):
     def run(pairs):
         torch.cuda.synchronize()
         best = None
-        for _ in range(3):
+        for _ in range(5):                           # best of five: the host may be busy (eight ranks share it)
             t0 = time.perf_counter()
             for st, g in pairs:
                 with torch.cuda.stream(st):
