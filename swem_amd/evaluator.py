@@ -151,7 +151,7 @@ class FrameGraph:
         with torch.no_grad():
             # one eager pass on a side stream (also sizes every workspace), then restore the state it consumed
             saved = {k: v.clone() for k, v in self.state.items()}
-            s = torch.cuda.Stream()
+            s = ops.new_stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 frame_step(self.model, self.frame, self.out_size)
@@ -161,7 +161,7 @@ class FrameGraph:
             core.memories['update'].bases = self.state
             # capture on a stream of this graph's own: scratch buffers are per stream (ops.workspace), and graphs that are
             # replayed concurrently must not share one (torch's default capture stream is one object for all captures)
-            self.capture_stream = torch.cuda.Stream()
+            self.capture_stream = ops.new_stream()
             with torch.cuda.graph(self.graph, stream=self.capture_stream):
                 self.pred = frame_step(self.model, self.frame, self.out_size)
                 new = core.memories['update'].bases
@@ -241,19 +241,19 @@ def overlapping_streams(n, device=None, tries=12):
             best = dt if best is None else min(best, dt)
         return best
     chosen = []
-    first = torch.cuda.Stream()
+    first = ops.new_stream()
     chosen.append((first, chain(first, 0)))
     t1 = run(chosen)
     k = 1
     while len(chosen) < n and k < tries + n:
-        cand = torch.cuda.Stream()
+        cand = ops.new_stream()
         pair = (cand, chain(cand, k))
         k += 1
         # (measured with this probe: pairs on different queues 1.3-1.5 x the single-stream time, pairs on one queue 1.8-1.9 x)
         if all(run([c, pair]) < 1.65 * t1 for c in chosen):
             chosen.append(pair)
     while len(chosen) < n:                     # no further overlapping candidate found: fall back to plain streams
-        chosen.append((torch.cuda.Stream(), None))
+        chosen.append((ops.new_stream(), None))
     return [st for st, _ in chosen]
 
 

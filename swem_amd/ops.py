@@ -29,6 +29,26 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_hip = None
+
+
+def new_stream():
+    """A HIP stream of its own.  torch.cuda.Stream() hands out 32 pooled streams round robin, so the 33rd request is the
+    first stream again; scratch buffers are keyed by stream (workspace()) and captured graphs own theirs, so an aliased
+    stream would let two concurrent users share one.  hipStreamCreateWithFlags + ExternalStream has no such limit."""
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL('libamdhip64.so')
+        _hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        _hip.hipStreamCreateWithFlags.restype = C.c_int
+    h = C.c_void_p()
+    torch.cuda.current_device()                      # the HIP context of the current device exists
+    rc = _hip.hipStreamCreateWithFlags(C.byref(h), 1)   # hipStreamNonBlocking
+    if rc != 0 or not h.value:
+        raise _lib.SwemHipError('hipStreamCreateWithFlags failed (%d)' % rc)
+    return torch.cuda.ExternalStream(h.value)
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
