@@ -102,7 +102,8 @@ int swem_split_bf16x3_f32(void *stream, const float *x, void *out, long long npi
  * Every fragment goes HBM/L2 -> LDS by buffer-load-to-LDS (no register staging, no vector arithmetic in the k-loop).
  * Output, scale/shift/residual/ReLU-out/GLU, plan and workspace as swem_conv2d_nhwc_f32 (math bit ignored).
  * Plan bits 20-23 pick a kernel variant: 0 = the tile's default LDS ring (three stages for 64x64, two otherwise),
- * 1 = the other stage count, 2 / 3 = the 128x128 tile on eight waves with two / three stages. */
+ * 1 = the other stage count, 2 / 3 = the 128x128 tile on eight waves with two / three stages, 4 / 6 = variants 0 / 2 on
+ * v_mfma_f32_16x16x32_bf16 instead of 32x32x16; bits 24-27 = K-split factor of the last, partly filled round of tiles. */
 int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1, int c1,
                             long long bs1, long long ps1, const void *x2, int c2, long long bs2, long long ps2, int B,
                             int H, int W, const void *w_bf16x3, const float *scale, const float *shift,

@@ -285,8 +285,10 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
                 if math == 1:                      # pre-split kernel variants: other stage count, 8-wave 128x128 tile
                     base = wm | wn << 4 | ns << 8 | math << 16
                     cands.append(base | 1 << 20)
+                    cands.append(base | 4 << 20)              # 16x16x32 MFMA shape
                     if wm == 2 and wn == 2:
                         cands.append(base | 2 << 20)
+                        cands.append(base | 6 << 20)
                     if ns == 1 and blocks > 256 and nkb >= 16:   # tail split: the last, partly filled round over K
                         for ts in (4, 8):
                             cands.append(base | ts << 24)

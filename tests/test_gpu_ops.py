@@ -218,7 +218,8 @@ def test_bicubic_flip_lincomb_inject(lib):
 
 
 @pytest.mark.parametrize('plan', [0x00011, 0x00021, 0x00022, 0x00211, 0x10011, 0x10021, 0x10022, 0x10321,
-                                  0x110011, 0x110021, 0x110022, 0x210022, 0x310022, 0x210222],
+                                  0x110011, 0x110021, 0x110022, 0x210022, 0x310022, 0x210222,
+                                  0x410011, 0x410021, 0x410022, 0x610022, 0x410221],
                          ids=lambda p: 'math%d_wm%d_wn%d_ns%d' % (p >> 16, p & 15, (p >> 4) & 15, (p >> 8) & 255))
 def test_conv2d_plans_and_math_modes(lib, plan):
     """Every tiling / K-split / math mode of the fast conv kernel gives the same convolution: fp32 MFMA and the
