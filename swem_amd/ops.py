@@ -38,7 +38,16 @@ def new_stream():
     stream would let two concurrent users share one.  hipStreamCreateWithFlags + ExternalStream has no such limit."""
     global _hip
     if _hip is None:
-        _hip = C.CDLL('libamdhip64.so')
+        path = 'libamdhip64.so'
+        try:                                          # the very runtime instance torch itself has mapped
+            with open('/proc/self/maps') as f:
+                for line in f:
+                    if 'libamdhip64' in line:
+                        path = line.split()[-1]
+                        break
+        except OSError:
+            pass
+        _hip = C.CDLL(path)
         _hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
         _hip.hipStreamCreateWithFlags.restype = C.c_int
     h = C.c_void_p()
