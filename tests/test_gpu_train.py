@@ -497,3 +497,24 @@ def test_one_step_five_objects_vs_oracle(lib):
     rels = sorted(abs(float(params[k].grad.double().norm()) - float(g.double().norm())) / (float(g.double().norm()) + 1e-12)
                   for k, g in ref_g.items() if g is not None)
     assert rels[len(rels) // 2] < 2e-3 and rels[int(len(rels) * 0.9)] < 5e-2, (rels[len(rels) // 2], rels[-5:])
+
+
+def test_training_reduces_the_loss_on_a_fixed_batch(lib):
+    """Twelve optimizer steps on one fixed batch (graph replay from the third step on): the loss goes down -- the whole loop (forward, loss, backward, all-lanes gradient sum, AdamW, scheduler) pulls in one direction."""
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    case = dict(tc['cases']['r18'], hw=[128, 128])
+    cfg = O.make_cfg(**case['cfg'])
+    model, _ = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+    solver = dict(tc['solver_cfg'], BASE_LR=2e-4, PRETRAIN_ITERS=[1000, 2000])
+    tr = SWEMTrainer(dict(SOLVER=solver, LOSS=tc['loss_cfg'], AMP=False), model)
+    frames, init_mask, label, valid = [t.to(DEV) for t in H.train_batch(case)]
+    torch.manual_seed(23)
+    hist = []
+    for it in range(12):
+        losses, _ = tr.one_step(frames, init_mask, valid, label, 5)      # plain CE + IoU (below start_warm)
+        hist.append(float(losses['total_loss']))
+    assert tr._graph is not None
+    assert hist[-1] < 0.8 * hist[0], hist
+    # (every step draws new random bases, so single steps may go up)
+    assert sum(1 for a, b in zip(hist, hist[1:]) if b < a) >= 6, hist
