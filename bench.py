@@ -263,7 +263,7 @@ def main():
                     'layers the tuner runs in bf16x6 mode execute 6 bf16-MFMA products per fp32 product, their own ceiling is 2500/6 = 417 TFLOP/s; algorithmic bytes = every input map once + filters + output in fp32, the measured traffic adds the bf16x3 planes (1.5x an fp32 map, written by the split and read by the conv) and the Infinity-Cache-served halo re-reads that FETCH_SIZE counts' % nprof + tnote,
             'plans_bf16x6': sum(1 for v in ops._CONV_PLANS.values() if (v >> 16) & 1), 'plans_total': len(ops._CONV_PLANS)}
         if args.no_em:
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and world == 1:
                 out['cpu_baseline'] = cpu_baseline(frames_cpu, m0_cpu, sd)
             print(json.dumps(out))
             if torch.distributed.is_initialized():
@@ -350,7 +350,7 @@ def main():
                           'stream replayed together (device time per frame = round time / sequences); `isolated` = one '
                           'sequence alone (20 back-to-back calls on one frame\'s real arguments); algorithmic FLOPs '
                           '4PL(C(3T-1)+V) + 4LmP(C+V) per object' % nseq)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only
             out['cpu_baseline'] = cpu_baseline(frames_cpu, m0_cpu, sd)
     if rank == 0:
         print(json.dumps(out))
