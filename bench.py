@@ -134,11 +134,13 @@ def main():
     if rank == 0:
         __graft_entry__.build()
     sdist.barrier()
-    from oracle import swem_oracle as O
+    from types import SimpleNamespace
     from swem_amd import ops, synth, weights
     from swem_amd.swem import SWEM
 
-    cfg = O.make_cfg(**CFG)
+    # (the oracle is imported by the cpu_baseline leg only: it is the checker, never part of what is measured)
+    cfg = SimpleNamespace(**dict(dict(KEYDIM=128, VALDIM=512, NUM_BASES=256, NUM_EM_ITERS=4, EM_TAU=0.05, TOPL=64,
+                                      SINGLE_OBJ=False, BACKBONE='resnet50'), **CFG))
     n_obj = args.objects
     nseq = max(1, args.seqs)
     if args.load_plans:
