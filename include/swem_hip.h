@@ -79,7 +79,9 @@ int swem_device_cus(void);
  *   plan    : tiling hint, 0 = built-in heuristic; else  wm | wn << 4 | nsplit << 8 | math << 16  with wave tile
  *             (32*wm) x (32*wn) in {1x1, 1x2, 2x2}, nsplit K-splits, math 0 = fp32 MFMA, 1 = "bf16x6": operands
  *             split exactly into three bf16 terms while they are staged, six bf16 MFMA products, fp32 accumulation
- *             (fp32-level error, 2.7x the fp32-MFMA rate; swem_conv2d_nhwc_bf16x3 is the pre-split form).  Results are identical up to fp32 rounding; callers may time candidates once
+ *             (fp32-level error, 2.7x the fp32-MFMA rate; swem_conv2d_nhwc_bf16x3 is the pre-split form), 2 = plain bf16
+ *             (pre-split entry only: plane 0 = the operands rounded to nearest-even bf16, ONE product, fp32 accumulation --
+ *             the mixed-precision training mode, config.AMP).  Modes 0 and 1 give identical results up to fp32 rounding; callers may time candidates once
  *             per layer shape and pass the fastest
  *   ws      : workspace for split-K partial sums (swem_conv2d_workspace bytes for the same plan)
  */

@@ -217,7 +217,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         wsb = _lib.query('swem_conv2d_workspace', B, H, W, cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad,
                          flags, plan)
         ws = workspace(wsb, x0.device) if wsb else None
-        if (plan >> 16) & 1 and presplit_ok:
+        if (plan >> 16) & 3 and presplit_ok:
             # bf16x6 math: sources split once per tensor (input ReLU folded into the split), filters split at pack time
             sargs = []
             for i, s_ in enumerate(srcs):
@@ -235,9 +235,11 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
                   _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw, pack.stride,
                   pack.pad, flags, plan, _ptr(ws), wsb)
 
-    sig = (cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags, B, H, W)
+    sig = (cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags, B, H, W) + _PLAN_TAG
     explicit = plan is not None
     plan = plan if explicit else _CONV_PLANS.get(sig, 0)
+    if plan == 0 and len(_PLAN_TAG) == 2 and not AUTOTUNE:
+        plan = _PLAN_TAG[1] << 16                  # conv_math((m,)) without tuning: the heuristic tile in math mode m
     if AUTOTUNE and not explicit and plan == 0 and not torch.cuda.is_current_stream_capturing():
         plan = _CONV_PLANS[sig] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
                                             -(-pack.kh * pack.kw * cin // 32), pack.glu, fresh_kw=True)
@@ -254,6 +256,26 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
                            '%dx%dx%d k%d s%d %d->%d' % (B, H, W, pack.kh, pack.stride, pack.cin_true, ncols),
                            in_bytes + 4.0 * ncols * pack.kh * pack.kw * pack.cin_true + 4.0 * B * Ho * Wo * pack.cout))
     return y
+
+
+_PLAN_TAG = ()
+
+
+class conv_math:
+    """Context: restrict the math modes the conv tuner may choose (0 fp32 MFMA, 1 bf16x6, 2 plain bf16) and keep the plans
+    tuned under it apart from the default ones.  The training step uses (2,) for config.AMP."""
+
+    def __init__(self, modes):
+        self.modes = tuple(modes)
+
+    def __enter__(self):
+        global CONV_MATH_MODES, _PLAN_TAG
+        self.saved = (CONV_MATH_MODES, _PLAN_TAG)
+        CONV_MATH_MODES, _PLAN_TAG = self.modes, ('math',) + self.modes
+
+    def __exit__(self, *a):
+        global CONV_MATH_MODES, _PLAN_TAG
+        CONV_MATH_MODES, _PLAN_TAG = self.saved
 
 
 def AUTOTUNE_PENDING():
@@ -291,7 +313,7 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
                 continue
             for math in CONV_MATH_MODES:
                 cands.append(wm | wn << 4 | ns << 8 | math << 16)
-                if math == 1:                      # pre-split kernel variants: other stage count, 8-wave 128x128 tile
+                if math in (1, 2):                 # pre-split kernel variants: other stage count, 8-wave 128x128 tile
                     base = wm | wn << 4 | ns << 8 | math << 16
                     cands.append(base | 1 << 20)
                     cands.append(base | 4 << 20)              # 16x16x32 MFMA shape

@@ -13,8 +13,10 @@ number of GPUs only if asked (solver.py:31-34, ``num_gpu``), so does ``SWEMTrain
 How the batch is run: clips are independent (frozen BatchNorm, per-clip memory), so every clip is its own forward /
 per-clip loss with weight 1/B / backward.  Up to ``lanes`` clips are in flight at once, each on its own stream with its
 own flat gradient buffer (the in-kernel accumulation is a plain read-modify-write); the lanes' buffers are summed into
-the optimizer's.  That equals the reference's batched step (``total = mean_b``).  Mixed precision (config.AMP) is not built: the step runs in fp32 (bf16x6 / fp32 MFMA).
+the optimizer's.  That equals the reference's batched step (``total = mean_b``).  Mixed precision (config.AMP): the
+convolutions' forward and data gradient take bf16 operands (one MFMA product, fp32 accumulate); everything else is fp32.
 """
+import contextlib
 import math
 
 import torch
@@ -152,8 +154,11 @@ class SWEMTrainer:
     def __init__(self, config, model, num_gpu=None, use_graph=True, lanes=4):
         self.config = config
         self.model = model
-        if _get(config, 'AMP'):
-            raise NotImplementedError('AMP training is not built on the HIP path (fp32-accurate step only)')
+        # config.AMP (configs/config.py:89, basic_trainer.py:83-86,222): the reference runs the forward under fp16
+        # autocast with a GradScaler.  Here AMP = the convolutions (forward and data gradient) round their operands to
+        # bf16 and take ONE MFMA product with fp32 accumulation (conv math mode 2); activations, EM, matching, the loss,
+        # the weight gradient and the optimizer stay fp32.  bf16 keeps fp32's exponent range, so no loss scaling.
+        self.amp = bool(_get(config, 'AMP'))
         dev = next(model.parameters()).device
         model.train()
         for mod in model.modules():                    # BasicTrainer.set_bn_eval (swem_trainer.py:37-39)
@@ -299,7 +304,8 @@ class SWEMTrainer:
             self._graph.replay()
             results, p = self._graph_out, (1.0 if p is None else p)
         else:
-            results, p = self._clips(cur_iter)
+            with self._math():
+                results, p = self._clips(cur_iter)
             self._eager_steps += 1
         sdist.allreduce_sum_(self.optimizer.grad)                      # RCCL over xGMI; no-op for one process
         self.optimizer.step()
@@ -308,9 +314,12 @@ class SWEMTrainer:
         losses = {'total_loss': sums[0], 'main_loss': sums[1], 'aux_loss': sums[2], 'p': p}
         return losses, results
 
+    def _math(self):
+        return ops.conv_math((2,)) if self.amp else contextlib.nullcontext()
+
     def _capture(self, cur_iter):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g), self._math():
             out, _ = self._clips(cur_iter)
         self._graph, self._graph_out = g, out

@@ -246,6 +246,31 @@ def test_conv2d_plans_and_math_modes(lib, plan):
         close(back(y), ref, 2e-5, 'glu plan %#x' % plan)
 
 
+@pytest.mark.parametrize('plan', [0x20011, 0x20021, 0x20022, 0x120021, 0x220022, 0x420011, 0x420021, 0x620022, 0x20221,
+                                  0x4020021], ids=lambda p: '%#x' % p)
+def test_conv2d_plain_bf16_mode(lib, plan):
+    """Math mode 2 (mixed-precision training, config.AMP): operands rounded to bf16 once, ONE MFMA product, fp32
+    accumulate.  On bf16-representable operands it is the fp32 convolution up to summation order; on general ones it
+    is the convolution of the rounded operands (what torch.autocast computes for this layer)."""
+    g = torch.Generator().manual_seed(78)
+    B, Cin, H, W, Cout = 2, 160, 21, 37, 192
+    x = torch.randn(B, Cin, H, W, generator=g) * 3
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.03
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(B, Cout, H, W, generator=g)
+    xr, wr = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.relu(F.conv2d(F.relu(xr), wr, b, padding=1) + res)
+    y = ops.conv2d([nhwc(xr)], ops.pack_conv(wr.to(DEV), b.to(DEV)), relu_in=True, relu_out=True, residual=nhwc(res),
+                   plan=plan)
+    close(back(y), ref, 2e-5, 'bf16 conv on representable operands, plan %#x' % plan)
+    y = ops.conv2d([nhwc(x)], ops.pack_conv(w.to(DEV), b.to(DEV)), relu_in=True, relu_out=True, residual=nhwc(res),
+                   plan=plan)
+    close(back(y), ref, 2e-5, 'bf16 conv rounds its operands to nearest-even, plan %#x' % plan)
+    full = F.relu(F.conv2d(F.relu(x), w, b, padding=1) + res)
+    err = float((back(y) - full).abs().max() / full.abs().max())
+    assert 1e-5 < err < 1e-2, err             # really one bf16 product (not the exact six), and no worse than bf16
+
+
 @pytest.mark.parametrize('plan', [0x4010021, 0x8010011, 0x4210022, 0x4010022], ids=lambda p: '%#x' % p)
 def test_conv2d_tail_split(lib, plan):
     """Plan bits 24-27: the last, partly filled round of tiles is launched a second time split over K and reduced over

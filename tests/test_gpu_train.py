@@ -518,3 +518,37 @@ def test_training_reduces_the_loss_on_a_fixed_batch(lib):
     assert hist[-1] < 0.8 * hist[0], hist
     # (every step draws new random bases, so single steps may go up)
     assert sum(1 for a, b in zip(hist, hist[1:]) if b < a) >= 6, hist
+
+
+def test_amp_step_tracks_the_fp32_step(lib):
+    """config.AMP (configs/config.py:89): the convolutions' forward / data gradient run on bf16 operands (one MFMA
+    product, fp32 accumulate; the reference autocasts to fp16 with a GradScaler, basic_trainer.py:83-86,222).  The step
+    must stay a bf16-level perturbation of the fp32 step -- same loss to a percent, flat gradient aligned -- and must
+    really be the reduced-precision one (not bit-equal to fp32).  Graph replay of the AMP step equals its eager form."""
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    case = dict(tc['cases']['r18'], hw=[128, 128])
+    cfg = O.make_cfg(**case['cfg'])
+    frames, init_mask, label, valid = [t.to(DEV) for t in H.train_batch(case)]
+    out = {}
+    for name, amp, graph in (('fp32', False, False), ('amp', True, False), ('amp_graph', True, True)):
+        model, _ = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+        tr = SWEMTrainer(dict(SOLVER=dict(tc['solver_cfg'], BASE_LR=1e-4), LOSS=tc['loss_cfg'], AMP=amp), model,
+                         use_graph=graph)
+        torch.manual_seed(31)
+        hist = []
+        for it in (5, 6, 7, 8):
+            losses, _ = tr.one_step(frames, init_mask, valid, label, it)
+            hist.append(float(losses['total_loss']))
+            if it == 5:
+                g0 = tr.optimizer.grad.detach().clone()
+        assert (tr._graph is not None) == graph
+        out[name] = (hist, g0, tr.optimizer.param.detach().clone())
+    (h32, g32, _), (ha, ga, pa), (hg, gg, pg) = out['fp32'], out['amp'], out['amp_graph']
+    assert abs(ha[0] - h32[0]) < 1e-2 * abs(h32[0]), (ha, h32)
+    assert ha[0] != h32[0] and not torch.equal(ga, g32)
+    cos = float((ga.double() * g32.double()).sum() / (ga.double().norm() * g32.double().norm()))
+    assert cos > 0.98, cos
+    assert abs(float(ga.norm()) / float(g32.norm()) - 1) < 0.05
+    assert hg == ha and torch.equal(gg, ga) and torch.equal(pg, pa)
+    assert all(abs(a - b) < 0.05 * abs(b) for a, b in zip(ha, h32)), (ha, h32)

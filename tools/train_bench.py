@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--backbone', default='resnet50')
     ap.add_argument('--no-autotune', action='store_true')
     ap.add_argument('--lanes', type=int, default=4, help='clips in flight at once (streams)')
+    ap.add_argument('--amp', action='store_true', help='config.AMP: bf16-operand convolutions')
     ap.add_argument('--save-plans', default=None)
     ap.add_argument('--load-plans', default=None, help='reuse tuned conv plans (profiler runs)')
     a = ap.parse_args()
@@ -43,7 +44,7 @@ def main():
     tr = SWEMTrainer(dict(SOLVER=dict(STAGE=0, BASE_LR=2e-5, PRETRAIN_ITERS=[150000, 300000], GAMMA=0.1,
                                       OPTIMIZER='AdamW', WEIGHT_DECAY=5e-4),
                           LOSS=dict(NAME='boots_ce', BS_RATIO=0.3, BS_PERIOD=[20000, 70000], AUX='iou', AUX_RATIO=1.0),
-                          AMP=False), model, lanes=a.lanes)
+                          AMP=a.amp), model, lanes=a.lanes)
     fr, im, lb = [], [], []
     for i in range(a.clips):
         frames, per = synth.make_clip(t=3, h=a.size, w=a.size, n_obj=a.objects, out_hw=(a.size, a.size), seed=50 + i,
@@ -67,8 +68,8 @@ def main():
         losses, _ = tr.one_step(frames, init_mask, valid, label, 30000 + it)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / a.steps
-    print(json.dumps({'metric': 'training clips/s (3 x %dx%d frames, %d objects, %s, fp32-accurate)' % (
-        a.size, a.size, a.objects, a.backbone), 'value': a.clips / dt, 'ms_per_step': dt * 1e3, 'clips_per_step': a.clips,
+    print(json.dumps({'metric': 'training clips/s (3 x %dx%d frames, %d objects, %s, %s)' % (
+        a.size, a.size, a.objects, a.backbone, 'AMP: bf16 conv operands' if a.amp else 'fp32-accurate'), 'value': a.clips / dt, 'ms_per_step': dt * 1e3, 'clips_per_step': a.clips,
         'total_loss': float(losses['total_loss']), 'graph': tr._graph is not None, 'lanes': a.lanes, 'peak_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30}))
 
 
