@@ -61,6 +61,18 @@ int swem_conv2d_wgrad_f32(void *stream, const float *dy, const float *x0, int c0
                           int c1, long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W, int Cout,
                           int KH, int KW, int stride, int pad, int relu_in, float *dw, int cin_store, int accumulate,
                           void *ws, size_t ws_bytes);
+/* The same weight gradient on the bf16 matrix pipe from PRE-SPLIT operands (swem_split_bf16x3_f32, swem_hip.h): dy3 =
+ * plane 0 of the split of dY ([3][Cout/8][B*Ho*Wo][8], plane stride dy_ps elements), xK = plane 0 of the split of source
+ * K (act already folded into the split; plane stride psK, batch stride bsK in elements, 0 = shared map).  Channel counts
+ * are multiples of 8.  math 1 = bf16x6 (six products of the exact three-way split, fp32-level error), 2 = plain bf16
+ * (plane 0, one product: config.AMP).  plan 0 = heuristic, else  tile | pixel_slices << 4  (tile 1 = 64x64, 2 = 128x128). */
+size_t swem_conv2d_wgrad_bf16x3_workspace(int B, int H, int W, int c0, int c1, int c2, int Cout, int KH, int KW,
+                                          int stride, int pad, int plan);
+int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3, long long dy_ps, const unsigned short *x0, int c0,
+                             long long bs0, long long ps0, const unsigned short *x1, int c1, long long bs1,
+                             long long ps1, const unsigned short *x2, int c2, long long bs2, long long ps2, int B, int H,
+                             int W, int Cout, int KH, int KW, int stride, int pad, int math, float *dw, int cin_store,
+                             int accumulate, int plan, void *ws, size_t ws_bytes);
 /* column sums of a [M][C] matrix: out1[c] (+)= sum_m a[m][c], out2[c] (+)= sum_m a[m][c]*b[m][c]  (bias and frozen
  * BatchNorm parameter gradients); either output may be NULL */
 size_t swem_colsum_workspace(long long M, int C);

@@ -98,6 +98,51 @@ def _dgrad_pack(weight, off, c, stride, pad, cin_pad):
     return pk
 
 
+def wgrad_math(cs, cout, kh, kw, M):
+    """Which kernel takes a layer's weight gradient: 0 = fp32 MFMA on the fp32 tensors, 1 = bf16x6 / 2 = plain bf16 on
+    the pre-split planes (include/swem_hip_train.h).  Under ops.conv_math((2,)) (config.AMP) every layer the bf16 kernel
+    is not slower on takes plain bf16; otherwise the large 3x3 layers take bf16x6 (fp32-level error) -- measured with
+    tools/wgrad_bench.py on the training shapes."""
+    if any(c % 8 for c in cs) or cout % 8:
+        return 0
+    big = cout >= 128 and all(c >= 128 for c in cs)
+    if ops._PLAN_TAG == ('math', 2):
+        return 2 if (kh * kw > 1 or (big and M >= 2048)) else 0
+    return 1 if (big and kh * kw > 1 and 1 in ops.CONV_MATH_MODES) else 0
+
+
+def _wgrad(dy, srcs, weight, stride, pad, relu_in):
+    """dW (+)= dY^T * act(x) into the parameter's gradient view (swem_conv2d_wgrad_f32 / _bf16x3)."""
+    B, Ho, Wo, Cout = dy.shape
+    H, W = srcs[0].shape[1:3]
+    dev = dy.device
+    kh, kw = weight.shape[2:]
+    cs = [s.shape[3] for s in srcs]
+    math = wgrad_math(cs, Cout, kh, kw, B * Ho * Wo)
+    args = []
+    for s in srcs:
+        bs = 0 if (s.shape[0] == 1 and B > 1) else (s.stride(0) if s.shape[0] > 1 else H * W * s.shape[3])
+        if math:
+            sp = ops.presplit(s, relu_in)
+            args += [sp.data_ptr(), s.shape[3], bs, sp.stride(0)]
+        else:
+            args += [s.data_ptr(), s.shape[3], bs]
+    for _ in range(3 - len(srcs)):
+        args += [0, 0, 0, 0] if math else [0, 0, 0]
+    cs = cs + [0, 0]
+    if math:
+        d3 = ops.presplit(dy, False)
+        wsb = _lib.query('swem_conv2d_wgrad_bf16x3_workspace', B, H, W, cs[0], cs[1], cs[2], Cout, kh, kw, stride, pad, 0)
+        ws = _ws(wsb, dev)
+        _lib.call('swem_conv2d_wgrad_bf16x3', ops._stream(), d3.data_ptr(), d3.stride(0), *args, B, H, W, Cout, kh, kw,
+                  stride, pad, math, _grad(weight).data_ptr(), weight.shape[1], 1, 0, ws.data_ptr(), wsb)
+        return
+    wsb = _lib.query('swem_conv2d_wgrad_workspace', B, H, W, cs[0], cs[1], cs[2], Cout, kh, kw, stride, pad)
+    ws = _ws(wsb, dev)
+    _lib.call('swem_conv2d_wgrad_f32', ops._stream(), dy.data_ptr(), *args, B, H, W, Cout, kh, kw, stride, pad,
+              int(relu_in), _grad(weight).data_ptr(), weight.shape[1], 1, ws.data_ptr(), wsb)
+
+
 class _Conv(Function):
     """y = conv(act(cat(srcs)), W) + b (+ residual); act = ReLU when relu_in (networks.py:22-32 pre-activation blocks,
     mod_resnet convs, modules.py:25-26, swem.py:33).  A source with batch 1 is shared by all `batch` items."""
@@ -123,18 +168,7 @@ class _Conv(Function):
             colsum(dy, out1=_grad(bias))
         H, W = srcs[0].shape[1:3]
         if weight.requires_grad:
-            cs = [s.shape[3] for s in srcs] + [0, 0]
-            args = []
-            for s in srcs:
-                bs = 0 if (s.shape[0] == 1 and B > 1) else (s.stride(0) if s.shape[0] > 1 else H * W * s.shape[3])
-                args += [s.data_ptr(), s.shape[3], bs]
-            for _ in range(3 - len(srcs)):
-                args += [0, 0, 0]
-            kh, kw = weight.shape[2:]
-            wsb = _lib.query('swem_conv2d_wgrad_workspace', B, H, W, cs[0], cs[1], cs[2], Cout, kh, kw, stride, pad)
-            ws = _ws(wsb, dev)
-            _lib.call('swem_conv2d_wgrad_f32', ops._stream(), dy.data_ptr(), *args, B, H, W, Cout, kh, kw, stride, pad,
-                      int(relu_in), _grad(weight).data_ptr(), weight.shape[1], 1, ws.data_ptr(), wsb)
+            _wgrad(dy, srcs, weight, stride, pad, relu_in)
         grads = []
         off = 0
         for i, s in enumerate(srcs):

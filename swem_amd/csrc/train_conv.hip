@@ -10,6 +10,7 @@
 // reduce kernel, which also writes the reference's OIHW layout and accumulates into the gradient buffer.
 #include "../../include/swem_hip_train.h"
 #include "common.h"
+#include "lds_dma.h"
 
 namespace {
 
@@ -96,6 +97,200 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
         for (int j = 0; j < WT; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
     }
+  }
+  float *dst = p.partial + (long long)blockIdx.z * p.Cout * p.K + (long long)tap * p.Cin + p.c_off;
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const int c = ci0 + wc * 32 * WT + 32 * j + r;
+      if (c >= p.cs) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wn * 32 * WT + 32 * i + acc_row(e, h);
+        if (n < p.Cout) dst[(long long)n * p.K + c] = acc[i][j][e];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The same weight gradient on the bf16 matrix pipe, from the PRE-SPLIT planes the forward / data-gradient convolutions
+// already made (swem_split_bf16x3_f32: [plane][C/8][pixel][8 bf16]).  NPL = 3: exact three-way split of both operands,
+// six products, fp32 accumulate (fp32-level error, as the forward's bf16x6 mode); NPL = 1: plane 0 only, one product
+// (config.AMP).
+//
+// The reduction axis is the PIXEL, which is the strided axis of both operands -- the bf16 MFMA wants 8 consecutive k per
+// lane.  LDS keeps 32-pixel x 64-channel images as they lie in memory ([pixel][64 bf16] = 128-byte rows) and the
+// fragments are read with ds_read_b64_tr_b16, the hardware transpose (4 pixels x 16 channels per 16-lane group).  The
+// images are filled by buffer_load ... lds: one transfer = 8 pixel rows x 8 sixteen-byte chunks, lane -> LDS slot is
+// fixed (lane-linear), so the conflict-avoiding swizzle -- chunk ^= 4 for rows with bit 1 set; the four rows one
+// transposed read touches then sit in four different 64-byte bank groups -- is applied on the GLOBAL side: the lane
+// that owns slot (row, c') fetches chunk c' ^ swz(row).  Each chunk is one (pixel, 8-channel group) cell of the
+// channel-group-major planes, so a transfer reads eight 128-byte lines; taps that fall outside the image and rows
+// past the slice use an out-of-range offset and land as zeros.  Wave w fills rows 8w..8w+7 of every image of a slab:
+// one pixel decode per lane, advanced by 32 pixels per slab with carries instead of divisions.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+typedef short wg_s16x8 __attribute__((ext_vector_type(8)));
+constexpr unsigned WG_OOB = 0xfffffff0u;
+
+struct WgradBP {
+  const unsigned short *dy3;  // [3][Cout/8][M][8]
+  const unsigned short *x3;   // [3][cs/8][npix][8] of the current source
+  long long dps, xps;         // plane strides in elements
+  long long xbs_pix;          // batch stride of x in pixels (0 = one map shared by every batch item)
+  int xnpix;                  // pixels per plane of x
+  int cs, c_off;
+  int B, H, W, Ho, Wo, Cout, Cin, KH, KW, stride, pad;
+  int M, m_per_split, ctiles, K;
+  float *partial;             // [zsplit][Cout][K]
+};
+
+__device__ __forceinline__ wg_s16x4 lds_tr16(unsigned addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3))) *)(size_t)addr);
+}
+__device__ __forceinline__ f32x16 wg_mfma(wg_s16x8 a, wg_s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, a), __builtin_bit_cast(wg_bf16x8, b), c, 0,
+                                                 0, 0);
+}
+
+template <int WT, int NPL>
+__global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
+  constexpr int BT = 64 * WT;
+  constexpr int IMG = 32 * 128;                 // bytes of one 32-pixel x 64-channel image
+  constexpr int OPB = WT * NPL * IMG;           // one operand of one stage: [image][plane]
+  constexpr int STAGE = 2 * OPB;                // dY images, then x images
+  constexpr int NDMA = 2 * WT * NPL;            // transfers per wave per slab
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * BT;
+  const int tap = blockIdx.y / p.ctiles, ci0 = (blockIdx.y - tap * p.ctiles) * BT;
+  const int ky = tap / p.KW, kx = tap - ky * p.KW;
+  const int m_begin = blockIdx.z * p.m_per_split, m_end = min(p.M, m_begin + p.m_per_split);
+
+  // ---- transfers: this lane's slot is (row 8 wave + lane/8, chunk' lane%8) of every image
+  const int lrow = 8 * wave + (lane >> 3);
+  const int ch = (lane & 7) ^ (((lrow >> 1) & 1) << 2);   // the chunk (8-channel group) that lands in this slot
+  int m = m_begin + lrow;
+  int b, oy, ox;
+  {
+    const int HoWo = p.Ho * p.Wo;
+    b = m / HoWo;
+    const int rem = m - b * HoWo;
+    oy = rem / p.Wo;
+    ox = rem - oy * p.Wo;
+  }
+  const unsigned dgroup = (unsigned)p.M * 16u, xgroup = (unsigned)p.xnpix * 16u;   // bytes per 8-channel group
+  bool dok[WT], xok[WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i) {
+    dok[i] = n0 / 8 + 8 * i + ch < p.Cout / 8;
+    xok[i] = ci0 / 8 + 8 * i + ch < p.cs / 8;
+  }
+  const i32x4 rsd = raw_rsrc(p.dy3, (unsigned)(3 * p.dps * 2));
+  const i32x4 rsx = raw_rsrc(p.x3, (unsigned)(3 * p.xps * 2));
+  const unsigned dplane = (unsigned)(p.dps * 2), xplane = (unsigned)(p.xps * 2);
+  const unsigned d_base = (unsigned)(n0 / 8) * dgroup, x_base = (unsigned)(ci0 / 8) * xgroup;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const unsigned lds_w = lds0 + (unsigned)wave * 1024u;   // rows 8w..8w+7 of an image
+  auto issue = [&](int stage) {
+    const bool mok = m < m_end;
+    const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+    const bool pok = mok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const unsigned dv = (unsigned)ch * dgroup + (unsigned)m * 16u;
+    const unsigned xv = (unsigned)ch * xgroup + (unsigned)((long long)b * p.xbs_pix + (long long)iy * p.W + ix) * 16u;
+    const unsigned sd = lds_w + (unsigned)stage * STAGE, sx = sd + OPB;
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+        dma16(rsd, sd + (i * NPL + pl) * IMG, (mok && dok[i]) ? dv : WG_OOB, d_base + i * 8 * dgroup + pl * dplane);
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+        dma16(rsx, sx + (i * NPL + pl) * IMG, (pok && xok[i]) ? xv : WG_OOB, x_base + i * 8 * xgroup + pl * xplane);
+  };
+  auto advance = [&]() {
+    m += 32;
+    ox += 32;
+    while (ox >= p.Wo) {
+      ox -= p.Wo;
+      ++oy;
+    }
+    while (oy >= p.Ho) {
+      oy -= p.Ho;
+      ++b;
+    }
+  };
+
+  // ---- fragment reads: 16-lane group g = lane/16 -> (k half h = g/2, channel half gg = g%2); lane 4q + pp of the group
+  // supplies pixel row 8h + 4t + q, bytes 8 pp .. 8 pp + 7 of the group's 32-byte run (read t = 0, 1; 16 pixels per k-step)
+  const int gg = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+  const unsigned swz = (unsigned)((q >> 1) & 1) << 2;
+  unsigned fr[2];   // byte offset inside an image for sub-tile (32 channels) 0 / 1
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    fr[j] = (unsigned)(8 * h + q) * 128u + ((((unsigned)(4 * j) ^ swz) + 2u * gg + (pp >> 1)) * 16u) + 8u * (pp & 1);
+  // this wave's sub-tiles: filters 32 WT wn + 32 i, channels 32 WT wc + 32 j
+  const unsigned dimg = lds0 + (WT == 2 ? wn : 0) * (NPL * IMG), ximg = lds0 + OPB + (WT == 2 ? wc : 0) * (NPL * IMG);
+
+  f32x16 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int st = 0;
+  for (int mb = m_begin; mb < m_end; mb += 32) {
+    if (mb + 32 < m_end) {
+      advance();
+      issue(st ^ 1);
+    }
+    const unsigned so = (unsigned)st * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      wg_s16x8 a[NPL][WT], bb[NPL][WT];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+        for (int i = 0; i < WT; ++i) {
+          const unsigned ad = dimg + so + pl * IMG + ks * 2048 + fr[WT == 2 ? i : wn];
+          a[pl][i] = __builtin_shufflevector(lds_tr16(ad), lds_tr16(ad + 512), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+          const unsigned ad = ximg + so + pl * IMG + ks * 2048 + fr[WT == 2 ? j : wc];
+          bb[pl][j] = __builtin_shufflevector(lds_tr16(ad), lds_tr16(ad + 512), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+          f32x16 c = acc[i][j];
+          if constexpr (NPL == 3) {
+            c = wg_mfma(a[0][i], bb[2][j], c);
+            c = wg_mfma(a[2][i], bb[0][j], c);
+            c = wg_mfma(a[1][i], bb[1][j], c);
+            c = wg_mfma(a[0][i], bb[1][j], c);
+            c = wg_mfma(a[1][i], bb[0][j], c);
+          }
+          c = wg_mfma(a[0][i], bb[0][j], c);
+          acc[i][j] = c;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next slab has landed (this wave's share)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of stage st are done
+    __builtin_amdgcn_s_barrier();
+    st ^= 1;
   }
   float *dst = p.partial + (long long)blockIdx.z * p.Cout * p.K + (long long)tap * p.Cin + p.c_off;
 #pragma unroll
@@ -268,6 +463,103 @@ extern "C" int swem_conv2d_wgrad_f32(void *stream, const float *dy, const float 
     if (pl.wt == 2) hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, st, p);
     SWEM_CHECK_LAUNCH("conv_wgrad_kernel");
+    off += cs[s];
+  }
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((long long)Cout * p.K, 256)), dim3(256), 0, st, p.partial, dw,
+                     Cout, Cin, KH * KW, cin_store, pl.zsplit, accumulate);
+  SWEM_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
+  return SWEM_OK;
+}
+
+// ---- bf16-pipe weight gradient (pre-split planes)
+static WgradPlan wgrad_bf_plan(long long M, int Cout, int KH, int KW, int c0, int c1, int c2, int plan) {
+  WgradPlan pl;
+  const bool big = Cout >= 128 && c0 >= 128 && (c1 == 0 || c1 >= 128) && (c2 == 0 || c2 >= 128);
+  pl.wt = (plan & 15) ? (plan & 15) : (big ? 2 : 1);
+  if (pl.wt != 1 && pl.wt != 2) pl.wt = 1;
+  const int bt = 64 * pl.wt;
+  long long tiles = (long long)cdiv(Cout, bt) * KH * KW * (cdiv(c0, bt) + (c1 ? cdiv(c1, bt) : 0) + (c2 ? cdiv(c2, bt) : 0));
+  long long zs = (plan >> 4) > 0 ? (plan >> 4) : (pl.wt == 2 ? 512 : 1024) / (tiles > 0 ? tiles : 1);
+  const long long zmax = (M + 127) / 128;
+  if (zs > zmax) zs = zmax;
+  if (zs < 1) zs = 1;
+  long long per = ((M + zs - 1) / zs + 31) / 32 * 32;
+  pl.m_per_split = (int)per;
+  pl.zsplit = (int)((M + per - 1) / per);
+  return pl;
+}
+
+template <int WT, int NPL>
+static int launch_wgrad_bf(const WgradBP &p, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = 2 * 2 * WT * NPL * 4096;
+  SWEM_ALLOW_LDS((conv_wgrad_bf_kernel<WT, NPL>), lds);
+  hipLaunchKernelGGL((conv_wgrad_bf_kernel<WT, NPL>), grid, dim3(256), lds, st, p);
+  return SWEM_OK;
+}
+
+extern "C" size_t swem_conv2d_wgrad_bf16x3_workspace(int B, int H, int W, int c0, int c1, int c2, int Cout, int KH,
+                                                     int KW, int stride, int pad, int plan) {
+  if (stride <= 0) return 0;
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const long long M = (long long)B * Ho * Wo;
+  WgradPlan pl = wgrad_bf_plan(M, Cout, KH, KW, c0, c1, c2, plan);
+  return (size_t)pl.zsplit * Cout * KH * KW * (c0 + c1 + c2) * sizeof(float);
+}
+
+extern "C" int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3, long long dy_ps,
+                                        const unsigned short *x0, int c0, long long bs0, long long ps0,
+                                        const unsigned short *x1, int c1, long long bs1, long long ps1,
+                                        const unsigned short *x2, int c2, long long bs2, long long ps2, int B, int H,
+                                        int W, int Cout, int KH, int KW, int stride, int pad, int math, float *dw,
+                                        int cin_store, int accumulate, int plan, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(dy3 && x0 && dw, SWEM_E_ARG, "conv2d_wgrad_bf16x3: null pointer");
+  SWEM_REQUIRE((c1 == 0 || x1) && (c2 == 0 || x2) && c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0 && c2 % 8 == 0 &&
+                   Cout % 8 == 0 && Cout > 0,
+               SWEM_E_SHAPE, "conv2d_wgrad_bf16x3: channel counts must be multiples of 8");
+  SWEM_REQUIRE(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, SWEM_E_SHAPE,
+               "conv2d_wgrad_bf16x3: bad geometry");
+  SWEM_REQUIRE(math == 1 || math == 2, SWEM_E_ARG, "conv2d_wgrad_bf16x3: math must be 1 (bf16x6) or 2 (bf16)");
+  const int Cin = c0 + c1 + c2;
+  SWEM_REQUIRE(cin_store > 0 && cin_store <= Cin, SWEM_E_SHAPE, "conv2d_wgrad_bf16x3: cin_store out of range");
+  WgradBP p;
+  p.dy3 = dy3;
+  p.dps = dy_ps;
+  p.B = B; p.H = H; p.W = W;
+  p.Ho = (H + 2 * pad - KH) / stride + 1;
+  p.Wo = (W + 2 * pad - KW) / stride + 1;
+  SWEM_REQUIRE(p.Ho > 0 && p.Wo > 0, SWEM_E_SHAPE, "conv2d_wgrad_bf16x3: empty output");
+  const long long M = (long long)B * p.Ho * p.Wo;
+  SWEM_REQUIRE(M * 128 < (1ll << 32) && dy_ps == M * Cout, SWEM_E_SHAPE,
+               "conv2d_wgrad_bf16x3: dY planes must be [Cout/8][B*Ho*Wo][8] and below 4 GiB per 64 channels");
+  p.M = (int)M;
+  p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+  p.K = KH * KW * Cin;
+  WgradPlan pl = wgrad_bf_plan(M, Cout, KH, KW, c0, c1, c2, plan);
+  const size_t need = (size_t)pl.zsplit * Cout * p.K * sizeof(float);
+  SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_wgrad_bf16x3: workspace %zu < %zu bytes", ws_bytes,
+               need);
+  p.partial = static_cast<float *>(ws);
+  p.m_per_split = pl.m_per_split;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned short *xs[3] = {x0, x1, x2};
+  const int cs[3] = {c0, c1, c2};
+  const long long bss[3] = {bs0, bs1, bs2}, pss[3] = {ps0, ps1, ps2};
+  const int bt = 64 * pl.wt;
+  int off = 0;
+  for (int s = 0; s < 3; ++s) {
+    if (cs[s] == 0) continue;
+    SWEM_REQUIRE(pss[s] % cs[s] == 0 && bss[s] % cs[s] == 0 && pss[s] / cs[s] * 128 < (1ll << 32), SWEM_E_SHAPE,
+                 "conv2d_wgrad_bf16x3: source %d plane / batch stride", s);
+    p.x3 = xs[s]; p.cs = cs[s]; p.c_off = off; p.xps = pss[s];
+    p.xnpix = (int)(pss[s] / cs[s]);
+    p.xbs_pix = bss[s] / cs[s];
+    p.ctiles = cdiv(cs[s], bt);
+    dim3 grid(cdiv(Cout, bt), KH * KW * p.ctiles, pl.zsplit);
+    int rc;
+    if (pl.wt == 2) rc = math == 1 ? launch_wgrad_bf<2, 3>(p, grid, st) : launch_wgrad_bf<2, 1>(p, grid, st);
+    else rc = math == 1 ? launch_wgrad_bf<1, 3>(p, grid, st) : launch_wgrad_bf<1, 1>(p, grid, st);
+    if (rc != SWEM_OK) return rc;
+    SWEM_CHECK_LAUNCH("conv_wgrad_bf_kernel");
     off += cs[s];
   }
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((long long)Cout * p.K, 256)), dim3(256), 0, st, p.partial, dw,

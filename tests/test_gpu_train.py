@@ -520,6 +520,65 @@ def test_training_reduces_the_loss_on_a_fixed_batch(lib):
     assert sum(1 for a, b in zip(hist, hist[1:]) if b < a) >= 6, hist
 
 
+@pytest.mark.parametrize('math', [1, 2], ids=['bf16x6', 'bf16'])
+@pytest.mark.parametrize('case', [
+    dict(cins=[(256, 2)], cout=256, k=3, s=1, hw=(24, 24), relu_in=True),          # 128x128 tiles, whole
+    dict(cins=[(136, 2)], cout=200, k=3, s=2, hw=(21, 19), relu_in=False),         # 128x128 tiles, ragged; odd size
+    dict(cins=[(72, 3)], cout=40, k=3, s=1, hw=(25, 23), relu_in=False),           # 64x64 tiles, ragged both ways
+    dict(cins=[(64, 1)], cout=128, k=1, s=2, hw=(16, 15), relu_in=True, pad=0),    # 1x1 stride 2 without padding
+    dict(cins=[(128, 3), (256, 1), (128, 3)], cout=128, k=3, s=1, hw=(9, 11), relu_in=False),   # shared middle source
+    dict(cins=[(8, 2)], cout=64, k=7, s=2, hw=(32, 40), relu_in=False, pad=3, cin_store=5),     # value-encoder stem
+], ids=['whole128', 'ragged128_s2', 'ragged64', '1x1_s2', 'three_src_shared', 'stem7x7'])
+def test_conv_wgrad_bf16_pipe(lib, case, math):
+    """swem_conv2d_wgrad_bf16x3: the weight gradient from the pre-split bf16 planes (LDS images read through the
+    hardware transpose).  math 1 (six products) carries fp32-level error against F.conv2d's autograd in fp64; math 2
+    (config.AMP) equals the fp64 gradient of the bf16-ROUNDED operands to fp32 level and the true one to bf16 level."""
+    from swem_amd import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    k, s = case['k'], case['s']
+    pad = case.get('pad', k // 2)
+    H, W = case['hw']
+    B = max(b for _, b in case['cins'])
+    xs = [torch.randn(b, c, H, W, generator=g) for c, b in case['cins']]
+    cin = sum(c for c, _ in case['cins'])
+    cout = case['cout']
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    dy = torch.randn(B, cout, Ho, Wo, generator=g)
+
+    def ref(rnd):
+        xcat = torch.cat([x.expand(B, -1, -1, -1) for x in xs], 1)
+        xcat = F.relu(xcat) if case['relu_in'] else xcat
+        w = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+        F.conv2d(rnd(xcat).double(), w, stride=s, padding=pad).backward(rnd(dy).double())
+        return w.grad
+    srcs = [nhwc(x) for x in xs]
+    d = nhwc(dy)
+    d3 = ops.presplit(d, False)
+    args = []
+    for t in srcs:
+        sp = ops.presplit(t, case['relu_in'])
+        args += [sp.data_ptr(), t.shape[3], 0 if (t.shape[0] == 1 and B > 1) else H * W * t.shape[3], sp.stride(0)]
+    cs = [t.shape[3] for t in srcs] + [0, 0]
+    for _ in range(3 - len(srcs)):
+        args += [0, 0, 0, 0]
+    cin_store = case.get('cin_store', cin)
+    for plan in (0, 1 | 3 << 4, 2 | 1 << 4):
+        wsb = _lib.query('swem_conv2d_wgrad_bf16x3_workspace', B, H, W, cs[0], cs[1], cs[2], cout, k, k, s, pad, plan)
+        ws = ops.workspace(wsb, d.device)
+        dw = torch.full((cout, cin_store, k, k), 0.5, device=DEV)
+        for acc in (0, 1):                        # plain store, then accumulate on top of it
+            _lib.call('swem_conv2d_wgrad_bf16x3', ops._stream(), d3.data_ptr(), d3.stride(0), *args, B, H, W, cout, k, k, s,
+                      pad, math, dw.data_ptr(), cin_store, acc, plan, ws.data_ptr(), wsb)
+        got = dw.cpu().double() / 2
+        exact = ref(lambda t: t)[:, :cin_store]
+        if math == 1:
+            close(got, exact, 3e-5, 'dW bf16x6 plan %#x' % plan)
+        else:
+            close(got, ref(lambda t: t.bfloat16().float())[:, :cin_store], 3e-5, 'dW bf16 (rounded operands) plan %#x' % plan)
+            err = float((got - exact).abs().max() / exact.abs().max())
+            assert 1e-5 < err < 2e-2, err
+
+
 def test_amp_step_tracks_the_fp32_step(lib):
     """config.AMP (configs/config.py:89): the convolutions' forward / data gradient run on bf16 operands (one MFMA
     product, fp32 accumulate; the reference autocasts to fp16 with a GradScaler, basic_trainer.py:83-86,222).  The step

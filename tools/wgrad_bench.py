@@ -10,8 +10,12 @@ from swem_amd import _lib, ops  # noqa: E402
 SHAPES = [  # B, H, W, Cin, Cout, k, stride
     (2, 96, 96, 256, 256, 3, 1), (2, 48, 48, 512, 256, 3, 1), (2, 24, 24, 512, 512, 3, 1), (2, 24, 24, 1280, 512, 3, 1),
     (2, 24, 24, 1152, 512, 3, 1), (1, 24, 24, 1024, 256, 1, 1), (1, 24, 24, 256, 256, 3, 1), (1, 96, 96, 64, 64, 3, 1),
-    (2, 96, 96, 64, 64, 3, 1), (1, 48, 48, 128, 128, 3, 1), (1, 96, 96, 64, 256, 1, 1),
+    (2, 96, 96, 64, 64, 3, 1), (1, 48, 48, 128, 128, 3, 1), (1, 96, 96, 64, 256, 1, 1), (2, 48, 48, 256, 512, 3, 2), (2, 25, 23, 72, 40, 3, 1),
+    (2, 96, 96, 256, 64, 1, 1), (1, 192, 192, 64, 64, 3, 1),
 ]
+
+
+PLANS = [0] + [wt | z << 4 for wt in (1, 2) for z in (1, 2, 4, 8, 16)] if '--tune' in sys.argv else [0]
 
 
 def main():
@@ -28,18 +32,40 @@ def main():
         def run():
             _lib.call('swem_conv2d_wgrad_f32', ops._stream(), dy.data_ptr(), x.data_ptr(), ci, H * W * ci, 0, 0, 0, 0, 0, 0,
                       B, H, W, co, k, k, s, pad, 0, dw.data_ptr(), ci, 0, ws.data_ptr(), wsb)
-        for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        us = 1e3 * e0.elapsed_time(e1) / 20
+        def timed(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return 1e3 * e0.elapsed_time(e1) / 20
+        us = timed(run)
         fl = 2.0 * B * Ho * Wo * co * k * k * ci
-        print('%dx%dx%d k%d %4d->%4d  %8.1f us  %6.1f TFLOP/s  (ws %.0f MB)' % (B, H, W, k, ci, co, us, fl / us / 1e6, wsb / 2 ** 20))
+        ref = dw.clone()
+        line = '%dx%dx%d k%d s%d %4d->%4d  fp32 %7.1f us %6.1f TF |' % (B, H, W, k, s, ci, co, us, fl / us / 1e6)
+        if ci % 8 == 0 and co % 8 == 0:
+            x3, d3 = ops.presplit(x), ops.presplit(dy)
+            for math, plans in ((1, PLANS), (2, PLANS)):
+                best = None
+                for plan in plans:
+                    wsb2 = _lib.query('swem_conv2d_wgrad_bf16x3_workspace', B, H, W, ci, 0, 0, co, k, k, s, pad, plan)
+                    ws2 = ops.workspace(wsb2, x.device)
+
+                    def runb():
+                        _lib.call('swem_conv2d_wgrad_bf16x3', ops._stream(), d3.data_ptr(), d3.stride(0), x3.data_ptr(), ci,
+                                  H * W * ci, x3.stride(0), 0, 0, 0, 0, 0, 0, 0, 0, B, H, W, co, k, k, s, pad, math,
+                                  dw.data_ptr(), ci, 0, plan, ws2.data_ptr(), wsb2)
+                    t = timed(runb)
+                    err = float((dw - ref).abs().max() / ref.abs().max())
+                    if best is None or t < best[0]:
+                        best = (t, plan, err)
+                line += ' %s %7.1f us %6.1f TF plan %#x err %.1e |' % ('bf16x6' if math == 1 else 'bf16', best[0],
+                                                                       fl / best[0] / 1e6, best[1], best[2])
+        print(line, flush=True)
 
 
 if __name__ == '__main__':
