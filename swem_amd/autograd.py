@@ -19,10 +19,23 @@ from torch.autograd import Function
 from . import _lib, ops
 
 _PACKS = {}      # (id(weight), tag) -> packed operand; parameters change every optimizer step: new_step() clears it
+_RECIPES = {}    # (id(weight), tag) -> builder of that pack, recorded the first time a step needs it
 
 
-def new_step():
+def new_step(prebuild=False):
+    """Drop the packed filters of the previous step.  prebuild: re-pack everything the previous steps used right away on
+    the current stream -- the training step calls this before it forks its lanes, so the clips in flight share ONE set
+    of packs (built lazily inside a lane they would be private to it: another lane's stream could not see them safely)."""
     _PACKS.clear()
+    if prebuild:
+        for key, build in _RECIPES.items():
+            _PACKS[key] = build()
+
+
+def reset():
+    """Forget the recorded packs (a new trainer / model)."""
+    _PACKS.clear()
+    _RECIPES.clear()
 
 
 def ensure_grads(params):
@@ -76,26 +89,32 @@ def sum_batch(x, out=None, accumulate=False):
 
 
 # --------------------------------------------------------------------------------------------- convolution
-def _fwd_pack(weight, bias, stride, pad, cin_pad):
-    key = (id(weight), 'fwd', cin_pad, _LANE)
+def _shared_pack(key, build):
+    """The step's shared pack if new_step(prebuild=True) made it, else this lane's own (and remember how to build it)."""
     pk = _PACKS.get(key)
     if pk is None:
-        pk = _PACKS[key] = ops.pack_conv(weight, bias, None, stride, pad, cin_pad=cin_pad)
+        _RECIPES.setdefault(key, build)
+        pk = _PACKS.get(key + (_LANE,))
+        if pk is None:
+            pk = _PACKS[key + (_LANE,)] = build()
     return pk
+
+
+def _fwd_pack(weight, bias, stride, pad, cin_pad):
+    return _shared_pack((id(weight), 'fwd', cin_pad),
+                        lambda: ops.pack_conv(weight, bias, None, stride, pad, cin_pad=cin_pad))
 
 
 def _dgrad_pack(weight, off, c, stride, pad, cin_pad):
     """Filters of the data-gradient GEMM for the source that owns input channels [off, off+c): [c][KH][KW][Cout]."""
-    key = (id(weight), 'dgrad', off, c, cin_pad, _LANE)
-    pk = _PACKS.get(key)
-    if pk is None:
+    def build():
         co, ci, kh, kw = weight.shape
         w = weight.detach()
         if cin_pad is not None and cin_pad != ci:
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_pad - ci))
         wt = w[:, off:off + c].permute(1, 2, 3, 0).contiguous()        # [c][KH][KW][Cout]
-        pk = _PACKS[key] = ops.ConvPack(wt, None, None, c, kh, kw, stride, pad)
-    return pk
+        return ops.ConvPack(wt, None, None, c, kh, kw, stride, pad)
+    return _shared_pack((id(weight), 'dgrad', off, c, cin_pad), build)
 
 
 def wgrad_math(cs, cout, kh, kw, M):

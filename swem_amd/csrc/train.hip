@@ -414,11 +414,19 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ c
 // Backward of bn_act in one pass: dz = dy * (y > 0) (also the residual's gradient), dc = dz * alpha (the conv output's
 // gradient), and per block the column partials s1 = sum dz, s2 = sum dz * c for the BatchNorm parameters.
 // Block = 16 channel quads x 16 row lanes over BN_ROWS rows.
-constexpr int BN_ROWS = 512;
+// Rows per block: enough blocks to fill the chip (a 192x192x64 stem map has ONE 64-channel column block), at most 512
+// rows, a multiple of the 16 row lanes.
+static inline int bn_rows(long long M, int C) {
+  const long long cb = cdiv(C / 4, 16);
+  long long rows = (M * cb + 2047) / 2048;
+  rows = (rows + 15) / 16 * 16;
+  return (int)(rows < 32 ? 32 : (rows > 512 ? 512 : rows));
+}
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
                                                          const float *__restrict__ c, const float *__restrict__ alpha,
                                                          float *__restrict__ dz, float *__restrict__ dc,
-                                                         float *__restrict__ part, long long M, int C, int relu) {
+                                                         float *__restrict__ part, long long M, int C, int relu,
+                                                         int BN_ROWS) {
   __shared__ float4 sh1[256], sh2[256];
   const int cq = C / 4;
   const int c4 = blockIdx.x * 16 + (threadIdx.x & 15);
@@ -427,6 +435,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   if (c4 < cq) {
     const float4 a = ld4t(alpha + c4 * 4);
+#pragma unroll 2
     for (long long m = m0 + rsub; m < m1; m += 16) {
       const long long i = m * C + c4 * 4;
       float4 g = ld4t(dy + i);
@@ -459,16 +468,26 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict
   }
 }
 // dgamma += invstd * (s2 - mean * s1); dbeta += s1, with s1 / s2 summed over the row blocks in order
-__global__ void bn_param_grad_kernel(const float *__restrict__ part, int nrow, const float *__restrict__ mean,
-                                     const float *__restrict__ invstd, float *__restrict__ dgamma,
-                                     float *__restrict__ dbeta, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// (block = 64 channels x 4 row lanes; lane r sums rows r, r+4, ... in order, the four lanes are combined in order)
+__global__ __launch_bounds__(256) void bn_param_grad_kernel(const float *__restrict__ part, int nrow,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd, float *__restrict__ dgamma,
+                                                            float *__restrict__ dbeta, int C) {
+  __shared__ float sh[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s1 = 0.f, s2 = 0.f;
-  for (int j = 0; j < nrow; ++j) {
-    s1 += part[((long long)j * 2) * C + c];
-    s2 += part[((long long)j * 2 + 1) * C + c];
-  }
+  if (c < C)
+    for (int j = rl; j < nrow; j += 4) {
+      s1 += part[((long long)j * 2) * C + c];
+      s2 += part[((long long)j * 2 + 1) * C + c];
+    }
+  sh[0][rl][cl] = s1;
+  sh[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  s1 = ((sh[0][0][cl] + sh[0][1][cl]) + sh[0][2][cl]) + sh[0][3][cl];
+  s2 = ((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl];
   if (dgamma) dgamma[c] += invstd[c] * (s2 - mean[c] * s1);
   if (dbeta) dbeta[c] += s1;
 }
@@ -780,7 +799,7 @@ extern "C" int swem_bn_act_f32(void *stream, const float *c, const float *alpha,
 }
 extern "C" size_t swem_bn_act_bwd_workspace(long long M, int C) {
   if (M <= 0 || C <= 0) return 0;
-  return (size_t)cdiv(M, BN_ROWS) * 2 * C * sizeof(float);
+  return (size_t)cdiv(M, bn_rows(M, C)) * 2 * C * sizeof(float);
 }
 extern "C" int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y, const float *c, const float *alpha,
                                    const float *mean, const float *invstd, float *dz, float *dc, float *dgamma,
@@ -788,7 +807,7 @@ extern "C" int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y
   SWEM_REQUIRE(dy && alpha && dc && (y || !relu) && C % 4 == 0 && M > 0, SWEM_E_ARG, "bn_act_bwd: bad argument");
   const bool params = dgamma || dbeta;
   SWEM_REQUIRE(!params || (c && mean && invstd), SWEM_E_ARG, "bn_act_bwd: parameter gradients need c, mean, invstd");
-  const int nrow = cdiv(M, BN_ROWS);
+  const int rows = bn_rows(M, C), nrow = cdiv(M, rows);
   float *part = nullptr;
   if (params) {
     const size_t need = swem_bn_act_bwd_workspace(M, C);
@@ -796,10 +815,10 @@ extern "C" int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y
     part = static_cast<float *>(ws);
   }
   hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(cdiv(C / 4, 16), nrow), dim3(256), 0, STT, dy, y, c, alpha, dz, dc, part, M,
-                     C, relu);
+                     C, relu, rows);
   SWEM_CHECK_LAUNCH("bn_act_bwd_kernel");
   if (params) {
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, STT, part, nrow, mean, invstd, dgamma,
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 64)), dim3(256), 0, STT, part, nrow, mean, invstd, dgamma,
                        dbeta, C);
     SWEM_CHECK_LAUNCH("bn_param_grad_kernel");
   }

@@ -160,7 +160,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
   constexpr int IMG = 32 * 128;                 // bytes of one 32-pixel x 64-channel image
   constexpr int OPB = WT * NPL * IMG;           // one operand of one stage: [image][plane]
   constexpr int STAGE = 2 * OPB;                // dY images, then x images
-  constexpr int NDMA = 2 * WT * NPL;            // transfers per wave per slab
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -307,28 +306,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
     }
 }
 
-// sum the pixel slices in order, write OIHW (the reference's parameter layout), optionally accumulate
+// sum the pixel slices in order, write OIHW (the reference's parameter layout), optionally accumulate.  Block = one
+// filter x 64 input channels: the partials are read along ci (coalesced) for every tap, transposed through LDS, and
+// stored as one contiguous run of 64 * taps floats of dw.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial,
                                                                 float *__restrict__ dw, int Cout, int Cin, int taps,
                                                                 int Cin_store, int zsplit, int accumulate) {
-  const long long K = (long long)taps * Cin;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)Cout * K) return;
-  const int n = (int)(i / K);
-  const long long k = i - (long long)n * K;
-  const int tap = (int)(k / Cin), ci = (int)(k - (long long)tap * Cin);
-  if (ci >= Cin_store) return;       // zero-padded input channels of the stems have no parameter
-  float s = 0.f;
-  for (int z = 0; z < zsplit; ++z) s += partial[(long long)z * Cout * K + i];
-  float *o = dw + ((long long)n * Cin_store + ci) * taps + tap;
-  *o = accumulate ? *o + s : s;
+  extern __shared__ float red_s[];   // [64][taps]
+  const int n = blockIdx.y, c0 = blockIdx.x * 64;
+  const int nc = min(64, Cin_store - c0);
+  const long long K = (long long)taps * Cin, zs = (long long)Cout * K;
+  const float *src = partial + (long long)n * K + c0;
+  for (int idx = threadIdx.x; idx < 64 * taps; idx += 256) {
+    const int tap = idx >> 6, cl = idx & 63;
+    float s = 0.f;
+    if (cl < nc)
+      for (int z = 0; z < zsplit; ++z) s += src[z * zs + (long long)tap * Cin + cl];
+    red_s[cl * taps + tap] = s;
+  }
+  __syncthreads();
+  float *o = dw + ((long long)n * Cin_store + c0) * taps;
+  for (int idx = threadIdx.x; idx < nc * taps; idx += 256) o[idx] = accumulate ? o[idx] + red_s[idx] : red_s[idx];
 }
 
 // per-column sums of a [M][C] matrix (optionally of the product with a second one): stage 1 = one partial row per
 // block row, stage 2 = fixed-order sum.  Serves the bias / frozen-BatchNorm parameter gradients.
-constexpr int CS_ROWS = 512;  // rows per stage-1 block
+static inline int cs_rows(long long M, int C) {  // rows per stage-1 block: enough blocks to fill the chip, <= 512
+  const long long cb = cdiv(C / 4, 16);
+  long long rows = (M * cb + 2047) / 2048;
+  rows = (rows + 15) / 16 * 16;
+  return (int)(rows < 32 ? 32 : (rows > 512 ? 512 : rows));
+}
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ a, const float *__restrict__ b,
-                                                             float *__restrict__ part, long long M, int C) {
+                                                             float *__restrict__ part, long long M, int C, int CS_ROWS) {
   __shared__ float4 sh1[256], sh2[256];
   const int cq = C / 4;
   const int c4 = blockIdx.x * 16 + (threadIdx.x & 15);
@@ -361,13 +371,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, float *__restrict__ out1,
                                                            float *__restrict__ out2, int nrow, int C,
                                                            int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  // block = 64 columns x 4 row lanes; lane r sums rows r, r+4, ... in order, the lanes are combined in order
+  __shared__ float sh[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s1 = 0.f, s2 = 0.f;
-  for (int j = 0; j < nrow; ++j) {
-    s1 += part[((long long)j * 2) * C + c];
-    s2 += part[((long long)j * 2 + 1) * C + c];
-  }
+  if (c < C)
+    for (int j = rl; j < nrow; j += 4) {
+      s1 += part[((long long)j * 2) * C + c];
+      s2 += part[((long long)j * 2 + 1) * C + c];
+    }
+  sh[0][rl][cl] = s1;
+  sh[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  s1 = ((sh[0][0][cl] + sh[0][1][cl]) + sh[0][2][cl]) + sh[0][3][cl];
+  s2 = ((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl];
   if (out1) out1[c] = accumulate ? out1[c] + s1 : s1;
   if (out2) out2[c] = accumulate ? out2[c] + s2 : s2;
 }
@@ -465,7 +484,7 @@ extern "C" int swem_conv2d_wgrad_f32(void *stream, const float *dy, const float 
     SWEM_CHECK_LAUNCH("conv_wgrad_kernel");
     off += cs[s];
   }
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((long long)Cout * p.K, 256)), dim3(256), 0, st, p.partial, dw,
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(cin_store, 64), Cout), dim3(256), 64 * KH * KW * sizeof(float), st, p.partial, dw,
                      Cout, Cin, KH * KW, cin_store, pl.zsplit, accumulate);
   SWEM_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
   return SWEM_OK;
@@ -562,7 +581,7 @@ extern "C" int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3,
     SWEM_CHECK_LAUNCH("conv_wgrad_bf_kernel");
     off += cs[s];
   }
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((long long)Cout * p.K, 256)), dim3(256), 0, st, p.partial, dw,
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(cin_store, 64), Cout), dim3(256), 64 * KH * KW * sizeof(float), st, p.partial, dw,
                      Cout, Cin, KH * KW, cin_store, pl.zsplit, accumulate);
   SWEM_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
   return SWEM_OK;
@@ -570,7 +589,7 @@ extern "C" int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3,
 
 extern "C" size_t swem_colsum_workspace(long long M, int C) {
   if (M <= 0 || C <= 0) return 0;
-  return (size_t)cdiv(M, CS_ROWS) * 2 * C * sizeof(float);
+  return (size_t)cdiv(M, cs_rows(M, C)) * 2 * C * sizeof(float);
 }
 
 extern "C" int swem_colsum_f32(void *stream, const float *a, const float *b, float *out1, float *out2, long long M,
@@ -580,11 +599,11 @@ extern "C" int swem_colsum_f32(void *stream, const float *a, const float *b, flo
   const size_t need = swem_colsum_workspace(M, C);
   SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "colsum: workspace %zu < %zu bytes", ws_bytes, need);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int nrow = cdiv(M, CS_ROWS);
+  const int rows = cs_rows(M, C), nrow = cdiv(M, rows);
   float *part = static_cast<float *>(ws);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C / 4, 16), nrow), dim3(256), 0, st, a, b, part, M, C);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C / 4, 16), nrow), dim3(256), 0, st, a, b, part, M, C, rows);
   SWEM_CHECK_LAUNCH("colsum_partial_kernel");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, out1, out2, nrow, C, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, part, out1, out2, nrow, C, accumulate);
   SWEM_CHECK_LAUNCH("colsum_final_kernel");
   return SWEM_OK;
 }

@@ -91,7 +91,11 @@ class ConvPack:
         self.cin_true = self.cin          # channels of the reference conv (without layout padding)
         co, kk = w.shape[0], w.shape[1] * w.shape[2] * w.shape[3]
         # the same filters as three bf16 planes, k/8-group major [K/8][Cout'][8] (bf16x6 math mode, pre-split form)
-        self.w3 = split_bf16x3(w.reshape(co, kk // 8, 8).permute(1, 0, 2).contiguous()) if kk % 8 == 0 else None
+        # (the activation split kernel on the [Cout'][K] matrix: one launch; the training step re-packs every step)
+        self.w3 = None
+        if kk % 8 == 0:
+            self.w3 = torch.empty((3, co * kk), dtype=torch.bfloat16, device=w.device)
+            _lib.call('swem_split_bf16x3_f32', _stream(), w.data_ptr(), self.w3.data_ptr(), co, kk, 0)
 
 
 def split_bf16x3(w):

@@ -164,6 +164,7 @@ class SWEMTrainer:
         for mod in model.modules():                    # BasicTrainer.set_bn_eval (swem_trainer.py:37-39)
             if mod.__class__.__name__.find('BatchNorm') != -1:
                 mod.eval()
+        A.reset()
         self.optimizer = optim.make_optimizer(_get(config, 'SOLVER'), model, num_gpu)
         self.lr_scheduler = optim.make_lr_scheduler(_get(config, 'SOLVER'), self.optimizer)
         self.criterion = L.get_criterion(_get(config, 'LOSS'), None, 1, 1, dev)
@@ -245,7 +246,7 @@ class SWEMTrainer:
         B = bf['frames'].shape[0]
         ls = self._lanes(B)
         n = len(ls['streams'])
-        A.new_step()
+        A.new_step(prebuild=True)
         ls['flat'].zero_()
         ls['sums'].zero_()
         main = torch.cuda.current_stream()
