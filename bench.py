@@ -308,7 +308,7 @@ def main():
         def em_concurrent(n_streams, reps=20):
             a_mem, k_mem = cap['mem']
             a_mat, k_mat = cap['match']
-            graphs, sts = [], []
+            graphs, sts, keep = [], [], []      # keep: the graphs replay on these argument tensors
             em_streams = evaluator.overlapping_streams(n_streams)
             for si in range(n_streams):
                 am = [t.clone() if torch.is_tensor(t) else t for t in a_mem]
@@ -327,6 +327,7 @@ def main():
                             fn()
                 graphs.append(gr)
                 sts.append(st_)
+                keep.append((am, aq))
             torch.cuda.synchronize()
             best = None
             for _ in range(3):

@@ -100,12 +100,16 @@ int swem_split_bf16x3_f32(void *stream, const float *x, void *out, long long npi
 /* The same convolution as swem_conv2d_nhwc_f32 in bf16x6 math with PRE-SPLIT sources and filters: xK = plane 0 of
  * source K in the layout above (npix = all pixels of its storage; bsK = fp32-element batch stride as before, a
  * multiple of cK), psK = elements between its three planes (npix * cK), cK % 32 == 0;
- * w_bf16x3 = three planes [K/8][Cout'][8], K = KH*KW*Cin ordered (ky, kx, ci).
+ * w_bf16x3 = three planes [K/8][Cout'][8], K = KH*KW*Cin ordered (ci / 32, ky, kx, ci % 32) over the concatenated input
+ * channels ("channel-block major": the KH*KW taps of a 32-channel block are consecutive k-blocks, so a tile's activations
+ * are fetched from HBM once instead of once per tap); KH*KW <= 64.
  * Every fragment goes HBM/L2 -> LDS by buffer-load-to-LDS (no register staging, no vector arithmetic in the k-loop).
  * Output, scale/shift/residual/ReLU-out/GLU, plan and workspace as swem_conv2d_nhwc_f32 (math bit ignored).
  * Plan bits 20-23 pick a kernel variant: 0 = the tile's default LDS ring (three stages for 64x64, two otherwise),
  * 1 = the other stage count, 2 / 3 = the 128x128 tile on eight waves with two / three stages, 4 / 6 = variants 0 / 2 on
- * v_mfma_f32_16x16x32_bf16 instead of 32x32x16; bits 24-27 = K-split factor of the last, partly filled round of tiles. */
+ * v_mfma_f32_16x16x32_bf16 instead of 32x32x16; bits 24-27 = K-split factor of the last, partly filled round of tiles; bits 28-29 = log2 of the XCD partition of the
+ * N tiles (1-3: 2 / 4 / 8 groups of N tiles, 8/groups XCDs per group, each XCD reading only its group's filters; 0: chosen
+ * by the traffic model groups * activations + (8 / groups) * filters; ignored where the N tiles do not divide). */
 int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1, int c1,
                             long long bs1, long long ps1, const void *x2, int c2, long long bs2, long long ps2, int B,
                             int H, int W, const void *w_bf16x3, const float *scale, const float *shift,

@@ -41,11 +41,13 @@ struct ConvP {
   const unsigned short *wsplit;  // optional [3][Ncols][K] bf16: the filters pre-split into hi/mid/lo planes
   const unsigned short *xs[3];   // pre-split activations (conv_igemm_bf3s_kernel): plane 0 of each source
   long long ps[3];               // ... and the element stride between a source's three planes
+  int bsp[3], npx[3];            // pre-split sources: batch stride in pixels, pixels per plane (host-side divisions)
   float *y;
   int Cout, Ncols, KH, KW, stride, pad, flags;
   int nkb, kb_per_split;
   float *partial;
   int nplanes;  // 3 = bf16x6 (hi/mid/lo planes, six products), 1 = plain bf16 (hi plane only)
+  int xpn;      // XCD partition of the N tiles (1, 2, 4, 8): see tile_coords
   int mt0;      // first M tile of this launch (the tail launch of a tail-split layer starts further down)
   int part_m0;  // first output row held by `partial` (rows are stored relative to it)
 };
@@ -61,13 +63,19 @@ __device__ __forceinline__ float relu1(float x) {
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so the
 // linear id is remapped to give every XCD one contiguous range of tiles, with the N tiles of one M tile adjacent:
 // the tiles that share activation rows (same M tile, neighbouring M tiles' 3x3 halo) then hit the same L2.
+// With xpn > 1 the N tiles are first cut into xpn groups and the order runs group by group (M tiles outer, the group's
+// N tiles inner): 8 / xpn XCDs share one group and split its M tiles, so an XCD fetches 1/xpn of the filters and
+// xpn/8 of the activations instead of all filters and 1/8 of the activations -- the cheaper cut where the filters
+// outweigh the activations (the 30x54 layers: 60 MB of filter planes against 20 MB of activation planes).
 // Placement only changes speed, never results.
-__device__ __forceinline__ void tile_coords(int &mt, int &nt) {
+__device__ __forceinline__ void tile_coords(int &mt, int &nt, int xpn = 1) {
   const int nwg = gridDim.x * gridDim.y, id = blockIdx.x + blockIdx.y * gridDim.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, local = id >> 3;
   const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  mt = nid / (int)gridDim.y;
-  nt = nid - mt * (int)gridDim.y;
+  const int ng = (int)gridDim.y / xpn, G = (int)gridDim.x * ng;   // N tiles per group, tiles per group
+  const int jn = nid / G, rem = nid - jn * G;
+  mt = rem / ng;
+  nt = jn * ng + rem - mt * ng;
 }
 
 __device__ __forceinline__ float4 relu4(float4 v) { return make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)); }
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvP p) {
 
   // buffer descriptors (wave-uniform: built from kernel arguments and block-uniform scalars only)
   const long long HWin = (long long)p.H * p.W;
-  auto src_rsrc = [&](int sidx) {
+  auto src_rsrc = [&](int sidx) __attribute__((always_inline)) {
     const float *base = sidx == 0 ? p.x[0] : (sidx == 1 ? p.x[1] : p.x[2]);
     const int cs = sidx == 0 ? p.c[0] : (sidx == 1 ? p.c[1] : p.c[2]);
     const long long bs = sidx == 0 ? p.bs[0] : (sidx == 1 ? p.bs[1] : p.bs[2]);
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(ConvP p) {
   const int kq = tid & 7, rbase = tid >> 3;
 
   const long long HWin = (long long)p.H * p.W;
-  auto src_rsrc = [&](int sidx) {
+  auto src_rsrc = [&](int sidx) __attribute__((always_inline)) {
     const float *base = sidx == 0 ? p.x[0] : (sidx == 1 ? p.x[1] : p.x[2]);
     const int cs = sidx == 0 ? p.c[0] : (sidx == 1 ? p.c[1] : p.c[2]);
     const long long bs = sidx == 0 ? p.bs[0] : (sidx == 1 ? p.bs[1] : p.bs[2]);
@@ -851,11 +859,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   int tm, tn;
-  tile_coords(tm, tn);
+  tile_coords(tm, tn, p.xpn);
   tm += p.mt0;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  auto src_rsrc = [&](int sidx) {
+  auto src_rsrc = [&](int sidx) __attribute__((always_inline)) {
     const unsigned short *base = sidx == 0 ? p.xs[0] : (sidx == 1 ? p.xs[1] : p.xs[2]);
     const long long ps = sidx == 0 ? p.ps[0] : (sidx == 1 ? p.ps[1] : p.ps[2]);
     return raw_rsrc(base, (unsigned)(3 * ps * 2));
@@ -893,45 +901,69 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   unsigned a_base = 0;              // scalar offset of (current k-block, group g) in plane 0 of the current source
   unsigned w_base = 0;              // ... of the filter planes
   i32x4 rsa;
-  auto set_tap = [&](const KPos &q) {
-    const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
-    const long long bs = q.src == 0 ? p.bs[0] : (q.src == 1 ? p.bs[1] : p.bs[2]);
+  // K order of this kernel: k = (ci / 32, ky, kx, ci % 32) over the concatenated input channels ("channel-block major";
+  // the filter planes are packed in that order).  With the usual tap-major order (ky, kx, ci) a tap is one pass over all
+  // input channels, so a block re-reads its pixels' neighbourhood KH*KW times, each time long after the last: with ~13
+  // blocks per XCD the footprint of a pass exceeds the 4 MiB L2 and the activations are fetched once per tap (measured
+  // on 2x30x54x1280 -> 512: 8 x filters + 9 x activations).  Here the KH*KW taps of one 32-channel block are
+  // consecutive k-blocks and the re-reads hit the L2 right away.  The tap changes every k-block, so its per-lane cost
+  // must be a couple of vector instructions: the lane keeps the pixel index of tap (0, 0) and a validity bit per tap;
+  // the tap's offset is that index plus a wave-uniform delta (forward: +(ky W + kx); data gradient: -((ky >> s) W +
+  // (kx >> s)) with s = stride - 1, because a valid tap has i = (o0 - k) / stride = (o0 >> s) - (k >> s)).
+  const int dsh = (p.flags & SWEM_CONV_DGRAD) ? p.stride - 1 : 0;
+  int pix0[WM];
+  unsigned long long tmask[WM];
 #pragma unroll
-    for (int j = 0; j < WM; ++j) {
-      int iy, ix;
-      const bool oky = tap_coord(p, iy0[j], q.ky, p.H, iy), okx = tap_coord(p, ix0[j], q.kx, p.W, ix);
-      const bool ok = bidx[j] >= 0 && oky && okx;
-      const long long pix = bidx[j] * (bs / cs) + (long long)iy * p.W + ix;  // pixel index in the source's storage
-      avoff[j] = ok ? (unsigned)(pix * 16) : OOB;
-    }
+  for (int j = 0; j < WM; ++j) {
+    unsigned long long mk = 0;
+    for (int ky = 0; ky < p.KH; ++ky)
+      for (int kx = 0; kx < p.KW; ++kx) {
+        int iy, ix;
+        const bool ok = bidx[j] >= 0 && tap_coord(p, iy0[j], ky, p.H, iy) && tap_coord(p, ix0[j], kx, p.W, ix);
+        mk |= (unsigned long long)(ok ? 1 : 0) << (ky * p.KW + kx);
+      }
+    tmask[j] = mk;
+  }
+  auto set_src = [&](const KPos &q) __attribute__((always_inline)) {
     const long long ps = q.src == 0 ? p.ps[0] : (q.src == 1 ? p.ps[1] : p.ps[2]);
+    const int npx = q.src == 0 ? p.npx[0] : (q.src == 1 ? p.npx[1] : p.npx[2]);
+    const int bsp = q.src == 0 ? p.bsp[0] : (q.src == 1 ? p.bsp[1] : p.bsp[2]);
     aplane = (unsigned)(ps * 2);
-    agroup = (unsigned)(ps / cs * 16);  // pixels in the plane * 16 bytes
+    agroup = (unsigned)npx * 16u;       // pixels in the plane * 16 bytes
     a_base = (unsigned)(q.ci0 / 8 + g) * agroup;
     rsa = src_rsrc(q.src);
+#pragma unroll
+    for (int j = 0; j < WM; ++j)
+      pix0[j] = (bidx[j] < 0 ? 0 : bidx[j]) * bsp + (iy0[j] >> dsh) * p.W + (ix0[j] >> dsh);
   };
-  auto advance = [&](KPos &q) {
-    q.ci0 += BK;
-    a_base += (BK / 8) * agroup;
+  auto set_tap = [&](const KPos &q) __attribute__((always_inline)) {
+    const int t = q.ky * p.KW + q.kx;
+    const int d = (q.ky >> dsh) * p.W + (q.kx >> dsh);
+    const int delta = (p.flags & SWEM_CONV_DGRAD) ? -d : d;
+#pragma unroll
+    for (int j = 0; j < WM; ++j) avoff[j] = ((tmask[j] >> t) & 1ull) ? (unsigned)(pix0[j] + delta) * 16u : OOB;
+  };
+  auto advance = [&](KPos &q) __attribute__((always_inline)) {
     w_base += (BK / 8) * wgroup;
-    const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
-    if (q.ci0 >= cs) {
-      q.ci0 = 0;
-      ++q.src;
-      const int cn = q.src == 1 ? p.c[1] : (q.src == 2 ? p.c[2] : 0);
-      if (cn == 0) {
-        q.src = 0;
-        if (++q.kx == p.KW) {
-          q.kx = 0;
-          ++q.ky;
+    if (++q.kx == p.KW) {
+      q.kx = 0;
+      if (++q.ky == p.KH) {
+        q.ky = 0;
+        q.ci0 += BK;
+        a_base += (BK / 8) * agroup;
+        const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
+        if (q.ci0 >= cs) {
+          q.ci0 = 0;
+          ++q.src;
+          set_src(q);
         }
       }
-      set_tap(q);
     }
+    set_tap(q);
   };
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   const unsigned lds_a = lds0 + (unsigned)g * (SA * 16), lds_b = lds0 + NST * NPL * PA * 16 + (unsigned)g * (SB * 16);
-  auto issue = [&](int stage) {
+  auto issue = [&](int stage) __attribute__((always_inline)) {
     const unsigned sa = lds_a + (unsigned)stage * (NPL * PA * 16), sb = lds_b + (unsigned)stage * (NPL * PB * 16);
     if (NW == 4 || half == 0) {
 #pragma unroll
@@ -972,7 +1004,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   // this wave, i.e. everything up to block kb+1) and a raw s_barrier publish stage (kb+1)%NST.  __syncthreads() would
   // drain vmcnt(0) and serialise the ~1-2 us L2/MALL -> LDS latency with every 0.3 us of MFMA work.
   KPos q;
-  kpos_init(q, p, kb_begin);
+  {   // k-block kb = (channel block, tap)
+    const int taps = p.KH * p.KW;
+    int cb = kb_begin / taps;
+    const int t = kb_begin - cb * taps;
+    q.ky = t / p.KW;
+    q.kx = t - q.ky * p.KW;
+    q.src = 0;
+    int ci = cb * BK;
+    if (ci >= p.c[0]) {
+      ci -= p.c[0];
+      q.src = 1;
+      if (ci >= p.c[1]) {
+        ci -= p.c[1];
+        q.src = 2;
+      }
+    }
+    q.ci0 = ci;
+    set_src(q);
+  }
   w_base = (unsigned)(kb_begin * (BK / 8) + g) * wgroup;
   set_tap(q);
   issue(0);
@@ -1330,7 +1380,7 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
   Plan pl = resolve_plan(plan, p.M, p.Ncols, p.nkb, glu);
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;
-  p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3;
+  p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.xpn = 1;
   if (pl.nsplit > 1) {
     size_t need = (size_t)pl.nsplit * M * p.Ncols * sizeof(float);
     SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d: workspace %zu < %zu bytes", ws_bytes, need);
@@ -1442,6 +1492,10 @@ extern "C" int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, lon
   p.ps[0] = ps0; p.ps[1] = x1 ? ps1 : ps0; p.ps[2] = x2 ? ps2 : ps0;
   p.c[0] = c0; p.c[1] = c1; p.c[2] = c2;
   p.bs[0] = bs0; p.bs[1] = bs1; p.bs[2] = bs2;
+  for (int i = 0; i < 3; ++i) {
+    p.bsp[i] = p.c[i] > 0 ? (int)(p.bs[i] / p.c[i]) : 0;
+    p.npx[i] = p.c[i] > 0 ? (int)(p.ps[i] / p.c[i]) : 0;
+  }
   SWEM_REQUIRE(ps0 * 6 < (1ll << 31) && p.ps[1] * 6 < (1ll << 31) && p.ps[2] * 6 < (1ll << 31), SWEM_E_SHAPE,
                "conv2d_bf16x3: a source exceeds the 2 GiB buffer-descriptor range");
   p.B = B; p.H = H; p.W = W;
@@ -1462,16 +1516,44 @@ extern "C" int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, lon
   Plan pl = resolve_plan(plan, p.M, p.Ncols, p.nkb, glu);
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;
-  p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3;
+  p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.xpn = 1;
   if (pl.nsplit > 1) {
     size_t need = (size_t)pl.nsplit * M * p.Ncols * sizeof(float);
     SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_bf16x3: workspace %zu < %zu bytes", ws_bytes, need);
     p.partial = static_cast<float *>(ws);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  SWEM_REQUIRE(KH * KW <= 64, SWEM_E_SHAPE, "conv2d_bf16x3: at most 64 filter taps (one validity bit per tap and pixel)");
   const int variant = (plan >> 20) & 15;
   p.nplanes = ((plan >> 16) & 3) == 2 ? 1 : 3;   // math 2 = plain bf16 (mixed-precision training), else bf16x6
   const int mtiles = cdiv(p.M, 64 * pl.wm), ntiles = cdiv(p.Ncols, 64 * pl.wn);
+  // XCD partition of the N tiles: plan bits 28-29 force 2 / 4 / 8 groups; 0 = the cut with the least fetch traffic by
+  // the model  groups * activations + (8 / groups) * filters  (each XCD reads its groups' filters and its share of the
+  // M tiles' activations once: measured 533 -> 166 MB on 2x30x54x1280 -> 512 together with the channel-block K order)
+  p.xpn = 1 << ((plan >> 28) & 3);
+  if (((plan >> 28) & 3) == 0) {
+    static int forced = -1;
+    if (forced < 0) {
+      const char *e = getenv("SWEM_CONV_XPN");
+      forced = e ? atoi(e) : 0;
+    }
+    if (forced > 0) {
+      p.xpn = forced;
+    } else {
+      const double abytes = (double)B * H * W * p.Cin, wbytes = (double)p.Ncols * p.K;
+      double best = abytes + 8.0 * wbytes;
+      for (int pn = 2; pn <= 8; pn *= 2) {
+        if (ntiles % pn) continue;
+        const double cost = pn * abytes + (8.0 / pn) * wbytes;
+        if (cost < 0.9 * best) {
+          best = cost;
+          p.xpn = pn;
+        }
+      }
+    }
+  }
+  if (p.xpn != 1 && p.xpn != 2 && p.xpn != 4 && p.xpn != 8) p.xpn = 1;
+  if (ntiles % p.xpn) p.xpn = 1;
   auto run = [&](const ConvP &q, dim3 grid) {
     if (pl.wm == 2 && pl.wn == 2) return launch_bf3s<2, 2>(q, grid, st, variant);
     if (pl.wm == 1 && pl.wn == 2) return launch_bf3s<1, 2>(q, grid, st, variant);

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ c
 // rows, a multiple of the 16 row lanes.
 static inline int bn_rows(long long M, int C) {
   const long long cb = cdiv(C / 4, 16);
-  long long rows = (M * cb + 2047) / 2048;
+  long long rows = (M * cb + 1023) / 1024;
   rows = (rows + 15) / 16 * 16;
   return (int)(rows < 32 ? 32 : (rows > 512 ? 512 : rows));
 }
@@ -468,17 +468,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict
   }
 }
 // dgamma += invstd * (s2 - mean * s1); dbeta += s1, with s1 / s2 summed over the row blocks in order
-// (block = 64 channels x 4 row lanes; lane r sums rows r, r+4, ... in order, the four lanes are combined in order)
+// (block = 16 channels x 16 row lanes; lane r sums rows r, r+16, ... in order, the lanes are combined in order)
 __global__ __launch_bounds__(256) void bn_param_grad_kernel(const float *__restrict__ part, int nrow,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd, float *__restrict__ dgamma,
                                                             float *__restrict__ dbeta, int C) {
-  __shared__ float sh[2][4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ float sh[2][16][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float s1 = 0.f, s2 = 0.f;
   if (c < C)
-    for (int j = rl; j < nrow; j += 4) {
+    for (int j = rl; j < nrow; j += 16) {
       s1 += part[((long long)j * 2) * C + c];
       s2 += part[((long long)j * 2 + 1) * C + c];
     }
@@ -486,8 +486,12 @@ __global__ __launch_bounds__(256) void bn_param_grad_kernel(const float *__restr
   sh[1][rl][cl] = s2;
   __syncthreads();
   if (rl != 0 || c >= C) return;
-  s1 = ((sh[0][0][cl] + sh[0][1][cl]) + sh[0][2][cl]) + sh[0][3][cl];
-  s2 = ((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl];
+  s1 = sh[0][0][cl];
+  s2 = sh[1][0][cl];
+  for (int j = 1; j < 16; ++j) {
+    s1 += sh[0][j][cl];
+    s2 += sh[1][j][cl];
+  }
   if (dgamma) dgamma[c] += invstd[c] * (s2 - mean[c] * s1);
   if (dbeta) dbeta[c] += s1;
 }
@@ -818,7 +822,7 @@ extern "C" int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y
                      C, relu, rows);
   SWEM_CHECK_LAUNCH("bn_act_bwd_kernel");
   if (params) {
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 64)), dim3(256), 0, STT, part, nrow, mean, invstd, dgamma,
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 16)), dim3(256), 0, STT, part, nrow, mean, invstd, dgamma,
                        dbeta, C);
     SWEM_CHECK_LAUNCH("bn_param_grad_kernel");
   }

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
 // block row, stage 2 = fixed-order sum.  Serves the bias / frozen-BatchNorm parameter gradients.
 static inline int cs_rows(long long M, int C) {  // rows per stage-1 block: enough blocks to fill the chip, <= 512
   const long long cb = cdiv(C / 4, 16);
-  long long rows = (M * cb + 2047) / 2048;
+  long long rows = (M * cb + 1023) / 1024;
   rows = (rows + 15) / 16 * 16;
   return (int)(rows < 32 ? 32 : (rows > 512 ? 512 : rows));
 }
@@ -371,13 +371,13 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, float *__restrict__ out1,
                                                            float *__restrict__ out2, int nrow, int C,
                                                            int accumulate) {
-  // block = 64 columns x 4 row lanes; lane r sums rows r, r+4, ... in order, the lanes are combined in order
-  __shared__ float sh[2][4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  // block = 16 columns x 16 row lanes; lane r sums rows r, r+16, ... in order, the lanes are combined in order
+  __shared__ float sh[2][16][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float s1 = 0.f, s2 = 0.f;
   if (c < C)
-    for (int j = rl; j < nrow; j += 4) {
+    for (int j = rl; j < nrow; j += 16) {
       s1 += part[((long long)j * 2) * C + c];
       s2 += part[((long long)j * 2 + 1) * C + c];
     }
@@ -385,8 +385,12 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restri
   sh[1][rl][cl] = s2;
   __syncthreads();
   if (rl != 0 || c >= C) return;
-  s1 = ((sh[0][0][cl] + sh[0][1][cl]) + sh[0][2][cl]) + sh[0][3][cl];
-  s2 = ((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl];
+  s1 = sh[0][0][cl];
+  s2 = sh[1][0][cl];
+  for (int j = 1; j < 16; ++j) {
+    s1 += sh[0][j][cl];
+    s2 += sh[1][j][cl];
+  }
   if (out1) out1[c] = accumulate ? out1[c] + s1 : s1;
   if (out2) out2[c] = accumulate ? out2[c] + s2 : s2;
 }
@@ -603,7 +607,7 @@ extern "C" int swem_colsum_f32(void *stream, const float *a, const float *b, flo
   float *part = static_cast<float *>(ws);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C / 4, 16), nrow), dim3(256), 0, st, a, b, part, M, C, rows);
   SWEM_CHECK_LAUNCH("colsum_partial_kernel");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, part, out1, out2, nrow, C, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, part, out1, out2, nrow, C, accumulate);
   SWEM_CHECK_LAUNCH("colsum_final_kernel");
   return SWEM_OK;
 }

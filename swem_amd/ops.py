@@ -4,6 +4,7 @@ torch is used for device memory and the current HIP stream only; every value is 
 a kernel of libswem_hip.so.  All activations are NHWC fp32 tensors ``(B, H, W, C)``.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -92,10 +93,15 @@ class ConvPack:
         co, kk = w.shape[0], w.shape[1] * w.shape[2] * w.shape[3]
         # the same filters as three bf16 planes, k/8-group major [K/8][Cout'][8] (bf16x6 math mode, pre-split form)
         # (the activation split kernel on the [Cout'][K] matrix: one launch; the training step re-packs every step)
+        # the planes' K axis runs (ci / 32, ky, kx, ci % 32), not (ky, kx, ci): swem_conv2d_nhwc_bf16x3 walks the taps of
+        # one 32-channel block back to back, so a tile's activations are fetched once instead of once per tap
         self.w3 = None
-        if kk % 8 == 0:
+        if kk % 8 == 0 and self.cin % 32 == 0 and kh * kw <= 64:
+            wk = w
+            if kh * kw > 1:
+                wk = w.reshape(co, kh * kw, self.cin // 32, 32).permute(0, 2, 1, 3).contiguous()
             self.w3 = torch.empty((3, co * kk), dtype=torch.bfloat16, device=w.device)
-            _lib.call('swem_split_bf16x3_f32', _stream(), w.data_ptr(), self.w3.data_ptr(), co, kk, 0)
+            _lib.call('swem_split_bf16x3_f32', _stream(), wk.data_ptr(), self.w3.data_ptr(), co, kk, 0)
 
 
 def split_bf16x3(w):
@@ -329,8 +335,7 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
                             cands.append(base | ts << 24)
                             if wm == 2 and wn == 2:
                                 cands.append(base | 2 << 20 | ts << 24)
-    best, best_t = 0, float('inf')
-    for plan in cands:
+    def timed(plan):
         launch(plan)                               # warm (also grows the workspace)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -338,7 +343,10 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
             launch(plan, True) if fresh_kw else launch(plan)
         e1.record()
         e1.synchronize()
-        t = e0.elapsed_time(e1)
+        return e0.elapsed_time(e1)
+    best, best_t = 0, float('inf')
+    for plan in cands:
+        t = timed(plan)
         if t < best_t:
             best, best_t = plan, t
     return best

@@ -271,6 +271,24 @@ def test_conv2d_plain_bf16_mode(lib, plan):
     assert 1e-5 < err < 1e-2, err             # really one bf16 product (not the exact six), and no worse than bf16
 
 
+@pytest.mark.parametrize('plan', [0x10010011, 0x20010011, 0x30010011, 0x10010021, 0x20010022, 0x30210022, 0x24010021,
+                                  0x20020021, 0x10010211], ids=lambda p: '%#x' % p)
+def test_conv2d_xcd_partition(lib, plan):
+    """Plan bits 28-29: the tile grid is dealt to the 8 XCDs in 2 / 4 / 8 groups of N tiles instead of ranges of M tiles.
+    Placement never changes a tile's arithmetic: the result is BIT-identical to the default placement."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 96, 30, 54, generator=g)
+    w = torch.randn(512, 96, 3, 3, generator=g) * 0.05
+    b = torch.randn(512, generator=g)
+    pack = ops.pack_conv(w.to(DEV), b.to(DEV))
+    xs = nhwc(x)
+    base = ops.conv2d([xs], pack, relu_in=True, plan=plan & 0x0fffffff)
+    y = ops.conv2d([xs], pack, relu_in=True, plan=plan)
+    assert torch.equal(y, base)
+    ref = F.conv2d(F.relu(x), w, b, padding=1)
+    close(back(y), ref, 2e-5 if (plan >> 16) & 3 == 1 else 1e-2, 'xcd-partitioned conv')
+
+
 @pytest.mark.parametrize('plan', [0x4010021, 0x8010011, 0x4210022, 0x4010022], ids=lambda p: '%#x' % p)
 def test_conv2d_tail_split(lib, plan):
     """Plan bits 24-27: the last, partly filled round of tiles is launched a second time split over K and reduced over
