@@ -240,44 +240,62 @@ class SWEMTrainer:
                                 'views': views, 'sums': torch.zeros((n, 3), dtype=torch.float32, device=self.device)}
         return self._lane_state
 
-    def _clips(self, cur_iter):
-        """zero_grad + forward / loss / backward of every clip on the static buffers; returns (results, p)."""
+    # The step's clip work in three parts, so that it can run eagerly or as HIP graphs: `_pre` (main stream: re-pack the
+    # filters once for all lanes, zero the lanes' gradient buffers), `_lane(l)` (lane l's clips: forward / loss / backward
+    # on the lane's stream and gradient buffer), `_post` (main stream: lanes' gradients and losses summed).
+    def _pre(self):
+        ls = self._lanes(self.buf['frames'].shape[0])
+        A.new_step(prebuild=True)
+        ls['flat'].zero_()
+        ls['sums'].zero_()
+        self._results = [None] * self.buf['frames'].shape[0]
+
+    def _lane(self, l, cur_iter):
         bf = self.buf
         B = bf['frames'].shape[0]
         ls = self._lanes(B)
         n = len(ls['streams'])
-        A.new_step(prebuild=True)
-        ls['flat'].zero_()
-        ls['sums'].zero_()
+        p = 1.0
+        A.use_lane(l, ls['views'][l])
+        for b in range(l, B, n):
+            vo = None if bf['valid'] is None else bf['valid'][b:b + 1]
+            prior = {'kappa': bf['kappa0'][b], 'nu': bf['nu0'], 'zita': bf['zita0']}
+            logits_list, res = self.clip_forward(bf['frames'][b:b + 1], bf['init_mask'][b:b + 1], vo, prior)
+            out = self.criterion.clip_loss(logits_list, bf['label'][b:b + 1, 1:], cur_iter, vo, k_dev=bf['k'])
+            vec = out['_vec']                                      # (total, main, aux) of this clip
+            vec.backward(bf['gout'])
+            ls['sums'][l].copy_(ops.lincomb(ls['sums'][l], 1.0, vec.detach(), 1.0 / B))
+            self._results[b] = torch.stack(res, dim=1)             # (1, T-1, H, W)
+            p = out['p']
+        A.use_lane(0, None)
+        return p
+
+    def _post(self):
+        bf = self.buf
+        ls = self._lanes(bf['frames'].shape[0])
+        A.sum_batch(ls['flat'], out=self.optimizer.grad.view(1, -1))   # lanes' gradients -> the optimizer's buffer
+        tot = ls['sums'][0]
+        for l in range(1, len(ls['streams'])):
+            tot = ops.lincomb(tot, 1.0, ls['sums'][l], 1.0)
+        bf['sums'].copy_(tot)
+        return torch.cat(self._results, dim=0)
+
+    def _clips(self, cur_iter):
+        """zero_grad + forward / loss / backward of every clip on the static buffers; returns (results, p)."""
+        ls = self._lanes(self.buf['frames'].shape[0])
         main = torch.cuda.current_stream()
-        results, p = [None] * B, 1.0
+        self._pre()
+        p = 1.0
         for st in ls['streams']:
             if st is not None:
-                st.wait_stream(main)                                   # fork (also inside a graph capture)
-        for b in range(B):
-            l = b % n
-            st = ls['streams'][l]
+                st.wait_stream(main)                                   # fork
+        for l, st in enumerate(ls['streams']):
             with torch.cuda.stream(st if st is not None else main):
-                A.use_lane(l, ls['views'][l])
-                vo = None if bf['valid'] is None else bf['valid'][b:b + 1]
-                prior = {'kappa': bf['kappa0'][b], 'nu': bf['nu0'], 'zita': bf['zita0']}
-                logits_list, res = self.clip_forward(bf['frames'][b:b + 1], bf['init_mask'][b:b + 1], vo, prior)
-                out = self.criterion.clip_loss(logits_list, bf['label'][b:b + 1, 1:], cur_iter, vo, k_dev=bf['k'])
-                vec = out['_vec']                                      # (total, main, aux) of this clip
-                vec.backward(bf['gout'])
-                ls['sums'][l].copy_(ops.lincomb(ls['sums'][l], 1.0, vec.detach(), 1.0 / B))
-                results[b] = torch.stack(res, dim=1)                   # (1, T-1, H, W)
-                p = out['p']
-        A.use_lane(0, None)
+                p = self._lane(l, cur_iter)
         for st in ls['streams']:
             if st is not None:
                 main.wait_stream(st)                                   # join
-        A.sum_batch(ls['flat'], out=self.optimizer.grad.view(1, -1))   # lanes' gradients -> the optimizer's buffer
-        tot = ls['sums'][0]
-        for l in range(1, n):
-            tot = ops.lincomb(tot, 1.0, ls['sums'][l], 1.0)
-        bf['sums'].copy_(tot)
-        return torch.cat(results, dim=0), p
+        return self._post(), p
 
     def one_step(self, frames, init_mask, valid_obj, label, cur_iter):
         """swem_trainer.py:59-108.  With ``use_graph`` (default) the clips' forward/backward is captured into a HIP graph
@@ -302,7 +320,7 @@ class SWEMTrainer:
         if self.use_graph and self._eager_steps >= 2 and self._graph is None and not ops.AUTOTUNE_PENDING():
             self._capture(cur_iter)
         if self._graph is not None:
-            self._graph.replay()
+            self._replay()
             results, p = self._graph_out, (1.0 if p is None else p)
         else:
             with self._math():
@@ -319,8 +337,47 @@ class SWEMTrainer:
         return ops.conv_math((2,)) if self.amp else contextlib.nullcontext()
 
     def _capture(self, cur_iter):
+        """One HIP graph per part: `_pre` and `_post` on the main stream, one graph per lane on the lane's own (probed)
+        stream.  A single graph with forked branches leaves the placement of the branches to the runtime, and two lanes on
+        one hardware queue serialise (measured: 40 to 56 clips/s from run to run); separate graphs replay on the streams
+        that `evaluator.overlapping_streams` found to overlap."""
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g), self._math():
-            out, _ = self._clips(cur_iter)
-        self._graph, self._graph_out = g, out
+        ls = self._lanes(self.buf['frames'].shape[0])
+        main = torch.cuda.current_stream()
+        with self._math():
+            g_pre = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_pre):
+                self._pre()
+            lanes = []
+            for l, st in enumerate(ls['streams']):
+                g = torch.cuda.CUDAGraph()
+                if st is None:
+                    with torch.cuda.graph(g):
+                        self._lane(l, cur_iter)
+                else:
+                    st.wait_stream(main)
+                    with torch.cuda.graph(g, stream=st):
+                        self._lane(l, cur_iter)
+                lanes.append(g)
+            g_post = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_post):
+                out = self._post()
+        torch.cuda.synchronize()
+        self._graph, self._graph_out = (g_pre, lanes, g_post), out
+
+    def _replay(self):
+        g_pre, lanes, g_post = self._graph
+        ls = self._lane_state
+        main = torch.cuda.current_stream()
+        g_pre.replay()
+        for st, g in zip(ls['streams'], lanes):
+            if st is None:
+                g.replay()
+            else:
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    g.replay()
+        for st in ls['streams']:
+            if st is not None:
+                main.wait_stream(st)
+        g_post.replay()
