@@ -8,6 +8,9 @@ so is this one, with the resize / argmax / one-hot steps on HIP kernels instead 
 """
 import time
 
+import os
+import sys
+
 import torch
 
 from . import ops
@@ -258,7 +261,10 @@ def overlapping_streams(n, device=None, tries=12):
         pair = (cand, chain(cand, k))
         k += 1
         # (measured with this probe: pairs on different queues 1.3-1.5 x the single-stream time, pairs on one queue 1.8-1.9 x)
-        if all(run([c, pair]) < 1.65 * t1 for c in chosen):
+        ratios = [run([c, pair]) / t1 for c in chosen]
+        if os.environ.get('SWEM_PROBE_DEBUG'):
+            print('probe: candidate %d ratios %s' % (k, ' '.join('%.2f' % v for v in ratios)), file=sys.stderr)
+        if all(v < 1.65 for v in ratios):
             chosen.append(pair)
     while len(chosen) < n:                     # no further overlapping candidate found: fall back to plain streams
         chosen.append((ops.new_stream(), None))

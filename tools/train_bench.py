@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Times SWEMTrainer.one_step (reference swem_trainer.py:59-108) on the reference's training shapes
 (configs/config.py: 3 frames of 384x384 per clip, MAX_NUM_OBJS = 2, ResNet-50, K = 256, 4 EM iterations).
-   python tools/train_bench.py [--clips 4] [--steps 5] [--warmup 2] [--size 384] [--no-autotune]"""
+   python tools/train_bench.py [--clips 4] [--steps 5] [--warmup 2] [--size 384] [--objects 2] [--amp] [--no-autotune]
+Data parallel (BASELINE configs C / D: batch 32 = 4 clips on each of 8 GPUs): one process per GPU under torchrun,
+   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/train_bench.py --clips 4
+every rank steps its own clips, the flat gradient buffer is all-reduced over RCCL before the optimizer step
+(swem_amd.dist.allreduce_sum_); rank 0 prints the whole-job clips/s (clips of all ranks / slowest rank's time)."""
 import argparse
 import json
 import os
@@ -30,7 +34,12 @@ def main():
     ap.add_argument('--save-plans', default=None)
     ap.add_argument('--load-plans', default=None, help='reuse tuned conv plans (profiler runs)')
     a = ap.parse_args()
-    dev = torch.device('cuda:0')
+    from swem_amd import dist as sdist
+    rank, local_rank, world = sdist.env_world()
+    local_rank = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    sdist.init()
     cfg = SimpleNamespace(KEYDIM=128, VALDIM=512, NUM_BASES=256, NUM_EM_ITERS=4, EM_TAU=0.05, TOPL=64, SINGLE_OBJ=False,
                           BACKBONE=a.backbone)
     model = SWEM(cfg)
@@ -47,7 +56,7 @@ def main():
                           AMP=a.amp), model, lanes=a.lanes)
     fr, im, lb = [], [], []
     for i in range(a.clips):
-        frames, per = synth.make_clip(t=3, h=a.size, w=a.size, n_obj=a.objects, out_hw=(a.size, a.size), seed=50 + i,
+        frames, per = synth.make_clip(t=3, h=a.size, w=a.size, n_obj=a.objects, out_hw=(a.size, a.size), seed=50 + i + 16 * rank,
                                       all_masks=True)
         lab = torch.stack([m[0].argmax(0) for m in per])
         fr.append(frames[0])
@@ -62,15 +71,24 @@ def main():
     ops.AUTOTUNE = False
     for it in range(2):                      # the first step after tuning captures the HIP graph, the second replays it
         losses, _ = tr.one_step(frames, init_mask, valid, label, 30000 + it)
+    sdist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
     for it in range(a.steps):
         losses, _ = tr.one_step(frames, init_mask, valid, label, 30000 + it)
     torch.cuda.synchronize()
-    dt = (time.time() - t0) / a.steps
-    print(json.dumps({'metric': 'training clips/s (3 x %dx%d frames, %d objects, %s, %s)' % (
+    elapsed = time.time() - t0
+    sdist.barrier()
+    total, elapsed = sdist.reduce_counters(a.clips * a.steps, elapsed, device=dev)
+    dt = elapsed / a.steps
+    a.clips = total // a.steps
+    if rank == 0:
+        print(json.dumps({'metric': 'training clips/s (3 x %dx%d frames, %d objects, %s, %s)' % (
         a.size, a.size, a.objects, a.backbone, 'AMP: bf16 conv operands' if a.amp else 'fp32-accurate'), 'value': a.clips / dt, 'ms_per_step': dt * 1e3, 'clips_per_step': a.clips,
-        'total_loss': float(losses['total_loss']), 'graph': tr._graph is not None, 'lanes': a.lanes, 'peak_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30}))
+        'total_loss': float(losses['total_loss']), 'graph': tr._graph is not None, 'lanes': a.lanes, 'n_gpus': world,
+        'peak_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30}))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':
