@@ -311,14 +311,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
 // stored as one contiguous run of 64 * taps floats of dw.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial,
                                                                 float *__restrict__ dw, int Cout, int Cin, int taps,
-                                                                int Cin_store, int zsplit, int accumulate) {
-  extern __shared__ float red_s[];   // [64][taps]
-  const int n = blockIdx.y, c0 = blockIdx.x * 64;
-  const int nc = min(64, Cin_store - c0);
+                                                                int Cin_store, int zsplit, int accumulate, int cpb) {
+  extern __shared__ float red_s[];   // [cpb][taps]; cpb = 64 or 16 input channels per block (16: enough blocks for small layers)
+  const int n = blockIdx.y, c0 = blockIdx.x * cpb;
+  const int nc = min(cpb, Cin_store - c0);
   const long long K = (long long)taps * Cin, zs = (long long)Cout * K;
   const float *src = partial + (long long)n * K + c0;
-  for (int idx = threadIdx.x; idx < 64 * taps; idx += 256) {
-    const int tap = idx >> 6, cl = idx & 63;
+  for (int idx = threadIdx.x; idx < cpb * taps; idx += 256) {
+    const int tap = idx / cpb, cl = idx - tap * cpb;
     float s = 0.f;
     if (cl < nc)
       for (int z = 0; z < zsplit; ++z) s += src[z * zs + (long long)tap * Cin + cl];
@@ -327,6 +327,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
   __syncthreads();
   float *o = dw + ((long long)n * Cin_store + c0) * taps;
   for (int idx = threadIdx.x; idx < nc * taps; idx += 256) o[idx] = accumulate ? o[idx] + red_s[idx] : red_s[idx];
+}
+static inline void launch_wgrad_reduce(hipStream_t st, const float *partial, float *dw, int Cout, int Cin, int taps,
+                                       int cin_store, int zsplit, int accumulate) {
+  const int cpb = (long long)cdiv(cin_store, 64) * Cout < 1024 ? 16 : 64;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(cin_store, cpb), Cout), dim3(256), cpb * taps * sizeof(float), st,
+                     partial, dw, Cout, Cin, taps, cin_store, zsplit, accumulate, cpb);
 }
 
 // per-column sums of a [M][C] matrix (optionally of the product with a second one): stage 1 = one partial row per
@@ -415,22 +421,31 @@ __global__ __launch_bounds__(256) void sum_batch_kernel(const float *__restrict_
 struct WgradPlan {
   int wt, zsplit, m_per_split;
 };
-WgradPlan wgrad_plan(long long M, int Cout, int KH, int KW, int c0, int c1, int c2) {
+// Tile and pixel slices (measured with tools/wgrad_bench.py --tune on the training shapes): the 128x128 tile where the
+// grid is large enough without many slices (>= 128 tiles, or >= 4096 pixels to cut), else 64x64; slices so that
+// tiles x slices is about two blocks per CU, at most 16 (every slice is a full partial gradient: written by the GEMM
+// and read by the reduce) and at least 128 pixels each.
+static WgradPlan wgrad_pick(long long M, int Cout, int KH, int KW, int c0, int c1, int c2, int plan) {
   WgradPlan pl;
+  auto tiles_of = [&](int bt) {
+    return (long long)cdiv(Cout, bt) * KH * KW * (cdiv(c0, bt) + (c1 ? cdiv(c1, bt) : 0) + (c2 ? cdiv(c2, bt) : 0));
+  };
   const bool big = Cout >= 128 && c0 >= 128 && (c1 == 0 || c1 >= 128) && (c2 == 0 || c2 >= 128);
-  // 128x128 tiles only where the pixel count is large (measured on the reference's training shapes: below ~20k pixels the
-  // 64x64 tile's larger grid needs fewer pixel slices, i.e. less partial-sum traffic, and wins by ~5 % of the step)
-  pl.wt = (big && M >= 20000) ? 2 : 1;
-  const int bt = 64 * pl.wt;
-  long long tiles = (long long)cdiv(Cout, bt) * KH * KW * (cdiv(c0, bt) + (c1 ? cdiv(c1, bt) : 0) + (c2 ? cdiv(c2, bt) : 0));
-  long long zs = 1024 / (tiles > 0 ? tiles : 1);
-  const long long zmax = (M + 255) / 256;
+  pl.wt = (plan & 15) ? (plan & 15) : ((big && (tiles_of(128) >= 128 || M >= 4096)) ? 2 : 1);
+  if (pl.wt != 1 && pl.wt != 2) pl.wt = 1;
+  const long long tiles = tiles_of(64 * pl.wt);
+  long long zs = (plan >> 4) > 0 ? (plan >> 4) : (512 + tiles - 1) / (tiles > 0 ? tiles : 1);
+  const long long zmax = (M + 127) / 128;
+  if (zs > 16 && (plan >> 4) == 0) zs = 16;
   if (zs > zmax) zs = zmax;
   if (zs < 1) zs = 1;
   long long per = ((M + zs - 1) / zs + 31) / 32 * 32;
   pl.m_per_split = (int)per;
   pl.zsplit = (int)((M + per - 1) / per);
   return pl;
+}
+WgradPlan wgrad_plan(long long M, int Cout, int KH, int KW, int c0, int c1, int c2) {
+  return wgrad_pick(M, Cout, KH, KW, c0, c1, c2, 0);
 }
 
 }  // namespace
@@ -488,28 +503,14 @@ extern "C" int swem_conv2d_wgrad_f32(void *stream, const float *dy, const float 
     SWEM_CHECK_LAUNCH("conv_wgrad_kernel");
     off += cs[s];
   }
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(cin_store, 64), Cout), dim3(256), 64 * KH * KW * sizeof(float), st, p.partial, dw,
-                     Cout, Cin, KH * KW, cin_store, pl.zsplit, accumulate);
+  launch_wgrad_reduce(st, p.partial, dw, Cout, Cin, KH * KW, cin_store, pl.zsplit, accumulate);
   SWEM_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
   return SWEM_OK;
 }
 
 // ---- bf16-pipe weight gradient (pre-split planes)
 static WgradPlan wgrad_bf_plan(long long M, int Cout, int KH, int KW, int c0, int c1, int c2, int plan) {
-  WgradPlan pl;
-  const bool big = Cout >= 128 && c0 >= 128 && (c1 == 0 || c1 >= 128) && (c2 == 0 || c2 >= 128);
-  pl.wt = (plan & 15) ? (plan & 15) : (big ? 2 : 1);
-  if (pl.wt != 1 && pl.wt != 2) pl.wt = 1;
-  const int bt = 64 * pl.wt;
-  long long tiles = (long long)cdiv(Cout, bt) * KH * KW * (cdiv(c0, bt) + (c1 ? cdiv(c1, bt) : 0) + (c2 ? cdiv(c2, bt) : 0));
-  long long zs = (plan >> 4) > 0 ? (plan >> 4) : (pl.wt == 2 ? 512 : 1024) / (tiles > 0 ? tiles : 1);
-  const long long zmax = (M + 127) / 128;
-  if (zs > zmax) zs = zmax;
-  if (zs < 1) zs = 1;
-  long long per = ((M + zs - 1) / zs + 31) / 32 * 32;
-  pl.m_per_split = (int)per;
-  pl.zsplit = (int)((M + per - 1) / per);
-  return pl;
+  return wgrad_pick(M, Cout, KH, KW, c0, c1, c2, plan);
 }
 
 template <int WT, int NPL>
@@ -585,8 +586,7 @@ extern "C" int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3,
     SWEM_CHECK_LAUNCH("conv_wgrad_bf_kernel");
     off += cs[s];
   }
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(cin_store, 64), Cout), dim3(256), 64 * KH * KW * sizeof(float), st, p.partial, dw,
-                     Cout, Cin, KH * KW, cin_store, pl.zsplit, accumulate);
+  launch_wgrad_reduce(st, p.partial, dw, Cout, Cin, KH * KW, cin_store, pl.zsplit, accumulate);
   SWEM_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
   return SWEM_OK;
 }
