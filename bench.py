@@ -197,6 +197,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step_all()
+    # (the blocking synchronize sleeps on an interrupt; on hosts that deliver it late -- wake-ups quantised to 100 ms were
+    # measured here -- the clock would include up to a tick of idle time: poll the streams' events first)
+    ops.spin_sync(streams)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     sdist.barrier()

@@ -59,6 +59,21 @@ def new_stream():
     return torch.cuda.ExternalStream(h.value)
 
 
+def spin_sync(streams=None):
+    """Wait for the work queued so far on `streams` (default: the current stream) by POLLING events.  A blocking wait
+    (hipDeviceSynchronize / hipEventSynchronize) sleeps on an interrupt; where interrupts are delivered late (virtualised
+    hosts: wake-ups quantised to 100 ms were measured) the caller loses up to a tick per wait -- and a benchmark's clock
+    with it.  Polling returns within microseconds of completion."""
+    evs = []
+    for st in (streams or [torch.cuda.current_stream()]):
+        e = torch.cuda.Event()
+        e.record(st)
+        evs.append(e)
+    for e in evs:
+        while not e.query():
+            pass
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 

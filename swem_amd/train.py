@@ -310,10 +310,25 @@ class SWEMTrainer:
         bf['label'].copy_(label)
         if valid_obj is not None:
             bf['valid'].copy_(valid_obj)
-        bf['kappa0'].copy_(random_init_host(B, N, bf['kappa0'].shape[3], core.n_bases))
+        # the random bases are drawn on the host (the global torch CPU generator, as the fixtures of the reference step) and
+        # reach the device through a ring of three pinned buffers: a pageable copy would block the host until the previous
+        # step has drained, i.e. serialise host and device every step
+        ring = self.__dict__.setdefault('_kappa_ring', {})
+        if ring.get('shape') != tuple(bf['kappa0'].shape):
+            ring.update(shape=tuple(bf['kappa0'].shape), i=0, ev=[None] * 3,
+                        pin=[torch.empty(bf['kappa0'].shape, dtype=torch.float32).pin_memory() for _ in range(3)])
+        i = ring['i'] = (ring['i'] + 1) % 3
+        if ring['ev'][i] is not None:
+            ring['ev'][i].synchronize()                 # the copy issued three steps ago has long finished
+        ring['pin'][i].copy_(random_init_host(B, N, bf['kappa0'].shape[3], core.n_bases))
+        bf['kappa0'].copy_(ring['pin'][i], non_blocking=True)
+        ring['ev'][i] = torch.cuda.Event()
+        ring['ev'][i].record()
         # mean over the clips of this rank and over the ranks (DistributedDataParallel averages, swem_trainer.py:41-43)
         world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-        bf['gout'].copy_(torch.tensor([1.0 / (B * world), 0.0, 0.0]))
+        if getattr(self, '_gout_for', None) != (B, world, id(bf['gout'])):
+            bf['gout'].copy_(torch.tensor([1.0 / (B * world), 0.0, 0.0]))
+            self._gout_for = (B, world, id(bf['gout']))
         H, W = init_mask.shape[-2:]
         p, k = self.criterion.top_k(cur_iter, H * W)
         bf['k'].fill_(k)

@@ -60,6 +60,7 @@ def main():
     t1 = time.perf_counter()
     for _ in range(a.frames - 4):
         pred = runner.step()
+    ops.spin_sync()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     mem1 = torch.cuda.memory_allocated()

@@ -31,6 +31,7 @@ def main():
     ap.add_argument('--no-autotune', action='store_true')
     ap.add_argument('--lanes', type=int, default=4, help='clips in flight at once (streams)')
     ap.add_argument('--amp', action='store_true', help='config.AMP: bf16-operand convolutions')
+    ap.add_argument('--per-step', action='store_true', help='synchronise and print every step time (stderr)')
     ap.add_argument('--save-plans', default=None)
     ap.add_argument('--load-plans', default=None, help='reuse tuned conv plans (profiler runs)')
     a = ap.parse_args()
@@ -74,10 +75,18 @@ def main():
     sdist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
+    per_step = []
     for it in range(a.steps):
+        ts = time.time()
         losses, _ = tr.one_step(frames, init_mask, valid, label, 30000 + it)
+        if a.per_step:
+            ops.spin_sync()
+            per_step.append(1e3 * (time.time() - ts))
+    ops.spin_sync()
     torch.cuda.synchronize()
     elapsed = time.time() - t0
+    if per_step and rank == 0:
+        print('per-step ms: ' + ' '.join('%.1f' % v for v in per_step), file=sys.stderr)
     sdist.barrier()
     total, elapsed = sdist.reduce_counters(a.clips * a.steps, elapsed, device=dev)
     dt = elapsed / a.steps
