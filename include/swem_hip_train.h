@@ -87,13 +87,15 @@ int swem_sum_batch_f32(void *stream, const float *x, float *y, int B, long long 
  *   y = act(c * alpha + shift + res),  alpha = gamma / sqrt(var + eps),  shift = beta - mean * alpha
  *   bwd (one pass + a per-channel finish): dz = dy * (y > 0) (also the residual's gradient, optional), dc = dz * alpha,
  *   dgamma += invstd * (sum dz*c - mean * sum dz), dbeta += sum dz  (either may be NULL; the conv bias's gradient is the
- *   column sum of dc, taken by the convolution's own backward) */
+ *   column sum of dc, taken by the convolution's own backward)
+ *   planes (optional, C % 8 == 0): also write the bf16 planes [3][C/8][M][8] of y (forward) / of dc (backward) exactly as
+ *   swem_split_bf16x3_f32 would, for the convolution that consumes them */
 int swem_bn_act_f32(void *stream, const float *c, const float *alpha, const float *shift, const float *res, float *y,
-                    long long M, int C, int relu);
+                    long long M, int C, int relu, void *planes);
 size_t swem_bn_act_bwd_workspace(long long M, int C);
 int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y, const float *c, const float *alpha,
                         const float *mean, const float *invstd, float *dz, float *dc, float *dgamma, float *dbeta,
-                        long long M, int C, int relu, void *ws, size_t ws_bytes);
+                        long long M, int C, int relu, void *planes, void *ws, size_t ws_bytes);
 /* backward of swem_cbam_f32 (y = x + CBAM(x), attentions.py:22-84): dx [B][H][W][C]; the gradients of the six
  * parameters (mlp.1 / mlp.3 weight+bias, spatial conv weight [1][2][7][7] + bias) are ACCUMULATED.  Ties of the two
  * max-pools send the gradient to the first maximum. */

@@ -68,9 +68,9 @@ SIGNATURES = {
     'swem_colsum_workspace': (_sz, [_ll, _i]),
     'swem_colsum_f32': (_i, [_p, _p, _p, _p, _p, _ll, _i, _i, _p, _sz]),
     'swem_sum_batch_f32': (_i, [_p, _p, _p, _i, _ll, _i]),
-    'swem_bn_act_f32': (_i, [_p, _p, _p, _p, _p, _p, _ll, _i, _i]),
+    'swem_bn_act_f32': (_i, [_p, _p, _p, _p, _p, _p, _ll, _i, _i, _p]),
     'swem_bn_act_bwd_workspace': (_sz, [_ll, _i]),
-    'swem_bn_act_bwd_f32': (_i, [_p] * 11 + [_ll, _i, _i, _p, _sz]),
+    'swem_bn_act_bwd_f32': (_i, [_p] * 11 + [_ll, _i, _i, _p, _p, _sz]),
     'swem_cbam_bwd_workspace': (_sz, [_i, _i, _i, _i]),
     'swem_cbam_bwd_f32': (_i, [_p] * 16 + [_i] * 5 + [_p, _sz]),
     'swem_bn_fold_f32': (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _i]),

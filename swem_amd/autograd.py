@@ -36,6 +36,7 @@ def reset():
     """Forget the recorded packs (a new trainer / model)."""
     _PACKS.clear()
     _RECIPES.clear()
+    ops.SPLIT_HINTS.clear()
 
 
 def ensure_grads(params):
@@ -217,12 +218,17 @@ class _BNAct(Function):
     def forward(ctx, c, gamma, beta, mean, var, res, relu, eps):
         Cc = c.shape[-1]
         M = c.numel() // Cc
-        fold = torch.empty((3, Cc), dtype=torch.float32, device=c.device)     # alpha, shift, invstd
-        _lib.call('swem_bn_fold_f32', ops._stream(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(),
-                  eps, fold[0].data_ptr(), fold[1].data_ptr(), fold[2].data_ptr(), Cc)
+
+        def build():
+            f = torch.empty((3, Cc), dtype=torch.float32, device=c.device)     # alpha, shift, invstd
+            _lib.call('swem_bn_fold_f32', ops._stream(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                      var.data_ptr(), eps, f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr(), Cc)
+            return f
+        fold = _shared_pack((id(gamma), 'bnfold', eps), build)     # once per step, shared by the frames and the lanes
         y = torch.empty_like(c)
+        planes = _planes_for((id(gamma), 'y'), y, M, Cc)
         _lib.call('swem_bn_act_f32', ops._stream(), c.data_ptr(), fold[0].data_ptr(), fold[1].data_ptr(), ops._ptr(res),
-                  y.data_ptr(), M, Cc, int(relu))
+                  y.data_ptr(), M, Cc, int(relu), ops._ptr(planes))
         ctx.save_for_backward(c, y, fold, gamma, beta, mean)     # (saved_tensors keeps the output without a cycle)
         ctx.flags = (relu, res is not None)
         return y
@@ -239,11 +245,24 @@ class _BNAct(Function):
         want = gamma.requires_grad or beta.requires_grad
         wsb = _lib.query('swem_bn_act_bwd_workspace', M, Cc) if want else 0
         ws = _ws(wsb, c.device) if want else None
+        planes = _planes_for((id(gamma), 'dc'), dc, M, Cc)
         _lib.call('swem_bn_act_bwd_f32', ops._stream(), dy.data_ptr(), y.data_ptr(), c.data_ptr(), fold[0].data_ptr(),
                   mean.data_ptr(), fold[2].data_ptr(), ops._ptr(dz), dc.data_ptr(),
                   _grad(gamma).data_ptr() if gamma.requires_grad else 0, _grad(beta).data_ptr() if beta.requires_grad else 0,
-                  M, Cc, int(relu), ops._ptr(ws), wsb)
+                  M, Cc, int(relu), ops._ptr(planes), ops._ptr(ws), wsb)
         return dc, None, None, None, None, (dz if has_res else None), None, None
+
+
+def _planes_for(site, t, M, Cc):
+    """The bf16 planes of a stage's output, written by the stage itself when an earlier step saw a convolution split this
+    output (ops.SPLIT_HINTS): attached to the tensor where ops.presplit looks for them.  Otherwise the tensor is tagged
+    with its producer so that a later split records the hint."""
+    if Cc % 8 == 0 and site in ops.SPLIT_HINTS:
+        planes = torch.empty((3, M * Cc), dtype=torch.bfloat16, device=t.device)
+        t.__dict__['_swem_split'] = {False: planes}
+        return planes
+    t.__dict__['_swem_site'] = site
+    return None
 
 
 def bn_act(c, bn, res=None, relu=True, eps=1e-5):

@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "lds_dma.h"
+#include "bf16_split.h"
 
 namespace {
 
@@ -533,26 +534,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvP p) {
 // the bf16 MFMA co-executes with the vector ALU, so the splitting arithmetic of one wave hides behind another's MFMAs.
 // Same tiling, loads, k-block bookkeeping and epilogue as conv_igemm_pipe_kernel; LDS holds three bf16 planes per
 // operand,  [plane][k/8][row][8 bf16], one 16-byte MFMA fragment per (row, k/8), plane stride padded by 16 bytes.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-  f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32, a in the low half
-}
-__device__ __forceinline__ float lo_f32(unsigned u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float hi_f32(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
-// x = hi + mid + lo per element; returns the three planes' 8-byte pieces (4 consecutive k each)
-__device__ __forceinline__ void split3(float4 v, uint2 &h, uint2 &m, uint2 &l) {
-  h.x = pack_bf16(v.x, v.y);
-  h.y = pack_bf16(v.z, v.w);
-  const float rx = v.x - lo_f32(h.x), ry = v.y - hi_f32(h.x), rz = v.z - lo_f32(h.y), rw = v.w - hi_f32(h.y);
-  m.x = pack_bf16(rx, ry);
-  m.y = pack_bf16(rz, rw);
-  l.x = pack_bf16(rx - lo_f32(m.x), ry - hi_f32(m.x));
-  l.y = pack_bf16(rz - lo_f32(m.y), rw - hi_f32(m.y));
-}
 __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }

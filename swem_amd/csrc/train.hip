@@ -5,6 +5,7 @@
 
 #include "../../include/swem_hip_train.h"
 #include "common.h"
+#include "bf16_split.h"
 
 namespace {
 
@@ -395,9 +396,24 @@ __device__ __forceinline__ void lerp_span(int s, float scale, int out, int &d0, 
 }
 
 // ---- frozen BatchNorm + residual + ReLU as its own stage (training keeps the raw conv output for the BN gradients)
+// Optional second output of the two BatchNorm stages: the bf16 planes of the value just written, [plane][C/8][M][8]
+// (swem_split_bf16x3_f32's layout and rounding), so that the convolution that consumes it -- forward: the next layer,
+// backward: this layer's data / weight gradient -- finds its operand split already (one launch and one read of the
+// fp32 map less per BatchNorm call).  A thread owns 4 consecutive channels of one row = half a 16-byte cell.
+__device__ __forceinline__ void store_planes4(unsigned short *__restrict__ planes, long long M, int C, long long m, int c,
+                                              float4 v) {
+  uint2 h, md, l;
+  split3(v, h, md, l);
+  const long long cell = ((long long)(c >> 3) * M + m) * 8 + (c & 4);
+  const long long plane = M * C;
+  *reinterpret_cast<uint2 *>(planes + cell) = h;
+  *reinterpret_cast<uint2 *>(planes + plane + cell) = md;
+  *reinterpret_cast<uint2 *>(planes + 2 * plane + cell) = l;
+}
 __global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ c, const float *__restrict__ alpha,
                                                      const float *__restrict__ shift, const float *__restrict__ res,
-                                                     float *__restrict__ y, long long M, int C, int relu) {
+                                                     float *__restrict__ y, long long M, int C, int relu,
+                                                     unsigned short *__restrict__ planes) {
   const int cq = C / 4;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= M * cq) return;
@@ -410,6 +426,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ c
   }
   if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
   st4t(y + i * 4, o);
+  if (planes) store_planes4(planes, M, C, i / cq, c4 * 4, o);
 }
 // Backward of bn_act in one pass: dz = dy * (y > 0) (also the residual's gradient), dc = dz * alpha (the conv output's
 // gradient), and per block the column partials s1 = sum dz, s2 = sum dz * c for the BatchNorm parameters.
@@ -426,7 +443,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict
                                                          const float *__restrict__ c, const float *__restrict__ alpha,
                                                          float *__restrict__ dz, float *__restrict__ dc,
                                                          float *__restrict__ part, long long M, int C, int relu,
-                                                         int BN_ROWS) {
+                                                         int BN_ROWS, unsigned short *__restrict__ planes) {
   __shared__ float4 sh1[256], sh2[256];
   const int cq = C / 4;
   const int c4 = blockIdx.x * 16 + (threadIdx.x & 15);
@@ -444,7 +461,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict
         g = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
       }
       if (dz) st4t(dz + i, g);
-      st4t(dc + i, make_float4(g.x * a.x, g.y * a.y, g.z * a.z, g.w * a.w));
+      const float4 gc = make_float4(g.x * a.x, g.y * a.y, g.z * a.z, g.w * a.w);
+      st4t(dc + i, gc);
+      if (planes) store_planes4(planes, M, C, m, c4 * 4, gc);
       if (part) {
         const float4 v = ld4t(c + i);
         s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
@@ -795,9 +814,11 @@ __global__ __launch_bounds__(256) void prep_value_bwd_kernel(const float *__rest
 #define STT static_cast<hipStream_t>(stream)
 
 extern "C" int swem_bn_act_f32(void *stream, const float *c, const float *alpha, const float *shift, const float *res,
-                               float *y, long long M, int C, int relu) {
+                               float *y, long long M, int C, int relu, void *planes) {
   SWEM_REQUIRE(c && alpha && shift && y && C % 4 == 0 && M > 0, SWEM_E_ARG, "bn_act: bad argument");
-  hipLaunchKernelGGL(bn_act_kernel, grid1t(M * (C / 4)), dim3(256), 0, STT, c, alpha, shift, res, y, M, C, relu);
+  SWEM_REQUIRE(!planes || C % 8 == 0, SWEM_E_SHAPE, "bn_act: the bf16 planes need C %% 8 == 0");
+  hipLaunchKernelGGL(bn_act_kernel, grid1t(M * (C / 4)), dim3(256), 0, STT, c, alpha, shift, res, y, M, C, relu,
+                     static_cast<unsigned short *>(planes));
   SWEM_CHECK_LAUNCH("bn_act_kernel");
   return SWEM_OK;
 }
@@ -807,8 +828,10 @@ extern "C" size_t swem_bn_act_bwd_workspace(long long M, int C) {
 }
 extern "C" int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y, const float *c, const float *alpha,
                                    const float *mean, const float *invstd, float *dz, float *dc, float *dgamma,
-                                   float *dbeta, long long M, int C, int relu, void *ws, size_t ws_bytes) {
+                                   float *dbeta, long long M, int C, int relu, void *planes, void *ws,
+                                   size_t ws_bytes) {
   SWEM_REQUIRE(dy && alpha && dc && (y || !relu) && C % 4 == 0 && M > 0, SWEM_E_ARG, "bn_act_bwd: bad argument");
+  SWEM_REQUIRE(!planes || C % 8 == 0, SWEM_E_SHAPE, "bn_act_bwd: the bf16 planes need C %% 8 == 0");
   const bool params = dgamma || dbeta;
   SWEM_REQUIRE(!params || (c && mean && invstd), SWEM_E_ARG, "bn_act_bwd: parameter gradients need c, mean, invstd");
   const int rows = bn_rows(M, C), nrow = cdiv(M, rows);
@@ -819,7 +842,7 @@ extern "C" int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y
     part = static_cast<float *>(ws);
   }
   hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(cdiv(C / 4, 16), nrow), dim3(256), 0, STT, dy, y, c, alpha, dz, dc, part, M,
-                     C, relu, rows);
+                     C, relu, rows, static_cast<unsigned short *>(planes));
   SWEM_CHECK_LAUNCH("bn_act_bwd_kernel");
   if (params) {
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 16)), dim3(256), 0, STT, part, nrow, mean, invstd, dgamma,

@@ -181,6 +181,9 @@ def presplit(t, relu=False):
     cache = t.__dict__.setdefault('_swem_split', {})
     sp = cache.get(relu)
     if sp is None:
+        site = t.__dict__.get('_swem_site')
+        if site is not None and not relu:
+            SPLIT_HINTS.add(site)          # the producer of this tensor can write the planes itself next time
         B, H, W, Cc = t.shape
         if B > 1 and t.stride(0) % Cc:
             raise _lib.SwemHipError('presplit: batch stride must be a multiple of the channel count')
@@ -284,6 +287,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
 
 
 _PLAN_TAG = ()
+SPLIT_HINTS = set()   # producer sites (autograd stages) whose output was later split: they write the planes themselves
 
 
 class conv_math:

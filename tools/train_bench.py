@@ -87,6 +87,8 @@ def main():
     elapsed = time.time() - t0
     if per_step and rank == 0:
         print('per-step ms: ' + ' '.join('%.1f' % v for v in per_step), file=sys.stderr)
+        srt = sorted(per_step)
+        print('per-step min %.1f  median %.1f ms' % (srt[0], srt[len(srt) // 2]), file=sys.stderr)
     sdist.barrier()
     total, elapsed = sdist.reduce_counters(a.clips * a.steps, elapsed, device=dev)
     dt = elapsed / a.steps
