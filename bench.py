@@ -344,17 +344,20 @@ def main():
             tf = em_flops_per_frame(n_obj) * n_streams * reps / best / 1e12
             return {'sequences': n_streams, 'us_per_round': round(1e6 * best / reps, 1), 'achieved': round(tf, 2),
                     'frac': round(tf / FP32_MATRIX_PEAK_TFLOPS, 4)}
-        conc = [em_concurrent(n) for n in sorted({2, nseq, 4}) if n > 1]
+        conc = [em_concurrent(n) for n in sorted({1, 2, nseq, 4})]
         em = out['em_matching']
-        em['concurrent'] = conc
+        em['concurrent'] = [c for c in conc if c['sequences'] > 1]
         mine = [c for c in conc if c['sequences'] == nseq]
-        if mine:       # the number for THIS run's configuration first; the single-sequence figure stays as `isolated`
-            em['isolated'] = {'ms_per_frame': em['ms_per_frame'], 'achieved': em['achieved'], 'frac': em['frac']}
+        if mine:       # the number for THIS run's configuration first; the single-sequence figures stay as `isolated`
+            one = [c for c in conc if c['sequences'] == 1][0]
+            em['isolated'] = {'ms_per_frame': round(one['us_per_round'] / 1e3, 3), 'achieved': one['achieved'],
+                              'frac': one['frac'], 'launch': 'hipGraph replay, one stream',
+                              'eager': {'ms_per_frame': em['ms_per_frame'], 'achieved': em['achieved'], 'frac': em['frac']}}
             em['achieved'], em['frac'] = mine[0]['achieved'], mine[0]['frac']
             em['ms_per_frame'] = round(mine[0]['us_per_round'] / nseq / 1e3, 3)
             em['note'] = ('memorize + match of the %d sequences this configuration keeps in flight per GPU, one HIP graph per '
                           'stream replayed together (device time per frame = round time / sequences); `isolated` = one '
-                          'sequence alone (20 back-to-back calls on one frame\'s real arguments); algorithmic FLOPs '
+                          'sequence alone (the same graph on one stream; `eager` = 20 back-to-back eager calls); algorithmic FLOPs '
                           '4PL(C(3T-1)+V) + 4LmP(C+V) per object' % nseq)
         if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only
             out['cpu_baseline'] = cpu_baseline(frames_cpu, m0_cpu, sd)
