@@ -65,7 +65,8 @@ int swem_conv2d_wgrad_f32(void *stream, const float *dy, const float *x0, int c0
  * plane 0 of the split of dY ([3][Cout/8][B*Ho*Wo][8], plane stride dy_ps elements), xK = plane 0 of the split of source
  * K (act already folded into the split; plane stride psK, batch stride bsK in elements, 0 = shared map).  Channel counts
  * are multiples of 8.  math 1 = bf16x6 (six products of the exact three-way split, fp32-level error), 2 = plain bf16
- * (plane 0, one product: config.AMP).  plan 0 = heuristic, else  tile | pixel_slices << 4  (tile 1 = 64x64, 2 = 128x128). */
+ * (plane 0, one product: config.AMP).  plan 0 = heuristic, else  tile | pixel_slices << 4 | flip << 12  (tile 1 = 64x64, 2 = 128x128; pixel_slices <= 255; flip = 1 takes the
+ * other LDS slab depth: the default is 16 pixels per slab for the six-product 128x128 tile, 32 otherwise). */
 size_t swem_conv2d_wgrad_bf16x3_workspace(int B, int H, int W, int c0, int c1, int c2, int Cout, int KH, int KW,
                                           int stride, int pad, int plan);
 int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3, long long dy_ps, const unsigned short *x0, int c0,

@@ -154,10 +154,13 @@ __device__ __forceinline__ f32x16 wg_mfma(wg_s16x8 a, wg_s16x8 b, f32x16 c) {
                                                  0, 0);
 }
 
-template <int WT, int NPL>
+// KS = pixels per slab: 32 (every wave fills rows 8w..8w+7 of all images) or 16 (waves 0,1 fill the dY images, waves 2,3
+// the x images; half the LDS per stage, so the six-product mode keeps three blocks per CU instead of one).
+template <int WT, int NPL, int KS>
 __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
+  static_assert(KS == 16 || KS == 32, "slab of 16 or 32 pixels");
   constexpr int BT = 64 * WT;
-  constexpr int IMG = 32 * 128;                 // bytes of one 32-pixel x 64-channel image
+  constexpr int IMG = KS * 128;                 // bytes of one KS-pixel x 64-channel image
   constexpr int OPB = WT * NPL * IMG;           // one operand of one stage: [image][plane]
   constexpr int STAGE = 2 * OPB;                // dY images, then x images
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -170,7 +173,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
   const int m_begin = blockIdx.z * p.m_per_split, m_end = min(p.M, m_begin + p.m_per_split);
 
   // ---- transfers: this lane's slot is (row 8 wave + lane/8, chunk' lane%8) of every image
-  const int lrow = 8 * wave + (lane >> 3);
+  const int lrow = (KS == 32 ? 8 * wave : 8 * (wave & 1)) + (lane >> 3);
+  const bool move_d = KS == 32 || wave < 2, move_x = KS == 32 || wave >= 2;   // which operand this wave transfers
   const int ch = (lane & 7) ^ (((lrow >> 1) & 1) << 2);   // the chunk (8-channel group) that lands in this slot
   int m = m_begin + lrow;
   int b, oy, ox;
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
   const unsigned dplane = (unsigned)(p.dps * 2), xplane = (unsigned)(p.xps * 2);
   const unsigned d_base = (unsigned)(n0 / 8) * dgroup, x_base = (unsigned)(ci0 / 8) * xgroup;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
-  const unsigned lds_w = lds0 + (unsigned)wave * 1024u;   // rows 8w..8w+7 of an image
+  const unsigned lds_w = lds0 + (unsigned)(KS == 32 ? wave : (wave & 1)) * 1024u;   // this wave's 8 rows of an image
   auto issue = [&](int stage) {
     const bool mok = m < m_end;
     const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
@@ -201,20 +205,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
     const unsigned dv = (unsigned)ch * dgroup + (unsigned)m * 16u;
     const unsigned xv = (unsigned)ch * xgroup + (unsigned)((long long)b * p.xbs_pix + (long long)iy * p.W + ix) * 16u;
     const unsigned sd = lds_w + (unsigned)stage * STAGE, sx = sd + OPB;
+    if (move_d) {
 #pragma unroll
-    for (int i = 0; i < WT; ++i)
+      for (int i = 0; i < WT; ++i)
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl)
-        dma16(rsd, sd + (i * NPL + pl) * IMG, (mok && dok[i]) ? dv : WG_OOB, d_base + i * 8 * dgroup + pl * dplane);
+        for (int pl = 0; pl < NPL; ++pl)
+          dma16(rsd, sd + (i * NPL + pl) * IMG, (mok && dok[i]) ? dv : WG_OOB, d_base + i * 8 * dgroup + pl * dplane);
+    }
+    if (move_x) {
 #pragma unroll
-    for (int i = 0; i < WT; ++i)
+      for (int i = 0; i < WT; ++i)
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl)
-        dma16(rsx, sx + (i * NPL + pl) * IMG, (pok && xok[i]) ? xv : WG_OOB, x_base + i * 8 * xgroup + pl * xplane);
+        for (int pl = 0; pl < NPL; ++pl)
+          dma16(rsx, sx + (i * NPL + pl) * IMG, (pok && xok[i]) ? xv : WG_OOB, x_base + i * 8 * xgroup + pl * xplane);
+    }
   };
   auto advance = [&]() {
-    m += 32;
-    ox += 32;
+    m += KS;
+    ox += KS;
     while (ox >= p.Wo) {
       ox -= p.Wo;
       ++oy;
@@ -248,14 +256,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int st = 0;
-  for (int mb = m_begin; mb < m_end; mb += 32) {
-    if (mb + 32 < m_end) {
+  for (int mb = m_begin; mb < m_end; mb += KS) {
+    if (mb + KS < m_end) {
       advance();
       issue(st ^ 1);
     }
     const unsigned so = (unsigned)st * STAGE;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS / 16; ++ks) {
       wg_s16x8 a[NPL][WT], bb[NPL][WT];
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
@@ -425,18 +433,19 @@ struct WgradPlan {
 // grid is large enough without many slices (>= 128 tiles, or >= 4096 pixels to cut), else 64x64; slices so that
 // tiles x slices is about two blocks per CU, at most 16 (every slice is a full partial gradient: written by the GEMM
 // and read by the reduce) and at least 128 pixels each.
-static WgradPlan wgrad_pick(long long M, int Cout, int KH, int KW, int c0, int c1, int c2, int plan) {
+static WgradPlan wgrad_pick(long long M, int Cout, int KH, int KW, int c0, int c1, int c2, int plan, int min_tiles2 = 128) {
   WgradPlan pl;
   auto tiles_of = [&](int bt) {
     return (long long)cdiv(Cout, bt) * KH * KW * (cdiv(c0, bt) + (c1 ? cdiv(c1, bt) : 0) + (c2 ? cdiv(c2, bt) : 0));
   };
   const bool big = Cout >= 128 && c0 >= 128 && (c1 == 0 || c1 >= 128) && (c2 == 0 || c2 >= 128);
-  pl.wt = (plan & 15) ? (plan & 15) : ((big && (tiles_of(128) >= 128 || M >= 4096)) ? 2 : 1);
+  pl.wt = (plan & 15) ? (plan & 15) : ((big && (tiles_of(128) >= min_tiles2 || M >= 4096)) ? 2 : 1);
   if (pl.wt != 1 && pl.wt != 2) pl.wt = 1;
   const long long tiles = tiles_of(64 * pl.wt);
-  long long zs = (plan >> 4) > 0 ? (plan >> 4) : (512 + tiles - 1) / (tiles > 0 ? tiles : 1);
+  const int zforce = (plan >> 4) & 255;
+  long long zs = zforce > 0 ? zforce : (512 + tiles - 1) / (tiles > 0 ? tiles : 1);
   const long long zmax = (M + 127) / 128;
-  if (zs > 16 && (plan >> 4) == 0) zs = 16;
+  if (zs > 16 && zforce == 0) zs = 16;
   if (zs > zmax) zs = zmax;
   if (zs < 1) zs = 1;
   long long per = ((M + zs - 1) / zs + 31) / 32 * 32;
@@ -509,15 +518,16 @@ extern "C" int swem_conv2d_wgrad_f32(void *stream, const float *dy, const float 
 }
 
 // ---- bf16-pipe weight gradient (pre-split planes)
-static WgradPlan wgrad_bf_plan(long long M, int Cout, int KH, int KW, int c0, int c1, int c2, int plan) {
-  return wgrad_pick(M, Cout, KH, KW, c0, c1, c2, plan);
+// (the six-product mode takes the 128x128 tile from 64 tiles on: with the 16-pixel slab it keeps three blocks per CU)
+static WgradPlan wgrad_bf_plan(long long M, int Cout, int KH, int KW, int c0, int c1, int c2, int plan, int math) {
+  return wgrad_pick(M, Cout, KH, KW, c0, c1, c2, plan, math == 1 ? 64 : 128);
 }
 
-template <int WT, int NPL>
+template <int WT, int NPL, int KS>
 static int launch_wgrad_bf(const WgradBP &p, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = 2 * 2 * WT * NPL * 4096;
-  SWEM_ALLOW_LDS((conv_wgrad_bf_kernel<WT, NPL>), lds);
-  hipLaunchKernelGGL((conv_wgrad_bf_kernel<WT, NPL>), grid, dim3(256), lds, st, p);
+  constexpr size_t lds = 2 * 2 * WT * NPL * KS * 128;
+  SWEM_ALLOW_LDS((conv_wgrad_bf_kernel<WT, NPL, KS>), lds);
+  hipLaunchKernelGGL((conv_wgrad_bf_kernel<WT, NPL, KS>), grid, dim3(256), lds, st, p);
   return SWEM_OK;
 }
 
@@ -526,8 +536,9 @@ extern "C" size_t swem_conv2d_wgrad_bf16x3_workspace(int B, int H, int W, int c0
   if (stride <= 0) return 0;
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const long long M = (long long)B * Ho * Wo;
-  WgradPlan pl = wgrad_bf_plan(M, Cout, KH, KW, c0, c1, c2, plan);
-  return (size_t)pl.zsplit * Cout * KH * KW * (c0 + c1 + c2) * sizeof(float);
+  const int z1 = wgrad_bf_plan(M, Cout, KH, KW, c0, c1, c2, plan, 1).zsplit;   // either math mode may follow
+  const int z2 = wgrad_bf_plan(M, Cout, KH, KW, c0, c1, c2, plan, 2).zsplit;
+  return (size_t)(z1 > z2 ? z1 : z2) * Cout * KH * KW * (c0 + c1 + c2) * sizeof(float);
 }
 
 extern "C" int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3, long long dy_ps,
@@ -558,7 +569,7 @@ extern "C" int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3,
   p.M = (int)M;
   p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.K = KH * KW * Cin;
-  WgradPlan pl = wgrad_bf_plan(M, Cout, KH, KW, c0, c1, c2, plan);
+  WgradPlan pl = wgrad_bf_plan(M, Cout, KH, KW, c0, c1, c2, plan, math);
   const size_t need = (size_t)pl.zsplit * Cout * p.K * sizeof(float);
   SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_wgrad_bf16x3: workspace %zu < %zu bytes", ws_bytes,
                need);
@@ -580,8 +591,16 @@ extern "C" int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3,
     p.ctiles = cdiv(cs[s], bt);
     dim3 grid(cdiv(Cout, bt), KH * KW * p.ctiles, pl.zsplit);
     int rc;
-    if (pl.wt == 2) rc = math == 1 ? launch_wgrad_bf<2, 3>(p, grid, st) : launch_wgrad_bf<2, 1>(p, grid, st);
-    else rc = math == 1 ? launch_wgrad_bf<1, 3>(p, grid, st) : launch_wgrad_bf<1, 1>(p, grid, st);
+    // slab: 16 pixels for the six-product 128x128 tile (48 KB of LDS instead of 96: three blocks per CU), else 32;
+    // plan bit 12 flips the choice (tools/wgrad_bench.py)
+    const bool ks16 = ((pl.wt == 2 && math == 1) != (((plan >> 12) & 1) != 0));
+    if (pl.wt == 2) {
+      if (math == 1) rc = ks16 ? launch_wgrad_bf<2, 3, 16>(p, grid, st) : launch_wgrad_bf<2, 3, 32>(p, grid, st);
+      else rc = ks16 ? launch_wgrad_bf<2, 1, 16>(p, grid, st) : launch_wgrad_bf<2, 1, 32>(p, grid, st);
+    } else {
+      if (math == 1) rc = ks16 ? launch_wgrad_bf<1, 3, 16>(p, grid, st) : launch_wgrad_bf<1, 3, 32>(p, grid, st);
+      else rc = ks16 ? launch_wgrad_bf<1, 1, 16>(p, grid, st) : launch_wgrad_bf<1, 1, 32>(p, grid, st);
+    }
     if (rc != SWEM_OK) return rc;
     SWEM_CHECK_LAUNCH("conv_wgrad_bf_kernel");
     off += cs[s];

@@ -562,7 +562,7 @@ def test_conv_wgrad_bf16_pipe(lib, case, math):
     for _ in range(3 - len(srcs)):
         args += [0, 0, 0, 0]
     cin_store = case.get('cin_store', cin)
-    for plan in (0, 1 | 3 << 4, 2 | 1 << 4):
+    for plan in (0, 1 | 3 << 4, 2 | 1 << 4, 2 | 2 << 4 | 1 << 12, 1 | 1 << 12):
         wsb = _lib.query('swem_conv2d_wgrad_bf16x3_workspace', B, H, W, cs[0], cs[1], cs[2], cout, k, k, s, pad, plan)
         ws = ops.workspace(wsb, d.device)
         dw = torch.full((cout, cin_store, k, k), 0.5, device=DEV)

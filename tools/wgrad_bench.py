@@ -15,7 +15,7 @@ SHAPES = [  # B, H, W, Cin, Cout, k, stride
 ]
 
 
-PLANS = [0] + [wt | z << 4 for wt in (1, 2) for z in (1, 2, 4, 8, 16)] if '--tune' in sys.argv else [0]
+PLANS = ([0, 1 << 12] + [wt | z << 4 | f << 12 for wt in (1, 2) for z in (1, 2, 4, 8, 16) for f in (0, 1)]) if '--tune' in sys.argv else [0]
 
 
 def main():
