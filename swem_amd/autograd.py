@@ -357,6 +357,29 @@ def concat2(x0, x1, batch):
     return _Concat2.apply(x0, x1, batch)
 
 
+class _Unbatch(Function):
+    """(n, ...) -> n tensors (1, ...): the frames of a clip go through the key encoder in ONE pass (BatchNorm is frozen, so a
+    sample's result does not depend on its batch mates) and are handed to the frame loop one by one; the backward puts
+    the frames' gradients back side by side (zeros for a frame whose output was not used)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.meta = (x.shape, n)
+        return tuple(x[i:i + 1].clone() for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shape, n = ctx.meta
+        ref = next(g for g in grads if g is not None)
+        parts = [g if g is not None else torch.zeros((1,) + tuple(shape[1:]), dtype=ref.dtype, device=ref.device)
+                 for g in grads]
+        return torch.cat(parts, 0), None
+
+
+def unbatch(x, n):
+    return _Unbatch.apply(x, n)
+
+
 class _GLU(Function):
     """modules.py:25-26: layer_f(x) * sigmoid(layer_a(x)) on the two convolutions' outputs."""
 
