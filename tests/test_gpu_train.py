@@ -183,6 +183,41 @@ def test_bn_act_backward(lib, relu, with_res):
         close(back(rx.grad), res.grad, 1e-6, 'dres')
 
 
+def test_bn_stages_write_the_operand_planes(lib):
+    """When a convolution split a BatchNorm stage's output in an earlier step (ops.SPLIT_HINTS), the stage writes the bf16
+    planes itself: they are BIT-identical to what swem_split_bf16x3_f32 makes of the same tensor (forward: y; backward: dc),
+    and ops.presplit finds them on the tensor instead of launching the split."""
+    from swem_amd import autograd as A, ops
+    A.reset()
+    g = torch.Generator().manual_seed(12)
+    B, Cc, H, W = 2, 64, 9, 13
+    mean, var = torch.randn(Cc, generator=g).to(DEV), (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+    gp, bp = param(torch.rand(Cc, generator=g) + 0.5), param(torch.randn(Cc, generator=g))
+    c = nhwc(torch.randn(B, Cc, H, W, generator=g))
+    dy = nhwc(torch.randn(B, Cc, H, W, generator=g))
+
+    def run():
+        A.new_step()
+        cx = c.clone().requires_grad_(True)
+        y = A.bn_act(cx, (gp, bp, mean, var), relu=True)
+        hinted = '_swem_split' in y.__dict__
+        py = ops.presplit(y, False).clone()                       # the next layer's conv asks for the split of y
+        seen = {}
+
+        def hook(gr):                                              # the conv backward asks for the split of dc
+            seen['dc'] = (gr.clone(), '_swem_split' in gr.__dict__, ops.presplit(gr, False).clone())
+        cx.register_hook(hook)
+        y.backward(dy)
+        return hinted, py, seen['dc']
+    h0, py0, (dc0, hd0, pd0) = run()                               # first step: the split kernel runs, the hints are recorded
+    assert not h0 and not hd0 and (id(gp), 'y') in ops.SPLIT_HINTS and (id(gp), 'dc') in ops.SPLIT_HINTS
+    h1, py1, (dc1, hd1, pd1) = run()                               # second step: the stages write the planes
+    assert h1 and hd1
+    assert torch.equal(py0.view(torch.int16), py1.view(torch.int16)) and torch.equal(dc0, dc1)
+    assert torch.equal(pd0.view(torch.int16), pd1.view(torch.int16))
+    A.reset()
+
+
 def test_maxpool_upsample_glu_backward(lib):
     from swem_amd import autograd as A
     g = torch.Generator().manual_seed(9)
