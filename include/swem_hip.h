@@ -107,7 +107,8 @@ int swem_split_bf16x3_f32(void *stream, const float *x, void *out, long long npi
  * Output, scale/shift/residual/ReLU-out/GLU, plan and workspace as swem_conv2d_nhwc_f32 (math bit ignored).
  * Plan bits 20-23 pick a kernel variant: 0 = the tile's default LDS ring (three stages for 64x64, two otherwise),
  * 1 = the other stage count, 2 / 3 = the 128x128 tile on eight waves with two / three stages, 4 / 6 = variants 0 / 2 on
- * v_mfma_f32_16x16x32_bf16 instead of 32x32x16; bits 24-27 = K-split factor of the last, partly filled round of tiles; bits 28-29 = log2 of the XCD partition of the
+ * v_mfma_f32_16x16x32_bf16 instead of 32x32x16, 8 / 9 = the 128x128 tile on four waves with 16-k blocks and two / three stages
+ * (half the LDS per stage: three / two blocks per CU instead of one); bits 24-27 = K-split factor of the last, partly filled round of tiles; bits 28-29 = log2 of the XCD partition of the
  * N tiles (1-3: 2 / 4 / 8 groups of N tiles, 8/groups XCDs per group, each XCD reading only its group's filters; 0: chosen
  * by the traffic model groups * activations + (8 / groups) * filters; ignored where the N tiles do not divide). */
 int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1, int c1,

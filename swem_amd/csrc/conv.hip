@@ -816,8 +816,11 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP &p, f32x4v (&acc)[TM
 // per FLOP, but the chip holds a higher clock on this shape under a dense bf16 load (MI355X_MICROARCH.md, DVFS item 7).
 // NPL = 3: the six-product bf16x6 arithmetic on the hi/mid/lo planes; NPL = 1: plain bf16 (hi plane only, one product) --
 // the mixed-precision mode of the training step (config.AMP), never the default.
-template <int WM, int WN, int NST, int NW, bool M16, int NPL>
+// KG = k/8 groups per k-block: 4 (32 k, the default) or 2 (16 k: half the LDS per stage -- the 128x128 tile then fits three
+// blocks of four waves per CU instead of one block; a k-block is half of a (channel block, tap) cell of the K order).
+template <int WM, int WN, int NST, int NW, bool M16, int NPL, int KG = 4>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kernel(ConvP p) {
+  static_assert(KG == 4 || (KG == 2 && !M16 && NW == 4), "16-k blocks: four waves, 32x32x16 MFMA");
   // block tile 64WM x 64WN, NW waves as an (NW/2) x 2 grid, each owning TM x TN 32x32 accumulator tiles
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int TM = 4 * WM / NW, TN = WN;
@@ -825,11 +828,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   // slot stride per k/8 group: the 16x16x32 fragment read mixes two k/8 groups inside one 16-lane bank group, which is
   // conflict free when the stride is a multiple of 16 slots; the 32x32x16 read does not care (kept as it was)
   constexpr int SA = BM + (M16 ? 0 : 1), SB = BN + (M16 ? 0 : 1);
-  constexpr int PA = 4 * SA, PB = 4 * SB;
-  constexpr int NA = NPL * 4 * WM, NB = NPL * 4 * WN;  // 64-row fragment runs per k-block
+  constexpr int PA = KG * SA, PB = KG * SB;
+  constexpr int NA = NPL * KG * WM, NB = NPL * KG * WN;  // 64-row fragment runs per k-block
   // NST LDS stages: the transfers run NST-1 k-blocks ahead of the MFMAs
   constexpr int NDMA = (NA + NB) / NW;             // transfers per wave per k-block
-  static_assert(NW == 4 || WM == WN, "eight waves: four move the A image, four the B image, the same count each");
+  static_assert(NW == KG || WM == WN, "split roles: half the waves move the A image, half the B image, the same count each");
   static_assert((NA + NB) % NW == 0, "every wave must issue the same number of transfers (counted vmcnt)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4 *As = reinterpret_cast<uint4 *>(smem);  // [NST][3][PA]
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   // compile-time constant and the wave only adds its group's offsets, kept in scalars that advance by one add per k-block.
   // (With eight waves, waves 0-3 move the A image and 4-7 the B image.)  Scalar instructions share the wave's issue
   // slot with the MFMAs: the first version of this loop spent 24 % of its wave cycles on ~190 of them per k-block.
-  const int g = wave & 3, half = wave >> 2;
+  const int g = wave % KG, half = wave / KG;   // (NW == KG: every wave moves both images of its group)
   unsigned avoff[WM];
   unsigned aplane = 0, agroup = 0;  // byte strides between the planes / the 8-channel groups of the current source
   unsigned a_base = 0;              // scalar offset of (current k-block, group g) in plane 0 of the current source
@@ -924,14 +927,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
 #pragma unroll
     for (int j = 0; j < WM; ++j) avoff[j] = ((tmask[j] >> t) & 1ull) ? (unsigned)(pix0[j] + delta) * 16u : OOB;
   };
+  int khalf = 0;   // KG == 2: which 16-channel half of the current (channel block, tap) cell
   auto advance = [&](KPos &q) __attribute__((always_inline)) {
-    w_base += (BK / 8) * wgroup;
+    w_base += KG * wgroup;
+    if (KG == 2) {
+      khalf ^= 1;
+      if (khalf) {                 // second half of the same cell: the same tap, the next two channel groups
+        a_base += 2 * agroup;
+        return;
+      }
+      a_base -= 2 * agroup;
+    }
     if (++q.kx == p.KW) {
       q.kx = 0;
       if (++q.ky == p.KH) {
         q.ky = 0;
         q.ci0 += BK;
-        a_base += (BK / 8) * agroup;
+        a_base += 4 * agroup;
         const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
         if (q.ci0 >= cs) {
           q.ci0 = 0;
@@ -946,13 +958,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   const unsigned lds_a = lds0 + (unsigned)g * (SA * 16), lds_b = lds0 + NST * NPL * PA * 16 + (unsigned)g * (SB * 16);
   auto issue = [&](int stage) __attribute__((always_inline)) {
     const unsigned sa = lds_a + (unsigned)stage * (NPL * PA * 16), sb = lds_b + (unsigned)stage * (NPL * PB * 16);
-    if (NW == 4 || half == 0) {
+    if (NW == KG || half == 0) {
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
         for (int j = 0; j < WM; ++j) dma16(rsa, sa + (pl * PA + j * 64) * 16, avoff[j], a_base + pl * aplane);
     }
-    if (NW == 4 || half == 1) {
+    if (NW == KG || half == 1) {
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
@@ -978,8 +990,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   }
 
-  const int kb_begin = blockIdx.z * p.kb_per_split;
-  const int kb_end = min(p.nkb, kb_begin + p.kb_per_split);
+  const int kb_begin32 = blockIdx.z * p.kb_per_split;
+  const int kb_begin = kb_begin32 * (4 / KG);                       // in this kernel's k-blocks (16 or 32 k)
+  const int kb_end = min(p.nkb, kb_begin32 + p.kb_per_split) * (4 / KG);
   // Ring of NST stages.  In iteration kb the transfers of block kb+NST-1 are issued into the stage that was read in
   // iteration kb-1, the MFMAs run on stage kb%NST, then a COUNTED wait (all but the newest (NST-2)*NDMA transfers of
   // this wave, i.e. everything up to block kb+1) and a raw s_barrier publish stage (kb+1)%NST.  __syncthreads() would
@@ -987,8 +1000,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   KPos q;
   {   // k-block kb = (channel block, tap)
     const int taps = p.KH * p.KW;
-    int cb = kb_begin / taps;
-    const int t = kb_begin - cb * taps;
+    int cb = kb_begin32 / taps;
+    const int t = kb_begin32 - cb * taps;
     q.ky = t / p.KW;
     q.kx = t - q.ky * p.KW;
     q.src = 0;
@@ -1004,7 +1017,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
     q.ci0 = ci;
     set_src(q);
   }
-  w_base = (unsigned)(kb_begin * (BK / 8) + g) * wgroup;
+  w_base = (unsigned)(kb_begin32 * 4 + g) * wgroup;
   set_tap(q);
   issue(0);
   if (NST == 3) {
@@ -1057,7 +1070,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
     const uint4 *Ab = As + st * NPL * PA + wm * 32 * TM + r;
       const uint4 *Bb = Bs + st * NPL * PB + wn * 32 * TN + r;
   #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
+      for (int s2 = 0; s2 < KG / 2; ++s2) {
         const int k8 = 2 * s2 + h;
         uint4 a[NPL][TM], b[NPL][TN];
   #pragma unroll
@@ -1213,17 +1226,17 @@ int launch_bf3(const ConvP &p, dim3 grid, hipStream_t st) {
   return SWEM_OK;
 }
 
-template <int WM, int WN, int NST, int NW, bool M16 = false>
+template <int WM, int WN, int NST, int NW, bool M16 = false, int KG = 4>
 int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st) {
   if (p.nplanes == 1) {   // plain bf16 (one plane, one product): a third of the LDS, the same tiles
-    constexpr size_t lds1 = NST * 1 * 4 * (64 * WM + 1 + 64 * WN + 1) * 16;
-    SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1>), lds1);
-    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1>), grid, dim3(64 * NW), lds1, st, p);
+    constexpr size_t lds1 = NST * 1 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;
+    SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG>), lds1);
+    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG>), grid, dim3(64 * NW), lds1, st, p);
     return SWEM_OK;
   }
-  constexpr size_t lds = NST * 3 * 4 * (64 * WM + 1 + 64 * WN + 1) * 16;  // NST stages x 3 planes
-  SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 3>), lds);
-  hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 3>), grid, dim3(64 * NW), lds, st, p);
+  constexpr size_t lds = NST * 3 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;  // NST stages x 3 planes
+  SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 3, KG>), lds);
+  hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 3, KG>), grid, dim3(64 * NW), lds, st, p);
   return SWEM_OK;
 }
 
@@ -1236,6 +1249,8 @@ int launch_bf3s(const ConvP &p, dim3 grid, hipStream_t st, int variant) {
     if (variant == 2) return launch_bf3s_n<2, 2, 2, 8>(p, grid, st);
     if (variant == 3) return launch_bf3s_n<2, 2, 3, 8>(p, grid, st);
     if (variant == 6) return launch_bf3s_n<2, 2, 2, 8, true>(p, grid, st);
+    if (variant == 8) return launch_bf3s_n<2, 2, 2, 4, false, 2>(p, grid, st);   // 16-k blocks: three blocks per CU
+    if (variant == 9) return launch_bf3s_n<2, 2, 3, 4, false, 2>(p, grid, st);   // ... three stages: two blocks per CU
   }
   if (variant == 4)
     return (WM * WN == 1) ? launch_bf3s_n<WM, WN, 3, 4, true>(p, grid, st) : launch_bf3s_n<WM, WN, 2, 4, true>(p, grid, st);

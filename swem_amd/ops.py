@@ -349,11 +349,14 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
                     if wm == 2 and wn == 2:
                         cands.append(base | 2 << 20)
                         cands.append(base | 6 << 20)
+                        cands.append(base | 8 << 20)          # 16-k blocks: three blocks of four waves per CU
+                        cands.append(base | 9 << 20)          # ... with three LDS stages (two blocks per CU)
                     if ns == 1 and blocks > 256 and nkb >= 16:   # tail split: the last, partly filled round over K
                         for ts in (4, 8):
                             cands.append(base | ts << 24)
                             if wm == 2 and wn == 2:
                                 cands.append(base | 2 << 20 | ts << 24)
+                                cands.append(base | 8 << 20 | ts << 24)
     def timed(plan):
         launch(plan)                               # warm (also grows the workspace)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -219,7 +219,7 @@ def test_bicubic_flip_lincomb_inject(lib):
 
 @pytest.mark.parametrize('plan', [0x00011, 0x00021, 0x00022, 0x00211, 0x10011, 0x10021, 0x10022, 0x10321,
                                   0x110011, 0x110021, 0x110022, 0x210022, 0x310022, 0x210222,
-                                  0x410011, 0x410021, 0x410022, 0x610022, 0x410221],
+                                  0x410011, 0x410021, 0x410022, 0x610022, 0x410221, 0x810022, 0x910022, 0x810222, 0x910322],
                          ids=lambda p: 'math%d_wm%d_wn%d_ns%d' % (p >> 16, p & 15, (p >> 4) & 15, (p >> 8) & 255))
 def test_conv2d_plans_and_math_modes(lib, plan):
     """Every tiling / K-split / math mode of the fast conv kernel gives the same convolution: fp32 MFMA and the
@@ -246,7 +246,7 @@ def test_conv2d_plans_and_math_modes(lib, plan):
         close(back(y), ref, 2e-5, 'glu plan %#x' % plan)
 
 
-@pytest.mark.parametrize('plan', [0x20011, 0x20021, 0x20022, 0x120021, 0x220022, 0x420011, 0x420021, 0x620022, 0x20221,
+@pytest.mark.parametrize('plan', [0x20011, 0x20021, 0x20022, 0x120021, 0x220022, 0x420011, 0x420021, 0x620022, 0x20221, 0x820022, 0x920022,
                                   0x4020021], ids=lambda p: '%#x' % p)
 def test_conv2d_plain_bf16_mode(lib, plan):
     """Math mode 2 (mixed-precision training, config.AMP): operands rounded to bf16 once, ONE MFMA product, fp32
@@ -271,7 +271,7 @@ def test_conv2d_plain_bf16_mode(lib, plan):
     assert 1e-5 < err < 1e-2, err             # really one bf16 product (not the exact six), and no worse than bf16
 
 
-@pytest.mark.parametrize('plan', [0x10010011, 0x20010011, 0x30010011, 0x10010021, 0x20010022, 0x30210022, 0x24010021,
+@pytest.mark.parametrize('plan', [0x10010011, 0x20010011, 0x30010011, 0x10010021, 0x20010022, 0x30210022, 0x24010021, 0x20810022,
                                   0x20020021, 0x10010211], ids=lambda p: '%#x' % p)
 def test_conv2d_xcd_partition(lib, plan):
     """Plan bits 28-29: the tile grid is dealt to the 8 XCDs in 2 / 4 / 8 groups of N tiles instead of ranges of M tiles.
@@ -289,7 +289,7 @@ def test_conv2d_xcd_partition(lib, plan):
     close(back(y), ref, 2e-5 if (plan >> 16) & 3 == 1 else 1e-2, 'xcd-partitioned conv')
 
 
-@pytest.mark.parametrize('plan', [0x4010021, 0x8010011, 0x4210022, 0x4010022], ids=lambda p: '%#x' % p)
+@pytest.mark.parametrize('plan', [0x4010021, 0x8010011, 0x4210022, 0x4010022, 0x4810022], ids=lambda p: '%#x' % p)
 def test_conv2d_tail_split(lib, plan):
     """Plan bits 24-27: the last, partly filled round of tiles is launched a second time split over K and reduced over
     its rows only; the result equals the plain launch's up to fp32 summation order."""
