@@ -119,15 +119,6 @@ class ConvPack:
             _lib.call('swem_split_bf16x3_f32', _stream(), wk.data_ptr(), self.w3.data_ptr(), co, kk, 0)
 
 
-def split_bf16x3(w):
-    """w (fp32) -> (3, ...) bf16 with w = hi + mid + lo, round-to-nearest residuals (one-time weight packing)."""
-    hi = w.to(torch.bfloat16)
-    r1 = w - hi.float()
-    mid = r1.to(torch.bfloat16)
-    lo = (r1 - mid.float()).to(torch.bfloat16)
-    return torch.stack([hi, mid, lo]).contiguous()
-
-
 def pack_conv(weight, bias=None, bn=None, stride=1, pad=None, cin_pad=None, eps=1e-5):
     """OIHW weight (+bias, + frozen BatchNorm (gamma, beta, mean, var)) -> ConvPack.
     BN folding follows ATen's eval-mode batch_norm: alpha = gamma/sqrt(var+eps), y = x*alpha + (beta - mean*alpha)."""
