@@ -122,6 +122,14 @@ def main():
     rank, local_rank, world = sdist.env_world()
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (the reference is launched through
+        # torch.distributed.launch, train.py:22-41).  Nothing in this process has touched the GPU yet; the ranks are
+        # fresh child interpreters, this parent relays rank 0's JSON line and the exit code.
+        rc, text = sdist.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
+        sys.stdout.write(text)
+        sys.stdout.flush()
+        raise SystemExit(rc)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: swem_amd has no CPU path')
     # one rank per GPU; (ranks wrap around only when a multi-rank run is rehearsed on a smaller box, SWEM_DIST_BACKEND=gloo)
@@ -129,6 +137,9 @@ def main():
     torch.cuda.set_device(local_rank)        # before the RCCL communicator is created
     dev = torch.device('cuda', local_rank)
     sdist.init()
+    ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    if ranks != args.gpus:
+        raise SystemExit('--gpus %d but the process group has %d ranks' % (args.gpus, ranks))
 
     import __graft_entry__
     if rank == 0:
@@ -210,7 +221,7 @@ def main():
         fps = total_frames / max_t
         out = {
             'metric': 'frames/sec (480p, K=256 bases, multi-object SWEM inference)', 'value': round(fps, 3),
-            'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': ranks, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * max_t / args.steps, 3), 'ms_per_frame': round(1e3 * max_t / total_frames * world, 3),
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

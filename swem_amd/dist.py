@@ -29,6 +29,29 @@ def init(backend=None):
     return rank, local_rank, world
 
 
+def launch_ranks(n, argv, env=None, timeout=None):
+    """Start `n` ranks of the script `argv[0]` (one process per GPU) as CHILD processes and wait for them: the
+    reference is launched through torch.distributed.launch (train.py:22-41, train_swem_s3.sh:23); here a plain
+    ``python bench.py --gpus N`` does that launch itself.  Must be called BEFORE the calling process touches the GPU
+    (no HIP call, no torch.cuda query): the children are fresh interpreters started by torch.distributed.run, the
+    parent only relays their output and exit code -- it never execs over a GPU-initialised process.
+    Returns (exit code, captured stdout of the job)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ if env is None else env)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(int(n)),
+           '--master-addr', '127.0.0.1', '--master-port', str(port)] + list(argv)
+    p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, timeout=timeout)
+    return p.returncode, p.stdout.decode(errors='replace')
+
+
 def shard(items, rank, world):
     """Round-robin partition: every item goes to exactly one rank."""
     return [it for i, it in enumerate(items) if i % world == rank]

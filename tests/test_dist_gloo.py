@@ -52,3 +52,25 @@ def test_single_process_is_a_no_op():
     assert sdist.reduce_counters(5, 0.5) == (5, 0.5)
     t = torch.ones(10)
     assert sdist.allreduce_sum_(t) is t and float(t.sum()) == 10.0
+
+
+def test_launch_ranks_starts_a_real_two_rank_group():
+    """bench.py --gpus N without torchrun starts its N ranks through dist.launch_ranks (reference: torch.distributed.launch,
+    train.py:22-41): the children must form ONE process group of N ranks and rank 0's line must come back."""
+    import json
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_dist_probe.py')
+    env = dict(os.environ, RANK='5', WORLD_SIZE='1')          # a stale environment must not leak into the ranks
+    rc, text = sdist.launch_ranks(2, [probe, '--gpus', '2'], env=env, timeout=300)
+    assert rc == 0, text
+    line = json.loads([ln for ln in text.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['ranks'] == 2
+    assert line['frames'] == 6 and line['seconds'] == 2.0 and line['argv'] == ['--gpus', '2']
+    assert sys.executable
+
+
+def test_bench_self_launch_comes_before_any_gpu_call():
+    """The parent of `python bench.py --gpus 2` must hand over to child ranks before it queries the GPU."""
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'bench.py')).read()
+    main = src[src.index('def main():'):]
+    assert main.index('sdist.launch_ranks(') < main.index('torch.cuda.')

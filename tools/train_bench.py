@@ -34,9 +34,14 @@ def main():
     ap.add_argument('--per-step', action='store_true', help='synchronise and print every step time (stderr)')
     ap.add_argument('--save-plans', default=None)
     ap.add_argument('--load-plans', default=None, help='reuse tuned conv plans (profiler runs)')
+    ap.add_argument('--gpus', type=int, default=1, help='ranks (one per GPU); without torchrun the ranks are started here')
     a = ap.parse_args()
     from swem_amd import dist as sdist
     rank, local_rank, world = sdist.env_world()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:      # before any GPU call: the ranks are child processes
+        rc, text = sdist.launch_ranks(a.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
+        sys.stdout.write(text)
+        raise SystemExit(rc)
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -97,6 +102,7 @@ def main():
         print(json.dumps({'metric': 'training clips/s (3 x %dx%d frames, %d objects, %s, %s)' % (
         a.size, a.size, a.objects, a.backbone, 'AMP: bf16 conv operands' if a.amp else 'fp32-accurate'), 'value': a.clips / dt, 'ms_per_step': dt * 1e3, 'clips_per_step': a.clips,
         'total_loss': float(losses['total_loss']), 'graph': tr._graph is not None, 'lanes': a.lanes, 'n_gpus': world,
+        'rccl_ranks': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
         'peak_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30}))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
