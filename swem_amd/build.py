@@ -19,8 +19,8 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'swem_hip.h'),
-            os.path.join(HERE, '..', 'include', 'swem_hip_train.h')]
+    import glob
+    hdrs = sorted(glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, '..', 'include', '*.h')))
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -89,3 +89,17 @@ def allreduce_sum_(flat, bucket_bytes=64 << 20):
     for w in works:
         w.wait()
     return flat
+
+
+def broadcast_model_(flat_param, module=None, src=0):
+    """Rank `src`'s parameters (one flat buffer, optim.flatten_parameters) and the module's buffers (BatchNorm running
+    statistics, mean / std) to every rank: what DistributedDataParallel does once in its constructor
+    (swem_trainer.py:41-43).  No-op for one process."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return flat_param
+    dist.broadcast(flat_param, src=src)
+    if module is not None:
+        for b in module.buffers():
+            if b.numel():
+                dist.broadcast(b, src=src)
+    return flat_param

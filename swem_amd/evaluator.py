@@ -134,8 +134,11 @@ class FrameGraph:
     lives in static buffers: the captured memorize writes fresh bases, a device copy moves them into the static
     ones at the end of the graph.  Requires both banks to exist (i.e. at least two frames already processed)."""
 
-    def __init__(self, model, frame_shape, out_size):
+    def __init__(self, model, frame_shape, out_size, streams=None):
+        """streams: (warm-up stream, capture stream) to reuse (SequencePool keeps one pair per lane: a DAVIS / YouTube-VOS
+        sweep re-captures for every new object count or frame shape, and HIP streams are never garbage collected)."""
         self.model, self.out_size = model, (int(out_size[0]), int(out_size[1]))
+        self.streams = streams
         core = model.swem_core
         upd = core.memories['update'].bases
         if upd is None or core.memories['first'].bases is None:
@@ -154,7 +157,9 @@ class FrameGraph:
         with torch.no_grad():
             # one eager pass on a side stream (also sizes every workspace), then restore the state it consumed
             saved = {k: v.clone() for k, v in self.state.items()}
-            s = ops.new_stream()
+            if self.streams is None:
+                self.streams = (ops.new_stream(), ops.new_stream())
+            s = self.streams[0]
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 frame_step(self.model, self.frame, self.out_size)
@@ -164,8 +169,9 @@ class FrameGraph:
             core.memories['update'].bases = self.state
             # capture on a stream of this graph's own: scratch buffers are per stream (ops.workspace), and graphs that are
             # replayed concurrently must not share one (torch's default capture stream is one object for all captures)
-            self.capture_stream = ops.new_stream()
-            with torch.cuda.graph(self.graph, stream=self.capture_stream):
+            # (their scratch is allocated inside the capture and owned by the graph: ops.private_workspaces)
+            self.capture_stream = self.streams[1]
+            with ops.private_workspaces(), torch.cuda.graph(self.graph, stream=self.capture_stream):
                 self.pred = frame_step(self.model, self.frame, self.out_size)
                 new = core.memories['update'].bases
                 for k in self.state:
@@ -285,6 +291,7 @@ class SequencePool:
         n = len(self.models)
         self.streams = overlapping_streams(n) if n > 1 else [torch.cuda.current_stream()]
         self.graphs = [None] * n
+        self.graph_streams = [None] * n      # per lane: (warm-up stream, capture stream), reused by every re-capture
         self.use_graph = use_graph
 
     def run(self, sequences, seeds=None):
@@ -320,7 +327,10 @@ class SequencePool:
                             if g is not None and g.frame.shape == frames[:, i].shape and g.out_size == out_size:
                                 bound = getattr(g, '_bound_to', None) == si or g.rebind()
                             if not bound and model.swem_core.memories['update'].bases is not None:
-                                g = self.graphs[li] = FrameGraph(model, frames[:, i].shape, out_size).capture(frames[:, i])
+                                self.graphs[li] = None        # the replaced graph (and its private pool) goes first
+                                g = FrameGraph(model, frames[:, i].shape, out_size, streams=self.graph_streams[li])
+                                g.capture(frames[:, i])
+                                self.graphs[li], self.graph_streams[li] = g, g.streams
                                 bound = True
                             if bound:
                                 g._bound_to = si

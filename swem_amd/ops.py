@@ -97,6 +97,22 @@ def workspace(nbytes, device):
     return buf
 
 
+class private_workspaces:
+    """Scope for a HIP-graph capture: scratch buffers requested inside are allocated INSIDE the capture (so they belong to
+    the graph's private pool and live exactly as long as the graph), never taken from -- or left in -- the grow-only
+    per-stream cache.  Without it a graph captured on a stream that had already run eagerly holds a raw pointer to a cached
+    buffer, which a later, larger eager request on that stream replaces and frees under the graph."""
+
+    def __enter__(self):
+        self.saved = dict(_ws)
+        _ws.clear()
+        return self
+
+    def __exit__(self, *a):
+        _ws.clear()
+        _ws.update(self.saved)
+
+
 class ConvPack:
     """Weights of one conv in kernel layout: w [Cout'][KH][KW][Cin_pad] plus per-filter scale / shift."""
 

@@ -166,6 +166,10 @@ class SWEMTrainer:
                 mod.eval()
         A.reset()
         self.optimizer = optim.make_optimizer(_get(config, 'SOLVER'), model, num_gpu)
+        # DistributedDataParallel's constructor broadcasts rank 0's parameters AND buffers (swem_trainer.py:41-43;
+        # broadcast_buffers=False only stops the per-iteration re-broadcast): without it rank-local initialisation
+        # (FROM_SCRATCH, the orthogonal fifth stem channel of checkpoint.adapt_state_dict) would train W different models
+        sdist.broadcast_model_(self.optimizer.param, model)
         self.lr_scheduler = optim.make_lr_scheduler(_get(config, 'SOLVER'), self.optimizer)
         self.criterion = L.get_criterion(_get(config, 'LOSS'), None, 1, 1, dev)
         self.graph = TrainGraph(model)
@@ -347,6 +351,9 @@ class SWEMTrainer:
         sdist.allreduce_sum_(self.optimizer.grad)                      # RCCL over xGMI; no-op for one process
         self.optimizer.step()
         self.lr_scheduler.step()
+        # the parameters changed in place: inference through this model (validation, encode_key / segment modes) must not run
+        # on the conv packs of the engine built before the step
+        self.model.invalidate()
         sums = bf['sums']
         losses = {'total_loss': sums[0], 'main_loss': sums[1], 'aux_loss': sums[2], 'p': p}
         return losses, results
@@ -362,7 +369,10 @@ class SWEMTrainer:
         torch.cuda.synchronize()
         ls = self._lanes(self.buf['frames'].shape[0])
         main = torch.cuda.current_stream()
-        with self._math():
+        # scratch buffers of the captured launches are allocated inside the captures (ops.private_workspaces): the eager
+        # warm-up steps left cached workspaces on these very streams, and a graph must not point into a cache entry that a
+        # later, larger eager request (e.g. 480p validation between steps) replaces
+        with self._math(), ops.private_workspaces():
             g_pre = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_pre):
                 self._pre()

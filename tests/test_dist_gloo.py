@@ -27,6 +27,12 @@ def _worker(rank, world, port, q):
     flat = torch.full((1000003,), float(r + 1))
     sdist.allreduce_sum_(flat, bucket_bytes=1 << 20)
     assert float(flat.min()) == float(flat.max()) == 3.0
+    # training start: rank 0's parameters and buffers reach every rank (DistributedDataParallel's constructor broadcast)
+    lin = torch.nn.BatchNorm1d(5)
+    lin.running_mean.fill_(float(r + 7))
+    fp = torch.full((1001,), float(r + 1))
+    sdist.broadcast_model_(fp, lin)
+    assert float(fp.min()) == float(fp.max()) == 1.0 and float(lin.running_mean.max()) == 7.0
     q.put((r, mine, frames, secs))
     dist.destroy_process_group()
 

@@ -646,3 +646,38 @@ def test_amp_step_tracks_the_fp32_step(lib):
     assert abs(float(ga.norm()) / float(g32.norm()) - 1) < 0.05
     assert hg == ha and torch.equal(gg, ga) and torch.equal(pg, pa)
     assert all(abs(a - b) < 0.05 * abs(b) for a, b in zip(ha, h32)), (ha, h32)
+
+
+def test_inference_after_a_step_sees_the_updated_weights(lib):
+    """SWEM.engine() caches packed conv filters; an optimizer step changes the parameters in place, so the trainer
+    invalidates the cache: inference through the trained model equals a fresh model loaded from its state_dict()."""
+    from swem_amd import evaluator, synth
+    from swem_amd.swem import SWEM
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    case = dict(tc['cases']['r18'], hw=[128, 128])
+    cfg = O.make_cfg(**case['cfg'])
+    model, _ = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+    frames, m0 = synth.make_clip(t=3, h=128, w=192, n_obj=2, seed=8)
+    frames, m0 = frames.to(DEV), m0.to(DEV)
+
+    def infer(m):
+        m.swem_core.init_on_host = True
+        with torch.no_grad():
+            torch.manual_seed(5)
+            _, scores = evaluator.evaluate_davis_seq(m, frames, [m0, None, None], (128, 192))
+        return scores[-1].clone()
+    before = infer(model)                                   # builds (and caches) the engine on the initial weights
+    solver = dict(tc['solver_cfg'], BASE_LR=1e-2)           # a step large enough to move the outputs visibly
+    trainer = SWEMTrainer(dict(SOLVER=solver, LOSS=tc['loss_cfg'], AMP=False), model, use_graph=False)
+    fr, im, lb, va = [t.to(DEV) for t in H.train_batch(case)]
+    torch.manual_seed(91)
+    trainer.one_step(fr, im, va, lb, 5)
+    model.eval()
+    after = infer(model)
+    fresh = SWEM(cfg)
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    fresh = fresh.eval().to(DEV)
+    ref = infer(fresh)
+    assert float((after - before).abs().max()) > 1e-3, 'the step did not move the outputs: the test is vacuous'
+    assert torch.equal(after, ref)
