@@ -201,10 +201,50 @@ class Core:
 # --------------------------------------------------------------------------- #
 # Networks (methods/basic_modules/{networks,mod_resnet,attentions}.py)
 # --------------------------------------------------------------------------- #
+# Mixed-precision restatement (test_gpu_train.py::test_amp_step_vs_rounded_operand_oracle).  The reference's config.AMP is
+# fp16 autocast (basic_trainer.py:83-86,222); the build's AMP rounds the CONVOLUTION operands to bf16 (round to nearest
+# even) and accumulates in fp32.  ROUNDED_CONV, when set, is a policy  f(name, x, w, stride) -> (fwd, dgrad, wgrad)  that
+# says which of a layer's three GEMMs take rounded operands; the arithmetic below is then exactly "fp32 conv on rounded
+# operands" for those.  None (the default) = the reference's fp32 path, untouched.
+ROUNDED_CONV = None
+
+
+def _bf16r(t):
+    return t.bfloat16().to(t.dtype)
+
+
+class _ConvRounded(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, flags):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, flags, b is not None)
+        xf, wf = (_bf16r(x), _bf16r(w)) if flags[0] else (x, w)
+        return F.conv2d(xf, wf, b, stride=stride, padding=pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, flags, has_b = ctx.cfg
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            d, ww = (_bf16r(dy), _bf16r(w)) if flags[1] else (dy, w)
+            dx = torch.nn.grad.conv2d_input(x.shape, ww, d, stride=stride, padding=pad)
+        if ctx.needs_input_grad[1]:
+            d, xx = (_bf16r(dy), _bf16r(x)) if flags[2] else (dy, x)
+            dw = torch.nn.grad.conv2d_weight(xx, w.shape, d, stride=stride, padding=pad)
+        if has_b and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3))
+        return dx, dw, db, None, None, None
+
+
 def conv(sd, name, x, stride=1, pad=None):
     w = sd[name + '.weight']
     if pad is None:
         pad = w.shape[-1] // 2
+    if ROUNDED_CONV is not None:
+        flags = ROUNDED_CONV(name, x, w, stride)
+        if any(flags):
+            return _ConvRounded.apply(x, w, sd.get(name + '.bias'), stride, pad, tuple(flags))
     return F.conv2d(x, w, sd.get(name + '.bias'), stride=stride, padding=pad)
 
 

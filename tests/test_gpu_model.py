@@ -4,8 +4,10 @@ clips generated from the reference.
 Stage tests feed the HIP stage the ORACLE's inputs, so errors do not compound (tolerance 1e-4 relative to the
 tensor's max, fp32 everywhere).  End-to-end clips are free running: the reference's own fp32-vs-fp64 noise floor
 on these clips is 0.4-0.7 in the logits (stored in the fixtures, SURVEY.md section 7.2: low-mass bases are
-rounding noise), so the end-to-end bar is  max(1e-3, 2 x floor)  on the logits and an index-map agreement at least
-as good as the reference's own fp32-vs-fp64 agreement; frame 1, which precedes any chaotic feedback, is held to 1e-3."""
+rounding noise, and already frame 1 reads a memory built by several EM iterations), so the free-running bar is
+max(1e-3, 2 x floor)  on the logits and an index-map agreement at least as good as the reference's own fp32-vs-fp64
+agreement.  The 1e-3 / 0.9995 bars of the north star are asserted per frame with the memory TEACHER-FORCED from the oracle
+(tests/test_gpu_parity.py); the numbers measured here are written to the round's parity report (helpers.record_parity)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -158,6 +160,9 @@ def test_clip_vs_golden(lib, golden, name, kw, sub):
     for i, (dl, agree, dctx) in enumerate(rows):
         print('%s frame %d: |dlogits| %.3g (reference fp32-vs-fp64 floor %.3g)  index agree %.6f (floor %.6f)  |dctx| %.3g'
               % (name, i + 1, dl, float(floor[i]), agree, float(agree64[i]), dctx))
+    H.record_parity('free_running_' + name.split('.')[0], [
+        {'frame': i + 1, 'dlogits_max': dl, 'reference_fp32_vs_fp64_floor': float(floor[i]), 'index_agreement': agree,
+         'reference_fp32_vs_fp64_agreement': float(agree64[i]), 'dcontext_max': dctx} for i, (dl, agree, dctx) in enumerate(rows)])
     # before the memory is involved the 1e-4 bar holds
     assert relmax(trace[0]['qk16'], fx['qk16_0']) < 1e-4
     for i, (dl, agree, _) in enumerate(rows):
@@ -227,13 +232,18 @@ def test_ytvos_loop_and_tta_vs_golden(lib, golden):
         print('ytvos frame %d: index agreement %.6f (reference fp32-vs-fp64 %.6f)' % (i + 1, agree, float(fx['agree64'][i])))
         assert agree >= min(0.9995, float(fx['agree64'][i]) - 0.01)
     assert int(preds[0].max()) <= 1 and int(preds[-1].max()) == 2
+    rec = {'ytvos_index_agreement': [float((p.cpu().to(torch.uint8) == fx['pred%d' % i]).float().mean())
+                                     for i, p in enumerate(preds)],
+           'reference_fp32_vs_fp64_agreement': [float(v) for v in fx['agree64']]}
     with torch.no_grad():
         tta = evaluator.evaluate_davis_seq_ms(H.SeededInit(model, 79), frames[:, :3].to(DEV),
                                               [per_frame[0].to(DEV), None, None], (240, 432), scales=(240, 288), is_flip=True)
     for i, p in enumerate(tta):
         agree = float((p.cpu().to(torch.uint8) == fx['tta%d' % i]).float().mean())
         print('tta frame %d: index agreement %.6f' % (i + 1, agree))
+        rec.setdefault('tta_index_agreement', []).append(agree)
         assert agree >= 0.97
+    H.record_parity('free_running_g8_ytvos_tta', rec)
 
 
 @pytest.mark.parametrize('n_obj,h,w,bases,topl', [(1, 96, 160, 64, 64), (5, 112, 176, 64, 32), (3, 80, 144, 128, 64)],

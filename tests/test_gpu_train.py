@@ -334,7 +334,7 @@ def test_heads_backward(lib):
     close(hm.grad.cpu(), masks.grad, 1e-6, 'd masks')
 
 
-@pytest.mark.parametrize('L,banks,topl,N', [(64, 1, 32, 2), (64, 2, 64, 2), (128, 2, 64, 2), (64, 2, 32, 5)])
+@pytest.mark.parametrize('L,banks,topl,N', [(64, 1, 32, 2), (64, 2, 64, 2), (128, 2, 64, 2), (64, 2, 32, 5), (256, 2, 64, 2)])
 def test_match_backward(lib, L, banks, topl, N):
     """get_affinity + perm_inv_feat: d qk (through the l2norm, the joint softmax and the top-l prefix features) and
     d nu for both banks, against the oracle under autograd."""
@@ -403,7 +403,7 @@ def test_memorize_backward(lib):
     close(hv.grad.cpu(), v.grad[0].flatten(2).permute(0, 2, 1), 1e-3, 'd v')
 
 
-@pytest.mark.parametrize('tag,it', [('r18', 5), ('r18', 45), ('r50', 45)])
+@pytest.mark.parametrize('tag,it', [('r18', 5), ('r18', 45), ('r50', 45), ('r50k256', 45), ('r50k256n5', 45)])
 def test_one_step_matches_reference_trainer(golden, lib, tag, it):
     """a18: SWEMTrainer.one_step on HIP against the losses, index maps, per-parameter gradient norms and the AdamW
     update recorded from the REFERENCE trainer (tests/golden/make_golden_train.py)."""
@@ -444,6 +444,13 @@ def test_one_step_matches_reference_trainer(golden, lib, tag, it):
     fe = fx['floor64_elem'].tolist()
     print('   elementwise rel err: pred.weight %.2e (floor %.1e), key_proj.bias %.2e (%.1e), value conv1.weight %.2e (%.1e)'
           % (errs[0], fe[0], errs[1], fe[1], errs[2], fe[2]))
+    H.record_parity('train_step_%s_it%d' % (tag, it), {
+        'losses': got, 'reference_losses': {k: float(fx[k]) for k in got}, 'reference_fp32_vs_fp64_loss_floor': float(fx['floor64_loss']),
+        'index_agreement': agree, 'reference_fp32_vs_fp64_agreement': float(fx['agree64']),
+        'grad_norm_rel_err': {'median': srt[len(srt) // 2], 'p90': srt[int(len(srt) * 0.9)], 'worst': srt[-1]},
+        'reference_fp32_vs_fp64_grad_norm_floor': {'median': sorted(floors)[len(floors) // 2], 'max': max(floors)},
+        'elementwise_rel_err': dict(zip(('decoder.pred.weight', 'key_proj.key_proj.bias', 'value_encoder.conv1.weight'), errs)),
+        'parameters_compared': len(names)})
     for k in got:
         assert got[k] == pytest.approx(float(fx[k]), rel=max(1e-4, 5 * float(fx['floor64_loss']))), k
     assert losses['p'] == pytest.approx(float(fx['p']))
@@ -646,6 +653,69 @@ def test_amp_step_tracks_the_fp32_step(lib):
     assert abs(float(ga.norm()) / float(g32.norm()) - 1) < 0.05
     assert hg == ha and torch.equal(gg, ga) and torch.equal(pg, pa)
     assert all(abs(a - b) < 0.05 * abs(b) for a, b in zip(ha, h32)), (ha, h32)
+
+
+def amp_policy(topl):
+    """Which GEMMs of a conv layer the build's config.AMP runs on bf16-rounded operands (mirrors ops.conv2d's pre-split
+    condition and autograd.wgrad_math under ops.conv_math((2,))): forward when every source has a multiple of 32
+    channels, data gradient when Cout is one, weight gradient for every 3x3 / 7x7 layer whose channel counts are
+    multiples of 8 and for the large 1x1 layers; the prediction head and the two stems (3 / 5 input channels) stay fp32."""
+    multi = {'value_encoder.fuser.block1.conv1': None, 'value_encoder.fuser.block1.downsample': None,
+             'swem_core.fusion_layer.layer_f': (512, 512, 2 * topl), 'swem_core.fusion_layer.layer_a': (512, 512, 2 * topl)}
+
+    def policy(name, x, w, stride):
+        co, ci, kh, kw = w.shape
+        if name == 'decoder.pred' or ci < 8:
+            return (False, False, False)
+        cs = multi.get(name) or ((256, ci - 256) if name in multi else (ci,))
+        M = x.shape[0] * (x.shape[2] // stride) * (x.shape[3] // stride)
+        fwd = all(c % 32 == 0 for c in cs) and (ci * kh * kw) % 8 == 0
+        dgrad = co % 32 == 0
+        big = co >= 128 and all(c >= 128 for c in cs)
+        wgrad = all(c % 8 == 0 for c in cs) and co % 8 == 0 and (kh * kw > 1 or (big and M >= 2048))
+        return (fwd, dgrad, wgrad)
+    return policy
+
+
+def test_amp_step_vs_rounded_operand_oracle(lib):
+    """config.AMP against an ORACLE of the same arithmetic: the CPU restatement with every bf16-mode GEMM replaced by an
+    fp32 convolution on bf16-ROUNDED operands (oracle.ROUNDED_CONV), forward, data gradient and weight gradient.  The HIP
+    step must agree with it like the fp32 step agrees with the fp32 oracle (losses 1e-4, gradient norms to a few 1e-3),
+    and must be far closer to it than to the fp32 oracle -- i.e. the bf16 error is the rounding of the operands and
+    nothing else."""
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    case = dict(tc['cases']['r18'], hw=[128, 128], b=1, valid=[[1, 1, 1]])
+    cfg = O.make_cfg(**case['cfg'])
+    frames, init_mask, label, valid = H.train_batch(case)
+    model, sd = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+    res = {}
+    for name, pol in (('fp32', None), ('rounded', amp_policy(cfg.TOPL))):
+        O.ROUNDED_CONV = pol
+        try:
+            torch.manual_seed(91)
+            ol, _, og, _ = O.train_one_step(H.trainable_sd(sd, model), cfg, frames, init_mask, valid, label, 45, tc['loss_cfg'])
+        finally:
+            O.ROUNDED_CONV = None
+        res[name] = ({k: float(v) for k, v in ol.items() if k != 'p'}, {k: g for k, g in og.items() if g is not None})
+    tr = SWEMTrainer(dict(SOLVER=tc['solver_cfg'], LOSS=tc['loss_cfg'], AMP=True), model, use_graph=False)
+    torch.manual_seed(91)
+    losses, _ = tr.one_step(frames.to(DEV), init_mask.to(DEV), valid.to(DEV), label.to(DEV), 45)
+    params = dict(model.named_parameters())
+    out = {}
+    for name, (ol, og) in res.items():
+        rel = sorted(abs(float(params[k].grad.double().norm()) - float(g.double().norm())) / (float(g.double().norm()) + 1e-12)
+                     for k, g in og.items())
+        flat_h = torch.cat([params[k].grad.flatten().cpu().double() for k in og])
+        flat_o = torch.cat([g.flatten().double() for g in og.values()])
+        out[name] = {'loss_rel': abs(float(losses['total_loss']) - ol['total_loss']) / ol['total_loss'],
+                     'grad_norm_rel_median': rel[len(rel) // 2], 'grad_norm_rel_p90': rel[int(0.9 * len(rel))],
+                     'flat_grad_rel_l2': float((flat_h - flat_o).norm() / flat_o.norm())}
+    print('AMP step vs oracles:', out)
+    H.record_parity('amp_step_vs_rounded_operand_oracle', out)
+    r, f = out['rounded'], out['fp32']
+    assert r['loss_rel'] < 2e-4 and r['grad_norm_rel_median'] < 2e-3 and r['flat_grad_rel_l2'] < 2e-2, out
+    assert r['flat_grad_rel_l2'] < 0.5 * f['flat_grad_rel_l2'], out
 
 
 def test_inference_after_a_step_sees_the_updated_weights(lib):

@@ -101,7 +101,7 @@ def test_ytvos_loop_and_tta(golden):
         assert torch.equal(p.to(torch.uint8), fx['tta%d' % i])
 
 
-@pytest.mark.parametrize('tag,it', [('r18', 5), ('r18', 45), ('r50', 45)])
+@pytest.mark.parametrize('tag,it', [('r18', 5), ('r18', 45), ('r50', 45), ('r50k256', 45), ('r50k256n5', 45)])
 def test_train_step_matches_reference_trainer(golden, tag, it):
     """a18 / f3: the oracle's training step (forward with gradients, BootstrappedCE + IoU loss, autograd) against the
     losses, index maps and per-parameter gradient norms recorded from the reference's SWEMTrainer.one_step."""
