@@ -287,7 +287,7 @@ def main():
             return
         # EM / matching: capture the arguments of one real memorize + match call, then time 20 back-to-back
         # repetitions of each with HIP events (queue kept full, so this is device time, not host launch time)
-        orig_mem, orig_match = ops.memorize, ops.match
+        orig_mem, orig_match = ops.memorize, ops.match_packed
         cap = {}
 
         def grab(name, fn):
@@ -295,9 +295,9 @@ def main():
                 cap[name] = (a, k)
                 return fn(*a, **k)
             return wrap
-        ops.memorize, ops.match = grab('mem', orig_mem), grab('match', orig_match)
+        ops.memorize, ops.match_packed = grab('mem', orig_mem), grab('match', orig_match)
         runner.step()
-        ops.memorize, ops.match = orig_mem, orig_match
+        ops.memorize, ops.match_packed = orig_mem, orig_match
         torch.cuda.synchronize()
         reps = 20
         em_ms = 0.0
@@ -327,10 +327,13 @@ def main():
             for si in range(n_streams):
                 am = [t.clone() if torch.is_tensor(t) else t for t in a_mem]
                 aq = [t.clone() if torch.is_tensor(t) else t for t in a_mat]
+                pk = tuple(t.clone() for t in k_mem['pack'])          # every stream its own packed banks
+                k_mem = dict(k_mem, pack=pk)
+                aq[1] = pk
                 st_ = em_streams[si]
                 st_.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st_):
-                    def fn():
+                    def fn(am=am, aq=aq, k_mem=k_mem):
                         orig_mem(*am, **k_mem)
                         orig_match(*aq, **k_mat)
                     fn()

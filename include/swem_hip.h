@@ -184,38 +184,52 @@ int swem_transpose_f32(void *stream, const float *in, float *out, int batch, int
 
 /* ------------------------------------------------------------------------------------
  * Sequential weighted EM (methods/SWEM/modules.py).  NK = 2*N (object-major, class minor).
- * Pp = P rounded up to a multiple of 32 (swem_em_pad(P)).
+ * Every operand is read as it lies in memory (pixel-major NHWC maps): there are no transposed copies.
  *   x     [P][C]      raw key of the frame, one row per pixel (reference x_t)
- *   xT    [C][Pp]     the same transposed (reference x), pad columns 0
+ *   v     [N][P][V]   value map per object, one row per pixel
  *   kn    [NK][C/4][L][4]  l2-normalised bases, channel-group major: kn[nk][c/4][l][c%4] = kappa[nk][c][l]/(|.|+eps)
  *                      (modules.py:115; the GEMM kernels put one base on every lane: this keeps their loads coalesced)
- *   zT    [NK][L][Pp] responsibilities, one row per base, pad columns 0
+ *   z     [N][Pz][2L] responsibilities, one row per PIXEL: z[n][p][cls*L + l], Pz = swem_em_pad(P) rows per object
+ *                      (rows >= P are never read by the M step)
+ * Key dimension C = 64 or 128 for the E/W step (the reference default KEYDIM is 128, configs/config.py:52), C = 128 for
+ * the M step and swem_memorize_*; L = 64, 128 or 256; V a multiple of 128.
  */
-int swem_em_pad(int P);
+int swem_em_pad(int P); /* rows of a z buffer per object: P rounded up to a multiple of 128 */
 /* kn = l2-normalised bases in the layout above   modules.py:7-9,115 */
 int swem_em_norm_bases_f32(void *stream, const float *kappa /*[NK][C][L]*/, float *kn, int NK, int C, int L);
 /* E and/or W step on one GEMM (they share x_t . l2norm(kappa)):
- *   do_w: weights = masks * (1 - p_own)          modules.py:93-110  -> w_out [NK][P]
- *   do_e: z = softmax((s - rowmax)/tau) * weights modules.py:112-120 -> zT
+ *   do_w: weights = masks * (1 - p_own)          modules.py:93-110  -> w_out [NK][P] (optional)
+ *   do_e: z = softmax((s - rowmax)/tau) * weights modules.py:112-120 -> z
  *         (weights = result of do_w when set, else w_in [NK][P]) */
 int swem_em_ew_f32(void *stream, const float *x, const float *kn, const float *masks /*[NK][P]*/,
-                   const float *w_in, float *w_out, float *zT, int N, int C, int P, int L, float tau, int do_w,
+                   const float *w_in, float *w_out, float *z, int N, int C, int P, int L, float tau, int do_w,
                    int do_e);
-/* M step, modules.py:122-127 (rows = C, A = xT, a_batch_div = 0) and the value update
- * modules.py:164-165 (rows = V, A = vT [N][V][Pp], a_batch_div = 2):
- *   zita = zita_prev + sum_p z ;  out = (zita_prev * prev + A . z) / zita
- * prev/out [NK][R][L]; zita_prev/zita_out [NK][L]; kn_out (optional, rows == C only) [NK][L][R] */
+/* M step, modules.py:122-127 (R = C rows, A = x [P][C], a_per_object = 0) and the value update
+ * modules.py:164-165 (R = V rows, A = v [N][P][V], a_per_object = 1):
+ *   zita = zita_prev + sum_p z ;  out = (zita_prev * prev + A^T . z) / zita
+ * prev/out [NK][R][L]; zita_prev/zita_out [NK][L]; kn_out (optional, key rows only) in the kn layout above.
+ * The sum over P is split over pixel chunks and reduced in a fixed order (deterministic, no atomics). */
 size_t swem_em_mstep_workspace(int NK, int R, int P, int L);
-int swem_em_mstep_f32(void *stream, const float *A, int a_batch_div, const float *zT, const float *prev,
+int swem_em_mstep_f32(void *stream, const float *A, int a_per_object, const float *z, const float *prev,
                       const float *zita_prev, float *out, float *zita_out, float *kn_out, int NK, int R, int P,
                       int L, void *ws, size_t ws_bytes);
-/* whole SWEMCore.swem() for one frame (modules.py:129-168): T x (E, M, W) + value update.
+/* whole SWEMCore.swem() for one frame (modules.py:129-168): T x (E, M, W) + value update, three launches per iteration.
  *   v [N][P][V] NHWC value map; masks [N][2][P]; *_prev = prior bases (random_init output on frame 0) */
 size_t swem_memorize_workspace(int N, int C, int V, int P, int L);
 int swem_memorize_f32(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
                       const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out,
                       float *zita_out, int N, int C, int V, int P, int L, int T, float tau, void *ws,
                       size_t ws_bytes);
+/* The same with matching's PACKED banks kept current, so that swem_match_packed_f32 needs no per-frame repacking
+ * (modules.py:295-306 `get_mem` concatenates the banks on every frame; here the caller owns one persistent pack):
+ *   mkn [2N][C/4][2L][4]  l2-normalised key bases of both banks, rows [0,L) 'first', [L,2L) 'update'
+ *   mvp [N][V][4L]        value bases, mvp[n][v][cls*2L + bank*L + l]
+ * prior_packed != 0: the prior's normalised keys are READ from the pack's 'update' half (written there by the previous
+ * frame's call: kappa_prev must be that frame's kappa_out); the new bases are WRITTEN to bank `bank` (0 'first', 1 'update'). */
+int swem_memorize_packed_f32(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
+                             const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out,
+                             float *zita_out, float *mkn, float *mvp, int prior_packed, int bank, int N, int C, int V,
+                             int P, int L, int T, float tau, void *ws, size_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------
  * Matching (modules.py:198-208, 232-289): l2norm, affinity, joint {bg,fg} softmax, value
@@ -231,6 +245,17 @@ size_t swem_match_workspace(int N, int C, int V, int P, int L, int nbanks, int r
 int swem_match_f32(void *stream, const float *qk, const float *kappa_first, const float *nu_first,
                    const float *kappa_update, const float *nu_update, float *mem_out, float *S, int N, int C,
                    int V, int P, int L, int topl, float tau, int readout_plan, void *ws, size_t ws_bytes);
+
+/* Matching on banks the caller keeps PACKED (layouts at swem_memorize_packed_f32): the reference concatenates and
+ * normalises both banks on every frame (modules.py:282-283, 295-306); the 'first' bank never changes after frame 0 and the
+ * 'update' bank's packed form is a by-product of memorize, so a persistent pack removes that work from the frame.
+ * swem_match_pack_bank_f32 (re)builds one bank of a pack from the reference-layout bases (nbanks = 1: a pack of one bank). */
+int swem_match_pack_bank_f32(void *stream, const float *kappa, const float *nu, float *mkn, float *mvp, int bank,
+                             int nbanks, int N, int C, int V, int L);
+size_t swem_match_packed_workspace(int N, int C, int V, int P, int L, int readout_plan);
+int swem_match_packed_f32(void *stream, const float *qk, const float *mkn, const float *mvp, float *mem_out, float *S,
+                          int N, int C, int V, int P, int L, int topl, float tau, int readout_plan, void *ws,
+                          size_t ws_bytes);
 
 #ifdef __cplusplus
 }

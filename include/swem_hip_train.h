@@ -135,15 +135,15 @@ int swem_prep_value_input_bwd_f32(void *stream, const float *dxin, float *dmasks
 /* ------------------------------------------------------------------------------------
  * EM / matching in the training step.  The E, M and W steps run under no_grad in the reference (modules.py:93,112,122):
  * only the value update nu = (zita_prev*nu_prev + v.z)/zita (:164-165) and the matching carry gradient.
- * swem_memorize_train_f32 = swem_memorize_f32 that also returns the last responsibilities zT [2N][L][Pp]
- * (Pp = swem_em_pad(P)) for swem_nu_update_bwd_f32:
+ * swem_memorize_train_f32 = swem_memorize_f32 that also returns the last responsibilities z [N][Pz][2L]
+ * (Pz = swem_em_pad(P), rows >= P zero) for swem_nu_update_bwd_f32:
  *   dv [N][P][V] (the NHWC value map's gradient), dnu_prev [2N][V][L] (may be NULL) from dnu [2N][V][L] */
 int swem_memorize_train_f32(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
                             const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out,
-                            float *zita_out, float *zT_out, int N, int C, int V, int P, int L, int T, float tau,
+                            float *zita_out, float *z_out, int N, int C, int V, int P, int L, int T, float tau,
                             void *ws, size_t ws_bytes);
 size_t swem_nu_update_bwd_workspace(int N, int V, int P, int L);
-int swem_nu_update_bwd_f32(void *stream, const float *zT, const float *zita_prev, const float *zita, const float *dnu,
+int swem_nu_update_bwd_f32(void *stream, const float *z, const float *zita_prev, const float *zita, const float *dnu,
                            float *dv, float *dnu_prev, int N, int V, int P, int L, void *ws, size_t ws_bytes);
 /* backward of swem_match_f32 for the N <= 7 objects of one clip: dmem [N][Pm][V] and dS [N][P][2*topl] (dS may be NULL)
  * -> dqk [P][C] (summed over objects; through the query's l2norm), dnu_first / dnu_update [N][2][V][L].

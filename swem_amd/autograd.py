@@ -521,8 +521,7 @@ class _Memorize(Function):
         kappa = torch.empty_like(kappa_prev)
         nu = torch.empty_like(nu_prev)
         zita = torch.empty_like(zita_prev)
-        Pp = _lib.query('swem_em_pad', P)
-        zT = torch.empty((2 * N, L, Pp), dtype=torch.float32, device=dev)
+        zT = torch.empty((N, _lib.query('swem_em_pad', P), 2 * L), dtype=torch.float32, device=dev)   # pixel-major z
         wsb = _lib.query('swem_memorize_workspace', N, Cc, V, P, L)
         ws = _ws(wsb, dev)
         _lib.call('swem_memorize_train_f32', ops._stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(),

@@ -1,32 +1,44 @@
 // Sequential weighted EM (reference methods/SWEM/modules.py:93-168) on the gfx950 fp32 matrix cores.
 //
-// Data layout (device, fp32; NK = 2*N, class minor; Pp = P rounded up to 32):
-//   x  [P][C]       raw key, one row per pixel          (reference x_t)
-//   xT [C][Pp]      transposed copy, zero padded        (reference x)
-//   kn [NK][L][C]   l2-normalised bases, row per base   (l2norm(kappa, dim=-2), modules.py:115)
-//   zT [NK][L][Pp]  responsibilities, row per base, pad columns zero  (Pp = P rounded up to 32)
-// With the K dimension contiguous in every operand, each lane loads 16 bytes and feeds four
-// v_mfma_f32_32x32x2_f32 steps (common.h: mfma32x4).
+// Data layout (device, fp32; NK = 2*N, class minor).  Every operand is read as it lies in memory: no transposed copies.
+//   x  [P][C]            raw key, one row per pixel          (reference x_t; NHWC feature map as the encoder wrote it)
+//   v  [N][P][V]         value map per object, pixel-major   (NHWC)
+//   kn [NK][C/4][R][4]   l2-normalised bases, channel-group major; a bank occupies rows [off, off+L) of R >= L rows
+//                        (R = L inside memorize; R = 2L, off = L when it is the 'update' half of matching's packed banks)
+//   z  [N][Pz][2L]       responsibilities, one row per PIXEL: z[n][p][cls*L + l]; Pz = swem_em_pad(P) rows allocated,
+//                        rows [0, ceil16(P)) written (pad pixels as zeros)
 //
-// Kernels per EM iteration (4 small launches):
-//   em_ew      : one GEMM  s = x_t . kn  per 32-pixel tile serves BOTH the W step of the previous iteration
-//                (cosine = s / (|x|+eps), joint {bg,fg} max, exp-sums, weights = mask * (1 - p)) and the E step
-//                (row softmax of s/tau, times weights).  The pixel sits on the MFMA lane, the base index in the
-//                accumulator registers, so the row reductions are in-register + one cross-half shuffle + one LDS
-//                exchange between the 4 waves (2 classes x 2 halves of L).
-//   M GEMM     : xT . z (or vT . z for the value update) for both classes of an object side by side, run by the
-//                implicit-GEMM conv kernel as a batched 1x1 "conv" (LDS-staged, split over P, deterministic).
-//   em_zsum    : zita = zita_ + sum_p z (one wave per base row).
-//   em_finalize: fixed-order slab reduction (deterministic) and the prior blend (zita_*kappa_ + S)/zita; the key-base
-//                variant also emits the next iteration's normalised transposed bases (block-local column norms).
+// Three launches per EM iteration (a dependent kernel boundary costs ~1.5 us on this chip, a grid-wide barrier inside a
+// persistent kernel 4-7 us and a split-K seam with a last-arriver combine 5-13 us: MI355X_MICROARCH.md, price list --
+// so the iteration is three well-filled kernels, not one cooperative one):
+//   em_ew16    : block = (object, 16-pixel tile), 8 waves = 2 classes x 4 base quarters.  One GEMM  s = kn . x_t  on
+//                v_mfma_f32_16x16x4_f32 serves BOTH the W step of the previous iteration (cosine = s / (|x|+eps), joint
+//                {bg,fg} max, exp-sums, weights = mask * (1 - p)) and the E step (softmax of s/tau over the class's bases,
+//                times weights).  The pixel sits on the MFMA column lane, four bases of a tile in the accumulator
+//                registers: row reductions are in-register + two shuffles + ONE LDS exchange for the maxima and one for the
+//                sums.  The pixel's key (all C channels) lives in registers; every base row is loaded exactly once per
+//                block, all loads issued before the first MFMA.  z leaves as 16-byte stores, 64 contiguous bytes per pixel
+//                and tile.  204 blocks at config B (P = 1620, N = 2) instead of the 102 a 32-pixel tile gives.
+//   em_mstep   : S = X^T . z over a CHUNK of pixels (split-P): block = (object-class, 32 bases) x (128 rows of X) x chunk,
+//                8 waves = 4 row tiles x 2 halves of the chunk, v_mfma_f32_32x32x2_f32.  X = x (key bases) or v[n]
+//                (value bases, last iteration only: both in ONE launch).  Operands are fetched by raw buffer loads whose
+//                pixel offset travels in the scalar offset (no vector arithmetic in the loop; pixels >= P read as zeros by
+//                the buffer's range check), all issued up front.  Partial sums go to Spart[chunk][nk][row][L]; the column
+//                sums of z (zita's increment) ride along.
+//   em_finalize: fixed-order sum over the chunks (deterministic), prior blend (zita_*prev + S)/zita, and for the key
+//                bases the l2-normalised kn the next E/W step reads (block = 32 bases x all C rows: norms are block-local).
+//                On the last iteration it can also write the bases straight into matching's packed banks.
 #include "../../include/swem_hip_train.h"
 #include "common.h"
 
 namespace {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
 
-// kn[nk][c/4][l][c%4] = kappa[nk][c][l] / (||kappa[nk][:][l]|| + eps).  Block: 32 bases x all channels.
+// kn[nk][c/4][off + l][c%4] = kappa[nk][c][l] / (||kappa[nk][:][l]|| + eps).  Block: 32 bases x all channels.
 __global__ __launch_bounds__(256) void em_norm_bases_kernel(const float *__restrict__ kappa, float *__restrict__ kn,
                                                             int C, int L, int out_rows, int out_off) {
   extern __shared__ float sm[];  // tile[C][33], part[8][32], nrm[32]
@@ -48,9 +60,8 @@ __global__ __launch_bounds__(256) void em_norm_bases_kernel(const float *__restr
     nrm[threadIdx.x] = sqrtf(s) + SWEM_L2_EPS;
   }
   __syncthreads();
-  // kn is channel-group major, [nk][C/4][row][4]: the E/W and affinity kernels put one base row on every lane, and with
-  // row-major [row][C] every lane of a load touched its own cache line (32 lines per instruction, the blocks' GEMMs were
-  // bound by that: 15 of em_ew's 19 us); here the 32 rows' 16-byte chunks of one k-step are contiguous.
+  // channel-group major: the E/W and affinity kernels put one base row on every lane, so the 16 (32) rows' 16-byte chunks
+  // of one k-step are contiguous
   for (int idx = threadIdx.x; idx < 32 * C; idx += 256) {
     const int e = idx & 3, ll = (idx >> 2) & 31, c4 = idx >> 7;
     if (l0 + ll < L)
@@ -58,285 +69,293 @@ __global__ __launch_bounds__(256) void em_norm_bases_kernel(const float *__restr
   }
 }
 
-// L = 32 * LT * WPC bases per class: WPC waves per class, LT 32-base tiles per wave.  The block is 2*WPC waves; more waves
-// per block shorten every wave's MFMA chain and epilogue (there are only P/32 x N blocks: 102 at config B, well under the
-// 256 CUs, so the kernel's time is one block's latency).
-template <int LT, int WPC>
-__global__ __launch_bounds__(128 * WPC) void em_ew_kernel(const float *__restrict__ x, const float *__restrict__ kn,
-                                                    const float *__restrict__ masks, const float *__restrict__ w_in,
-                                                    float *__restrict__ w_out, float *__restrict__ zT, int C, int P,
-                                                    int Pp, int L, float tau, int do_w, int do_e) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int XS = C + 4;
-  float *xs = sm;             // [32][C+4]
-  constexpr int NW = 2 * WPC;
-  float *xn = xs + 32 * XS;   // [32]
-  float *red = xn + 32;       // [3][NW][32]
+// ---------------------------------------------------------------------------------------------------- E / W step
+// L = 64 * LT bases per class (LT 16-base MFMA tiles per wave), C = 16 * CM channels.
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; D[i][j] lives in lane
+// (j + 16 g), register r, with i = 4 g + r.  A = base rows, B = pixels: the pixel is on the lane, 4 bases in the registers.
+// One 16-byte load feeds four k-steps: lane group g takes channels 16 m + 4 g + e (e = 0..3) of chunk m -- a permutation
+// of the channel order that A and B share, so the sum runs over the same products.
+template <int LT, int CM>
+__global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ x, const float *__restrict__ kn,
+                                                      int kn_rows, int kn_off, const float *__restrict__ masks,
+                                                      const float *__restrict__ w_in, float *__restrict__ w_out,
+                                                      float *__restrict__ z, int P, int Pz, float tau, int do_w,
+                                                      int do_e) {
+  constexpr int C = 16 * CM, L = 64 * LT;
+  __shared__ float red[3][8][16];  // per-wave maxima / W exp-sums / E exp-sums per pixel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int cls = wave / WPC, lh = wave % WPC;
-  const int n = blockIdx.y, p0 = blockIdx.x * 32;
-  const int nk = n * 2 + cls;
-  const int cq = C / 4;
-  for (int idx = tid; idx < 32 * cq; idx += 64 * NW) {
-    int row = idx / cq, c4 = idx - row * cq;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p0 + row < P) v = ld4(x + (long long)(p0 + row) * C + c4 * 4);
-    *reinterpret_cast<float4 *>(xs + row * XS + c4 * 4) = v;
-  }
-  __syncthreads();
-  for (int rr = 0; rr < 32 / NW; ++rr) {
-    int row = wave * (32 / NW) + rr;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      float v = xs[row * XS + c];
-      s += v * v;
-    }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) xn[row] = sqrtf(s) + SWEM_L2_EPS;
+  const int li = lane & 15, g = lane >> 4;
+  const int cls = wave >> 2, q = wave & 3;
+  const int n = blockIdx.y, p = blockIdx.x * 16 + li;
+  const int nk = 2 * n + cls;
+  const bool pin = p < P;
+  // base rows of this wave: [q*16*LT, (q+1)*16*LT) of class cls; lane (li, g) loads row li of every tile, chunk 4m + g
+  const float *kb = kn + (((long long)nk * (C / 4) + g) * kn_rows + kn_off + q * 16 * LT + li) * 4;
+  float4 a[CM][LT];
+#pragma unroll
+  for (int m = 0; m < CM; ++m)
+#pragma unroll
+    for (int t = 0; t < LT; ++t) a[m][t] = ld4(kb + ((long long)4 * m * kn_rows + 16 * t) * 4);
+  float4 xf[CM];
+#pragma unroll
+  for (int m = 0; m < CM; ++m)
+    xf[m] = pin ? ld4(x + (long long)p * C + 16 * m + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float ss = 0.f;
+#pragma unroll
+  for (int m = 0; m < CM; ++m) ss += (xf[m].x * xf[m].x + xf[m].y * xf[m].y) + (xf[m].z * xf[m].z + xf[m].w * xf[m].w);
+  ss += __shfl_xor(ss, 16);
+  ss += __shfl_xor(ss, 32);
+  const float xnorm = sqrtf(ss) + SWEM_L2_EPS;
+
+  f32x4 acc[LT];
+#pragma unroll
+  for (int t = 0; t < LT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < CM; ++m) {
+#pragma unroll
+    for (int t = 0; t < LT; ++t) acc[t] = mfma16(a[m][t].x, xf[m].x, acc[t]);
+#pragma unroll
+    for (int t = 0; t < LT; ++t) acc[t] = mfma16(a[m][t].y, xf[m].y, acc[t]);
+#pragma unroll
+    for (int t = 0; t < LT; ++t) acc[t] = mfma16(a[m][t].z, xf[m].z, acc[t]);
+#pragma unroll
+    for (int t = 0; t < LT; ++t) acc[t] = mfma16(a[m][t].w, xf[m].w, acc[t]);
   }
 
-  f32x16 acc[LT];
+  // maxima of the raw logits over this wave's bases; the W step's cosine is s / (|x| + eps) with a positive per-pixel
+  // factor, so its joint maximum is that factor times the larger class maximum (rounding is monotonic): one exchange
+  float ml = -__builtin_huge_valf();
 #pragma unroll
   for (int t = 0; t < LT; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-  const int lbase = lh * 32 * LT;
-  const float *krow = kn + (((long long)nk * (C / 4) + h) * L + lbase + r) * 4;  // chunk (2j + h) of row lbase + r
-  const float *xrow = xs + r * XS + 4 * h;
-  {
-    // The base rows stream from L2 (every lane its own row: 32 cache lines per load instruction) with one wave per SIMD,
-    // so nothing but the wave's own prefetch hides the ~1 us round trip: a register ring keeps PF k-steps in flight
-    // (with one step ahead the 16-step loop was latency bound: 24 us for 7 us of MFMA work).
-    constexpr int PF = 4;
-    float4 ring[PF][LT];
-    const int steps = C / 8;
-#pragma unroll
-    for (int d = 0; d < PF; ++d)
-#pragma unroll
-      for (int t = 0; t < LT; ++t) ring[d][t] = ld4(krow + ((long long)2 * min(d, steps - 1) * L + t * 32) * 4);
-    for (int j0 = 0; j0 < steps; j0 += PF) {
-#pragma unroll
-      for (int d = 0; d < PF; ++d) {
-        const int j = j0 + d;
-        if (j < steps) {
-          float4 b4 = *reinterpret_cast<const float4 *>(xrow + 8 * j);
-          float4 a4[LT];
-#pragma unroll
-          for (int t = 0; t < LT; ++t) a4[t] = ring[d][t];
-          const int jn = min(j + PF, steps - 1);
-#pragma unroll
-          for (int t = 0; t < LT; ++t) ring[d][t] = ld4(krow + ((long long)2 * jn * L + t * 32) * 4);
-#pragma unroll
-          for (int t = 0; t < LT; ++t) acc[t] = mfma32x4(a4[t], b4, acc[t]);
-        }
-      }
-    }
-  }
-  __syncthreads();  // xn visible
-
-  const int p = p0 + r;
-  const bool pin = p < P;
+    for (int e = 0; e < 4; ++e) ml = fmaxf(ml, acc[t][e]);
+  ml = fmaxf(ml, __shfl_xor(ml, 16));
+  ml = fmaxf(ml, __shfl_xor(ml, 32));
+  if (g == 0) red[0][wave][li] = ml;
+  __syncthreads();
+  const float m_bg = fmaxf(fmaxf(red[0][0][li], red[0][1][li]), fmaxf(red[0][2][li], red[0][3][li]));
+  const float m_fg = fmaxf(fmaxf(red[0][4][li], red[0][5][li]), fmaxf(red[0][6][li], red[0][7][li]));
   const float k2 = SWEM_LOG2E / tau;
-  float wgt;
+  const float rden = 1.0f / xnorm;  // one reciprocal per pixel instead of a division per base
   if (do_w) {
-    // W step (modules.py:98-108): cosine, joint max over L and {bg,fg}, exp sums, 1 - p literally
-    const float rden = 1.0f / xn[r];  // cosine = s / (|x| + eps): one reciprocal per pixel instead of a division per base
-    float m = -__builtin_huge_valf();
+    // W step (modules.py:98-108): exp-sums of the cosines against the joint maximum
+    const float mw = fmaxf(m_bg, m_fg) * rden;
+    float sw = 0.f;
 #pragma unroll
     for (int t = 0; t < LT; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) m = fmaxf(m, acc[t][e] * rden);
-    m = fmaxf(m, __shfl_xor(m, 32));
-    if (h == 0) red[wave * 32 + r] = m;
-    __syncthreads();
-    m = red[r];
-#pragma unroll
-    for (int q = 1; q < NW; ++q) m = fmaxf(m, red[q * 32 + r]);
+      for (int e = 0; e < 4; ++e) sw += exp_scaled(acc[t][e] * rden - mw, k2);
+    sw += __shfl_xor(sw, 16);
+    sw += __shfl_xor(sw, 32);
+    if (g == 0) red[1][wave][li] = sw;
+  }
+  if (do_e) {
+    // E step (modules.py:116-119): exp against the class's own row maximum
+    const float me = cls ? m_fg : m_bg;
     float se = 0.f;
 #pragma unroll
     for (int t = 0; t < LT; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) se += exp_scaled(acc[t][e] * rden - m, k2);
+      for (int e = 0; e < 4; ++e) {
+        const float v = exp_scaled(acc[t][e] - me, k2);
+        acc[t][e] = v;
+        se += v;
+      }
+    se += __shfl_xor(se, 16);
     se += __shfl_xor(se, 32);
-    if (h == 0) red[NW * 32 + wave * 32 + r] = se;
-    __syncthreads();
-    float s_bg = 0.f, s_fg = 0.f;
-#pragma unroll
-    for (int q = 0; q < WPC; ++q) {
-      s_bg += red[NW * 32 + q * 32 + r];
-      s_fg += red[NW * 32 + (WPC + q) * 32 + r];
-    }
+    if (g == 0) red[2][wave][li] = se;
+  }
+  __syncthreads();
+  float wgt;
+  if (do_w) {
+    const float s_bg = (red[1][0][li] + red[1][1][li]) + (red[1][2][li] + red[1][3][li]);
+    const float s_fg = (red[1][4][li] + red[1][5][li]) + (red[1][6][li] + red[1][7][li]);
     const float prop = (cls ? s_fg : s_bg) / (s_bg + s_fg);
     const float mk = pin ? masks[(long long)nk * P + p] : 0.f;
-    wgt = mk * (1.f - prop);
-    if (lh == 0 && h == 0 && pin && w_out) w_out[(long long)nk * P + p] = wgt;
+    wgt = mk * (1.f - prop);  // 1 - p literally, as the reference
+    if (w_out && q == 0 && g == 0 && pin) w_out[(long long)nk * P + p] = wgt;
   } else {
     wgt = pin ? w_in[(long long)nk * P + p] : 0.f;
   }
   if (!do_e) return;
-  // E step (modules.py:116-119)
-  float m = -__builtin_huge_valf();
+  const float se = (red[2][4 * cls][li] + red[2][4 * cls + 1][li]) + (red[2][4 * cls + 2][li] + red[2][4 * cls + 3][li]);
+  const float zscale = pin ? wgt / se : 0.f;  // softmax normalisation and the pixel weight in one factor
+  float *dst = z + ((long long)n * Pz + p) * (2 * L) + cls * L + q * 16 * LT + 4 * g;
 #pragma unroll
   for (int t = 0; t < LT; ++t)
+    *reinterpret_cast<float4 *>(dst + 16 * t) =
+        make_float4(acc[t][0] * zscale, acc[t][1] * zscale, acc[t][2] * zscale, acc[t][3] * zscale);
+}
+
+// ---------------------------------------------------------------------------------------------------- M step (split-P)
+struct MStepP {
+  const float *x;  // [P][C] key rows (row space [0, Ck)), or NULL when Ck == 0
+  const float *v;  // [N][P][V] value rows (row space [Ck, Ck + Vv)), or NULL
+  const float *z;  // [N][Pz][2L]
+  float *Spart;    // [nch][NK][Rtot][L]
+  float *zpart;    // [nch][NK][L]
+  int Ck, C, V, P, Pz, L, NK, Rtot;
+};
+
+// Block = (nk, 32 bases) x (128 rows of the row space) x chunk of 4*STEPS pixels; wave = (row tile ct, chunk half kh).
+template <int STEPS>
+__global__ __launch_bounds__(512) void em_mstep_kernel(MStepP p) {
+  __shared__ float red[4][16][64];
+  __shared__ float zred[2][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, kk = lane >> 5;
+  const int ct = wave & 3, kh = wave >> 2;
+  const int tiles = p.L / 32;
+  const int nk = blockIdx.x / tiles, l0 = (blockIdx.x - nk * tiles) * 32;
+  const int n = nk >> 1, cls = nk & 1;
+  const int row0 = blockIdx.y * 128;
+  const int chunk = blockIdx.z;
+  const int pw0 = chunk * 4 * STEPS + kh * 2 * STEPS;  // first pixel of this wave's half chunk
+  // wave-uniform descriptors: the row operand (x or v[n]) and z[n]; offsets beyond P rows read as zeros
+  const bool key = row0 < p.Ck;
+  const float *src = key ? p.x : p.v + (long long)n * p.P * p.V;
+  const int stride = key ? p.C : p.V;
+  const int col = (key ? row0 : row0 - p.Ck) + 32 * ct;
+  __amdgpu_buffer_rsrc_t ra =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, (int)((long long)p.P * stride * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.z + (long long)n * p.Pz * 2 * p.L), 0, (int)((long long)p.P * 2 * p.L * 4), 0x00020000);
+  const unsigned va = (unsigned)((kk * stride + col + i) * 4);
+  const unsigned vb = (unsigned)((kk * 2 * p.L + cls * p.L + l0 + i) * 4);
+  const unsigned sa = (unsigned)stride * 8u, sb = (unsigned)p.L * 16u;  // bytes per step (two pixels)
+  float av[STEPS], bv[STEPS];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) m = fmaxf(m, acc[t][e]);
-  m = fmaxf(m, __shfl_xor(m, 32));
-  if (h == 0) red[2 * NW * 32 + wave * 32 + r] = m;
+  for (int s = 0; s < STEPS; ++s) {
+    av[s] = __builtin_amdgcn_raw_buffer_load_b32(ra, va, (unsigned)(pw0 + 2 * s) * (sa / 2), 0);
+    bv[s] = __builtin_amdgcn_raw_buffer_load_b32(rb, vb, (unsigned)(pw0 + 2 * s) * (sb / 2), 0);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float zs = 0.f;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    acc = mfma32(av[s], bv[s], acc);
+    zs += bv[s];
+  }
+  zs += __shfl_xor(zs, 32);
+  if (kh == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[ct][e][lane] = acc[e];
+  }
+  if (ct == 0 && lane < 32) zred[kh][lane] = zs;
   __syncthreads();
-  m = red[2 * NW * 32 + cls * WPC * 32 + r];
+  if (kh == 1) return;
+  float *dst = p.Spart + (((long long)chunk * p.NK + nk) * p.Rtot + row0 + 32 * ct) * p.L + l0 + i;
 #pragma unroll
-  for (int q = 1; q < WPC; ++q) m = fmaxf(m, red[2 * NW * 32 + (cls * WPC + q) * 32 + r]);
-  float se = 0.f;
-#pragma unroll
-  for (int t = 0; t < LT; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float v = exp_scaled(acc[t][e] - m, k2);
-      acc[t][e] = v;
-      se += v;
-    }
-  se += __shfl_xor(se, 32);
-  __syncthreads();  // everyone has read the maxima before the slots are reused for the sums
-  if (h == 0) red[2 * NW * 32 + wave * 32 + r] = se;
-  __syncthreads();
-  se = 0.f;
-#pragma unroll
-  for (int q = 0; q < WPC; ++q) se += red[2 * NW * 32 + (cls * WPC + q) * 32 + r];
-  const float zscale = wgt / se;  // softmax normalisation and the pixel weight in one factor
-  if (p < Pp) {
-    float *dst = zT + ((long long)nk * L + lbase) * Pp + p;
-#pragma unroll
-    for (int t = 0; t < LT; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int l = 32 * t + acc_row(e, h);
-        dst[(long long)l * Pp] = pin ? acc[t][e] * zscale : 0.f;
-      }
-  }
+  for (int e = 0; e < 16; ++e) dst[(long long)acc_row(e, kk) * p.L] = acc[e] + red[ct][e][lane];
+  if (ct == 0 && lane < 32 && blockIdx.y == 0)
+    p.zpart[((long long)chunk * p.NK + nk) * p.L + l0 + lane] = zred[0][lane] + zred[1][lane];
 }
 
-// zita[nk][l] = zita_prev[nk][l] + sum_p zT[nk][l][p]: one wave per base row, 16-byte coalesced reads, fixed order
-__global__ __launch_bounds__(256) void em_zsum_kernel(const float *__restrict__ zT, const float *__restrict__ zita_prev,
-                                                      float *__restrict__ zt, float *__restrict__ zita_out, int rows,
-                                                      int Pp) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float *zr = zT + (long long)row * Pp;
-  float s = 0.f;
-  for (int k = lane * 4; k < Pp; k += 256) {
-    float4 v = ld4(zr + k);
-    s += (v.x + v.y) + (v.z + v.w);
-  }
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) {
-    float z = zita_prev[row] + s;
-    zt[row] = z;
-    if (zita_out) zita_out[row] = z;
-  }
-}
+// ---------------------------------------------------------------------------------------------------- finalize
+struct FinP {
+  const float *Spart, *zpart;
+  const float *kappa_prev, *nu_prev, *zita_prev;
+  const float *zita_in;  // when set, zita is read from here instead of zita_prev + sum of zpart
+  float *kappa_out, *nu_out, *zita_out;
+  float *kn_out;          // optional: normalised key bases [NK][C/4][kn_rows][4] at row offset kn_off
+  float *mvp_out;         // optional: value bases packed for matching, mvp[n][v][cls*mvp_lm + mvp_off + l]
+  int kn_rows, kn_off, mvp_lm, mvp_off;
+  int Ck, C, V, L, NK, Rtot, nch;
+};
 
-// out[nk][row][l] = (zita_prev[l] * prev[row][l] + S[n][row][cls*L + l]) / zita[l],  nk = 2n + cls
-// (S = A . z for both classes of an object, produced by the GEMM with the classes side by side).  Block: 32 bases x 32 rows.
-__global__ __launch_bounds__(256) void em_finalize_kernel(const float *__restrict__ S, const float *__restrict__ prev,
-                                                          const float *__restrict__ zita_prev,
-                                                          const float *__restrict__ zt, float *__restrict__ out, int NK,
-                                                          int R, int L) {
-  const int nk = blockIdx.y, l = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int row0 = blockIdx.z * 32 + (threadIdx.x >> 5);
-  const float zp = zita_prev[(long long)nk * L + l], z = zt[(long long)nk * L + l];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = row0 + 8 * i;
-    if (row >= R) break;
-    const long long o = ((long long)nk * R + row) * L + l;
-    const float s = S[((long long)(nk >> 1) * R + row) * (2 * L) + (nk & 1) * L + l];
-    out[o] = (zp * prev[o] + s) / z;
-  }
-}
-
-// Same blend for the key bases (R = C rows), fused with the l2-normalised transposed copy the next E/W step reads:
-// block = 32 bases x all C rows, so the column norms are block-local.
-__global__ __launch_bounds__(1024) void em_finalize_norm_kernel(const float *__restrict__ S,
-                                                                const float *__restrict__ prev,
-                                                                const float *__restrict__ zita_prev,
-                                                                float *__restrict__ zt, float *__restrict__ out,
-                                                                float *__restrict__ kn_out, int NK, int R, int L,
-                                                                const float *__restrict__ zT, float *__restrict__ zita_out,
-                                                                int Pp) {
-  extern __shared__ float sm[];  // tile[R][33], red[32][32], nrm[32]
-  float *tile = sm, *red = sm + R * 33, *nrm = red + 1024;
+// Block = (32 bases, nk, 128-row group of the row space); 1024 threads = 32 bases x 32 row lanes.
+__global__ __launch_bounds__(1024) void em_finalize_kernel(FinP p) {
+  __shared__ float tile[128 * 33];
+  __shared__ float part[8][32];
+  __shared__ float zl[32], nrm[32];
   const int nk = blockIdx.y, l0 = blockIdx.x * 32;
-  const int l = threadIdx.x & 31, g = threadIdx.x >> 5;  // 32 row groups: enough loads in flight to hide the slab reads
-  if (zT) {
-    // zita = zita_prev + sum_p z for this block's 32 bases (em_zsum_kernel's order: one wave per row, the same partial
-    // sums), fused here to save a launch per EM iteration; published through zt for the value update
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // 16 waves, 2 rows each
-    for (int rr = w; rr < 32; rr += 16) {
-      const float *zr = zT + ((long long)nk * L + l0 + rr) * Pp;
+  const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int row0 = blockIdx.z * 128;
+  const bool key = row0 < p.Ck;
+  if (threadIdx.x < 32) {
+    float zv;
+    if (p.zita_in) {
+      zv = p.zita_in[(long long)nk * p.L + l0 + l];
+    } else {
       float s = 0.f;
-      for (int k = lane * 4; k < Pp; k += 256) {
-        float4 v = ld4(zr + k);
-        s += (v.x + v.y) + (v.z + v.w);
-      }
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-      if (lane == 0) {
-        const float zv = zita_prev[(long long)nk * L + l0 + rr] + s;
-        nrm[rr] = zv;
-        zt[(long long)nk * L + l0 + rr] = zv;
-        if (zita_out) zita_out[(long long)nk * L + l0 + rr] = zv;
-      }
+      for (int ch = 0; ch < p.nch; ++ch) s += p.zpart[((long long)ch * p.NK + nk) * p.L + l0 + l];
+      zv = p.zita_prev[(long long)nk * p.L + l0 + l] + s;
     }
-    __syncthreads();
+    zl[l] = zv;
+    if (p.zita_out && blockIdx.z == 0) p.zita_out[(long long)nk * p.L + l0 + l] = zv;
   }
-  const float zp = zita_prev[(long long)nk * L + l0 + l], z = zT ? nrm[l] : zt[(long long)nk * L + l0 + l];
-  __syncthreads();  // nrm is reused for the column norms below
-  for (int row = g; row < R; row += 32) {
-    const long long o = ((long long)nk * R + row) * L + l0 + l;
-    const float s = S[((long long)(nk >> 1) * R + row) * (2 * L) + (nk & 1) * L + l0 + l];
-    const float v = (zp * prev[o] + s) / z;
-    out[o] = v;
-    tile[row * 33 + l] = v;
+  __syncthreads();
+  const float zp = p.zita_prev[(long long)nk * p.L + l0 + l], zt = zl[l];
+  const int R = key ? p.C : p.V;
+  const int rbase = key ? row0 : row0 - p.Ck;
+  const float *prev = key ? p.kappa_prev : p.nu_prev;
+  float *out = key ? p.kappa_out : p.nu_out;
+  const int n = nk >> 1, cls = nk & 1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rr = g + 32 * q;
+    const int row = rbase + rr;
+    float v = 0.f;
+    if (row < R) {
+      float s = 0.f;
+      const float *sp = p.Spart + ((long long)nk * p.Rtot + row0 + rr) * p.L + l0 + l;
+      const long long cs = (long long)p.NK * p.Rtot * p.L;
+      for (int ch = 0; ch < p.nch; ++ch) s += sp[ch * cs];
+      const long long o = ((long long)nk * R + row) * p.L + l0 + l;
+      v = (zp * prev[o] + s) / zt;
+      out[o] = v;
+      if (!key && p.mvp_out)
+        p.mvp_out[((long long)n * p.V + row) * (2 * p.mvp_lm) + cls * p.mvp_lm + p.mvp_off + l0 + l] = v;
+    }
+    if (key) tile[rr * 33 + l] = v;
   }
+  if (!key || !p.kn_out) return;
   __syncthreads();
   if (g < 8) {  // column norms from the tile, in the association of em_norm_bases_kernel (bit-identical kn)
     float ss = 0.f;
-    for (int c = g; c < R; c += 8) {
+    for (int c = g; c < p.C; c += 8) {
       const float v = tile[c * 33 + l];
       ss += v * v;
     }
-    red[g * 32 + l] = ss;
+    part[g][l] = ss;
   }
   __syncthreads();
   if (threadIdx.x < 32) {
     float s = 0.f;
-    for (int i = 0; i < 8; ++i) s += red[i * 32 + threadIdx.x];
+    for (int i = 0; i < 8; ++i) s += part[i][threadIdx.x];
     nrm[threadIdx.x] = sqrtf(s) + SWEM_L2_EPS;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 32 * R; idx += 1024) {  // [nk][R/4][l][4], as em_norm_bases_kernel
+  for (int idx = threadIdx.x; idx < 32 * p.C; idx += 1024) {
     const int e = idx & 3, ll = (idx >> 2) & 31, c4 = idx >> 7;
-    kn_out[(((long long)nk * (R / 4) + c4) * L + l0 + ll) * 4 + e] = tile[(c4 * 4 + e) * 33 + ll] / nrm[ll];
+    p.kn_out[(((long long)nk * (p.C / 4) + c4) * p.kn_rows + p.kn_off + l0 + ll) * 4 + e] = tile[(c4 * 4 + e) * 33 + ll] / nrm[ll];
   }
 }
 
 struct MWs {
-  size_t S, conv, zt, total;
+  size_t Spart, zpart, total;
+  int nch, steps;
 };
-// workspace of one M step: S [N][R][2L], the GEMM's split-K scratch, zita scratch
-MWs mstep_ws(int NK, int R, int P, int L) {
+// workspace of one M step over a row space of Rtot rows: chunk partials of S and of the column sums of z
+MWs mstep_ws(int NK, int Rtot, int P, int L) {
   MWs w;
-  const int N = NK / 2, Pp = swem_em_pad(P);
+  // 208-pixel chunks (52 two-pixel steps per half-chunk wave) unless that leaves most of the chip idle.  The choice
+  // depends on the key rows' grid only, so that every M step of a memorize (keys alone, keys + values) and the step-level
+  // entry point cut P the same way: the same partial sums in the same order whatever the row space
+  w.steps = 52;
+  long long blocks = (long long)NK * (L / 32) * cdiv(P, 4 * w.steps);
+  if (blocks < 160) w.steps = 26;
+  w.nch = cdiv(P, 4 * w.steps);
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t at = o;
     o = align_up(o + bytes, 256);
     return at;
   };
-  w.S = take((size_t)N * R * 2 * L * sizeof(float));
-  w.conv = take(swem_conv2d_workspace(N, R, 1, Pp, 2 * L, 1, 1, 1, 0, 0, 0));
-  w.zt = take((size_t)NK * L * sizeof(float));
+  w.Spart = take((size_t)w.nch * NK * Rtot * L * sizeof(float));
+  w.zpart = take((size_t)w.nch * NK * L * sizeof(float));
   w.total = o;
   return w;
 }
@@ -345,13 +364,13 @@ MWs mstep_ws(int NK, int R, int P, int L) {
 
 #define ST static_cast<hipStream_t>(stream)
 
-extern "C" int swem_em_pad(int P) { return (P + 31) / 32 * 32; }
+extern "C" int swem_em_pad(int P) { return (P + 127) / 128 * 128; }
 
-// kn rows of bank `kappa` land at row out_off + l of an [NK][out_rows][C] image (matching concatenates banks)
+// kn rows of bank `kappa` land at row out_off + l of an [NK][C/4][out_rows][4] image (matching concatenates banks)
 int swem_norm_bases_into(void *stream, const float *kappa, float *kn, int NK, int C, int L, int out_rows,
                          int out_off) {
   SWEM_REQUIRE(kappa && kn && NK > 0 && C > 0 && L > 0, SWEM_E_ARG, "em_norm_bases: bad argument");
-  SWEM_REQUIRE(C <= 1024, SWEM_E_SHAPE, "em_norm_bases: C > 1024");
+  SWEM_REQUIRE(C <= 1024 && C % 4 == 0, SWEM_E_SHAPE, "em_norm_bases: C must be a multiple of 4, at most 1024");
   size_t lds = ((size_t)C * 33 + 256 + 32) * sizeof(float);
   hipLaunchKernelGGL(em_norm_bases_kernel, dim3(cdiv(L, 32), NK), dim3(256), lds, ST, kappa, kn, C, L, out_rows,
                      out_off);
@@ -363,84 +382,97 @@ extern "C" int swem_em_norm_bases_f32(void *stream, const float *kappa, float *k
   return swem_norm_bases_into(stream, kappa, kn, NK, C, L, L, 0);
 }
 
-extern "C" int swem_em_ew_f32(void *stream, const float *x, const float *kn, const float *masks, const float *w_in,
-                              float *w_out, float *zT, int N, int C, int P, int L, float tau, int do_w, int do_e) {
-  SWEM_REQUIRE(x && kn && N > 0 && P > 0, SWEM_E_ARG, "em_ew: bad argument");
-  SWEM_REQUIRE(C % 8 == 0 && C <= 512, SWEM_E_SHAPE, "em_ew: C must be a multiple of 8 and <= 512 (got %d)", C);
-  SWEM_REQUIRE(L == 64 || L == 128 || L == 256, SWEM_E_SHAPE, "em_ew: L must be 64, 128 or 256 (got %d)", L);
-  SWEM_REQUIRE(!do_w || masks, SWEM_E_ARG, "em_ew: W step needs masks");
-  SWEM_REQUIRE(do_w || !do_e || w_in, SWEM_E_ARG, "em_ew: E step without W step needs w_in");
-  SWEM_REQUIRE(!do_e || zT, SWEM_E_ARG, "em_ew: E step needs zT");
-  SWEM_REQUIRE(tau > 0.f, SWEM_E_ARG, "em_ew: tau must be positive");
-  const int Pp = swem_em_pad(P);
-  dim3 grid(cdiv(P, 32), N);
-  // 64 bases per class: 2 waves per class; 128: 4 waves x 1 tile; 256: 4 waves x 2 tiles (8-wave blocks)
-#define EW(LT_, WPC_)                                                                                               \
-  hipLaunchKernelGGL((em_ew_kernel<LT_, WPC_>), grid, dim3(128 * WPC_),                                              \
-                     ((size_t)32 * (C + 4) + 32 + 3 * 2 * WPC_ * 32) * sizeof(float), ST, x, kn, masks, w_in, w_out, zT, \
-                     C, P, Pp, L, tau, do_w, do_e)
-  if (L == 64) EW(1, 2);
-  else if (L == 128) EW(1, 4);
-  else EW(2, 4);
+namespace {
+int ew_launch(void *stream, const float *x, const float *kn, int kn_rows, int kn_off, const float *masks,
+              const float *w_in, float *w_out, float *z, int N, int C, int P, int L, float tau, int do_w, int do_e) {
+  const int Pz = swem_em_pad(P);
+  dim3 grid(cdiv(P, 16), N);
+#define EW(LT_, CM_)                                                                                                  \
+  hipLaunchKernelGGL((em_ew16_kernel<LT_, CM_>), grid, dim3(512), 0, ST, x, kn, kn_rows, kn_off, masks, w_in, w_out, z, \
+                     P, Pz, tau, do_w, do_e)
+  if (C == 128) {
+    if (L == 64) EW(1, 8);
+    else if (L == 128) EW(2, 8);
+    else EW(4, 8);
+  } else {
+    if (L == 64) EW(1, 4);
+    else if (L == 128) EW(2, 4);
+    else EW(4, 4);
+  }
 #undef EW
   SWEM_CHECK_LAUNCH("em_ew");
   return SWEM_OK;
 }
+}  // namespace
 
-extern "C" size_t swem_em_mstep_workspace(int NK, int R, int P, int L) { return mstep_ws(NK, R, P, L).total; }
+extern "C" int swem_em_ew_f32(void *stream, const float *x, const float *kn, const float *masks, const float *w_in,
+                              float *w_out, float *z, int N, int C, int P, int L, float tau, int do_w, int do_e) {
+  SWEM_REQUIRE(x && kn && N > 0 && P > 0, SWEM_E_ARG, "em_ew: bad argument");
+  SWEM_REQUIRE(C == 64 || C == 128, SWEM_E_SHAPE, "em_ew: the key dimension must be 64 or 128 (got %d)", C);
+  SWEM_REQUIRE(L == 64 || L == 128 || L == 256, SWEM_E_SHAPE, "em_ew: L must be 64, 128 or 256 (got %d)", L);
+  SWEM_REQUIRE(!do_w || masks, SWEM_E_ARG, "em_ew: W step needs masks");
+  SWEM_REQUIRE(do_w || !do_e || w_in, SWEM_E_ARG, "em_ew: E step without W step needs w_in");
+  SWEM_REQUIRE(!do_e || z, SWEM_E_ARG, "em_ew: E step needs z");
+  SWEM_REQUIRE(tau > 0.f, SWEM_E_ARG, "em_ew: tau must be positive");
+  return ew_launch(stream, x, kn, L, 0, masks, w_in, w_out, z, N, C, P, L, tau, do_w, do_e);
+}
 
 namespace {
-// zsum_mode: 0 = separate em_zsum launch (the step-level entry point), 1 = fused into the finalize+norm kernel (key bases
-// inside memorize), 2 = zt already holds zita (the value update reuses the last key step's)
-int mstep_impl(void *stream, const float *A, int a_batch_div, const float *zT, const float *prev, const float *zita_prev,
-               float *out, float *zita_out, float *kn_out, int NK, int R, int P, int L, float *S, void *conv_ws,
-               size_t conv_bytes, float *zt, int zsum_mode) {
-  const int Pp = swem_em_pad(P), N = NK / 2;
-  // S[n] = A[n] . [z_bg | z_fg]^T : a batched GEMM on the conv kernel: an R x 1 "image" with Pp channels per object
-  // (A shared by all objects when a_batch_div == 0), 2L 1x1 filters per object = its two classes' rows of zT
-  int rc = swem_conv2d_nhwc_f32(stream, A, Pp, a_batch_div ? (long long)R * Pp : 0, nullptr, 0, 0, nullptr, 0, 0, N, R, 1,
-                                zT, (long long)2 * L * Pp, nullptr, nullptr, nullptr, 0, S, 2 * L, 1, 1, 1, 0, 0, 0, conv_ws,
-                                conv_bytes);
-  if (rc) return rc;
-  if (zsum_mode == 0) {
-    hipLaunchKernelGGL(em_zsum_kernel, dim3(cdiv(NK * L, 4)), dim3(256), 0, ST, zT, zita_prev, zt, zita_out, NK * L, Pp);
-    SWEM_CHECK_LAUNCH("em_zsum");
-  }
-  if (kn_out) {
-    size_t lds = ((size_t)R * 33 + 1024 + 32) * sizeof(float);
-    hipLaunchKernelGGL(em_finalize_norm_kernel, dim3(L / 32, NK), dim3(1024), lds, ST, S, prev, zita_prev, zt, out,
-                       kn_out, NK, R, L, zsum_mode == 1 ? zT : nullptr, zita_out, Pp);
-  } else {
-    hipLaunchKernelGGL(em_finalize_kernel, dim3(L / 32, NK, cdiv(R, 32)), dim3(256), 0, ST, S, prev, zita_prev, zt, out,
-                       NK, R, L);
-  }
+// One M step over the row space [keys (Ck rows of x) | values (Vv rows of v)] and the finalize of both.
+int mstep_impl(void *stream, const float *x, const float *v, const float *z, const float *kappa_prev,
+               const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out,
+               float *kn_out, int kn_rows, int kn_off, float *mvp_out, int mvp_lm, int mvp_off, int NK, int Ck, int Vv,
+               int C, int V, int P, int L, char *ws) {
+  const int Rtot = Ck + Vv;
+  MWs w = mstep_ws(NK, Rtot, P, L);
+  MStepP mp;
+  mp.x = x;
+  mp.v = v;
+  mp.z = z;
+  mp.Spart = reinterpret_cast<float *>(ws + w.Spart);
+  mp.zpart = reinterpret_cast<float *>(ws + w.zpart);
+  mp.Ck = Ck, mp.C = C, mp.V = V, mp.P = P, mp.Pz = swem_em_pad(P), mp.L = L, mp.NK = NK, mp.Rtot = Rtot;
+  dim3 grid(NK * (L / 32), Rtot / 128, w.nch);
+  if (w.steps == 52) hipLaunchKernelGGL((em_mstep_kernel<52>), grid, dim3(512), 0, ST, mp);
+  else hipLaunchKernelGGL((em_mstep_kernel<26>), grid, dim3(512), 0, ST, mp);
+  SWEM_CHECK_LAUNCH("em_mstep");
+  FinP fp;
+  fp.Spart = mp.Spart, fp.zpart = mp.zpart;
+  fp.kappa_prev = kappa_prev, fp.nu_prev = nu_prev, fp.zita_prev = zita_prev, fp.zita_in = nullptr;
+  fp.kappa_out = kappa_out, fp.nu_out = nu_out, fp.zita_out = zita_out;
+  fp.kn_out = kn_out, fp.mvp_out = mvp_out;
+  fp.kn_rows = kn_rows, fp.kn_off = kn_off, fp.mvp_lm = mvp_lm, fp.mvp_off = mvp_off;
+  fp.Ck = Ck, fp.C = C, fp.V = V, fp.L = L, fp.NK = NK, fp.Rtot = Rtot, fp.nch = w.nch;
+  hipLaunchKernelGGL(em_finalize_kernel, dim3(L / 32, NK, Rtot / 128), dim3(1024), 0, ST, fp);
   SWEM_CHECK_LAUNCH("em_finalize");
   return SWEM_OK;
 }
 }  // namespace
 
-extern "C" int swem_em_mstep_f32(void *stream, const float *A, int a_batch_div, const float *zT, const float *prev,
+extern "C" size_t swem_em_mstep_workspace(int NK, int R, int P, int L) { return mstep_ws(NK, R, P, L).total; }
+
+extern "C" int swem_em_mstep_f32(void *stream, const float *A, int a_per_object, const float *z, const float *prev,
                                  const float *zita_prev, float *out, float *zita_out, float *kn_out, int NK, int R,
                                  int P, int L, void *ws, size_t ws_bytes) {
-  SWEM_REQUIRE(A && zT && prev && zita_prev && out, SWEM_E_ARG, "em_mstep: null pointer");
+  SWEM_REQUIRE(A && z && prev && zita_prev && out, SWEM_E_ARG, "em_mstep: null pointer");
   SWEM_REQUIRE(NK % 2 == 0 && L % 32 == 0 && R % 128 == 0, SWEM_E_SHAPE,
                "em_mstep: need NK even, L %% 32 == 0 and R %% 128 == 0 (got %d, %d, %d)", NK, L, R);
-  SWEM_REQUIRE(a_batch_div == 0 || a_batch_div == 2, SWEM_E_ARG, "em_mstep: a_batch_div must be 0 (shared A) or 2");
-  SWEM_REQUIRE(!kn_out || R <= 1024, SWEM_E_SHAPE, "em_mstep: kn_out needs R <= 1024");
+  SWEM_REQUIRE(!kn_out || (R == 128 && !a_per_object), SWEM_E_SHAPE, "em_mstep: kn_out needs the key rows (R == 128, shared A)");
   MWs w = mstep_ws(NK, R, P, L);
   SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "em_mstep: workspace %zu < %zu", ws_bytes, w.total);
-  char *base = static_cast<char *>(ws);
-  return mstep_impl(stream, A, a_batch_div, zT, prev, zita_prev, out, zita_out, kn_out, NK, R, P, L,
-                    reinterpret_cast<float *>(base + w.S), base + w.conv, w.zt - w.conv,
-                    reinterpret_cast<float *>(base + w.zt), 0);
+  if (a_per_object)  // value rows: A = v [N][P][R]
+    return mstep_impl(stream, nullptr, A, z, nullptr, prev, zita_prev, nullptr, out, zita_out, nullptr, 0, 0, nullptr, 0, 0,
+                      NK, 0, R, 0, R, P, L, static_cast<char *>(ws));
+  return mstep_impl(stream, A, nullptr, z, prev, nullptr, zita_prev, out, nullptr, zita_out, kn_out, L, 0, nullptr, 0, 0, NK, R,
+                    0, R, 0, P, L, static_cast<char *>(ws));
 }
 
 namespace {
 struct MemWs {
-  size_t xT, vT, kn, zT, wb, ztb, part, total;
+  size_t kn, z, part, total;
 };
 MemWs memorize_ws(int N, int C, int V, int P, int L) {
-  const int Pp = swem_em_pad(P), NK = 2 * N;
+  const int Pz = swem_em_pad(P), NK = 2 * N;
   MemWs w;
   size_t o = 0;
   auto take = [&](size_t bytes) {
@@ -448,16 +480,58 @@ MemWs memorize_ws(int N, int C, int V, int P, int L) {
     o = align_up(o + bytes, 256);
     return at;
   };
-  w.xT = take((size_t)C * Pp * 4);
-  w.vT = take((size_t)N * V * Pp * 4);
   w.kn = take((size_t)NK * L * C * 4);
-  w.zT = take((size_t)NK * L * Pp * 4);
-  w.wb = take((size_t)NK * P * 4);
-  w.ztb = take((size_t)NK * L * 4);
-  size_t p1 = swem_em_mstep_workspace(NK, C, P, L), p2 = swem_em_mstep_workspace(NK, V, P, L);
+  w.z = take((size_t)N * Pz * 2 * L * 4);
+  size_t p1 = mstep_ws(NK, C, P, L).total, p2 = mstep_ws(NK, C + V, P, L).total;
   w.part = take(p1 > p2 ? p1 : p2);
   w.total = o;
   return w;
+}
+
+int memorize_impl(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
+                  const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out, int N,
+                  int C, int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes, float *z_ext,
+                  const float *kn_prior, int knp_rows, int knp_off, float *kn_out, int kno_rows, int kno_off,
+                  float *mvp_out, int mvp_lm, int mvp_off) {
+  SWEM_REQUIRE(x && v && masks && kappa_prev && nu_prev && zita_prev && kappa_out && nu_out && zita_out, SWEM_E_ARG,
+               "memorize: null pointer");
+  SWEM_REQUIRE(T >= 1, SWEM_E_ARG, "memorize: T < 1");
+  SWEM_REQUIRE(kappa_out != kappa_prev && nu_out != nu_prev && zita_out != zita_prev, SWEM_E_ARG,
+               "memorize: outputs must not alias the prior bases (the prior is read by every iteration)");
+  SWEM_REQUIRE(C == 64 || C == 128, SWEM_E_SHAPE, "memorize: the key dimension must be 64 or 128 (got %d)", C);
+  SWEM_REQUIRE(L == 64 || L == 128 || L == 256, SWEM_E_SHAPE, "memorize: L must be 64, 128 or 256 (got %d)", L);
+  SWEM_REQUIRE(V % 128 == 0, SWEM_E_SHAPE, "memorize: the value dimension must be a multiple of 128 (got %d)", V);
+  SWEM_REQUIRE(C == 128, SWEM_E_SHAPE, "memorize: the M step takes 128 key channels (got %d)", C);
+  SWEM_REQUIRE(tau > 0.f, SWEM_E_ARG, "memorize: tau must be positive");
+  MemWs w = memorize_ws(N, C, V, P, L);
+  SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "memorize: workspace %zu < %zu", ws_bytes, w.total);
+  char *base = static_cast<char *>(ws);
+  float *kn = (float *)(base + w.kn);
+  float *z = z_ext ? z_ext : (float *)(base + w.z);
+  const int NK = 2 * N, Pz = swem_em_pad(P);
+  int rc;
+  if (z_ext && hipMemsetAsync(z_ext, 0, (size_t)N * Pz * 2 * L * 4, ST) != hipSuccess) {
+    swem_set_error("memorize: memset failed");   // (training keeps z: rows [P, Pz) must read as zeros in the backward GEMM)
+    return SWEM_E_HIP;
+  }
+  const float *kcur = kn_prior;
+  int krows = knp_rows, koff = knp_off;
+  if (!kcur) {
+    if ((rc = swem_em_norm_bases_f32(stream, kappa_prev, kn, NK, C, L))) return rc;
+    kcur = kn, krows = L, koff = 0;
+  }
+  for (int it = 0; it < T; ++it) {
+    const bool last = it == T - 1;
+    // W step of iteration it-1 (modules.py:161-162) and E step of iteration it share one GEMM
+    if ((rc = ew_launch(stream, x, kcur, krows, koff, masks, masks, nullptr, z, N, C, P, L, tau, it > 0, 1))) return rc;
+    // key bases every iteration; the value bases (modules.py:164-165) from the LAST z, in the same two launches
+    if ((rc = mstep_impl(stream, x, last ? v : nullptr, z, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out,
+                         last ? kn_out : kn, last ? kno_rows : L, last ? kno_off : 0, last ? mvp_out : nullptr, mvp_lm,
+                         mvp_off, NK, C, last ? V : 0, C, V, P, L, base + w.part)))
+      return rc;
+    kcur = kn, krows = L, koff = 0;
+  }
+  return SWEM_OK;
 }
 }  // namespace
 
@@ -465,67 +539,39 @@ extern "C" size_t swem_memorize_workspace(int N, int C, int V, int P, int L) {
   return memorize_ws(N, C, V, P, L).total;
 }
 
-namespace {
-int memorize_impl(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
-                  const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out, int N,
-                  int C, int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes, float *zT_ext);
-}
 extern "C" int swem_memorize_f32(void *stream, const float *x, const float *v, const float *masks,
                                  const float *kappa_prev, const float *nu_prev, const float *zita_prev,
                                  float *kappa_out, float *nu_out, float *zita_out, int N, int C, int V, int P, int L,
                                  int T, float tau, void *ws, size_t ws_bytes) {
   return memorize_impl(stream, x, v, masks, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out, N, C, V, P, L, T,
-                       tau, ws, ws_bytes, nullptr);
+                       tau, ws, ws_bytes, nullptr, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0);
 }
-// training: the same, and the last E step's responsibilities zT [2N][L][Pp] are kept for the value update's backward
+
+// The same with matching's packed banks kept current (swem_match_packed_f32): the prior's normalised form is READ from
+// the pack's 'update' half when `prior_packed` (it was written there by the previous frame's call), and the new bases'
+// normalised keys / packed values are WRITTEN to bank `bank` (0 = 'first', 1 = 'update') of the pack.
+extern "C" int swem_memorize_packed_f32(void *stream, const float *x, const float *v, const float *masks,
+                                        const float *kappa_prev, const float *nu_prev, const float *zita_prev,
+                                        float *kappa_out, float *nu_out, float *zita_out, float *mkn, float *mvp,
+                                        int prior_packed, int bank, int N, int C, int V, int P, int L, int T, float tau,
+                                        void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(mkn && mvp, SWEM_E_ARG, "memorize_packed: null pack");
+  SWEM_REQUIRE(bank == 0 || bank == 1, SWEM_E_ARG, "memorize_packed: bank must be 0 or 1");
+  return memorize_impl(stream, x, v, masks, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out, N, C, V, P, L, T,
+                       tau, ws, ws_bytes, nullptr, prior_packed ? mkn : nullptr, 2 * L, L, mkn, 2 * L, bank * L, mvp,
+                       2 * L, bank * L);
+}
+
+// training: the same as swem_memorize_f32, and the last E step's responsibilities z [N][Pz][2L] (Pz = swem_em_pad(P), rows
+// >= P zero) are kept for the value update's backward
 extern "C" int swem_memorize_train_f32(void *stream, const float *x, const float *v, const float *masks,
                                        const float *kappa_prev, const float *nu_prev, const float *zita_prev,
-                                       float *kappa_out, float *nu_out, float *zita_out, float *zT_out, int N, int C,
+                                       float *kappa_out, float *nu_out, float *zita_out, float *z_out, int N, int C,
                                        int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes) {
-  SWEM_REQUIRE(zT_out, SWEM_E_ARG, "memorize_train: zT_out is null");
+  SWEM_REQUIRE(z_out, SWEM_E_ARG, "memorize_train: z_out is null");
   return memorize_impl(stream, x, v, masks, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out, N, C, V, P, L, T,
-                       tau, ws, ws_bytes, zT_out);
+                       tau, ws, ws_bytes, z_out, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0);
 }
-namespace {
-int memorize_impl(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
-                  const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out, int N,
-                  int C, int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes, float *zT_ext) {
-  SWEM_REQUIRE(x && v && masks && kappa_prev && nu_prev && zita_prev && kappa_out && nu_out && zita_out, SWEM_E_ARG,
-               "memorize: null pointer");
-  SWEM_REQUIRE(T >= 1, SWEM_E_ARG, "memorize: T < 1");
-  SWEM_REQUIRE(kappa_out != kappa_prev && nu_out != nu_prev && zita_out != zita_prev, SWEM_E_ARG,
-               "memorize: outputs must not alias the prior bases (the prior is read by every iteration)");
-  MemWs w = memorize_ws(N, C, V, P, L);
-  SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "memorize: workspace %zu < %zu", ws_bytes, w.total);
-  char *base = static_cast<char *>(ws);
-  float *xT = (float *)(base + w.xT), *vT = (float *)(base + w.vT), *kn = (float *)(base + w.kn);
-  float *zT = zT_ext ? zT_ext : (float *)(base + w.zT), *wb = (float *)(base + w.wb);
-  // the two M steps' scratch (S, split-K partials, zita) carved from the shared slot
-  MWs wk = mstep_ws(2 * N, C, P, L), wv = mstep_ws(2 * N, V, P, L);
-  char *part = base + w.part;
-  float *Sk = (float *)(part + wk.S), *Sv = (float *)(part + wv.S);
-  void *convk = part + wk.conv, *convv = part + wv.conv;
-  const size_t convk_bytes = wk.zt - wk.conv, convv_bytes = wv.zt - wv.conv;
-  float *ztb = (float *)(base + w.ztb);
-  const int Pp = swem_em_pad(P), NK = 2 * N;
-  int rc;
-  if ((rc = swem_transpose_f32(stream, x, xT, 1, P, C, Pp))) return rc;
-  if ((rc = swem_transpose_f32(stream, v, vT, N, P, V, Pp))) return rc;
-  if ((rc = swem_em_norm_bases_f32(stream, kappa_prev, kn, NK, C, L))) return rc;
-  for (int it = 0; it < T; ++it) {
-    // W step of iteration it-1 (modules.py:161-162) and E step of iteration it share one GEMM
-    if ((rc = swem_em_ew_f32(stream, x, kn, masks, masks, wb, zT, N, C, P, L, tau, it > 0, 1))) return rc;
-    // key bases: GEMM + one kernel for zita, the prior blend and the next iteration's normalised bases (the last
-    // iteration's kn lands in the same scratch and is simply not used)
-    if ((rc = mstep_impl(stream, xT, 0, zT, kappa_prev, zita_prev, kappa_out, zita_out, kn, NK, C, P, L, Sk, convk,
-                         convk_bytes, ztb, 1)))
-      return rc;
-  }
-  // value bases from the last z (modules.py:164-165); zita is the one just written (ztb)
-  return mstep_impl(stream, vT, 2, zT, nu_prev, zita_prev, nu_out, nullptr, nullptr, NK, V, P, L, Sv, convv, convv_bytes,
-                    ztb, 2);
-}
-}  // namespace
 
 // ------------------------------------------------------------------------------------------------ backward (training)
 // nu = (zita_prev * nu_prev + v . z) / zita  (modules.py:164-165) is the only part of swem() that carries gradient
@@ -547,11 +593,11 @@ __global__ void nu_bwd_prep_kernel(const float *__restrict__ dnu, const float *_
   if (dnu_prev) dnu_prev[i] = g * zita_prev[t * L + l];
 }
 struct NuBwdWs {
-  size_t Gp, zTt, dvp, conv, total;
+  size_t Gp, dvp, conv, total;
 };
 NuBwdWs nu_bwd_ws(int N, int V, int P, int L) {
   NuBwdWs w;
-  const int Pm = swem_match_pad(P);
+  const int Pm = swem_em_pad(P);
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t at = o;
@@ -559,7 +605,6 @@ NuBwdWs nu_bwd_ws(int N, int V, int P, int L) {
     return at;
   };
   w.Gp = take((size_t)N * V * 2 * L * 4);
-  w.zTt = take((size_t)N * Pm * 2 * L * 4);
   w.dvp = take((size_t)N * Pm * V * 4);
   w.conv = take(swem_conv2d_workspace(N, Pm, 1, 2 * L, V, 1, 1, 1, 0, 0, 0));
   w.total = o;
@@ -569,31 +614,23 @@ NuBwdWs nu_bwd_ws(int N, int V, int P, int L) {
 
 extern "C" size_t swem_nu_update_bwd_workspace(int N, int V, int P, int L) { return nu_bwd_ws(N, V, P, L).total; }
 
-extern "C" int swem_nu_update_bwd_f32(void *stream, const float *zT, const float *zita_prev, const float *zita,
+extern "C" int swem_nu_update_bwd_f32(void *stream, const float *z, const float *zita_prev, const float *zita,
                                       const float *dnu, float *dv, float *dnu_prev, int N, int V, int P, int L, void *ws,
                                       size_t ws_bytes) {
-  SWEM_REQUIRE(zT && zita_prev && zita && dnu && dv, SWEM_E_ARG, "nu_update_bwd: null pointer");
+  SWEM_REQUIRE(z && zita_prev && zita && dnu && dv, SWEM_E_ARG, "nu_update_bwd: null pointer");
   SWEM_REQUIRE(N > 0 && V % 4 == 0 && L % 32 == 0, SWEM_E_SHAPE, "nu_update_bwd: need V %% 4 == 0 and L %% 32 == 0");
   NuBwdWs w = nu_bwd_ws(N, V, P, L);
   SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "nu_update_bwd: workspace %zu < %zu", ws_bytes, w.total);
   char *base = static_cast<char *>(ws);
-  float *Gp = (float *)(base + w.Gp), *zTt = (float *)(base + w.zTt), *dvp = (float *)(base + w.dvp);
-  const int Pp = swem_em_pad(P), Pm = swem_match_pad(P);
+  float *Gp = (float *)(base + w.Gp), *dvp = (float *)(base + w.dvp);
+  const int Pm = swem_em_pad(P);
   hipLaunchKernelGGL(nu_bwd_prep_kernel, dim3(cdiv((long long)N * 2 * V * L, 256)), dim3(256), 0, ST, dnu, zita,
                      zita_prev, Gp, dnu_prev, N, V, L);
   SWEM_CHECK_LAUNCH("nu_bwd_prep");
-  // z pixel-major per object: zT[n] is [2L][Pp] -> [Pp][2L], rows padded with zeros to the GEMM tile (Pm)
-  if (hipMemsetAsync(zTt, 0, (size_t)N * Pm * 2 * L * 4, ST) != hipSuccess) {
-    swem_set_error("nu_update_bwd: memset failed");
-    return SWEM_E_HIP;
-  }
+  // dv[n] = z[n] . Gp[n]^T : batched GEMM on the conv kernel; z is already pixel-major with Pm zero-padded rows per object
+  // (a Pm x 1 image with 2L channels, V filters per object)
   int rc;
-  for (int n = 0; n < N; ++n)
-    if ((rc = swem_transpose_f32(stream, zT + (long long)n * 2 * L * Pp, zTt + (long long)n * Pm * 2 * L, 1, 2 * L, Pp,
-                                 2 * L)))
-      return rc;
-  // dv[n] = z[n] . Gp[n]^T : batched GEMM on the conv kernel (a Pm x 1 image with 2L channels, V filters per object)
-  if ((rc = swem_conv2d_nhwc_f32(stream, zTt, 2 * L, (long long)Pm * 2 * L, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, Gp,
+  if ((rc = swem_conv2d_nhwc_f32(stream, z, 2 * L, (long long)Pm * 2 * L, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, Gp,
                                  (long long)V * 2 * L, nullptr, nullptr, nullptr, 0, dvp, V, 1, 1, 1, 0, 0, 0,
                                  base + w.conv, w.total - w.conv)))
     return rc;

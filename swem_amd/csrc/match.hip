@@ -420,35 +420,12 @@ extern "C" size_t swem_match_workspace(int N, int C, int V, int P, int L, int nb
   return match_ws(N, C, V, P, L, nbanks, readout_plan).total;
 }
 
-extern "C" int swem_match_f32(void *stream, const float *qk, const float *kappa_first, const float *nu_first,
-                              const float *kappa_update, const float *nu_update, float *mem_out, float *S, int N,
-                              int C, int V, int P, int L, int topl, float tau, int readout_plan, void *ws,
-                              size_t ws_bytes) {
-  SWEM_REQUIRE(qk && kappa_first && nu_first && mem_out && S, SWEM_E_ARG, "match: null pointer");
-  SWEM_REQUIRE((kappa_update == nullptr) == (nu_update == nullptr), SWEM_E_ARG, "match: update bank half given");
-  const int nbanks = kappa_update ? 2 : 1;
-  const int Lm = nbanks * L, Ltot = 2 * Lm;
-  SWEM_REQUIRE(Lm == 64 || Lm == 128 || Lm == 256 || Lm == 512, SWEM_E_SHAPE,
-               "match: bases per class must be 64, 128, 256 or 512 (got %d)", Lm);
-  SWEM_REQUIRE(C % 8 == 0 && C <= 1024 && V % 4 == 0 && L % 4 == 0, SWEM_E_SHAPE,
-               "match: need C %% 8 == 0, C <= 1024, V %% 4 == 0");
-  SWEM_REQUIRE(topl >= 1 && topl <= 64 && topl <= Lm, SWEM_E_SHAPE, "match: topl must be in [1, 64] (got %d)", topl);
-  SWEM_REQUIRE(tau > 0.f, SWEM_E_ARG, "match: tau must be positive");
-  const int Pm = swem_match_pad(P);
-  MatchWs w = match_ws(N, C, V, P, L, nbanks, readout_plan);
-  SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "match: workspace %zu < %zu", ws_bytes, w.total);
-  char *base = static_cast<char *>(ws);
-  float *mkn = (float *)(base + w.mkn), *mvp = (float *)(base + w.mvp), *pT = (float *)(base + w.pT);
+namespace {
+// affinity + top-l features + readout on PACKED banks: mkn [2N][C/4][Lm][4], mvp [N][V][2Lm]
+int match_core(void *stream, const float *qk, const float *mkn, const float *mvp, float *pT, float *mem_out, float *S, int N,
+               int C, int V, int P, int Lm, int topl, float tau, int readout_plan, void *conv_ws, size_t conv_bytes) {
+  const int Pm = swem_match_pad(P), Ltot = 2 * Lm;
   int rc;
-  if ((rc = swem_norm_bases_into(stream, kappa_first, mkn, 2 * N, C, L, Lm, 0))) return rc;
-  if (nbanks == 2 && (rc = swem_norm_bases_into(stream, kappa_update, mkn, 2 * N, C, L, Lm, L))) return rc;
-  {
-    long long work = (long long)N * 2 * V * (L / 4);
-    hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu_first, mvp, N, V, L, Lm, 0);
-    if (nbanks == 2)
-      hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu_update, mvp, N, V, L, Lm, L);
-    SWEM_CHECK_LAUNCH("pack_values");
-  }
   dim3 gridt(cdiv((long long)N * P, 4));
   if ((rc = launch_affinity(ST, qk, mkn, pT, N, C, P, Pm, Lm, tau))) return rc;
 #define TOPL(J_) hipLaunchKernelGGL((match_topl_kernel<J_>), gridt, dim3(256), 0, ST, pT, S, N, P, Pm, topl)
@@ -462,7 +439,74 @@ extern "C" int swem_match_f32(void *stream, const float *qk, const float *kappa_
   // "image" of Pm x 1 pixels with Ltot channels, 1x1 filters = the V value rows of object n (w_bs = V*Ltot)
   return swem_conv2d_nhwc_f32(stream, pT, Ltot, (long long)Pm * Ltot, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, mvp,
                               (long long)V * Ltot, nullptr, nullptr, nullptr, 0, mem_out, V, 1, 1, 1, 0, 0,
-                              readout_plan, base + w.conv, w.total - w.conv);
+                              readout_plan, conv_ws, conv_bytes);
+}
+
+int match_check(int C, int V, int L, int Lm, int topl, float tau) {
+  SWEM_REQUIRE(Lm == 64 || Lm == 128 || Lm == 256 || Lm == 512, SWEM_E_SHAPE,
+               "match: bases per class must be 64, 128, 256 or 512 (got %d)", Lm);
+  SWEM_REQUIRE(C % 8 == 0 && C <= 1024 && V % 4 == 0 && L % 4 == 0, SWEM_E_SHAPE,
+               "match: need C %% 8 == 0, C <= 1024, V %% 4 == 0");
+  SWEM_REQUIRE(topl >= 1 && topl <= 64 && topl <= Lm, SWEM_E_SHAPE, "match: topl must be in [1, 64] (got %d)", topl);
+  SWEM_REQUIRE(tau > 0.f, SWEM_E_ARG, "match: tau must be positive");
+  return SWEM_OK;
+}
+}  // namespace
+
+// one bank's bases into the packed form matching reads (modules.py:295-306 `get_mem` + the l2norm of :283)
+extern "C" int swem_match_pack_bank_f32(void *stream, const float *kappa, const float *nu, float *mkn, float *mvp,
+                                        int bank, int nbanks, int N, int C, int V, int L) {
+  SWEM_REQUIRE(kappa && nu && mkn && mvp, SWEM_E_ARG, "match_pack_bank: null pointer");
+  SWEM_REQUIRE(nbanks >= 1 && nbanks <= 2 && bank >= 0 && bank < nbanks, SWEM_E_ARG, "match_pack_bank: bad bank index");
+  const int Lm = nbanks * L;
+  int rc;
+  if ((rc = swem_norm_bases_into(stream, kappa, mkn, 2 * N, C, L, Lm, bank * L))) return rc;
+  const long long work = (long long)N * 2 * V * (L / 4);
+  hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu, mvp, N, V, L, Lm, bank * L);
+  SWEM_CHECK_LAUNCH("pack_values");
+  return SWEM_OK;
+}
+
+extern "C" int swem_match_f32(void *stream, const float *qk, const float *kappa_first, const float *nu_first,
+                              const float *kappa_update, const float *nu_update, float *mem_out, float *S, int N,
+                              int C, int V, int P, int L, int topl, float tau, int readout_plan, void *ws,
+                              size_t ws_bytes) {
+  SWEM_REQUIRE(qk && kappa_first && nu_first && mem_out && S, SWEM_E_ARG, "match: null pointer");
+  SWEM_REQUIRE((kappa_update == nullptr) == (nu_update == nullptr), SWEM_E_ARG, "match: update bank half given");
+  const int nbanks = kappa_update ? 2 : 1;
+  const int Lm = nbanks * L;
+  int rc;
+  if ((rc = match_check(C, V, L, Lm, topl, tau))) return rc;
+  MatchWs w = match_ws(N, C, V, P, L, nbanks, readout_plan);
+  SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "match: workspace %zu < %zu", ws_bytes, w.total);
+  char *base = static_cast<char *>(ws);
+  float *mkn = (float *)(base + w.mkn), *mvp = (float *)(base + w.mvp), *pT = (float *)(base + w.pT);
+  if ((rc = swem_match_pack_bank_f32(stream, kappa_first, nu_first, mkn, mvp, 0, nbanks, N, C, V, L))) return rc;
+  if (nbanks == 2 && (rc = swem_match_pack_bank_f32(stream, kappa_update, nu_update, mkn, mvp, 1, nbanks, N, C, V, L)))
+    return rc;
+  return match_core(stream, qk, mkn, mvp, pT, mem_out, S, N, C, V, P, Lm, topl, tau, readout_plan, base + w.conv,
+                    w.total - w.conv);
+}
+
+// The same on banks the caller keeps packed (swem_match_pack_bank_f32 / swem_memorize_packed_f32): no per-frame
+// normalisation and repacking of 2 x 2 banks.  Both banks: mkn [2N][C/4][2L][4], mvp [N][V][4L].
+extern "C" size_t swem_match_packed_workspace(int N, int C, int V, int P, int L, int readout_plan) {
+  MatchWs w = match_ws(N, C, V, P, L, 2, readout_plan);
+  return w.total - w.pT;
+}
+
+extern "C" int swem_match_packed_f32(void *stream, const float *qk, const float *mkn, const float *mvp, float *mem_out,
+                                     float *S, int N, int C, int V, int P, int L, int topl, float tau, int readout_plan,
+                                     void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(qk && mkn && mvp && mem_out && S, SWEM_E_ARG, "match_packed: null pointer");
+  int rc;
+  if ((rc = match_check(C, V, L, 2 * L, topl, tau))) return rc;
+  MatchWs w = match_ws(N, C, V, P, L, 2, readout_plan);
+  SWEM_REQUIRE(ws && ws_bytes >= w.total - w.pT, SWEM_E_WORKSPACE, "match_packed: workspace %zu < %zu", ws_bytes,
+               w.total - w.pT);
+  char *base = static_cast<char *>(ws) - w.pT;     // the workspace starts at the probability slot
+  return match_core(stream, qk, mkn, mvp, (float *)(base + w.pT), mem_out, S, N, C, V, P, 2 * L, topl, tau, readout_plan,
+                    base + w.conv, w.total - w.conv);
 }
 
 // backward of swem_match_f32 for one clip: d mem_out [N][Pm][V] and dS [N][P][2*topl] (either may be NULL) ->

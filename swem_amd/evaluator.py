@@ -167,6 +167,9 @@ class FrameGraph:
             for k in self.state:
                 self.state[k].copy_(saved[k])
             core.memories['update'].bases = self.state
+            # matching's packed banks (SWEMCore._pack) are static buffers of the model: bring them in line with the restored
+            # state now, so that the captured frame finds them current and contains no repacking
+            self.pack = core.repack()
             # capture on a stream of this graph's own: scratch buffers are per stream (ops.workspace), and graphs that are
             # replayed concurrently must not share one (torch's default capture stream is one object for all captures)
             # (their scratch is allocated inside the capture and owned by the graph: ops.private_workspaces)
@@ -177,6 +180,7 @@ class FrameGraph:
                 for k in self.state:
                     self.state[k].copy_(new[k])
             core.memories['update'].bases = self.state
+            core.restamp()          # the captured memorize rewrites the pack's 'update' half together with the state
         return self
 
     def rebind(self):
@@ -186,6 +190,9 @@ class FrameGraph:
         cur_first, cur_upd = core.memories['first'].bases, core.memories['update'].bases
         if cur_first is None or cur_upd is None or cur_first['kappa'].shape != self.first['kappa'].shape:
             return False
+        if core._pack is not self.pack:        # the graph holds the addresses of the pack it was captured with
+            return False
+        core.repack()                          # (no-op when memorize kept it current, as it does)
         for k in self.first:
             if cur_first[k] is not self.first[k]:
                 self.first[k].copy_(cur_first[k])
@@ -193,6 +200,7 @@ class FrameGraph:
                 self.state[k].copy_(cur_upd[k])
         core.memories['first'].bases = self.first
         core.memories['update'].bases = self.state
+        core.restamp()
         return True
 
     def run(self, frame):

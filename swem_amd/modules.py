@@ -96,10 +96,53 @@ class SWEMCore(nn.Module):
         self.fusion_layer = FeatureFusionLayer(valdim * 2 + self.topl * 2, valdim)
         self.init_on_host = False
         self._engine = None  # set by SWEM (the fusion conv needs the packed GLU weights)
+        # matching's packed form of the two banks (l2-normalised keys, class-concatenated values: what modules.py:282-283,
+        # 295-306 rebuild on every frame), kept current by memorize itself; `_stamp[b]` names the bank tensor (and its
+        # version) bank b of the pack was built from -- any other tensor in the bank (injected by a test, restored by a
+        # checkpoint, grown by a new object) makes matching repack that bank first
+        self._pack = None
+        self._stamp = [None, None]
 
     def empty(self):
         for key in self.memories.keys():
             self.memories[key].initial_memory()
+        self._stamp = [None, None]       # (the pack's buffers are kept: a captured frame graph holds their addresses)
+
+    # ------------------------------------------------------------------ packed banks
+    def _pack_for(self, N, Ck, device):
+        shape = (2 * N, Ck // 4, 2 * self.n_bases, 4)
+        if self._pack is None or tuple(self._pack[0].shape) != shape or self._pack[0].device != device:
+            self._pack = ops.new_pack(N, Ck, self.valdim, self.n_bases, device)
+            self._stamp = [None, None]
+        return self._pack
+
+    @staticmethod
+    def _stamp_of(bases):
+        return (bases['kappa'], bases['kappa']._version, bases['nu'], bases['nu']._version)
+
+    def _stamped(self, bank, bases):
+        st = self._stamp[bank]
+        return (st is not None and st[0] is bases['kappa'] and st[1] == bases['kappa']._version
+                and st[2] is bases['nu'] and st[3] == bases['nu']._version)
+
+    def restamp(self):
+        """Declare the pack consistent with the banks as they stand (after a frame graph moved new bases into its static
+        bank tensors: the pack was updated by the same graph)."""
+        for b, key in enumerate(('first', 'update')):
+            bases = self.memories[key].bases
+            self._stamp[b] = None if bases is None else self._stamp_of(bases)
+
+    def repack(self):
+        """Rebuild whatever part of the pack does not belong to the current bank tensors."""
+        first, update = self.memories['first'].bases, self.memories['update'].bases
+        N, _, Ck, L = first['kappa'].shape[1:]
+        pack = self._pack_for(N, Ck, first['kappa'].device)
+        for b, bases in enumerate((first, update)):
+            if bases is not None and not self._stamped(b, bases):
+                ops.pack_bank(bases['kappa'].reshape(N, 2, Ck, L).contiguous(), bases['nu'].reshape(N, 2, -1, L).contiguous(),
+                              pack, b)
+                self._stamp[b] = self._stamp_of(bases)
+        return pack
 
     # ------------------------------------------------------------------ single EM steps (modules.py:93-127)
     def sww_step(self, kappa, x_t, masks):
@@ -119,25 +162,22 @@ class SWEMCore(nn.Module):
         kn = ops.em_norm_bases(kappa.reshape(N * 2, *kappa.shape[-2:]).contiguous())
         x = x_t.reshape(x_t.shape[-2], x_t.shape[-1]).contiguous()
         P = x.shape[0]
-        _, zT = ops.em_ew(x, kn, None, weights.reshape(N * 2, -1).contiguous(), self.tau, False, True)
-        return zT[:, :, :P].transpose(1, 2).reshape(B, N, 2, P, L)
+        _, z = ops.em_ew(x, kn, None, weights.reshape(N * 2, -1).contiguous(), self.tau, False, True)
+        return z[:, :P].view(N, P, 2, L).permute(0, 2, 1, 3).reshape(B, N, 2, P, L)     # kernel layout: z[n][p][cls*L + l]
 
     def swm_step(self, z, x, kappa_, zita_):
         """z (B,N,2,P,L), x (B,1,1,Ck,P) -> kappa (B,N,2,Ck,L), zita (B,N,2,1,L)."""
         B, N, _, P, L = z.shape
         assert B == 1
-        Pp = ops.em_pad(P)
-        zT = ops.transpose(z.reshape(N * 2, P, L).contiguous())          # (NK, L, P)
-        if Pp != P:
-            zT = torch.nn.functional.pad(zT, (0, Pp - P)).contiguous()
-        xT = x.reshape(x.shape[-2], P)
-        xT = torch.nn.functional.pad(xT, (0, Pp - P)).contiguous()
-        kappa, zita, _ = ops.em_mstep(xT, 0, zT, kappa_.reshape(N * 2, -1, L).contiguous(),
+        zp = torch.zeros((N, ops.em_pad(P), 2 * L), dtype=torch.float32, device=z.device)
+        zp[:, :P] = z.reshape(N, 2, P, L).permute(0, 2, 1, 3).reshape(N, P, 2 * L)
+        xp = x.reshape(x.shape[-2], P).t().contiguous()                          # (P, Ck) pixel-major
+        kappa, zita, _ = ops.em_mstep(xp, False, zp, kappa_.reshape(N * 2, -1, L).contiguous(),
                                       zita_.reshape(N * 2, L).contiguous(), P)
         return kappa.view(B, N, 2, -1, L), zita.view(B, N, 2, 1, L)
 
     # ------------------------------------------------------------------ modules.py:129-168
-    def swem(self, x, v, masks, bases_=None):
+    def swem(self, x, v, masks, bases_=None, pack=None, prior_packed=False, bank=1):
         B, Ck, H, W = x.shape
         N = masks.shape[1]
         if B != 1:
@@ -162,7 +202,8 @@ class SWEMCore(nn.Module):
         mk = masks.reshape(N, 2, H * W).contiguous()
         kappa, nu, zita = ops.memorize(xp, vp, mk, kappa_.reshape(N, 2, Ck, L).contiguous(),
                                        nu_.reshape(N, 2, -1, L).contiguous(), zita_.reshape(N, 2, L).contiguous(),
-                                       self.n_iters, self.tau)
+                                       self.n_iters, self.tau, pack=pack, prior_packed=prior_packed and N_new <= 0,
+                                       bank=bank)
         return {'kappa': kappa.view(B, N, 2, Ck, L), 'nu': nu.view(B, N, 2, -1, L),
                 'zita': zita.view(B, N, 2, 1, L)}
 
@@ -184,15 +225,24 @@ class SWEMCore(nn.Module):
 
     # ------------------------------------------------------------------ modules.py:183-193
     def memorize(self, qk, qv, masks):
-        if self.memories['update'].bases is None:
-            bases = self.swem(qk, qv, masks, self.memories['first'].bases)
+        first, update = self.memories['first'], self.memories['update']
+        frame0 = first.bases is None
+        prior = first.bases if update.bases is None else update.bases
+        N = masks.shape[1]
+        grown = not frame0 and N > first.bases['kappa'].shape[1]       # new object ids (YouTube-VOS): the pack is rebuilt
+        pack = None if grown else self._pack_for(N, qk.shape[1], qk.device)
+        bank = 0 if frame0 else 1
+        prior_packed = pack is not None and update.bases is not None and self._stamped(1, update.bases)
+        bases = self.swem(qk, qv, masks, prior, pack=pack, prior_packed=prior_packed, bank=bank)
+        if frame0:
+            first.update(bases)
         else:
-            bases = self.swem(qk, qv, masks, self.memories['update'].bases)
-        if self.memories['first'].bases is None:
-            self.memories['first'].update(bases)
+            first.update(bases)
+            update.update(bases)
+        if pack is not None:
+            self._stamp[bank] = self._stamp_of(bases)
         else:
-            self.memories['first'].update(bases)
-            self.memories['update'].update(bases)
+            self._stamp = [None, None]
 
     # ------------------------------------------------------------------ modules.py:232-293
     def _affinity_readout(self, qk, first, update):
@@ -207,7 +257,10 @@ class SWEMCore(nn.Module):
         if update is not None:
             ku = update['kappa'].reshape(N, 2, Ck, L).contiguous()
             nu = update['nu'].reshape(N, 2, -1, L).contiguous()
-        mem_out, S = ops.match(xp, kf, nf, ku, nu, self.topl, self.tau)
+        if update is not None:       # both banks: matching reads the persistent pack (kept current by memorize)
+            mem_out, S = ops.match_packed(xp, self.repack(), L, self.topl, self.tau)
+        else:                        # the first matched frame of a sequence: one bank, packed in the call's workspace
+            mem_out, S = ops.match(xp, kf, nf, ku, nu, self.topl, self.tau)
         # mem_out keeps a row pitch per object (ops.match): NHWC images, free batch stride
         return S.view(N, H, W, -1), mem_out.unflatten(1, (H, W))
 

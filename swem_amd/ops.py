@@ -575,35 +575,36 @@ def em_norm_bases(kappa):
 
 
 def em_ew(x, kn, masks, w_in, tau, do_w, do_e):
-    """x (P,C), kn (NK,L,C), masks/w_in (NK,P) -> (weights (NK,P) or None, zT (NK,L,Pp) or None)."""
+    """x (P,C), kn (NK,C/4,L,4), masks/w_in (NK,P) -> (weights (NK,P) or None, z (N,Pz,2L) pixel-major or None)."""
     _chk(x)
     _chk(kn)
     P, Cc = x.shape
     NK, _, L, _ = kn.shape
-    Pp = em_pad(P)
     w_out = torch.empty((NK, P), dtype=torch.float32, device=x.device) if do_w else None
-    zT = torch.empty((NK, L, Pp), dtype=torch.float32, device=x.device) if do_e else None
+    z = torch.zeros((NK // 2, em_pad(P), 2 * L), dtype=torch.float32, device=x.device) if do_e else None
     _lib.call('swem_em_ew_f32', _stream(), x.data_ptr(), kn.data_ptr(), _ptr(masks), _ptr(w_in), _ptr(w_out),
-              _ptr(zT), NK // 2, Cc, P, L, float(tau), int(do_w), int(do_e))
-    return w_out, zT
+              _ptr(z), NK // 2, Cc, P, L, float(tau), int(do_w), int(do_e))
+    return w_out, z
 
 
-def em_mstep(A, a_div, zT, prev, zita_prev, P, want_kn=False):
-    """A (.., R, Pp); zT (NK, L, Pp); prev (NK, R, L); zita_prev (NK, L) -> out, zita, kn."""
-    NK, L, Pp = zT.shape
+def em_mstep(A, per_object, z, prev, zita_prev, P, want_kn=False):
+    """A (P,R) shared or (N,P,R) per object, pixel-major; z (N,Pz,2L); prev (NK,R,L); zita_prev (NK,L) -> out, zita, kn."""
+    N, _, L2 = z.shape
+    NK, L = 2 * N, L2 // 2
     R = prev.shape[1]
     out = torch.empty_like(prev)
     zita = torch.empty_like(zita_prev)
     kn = torch.empty((NK, R // 4, L, 4), dtype=torch.float32, device=prev.device) if want_kn else None
     wsb = _lib.query('swem_em_mstep_workspace', NK, R, P, L)
     ws = workspace(wsb, prev.device)
-    _lib.call('swem_em_mstep_f32', _stream(), A.data_ptr(), a_div, zT.data_ptr(), prev.data_ptr(),
+    _lib.call('swem_em_mstep_f32', _stream(), _chk(A).data_ptr(), int(per_object), _chk(z).data_ptr(), prev.data_ptr(),
               zita_prev.data_ptr(), out.data_ptr(), zita.data_ptr(), _ptr(kn), NK, R, P, L, ws.data_ptr(), wsb)
     return out, zita, kn
 
 
-def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau):
-    """x (P,C); v (N,P,V); masks (N,2,P); bases (N,2,C,L)/(N,2,V,L)/(N,2,L) -> new bases."""
+def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau, pack=None, prior_packed=False, bank=1):
+    """x (P,C); v (N,P,V); masks (N,2,P); bases (N,2,C,L)/(N,2,V,L)/(N,2,L) -> new bases.
+    pack = (mkn, mvp): matching's packed banks, kept current by this call (swem_memorize_packed_f32)."""
     for t in (x, v, masks, kappa_prev, nu_prev, zita_prev):
         _chk(t)
     P, Cc = x.shape
@@ -612,6 +613,12 @@ def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau):
     kappa, nu, zita = torch.empty_like(kappa_prev), torch.empty_like(nu_prev), torch.empty_like(zita_prev)
     wsb = _lib.query('swem_memorize_workspace', N, Cc, V, P, L)
     ws = workspace(wsb, x.device)
+    if pack is not None:
+        _lib.call('swem_memorize_packed_f32', _stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(),
+                  kappa_prev.data_ptr(), nu_prev.data_ptr(), zita_prev.data_ptr(), kappa.data_ptr(), nu.data_ptr(),
+                  zita.data_ptr(), _chk(pack[0]).data_ptr(), _chk(pack[1]).data_ptr(), int(prior_packed), int(bank), N, Cc,
+                  V, P, L, int(T), float(tau), ws.data_ptr(), wsb)
+        return kappa, nu, zita
     _lib.call('swem_memorize_f32', _stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(), kappa_prev.data_ptr(),
               nu_prev.data_ptr(), zita_prev.data_ptr(), kappa.data_ptr(), nu.data_ptr(), zita.data_ptr(), N, Cc, V,
               P, L, int(T), float(tau), ws.data_ptr(), wsb)
@@ -649,5 +656,44 @@ def match(qk, kappa_first, nu_first, kappa_update, nu_update, topl, tau):
     plan = _MATCH_PLANS.get(key, 0)
     if AUTOTUNE and plan == 0 and not torch.cuda.is_current_stream_capturing():
         plan = _MATCH_PLANS[key] = _autotune(launch, N * Pm, V, 2 * nb * L // 32, False)
+    launch(plan)
+    return mem_out[:, :P], S
+
+
+def new_pack(N, Cc, V, L, device):
+    """Matching's persistent packed banks for N objects (include/swem_hip.h, swem_memorize_packed_f32)."""
+    return (torch.zeros((2 * N, Cc // 4, 2 * L, 4), dtype=torch.float32, device=device),
+            torch.zeros((N, V, 4 * L), dtype=torch.float32, device=device))
+
+
+def pack_bank(kappa, nu, pack, bank):
+    """bases (N,2,C,L) / (N,2,V,L) -> bank `bank` of a two-bank pack."""
+    _chk(kappa)
+    _chk(nu)
+    N, _, Cc, L = kappa.shape
+    _lib.call('swem_match_pack_bank_f32', _stream(), kappa.data_ptr(), nu.data_ptr(), pack[0].data_ptr(),
+              pack[1].data_ptr(), int(bank), 2, N, Cc, nu.shape[2], L)
+
+
+def match_packed(qk, pack, L, topl, tau):
+    """qk (P,C); pack = (mkn (2N,C/4,2L,4), mvp (N,V,4L)) -> mem_out (N,P,V) view, S (N,P,2*topl)."""
+    _chk(qk)
+    mkn, mvp = _chk(pack[0]), _chk(pack[1])
+    P, Cc = qk.shape
+    N, V = mvp.shape[0], mvp.shape[1]
+    Pm = _lib.query('swem_match_pad', P)
+    mem_out = torch.empty((N, Pm, V), dtype=torch.float32, device=qk.device)
+    S = torch.empty((N, P, 2 * topl), dtype=torch.float32, device=qk.device)
+
+    def launch(plan):
+        wsb = _lib.query('swem_match_packed_workspace', N, Cc, V, P, L, plan)
+        ws = workspace(wsb, qk.device)
+        _lib.call('swem_match_packed_f32', _stream(), qk.data_ptr(), mkn.data_ptr(), mvp.data_ptr(), mem_out.data_ptr(),
+                  S.data_ptr(), N, Cc, V, P, L, int(topl), float(tau), plan, ws.data_ptr(), wsb)
+
+    key = (N, Cc, V, P, L, 2)
+    plan = _MATCH_PLANS.get(key, 0)
+    if AUTOTUNE and plan == 0 and not torch.cuda.is_current_stream_capturing():
+        plan = _MATCH_PLANS[key] = _autotune(launch, N * Pm, V, 4 * L // 32, False)
     launch(plan)
     return mem_out[:, :P], S

@@ -38,7 +38,7 @@ def test_version_and_error_channel(lib):
 
 
 def test_size_queries(lib):
-    assert lib.swem_em_pad(1620) == 1632 and lib.swem_em_pad(1632) == 1632
+    assert lib.swem_em_pad(1620) == 1664 and lib.swem_em_pad(1664) == 1664
     assert lib.swem_match_pad(1620) == 1664
     assert lib.swem_match_workspace(2, 128, 512, 1620, 256, 2, 0) >= 2 * 1024 * (128 + 512 + 1664) * 4
     assert lib.swem_memorize_workspace(2, 128, 512, 1620, 256) > 0

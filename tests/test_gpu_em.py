@@ -50,10 +50,10 @@ def test_single_steps_vs_golden(lib, golden):
     assert relmax(kap, g['kappa_m']) < 1e-5, 'M step kappa'
     # value update (modules.py:164-165) = the same M kernel with the value map as A
     P = x_t.shape[-2]
-    Pp = ops.em_pad(P)
-    zT = torch.nn.functional.pad(g['z'].reshape(4, P, 64).transpose(1, 2), (0, Pp - P))
-    vT = torch.nn.functional.pad(g['v'].flatten(3)[0], (0, Pp - P))                # (N, V, Pp)
-    nu, _, _ = ops.em_mstep(d(vT), 2, d(zT), d(g['nu_prev'].reshape(4, 128, 64)), d(g['zita_prev'].reshape(4, 64)), P)
+    zp = torch.zeros(2, ops.em_pad(P), 128)
+    zp[:, :P] = g['z'].reshape(2, 2, P, 64).permute(0, 2, 1, 3).reshape(2, P, 128)     # z[n][p][cls*L + l]
+    vp = g['v'].flatten(3)[0].transpose(1, 2).contiguous()                          # (N, P, V) pixel-major
+    nu, _, _ = ops.em_mstep(d(vp), True, d(zp), d(g['nu_prev'].reshape(4, 128, 64)), d(g['zita_prev'].reshape(4, 64)), P)
     assert relmax(nu.view(1, 2, 2, 128, 64), g['nu']) < 1e-5, 'nu update'
 
 

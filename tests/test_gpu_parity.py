@@ -51,8 +51,11 @@ def test_teacher_forced_config_b_clip(lib, golden):
             oqk, oqv, os16, os8, os4 = om('encode_key', frames[:, i])
             octx, on = om('match', oqk, oqv)
             ologits, oprob = om('segment', on, octx, os8, os4, None, out)
-            # the oracle IS the reference on this clip: its logits are the fixture's
-            assert float((ologits[:, :, ::8, ::8] - fx['logits%d' % (i - 1)]).abs().max()) == 0.0
+            # the oracle is bit-identical to the reference where the fixture was made (tests/test_oracle_golden.py, CPU
+            # suite); on another host CPU (other BLAS kernels / thread count) it is a second fp32 evaluation of the same
+            # chaotic recursion, so against the fixture it is only held to the reference's own fp32-vs-fp64 floor
+            d_fix = float((ologits[:, :, ::8, ::8] - fx['logits%d' % (i - 1)]).abs().max())
+            assert d_fix <= max(1e-3, 2 * float(fx['floor64'][i - 1])), d_fix
             fr = frames[:, i].to(DEV)
             qk, qv, s16h, s8, s4 = model('encode_key', fr)
             ctx, n = model('match', qk, qv)
@@ -68,7 +71,8 @@ def test_teacher_forced_config_b_clip(lib, golden):
             row = {'frame': i, 'dlogits_max': dl, 'dlogits_beyond_ulp_slack': excess, 'index_agreement': agree,
                    'qk16_rel': relmax(qk, oqk), 'context_rel': relmax(ctx, octx), 'context_rel_stage': relmax(ctx_s, octx),
                    'dlogits_stage_max': float((lg_s.cpu() - ologits).abs().max()),
-                   'reference_fp32_vs_fp64_free_running_floor': float(fx['floor64'][i - 1])}
+                   'reference_fp32_vs_fp64_free_running_floor': float(fx['floor64'][i - 1]),
+                   'oracle_on_this_host_vs_fixture_dlogits': d_fix}
             # ---- memorize from identical inputs (the oracle's), identical prior
             if i < t - 1:
                 opm = F.interpolate(oprob, size=(h, w), mode='bilinear', align_corners=False)

@@ -42,25 +42,32 @@ def main():
     nu = torch.randn(N, 2, V, L, generator=g).to(dev)
     zita = (torch.rand(N, 2, L, generator=g) * 3 + 0.1).to(dev)
     kn = ops.em_norm_bases(kappa.view(2 * N, C, L))
-    Pp = ops.em_pad(P)
-    xT = ops.transpose(x.view(1, P, C), ld=Pp)
     w, zT = ops.em_ew(x, kn, masks.view(2 * N, P), masks.view(2 * N, P), tau, True, True)
     fl_e = 2.0 * P * C * 2 * L * N
+    pack = ops.new_pack(N, C, V, L, dev)
+    ops.pack_bank(kappa, nu, pack, 0)
+    ops.pack_bank(kappa, nu, pack, 1)
     rows = [
         ('em_norm_bases', lambda: ops.em_norm_bases(kappa.view(2 * N, C, L)), 0),
         ('em_ew (W+E)', lambda: ops.em_ew(x, kn, masks.view(2 * N, P), masks.view(2 * N, P), tau, True, True), 2 * fl_e),
         ('em_ew (W only)', lambda: ops.em_ew(x, kn, masks.view(2 * N, P), None, tau, True, False), fl_e),
         ('em_ew (E only)', lambda: ops.em_ew(x, kn, None, masks.view(2 * N, P), tau, False, True), fl_e),
-        ('em_mstep keys (GEMM+zsum+finalize+norm)', lambda: ops.em_mstep(xT, 0, zT, kappa.view(2 * N, C, L),
+        ('em_mstep keys (split-P GEMM + finalize+norm)', lambda: ops.em_mstep(x, False, zT, kappa.view(2 * N, C, L),
                                                                           zita.view(2 * N, L), P, True), fl_e),
-        ('memorize (T=5)', lambda: ops.memorize(x, v, masks, kappa, nu, zita, T, tau), 4.0 * P * L * (C * (3 * T - 1) + V) * N),
-        ('match (2 banks)', lambda: ops.match(x, kappa, nu, kappa, nu, topl, tau), 4.0 * 2 * L * P * (C + V) * N),
+        ('em_mstep values (split-P GEMM + finalize)', lambda: ops.em_mstep(v, True, zT, nu.view(2 * N, V, L),
+                                                                            zita.view(2 * N, L), P), 2.0 * P * V * 2 * L * N),
+        ('memorize (T=5)', lambda: ops.memorize(x, v, masks, kappa, nu, zita, T, tau), 0),
+        ('match (2 banks, packed in the call)', lambda: ops.match(x, kappa, nu, kappa, nu, topl, tau), 0),
+        ('memorize (T=5, packed banks kept)', lambda: ops.memorize(x, v, masks, kappa, nu, zita, T, tau, pack=pack,
+                                                                  prior_packed=True, bank=1),
+         4.0 * P * L * (C * (3 * T - 1) + V) * N),
+        ('match (persistent pack)', lambda: ops.match_packed(x, pack, L, topl, tau), 4.0 * 2 * L * P * (C + V) * N),
     ]
     tot_t = tot_f = 0.0
     for name, fn, fl in rows:
         us = timeit(fn)
         print('%-44s %8.1f us  %6.1f TFLOP/s' % (name, us, fl / us / 1e6 if fl else 0))
-        if name.startswith(('memorize', 'match')):
+        if name.startswith(('memorize', 'match')) and fl:
             tot_t += us
             tot_f += fl
     print('%-44s %8.1f us  %6.1f TFLOP/s = %.1f %% of 157.3' % ('memorize + match', tot_t, tot_f / tot_t / 1e6,
@@ -83,9 +90,13 @@ def concurrent(n_streams, objects=2, reps=30, prio=False):
         zita = (torch.rand(N, 2, L, generator=g) * 3 + 0.1).to(dev)
         st = torch.cuda.Stream(priority=-(si % 2)) if prio else torch.cuda.Stream()
         with torch.cuda.stream(st):
-            def fn():
-                k2, n2, z2 = ops.memorize(x, v, masks, kappa, nu, zita, T, tau)
-                ops.match(x, kappa, nu, k2, n2, topl, tau)
+            pack = ops.new_pack(N, C, V, L, dev)
+            ops.pack_bank(kappa, nu, pack, 0)
+            ops.pack_bank(kappa, nu, pack, 1)
+
+            def fn(x=x, v=v, masks=masks, kappa=kappa, nu=nu, zita=zita, pack=pack):
+                ops.memorize(x, v, masks, kappa, nu, zita, T, tau, pack=pack, prior_packed=True, bank=1)
+                ops.match_packed(x, pack, L, topl, tau)
             for _ in range(2):
                 fn()
             st.synchronize()
