@@ -21,9 +21,9 @@
 //                and tile.  204 blocks at config B (P = 1620, N = 2) instead of the 102 a 32-pixel tile gives.
 //   em_mstep   : S = X^T . z over a CHUNK of pixels (split-P): block = (object-class, 32 bases) x (128 rows of X) x chunk,
 //                8 waves = 4 row tiles x 2 halves of the chunk, v_mfma_f32_32x32x2_f32.  X = x (key bases) or v[n]
-//                (value bases, last iteration only: both in ONE launch).  Operands are fetched by raw buffer loads whose
-//                pixel offset travels in the scalar offset (no vector arithmetic in the loop; pixels >= P read as zeros by
-//                the buffer's range check), all issued up front.  Partial sums go to Spart[chunk][nk][row][L]; the column
+//                (value bases, last iteration only: both in ONE launch).  Operands are fetched by raw buffer loads
+//                (pixels >= P read as zeros by the buffer's range check on the vector offset: no masks), issued ahead of
+//                the MFMA chain.  Partial sums go to Spart[chunk][nk][row][L]; the column
 //                sums of z (zita's increment) ride along.
 //   em_finalize: fixed-order sum over the chunks (deterministic), prior blend (zita_*prev + S)/zita, and for the key
 //                bases the l2-normalised kn the next E/W step reads (block = 32 bases x all C rows: norms are block-local).
@@ -31,9 +31,34 @@
 #include "../../include/swem_hip_train.h"
 #include "common.h"
 
+// Debug build only (-DSWEM_EM_STAMPS): in-kernel clock stamps of block 0 / wave 0, written to a buffer set by
+// swem_debug_set_stamps (tools/em_stamps.py).  The product build contains none of it.
+#ifdef SWEM_EM_STAMPS
+static long long *g_stamps = nullptr;
+static int g_slot = 0;
+extern "C" void swem_debug_set_stamps(void *p) {
+  g_stamps = static_cast<long long *>(p);
+  g_slot = 0;
+}
+#define STAMP_ARG , long long *stamps
+#define STAMP_PASS , (g_stamps ? g_stamps + 16 * (g_slot++) : nullptr)
+#define STAMP(i)                                                                                       \
+  do {                                                                                                 \
+    if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {         \
+      stamps[2 * (i)] = (long long)__builtin_amdgcn_s_memtime();                                       \
+      stamps[2 * (i) + 1] = (long long)__builtin_amdgcn_s_memrealtime();                               \
+    }                                                                                                  \
+  } while (0)
+#else
+#define STAMP_ARG
+#define STAMP_PASS
+#define STAMP(i)
+#endif
+
 namespace {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -80,8 +105,9 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
                                                       int kn_rows, int kn_off, const float *__restrict__ masks,
                                                       const float *__restrict__ w_in, float *__restrict__ w_out,
                                                       float *__restrict__ z, int P, int Pz, float tau, int do_w,
-                                                      int do_e) {
+                                                      int do_e STAMP_ARG) {
   constexpr int C = 16 * CM, L = 64 * LT;
+  STAMP(0);
   __shared__ float red[3][8][16];  // per-wave maxima / W exp-sums / E exp-sums per pixel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -91,15 +117,29 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
   const bool pin = p < P;
   // base rows of this wave: [q*16*LT, (q+1)*16*LT) of class cls; lane (li, g) loads row li of every tile, chunk 4m + g
   const float *kb = kn + (((long long)nk * (C / 4) + g) * kn_rows + kn_off + q * 16 * LT + li) * 4;
+  // issue order = arrival order (vmcnt counts in order): the pixel's key first, then the base rows chunk by chunk, so the
+  // MFMAs of chunk m wait for chunk m only and the rest of the 256 KB streams in behind them
+  // (buffer loads: pad pixels p >= P read as zeros by the range check -- no select in front of the MFMAs)
+  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, P * C * 4, 0x00020000);
+  float4 xf[CM];
+#pragma unroll
+  for (int m = 0; m < CM; ++m) {
+    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)((p * C + 16 * m + 4 * g) * 4), 0, 0);
+    xf[m] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+  }
+  // the pixel's mask (W step) or incoming weight, needed only in the epilogue: fetched now, behind nothing
+  __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>((do_w ? masks : w_in) + (long long)nk * P), 0, P * 4, 0x00020000);
+  const float mk = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, (unsigned)(p * 4), 0, 0));
   float4 a[CM][LT];
 #pragma unroll
   for (int m = 0; m < CM; ++m)
 #pragma unroll
     for (int t = 0; t < LT; ++t) a[m][t] = ld4(kb + ((long long)4 * m * kn_rows + 16 * t) * 4);
-  float4 xf[CM];
-#pragma unroll
-  for (int m = 0; m < CM; ++m)
-    xf[m] = pin ? ld4(x + (long long)p * C + 16 * m + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // keep every load above the MFMA chain: left alone, the scheduler sinks each load to just before its use to save
+  // registers and the wave then pays one L2 round trip per chunk (seen in the ISA: vmcnt(1) in front of every MFMA group)
+  __builtin_amdgcn_sched_barrier(0);
+  STAMP(1);
   float ss = 0.f;
 #pragma unroll
   for (int m = 0; m < CM; ++m) ss += (xf[m].x * xf[m].x + xf[m].y * xf[m].y) + (xf[m].z * xf[m].z + xf[m].w * xf[m].w);
@@ -132,7 +172,9 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
   ml = fmaxf(ml, __shfl_xor(ml, 16));
   ml = fmaxf(ml, __shfl_xor(ml, 32));
   if (g == 0) red[0][wave][li] = ml;
+  STAMP(2);
   __syncthreads();
+  STAMP(3);
   const float m_bg = fmaxf(fmaxf(red[0][0][li], red[0][1][li]), fmaxf(red[0][2][li], red[0][3][li]));
   const float m_fg = fmaxf(fmaxf(red[0][4][li], red[0][5][li]), fmaxf(red[0][6][li], red[0][7][li]));
   const float k2 = SWEM_LOG2E / tau;
@@ -165,17 +207,18 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
     se += __shfl_xor(se, 32);
     if (g == 0) red[2][wave][li] = se;
   }
+  STAMP(4);
   __syncthreads();
+  STAMP(5);
   float wgt;
   if (do_w) {
     const float s_bg = (red[1][0][li] + red[1][1][li]) + (red[1][2][li] + red[1][3][li]);
     const float s_fg = (red[1][4][li] + red[1][5][li]) + (red[1][6][li] + red[1][7][li]);
     const float prop = (cls ? s_fg : s_bg) / (s_bg + s_fg);
-    const float mk = pin ? masks[(long long)nk * P + p] : 0.f;
     wgt = mk * (1.f - prop);  // 1 - p literally, as the reference
     if (w_out && q == 0 && g == 0 && pin) w_out[(long long)nk * P + p] = wgt;
   } else {
-    wgt = pin ? w_in[(long long)nk * P + p] : 0.f;
+    wgt = mk;
   }
   if (!do_e) return;
   const float se = (red[2][4 * cls][li] + red[2][4 * cls + 1][li]) + (red[2][4 * cls + 2][li] + red[2][4 * cls + 3][li]);
@@ -185,6 +228,11 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
   for (int t = 0; t < LT; ++t)
     *reinterpret_cast<float4 *>(dst + 16 * t) =
         make_float4(acc[t][0] * zscale, acc[t][1] * zscale, acc[t][2] * zscale, acc[t][3] * zscale);
+  STAMP(6);
+#ifdef SWEM_EM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(7);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------- M step (split-P)
@@ -199,7 +247,8 @@ struct MStepP {
 
 // Block = (nk, 32 bases) x (128 rows of the row space) x chunk of 4*STEPS pixels; wave = (row tile ct, chunk half kh).
 template <int STEPS>
-__global__ __launch_bounds__(512) void em_mstep_kernel(MStepP p) {
+__global__ __launch_bounds__(512) void em_mstep_kernel(MStepP p STAMP_ARG) {
+  STAMP(0);
   __shared__ float red[4][16][64];
   __shared__ float zred[2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -220,37 +269,50 @@ __global__ __launch_bounds__(512) void em_mstep_kernel(MStepP p) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, (int)((long long)p.P * stride * 4), 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(p.z + (long long)n * p.Pz * 2 * p.L), 0, (int)((long long)p.P * 2 * p.L * 4), 0x00020000);
-  const unsigned va = (unsigned)((kk * stride + col + i) * 4);
-  const unsigned vb = (unsigned)((kk * 2 * p.L + cls * p.L + l0 + i) * 4);
+  // the pixel offset travels in the VECTOR offset: the hardware range-checks voffset + immediate against num_records (the
+  // scalar offset is added after the check), so pixels >= P come back as zeros without touching memory
+  const unsigned va = (unsigned)(((pw0 + kk) * stride + col + i) * 4);
+  const unsigned vb = (unsigned)(((pw0 + kk) * 2 * p.L + cls * p.L + l0 + i) * 4);
   const unsigned sa = (unsigned)stride * 8u, sb = (unsigned)p.L * 16u;  // bytes per step (two pixels)
   float av[STEPS], bv[STEPS];
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
-    av[s] = __builtin_amdgcn_raw_buffer_load_b32(ra, va, (unsigned)(pw0 + 2 * s) * (sa / 2), 0);
-    bv[s] = __builtin_amdgcn_raw_buffer_load_b32(rb, vb, (unsigned)(pw0 + 2 * s) * (sb / 2), 0);
+    av[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, va + s * sa, 0, 0));
+    bv[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, vb + s * sb, 0, 0));
   }
+  __builtin_amdgcn_sched_barrier(0);  // all loads in flight before the MFMA chain (see em_ew16_kernel)
+  STAMP(1);
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  float zs = 0.f;
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    acc = mfma32(av[s], bv[s], acc);
-    zs += bv[s];
-  }
+  for (int s = 0; s < STEPS; ++s) acc = mfma32(av[s], bv[s], acc);
+  // the column sums of z after the MFMA chain (in front of it the adds wait for the LAST load and the chain with them)
+  // (the empty asm makes the sum's start depend on the accumulator: instruction selection otherwise emits the adds first)
+  float zs = 0.f;
+  asm volatile("" : "+v"(zs) : "v"(acc[0]));
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) zs += bv[s];
   zs += __shfl_xor(zs, 32);
   if (kh == 1) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[ct][e][lane] = acc[e];
   }
   if (ct == 0 && lane < 32) zred[kh][lane] = zs;
+  STAMP(2);
   __syncthreads();
+  STAMP(3);
   if (kh == 1) return;
   float *dst = p.Spart + (((long long)chunk * p.NK + nk) * p.Rtot + row0 + 32 * ct) * p.L + l0 + i;
 #pragma unroll
   for (int e = 0; e < 16; ++e) dst[(long long)acc_row(e, kk) * p.L] = acc[e] + red[ct][e][lane];
   if (ct == 0 && lane < 32 && blockIdx.y == 0)
     p.zpart[((long long)chunk * p.NK + nk) * p.L + l0 + lane] = zred[0][lane] + zred[1][lane];
+  STAMP(4);
+#ifdef SWEM_EM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(5);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------- finalize
@@ -266,53 +328,71 @@ struct FinP {
 };
 
 // Block = (32 bases, nk, 128-row group of the row space); 1024 threads = 32 bases x 32 row lanes.
-__global__ __launch_bounds__(1024) void em_finalize_kernel(FinP p) {
+constexpr int FIN_CH = 8;  // chunk partials fetched together (config B: all 8)
+__global__ __launch_bounds__(1024) void em_finalize_kernel(FinP p STAMP_ARG) {
+  STAMP(0);
   __shared__ float tile[128 * 33];
   __shared__ float part[8][32];
-  __shared__ float zl[32], nrm[32];
+  __shared__ float nrm[32];
   const int nk = blockIdx.y, l0 = blockIdx.x * 32;
   const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int row0 = blockIdx.z * 128;
   const bool key = row0 < p.Ck;
-  if (threadIdx.x < 32) {
-    float zv;
-    if (p.zita_in) {
-      zv = p.zita_in[(long long)nk * p.L + l0 + l];
-    } else {
-      float s = 0.f;
-      for (int ch = 0; ch < p.nch; ++ch) s += p.zpart[((long long)ch * p.NK + nk) * p.L + l0 + l];
-      zv = p.zita_prev[(long long)nk * p.L + l0 + l] + s;
-    }
-    zl[l] = zv;
-    if (p.zita_out && blockIdx.z == 0) p.zita_out[(long long)nk * p.L + l0 + l] = zv;
-  }
-  __syncthreads();
-  const float zp = p.zita_prev[(long long)nk * p.L + l0 + l], zt = zl[l];
+  const float zp = p.zita_prev[(long long)nk * p.L + l0 + l];
   const int R = key ? p.C : p.V;
   const int rbase = key ? row0 : row0 - p.Ck;
   const float *prev = key ? p.kappa_prev : p.nu_prev;
   float *out = key ? p.kappa_out : p.nu_out;
   const int n = nk >> 1, cls = nk & 1;
+  float pv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    pv[q] = rbase + g + 32 * q < R ? prev[((long long)nk * R + rbase + g + 32 * q) * p.L + l0 + l] : 0.f;
+  // ONE round trip for everything this thread reads: the prior above, and per chunk the column-sum partial of its base
+  // (every thread sums zita itself -- the same addresses in all 32 row lanes, cache hits -- instead of a first phase behind
+  // a barrier) and the S partials of its four rows.  Every load of a chunk group is in flight before the first add (a
+  // dependent chain of L2 / Infinity-Cache round trips was most of this kernel's time); sums run in chunk order.
+  const long long cs = (long long)p.NK * p.Rtot * p.L;
+  float sums[4] = {0.f, 0.f, 0.f, 0.f}, zsum = 0.f;
+  for (int c0 = 0; c0 < p.nch; c0 += FIN_CH) {
+    float t[4][FIN_CH], tz[FIN_CH];
+#pragma unroll
+    for (int ch = 0; ch < FIN_CH; ++ch)
+      tz[ch] = (c0 + ch < p.nch && !p.zita_in) ? p.zpart[((long long)(c0 + ch) * p.NK + nk) * p.L + l0 + l] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float *sp = p.Spart + ((long long)nk * p.Rtot + row0 + g + 32 * q) * p.L + l0 + l;
+#pragma unroll
+      for (int ch = 0; ch < FIN_CH; ++ch) t[q][ch] = (c0 + ch < p.nch && rbase + g + 32 * q < R) ? sp[(c0 + ch) * cs] : 0.f;
+    }
+#pragma unroll
+    for (int ch = 0; ch < FIN_CH; ++ch) zsum += tz[ch];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int ch = 0; ch < FIN_CH; ++ch) sums[q] += t[q][ch];
+  }
+  STAMP(1);
+  const float zt = p.zita_in ? p.zita_in[(long long)nk * p.L + l0 + l] : zp + zsum;
+  if (p.zita_out && blockIdx.z == 0 && g == 0) p.zita_out[(long long)nk * p.L + l0 + l] = zt;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int rr = g + 32 * q;
     const int row = rbase + rr;
     float v = 0.f;
     if (row < R) {
-      float s = 0.f;
-      const float *sp = p.Spart + ((long long)nk * p.Rtot + row0 + rr) * p.L + l0 + l;
-      const long long cs = (long long)p.NK * p.Rtot * p.L;
-      for (int ch = 0; ch < p.nch; ++ch) s += sp[ch * cs];
       const long long o = ((long long)nk * R + row) * p.L + l0 + l;
-      v = (zp * prev[o] + s) / zt;
+      v = (zp * pv[q] + sums[q]) / zt;
       out[o] = v;
       if (!key && p.mvp_out)
         p.mvp_out[((long long)n * p.V + row) * (2 * p.mvp_lm) + cls * p.mvp_lm + p.mvp_off + l0 + l] = v;
     }
     if (key) tile[rr * 33 + l] = v;
   }
+  STAMP(2);
   if (!key || !p.kn_out) return;
   __syncthreads();
+  STAMP(3);
   if (g < 8) {  // column norms from the tile, in the association of em_norm_bases_kernel (bit-identical kn)
     float ss = 0.f;
     for (int c = g; c < p.C; c += 8) {
@@ -332,6 +412,11 @@ __global__ __launch_bounds__(1024) void em_finalize_kernel(FinP p) {
     const int e = idx & 3, ll = (idx >> 2) & 31, c4 = idx >> 7;
     p.kn_out[(((long long)nk * (p.C / 4) + c4) * p.kn_rows + p.kn_off + l0 + ll) * 4 + e] = tile[(c4 * 4 + e) * 33 + ll] / nrm[ll];
   }
+  STAMP(4);
+#ifdef SWEM_EM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(5);
+#endif
 }
 
 struct MWs {
@@ -389,7 +474,7 @@ int ew_launch(void *stream, const float *x, const float *kn, int kn_rows, int kn
   dim3 grid(cdiv(P, 16), N);
 #define EW(LT_, CM_)                                                                                                  \
   hipLaunchKernelGGL((em_ew16_kernel<LT_, CM_>), grid, dim3(512), 0, ST, x, kn, kn_rows, kn_off, masks, w_in, w_out, z, \
-                     P, Pz, tau, do_w, do_e)
+                     P, Pz, tau, do_w, do_e STAMP_PASS)
   if (C == 128) {
     if (L == 64) EW(1, 8);
     else if (L == 128) EW(2, 8);
@@ -433,8 +518,8 @@ int mstep_impl(void *stream, const float *x, const float *v, const float *z, con
   mp.zpart = reinterpret_cast<float *>(ws + w.zpart);
   mp.Ck = Ck, mp.C = C, mp.V = V, mp.P = P, mp.Pz = swem_em_pad(P), mp.L = L, mp.NK = NK, mp.Rtot = Rtot;
   dim3 grid(NK * (L / 32), Rtot / 128, w.nch);
-  if (w.steps == 52) hipLaunchKernelGGL((em_mstep_kernel<52>), grid, dim3(512), 0, ST, mp);
-  else hipLaunchKernelGGL((em_mstep_kernel<26>), grid, dim3(512), 0, ST, mp);
+  if (w.steps == 52) hipLaunchKernelGGL((em_mstep_kernel<52>), grid, dim3(512), 0, ST, mp STAMP_PASS);
+  else hipLaunchKernelGGL((em_mstep_kernel<26>), grid, dim3(512), 0, ST, mp STAMP_PASS);
   SWEM_CHECK_LAUNCH("em_mstep");
   FinP fp;
   fp.Spart = mp.Spart, fp.zpart = mp.zpart;
@@ -443,7 +528,7 @@ int mstep_impl(void *stream, const float *x, const float *v, const float *z, con
   fp.kn_out = kn_out, fp.mvp_out = mvp_out;
   fp.kn_rows = kn_rows, fp.kn_off = kn_off, fp.mvp_lm = mvp_lm, fp.mvp_off = mvp_off;
   fp.Ck = Ck, fp.C = C, fp.V = V, fp.L = L, fp.NK = NK, fp.Rtot = Rtot, fp.nch = w.nch;
-  hipLaunchKernelGGL(em_finalize_kernel, dim3(L / 32, NK, Rtot / 128), dim3(1024), 0, ST, fp);
+  hipLaunchKernelGGL(em_finalize_kernel, dim3(L / 32, NK, Rtot / 128), dim3(1024), 0, ST, fp STAMP_PASS);
   SWEM_CHECK_LAUNCH("em_finalize");
   return SWEM_OK;
 }

@@ -174,6 +174,112 @@ __global__ __launch_bounds__(64 * NW) void match_affinity_kernel(const float *__
   }
 }
 
+// K1 on 16-pixel tiles (the shape of em.hip's E/W kernel): block = (object, 16-pixel tile), 8 waves; wave w owns the
+// 16*TW bases [w*16*TW, +16*TW) of the concatenated bank order (class w / 4).  v_mfma_f32_16x16x4_f32 with the base rows as
+// A and the pixels as B: the pixel is on the lane, four bases of a tile in the accumulator registers.  The query pixel's
+// key stays in registers (normalised there: modules.py:282); every base row is loaded once per block, all loads of a pass
+// issued before its MFMAs.  Twice the blocks of the 32-pixel kernel (204 at config B) and half the MFMA chain per wave.
+typedef unsigned u32x4m __attribute__((ext_vector_type(4)));
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+template <int TW, int CM>  // TW 16-base tiles per wave (Ltot = 128 * TW), C = 16 * CM
+__global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__restrict__ qk, const float *__restrict__ mkn,
+                                                               float *__restrict__ pT, int P, int Pm, float tau) {
+  constexpr int C = 16 * CM, Ltot = 128 * TW, Lm = Ltot / 2;
+  constexpr int TP = TW > 4 ? 4 : TW, NPASS = TW / TP;   // tiles per pass: at most 4 (32 x 16 bytes of base rows in flight)
+  __shared__ float red[2][8][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int n = blockIdx.y, p = blockIdx.x * 16 + li;
+  const int cls = wave >> 2, wq = wave & 3;
+  __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(qk), 0, P * C * 4, 0x00020000);
+  float4 xf[CM];
+#pragma unroll
+  for (int m = 0; m < CM; ++m) {
+    u32x4m t = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)((p * C + 16 * m + 4 * g) * 4), 0, 0);
+    xf[m] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+  }
+  const float *kb = mkn + (((long long)(2 * n + cls) * (C / 4) + g) * Lm + wq * 16 * TW + li) * 4;
+  float4 a[CM][TP];
+#pragma unroll
+  for (int m = 0; m < CM; ++m)
+#pragma unroll
+    for (int t = 0; t < TP; ++t) a[m][t] = ld4(kb + ((long long)4 * m * Lm + 16 * t) * 4);
+  __builtin_amdgcn_sched_barrier(0);   // every load above the MFMA chain (em.hip, em_ew16_kernel)
+  // l2norm of the query pixel (modules.py:282): q / (|q| + eps), on the registers
+  float ss = 0.f;
+#pragma unroll
+  for (int m = 0; m < CM; ++m) ss += (xf[m].x * xf[m].x + xf[m].y * xf[m].y) + (xf[m].z * xf[m].z + xf[m].w * xf[m].w);
+  ss += __shfl_xor(ss, 16);
+  ss += __shfl_xor(ss, 32);
+  const float den = sqrtf(ss) + SWEM_L2_EPS;
+#pragma unroll
+  for (int m = 0; m < CM; ++m) {
+    xf[m].x /= den;
+    xf[m].y /= den;
+    xf[m].z /= den;
+    xf[m].w /= den;
+  }
+  f32x4m acc[TW];
+#pragma unroll
+  for (int t = 0; t < TW; ++t) acc[t] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+    for (int m = 0; m < CM; ++m) {
+#pragma unroll
+      for (int t = 0; t < TP; ++t)
+        acc[ps * TP + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][t].x, xf[m].x, acc[ps * TP + t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TP; ++t)
+        acc[ps * TP + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][t].y, xf[m].y, acc[ps * TP + t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TP; ++t)
+        acc[ps * TP + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][t].z, xf[m].z, acc[ps * TP + t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TP; ++t)
+        acc[ps * TP + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][t].w, xf[m].w, acc[ps * TP + t], 0, 0, 0);
+      if (ps + 1 < NPASS) {   // the next pass's rows of this chunk take the registers just consumed
+#pragma unroll
+        for (int t = 0; t < TP; ++t) a[m][t] = ld4(kb + ((long long)4 * m * Lm + 16 * ((ps + 1) * TP + t)) * 4);
+      }
+    }
+  }
+  // joint {bg, fg} softmax over all Ltot bases (modules.py:248-250, 265-266)
+  float ml = -__builtin_huge_valf();
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ml = fmaxf(ml, acc[t][e]);
+  ml = fmaxf(ml, __shfl_xor(ml, 16));
+  ml = fmaxf(ml, __shfl_xor(ml, 32));
+  if (g == 0) red[0][wave][li] = ml;
+  __syncthreads();
+  float mx = red[0][0][li];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) mx = fmaxf(mx, red[0][q][li]);
+  const float k2 = SWEM_LOG2E / tau;
+  float se = 0.f;
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = exp_scaled(acc[t][e] - mx, k2);
+      acc[t][e] = v;
+      se += v;
+    }
+  se += __shfl_xor(se, 16);
+  se += __shfl_xor(se, 32);
+  if (g == 0) red[1][wave][li] = se;
+  __syncthreads();
+  const float esum = ((red[1][0][li] + red[1][1][li]) + (red[1][2][li] + red[1][3][li])) +
+                     ((red[1][4][li] + red[1][5][li]) + (red[1][6][li] + red[1][7][li]));
+  const float inv = p < P ? 1.0f / esum : 0.f;   // rows of pad pixels are written as zeros
+  float *dst = pT + ((long long)n * Pm + p) * Ltot + wave * 16 * TW + 4 * g;
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+    *reinterpret_cast<float4 *>(dst + 16 * t) = make_float4(acc[t][0] * inv, acc[t][1] * inv, acc[t][2] * inv, acc[t][3] * inv);
+}
+
 // K3: top-l prefix features (modules.py:198-208).  One wave per (object, pixel): the Lm probabilities of each class are
 // sorted across the wave (bitonic network on J registers per lane + pairwise top-64 merges), a wave scan gives the
 // prefix sums and feat = c_bg / (c_bg + c_fg) (invariant to the common 1/sum factor of the row).
@@ -218,6 +324,33 @@ __global__ __launch_bounds__(256) void match_topl_kernel(const float *__restrict
 // (there are only Pm/32 x N blocks, so a block's latency is the kernel's time)
 static int launch_affinity(hipStream_t st, const float *qk, const float *mkn, float *pT, int N, int C, int P, int Pm, int Lm,
                            float tau) {
+  if (C == 128 || C == 64) {
+    // the grid covers all Pm rows of pT: the readout GEMM's last row tile reads rows [P, Pm), which pad tiles write as zeros
+    dim3 grid16(Pm / 16, N);
+#define AFF16(TW_, CM_)                                                                                              \
+  hipLaunchKernelGGL((match_affinity16_kernel<TW_, CM_>), grid16, dim3(512), 0, st, qk, mkn, pT, P, Pm, tau)
+    if (C == 128) {
+      if (Lm == 64) AFF16(1, 8);
+      else if (Lm == 128) AFF16(2, 8);
+      else if (Lm == 256) AFF16(4, 8);
+      else if (Lm == 512) AFF16(8, 8);
+      else {
+        swem_set_error("match: bases per class must be 64, 128, 256 or 512 (got %d)", Lm);
+        return SWEM_E_SHAPE;
+      }
+    } else {
+      if (Lm == 64) AFF16(1, 4);
+      else if (Lm == 128) AFF16(2, 4);
+      else if (Lm == 256) AFF16(4, 4);
+      else if (Lm == 512) AFF16(8, 4);
+      else {
+        swem_set_error("match: bases per class must be 64, 128, 256 or 512 (got %d)", Lm);
+        return SWEM_E_SHAPE;
+      }
+    }
+#undef AFF16
+    return SWEM_OK;
+  }
   dim3 grid(Pm / 32, N);
 #define AFF(J_, NW_)                                                                                          \
   hipLaunchKernelGGL((match_affinity_kernel<J_, NW_>), grid, dim3(64 * NW_),                                   \

@@ -172,9 +172,9 @@ class FrameGraph:
             self.pack = core.repack()
             # capture on a stream of this graph's own: scratch buffers are per stream (ops.workspace), and graphs that are
             # replayed concurrently must not share one (torch's default capture stream is one object for all captures)
-            # (their scratch is allocated inside the capture and owned by the graph: ops.private_workspaces)
+            # (scratch requested while capturing is allocated inside the capture and owned by the graph: ops.workspace)
             self.capture_stream = self.streams[1]
-            with ops.private_workspaces(), torch.cuda.graph(self.graph, stream=self.capture_stream):
+            with torch.cuda.graph(self.graph, stream=self.capture_stream):
                 self.pred = frame_step(self.model, self.frame, self.out_size)
                 new = core.memories['update'].bases
                 for k in self.state:

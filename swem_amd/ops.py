@@ -37,20 +37,7 @@ def new_stream():
     """A HIP stream of its own.  torch.cuda.Stream() hands out 32 pooled streams round robin, so the 33rd request is the
     first stream again; scratch buffers are keyed by stream (workspace()) and captured graphs own theirs, so an aliased
     stream would let two concurrent users share one.  hipStreamCreateWithFlags + ExternalStream has no such limit."""
-    global _hip
-    if _hip is None:
-        path = 'libamdhip64.so'
-        try:                                          # the very runtime instance torch itself has mapped
-            with open('/proc/self/maps') as f:
-                for line in f:
-                    if 'libamdhip64' in line:
-                        path = line.split()[-1]
-                        break
-        except OSError:
-            pass
-        _hip = C.CDLL(path)
-        _hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
-        _hip.hipStreamCreateWithFlags.restype = C.c_int
+    _hip_runtime()
     h = C.c_void_p()
     torch.cuda.current_device()                      # the HIP context of the current device exists
     rc = _hip.hipStreamCreateWithFlags(C.byref(h), 1)   # hipStreamNonBlocking
@@ -85,32 +72,57 @@ def _chk(t, name='tensor'):
     return t
 
 
+def _hip_runtime():
+    """The HIP runtime instance torch itself has mapped (ctypes handle)."""
+    global _hip
+    if _hip is None:
+        path = 'libamdhip64.so'
+        try:
+            with open('/proc/self/maps') as f:
+                for line in f:
+                    if 'libamdhip64' in line:
+                        path = line.split()[-1]
+                        break
+        except OSError:
+            pass
+        _hip = C.CDLL(path)
+        _hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        _hip.hipStreamCreateWithFlags.restype = C.c_int
+        _hip.hipStreamGetCaptureInfo.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]
+        _hip.hipStreamGetCaptureInfo.restype = C.c_int
+    return _hip
+
+
+def _capture_id(stream_ptr):
+    """Id of the graph capture the stream is recording into, or None."""
+    status, cid = C.c_int(0), C.c_ulonglong(0)
+    rc = _hip_runtime().hipStreamGetCaptureInfo(C.c_void_p(stream_ptr), C.byref(status), C.byref(cid))
+    return cid.value if rc == 0 and status.value == 1 else None       # hipStreamCaptureStatusActive
+
+
+_ws_capture = {}     # (capture id, device, stream) -> buffer allocated INSIDE that capture
+
+
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream): the library never allocates, and sequences that run
-    concurrently on different streams must not share scratch."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream().cuda_stream)
-    buf = _ws.get(key)
+    concurrently on different streams must not share scratch.  While the stream is being captured into a HIP graph the
+    buffer is allocated inside that capture (one per capture, device and stream): it then belongs to the graph's private
+    pool and lives exactly as long as the graph.  A captured launch never sees a buffer of the eager cache (a later, larger
+    eager request on that stream replaces and frees it) nor one of an earlier capture (its graph may be gone)."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    st = torch.cuda.current_stream().cuda_stream
+    cid = _capture_id(st)
+    if cid is None:
+        cache, key = _ws, (dev, st)
+    else:
+        cache, key = _ws_capture, (cid, dev, st)
+        if _ws_capture and next(iter(_ws_capture))[0] != cid:
+            _ws_capture.clear()                # a new capture: the previous one's buffers stay with their graph
+    buf = cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _ws[key] = buf
+        cache[key] = buf
     return buf
-
-
-class private_workspaces:
-    """Scope for a HIP-graph capture: scratch buffers requested inside are allocated INSIDE the capture (so they belong to
-    the graph's private pool and live exactly as long as the graph), never taken from -- or left in -- the grow-only
-    per-stream cache.  Without it a graph captured on a stream that had already run eagerly holds a raw pointer to a cached
-    buffer, which a later, larger eager request on that stream replaces and frees under the graph."""
-
-    def __enter__(self):
-        self.saved = dict(_ws)
-        _ws.clear()
-        return self
-
-    def __exit__(self, *a):
-        _ws.clear()
-        _ws.update(self.saved)
 
 
 class ConvPack:

@@ -369,10 +369,10 @@ class SWEMTrainer:
         torch.cuda.synchronize()
         ls = self._lanes(self.buf['frames'].shape[0])
         main = torch.cuda.current_stream()
-        # scratch buffers of the captured launches are allocated inside the captures (ops.private_workspaces): the eager
-        # warm-up steps left cached workspaces on these very streams, and a graph must not point into a cache entry that a
-        # later, larger eager request (e.g. 480p validation between steps) replaces
-        with self._math(), ops.private_workspaces():
+        # (scratch buffers of the captured launches are allocated inside the captures, ops.workspace: the eager warm-up
+        # steps left cached workspaces on these very streams, and a graph must not point into a cache entry that a later,
+        # larger eager request -- e.g. 480p validation between steps -- replaces)
+        with self._math():
             g_pre = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_pre):
                 self._pre()

@@ -31,6 +31,7 @@ def timeit(fn, reps=50):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--objects', type=int, default=2)
+    ap.add_argument('--autotune', action='store_true', help='let the on-device tuner pick the readout GEMM plan first')
     a = ap.parse_args()
     dev = 'cuda:0'
     N, P, C, V, L, T, tau, topl = a.objects, 1620, 128, 512, 256, 5, 0.05, 64
@@ -47,6 +48,11 @@ def main():
     pack = ops.new_pack(N, C, V, L, dev)
     ops.pack_bank(kappa, nu, pack, 0)
     ops.pack_bank(kappa, nu, pack, 1)
+    if a.autotune:
+        ops.AUTOTUNE = True
+        ops.match_packed(x, pack, L, topl, tau)
+        ops.AUTOTUNE = False
+        print('tuned readout plans:', {k: hex(v) for k, v in ops._MATCH_PLANS.items()})
     rows = [
         ('em_norm_bases', lambda: ops.em_norm_bases(kappa.view(2 * N, C, L)), 0),
         ('em_ew (W+E)', lambda: ops.em_ew(x, kn, masks.view(2 * N, P), masks.view(2 * N, P), tau, True, True), 2 * fl_e),
@@ -79,7 +85,7 @@ def concurrent(n_streams, objects=2, reps=30, prio=False):
     runs: bench.py --seqs): aggregate algorithmic TFLOP/s of the EM/matching phase when the GPU is shared."""
     dev = 'cuda:0'
     N, P, C, V, L, T, tau, topl = objects, 1620, 128, 512, 256, 5, 0.05, 64
-    graphs, streams = [], []
+    graphs, streams, keep = [], [], []      # keep: the graphs replay on these tensors
     for si in range(n_streams):
         g = torch.Generator().manual_seed(10 + si)
         x = torch.randn(P, C, generator=g).to(dev)
@@ -88,7 +94,7 @@ def concurrent(n_streams, objects=2, reps=30, prio=False):
         kappa = torch.nn.functional.normalize(torch.randn(N, 2, C, L, generator=g), dim=2).to(dev)
         nu = torch.randn(N, 2, V, L, generator=g).to(dev)
         zita = (torch.rand(N, 2, L, generator=g) * 3 + 0.1).to(dev)
-        st = torch.cuda.Stream(priority=-(si % 2)) if prio else torch.cuda.Stream()
+        st = torch.cuda.Stream(priority=-(si % 2)) if prio else ops.new_stream()
         with torch.cuda.stream(st):
             pack = ops.new_pack(N, C, V, L, dev)
             ops.pack_bank(kappa, nu, pack, 0)
@@ -106,6 +112,7 @@ def concurrent(n_streams, objects=2, reps=30, prio=False):
                     fn()
         graphs.append(gr)
         streams.append(st)
+        keep.append(fn)
     torch.cuda.synchronize()
     import time
     for _ in range(2):
@@ -122,7 +129,5 @@ def concurrent(n_streams, objects=2, reps=30, prio=False):
 
 if __name__ == '__main__':
     main()
-    for ns in (1, 2, 2, 3, 4):
+    for ns in (1, 2, 3, 4):
         concurrent(ns)
-    for ns in (2, 2, 4):
-        concurrent(ns, prio=True)
