@@ -371,7 +371,7 @@ def test_match_backward(lib, L, banks, topl, N):
     # class)'s top-l (+1: the cut) values are equal to fp32 rounding, two correct evaluations order them differently (torch.topk
     # picks one order, the kernel gives tied elements the same rank: include/swem_hip_train.h) and d qk of that PIXEL changes
     # by O(d c_i).  Measure zero in exact arithmetic, but a fixed seed can sit on one: pixels whose sorted affinities come
-    # closer than 2e-5 exponent units (~10 fp32 ulps of the logit) are left out of the comparison.
+    # closer than 5e-6 exponent units (~4 fp32 ulps of the logit) are left out of the comparison.
     Lm = mk.shape[-1]
     with torch.no_grad():
         qn = O.l2norm(q64.detach(), 1).flatten(2)[:, None, None]
@@ -379,8 +379,9 @@ def test_match_backward(lib, L, banks, topl, N):
         srt = aff.sort(dim=3, descending=True)[0]
         kk = min(topl, Lm - 1)
         gap = ((srt[:, :, :, :kk] - srt[:, :, :, 1:kk + 1]) / 0.05).amin(dim=3)                  # 1,N,2,P
-        keep = (gap > 2e-5).all(dim=1).all(dim=1)[0]
-    assert float(keep.float().mean()) > 0.8
+        keep = (gap > 5e-6).all(dim=1).all(dim=1)[0]
+    print('pixels compared: %d of %d' % (int(keep.sum()), P))
+    assert float(keep.float().mean()) > 0.5
     ref64 = ref64[keep]
     scale = float(ref64.abs().max())
     err_cpu = float((qk.grad[0].flatten(1).t().double()[keep] - ref64).abs().max())
