@@ -9,15 +9,16 @@ Workload (BASELINE.json configs[1]): synthetic structured 480x864 clip, ResNet-5
 encoder, K=256 bases, 5 EM iterations, 2 objects, output 480x854, random weights of the reference architecture.
 A "step" is one steady-state frame of the reference's per-sequence loop (swem_evaluator.py:72-97):
 encode_key -> match -> segment -> argmax/one-hot -> bilinear -> encode_value -> memorize, for each of the --seqs
-independent sequences a GPU works on concurrently (default 2, one HIP stream + one HIP graph each: the second
-sequence fills the CUs the first leaves idle in small layers and kernel tails; --seqs 1 = strictly one at a time).  Frames are resident in
+independent sequences a GPU works on concurrently (default 4, one HIP stream + one HIP graph each: the others'
+kernels fill the CUs one sequence leaves idle in small layers and kernel tails; --seqs 1 = strictly one at a time).  Frames are resident in
 HBM before the timed region (the reference also excludes the H2D copy, basic_evaluator.py:157-176).
 Every rank runs its own clip (sequences are independent: weak scaling, no data-path collective);
 value = frames of all ranks / max-over-ranks time.
 
 Extra objects in the JSON line:
-  roofline     -- dominant kernel = the implicit-GEMM conv (fp32 MFMA): useful conv FLOPs of the timed frames
-                  / summed launch durations (HIP events on the launch stream), vs 157.3 TFLOP/s fp32-matrix peak.
+  roofline     -- dominant kernel = the implicit-GEMM conv in bf16x6 mode: useful conv FLOPs / summed launch durations
+                  (HIP events on the launch stream) against ITS pipe's ceiling (dense bf16 MFMA peak / 6 products);
+                  `pipes` has the fp32-MFMA layers against 157.3 TFLOP/s; `whole_frame` prices the timed configuration.
   em_matching  -- the same for the EM/matching kernels (algorithmic FLOPs of SURVEY.md section 8d).
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference's PyTorch path) on the same clip, bounded sample.
 """
@@ -37,6 +38,7 @@ H, W, OUT_HW, N_OBJ = 480, 864, (480, 854), 2
 CFG = dict(BACKBONE='resnet50', NUM_BASES=256, NUM_EM_ITERS=5, SINGLE_OBJ=False, KEYDIM=128, VALDIM=512,
            EM_TAU=0.05, TOPL=64)
 FP32_MATRIX_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+BF16X6_PEAK_TFLOPS = round(2500.0 / 6, 1)  # dense bf16 MFMA peak / six products per fp32 product (bf16x6 conv mode)
 
 
 def algorithmic_flops_per_frame(n):
@@ -83,21 +85,40 @@ class FrameRunner:
         self.graph = evaluator.FrameGraph(self.model, self.frames[:, 1].shape, OUT_HW).capture(self.frames[:, 1])
 
 
-def cpu_baseline(frames, m0, sd, n_frames=3):
-    """The CPU oracle (a port of the reference's PyTorch path) on the same clip: frame 0 + n_frames frames."""
+def cpu_baseline(frames, m0, sd, n_frames=20, warm=2):
+    """The CPU oracle (a port of the reference's PyTorch path) on the same clip: frame 0 and `warm` frames untimed, then
+    the mean over `n_frames` steady-state frames, every host thread torch finds."""
     from oracle import swem_oracle as O
+    import torch.nn.functional as F
     cfg = O.make_cfg(**CFG)
     threads = torch.get_num_threads()
-    fr = frames[:, :n_frames + 1].cpu()
+    fr, m0 = frames.cpu(), m0.cpu()
+    t_clip, (h, w) = fr.shape[1], fr.shape[-2:]
+    model = O.Model(sd, cfg)
     with torch.no_grad():
         torch.manual_seed(0)
+        mk16, _, s16, _, _ = model('encode_key', fr[:, 0])
+        model('init', mk16, model('encode_value', fr[:, 0], F.interpolate(m0, size=(h, w), mode='nearest').float(), s16), m0)
+
+        def frame(i):                     # swem_evaluator.py:72-97, every frame memorised
+            f = fr[:, 1 + i % (t_clip - 1)]
+            qk16, qv16, s16, s8, s4 = model('encode_key', f)
+            context, n = model('match', qk16, qv16)
+            logits, pred_mask = model('segment', n, context, s8, s4, None, OUT_HW)
+            pred = torch.argmax(pred_mask, dim=1, keepdim=True)
+            hard = (pred.expand(-1, n + 1, -1, -1) == torch.arange(n + 1).view(1, -1, 1, 1)).type_as(pred)
+            pm = F.interpolate(pred_mask, size=(h, w), mode='bilinear', align_corners=False)
+            model('memorize', qk16, model('encode_value', f, pm, s16), hard, pm)
+        for i in range(warm):
+            frame(i)
         t0 = time.time()
-        O.evaluate_seq(O.Model(sd, cfg), fr, [m0.cpu()] + [None] * n_frames, OUT_HW)
+        for i in range(n_frames):
+            frame(warm + i)
         dt = time.time() - t0
-    return {'value': round((n_frames + 1) / dt, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
-            'sample': 'oracle/swem_oracle.py evaluate_seq on frame 0 + %d frames of the same 480x864 clip '
-                      '(all frames counted, as basic_evaluator.py:171-176), %d torch CPU threads, %.1f s'
-                      % (n_frames, threads, dt)}
+    return {'value': round(n_frames / dt, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            'sample': 'oracle/swem_oracle.py, the same 480x864 clip: frame 0 + %d warm-up frames untimed, then %d steady-state '
+                      'frames (encode_key, match, segment, encode_value, memorize) in %.1f s on %d torch CPU threads'
+                      % (warm, n_frames, dt, threads)}
 
 
 def main():
@@ -115,6 +136,8 @@ def main():
                     help='independent sequences processed concurrently per GPU, each on its own HIP stream')
     ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
     ap.add_argument('--no-em', action='store_true', help='skip the EM/matching timing legs (profiler runs)')
+    ap.add_argument('--trace-layers', default=None, help='write the per-launch conv list of the eager roofline frames (JSON)')
+    ap.add_argument('--cpu-frames', type=int, default=20, help='timed frames of the CPU baseline (after 2 warm-up frames)')
     ap.add_argument('--max-split', type=int, default=0, help='cap the K-split factors the conv tuner may choose (0 = all)')
     args = ap.parse_args()
 
@@ -239,48 +262,98 @@ def main():
         nprof = min(args.steps, 5)
         runner.graph = None                     # per-launch timing needs eager launches (same kernels, same plans)
         ops.CONV_TRACE = []
+        # (matching's readout GEMM also runs on a conv kernel, launched by the library itself: a marker keeps the launch list
+        # aligned with a rocprofv3 kernel trace, tools/conv_by_layer.py; it is priced in `em_matching`, not here)
+        real_mp = ops.match_packed
+
+        def marked(qk_, pack_, L_, topl_, tau_):
+            ops.CONV_TRACE.append((None, None, 2.0 * pack_[1].shape[0] * qk_.shape[0] * pack_[1].shape[1] * pack_[1].shape[2],
+                                   'matching readout GEMM', 0.0, 0, 'readout'))
+            return real_mp(qk_, pack_, L_, topl_, tau_)
+        ops.match_packed = marked
         for _ in range(nprof):
             runner.step()
         torch.cuda.synchronize()
-        tr, ops.CONV_TRACE = ops.CONV_TRACE, None
-        ms = sum(t_[0].elapsed_time(t_[1]) for t_ in tr)
+        ops.match_packed = real_mp
+        tr_all, ops.CONV_TRACE = ops.CONV_TRACE, None
+        tr = [t_ for t_ in tr_all if t_[0] is not None]
+        if args.trace_layers:                   # per-launch list for tools/conv_by_layer.py (joined with rocprofv3 durations)
+            with open(args.trace_layers, 'w') as f:
+                json.dump({'frames': nprof, 'launches': [{'layer': t_[3], 'flops': t_[2], 'bytes': t_[4], 'plan': t_[5],
+                                                          'pipe': t_[6], 'event_us': None if t_[0] is None else
+                                                          1e3 * t_[0].elapsed_time(t_[1])} for t_ in tr_all]}, f)
         if args.conv_report:
             agg = {}
-            for e0, e1, f, d, _ in tr:
-                a = agg.setdefault(d, [0, 0.0, 0.0])
-                a[0] += 1
-                a[1] += e0.elapsed_time(e1)
-                a[2] += f
-            print('%-34s %5s %9s %9s %8s' % ('conv shape (BxHxW k s cin->ncols)', 'n/frm', 'us/call', 'ms/frame', 'TFLOP/s'),
-                  file=sys.stderr)
-            for d, (c, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                print('%-34s %5.1f %9.1f %9.3f %8.1f' % (d, c / nprof, 1e3 * t / c, t / nprof, f / (t * 1e-3) / 1e12),
+            for t_ in tr:
+                a_ = agg.setdefault((t_[3], t_[6]), [0, 0.0, 0.0])
+                a_[0] += 1
+                a_[1] += t_[0].elapsed_time(t_[1])
+                a_[2] += t_[2]
+            print('%-34s %5s %5s %9s %9s %8s' % ('conv shape (BxHxW k s cin->ncols)', 'pipe', 'n/frm', 'us/call', 'ms/frame',
+                                                 'TFLOP/s'), file=sys.stderr)
+            for (d, pipe), (c, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print('%-34s %5s %5.1f %9.1f %9.3f %8.1f' % (d, pipe, c / nprof, 1e3 * t / c, t / nprof, f / (t * 1e-3) / 1e12),
                       file=sys.stderr)
-        flops = sum(t_[2] for t_ in tr)
-        alg_bytes = sum(t_[4] for t_ in tr) / len(tr)
-        ach = flops / (ms * 1e-3) / 1e12
-        traffic, tnote = None, ''
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_conv_traffic.json')) as f:
-                tj = json.load(f)
-            traffic = tj['hbm_bytes_per_launch']
-            tnote = ('; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from the separate rocprofv3 --pmc passes in '
-                     'profiles/r01_conv_traffic.json (not re-measured in this run)')
-        except (OSError, KeyError, ValueError):
-            pass
+        # The conv family runs on TWO matrix pipes with different ceilings: layers in bf16x6 mode issue six bf16 MFMA
+        # products per fp32 product (ceiling: dense bf16 peak / 6), the rest run v_mfma_f32_32x32x2_f32.  Each pipe's useful
+        # FLOPs are priced against its own ceiling; `roofline` is the pipe that holds most of the time.
+        pipes = {}
+        for t_ in tr:
+            d = pipes.setdefault(t_[6], {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'n': 0})
+            d['ms'] += t_[0].elapsed_time(t_[1])
+            d['flops'] += t_[2]
+            d['bytes'] += t_[4]
+            d['n'] += 1
+        peaks = {'bf16': BF16X6_PEAK_TFLOPS, 'fp32': FP32_MATRIX_PEAK_TFLOPS}
+        per_pipe = {}
+        for k, d in pipes.items():
+            ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            per_pipe[k] = {'achieved': round(ach, 2), 'peak': peaks[k], 'frac': round(ach / peaks[k], 4),
+                           'launches_per_frame': d['n'] // nprof, 'avg_launch_us': round(1e3 * d['ms'] / d['n'], 2),
+                           'ms_per_frame': round(d['ms'] / nprof, 3), 'gflop_per_launch': round(d['flops'] / d['n'] / 1e9, 3),
+                           'algorithmic_bytes_per_launch': int(d['bytes'] / d['n'])}
+        dom = max(pipes, key=lambda k: pipes[k]['ms'])
+        traffic, tsrc = None, None
+        for name in ('r02_conv_traffic.json', 'r01_conv_traffic.json'):
+            try:
+                with open(os.path.join(ROOT, 'profiles', name)) as f:
+                    traffic, tsrc = json.load(f)['hbm_bytes_per_launch'], 'profiles/' + name
+                break
+            except (OSError, KeyError, ValueError):
+                pass
         out['roofline'] = {
-            'bound': 'mfma', 'kernel': 'implicit-GEMM conv family: conv_igemm_bf3s (bf16x6, pre-split, LDS-DMA) / conv_igemm_pipe (fp32 MFMA) / stems, + operand split and split-K reduce kernels', 'achieved': round(ach, 2),
-            'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
-            'traffic': traffic, 'algorithmic_bytes_per_launch': int(alg_bytes), 'launches_per_frame': len(tr) // nprof,
-            'avg_launch_us': round(1e3 * ms / len(tr), 2), 'gflop_per_launch': round(flops / len(tr) / 1e9, 3),
-            'conv_ms_per_frame': round(ms / nprof, 3),
-            'note': 'useful conv FLOPs (2*M*Cout*KH*KW*Cin, unpadded) of %d frames / summed per-launch HIP-event '
-                    'durations (operand-split and split-K reduce launches included); peak = fp32 matrix rate (the arithmetic is fp32-accurate); '
-                    'layers the tuner runs in bf16x6 mode execute 6 bf16-MFMA products per fp32 product, their own ceiling is 2500/6 = 417 TFLOP/s; algorithmic bytes = every input map once + filters + output in fp32, the measured traffic adds the bf16x3 planes (1.5x an fp32 map, written by the split and read by the conv) and the Infinity-Cache-served halo re-reads that FETCH_SIZE counts' % nprof + tnote,
+            'bound': 'mfma',
+            'kernel': ('conv_igemm_bf3s_kernel: implicit-GEMM conv, bf16x6 arithmetic (exact 3-way bf16 split of both operands, six '
+                       'v_mfma_f32_32x32x16_bf16 products, fp32 accumulate) on pre-split operands moved by LDS-DMA; its operand-split '
+                       'and split-K reduce launches are inside the timed intervals') if dom == 'bf16' else
+                      'conv_igemm_pipe_kernel: implicit-GEMM conv on v_mfma_f32_32x32x2_f32',
+            'achieved': per_pipe[dom]['achieved'], 'peak': per_pipe[dom]['peak'], 'unit': 'TFLOP/s',
+            'frac': per_pipe[dom]['frac'], 'traffic': traffic, 'traffic_source': tsrc,
+            'traffic_note': 'fabric-side bytes per conv launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches, from separate rocprofv3 '
+                            '--pmc passes (tools/pmc_bench_traffic.sh); NOT re-measured by this run',
+            'peak_note': 'bf16 pipe: 2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 product = %.1f useful TFLOP/s; fp32 pipe: '
+                         '%.1f (MI355X_MICROARCH.md)' % (BF16X6_PEAK_TFLOPS, FP32_MATRIX_PEAK_TFLOPS),
+            'pipes': per_pipe,
+            'frac_bf16_pipe': per_pipe.get('bf16', {}).get('frac'), 'frac_fp32_pipe': per_pipe.get('fp32', {}).get('frac'),
+            'conv_ms_per_frame_eager_one_stream': round(sum(d['ms'] for d in pipes.values()) / nprof, 3),
+            'note': 'useful conv FLOPs (2*M*Cout*KH*KW*Cin, unpadded) of %d eager frames of ONE sequence / summed per-launch '
+                    'HIP-event durations on the launch stream; the timed region above is graph replay of %d sequence(s) on %d '
+                    'stream(s), whose kernels overlap -- `whole_frame` prices THAT' % (nprof, nseq, nseq),
             'plans_bf16x6': sum(1 for v in ops._CONV_PLANS.values() if (v >> 16) & 1), 'plans_total': len(ops._CONV_PLANS)}
+        # whole frame of the TIMED configuration against the blended ceiling: every FLOP priced at its pipe's peak
+        conv_fl = {k: d['flops'] / nprof for k, d in pipes.items()}
+        em_fl = em_flops_per_frame(n_obj)
+        t_ideal = sum(conv_fl.get(k, 0.0) / (peaks[k] * 1e12) for k in peaks) + em_fl / (FP32_MATRIX_PEAK_TFLOPS * 1e12)
+        t_frame = max_t / total_frames * world
+        out['whole_frame'] = {'executed_gflop_per_frame': round((sum(conv_fl.values()) + em_fl) / 1e9, 1),
+                              'gflop_bf16_pipe': round(conv_fl.get('bf16', 0.0) / 1e9, 1),
+                              'gflop_fp32_pipe': round((conv_fl.get('fp32', 0.0) + em_fl) / 1e9, 1),
+                              'ms_per_frame_timed': round(1e3 * t_frame, 3), 'ms_per_frame_at_pipe_peaks': round(1e3 * t_ideal, 3),
+                              'frac_of_blended_mfma_ceiling': round(t_ideal / t_frame, 4),
+                              'achieved_tflops': round((sum(conv_fl.values()) + em_fl) / t_frame / 1e12, 1)}
         if args.no_em:
             if not args.no_cpu_baseline and world == 1:
-                out['cpu_baseline'] = cpu_baseline(frames_cpu, m0_cpu, sd)
+                out['cpu_baseline'] = cpu_baseline(frames_cpu, m0_cpu, sd, n_frames=args.cpu_frames)
             print(json.dumps(out))
             if torch.distributed.is_initialized():
                 torch.distributed.destroy_process_group()
@@ -374,7 +447,7 @@ def main():
                           'sequence alone (the same graph on one stream; `eager` = 20 back-to-back eager calls); algorithmic FLOPs '
                           '4PL(C(3T-1)+V) + 4LmP(C+V) per object' % nseq)
         if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only
-            out['cpu_baseline'] = cpu_baseline(frames_cpu, m0_cpu, sd)
+            out['cpu_baseline'] = cpu_baseline(frames_cpu, m0_cpu, sd, n_frames=args.cpu_frames)
     if rank == 0:
         print(json.dumps(out))
     if torch.distributed.is_initialized():

@@ -297,11 +297,13 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     if CONV_TRACE is not None:
         e1.record()
         ncols = pack.cout * (2 if pack.glu else 1)
-        # (events, useful FLOPs, label, algorithmic bytes: every input map once + filters + output, fp32)
         in_bytes = 4.0 * sum(s_.shape[0] * H * W * s_.shape[3] for s_ in srcs)
+        # (events, useful FLOPs, label, algorithmic bytes, plan, pipe: 'bf16' = six bf16-MFMA products per fp32 product on the
+        # pre-split kernel, 'fp32' = v_mfma_f32_32x32x2_f32)
         CONV_TRACE.append((e0, e1, 2.0 * B * Ho * Wo * ncols * pack.kh * pack.kw * pack.cin_true,
                            '%dx%dx%d k%d s%d %d->%d' % (B, H, W, pack.kh, pack.stride, pack.cin_true, ncols),
-                           in_bytes + 4.0 * ncols * pack.kh * pack.kw * pack.cin_true + 4.0 * B * Ho * Wo * pack.cout))
+                           in_bytes + 4.0 * ncols * pack.kh * pack.kw * pack.cin_true + 4.0 * B * Ho * Wo * pack.cout,
+                           plan, 'bf16' if ((plan >> 16) & 3 and (presplit_ok or (plan >> 16) & 3 == 1)) else 'fp32'))
     return y
 
 

@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Joins the per-launch conv list of bench.py (--trace-layers: layer shape, useful FLOPs, pipe, plan, in launch order) with
+the rocprofv3 kernel trace of THE SAME RUN, so that every conv layer's TFLOP/s and the per-pipe roofline fractions can be
+recomputed from profiles/ alone.
+
+    rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 bench.py --steps 6 --warmup 2 --no-graph --seqs 1 \
+        --no-em --no-cpu-baseline --load-plans PLANS --trace-layers OUT/layers.json
+    python tools/conv_by_layer.py OUT/layers.json OUT/*/*_kernel_trace.csv profiles/r02_conv_by_layer.csv
+
+A traced launch = [operand-split kernels] + ONE implicit-GEMM kernel + [split-K reduce kernel].  bench.py's traced frames are
+the last conv launches of the run, so the last len(launches) implicit-GEMM dispatches of the trace are matched in order."""
+import csv
+import json
+import sys
+
+PEAK = {'bf16': 2500.0 / 6, 'fp32': 157.3, 'readout': 157.3}
+
+
+def main(layers_json, trace_csv, out_csv):
+    launches = json.load(open(layers_json))['launches']
+    rows = sorted(csv.DictReader(open(trace_csv)), key=lambda r: int(r['Start_Timestamp']))
+    main_idx = [i for i, r in enumerate(rows) if 'conv_igemm' in r['Kernel_Name']]
+    assert len(main_idx) >= len(launches), (len(main_idx), len(launches))
+    main_idx = main_idx[-len(launches):]
+    dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    agg = {}
+    prev = main_idx[0] - 8
+    for li, (mi, la) in enumerate(zip(main_idx, launches)):
+        t_main, t_split, t_red = dur(rows[mi]), 0.0, 0.0
+        for j in range(max(prev + 1, mi - 6), mi):                # operand splits issued for this launch
+            if 'split_bf16x3' in rows[j]['Kernel_Name']:
+                t_split += dur(rows[j])
+        if mi + 1 < len(rows) and 'conv_splitk_epilogue' in rows[mi + 1]['Kernel_Name']:
+            t_red = dur(rows[mi + 1])
+        prev = mi
+        kname = rows[mi]['Kernel_Name'].split('(')[0].replace('void (anonymous namespace)::', '')
+        a = agg.setdefault((la['layer'], la['pipe'], '%#x' % la['plan'], kname), [0, 0.0, 0.0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += la['flops']
+        a[2] += t_main
+        a[3] += t_split
+        a[4] += t_red
+        a[5] += la['event_us'] or 0.0
+    frames = json.load(open(layers_json))['frames']
+    with open(out_csv, 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['layer (BxHxW k s cin->ncols)', 'pipe', 'plan', 'kernel', 'launches_per_frame', 'gflop_per_launch',
+                    'main_kernel_us', 'operand_split_us', 'splitk_reduce_us', 'total_us', 'hip_event_us', 'tflops_useful',
+                    'pipe_peak_tflops', 'frac_of_pipe_peak', 'ms_per_frame'])
+        tot = {}
+        for (layer, pipe, plan, kname), (n, fl, tm, ts, tr_, te) in sorted(agg.items(), key=lambda kv: -(kv[1][2] + kv[1][3] + kv[1][4])):
+            t = tm + ts + tr_
+            tf = fl / (t * 1e-6) / 1e12
+            w.writerow([layer, pipe, plan, kname, '%.1f' % (n / frames), '%.3f' % (fl / n / 1e9), '%.1f' % (tm / n),
+                        '%.1f' % (ts / n), '%.1f' % (tr_ / n), '%.1f' % (t / n), '%.1f' % (te / n), '%.1f' % tf,
+                        '%.1f' % PEAK[pipe], '%.4f' % (tf / PEAK[pipe]), '%.3f' % (t / frames / 1e3)])
+            d = tot.setdefault(pipe, [0.0, 0.0])
+            d[0] += fl
+            d[1] += t
+        for pipe, (fl, t) in sorted(tot.items()):
+            tf = fl / (t * 1e-6) / 1e12
+            w.writerow(['TOTAL ' + pipe + ' pipe', pipe, '', '', '', '', '', '', '', '', '', '%.1f' % tf, '%.1f' % PEAK[pipe],
+                        '%.4f' % (tf / PEAK[pipe]), '%.3f' % (t / frames / 1e3)])
+            print('%s pipe: %.1f useful TFLOP/s = %.3f of %.1f (%.3f ms per frame, rocprofv3 kernel durations)'
+                  % (pipe, tf, tf / PEAK[pipe], PEAK[pipe], t / frames / 1e3))
+
+
+if __name__ == '__main__':
+    main(*sys.argv[1:4])
