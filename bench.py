@@ -39,6 +39,7 @@ CFG = dict(BACKBONE='resnet50', NUM_BASES=256, NUM_EM_ITERS=5, SINGLE_OBJ=False,
            EM_TAU=0.05, TOPL=64)
 FP32_MATRIX_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 BF16X6_PEAK_TFLOPS = round(2500.0 / 6, 1)  # dense bf16 MFMA peak / six products per fp32 product (bf16x6 conv mode)
+BF16X3_PEAK_TFLOPS = round(2500.0 / 3, 1)  # ... / three products (bf16x3 mode: hi + mid planes)
 
 
 def algorithmic_flops_per_frame(n):
@@ -304,7 +305,7 @@ def main():
             d['flops'] += t_[2]
             d['bytes'] += t_[4]
             d['n'] += 1
-        peaks = {'bf16': BF16X6_PEAK_TFLOPS, 'fp32': FP32_MATRIX_PEAK_TFLOPS}
+        peaks = {'bf16': BF16X6_PEAK_TFLOPS, 'bf16x3': BF16X3_PEAK_TFLOPS, 'fp32': FP32_MATRIX_PEAK_TFLOPS}
         per_pipe = {}
         for k, d in pipes.items():
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
@@ -323,23 +324,27 @@ def main():
                 pass
         out['roofline'] = {
             'bound': 'mfma',
-            'kernel': ('conv_igemm_bf3s_kernel: implicit-GEMM conv, bf16x6 arithmetic (exact 3-way bf16 split of both operands, six '
-                       'v_mfma_f32_32x32x16_bf16 products, fp32 accumulate) on pre-split operands moved by LDS-DMA; its operand-split '
-                       'and split-K reduce launches are inside the timed intervals') if dom == 'bf16' else
+            'kernel': ('conv_igemm_bf3s_kernel: implicit-GEMM conv on pre-split bf16 planes moved by LDS-DMA, %s, fp32 accumulate; '
+                       'its operand-split and split-K reduce launches are inside the timed intervals'
+                       % ('bf16x6 arithmetic (three planes per operand, six v_mfma_f32_32x32x16_bf16 products)' if dom == 'bf16'
+                          else 'bf16x3 arithmetic (hi + mid planes, three bf16 MFMA products)')) if dom != 'fp32' else
                       'conv_igemm_pipe_kernel: implicit-GEMM conv on v_mfma_f32_32x32x2_f32',
             'achieved': per_pipe[dom]['achieved'], 'peak': per_pipe[dom]['peak'], 'unit': 'TFLOP/s',
             'frac': per_pipe[dom]['frac'], 'traffic': traffic, 'traffic_source': tsrc,
             'traffic_note': 'fabric-side bytes per conv launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches, from separate rocprofv3 '
                             '--pmc passes (tools/pmc_bench_traffic.sh); NOT re-measured by this run',
-            'peak_note': 'bf16 pipe: 2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 product = %.1f useful TFLOP/s; fp32 pipe: '
-                         '%.1f (MI355X_MICROARCH.md)' % (BF16X6_PEAK_TFLOPS, FP32_MATRIX_PEAK_TFLOPS),
+            'peak_note': 'bf16 pipes: 2500 TFLOP/s dense bf16 MFMA / products per fp32 product: bf16x6 %.1f, bf16x3 %.1f useful '
+                         'TFLOP/s; fp32 pipe: %.1f (MI355X_MICROARCH.md)' % (BF16X6_PEAK_TFLOPS, BF16X3_PEAK_TFLOPS,
+                                                                             FP32_MATRIX_PEAK_TFLOPS),
             'pipes': per_pipe,
-            'frac_bf16_pipe': per_pipe.get('bf16', {}).get('frac'), 'frac_fp32_pipe': per_pipe.get('fp32', {}).get('frac'),
+            'frac_bf16_pipe': per_pipe.get('bf16', {}).get('frac'), 'frac_bf16x3_pipe': per_pipe.get('bf16x3', {}).get('frac'),
+            'frac_fp32_pipe': per_pipe.get('fp32', {}).get('frac'),
             'conv_ms_per_frame_eager_one_stream': round(sum(d['ms'] for d in pipes.values()) / nprof, 3),
             'note': 'useful conv FLOPs (2*M*Cout*KH*KW*Cin, unpadded) of %d eager frames of ONE sequence / summed per-launch '
                     'HIP-event durations on the launch stream; the timed region above is graph replay of %d sequence(s) on %d '
                     'stream(s), whose kernels overlap -- `whole_frame` prices THAT' % (nprof, nseq, nseq),
-            'plans_bf16x6': sum(1 for v in ops._CONV_PLANS.values() if (v >> 16) & 1), 'plans_total': len(ops._CONV_PLANS)}
+            'plans_bf16x6': sum(1 for v in ops._CONV_PLANS.values() if (v >> 16) & 3 == 1),
+            'plans_bf16x3': sum(1 for v in ops._CONV_PLANS.values() if (v >> 16) & 3 == 3), 'plans_total': len(ops._CONV_PLANS)}
         # whole frame of the TIMED configuration against the blended ceiling: every FLOP priced at its pipe's peak
         conv_fl = {k: d['flops'] / nprof for k, d in pipes.items()}
         em_fl = em_flops_per_frame(n_obj)
@@ -347,6 +352,7 @@ def main():
         t_frame = max_t / total_frames * world
         out['whole_frame'] = {'executed_gflop_per_frame': round((sum(conv_fl.values()) + em_fl) / 1e9, 1),
                               'gflop_bf16_pipe': round(conv_fl.get('bf16', 0.0) / 1e9, 1),
+                              'gflop_bf16x3_pipe': round(conv_fl.get('bf16x3', 0.0) / 1e9, 1),
                               'gflop_fp32_pipe': round((conv_fl.get('fp32', 0.0) + em_fl) / 1e9, 1),
                               'ms_per_frame_timed': round(1e3 * t_frame, 3), 'ms_per_frame_at_pipe_peaks': round(1e3 * t_ideal, 3),
                               'frac_of_blended_mfma_ceiling': round(t_ideal / t_frame, 4),

@@ -104,7 +104,10 @@ int swem_split_bf16x3_f32(void *stream, const float *x, void *out, long long npi
  * channels ("channel-block major": the KH*KW taps of a 32-channel block are consecutive k-blocks, so a tile's activations
  * are fetched from HBM once instead of once per tap); KH*KW <= 64.
  * Every fragment goes HBM/L2 -> LDS by buffer-load-to-LDS (no register staging, no vector arithmetic in the k-loop).
- * Output, scale/shift/residual/ReLU-out/GLU, plan and workspace as swem_conv2d_nhwc_f32 (math bit ignored).
+ * Output, scale/shift/residual/ReLU-out/GLU, plan and workspace as swem_conv2d_nhwc_f32.  The plan's math field picks the
+ * arithmetic on these planes: 1 (or 0) = bf16x6, all three planes, six products (fp32-level error); 3 = "bf16x3", planes
+ * hi and mid only, the three products hi.hi + hi.mid + mid.hi (16 significant bits per operand, ~2^-16 relative per
+ * product; half the MFMA work and two thirds of the LDS); 2 = plain bf16 (plane 0, one product: config.AMP).
  * Plan bits 20-23 pick a kernel variant: 0 = the tile's default LDS ring (three stages for 64x64, two otherwise),
  * 1 = the other stage count, 2 / 3 = the 128x128 tile on eight waves with two / three stages, 4 / 6 = variants 0 / 2 on
  * v_mfma_f32_16x16x32_bf16 instead of 32x32x16, 8 / 9 = the 128x128 tile on four waves with 16-k blocks and two / three stages

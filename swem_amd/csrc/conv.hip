@@ -1060,6 +1060,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
             c = mfma_bf16_16(a[0][i], b[2][jn], c);
             c = mfma_bf16_16(a[2][i], b[0][jn], c);
             c = mfma_bf16_16(a[1][i], b[1][jn], c);
+          }
+          if constexpr (NPL >= 2) {   // NPL == 2: "bf16x3", the three products above 2^-16
             c = mfma_bf16_16(a[0][i], b[1][jn], c);
             c = mfma_bf16_16(a[1][i], b[0][jn], c);
           }
@@ -1089,6 +1091,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
               c = mfma_bf16(a[0][i], b[2][jn], c);
               c = mfma_bf16(a[2][i], b[0][jn], c);
               c = mfma_bf16(a[1][i], b[1][jn], c);
+            }
+            if constexpr (NPL >= 2) {
               c = mfma_bf16(a[0][i], b[1][jn], c);
               c = mfma_bf16(a[1][i], b[0][jn], c);
             }
@@ -1232,6 +1236,12 @@ int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st) {
     constexpr size_t lds1 = NST * 1 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;
     SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG>), lds1);
     hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG>), grid, dim3(64 * NW), lds1, st, p);
+    return SWEM_OK;
+  }
+  if (p.nplanes == 2) {   // "bf16x3": hi and mid planes, three products (hi.hi + hi.mid + mid.hi): two thirds of the LDS
+    constexpr size_t lds2 = NST * 2 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;
+    SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 2, KG>), lds2);
+    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 2, KG>), grid, dim3(64 * NW), lds2, st, p);
     return SWEM_OK;
   }
   constexpr size_t lds = NST * 3 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;  // NST stages x 3 planes
@@ -1521,7 +1531,9 @@ extern "C" int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, lon
   hipStream_t st = static_cast<hipStream_t>(stream);
   SWEM_REQUIRE(KH * KW <= 64, SWEM_E_SHAPE, "conv2d_bf16x3: at most 64 filter taps (one validity bit per tap and pixel)");
   const int variant = (plan >> 20) & 15;
-  p.nplanes = ((plan >> 16) & 3) == 2 ? 1 : 3;   // math 2 = plain bf16 (mixed-precision training), else bf16x6
+  // math 2 = plain bf16 (mixed-precision training), 3 = "bf16x3" (hi + mid planes, three products: 16 significant bits per
+  // operand, ~2^-16 relative error per product), else bf16x6
+  p.nplanes = ((plan >> 16) & 3) == 2 ? 1 : (((plan >> 16) & 3) == 3 ? 2 : 3);
   const int mtiles = cdiv(p.M, 64 * pl.wm), ntiles = cdiv(p.Ncols, 64 * pl.wn);
   // XCD partition of the N tiles: plan bits 28-29 force 2 / 4 / 8 groups; 0 = the cut with the least fetch traffic by
   // the model  groups * activations + (8 / groups) * filters  (each XCD reads its groups' filters and its share of the

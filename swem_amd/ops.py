@@ -21,7 +21,10 @@ CONV_TRACE = None
 # fp32 summation order, but tuning costs a few milliseconds per layer shape.
 AUTOTUNE = False
 _CONV_PLANS = {}      # layer signature + input shape -> plan hint (shared by every model instance in the process)
-CONV_MATH_MODES = (0, 1)   # 0 = fp32 MFMA, 1 = bf16x6 (exact 3-way bf16 split, fp32-level error); both are tuned over
+# math modes the conv tuner may choose from: 0 = fp32 MFMA, 1 = bf16x6 (exact 3-way bf16 split, six products: fp32-level
+# error), 3 = bf16x3 (hi + mid planes, the three products above 2^-16: 16 significant bits per operand, half the MFMA work
+# of bf16x6; the per-stage 1e-4 and per-frame 1e-3 parity bars are asserted with it enabled)
+CONV_MATH_MODES = (0, 1, 3)
 _TUNE_TILES = ((2, 2), (1, 2), (1, 1))
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
 
@@ -298,12 +301,13 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         e1.record()
         ncols = pack.cout * (2 if pack.glu else 1)
         in_bytes = 4.0 * sum(s_.shape[0] * H * W * s_.shape[3] for s_ in srcs)
-        # (events, useful FLOPs, label, algorithmic bytes, plan, pipe: 'bf16' = six bf16-MFMA products per fp32 product on the
-        # pre-split kernel, 'fp32' = v_mfma_f32_32x32x2_f32)
+        # (events, useful FLOPs, label, algorithmic bytes, plan, pipe: 'bf16' = six bf16-MFMA products per fp32 product,
+        # 'bf16x3' = three, 'fp32' = v_mfma_f32_32x32x2_f32)
         CONV_TRACE.append((e0, e1, 2.0 * B * Ho * Wo * ncols * pack.kh * pack.kw * pack.cin_true,
                            '%dx%dx%d k%d s%d %d->%d' % (B, H, W, pack.kh, pack.stride, pack.cin_true, ncols),
                            in_bytes + 4.0 * ncols * pack.kh * pack.kw * pack.cin_true + 4.0 * B * Ho * Wo * pack.cout,
-                           plan, 'bf16' if ((plan >> 16) & 3 and (presplit_ok or (plan >> 16) & 3 == 1)) else 'fp32'))
+                           plan, ('bf16x3' if (plan >> 16) & 3 == 3 and presplit_ok else
+                                  'bf16' if ((plan >> 16) & 3 and (presplit_ok or (plan >> 16) & 1)) else 'fp32')))
     return y
 
 
@@ -363,7 +367,7 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
                 continue
             for math in CONV_MATH_MODES:
                 cands.append(wm | wn << 4 | ns << 8 | math << 16)
-                if math in (1, 2):                 # pre-split kernel variants: other stage count, 8-wave 128x128 tile
+                if math in (1, 2, 3):              # pre-split kernel variants: other stage count, 8-wave 128x128 tile
                     base = wm | wn << 4 | ns << 8 | math << 16
                     cands.append(base | 1 << 20)
                     cands.append(base | 4 << 20)              # 16x16x32 MFMA shape

@@ -271,6 +271,36 @@ def test_conv2d_plain_bf16_mode(lib, plan):
     assert 1e-5 < err < 1e-2, err             # really one bf16 product (not the exact six), and no worse than bf16
 
 
+@pytest.mark.parametrize('plan', [0x30011, 0x30021, 0x30022, 0x130021, 0x230022, 0x430011, 0x430021, 0x630022, 0x30221, 0x830022,
+                                  0x930022, 0x4030021], ids=lambda p: '%#x' % p)
+def test_conv2d_bf16x3_mode(lib, plan):
+    """Math mode 3 ("bf16x3"): each operand is taken as hi + mid (two bf16 terms = 16 significant bits) and the product is
+    hi.hi + hi.mid + mid.hi in fp32 -- half the matrix-core work of bf16x6.  On operands that HAVE only 16 significant bits it
+    is the fp32 convolution up to the dropped mid.mid term (2^-16 of a product); on general fp32 operands the error is that of
+    truncating the operands to 16 bits: measured here against the fp32 convolution and held to 2e-5 of the output's range."""
+    g = torch.Generator().manual_seed(79)
+    B, Cin, H, W, Cout = 2, 160, 21, 37, 192
+    x = torch.randn(B, Cin, H, W, generator=g) * 3
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.03
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(B, Cout, H, W, generator=g)
+
+    def two_terms(t):                       # hi + mid: what planes 0 and 1 of the exact split hold
+        hi = t.bfloat16().float()
+        return hi + (t - hi).bfloat16().float()
+    x2, w2 = two_terms(x), two_terms(w)
+    ref2 = F.relu(F.conv2d(F.relu(x2).double(), w2.double(), b.double(), padding=1) + res.double()).float()
+    y = ops.conv2d([nhwc(x)], ops.pack_conv(w.to(DEV), b.to(DEV)), relu_in=True, relu_out=True, residual=nhwc(res), plan=plan)
+    close(back(y), ref2, 1e-5, 'bf16x3 conv = conv of the 16-bit operands, plan %#x' % plan)
+    full = F.relu(F.conv2d(F.relu(x).double(), w.double(), b.double(), padding=1) + res.double()).float()
+    err = float((back(y) - full).abs().max() / full.abs().max())
+    y6 = ops.conv2d([nhwc(x)], ops.pack_conv(w.to(DEV), b.to(DEV)), relu_in=True, relu_out=True, residual=nhwc(res),
+                    plan=(plan & ~0x30000) | 0x10000)
+    err6 = float((back(y6) - full).abs().max() / full.abs().max())
+    print('plan %#x: bf16x3 error %.2e of the output range (bf16x6: %.2e)' % (plan, err, err6))
+    assert err6 < 2e-6 < err < 2e-5, (err, err6)     # really the three-product mode, and within its error budget
+
+
 @pytest.mark.parametrize('plan', [0x10010011, 0x20010011, 0x30010011, 0x10010021, 0x20010022, 0x30210022, 0x24010021, 0x20810022,
                                   0x20020021, 0x10010211], ids=lambda p: '%#x' % p)
 def test_conv2d_xcd_partition(lib, plan):

@@ -13,7 +13,7 @@ import csv
 import json
 import sys
 
-PEAK = {'bf16': 2500.0 / 6, 'fp32': 157.3, 'readout': 157.3}
+PEAK = {'bf16': 2500.0 / 6, 'bf16x3': 2500.0 / 3, 'fp32': 157.3, 'readout': 157.3}
 
 
 def main(layers_json, trace_csv, out_csv):
