@@ -261,7 +261,8 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         _chk(residual, 'conv residual')
         res_bs = 0 if (res_broadcast or (residual.shape[0] == 1 and B > 1)) else Ho * Wo * pack.cout
 
-    presplit_ok = pack.w3 is not None and all(s_.shape[3] % 32 == 0 for s_ in srcs)
+    pipe_ok = all(s_.shape[3] % 32 == 0 for s_ in srcs)      # (the register-staged kernels' condition, conv.hip)
+    presplit_ok = pack.w3 is not None and pipe_ok
 
     def launch(plan, fresh=False):
         wsb = _lib.query('swem_conv2d_workspace', B, H, W, cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad,
@@ -307,7 +308,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
                            '%dx%dx%d k%d s%d %d->%d' % (B, H, W, pack.kh, pack.stride, pack.cin_true, ncols),
                            in_bytes + 4.0 * ncols * pack.kh * pack.kw * pack.cin_true + 4.0 * B * Ho * Wo * pack.cout,
                            plan, ('bf16x3' if (plan >> 16) & 3 == 3 and presplit_ok else
-                                  'bf16' if ((plan >> 16) & 3 and (presplit_ok or (plan >> 16) & 1)) else 'fp32')))
+                                  'bf16' if ((plan >> 16) & 3 and (presplit_ok or ((plan >> 16) & 1 and pipe_ok))) else 'fp32')))
     return y
 
 
