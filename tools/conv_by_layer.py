@@ -33,7 +33,8 @@ def main(layers_json, trace_csv, out_csv):
         if mi + 1 < len(rows) and 'conv_splitk_epilogue' in rows[mi + 1]['Kernel_Name']:
             t_red = dur(rows[mi + 1])
         prev = mi
-        kname = rows[mi]['Kernel_Name'].split('(')[0].replace('void (anonymous namespace)::', '')
+        import re
+        kname = re.search(r'(conv_igemm\w*(<[^>]*>)?)', rows[mi]['Kernel_Name']).group(1).replace(', ', ' ')
         a = agg.setdefault((la['layer'], la['pipe'], '%#x' % la['plan'], kname), [0, 0.0, 0.0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += la['flops']
