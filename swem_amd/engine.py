@@ -64,6 +64,14 @@ class _ResBlock:
         return ops.conv2d([r], self.c2, relu_in=True, residual=res)
 
 
+def per_object(t, n):
+    """(B, ...) -> (B*n, ...): item b repeated for each of its n objects, clip-major like the reference's
+    ``unsqueeze(1).expand(-1, n, ...).flatten(0, 1)`` (swem.py:52-53, 94-95).  The conv kernels broadcast ONE image over a
+    batch (batch stride 0); with several clips in the batch the per-clip repeat is materialised (a device copy of a 1/16-
+    or 1/4-scale map)."""
+    return t.unsqueeze(1).expand(t.shape[0], n, *t.shape[1:]).reshape(t.shape[0] * n, *t.shape[1:]).contiguous()
+
+
 class Engine:
     def __init__(self, model):
         dev = next(model.parameters()).device
@@ -121,8 +129,7 @@ class Engine:
         B = frame.shape[0]
         N = masks.shape[1] - 1
         if B != 1 and N != 1:
-            # s16 must repeat per object inside each batch item; the conv broadcast covers B == 1 or N == 1 only
-            raise NotImplementedError('encode_value: batch > 1 with several objects needs an expanded s16')
+            s16 = per_object(s16, N)      # clip b's feature map for each of its N objects (swem.py:52-53 .expand)
         x = ops.prep_value_input(frame, masks, self.v_mean, self.v_std, self.single_obj)
         x = ops.maxpool(ops.conv2d([x], self.v_stem, relu_out=True))
         for st in self.v_stages:
@@ -134,13 +141,17 @@ class Engine:
 
     # modules.py:286-291
     def fuse_context(self, mem_out, qv16, s_feat):
-        return ops.conv2d([mem_out, qv16, s_feat], self.glu, batch=mem_out.shape[0])
+        BN = mem_out.shape[0]
+        if qv16.shape[0] not in (1, BN):
+            qv16 = per_object(qv16, BN // qv16.shape[0])     # (B,...) -> (B*N,...): modules.py:287 .expand_as
+        return ops.conv2d([mem_out, qv16, s_feat], self.glu, batch=BN)
 
     # networks.py:208-213 ; the skip convs see the same s8/s4 for every object (swem.py:94-95): computed once
     def decoder_logit(self, context, s8, s4):
+        BN, B = context.shape[0], s8.shape[0]
         x = self.compress([context])
         sk = ops.conv2d([s8], self.skip8)
-        x = self.out8([ops.upsample_add(sk, x)])
+        x = self.out8([ops.upsample_add(sk if B in (1, BN) else per_object(sk, BN // B), x)])
         sk = ops.conv2d([s4], self.skip4)
-        x = self.out4([ops.upsample_add(sk, x)])
+        x = self.out4([ops.upsample_add(sk if B in (1, BN) else per_object(sk, BN // B), x)])
         return ops.pred_head(x, self.pred_w, self.pred_b)

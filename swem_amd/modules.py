@@ -9,7 +9,8 @@ Tensors cross this boundary in the reference's shapes: ``qk (B,Ck,h,w)``, ``qv (
 ``(B,Cv,h,w)``, ``masks (B,N,2,h,w)``, bases ``kappa (B,N,2,Ck,L)``, ``nu (B,N,2,Cv,L)``,
 ``zita (B,N,2,1,L)``.  Feature maps produced by this package are channels-last in memory, so the
 ``(P,C)`` pixel-major views the kernels want are free; foreign NCHW inputs are repacked by the
-transpose kernel.  B must be 1 (the reference evaluator's case; objects of one frame are batched as N).
+transpose kernel.  The kernels take ONE frame's key and its N objects per call (the evaluator's case, B = 1); a batch of
+B clips (the trainer's call shape, swem_trainer.py:59-90) is B such calls on slices -- clips share nothing in the EM.
 """
 import math
 
@@ -135,6 +136,7 @@ class SWEMCore(nn.Module):
     def repack(self):
         """Rebuild whatever part of the pack does not belong to the current bank tensors."""
         first, update = self.memories['first'].bases, self.memories['update'].bases
+        assert first['kappa'].shape[0] == 1, 'the persistent pack serves one sequence (B = 1)'
         N, _, Ck, L = first['kappa'].shape[1:]
         pack = self._pack_for(N, Ck, first['kappa'].device)
         for b, bases in enumerate((first, update)):
@@ -180,8 +182,6 @@ class SWEMCore(nn.Module):
     def swem(self, x, v, masks, bases_=None, pack=None, prior_packed=False, bank=1):
         B, Ck, H, W = x.shape
         N = masks.shape[1]
-        if B != 1:
-            raise NotImplementedError('swem_amd.SWEMCore: batch > 1 is not built yet (inference uses B = 1)')
         if bases_ is None:
             kappa_, nu_, zita_ = self.random_init(size=(B, N, 2, Ck, self.n_bases), dtype=x.dtype, device=x.device)
         else:
@@ -194,18 +194,23 @@ class SWEMCore(nn.Module):
             nu_ = torch.cat([nu_, new_nu], dim=1)
             zita_ = torch.cat([zita_, new_zita], dim=1)
         L = self.n_bases
-        xp = to_pixel_major(x).view(H * W, Ck)                       # (P, C)
+        xp = to_pixel_major(x).view(B, H * W, Ck)                    # (B, P, C)
         if v.dim() == 5:                                             # (B,N,V,h,w) reference layout
-            vp = to_pixel_major(v.flatten(0, 1)).view(N, H * W, -1)
+            vp = to_pixel_major(v.flatten(0, 1)).view(B, N, H * W, -1)
         else:                                                        # engine output (B*N,h,w,V) NHWC
-            vp = v.view(N, H * W, -1)
-        mk = masks.reshape(N, 2, H * W).contiguous()
-        kappa, nu, zita = ops.memorize(xp, vp, mk, kappa_.reshape(N, 2, Ck, L).contiguous(),
-                                       nu_.reshape(N, 2, -1, L).contiguous(), zita_.reshape(N, 2, L).contiguous(),
-                                       self.n_iters, self.tau, pack=pack, prior_packed=prior_packed and N_new <= 0,
-                                       bank=bank)
-        return {'kappa': kappa.view(B, N, 2, Ck, L), 'nu': nu.view(B, N, 2, -1, L),
-                'zita': zita.view(B, N, 2, 1, L)}
+            vp = v.view(B, N, H * W, -1)
+        mk = masks.reshape(B, N, 2, H * W).contiguous()
+        outs = []
+        for b in range(B):                                           # clips are independent (one key map per clip)
+            outs.append(ops.memorize(xp[b], vp[b], mk[b], kappa_[b].reshape(N, 2, Ck, L).contiguous(),
+                                     nu_[b].reshape(N, 2, -1, L).contiguous(), zita_[b].reshape(N, 2, L).contiguous(),
+                                     self.n_iters, self.tau, pack=pack if B == 1 else None,
+                                     prior_packed=prior_packed and N_new <= 0 and B == 1, bank=bank))
+        if B == 1:
+            kappa, nu, zita = outs[0]
+            return {'kappa': kappa.view(B, N, 2, Ck, L), 'nu': nu.view(B, N, 2, -1, L), 'zita': zita.view(B, N, 2, 1, L)}
+        return {'kappa': torch.stack([o[0] for o in outs]), 'nu': torch.stack([o[1] for o in outs]),
+                'zita': torch.stack([o[2] for o in outs]).unsqueeze(-2)}
 
     def random_init(self, size, norm_dim=-2, dtype=None, device=None):
         """modules.py:170-178.  Host-side on purpose: the bases are drawn from the torch
@@ -230,7 +235,7 @@ class SWEMCore(nn.Module):
         prior = first.bases if update.bases is None else update.bases
         N = masks.shape[1]
         grown = not frame0 and N > first.bases['kappa'].shape[1]       # new object ids (YouTube-VOS): the pack is rebuilt
-        pack = None if grown else self._pack_for(N, qk.shape[1], qk.device)
+        pack = None if (grown or qk.shape[0] != 1) else self._pack_for(N, qk.shape[1], qk.device)
         bank = 0 if frame0 else 1
         prior_packed = pack is not None and update.bases is not None and self._stamped(1, update.bases)
         bases = self.swem(qk, qv, masks, prior, pack=pack, prior_packed=prior_packed, bank=bank)
@@ -246,23 +251,29 @@ class SWEMCore(nn.Module):
 
     # ------------------------------------------------------------------ modules.py:232-293
     def _affinity_readout(self, qk, first, update):
-        """get_affinity + perm_inv_feat in one kernel.  qk (1,Ck,h,w) RAW (normalised in-kernel, modules.py:282-283) -> S (N,h,w,2l) and mem_out (N,h,w,V), NHWC."""
+        """get_affinity + perm_inv_feat in one kernel.  qk (B,Ck,h,w) RAW (normalised in-kernel, modules.py:282-283) ->
+        S (B*N,h,w,2l) and mem_out (B*N,h,w,V), NHWC, clip-major like the reference's flatten(0, 1)."""
         B, Ck, H, W = qk.shape
-        assert B == 1
-        xp = to_pixel_major(qk).view(H * W, Ck)
+        xp = to_pixel_major(qk).view(B, H * W, Ck)
         N, L = first['kappa'].shape[1], first['kappa'].shape[-1]
-        kf = first['kappa'].reshape(N, 2, Ck, L).contiguous()
-        nf = first['nu'].reshape(N, 2, -1, L).contiguous()
-        ku = nu = None
-        if update is not None:
-            ku = update['kappa'].reshape(N, 2, Ck, L).contiguous()
-            nu = update['nu'].reshape(N, 2, -1, L).contiguous()
-        if update is not None:       # both banks: matching reads the persistent pack (kept current by memorize)
-            mem_out, S = ops.match_packed(xp, self.repack(), L, self.topl, self.tau)
-        else:                        # the first matched frame of a sequence: one bank, packed in the call's workspace
-            mem_out, S = ops.match(xp, kf, nf, ku, nu, self.topl, self.tau)
-        # mem_out keeps a row pitch per object (ops.match): NHWC images, free batch stride
-        return S.view(N, H, W, -1), mem_out.unflatten(1, (H, W))
+        if B == 1 and update is not None:       # both banks: matching reads the persistent pack (kept current by memorize)
+            mem_out, S = ops.match_packed(xp[0], self.repack(), L, self.topl, self.tau)
+            # mem_out keeps a row pitch per object (ops.match): NHWC images, free batch stride
+            return S.view(N, H, W, -1), mem_out.unflatten(1, (H, W))
+        mems, Ss = [], []
+        for b in range(B):     # the first matched frame of a sequence (one bank) or a batch of clips: packed in the call
+            kf = first['kappa'][b].reshape(N, 2, Ck, L).contiguous()
+            nf = first['nu'][b].reshape(N, 2, -1, L).contiguous()
+            ku = nu = None
+            if update is not None:
+                ku = update['kappa'][b].reshape(N, 2, Ck, L).contiguous()
+                nu = update['nu'][b].reshape(N, 2, -1, L).contiguous()
+            mem_out, S = ops.match(xp[b], kf, nf, ku, nu, self.topl, self.tau)
+            mems.append(mem_out)
+            Ss.append(S)
+        if B == 1:
+            return Ss[0].view(N, H, W, -1), mems[0].unflatten(1, (H, W))
+        return torch.cat(Ss).view(B * N, H, W, -1), torch.cat([m.contiguous() for m in mems]).view(B * N, H, W, -1)
 
     def matching(self, qk, qv):
         first, update = self.memories['first'].bases, self.memories['update'].bases
@@ -271,11 +282,11 @@ class SWEMCore(nn.Module):
         if update is not None and update['kappa'].shape[1] != first['kappa'].shape[1]:
             raise RuntimeError('memory banks disagree on the number of objects')
         S, mem_out = self._affinity_readout(qk, first, update)
-        qvp = to_pixel_major(qv)                                      # (1,h,w,V), shared by all objects
+        qvp = to_pixel_major(qv)                                      # (B,h,w,V), clip b's map shared by its objects
         if self._engine is None:
             raise RuntimeError('SWEMCore.matching needs the owning SWEM model (packed fusion weights)')
-        ctx = self._engine().fuse_context(mem_out, qvp, S)           # (N,h,w,V) NHWC
-        return ctx.permute(0, 3, 1, 2), mem_out.shape[0]
+        ctx = self._engine().fuse_context(mem_out, qvp, S)           # (B*N,h,w,V) NHWC
+        return ctx.permute(0, 3, 1, 2), first['kappa'].shape[1]
 
     def get_mem(self):
         """modules.py:295-306 (inspection only: matching reads the banks directly)."""

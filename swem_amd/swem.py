@@ -86,8 +86,6 @@ class SWEM(nn.Module):
     # ------------------------------------------------------------------ swem.py:92-116
     def decode(self, n, context, s8, s4, valid_obj, out_size):
         B = s8.shape[0]
-        if B != 1 and n != 1:
-            raise NotImplementedError('decode: batch > 1 with several objects is not built yet')
         logit4 = self.engine().decoder_logit(to_pixel_major(context), to_pixel_major(s8), to_pixel_major(s4))
         logits, pred_mask, _ = ops.decode_head(logit4, B, n, tuple(int(v) for v in out_size), valid=valid_obj)
         return logits, pred_mask

@@ -118,6 +118,66 @@ def test_stages_vs_oracle(lib, kw, h, w, n_obj):
         assert logits_close(l2, ol2, tol)
 
 
+def test_batch_of_two_clips_vs_oracle(lib):
+    """The trainer's call shape (swem_trainer.py:59-90): every mode with a BATCH of clips, B = 2 here, N = 2 objects each.
+    The body of the reference's one_step loop -- encode_key, encode_value, init, match, segment(valid_obj), memorize, match
+    on both banks -- against the oracle stage by stage (the oracle's inputs go into every HIP stage), clip-major layouts
+    (B*N, ...) as the reference's flatten(0, 1)."""
+    from swem_amd import synth
+    cfg = O.make_cfg(**CFG_A)
+    model, sd = H.make_model_and_sd(cfg, wseed=13, device=DEV)
+    h, w, n_obj = 128, 192, 2
+    clips = [synth.make_clip(t=3, h=h, w=w, n_obj=n_obj, seed=60 + b, all_masks=True) for b in range(2)]
+    frames = torch.cat([c[0] for c in clips])                               # (2, 3, 3, h, w)
+    m0 = torch.cat([c[1][0] for c in clips])                                # (2, N+1, h, w)
+    valid = torch.tensor([[1., 1., 1.], [1., 1., 0.]])
+    om = O.Model(sd, cfg)
+    d = lambda t: t.to(DEV)
+    with torch.no_grad():
+        oqk, oqv, os16, os8, os4 = om('encode_key', frames[:, 0])
+        qk, qv, s16, s8, s4 = model('encode_key', d(frames[:, 0]))
+        for name, a, b in (('s4', s4, os4), ('s16', s16, os16), ('qk16', qk, oqk), ('qv16', qv, oqv)):
+            assert a.shape == b.shape and relmax(a, b) < 1e-4, name
+        omv = om('encode_value', frames[:, 0], m0, os16)
+        mv = model('encode_value', d(frames[:, 0]), d(m0), d(os16))
+        assert mv.shape == omv.shape == (2, n_obj, 512, h // 16, w // 16) and relmax(mv, omv) < 1e-4
+        torch.manual_seed(5)
+        om('init', oqk, omv, m0)
+        torch.manual_seed(5)
+        model('init', d(oqk), d(omv), d(m0))
+        ob, hb = om.core.first.bases, model.swem_core.memories['first'].bases
+        assert hb['kappa'].shape == ob['kappa'].shape == (2, n_obj, 2, 128, 64)
+        zr = ob['zita'].squeeze(-2).unsqueeze(-2)
+        for name in ('kappa', 'nu'):
+            err = ((hb[name].cpu() - ob[name]) * zr).abs().max() / (ob[name] * zr).abs().max()
+            assert err < 5e-5, 'init %s mass-weighted rel err %.3g' % (name, err)
+        # frame 1: match on the first bank, segment with valid_obj, memorize -> the update bank
+        model.swem_core.memories['first'].bases = {k: d(t) for k, t in ob.items()}
+        oqk1, oqv1, os16_1, os8_1, os4_1 = om('encode_key', frames[:, 1])
+        octx, on = om('match', oqk1, oqv1)
+        ctx, n = model('match', d(oqk1), d(oqv1))
+        assert n == on == n_obj and ctx.shape == octx.shape == (2 * n_obj, 512, h // 16, w // 16)
+        assert relmax(ctx, octx) < 1e-4, 'match (one bank) context rel err %.3g' % relmax(ctx, octx)
+        ologits, oprob = om('segment', on, octx, os8_1, os4_1, valid, (h, w))
+        logits, prob = model('segment', n, d(octx), d(os8_1), d(os4_1), d(valid), (h, w))
+        assert logits.shape == ologits.shape == (2, n_obj + 1, h, w)
+        assert logits_close(logits, ologits, 1e-3), float((logits.cpu() - ologits).abs().max())
+        assert float((prob.cpu().argmax(1) == oprob.argmax(1)).float().mean()) > 0.9995
+        opred = oprob.argmax(1, keepdim=True)
+        ohard = (opred.expand(-1, n_obj + 1, -1, -1) == torch.arange(n_obj + 1).view(1, -1, 1, 1)).long()
+        omv1 = om('encode_value', frames[:, 1], oprob, os16_1)
+        model('memorize', d(oqk1), d(omv1), d(ohard), d(oprob))
+        om('memorize', oqk1, omv1, ohard, oprob)
+        ou, hu = om.core.upd.bases, model.swem_core.memories['update'].bases
+        assert hu['kappa'].shape == ou['kappa'].shape
+        # frame 2: match on both banks (the oracle's)
+        model.swem_core.memories['update'].bases = {k: d(t) for k, t in ou.items()}
+        oqk2, oqv2, _, _, _ = om('encode_key', frames[:, 2])
+        octx2, _ = om('match', oqk2, oqv2)
+        ctx2, _ = model('match', d(oqk2), d(oqv2))
+        assert relmax(ctx2, octx2) < 1e-4, 'match (two banks) context rel err %.3g' % relmax(ctx2, octx2)
+
+
 def test_stages_vs_oracle_with_tuned_plans(lib):
     """The bench configuration: per-layer plans chosen by the on-device autotuner, which mixes the fp32-MFMA kernel and
     the bf16x6 mode (exact 3-way bf16 split, pre-split operands moved by LDS-DMA).  Same stage-by-stage bars as above."""
