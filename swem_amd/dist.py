@@ -103,3 +103,16 @@ def broadcast_model_(flat_param, module=None, src=0):
             if b.numel():
                 dist.broadcast(b, src=src)
     return flat_param
+
+
+def allreduce_sum_async(t, bucket_bytes=64 << 20, mean=False):
+    """Start the in-place SUM all-reduce of a flat device tensor in buckets and return the work handles (empty for one
+    process).  The collectives run on the process group's own stream behind what the CURRENT stream has queued so far; the
+    caller overlaps them with later launches and calls ``.wait()`` on the handles before it consumes the result.
+    mean: divide by the world size first (loss scalars: basic_trainer.py:105-110)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return []
+    if mean:
+        t.div_(dist.get_world_size())
+    n = max(1, bucket_bytes // t.element_size())
+    return [dist.all_reduce(t[i:i + n], op=dist.ReduceOp.SUM, async_op=True) for i in range(0, t.numel(), n)]

@@ -6,8 +6,10 @@ signature and return value ``(losses, results)``.  The clip loop, the loss (``lo
 (``optim.FlatAdamW`` + ``MultiStepLR``) run through ``swem_amd.autograd`` / ``libswem_hip.so``; the model's parameters
 live in one flat buffer and their gradients are accumulated in-kernel.
 
-Data parallel: every rank steps its own clips; one bucketed all-reduce of the flat gradient buffer (dist.py) precedes the
-optimizer step, the 1/world factor is folded into the loss gradient.  The reference scales the learning rate by the
+Data parallel: every rank steps its own clips; the flat gradient buffer is all-reduced over RCCL in two slices -- everything
+but the key-encoder trunk as soon as the lanes have back-propagated down to the trunk (in flight during the trunk's
+backward), the trunk's slice and the three loss scalars (one 3-float message) at the end -- and the 1/world factor is folded
+into the loss gradient.  The reference scales the learning rate by the
 number of GPUs only if asked (solver.py:31-34, ``num_gpu``), so does ``SWEMTrainer(num_gpu=...)``.
 
 How the batch is run: clips are independent (frozen BatchNorm, per-clip memory), so every clip is its own forward /
@@ -72,9 +74,11 @@ class TrainGraph:
             res = A.conv2d(srcs, rb.downsample.weight, rb.downsample.bias, batch=batch)
         return A.conv2d([r], rb.conv2.weight, rb.conv2.bias, relu_in=True, residual=res)
 
-    # swem.py:39-43 + networks.py:160-182
-    def encode_key(self, frame):
-        m, ke = self.m, self.m.key_encoder
+    # swem.py:39-43 + networks.py:160-182, in two parts: the ResNet trunk (every parameter of `key_encoder`, the FIRST slice of
+    # the flat parameter buffer) and the two 3x3 projections on its 1/16 map.  The step back-propagates through the trunk in a
+    # phase of its own (SWEMTrainer: the rest of the gradient is all-reduced meanwhile).
+    def key_trunk(self, frame):
+        ke = self.m.key_encoder
         x = ops.prep_key_input(frame, self.k_mean, self.k_std)
         x = A.maxpool(A.bn_act(A.conv2d([x], ke.conv1.weight, None, stride=2, pad=3, cin_pad=4), _bn(ke.bn1)))
         feats = []
@@ -83,8 +87,17 @@ class TrainGraph:
                 x = self._block(blk, x)
             feats.append(x)
         s4, s8, s16 = feats
+        return s16, s8, s4
+
+    def key_project(self, s16):
+        m = self.m
         qk16 = A.conv2d([s16], m.key_proj.key_proj.weight, m.key_proj.key_proj.bias)
         qv16 = A.conv2d([s16], m.key_comp.weight, m.key_comp.bias)
+        return qk16, qv16
+
+    def encode_key(self, frame):
+        s16, s8, s4 = self.key_trunk(frame)
+        qk16, qv16 = self.key_project(s16)
         return qk16, qv16, s16, s8, s4
 
     # swem.py:45-62 + networks.py:113-129, 43-50
@@ -170,6 +183,14 @@ class SWEMTrainer:
         # broadcast_buffers=False only stops the per-iteration re-broadcast): without it rank-local initialisation
         # (FROM_SCRATCH, the orthogonal fifth stem channel of checkpoint.adapt_state_dict) would train W different models
         sdist.broadcast_model_(self.optimizer.param, model)
+        # the key-encoder trunk's parameters are the first slice of the flat buffers (model.parameters() order)
+        ke = {id(q) for q in model.key_encoder.parameters()}
+        idx = [i for i, q in enumerate(self.optimizer.params) if id(q) in ke]
+        assert idx == list(range(len(idx))), 'key_encoder must come first in model.parameters()'
+        nxt = self.optimizer.params[len(idx)] if len(idx) < len(self.optimizer.params) else None
+        self.trunk_end = (nxt.data_ptr() - self.optimizer.param.data_ptr()) // 4 if nxt is not None else self.optimizer.param.numel()
+        self._works = []
+        self._trunks = []
         self.lr_scheduler = optim.make_lr_scheduler(_get(config, 'SOLVER'), self.optimizer)
         self.criterion = L.get_criterion(_get(config, 'LOSS'), None, 1, 1, dev)
         self.graph = TrainGraph(model)
@@ -185,7 +206,13 @@ class SWEMTrainer:
         out_size = tuple(init_mask.shape[-2:])
         # the key encoder does not depend on the memory: all t frames go through it in one pass (a third of its launches,
         # three times larger kernels); frozen BatchNorm keeps every frame's result what a per-frame call gives
-        enc = [A.unbatch(e, t) for e in g.encode_key(frames[0])]            # [qk16, qv16, s16, s8, s4][frame]
+        trunk = g.key_trunk(frames[0])                                       # (s16, s8, s4), all t frames
+        # the trunk's backward is a phase of its own (`trunk_backward`): everything downstream differentiates towards
+        # detached copies, whose .grad the second phase feeds into the trunk
+        cut = [o.detach().requires_grad_(True) for o in trunk]
+        qk_all, qv_all = g.key_project(cut[0])
+        enc = [A.unbatch(e, t) for e in (qk_all, qv_all, cut[0], cut[1], cut[2])]   # [qk16, qv16, s16, s8, s4][frame]
+        self._trunks.append((trunk, cut))
         mk16, s16 = enc[0][0], enc[2][0]
         mv16 = g.encode_value(frames[:, 0], init_mask.float(), s16)
         first = g.memorize(mk16, mv16, init_mask, init_mask.float(), prior0)
@@ -256,14 +283,17 @@ class SWEMTrainer:
         ls['flat'].zero_()
         ls['sums'].zero_()
         self._results = [None] * self.buf['frames'].shape[0]
+        self._lane_trunks = [[] for _ in ls['streams']]
 
     def _lane(self, l, cur_iter):
+        """Phase A of lane l: its clips' forward, loss and the backward of everything BUT the key-encoder trunk."""
         bf = self.buf
         B = bf['frames'].shape[0]
         ls = self._lanes(B)
         n = len(ls['streams'])
         p = 1.0
         A.use_lane(l, ls['views'][l])
+        self._trunks = self._lane_trunks[l]
         for b in range(l, B, n):
             vo = None if bf['valid'] is None else bf['valid'][b:b + 1]
             prior = {'kappa': bf['kappa0'][b], 'nu': bf['nu0'], 'zita': bf['zita0']}
@@ -277,10 +307,32 @@ class SWEMTrainer:
         A.use_lane(0, None)
         return p
 
+    def _lane_trunk(self, l):
+        """Phase B of lane l: the key-encoder trunk's backward for the lane's clips (its parameters are the first slice of the
+        flat buffer; meanwhile the rest of the gradient is summed over the lanes and all-reduced, `_post_rest`)."""
+        ls = self._lane_state
+        A.use_lane(l, ls['views'][l])
+        for trunk, cut in self._lane_trunks[l]:
+            pairs = [(o, c.grad) for o, c in zip(trunk, cut) if c.grad is not None]
+            torch.autograd.backward([o for o, _ in pairs], [g_ for _, g_ in pairs])
+        self._lane_trunks[l] = []
+        A.use_lane(0, None)
+
+    def _post_rest(self):
+        """Lanes' gradients of everything but the trunk -> the optimizer's buffer (slice [trunk_end, end))."""
+        self._sum_lanes(self.trunk_end, self.optimizer.grad.numel())
+
+    def _sum_lanes(self, lo, hi):
+        """optimizer.grad[lo:hi] = sum over the lanes of their buffers' [lo:hi) (lane order: the same sum every step)."""
+        ls = self._lane_state
+        out = self.optimizer.grad[lo:hi].view(1, -1)
+        for l in range(ls['flat'].shape[0]):
+            A.sum_batch(ls['flat'][l:l + 1, lo:hi], out=out, accumulate=l > 0)
+
     def _post(self):
         bf = self.buf
         ls = self._lanes(bf['frames'].shape[0])
-        A.sum_batch(ls['flat'], out=self.optimizer.grad.view(1, -1))   # lanes' gradients -> the optimizer's buffer
+        self._sum_lanes(0, self.trunk_end)                                     # the trunk's slice
         tot = ls['sums'][0]
         for l in range(1, len(ls['streams'])):
             tot = ops.lincomb(tot, 1.0, ls['sums'][l], 1.0)
@@ -288,7 +340,9 @@ class SWEMTrainer:
         return torch.cat(self._results, dim=0)
 
     def _clips(self, cur_iter):
-        """zero_grad + forward / loss / backward of every clip on the static buffers; returns (results, p)."""
+        """zero_grad + forward / loss / backward of every clip on the static buffers; returns (results, p).
+        Data parallel: the all-reduce of the non-trunk gradient (6/7 of the parameters) is started as soon as every lane has
+        finished phase A and runs while the lanes back-propagate through the key-encoder trunk."""
         ls = self._lanes(self.buf['frames'].shape[0])
         main = torch.cuda.current_stream()
         self._pre()
@@ -301,8 +355,30 @@ class SWEMTrainer:
                 p = self._lane(l, cur_iter)
         for st in ls['streams']:
             if st is not None:
+                main.wait_stream(st)                                   # phase A of every lane
+        self._post_rest()
+        self._reduce_rest()
+        for l, st in enumerate(ls['streams']):
+            with torch.cuda.stream(st if st is not None else main):
+                self._lane_trunk(l)
+        for st in ls['streams']:
+            if st is not None:
                 main.wait_stream(st)                                   # join
         return self._post(), p
+
+    # ------------------------------------------------------------------ data-parallel reduction (RCCL over xGMI)
+    def _reduce_rest(self):
+        """Start the all-reduce of the gradient slice that phase A completed; waited for in `_reduce_finish`."""
+        self._works = sdist.allreduce_sum_async(self.optimizer.grad[self.trunk_end:])
+
+    def _reduce_finish(self):
+        """All-reduce the trunk's slice and the three loss scalars (ONE 3-float all-reduce instead of the reference's three,
+        basic_trainer.py:105-110,240-243; no host synchronisation), then wait for everything in flight."""
+        works = self._works + sdist.allreduce_sum_async(self.optimizer.grad[:self.trunk_end])
+        works += sdist.allreduce_sum_async(self.buf['sums'], mean=True)
+        for w in works:
+            w.wait()
+        self._works = []
 
     def one_step(self, frames, init_mask, valid_obj, label, cur_iter):
         """swem_trainer.py:59-108.  With ``use_graph`` (default) the clips' forward/backward is captured into a HIP graph
@@ -348,7 +424,7 @@ class SWEMTrainer:
             with self._math():
                 results, p = self._clips(cur_iter)
             self._eager_steps += 1
-        sdist.allreduce_sum_(self.optimizer.grad)                      # RCCL over xGMI; no-op for one process
+        self._reduce_finish()                                          # RCCL over xGMI; no-op for one process
         self.optimizer.step()
         self.lr_scheduler.step()
         # the parameters changed in place: inference through this model (validation, encode_key / segment modes) must not run
@@ -376,7 +452,7 @@ class SWEMTrainer:
             g_pre = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_pre):
                 self._pre()
-            lanes = []
+            lanes_a, lanes_b = [], []
             for l, st in enumerate(ls['streams']):
                 g = torch.cuda.CUDAGraph()
                 if st is None:
@@ -386,23 +462,47 @@ class SWEMTrainer:
                     st.wait_stream(main)
                     with torch.cuda.graph(g, stream=st):
                         self._lane(l, cur_iter)
-                lanes.append(g)
+                lanes_a.append(g)
+            g_rest = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_rest):
+                self._post_rest()
+            for l, st in enumerate(ls['streams']):
+                # phase B reads tensors phase A allocated (the trunk's activations, the cut's gradients): same memory pool
+                g = torch.cuda.CUDAGraph()
+                if st is None:
+                    with torch.cuda.graph(g, pool=lanes_a[l].pool()):
+                        self._lane_trunk(l)
+                else:
+                    with torch.cuda.graph(g, stream=st, pool=lanes_a[l].pool()):
+                        self._lane_trunk(l)
+                lanes_b.append(g)
             g_post = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_post):
                 out = self._post()
         torch.cuda.synchronize()
-        self._graph, self._graph_out = (g_pre, lanes, g_post), out
+        self._graph, self._graph_out = (g_pre, lanes_a, g_rest, lanes_b, g_post), out
 
     def _replay(self):
-        g_pre, lanes, g_post = self._graph
+        g_pre, lanes_a, g_rest, lanes_b, g_post = self._graph
         ls = self._lane_state
         main = torch.cuda.current_stream()
         g_pre.replay()
-        for st, g in zip(ls['streams'], lanes):
+        for st, g in zip(ls['streams'], lanes_a):
             if st is None:
                 g.replay()
             else:
                 st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    g.replay()
+        for st in ls['streams']:
+            if st is not None:
+                main.wait_stream(st)                       # phase A of every lane
+        g_rest.replay()
+        self._reduce_rest()                                # in flight while the lanes run phase B
+        for st, g in zip(ls['streams'], lanes_b):
+            if st is None:
+                g.replay()
+            else:
                 with torch.cuda.stream(st):
                     g.replay()
         for st in ls['streams']:

@@ -775,3 +775,47 @@ def test_inference_after_a_step_sees_the_updated_weights(lib):
     ref = infer(fresh)
     assert float((after - before).abs().max()) > 1e-3, 'the step did not move the outputs: the test is vacuous'
     assert torch.equal(after, ref)
+
+
+@pytest.mark.parametrize('graph', [False, True], ids=['eager', 'graph'])
+def test_two_ranks_one_clip_each_equal_one_rank_two_clips(lib, tmp_path, graph):
+    """Data parallel (swem_trainer.py:41-43: DistributedDataParallel): two ranks that step one clip each -- parameters
+    broadcast from rank 0 at start-up, gradient all-reduced in two overlapped slices, loss scalars in one 3-float message --
+    end with the parameters of ONE rank stepping both clips, on every rank, and report the batch's mean losses.
+    Rehearsed on one GPU over gloo (the RCCL path is the same torch.distributed calls)."""
+    import os
+    from swem_amd import dist as sdist, train
+    from swem_amd.train import SWEMTrainer
+    steps = 4 if graph else 2                        # (the graph is captured after two eager steps)
+    out = str(tmp_path / 'ranks.pt')
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_dist_train_probe.py')
+    env = dict(os.environ, SWEM_DIST_BACKEND='gloo')
+    rc, text = sdist.launch_ranks(2, [probe, out, str(steps)] + (['graph'] if graph else []), env=env, timeout=900)
+    assert rc == 0, text
+    got = torch.load(out)
+    assert got['world'] == 2 and got['same_on_all_ranks']
+    # the same two clips on one rank
+    tc = H.train_cases()
+    case = dict(tc['cases']['r18'], hw=[128, 128])
+    cfg = O.make_cfg(**case['cfg'])
+    model, _ = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+    frames, init_mask, label, valid = [t.to(DEV) for t in H.train_batch(case)]
+    tr = SWEMTrainer(dict(SOLVER=dict(tc['solver_cfg'], BASE_LR=1e-4), LOSS=tc['loss_cfg'], AMP=False), model, use_graph=graph)
+    real = train.random_init_host
+    hist = []
+    try:
+        for it in range(steps):
+            torch.manual_seed(1000 + it)
+            full = real(2, case['n'], 128, cfg.NUM_BASES)
+            train.random_init_host = lambda B, N, Cc, Lb, _f=full: _f.clone()
+            losses, _ = tr.one_step(frames, init_mask, valid, label, 5 + it)
+            hist.append([float(losses[k]) for k in ('total_loss', 'main_loss', 'aux_loss')])
+    finally:
+        train.random_init_host = real
+    one = tr.optimizer.param.detach().cpu()
+    d = float((one - got['param']).abs().max())
+    print('two ranks vs one rank: max |dparam| %.3g, losses %s vs %s' % (d, got['hist'][-1], hist[-1]))
+    # each clip's gradient is the same deterministic kernel sequence on both sides; the two-addend sums commute
+    assert torch.equal(one, got['param']), d
+    for a, b in zip(got['hist'], hist):
+        assert a == pytest.approx(b, rel=1e-6)
