@@ -435,7 +435,9 @@ class SWEMTrainer:
         return losses, results
 
     def _math(self):
-        return ops.conv_math((2,)) if self.amp else contextlib.nullcontext()
+        """Conv math modes of the step: config.AMP = plain bf16 operands; otherwise the fp32-level modes only (fp32 MFMA and
+        bf16x6) -- the 16-bit-operand bf16x3 mode the inference tuner may pick is kept out of the gradient path."""
+        return ops.conv_math((2,)) if self.amp else ops.conv_math((0, 1))
 
     def _capture(self, cur_iter):
         """One HIP graph per part: `_pre` and `_post` on the main stream, one graph per lane on the lane's own (probed)
