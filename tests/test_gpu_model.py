@@ -475,3 +475,24 @@ def test_sequence_pool_equals_sequential_evaluation(lib):
 def synth_clip(t, h, w, n, seed):
     from swem_amd import synth
     return synth.make_clip(t=t, h=h, w=w, n_obj=n, out_hw=(h, w), seed=seed)
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself(lib):
+    """`python bench.py --gpus 2` WITHOUT torchrun must come back with n_gpus = 2 from a real two-rank process group (the
+    parent starts the ranks as child processes before it touches the GPU).  Rehearsed on this one-GPU box: both ranks share
+    device 0 and the counter reduction runs over gloo (SWEM_DIST_BACKEND); on an 8-GPU node the same launch uses RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    env = dict(os.environ, SWEM_DIST_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
+                          '--seqs', '1', '--no-autotune', '--no-cpu-baseline', '--no-em'], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['scaling'] == 'weak'
+    assert line['config']['frames_per_step'] == 1 and line['value'] > 0
