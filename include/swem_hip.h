@@ -120,6 +120,25 @@ int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0,
                             const float *res, long long res_bs, float *y, int Cout, int KH, int KW, int stride,
                             int pad, int flags, int plan, void *ws, size_t ws_bytes);
 
+/* The two convolutions with a FUSED OPERAND SPLIT of their output: besides y, the epilogue writes y's bf16 planes in the
+ * layout swem_split_bf16x3_f32 produces ([plane][Cout/8][M][8], M = B*Ho*Wo pixels, plane stride M*Cout elements), for the
+ * convolutions that consume y pre-split -- no split launch and no re-read of y per consumer.
+ *   planes       : planes of y, or NULL;  nplanes = 2 (hi, mid: every consumer runs bf16x3 / plain bf16) or 3
+ *   planes_relu  : planes of relu(y) (for a consumer that applies its input ReLU while splitting, networks.py:26-27), or NULL
+ * Bit-identical to swem_split_bf16x3_f32 on y.  Needs Cout % 8 == 0, not available with SWEM_CONV_GLU. */
+int swem_conv2d_nhwc_f32_planes(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
+                                long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
+                                const float *w, long long w_bs, const float *scale, const float *shift, const float *res,
+                                long long res_bs, float *y, int Cout, int KH, int KW, int stride, int pad, int flags,
+                                int plan, void *ws, size_t ws_bytes, void *planes, int nplanes, void *planes_relu,
+                                int nplanes_relu);
+int swem_conv2d_nhwc_bf16x3_planes(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1,
+                                   int c1, long long bs1, long long ps1, const void *x2, int c2, long long bs2,
+                                   long long ps2, int B, int H, int W, const void *w_bf16x3, const float *scale,
+                                   const float *shift, const float *res, long long res_bs, float *y, int Cout, int KH,
+                                   int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
+                                   void *planes, int nplanes, void *planes_relu, int nplanes_relu);
+
 /* ------------------------------------------------------------------------------------
  * Pointwise / pooling / resampling kernels.
  */

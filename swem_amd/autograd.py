@@ -259,7 +259,7 @@ def _planes_for(site, t, M, Cc):
     with its producer so that a later split records the hint."""
     if Cc % 8 == 0 and site in ops.SPLIT_HINTS:
         planes = torch.empty((3, M * Cc), dtype=torch.bfloat16, device=t.device)
-        t.__dict__['_swem_split'] = {False: planes}
+        t.__dict__['_swem_split'] = {False: (planes, 3)}
         return planes
     t.__dict__['_swem_site'] = site
     return None

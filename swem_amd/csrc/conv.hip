@@ -51,6 +51,12 @@ struct ConvP {
   int xpn;      // XCD partition of the N tiles (1, 2, 4, 8): see tile_coords
   int mt0;      // first M tile of this launch (the tail launch of a tail-split layer starts further down)
   int part_m0;  // first output row held by `partial` (rows are stored relative to it)
+  // Optional: the output's bf16 planes, written by the epilogue itself for the convolutions that will consume this tensor
+  // pre-split (the layout swem_split_bf16x3_f32 produces, [plane][Cout/8][M][8]): variant 0 = the planes of y, variant 1 =
+  // the planes of relu(y) (a consumer that applies its input ReLU while splitting).  NULL = not wanted.
+  unsigned short *ysp[2];
+  int ysp_npl[2];     // planes to write per variant: 2 (hi, mid: all consumers run bf16x3) or 3
+  long long ysp_ps;   // elements between the planes (M * Cout)
 };
 
 // One v_max_f32 per element.  fmaxf() costs two (hipcc first canonicalises the operand with v_max x,x), and in the fp32
@@ -105,6 +111,54 @@ __device__ __forceinline__ int tap_origin(const ConvP &p, int o) {
   return (p.flags & SWEM_CONV_DGRAD) ? o + p.pad : o * p.stride - p.pad;
 }
 
+// ---- output planes from the epilogue (fused operand split) ----------------------------------------------------------
+// A wave stages one 32-pixel x 32-channel tile of final outputs in its own slice of the (now idle) operand LDS as dwords
+// (hi | mid << 16), re-reads it as 16-byte runs of 8 channels and stores them into the [C/8][M][8] planes; a second pass
+// does the lo plane when three are wanted.  The split is bf16_split.h's (bit-identical to swem_split_bf16x3_f32).
+constexpr int PL_STRIDE = 36;                     // dwords per staged row: 16-byte aligned, conflict-free b128 reads
+constexpr int PL_BYTES = 32 * PL_STRIDE * 4;      // LDS bytes per wave
+__device__ __forceinline__ unsigned *planes_lds() {
+  extern __shared__ __attribute__((aligned(16))) char smem_pl[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  return reinterpret_cast<unsigned *>(smem_pl + wave * PL_BYTES);
+}
+__device__ __forceinline__ void split_bf16_3(float v, unsigned &hm, unsigned &lo) {
+  const unsigned h = pack_bf16(v, 0.f) & 0xffffu;
+  const float r1 = v - lo_f32(h);
+  const unsigned m = pack_bf16(r1, 0.f) & 0xffffu;
+  const float r2 = r1 - lo_f32(m);
+  hm = h | (m << 16);
+  lo = pack_bf16(r2, 0.f) & 0xffffu;
+}
+// Flush the staged tile (rows m_base + [0,32), channels n_base + [0,32)); pass 0 writes planes 0 and 1 from (hi | mid << 16)
+// dwords, pass 1 writes plane 2 from dwords holding lo in their low half.
+__device__ __forceinline__ void planes_flush(const ConvP &p, const unsigned *lds, unsigned short *dst, int m_base, int n_base,
+                                             int pass) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's staging writes have landed
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int id = lane + 64 * c, k = id >> 5, ml = id & 31;   // 8-channel group k of row ml: consecutive lanes = consecutive pixels
+    const int m = m_base + ml, n = n_base + 8 * k;
+    const uint4 a = *reinterpret_cast<const uint4 *>(lds + ml * PL_STRIDE + 8 * k);
+    const uint4 b = *reinterpret_cast<const uint4 *>(lds + ml * PL_STRIDE + 8 * k + 4);
+    if (m < p.M && n < p.Cout) {
+      unsigned short *q = dst + ((long long)(n >> 3) * p.M + m) * 8;
+      uint4 lo4 = make_uint4(__builtin_amdgcn_perm(a.y, a.x, 0x05040100), __builtin_amdgcn_perm(a.w, a.z, 0x05040100),
+                             __builtin_amdgcn_perm(b.y, b.x, 0x05040100), __builtin_amdgcn_perm(b.w, b.z, 0x05040100));
+      if (pass == 0) {
+        uint4 hi4 = make_uint4(__builtin_amdgcn_perm(a.y, a.x, 0x07060302), __builtin_amdgcn_perm(a.w, a.z, 0x07060302),
+                               __builtin_amdgcn_perm(b.y, b.x, 0x07060302), __builtin_amdgcn_perm(b.w, b.z, 0x07060302));
+        *reinterpret_cast<uint4 *>(q) = lo4;                    // plane 0: the low halves (hi terms)
+        *reinterpret_cast<uint4 *>(q + p.ysp_ps) = hi4;         // plane 1: the high halves (mid terms)
+      } else {
+        *reinterpret_cast<uint4 *>(q + 2 * p.ysp_ps) = lo4;     // plane 2
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // the reads are done before the next tile is staged
+}
+
 // Epilogue shared by both kernels: raw split-K partials, or scale/shift (+residual, ReLU) / GLU gate, NHWC stores.
 template <int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][WN], int m0, int n0, int wm, int wn,
@@ -150,18 +204,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][
       return;
     }
   }
+  const bool planes = p.ysp[0] || p.ysp[1];
+  unsigned *lds = nullptr;
+  if (planes) {
+    __syncthreads();   // every wave is done with the operand stages: the LDS is free for the plane staging
+    lds = planes_lds();
+  }
 #pragma unroll
   for (int jn = 0; jn < WN; ++jn) {
     const int n = ncol0 + 32 * jn + r;
-    if (n >= p.Ncols) continue;
-    const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
+    const bool nin = n < p.Ncols;
+    const float sc = (nin && p.scale) ? p.scale[n] : 1.f, sh = (nin && p.shift) ? p.shift[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         int m = mrow0 + 32 * i + acc_row(e, h);
-        if (m < p.M) {
-          float v = acc[i][jn][e] * sc + sh;
+        float v = acc[i][jn][e] * sc + sh;
+        if (m < p.M && nin) {
           if (p.res) {
             int b = m / HoWo;
             const float rv = p.res[(long long)b * p.res_bs + (long long)(m - b * HoWo) * p.Cout + n];
@@ -170,7 +230,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][
           if (relu_out) v = fmaxf(v, 0.f);
           p.y[(long long)m * p.Cout + n] = v;
         }
+        acc[i][jn][e] = v;     // the final value, kept for the planes below
       }
+      if (planes) {
+#pragma unroll
+        for (int var = 0; var < 2; ++var) {
+          if (!p.ysp[var]) continue;
+          unsigned lo[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            unsigned hm;
+            split_bf16_3(var ? relu1(acc[i][jn][e]) : acc[i][jn][e], hm, lo[e]);
+            lds[acc_row(e, h) * PL_STRIDE + r] = hm;
+          }
+          planes_flush(p, lds, p.ysp[var], mrow0 + 32 * i, ncol0 + 32 * jn, 0);
+          if (p.ysp_npl[var] == 3) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lds[acc_row(e, h) * PL_STRIDE + r] = lo[e];
+            planes_flush(p, lds, p.ysp[var], mrow0 + 32 * i, ncol0 + 32 * jn, 1);
+          }
+        }
+      }
+    }
   }
 }
 
@@ -791,15 +872,15 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP &p, f32x4v (&acc)[TM
 #pragma unroll
   for (int j = 0; j < TN2; ++j) {
     const int n = ncol0 + 16 * j + col;
-    if (n >= p.Ncols) continue;
-    const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
+    const bool nin = n < p.Ncols;
+    const float sc = (nin && p.scale) ? p.scale[n] : 1.f, sh = (nin && p.shift) ? p.shift[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM2; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = mrow0 + 16 * i + 4 * rg + e;
-        if (m < p.M) {
-          float v = acc[i][j][e] * sc + sh;
+        float v = acc[i][j][e] * sc + sh;
+        if (m < p.M && nin) {
           if (p.res) {
             const int b = m / HoWo;
             const float rv = p.res[(long long)b * p.res_bs + (long long)(m - b * HoWo) * p.Cout + n];
@@ -808,8 +889,45 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP &p, f32x4v (&acc)[TM
           if (relu_out) v = fmaxf(v, 0.f);
           p.y[(long long)m * p.Cout + n] = v;
         }
+        acc[i][j][e] = v;
       }
   }
+  if (!(p.ysp[0] || p.ysp[1])) return;
+  // output planes: 32 x 32 sub-tiles (2 x 2 accumulator tiles) through the wave's LDS slice
+  static_assert(TM2 % 2 == 0 && TN2 % 2 == 0, "the plane staging works on 32 x 32 sub-tiles");
+  __syncthreads();
+  unsigned *lds = planes_lds();
+#pragma unroll
+  for (int i0 = 0; i0 < TM2; i0 += 2)
+#pragma unroll
+    for (int j0 = 0; j0 < TN2; j0 += 2)
+#pragma unroll
+      for (int var = 0; var < 2; ++var) {
+        if (!p.ysp[var]) continue;
+        unsigned lo[16];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = acc[i0 + ii][j0 + jj][e];
+              unsigned hm;
+              split_bf16_3(var ? relu1(v) : v, hm, lo[(ii * 2 + jj) * 4 + e]);
+              lds[(16 * ii + 4 * rg + e) * PL_STRIDE + 16 * jj + col] = hm;
+            }
+        planes_flush(p, lds, p.ysp[var], mrow0 + 16 * i0, ncol0 + 16 * j0, 0);
+        if (p.ysp_npl[var] == 3) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                lds[(16 * ii + 4 * rg + e) * PL_STRIDE + 16 * jj + col] = lo[(ii * 2 + jj) * 4 + e];
+          planes_flush(p, lds, p.ysp[var], mrow0 + 16 * i0, ncol0 + 16 * j0, 1);
+        }
+      }
 }
 
 // M16: the products run on v_mfma_f32_16x16x32_bf16 (one k-block = one MFMA k-step) instead of 32x32x16: the same cycles
@@ -1164,6 +1282,25 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
     if (p.flags & SWEM_CONV_RELU_OUT) v = relu4(v);
   }
   *reinterpret_cast<float4 *>(p.y + (long long)m * p.Cout + co) = v;
+  if (!(p.ysp[0] || p.ysp[1]) || glu) return;
+  // output planes (fused operand split): an even lane and its odd neighbour hold the 8 channels of one 16-byte run
+  // (Cout / 4 is even -- Cout % 8 == 0 is the planes' precondition -- so a pair never straddles two pixels)
+#pragma unroll
+  for (int var = 0; var < 2; ++var) {
+    if (!p.ysp[var]) continue;
+    const float4 q = var ? relu4(v) : v;
+    uint2 h, mm, l;
+    split3(q, h, mm, l);
+    const uint2 h2 = make_uint2(__shfl_down(h.x, 1), __shfl_down(h.y, 1));
+    const uint2 m2 = make_uint2(__shfl_down(mm.x, 1), __shfl_down(mm.y, 1));
+    const uint2 l2 = make_uint2(__shfl_down(l.x, 1), __shfl_down(l.y, 1));
+    if ((co & 4) == 0) {
+      unsigned short *d = p.ysp[var] + ((long long)(co >> 3) * p.M + m) * 8;
+      *reinterpret_cast<uint4 *>(d) = make_uint4(h.x, h.y, h2.x, h2.y);
+      *reinterpret_cast<uint4 *>(d + p.ysp_ps) = make_uint4(mm.x, mm.y, m2.x, m2.y);
+      if (p.ysp_npl[var] == 3) *reinterpret_cast<uint4 *>(d + 2 * p.ysp_ps) = make_uint4(l.x, l.y, l2.x, l2.y);
+    }
+  }
 }
 
 struct Plan {
@@ -1230,12 +1367,20 @@ int launch_bf3(const ConvP &p, dim3 grid, hipStream_t st) {
   return SWEM_OK;
 }
 
+// dynamic LDS of a launch: the operand stages, or -- where a small tile's stages are smaller -- the plane staging of the
+// epilogue (one PL_BYTES slice per wave), when output planes are wanted
+static inline size_t lds_with_planes(const ConvP &p, size_t lds, int nwaves) {
+  const size_t need = (p.ysp[0] || p.ysp[1]) ? (size_t)nwaves * PL_BYTES : 0;
+  return lds < need ? need : lds;
+}
+
 template <int WM, int WN, int NST, int NW, bool M16 = false, int KG = 4>
 int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st) {
   if (p.nplanes == 1) {   // plain bf16 (one plane, one product): a third of the LDS, the same tiles
     constexpr size_t lds1 = NST * 1 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;
     SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG>), lds1);
-    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG>), grid, dim3(64 * NW), lds1, st, p);
+    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG>), grid, dim3(64 * NW),
+                       lds_with_planes(p, lds1, NW), st, p);
     return SWEM_OK;
   }
   if (p.nplanes == 2) {   // "bf16x3": hi and mid planes, three products (hi.hi + hi.mid + mid.hi): two thirds of the LDS
@@ -1272,7 +1417,7 @@ template <int WM, int WN, bool DB>
 int launch(const ConvP &p, dim3 grid, hipStream_t st) {
   constexpr size_t lds = (DB ? 2 : 1) * KQ * (64 * WM + 1 + 64 * WN + 1) * sizeof(float4);
   SWEM_ALLOW_LDS((conv_igemm_kernel<WM, WN, DB>), lds);
-  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, DB>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, DB>), grid, dim3(256), lds_with_planes(p, lds, 4), st, p);
   return SWEM_OK;
 }
 
@@ -1347,11 +1492,57 @@ extern "C" size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, 
   return (size_t)pl.nsplit * M * Ncols * sizeof(float);
 }
 
+namespace {
+struct PlaneOut {
+  void *planes[2];
+  int npl[2];
+};
+// validate the optional output planes and put them into the launch parameters (after p.M / p.Cout are set)
+int set_planes(ConvP &p, const PlaneOut *po, bool glu, const char *who) {
+  p.ysp[0] = p.ysp[1] = nullptr;
+  p.ysp_npl[0] = p.ysp_npl[1] = 3;
+  p.ysp_ps = (long long)p.M * p.Cout;
+  if (!po || (!po->planes[0] && !po->planes[1])) return SWEM_OK;
+  SWEM_REQUIRE(!glu && p.Cout % 8 == 0, SWEM_E_SHAPE, "%s: output planes need Cout %% 8 == 0 and no GLU", who);
+  for (int v = 0; v < 2; ++v) {
+    SWEM_REQUIRE(!po->planes[v] || po->npl[v] == 2 || po->npl[v] == 3, SWEM_E_ARG, "%s: 2 or 3 output planes", who);
+    p.ysp[v] = static_cast<unsigned short *>(po->planes[v]);
+    p.ysp_npl[v] = po->npl[v];
+  }
+  return SWEM_OK;
+}
+int conv2d_f32_impl(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1, long long bs1,
+                    const float *x2, int c2, long long bs2, int B, int H, int W, const float *w, long long w_bs,
+                    const float *scale, const float *shift, const float *res, long long res_bs, float *y, int Cout, int KH,
+                    int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes, const PlaneOut *po);
+}  // namespace
+
 extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
                                     long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
                                     const float *w, long long w_bs, const float *scale, const float *shift,
                                     const float *res, long long res_bs, float *y, int Cout, int KH, int KW, int stride,
                                     int pad, int flags, int plan, void *ws, size_t ws_bytes) {
+  return conv2d_f32_impl(stream, x0, c0, bs0, x1, c1, bs1, x2, c2, bs2, B, H, W, w, w_bs, scale, shift, res, res_bs, y, Cout,
+                         KH, KW, stride, pad, flags, plan, ws, ws_bytes, nullptr);
+}
+
+extern "C" int swem_conv2d_nhwc_f32_planes(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
+                                           long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
+                                           const float *w, long long w_bs, const float *scale, const float *shift,
+                                           const float *res, long long res_bs, float *y, int Cout, int KH, int KW,
+                                           int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
+                                           void *planes, int nplanes, void *planes_relu, int nplanes_relu) {
+  PlaneOut po{{planes, planes_relu}, {nplanes, nplanes_relu}};
+  return conv2d_f32_impl(stream, x0, c0, bs0, x1, c1, bs1, x2, c2, bs2, B, H, W, w, w_bs, scale, shift, res, res_bs, y, Cout,
+                         KH, KW, stride, pad, flags, plan, ws, ws_bytes, &po);
+}
+
+namespace {
+int conv2d_f32_impl(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1, long long bs1,
+                    const float *x2, int c2, long long bs2, int B, int H, int W,
+                    const float *w, long long w_bs, const float *scale, const float *shift, const float *res,
+                    long long res_bs, float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan, void *ws,
+                    size_t ws_bytes, const PlaneOut *po) {
   SWEM_REQUIRE(x0 && w && y, SWEM_E_ARG, "conv2d: null pointer");
   if (!x1) c1 = 0;
   if (!x2) c2 = 0;
@@ -1387,6 +1578,7 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;
   p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.xpn = 1;
+  if (int prc = set_planes(p, po, glu, "conv2d")) return prc;
   if (pl.nsplit > 1) {
     size_t need = (size_t)pl.nsplit * M * p.Ncols * sizeof(float);
     SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d: workspace %zu < %zu bytes", ws_bytes, need);
@@ -1436,6 +1628,7 @@ extern "C" int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long 
   }
   return SWEM_OK;
 }
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
@@ -1472,12 +1665,39 @@ extern "C" int swem_split_bf16x3_f32(void *stream, const float *x, void *out, lo
   return SWEM_OK;
 }
 
+namespace {
+int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1, int c1,
+                       long long bs1, long long ps1, const void *x2, int c2, long long bs2, long long ps2, int B, int H, int W,
+                       const void *w_bf16x3, const float *scale, const float *shift, const float *res, long long res_bs,
+                       float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
+                       const PlaneOut *po);
+}
 extern "C" int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0, long long ps0,
                                        const void *x1, int c1, long long bs1, long long ps1, const void *x2, int c2,
                                        long long bs2, long long ps2, int B, int H, int W, const void *w_bf16x3,
                                        const float *scale, const float *shift, const float *res, long long res_bs,
                                        float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan,
                                        void *ws, size_t ws_bytes) {
+  return conv2d_bf16x3_impl(stream, x0, c0, bs0, ps0, x1, c1, bs1, ps1, x2, c2, bs2, ps2, B, H, W, w_bf16x3, scale, shift, res,
+                            res_bs, y, Cout, KH, KW, stride, pad, flags, plan, ws, ws_bytes, nullptr);
+}
+extern "C" int swem_conv2d_nhwc_bf16x3_planes(void *stream, const void *x0, int c0, long long bs0, long long ps0,
+                                              const void *x1, int c1, long long bs1, long long ps1, const void *x2, int c2,
+                                              long long bs2, long long ps2, int B, int H, int W, const void *w_bf16x3,
+                                              const float *scale, const float *shift, const float *res, long long res_bs,
+                                              float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan,
+                                              void *ws, size_t ws_bytes, void *planes, int nplanes, void *planes_relu,
+                                              int nplanes_relu) {
+  PlaneOut po{{planes, planes_relu}, {nplanes, nplanes_relu}};
+  return conv2d_bf16x3_impl(stream, x0, c0, bs0, ps0, x1, c1, bs1, ps1, x2, c2, bs2, ps2, B, H, W, w_bf16x3, scale, shift, res,
+                            res_bs, y, Cout, KH, KW, stride, pad, flags, plan, ws, ws_bytes, &po);
+}
+namespace {
+int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1, int c1,
+                       long long bs1, long long ps1, const void *x2, int c2, long long bs2, long long ps2, int B, int H, int W,
+                       const void *w_bf16x3, const float *scale, const float *shift, const float *res, long long res_bs,
+                       float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
+                       const PlaneOut *po) {
   SWEM_REQUIRE(x0 && w_bf16x3 && y, SWEM_E_ARG, "conv2d_bf16x3: null pointer");
   if (!x1) c1 = 0;
   if (!x2) c2 = 0;
@@ -1523,6 +1743,7 @@ extern "C" int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, lon
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;
   p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.xpn = 1;
+  if (int prc = set_planes(p, po, glu, "conv2d_bf16x3")) return prc;
   if (pl.nsplit > 1) {
     size_t need = (size_t)pl.nsplit * M * p.Ncols * sizeof(float);
     SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_bf16x3: workspace %zu < %zu bytes", ws_bytes, need);
@@ -1594,3 +1815,4 @@ extern "C" int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, lon
   }
   return SWEM_OK;
 }
+}  // namespace

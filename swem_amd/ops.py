@@ -20,6 +20,9 @@ CONV_TRACE = None
 # keeps the fastest (passed to the library as the `plan` hint).  Off by default: results never depend on it beyond
 # fp32 summation order, but tuning costs a few milliseconds per layer shape.
 AUTOTUNE = False
+# conv epilogues write the bf16 planes of outputs that later convolutions consume pre-split (learned per layer on the first
+# frames: SPLIT_HINTS) instead of a separate split launch per consumer tensor
+FUSE_SPLIT = True
 _CONV_PLANS = {}      # layer signature + input shape -> plan hint (shared by every model instance in the process)
 # math modes the conv tuner may choose from: 0 = fp32 MFMA, 1 = bf16x6 (exact 3-way bf16 split, six products: fp32-level
 # error), 3 = bf16x3 (hi + mid planes, the three products above 2^-16: 16 significant bits per operand, half the MFMA work
@@ -196,24 +199,29 @@ def _chk_src(t):
     return t
 
 
-def presplit(t, relu=False):
-    """Three bf16 planes, each [C/8][npix][8], of an NHWC fp32 activation with t = hi + mid + lo (of relu(t) if asked),
-    computed once per tensor and cached on it: conv inputs are never modified after they are produced.  npix covers the
-    tensor's storage range (a batch stride larger than one image, as match's mem_out has, is kept)."""
+def presplit(t, relu=False, nplanes=3):
+    """bf16 planes, each [C/8][npix][8], of an NHWC fp32 activation with t = hi + mid + lo (of relu(t) if asked), computed
+    once per tensor and cached on it: conv inputs are never modified after they are produced.  npix covers the tensor's
+    storage range (a batch stride larger than one image, as match's mem_out has, is kept).  nplanes: how many of the three
+    the caller reads (2 for a bf16x3 / plain-bf16 consumer).  A producer that knows its consumers writes the planes itself
+    (conv2d's epilogue, the frozen-BN stages of the training step): the request is recorded under the producer's site so
+    that it can do so from the next frame / step on."""
     cache = t.__dict__.setdefault('_swem_split', {})
-    sp = cache.get(relu)
-    if sp is None:
-        site = t.__dict__.get('_swem_site')
-        if site is not None and not relu:
-            SPLIT_HINTS.add(site)          # the producer of this tensor can write the planes itself next time
+    ent = cache.get(relu)
+    site = t.__dict__.get('_swem_site')
+    if site is not None:
+        h = SPLIT_HINTS.setdefault(site, {})
+        if h.get(relu, 0) < nplanes:
+            h[relu] = nplanes              # the producer of this tensor can write the planes itself next time
+    if ent is None or ent[1] < nplanes:
         B, H, W, Cc = t.shape
         if B > 1 and t.stride(0) % Cc:
             raise _lib.SwemHipError('presplit: batch stride must be a multiple of the channel count')
         npix = (B - 1) * (t.stride(0) // Cc) + H * W if B > 1 else H * W
         sp = torch.empty((3, npix * Cc), dtype=torch.bfloat16, device=t.device)
         _lib.call('swem_split_bf16x3_f32', _stream(), t.data_ptr(), sp.data_ptr(), npix, Cc, int(relu))
-        cache[relu] = sp
-    return sp
+        ent = cache[relu] = (sp, 3)
+    return ent[0]
 
 
 DGRAD, DGRAD_EH, DGRAD_EW, MASK_POS = 8, 16, 32, 64
@@ -264,27 +272,44 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     pipe_ok = all(s_.shape[3] % 32 == 0 for s_ in srcs)      # (the register-staged kernels' condition, conv.hip)
     presplit_ok = pack.w3 is not None and pipe_ok
 
+    # the output's own bf16 planes, if the convolutions that consumed this layer's output on an earlier frame split it:
+    # the epilogue writes them (fused operand split: no split launch, no re-read of y)
+    site = ('conv', id(pack), B, H, W, flags)
+    want = SPLIT_HINTS.get(site) if (FUSE_SPLIT and dgrad is None and not pack.glu and pack.cout % 8 == 0) else None
+    planes = {}
+
     def launch(plan, fresh=False):
         wsb = _lib.query('swem_conv2d_workspace', B, H, W, cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad,
                          flags, plan)
         ws = workspace(wsb, x0.device) if wsb else None
+        pargs = [0, 3, 0, 3]
+        if want:
+            for relu_v, npl in want.items():
+                sp = planes.get(relu_v)
+                if sp is None:
+                    sp = planes[relu_v] = (torch.empty((3, B * Ho * Wo * pack.cout), dtype=torch.bfloat16,
+                                                       device=x0.device), npl)
+                pargs[2 * int(relu_v)], pargs[2 * int(relu_v) + 1] = sp[0].data_ptr(), npl
         if (plan >> 16) & 3 and presplit_ok:
-            # bf16x6 math: sources split once per tensor (input ReLU folded into the split), filters split at pack time
+            # bf16 math: sources split once per tensor (input ReLU folded into the split), filters split at pack time
+            need = 3 if (plan >> 16) & 3 == 1 else 2
             sargs = []
             for i, s_ in enumerate(srcs):
-                if fresh:
+                # (tuning charges a candidate the split of its inputs -- except inputs a conv epilogue produces: those arrive
+                # with their planes from the second frame on, FUSE_SPLIT)
+                if fresh and not (FUSE_SPLIT and s_.__dict__.get('_swem_site', (None,))[0] == 'conv'):
                     s_.__dict__.pop('_swem_split', None)
-                sp = presplit(s_, relu_in)
+                sp = presplit(s_, relu_in, need)
                 sargs += [sp.data_ptr(), s_.shape[3], args[3 * i + 2], sp.stride(0)]
             for _ in range(3 - len(srcs)):
                 sargs += [0, 0, 0, 0]
-            _lib.call('swem_conv2d_nhwc_bf16x3', _stream(), *sargs, B, H, W, pack.w3.data_ptr(), _ptr(pack.scale),
+            _lib.call('swem_conv2d_nhwc_bf16x3_planes', _stream(), *sargs, B, H, W, pack.w3.data_ptr(), _ptr(pack.scale),
                       _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw,
-                      pack.stride, pack.pad, flags & ~RELU_IN, plan, _ptr(ws), wsb)
+                      pack.stride, pack.pad, flags & ~RELU_IN, plan, _ptr(ws), wsb, *pargs)
             return
-        _lib.call('swem_conv2d_nhwc_f32', _stream(), *args, B, H, W, pack.w.data_ptr(), 0, _ptr(pack.scale),
+        _lib.call('swem_conv2d_nhwc_f32_planes', _stream(), *args, B, H, W, pack.w.data_ptr(), 0, _ptr(pack.scale),
                   _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw, pack.stride,
-                  pack.pad, flags, plan, _ptr(ws), wsb)
+                  pack.pad, flags, plan, _ptr(ws), wsb, *pargs)
 
     sig = (cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags, B, H, W) + _PLAN_TAG
     explicit = plan is not None
@@ -298,6 +323,10 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     launch(plan)
+    if out is None:
+        y.__dict__['_swem_site'] = site
+        if planes:
+            y.__dict__['_swem_split'] = dict(planes)
     if CONV_TRACE is not None:
         e1.record()
         ncols = pack.cout * (2 if pack.glu else 1)
@@ -313,7 +342,8 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
 
 
 _PLAN_TAG = ()
-SPLIT_HINTS = set()   # producer sites (autograd stages) whose output was later split: they write the planes themselves
+# producer site -> {relu variant: planes wanted}: outputs that were later split; the producer writes the planes itself
+SPLIT_HINTS = {}
 
 
 class conv_math:

@@ -271,6 +271,45 @@ def test_conv2d_plain_bf16_mode(lib, plan):
     assert 1e-5 < err < 1e-2, err             # really one bf16 product (not the exact six), and no worse than bf16
 
 
+@pytest.mark.parametrize('plan', [0x00011, 0x00022, 0x00211, 0x10021, 0x10022, 0x10321, 0x30011, 0x30021, 0x30022, 0x230022,
+                                  0x430011, 0x430021, 0x630022, 0x30221, 0x830022, 0x4030021, 0x8030022],
+                         ids=lambda p: '%#x' % p)
+def test_conv2d_fused_output_planes(lib, plan):
+    """The conv epilogues (32x32 and 16x16 accumulator layouts, the split-K reduce kernel, the tail split; fp32, bf16x6 and
+    bf16x3 kernels) write the output's bf16 planes themselves once a consumer has asked for them (ops.SPLIT_HINTS): y is
+    unchanged and the planes are BIT-IDENTICAL to swem_split_bf16x3_f32 on y -- both variants (planes of y, planes of
+    relu(y)), two or three planes."""
+    g = torch.Generator().manual_seed(81)
+    B, Cin, H, W, Cout = 2, 160, 21, 37, 192
+    x = nhwc(torch.randn(B, Cin, H, W, generator=g) * 3)
+    res = nhwc(torch.randn(B, Cout, H, W, generator=g))
+    pack = ops.pack_conv((torch.randn(Cout, Cin, 3, 3, generator=g) * 0.03).to(DEV), (torch.randn(Cout, generator=g) * 0.1).to(DEV))
+    ops.SPLIT_HINTS.clear()
+    y0 = ops.conv2d([x], pack, relu_in=True, residual=res, plan=plan)
+    assert '_swem_split' not in y0.__dict__
+    M = B * H * W
+
+    def split(t, relu):
+        sp = torch.empty((3, M * Cout), dtype=torch.bfloat16, device=DEV)
+        lib_call = __import__('swem_amd')._lib.call
+        lib_call('swem_split_bf16x3_f32', ops._stream(), t.data_ptr(), sp.data_ptr(), M, Cout, int(relu))
+        return sp
+    try:
+        ops.SPLIT_HINTS[y0._swem_site] = {False: 3, True: 2}
+        y1 = ops.conv2d([x], pack, relu_in=True, residual=res, plan=plan)
+        assert torch.equal(y1, y0)
+        got = y1.__dict__['_swem_split']
+        assert got[False][1] == 3 and got[True][1] == 2
+        assert torch.equal(got[False][0].view(torch.int16), split(y0, False).view(torch.int16))
+        assert torch.equal(got[True][0][:2].view(torch.int16), split(y0, True)[:2].view(torch.int16))
+        # a consumer finds them (no split launch), one that needs the third plane of the relu variant re-splits
+        fused_relu = got[True][0]
+        assert ops.presplit(y1, False, 3) is got[False][0] and ops.presplit(y1, True, 2) is fused_relu
+        assert ops.presplit(y1, True, 3) is not fused_relu
+    finally:
+        ops.SPLIT_HINTS.clear()
+
+
 @pytest.mark.parametrize('plan', [0x30011, 0x30021, 0x30022, 0x130021, 0x230022, 0x430011, 0x430021, 0x630022, 0x30221, 0x830022,
                                   0x930022, 0x4030021], ids=lambda p: '%#x' % p)
 def test_conv2d_bf16x3_mode(lib, plan):
