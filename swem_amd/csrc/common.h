@@ -75,3 +75,22 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- debug stamps (-DSWEM_EM_STAMPS builds only; see em.hip) ---------------------------------------------------------
+#ifdef SWEM_EM_STAMPS
+extern long long *g_swem_stamps;
+extern int g_swem_stamp_slot;
+#define STAMP_ARG , long long *stamps
+#define STAMP_PASS , (g_swem_stamps ? g_swem_stamps + 16 * (g_swem_stamp_slot++) : nullptr)
+#define STAMP(i)                                                                                       \
+  do {                                                                                                 \
+    if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {         \
+      stamps[2 * (i)] = (long long)__builtin_amdgcn_s_memtime();                                       \
+      stamps[2 * (i) + 1] = (long long)__builtin_amdgcn_s_memrealtime();                               \
+    }                                                                                                  \
+  } while (0)
+#else
+#define STAMP_ARG
+#define STAMP_PASS
+#define STAMP(i)
+#endif

@@ -937,7 +937,8 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP &p, f32x4v (&acc)[TM
 // KG = k/8 groups per k-block: 4 (32 k, the default) or 2 (16 k: half the LDS per stage -- the 128x128 tile then fits three
 // blocks of four waves per CU instead of one block; a k-block is half of a (channel block, tap) cell of the K order).
 template <int WM, int WN, int NST, int NW, bool M16, int NPL, int KG = 4>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kernel(ConvP p) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kernel(ConvP p STAMP_ARG) {
+  STAMP(0);
   static_assert(KG == 4 || (KG == 2 && !M16 && NW == 4), "16-k blocks: four waves, 32x32x16 MFMA");
   // block tile 64WM x 64WN, NW waves as an (NW/2) x 2 grid, each owning TM x TN 32x32 accumulator tiles
   constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -1137,19 +1138,27 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   }
   w_base = (unsigned)(kb_begin32 * 4 + g) * wgroup;
   set_tap(q);
+  STAMP(1);
+  // wait until at most `c` of this wave's k-block transfers (NDMA instructions each) are still in flight
+  auto wait_blocks = [&](int c) __attribute__((always_inline)) {
+    static_assert(3 * NDMA <= 63, "vmcnt is a 6-bit counter");
+    if (c <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (c == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    else if (c == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");
+  };
   issue(0);
-  if (NST == 3) {
-    if (kb_begin + 1 < kb_end) {
+  int issued = 1;   // k-blocks handed to the DMA so far (relative to kb_begin)
+#pragma unroll
+  for (int d = 1; d < NST - 1; ++d)
+    if (kb_begin + d < kb_end) {
       advance(q);
-      issue(1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      issue(d);
+      ++issued;
     }
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  wait_blocks(issued - 1);   // block 0 has landed; the younger ones may stay in flight
   __builtin_amdgcn_s_barrier();
+  STAMP(2);
   int st = 0;
   for (int kb = kb_begin; kb < kb_end; ++kb) {
     const bool ahead = kb + NST - 1 < kb_end;
@@ -1219,15 +1228,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
           }
       }
     }
-    // block kb+1 must have landed (this wave's share); with three stages block kb+2 may stay in flight
-    if (NST == 3 && ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // block kb+1 must have landed (this wave's share); the blocks behind it (up to kb+NST-1) may stay in flight
+    {
+      const int last = min(kb + NST - 1, kb_end - 1);   // youngest block issued so far
+      wait_blocks(last - (kb + 1));
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of stage st are done
     __builtin_amdgcn_s_barrier();
     st = st == NST - 1 ? 0 : st + 1;
   }
+  STAMP(3);
   if constexpr (M16) conv_epilogue16<2 * TM, 2 * TN>(p, acc16, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
   else conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, r, h);
+  STAMP(4);
+#ifdef SWEM_EM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(5);
+#endif
 }
 
 // Reduce split-K partials in z order and apply the same epilogue.  One thread per 4 output channels.
@@ -1380,19 +1397,24 @@ int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st) {
     constexpr size_t lds1 = NST * 1 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;
     SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG>), lds1);
     hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG>), grid, dim3(64 * NW),
-                       lds_with_planes(p, lds1, NW), st, p);
+                       lds_with_planes(p, lds1, NW), st, p STAMP_PASS);
     return SWEM_OK;
   }
   if (p.nplanes == 2) {   // "bf16x3": hi and mid planes, three products (hi.hi + hi.mid + mid.hi): two thirds of the LDS
     constexpr size_t lds2 = NST * 2 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;
     SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 2, KG>), lds2);
-    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 2, KG>), grid, dim3(64 * NW), lds2, st, p);
+    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 2, KG>), grid, dim3(64 * NW), lds2, st, p STAMP_PASS);
     return SWEM_OK;
   }
-  constexpr size_t lds = NST * 3 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;  // NST stages x 3 planes
-  SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 3, KG>), lds);
-  hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 3, KG>), grid, dim3(64 * NW), lds, st, p);
-  return SWEM_OK;
+  if constexpr (NST <= 3) {
+    constexpr size_t lds = NST * 3 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;  // NST stages x 3 planes
+    SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 3, KG>), lds);
+    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 3, KG>), grid, dim3(64 * NW), lds, st, p STAMP_PASS);
+    return SWEM_OK;
+  } else {
+    swem_set_error("conv2d_bf16x3: a four-stage ring needs at most two planes");
+    return SWEM_E_ARG;
+  }
 }
 
 // variant (plan bits 20-23): 0 = the tile's default; 1 = three LDS stages instead of two (or two instead of three);
@@ -1400,7 +1422,19 @@ int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st) {
 // 16x16x32 MFMA shape
 template <int WM, int WN>
 int launch_bf3s(const ConvP &p, dim3 grid, hipStream_t st, int variant) {
+  // deeper rings (round 2): with two planes a stage is 33 KB for the 128x128 tile, so FOUR stages fit; the k-loop of every
+  // tile was bound by the L2 / Infinity-Cache -> LDS latency of the one or two k-blocks in flight (in-kernel stamps,
+  // tools/conv_stamps.py: 2600 cycles per k-block against 768 of MFMA on the 128x128 tile, 830 against 192 on 64x64)
+  if (p.nplanes <= 2) {
+    if constexpr (WM == 2 && WN == 2) {
+      if (variant == 12) return launch_bf3s_n<2, 2, 4, 8>(p, grid, st);
+      if (variant == 13) return launch_bf3s_n<2, 2, 4, 8, true>(p, grid, st);
+    }
+    if (variant == 10) return launch_bf3s_n<WM, WN, 4, 4>(p, grid, st);
+    if (variant == 11) return launch_bf3s_n<WM, WN, 4, 4, true>(p, grid, st);
+  }
   if constexpr (WM == 2 && WN == 2) {
+    if (variant == 14) return launch_bf3s_n<2, 2, 3, 8, true>(p, grid, st);
     if (variant == 2) return launch_bf3s_n<2, 2, 2, 8>(p, grid, st);
     if (variant == 3) return launch_bf3s_n<2, 2, 3, 8>(p, grid, st);
     if (variant == 6) return launch_bf3s_n<2, 2, 2, 8, true>(p, grid, st);

@@ -31,28 +31,15 @@
 #include "../../include/swem_hip_train.h"
 #include "common.h"
 
-// Debug build only (-DSWEM_EM_STAMPS): in-kernel clock stamps of block 0 / wave 0, written to a buffer set by
-// swem_debug_set_stamps (tools/em_stamps.py).  The product build contains none of it.
+// Debug build only (-DSWEM_EM_STAMPS): in-kernel clock stamps of block 0 / wave 0 (common.h), written to a buffer set by
+// swem_debug_set_stamps (tools/em_stamps.py, tools/conv_stamps.py).  The product build contains none of it.
 #ifdef SWEM_EM_STAMPS
-static long long *g_stamps = nullptr;
-static int g_slot = 0;
+long long *g_swem_stamps = nullptr;
+int g_swem_stamp_slot = 0;
 extern "C" void swem_debug_set_stamps(void *p) {
-  g_stamps = static_cast<long long *>(p);
-  g_slot = 0;
+  g_swem_stamps = static_cast<long long *>(p);
+  g_swem_stamp_slot = 0;
 }
-#define STAMP_ARG , long long *stamps
-#define STAMP_PASS , (g_stamps ? g_stamps + 16 * (g_slot++) : nullptr)
-#define STAMP(i)                                                                                       \
-  do {                                                                                                 \
-    if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {         \
-      stamps[2 * (i)] = (long long)__builtin_amdgcn_s_memtime();                                       \
-      stamps[2 * (i) + 1] = (long long)__builtin_amdgcn_s_memrealtime();                               \
-    }                                                                                                  \
-  } while (0)
-#else
-#define STAMP_ARG
-#define STAMP_PASS
-#define STAMP(i)
 #endif
 
 namespace {

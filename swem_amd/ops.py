@@ -402,11 +402,18 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
                     base = wm | wn << 4 | ns << 8 | math << 16
                     cands.append(base | 1 << 20)
                     cands.append(base | 4 << 20)              # 16x16x32 MFMA shape
+                    if math != 1:                             # four-stage rings (one or two planes only)
+                        cands.append(base | 10 << 20)
+                        cands.append(base | 11 << 20)
                     if wm == 2 and wn == 2:
                         cands.append(base | 2 << 20)
                         cands.append(base | 6 << 20)
                         cands.append(base | 8 << 20)          # 16-k blocks: three blocks of four waves per CU
                         cands.append(base | 9 << 20)          # ... with three LDS stages (two blocks per CU)
+                        cands.append(base | 14 << 20)         # eight waves, 16x16x32 MFMA, three stages
+                        if math != 1:
+                            cands.append(base | 12 << 20)     # eight waves, four stages
+                            cands.append(base | 13 << 20)     # ... on the 16x16x32 MFMA
                     if ns == 1 and blocks > 256 and nkb >= 16:   # tail split: the last, partly filled round over K
                         for ts in (4, 8):
                             cands.append(base | ts << 24)

@@ -18,15 +18,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--objects', type=int, default=2)
     a = ap.parse_args()
-    csrc = os.path.join(ROOT, 'swem_amd', 'csrc')
-    out = os.path.join(ROOT, 'swem_amd', 'libswem_hip_stamps.so')      # (git-ignored; travels to the GPU box)
-    srcs = sorted(glob.glob(os.path.join(csrc, '*.hip')))
-    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
-        objs = [os.path.join(csrc, os.path.basename(s).replace('.hip', '.o')) for s in srcs if not s.endswith('em.hip')]
-        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
-                               '-DSWEM_EM_STAMPS', '-c', os.path.join(csrc, 'em.hip'), '-o', '/tmp/em_stamps.o'])
-        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out,
-                               '/tmp/em_stamps.o'] + objs)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import conv_stamps
+    out = conv_stamps.build()
     from swem_amd import _lib
     _lib.LIB_PATH = out
     import torch
