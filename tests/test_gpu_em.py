@@ -185,3 +185,42 @@ def test_config_b_size_properties(lib):
     mem = mem.cpu()                                                         # (N,P,V)
     tol = 1e-4 * float(allnu.abs().max())
     assert (mem >= lo[:, None] - tol).all() and (mem <= hi[:, None] + tol).all()
+
+
+@pytest.mark.parametrize('L', [64, 256])
+def test_packed_banks_equal_the_per_frame_packing(lib, L):
+    """swem_memorize_packed_f32 / swem_match_packed_f32 (the persistent packed banks SWEMCore keeps: no per-frame `cat` +
+    2 x `l2norm` of both banks, modules.py:282-283, 295-306) give BIT-IDENTICAL results to swem_memorize_f32 /
+    swem_match_f32, which normalise and pack inside the call -- over two frames, with the second memorize reading its
+    prior's normalised form from the pack the first one wrote."""
+    g = torch.Generator().manual_seed(300 + L)
+    h, w, C, V, N, T = 12, 20, 128, 128, 2, 3
+    P = h * w
+    x0, v0, m0 = H.em_inputs(h, w, C, V, N, g)
+    x1, v1, m1 = H.em_inputs(h, w, C, V, N, g)
+    x2, v2, m2 = H.em_inputs(h, w, C, V, N, g)
+    pm = lambda x: d(x[0].flatten(1).t())                                   # (P, C)
+    pv = lambda v: d(v[0].flatten(2).transpose(1, 2))                        # (N, P, V)
+    pk = lambda m: d(m[0].flatten(2))                                        # (N, 2, P)
+    torch.manual_seed(L)
+    kap, nu, zita = [d(t[0]) for t in O.random_init((1, N, 2, C, L), V)]
+    zita = zita[:, :, 0].contiguous()
+    # frame 0 -> 'first' bank, frame 1 -> 'update' bank, frame 2 -> 'update' again (prior read from the pack)
+    ref0 = ops.memorize(pm(x0), pv(v0), pk(m0), kap, nu, zita, T, 0.05)
+    ref1 = ops.memorize(pm(x1), pv(v1), pk(m1), *ref0, T, 0.05)
+    ref2 = ops.memorize(pm(x2), pv(v2), pk(m2), *ref1, T, 0.05)
+    pack = ops.new_pack(N, C, V, L, DEV)
+    got0 = ops.memorize(pm(x0), pv(v0), pk(m0), kap, nu, zita, T, 0.05, pack=pack, prior_packed=False, bank=0)
+    got1 = ops.memorize(pm(x1), pv(v1), pk(m1), *got0, T, 0.05, pack=pack, prior_packed=False, bank=1)
+    got2 = ops.memorize(pm(x2), pv(v2), pk(m2), *got1, T, 0.05, pack=pack, prior_packed=True, bank=1)
+    for a, b in zip(ref0 + ref1 + ref2, got0 + got1 + got2):
+        assert torch.equal(a, b)
+    qx, _ = H.structured_keys(P, C, 6, g)
+    mem_r, S_r = ops.match(d(qx), ref0[0], ref0[1], ref2[0], ref2[1], 64, 0.05)
+    mem_p, S_p = ops.match_packed(d(qx), pack, L, 64, 0.05)
+    assert torch.equal(mem_r, mem_p) and torch.equal(S_r, S_p)
+    # a pack rebuilt from the bases (SWEMCore.repack) is the pack memorize kept
+    pack2 = ops.new_pack(N, C, V, L, DEV)
+    ops.pack_bank(ref0[0], ref0[1], pack2, 0)
+    ops.pack_bank(ref2[0], ref2[1], pack2, 1)
+    assert torch.equal(pack2[0], pack[0]) and torch.equal(pack2[1], pack[1])
