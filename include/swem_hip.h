@@ -209,33 +209,41 @@ int swem_transpose_f32(void *stream, const float *in, float *out, int batch, int
  * Every operand is read as it lies in memory (pixel-major NHWC maps): there are no transposed copies.
  *   x     [P][C]      raw key of the frame, one row per pixel (reference x_t)
  *   v     [N][P][V]   value map per object, one row per pixel
- *   kn    [NK][C/4][L][4]  l2-normalised bases, channel-group major: kn[nk][c/4][l][c%4] = kappa[nk][c][l]/(|.|+eps)
- *                      (modules.py:115; the GEMM kernels put one base on every lane: this keeps their loads coalesced)
+ *   kp    [NK][C/4+1][L][4]  "packed keys": the key bases channel-group major, kp[nk][c/4][l][c%4] = kappa[nk][c][l]
+ *                      (the GEMM kernels put one base on every lane: this keeps their loads coalesced), plus one more
+ *                      group, kp[nk][C/4][l][0..3] = the squared norm of base l as C/32 partial sums (32 channels each).
+ *                      The E/W and affinity kernels apply l2norm (modules.py:7-9) with them as the rows enter the
+ *                      GEMM: kappa[:, l] / (|kappa[:, l]| + eps) -- so the M step, which writes both, is followed directly
+ *                      by the next E step with no normalising kernel in between
  *   z     [N][Pz][2L] responsibilities, one row per PIXEL: z[n][p][cls*L + l], Pz = swem_em_pad(P) rows per object
  *                      (rows >= P are never read by the M step)
- * Key dimension C = 64 or 128 for the E/W step (the reference default KEYDIM is 128, configs/config.py:52), C = 128 for
- * the M step and swem_memorize_*; L = 64, 128 or 256; V a multiple of 128.
+ * Key dimension C = 64 or 128 (the reference default KEYDIM is 128, configs/config.py:52); L = 64, 128 or 256; V a
+ * multiple of 32.
  */
 int swem_em_pad(int P); /* rows of a z buffer per object: P rounded up to a multiple of 128 */
-/* kn = l2-normalised bases in the layout above   modules.py:7-9,115 */
+/* l2norm over the channel dimension, modules.py:7-9: kn[nk][c/4][l][c%4] = kappa[nk][c][l] / (|kappa[nk][:][l]| + eps) */
 int swem_em_norm_bases_f32(void *stream, const float *kappa /*[NK][C][L]*/, float *kn, int NK, int C, int L);
-/* E and/or W step on one GEMM (they share x_t . l2norm(kappa)):
+/* the packed keys kp of bases in the reference's layout ((C/4 + 1) * L * 4 floats per nk) */
+int swem_em_pack_bases_f32(void *stream, const float *kappa /*[NK][C][L]*/, float *kp, int NK, int C, int L);
+/* E and/or W step on one GEMM (they share x_t . l2norm(kappa)); kp = packed keys (normalised in the kernel):
  *   do_w: weights = masks * (1 - p_own)          modules.py:93-110  -> w_out [NK][P] (optional)
  *   do_e: z = softmax((s - rowmax)/tau) * weights modules.py:112-120 -> z
  *         (weights = result of do_w when set, else w_in [NK][P]) */
-int swem_em_ew_f32(void *stream, const float *x, const float *kn, const float *masks /*[NK][P]*/,
+int swem_em_ew_f32(void *stream, const float *x, const float *kp, const float *masks /*[NK][P]*/,
                    const float *w_in, float *w_out, float *z, int N, int C, int P, int L, float tau, int do_w,
                    int do_e);
 /* M step, modules.py:122-127 (R = C rows, A = x [P][C], a_per_object = 0) and the value update
- * modules.py:164-165 (R = V rows, A = v [N][P][V], a_per_object = 1):
+ * modules.py:164-165 (R = V rows, A = v [N][P][V], a_per_object = 1), ONE launch:
  *   zita = zita_prev + sum_p z ;  out = (zita_prev * prev + A^T . z) / zita
- * prev/out [NK][R][L]; zita_prev/zita_out [NK][L]; kn_out (optional, key rows only) in the kn layout above.
- * The sum over P is split over pixel chunks and reduced in a fixed order (deterministic, no atomics). */
+ * prev/out [NK][R][L]; zita_prev/zita_out [NK][L]; kp_out (optional, key rows only): `out` as packed keys.
+ * A block owns 16 bases x 32 rows over ALL pixels and sums its waves in a fixed order (deterministic, no atomics, no
+ * partial sums in memory); R a multiple of 32.  The workspace query remains for callers of the earlier split-P version
+ * and returns 0; ws may be NULL. */
 size_t swem_em_mstep_workspace(int NK, int R, int P, int L);
 int swem_em_mstep_f32(void *stream, const float *A, int a_per_object, const float *z, const float *prev,
-                      const float *zita_prev, float *out, float *zita_out, float *kn_out, int NK, int R, int P,
+                      const float *zita_prev, float *out, float *zita_out, float *kp_out, int NK, int R, int P,
                       int L, void *ws, size_t ws_bytes);
-/* whole SWEMCore.swem() for one frame (modules.py:129-168): T x (E, M, W) + value update, three launches per iteration.
+/* whole SWEMCore.swem() for one frame (modules.py:129-168): T x (E, M, W) + value update, two launches per iteration.
  *   v [N][P][V] NHWC value map; masks [N][2][P]; *_prev = prior bases (random_init output on frame 0) */
 size_t swem_memorize_workspace(int N, int C, int V, int P, int L);
 int swem_memorize_f32(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
@@ -244,9 +252,9 @@ int swem_memorize_f32(void *stream, const float *x, const float *v, const float 
                       size_t ws_bytes);
 /* The same with matching's PACKED banks kept current, so that swem_match_packed_f32 needs no per-frame repacking
  * (modules.py:295-306 `get_mem` concatenates the banks on every frame; here the caller owns one persistent pack):
- *   mkn [2N][C/4][2L][4]  l2-normalised key bases of both banks, rows [0,L) 'first', [L,2L) 'update'
+ *   mkn [2N][C/4+1][2L][4] packed keys (see kp above) of both banks, rows [0,L) 'first', [L,2L) 'update'
  *   mvp [N][V][4L]        value bases, mvp[n][v][cls*2L + bank*L + l]
- * prior_packed != 0: the prior's normalised keys are READ from the pack's 'update' half (written there by the previous
+ * prior_packed != 0: the prior's packed keys are READ from the pack's 'update' half (written there by the previous
  * frame's call: kappa_prev must be that frame's kappa_out); the new bases are WRITTEN to bank `bank` (0 'first', 1 'update'). */
 int swem_memorize_packed_f32(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
                              const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out,

@@ -45,6 +45,7 @@ SIGNATURES = {
     'swem_transpose_f32': (_i, [_p, _p, _p, _i, _i, _i, _i]),
     'swem_em_pad': (_i, [_i]),
     'swem_em_norm_bases_f32': (_i, [_p, _p, _p, _i, _i, _i]),
+    'swem_em_pack_bases_f32': (_i, [_p, _p, _p, _i, _i, _i]),
     'swem_em_ew_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i]),
     'swem_em_mstep_workspace': (_sz, [_i, _i, _i, _i]),
     'swem_em_mstep_f32': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz]),

@@ -7,9 +7,10 @@
 #include "../../include/swem_hip.h"
 
 void swem_set_error(const char *fmt, ...);
-// em.hip: l2-normalise + transpose one bank of key bases into rows [out_off, out_off+L) of [NK][out_rows][C]
+// em.hip: one bank of key bases into rows [out_off, out_off+L) of a packed-keys image [NK][C/4][out_rows][4],
+// l2-normalised (normalize = 1) or as they are (0)
 int swem_norm_bases_into(void *stream, const float *kappa, float *kn, int NK, int C, int L, int out_rows,
-                         int out_off);
+                         int out_off, int normalize);
 // raise the dynamic-LDS limit of a kernel once (needed above 64 KiB)
 #define SWEM_ALLOW_LDS(kernel, bytes)                                                                   \
   do {                                                                                                  \

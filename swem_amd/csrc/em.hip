@@ -3,31 +3,32 @@
 // Data layout (device, fp32; NK = 2*N, class minor).  Every operand is read as it lies in memory: no transposed copies.
 //   x  [P][C]            raw key, one row per pixel          (reference x_t; NHWC feature map as the encoder wrote it)
 //   v  [N][P][V]         value map per object, pixel-major   (NHWC)
-//   kn [NK][C/4][R][4]   l2-normalised bases, channel-group major; a bank occupies rows [off, off+L) of R >= L rows
-//                        (R = L inside memorize; R = 2L, off = L when it is the 'update' half of matching's packed banks)
+//   kp [NK][C/4+1][R][4] "packed keys": the key bases channel-group major, plus one group holding every base row's squared
+//                        norm as C/32 partial sums; a bank occupies rows [off, off+L) of R >= L rows (R = L inside
+//                        memorize; R = 2L, off = L when it is the 'update' half of matching's packed banks)
 //   z  [N][Pz][2L]       responsibilities, one row per PIXEL: z[n][p][cls*L + l]; Pz = swem_em_pad(P) rows allocated,
 //                        rows [0, ceil16(P)) written (pad pixels as zeros)
 //
-// Three launches per EM iteration (a dependent kernel boundary costs ~1.5 us on this chip, a grid-wide barrier inside a
+// TWO launches per EM iteration (a dependent kernel boundary costs ~1.5-2 us on this chip, a grid-wide barrier inside a
 // persistent kernel 4-7 us and a split-K seam with a last-arriver combine 5-13 us: MI355X_MICROARCH.md, price list --
-// so the iteration is three well-filled kernels, not one cooperative one):
-//   em_ew16    : block = (object, 16-pixel tile), 8 waves = 2 classes x 4 base quarters.  One GEMM  s = kn . x_t  on
-//                v_mfma_f32_16x16x4_f32 serves BOTH the W step of the previous iteration (cosine = s / (|x|+eps), joint
+// so the iteration is two well-filled kernels, not one cooperative one):
+//   em_ew16    : block = (object, 16-pixel tile), 8 waves = 2 classes x 4 base quarters.  One GEMM  s = l2norm(kappa) . x_t
+//                on v_mfma_f32_16x16x4_f32 serves BOTH the W step of the previous iteration (cosine = s / (|x|+eps), joint
 //                {bg,fg} max, exp-sums, weights = mask * (1 - p)) and the E step (softmax of s/tau over the class's bases,
 //                times weights).  The pixel sits on the MFMA column lane, four bases of a tile in the accumulator
 //                registers: row reductions are in-register + two shuffles + ONE LDS exchange for the maxima and one for the
 //                sums.  The pixel's key (all C channels) lives in registers; every base row is loaded exactly once per
-//                block, all loads issued before the first MFMA.  z leaves as 16-byte stores, 64 contiguous bytes per pixel
-//                and tile.  204 blocks at config B (P = 1620, N = 2) instead of the 102 a 32-pixel tile gives.
-//   em_mstep   : S = X^T . z over a CHUNK of pixels (split-P): block = (object-class, 32 bases) x (128 rows of X) x chunk,
-//                8 waves = 4 row tiles x 2 halves of the chunk, v_mfma_f32_32x32x2_f32.  X = x (key bases) or v[n]
-//                (value bases, last iteration only: both in ONE launch).  Operands are fetched by raw buffer loads
-//                (pixels >= P read as zeros by the buffer's range check on the vector offset: no masks), issued ahead of
-//                the MFMA chain.  Partial sums go to Spart[chunk][nk][row][L]; the column
-//                sums of z (zita's increment) ride along.
-//   em_finalize: fixed-order sum over the chunks (deterministic), prior blend (zita_*prev + S)/zita, and for the key
-//                bases the l2-normalised kn the next E/W step reads (block = 32 bases x all C rows: norms are block-local).
-//                On the last iteration it can also write the bases straight into matching's packed banks.
+//                block, all loads issued before the first MFMA, and scaled by 1 / (|row| + eps) (l2norm, modules.py:7-9)
+//                from the norms kept in the pack.  z leaves as 16-byte stores, 64 contiguous bytes per pixel and tile.
+//                204 blocks at config B (P = 1620, N = 2).
+//   em_mstep   : the whole M step: block = (object-class, 16 bases) x (32 rows of X) over ALL pixels, X = x (key bases) or
+//                v[n] (value bases, last iteration only: both in ONE launch); 8 waves take the 4-pixel k-steps round robin,
+//                the block sums them in wave order (deterministic), adds the column sums of z to zita, blends with the
+//                prior (zita_prev * prev + S) / zita and writes the bases in the reference's layout AND as packed keys
+//                with their norm partials (on the last iteration straight into matching's packed banks).
+//                256 blocks for the key rows at config B: the only cut of this small GEMM that fills the chip without
+//                splitting the pixel sum across blocks -- which is what made round 1's third kernel (and a 4 MB round
+//                trip of partial sums) necessary.
 #include "../../include/swem_hip_train.h"
 #include "common.h"
 
@@ -50,13 +51,18 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// kn[nk][c/4][off + l][c%4] = kappa[nk][c][l] / (||kappa[nk][:][l]|| + eps).  Block: 32 bases x all channels.
+// normalize = 1 (l2norm, modules.py:7-9):  kn[nk][c/4][off + l][c%4] = kappa[nk][c][l] / (||kappa[nk][:][l]|| + eps), C/4 groups.
+// normalize = 0 ("packed keys", what the E/W and affinity kernels read): the plain re-layout, C/4 + 1 groups -- the extra
+// group holds the squared norm of every base row as C/32 partial sums (one per 32 channels, balanced tree in channel
+// order: exactly what the M step's blocks write, so a pack built here equals one the M step kept, bit for bit).
+// Block: 32 bases x all channels.
 __global__ __launch_bounds__(256) void em_norm_bases_kernel(const float *__restrict__ kappa, float *__restrict__ kn,
-                                                            int C, int L, int out_rows, int out_off) {
+                                                            int C, int L, int out_rows, int out_off, int normalize) {
   extern __shared__ float sm[];  // tile[C][33], part[8][32], nrm[32]
   float *tile = sm, *part = sm + C * 33, *nrm = part + 256;
   const int nk = blockIdx.y, l0 = blockIdx.x * 32;
   const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int KG = normalize ? C / 4 : C / 4 + 1;
   const float *src = kappa + (long long)nk * C * L + l0 + l;
   float ss = 0.f;
   for (int c = g; c < C; c += 8) {
@@ -69,7 +75,24 @@ __global__ __launch_bounds__(256) void em_norm_bases_kernel(const float *__restr
   if (threadIdx.x < 32) {
     float s = 0.f;
     for (int i = 0; i < 8; ++i) s += part[i * 32 + threadIdx.x];
-    nrm[threadIdx.x] = sqrtf(s) + SWEM_L2_EPS;
+    nrm[threadIdx.x] = normalize ? sqrtf(s) + SWEM_L2_EPS : 1.0f;
+  }
+  if (!normalize && g < 4 && l0 + l < L) {
+    float q[32];
+    float r = 0.f;
+    if (32 * g < C) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float t = tile[(32 * g + j) * 33 + l];
+        q[j] = __fmul_rn(t, t);
+      }
+#pragma unroll
+      for (int w = 1; w < 32; w <<= 1)
+#pragma unroll
+        for (int j = 0; j < 32; j += 2 * w) q[j] = __fadd_rn(q[j], q[j + w]);
+      r = q[0];
+    }
+    kn[(((long long)nk * KG + C / 4) * out_rows + out_off + l0 + l) * 4 + g] = r;
   }
   __syncthreads();
   // channel-group major: the E/W and affinity kernels put one base row on every lane, so the 16 (32) rows' 16-byte chunks
@@ -77,7 +100,7 @@ __global__ __launch_bounds__(256) void em_norm_bases_kernel(const float *__restr
   for (int idx = threadIdx.x; idx < 32 * C; idx += 256) {
     const int e = idx & 3, ll = (idx >> 2) & 31, c4 = idx >> 7;
     if (l0 + ll < L)
-      kn[(((long long)nk * (C / 4) + c4) * out_rows + out_off + l0 + ll) * 4 + e] = tile[(c4 * 4 + e) * 33 + ll] / nrm[ll];
+      kn[(((long long)nk * KG + c4) * out_rows + out_off + l0 + ll) * 4 + e] = tile[(c4 * 4 + e) * 33 + ll] / nrm[ll];
   }
 }
 
@@ -103,7 +126,7 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
   const int nk = 2 * n + cls;
   const bool pin = p < P;
   // base rows of this wave: [q*16*LT, (q+1)*16*LT) of class cls; lane (li, g) loads row li of every tile, chunk 4m + g
-  const float *kb = kn + (((long long)nk * (C / 4) + g) * kn_rows + kn_off + q * 16 * LT + li) * 4;
+  const float *kb = kn + (((long long)nk * (C / 4 + 1) + g) * kn_rows + kn_off + q * 16 * LT + li) * 4;
   // issue order = arrival order (vmcnt counts in order): the pixel's key first, then the base rows chunk by chunk, so the
   // MFMAs of chunk m wait for chunk m only and the rest of the 256 KB streams in behind them
   // (buffer loads: pad pixels p >= P read as zeros by the range check -- no select in front of the MFMAs)
@@ -118,13 +141,20 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
   __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>((do_w ? masks : w_in) + (long long)nk * P), 0, P * 4, 0x00020000);
   const float mk = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, (unsigned)(p * 4), 0, 0));
+  float4 nq[LT];   // the rows' squared norms (partial sums), group C/4 of the pack
+#pragma unroll
+  for (int t = 0; t < LT; ++t) nq[t] = ld4(kb + ((long long)(C / 4 - g) * kn_rows + 16 * t) * 4);
+  // Every base row is requested before the first MFMA.  (Measured alternatives: left alone, the scheduler sinks each load
+  // to just before its use -- one L2 round trip per chunk, vmcnt(1) in front of every MFMA group; streaming the rows 4
+  // chunks ahead of the MFMAs that consume them, to start the chain while the CU's memory pipe -- 64 bytes a clock, ~2 us
+  // for the 8 waves' 256 KB -- is still delivering, made the kernel 2 us SLOWER: the in-order issue of a wave's loads
+  // between its MFMA groups stalls the chain more than the early start gains.  EW_AHEAD = CM keeps everything up front.)
+  constexpr int EW_AHEAD = CM;
   float4 a[CM][LT];
 #pragma unroll
-  for (int m = 0; m < CM; ++m)
+  for (int m = 0; m < EW_AHEAD; ++m)
 #pragma unroll
     for (int t = 0; t < LT; ++t) a[m][t] = ld4(kb + ((long long)4 * m * kn_rows + 16 * t) * 4);
-  // keep every load above the MFMA chain: left alone, the scheduler sinks each load to just before its use to save
-  // registers and the wave then pays one L2 round trip per chunk (seen in the ISA: vmcnt(1) in front of every MFMA group)
   __builtin_amdgcn_sched_barrier(0);
   STAMP(1);
   float ss = 0.f;
@@ -137,8 +167,24 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
   f32x4 acc[LT];
 #pragma unroll
   for (int t = 0; t < LT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // l2norm of the bases (modules.py:7-9, :95, :114).  The rows arrive raw with their squared norms beside them (packed
+  // keys: the M step writes both, no kernel in between normalises); every lane scales ITS row's fragments on the way into
+  // the MFMA chain -- vector work that hides behind the other wave's MFMAs (measured: no change in kernel time).
+  // Scaling the GEMM's OUTPUT instead (16 multiplies per lane, not 128) doubled the EM's rounding noise: bases grow to
+  // norm ~24 at config sizes and the fp32 MFMA chain on un-normalised rows lands 2x further from float64 after three
+  // iterations than the reference's own fp32 arithmetic (tools/em_noise.py); with the rows scaled first it lands as close.
+  float rn[LT];
+#pragma unroll
+  for (int t = 0; t < LT; ++t) rn[t] = 1.0f / (sqrtf((nq[t].x + nq[t].y) + (nq[t].z + nq[t].w)) + SWEM_L2_EPS);
 #pragma unroll
   for (int m = 0; m < CM; ++m) {
+#pragma unroll
+    for (int t = 0; t < LT; ++t) a[m][t].x *= rn[t], a[m][t].y *= rn[t], a[m][t].z *= rn[t], a[m][t].w *= rn[t];
+    if (m + EW_AHEAD < CM) {
+#pragma unroll
+      for (int t = 0; t < LT; ++t) a[m + EW_AHEAD][t] = ld4(kb + ((long long)4 * (m + EW_AHEAD) * kn_rows + 16 * t) * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < LT; ++t) acc[t] = mfma16(a[m][t].x, xf[m].x, acc[t]);
 #pragma unroll
@@ -147,8 +193,12 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
     for (int t = 0; t < LT; ++t) acc[t] = mfma16(a[m][t].z, xf[m].z, acc[t]);
 #pragma unroll
     for (int t = 0; t < LT; ++t) acc[t] = mfma16(a[m][t].w, xf[m].w, acc[t]);
+    __builtin_amdgcn_sched_barrier(0);
   }
-
+  // l2norm of the bases (modules.py:7-9, :95, :114) on the GEMM's output: s = (x . kappa) / (|kappa| + eps).  The rows
+  // arrive raw with their squared norms beside them (packed keys): the M step writes both and no kernel in between
+  // normalises.  Lane (li, g = 0) holds row li's norm; the accumulator registers hold bases 4 g + r: one 16-float exchange
+  // per tile inside the wave.
   // maxima of the raw logits over this wave's bases; the W step's cosine is s / (|x| + eps) with a positive per-pixel
   // factor, so its joint maximum is that factor times the larger class maximum (rounding is monotonic): one exchange
   float ml = -__builtin_huge_valf();
@@ -222,214 +272,167 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------- M step (split-P)
+// ---------------------------------------------------------------------------------------------------- M step
 struct MStepP {
   const float *x;  // [P][C] key rows (row space [0, Ck)), or NULL when Ck == 0
   const float *v;  // [N][P][V] value rows (row space [Ck, Ck + Vv)), or NULL
   const float *z;  // [N][Pz][2L]
-  float *Spart;    // [nch][NK][Rtot][L]
-  float *zpart;    // [nch][NK][L]
-  int Ck, C, V, P, Pz, L, NK, Rtot;
+  const float *kappa_prev, *nu_prev, *zita_prev;
+  float *kappa_out, *nu_out, *zita_out;
+  float *kp_out;   // optional: the new key bases packed [NK][C/4][kp_rows][4] at row offset kp_off (what E/W / affinity read)
+  float *mvp_out;  // optional: value bases packed for matching, mvp[n][v][cls*mvp_lm + mvp_off + l]
+  int kp_rows, kp_off, mvp_lm, mvp_off;
+  int Ck, C, V, P, Pz, L, NK, nrt, total;  // nrt = 32-row tiles of the row space, total = NK * (L/16) * nrt blocks
 };
 
-// Block = (nk, 32 bases) x (128 rows of the row space) x chunk of 4*STEPS pixels; wave = (row tile ct, chunk half kh).
-template <int STEPS>
-__global__ __launch_bounds__(512) void em_mstep_kernel(MStepP p STAMP_ARG) {
+// One launch = the whole M step (modules.py:122-127, 164-165), no partial sums in memory and no second kernel:
+// block = (object-class, 16 bases) x (32 rows of the row space) over ALL pixels; the 8 waves take the 4-pixel k-steps
+// round robin (wave w: steps w, w + 8, ...), two v_mfma_f32_16x16x4_f32 tiles each (A = z^T: base on the row lane, B =
+// the 32 rows), and the block sums its 8 waves in wave order through the LDS (deterministic), adds the column sums of z to
+// zita and blends with the prior: out = (zita_prev * prev + S) / zita.  512 output tiles of 16 x 16 at config B = two per
+// CU: the only cut of this GEMM that fills 256 CUs without splitting the pixel sum across blocks.  Operands come by raw
+// buffer loads (dwords: z is pixel-major, a lane needs ONE base of FOUR pixels per step; pixels >= P read as zeros by the
+// range check on the vector offset), three groups of MG steps in flight ahead of the MFMA chain.
+// Blocks that share z columns sit on one XCD (blockIdx -> tile order below): an XCD's L2 holds its 1/8 of z plus x.
+constexpr int MG = 17;  // k-steps per load group (3 dwords each)
+struct MGroup {
+  float za[MG], xa[MG], xb[MG];
+};
+__device__ __forceinline__ void mgroup_load(MGroup &q, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, unsigned &oa,
+                                            unsigned &ob, unsigned sa, unsigned sb) {
+#pragma unroll
+  for (int s = 0; s < MG; ++s) {   // running offsets: one address register per operand, not one per load in flight
+    q.za[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, ob, 0, 0));
+    q.xa[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, oa, 0, 0));
+    q.xb[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, oa + 64u, 0, 0));
+    oa += sa;
+    ob += sb;
+  }
+}
+// two accumulators per tile (even / odd steps of the group): independent MFMA chains back to back
+__device__ __forceinline__ void mgroup_mfma(const MGroup &q, f32x4 (&acc)[4], float &zs) {
+#pragma unroll
+  for (int s = 0; s < MG; ++s) {
+    acc[2 * (s & 1)] = mfma16(q.za[s], q.xa[s], acc[2 * (s & 1)]);
+    acc[2 * (s & 1) + 1] = mfma16(q.za[s], q.xb[s], acc[2 * (s & 1) + 1]);
+  }
+  // the column sums of z behind the chain (in front of it the adds would wait for the group's last load)
+  asm volatile("" : "+v"(zs) : "v"(acc[0][0]));
+#pragma unroll
+  for (int s = 0; s < MG; ++s) zs += q.za[s];
+}
+
+template <bool LOOP>   // LOOP: more than three load groups per wave (P > 1632)
+__global__ __launch_bounds__(512, LOOP ? 2 : 4) void em_mstep_kernel(MStepP p STAMP_ARG) {   // (512, waves per SIMD): two blocks per CU
   STAMP(0);
-  __shared__ float red[4][16][64];
-  __shared__ float zred[2][32];
+  __shared__ float red[8][2][4][64];
+  __shared__ float zred[8][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 31, kk = lane >> 5;
-  const int ct = wave & 3, kh = wave >> 2;
-  const int tiles = p.L / 32;
-  const int nk = blockIdx.x / tiles, l0 = (blockIdx.x - nk * tiles) * 32;
+  const int li = lane & 15, g = lane >> 4;
+  // consecutive blockIdx go round the 8 XCDs: XCD k takes the k-th eighth of the tile order (base tile major)
+  const int per = gridDim.x >> 3;
+  const int u = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (u >= p.total) return;
+  const int bt = u / p.nrt, rt = u - bt * p.nrt;
+  const int tiles = p.L / 16;
+  const int nk = bt / tiles, l0 = (bt - nk * tiles) * 16;
   const int n = nk >> 1, cls = nk & 1;
-  const int row0 = blockIdx.y * 128;
-  const int chunk = blockIdx.z;
-  const int pw0 = chunk * 4 * STEPS + kh * 2 * STEPS;  // first pixel of this wave's half chunk
-  // wave-uniform descriptors: the row operand (x or v[n]) and z[n]; offsets beyond P rows read as zeros
+  const int row0 = rt * 32;
   const bool key = row0 < p.Ck;
   const float *src = key ? p.x : p.v + (long long)n * p.P * p.V;
   const int stride = key ? p.C : p.V;
-  const int col = (key ? row0 : row0 - p.Ck) + 32 * ct;
+  const int col = key ? row0 : row0 - p.Ck;
   __amdgpu_buffer_rsrc_t ra =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, (int)((long long)p.P * stride * 4), 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(p.z + (long long)n * p.Pz * 2 * p.L), 0, (int)((long long)p.P * 2 * p.L * 4), 0x00020000);
-  // the pixel offset travels in the VECTOR offset: the hardware range-checks voffset + immediate against num_records (the
-  // scalar offset is added after the check), so pixels >= P come back as zeros without touching memory
-  const unsigned va = (unsigned)(((pw0 + kk) * stride + col + i) * 4);
-  const unsigned vb = (unsigned)(((pw0 + kk) * 2 * p.L + cls * p.L + l0 + i) * 4);
-  const unsigned sa = (unsigned)stride * 8u, sb = (unsigned)p.L * 16u;  // bytes per step (two pixels)
-  float av[STEPS], bv[STEPS];
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    av[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, va + s * sa, 0, 0));
-    bv[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, vb + s * sb, 0, 0));
-  }
-  __builtin_amdgcn_sched_barrier(0);  // all loads in flight before the MFMA chain (see em_ew16_kernel)
-  STAMP(1);
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) acc = mfma32(av[s], bv[s], acc);
-  // the column sums of z after the MFMA chain (in front of it the adds wait for the LAST load and the chain with them)
-  // (the empty asm makes the sum's start depend on the accumulator: instruction selection otherwise emits the adds first)
-  float zs = 0.f;
-  asm volatile("" : "+v"(zs) : "v"(acc[0]));
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) zs += bv[s];
-  zs += __shfl_xor(zs, 32);
-  if (kh == 1) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) red[ct][e][lane] = acc[e];
-  }
-  if (ct == 0 && lane < 32) zred[kh][lane] = zs;
-  STAMP(2);
-  __syncthreads();
-  STAMP(3);
-  if (kh == 1) return;
-  float *dst = p.Spart + (((long long)chunk * p.NK + nk) * p.Rtot + row0 + 32 * ct) * p.L + l0 + i;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) dst[(long long)acc_row(e, kk) * p.L] = acc[e] + red[ct][e][lane];
-  if (ct == 0 && lane < 32 && blockIdx.y == 0)
-    p.zpart[((long long)chunk * p.NK + nk) * p.L + l0 + lane] = zred[0][lane] + zred[1][lane];
-  STAMP(4);
-#ifdef SWEM_EM_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  STAMP(5);
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------- finalize
-struct FinP {
-  const float *Spart, *zpart;
-  const float *kappa_prev, *nu_prev, *zita_prev;
-  const float *zita_in;  // when set, zita is read from here instead of zita_prev + sum of zpart
-  float *kappa_out, *nu_out, *zita_out;
-  float *kn_out;          // optional: normalised key bases [NK][C/4][kn_rows][4] at row offset kn_off
-  float *mvp_out;         // optional: value bases packed for matching, mvp[n][v][cls*mvp_lm + mvp_off + l]
-  int kn_rows, kn_off, mvp_lm, mvp_off;
-  int Ck, C, V, L, NK, Rtot, nch;
-};
-
-// Block = (32 bases, nk, 128-row group of the row space); 1024 threads = 32 bases x 32 row lanes.
-constexpr int FIN_CH = 8;  // chunk partials fetched together (config B: all 8)
-__global__ __launch_bounds__(1024) void em_finalize_kernel(FinP p STAMP_ARG) {
-  STAMP(0);
-  __shared__ float tile[128 * 33];
-  __shared__ float part[8][32];
-  __shared__ float nrm[32];
-  const int nk = blockIdx.y, l0 = blockIdx.x * 32;
-  const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int row0 = blockIdx.z * 128;
-  const bool key = row0 < p.Ck;
-  const float zp = p.zita_prev[(long long)nk * p.L + l0 + l];
+  // the epilogue's operands first: output element (base l0 + oi, row col + oj) of this thread; a wave = 2 bases x 32 rows
+  const int oj = tid & 31, oi = tid >> 5;
   const int R = key ? p.C : p.V;
-  const int rbase = key ? row0 : row0 - p.Ck;
-  const float *prev = key ? p.kappa_prev : p.nu_prev;
-  float *out = key ? p.kappa_out : p.nu_out;
-  const int n = nk >> 1, cls = nk & 1;
-  float pv[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    pv[q] = rbase + g + 32 * q < R ? prev[((long long)nk * R + rbase + g + 32 * q) * p.L + l0 + l] : 0.f;
-  // ONE round trip for everything this thread reads: the prior above, and per chunk the column-sum partial of its base
-  // (every thread sums zita itself -- the same addresses in all 32 row lanes, cache hits -- instead of a first phase behind
-  // a barrier) and the S partials of its four rows.  Every load of a chunk group is in flight before the first add (a
-  // dependent chain of L2 / Infinity-Cache round trips was most of this kernel's time); sums run in chunk order.
-  const long long cs = (long long)p.NK * p.Rtot * p.L;
-  float sums[4] = {0.f, 0.f, 0.f, 0.f}, zsum = 0.f;
-  for (int c0 = 0; c0 < p.nch; c0 += FIN_CH) {
-    float t[4][FIN_CH], tz[FIN_CH];
-#pragma unroll
-    for (int ch = 0; ch < FIN_CH; ++ch)
-      tz[ch] = (c0 + ch < p.nch && !p.zita_in) ? p.zpart[((long long)(c0 + ch) * p.NK + nk) * p.L + l0 + l] : 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float *sp = p.Spart + ((long long)nk * p.Rtot + row0 + g + 32 * q) * p.L + l0 + l;
-#pragma unroll
-      for (int ch = 0; ch < FIN_CH; ++ch) t[q][ch] = (c0 + ch < p.nch && rbase + g + 32 * q < R) ? sp[(c0 + ch) * cs] : 0.f;
-    }
-#pragma unroll
-    for (int ch = 0; ch < FIN_CH; ++ch) zsum += tz[ch];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int ch = 0; ch < FIN_CH; ++ch) sums[q] += t[q][ch];
-  }
+  const float zp = p.zita_prev[(long long)nk * p.L + l0 + oi];
+  const float pv = (key ? p.kappa_prev : p.nu_prev)[((long long)nk * R + col + oj) * p.L + l0 + oi];
+  // pixel of (step t of this wave, lane group g) = 4 * (wave + 8 t) + g; it travels in the VECTOR offset (range-checked)
+  const unsigned va = (unsigned)(((4 * wave + g) * stride + col + li) * 4);
+  const unsigned vb = (unsigned)(((4 * wave + g) * 2 * p.L + cls * p.L + l0 + li) * 4);
+  const unsigned sa = (unsigned)stride * 128u, sb = (unsigned)p.L * 256u;  // bytes per step of one wave (32 pixels)
+  const int T = ((p.P + 3) / 4 + 7) / 8, ng = (T + MG - 1) / MG;
+  MGroup qa, qb, qc;
+  unsigned oa = va, ob = vb;   // groups are loaded in step order, whichever registers they land in
+  mgroup_load(qa, ra, rb, oa, ob, sa, sb);
+  mgroup_load(qb, ra, rb, oa, ob, sa, sb);   // (a group past the last pixel reads zeros without touching memory)
+  __builtin_amdgcn_sched_barrier(0);  // two groups in flight before the MFMA chain (see em_ew16_kernel)
   STAMP(1);
-  const float zt = p.zita_in ? p.zita_in[(long long)nk * p.L + l0 + l] : zp + zsum;
-  if (p.zita_out && blockIdx.z == 0 && g == 0) p.zita_out[(long long)nk * p.L + l0 + l] = zt;
+  f32x4 acc[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int rr = g + 32 * q;
-    const int row = rbase + rr;
-    float v = 0.f;
-    if (row < R) {
-      const long long o = ((long long)nk * R + row) * p.L + l0 + l;
-      v = (zp * pv[q] + sums[q]) / zt;
-      out[o] = v;
-      if (!key && p.mvp_out)
-        p.mvp_out[((long long)n * p.V + row) * (2 * p.mvp_lm) + cls * p.mvp_lm + p.mvp_off + l0 + l] = v;
+  for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float zs = 0.f;
+  // the third group is requested behind the first one's MFMAs: by then the memory pipe has delivered most of the first two
+  // (it moves 64 bytes a clock per CU: the 8 waves' two groups are ~1.5 us of its time), and the wait counter (63 at most)
+  // still resolves every group exactly
+#define MPHASE(stmt) stmt; __builtin_amdgcn_sched_barrier(0)   /* phases stay in program order (register pressure) */
+  if constexpr (!LOOP) {   // up to 1632 pixels (config B: 1620): straight-line code, the waits are exact per group
+    MPHASE(mgroup_mfma(qa, acc, zs));
+    MPHASE(mgroup_load(qc, ra, rb, oa, ob, sa, sb));
+    if (ng > 1) { MPHASE(mgroup_mfma(qb, acc, zs)); }
+    if (ng > 2) { MPHASE(mgroup_mfma(qc, acc, zs)); }
+  } else {
+    for (int gi = 0; gi < ng; gi += 3) {
+      MPHASE(mgroup_mfma(qa, acc, zs));
+      MPHASE(mgroup_load(qc, ra, rb, oa, ob, sa, sb));
+      MPHASE(mgroup_mfma(qb, acc, zs));
+      MPHASE(mgroup_load(qa, ra, rb, oa, ob, sa, sb));
+      MPHASE(mgroup_mfma(qc, acc, zs));
+      MPHASE(mgroup_load(qb, ra, rb, oa, ob, sa, sb));
     }
-    if (key) tile[rr * 33 + l] = v;
   }
+#undef MPHASE
+  zs += __shfl_xor(zs, 16);
+  zs += __shfl_xor(zs, 32);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[wave][0][e][lane] = acc[0][e] + acc[2][e];
+    red[wave][1][e][lane] = acc[1][e] + acc[3][e];
+  }
+  if (lane < 16) zred[wave][lane] = zs;
   STAMP(2);
-  if (!key || !p.kn_out) return;
   __syncthreads();
   STAMP(3);
-  if (g < 8) {  // column norms from the tile, in the association of em_norm_bases_kernel (bit-identical kn)
-    float ss = 0.f;
-    for (int c = g; c < p.C; c += 8) {
-      const float v = tile[c * 33 + l];
-      ss += v * v;
+  // D[i = base][j = row] of a tile lives in lane j + 16 (i >> 2), register i & 3
+  const int tt = oj >> 4, sl = (oj & 15) + 16 * (oi >> 2), sr = oi & 3;
+  float S = 0.f, zsum = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    S += red[w][tt][sr][sl];
+    zsum += zred[w][oi];
+  }
+  const float zt = zp + zsum;
+  const float val = (zp * pv + S) / zt;
+  const int row = col + oj;
+  if (key) {
+    p.kappa_out[((long long)nk * p.C + row) * p.L + l0 + oi] = val;
+    if (p.kp_out) {
+      const int KG = p.C / 4 + 1;
+      p.kp_out[(((long long)nk * KG + (row >> 2)) * p.kp_rows + p.kp_off + l0 + oi) * 4 + (row & 3)] = val;
+      // the row tile's share of the bases' squared norms (group C/4 of the pack): balanced tree over the 32 rows, the order
+      // em_norm_bases_kernel reproduces
+      float q = __fmul_rn(val, val);
+#pragma unroll
+      for (int w = 1; w < 32; w <<= 1) q = __fadd_rn(q, __shfl_xor(q, w));
+      float *nq = p.kp_out + (((long long)nk * KG + p.C / 4) * p.kp_rows + p.kp_off + l0 + oi) * 4;
+      if (oj == 0) nq[rt] = q;
+      if (rt == 0 && p.C == 64 && oj >= 2 && oj < 4) nq[oj] = 0.f;
     }
-    part[g][l] = ss;
-  }
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    float s = 0.f;
-    for (int i = 0; i < 8; ++i) s += part[i][threadIdx.x];
-    nrm[threadIdx.x] = sqrtf(s) + SWEM_L2_EPS;
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < 32 * p.C; idx += 1024) {
-    const int e = idx & 3, ll = (idx >> 2) & 31, c4 = idx >> 7;
-    p.kn_out[(((long long)nk * (p.C / 4) + c4) * p.kn_rows + p.kn_off + l0 + ll) * 4 + e] = tile[(c4 * 4 + e) * 33 + ll] / nrm[ll];
+    if (rt == 0 && oj == 0 && p.zita_out) p.zita_out[(long long)nk * p.L + l0 + oi] = zt;
+  } else {
+    p.nu_out[((long long)nk * p.V + row) * p.L + l0 + oi] = val;
+    if (p.mvp_out) p.mvp_out[((long long)n * p.V + row) * (2 * p.mvp_lm) + cls * p.mvp_lm + p.mvp_off + l0 + oi] = val;
+    if (p.Ck == 0 && rt == 0 && oj == 0 && p.zita_out) p.zita_out[(long long)nk * p.L + l0 + oi] = zt;
   }
   STAMP(4);
 #ifdef SWEM_EM_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   STAMP(5);
 #endif
-}
-
-struct MWs {
-  size_t Spart, zpart, total;
-  int nch, steps;
-};
-// workspace of one M step over a row space of Rtot rows: chunk partials of S and of the column sums of z
-MWs mstep_ws(int NK, int Rtot, int P, int L) {
-  MWs w;
-  // 208-pixel chunks (52 two-pixel steps per half-chunk wave) unless that leaves most of the chip idle.  The choice
-  // depends on the key rows' grid only, so that every M step of a memorize (keys alone, keys + values) and the step-level
-  // entry point cut P the same way: the same partial sums in the same order whatever the row space
-  w.steps = 52;
-  long long blocks = (long long)NK * (L / 32) * cdiv(P, 4 * w.steps);
-  if (blocks < 160) w.steps = 26;
-  w.nch = cdiv(P, 4 * w.steps);
-  size_t o = 0;
-  auto take = [&](size_t bytes) {
-    size_t at = o;
-    o = align_up(o + bytes, 256);
-    return at;
-  };
-  w.Spart = take((size_t)w.nch * NK * Rtot * L * sizeof(float));
-  w.zpart = take((size_t)w.nch * NK * L * sizeof(float));
-  w.total = o;
-  return w;
 }
 
 }  // namespace
@@ -438,20 +441,25 @@ MWs mstep_ws(int NK, int Rtot, int P, int L) {
 
 extern "C" int swem_em_pad(int P) { return (P + 127) / 128 * 128; }
 
-// kn rows of bank `kappa` land at row out_off + l of an [NK][C/4][out_rows][4] image (matching concatenates banks)
-int swem_norm_bases_into(void *stream, const float *kappa, float *kn, int NK, int C, int L, int out_rows,
-                         int out_off) {
+// rows of bank `kappa` land at row out_off + l of an [NK][C/4][out_rows][4] image (matching concatenates banks);
+// normalize = 0: the plain re-layout ("packed keys": their readers normalise the rows themselves)
+int swem_norm_bases_into(void *stream, const float *kappa, float *kn, int NK, int C, int L, int out_rows, int out_off,
+                         int normalize) {
   SWEM_REQUIRE(kappa && kn && NK > 0 && C > 0 && L > 0, SWEM_E_ARG, "em_norm_bases: bad argument");
   SWEM_REQUIRE(C <= 1024 && C % 4 == 0, SWEM_E_SHAPE, "em_norm_bases: C must be a multiple of 4, at most 1024");
   size_t lds = ((size_t)C * 33 + 256 + 32) * sizeof(float);
   hipLaunchKernelGGL(em_norm_bases_kernel, dim3(cdiv(L, 32), NK), dim3(256), lds, ST, kappa, kn, C, L, out_rows,
-                     out_off);
+                     out_off, normalize);
   SWEM_CHECK_LAUNCH("em_norm_bases");
   return SWEM_OK;
 }
 
 extern "C" int swem_em_norm_bases_f32(void *stream, const float *kappa, float *kn, int NK, int C, int L) {
-  return swem_norm_bases_into(stream, kappa, kn, NK, C, L, L, 0);
+  return swem_norm_bases_into(stream, kappa, kn, NK, C, L, L, 0, 1);
+}
+
+extern "C" int swem_em_pack_bases_f32(void *stream, const float *kappa, float *kp, int NK, int C, int L) {
+  return swem_norm_bases_into(stream, kappa, kp, NK, C, L, L, 0, 0);
 }
 
 namespace {
@@ -490,58 +498,52 @@ extern "C" int swem_em_ew_f32(void *stream, const float *x, const float *kn, con
 }
 
 namespace {
-// One M step over the row space [keys (Ck rows of x) | values (Vv rows of v)] and the finalize of both.
+// One M step over the row space [keys (Ck rows of x) | values (Vv rows of v)]: one launch.
 int mstep_impl(void *stream, const float *x, const float *v, const float *z, const float *kappa_prev,
                const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out,
-               float *kn_out, int kn_rows, int kn_off, float *mvp_out, int mvp_lm, int mvp_off, int NK, int Ck, int Vv,
-               int C, int V, int P, int L, char *ws) {
-  const int Rtot = Ck + Vv;
-  MWs w = mstep_ws(NK, Rtot, P, L);
+               float *kp_out, int kp_rows, int kp_off, float *mvp_out, int mvp_lm, int mvp_off, int NK, int Ck, int Vv,
+               int C, int V, int P, int L) {
   MStepP mp;
-  mp.x = x;
-  mp.v = v;
-  mp.z = z;
-  mp.Spart = reinterpret_cast<float *>(ws + w.Spart);
-  mp.zpart = reinterpret_cast<float *>(ws + w.zpart);
-  mp.Ck = Ck, mp.C = C, mp.V = V, mp.P = P, mp.Pz = swem_em_pad(P), mp.L = L, mp.NK = NK, mp.Rtot = Rtot;
-  dim3 grid(NK * (L / 32), Rtot / 128, w.nch);
-  if (w.steps == 52) hipLaunchKernelGGL((em_mstep_kernel<52>), grid, dim3(512), 0, ST, mp STAMP_PASS);
-  else hipLaunchKernelGGL((em_mstep_kernel<26>), grid, dim3(512), 0, ST, mp STAMP_PASS);
+  mp.x = x, mp.v = v, mp.z = z;
+  mp.kappa_prev = kappa_prev, mp.nu_prev = nu_prev, mp.zita_prev = zita_prev;
+  mp.kappa_out = kappa_out, mp.nu_out = nu_out, mp.zita_out = zita_out;
+  mp.kp_out = kp_out, mp.mvp_out = mvp_out;
+  mp.kp_rows = kp_rows, mp.kp_off = kp_off, mp.mvp_lm = mvp_lm, mp.mvp_off = mvp_off;
+  mp.Ck = Ck, mp.C = C, mp.V = V, mp.P = P, mp.Pz = swem_em_pad(P), mp.L = L, mp.NK = NK;
+  mp.nrt = (Ck + Vv) / 32;
+  mp.total = NK * (L / 16) * mp.nrt;
+  const dim3 grid((mp.total + 7) / 8 * 8);
+  if (P <= 4 * 8 * 3 * MG) hipLaunchKernelGGL(em_mstep_kernel<false>, grid, dim3(512), 0, ST, mp STAMP_PASS);
+  else hipLaunchKernelGGL(em_mstep_kernel<true>, grid, dim3(512), 0, ST, mp STAMP_PASS);
   SWEM_CHECK_LAUNCH("em_mstep");
-  FinP fp;
-  fp.Spart = mp.Spart, fp.zpart = mp.zpart;
-  fp.kappa_prev = kappa_prev, fp.nu_prev = nu_prev, fp.zita_prev = zita_prev, fp.zita_in = nullptr;
-  fp.kappa_out = kappa_out, fp.nu_out = nu_out, fp.zita_out = zita_out;
-  fp.kn_out = kn_out, fp.mvp_out = mvp_out;
-  fp.kn_rows = kn_rows, fp.kn_off = kn_off, fp.mvp_lm = mvp_lm, fp.mvp_off = mvp_off;
-  fp.Ck = Ck, fp.C = C, fp.V = V, fp.L = L, fp.NK = NK, fp.Rtot = Rtot, fp.nch = w.nch;
-  hipLaunchKernelGGL(em_finalize_kernel, dim3(L / 32, NK, Rtot / 128), dim3(1024), 0, ST, fp STAMP_PASS);
-  SWEM_CHECK_LAUNCH("em_finalize");
   return SWEM_OK;
 }
 }  // namespace
 
-extern "C" size_t swem_em_mstep_workspace(int NK, int R, int P, int L) { return mstep_ws(NK, R, P, L).total; }
+// (the M step needs no scratch any more; the query stays in the ABI and reports zero)
+extern "C" size_t swem_em_mstep_workspace(int NK, int R, int P, int L) {
+  (void)NK, (void)R, (void)P, (void)L;
+  return 0;
+}
 
 extern "C" int swem_em_mstep_f32(void *stream, const float *A, int a_per_object, const float *z, const float *prev,
-                                 const float *zita_prev, float *out, float *zita_out, float *kn_out, int NK, int R,
+                                 const float *zita_prev, float *out, float *zita_out, float *kp_out, int NK, int R,
                                  int P, int L, void *ws, size_t ws_bytes) {
+  (void)ws, (void)ws_bytes;
   SWEM_REQUIRE(A && z && prev && zita_prev && out, SWEM_E_ARG, "em_mstep: null pointer");
-  SWEM_REQUIRE(NK % 2 == 0 && L % 32 == 0 && R % 128 == 0, SWEM_E_SHAPE,
-               "em_mstep: need NK even, L %% 32 == 0 and R %% 128 == 0 (got %d, %d, %d)", NK, L, R);
-  SWEM_REQUIRE(!kn_out || (R == 128 && !a_per_object), SWEM_E_SHAPE, "em_mstep: kn_out needs the key rows (R == 128, shared A)");
-  MWs w = mstep_ws(NK, R, P, L);
-  SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "em_mstep: workspace %zu < %zu", ws_bytes, w.total);
+  SWEM_REQUIRE(NK % 2 == 0 && L % 16 == 0 && R % 32 == 0, SWEM_E_SHAPE,
+               "em_mstep: need NK even, L %% 16 == 0 and R %% 32 == 0 (got %d, %d, %d)", NK, L, R);
+  SWEM_REQUIRE(!kp_out || !a_per_object, SWEM_E_SHAPE, "em_mstep: kp_out goes with the key rows (shared A)");
   if (a_per_object)  // value rows: A = v [N][P][R]
     return mstep_impl(stream, nullptr, A, z, nullptr, prev, zita_prev, nullptr, out, zita_out, nullptr, 0, 0, nullptr, 0, 0,
-                      NK, 0, R, 0, R, P, L, static_cast<char *>(ws));
-  return mstep_impl(stream, A, nullptr, z, prev, nullptr, zita_prev, out, nullptr, zita_out, kn_out, L, 0, nullptr, 0, 0, NK, R,
-                    0, R, 0, P, L, static_cast<char *>(ws));
+                      NK, 0, R, 0, R, P, L);
+  return mstep_impl(stream, A, nullptr, z, prev, nullptr, zita_prev, out, nullptr, zita_out, kp_out, L, 0, nullptr, 0, 0, NK, R,
+                    0, R, 0, P, L);
 }
 
 namespace {
 struct MemWs {
-  size_t kn, z, part, total;
+  size_t kn, z, total;
 };
 MemWs memorize_ws(int N, int C, int V, int P, int L) {
   const int Pz = swem_em_pad(P), NK = 2 * N;
@@ -552,10 +554,8 @@ MemWs memorize_ws(int N, int C, int V, int P, int L) {
     o = align_up(o + bytes, 256);
     return at;
   };
-  w.kn = take((size_t)NK * L * C * 4);
+  w.kn = take((size_t)NK * L * (C + 4) * 4);   // packed keys: C/4 + 1 groups
   w.z = take((size_t)N * Pz * 2 * L * 4);
-  size_t p1 = mstep_ws(NK, C, P, L).total, p2 = mstep_ws(NK, C + V, P, L).total;
-  w.part = take(p1 > p2 ? p1 : p2);
   w.total = o;
   return w;
 }
@@ -572,8 +572,7 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
                "memorize: outputs must not alias the prior bases (the prior is read by every iteration)");
   SWEM_REQUIRE(C == 64 || C == 128, SWEM_E_SHAPE, "memorize: the key dimension must be 64 or 128 (got %d)", C);
   SWEM_REQUIRE(L == 64 || L == 128 || L == 256, SWEM_E_SHAPE, "memorize: L must be 64, 128 or 256 (got %d)", L);
-  SWEM_REQUIRE(V % 128 == 0, SWEM_E_SHAPE, "memorize: the value dimension must be a multiple of 128 (got %d)", V);
-  SWEM_REQUIRE(C == 128, SWEM_E_SHAPE, "memorize: the M step takes 128 key channels (got %d)", C);
+  SWEM_REQUIRE(V % 32 == 0, SWEM_E_SHAPE, "memorize: the value dimension must be a multiple of 32 (got %d)", V);
   SWEM_REQUIRE(tau > 0.f, SWEM_E_ARG, "memorize: tau must be positive");
   MemWs w = memorize_ws(N, C, V, P, L);
   SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "memorize: workspace %zu < %zu", ws_bytes, w.total);
@@ -589,7 +588,7 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
   const float *kcur = kn_prior;
   int krows = knp_rows, koff = knp_off;
   if (!kcur) {
-    if ((rc = swem_em_norm_bases_f32(stream, kappa_prev, kn, NK, C, L))) return rc;
+    if ((rc = swem_em_pack_bases_f32(stream, kappa_prev, kn, NK, C, L))) return rc;
     kcur = kn, krows = L, koff = 0;
   }
   for (int it = 0; it < T; ++it) {
@@ -599,7 +598,7 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
     // key bases every iteration; the value bases (modules.py:164-165) from the LAST z, in the same two launches
     if ((rc = mstep_impl(stream, x, last ? v : nullptr, z, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out,
                          last ? kn_out : kn, last ? kno_rows : L, last ? kno_off : 0, last ? mvp_out : nullptr, mvp_lm,
-                         mvp_off, NK, C, last ? V : 0, C, V, P, L, base + w.part)))
+                         mvp_off, NK, C, last ? V : 0, C, V, P, L)))
       return rc;
     kcur = kn, krows = L, koff = 0;
   }

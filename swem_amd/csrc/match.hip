@@ -36,145 +36,69 @@ __global__ void pack_values_kernel(const float *__restrict__ nu, float *__restri
   *reinterpret_cast<float4 *>(mvp + ((long long)n * V + v) * (2 * Lm) + cls * Lm + off + l4 * 4) = val;
 }
 
-__device__ __forceinline__ float sort64_desc(float v, int lane) {
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      float o = __shfl_xor(v, j);
-      bool desc = (lane & k) == 0;
-      bool lower = (lane & j) == 0;
-      v = (lower == desc) ? fmaxf(v, o) : fminf(v, o);
-    }
-  }
-  return v;
+// Wave-wide bitonic sorting of NON-NEGATIVE floats (the exp values of matching): on their bit patterns an unsigned integer
+// compare orders them like the float compare, without the canonicalising v_max x,x hipcc puts in front of fmaxf/fminf.
+// The partner lane (lane ^ j) comes by DPP for j = 1, 2 (quad_perm), 4 (row_shl / row_shr on alternating banks) and 8
+// (row_ror:8) -- vector-ALU moves, no LDS crossbar -- and by ds_bpermute only across the 16-lane rows (j = 16, 32):
+// 18 of a 64-lane sort's 21 stages and 4 of a merge's 6 stay off the LDS.  (Round 1 issued one ds_bpermute + ~6 vector
+// instructions per compare-exchange: the top-l kernel was bound by vector issue, ~2500 instructions per pixel.)
+template <int J>
+__device__ __forceinline__ unsigned partner(unsigned v) {
+  if constexpr (J == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // [2,3,0,1]
+  else if constexpr (J == 4) {
+    int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);   // banks 0, 2: lane i <- lane i + 4
+    return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);   // banks 1, 3: lane i <- lane i - 4
+  } else if constexpr (J == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
+  else return (unsigned)__shfl_xor((int)v, J);
+}
+template <int K, int J>
+__device__ __forceinline__ unsigned cmpex(unsigned v, int lane) {
+  const unsigned o = partner<J>(v);
+  const bool keep_max = ((lane & K) == 0) == ((lane & J) == 0);   // K = 64 never matches a lane bit: descending overall
+  const unsigned mx = v > o ? v : o, mn = v > o ? o : v;
+  return keep_max ? mx : mn;
+}
+__device__ __forceinline__ float sort64_desc(float vf, int lane) {
+  unsigned v = __float_as_uint(vf);
+  v = cmpex<2, 1>(v, lane);
+  v = cmpex<4, 2>(v, lane);
+  v = cmpex<4, 1>(v, lane);
+  v = cmpex<8, 4>(v, lane);
+  v = cmpex<8, 2>(v, lane);
+  v = cmpex<8, 1>(v, lane);
+  v = cmpex<16, 8>(v, lane);
+  v = cmpex<16, 4>(v, lane);
+  v = cmpex<16, 2>(v, lane);
+  v = cmpex<16, 1>(v, lane);
+  v = cmpex<32, 16>(v, lane);
+  v = cmpex<32, 8>(v, lane);
+  v = cmpex<32, 4>(v, lane);
+  v = cmpex<32, 2>(v, lane);
+  v = cmpex<32, 1>(v, lane);
+  v = cmpex<64, 32>(v, lane);
+  v = cmpex<64, 16>(v, lane);
+  v = cmpex<64, 8>(v, lane);
+  v = cmpex<64, 4>(v, lane);
+  v = cmpex<64, 2>(v, lane);
+  v = cmpex<64, 1>(v, lane);
+  return __uint_as_float(v);
 }
 // a, b descending across the wave -> the 64 largest of their union, descending
 __device__ __forceinline__ float merge_top64(float a, float b, int lane) {
-  float v = fmaxf(a, __shfl(b, 63 - lane));
-#pragma unroll
-  for (int j = 32; j > 0; j >>= 1) {
-    float o = __shfl_xor(v, j);
-    v = ((lane & j) == 0) ? fmaxf(v, o) : fminf(v, o);
-  }
-  return v;
+  const unsigned ua = __float_as_uint(a), ub = (unsigned)__shfl((int)__float_as_uint(b), 63 - lane);
+  unsigned v = ua > ub ? ua : ub;
+  v = cmpex<64, 32>(v, lane);
+  v = cmpex<64, 16>(v, lane);
+  v = cmpex<64, 8>(v, lane);
+  v = cmpex<64, 4>(v, lane);
+  v = cmpex<64, 2>(v, lane);
+  v = cmpex<64, 1>(v, lane);
+  return __uint_as_float(v);
 }
 
-// K1: affinity + joint softmax.  Block = (object, 32-pixel tile); wave w owns bases [w*32J, +32J).
-// pT[n][p][l] = exp((aff - max)/tau) / sum   (pixel-major, one row of Ltot probabilities per pixel; rows >= P are 0)
-template <int J, int NW>  // NW waves x J 32-base tiles: Ltot = 32 * J * NW = 2 Lm
-__global__ __launch_bounds__(64 * NW) void match_affinity_kernel(const float *__restrict__ qk,
-                                                             const float *__restrict__ mkn, float *__restrict__ pT,
-                                                             int C, int P, int Pm, float tau) {
-  constexpr int Ltot = 32 * J * NW;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int QS = C + 4;
-  float *qs = sm;             // [32][C+4]
-  float *red = qs + 32 * QS;  // [2][NW][32]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int n = blockIdx.y, p0 = blockIdx.x * 32;
-  const int cq = C / 4;
-  for (int idx = tid; idx < 32 * cq; idx += 64 * NW) {
-    int row = idx / cq, c4 = idx - row * cq;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p0 + row < P) v = ld4(qk + (long long)(p0 + row) * C + c4 * 4);
-    *reinterpret_cast<float4 *>(qs + row * QS + c4 * 4) = v;
-  }
-  __syncthreads();
-  for (int rr = 0; rr < 32 / NW; ++rr) {  // l2norm of the query pixels (modules.py:282)
-    int row = wave * (32 / NW) + rr;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      float v = qs[row * QS + c];
-      s += v * v;
-    }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float den = sqrtf(s) + SWEM_L2_EPS;
-    for (int c = lane; c < C; c += 64) qs[row * QS + c] /= den;
-  }
-  __syncthreads();
-  f32x16 acc[J];
-#pragma unroll
-  for (int t = 0; t < J; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-  {
-    // mkn is [2n + cls][C/4][Lm][4] (em_norm_bases_kernel); a wave's 32 J rows lie inside one class
-    constexpr int Lm = Ltot / 2, WPC = NW / 2;
-    const float *krow = mkn + (((long long)(2 * n + wave / WPC) * (C / 4) + h) * Lm + (wave % WPC) * 32 * J + r) * 4;
-    const float *qrow = qs + r * QS + 4 * h;
-    // operands stream from L2 with one wave per SIMD: a register ring keeps PF k-steps in flight (see em_ew_kernel)
-    constexpr int PF = J <= 4 ? 4 : 2;   // J float4 per step; the accumulators already take 16 J registers
-    float4 ring[PF][J];
-    const int steps = C / 8;
-#pragma unroll
-    for (int d = 0; d < PF; ++d)
-#pragma unroll
-      for (int t = 0; t < J; ++t) ring[d][t] = ld4(krow + ((long long)2 * min(d, steps - 1) * Lm + t * 32) * 4);
-    for (int j0 = 0; j0 < steps; j0 += PF) {
-#pragma unroll
-      for (int d = 0; d < PF; ++d) {
-        const int j = j0 + d;
-        if (j < steps) {
-          float4 b4 = *reinterpret_cast<const float4 *>(qrow + 8 * j);
-          float4 a4[J];
-#pragma unroll
-          for (int t = 0; t < J; ++t) a4[t] = ring[d][t];
-          const int jn = min(j + PF, steps - 1);
-#pragma unroll
-          for (int t = 0; t < J; ++t) ring[d][t] = ld4(krow + ((long long)2 * jn * Lm + t * 32) * 4);
-#pragma unroll
-          for (int t = 0; t < J; ++t) acc[t] = mfma32x4(a4[t], b4, acc[t]);
-        }
-      }
-    }
-  }
-  float m = -__builtin_huge_valf();
-#pragma unroll
-  for (int t = 0; t < J; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) m = fmaxf(m, acc[t][e]);
-  m = fmaxf(m, __shfl_xor(m, 32));
-  if (h == 0) red[wave * 32 + r] = m;
-  __syncthreads();
-  m = red[r];
-#pragma unroll
-  for (int q = 1; q < NW; ++q) m = fmaxf(m, red[q * 32 + r]);
-  float se = 0.f;
-  const float k2 = SWEM_LOG2E / tau;
-#pragma unroll
-  for (int t = 0; t < J; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float v = exp_scaled(acc[t][e] - m, k2);
-      acc[t][e] = v;
-      se += v;
-    }
-  se += __shfl_xor(se, 32);
-  if (h == 0) red[NW * 32 + wave * 32 + r] = se;
-  __syncthreads();
-  float part4[NW / 4];   // pairwise tree, (a+b)+(c+d) per four waves: the association the 4-wave kernel always had
-#pragma unroll
-  for (int q = 0; q < NW / 4; ++q)
-    part4[q] = (red[NW * 32 + (4 * q) * 32 + r] + red[NW * 32 + (4 * q + 1) * 32 + r]) +
-               (red[NW * 32 + (4 * q + 2) * 32 + r] + red[NW * 32 + (4 * q + 3) * 32 + r]);
-  float esum = part4[0];
-#pragma unroll
-  for (int q = 1; q < NW / 4; ++q) esum += part4[q];
-  const float inv = (p0 + r < P) ? 1.0f / esum : 0.f;  // padded rows are written as zeros
-  if (p0 + r < Pm) {
-    float *dst = pT + ((long long)n * Pm + p0 + r) * Ltot + wave * 32 * J + 4 * h;
-#pragma unroll
-    for (int t = 0; t < J; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4 *>(dst + 32 * t + 8 * g) = make_float4(
-            acc[t][4 * g] * inv, acc[t][4 * g + 1] * inv, acc[t][4 * g + 2] * inv, acc[t][4 * g + 3] * inv);
-  }
-}
-
-// K1 on 16-pixel tiles (the shape of em.hip's E/W kernel): block = (object, 16-pixel tile), 8 waves; wave w owns the
+// K1: affinity + joint softmax, pT[n][p][l] = exp((aff - max)/tau) / sum  (pixel-major, one row of Ltot probabilities per
+// pixel; rows >= P are 0).  16-pixel tiles (the shape of em.hip's E/W kernel): block = (object, 16-pixel tile), 8 waves; wave w owns the
 // 16*TW bases [w*16*TW, +16*TW) of the concatenated bank order (class w / 4).  v_mfma_f32_16x16x4_f32 with the base rows as
 // A and the pixels as B: the pixel is on the lane, four bases of a tile in the accumulator registers.  The query pixel's
 // key stays in registers (normalised there: modules.py:282); every base row is loaded once per block, all loads of a pass
@@ -198,12 +122,15 @@ __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__re
     u32x4m t = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)((p * C + 16 * m + 4 * g) * 4), 0, 0);
     xf[m] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
   }
-  const float *kb = mkn + (((long long)(2 * n + cls) * (C / 4) + g) * Lm + wq * 16 * TW + li) * 4;
+  const float *kb = mkn + (((long long)(2 * n + cls) * (C / 4 + 1) + g) * Lm + wq * 16 * TW + li) * 4;
   float4 a[CM][TP];
 #pragma unroll
   for (int m = 0; m < CM; ++m)
 #pragma unroll
     for (int t = 0; t < TP; ++t) a[m][t] = ld4(kb + ((long long)4 * m * Lm + 16 * t) * 4);
+  float4 nq[TW];   // group C/4 of the pack: the rows' squared norms as partial sums
+#pragma unroll
+  for (int t = 0; t < TW; ++t) nq[t] = ld4(kb + ((long long)(C / 4 - g) * Lm + 16 * t) * 4);
   __builtin_amdgcn_sched_barrier(0);   // every load above the MFMA chain (em.hip, em_ew16_kernel)
   // l2norm of the query pixel (modules.py:282): q / (|q| + eps), on the registers
   float ss = 0.f;
@@ -222,10 +149,20 @@ __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__re
   f32x4m acc[TW];
 #pragma unroll
   for (int t = 0; t < TW; ++t) acc[t] = f32x4m{0.f, 0.f, 0.f, 0.f};
+  // l2norm of the bases (modules.py:283): every lane scales its rows' fragments by 1 / (|row| + eps), from the squared
+  // norms kept beside the packed keys, on the way into the MFMA chain (em.hip, em_ew16_kernel, says why not on the output)
+  float rn[TW];
+#pragma unroll
+  for (int t = 0; t < TW; ++t) rn[t] = 1.0f / (sqrtf((nq[t].x + nq[t].y) + (nq[t].z + nq[t].w)) + SWEM_L2_EPS);
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
     for (int m = 0; m < CM; ++m) {
+#pragma unroll
+      for (int t = 0; t < TP; ++t) {
+        const float r = rn[ps * TP + t];
+        a[m][t].x *= r, a[m][t].y *= r, a[m][t].z *= r, a[m][t].w *= r;
+      }
 #pragma unroll
       for (int t = 0; t < TP; ++t)
         acc[ps * TP + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][t].x, xf[m].x, acc[ps * TP + t], 0, 0, 0);
@@ -351,20 +288,8 @@ static int launch_affinity(hipStream_t st, const float *qk, const float *mkn, fl
 #undef AFF16
     return SWEM_OK;
   }
-  dim3 grid(Pm / 32, N);
-#define AFF(J_, NW_)                                                                                          \
-  hipLaunchKernelGGL((match_affinity_kernel<J_, NW_>), grid, dim3(64 * NW_),                                   \
-                     ((size_t)32 * (C + 4) + 2 * NW_ * 32) * sizeof(float), st, qk, mkn, pT, C, P, Pm, tau)
-  if (Lm == 64) AFF(1, 4);
-  else if (Lm == 128) AFF(2, 4);
-  else if (Lm == 256) AFF(2, 8);
-  else if (Lm == 512) AFF(4, 8);
-  else {
-    swem_set_error("match: bases per class must be 64, 128, 256 or 512 (got %d)", Lm);
-    return SWEM_E_SHAPE;
-  }
-#undef AFF
-  return SWEM_OK;
+  swem_set_error("match: the key dimension must be 64 or 128 (got %d)", C);
+  return SWEM_E_SHAPE;
 }
 
 struct MatchWs {
@@ -380,7 +305,7 @@ MatchWs match_ws(int N, int C, int V, int P, int L, int nbanks, int plan) {
     o = align_up(o + bytes, 256);
     return at;
   };
-  w.mkn = take((size_t)N * Ltot * C * 4);
+  w.mkn = take((size_t)N * Ltot * (C + 4) * 4);   // packed keys: C/4 + 1 groups
   w.mvp = take((size_t)N * V * Ltot * 4);
   w.pT = take((size_t)N * Pm * Ltot * 4);
   w.conv = take(swem_conv2d_workspace(N, Pm, 1, (int)Ltot, V, 1, 1, 1, 0, 0, plan));
@@ -517,7 +442,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *__restrict
 }
 
 struct MatchBwdWs {
-  size_t fwd, mvpT, dP, mknT, dmvp, dqn, conv, wgrad, total;
+  size_t fwd, mknn, mvpT, dP, mknT, dmvp, dqn, conv, wgrad, total;
 };
 MatchBwdWs match_bwd_ws(int N, int C, int V, int P, int L, int nbanks) {
   MatchBwdWs w;
@@ -530,6 +455,7 @@ MatchBwdWs match_bwd_ws(int N, int C, int V, int P, int L, int nbanks) {
     return at;
   };
   w.fwd = take(match_ws(N, C, V, P, L, nbanks, 0).total);
+  w.mknn = take((size_t)N * Ltot * C * 4);
   w.mvpT = take((size_t)N * Ltot * V * 4);
   w.dP = take((size_t)N * Pm * Ltot * 4);
   w.mknT = take((size_t)2 * C * N * Ltot * 4);   // + room for one group's packed filters when N > 3
@@ -554,7 +480,7 @@ extern "C" size_t swem_match_workspace(int N, int C, int V, int P, int L, int nb
 }
 
 namespace {
-// affinity + top-l features + readout on PACKED banks: mkn [2N][C/4][Lm][4], mvp [N][V][2Lm]
+// affinity + top-l features + readout on PACKED banks: mkn [2N][C/4+1][Lm][4], mvp [N][V][2Lm]
 int match_core(void *stream, const float *qk, const float *mkn, const float *mvp, float *pT, float *mem_out, float *S, int N,
                int C, int V, int P, int Lm, int topl, float tau, int readout_plan, void *conv_ws, size_t conv_bytes) {
   const int Pm = swem_match_pad(P), Ltot = 2 * Lm;
@@ -578,8 +504,8 @@ int match_core(void *stream, const float *qk, const float *mkn, const float *mvp
 int match_check(int C, int V, int L, int Lm, int topl, float tau) {
   SWEM_REQUIRE(Lm == 64 || Lm == 128 || Lm == 256 || Lm == 512, SWEM_E_SHAPE,
                "match: bases per class must be 64, 128, 256 or 512 (got %d)", Lm);
-  SWEM_REQUIRE(C % 8 == 0 && C <= 1024 && V % 4 == 0 && L % 4 == 0, SWEM_E_SHAPE,
-               "match: need C %% 8 == 0, C <= 1024, V %% 4 == 0");
+  SWEM_REQUIRE((C == 64 || C == 128) && V % 4 == 0 && L % 4 == 0, SWEM_E_SHAPE,
+               "match: need C = 64 or 128 and V %% 4 == 0 (got C = %d, V = %d)", C, V);
   SWEM_REQUIRE(topl >= 1 && topl <= 64 && topl <= Lm, SWEM_E_SHAPE, "match: topl must be in [1, 64] (got %d)", topl);
   SWEM_REQUIRE(tau > 0.f, SWEM_E_ARG, "match: tau must be positive");
   return SWEM_OK;
@@ -593,7 +519,7 @@ extern "C" int swem_match_pack_bank_f32(void *stream, const float *kappa, const 
   SWEM_REQUIRE(nbanks >= 1 && nbanks <= 2 && bank >= 0 && bank < nbanks, SWEM_E_ARG, "match_pack_bank: bad bank index");
   const int Lm = nbanks * L;
   int rc;
-  if ((rc = swem_norm_bases_into(stream, kappa, mkn, 2 * N, C, L, Lm, bank * L))) return rc;
+  if ((rc = swem_norm_bases_into(stream, kappa, mkn, 2 * N, C, L, Lm, bank * L, 0))) return rc;
   const long long work = (long long)N * 2 * V * (L / 4);
   hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu, mvp, N, V, L, Lm, bank * L);
   SWEM_CHECK_LAUNCH("pack_values");
@@ -622,7 +548,7 @@ extern "C" int swem_match_f32(void *stream, const float *qk, const float *kappa_
 }
 
 // The same on banks the caller keeps packed (swem_match_pack_bank_f32 / swem_memorize_packed_f32): no per-frame
-// normalisation and repacking of 2 x 2 banks.  Both banks: mkn [2N][C/4][2L][4], mvp [N][V][4L].
+// normalisation and repacking of 2 x 2 banks.  Both banks: mkn [2N][C/4+1][2L][4], mvp [N][V][4L].
 extern "C" size_t swem_match_packed_workspace(int N, int C, int V, int P, int L, int readout_plan) {
   MatchWs w = match_ws(N, C, V, P, L, 2, readout_plan);
   return w.total - w.pT;
@@ -669,8 +595,12 @@ extern "C" int swem_match_bwd_f32(void *stream, const float *qk, const float *ka
   float *mvpT = (float *)(base + w.mvpT), *dP = (float *)(base + w.dP), *mknT = (float *)(base + w.mknT);
   float *dmvp = (float *)(base + w.dmvp), *dqn = (float *)(base + w.dqn);
   int rc;
-  if ((rc = swem_norm_bases_into(stream, kappa_first, mkn, 2 * N, C, L, Lm, 0))) return rc;
-  if (nbanks == 2 && (rc = swem_norm_bases_into(stream, kappa_update, mkn, 2 * N, C, L, Lm, L))) return rc;
+  // packed keys twice: raw for the affinity kernel (it normalises, exactly as in the forward), normalised for the d qn GEMM
+  float *mknn = (float *)(base + w.mknn);
+  if ((rc = swem_norm_bases_into(stream, kappa_first, mkn, 2 * N, C, L, Lm, 0, 0))) return rc;
+  if (nbanks == 2 && (rc = swem_norm_bases_into(stream, kappa_update, mkn, 2 * N, C, L, Lm, L, 0))) return rc;
+  if ((rc = swem_norm_bases_into(stream, kappa_first, mknn, 2 * N, C, L, Lm, 0, 1))) return rc;
+  if (nbanks == 2 && (rc = swem_norm_bases_into(stream, kappa_update, mknn, 2 * N, C, L, Lm, L, 1))) return rc;
   const long long work = (long long)N * 2 * V * (L / 4);
   hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu_first, mvp, N, V, L, Lm, 0);
   if (nbanks == 2)
@@ -704,7 +634,7 @@ extern "C" int swem_match_bwd_f32(void *stream, const float *qk, const float *ka
 #undef PIX
   SWEM_CHECK_LAUNCH("match_bwd_pixel");
   // (4) d qn = sum_n da[n] . mkn[n]: one GEMM with the objects as concatenated sources (filters [C][N*Ltot])
-  hipLaunchKernelGGL(kn_cmajor_kernel, dim3(cdiv((long long)C * N * Ltot, 256)), dim3(256), 0, ST, mkn, mknT, N, C, Lm);
+  hipLaunchKernelGGL(kn_cmajor_kernel, dim3(cdiv((long long)C * N * Ltot, 256)), dim3(256), 0, ST, mknn, mknT, N, C, Lm);
   SWEM_CHECK_LAUNCH("kn_cmajor");
   // (the conv kernel concatenates up to three sources: objects go in groups of three, later groups add onto the result)
   for (int n0 = 0; n0 < N; n0 += 3) {

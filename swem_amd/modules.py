@@ -151,7 +151,7 @@ class SWEMCore(nn.Module):
         """kappa (B,N,2,Ck,L), x_t (B,1,1,P,Ck), masks (B,N,2,P,1) -> weights (B,N,2,P,1)."""
         B, N = kappa.shape[:2]
         assert B == 1
-        kn = ops.em_norm_bases(kappa.reshape(N * 2, *kappa.shape[-2:]).contiguous())
+        kn = ops.em_pack_bases(kappa.reshape(N * 2, *kappa.shape[-2:]).contiguous())
         x = x_t.reshape(x_t.shape[-2], x_t.shape[-1]).contiguous()
         w, _ = ops.em_ew(x, kn, masks.reshape(N * 2, -1).contiguous(), None, self.tau, True, False)
         return w.view(B, N, 2, -1, 1)
@@ -161,7 +161,7 @@ class SWEMCore(nn.Module):
         B, N = kappa.shape[:2]
         assert B == 1
         L = kappa.shape[-1]
-        kn = ops.em_norm_bases(kappa.reshape(N * 2, *kappa.shape[-2:]).contiguous())
+        kn = ops.em_pack_bases(kappa.reshape(N * 2, *kappa.shape[-2:]).contiguous())
         x = x_t.reshape(x_t.shape[-2], x_t.shape[-1]).contiguous()
         P = x.shape[0]
         _, z = ops.em_ew(x, kn, None, weights.reshape(N * 2, -1).contiguous(), self.tau, False, True)

@@ -630,8 +630,17 @@ def em_norm_bases(kappa):
     return kn
 
 
+def em_pack_bases(kappa):
+    """kappa (NK, C, L) -> kp (NK, C/4 + 1, L, 4): the packed keys the E/W kernel reads (bases + their squared norms)."""
+    _chk(kappa)
+    NK, Cc, L = kappa.shape
+    kp = torch.empty((NK, Cc // 4 + 1, L, 4), dtype=torch.float32, device=kappa.device)
+    _lib.call('swem_em_pack_bases_f32', _stream(), kappa.data_ptr(), kp.data_ptr(), NK, Cc, L)
+    return kp
+
+
 def em_ew(x, kn, masks, w_in, tau, do_w, do_e):
-    """x (P,C), kn (NK,C/4,L,4), masks/w_in (NK,P) -> (weights (NK,P) or None, z (N,Pz,2L) pixel-major or None)."""
+    """x (P,C), kn = packed keys (NK,C/4+1,L,4), masks/w_in (NK,P) -> (weights (NK,P) or None, z (N,Pz,2L) pixel-major or None)."""
     _chk(x)
     _chk(kn)
     P, Cc = x.shape
@@ -650,7 +659,7 @@ def em_mstep(A, per_object, z, prev, zita_prev, P, want_kn=False):
     R = prev.shape[1]
     out = torch.empty_like(prev)
     zita = torch.empty_like(zita_prev)
-    kn = torch.empty((NK, R // 4, L, 4), dtype=torch.float32, device=prev.device) if want_kn else None
+    kn = torch.empty((NK, R // 4 + 1, L, 4), dtype=torch.float32, device=prev.device) if want_kn else None
     wsb = _lib.query('swem_em_mstep_workspace', NK, R, P, L)
     ws = workspace(wsb, prev.device)
     _lib.call('swem_em_mstep_f32', _stream(), _chk(A).data_ptr(), int(per_object), _chk(z).data_ptr(), prev.data_ptr(),
@@ -718,7 +727,7 @@ def match(qk, kappa_first, nu_first, kappa_update, nu_update, topl, tau):
 
 def new_pack(N, Cc, V, L, device):
     """Matching's persistent packed banks for N objects (include/swem_hip.h, swem_memorize_packed_f32)."""
-    return (torch.zeros((2 * N, Cc // 4, 2 * L, 4), dtype=torch.float32, device=device),
+    return (torch.zeros((2 * N, Cc // 4 + 1, 2 * L, 4), dtype=torch.float32, device=device),
             torch.zeros((N, V, 4 * L), dtype=torch.float32, device=device))
 
 

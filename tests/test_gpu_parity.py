@@ -16,6 +16,7 @@ from tests import helpers as H
 from tests.test_gpu_model import CFG_B, DEV, logit_bound, logits_close, relmax
 
 pytestmark = pytest.mark.gpu
+REORDER_DRAWS = 6      # fp32 evaluations of the reference's memorize with permuted key channels (the EM's noise yardstick)
 
 
 def _to_dev(bases):
@@ -86,15 +87,35 @@ def teacher_forced_clip(model, om, frames, m0, out, fixture=None, seed=77, tol=1
                              om.core.n_bases, om.core.n_iters, om.core.tau, om.core.valdim)
                 om('memorize', oqk, omv, ohard, opm)
                 ob, hb = om.core.upd.bases, core.memories['update'].bases
+                # how far the reference's OWN fp32 arithmetic lands from float64 is one draw of an amplified rounding error
+                # (the same frame of the five-object edge clip: 3.2e-4 on the GPU box's CPU, 2.0e-3 on the build container's).  A steadier yardstick: the same fp32 memorize under REORDER_DRAWS
+                # mathematically neutral re-orderings of its sums (the key channels permuted in x and in the prior bases
+                # alike, the result permuted back) -- the spread of the reference against itself
+                draws = {'kappa': [], 'nu': [], 'zita': []}
+                gperm = torch.Generator().manual_seed(11 * i)
+                with torch.random.fork_rng():
+                    for k in range(REORDER_DRAWS):
+                        perm = torch.randperm(oqk.shape[1], generator=gperm)
+                        inv = torch.argsort(perm)
+                        pr = dict(prior, kappa=prior['kappa'][..., perm, :].contiguous())
+                        bp = O.swem(oqk[:, perm].contiguous(), omv, mk, pr, om.core.n_bases, om.core.n_iters, om.core.tau,
+                                    om.core.valdim)
+                        draws['kappa'].append(_mass_err(bp['kappa'][..., inv, :].double(), b64['kappa'], b64['zita']))
+                        draws['nu'].append(_mass_err(bp['nu'].double(), b64['nu'], b64['zita']))
+                        draws['zita'].append(relmax(bp['zita'].double(), b64['zita']))
                 for name in ('kappa', 'nu'):
                     row[name + '_mass_rel'] = _mass_err(hb[name], ob[name], ob['zita'])
                     row[name + '_mass_rel_vs_fp64'] = _mass_err(hb[name].double(), b64[name], b64['zita'])
                     row[name + '_mass_rel_reference_fp32_vs_fp64'] = _mass_err(ob[name].double(), b64[name], b64['zita'])
+                    row[name + '_mass_rel_reference_fp32_reordered_vs_fp64'] = draws[name]
                 row['zita_rel'] = relmax(hb['zita'], ob['zita'])
                 row['zita_rel_vs_fp64'] = relmax(hb['zita'].double(), b64['zita'])
                 row['zita_rel_reference_fp32_vs_fp64'] = relmax(ob['zita'].double(), b64['zita'])
+                row['zita_rel_reference_fp32_reordered_vs_fp64'] = draws['zita']
             rows.append(row)
-            print('teacher-forced frame %d: %s' % (i, {k: ('%.3g' % v if isinstance(v, float) else v) for k, v in row.items()}))
+            print('teacher-forced frame %d: %s' % (i, {k: ('%.3g' % v if isinstance(v, float) else
+                                                           ['%.3g' % e for e in v] if isinstance(v, list) else v)
+                                                       for k, v in row.items()}))
             assert logits_close(lg_s, ologits, tol), 'stage logits frame %d: %.3g' % (i, row['dlogits_stage_max'])
             assert row['context_rel_stage'] < 1e-4
             assert logits_close(logits, ologits, tol), 'frame %d: |dlogits| %.3g (beyond the ulp slack: %.3g)' % (i, dl, excess)
@@ -102,8 +123,8 @@ def teacher_forced_clip(model, om, frames, m0, out, fixture=None, seed=77, tol=1
             if i < t - 1:
                 assert row['encode_value_rel'] < 1e-4
                 for name in ('kappa_mass_rel', 'nu_mass_rel', 'zita_rel'):
-                    floor = row[name + '_reference_fp32_vs_fp64']
-                    assert row[name + '_vs_fp64'] <= max(1e-4, 4 * floor), (name, row)
+                    floor = max([row[name + '_reference_fp32_vs_fp64']] + row[name + '_reference_fp32_reordered_vs_fp64'])
+                    assert row[name + '_vs_fp64'] <= max(1e-4, 2 * floor), (name, row)
     return rows
 
 

@@ -410,9 +410,21 @@ def test_memorize_backward(lib):
     hx = x[0].flatten(1).t().contiguous().to(DEV)
     kap, nu, zita = A.memorize(hv, hnu, hx, m[0].flatten(2).contiguous().to(DEV), prior['kappa'][0].contiguous().to(DEV),
                                prior['zita'][0, :, :, 0].contiguous().to(DEV), T, 0.05)
-    close(zita.cpu(), ref['zita'][0, :, :, 0], 1e-4, 'zita')
-    mass = ref['zita'][0]
-    close((nu.cpu() * mass), (ref['nu'][0] * mass).detach(), 1e-4, 'nu * zita')
+    # the forward against float64 (T iterations amplify rounding: two fp32 evaluations of this input -- the reference with
+    # its key channels re-ordered -- differ from each other by up to 1.8e-4 and from float64 by 2e-5 .. 1e-4): the HIP
+    # result may be as far from float64 as twice the reference's own fp32 arithmetic is
+    with torch.no_grad():
+        r64 = O.swem(x.double(), v.detach().double(), m.double(), {k: t.detach().double() for k, t in prior.items()}, L, T,
+                     0.05, V)
+    mass = r64['zita'][0]
+
+    def err64(nu_, zita_):
+        return (float(((nu_.double() - r64['nu'][0]) * mass).abs().max() / (r64['nu'][0] * mass).abs().max()),
+                float((zita_.double() - r64['zita'][0, :, :, 0]).abs().max() / r64['zita'].abs().max()))
+    floor = err64(ref['nu'][0].detach(), ref['zita'][0, :, :, 0])
+    got = err64(nu.detach().cpu(), zita.cpu())
+    print('memorize vs float64: hip nu*zita %.3g zita %.3g   reference fp32 %.3g %.3g' % (got + floor))
+    assert got[0] <= max(1e-4, 2 * floor[0]) and got[1] <= max(1e-4, 2 * floor[1]), (got, floor)
     (nu * dnu[0].to(DEV)).sum().backward()
     # identical z would make these exact; the fp32 EM differs by rounding, so compare mass-weighted like the forward
     close(hnu.grad.cpu(), prior['nu'].grad[0], 1e-3, 'd nu_prev')

@@ -42,7 +42,7 @@ def main():
     kappa = torch.nn.functional.normalize(torch.randn(N, 2, C, L, generator=g), dim=2).to(dev)
     nu = torch.randn(N, 2, V, L, generator=g).to(dev)
     zita = (torch.rand(N, 2, L, generator=g) * 3 + 0.1).to(dev)
-    kn = ops.em_norm_bases(kappa.view(2 * N, C, L))
+    kn = ops.em_pack_bases(kappa.view(2 * N, C, L))
     w, zT = ops.em_ew(x, kn, masks.view(2 * N, P), masks.view(2 * N, P), tau, True, True)
     fl_e = 2.0 * P * C * 2 * L * N
     pack = ops.new_pack(N, C, V, L, dev)
@@ -58,9 +58,9 @@ def main():
         ('em_ew (W+E)', lambda: ops.em_ew(x, kn, masks.view(2 * N, P), masks.view(2 * N, P), tau, True, True), 2 * fl_e),
         ('em_ew (W only)', lambda: ops.em_ew(x, kn, masks.view(2 * N, P), None, tau, True, False), fl_e),
         ('em_ew (E only)', lambda: ops.em_ew(x, kn, None, masks.view(2 * N, P), tau, False, True), fl_e),
-        ('em_mstep keys (split-P GEMM + finalize+norm)', lambda: ops.em_mstep(x, False, zT, kappa.view(2 * N, C, L),
+        ('em_mstep keys (one launch)', lambda: ops.em_mstep(x, False, zT, kappa.view(2 * N, C, L),
                                                                           zita.view(2 * N, L), P, True), fl_e),
-        ('em_mstep values (split-P GEMM + finalize)', lambda: ops.em_mstep(v, True, zT, nu.view(2 * N, V, L),
+        ('em_mstep values (one launch)', lambda: ops.em_mstep(v, True, zT, nu.view(2 * N, V, L),
                                                                             zita.view(2 * N, L), P), 2.0 * P * V * 2 * L * N),
         ('memorize (T=5)', lambda: ops.memorize(x, v, masks, kappa, nu, zita, T, tau), 0),
         ('match (2 banks, packed in the call)', lambda: ops.match(x, kappa, nu, kappa, nu, topl, tau), 0),

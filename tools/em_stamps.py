@@ -54,7 +54,7 @@ def main():
         gr.replay()
     torch.cuda.synchronize()
     st = stamps.cpu().view(64, 8, 2)
-    names = ['ew', 'mstep', 'fin'] * T
+    names = ['ew', 'mstep'] * T
     prev_end = None
     for i, nm in enumerate(names):
         row = st[i]
