@@ -272,6 +272,22 @@ def main():
                                    'matching readout GEMM', 0.0, 0, 'readout'))
             return real_mp(qk_, pack_, L_, topl_, tau_)
         ops.match_packed = marked
+        # The launch stream must never run dry while the frames are traced: with an empty queue a launch's event interval is
+        # the HOST's enqueue time (~10 us per Python call), not the kernel's.  A spin kernel holds the GPU back until the host
+        # has enqueued all traced frames; the intervals then lie between back-to-back packets of one in-order queue.
+        torch.cuda.synchronize()
+        t_host = time.perf_counter()
+        runner.step()
+        t_host = time.perf_counter() - t_host       # host time to enqueue one eager frame
+        torch.cuda.synchronize()
+        ops.CONV_TRACE = []
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        torch.cuda._sleep(10_000_000)
+        c1.record()
+        torch.cuda.synchronize()
+        cyc_per_ms = 10_000_000 / c0.elapsed_time(c1)
+        torch.cuda._sleep(int(cyc_per_ms * 1e3 * t_host * nprof * 1.2))
         for _ in range(nprof):
             runner.step()
         torch.cuda.synchronize()
@@ -341,7 +357,8 @@ def main():
             'frac_fp32_pipe': per_pipe.get('fp32', {}).get('frac'),
             'conv_ms_per_frame_eager_one_stream': round(sum(d['ms'] for d in pipes.values()) / nprof, 3),
             'note': 'useful conv FLOPs (2*M*Cout*KH*KW*Cin, unpadded) of %d eager frames of ONE sequence / summed per-launch '
-                    'HIP-event durations on the launch stream; the timed region above is graph replay of %d sequence(s) on %d '
+                    'HIP-event durations on the launch stream (the queue held full behind a spin kernel: the intervals are '
+                    'GPU time between back-to-back packets, not host enqueue time); the timed region above is graph replay of %d sequence(s) on %d '
                     'stream(s), whose kernels overlap -- `whole_frame` prices THAT' % (nprof, nseq, nseq),
             'plans_bf16x6': sum(1 for v in ops._CONV_PLANS.values() if (v >> 16) & 3 == 1),
             'plans_bf16x3': sum(1 for v in ops._CONV_PLANS.values() if (v >> 16) & 3 == 3), 'plans_total': len(ops._CONV_PLANS)}

@@ -254,12 +254,15 @@ int swem_memorize_f32(void *stream, const float *x, const float *v, const float 
  * (modules.py:295-306 `get_mem` concatenates the banks on every frame; here the caller owns one persistent pack):
  *   mkn [2N][C/4+1][2L][4] packed keys (see kp above) of both banks, rows [0,L) 'first', [L,2L) 'update'
  *   mvp [N][V][4L]        value bases, mvp[n][v][cls*2L + bank*L + l]
+ *   mvq [N][2][4L/8][V][8] (optional, bf16) the same value bases pre-split for the readout GEMM: planes hi and mid
+ *                         (x = hi + mid to 16 significant bits), k = cls*2L + bank*L + l in groups of 8 -- the filter layout
+ *                         of swem_conv2d_nhwc_bf16x3.  NULL: not kept (the readout then runs from mvp).
  * prior_packed != 0: the prior's packed keys are READ from the pack's 'update' half (written there by the previous
  * frame's call: kappa_prev must be that frame's kappa_out); the new bases are WRITTEN to bank `bank` (0 'first', 1 'update'). */
 int swem_memorize_packed_f32(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
                              const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out,
-                             float *zita_out, float *mkn, float *mvp, int prior_packed, int bank, int N, int C, int V,
-                             int P, int L, int T, float tau, void *ws, size_t ws_bytes);
+                             float *zita_out, float *mkn, float *mvp, void *mvq, int prior_packed, int bank, int N, int C,
+                             int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------
  * Matching (modules.py:198-208, 232-289): l2norm, affinity, joint {bg,fg} softmax, value
@@ -279,12 +282,18 @@ int swem_match_f32(void *stream, const float *qk, const float *kappa_first, cons
 /* Matching on banks the caller keeps PACKED (layouts at swem_memorize_packed_f32): the reference concatenates and
  * normalises both banks on every frame (modules.py:282-283, 295-306); the 'first' bank never changes after frame 0 and the
  * 'update' bank's packed form is a by-product of memorize, so a persistent pack removes that work from the frame.
- * swem_match_pack_bank_f32 (re)builds one bank of a pack from the reference-layout bases (nbanks = 1: a pack of one bank). */
-int swem_match_pack_bank_f32(void *stream, const float *kappa, const float *nu, float *mkn, float *mvp, int bank,
+ * swem_match_pack_bank_f32 (re)builds one bank of a pack from the reference-layout bases (nbanks = 1: a pack of one bank;
+ * mvq may be NULL).
+ * Readout arithmetic (modules.py:272-273, mem_out = p . nu): readout_plan's math field 0 = fp32 matrix cores, 1 = bf16x6
+ * (operands split in the kernel, fp32-level error), 3 = "bf16x3" on PRE-SPLIT planes -- the affinity kernel also writes
+ * the probabilities as bf16 planes hi / mid, the filters are the pack's mvq (required for this mode; without it the call
+ * falls back to the fp32 kernel), three bf16 products: ~2^-16 relative per product, the arithmetic of the convolutions that
+ * consume mem_out. */
+int swem_match_pack_bank_f32(void *stream, const float *kappa, const float *nu, float *mkn, float *mvp, void *mvq, int bank,
                              int nbanks, int N, int C, int V, int L);
 size_t swem_match_packed_workspace(int N, int C, int V, int P, int L, int readout_plan);
-int swem_match_packed_f32(void *stream, const float *qk, const float *mkn, const float *mvp, float *mem_out, float *S,
-                          int N, int C, int V, int P, int L, int topl, float tau, int readout_plan, void *ws,
+int swem_match_packed_f32(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq, float *mem_out,
+                          float *S, int N, int C, int V, int P, int L, int topl, float tau, int readout_plan, void *ws,
                           size_t ws_bytes);
 
 #ifdef __cplusplus

@@ -51,13 +51,13 @@ SIGNATURES = {
     'swem_em_mstep_f32': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz]),
     'swem_memorize_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'swem_memorize_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _sz]),
-    'swem_memorize_packed_f32': (_i, [_p] * 12 + [_i] * 8 + [_f, _p, _sz]),
+    'swem_memorize_packed_f32': (_i, [_p] * 13 + [_i] * 8 + [_f, _p, _sz]),
     'swem_match_pad': (_i, [_i]),
     'swem_match_workspace': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'swem_match_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _sz]),
-    'swem_match_pack_bank_f32': (_i, [_p] * 5 + [_i] * 6),
+    'swem_match_pack_bank_f32': (_i, [_p] * 6 + [_i] * 6),
     'swem_match_packed_workspace': (_sz, [_i] * 6),
-    'swem_match_packed_f32': (_i, [_p] * 6 + [_i] * 6 + [_f, _i, _p, _sz]),
+    'swem_match_packed_f32': (_i, [_p] * 7 + [_i] * 6 + [_f, _i, _p, _sz]),
     # ---- include/swem_hip_train.h
     'swem_vos_loss_workspace': (_sz, [_i, _i, _ll]),
     'swem_vos_loss_frame_fwd_f32': (_i, [_p, _p, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _ll, _ll, _p, _p, _sz]),

@@ -971,7 +971,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
     const long long ps = sidx == 0 ? p.ps[0] : (sidx == 1 ? p.ps[1] : p.ps[2]);
     return raw_rsrc(base, (unsigned)(3 * ps * 2));
   };
-  const i32x4 rsw = raw_rsrc(p.wsplit, (unsigned)((long long)3 * p.Ncols * p.K * 2));
+  // (per-batch filter planes -- matching's value readout, a batched GEMM: tiles never straddle two batch items)
+  const i32x4 rsw = raw_rsrc(p.wsplit + (p.w_bs ? (long long)(m0 / (p.Ho * p.Wo)) * p.w_bs : 0ll),
+                             (unsigned)((long long)3 * p.Ncols * p.K * 2));
   const unsigned wplane = (unsigned)((long long)p.Ncols * p.K * 2);
   const unsigned wgroup = (unsigned)p.Ncols * 16u;  // bytes per k/8 group of the filter planes
 
@@ -1704,7 +1706,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
                        long long bs1, long long ps1, const void *x2, int c2, long long bs2, long long ps2, int B, int H, int W,
                        const void *w_bf16x3, const float *scale, const float *shift, const float *res, long long res_bs,
                        float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
-                       const PlaneOut *po);
+                       const PlaneOut *po, long long w_bs = 0);
 }
 extern "C" int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0, long long ps0,
                                        const void *x1, int c1, long long bs1, long long ps1, const void *x2, int c2,
@@ -1726,12 +1728,18 @@ extern "C" int swem_conv2d_nhwc_bf16x3_planes(void *stream, const void *x0, int 
   return conv2d_bf16x3_impl(stream, x0, c0, bs0, ps0, x1, c1, bs1, ps1, x2, c2, bs2, ps2, B, H, W, w_bf16x3, scale, shift, res,
                             res_bs, y, Cout, KH, KW, stride, pad, flags, plan, ws, ws_bytes, &po);
 }
+// batched GEMM on pre-split planes (common.h): y[b] = x[b] . w[b]^T with per-batch filter planes, w_bs bf16 elements apart
+int swem_gemm_bf16x3_batched(void *stream, const void *x, int K, long long bs, long long ps, int B, int M, const void *w,
+                             long long w_bs, float *y, int Ncols, int plan, void *ws, size_t ws_bytes) {
+  return conv2d_bf16x3_impl(stream, x, K, bs, ps, nullptr, 0, 0, 0, nullptr, 0, 0, 0, B, M, 1, w, nullptr, nullptr, nullptr, 0, y,
+                            Ncols, 1, 1, 1, 0, 0, plan, ws, ws_bytes, nullptr, w_bs);
+}
 namespace {
 int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1, int c1,
                        long long bs1, long long ps1, const void *x2, int c2, long long bs2, long long ps2, int B, int H, int W,
                        const void *w_bf16x3, const float *scale, const float *shift, const float *res, long long res_bs,
                        float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
-                       const PlaneOut *po) {
+                       const PlaneOut *po, long long w_bs) {
   SWEM_REQUIRE(x0 && w_bf16x3 && y, SWEM_E_ARG, "conv2d_bf16x3: null pointer");
   if (!x1) c1 = 0;
   if (!x2) c2 = 0;
@@ -1769,11 +1777,13 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   SWEM_REQUIRE(M < (1ll << 31), SWEM_E_SHAPE, "conv2d_bf16x3: too large");
   p.M = (int)M;
   p.w = nullptr; p.wsplit = static_cast<const unsigned short *>(w_bf16x3);
-  p.scale = scale; p.shift = shift; p.res = res; p.res_bs = res_bs; p.w_bs = 0; p.y = y;
+  p.scale = scale; p.shift = shift; p.res = res; p.res_bs = res_bs; p.w_bs = w_bs; p.y = y;
   p.Cout = Cout; p.Ncols = glu ? 2 * Cout : Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.flags = flags;
   p.nkb = cdiv(p.K, BK);
   Plan pl = resolve_plan(plan, p.M, p.Ncols, p.nkb, glu);
+  SWEM_REQUIRE(w_bs == 0 || (p.Ho * p.Wo) % 128 == 0, SWEM_E_SHAPE,
+               "conv2d_bf16x3: per-batch filters need Ho*Wo (%d) to be a multiple of the 128-row tile", p.Ho * p.Wo);
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;
   p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.xpn = 1;

@@ -31,6 +31,7 @@
 //                trip of partial sums) necessary.
 #include "../../include/swem_hip_train.h"
 #include "common.h"
+#include "bf16_split.h"
 
 // Debug build only (-DSWEM_EM_STAMPS): in-kernel clock stamps of block 0 / wave 0 (common.h), written to a buffer set by
 // swem_debug_set_stamps (tools/em_stamps.py, tools/conv_stamps.py).  The product build contains none of it.
@@ -281,8 +282,10 @@ struct MStepP {
   float *kappa_out, *nu_out, *zita_out;
   float *kp_out;   // optional: the new key bases packed [NK][C/4][kp_rows][4] at row offset kp_off (what E/W / affinity read)
   float *mvp_out;  // optional: value bases packed for matching, mvp[n][v][cls*mvp_lm + mvp_off + l]
+  unsigned short *mvq_out;  // optional: the same as two bf16 planes (hi, mid) per object, [n][2][2*mvp_lm/8][V][8]
   int kp_rows, kp_off, mvp_lm, mvp_off;
   int Ck, C, V, P, Pz, L, NK, nrt, total;  // nrt = 32-row tiles of the row space, total = NK * (L/16) * nrt blocks
+  int rpg;                                 // row tiles per group of the tile order (a divisor of nrt)
 };
 
 // One launch = the whole M step (modules.py:122-127, 164-165), no partial sums in memory and no second kernel:
@@ -333,8 +336,12 @@ __global__ __launch_bounds__(512, LOOP ? 2 : 4) void em_mstep_kernel(MStepP p ST
   const int per = gridDim.x >> 3;
   const int u = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (u >= p.total) return;
-  const int bt = u / p.nrt, rt = u - bt * p.nrt;
+  // tile order: row tiles in groups of p.rpg, then base tile, then row tile inside the group -- an XCD's consecutive
+  // blocks share few z columns AND few row columns, so that both fit its 4 MB L2 (sized by mstep_impl)
   const int tiles = p.L / 16;
+  const int per_rg = p.NK * tiles * p.rpg;
+  const int rg = u / per_rg, ur = u - rg * per_rg;
+  const int bt = ur / p.rpg, rt = rg * p.rpg + (ur - bt * p.rpg);
   const int nk = bt / tiles, l0 = (bt - nk * tiles) * 16;
   const int n = nk >> 1, cls = nk & 1;
   const int row0 = rt * 32;
@@ -427,6 +434,28 @@ __global__ __launch_bounds__(512, LOOP ? 2 : 4) void em_mstep_kernel(MStepP p ST
     p.nu_out[((long long)nk * p.V + row) * p.L + l0 + oi] = val;
     if (p.mvp_out) p.mvp_out[((long long)n * p.V + row) * (2 * p.mvp_lm) + cls * p.mvp_lm + p.mvp_off + l0 + oi] = val;
     if (p.Ck == 0 && rt == 0 && oj == 0 && p.zita_out) p.zita_out[(long long)nk * p.L + l0 + oi] = zt;
+    if (p.mvq_out) {
+      // the readout GEMM's pre-split filter planes (match.hip): 8 consecutive bases of one value row are one 16-byte run, so
+      // the tile turns through the LDS (the reduction buffer is free again) and 64 threads store 16 bytes per plane
+      __syncthreads();
+      float *vt = &red[0][0][0][0];   // [16 bases][33]
+      vt[oi * 33 + oj] = val;
+      __syncthreads();
+      if (tid < 64) {
+        const int grp = tid >> 5, vr = tid & 31;
+        float4 a = make_float4(vt[(8 * grp) * 33 + vr], vt[(8 * grp + 1) * 33 + vr], vt[(8 * grp + 2) * 33 + vr],
+                               vt[(8 * grp + 3) * 33 + vr]);
+        float4 b = make_float4(vt[(8 * grp + 4) * 33 + vr], vt[(8 * grp + 5) * 33 + vr], vt[(8 * grp + 6) * 33 + vr],
+                               vt[(8 * grp + 7) * 33 + vr]);
+        uint2 h0, m0, lo0, h1, m1, lo1;
+        split3(a, h0, m0, lo0);
+        split3(b, h1, m1, lo1);
+        const int kg = (cls * p.mvp_lm + p.mvp_off + l0) / 8 + grp, ngrp = 2 * p.mvp_lm / 8;
+        unsigned short *base = p.mvq_out + (long long)n * 2 * ngrp * p.V * 8;
+        *reinterpret_cast<uint4 *>(base + ((long long)kg * p.V + col + vr) * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4 *>(base + ((long long)(ngrp + kg) * p.V + col + vr) * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+      }
+    }
   }
   STAMP(4);
 #ifdef SWEM_EM_STAMPS
@@ -502,16 +531,26 @@ namespace {
 int mstep_impl(void *stream, const float *x, const float *v, const float *z, const float *kappa_prev,
                const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out,
                float *kp_out, int kp_rows, int kp_off, float *mvp_out, int mvp_lm, int mvp_off, int NK, int Ck, int Vv,
-               int C, int V, int P, int L) {
+               int C, int V, int P, int L, unsigned short *mvq_out = nullptr) {
   MStepP mp;
   mp.x = x, mp.v = v, mp.z = z;
   mp.kappa_prev = kappa_prev, mp.nu_prev = nu_prev, mp.zita_prev = zita_prev;
   mp.kappa_out = kappa_out, mp.nu_out = nu_out, mp.zita_out = zita_out;
-  mp.kp_out = kp_out, mp.mvp_out = mvp_out;
+  mp.kp_out = kp_out, mp.mvp_out = mvp_out, mp.mvq_out = mvq_out;
   mp.kp_rows = kp_rows, mp.kp_off = kp_off, mp.mvp_lm = mvp_lm, mp.mvp_off = mvp_off;
   mp.Ck = Ck, mp.C = C, mp.V = V, mp.P = P, mp.Pz = swem_em_pad(P), mp.L = L, mp.NK = NK;
   mp.nrt = (Ck + Vv) / 32;
   mp.total = NK * (L / 16) * mp.nrt;
+  // An XCD runs total/8 consecutive tiles = (that / rpg) base tiles x rpg row tiles and reads 64 bytes per pixel of z for
+  // each of the former, 128 of x / v for each of the latter: least for rpg ~ sqrt(total / 16).  (Keys + values at config
+  // B: 1280 tiles; with all 20 row tiles in one group an XCD touches 5 MB -- more than its L2 -- with 10 it is 3.7 MB.)
+  mp.rpg = mp.nrt;
+  {
+    const float want = sqrtf((float)mp.total / 16.f);
+    float best = 1e30f;
+    for (int d = 1; d <= mp.nrt; ++d)
+      if (mp.nrt % d == 0 && fabsf((float)d - want) < best) best = fabsf((float)d - want), mp.rpg = d;
+  }
   const dim3 grid((mp.total + 7) / 8 * 8);
   if (P <= 4 * 8 * 3 * MG) hipLaunchKernelGGL(em_mstep_kernel<false>, grid, dim3(512), 0, ST, mp STAMP_PASS);
   else hipLaunchKernelGGL(em_mstep_kernel<true>, grid, dim3(512), 0, ST, mp STAMP_PASS);
@@ -564,7 +603,7 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
                   const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out, int N,
                   int C, int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes, float *z_ext,
                   const float *kn_prior, int knp_rows, int knp_off, float *kn_out, int kno_rows, int kno_off,
-                  float *mvp_out, int mvp_lm, int mvp_off) {
+                  float *mvp_out, int mvp_lm, int mvp_off, unsigned short *mvq_out = nullptr) {
   SWEM_REQUIRE(x && v && masks && kappa_prev && nu_prev && zita_prev && kappa_out && nu_out && zita_out, SWEM_E_ARG,
                "memorize: null pointer");
   SWEM_REQUIRE(T >= 1, SWEM_E_ARG, "memorize: T < 1");
@@ -598,7 +637,7 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
     // key bases every iteration; the value bases (modules.py:164-165) from the LAST z, in the same two launches
     if ((rc = mstep_impl(stream, x, last ? v : nullptr, z, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out,
                          last ? kn_out : kn, last ? kno_rows : L, last ? kno_off : 0, last ? mvp_out : nullptr, mvp_lm,
-                         mvp_off, NK, C, last ? V : 0, C, V, P, L)))
+                         mvp_off, NK, C, last ? V : 0, C, V, P, L, last ? mvq_out : nullptr)))
       return rc;
     kcur = kn, krows = L, koff = 0;
   }
@@ -624,13 +663,13 @@ extern "C" int swem_memorize_f32(void *stream, const float *x, const float *v, c
 extern "C" int swem_memorize_packed_f32(void *stream, const float *x, const float *v, const float *masks,
                                         const float *kappa_prev, const float *nu_prev, const float *zita_prev,
                                         float *kappa_out, float *nu_out, float *zita_out, float *mkn, float *mvp,
-                                        int prior_packed, int bank, int N, int C, int V, int P, int L, int T, float tau,
-                                        void *ws, size_t ws_bytes) {
+                                        void *mvq, int prior_packed, int bank, int N, int C, int V, int P, int L, int T,
+                                        float tau, void *ws, size_t ws_bytes) {
   SWEM_REQUIRE(mkn && mvp, SWEM_E_ARG, "memorize_packed: null pack");
   SWEM_REQUIRE(bank == 0 || bank == 1, SWEM_E_ARG, "memorize_packed: bank must be 0 or 1");
   return memorize_impl(stream, x, v, masks, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out, N, C, V, P, L, T,
                        tau, ws, ws_bytes, nullptr, prior_packed ? mkn : nullptr, 2 * L, L, mkn, 2 * L, bank * L, mvp,
-                       2 * L, bank * L);
+                       2 * L, bank * L, static_cast<unsigned short *>(mvq));
 }
 
 // training: the same as swem_memorize_f32, and the last E step's responsibilities z [N][Pz][2L] (Pz = swem_em_pad(P), rows

@@ -15,6 +15,7 @@
 //  per SIMD every global and LDS latency was exposed: 209 us per frame.  This split runs in a fraction of that.)
 #include "../../include/swem_hip_train.h"
 #include "common.h"
+#include "bf16_split.h"
 
 namespace {
 
@@ -34,6 +35,27 @@ __global__ void pack_values_kernel(const float *__restrict__ nu, float *__restri
   int n = (int)(t >> 1);
   float4 val = ld4(nu + i * 4);
   *reinterpret_cast<float4 *>(mvp + ((long long)n * V + v) * (2 * Lm) + cls * Lm + off + l4 * 4) = val;
+}
+
+// the readout GEMM's pre-split filters: mvq[n][plane][(cls*Lm + off + l)/8][v][l%8] = bf16 hi / mid of nu[n][cls][v][l]
+__global__ void pack_value_planes_kernel(const float *__restrict__ nu, unsigned short *__restrict__ mvq, int N, int V, int L,
+                                         int Lm, int off) {
+  const int l8n = L / 8;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)N * 2 * V * l8n) return;
+  const int v = (int)(i % V);     // value row fastest: consecutive threads store consecutive 16-byte runs
+  long long t = i / V;
+  const int l8 = (int)(t % l8n);
+  t /= l8n;
+  const int cls = (int)(t & 1), n = (int)(t >> 1);
+  const float *src = nu + (((long long)n * 2 + cls) * V + v) * L + l8 * 8;
+  uint2 h0, m0, lo0, h1, m1, lo1;
+  split3(ld4(src), h0, m0, lo0);
+  split3(ld4(src + 4), h1, m1, lo1);
+  const int ngrp = 2 * Lm / 8, kg = (cls * Lm + off) / 8 + l8;
+  unsigned short *base = mvq + (long long)n * 2 * ngrp * V * 8;
+  *reinterpret_cast<uint4 *>(base + ((long long)kg * V + v) * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  *reinterpret_cast<uint4 *>(base + ((long long)(ngrp + kg) * V + v) * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
 }
 
 // Wave-wide bitonic sorting of NON-NEGATIVE floats (the exp values of matching): on their bit patterns an unsigned integer
@@ -107,7 +129,8 @@ typedef unsigned u32x4m __attribute__((ext_vector_type(4)));
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 template <int TW, int CM>  // TW 16-base tiles per wave (Ltot = 128 * TW), C = 16 * CM
 __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__restrict__ qk, const float *__restrict__ mkn,
-                                                               float *__restrict__ pT, int P, int Pm, float tau) {
+                                                               float *__restrict__ pT, unsigned short *__restrict__ pq,
+                                                               int P, int Pm, float tau) {
   constexpr int C = 16 * CM, Ltot = 128 * TW, Lm = Ltot / 2;
   constexpr int TP = TW > 4 ? 4 : TW, NPASS = TW / TP;   // tiles per pass: at most 4 (32 x 16 bytes of base rows in flight)
   __shared__ float red[2][8][16];
@@ -213,8 +236,25 @@ __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__re
   const float inv = p < P ? 1.0f / esum : 0.f;   // rows of pad pixels are written as zeros
   float *dst = pT + ((long long)n * Pm + p) * Ltot + wave * 16 * TW + 4 * g;
 #pragma unroll
-  for (int t = 0; t < TW; ++t)
-    *reinterpret_cast<float4 *>(dst + 16 * t) = make_float4(acc[t][0] * inv, acc[t][1] * inv, acc[t][2] * inv, acc[t][3] * inv);
+  for (int t = 0; t < TW; ++t) {
+    acc[t][0] *= inv, acc[t][1] *= inv, acc[t][2] *= inv, acc[t][3] *= inv;
+    *reinterpret_cast<float4 *>(dst + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  }
+  if (pq) {
+    // the same probabilities as the readout GEMM's pre-split operand: bf16 planes hi / mid, [plane][Ltot/8][N*Pm][8]
+    // (conv.hip's activation layout).  The lane's four bases are half of an 8-channel group: 8 bytes per plane and tile,
+    // the 16 pixels x 2 halves of a group one contiguous 256-byte run.
+    const long long npix = (long long)gridDim.y * Pm, gp = (long long)n * Pm + p;
+    unsigned short *d0 = pq + (((long long)(wave * 2 * TW + (g >> 1)) * npix + gp) * 8 + 4 * (g & 1));
+    const long long plane = npix * Ltot;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      uint2 h, m, lo;
+      split3(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), h, m, lo);
+      *reinterpret_cast<uint2 *>(d0 + (long long)2 * t * npix * 8) = h;
+      *reinterpret_cast<uint2 *>(d0 + plane + (long long)2 * t * npix * 8) = m;
+    }
+  }
 }
 
 // K3: top-l prefix features (modules.py:198-208).  One wave per (object, pixel): the Lm probabilities of each class are
@@ -259,13 +299,13 @@ __global__ __launch_bounds__(256) void match_topl_kernel(const float *__restrict
 
 // Lm bases per class -> (tiles per wave J, waves NW) of the affinity kernel: blocks of 8 waves from 256 bases per class on
 // (there are only Pm/32 x N blocks, so a block's latency is the kernel's time)
-static int launch_affinity(hipStream_t st, const float *qk, const float *mkn, float *pT, int N, int C, int P, int Pm, int Lm,
-                           float tau) {
+static int launch_affinity(hipStream_t st, const float *qk, const float *mkn, float *pT, unsigned short *pq, int N, int C,
+                           int P, int Pm, int Lm, float tau) {
   if (C == 128 || C == 64) {
     // the grid covers all Pm rows of pT: the readout GEMM's last row tile reads rows [P, Pm), which pad tiles write as zeros
     dim3 grid16(Pm / 16, N);
 #define AFF16(TW_, CM_)                                                                                              \
-  hipLaunchKernelGGL((match_affinity16_kernel<TW_, CM_>), grid16, dim3(512), 0, st, qk, mkn, pT, P, Pm, tau)
+  hipLaunchKernelGGL((match_affinity16_kernel<TW_, CM_>), grid16, dim3(512), 0, st, qk, mkn, pT, pq, P, Pm, tau)
     if (C == 128) {
       if (Lm == 64) AFF16(1, 8);
       else if (Lm == 128) AFF16(2, 8);
@@ -293,7 +333,7 @@ static int launch_affinity(hipStream_t st, const float *qk, const float *mkn, fl
 }
 
 struct MatchWs {
-  size_t mkn, mvp, pT, conv, total;
+  size_t mkn, mvp, pT, pq, conv, total;
 };
 MatchWs match_ws(int N, int C, int V, int P, int L, int nbanks, int plan) {
   MatchWs w;
@@ -308,6 +348,7 @@ MatchWs match_ws(int N, int C, int V, int P, int L, int nbanks, int plan) {
   w.mkn = take((size_t)N * Ltot * (C + 4) * 4);   // packed keys: C/4 + 1 groups
   w.mvp = take((size_t)N * V * Ltot * 4);
   w.pT = take((size_t)N * Pm * Ltot * 4);
+  w.pq = take((size_t)N * Pm * Ltot * 4);   // the probabilities again as two bf16 planes (pre-split readout)
   w.conv = take(swem_conv2d_workspace(N, Pm, 1, (int)Ltot, V, 1, 1, 1, 0, 0, plan));
   w.total = o;
   return w;
@@ -481,12 +522,16 @@ extern "C" size_t swem_match_workspace(int N, int C, int V, int P, int L, int nb
 
 namespace {
 // affinity + top-l features + readout on PACKED banks: mkn [2N][C/4+1][Lm][4], mvp [N][V][2Lm]
-int match_core(void *stream, const float *qk, const float *mkn, const float *mvp, float *pT, float *mem_out, float *S, int N,
-               int C, int V, int P, int Lm, int topl, float tau, int readout_plan, void *conv_ws, size_t conv_bytes) {
+int match_core(void *stream, const float *qk, const float *mkn, const float *mvp, const unsigned short *mvq, float *pT,
+               unsigned short *pq, float *mem_out, float *S, int N, int C, int V, int P, int Lm, int topl, float tau,
+               int readout_plan, void *conv_ws, size_t conv_bytes) {
   const int Pm = swem_match_pad(P), Ltot = 2 * Lm;
   int rc;
   dim3 gridt(cdiv((long long)N * P, 4));
-  if ((rc = launch_affinity(ST, qk, mkn, pT, N, C, P, Pm, Lm, tau))) return rc;
+  // readout on pre-split planes ("bf16x3": hi + mid planes, three bf16 products -- the arithmetic of the convolutions that
+  // consume mem_out) when the plan asks for it and the caller keeps the value planes
+  const bool presplit = mvq && pq && ((readout_plan >> 16) & 3) == 3;
+  if ((rc = launch_affinity(ST, qk, mkn, pT, presplit ? pq : nullptr, N, C, P, Pm, Lm, tau))) return rc;
 #define TOPL(J_) hipLaunchKernelGGL((match_topl_kernel<J_>), gridt, dim3(256), 0, ST, pT, S, N, P, Pm, topl)
   if (Lm == 64) TOPL(1);
   else if (Lm == 128) TOPL(2);
@@ -496,6 +541,9 @@ int match_core(void *stream, const float *qk, const float *mkn, const float *mvp
   SWEM_CHECK_LAUNCH("match_affinity / match_topl");
   // value readout (modules.py:272-273) = batched GEMM  mem_out[n] = pT[n] . mvp[n]^T  on the conv kernel:
   // "image" of Pm x 1 pixels with Ltot channels, 1x1 filters = the V value rows of object n (w_bs = V*Ltot)
+  if (presplit)
+    return swem_gemm_bf16x3_batched(stream, pq, Ltot, (long long)Pm * Ltot, (long long)N * Pm * Ltot, N, Pm, mvq,
+                                    (long long)2 * V * Ltot, mem_out, V, readout_plan, conv_ws, conv_bytes);
   return swem_conv2d_nhwc_f32(stream, pT, Ltot, (long long)Pm * Ltot, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, mvp,
                               (long long)V * Ltot, nullptr, nullptr, nullptr, 0, mem_out, V, 1, 1, 1, 0, 0,
                               readout_plan, conv_ws, conv_bytes);
@@ -514,7 +562,7 @@ int match_check(int C, int V, int L, int Lm, int topl, float tau) {
 
 // one bank's bases into the packed form matching reads (modules.py:295-306 `get_mem` + the l2norm of :283)
 extern "C" int swem_match_pack_bank_f32(void *stream, const float *kappa, const float *nu, float *mkn, float *mvp,
-                                        int bank, int nbanks, int N, int C, int V, int L) {
+                                        void *mvq, int bank, int nbanks, int N, int C, int V, int L) {
   SWEM_REQUIRE(kappa && nu && mkn && mvp, SWEM_E_ARG, "match_pack_bank: null pointer");
   SWEM_REQUIRE(nbanks >= 1 && nbanks <= 2 && bank >= 0 && bank < nbanks, SWEM_E_ARG, "match_pack_bank: bad bank index");
   const int Lm = nbanks * L;
@@ -522,6 +570,11 @@ extern "C" int swem_match_pack_bank_f32(void *stream, const float *kappa, const 
   if ((rc = swem_norm_bases_into(stream, kappa, mkn, 2 * N, C, L, Lm, bank * L, 0))) return rc;
   const long long work = (long long)N * 2 * V * (L / 4);
   hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu, mvp, N, V, L, Lm, bank * L);
+  if (mvq) {
+    SWEM_REQUIRE(L % 8 == 0, SWEM_E_SHAPE, "match_pack_bank: value planes need L %% 8 == 0");
+    hipLaunchKernelGGL(pack_value_planes_kernel, dim3(cdiv(work / 2, 256)), dim3(256), 0, ST, nu,
+                       static_cast<unsigned short *>(mvq), N, V, L, Lm, bank * L);
+  }
   SWEM_CHECK_LAUNCH("pack_values");
   return SWEM_OK;
 }
@@ -540,11 +593,12 @@ extern "C" int swem_match_f32(void *stream, const float *qk, const float *kappa_
   SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "match: workspace %zu < %zu", ws_bytes, w.total);
   char *base = static_cast<char *>(ws);
   float *mkn = (float *)(base + w.mkn), *mvp = (float *)(base + w.mvp), *pT = (float *)(base + w.pT);
-  if ((rc = swem_match_pack_bank_f32(stream, kappa_first, nu_first, mkn, mvp, 0, nbanks, N, C, V, L))) return rc;
-  if (nbanks == 2 && (rc = swem_match_pack_bank_f32(stream, kappa_update, nu_update, mkn, mvp, 1, nbanks, N, C, V, L)))
+  if ((rc = swem_match_pack_bank_f32(stream, kappa_first, nu_first, mkn, mvp, nullptr, 0, nbanks, N, C, V, L))) return rc;
+  if (nbanks == 2 &&
+      (rc = swem_match_pack_bank_f32(stream, kappa_update, nu_update, mkn, mvp, nullptr, 1, nbanks, N, C, V, L)))
     return rc;
-  return match_core(stream, qk, mkn, mvp, pT, mem_out, S, N, C, V, P, Lm, topl, tau, readout_plan, base + w.conv,
-                    w.total - w.conv);
+  return match_core(stream, qk, mkn, mvp, nullptr, pT, nullptr, mem_out, S, N, C, V, P, Lm, topl, tau, readout_plan,
+                    base + w.conv, w.total - w.conv);
 }
 
 // The same on banks the caller keeps packed (swem_match_pack_bank_f32 / swem_memorize_packed_f32): no per-frame
@@ -554,9 +608,9 @@ extern "C" size_t swem_match_packed_workspace(int N, int C, int V, int P, int L,
   return w.total - w.pT;
 }
 
-extern "C" int swem_match_packed_f32(void *stream, const float *qk, const float *mkn, const float *mvp, float *mem_out,
-                                     float *S, int N, int C, int V, int P, int L, int topl, float tau, int readout_plan,
-                                     void *ws, size_t ws_bytes) {
+extern "C" int swem_match_packed_f32(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq,
+                                     float *mem_out, float *S, int N, int C, int V, int P, int L, int topl, float tau,
+                                     int readout_plan, void *ws, size_t ws_bytes) {
   SWEM_REQUIRE(qk && mkn && mvp && mem_out && S, SWEM_E_ARG, "match_packed: null pointer");
   int rc;
   if ((rc = match_check(C, V, L, 2 * L, topl, tau))) return rc;
@@ -564,8 +618,9 @@ extern "C" int swem_match_packed_f32(void *stream, const float *qk, const float 
   SWEM_REQUIRE(ws && ws_bytes >= w.total - w.pT, SWEM_E_WORKSPACE, "match_packed: workspace %zu < %zu", ws_bytes,
                w.total - w.pT);
   char *base = static_cast<char *>(ws) - w.pT;     // the workspace starts at the probability slot
-  return match_core(stream, qk, mkn, mvp, (float *)(base + w.pT), mem_out, S, N, C, V, P, 2 * L, topl, tau, readout_plan,
-                    base + w.conv, w.total - w.conv);
+  return match_core(stream, qk, mkn, mvp, static_cast<const unsigned short *>(mvq), (float *)(base + w.pT),
+                    (unsigned short *)(base + w.pq), mem_out, S, N, C, V, P, 2 * L, topl, tau, readout_plan, base + w.conv,
+                    w.total - w.conv);
 }
 
 // backward of swem_match_f32 for one clip: d mem_out [N][Pm][V] and dS [N][P][2*topl] (either may be NULL) ->
@@ -606,7 +661,7 @@ extern "C" int swem_match_bwd_f32(void *stream, const float *qk, const float *ka
   if (nbanks == 2)
     hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu_update, mvp, N, V, L, Lm, L);
   dim3 gridt(cdiv((long long)N * P, 4));
-  if ((rc = launch_affinity(ST, qk, mkn, pT, N, C, P, Pm, Lm, tau))) return rc;
+  if ((rc = launch_affinity(ST, qk, mkn, pT, nullptr, N, C, P, Pm, Lm, tau))) return rc;
   SWEM_CHECK_LAUNCH("match_bwd (forward recompute)");
   // (1) dP[n] = dmem[n] . mvp[n]   (batched GEMM on the conv kernel; filters = mvp[n]^T [Ltot][V])
   if ((rc = swem_transpose_f32(stream, mvp, mvpT, N, V, Ltot, V))) return rc;

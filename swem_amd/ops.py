@@ -681,8 +681,8 @@ def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau, pack=None, pri
     if pack is not None:
         _lib.call('swem_memorize_packed_f32', _stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(),
                   kappa_prev.data_ptr(), nu_prev.data_ptr(), zita_prev.data_ptr(), kappa.data_ptr(), nu.data_ptr(),
-                  zita.data_ptr(), _chk(pack[0]).data_ptr(), _chk(pack[1]).data_ptr(), int(prior_packed), int(bank), N, Cc,
-                  V, P, L, int(T), float(tau), ws.data_ptr(), wsb)
+                  zita.data_ptr(), _chk(pack[0]).data_ptr(), _chk(pack[1]).data_ptr(), _pack_planes(pack),
+                  int(prior_packed), int(bank), N, Cc, V, P, L, int(T), float(tau), ws.data_ptr(), wsb)
         return kappa, nu, zita
     _lib.call('swem_memorize_f32', _stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(), kappa_prev.data_ptr(),
               nu_prev.data_ptr(), zita_prev.data_ptr(), kappa.data_ptr(), nu.data_ptr(), zita.data_ptr(), N, Cc, V,
@@ -726,9 +726,20 @@ def match(qk, kappa_first, nu_first, kappa_update, nu_update, topl, tau):
 
 
 def new_pack(N, Cc, V, L, device):
-    """Matching's persistent packed banks for N objects (include/swem_hip.h, swem_memorize_packed_f32)."""
+    """Matching's persistent packed banks for N objects (include/swem_hip.h, swem_memorize_packed_f32): packed keys,
+    packed values, and the values again as bf16 planes (hi, mid) for the pre-split readout GEMM."""
     return (torch.zeros((2 * N, Cc // 4 + 1, 2 * L, 4), dtype=torch.float32, device=device),
-            torch.zeros((N, V, 4 * L), dtype=torch.float32, device=device))
+            torch.zeros((N, V, 4 * L), dtype=torch.float32, device=device),
+            torch.zeros((N, 2, 4 * L // 8, V, 8), dtype=torch.bfloat16, device=device))
+
+
+def _pack_planes(pack):
+    if len(pack) < 3 or pack[2] is None:
+        return None
+    q = pack[2]
+    if not (q.is_cuda and q.dtype == torch.bfloat16 and q.is_contiguous()):
+        raise _lib.SwemHipError('the value planes of a pack must be a contiguous bf16 device tensor')
+    return q.data_ptr()
 
 
 def pack_bank(kappa, nu, pack, bank):
@@ -737,11 +748,11 @@ def pack_bank(kappa, nu, pack, bank):
     _chk(nu)
     N, _, Cc, L = kappa.shape
     _lib.call('swem_match_pack_bank_f32', _stream(), kappa.data_ptr(), nu.data_ptr(), pack[0].data_ptr(),
-              pack[1].data_ptr(), int(bank), 2, N, Cc, nu.shape[2], L)
+              pack[1].data_ptr(), _pack_planes(pack), int(bank), 2, N, Cc, nu.shape[2], L)
 
 
 def match_packed(qk, pack, L, topl, tau):
-    """qk (P,C); pack = (mkn (2N,C/4,2L,4), mvp (N,V,4L)) -> mem_out (N,P,V) view, S (N,P,2*topl)."""
+    """qk (P,C); pack = (mkn (2N,C/4+1,2L,4), mvp (N,V,4L), mvq bf16 planes or None) -> mem_out (N,P,V) view, S (N,P,2*topl)."""
     _chk(qk)
     mkn, mvp = _chk(pack[0]), _chk(pack[1])
     P, Cc = qk.shape
@@ -753,8 +764,8 @@ def match_packed(qk, pack, L, topl, tau):
     def launch(plan):
         wsb = _lib.query('swem_match_packed_workspace', N, Cc, V, P, L, plan)
         ws = workspace(wsb, qk.device)
-        _lib.call('swem_match_packed_f32', _stream(), qk.data_ptr(), mkn.data_ptr(), mvp.data_ptr(), mem_out.data_ptr(),
-                  S.data_ptr(), N, Cc, V, P, L, int(topl), float(tau), plan, ws.data_ptr(), wsb)
+        _lib.call('swem_match_packed_f32', _stream(), qk.data_ptr(), mkn.data_ptr(), mvp.data_ptr(), _pack_planes(pack),
+                  mem_out.data_ptr(), S.data_ptr(), N, Cc, V, P, L, int(topl), float(tau), plan, ws.data_ptr(), wsb)
 
     key = (N, Cc, V, P, L, 2)
     plan = _MATCH_PLANS.get(key, 0)

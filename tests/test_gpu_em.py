@@ -224,3 +224,19 @@ def test_packed_banks_equal_the_per_frame_packing(lib, L):
     ops.pack_bank(ref0[0], ref0[1], pack2, 0)
     ops.pack_bank(ref2[0], ref2[1], pack2, 1)
     assert torch.equal(pack2[0], pack[0]) and torch.equal(pack2[1], pack[1])
+    # ... including the values' bf16 planes (hi, mid) the pre-split readout GEMM reads: hi + mid = nu to 16 significant bits
+    assert torch.equal(pack2[2].view(torch.int16), pack[2].view(torch.int16))
+    mvq = pack[2].float()                                                   # (N, 2, 4L/8, V, 8)
+    back = (mvq[:, 0] + mvq[:, 1]).permute(0, 2, 1, 3).reshape(N, V, 4 * L)     # [n][v][k]
+    assert float((back - pack[1]).abs().max()) <= 2.0 ** -16 * float(pack[1].abs().max())
+    # readout on the pre-split planes (plan math field 3: three bf16 products) against the fp32 readout
+    key = (N, C, V, P, L, 2)
+    try:
+        ops._MATCH_PLANS[key] = 2 | 2 << 4 | 1 << 8 | 3 << 16
+        mem_q, S_q = ops.match_packed(d(qx), pack, L, 64, 0.05)
+    finally:
+        ops._MATCH_PLANS.pop(key, None)
+    assert torch.equal(S_q, S_p)
+    err = float((mem_q - mem_p).abs().max()) / float(mem_p.abs().max())
+    print('bf16x3 readout vs fp32 readout: rel %.3g' % err)
+    assert 0 < err < 3e-5

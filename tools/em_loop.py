@@ -14,6 +14,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--objects', type=int, default=2)
     ap.add_argument('--reps', type=int, default=50)
+    ap.add_argument('--plan', type=lambda t: int(t, 0), default=0x130221,
+                    help='readout GEMM plan (include/swem_hip.h); default: what the tuner picks at config B, 0 = heuristic fp32')
     a = ap.parse_args()
     dev = 'cuda:0'
     N, P, C, V, L, T, tau, topl = a.objects, 1620, 128, 512, 256, 5, 0.05, 64
@@ -24,6 +26,8 @@ def main():
     kappa = torch.nn.functional.normalize(torch.randn(N, 2, C, L, generator=g), dim=2).to(dev)
     nu = torch.randn(N, 2, V, L, generator=g).to(dev)
     zita = (torch.rand(N, 2, L, generator=g) * 3 + 0.1).to(dev)
+    if a.plan:
+        ops._MATCH_PLANS[(N, C, V, P, L, 2)] = a.plan
     pack = ops.new_pack(N, C, V, L, dev)
     ops.pack_bank(kappa, nu, pack, 0)
     ops.pack_bank(kappa, nu, pack, 1)
