@@ -130,7 +130,7 @@ typedef float f32x4m __attribute__((ext_vector_type(4)));
 template <int TW, int CM>  // TW 16-base tiles per wave (Ltot = 128 * TW), C = 16 * CM
 __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__restrict__ qk, const float *__restrict__ mkn,
                                                                float *__restrict__ pT, unsigned short *__restrict__ pq,
-                                                               int P, int Pm, float tau) {
+                                                               float *__restrict__ S, int topl, int P, int Pm, float tau) {
   constexpr int C = 16 * CM, Ltot = 128 * TW, Lm = Ltot / 2;
   constexpr int TP = TW > 4 ? 4 : TW, NPASS = TW / TP;   // tiles per pass: at most 4 (32 x 16 bytes of base rows in flight)
   __shared__ float red[2][8][16];
@@ -234,11 +234,59 @@ __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__re
   const float esum = ((red[1][0][li] + red[1][1][li]) + (red[1][2][li] + red[1][3][li])) +
                      ((red[1][4][li] + red[1][5][li]) + (red[1][6][li] + red[1][7][li]));
   const float inv = p < P ? 1.0f / esum : 0.f;   // rows of pad pixels are written as zeros
-  float *dst = pT + ((long long)n * Pm + p) * Ltot + wave * 16 * TW + 4 * g;
 #pragma unroll
-  for (int t = 0; t < TW; ++t) {
-    acc[t][0] *= inv, acc[t][1] *= inv, acc[t][2] *= inv, acc[t][3] *= inv;
-    *reinterpret_cast<float4 *>(dst + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  for (int t = 0; t < TW; ++t) acc[t][0] *= inv, acc[t][1] *= inv, acc[t][2] *= inv, acc[t][3] *= inv;
+  if (pT) {
+    float *dst = pT + ((long long)n * Pm + p) * Ltot + wave * 16 * TW + 4 * g;
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+      *reinterpret_cast<float4 *>(dst + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  }
+  if (S) {
+    // Top-l prefix features (modules.py:198-208) of the tile's 16 pixels without the round trip of the probabilities
+    // through memory: class by class the tile turns through the LDS (pixel on the lane -> pixel per wave), wave w sorts
+    // pixels 2w and 2w+1 exactly as match_topl_kernel does (the same network on the same values: bit-identical features).
+    __shared__ __attribute__((aligned(16))) float pl[16][Lm + 4];
+    float cum[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      __syncthreads();   // the previous class has been read
+      if (cls == c) {
+        float *d = &pl[li][wq * 16 * TW + 4 * g];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) *reinterpret_cast<float4 *>(d + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        float v[TW];
+#pragma unroll
+        for (int j = 0; j < TW; ++j) v[j] = pl[2 * wave + sp][lane + 64 * j];
+#pragma unroll
+        for (int j = 0; j < TW; ++j) v[j] = sort64_desc(v[j], lane);
+#pragma unroll
+        for (int w = 1; w < TW; w <<= 1)
+#pragma unroll
+          for (int j = 0; j + w < TW; j += 2 * w) v[j] = merge_top64(v[j], v[j + w], lane);
+        float cs = v[0];
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+          const float tt = __shfl_up(cs, dd);
+          if (lane >= dd) cs += tt;
+        }
+        cum[sp][c] = cs;
+      }
+    }
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      const int pp = blockIdx.x * 16 + 2 * wave + sp;
+      if (pp < P && lane < topl) {
+        const float f = cum[sp][0] / (cum[sp][0] + cum[sp][1]);
+        float *dst = S + ((long long)n * P + pp) * (2 * topl);
+        dst[lane] = f;
+        dst[topl + lane] = 1.f - f;
+      }
+    }
   }
   if (pq) {
     // the same probabilities as the readout GEMM's pre-split operand: bf16 planes hi / mid, [plane][Ltot/8][N*Pm][8]
@@ -299,13 +347,14 @@ __global__ __launch_bounds__(256) void match_topl_kernel(const float *__restrict
 
 // Lm bases per class -> (tiles per wave J, waves NW) of the affinity kernel: blocks of 8 waves from 256 bases per class on
 // (there are only Pm/32 x N blocks, so a block's latency is the kernel's time)
-static int launch_affinity(hipStream_t st, const float *qk, const float *mkn, float *pT, unsigned short *pq, int N, int C,
-                           int P, int Pm, int Lm, float tau) {
+// S != NULL: the top-l features come out of the same launch (pT may then be NULL: nothing else reads the probabilities)
+static int launch_affinity(hipStream_t st, const float *qk, const float *mkn, float *pT, unsigned short *pq, float *S,
+                           int topl, int N, int C, int P, int Pm, int Lm, float tau) {
   if (C == 128 || C == 64) {
     // the grid covers all Pm rows of pT: the readout GEMM's last row tile reads rows [P, Pm), which pad tiles write as zeros
     dim3 grid16(Pm / 16, N);
 #define AFF16(TW_, CM_)                                                                                              \
-  hipLaunchKernelGGL((match_affinity16_kernel<TW_, CM_>), grid16, dim3(512), 0, st, qk, mkn, pT, pq, P, Pm, tau)
+  hipLaunchKernelGGL((match_affinity16_kernel<TW_, CM_>), grid16, dim3(512), 0, st, qk, mkn, pT, pq, S, topl, P, Pm, tau)
     if (C == 128) {
       if (Lm == 64) AFF16(1, 8);
       else if (Lm == 128) AFF16(2, 8);
@@ -531,14 +580,20 @@ int match_core(void *stream, const float *qk, const float *mkn, const float *mvp
   // readout on pre-split planes ("bf16x3": hi + mid planes, three bf16 products -- the arithmetic of the convolutions that
   // consume mem_out) when the plan asks for it and the caller keeps the value planes
   const bool presplit = mvq && pq && ((readout_plan >> 16) & 3) == 3;
-  if ((rc = launch_affinity(ST, qk, mkn, pT, presplit ? pq : nullptr, N, C, P, Pm, Lm, tau))) return rc;
+  if (presplit) {
+    // one launch: affinity + softmax, the probabilities as bf16 planes for the readout, and the top-l features
+    if ((rc = launch_affinity(ST, qk, mkn, nullptr, pq, S, topl, N, C, P, Pm, Lm, tau))) return rc;
+    SWEM_CHECK_LAUNCH("match_affinity (fused top-l)");
+  } else {
+    if ((rc = launch_affinity(ST, qk, mkn, pT, nullptr, nullptr, 0, N, C, P, Pm, Lm, tau))) return rc;
 #define TOPL(J_) hipLaunchKernelGGL((match_topl_kernel<J_>), gridt, dim3(256), 0, ST, pT, S, N, P, Pm, topl)
-  if (Lm == 64) TOPL(1);
-  else if (Lm == 128) TOPL(2);
-  else if (Lm == 256) TOPL(4);
-  else TOPL(8);
+    if (Lm == 64) TOPL(1);
+    else if (Lm == 128) TOPL(2);
+    else if (Lm == 256) TOPL(4);
+    else TOPL(8);
 #undef TOPL
-  SWEM_CHECK_LAUNCH("match_affinity / match_topl");
+    SWEM_CHECK_LAUNCH("match_affinity / match_topl");
+  }
   // value readout (modules.py:272-273) = batched GEMM  mem_out[n] = pT[n] . mvp[n]^T  on the conv kernel:
   // "image" of Pm x 1 pixels with Ltot channels, 1x1 filters = the V value rows of object n (w_bs = V*Ltot)
   if (presplit)
@@ -661,7 +716,7 @@ extern "C" int swem_match_bwd_f32(void *stream, const float *qk, const float *ka
   if (nbanks == 2)
     hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu_update, mvp, N, V, L, Lm, L);
   dim3 gridt(cdiv((long long)N * P, 4));
-  if ((rc = launch_affinity(ST, qk, mkn, pT, nullptr, N, C, P, Pm, Lm, tau))) return rc;
+  if ((rc = launch_affinity(ST, qk, mkn, pT, nullptr, nullptr, 0, N, C, P, Pm, Lm, tau))) return rc;
   SWEM_CHECK_LAUNCH("match_bwd (forward recompute)");
   // (1) dP[n] = dmem[n] . mvp[n]   (batched GEMM on the conv kernel; filters = mvp[n]^T [Ltot][V])
   if ((rc = swem_transpose_f32(stream, mvp, mvpT, N, V, Ltot, V))) return rc;
