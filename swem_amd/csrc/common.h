@@ -89,9 +89,12 @@ extern long long *g_swem_stamps;
 extern int g_swem_stamp_slot;
 #define STAMP_ARG , long long *stamps
 #define STAMP_PASS , (g_swem_stamps ? g_swem_stamps + 16 * (g_swem_stamp_slot++) : nullptr)
+#ifndef SWEM_STAMP_BLOCK
+#define SWEM_STAMP_BLOCK 0   /* which block of a launch writes the stamps (-DSWEM_STAMP_BLOCK=n) */
+#endif
 #define STAMP(i)                                                                                       \
   do {                                                                                                 \
-    if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {         \
+    if (stamps && blockIdx.x == SWEM_STAMP_BLOCK && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { \
       stamps[2 * (i)] = (long long)__builtin_amdgcn_s_memtime();                                       \
       stamps[2 * (i) + 1] = (long long)__builtin_amdgcn_s_memrealtime();                               \
     }                                                                                                  \

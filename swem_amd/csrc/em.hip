@@ -297,11 +297,12 @@ struct MStepP {
 // buffer loads (dwords: z is pixel-major, a lane needs ONE base of FOUR pixels per step; pixels >= P read as zeros by the
 // range check on the vector offset), three groups of MG steps in flight ahead of the MFMA chain.
 // Blocks that share z columns sit on one XCD (blockIdx -> tile order below): an XCD's L2 holds its 1/8 of z plus x.
-constexpr int MG = 17;  // k-steps per load group (3 dwords each)
+template <int MG>  // k-steps per load group (3 dwords each)
 struct MGroup {
   float za[MG], xa[MG], xb[MG];
 };
-__device__ __forceinline__ void mgroup_load(MGroup &q, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, unsigned &oa,
+template <int MG>
+__device__ __forceinline__ void mgroup_load(MGroup<MG> &q, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, unsigned &oa,
                                             unsigned &ob, unsigned sa, unsigned sb) {
 #pragma unroll
   for (int s = 0; s < MG; ++s) {   // running offsets: one address register per operand, not one per load in flight
@@ -313,7 +314,8 @@ __device__ __forceinline__ void mgroup_load(MGroup &q, __amdgpu_buffer_rsrc_t ra
   }
 }
 // two accumulators per tile (even / odd steps of the group): independent MFMA chains back to back
-__device__ __forceinline__ void mgroup_mfma(const MGroup &q, f32x4 (&acc)[4], float &zs) {
+template <int MG>
+__device__ __forceinline__ void mgroup_mfma(const MGroup<MG> &q, f32x4 (&acc)[4], float &zs) {
 #pragma unroll
   for (int s = 0; s < MG; ++s) {
     acc[2 * (s & 1)] = mfma16(q.za[s], q.xa[s], acc[2 * (s & 1)]);
@@ -325,8 +327,10 @@ __device__ __forceinline__ void mgroup_mfma(const MGroup &q, f32x4 (&acc)[4], fl
   for (int s = 0; s < MG; ++s) zs += q.za[s];
 }
 
-template <bool LOOP>   // LOOP: more than three load groups per wave (P > 1632)
-__global__ __launch_bounds__(512, LOOP ? 2 : 4) void em_mstep_kernel(MStepP p STAMP_ARG) {   // (512, waves per SIMD): two blocks per CU
+// LOOP = false: at most three load groups per wave (P <= 96 MG pixels), straight-line code; WPE = waves per SIMD the
+// register budget is cut for (blocks per CU = WPE / 2)
+template <bool LOOP, int MG, int WPE>
+__global__ __launch_bounds__(512, WPE) void em_mstep_kernel(MStepP p STAMP_ARG) {
   STAMP(0);
   __shared__ float red[8][2][4][64];
   __shared__ float zred[8][16];
@@ -353,8 +357,11 @@ __global__ __launch_bounds__(512, LOOP ? 2 : 4) void em_mstep_kernel(MStepP p ST
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, (int)((long long)p.P * stride * 4), 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(p.z + (long long)n * p.Pz * 2 * p.L), 0, (int)((long long)p.P * 2 * p.L * 4), 0x00020000);
-  // the epilogue's operands first: output element (base l0 + oi, row col + oj) of this thread; a wave = 2 bases x 32 rows
-  const int oj = tid & 31, oi = tid >> 5;
+  // the epilogue's operands first: output element (base l0 + oi, row col + oj) of this thread.  Key rows: a wave = 2 bases x
+  // 32 rows (the squared-norm partials are a reduction over the rows: five shuffles).  Value rows: a wave = 16 bases x 4
+  // rows -- the 16 bases of a row are 64 contiguous bytes of nu / mvp, one cache line segment per four lanes' worth (with
+  // the key mapping every lane of a store would touch its own line: 1.7 us of a value block's 2.7 us epilogue)
+  const int oj = key ? (tid & 31) : (tid >> 4), oi = key ? (tid >> 5) : (tid & 15);
   const int R = key ? p.C : p.V;
   const float zp = p.zita_prev[(long long)nk * p.L + l0 + oi];
   const float pv = (key ? p.kappa_prev : p.nu_prev)[((long long)nk * R + col + oj) * p.L + l0 + oi];
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(512, LOOP ? 2 : 4) void em_mstep_kernel(MStepP p ST
   const unsigned vb = (unsigned)(((4 * wave + g) * 2 * p.L + cls * p.L + l0 + li) * 4);
   const unsigned sa = (unsigned)stride * 128u, sb = (unsigned)p.L * 256u;  // bytes per step of one wave (32 pixels)
   const int T = ((p.P + 3) / 4 + 7) / 8, ng = (T + MG - 1) / MG;
-  MGroup qa, qb, qc;
+  MGroup<MG> qa, qb, qc;
   unsigned oa = va, ob = vb;   // groups are loaded in step order, whichever registers they land in
   mgroup_load(qa, ra, rb, oa, ob, sa, sb);
   mgroup_load(qb, ra, rb, oa, ob, sa, sb);   // (a group past the last pixel reads zeros without touching memory)
@@ -552,8 +559,10 @@ int mstep_impl(void *stream, const float *x, const float *v, const float *z, con
       if (mp.nrt % d == 0 && fabsf((float)d - want) < best) best = fabsf((float)d - want), mp.rpg = d;
   }
   const dim3 grid((mp.total + 7) / 8 * 8);
-  if (P <= 4 * 8 * 3 * MG) hipLaunchKernelGGL(em_mstep_kernel<false>, grid, dim3(512), 0, ST, mp STAMP_PASS);
-  else hipLaunchKernelGGL(em_mstep_kernel<true>, grid, dim3(512), 0, ST, mp STAMP_PASS);
+  // (measured alternatives: smaller load groups cut for three or four resident blocks per CU -- <true, 6, 6>, <true, 4, 8> --
+  // spill; the two-block form below is what the register file allows with the operands prefetched into registers)
+  if (P <= 4 * 8 * 3 * 17) hipLaunchKernelGGL((em_mstep_kernel<false, 17, 4>), grid, dim3(512), 0, ST, mp STAMP_PASS);
+  else hipLaunchKernelGGL((em_mstep_kernel<true, 17, 2>), grid, dim3(512), 0, ST, mp STAMP_PASS);
   SWEM_CHECK_LAUNCH("em_mstep");
   return SWEM_OK;
 }

@@ -23,7 +23,8 @@ def build():
     for name in ('em', 'conv'):
         o = '/tmp/%s_stamps.o' % name
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
-                               '-DSWEM_EM_STAMPS', '-c', os.path.join(csrc, name + '.hip'), '-o', o])
+                               '-DSWEM_EM_STAMPS', '-DSWEM_STAMP_BLOCK=%d' % int(os.environ.get('SWEM_STAMP_BLOCK', '0')),
+                               '-c', os.path.join(csrc, name + '.hip'), '-o', o])
         objs.append(o)
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
     return out
