@@ -156,6 +156,12 @@ int swem_maxpool3x3s2_nhwc_f32(void *stream, const float *x, float *y, int B, in
 /* y = skip + bilinear(low -> Ho x Wo, align_corners=False): networks.py:193-194.  skip_bs 0 = shared skip */
 int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long long skip_bs, const float *low, float *y,
                                int B, int Hl, int Wl, int Ho, int Wo, int C);
+/* The same, and the result's bf16 planes for the pre-split convolutions that consume it (layout of swem_split_bf16x3_f32):
+ * planes = of y, planes_relu = of relu(y) (either may be NULL), nplanes* = 2 (hi, mid) or 3 planes written, each
+ * B*Ho*Wo*C elements; C % 8 == 0.  Replaces a split launch (and its re-read of y) per consumer variant. */
+int swem_upsample_add_nhwc_f32_planes(void *stream, const float *skip, long long skip_bs, const float *low, float *y,
+                                      int B, int Hl, int Wl, int Ho, int Wo, int C, void *planes, int nplanes,
+                                      void *planes_relu, int nplanes_relu);
 /* F.interpolate / flip on NCHW planes; mode 0 = nearest (legacy), 1 = bilinear align_corners=False
  * (swem_evaluator.py:67,91), 2 = bicubic align_corners=False (swem_evaluator.py:43, basic_evaluator.py:160),
  * 3 = horizontal flip, same size (torch.flip(dims=[-1]), swem_evaluator.py:46-49) */

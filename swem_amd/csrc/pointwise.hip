@@ -3,6 +3,7 @@
 // with C % 4 == 0 so every lane moves 16 bytes; index arithmetic mirrors ATen's so index maps match.
 #include "../../include/swem_hip_train.h"
 #include "common.h"
+#include "bf16_split.h"
 
 namespace {
 
@@ -39,7 +40,10 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 __device__ __forceinline__ float4 f4lerp2(float l0, float4 a, float l1, float4 b) {
-  return make_float4(l0 * a.x + l1 * b.x, l0 * a.y + l1 * b.y, l0 * a.z + l1 * b.z, l0 * a.w + l1 * b.w);
+  // (the contraction spelled out: left to the compiler, two kernels may fuse different halves of l0 a + l1 b and differ in
+  // the last bit -- the planes-writing variants must reproduce the plain kernels exactly)
+  return make_float4(fmaf(l1, b.x, __fmul_rn(l0, a.x)), fmaf(l1, b.y, __fmul_rn(l0, a.y)), fmaf(l1, b.z, __fmul_rn(l0, a.z)),
+                     fmaf(l1, b.w, __fmul_rn(l0, a.w)));
 }
 
 __global__ void prep_key_input_kernel(const float *__restrict__ f, float3 mean, float3 stdv, float *__restrict__ out,
@@ -115,6 +119,50 @@ __global__ void upsample_add_kernel(const float *__restrict__ skip, long long sk
   float4 up = f4lerp2(ly.l0, r0, ly.l1, r1);
   float4 s = ld4(skip + (long long)b * skip_bs + ((long long)oy * Wo + ox) * C + c4 * 4);
   st4(y + i * 4, f4add(s, up));
+}
+
+// The same, and the result's bf16 planes (hi, mid[, lo]) for the convolutions that consume it pre-split -- with and / or
+// without their input ReLU (networks.py:26-27: ResBlock.conv1 sees relu(x), the downsample conv x).  Block = 32 pixels x 8
+// channel groups, thread = (pixel, 8 channels): the 8 threads of a pixel read / write 256 contiguous bytes of its row, and
+// per channel group 8 consecutive pixels store one 128-byte run of every plane (split_bf16x3_kernel's mapping, conv.hip).
+__global__ __launch_bounds__(256) void upsample_add_planes_kernel(const float *__restrict__ skip, long long skip_bs,
+                                                                  const float *__restrict__ low, float *__restrict__ y,
+                                                                  unsigned short *__restrict__ pl0, int npl0,
+                                                                  unsigned short *__restrict__ pl1, int npl1, int B, int Hl,
+                                                                  int Wl, int Ho, int Wo, int C) {
+  const long long npix = (long long)B * Ho * Wo;
+  const long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int cg = blockIdx.y * 8 + (threadIdx.x & 7);
+  if (pix >= npix || cg >= C / 8) return;
+  const int ox = (int)(pix % Wo);
+  long long t = pix / Wo;
+  const int oy = (int)(t % Ho), b = (int)(t / Ho);
+  Lerp ly = lerp_coord(oy, (float)Hl / (float)Ho, Hl), lx = lerp_coord(ox, (float)Wl / (float)Wo, Wl);
+  const float *base = low + (long long)b * Hl * Wl * C + cg * 8;
+  const float *sk = skip + (long long)b * skip_bs + ((long long)oy * Wo + ox) * C + cg * 8;
+  float4 v[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float4 r0 = f4lerp2(lx.l0, ld4(base + ((long long)ly.i0 * Wl + lx.i0) * C + 4 * h), lx.l1,
+                        ld4(base + ((long long)ly.i0 * Wl + lx.i1) * C + 4 * h));
+    float4 r1 = f4lerp2(lx.l0, ld4(base + ((long long)ly.i1 * Wl + lx.i0) * C + 4 * h), lx.l1,
+                        ld4(base + ((long long)ly.i1 * Wl + lx.i1) * C + 4 * h));
+    v[h] = f4add(ld4(sk + 4 * h), f4lerp2(ly.l0, r0, ly.l1, r1));
+    st4(y + pix * C + cg * 8 + 4 * h, v[h]);
+  }
+  const long long plane = npix * C, i = (long long)cg * npix + pix;
+#pragma unroll
+  for (int var = 0; var < 2; ++var) {
+    unsigned short *out = var ? pl1 : pl0;
+    const int npl = var ? npl1 : npl0;
+    if (!out) continue;
+    uint2 h0, m0, l0, h1, m1, l1;
+    split3(var ? make_float4(fmaxf(v[0].x, 0.f), fmaxf(v[0].y, 0.f), fmaxf(v[0].z, 0.f), fmaxf(v[0].w, 0.f)) : v[0], h0, m0, l0);
+    split3(var ? make_float4(fmaxf(v[1].x, 0.f), fmaxf(v[1].y, 0.f), fmaxf(v[1].z, 0.f), fmaxf(v[1].w, 0.f)) : v[1], h1, m1, l1);
+    *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+    if (npl > 2) *reinterpret_cast<uint4 *>(out + 2 * plane + i * 8) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+  }
 }
 
 __global__ void resize_planes_kernel(const float *__restrict__ x, float *__restrict__ y, int planes, int Hi, int Wi,
@@ -754,6 +802,20 @@ extern "C" int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long 
   hipLaunchKernelGGL(upsample_add_kernel, grid1((long long)B * Ho * Wo * (C / 4)), dim3(256), 0, ST, skip, skip_bs,
                      low, y, B, Hl, Wl, Ho, Wo, C);
   SWEM_CHECK_LAUNCH("upsample_add");
+  return SWEM_OK;
+}
+
+extern "C" int swem_upsample_add_nhwc_f32_planes(void *stream, const float *skip, long long skip_bs, const float *low,
+                                                 float *y, int B, int Hl, int Wl, int Ho, int Wo, int C, void *planes,
+                                                 int nplanes, void *planes_relu, int nplanes_relu) {
+  SWEM_REQUIRE(skip && low && y && C % 8 == 0, SWEM_E_SHAPE, "upsample_add_planes: need C %% 8 == 0");
+  SWEM_REQUIRE((!planes || (nplanes >= 2 && nplanes <= 3)) && (!planes_relu || (nplanes_relu >= 2 && nplanes_relu <= 3)),
+               SWEM_E_ARG, "upsample_add_planes: 2 or 3 planes per variant");
+  const long long npix = (long long)B * Ho * Wo;
+  hipLaunchKernelGGL(upsample_add_planes_kernel, dim3((unsigned)cdiv(npix, 32), (unsigned)cdiv(C / 8, 8)), dim3(256), 0, ST,
+                     skip, skip_bs, low, y, static_cast<unsigned short *>(planes), nplanes,
+                     static_cast<unsigned short *>(planes_relu), nplanes_relu, B, Hl, Wl, Ho, Wo, C);
+  SWEM_CHECK_LAUNCH("upsample_add_planes");
   return SWEM_OK;
 }
 

@@ -26,8 +26,20 @@ def l2norm(inp, dim):
     return inp / norm
 
 
+def as_nchw(t):
+    """NHWC tensor -> the NCHW-shaped view the reference's callers index.  The view remembers the tensor it came from: when it
+    comes back through `to_pixel_major` the ORIGINAL object is used again, with whatever a producing kernel cached on it
+    (the bf16 planes of a conv output, the site its next consumers report to: ops.presplit)."""
+    v = t.permute(0, 3, 1, 2)
+    v.__dict__['_swem_nhwc'] = t
+    return v
+
+
 def to_pixel_major(t):
     """(B,C,h,w) -> contiguous (B,h,w,C) memory; free for channels-last input."""
+    o = t.__dict__.get('_swem_nhwc')
+    if o is not None and o.data_ptr() == t.data_ptr() and o._version == t._version and o.shape[0] == t.shape[0]:
+        return o
     v = t.permute(0, 2, 3, 1)
     if v.is_contiguous():
         return v
@@ -286,7 +298,7 @@ class SWEMCore(nn.Module):
         if self._engine is None:
             raise RuntimeError('SWEMCore.matching needs the owning SWEM model (packed fusion weights)')
         ctx = self._engine().fuse_context(mem_out, qvp, S)           # (B*N,h,w,V) NHWC
-        return ctx.permute(0, 3, 1, 2), first['kappa'].shape[1]
+        return as_nchw(ctx), first['kappa'].shape[1]
 
     def get_mem(self):
         """modules.py:295-306 (inspection only: matching reads the banks directly)."""

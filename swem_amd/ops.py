@@ -297,7 +297,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
             for i, s_ in enumerate(srcs):
                 # (tuning charges a candidate the split of its inputs -- except inputs a conv epilogue produces: those arrive
                 # with their planes from the second frame on, FUSE_SPLIT)
-                if fresh and not (FUSE_SPLIT and s_.__dict__.get('_swem_site', (None,))[0] == 'conv'):
+                if fresh and not (FUSE_SPLIT and s_.__dict__.get('_swem_site', (None,))[0] in ('conv', 'upsample_add')):
                     s_.__dict__.pop('_swem_split', None)
                 sp = presplit(s_, relu_in, need)
                 sargs += [sp.data_ptr(), s_.shape[3], args[3 * i + 2], sp.stride(0)]
@@ -471,6 +471,19 @@ def maxpool(x):
     return y
 
 
+def _fused_planes(site, numel, device):
+    """(planes dict {relu: (tensor, nplanes)}, C-ABI argument list) for a producer at `site` whose consumers split its output
+    on an earlier frame (SPLIT_HINTS): the producer writes the planes itself."""
+    want = SPLIT_HINTS.get(site) if FUSE_SPLIT else None
+    planes, pargs = {}, [0, 3, 0, 3]
+    if want:
+        for relu_v, npl in want.items():
+            sp = torch.empty((3, numel), dtype=torch.bfloat16, device=device)
+            planes[relu_v] = (sp, npl)
+            pargs[2 * int(relu_v)], pargs[2 * int(relu_v) + 1] = sp.data_ptr(), npl
+    return planes, pargs
+
+
 def upsample_add(skip, low, batch=None):
     """skip (B or 1, Ho, Wo, C) + bilinear(low (B, Hl, Wl, C))."""
     _chk(skip)
@@ -479,8 +492,16 @@ def upsample_add(skip, low, batch=None):
     _, Ho, Wo, Cc = skip.shape
     y = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=low.device)
     sbs = 0 if (skip.shape[0] == 1 and B > 1) else Ho * Wo * Cc
-    _lib.call('swem_upsample_add_nhwc_f32', _stream(), skip.data_ptr(), sbs, low.data_ptr(), y.data_ptr(), B,
-              low.shape[1], low.shape[2], Ho, Wo, Cc)
+    site = ('upsample_add', B, Ho, Wo, Cc)
+    planes, pargs = _fused_planes(site, y.numel(), y.device) if Cc % 8 == 0 else ({}, None)
+    if planes:
+        _lib.call('swem_upsample_add_nhwc_f32_planes', _stream(), skip.data_ptr(), sbs, low.data_ptr(), y.data_ptr(), B,
+                  low.shape[1], low.shape[2], Ho, Wo, Cc, *pargs)
+        y.__dict__['_swem_split'] = planes
+    else:
+        _lib.call('swem_upsample_add_nhwc_f32', _stream(), skip.data_ptr(), sbs, low.data_ptr(), y.data_ptr(), B,
+                  low.shape[1], low.shape[2], Ho, Wo, Cc)
+    y.__dict__['_swem_site'] = site
     return y
 
 

@@ -13,12 +13,11 @@ from torch import nn
 
 from . import ops
 from .engine import Engine
-from .modules import SWEMCore, to_pixel_major
+from .modules import SWEMCore, as_nchw, to_pixel_major
 from .networks import Decoder, KeyEncoder, KeyProjection, ValueEncoder, ValueEncoderSO
 
 
-def _nchw(t):
-    return t.permute(0, 3, 1, 2)
+_nchw = as_nchw
 
 
 class SWEM(nn.Module):

@@ -310,6 +310,34 @@ def test_conv2d_fused_output_planes(lib, plan):
         ops.SPLIT_HINTS.clear()
 
 
+def test_upsample_add_fused_output_planes(lib):
+    """networks.py:193-194 with the result's bf16 planes written by the same launch (the decoder's ResBlocks consume it
+    pre-split, with and without their input ReLU): y bit-identical to the plain kernel, planes bit-identical to
+    swem_split_bf16x3_f32 on y."""
+    g = torch.Generator().manual_seed(5)
+    B, C, Hl, Wl, Ho, Wo = 2, 72, 15, 27, 30, 54
+    low = nhwc(torch.randn(B, C, Hl, Wl, generator=g))
+    skip = nhwc(torch.randn(1, C, Ho, Wo, generator=g))
+    ops.SPLIT_HINTS.clear()
+    y0 = ops.upsample_add(skip, low)
+    assert '_swem_split' not in y0.__dict__
+    M = B * Ho * Wo
+    try:
+        ops.SPLIT_HINTS[y0._swem_site] = {False: 2, True: 3}
+        y1 = ops.upsample_add(skip, low)
+        assert torch.equal(y1, y0)
+        got = y1.__dict__['_swem_split']
+        for relu in (False, True):
+            sp = torch.empty((3, M * C), dtype=torch.bfloat16, device=DEV)
+            __import__('swem_amd')._lib.call('swem_split_bf16x3_f32', ops._stream(), y0.data_ptr(), sp.data_ptr(), M, C, int(relu))
+            n = got[relu][1]
+            assert n == (3 if relu else 2)
+            assert torch.equal(got[relu][0][:n].view(torch.int16), sp[:n].view(torch.int16))
+        assert ops.presplit(y1, True, 3) is got[True][0]
+    finally:
+        ops.SPLIT_HINTS.clear()
+
+
 @pytest.mark.parametrize('plan', [0x30011, 0x30021, 0x30022, 0x130021, 0x230022, 0x430011, 0x430021, 0x630022, 0x30221, 0x830022,
                                   0x930022, 0x4030021, 0xa30011, 0xb30021, 0xa30022, 0xc30022, 0xd30022, 0xe30022, 0xa30211], ids=lambda p: '%#x' % p)
 def test_conv2d_bf16x3_mode(lib, plan):
