@@ -330,25 +330,76 @@ def main():
                            'ms_per_frame': round(d['ms'] / nprof, 3), 'gflop_per_launch': round(d['flops'] / d['n'] / 1e9, 3),
                            'algorithmic_bytes_per_launch': int(d['bytes'] / d['n'])}
         dom = max(pipes, key=lambda k: pipes[k]['ms'])
+        # the dominant KERNEL: launches grouped by the template instantiation their plan selects (math mode, block tile,
+        # variant = plan bits 20-23: conv.hip); `roofline` prices the one that holds most of the conv time against its pipe
+        def kernel_of(t_):
+            plan_, pipe_ = t_[5], t_[6]
+            if pipe_ == 'fp32':
+                return ('fp32', plan_ & 15, (plan_ >> 4) & 15, 0)
+            return (pipe_, plan_ & 15, (plan_ >> 4) & 15, (plan_ >> 20) & 15)
+        kern = {}
+        for t_ in tr:
+            d = kern.setdefault(kernel_of(t_), {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'n': 0})
+            d['ms'] += t_[0].elapsed_time(t_[1])
+            d['flops'] += t_[2]
+            d['bytes'] += t_[4]
+            d['n'] += 1
+        dk = max(kern, key=lambda k: kern[k]['ms'])
+        dkd = kern[dk]
+        dk_ach = dkd['flops'] / (dkd['ms'] * 1e-3) / 1e12
+        # rocprofv3's name of that instantiation (conv.hip: variant -> stages / waves / MFMA shape), for the committed stats
+        def bf3s_name(pipe_, wm_, wn_, var_):
+            one = (wm_, wn_) == (1, 1)
+            big = (wm_, wn_) == (2, 2)
+            nst, nw, m16, kg = (3 if one != (var_ == 1) else 2), 4, False, 4          # launch_bf3s (conv.hip), default / 1
+            if var_ in (12, 13) and big:
+                nst, nw, m16 = 4, 8, var_ == 13
+            elif var_ in (10, 11):
+                nst, m16 = 4, var_ == 11
+            elif big and var_ in (14, 2, 3, 6, 8, 9):
+                nst, nw, m16, kg = {14: (3, 8, True, 4), 2: (2, 8, False, 4), 3: (3, 8, False, 4), 6: (2, 8, True, 4),
+                                    8: (2, 4, False, 2), 9: (3, 4, False, 2)}[var_]
+            elif var_ == 4:
+                nst, m16 = (3 if one else 2), True
+            return 'conv_igemm_bf3s_kernel<%d, %d, %d, %d, %s, %d, %d>' % (wm_, wn_, nst, nw, 'true' if m16 else 'false',
+                                                                          2 if pipe_ == 'bf16x3' else 3, kg)
+        dk_name = bf3s_name(*dk) if dk[0] != 'fp32' else 'conv_igemm_pipe_kernel<%d, %d>' % (dk[1], dk[2])
         traffic, tsrc = None, None
-        for name in ('r02_conv_traffic.json', 'r01_conv_traffic.json'):
+        for name in ('r02_conv_traffic_by_kernel.json',):
             try:
                 with open(os.path.join(ROOT, 'profiles', name)) as f:
-                    traffic, tsrc = json.load(f)['hbm_bytes_per_launch'], 'profiles/' + name
-                break
+                    byk = json.load(f)
+                hit = [v for k, v in byk.items() if k.replace('void ', '').replace(' ', '') == dk_name.replace(' ', '')]
+                if hit:
+                    traffic, tsrc = hit[0]['bytes_per_launch'], 'profiles/' + name
             except (OSError, KeyError, ValueError):
                 pass
+        if traffic is None:
+            for name in ('r02_conv_traffic.json', 'r01_conv_traffic.json'):
+                try:
+                    with open(os.path.join(ROOT, 'profiles', name)) as f:
+                        traffic, tsrc = json.load(f)['hbm_bytes_per_launch'], 'profiles/' + name + ' (average over ALL conv launches)'
+                    break
+                except (OSError, KeyError, ValueError):
+                    pass
         out['roofline'] = {
             'bound': 'mfma',
-            'kernel': ('conv_igemm_bf3s_kernel: implicit-GEMM conv on pre-split bf16 planes moved by LDS-DMA, %s, fp32 accumulate; '
+            'kernel': (dk_name + ' -- implicit-GEMM conv on pre-split bf16 planes moved by LDS-DMA, %s, fp32 accumulate; '
                        'its operand-split and split-K reduce launches are inside the timed intervals'
                        % ('bf16x6 arithmetic (three planes per operand, six v_mfma_f32_32x32x16_bf16 products)' if dom == 'bf16'
                           else 'bf16x3 arithmetic (hi + mid planes, three bf16 MFMA products)')) if dom != 'fp32' else
                       'conv_igemm_pipe_kernel: implicit-GEMM conv on v_mfma_f32_32x32x2_f32',
-            'achieved': per_pipe[dom]['achieved'], 'peak': per_pipe[dom]['peak'], 'unit': 'TFLOP/s',
-            'frac': per_pipe[dom]['frac'], 'traffic': traffic, 'traffic_source': tsrc,
-            'traffic_note': 'fabric-side bytes per conv launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches, from separate rocprofv3 '
-                            '--pmc passes (tools/pmc_bench_traffic.sh); NOT re-measured by this run',
+            'achieved': round(dk_ach, 2), 'peak': peaks[dk[0]], 'unit': 'TFLOP/s',
+            'frac': round(dk_ach / peaks[dk[0]], 4), 'traffic': traffic, 'traffic_source': tsrc,
+            'dominant_kernel': {'rocprof_name': dk_name, 'plan_tile_variant': list(dk[1:]), 'launches_per_frame': dkd['n'] / nprof,
+                                'avg_launch_us': round(1e3 * dkd['ms'] / dkd['n'], 2),
+                                'share_of_conv_time': round(dkd['ms'] / sum(d_['ms'] for d_ in kern.values()), 3),
+                                'gflop_per_launch': round(dkd['flops'] / dkd['n'] / 1e9, 3),
+                                'algorithmic_bytes_per_launch': int(dkd['bytes'] / dkd['n']),
+                                'whole_pipe': {'achieved': per_pipe[dom]['achieved'], 'frac': per_pipe[dom]['frac']}},
+            'traffic_note': 'fabric-side bytes per launch of the dominant kernel, (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches, from '
+                            'separate rocprofv3 --pmc passes (tools/pmc_bench_traffic.sh, tools/pmc_by_kernel.py); NOT re-measured by '
+                            'this run',
             'peak_note': 'bf16 pipes: 2500 TFLOP/s dense bf16 MFMA / products per fp32 product: bf16x6 %.1f, bf16x3 %.1f useful '
                          'TFLOP/s; fp32 pipe: %.1f (MI355X_MICROARCH.md)' % (BF16X6_PEAK_TFLOPS, BF16X3_PEAK_TFLOPS,
                                                                              FP32_MATRIX_PEAK_TFLOPS),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-kernel HBM-side traffic from the two --pmc passes of tools/pmc_bench_traffic.sh:
-   python tools/pmc_by_kernel.py [gpurun_out/pmc_traffic]  ->  (2*FETCH_SIZE + WRITE_SIZE) KB per launch, by kernel."""
+   python tools/pmc_by_kernel.py [gpurun_out/pmc_traffic [out.json]]  ->  (2*FETCH_SIZE + WRITE_SIZE) KB per launch, by kernel."""
 import collections
 import csv
 import glob
@@ -18,6 +18,11 @@ for f in glob.glob(root + '/*/*/*counter_collection.csv'):
         if r['Counter_Name'] == 'FETCH_SIZE':
             cnt[k] += 1
 rows = sorted(agg.items(), key=lambda kv: -(2 * kv[1]['FETCH_SIZE'] + kv[1]['WRITE_SIZE']))
+if len(sys.argv) > 2:      # machine-readable copy: bench.py reads the dominant kernel's figure from it
+    import json
+    with open(sys.argv[2], 'w') as f:
+        json.dump({k: {'launches': cnt[k], 'bytes_per_launch': int((2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024 / max(cnt[k], 1))}
+                   for k, v in rows}, f, indent=1)
 tot = sum(2 * v['FETCH_SIZE'] + v['WRITE_SIZE'] for _, v in rows)
 for k, v in rows[:25]:
     t = 2 * v['FETCH_SIZE'] + v['WRITE_SIZE']
