@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libswem_hip.so')
+# (SWEM_HIP_LIB: another build of the same library -- the debug / tuning builds the tools make, e.g. tools/conv_stamps.py)
+LIB_PATH = os.environ.get('SWEM_HIP_LIB') or os.path.join(_HERE, 'libswem_hip.so')
 
 _p, _i, _ll, _f, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 

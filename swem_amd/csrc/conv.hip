@@ -1168,6 +1168,27 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
       advance(q);
       issue(st == 0 ? NST - 1 : st - 1);  // stage (kb+NST-1) % NST
     }
+    // Where the stage hand-over (counted wait for block kb+1 + s_barrier) sits inside the MFMA sequence: the MFMAs only
+    // touch registers once the fragments are read, so any of them may run before or after it.  In front of it they would
+    // hide the transfer this wave has just issued; behind it the waves of the block are decoupled while they compute (the
+    // barrier does not wait for the slowest wave's MFMAs) and the next transfer starts earlier.  Measured on the config-B
+    // layers (tools/conv_bench.py, tuned plans; SWEM_MFMA_FRONT = 0 / 1 / 2 = none / half / all of the MFMAs in front):
+    // 330 / 334 / 310 TFLOP/s on 2x120x216 256->256, 338 / 317 / 302 on 2x30x54 1280->512, 329 / 314 / 296 on 2x60x108
+    // 512->256 -- everything BEHIND the hand-over wins: the other resident block's MFMAs hide the transfer, not this one's.
+    // (The compiler's own scheduling had arrived at nearly this order by sinking the MFMAs below the asm waits; it is now
+    // pinned by scheduling barriers.)
+#ifndef SWEM_MFMA_FRONT
+#define SWEM_MFMA_FRONT 0
+#endif
+    auto hand_over = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      // block kb+1 must have landed (this wave's share); the blocks behind it (up to kb+NST-1) may stay in flight
+      const int last = min(kb + NST - 1, kb_end - 1);   // youngest block issued so far
+      wait_blocks(last - (kb + 1));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of stage st are done
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
     if constexpr (M16) {
       const int r16 = lane & 15, kg = lane >> 4;   // tile row / column, k/8 group of this lane
       const uint4 *Ab = As + st * NPL * PA + kg * SA + wm * 32 * TM + r16;
@@ -1180,8 +1201,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
 #pragma unroll
         for (int i = 0; i < 2 * TN; ++i) b[pl][i] = Bb[pl * PB + 16 * i];
       }
+      constexpr int FRONT = SWEM_MFMA_FRONT * TM < 2 * TM ? SWEM_MFMA_FRONT * TM : 2 * TM;
 #pragma unroll
-      for (int i = 0; i < 2 * TM; ++i)
+      for (int i = 0; i < 2 * TM; ++i) {
+        if (i == FRONT) hand_over();
 #pragma unroll
         for (int jn = 0; jn < 2 * TN; ++jn) {
           f32x4v c = acc16[i][jn];
@@ -1197,46 +1220,47 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
           c = mfma_bf16_16(a[0][i], b[0][jn], c);
           acc16[i][jn] = c;
         }
+      }
+      if (FRONT >= 2 * TM) hand_over();
     } else {
-    const uint4 *Ab = As + st * NPL * PA + wm * 32 * TM + r;
+      const uint4 *Ab = As + st * NPL * PA + wm * 32 * TM + r;
       const uint4 *Bb = Bs + st * NPL * PB + wn * 32 * TN + r;
-  #pragma unroll
+      uint4 a[KG / 2][NPL][TM], b[KG / 2][NPL][TN];
+#pragma unroll
       for (int s2 = 0; s2 < KG / 2; ++s2) {
         const int k8 = 2 * s2 + h;
-        uint4 a[NPL][TM], b[NPL][TN];
-  #pragma unroll
+#pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
-  #pragma unroll
-          for (int i = 0; i < TM; ++i) a[pl][i] = Ab[pl * PA + k8 * SA + 32 * i];
-  #pragma unroll
-          for (int i = 0; i < TN; ++i) b[pl][i] = Bb[pl * PB + k8 * SB + 32 * i];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[s2][pl][i] = Ab[pl * PA + k8 * SA + 32 * i];
+#pragma unroll
+          for (int i = 0; i < TN; ++i) b[s2][pl][i] = Bb[pl * PB + k8 * SB + 32 * i];
         }
-  #pragma unroll
+      }
+      constexpr int FRONT2 = SWEM_MFMA_FRONT >= 2 ? KG / 2 : (SWEM_MFMA_FRONT * (KG / 2)) / 2;   // k16 steps in front
+#pragma unroll
+      for (int s2 = 0; s2 < KG / 2; ++s2) {
+        if (s2 == FRONT2) hand_over();
+#pragma unroll
         for (int i = 0; i < TM; ++i)
-  #pragma unroll
+#pragma unroll
           for (int jn = 0; jn < TN; ++jn) {
             f32x16 c = acc[i][jn];
             if constexpr (NPL == 3) {
-              c = mfma_bf16(a[0][i], b[2][jn], c);
-              c = mfma_bf16(a[2][i], b[0][jn], c);
-              c = mfma_bf16(a[1][i], b[1][jn], c);
+              c = mfma_bf16(a[s2][0][i], b[s2][2][jn], c);
+              c = mfma_bf16(a[s2][2][i], b[s2][0][jn], c);
+              c = mfma_bf16(a[s2][1][i], b[s2][1][jn], c);
             }
             if constexpr (NPL >= 2) {
-              c = mfma_bf16(a[0][i], b[1][jn], c);
-              c = mfma_bf16(a[1][i], b[0][jn], c);
+              c = mfma_bf16(a[s2][0][i], b[s2][1][jn], c);
+              c = mfma_bf16(a[s2][1][i], b[s2][0][jn], c);
             }
-            c = mfma_bf16(a[0][i], b[0][jn], c);
+            c = mfma_bf16(a[s2][0][i], b[s2][0][jn], c);
             acc[i][jn] = c;
           }
       }
+      if (FRONT2 >= KG / 2) hand_over();
     }
-    // block kb+1 must have landed (this wave's share); the blocks behind it (up to kb+NST-1) may stay in flight
-    {
-      const int last = min(kb + NST - 1, kb_end - 1);   // youngest block issued so far
-      wait_blocks(last - (kb + 1));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of stage st are done
-    __builtin_amdgcn_s_barrier();
     st = st == NST - 1 ? 0 : st + 1;
   }
   STAMP(3);
