@@ -151,6 +151,14 @@ int swem_prep_key_input_f32(void *stream, const float *frames, const float *mean
  * frame NCHW [B][3][H][W], masks [B][N+1][H][W] -> NHWC [B*N][H][W][8] */
 int swem_prep_value_input_f32(void *stream, const float *frame, const float *masks, const float *mean3,
                               const float *std3, float *out, int B, int N, int H, int W, int single_obj);
+/* The same inputs in SPACE-TO-DEPTH form, for conv1 as a 4x4 / stride-1 / pad-1 convolution on 32 channels (K = 512 for the
+ * matrix cores instead of 7x7 / stride 2 on 3 or 5 channels): a 2x2 pixel block becomes one pixel of 4 phases x 8 channels,
+ * channel (py*2 + px)*8 + c, c = (r, g, b, mask, others, 0, 0, 0) (masks == NULL: key form, (r, g, b, 0, ...), N = 1);
+ * blocks stored behind one zero row and column: out NHWC [B*N][H/2+1][W/2+1][32] (may be NULL) and / or its bf16 planes
+ * (layout of swem_split_bf16x3_f32, nplanes = 2 or 3 written).  Filters: w'[co][dy][dx][(py*2+px)*8 + c] =
+ * w[co][2dy+py-1][2dx+px-1][c] (zero where the index is -1): swem_amd.ops.pack_stem_s2d.  H and W even. */
+int swem_prep_input_s2d_f32(void *stream, const float *frame, const float *masks, const float *mean3, const float *std3,
+                            float *out, void *planes, int nplanes, int B, int N, int H, int W, int single_obj);
 /* nn.MaxPool2d(3, 2, 1): mod_resnet.py:123.  NHWC, C % 4 == 0 */
 int swem_maxpool3x3s2_nhwc_f32(void *stream, const float *x, float *y, int B, int H, int W, int C);
 /* y = skip + bilinear(low -> Ho x Wo, align_corners=False): networks.py:193-194.  skip_bs 0 = shared skip */

@@ -30,6 +30,7 @@ SIGNATURES = {
                                      _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz]),
     'swem_prep_key_input_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i]),
     'swem_prep_value_input_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i]),
+    'swem_prep_input_s2d_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_maxpool3x3s2_nhwc_f32': (_i, [_p, _p, _p, _i, _i, _i, _i]),
     'swem_upsample_add_nhwc_f32': (_i, [_p, _p, _ll, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_upsample_add_nhwc_f32_planes': (_i, [_p, _p, _ll, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i]),

@@ -72,6 +72,59 @@ __global__ void prep_value_input_kernel(const float *__restrict__ f, const float
   st4(out + i * 8 + 4, make_float4(other, 0.f, 0.f, 0.f));
 }
 
+// ---- space-to-depth stems --------------------------------------------------------------------------------------
+// conv1 of both encoders is 7x7 / stride 2 / pad 3 on 3 (key) or 5 (value) input channels: K = 147 / 245, far too thin for
+// the matrix cores (the generic fp32 kernel runs it at 45-50 TFLOP/s: 5 % of a frame).  Folding the stride into the
+// channels -- a 2x2 pixel block becomes one "pixel" of 4 x 8 channels -- turns it into a 4x4 / stride 1 convolution on 32
+// channels (K = 512), which the pre-split bf16 kernel takes: out(o) reads input rows 2o-3 .. 2o+3 = blocks o-2 .. o+1, tap
+// dy = (ky+1) >> 1 of phase py = (ky+1) & 1 (the (dy, py) = (0, 0) tap has no filter row: zero).  The blocks are stored
+// shifted by one, behind a zero row and column, so that the asymmetric padding (2 before, 1 after) becomes the symmetric
+// pad = 1 the kernels know.  These kernels write that image (fp32, for the fp32 conv kernels) AND its bf16 planes: one
+// thread per ORIGINAL pixel = one 8-channel group of its block, 16 contiguous bytes per plane.
+// value input (swem.py:48-53, networks.py:115-117): channels (r, g, b, mask, other objects, 0, 0, 0); key input
+// (networks.py:161): (r, g, b, 0, ...); masks == NULL selects the key form.
+__global__ void prep_input_s2d_kernel(const float *__restrict__ f, const float *__restrict__ masks, float3 mean, float3 stdv,
+                                      float *__restrict__ out, unsigned short *__restrict__ planes, int nplanes, int B,
+                                      int N, int H, int W, int single_obj) {
+  const int Hb = H / 2 + 1, Wb = W / 2 + 1;
+  const long long npix = (long long)B * N * Hb * Wb;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (image, block row, block col, phase)
+  if (i >= npix * 4) return;
+  const int ph = (int)(i & 3);
+  const long long blk = i >> 2;
+  const int bx = (int)(blk % Wb);
+  long long t = blk / Wb;
+  const int by = (int)(t % Hb);
+  const long long bn = t / Hb;
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+  if (by > 0 && bx > 0) {
+    const int iy = 2 * (by - 1) + (ph >> 1), ix = 2 * (bx - 1) + (ph & 1);
+    const long long HW = (long long)H * W, pp = (long long)iy * W + ix;
+    const int b = (int)(bn / N), n = (int)(bn - (long long)b * N);
+    const float *src = f + (long long)b * 3 * HW + pp;
+    v0 = make_float4((src[0] - mean.x) / stdv.x, (src[HW] - mean.y) / stdv.y, (src[2 * HW] - mean.z) / stdv.z, 0.f);
+    if (masks) {
+      const float *mb = masks + (long long)b * (N + 1) * HW + pp;
+      const float m = mb[(long long)(n + 1) * HW];
+      v0.w = m;
+      v1.x = single_obj ? 0.f : (1.f - m - mb[0]);
+    }
+  }
+  if (out) {
+    st4(out + blk * 32 + ph * 8, v0);
+    st4(out + blk * 32 + ph * 8 + 4, v1);
+  }
+  if (planes) {
+    uint2 h0, m0, l0, h1, m1, l1;
+    split3(v0, h0, m0, l0);
+    split3(v1, h1, m1, l1);
+    const long long plane = npix * 32, o = ((long long)ph * npix + blk) * 8;
+    *reinterpret_cast<uint4 *>(planes + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    *reinterpret_cast<uint4 *>(planes + plane + o) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+    if (nplanes > 2) *reinterpret_cast<uint4 *>(planes + 2 * plane + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+  }
+}
+
 __global__ void maxpool_kernel(const float *__restrict__ x, float *__restrict__ y, int B, int H, int W, int C, int Ho,
                                int Wo) {
   const int cq = C / 4;
@@ -784,6 +837,20 @@ extern "C" int swem_prep_value_input_f32(void *stream, const float *frame, const
   hipLaunchKernelGGL(prep_value_input_kernel, grid1(n), dim3(256), 0, ST, frame, masks, m, s, out, B, N,
                      (long long)H * W, single_obj);
   SWEM_CHECK_LAUNCH("prep_value_input");
+  return SWEM_OK;
+}
+
+extern "C" int swem_prep_input_s2d_f32(void *stream, const float *frame, const float *masks, const float *mean3,
+                                       const float *std3, float *out, void *planes, int nplanes, int B, int N, int H, int W,
+                                       int single_obj) {
+  SWEM_REQUIRE(frame && mean3 && std3 && (out || planes) && B > 0 && N > 0, SWEM_E_ARG, "prep_input_s2d: bad argument");
+  SWEM_REQUIRE(H % 2 == 0 && W % 2 == 0, SWEM_E_SHAPE, "prep_input_s2d: the frame size must be even (got %dx%d)", H, W);
+  SWEM_REQUIRE(!planes || nplanes == 2 || nplanes == 3, SWEM_E_ARG, "prep_input_s2d: 2 or 3 planes");
+  float3 m = make_float3(mean3[0], mean3[1], mean3[2]), s = make_float3(std3[0], std3[1], std3[2]);
+  const long long n = (long long)B * N * (H / 2 + 1) * (W / 2 + 1) * 4;
+  hipLaunchKernelGGL(prep_input_s2d_kernel, grid1(n), dim3(256), 0, ST, frame, masks, m, s, out,
+                     static_cast<unsigned short *>(planes), nplanes, B, N, H, W, single_obj);
+  SWEM_CHECK_LAUNCH("prep_input_s2d");
   return SWEM_OK;
 }
 

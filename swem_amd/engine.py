@@ -83,12 +83,14 @@ class Engine:
         # --- key encoder (networks.py:132-170)
         self.k_mean, self.k_std = ops._f3(ke.mean), ops._f3(ke.std)
         self.k_stem = ops.pack_conv(ke.conv1.weight, None, _bn(ke.bn1), 2, 3, cin_pad=4)
+        self.k_stem_s2d = ops.pack_stem_s2d(ke.conv1.weight, None, _bn(ke.bn1))
         self.k_stages = [[_Block(b) for b in st] for st in (ke.res2, ke.layer2, ke.layer3)]
         self.key_proj = ops.pack_conv(model.key_proj.key_proj.weight, model.key_proj.key_proj.bias)
         self.key_comp = ops.pack_conv(model.key_comp.weight, model.key_comp.bias)
         # --- value encoder (networks.py:94-129)
         self.v_mean, self.v_std = ops._f3(ve.mean), ops._f3(ve.std)
         self.v_stem = ops.pack_conv(ve.conv1.weight, ve.conv1.bias, _bn(ve.bn1), 2, 3, cin_pad=8)
+        self.v_stem_s2d = ops.pack_stem_s2d(ve.conv1.weight, ve.conv1.bias, _bn(ve.bn1))
         self.v_stages = [[_Block(b) for b in st] for st in (ve.layer1, ve.layer2, ve.layer3)]
         self.fuse1 = _ResBlock(ve.fuser.block1)
         self.fuse2 = _ResBlock(ve.fuser.block2)
@@ -111,8 +113,11 @@ class Engine:
 
     # swem.py:39-43 + networks.py:160-182
     def encode_key(self, frames):
-        x = ops.prep_key_input(frames, self.k_mean, self.k_std)
-        x = ops.maxpool(ops.conv2d([x], self.k_stem, relu_out=True))
+        if ops.S2D_STEMS and frames.shape[2] % 2 == 0 and frames.shape[3] % 2 == 0:
+            x = ops.conv2d([ops.prep_input_s2d(frames, None, self.k_mean, self.k_std)], self.k_stem_s2d, relu_out=True)
+        else:
+            x = ops.conv2d([ops.prep_key_input(frames, self.k_mean, self.k_std)], self.k_stem, relu_out=True)
+        x = ops.maxpool(x)
         feats = []
         for st in self.k_stages:
             for blk in st:
@@ -130,8 +135,13 @@ class Engine:
         N = masks.shape[1] - 1
         if B != 1 and N != 1:
             s16 = per_object(s16, N)      # clip b's feature map for each of its N objects (swem.py:52-53 .expand)
-        x = ops.prep_value_input(frame, masks, self.v_mean, self.v_std, self.single_obj)
-        x = ops.maxpool(ops.conv2d([x], self.v_stem, relu_out=True))
+        if ops.S2D_STEMS and frame.shape[2] % 2 == 0 and frame.shape[3] % 2 == 0:
+            x = ops.conv2d([ops.prep_input_s2d(frame, masks, self.v_mean, self.v_std, self.single_obj)], self.v_stem_s2d,
+                           relu_out=True)
+        else:
+            x = ops.conv2d([ops.prep_value_input(frame, masks, self.v_mean, self.v_std, self.single_obj)], self.v_stem,
+                           relu_out=True)
+        x = ops.maxpool(x)
         for st in self.v_stages:
             for blk in st:
                 x = blk(x)

@@ -297,7 +297,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
             for i, s_ in enumerate(srcs):
                 # (tuning charges a candidate the split of its inputs -- except inputs a conv epilogue produces: those arrive
                 # with their planes from the second frame on, FUSE_SPLIT)
-                if fresh and not (FUSE_SPLIT and s_.__dict__.get('_swem_site', (None,))[0] in ('conv', 'upsample_add')):
+                if fresh and not (FUSE_SPLIT and s_.__dict__.get('_swem_site', (None,))[0] in ('conv', 'upsample_add', 'prep_s2d')):
                     s_.__dict__.pop('_swem_split', None)
                 sp = presplit(s_, relu_in, need)
                 sargs += [sp.data_ptr(), s_.shape[3], args[3 * i + 2], sp.stride(0)]
@@ -460,6 +460,52 @@ def prep_value_input(frame, masks, mean3, std3, single_obj):
     out = torch.empty((B * N, H, W, 8), dtype=torch.float32, device=frame.device)
     _lib.call('swem_prep_value_input_f32', _stream(), frame.data_ptr(), masks.data_ptr(), C.addressof(mean3),
               C.addressof(std3), out.data_ptr(), B, N, H, W, int(single_obj))
+    return out
+
+
+# conv1 of the encoders as a 4x4 / stride-1 convolution on the space-to-depth input (include/swem_hip.h,
+# swem_prep_input_s2d_f32): inference only (the training step keeps the 7x7 form, whose weight gradient it needs)
+S2D_STEMS = os.environ.get('SWEM_S2D_STEMS', '1') != '0'
+
+
+def pack_stem_s2d(weight, bias=None, bn=None):
+    """7x7 / stride-2 / pad-3 stem filters (Cout, Cin <= 8, 7, 7) -> the ConvPack of the equivalent 4x4 / stride-1 / pad-1
+    convolution on the space-to-depth input: w'[co][(py*2+px)*8 + c][dy][dx] = w[co][c][2dy+py-1][2dx+px-1]."""
+    co, ci, kh, kw = weight.shape
+    assert kh == 7 and kw == 7 and ci <= 8
+    w = weight.detach().float()
+    w2 = torch.zeros((co, 32, 4, 4), dtype=torch.float32, device=w.device)
+    for dy in range(4):
+        for py in range(2):
+            ky = 2 * dy + py - 1
+            if not 0 <= ky < 7:
+                continue
+            for dx in range(4):
+                for px in range(2):
+                    kx = 2 * dx + px - 1
+                    if 0 <= kx < 7:
+                        w2[:, (py * 2 + px) * 8:(py * 2 + px) * 8 + ci, dy, dx] = w[:, :, ky, kx]
+    pk = pack_conv(w2, bias, bn, 1, 1)
+    pk.cin_true = ci * 49 / 16.0          # useful FLOPs of the layer are the 7x7 convolution's (bench accounting)
+    return pk
+
+
+def prep_input_s2d(frame, masks, mean3, std3, single_obj=False):
+    """frame NCHW (B,3,H,W) [+ masks (B,N+1,H,W)] -> the normalised space-to-depth input NHWC (B*N, H/2+1, W/2+1, 32) with
+    its bf16 planes already attached (ops.presplit finds them: no split launch)."""
+    _chk(frame, 'frame')
+    B, _, H, W = frame.shape
+    N = 1
+    if masks is not None:
+        _chk(masks, 'masks')
+        N = masks.shape[1] - 1
+    Hb, Wb = H // 2 + 1, W // 2 + 1
+    out = torch.empty((B * N, Hb, Wb, 32), dtype=torch.float32, device=frame.device)
+    sp = torch.empty((3, out.numel()), dtype=torch.bfloat16, device=frame.device)
+    _lib.call('swem_prep_input_s2d_f32', _stream(), frame.data_ptr(), _ptr(masks), C.addressof(mean3), C.addressof(std3),
+              out.data_ptr(), sp.data_ptr(), 3, B, N, H, W, int(single_obj))
+    out.__dict__['_swem_split'] = {False: (sp, 3)}
+    out.__dict__['_swem_site'] = ('prep_s2d', B * N, H, W)
     return out
 
 

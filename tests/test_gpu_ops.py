@@ -310,6 +310,42 @@ def test_conv2d_fused_output_planes(lib, plan):
         ops.SPLIT_HINTS.clear()
 
 
+@pytest.mark.parametrize('value', [False, True], ids=['key_stem', 'value_stem'])
+def test_space_to_depth_stem_equals_the_7x7_stem(lib, value):
+    """conv1 of the encoders (networks.py:115-117,161; mod_resnet.py conv1 7x7 / stride 2 / pad 3) as a 4x4 / stride-1
+    convolution on the space-to-depth input (swem_prep_input_s2d_f32 + ops.pack_stem_s2d): the same sums in another order --
+    equal to the 7x7 form to fp32 rounding on the fp32 kernels, to the bf16x3 tolerance on the pre-split kernel (whose planes
+    the prep kernel writes itself)."""
+    g = torch.Generator().manual_seed(3)
+    B, N, Hh, Ww = 1, 2, 44, 76
+    frame = torch.rand(B, 3, Hh, Ww, generator=g).to(DEV)
+    masks = torch.softmax(torch.randn(B, N + 1, Hh, Ww, generator=g) * 3, 1).to(DEV)
+    ci = 5 if value else 3
+    w = (torch.randn(64, ci, 7, 7, generator=g) * 0.05).to(DEV)
+    bias = (torch.randn(64, generator=g) * 0.1).to(DEV) if value else None
+    bn = [t.to(DEV) for t in (torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1,
+                              torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5)]
+    mean3, std3 = ops._f3(torch.tensor([0.485, 0.456, 0.406])), ops._f3(torch.tensor([0.229, 0.224, 0.225]))
+    if value:
+        x7 = ops.prep_value_input(frame, masks, mean3, std3, False)
+        xs = ops.prep_input_s2d(frame, masks, mean3, std3, False)
+    else:
+        x7 = ops.prep_key_input(frame, mean3, std3)
+        xs = ops.prep_input_s2d(frame, None, mean3, std3)
+    ref = ops.conv2d([x7], ops.pack_conv(w, bias, bn, 2, 3, cin_pad=8 if value else 4), relu_out=True)
+    pk = ops.pack_stem_s2d(w, bias, bn)
+    got = ops.conv2d([xs], pk, relu_out=True, plan=0x11)                      # fp32 kernel
+    assert got.shape == ref.shape
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 2e-6 * scale
+    # the planes the prep kernel attached are the split of the fp32 image
+    sp = torch.empty((3, xs.numel()), dtype=torch.bfloat16, device=DEV)
+    __import__('swem_amd')._lib.call('swem_split_bf16x3_f32', ops._stream(), xs.data_ptr(), sp.data_ptr(), xs.numel() // 32, 32, 0)
+    assert torch.equal(xs.__dict__['_swem_split'][False][0].view(torch.int16), sp.view(torch.int16))
+    got3 = ops.conv2d([xs], pk, relu_out=True, plan=0x30011)                  # bf16x3 on the pre-split kernel
+    assert float((got3 - ref).abs().max()) < 3e-5 * scale
+
+
 def test_upsample_add_fused_output_planes(lib):
     """networks.py:193-194 with the result's bf16 planes written by the same launch (the decoder's ResBlocks consume it
     pre-split, with and without their input ReLU): y bit-identical to the plain kernel, planes bit-identical to
