@@ -123,7 +123,7 @@ class SWEMCore(nn.Module):
 
     # ------------------------------------------------------------------ packed banks
     def _pack_for(self, N, Ck, device):
-        shape = (2 * N, Ck // 4, 2 * self.n_bases, 4)
+        shape = (2 * N, Ck // 4 + 1, 2 * self.n_bases, 4)      # ops.new_pack: packed keys carry one extra group (norms)
         if self._pack is None or tuple(self._pack[0].shape) != shape or self._pack[0].device != device:
             self._pack = ops.new_pack(N, Ck, self.valdim, self.n_bases, device)
             self._stamp = [None, None]

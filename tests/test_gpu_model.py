@@ -273,6 +273,36 @@ def test_frame_graph_matches_eager(lib):
         assert torch.equal(be[k], bg[k]), k
 
 
+def test_persistent_pack_is_kept_across_frames(lib):
+    """SWEMCore keeps ONE packed copy of the banks: after the first two frames no frame re-packs a bank or allocates a new
+    pack (memorize writes the new bank's packed form itself, matching reads it)."""
+    from swem_amd import _lib, synth
+    cfg = O.make_cfg(**CFG_A)
+    model, _ = H.make_model_and_sd(cfg, 5, device=DEV)
+    frames, m0 = synth.make_clip(t=6, h=128, w=192, n_obj=2, seed=9)
+    calls, packs = [], []
+    real_call, real_new = _lib.call, ops.new_pack
+
+    def counting(name, *a):
+        if name in ('swem_match_pack_bank_f32', 'swem_em_pack_bases_f32', 'swem_em_norm_bases_f32'):
+            calls.append(name)
+        return real_call(name, *a)
+
+    def new_pack(*a):
+        packs.append(1)
+        return real_new(*a)
+    _lib.call, ops.new_pack = counting, new_pack
+    try:
+        with torch.no_grad():
+            torch.manual_seed(1)
+            evaluator.evaluate_davis_seq(model, frames.to(DEV), [m0.to(DEV)] + [None] * 5, (128, 192))
+    finally:
+        _lib.call, ops.new_pack = real_call, real_new
+    assert len(packs) == 1, packs
+    # frame 0 packs the random prior once (memorize without a packed prior); nothing after it
+    assert len(calls) <= 2, calls
+
+
 def test_ytvos_loop_and_tta_vs_golden(lib, golden):
     """f1 rows: evaluate_ytvos_seq with an object that appears at frame 2 (exercises N_new > 0 in swem() and
     MemoryBank.add_new) and the multi-scale + flip TTA, against the reference's index maps."""
