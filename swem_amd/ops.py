@@ -420,21 +420,24 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
                             if wm == 2 and wn == 2:
                                 cands.append(base | 2 << 20 | ts << 24)
                                 cands.append(base | 8 << 20 | ts << 24)
-    def timed(plan):
+    def timed(plan, n):
         launch(plan)                               # warm (also grows the workspace)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # a short spin kernel holds the queue while the host enqueues the n launches: the interval is then GPU time between
+        # back-to-back packets -- with an empty queue a 15 us layer measures the host's ~10 us per Python launch instead
+        torch.cuda._sleep(150_000 + 40_000 * n)
         e0.record()
-        for _ in range(reps):
+        for _ in range(n):
             launch(plan, True) if fresh_kw else launch(plan)
         e1.record()
         e1.synchronize()
-        return e0.elapsed_time(e1)
-    best, best_t = 0, float('inf')
-    for plan in cands:
-        t = timed(plan)
-        if t < best_t:
-            best, best_t = plan, t
-    return best
+        return e0.elapsed_time(e1) / n
+    first = sorted((timed(plan, reps), plan) for plan in cands)
+    # the candidates within 15 % of the fastest (at most four) are timed again, longer: the first pass is three launches each
+    short = [pl for t, pl in first[:4] if t <= 1.15 * first[0][0]]
+    if len(short) == 1:
+        return short[0]
+    return min((timed(plan, 3 * reps), plan) for plan in short)[1]
 
 
 def _f3(t):
