@@ -1149,10 +1149,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
     else if (c == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");
   };
+  // SWEM_ISSUE_LATE = 1: the transfer of block kb+NST is issued right behind the hand-over of iteration kb, into the stage
+  // that barrier has just released, and flies under this iteration's MFMAs (all NST stages hold data in flight);
+  // 0 (default): it is issued at the top of the next iteration, behind those MFMAs (NST-1 stages in flight).
+  // Measured (tools/conv_bench.py, tuned plans): 1 is SLOWER -- 308 against 330 TFLOP/s on 2x120x216 256->256, 296 against
+  // 338 on 2x30x54 1280->512, and the 1x1 layers on 30x54 maps take 36 us instead of 20: the eight waves' address work and
+  // transfer requests right behind the barrier hold up all their MFMA chains at once; at the top of the next iteration they
+  // trickle in as the waves finish.
+#ifndef SWEM_ISSUE_LATE
+#define SWEM_ISSUE_LATE 0
+#endif
+  constexpr int NPRO = SWEM_ISSUE_LATE ? NST : NST - 1;   // blocks issued before the loop
   issue(0);
   int issued = 1;   // k-blocks handed to the DMA so far (relative to kb_begin)
 #pragma unroll
-  for (int d = 1; d < NST - 1; ++d)
+  for (int d = 1; d < NPRO; ++d)
     if (kb_begin + d < kb_end) {
       advance(q);
       issue(d);
@@ -1163,8 +1174,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   STAMP(2);
   int st = 0;
   for (int kb = kb_begin; kb < kb_end; ++kb) {
-    const bool ahead = kb + NST - 1 < kb_end;
-    if (ahead) {
+    if (!SWEM_ISSUE_LATE && kb + NST - 1 < kb_end) {
       advance(q);
       issue(st == 0 ? NST - 1 : st - 1);  // stage (kb+NST-1) % NST
     }
@@ -1187,6 +1197,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
       wait_blocks(last - (kb + 1));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of stage st are done
       __builtin_amdgcn_s_barrier();
+      if (SWEM_ISSUE_LATE && kb + NST < kb_end) {   // every wave has read stage st: refill it with block kb+NST
+        advance(q);
+        issue(st);
+      }
       __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (M16) {
