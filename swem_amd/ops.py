@@ -207,6 +207,9 @@ def presplit(t, relu=False, nplanes=3):
     (conv2d's epilogue, the frozen-BN stages of the training step): the request is recorded under the producer's site so
     that it can do so from the next frame / step on."""
     cache = t.__dict__.setdefault('_swem_split', {})
+    if cache and t.__dict__.get('_swem_split_ver', t._version) != t._version:
+        cache.clear()                      # the tensor was modified in place after its planes were made
+    t.__dict__['_swem_split_ver'] = t._version
     ent = cache.get(relu)
     site = t.__dict__.get('_swem_site')
     if site is not None:
@@ -327,6 +330,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         y.__dict__['_swem_site'] = site
         if planes:
             y.__dict__['_swem_split'] = dict(planes)
+            y.__dict__['_swem_split_ver'] = y._version
     if CONV_TRACE is not None:
         e1.record()
         ncols = pack.cout * (2 if pack.glu else 1)
@@ -508,6 +512,7 @@ def prep_input_s2d(frame, masks, mean3, std3, single_obj=False):
     _lib.call('swem_prep_input_s2d_f32', _stream(), frame.data_ptr(), _ptr(masks), C.addressof(mean3), C.addressof(std3),
               out.data_ptr(), sp.data_ptr(), 3, B, N, H, W, int(single_obj))
     out.__dict__['_swem_split'] = {False: (sp, 3)}
+    out.__dict__['_swem_split_ver'] = out._version
     out.__dict__['_swem_site'] = ('prep_s2d', B * N, H, W)
     return out
 
@@ -547,6 +552,7 @@ def upsample_add(skip, low, batch=None):
         _lib.call('swem_upsample_add_nhwc_f32_planes', _stream(), skip.data_ptr(), sbs, low.data_ptr(), y.data_ptr(), B,
                   low.shape[1], low.shape[2], Ho, Wo, Cc, *pargs)
         y.__dict__['_swem_split'] = planes
+        y.__dict__['_swem_split_ver'] = y._version
     else:
         _lib.call('swem_upsample_add_nhwc_f32', _stream(), skip.data_ptr(), sbs, low.data_ptr(), y.data_ptr(), B,
                   low.shape[1], low.shape[2], Ho, Wo, Cc)

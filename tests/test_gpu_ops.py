@@ -369,7 +369,15 @@ def test_upsample_add_fused_output_planes(lib):
             n = got[relu][1]
             assert n == (3 if relu else 2)
             assert torch.equal(got[relu][0][:n].view(torch.int16), sp[:n].view(torch.int16))
-        assert ops.presplit(y1, True, 3) is got[True][0]
+        fused = got[True][0]
+        assert ops.presplit(y1, True, 3) is fused
+        # an in-place change of the tensor invalidates the planes a producer attached: the next consumer splits again
+        y1.mul_(2.0)
+        again = ops.presplit(y1, True, 3)
+        assert again is not fused
+        sp = torch.empty((3, M * C), dtype=torch.bfloat16, device=DEV)
+        __import__('swem_amd')._lib.call('swem_split_bf16x3_f32', ops._stream(), y1.data_ptr(), sp.data_ptr(), M, C, 1)
+        assert torch.equal(again.view(torch.int16), sp.view(torch.int16))
     finally:
         ops.SPLIT_HINTS.clear()
 

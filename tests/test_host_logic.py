@@ -150,3 +150,19 @@ def test_training_host_logic_matches_reference_semantics():
     torch.manual_seed(3)
     k, n, z = O.random_init((2, 2, 2, 8, 64), 4)
     assert torch.equal(kap, k) and float(z.max()) == pytest.approx(1e-6) and float(n.abs().max()) == 0.0
+
+
+def test_nchw_views_find_their_nhwc_tensor_again():
+    """SWEM.forward hands NHWC activations out as NCHW-shaped views (the reference's callers index them that way); when such a
+    view comes back in, the ORIGINAL tensor object -- and with it whatever a producing kernel cached on it (bf16 planes, the
+    site its consumers report to) -- is used again (ops.presplit drops cached planes whose tensor was modified in place since: tests/test_gpu_ops.py)."""
+    from swem_amd.modules import as_nchw, to_pixel_major
+    t = torch.randn(2, 5, 7, 8)                       # NHWC
+    t.__dict__['_swem_split'] = {'marker': 1}
+    v = as_nchw(t)
+    assert v.shape == (2, 8, 5, 7) and v.data_ptr() == t.data_ptr()
+    assert to_pixel_major(v) is t and to_pixel_major(v).__dict__['_swem_split'] == {'marker': 1}
+    back = to_pixel_major(as_nchw(torch.randn(2, 5, 7, 8)).clone(memory_format=torch.channels_last))
+    assert '_swem_split' not in back.__dict__         # a tensor from elsewhere: plain view, nothing attached
+    other = torch.randn(2, 8, 5, 7).contiguous(memory_format=torch.channels_last)
+    assert torch.equal(to_pixel_major(other), other.permute(0, 2, 3, 1))
