@@ -80,10 +80,12 @@ class FrameRunner:
         with torch.no_grad():
             return evaluator.frame_step(self.model, f, OUT_HW)
 
-    def enable_graph(self):
-        """Capture the steady-state frame into a HIP graph (both banks must exist: call after >= 2 eager steps)."""
+    def enable_graph(self, pipelined=False):
+        """Capture the steady-state frame into a HIP graph (both banks must exist: call after >= 2 eager steps).
+        pipelined: evaluator.PipelinedFrameGraph (the previous frame's memorize under this frame's key encoder)."""
         from swem_amd import evaluator
-        self.graph = evaluator.FrameGraph(self.model, self.frames[:, 1].shape, OUT_HW).capture(self.frames[:, 1])
+        cls = evaluator.PipelinedFrameGraph if pipelined else evaluator.FrameGraph
+        self.graph = cls(self.model, self.frames[:, 1].shape, OUT_HW).capture(self.frames[:, 1])
 
 
 def cpu_baseline(frames, m0, sd, n_frames=20, warm=2):
@@ -133,6 +135,9 @@ def main():
     ap.add_argument('--save-plans', default=None, help='write the tuned per-layer plans to this JSON file')
     ap.add_argument('--load-plans', default=None, help='reuse plans from this file (no tuning; for profiler runs)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay')
+    ap.add_argument('--pipeline', choices=('auto', 'on', 'off'), default='auto',
+                    help='software-pipelined frame graph (evaluator.PipelinedFrameGraph): +12 %% with one sequence, -10 %% with several '
+                         '(their streams already fill the hardware queues); auto = on for --seqs 1 only')
     ap.add_argument('--seqs', type=int, default=4,
                     help='independent sequences processed concurrently per GPU, each on its own HIP stream')
     ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
@@ -208,8 +213,9 @@ def main():
                 pass
             ops.AUTOTUNE = False
             if not args.no_graph:
-                runner.enable_graph()
+                runner.enable_graph(pipelined=args.pipeline == 'on' or (args.pipeline == 'auto' and nseq == 1))
                 runner.step()
+                runner.step()       # (the pipelined graph's first step runs eagerly: nothing is pending yet)
         torch.cuda.synchronize()
         runners.append(runner)
         streams.append(st)
@@ -253,7 +259,9 @@ def main():
                                    'K=256, 5 EM iters, %d objects, memorise every frame, %d sequence(s) per GPU' % (n_obj, nseq),
                        'objects': n_obj, 'frames_per_step': nseq, 'sequences_per_gpu': nseq, 'parallelism': 'seq-sharded x%d (no collective)' % world,
                        'weights': 'random init of the reference architecture (seeded)',
-                       'launch': 'eager' if args.no_graph else 'hipGraph replay of the steady-state frame'},
+                       'launch': 'eager' if args.no_graph else ('hipGraph replay of the steady-state frame' + (
+                           ', software-pipelined (previous frame\'s memorize under this frame\'s key encoder)'
+                           if (args.pipeline == 'on' or (args.pipeline == 'auto' and nseq == 1)) else ''))},
             'fps_per_gpu': round(fps / world, 3),
             'frame_algorithmic_tflops': round(algorithmic_flops_per_frame(n_obj) * fps / world / 1e12, 2),
         }

@@ -210,6 +210,124 @@ class FrameGraph:
         return self.pred
 
 
+class PipelinedFrameGraph(FrameGraph):
+    """FrameGraph with the frame software-pipelined for ONE sequence.  Within a sequence the only thing frame t needs from
+    frame t-1 is its memory update, and only at `match`: frame t's key encoder is independent of it.  The captured graph
+    therefore forks -- frame t-1's encode_value + memorize (its inputs kept in static "pending" buffers) run on a side branch
+    under frame t's encode_key -- and joins in front of match.  Every kernel sees exactly the data of the sequential order:
+    the index maps are bit-identical (tests/test_gpu_model.py); measured on config B, one sequence: 3.43 -> ~3.0 ms per frame.
+
+    The first run() after capture() / rebind() processes its frame eagerly with the memorize deferred (there is nothing pending
+    yet); flush() applies a pending memorize eagerly (the model's memory then equals the sequential loop's)."""
+
+    def __init__(self, model, frame_shape, out_size, streams=None, side_stream=None):
+        super().__init__(model, frame_shape, out_size, streams)
+        self.side = side_stream
+        self.pend = None            # static buffers: frame, soft masks, one-hot masks, key, 1/16 features of the pending frame
+        self.primed = False
+
+    def _front(self, frame):
+        """encode_key .. segment of one frame; returns the index map and what its deferred memorize needs."""
+        h, w = frame.shape[-2:]
+        qk16, qv16, s16, s8, s4 = self.model('encode_key', frame)
+        context, n = self.model('match', qk16, qv16)
+        _, pred_mask = self.model('segment', n, context, s8, s4, None, self.out_size)
+        pred, hard = ops.argmax_onehot(pred_mask, want_onehot=True)
+        pm = ops.resize_planes(pred_mask, (h, w), 'bilinear')
+        return pred, (frame, pm, hard, qk16, s16)
+
+    def _back(self):
+        """The pending frame's encode_value + memorize."""
+        frame, pm, hard, qk16, s16 = self.pend
+        self.model('memorize', qk16, self.model('encode_value', frame, pm, s16), hard, pm)
+
+    def _stash(self, cur):
+        if self.pend is None:
+            self.pend = [t.clone() for t in cur]
+        else:
+            for dst, src in zip(self.pend, cur):
+                if dst is not src:
+                    dst.copy_(src)
+
+    def _body(self, main, side):
+        core = self.model.swem_core
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._back()
+            new = core.memories['update'].bases
+            for k in self.state:
+                self.state[k].copy_(new[k])
+        pred, cur = None, None
+        qk16, qv16, s16, s8, s4 = self.model('encode_key', self.frame)        # under the side branch
+        main.wait_stream(side)
+        h, w = self.frame.shape[-2:]
+        context, n = self.model('match', qk16, qv16)
+        _, pred_mask = self.model('segment', n, context, s8, s4, None, self.out_size)
+        pred, hard = ops.argmax_onehot(pred_mask, want_onehot=True)
+        pm = ops.resize_planes(pred_mask, (h, w), 'bilinear')
+        self._stash((self.frame, pm, hard, qk16, s16))
+        return pred
+
+    def capture(self, example_frame):
+        core = self.model.swem_core
+        self.frame.copy_(example_frame)
+        with torch.no_grad():
+            if self.streams is None:
+                self.streams = (ops.new_stream(), ops.new_stream())
+            if self.side is None:
+                self.side = overlapping_streams(2)[1]
+            warm, cap = self.streams
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                # a pending frame to size the buffers (any frame will do: everything it touches is restored below)
+                saved = {k: v.clone() for k, v in self.state.items()}
+                _, cur = self._front(self.frame)
+                self._stash(cur)
+                self._body(warm, self.side)                      # one eager pass: sizes every workspace of both branches
+                warm.wait_stream(self.side)
+            torch.cuda.current_stream().wait_stream(warm)
+            for k in self.state:
+                self.state[k].copy_(saved[k])
+            core.memories['update'].bases = self.state
+            self.pack = core.repack()
+            self.capture_stream = cap
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.graph(self.graph, stream=cap):
+                self.pred = self._body(cap, self.side)
+            core.memories['update'].bases = self.state
+            core.restamp()
+        self.primed = False
+        return self
+
+    def rebind(self):
+        ok = super().rebind()
+        self.primed = False
+        return ok
+
+    def run(self, frame):
+        if not self.primed:        # nothing pending yet: this frame eagerly, its memorize deferred
+            with torch.no_grad():
+                pred, cur = self._front(frame)
+                self._stash(cur)
+            self.primed = True
+            return pred
+        self.frame.copy_(frame)
+        self.graph.replay()
+        return self.pred
+
+    def flush(self):
+        """Apply the pending memorize (eagerly): afterwards the model's memory is that of the sequential loop."""
+        if self.primed:
+            with torch.no_grad():
+                self._back()
+                new = self.model.swem_core.memories['update'].bases
+                for k in self.state:
+                    self.state[k].copy_(new[k])
+                self.model.swem_core.memories['update'].bases = self.state
+                self.model.swem_core.restamp()
+            self.primed = False
+
+
 def run_sequences(model, sequences, meter=None):
     """basic_evaluator.py:149-199 without the disk IO: sequences = iterable of (frames, init_mask, out_size)."""
     meter = meter or FrameSecondMeter()
@@ -292,7 +410,8 @@ class SequencePool:
     EM kernels, ~300 short launches per frame), so a second one's kernels fill the gaps (+18..25 % frames/s, bench.py).
     The lanes' streams are probed for real concurrency (`overlapping_streams`): two streams can share a hardware queue.
     After a sequence's first two frames (eager: they build the two banks) the steady-state frame is replayed from a HIP
-    graph that is captured once per lane and re-bound to each new sequence of the same shape."""
+    graph that is captured once per lane and re-bound to each new sequence of the same shape.  A pool of ONE model runs the
+    software-pipelined graph (PipelinedFrameGraph)."""
 
     def __init__(self, models, use_graph=True):
         self.models = list(models)
@@ -336,7 +455,10 @@ class SequencePool:
                                 bound = getattr(g, '_bound_to', None) == si or g.rebind()
                             if not bound and model.swem_core.memories['update'].bases is not None:
                                 self.graphs[li] = None        # the replaced graph (and its private pool) goes first
-                                g = FrameGraph(model, frames[:, i].shape, out_size, streams=self.graph_streams[li])
+                                # one lane: the frame software-pipelined (+12 % frames/s); several lanes already fill the
+                                # hardware queues, a forked graph per lane costs ~10 % there (bench.py --pipeline)
+                                cls = PipelinedFrameGraph if len(self.models) == 1 else FrameGraph
+                                g = cls(model, frames[:, i].shape, out_size, streams=self.graph_streams[li])
                                 g.capture(frames[:, i])
                                 self.graphs[li], self.graph_streams[li] = g, g.streams
                                 bound = True

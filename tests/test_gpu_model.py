@@ -273,6 +273,41 @@ def test_frame_graph_matches_eager(lib):
         assert torch.equal(be[k], bg[k]), k
 
 
+def test_pipelined_frame_graph_matches_eager(lib):
+    """evaluator.PipelinedFrameGraph (frame t-1's encode_value + memorize on a forked branch under frame t's encode_key) gives
+    the index maps of the sequential loop bit for bit, and after flush() the same memory."""
+    from swem_amd import synth
+    cfg = O.make_cfg(**CFG_A)
+    frames, m0 = synth.make_clip(t=6, h=128, w=192, n_obj=2, seed=9)
+    frames, m0 = frames.to(DEV), m0.to(DEV)
+    order = (3, 4, 5, 3, 4, 5, 2)
+
+    def run(pipelined):
+        model, _ = H.make_model_and_sd(cfg, wseed=4, device=DEV)
+        with torch.no_grad():
+            torch.manual_seed(11)
+            mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+            mv16 = model('encode_value', frames[:, 0], m0, s16)
+            model('init', mk16, mv16, m0)
+            preds = [evaluator.frame_step(model, frames[:, i], (128, 192)).clone() for i in (1, 2)]
+            g = evaluator.PipelinedFrameGraph(model, frames[:, 1].shape, (128, 192)).capture(frames[:, 1]) if pipelined else None
+            for i in order:
+                p = g.run(frames[:, i]) if pipelined else evaluator.frame_step(model, frames[:, i], (128, 192))
+                preds.append(p.clone())
+            if pipelined:
+                g.flush()
+            bases = {k: v.clone() for k, v in model.swem_core.memories['update'].bases.items()}
+        torch.cuda.synchronize()
+        return preds, bases
+
+    pe, be = run(False)
+    pg, bg = run(True)
+    for i, (a, b) in enumerate(zip(pe, pg)):
+        assert torch.equal(a, b), 'frame %d' % i
+    for k in be:
+        assert torch.equal(be[k], bg[k]), k
+
+
 def test_persistent_pack_is_kept_across_frames(lib):
     """SWEMCore keeps ONE packed copy of the banks: after the first two frames no frame re-packs a bank or allocates a new
     pack (memorize writes the new bank's packed form itself, matching reads it)."""
@@ -475,11 +510,13 @@ def test_module_level_vectors_vs_reference(lib, golden):
     assert logits_close(lg2.cpu(), fx['dec_logits_novalid'])
 
 
-def test_sequence_pool_equals_sequential_evaluation(lib):
-    """Two sequences in flight per GPU (two streams, HIP-graph replay re-bound from sequence to sequence) give the same
-    index maps as evaluating the sequences one after another with the plain loop."""
+@pytest.mark.parametrize('lanes', [2, 1], ids=['two_lanes', 'one_lane_pipelined'])
+def test_sequence_pool_equals_sequential_evaluation(lib, lanes):
+    """Two sequences in flight per GPU (two streams, HIP-graph replay re-bound from sequence to sequence) -- or one lane, whose
+    graph is the software-pipelined PipelinedFrameGraph -- give the same index maps as evaluating the sequences one after
+    another with the plain loop."""
     cfg = O.make_cfg(**CFG_A)
-    models = [H.make_model_and_sd(cfg, 5, DEV)[0] for _ in range(2)]
+    models = [H.make_model_and_sd(cfg, 5, DEV)[0] for _ in range(lanes)]
     seqs, seeds = [], [11, 12, 13, 14, 15]
     # same shape three times (the lane's graph is re-bound), then one object (re-captured), then another frame size
     for k, (t, hh, ww, n) in enumerate(((5, 240, 432, 2), (4, 240, 432, 2), (6, 240, 432, 2), (5, 240, 432, 1),
@@ -496,6 +533,7 @@ def test_sequence_pool_equals_sequential_evaluation(lib):
     got = pool.run(seqs, seeds=seeds)
     torch.cuda.synchronize()
     assert pool.graphs[0] is not None
+    assert isinstance(pool.graphs[0], evaluator.PipelinedFrameGraph) == (lanes == 1)
     for r, g_ in zip(ref, got):
         assert len(r) == len(g_)
         for a, b in zip(r, g_):
