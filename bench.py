@@ -88,13 +88,49 @@ class FrameRunner:
         self.graph = cls(self.model, self.frames[:, 1].shape, OUT_HW).capture(self.frames[:, 1])
 
 
+def host_cpu():
+    """CPU model and core counts of this host (lscpu / /proc/cpuinfo; the affinity mask bounds what this process may use)."""
+    import re
+    import subprocess
+    info = {'model': None, 'sockets': None, 'logical_cpus': os.cpu_count(), 'physical_cores': None,
+            'logical_cpus_available': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()}
+    try:
+        txt = subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout
+        get = lambda k: (re.search(r'^%s:\s*(.+)$' % re.escape(k), txt, re.M) or [None, None])[1]
+        info['model'] = get('Model name')
+        so, cps, tpc = get('Socket(s)'), get('Core(s) per socket'), get('Thread(s) per core')
+        if so and cps:
+            info['sockets'] = int(so)
+            info['physical_cores'] = int(so) * int(cps)
+        info['threads_per_core'] = int(tpc) if tpc else None
+    except (OSError, ValueError, subprocess.SubprocessError):
+        pass
+    tpc = info.get('threads_per_core') or 1
+    avail = info['logical_cpus_available']
+    try:                                   # a cgroup CPU quota (cpu.max: "<quota> <period>") bounds it further
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, per = f.read().split()[:2]
+        if q != 'max':
+            info['cgroup_cpu_quota'] = round(int(q) / int(per), 2)
+            avail = max(1, min(avail, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    # physical cores this process can use: the affinity mask / cgroup may expose fewer CPUs than the machine has
+    info['physical_cores_available'] = max(1, min(info['physical_cores'] or avail, avail // tpc if avail >= tpc else avail))
+    return info
+
+
 def cpu_baseline(frames, m0, sd, n_frames=20, warm=2):
     """The CPU oracle (a port of the reference's PyTorch path) on the same clip: frame 0 and `warm` frames untimed, then
     the mean over `n_frames` steady-state frames, every host thread torch finds."""
     from oracle import swem_oracle as O
     import torch.nn.functional as F
     cfg = O.make_cfg(**CFG)
-    threads = torch.get_num_threads()
+    cpu = host_cpu()
+    # one torch thread per PHYSICAL core (SURVEY.md section 8d): on an SMT host torch's default of one thread per logical CPU
+    # oversubscribes the FP units (round 2: 0.39 frames/s on 128 threads against 0.9 on 8 cores)
+    threads = max(1, min(cpu['physical_cores_available'] or torch.get_num_threads(), torch.get_num_threads()))
+    torch.set_num_threads(threads)
     fr, m0 = frames.cpu(), m0.cpu()
     t_clip, (h, w) = fr.shape[1], fr.shape[-2:]
     model = O.Model(sd, cfg)
@@ -118,10 +154,10 @@ def cpu_baseline(frames, m0, sd, n_frames=20, warm=2):
         for i in range(n_frames):
             frame(warm + i)
         dt = time.time() - t0
-    return {'value': round(n_frames / dt, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+    return {'value': round(n_frames / dt, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port', 'cpu': cpu,
             'sample': 'oracle/swem_oracle.py, the same 480x864 clip: frame 0 + %d warm-up frames untimed, then %d steady-state '
-                      'frames (encode_key, match, segment, encode_value, memorize) in %.1f s on %d torch CPU threads'
-                      % (warm, n_frames, dt, threads)}
+                      'frames (encode_key, match, segment, encode_value, memorize) in %.1f s on %d torch CPU threads '
+                      '(one per physical core available; %s)' % (warm, n_frames, dt, threads, cpu['model'])}
 
 
 def main():
@@ -142,6 +178,7 @@ def main():
                     help='independent sequences processed concurrently per GPU, each on its own HIP stream')
     ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
     ap.add_argument('--no-em', action='store_true', help='skip the EM/matching timing legs (profiler runs)')
+    ap.add_argument('--no-legs', action='store_true', help='skip the single-sequence and fp32-level legs (profiler runs)')
     ap.add_argument('--trace-layers', default=None, help='write the per-launch conv list of the eager roofline frames (JSON)')
     ap.add_argument('--cpu-frames', type=int, default=20, help='timed frames of the CPU baseline (after 2 warm-up frames)')
     ap.add_argument('--max-split', type=int, default=0, help='cap the K-split factors the conv tuner may choose (0 = all)')
@@ -183,68 +220,85 @@ def main():
                                       SINGLE_OBJ=False, BACKBONE='resnet50'), **CFG))
     n_obj = args.objects
     nseq = max(1, args.seqs)
+    from swem_amd import evaluator
+    book = ops.PlanBook()            # ONE book for every model of this process: tuned on the first sequence, read by all
     if args.load_plans:
-        ops.load_plans(args.load_plans)
-    ops.AUTOTUNE = not args.no_autotune and not args.load_plans   # per-layer plan chosen by timing, during warm-up only
+        book.load(args.load_plans)
     if args.max_split:
         ops._TUNE_SPLITS = tuple(v for v in ops._TUNE_SPLITS if v <= args.max_split)
-    runners, streams = [], []
-    sd = None
-    from swem_amd import evaluator
-    # streams that really overlap (two HIP streams can share a hardware queue and then serialise: evaluator.overlapping_streams)
-    seq_streams = evaluator.overlapping_streams(nseq) if nseq > 1 else [torch.cuda.current_stream()]
-    for si in range(nseq):
-        model = SWEM(cfg)
-        if sd is None:
-            sd = weights.fill_state_dict(model.state_dict(), seed=3, backbone='resnet50')
-        model.load_state_dict(sd)
-        model = model.eval().to(dev)
-        frames_cpu, m0_cpu = synth.make_clip(t=8, h=H, w=W, n_obj=n_obj, out_hw=OUT_HW, seed=123 + rank * 16 + si)
-        frames, m0 = frames_cpu.to(dev), m0_cpu.to(dev)
-        st = seq_streams[si]
-        if si == 0:
-            frames0_cpu, m0_0_cpu = frames_cpu, m0_cpu
-        with torch.cuda.stream(st):
-            torch.manual_seed(1234 + rank * 16 + si)
-            runner = FrameRunner(model, frames, m0)
-            for _ in range(max(args.warmup, 2)):
-                runner.step()
-            if si > 0 and runners:          # reuse the plans tuned on the first sequence
-                pass
-            ops.AUTOTUNE = False
-            if not args.no_graph:
-                runner.enable_graph(pipelined=args.pipeline == 'on' or (args.pipeline == 'auto' and nseq == 1))
-                runner.step()
-                runner.step()       # (the pipelined graph's first step runs eagerly: nothing is pending yet)
-        torch.cuda.synchronize()
-        runners.append(runner)
-        streams.append(st)
-    runner = runners[0]
-    frames_cpu, m0_cpu = frames0_cpu, m0_0_cpu
-    if args.save_plans and rank == 0:
-        ops.save_plans(args.save_plans)
+    tune = not args.no_autotune and not args.load_plans   # per-layer plan chosen by timing, during warm-up only
+    sd_box, clip_box = [None], {}
 
-    def step_all():
-        if nseq == 1:
-            runners[0].step()
-            return
-        for rn, st in zip(runners, streams):
+    def make_runners(n, pipelined, seed_base):
+        """n independent sequences, each its own model (memory banks) on its own probed stream, warmed up (the first one
+        tunes the plans of the current conv_math mode into `book`) and captured into its frame graph."""
+        rs, sts = [], []
+        # streams that really overlap (two HIP streams can share a hardware queue and then serialise: evaluator.overlapping_streams)
+        seq_streams = evaluator.overlapping_streams(n) if n > 1 else [torch.cuda.current_stream()]
+        for si in range(n):
+            model = SWEM(cfg)
+            if sd_box[0] is None:
+                sd_box[0] = weights.fill_state_dict(model.state_dict(), seed=3, backbone='resnet50')
+            model.load_state_dict(sd_box[0])
+            model = model.eval().to(dev)
+            model.book = book
+            seed = 123 + rank * 16 + si
+            if seed not in clip_box:
+                clip_box[seed] = synth.make_clip(t=8, h=H, w=W, n_obj=n_obj, out_hw=OUT_HW, seed=seed)
+            frames_cpu, m0_cpu = clip_box[seed]
+            st = seq_streams[si]
             with torch.cuda.stream(st):
-                rn.step()
+                torch.manual_seed(seed_base + rank * 16 + si)
+                rn = FrameRunner(model, frames_cpu.to(dev), m0_cpu.to(dev))
+                ops.AUTOTUNE = tune and si == 0
+                for _ in range(max(args.warmup, 2)):
+                    rn.step()
+                ops.AUTOTUNE = False
+                if not args.no_graph:
+                    rn.enable_graph(pipelined=pipelined)
+                    rn.step()
+                    rn.step()       # (the pipelined graph's first step runs eagerly: nothing is pending yet)
+            torch.cuda.synchronize()
+            rs.append(rn)
+            sts.append(st)
+        return rs, sts
+
+    def timed(rs, sts, steps):
+        """EXACTLY `steps` steps (one frame of every sequence each) between barrier + synchronize; (frames, seconds) over
+        all ranks: total frames, max-over-ranks time."""
+        sdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if len(rs) == 1:
+                rs[0].step()
+            else:
+                for rn, st in zip(rs, sts):
+                    with torch.cuda.stream(st):
+                        rn.step()
+        # (the blocking synchronize sleeps on an interrupt; on hosts that deliver it late -- wake-ups quantised to 100 ms were
+        # measured here -- the clock would include up to a tick of idle time: poll the streams' events first)
+        ops.spin_sync(sts)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        sdist.barrier()
+        return sdist.reduce_counters(steps * len(rs), elapsed, device=dev)
+
+    pipelined = args.pipeline == 'on' or (args.pipeline == 'auto' and nseq == 1)
+    runners, streams = make_runners(nseq, pipelined, 1234)
+    runner = runners[0]
+    frames_cpu, m0_cpu = clip_box[123 + rank * 16]
+    sd = sd_box[0]
+    if args.save_plans and rank == 0:
+        book.save(args.save_plans)
+    hist = book.math_histogram()
 
     # ---------------- timed region: exactly K steps between barrier + synchronize
-    sdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_all()
-    # (the blocking synchronize sleeps on an interrupt; on hosts that deliver it late -- wake-ups quantised to 100 ms were
-    # measured here -- the clock would include up to a tick of idle time: poll the streams' events first)
-    ops.spin_sync(streams)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    sdist.barrier()
-    total_frames, max_t = sdist.reduce_counters(args.steps * nseq, elapsed, device=dev)
+    total_frames, max_t = timed(runners, streams, args.steps)
+
+    def launch_text(pipe_):
+        return 'eager' if args.no_graph else ('hipGraph replay of the steady-state frame' + (
+            ', software-pipelined (previous frame\'s memorize under this frame\'s key encoder)' if pipe_ else ''))
 
     out = None
     if rank == 0:
@@ -254,17 +308,55 @@ def main():
             'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': ranks, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * max_t / args.steps, 3), 'ms_per_frame': round(1e3 * max_t / total_frames * world, 3),
             'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None,
+            # what the arithmetic IS (not a precision claim): storage and accumulation are fp32 everywhere, the convolutions'
+            # operands are what the plans say -- the mode that holds most layer shapes names the line, `dtype_detail` has all
+            'dtype': ('f32 storage + accumulate; conv operands bf16x3 (hi+mid bf16 planes = 16 significant bits, 3 MFMA products)'
+                      if hist['bf16x3'] >= max(hist['bf16x6'], 1) else
+                      'f32 storage + accumulate; conv operands bf16x6 (exact 3-way bf16 split = 24 significant bits, 6 MFMA products)'
+                      if hist['bf16x6'] else 'f32 (fp32 MFMA)'),
+            'dtype_detail': {'conv_layer_shapes_by_math': hist, 'em_and_affinity': 'fp32 MFMA',
+                             'matching_readout': 'bf16x3' if any((v >> 16) & 3 == 3 for v in book.match.values()) else 'fp32 MFMA',
+                             'fp32_level_leg': 'fp32_level (conv tuner restricted to fp32 MFMA / bf16x6)'},
+            'data': 'synthetic',
             'config': {'workload': 'DAVIS17-val-shaped synthetic 480x864 clip (out 480x854), ResNet-50 key encoder, '
                                    'K=256, 5 EM iters, %d objects, memorise every frame, %d sequence(s) per GPU' % (n_obj, nseq),
                        'objects': n_obj, 'frames_per_step': nseq, 'sequences_per_gpu': nseq, 'parallelism': 'seq-sharded x%d (no collective)' % world,
                        'weights': 'random init of the reference architecture (seeded)',
-                       'launch': 'eager' if args.no_graph else ('hipGraph replay of the steady-state frame' + (
-                           ', software-pipelined (previous frame\'s memorize under this frame\'s key encoder)'
-                           if (args.pipeline == 'on' or (args.pipeline == 'auto' and nseq == 1)) else ''))},
+                       'launch': launch_text(pipelined)},
             'fps_per_gpu': round(fps / world, 3),
             'frame_algorithmic_tflops': round(algorithmic_flops_per_frame(n_obj) * fps / world / 1e12, 2),
+            'plans': {'conv_layer_shapes_by_math': hist, 'digest': book.digest(),
+                      'source': args.load_plans or ('on-device tuner during warm-up' if tune else 'built-in heuristic (fp32 MFMA)'),
+                      'math_modes_allowed': list(ops.CONV_MATH_MODES)},
         }
+
+    # ---------------- the same workload in the reference's own FPS semantics (one sequence at a time,
+    # basic_evaluator.py:171-176) and at fp32-level conv arithmetic (fp32 MFMA / bf16x6 only), same steps, same clock
+    if not args.no_legs and world == 1:
+        if nseq != 1 and not args.no_graph:
+            r1, s1 = make_runners(1, args.pipeline != 'off', 2234)
+            f1, t1 = timed(r1, s1, args.steps)
+            if rank == 0:
+                out['single_sequence_fps'] = round(f1 / t1, 3)
+                out['single_sequence'] = {'value': round(f1 / t1, 3), 'unit': 'frames/s', 'ms_per_frame': round(1e3 * t1 / f1 * world, 3),
+                                          'steps': args.steps, 'sequences_per_gpu': 1, 'launch': launch_text(args.pipeline != 'off'),
+                                          'plans_digest': book.digest()}
+            del r1, s1
+        with ops.conv_math((0, 1)):
+            r32, s32 = make_runners(nseq, pipelined, 3234)
+            f32_, t32 = timed(r32, s32, args.steps)
+        if rank == 0:
+            h32 = {'fp32': 0, 'bf16x6': 0}
+            for k_, v_ in book.conv.items():
+                if k_[-3:] == ('math', 0, 1):
+                    h32['bf16x6' if (v_ >> 16) & 3 == 1 else 'fp32'] += 1
+            out['fp32_level'] = {'value': round(f32_ / t32, 3), 'unit': 'frames/s', 'ms_per_frame': round(1e3 * t32 / f32_ * world, 3),
+                                 'steps': args.steps, 'sequences_per_gpu': nseq, 'conv_layer_shapes_by_math': h32,
+                                 'note': 'the same workload with the conv tuner restricted to fp32 MFMA and bf16x6 (both '
+                                         'operands split exactly into three bf16 terms: fp32-level error), ops.conv_math((0, 1))'}
+        del r32, s32
+        torch.cuda.empty_cache()
 
     if world == 1:
         # ---------------- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream
@@ -419,8 +511,7 @@ def main():
                     'HIP-event durations on the launch stream (the queue held full behind a spin kernel: the intervals are '
                     'GPU time between back-to-back packets, not host enqueue time); the timed region above is graph replay of %d sequence(s) on %d '
                     'stream(s), whose kernels overlap -- `whole_frame` prices THAT' % (nprof, nseq, nseq),
-            'plans_bf16x6': sum(1 for v in ops._CONV_PLANS.values() if (v >> 16) & 3 == 1),
-            'plans_bf16x3': sum(1 for v in ops._CONV_PLANS.values() if (v >> 16) & 3 == 3), 'plans_total': len(ops._CONV_PLANS)}
+            'plans_bf16x6': hist['bf16x6'], 'plans_bf16x3': hist['bf16x3'], 'plans_total': sum(hist.values())}
         # whole frame of the TIMED configuration against the blended ceiling: every FLOP priced at its pipe's peak
         conv_fl = {k: d['flops'] / nprof for k, d in pipes.items()}
         em_fl = em_flops_per_frame(n_obj)

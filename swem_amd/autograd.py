@@ -29,14 +29,14 @@ def new_step(prebuild=False):
     _PACKS.clear()
     if prebuild:
         for key, build in _RECIPES.items():
-            _PACKS[key] = build()
+            _PACKS[key] = _keyed(build(), key)
 
 
 def reset():
     """Forget the recorded packs (a new trainer / model)."""
     _PACKS.clear()
     _RECIPES.clear()
-    ops.SPLIT_HINTS.clear()
+    ops.BOOK.hints.clear()
 
 
 def ensure_grads(params):
@@ -90,6 +90,14 @@ def sum_batch(x, out=None, accumulate=False):
 
 
 # --------------------------------------------------------------------------------------------- convolution
+def _keyed(pk, key):
+    """Filters are re-packed every step; the layer's name in the fused-split hints (ops.PlanBook.hints) must not change
+    with them: it is the pack's recipe key (the parameter's identity + role), the same for every step and every lane."""
+    if isinstance(pk, ops.ConvPack):
+        pk.site_key = ('train',) + tuple(key)
+    return pk
+
+
 def _shared_pack(key, build):
     """The step's shared pack if new_step(prebuild=True) made it, else this lane's own (and remember how to build it)."""
     pk = _PACKS.get(key)
@@ -97,7 +105,7 @@ def _shared_pack(key, build):
         _RECIPES.setdefault(key, build)
         pk = _PACKS.get(key + (_LANE,))
         if pk is None:
-            pk = _PACKS[key + (_LANE,)] = build()
+            pk = _PACKS[key + (_LANE,)] = _keyed(build(), key)
     return pk
 
 
@@ -257,7 +265,7 @@ def _planes_for(site, t, M, Cc):
     """The bf16 planes of a stage's output, written by the stage itself when an earlier step saw a convolution split this
     output (ops.SPLIT_HINTS): attached to the tensor where ops.presplit looks for them.  Otherwise the tensor is tagged
     with its producer so that a later split records the hint."""
-    if Cc % 8 == 0 and site in ops.SPLIT_HINTS:
+    if Cc % 8 == 0 and ops.BOOK.hints.get(site, {}).get(False):
         planes = torch.empty((3, M * Cc), dtype=torch.bfloat16, device=t.device)
         t.__dict__['_swem_split'] = {False: (planes, 3)}
         return planes

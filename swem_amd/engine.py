@@ -80,6 +80,10 @@ class Engine:
         self.device = dev
         self.single_obj = model.single_object
         ke, ve, dec = model.key_encoder, model.value_encoder, model.decoder
+        with ops.pack_keys('engine'):       # layer names for the model's PlanBook: the same for every re-built Engine
+            self._pack_all(model, ke, ve, dec)
+
+    def _pack_all(self, model, ke, ve, dec):
         # --- key encoder (networks.py:132-170)
         self.k_mean, self.k_std = ops._f3(ke.mean), ops._f3(ke.std)
         self.k_stem = ops.pack_conv(ke.conv1.weight, None, _bn(ke.bn1), 2, 3, cin_pad=4)

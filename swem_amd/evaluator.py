@@ -416,6 +416,8 @@ class SequencePool:
     def __init__(self, models, use_graph=True):
         self.models = list(models)
         n = len(self.models)
+        for m in self.models[1:]:            # the lanes run the same layers on the same shapes: one PlanBook for all of them
+            m.book = self.models[0].book
         self.streams = overlapping_streams(n) if n > 1 else [torch.cuda.current_stream()]
         self.graphs = [None] * n
         self.graph_streams = [None] * n      # per lane: (warm-up stream, capture stream), reused by every re-capture
@@ -427,6 +429,9 @@ class SequencePool:
         right before its memory is initialised (reproducible random bases whatever the interleaving)."""
         todo = list(enumerate(sequences))
         results = [None] * len(sequences)
+        for g in self.graphs:                # a graph is bound to ONE sequence of ONE run() call: never to an index that a
+            if g is not None:                # later call re-uses (it would replay on the previous sequence's banks)
+                g._bound_to = None
         lanes = [None] * len(self.models)          # per lane: [seq index, frames, out_size, next frame, preds]
         main = torch.cuda.current_stream()
         for st in self.streams:
@@ -452,7 +457,7 @@ class SequencePool:
                         bound = False
                         if self.use_graph and i >= 2:
                             if g is not None and g.frame.shape == frames[:, i].shape and g.out_size == out_size:
-                                bound = getattr(g, '_bound_to', None) == si or g.rebind()
+                                bound = getattr(g, '_bound_to', None) is lanes[li] or g.rebind()
                             if not bound and model.swem_core.memories['update'].bases is not None:
                                 self.graphs[li] = None        # the replaced graph (and its private pool) goes first
                                 # one lane: the frame software-pipelined (+12 % frames/s); several lanes already fill the
@@ -463,7 +468,7 @@ class SequencePool:
                                 self.graphs[li], self.graph_streams[li] = g, g.streams
                                 bound = True
                             if bound:
-                                g._bound_to = si
+                                g._bound_to = lanes[li]        # (the lane record of this sequence: unique per sequence)
                         if bound:
                             preds.append(g.run(frames[:, i]).clone())
                         else:

@@ -23,7 +23,113 @@ AUTOTUNE = False
 # conv epilogues write the bf16 planes of outputs that later convolutions consume pre-split (learned per layer on the first
 # frames: SPLIT_HINTS) instead of a separate split launch per consumer tensor
 FUSE_SPLIT = True
-_CONV_PLANS = {}      # layer signature + input shape -> plan hint (shared by every model instance in the process)
+
+
+class PlanBook:
+    """What a model LEARNS about its own launches: the tuned conv plans (layer signature + input shape -> plan hint), the
+    tuned readout plans of matching, and the fused-split hints (producer site -> planes its consumers asked for).  Every
+    `SWEM` owns one (`model.book`) and makes it the current one for the duration of a `model(mode, ...)` call; models that
+    run the same layers on the same shapes -- the lanes of a `SequencePool` -- share one.  Nothing learned under one model
+    reaches another: the arithmetic a conv runs (plan bits 16-17: 0 fp32 MFMA, 1 bf16x6, 2 plain bf16, 3 bf16x3) is a
+    property of the model under test, never of what ran earlier in the process.  Free-standing `ops.*` calls use the
+    process-wide default book (`ops.reset_plans()` empties it)."""
+
+    def __init__(self):
+        self.conv, self.match, self.hints = {}, {}, {}
+
+    def clear(self):
+        self.conv.clear()
+        self.match.clear()
+        self.hints.clear()
+
+    def math_histogram(self):
+        """{'fp32': n, 'bf16x6': n, 'bf16': n, 'bf16x3': n} over the conv plans (a plan of 0 is the fp32 heuristic)."""
+        names = ('fp32', 'bf16x6', 'bf16', 'bf16x3')
+        out = {n: 0 for n in names}
+        for v in self.conv.values():
+            out[names[(v >> 16) & 3]] += 1
+        return out
+
+    def digest(self):
+        """Short hash of the plans (which arithmetic and tiling a run used: printed by bench.py, recorded by the tests)."""
+        import hashlib
+        txt = repr(sorted((tuple(k), v) for k, v in self.conv.items())) + repr(sorted(self.match.items()))
+        return hashlib.sha1(txt.encode()).hexdigest()[:12]
+
+    def save(self, path):
+        import json
+        with open(path, 'w') as f:
+            json.dump({'conv': [[list(k), v] for k, v in self.conv.items()],
+                       'match': [[list(k), v] for k, v in self.match.items()]}, f)
+
+    def load(self, path):
+        import json
+        with open(path) as f:
+            d = json.load(f)
+        self.conv.update({tuple(k): v for k, v in d.get('conv', [])})
+        self.match.update({tuple(k): v for k, v in d.get('match', [])})
+        return self
+
+
+BOOK = PlanBook()     # the current book (the default one until a model makes its own current: use_book)
+MATH_RAN = None       # tests / bench set this to a dict: plan math field of every conv LAUNCH (what really ran) -> count
+
+
+class use_book:
+    """Context: make `book` the current PlanBook (SWEM.forward, SWEMTrainer.one_step)."""
+
+    def __init__(self, book):
+        self.book = book
+
+    def __enter__(self):
+        global BOOK
+        self.saved, BOOK = BOOK, self.book
+        return self.book
+
+    def __exit__(self, *a):
+        global BOOK
+        BOOK = self.saved
+
+
+def reset_plans():
+    """Forget everything the CURRENT book learned (tests: before every test)."""
+    BOOK.clear()
+
+
+def __getattr__(name):
+    # the current book's tables under their round-1/2 names (tools and tests poke them directly)
+    if name == '_CONV_PLANS':
+        return BOOK.conv
+    if name == '_MATCH_PLANS':
+        return BOOK.match
+    if name == 'SPLIT_HINTS':
+        return BOOK.hints
+    raise AttributeError(name)
+
+
+_PACK_KEY = [('pack',), 0]
+
+
+class pack_keys:
+    """Context: ConvPacks built inside get the site keys (prefix, 1), (prefix, 2), ... in construction order, so that a
+    re-built Engine of the same model finds the hints its predecessor's layers left in the model's book."""
+
+    def __init__(self, *prefix):
+        self.prefix = tuple(prefix)
+
+    def __enter__(self):
+        self.saved = list(_PACK_KEY)
+        _PACK_KEY[0], _PACK_KEY[1] = self.prefix, 0
+
+    def __exit__(self, *a):
+        if self.saved[0] == ('pack',):
+            self.saved[1] = max(self.saved[1], 0)
+        _PACK_KEY[0], _PACK_KEY[1] = self.saved
+
+
+def _next_pack_key():
+    _PACK_KEY[1] += 1
+    return _PACK_KEY[0] + (_PACK_KEY[1],)
 # math modes the conv tuner may choose from: 0 = fp32 MFMA, 1 = bf16x6 (exact 3-way bf16 split, six products: fp32-level
 # error), 3 = bf16x3 (hi + mid planes, the three products above 2^-16: 16 significant bits per operand, half the MFMA work
 # of bf16x6; the per-stage 1e-4 and per-frame 1e-3 parity bars are asserted with it enabled)
@@ -139,6 +245,9 @@ class ConvPack:
         self.cout, self.kh, self.kw, self.stride, self.pad, self.glu = cout, kh, kw, stride, pad, glu
         self.cin = w.shape[-1]
         self.cin_true = self.cin          # channels of the reference conv (without layout padding)
+        # names this layer in the fused-split hints (PlanBook.hints); unique per process unless built under pack_keys (never
+        # id(self): a recycled address would inherit a dead layer's hints)
+        self.site_key = _next_pack_key()
         co, kk = w.shape[0], w.shape[1] * w.shape[2] * w.shape[3]
         # the same filters as three bf16 planes, k/8-group major [K/8][Cout'][8] (bf16x6 math mode, pre-split form)
         # (the activation split kernel on the [Cout'][K] matrix: one launch; the training step re-packs every step)
@@ -213,7 +322,7 @@ def presplit(t, relu=False, nplanes=3):
     ent = cache.get(relu)
     site = t.__dict__.get('_swem_site')
     if site is not None:
-        h = SPLIT_HINTS.setdefault(site, {})
+        h = BOOK.hints.setdefault(site, {})
         if h.get(relu, 0) < nplanes:
             h[relu] = nplanes              # the producer of this tensor can write the planes itself next time
     if ent is None or ent[1] < nplanes:
@@ -277,8 +386,8 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
 
     # the output's own bf16 planes, if the convolutions that consumed this layer's output on an earlier frame split it:
     # the epilogue writes them (fused operand split: no split launch, no re-read of y)
-    site = ('conv', id(pack), B, H, W, flags)
-    want = SPLIT_HINTS.get(site) if (FUSE_SPLIT and dgrad is None and not pack.glu and pack.cout % 8 == 0) else None
+    site = ('conv', pack.site_key, B, H, W, flags)
+    want = BOOK.hints.get(site) if (FUSE_SPLIT and dgrad is None and not pack.glu and pack.cout % 8 == 0) else None
     planes = {}
 
     def launch(plan, fresh=False):
@@ -316,16 +425,21 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
 
     sig = (cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags, B, H, W) + _PLAN_TAG
     explicit = plan is not None
-    plan = plan if explicit else _CONV_PLANS.get(sig, 0)
+    plan = plan if explicit else BOOK.conv.get(sig, 0)
     if plan == 0 and len(_PLAN_TAG) == 2 and not AUTOTUNE:
         plan = _PLAN_TAG[1] << 16                  # conv_math((m,)) without tuning: the heuristic tile in math mode m
     if AUTOTUNE and not explicit and plan == 0 and not torch.cuda.is_current_stream_capturing():
-        plan = _CONV_PLANS[sig] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
+        plan = BOOK.conv[sig] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
                                             -(-pack.kh * pack.kw * cin // 32), pack.glu, fresh_kw=True)
     if CONV_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     launch(plan)
+    if MATH_RAN is not None:
+        m_ = (plan >> 16) & 3
+        if not presplit_ok:                # (what the library runs on the fp32 entry point: conv.hip, `emulate`)
+            m_ = 1 if (m_ & 1 and pipe_ok) else 0
+        MATH_RAN[m_] = MATH_RAN.get(m_, 0) + 1
     if out is None:
         y.__dict__['_swem_site'] = site
         if planes:
@@ -346,8 +460,6 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
 
 
 _PLAN_TAG = ()
-# producer site -> {relu variant: planes wanted}: outputs that were later split; the producer writes the planes itself
-SPLIT_HINTS = {}
 
 
 class conv_math:
@@ -372,20 +484,13 @@ def AUTOTUNE_PENDING():
     return bool(AUTOTUNE)
 
 
-def save_plans(path):
-    """Persist the tuned plans (profiling runs reload them instead of re-tuning under the profiler)."""
-    import json
-    with open(path, 'w') as f:
-        json.dump({'conv': [[list(k), v] for k, v in _CONV_PLANS.items()],
-                   'match': [[list(k), v] for k, v in _MATCH_PLANS.items()]}, f)
+def save_plans(path, book=None):
+    """Persist the tuned plans of `book` (default: the current one; profiling runs reload them instead of re-tuning)."""
+    (book or BOOK).save(path)
 
 
-def load_plans(path):
-    import json
-    with open(path) as f:
-        d = json.load(f)
-    _CONV_PLANS.update({tuple(k): v for k, v in d.get('conv', [])})
-    _MATCH_PLANS.update({tuple(k): v for k, v in d.get('match', [])})
+def load_plans(path, book=None):
+    return (book or BOOK).load(path)
 
 
 def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
@@ -528,7 +633,7 @@ def maxpool(x):
 def _fused_planes(site, numel, device):
     """(planes dict {relu: (tensor, nplanes)}, C-ABI argument list) for a producer at `site` whose consumers split its output
     on an earlier frame (SPLIT_HINTS): the producer writes the planes itself."""
-    want = SPLIT_HINTS.get(site) if FUSE_SPLIT else None
+    want = BOOK.hints.get(site) if FUSE_SPLIT else None
     planes, pargs = {}, [0, 3, 0, 3]
     if want:
         for relu_v, npl in want.items():
@@ -766,7 +871,14 @@ def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau, pack=None, pri
     return kappa, nu, zita
 
 
-_MATCH_PLANS = {}
+def _match_plan(key, launch, M, V, nkb):
+    """Readout plan of matching: the book's, else under conv_math((m,)) the heuristic tile in math mode m, else tuned."""
+    plan = BOOK.match.get(key + _PLAN_TAG, 0)
+    if plan == 0 and len(_PLAN_TAG) == 2 and not AUTOTUNE:
+        plan = _PLAN_TAG[1] << 16
+    if AUTOTUNE and plan == 0 and not torch.cuda.is_current_stream_capturing():
+        plan = BOOK.match[key + _PLAN_TAG] = _autotune(launch, M, V, nkb, False)
+    return plan
 
 
 def match(qk, kappa_first, nu_first, kappa_update, nu_update, topl, tau):
@@ -793,11 +905,7 @@ def match(qk, kappa_first, nu_first, kappa_update, nu_update, topl, tau):
                   _ptr(kappa_update), _ptr(nu_update), mem_out.data_ptr(), S.data_ptr(), N, Cc, V, P, L, int(topl),
                   float(tau), plan, ws.data_ptr(), wsb)
 
-    key = (N, Cc, V, P, L, nb)
-    plan = _MATCH_PLANS.get(key, 0)
-    if AUTOTUNE and plan == 0 and not torch.cuda.is_current_stream_capturing():
-        plan = _MATCH_PLANS[key] = _autotune(launch, N * Pm, V, 2 * nb * L // 32, False)
-    launch(plan)
+    launch(_match_plan((N, Cc, V, P, L, nb), launch, N * Pm, V, 2 * nb * L // 32))
     return mem_out[:, :P], S
 
 
@@ -843,9 +951,5 @@ def match_packed(qk, pack, L, topl, tau):
         _lib.call('swem_match_packed_f32', _stream(), qk.data_ptr(), mkn.data_ptr(), mvp.data_ptr(), _pack_planes(pack),
                   mem_out.data_ptr(), S.data_ptr(), N, Cc, V, P, L, int(topl), float(tau), plan, ws.data_ptr(), wsb)
 
-    key = (N, Cc, V, P, L, 2)
-    plan = _MATCH_PLANS.get(key, 0)
-    if AUTOTUNE and plan == 0 and not torch.cuda.is_current_stream_capturing():
-        plan = _MATCH_PLANS[key] = _autotune(launch, N * Pm, V, 4 * L // 32, False)
-    launch(plan)
+    launch(_match_plan((N, Cc, V, P, L, 2), launch, N * Pm, V, 4 * L // 32))
     return mem_out[:, :P], S

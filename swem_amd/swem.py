@@ -36,6 +36,9 @@ class SWEM(nn.Module):
         self.decoder = Decoder([valdim, nf[1], nf[2]], 256)
         self._eng = None
         self.swem_core._engine = self.engine
+        # tuned plans and fused-split hints of THIS model (ops.PlanBook); current for the duration of every forward() call.
+        # Models that run the same layers on the same shapes may share one (evaluator.SequencePool does): m.book = other.book
+        self.book = ops.PlanBook()
 
     # -- packed-weight cache: rebuilt after load_state_dict / .to() / .cuda()
     def engine(self):
@@ -90,6 +93,10 @@ class SWEM(nn.Module):
         return logits, pred_mask
 
     def forward(self, mode, *args, **kwargs):
+        with ops.use_book(self.book):
+            return self._dispatch(mode, *args, **kwargs)
+
+    def _dispatch(self, mode, *args, **kwargs):
         if mode == 'encode_key':
             return self.encode_key(*args, **kwargs)
         elif mode == 'encode_value':

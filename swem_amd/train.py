@@ -178,6 +178,9 @@ class SWEMTrainer:
             if mod.__class__.__name__.find('BatchNorm') != -1:
                 mod.eval()
         A.reset()
+        # what the step learns about its launches (tuned conv plans, fused-split hints) is the trainer's own: the model's
+        # inference book (validation between steps) and other trainers in the process never see it
+        self.book = ops.PlanBook()
         self.optimizer = optim.make_optimizer(_get(config, 'SOLVER'), model, num_gpu)
         # DistributedDataParallel's constructor broadcasts rank 0's parameters AND buffers (swem_trainer.py:41-43;
         # broadcast_buffers=False only stops the per-iteration re-broadcast): without it rank-local initialisation
@@ -437,7 +440,11 @@ class SWEMTrainer:
     def _math(self):
         """Conv math modes of the step: config.AMP = plain bf16 operands; otherwise the fp32-level modes only (fp32 MFMA and
         bf16x6) -- the 16-bit-operand bf16x3 mode the inference tuner may pick is kept out of the gradient path."""
-        return ops.conv_math((2,)) if self.amp else ops.conv_math((0, 1))
+        import contextlib
+        st = contextlib.ExitStack()
+        st.enter_context(ops.use_book(self.book))
+        st.enter_context(ops.conv_math((2,)) if self.amp else ops.conv_math((0, 1)))
+        return st
 
     def _capture(self, cur_iter):
         """One HIP graph per part: `_pre` and `_post` on the main stream, one graph per lane on the lane's own (probed)

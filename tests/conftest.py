@@ -31,3 +31,18 @@ def lib():
     from swem_amd import build, _lib
     build.build()
     return _lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _fresh_plans():
+    """Every test starts from an empty default PlanBook, the tuner off and no forced conv math: the arithmetic a test runs is
+    what the test itself selects (tests/helpers.py::arith), never what an earlier test left behind.  (Models own their books,
+    ops.PlanBook; this covers the free-standing ops.* calls.)"""
+    from swem_amd import ops
+    ops.reset_plans()
+    ops.AUTOTUNE = False
+    ops.MATH_RAN = None
+    assert ops._PLAN_TAG == (), 'a conv_math context leaked out of a test'
+    yield
+    ops.AUTOTUNE = False
+    ops.MATH_RAN = None

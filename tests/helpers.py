@@ -28,12 +28,73 @@ def clip_from_fixture(fx):
     return frames, m0
 
 
+ROUND = 'r03'
+ARITH_MODES = ('fp32', 'bf16x3', 'tuned')
+
+
+def tuned_plans_path():
+    """The newest committed plan file of the bench configuration (profiles/rNN_tuned_plans.json)."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'r[0-9][0-9]_tuned_plans.json')))
+    return files[-1] if files else None
+
+
+class arith:
+    """Context: the conv arithmetic a parity test runs, selected EXPLICITLY and checked afterwards.
+      'fp32'   -- no plans, no forced math: every GEMM on the fp32 MFMA (plan 0).
+      'bf16x3' -- ops.conv_math((3,)): every convolution the pre-split kernel can take AND matching's value readout run on
+                  the hi + mid bf16 planes (16 significant bits per operand, three products), the heuristic tile.
+      'tuned'  -- the bench's plans (profiles/rNN_tuned_plans.json) loaded into the model's book: the mix of tiles, K-splits
+                  and math modes the tuner chose at config B (other shapes find no plan and run fp32).
+    `ran` = {math field: conv launches} of what really ran; leaving the context asserts it matches the mode."""
+
+    def __init__(self, mode, *models, need_bf16x3=True):
+        from swem_amd import ops
+        self.ops, self.mode, self.models, self.need = ops, mode, models, need_bf16x3
+        self.ran, self.cm = {}, None
+
+    def __enter__(self):
+        ops = self.ops
+        assert self.mode in ARITH_MODES and ops.MATH_RAN is None
+        if self.mode == 'bf16x3':
+            self.cm = ops.conv_math((3,))
+            self.cm.__enter__()
+        elif self.mode == 'tuned':
+            path = tuned_plans_path()
+            assert path, 'no profiles/rNN_tuned_plans.json'
+            for m in self.models:              # models, or PlanBooks
+                getattr(m, 'book', m).load(path)
+        ops.MATH_RAN = self.ran
+        return self
+
+    def __exit__(self, et, ev, tb):
+        self.ops.MATH_RAN = None
+        if self.cm is not None:
+            self.cm.__exit__(et, ev, tb)
+        if et is None:
+            total = sum(self.ran.values())
+            assert total > 0, 'no conv launch was counted'
+            if self.mode == 'fp32':
+                assert set(self.ran) == {0}, self.ran
+            elif self.mode == 'bf16x3':
+                # everything but the layers the pre-split kernel cannot take (7x7 stems on 4 / 8 channels, 1-channel heads)
+                assert self.ran.get(3, 0) >= 0.85 * total and not self.ran.get(1) and not self.ran.get(2), self.ran
+            elif self.need:
+                assert self.ran.get(3, 0) > 0, self.ran
+        return False
+
+    def summary(self):
+        names = {0: 'fp32', 1: 'bf16x6', 2: 'bf16', 3: 'bf16x3'}
+        return {names[k]: v for k, v in sorted(self.ran.items())}
+
+
 def record_parity(key, data):
-    """Measured parity numbers of the GPU run -> gpurun_out/r02_parity.json (merged key by key; copied to
-    profiles/r02_parity.json and committed from the round's own GPU run).  Never fails a test."""
+    """Measured parity numbers of the GPU run -> gpurun_out/rNN_parity.json (merged key by key; copied to
+    profiles/rNN_parity.json and committed from the round's own GPU run).  Never fails a test."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'r02_parity.json')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', ROUND + '_parity.json')
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         cur = {}

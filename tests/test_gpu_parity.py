@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from oracle import swem_oracle as O
 from swem_amd import evaluator, ops
 from tests import helpers as H
-from tests.test_gpu_model import CFG_B, DEV, logit_bound, logits_close, relmax
+from tests.test_gpu_model import CFG_B, DEV, logit_bound, logits_close, probs_close, relmax
 
 pytestmark = pytest.mark.gpu
 REORDER_DRAWS = 6      # fp32 evaluations of the reference's memorize with permuted key channels (the EM's noise yardstick)
@@ -28,56 +28,42 @@ def _mass_err(got, ref, zita):
     return float(((got.cpu() - ref) * z).abs().max() / (ref * z).abs().max())
 
 
-def teacher_forced_clip(model, om, frames, m0, out, fixture=None, seed=77, tol=1e-3):
-    """Runs the ORACLE free (it is the reference, bit for bit, where the fixtures were made) and, frame by frame, the HIP
-    model from the oracle's memory: banks injected before the frame, then encode_key -> match -> segment on the HIP side
-    (logits, index map) and memorize from the oracle's inputs (bases).  Returns one dict of measured errors per frame and
-    asserts the north star's bars: logits within `tol` (+ the ulp slack of logit_bound), index maps >= 0.9995."""
+_TRAJ = {}
+
+
+def oracle_trajectory(key, om, frames, m0, out, fixture=None, seed=77):
+    """The ORACLE side of a teacher-forced clip, computed once per clip and shared by the arithmetic modes the test is
+    parametrised over: the oracle runs free (it is the reference, bit for bit, where the fixtures were made); per frame the
+    memory it matched against, its encoder / match / segment outputs, and for every memorize the inputs, its own result, the
+    float64 result from the same fp32 inputs and REORDER_DRAWS re-ordered fp32 evaluations (the EM's noise yardstick)."""
+    if key in _TRAJ:
+        return _TRAJ[key]
     t, (h, w) = frames.shape[1], frames.shape[-2:]
-    core = model.swem_core
-    rows = []
+    steps = []
     with torch.no_grad():
         torch.manual_seed(seed)
         mk16, _, s16, _, _ = om('encode_key', frames[:, 0])
         mfull = F.interpolate(m0, size=(h, w), mode='nearest')
         om('init', mk16, om('encode_value', frames[:, 0], mfull.float(), s16), m0)
         for i in range(1, t):
-            core.memories['first'].bases = _to_dev(om.core.first.bases)
-            core.memories['first'].n_objs = om.core.first.n_objs
-            core.memories['update'].bases = _to_dev(om.core.upd.bases)
+            st = {'frame': i, 'first': {k: v.clone() for k, v in om.core.first.bases.items()}, 'first_n': om.core.first.n_objs,
+                  'upd': None if om.core.upd.bases is None else {k: v.clone() for k, v in om.core.upd.bases.items()}}
             oqk, oqv, os16, os8, os4 = om('encode_key', frames[:, i])
             octx, on = om('match', oqk, oqv)
             ologits, oprob = om('segment', on, octx, os8, os4, None, out)
-            row = {'frame': i}
+            st.update(oqk=oqk, oqv=oqv, os16=os16, os8=os8, os4=os4, octx=octx, on=on, ologits=ologits, oprob=oprob,
+                      opred=oprob.argmax(1))
             if fixture is not None:
                 # on another host CPU (other BLAS kernels / thread count) the oracle is a second fp32 evaluation of the same
                 # chaotic recursion: against the fixture it is only held to the reference's own fp32-vs-fp64 floor
                 d_fix = float((ologits[:, :, ::8, ::8] - fixture['logits%d' % (i - 1)]).abs().max())
                 assert d_fix <= max(1e-3, 2 * float(fixture['floor64'][i - 1])), d_fix
-                row['oracle_on_this_host_vs_fixture_dlogits'] = d_fix
-                row['reference_fp32_vs_fp64_free_running_floor'] = float(fixture['floor64'][i - 1])
-            fr = frames[:, i].to(DEV)
-            qk, qv, s16h, s8, s4 = model('encode_key', fr)
-            ctx, n = model('match', qk, qv)
-            logits, prob = model('segment', n, ctx, s8, s4, None, out)
-            pred, hard = ops.argmax_onehot(prob, want_onehot=True)
-            opred = oprob.argmax(1)
-            dl = float((logits.cpu() - ologits).abs().max())
-            excess = float(((logits.cpu().double() - ologits.double()).abs() - logit_bound(ologits, 0.0)).max())
-            agree = float((pred.cpu() == opred).float().mean())
-            ctx_s, _ = model('match', oqk.to(DEV), oqv.to(DEV))          # stage-wise: the oracle's inputs
-            lg_s, _ = model('segment', n, octx.to(DEV), os8.to(DEV), os4.to(DEV), None, out)
-            row.update({'dlogits_max': dl, 'dlogits_beyond_ulp_slack': excess, 'index_agreement': agree,
-                        'qk16_rel': relmax(qk, oqk), 'context_rel': relmax(ctx, octx),
-                        'context_rel_stage': relmax(ctx_s, octx),
-                        'dlogits_stage_max': float((lg_s.cpu() - ologits).abs().max())})
+                st['oracle_on_this_host_vs_fixture_dlogits'] = d_fix
+                st['reference_fp32_vs_fp64_free_running_floor'] = float(fixture['floor64'][i - 1])
             if i < t - 1:
                 opm = F.interpolate(oprob, size=(h, w), mode='bilinear', align_corners=False)
-                ohard = (opred.unsqueeze(1) == torch.arange(on + 1).view(1, -1, 1, 1)).long()
+                ohard = (st['opred'].unsqueeze(1) == torch.arange(on + 1).view(1, -1, 1, 1)).long()
                 omv = om('encode_value', frames[:, i], opm, os16)
-                mv = model('encode_value', fr, opm.to(DEV), os16.to(DEV))
-                row['encode_value_rel'] = relmax(mv, omv)
-                model('memorize', oqk.to(DEV), omv.to(DEV), ohard.to(DEV), opm.to(DEV))
                 # yardstick for the EM (SURVEY.md section 7.2: the W step's 1 - p cancels, rounding is amplified over the
                 # iterations): the same memorize in float64 from the same fp32 inputs; the reference's own fp32 result
                 # differs from it by `floor`, a correct fp32 implementation by about as much
@@ -85,12 +71,11 @@ def teacher_forced_clip(model, om, frames, m0, out, fixture=None, seed=77, tol=1
                 mk = O.mask_prep(ohard, opm, oqk.shape[-2], oqk.shape[-1])
                 b64 = O.swem(oqk.double(), omv.double(), mk.double(), {k: v.double() for k, v in prior.items()},
                              om.core.n_bases, om.core.n_iters, om.core.tau, om.core.valdim)
-                om('memorize', oqk, omv, ohard, opm)
-                ob, hb = om.core.upd.bases, core.memories['update'].bases
                 # how far the reference's OWN fp32 arithmetic lands from float64 is one draw of an amplified rounding error
-                # (the same frame of the five-object edge clip: 3.2e-4 on the GPU box's CPU, 2.0e-3 on the build container's).  A steadier yardstick: the same fp32 memorize under REORDER_DRAWS
-                # mathematically neutral re-orderings of its sums (the key channels permuted in x and in the prior bases
-                # alike, the result permuted back) -- the spread of the reference against itself
+                # (the same frame of the five-object edge clip: 3.2e-4 on the GPU box's CPU, 2.0e-3 on the build container's).
+                # A steadier yardstick: the same fp32 memorize under REORDER_DRAWS mathematically neutral re-orderings of
+                # its sums (the key channels permuted in x and in the prior bases alike, the result permuted back) -- the
+                # spread of the reference against itself
                 draws = {'kappa': [], 'nu': [], 'zita': []}
                 gperm = torch.Generator().manual_seed(11 * i)
                 with torch.random.fork_rng():
@@ -103,6 +88,60 @@ def teacher_forced_clip(model, om, frames, m0, out, fixture=None, seed=77, tol=1
                         draws['kappa'].append(_mass_err(bp['kappa'][..., inv, :].double(), b64['kappa'], b64['zita']))
                         draws['nu'].append(_mass_err(bp['nu'].double(), b64['nu'], b64['zita']))
                         draws['zita'].append(relmax(bp['zita'].double(), b64['zita']))
+                om('memorize', oqk, omv, ohard, opm)
+                st.update(opm=opm, ohard=ohard, omv=omv, b64=b64, draws=draws,
+                          ob={k: v.clone() for k, v in om.core.upd.bases.items()})
+            steps.append(st)
+    _TRAJ[key] = steps
+    return steps
+
+
+def teacher_forced_clip(model, steps, frames, out, tol=1e-3):
+    """Frame by frame, the HIP model from the oracle's memory: banks injected before the frame, then encode_key -> match ->
+    segment on the HIP side (logits, probabilities, index map) and memorize from the oracle's inputs (bases).  Returns one
+    dict of measured errors per frame and asserts the north star's bars: logits within `tol` (+ the ulp slack of
+    logit_bound), probabilities within half that bound (probs_close), index maps >= 0.9995."""
+    t = frames.shape[1]
+    core = model.swem_core
+    rows = []
+    with torch.no_grad():
+        for st in steps:
+            i = st['frame']
+            core.memories['first'].bases = _to_dev(st['first'])
+            core.memories['first'].n_objs = st['first_n']
+            core.memories['update'].bases = _to_dev(st['upd'])
+            oqk, oqv, os16, os8, os4, octx, on = (st[k] for k in ('oqk', 'oqv', 'os16', 'os8', 'os4', 'octx', 'on'))
+            ologits, oprob, opred = st['ologits'], st['oprob'], st['opred']
+            row = {'frame': i}
+            for k in ('oracle_on_this_host_vs_fixture_dlogits', 'reference_fp32_vs_fp64_free_running_floor'):
+                if k in st:
+                    row[k] = st[k]
+            fr = frames[:, i].to(DEV)
+            qk, qv, s16h, s8, s4 = model('encode_key', fr)
+            ctx, n = model('match', qk, qv)
+            logits, prob = model('segment', n, ctx, s8, s4, None, out)
+            pred, hard = ops.argmax_onehot(prob, want_onehot=True)
+            dl = float((logits.cpu() - ologits).abs().max())
+            excess = float(((logits.cpu().double() - ologits.double()).abs() - logit_bound(ologits, 0.0)).max())
+            agree = float((pred.cpu() == opred).float().mean())
+            ctx_s, _ = model('match', oqk.to(DEV), oqv.to(DEV))          # stage-wise: the oracle's inputs
+            lg_s, _ = model('segment', n, octx.to(DEV), os8.to(DEV), os4.to(DEV), None, out)
+            row.update({'dlogits_max': dl, 'dlogits_beyond_ulp_slack': excess, 'index_agreement': agree,
+                        'dprob_max': float((prob.cpu() - oprob).abs().max()),
+                        # softmax is 1/2-Lipschitz in the max-norm of the logits: excess over half the channel-wise logit bound
+                        # (where two objects' probabilities both sit at the 1 - 1e-7 clamp the reference's own logits are
+                        # ulp noise of +-0.05, and the softmax over them moves by +-0.01: swem.py:111-116)
+                        'dprob_beyond_bound': float(((prob.cpu().double() - oprob.double()).abs()
+                                                     - 0.5 * logit_bound(ologits, tol).max(dim=1, keepdim=True)[0]).max()),
+                        'qk16_rel': relmax(qk, oqk), 'context_rel': relmax(ctx, octx),
+                        'context_rel_stage': relmax(ctx_s, octx),
+                        'dlogits_stage_max': float((lg_s.cpu() - ologits).abs().max())})
+            if i < t - 1:
+                opm, ohard, omv, b64, draws, ob = (st[k] for k in ('opm', 'ohard', 'omv', 'b64', 'draws', 'ob'))
+                mv = model('encode_value', fr, opm.to(DEV), os16.to(DEV))
+                row['encode_value_rel'] = relmax(mv, omv)
+                model('memorize', oqk.to(DEV), omv.to(DEV), ohard.to(DEV), opm.to(DEV))
+                hb = core.memories['update'].bases
                 for name in ('kappa', 'nu'):
                     row[name + '_mass_rel'] = _mass_err(hb[name], ob[name], ob['zita'])
                     row[name + '_mass_rel_vs_fp64'] = _mass_err(hb[name].double(), b64[name], b64['zita'])
@@ -119,6 +158,8 @@ def teacher_forced_clip(model, om, frames, m0, out, fixture=None, seed=77, tol=1
             assert logits_close(lg_s, ologits, tol), 'stage logits frame %d: %.3g' % (i, row['dlogits_stage_max'])
             assert row['context_rel_stage'] < 1e-4
             assert logits_close(logits, ologits, tol), 'frame %d: |dlogits| %.3g (beyond the ulp slack: %.3g)' % (i, dl, excess)
+            assert probs_close(prob, oprob, ologits, tol), 'frame %d: |dprob| %.3g (beyond its bound: %.3g)' % (
+                i, row['dprob_max'], row['dprob_beyond_bound'])
             assert agree >= 0.9995, 'frame %d index agreement %.6f' % (i, agree)
             if i < t - 1:
                 assert row['encode_value_rel'] < 1e-4
@@ -128,18 +169,26 @@ def teacher_forced_clip(model, om, frames, m0, out, fixture=None, seed=77, tol=1
     return rows
 
 
-def test_teacher_forced_config_b_clip(lib, golden):
+@pytest.mark.parametrize('mode', H.ARITH_MODES)
+def test_teacher_forced_config_b_clip(lib, golden, mode):
+    """BASELINE configs[1] in each conv arithmetic the product can run: exact fp32 MFMA, bf16x3 FORCED on every layer, and
+    the plans the bench loads.  The bars (1e-3 logits / probabilities, 0.9995 index maps) are the same in all three."""
     fx = golden('g7_configB.npz')
     cfg = O.make_cfg(**CFG_B)
     model, sd = H.make_model_and_sd(cfg, int(fx['wseed']), device=DEV)
     frames, m0 = H.clip_from_fixture(fx)
-    rows = teacher_forced_clip(model, O.Model(sd, cfg), frames, m0, (int(fx['out_h']), int(fx['out_w'])), fixture=fx)
-    H.record_parity('teacher_forced_configB_g7', rows)
+    out = (int(fx['out_h']), int(fx['out_w']))
+    steps = oracle_trajectory('g7', O.Model(sd, cfg), frames, m0, out, fixture=fx)
+    with H.arith(mode, model) as ar:
+        rows = teacher_forced_clip(model, steps, frames, out)
+    H.record_parity('teacher_forced_configB_g7[%s]' % mode, {'conv_launches_by_math': ar.summary(),
+                                                              'plans_digest': model.book.digest(), 'frames': rows})
 
 
 @pytest.mark.parametrize('n_obj,h,w,bases,topl', [(1, 96, 160, 64, 64), (5, 112, 176, 64, 32), (3, 80, 144, 128, 64)],
                          ids=['one_object', 'five_objects_topl32', 'three_objects_k128'])
-def test_teacher_forced_edge_shapes(lib, n_obj, h, w, bases, topl):
+@pytest.mark.parametrize('mode', ('fp32', 'bf16x3'))
+def test_teacher_forced_edge_shapes(lib, n_obj, h, w, bases, topl, mode):
     """The edge cases of test_gpu_model.py::test_edge_shapes_free_running (one object; the reference's maximum of five
     with a top-l smaller than the bank; 1/16 grids that are no multiple of the pixel tile; an object with an EMPTY first
     mask) held to the tight bars, frame by frame, from the oracle's memory."""
@@ -150,14 +199,19 @@ def test_teacher_forced_edge_shapes(lib, n_obj, h, w, bases, topl):
     if n_obj >= 3:
         m0[:, 0] += m0[:, n_obj]
         m0[:, n_obj] = 0
-    rows = teacher_forced_clip(model, O.Model(sd, cfg), frames, m0, (h, w), seed=3)
-    H.record_parity('teacher_forced_edge_%dobj_k%d' % (n_obj, bases), rows)
+    steps = oracle_trajectory(('edge', n_obj, bases), O.Model(sd, cfg), frames, m0, (h, w), seed=3)
+    with H.arith(mode, model) as ar:
+        rows = teacher_forced_clip(model, steps, frames, (h, w))
+    H.record_parity('teacher_forced_edge_%dobj_k%d[%s]' % (n_obj, bases, mode), {'conv_launches_by_math': ar.summary(),
+                                                                                 'frames': rows})
 
 
-def test_config_e_long_video(lib, golden):
+@pytest.mark.parametrize('mode', H.ARITH_MODES)
+def test_config_e_long_video(lib, golden, mode):
     """BASELINE config E: >= 1000 frames at 480x864, the memory re-estimated on EVERY frame (sequential base merging),
     one sequence.  The state never grows (allocation constant from the captured frame on), stays finite, the labels stay
-    alive, and the first three index maps are those of the 4-frame config-B clip (g7) evaluated by the plain loop."""
+    alive, and the first three index maps are those of the 4-frame config-B clip (g7) evaluated by the plain loop -- in each
+    conv arithmetic (helpers.arith)."""
     import time
     from swem_amd import synth
     fx = golden('g7_configB.npz')
@@ -167,12 +221,12 @@ def test_config_e_long_video(lib, golden):
     short, m0s = H.clip_from_fixture(fx)
     assert torch.equal(frames[:, :short.shape[1]], short) and torch.equal(m0, m0s)
     frames, m0 = frames.to(DEV), m0.to(DEV)
-    with torch.no_grad():
-        model, _ = H.make_model_and_sd(cfg, int(fx['wseed']), device=DEV)
+    model0, _ = H.make_model_and_sd(cfg, int(fx['wseed']), device=DEV)
+    model, _ = H.make_model_and_sd(cfg, int(fx['wseed']), device=DEV)
+    with torch.no_grad(), H.arith(mode, model0, model) as ar:
         torch.manual_seed(77)
-        ref, _ = evaluator.evaluate_davis_seq(model, frames[:, :4], [m0, None, None, None], out)
+        ref, _ = evaluator.evaluate_davis_seq(model0, frames[:, :4], [m0, None, None, None], out)
         ref = [p.clone() for p in ref]
-        model, _ = H.make_model_and_sd(cfg, int(fx['wseed']), device=DEV)
         torch.manual_seed(77)
         h, w = frames.shape[-2:]
         mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
@@ -197,6 +251,8 @@ def test_config_e_long_video(lib, golden):
     assert float(mem['update'].bases['zita'].sum()) > 0
     labels = sorted(int(v) for v in torch.unique(pred).tolist())
     assert labels == list(range(n_obj + 1)), labels
-    H.record_parity('config_e_long_video', {'frames': total, 'frames_per_s_graph_replay_default_plans': (total - 4) / dt,
-                                             'allocated_bytes': mem1, 'labels_last_frame': labels,
-                                             'first_three_index_maps_equal_plain_loop': True})
+    H.record_parity('config_e_long_video[%s]' % mode,
+                    {'frames': total, 'frames_per_s_graph_replay': (total - 4) / dt, 'conv_launches_by_math': ar.summary(),
+                     'plans_digest': model.book.digest(), 'allocated_bytes': mem1, 'labels_last_frame': labels,
+                     'first_three_index_maps_equal_plain_loop': True,
+                     'note': 'plain (not software-pipelined) frame graph, one sequence, first replays included'})

@@ -53,13 +53,13 @@ def main():
     sd['decoder.pred.weight'] = sd['decoder.pred.weight'] * 0.02
     model.load_state_dict(sd)
     model = model.to(dev)
-    if a.load_plans:
-        ops.load_plans(a.load_plans)
     ops.AUTOTUNE = not a.no_autotune and not a.load_plans
     tr = SWEMTrainer(dict(SOLVER=dict(STAGE=0, BASE_LR=2e-5, PRETRAIN_ITERS=[150000, 300000], GAMMA=0.1,
                                       OPTIMIZER='AdamW', WEIGHT_DECAY=5e-4),
                           LOSS=dict(NAME='boots_ce', BS_RATIO=0.3, BS_PERIOD=[20000, 70000], AUX='iou', AUX_RATIO=1.0),
                           AMP=a.amp), model, lanes=a.lanes)
+    if a.load_plans:
+        tr.book.load(a.load_plans)
     fr, im, lb = [], [], []
     for i in range(a.clips):
         frames, per = synth.make_clip(t=3, h=a.size, w=a.size, n_obj=a.objects, out_hw=(a.size, a.size), seed=50 + i + 16 * rank,
@@ -73,7 +73,7 @@ def main():
     for it in range(a.warmup):
         losses, _ = tr.one_step(frames, init_mask, valid, label, 30000 + it)
     if a.save_plans:
-        ops.save_plans(a.save_plans)
+        tr.book.save(a.save_plans)
     ops.AUTOTUNE = False
     for it in range(2):                      # the first step after tuning captures the HIP graph, the second replays it
         losses, _ = tr.one_step(frames, init_mask, valid, label, 30000 + it)
