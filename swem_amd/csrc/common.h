@@ -99,8 +99,24 @@ extern int g_swem_stamp_slot;
       stamps[2 * (i) + 1] = (long long)__builtin_amdgcn_s_memrealtime();                               \
     }                                                                                                  \
   } while (0)
+// accumulated cycles of a code region (diagnosis of the k-loops: time inside the counted waits / the barrier):
+//   STAMP_ACC_DECL(t); ... STAMP_T0(); <region> STAMP_ACC(t); ... STAMP_ACC_OUT(slot, t);
+#define STAMP_ACC_DECL(v) long long v = 0, v##_t0_ = 0
+#define STAMP_T0(v) v##_t0_ = (long long)__builtin_amdgcn_s_memtime()
+#define STAMP_ACC(v) v += (long long)__builtin_amdgcn_s_memtime() - v##_t0_
+#define STAMP_ACC_OUT(i, v)                                                                             \
+  do {                                                                                                 \
+    if (stamps && blockIdx.x == SWEM_STAMP_BLOCK && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { \
+      stamps[2 * (i)] = v;                                                                             \
+      stamps[2 * (i) + 1] = -1;                                                                        \
+    }                                                                                                  \
+  } while (0)
 #else
 #define STAMP_ARG
 #define STAMP_PASS
 #define STAMP(i)
+#define STAMP_ACC_DECL(v)
+#define STAMP_T0(v)
+#define STAMP_ACC(v)
+#define STAMP_ACC_OUT(i, v)
 #endif

@@ -26,6 +26,7 @@
 #include "common.h"
 #include "lds_dma.h"
 #include "bf16_split.h"
+#include <type_traits>
 
 namespace {
 
@@ -936,10 +937,16 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP &p, f32x4v (&acc)[TM
 // the mixed-precision mode of the training step (config.AMP), never the default.
 // KG = k/8 groups per k-block: 4 (32 k, the default) or 2 (16 k: half the LDS per stage -- the 128x128 tile then fits three
 // blocks of four waves per CU instead of one block; a k-block is half of a (channel block, tap) cell of the K order).
-template <int WM, int WN, int NST, int NW, bool M16, int NPL, int KG = 4>
+// PF ("prefetched fragments", round 3): the wave keeps the MFMA fragments of k-block kb in registers and reads those of
+// kb+1 from the LDS BETWEEN the MFMA groups of kb, into a second register set -- its matrix stream no longer stops for its
+// own transfer requests, fragment reads and the stage hand-over, and a stage is free for the next transfer one iteration
+// earlier (its fragments are in registers), so a ring of NST stages keeps NST-1 k-blocks in flight under the MFMAs instead of
+// NST-2 + a hand-over in front of them.  16x16x32 MFMA, one or two planes.
+template <int WM, int WN, int NST, int NW, bool M16, int NPL, int KG = 4, bool PF = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kernel(ConvP p STAMP_ARG) {
   STAMP(0);
   static_assert(KG == 4 || (KG == 2 && !M16 && NW == 4), "16-k blocks: four waves, 32x32x16 MFMA");
+  static_assert(!PF || (M16 && NPL <= 2 && KG == 4), "prefetched fragments: 16x16x32 MFMA, at most two planes");
   // block tile 64WM x 64WN, NW waves as an (NW/2) x 2 grid, each owning TM x TN 32x32 accumulator tiles
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int TM = 4 * WM / NW, TN = WN;
@@ -1159,123 +1166,220 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
 #ifndef SWEM_ISSUE_LATE
 #define SWEM_ISSUE_LATE 0
 #endif
-  constexpr int NPRO = SWEM_ISSUE_LATE ? NST : NST - 1;   // blocks issued before the loop
-  issue(0);
-  int issued = 1;   // k-blocks handed to the DMA so far (relative to kb_begin)
+  if constexpr (PF) {
+    // ---------------------------------------------------------------------------------------------------------------
+    // Prologue: all NST stages requested; block 0's fragments into register set 0; block 1 landed and published.
+    issue(0);
+    int issued = 1;
 #pragma unroll
-  for (int d = 1; d < NPRO; ++d)
-    if (kb_begin + d < kb_end) {
-      advance(q);
-      issue(d);
-      ++issued;
+    for (int d = 1; d < NST; ++d)
+      if (kb_begin + d < kb_end) {
+        advance(q);
+        issue(d);
+        ++issued;
+      }
+    wait_blocks(issued - 1);
+    __builtin_amdgcn_s_barrier();
+    STAMP(2);
+    const int r16 = lane & 15, kgl = lane >> 4;   // tile row / column, k/8 group of this lane
+    const uint4 *Ab0 = As + kgl * SA + wm * 32 * TM + r16;
+    const uint4 *Bb0 = Bs + kgl * SB + wn * 32 * TN + r16;
+    uint4 fa[2][NPL][2 * TM], fb[2][NPL][2 * TN];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+      for (int i = 0; i < 2 * TM; ++i) fa[0][pl][i] = Ab0[pl * PA + 16 * i];
+#pragma unroll
+      for (int i = 0; i < 2 * TN; ++i) fb[0][pl][i] = Bb0[pl * PB + 16 * i];
     }
-  wait_blocks(issued - 1);   // block 0 has landed; the younger ones may stay in flight
-  __builtin_amdgcn_s_barrier();
-  STAMP(2);
-  int st = 0;
-  for (int kb = kb_begin; kb < kb_end; ++kb) {
-    if (!SWEM_ISSUE_LATE && kb + NST - 1 < kb_end) {
-      advance(q);
-      issue(st == 0 ? NST - 1 : st - 1);  // stage (kb+NST-1) % NST
-    }
-    // Where the stage hand-over (counted wait for block kb+1 + s_barrier) sits inside the MFMA sequence: the MFMAs only
-    // touch registers once the fragments are read, so any of them may run before or after it.  In front of it they would
-    // hide the transfer this wave has just issued; behind it the waves of the block are decoupled while they compute (the
-    // barrier does not wait for the slowest wave's MFMAs) and the next transfer starts earlier.  Measured on the config-B
-    // layers (tools/conv_bench.py, tuned plans; SWEM_MFMA_FRONT = 0 / 1 / 2 = none / half / all of the MFMAs in front):
-    // 330 / 334 / 310 TFLOP/s on 2x120x216 256->256, 338 / 317 / 302 on 2x30x54 1280->512, 329 / 314 / 296 on 2x60x108
-    // 512->256 -- everything BEHIND the hand-over wins: the other resident block's MFMAs hide the transfer, not this one's.
-    // (The compiler's own scheduling had arrived at nearly this order by sinking the MFMAs below the asm waits; it is now
-    // pinned by scheduling barriers.)
-#ifndef SWEM_MFMA_FRONT
-#define SWEM_MFMA_FRONT 0
-#endif
-    auto hand_over = [&]() __attribute__((always_inline)) {
-      __builtin_amdgcn_sched_barrier(0);
-      // block kb+1 must have landed (this wave's share); the blocks behind it (up to kb+NST-1) may stay in flight
-      const int last = min(kb + NST - 1, kb_end - 1);   // youngest block issued so far
-      wait_blocks(last - (kb + 1));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of stage st are done
-      __builtin_amdgcn_s_barrier();
-      if (SWEM_ISSUE_LATE && kb + NST < kb_end) {   // every wave has read stage st: refill it with block kb+NST
+    wait_blocks(issued - 2);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the builtin, so that hipcc's own wait insertion knows the reads are done
+    __builtin_amdgcn_s_barrier();
+    int st = 0;   // stage of block kb: free from the top of iteration kb on (its fragments are in registers)
+    STAMP_ACC_DECL(t_vm);
+    STAMP_ACC_DECL(t_bar);
+    auto body = [&](auto CUR, int kb) __attribute__((always_inline)) {
+      constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
+      if (kb + NST < kb_end) {   // block kb+NST into the stage block kb occupied
         advance(q);
         issue(st);
       }
+      const int stn = st == NST - 1 ? 0 : st + 1;   // stage of block kb+1: landed and published by the previous hand-over
+      const bool more = kb + 1 < kb_end;
+      const uint4 *Ab = Ab0 + stn * NPL * PA, *Bb = Bb0 + stn * NPL * PB;
       __builtin_amdgcn_sched_barrier(0);
-    };
-    if constexpr (M16) {
-      const int r16 = lane & 15, kg = lane >> 4;   // tile row / column, k/8 group of this lane
-      const uint4 *Ab = As + st * NPL * PA + kg * SA + wm * 32 * TM + r16;
-      const uint4 *Bb = Bs + st * NPL * PB + kg * SB + wn * 32 * TN + r16;
-      uint4 a[NPL][2 * TM], b[NPL][2 * TN];
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-#pragma unroll
-        for (int i = 0; i < 2 * TM; ++i) a[pl][i] = Ab[pl * PA + 16 * i];
-#pragma unroll
-        for (int i = 0; i < 2 * TN; ++i) b[pl][i] = Bb[pl * PB + 16 * i];
-      }
-      constexpr int FRONT = SWEM_MFMA_FRONT * TM < 2 * TM ? SWEM_MFMA_FRONT * TM : 2 * TM;
 #pragma unroll
       for (int i = 0; i < 2 * TM; ++i) {
-        if (i == FRONT) hand_over();
+        if (more) {   // this group's share of block kb+1's fragments: row tile i, and the column tiles dealt to it
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) {
+            fa[nxt][pl][i] = Ab[pl * PA + 16 * i];
+#pragma unroll
+            for (int j = 0; j < 2 * TN; ++j)
+              if (j * (2 * TM) / (2 * TN) == i) fb[nxt][pl][j] = Bb[pl * PB + 16 * j];
+          }
+        }
 #pragma unroll
         for (int jn = 0; jn < 2 * TN; ++jn) {
           f32x4v c = acc16[i][jn];
-          if constexpr (NPL == 3) {
-            c = mfma_bf16_16(a[0][i], b[2][jn], c);
-            c = mfma_bf16_16(a[2][i], b[0][jn], c);
-            c = mfma_bf16_16(a[1][i], b[1][jn], c);
+          if constexpr (NPL >= 2) {   // "bf16x3": the three products above 2^-16, smallest first
+            c = mfma_bf16_16(fa[cur][0][i], fb[cur][1][jn], c);
+            c = mfma_bf16_16(fa[cur][1][i], fb[cur][0][jn], c);
           }
-          if constexpr (NPL >= 2) {   // NPL == 2: "bf16x3", the three products above 2^-16
-            c = mfma_bf16_16(a[0][i], b[1][jn], c);
-            c = mfma_bf16_16(a[1][i], b[0][jn], c);
-          }
-          c = mfma_bf16_16(a[0][i], b[0][jn], c);
+          c = mfma_bf16_16(fa[cur][0][i], fb[cur][0][jn], c);
           acc16[i][jn] = c;
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (FRONT >= 2 * TM) hand_over();
-    } else {
-      const uint4 *Ab = As + st * NPL * PA + wm * 32 * TM + r;
-      const uint4 *Bb = Bs + st * NPL * PB + wn * 32 * TN + r;
-      uint4 a[KG / 2][NPL][TM], b[KG / 2][NPL][TN];
+      if (more) {
+        // hand-over: this wave's share of block kb+2 has landed (the younger blocks may stay in flight), its reads of block
+        // kb+1's stage are done; the barrier publishes the one and frees the other
+        const int last = min(kb + NST, kb_end - 1);   // youngest block requested so far
+        STAMP_T0(t_vm);
+        if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else wait_blocks(last - (kb + 2));
+        STAMP_ACC(t_vm);
+        STAMP_T0(t_bar);
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the builtin, so that hipcc's own wait insertion knows the reads are done
+        __builtin_amdgcn_s_barrier();
+        STAMP_ACC(t_bar);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      st = stn;
+    };
+    for (int kb = kb_begin; kb < kb_end; kb += 2) {
+      body(std::integral_constant<int, 0>{}, kb);
+      if (kb + 1 < kb_end) body(std::integral_constant<int, 1>{}, kb + 1);
+    }
+    STAMP_ACC_OUT(6, t_vm);
+    STAMP_ACC_OUT(7, t_bar);
+  } else {
+    constexpr int NPRO = SWEM_ISSUE_LATE ? NST : NST - 1;   // blocks issued before the loop
+    issue(0);
+    int issued = 1;   // k-blocks handed to the DMA so far (relative to kb_begin)
 #pragma unroll
-      for (int s2 = 0; s2 < KG / 2; ++s2) {
-        const int k8 = 2 * s2 + h;
+    for (int d = 1; d < NPRO; ++d)
+      if (kb_begin + d < kb_end) {
+        advance(q);
+        issue(d);
+        ++issued;
+      }
+    wait_blocks(issued - 1);   // block 0 has landed; the younger ones may stay in flight
+    __builtin_amdgcn_s_barrier();
+    STAMP(2);
+    int st = 0;
+    STAMP_ACC_DECL(t_vm);
+    STAMP_ACC_DECL(t_bar);
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+      if (!SWEM_ISSUE_LATE && kb + NST - 1 < kb_end) {
+        advance(q);
+        issue(st == 0 ? NST - 1 : st - 1);  // stage (kb+NST-1) % NST
+      }
+      // Where the stage hand-over (counted wait for block kb+1 + s_barrier) sits inside the MFMA sequence: the MFMAs only
+      // touch registers once the fragments are read, so any of them may run before or after it.  In front of it they would
+      // hide the transfer this wave has just issued; behind it the waves of the block are decoupled while they compute (the
+      // barrier does not wait for the slowest wave's MFMAs) and the next transfer starts earlier.  Measured on the config-B
+      // layers (tools/conv_bench.py, tuned plans; SWEM_MFMA_FRONT = 0 / 1 / 2 = none / half / all of the MFMAs in front):
+      // 330 / 334 / 310 TFLOP/s on 2x120x216 256->256, 338 / 317 / 302 on 2x30x54 1280->512, 329 / 314 / 296 on 2x60x108
+      // 512->256 -- everything BEHIND the hand-over wins: the other resident block's MFMAs hide the transfer, not this one's.
+      // (The compiler's own scheduling had arrived at nearly this order by sinking the MFMAs below the asm waits; it is now
+      // pinned by scheduling barriers.)
+#ifndef SWEM_MFMA_FRONT
+#define SWEM_MFMA_FRONT 0
+#endif
+      auto hand_over = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        // block kb+1 must have landed (this wave's share); the blocks behind it (up to kb+NST-1) may stay in flight
+        const int last = min(kb + NST - 1, kb_end - 1);   // youngest block issued so far
+        STAMP_T0(t_vm);
+        wait_blocks(last - (kb + 1));
+        STAMP_ACC(t_vm);
+        STAMP_T0(t_bar);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of stage st are done
+        __builtin_amdgcn_s_barrier();
+        STAMP_ACC(t_bar);
+        if (SWEM_ISSUE_LATE && kb + NST < kb_end) {   // every wave has read stage st: refill it with block kb+NST
+          advance(q);
+          issue(st);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      if constexpr (M16) {
+        const int r16 = lane & 15, kg = lane >> 4;   // tile row / column, k/8 group of this lane
+        const uint4 *Ab = As + st * NPL * PA + kg * SA + wm * 32 * TM + r16;
+        const uint4 *Bb = Bs + st * NPL * PB + kg * SB + wn * 32 * TN + r16;
+        uint4 a[NPL][2 * TM], b[NPL][2 * TN];
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a[s2][pl][i] = Ab[pl * PA + k8 * SA + 32 * i];
+          for (int i = 0; i < 2 * TM; ++i) a[pl][i] = Ab[pl * PA + 16 * i];
 #pragma unroll
-          for (int i = 0; i < TN; ++i) b[s2][pl][i] = Bb[pl * PB + k8 * SB + 32 * i];
+          for (int i = 0; i < 2 * TN; ++i) b[pl][i] = Bb[pl * PB + 16 * i];
         }
-      }
-      constexpr int FRONT2 = SWEM_MFMA_FRONT >= 2 ? KG / 2 : (SWEM_MFMA_FRONT * (KG / 2)) / 2;   // k16 steps in front
+        constexpr int FRONT = SWEM_MFMA_FRONT * TM < 2 * TM ? SWEM_MFMA_FRONT * TM : 2 * TM;
 #pragma unroll
-      for (int s2 = 0; s2 < KG / 2; ++s2) {
-        if (s2 == FRONT2) hand_over();
+        for (int i = 0; i < 2 * TM; ++i) {
+          if (i == FRONT) hand_over();
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int jn = 0; jn < TN; ++jn) {
-            f32x16 c = acc[i][jn];
+          for (int jn = 0; jn < 2 * TN; ++jn) {
+            f32x4v c = acc16[i][jn];
             if constexpr (NPL == 3) {
-              c = mfma_bf16(a[s2][0][i], b[s2][2][jn], c);
-              c = mfma_bf16(a[s2][2][i], b[s2][0][jn], c);
-              c = mfma_bf16(a[s2][1][i], b[s2][1][jn], c);
+              c = mfma_bf16_16(a[0][i], b[2][jn], c);
+              c = mfma_bf16_16(a[2][i], b[0][jn], c);
+              c = mfma_bf16_16(a[1][i], b[1][jn], c);
             }
-            if constexpr (NPL >= 2) {
-              c = mfma_bf16(a[s2][0][i], b[s2][1][jn], c);
-              c = mfma_bf16(a[s2][1][i], b[s2][0][jn], c);
+            if constexpr (NPL >= 2) {   // NPL == 2: "bf16x3", the three products above 2^-16
+              c = mfma_bf16_16(a[0][i], b[1][jn], c);
+              c = mfma_bf16_16(a[1][i], b[0][jn], c);
             }
-            c = mfma_bf16(a[s2][0][i], b[s2][0][jn], c);
-            acc[i][jn] = c;
+            c = mfma_bf16_16(a[0][i], b[0][jn], c);
+            acc16[i][jn] = c;
           }
+        }
+        if (FRONT >= 2 * TM) hand_over();
+      } else {
+        const uint4 *Ab = As + st * NPL * PA + wm * 32 * TM + r;
+        const uint4 *Bb = Bs + st * NPL * PB + wn * 32 * TN + r;
+        uint4 a[KG / 2][NPL][TM], b[KG / 2][NPL][TN];
+#pragma unroll
+        for (int s2 = 0; s2 < KG / 2; ++s2) {
+          const int k8 = 2 * s2 + h;
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[s2][pl][i] = Ab[pl * PA + k8 * SA + 32 * i];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) b[s2][pl][i] = Bb[pl * PB + k8 * SB + 32 * i];
+          }
+        }
+        constexpr int FRONT2 = SWEM_MFMA_FRONT >= 2 ? KG / 2 : (SWEM_MFMA_FRONT * (KG / 2)) / 2;   // k16 steps in front
+#pragma unroll
+        for (int s2 = 0; s2 < KG / 2; ++s2) {
+          if (s2 == FRONT2) hand_over();
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+              f32x16 c = acc[i][jn];
+              if constexpr (NPL == 3) {
+                c = mfma_bf16(a[s2][0][i], b[s2][2][jn], c);
+                c = mfma_bf16(a[s2][2][i], b[s2][0][jn], c);
+                c = mfma_bf16(a[s2][1][i], b[s2][1][jn], c);
+              }
+              if constexpr (NPL >= 2) {
+                c = mfma_bf16(a[s2][0][i], b[s2][1][jn], c);
+                c = mfma_bf16(a[s2][1][i], b[s2][0][jn], c);
+              }
+              c = mfma_bf16(a[s2][0][i], b[s2][0][jn], c);
+              acc[i][jn] = c;
+            }
+        }
+        if (FRONT2 >= KG / 2) hand_over();
       }
-      if (FRONT2 >= KG / 2) hand_over();
+      st = st == NST - 1 ? 0 : st + 1;
     }
-    st = st == NST - 1 ? 0 : st + 1;
+    STAMP_ACC_OUT(6, t_vm);
+    STAMP_ACC_OUT(7, t_bar);
   }
   STAMP(3);
   if constexpr (M16) conv_epilogue16<2 * TM, 2 * TN>(p, acc16, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
@@ -1431,28 +1535,28 @@ static inline size_t lds_with_planes(const ConvP &p, size_t lds, int nwaves) {
   return lds < need ? need : lds;
 }
 
-template <int WM, int WN, int NST, int NW, bool M16 = false, int KG = 4>
+template <int WM, int WN, int NST, int NW, bool M16 = false, int KG = 4, bool PF = false>
 int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st) {
   if (p.nplanes == 1) {   // plain bf16 (one plane, one product): a third of the LDS, the same tiles
     constexpr size_t lds1 = NST * 1 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;
-    SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG>), lds1);
-    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG>), grid, dim3(64 * NW),
+    SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG, PF>), lds1);
+    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG, PF>), grid, dim3(64 * NW),
                        lds_with_planes(p, lds1, NW), st, p STAMP_PASS);
     return SWEM_OK;
   }
   if (p.nplanes == 2) {   // "bf16x3": hi and mid planes, three products (hi.hi + hi.mid + mid.hi): two thirds of the LDS
     constexpr size_t lds2 = NST * 2 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;
-    SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 2, KG>), lds2);
-    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 2, KG>), grid, dim3(64 * NW), lds2, st, p STAMP_PASS);
+    SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 2, KG, PF>), lds2);
+    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 2, KG, PF>), grid, dim3(64 * NW), lds2, st, p STAMP_PASS);
     return SWEM_OK;
   }
-  if constexpr (NST <= 3) {
+  if constexpr (NST <= 3 && !PF) {
     constexpr size_t lds = NST * 3 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;  // NST stages x 3 planes
     SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 3, KG>), lds);
     hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 3, KG>), grid, dim3(64 * NW), lds, st, p STAMP_PASS);
     return SWEM_OK;
   } else {
-    swem_set_error("conv2d_bf16x3: a four-stage ring needs at most two planes");
+    swem_set_error("conv2d_bf16x3: four-stage rings and prefetched fragments need at most two planes");
     return SWEM_E_ARG;
   }
 }
@@ -1469,6 +1573,13 @@ int launch_bf3s(const ConvP &p, dim3 grid, hipStream_t st, int variant) {
     if constexpr (WM == 2 && WN == 2) {
       if (variant == 12) return launch_bf3s_n<2, 2, 4, 8>(p, grid, st);
       if (variant == 13) return launch_bf3s_n<2, 2, 4, 8, true>(p, grid, st);
+    }
+    if constexpr (WM == 2 && WN == 2) {
+      // prefetched fragments (PF): 5 = four waves of 64x64, two stages (two blocks per CU); 15 = four waves, three stages (one
+      // block per CU, one wave per SIMD); 7 = eight waves of 32x64, four stages (one block per CU)
+      if (variant == 5) return launch_bf3s_n<2, 2, 2, 4, true, 4, true>(p, grid, st);
+      if (variant == 15) return launch_bf3s_n<2, 2, 3, 4, true, 4, true>(p, grid, st);
+      if (variant == 7) return launch_bf3s_n<2, 2, 4, 8, true, 4, true>(p, grid, st);
     }
     if (variant == 10) return launch_bf3s_n<WM, WN, 4, 4>(p, grid, st);
     if (variant == 11) return launch_bf3s_n<WM, WN, 4, 4, true>(p, grid, st);

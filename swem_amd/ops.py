@@ -523,12 +523,17 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
                         if math != 1:
                             cands.append(base | 12 << 20)     # eight waves, four stages
                             cands.append(base | 13 << 20)     # ... on the 16x16x32 MFMA
+                            cands.append(base | 5 << 20)      # prefetched fragments: four waves of 64x64, two stages
+                            cands.append(base | 15 << 20)     # ... three stages (one block per CU)
+                            cands.append(base | 7 << 20)      # ... eight waves of 32x64, four stages
                     if ns == 1 and blocks > 256 and nkb >= 16:   # tail split: the last, partly filled round over K
                         for ts in (4, 8):
                             cands.append(base | ts << 24)
                             if wm == 2 and wn == 2:
                                 cands.append(base | 2 << 20 | ts << 24)
                                 cands.append(base | 8 << 20 | ts << 24)
+                                if math != 1:
+                                    cands.append(base | 5 << 20 | ts << 24)
     def timed(plan, n):
         launch(plan)                               # warm (also grows the workspace)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -247,7 +247,7 @@ def test_conv2d_plans_and_math_modes(lib, plan):
 
 
 @pytest.mark.parametrize('plan', [0x20011, 0x20021, 0x20022, 0x120021, 0x220022, 0x420011, 0x420021, 0x620022, 0x20221, 0x820022, 0x920022,
-                                  0x4020021, 0xa20011, 0xd20022], ids=lambda p: '%#x' % p)
+                                  0x4020021, 0xa20011, 0xd20022, 0x520022, 0x720022, 0xf20022], ids=lambda p: '%#x' % p)
 def test_conv2d_plain_bf16_mode(lib, plan):
     """Math mode 2 (mixed-precision training, config.AMP): operands rounded to bf16 once, ONE MFMA product, fp32
     accumulate.  On bf16-representable operands it is the fp32 convolution up to summation order; on general ones it
@@ -272,7 +272,8 @@ def test_conv2d_plain_bf16_mode(lib, plan):
 
 
 @pytest.mark.parametrize('plan', [0x00011, 0x00022, 0x00211, 0x10021, 0x10022, 0x10321, 0x30011, 0x30021, 0x30022, 0x230022,
-                                  0x430011, 0x430021, 0x630022, 0x30221, 0x830022, 0x4030021, 0x8030022, 0xb30011, 0xd30022, 0xe30022],
+                                  0x430011, 0x430021, 0x630022, 0x30221, 0x830022, 0x4030021, 0x8030022, 0xb30011, 0xd30022, 0xe30022,
+                                  0x530022, 0x730022, 0xf30022],
                          ids=lambda p: '%#x' % p)
 def test_conv2d_fused_output_planes(lib, plan):
     """The conv epilogues (32x32 and 16x16 accumulator layouts, the split-K reduce kernel, the tail split; fp32, bf16x6 and
@@ -383,7 +384,8 @@ def test_upsample_add_fused_output_planes(lib):
 
 
 @pytest.mark.parametrize('plan', [0x30011, 0x30021, 0x30022, 0x130021, 0x230022, 0x430011, 0x430021, 0x630022, 0x30221, 0x830022,
-                                  0x930022, 0x4030021, 0xa30011, 0xb30021, 0xa30022, 0xc30022, 0xd30022, 0xe30022, 0xa30211], ids=lambda p: '%#x' % p)
+                                  0x930022, 0x4030021, 0xa30011, 0xb30021, 0xa30022, 0xc30022, 0xd30022, 0xe30022, 0xa30211,
+                                  0x530022, 0x730022, 0xf30022, 0x530222, 0x4530022], ids=lambda p: '%#x' % p)
 def test_conv2d_bf16x3_mode(lib, plan):
     """Math mode 3 ("bf16x3"): each operand is taken as hi + mid (two bf16 terms = 16 significant bits) and the product is
     hi.hi + hi.mid + mid.hi in fp32 -- half the matrix-core work of bf16x6.  On operands that HAVE only 16 significant bits it

@@ -80,10 +80,13 @@ def main():
         kk = int((row[:, 0] != 0).sum())
         if not kk:
             break
-        print('launch %d: cycles %s | ns %s | gap since previous launch\'s last stamp: %s ns'
-              % (i, [int(row[j, 0] - row[0, 0]) for j in range(kk)], [(int(row[j, 1]) - int(row[0, 1])) * 10 for j in range(kk)],
-                 '-' if prev is None else (int(row[0, 1]) - prev) * 10))
-        prev = int(row[kk - 1, 1])
+        acc = {j: int(row[j, 0]) for j in range(8) if int(row[j, 1]) == -1}      # accumulated regions (STAMP_ACC_OUT)
+        pts = [j for j in range(kk) if j not in acc]
+        print('launch %d: cycles %s | ns %s | gap since previous launch\'s last stamp: %s ns | cycles inside the counted vmcnt '
+              'waits %s, inside lgkmcnt(0) + s_barrier %s (wave 0 of the block, k-loop)'
+              % (i, [int(row[j, 0] - row[0, 0]) for j in pts], [(int(row[j, 1]) - int(row[0, 1])) * 10 for j in pts],
+                 '-' if prev is None else (int(row[0, 1]) - prev) * 10, acc.get(6), acc.get(7)))
+        prev = int(row[pts[-1], 1])
 
 
 if __name__ == '__main__':

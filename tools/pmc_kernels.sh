@@ -1,0 +1,69 @@
+#!/bin/bash
+# rocprofv3 --pmc passes (counters in their own runs, --kernel-trace only) of one command, summed per kernel, with the
+# derived figures the round's reports quote:
+#   bash tools/pmc_kernels.sh <out.txt> <kernel name regex> python3 <script> [args...]
+# The program itself follows `--` (no shell / env wrapper: the profiler's library initialises the GPU before the program starts).
+export TMPDIR=/tmp
+OUTTXT=$1; FILTER=$2; shift 2
+OUT=gpurun_out/pmc_$(basename $OUTTXT .txt); rm -rf $OUT; mkdir -p $OUT
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32" \
+           "FETCH_SIZE TCC_HIT_sum" \
+           "WRITE_SIZE TCC_REQ_sum TCC_MISS_sum"; do
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- "$@" > $OUT/g$i.log 2>&1
+  i=$((i+1))
+done
+python3 - "$OUT" "$FILTER" "$*" > $OUTTXT <<'PY'
+import csv, glob, collections, re, sys
+root, filt, cmd = sys.argv[1:4]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+nlaunch = collections.defaultdict(lambda: collections.Counter())
+dur = collections.defaultdict(list)
+for f in glob.glob(root + '/g*/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
+        k = re.sub(r'^void ', '', re.sub(r'\((?!anonymous).*', '', k))
+        agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+        nlaunch[k][r['Counter_Name']] += 1
+for f in glob.glob(root + '/g0/*/*kernel_trace.csv'):
+    for r in csv.DictReader(open(f)):
+        k = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
+        k = re.sub(r'^void ', '', re.sub(r'\((?!anonymous).*', '', k))
+        dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+print('rocprofv3 --kernel-trace --pmc, one counter group per run (tools/pmc_kernels.sh); command: %s' % cmd)
+print('counter values are SUMS over the launches of the kernel in that run; derived figures below each kernel.\n')
+for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get('SQ_WAVE_CYCLES', 0)):
+    if not re.search(filt, k):
+        continue
+    n = max(nlaunch[k].values())
+    print('%s   (%d launches per pass; kernel-trace duration under the profiler: avg %.1f us)' % (k, n, sum(dur[k]) / max(len(dur[k]), 1)))
+    for c, v in sorted(d.items()):
+        print('   %-36s %.5g' % (c, v))
+    g = d.get('GRBM_GUI_ACTIVE', 0) / max(nlaunch[k].get('GRBM_GUI_ACTIVE', 1), 1) * n / 8   # summed over 8 XCDs -> chip cycles
+    if g:
+        simd_cyc = g * 1024
+        print('   -- derived (chip-busy cycles of these launches = GRBM_GUI_ACTIVE / 8 = %.4g; x 1024 SIMDs = %.4g SIMD cycles)' % (g, simd_cyc))
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in d:
+            print('   mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles                  = %.3f' % (d['SQ_VALU_MFMA_BUSY_CYCLES'] / simd_cyc))
+        if 'SQ_LDS_IDX_ACTIVE' in d:
+            print('   lds_array_active = SQ_LDS_IDX_ACTIVE / (chip cycles x 256 CUs)      = %.3f   bank-conflict cycles / active = %.3f'
+                  % (d['SQ_LDS_IDX_ACTIVE'] / (g * 256), d.get('SQ_LDS_BANK_CONFLICT', 0) / max(d['SQ_LDS_IDX_ACTIVE'], 1)))
+    if 'SQ_WAVE_CYCLES' in d:
+        w = d['SQ_WAVE_CYCLES']
+        print('   of the wave cycles: parked in s_waitcnt / s_barrier (SQ_WAIT_ANY) %.3f, issue-stalled (SQ_WAIT_INST_ANY) %.3f '
+              '(of which LDS issue %.3f), issuing (SQ_ACTIVE_INST_ANY) %.3f' % (
+                  d.get('SQ_WAIT_ANY', 0) / w, d.get('SQ_WAIT_INST_ANY', 0) / w, d.get('SQ_WAIT_INST_LDS', 0) / w, d.get('SQ_ACTIVE_INST_ANY', 0) / w))
+    if 'SQ_INSTS_MFMA' in d and d['SQ_INSTS_MFMA']:
+        m = d['SQ_INSTS_MFMA']
+        print('   per MFMA: %.2f scalar, %.2f other vector, %.2f LDS, %.2f vector-memory instructions' % (
+            d.get('SQ_INSTS_SALU', 0) / m, (d.get('SQ_INSTS_VALU', 0) - m) / m, d.get('SQ_INSTS_LDS', 0) / m, d.get('SQ_INSTS_VMEM_RD', 0) / m))
+    if 'FETCH_SIZE' in d or 'WRITE_SIZE' in d:
+        fs, ws = d.get('FETCH_SIZE', 0), d.get('WRITE_SIZE', 0)
+        print('   fabric traffic per launch: (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) x 1024 B = %.2f MB (fetch %.2f MB x 2, write %.2f MB); '
+              'L2 hit rate %.3f' % ((2 * fs + ws) * 1024 / n / 1e6, fs * 1024 / n / 1e6, ws * 1024 / n / 1e6,
+                                    d.get('TCC_HIT_sum', 0) / max(d.get('TCC_HIT_sum', 0) + d.get('TCC_MISS_sum', 0), 1)))
+    print()
+PY
+tail -40 $OUTTXT
