@@ -67,6 +67,7 @@ class FrameRunner:
             model('init', mk16, mv16, m0)
 
         self.graph = None
+        self.look = None            # evaluator.LookaheadGraph: k frames per replay, the key encoder batched over them
 
     def next_frame(self):
         self.i = self.i % (self.t - 1) + 1
@@ -74,16 +75,49 @@ class FrameRunner:
 
     def step(self):
         from swem_amd import evaluator
+        if self.look is not None:
+            # one frame per call, as the reference's loop; every k-th call replays the group graph (the k frame chains of the
+            # group whose keys are ready + the batched key encoder of the next k frames).  With --steps a multiple of k the
+            # timed region holds exactly steps frames of work (otherwise up to k-1 more, never fewer).
+            if self.left == 0:
+                self.grp = (self.grp + 1) % len(self.groups)       # the group after the one whose keys are ready
+                self.preds = self.look.run(self.groups[self.grp])
+                self.left = self.look.k
+            self.left -= 1
+            return self.preds[self.look.k - 1 - self.left]
         f = self.next_frame()
         if self.graph is not None:
             return self.graph.run(f)
         with torch.no_grad():
             return evaluator.frame_step(self.model, f, OUT_HW)
 
-    def enable_graph(self, pipelined=False):
-        """Capture the steady-state frame into a HIP graph (both banks must exist: call after >= 2 eager steps).
-        pipelined: evaluator.PipelinedFrameGraph (the previous frame's memorize under this frame's key encoder)."""
+    def eager_group(self, k):
+        """k frames the way the look-ahead graphs run them, but eagerly (per-launch event timing): one batched key-encoder
+        pass, then the k frame chains."""
         from swem_amd import evaluator
+        with torch.no_grad():
+            grp = torch.cat([self.next_frame() for _ in range(k)])
+            keys = self.model('encode_key', grp)
+            for j in range(k):
+                evaluator.frame_chain(self.model, evaluator.key_item(keys, j), grp[j:j + 1], OUT_HW)
+
+    def enable_graph(self, pipelined=False, lookahead=0):
+        """Capture the steady state into HIP graphs (both banks must exist: call after >= 2 eager steps).
+        lookahead = k > 0: evaluator.LookaheadGraph (k frames per replay, one batched key-encoder pass for the next k;
+        pipelined: that pass on a side stream next to the current group's frame chains).  lookahead = 0: one frame per
+        replay; pipelined: evaluator.PipelinedFrameGraph (the previous frame's memorize under this frame's key encoder)."""
+        from swem_amd import evaluator
+        if lookahead > 0:
+            k = lookahead
+            # the clip's frames 1..t-1 cycle; the groups of k consecutive frames of that cycle, staged once
+            cyc = [1 + (self.i + j) % (self.t - 1) for j in range(k * (self.t - 1))]
+            self.groups = [torch.cat([self.frames[:, c] for c in cyc[g * k:(g + 1) * k]]).contiguous()
+                           for g in range(self.t - 1)]
+            self.look = evaluator.LookaheadGraph(self.model, self.frames[:, 1].shape, OUT_HW, k,
+                                                 overlap=pipelined).capture(self.groups[0])
+            self.look.prime(self.groups[0])
+            self.grp, self.left, self.preds = 0, 0, None
+            return
         cls = evaluator.PipelinedFrameGraph if pipelined else evaluator.FrameGraph
         self.graph = cls(self.model, self.frames[:, 1].shape, OUT_HW).capture(self.frames[:, 1])
 
@@ -174,6 +208,9 @@ def main():
     ap.add_argument('--pipeline', choices=('auto', 'on', 'off'), default='auto',
                     help='software-pipelined frame graph (evaluator.PipelinedFrameGraph): +12 %% with one sequence, -10 %% with several '
                          '(their streams already fill the hardware queues); auto = on for --seqs 1 only')
+    ap.add_argument('--lookahead', type=int, default=4,
+                    help='frames per graph replay with the key encoder batched over them (evaluator.LookaheadGraph); 0 = one frame '
+                         'per replay')
     ap.add_argument('--seqs', type=int, default=4,
                     help='independent sequences processed concurrently per GPU, each on its own HIP stream')
     ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
@@ -253,11 +290,13 @@ def main():
                 ops.AUTOTUNE = tune and si == 0
                 for _ in range(max(args.warmup, 2)):
                     rn.step()
-                ops.AUTOTUNE = False
                 if not args.no_graph:
-                    rn.enable_graph(pipelined=pipelined)
-                    rn.step()
-                    rn.step()       # (the pipelined graph's first step runs eagerly: nothing is pending yet)
+                    # (the look-ahead capture's eager passes tune the batched key-encoder shapes while the tuner is on)
+                    rn.enable_graph(pipelined=pipelined, lookahead=args.lookahead)
+                    ops.AUTOTUNE = False
+                    for _ in range(2 * max(args.lookahead, 1)):
+                        rn.step()   # (the pipelined one-frame graph's first step runs eagerly: nothing is pending yet)
+                ops.AUTOTUNE = False
             torch.cuda.synchronize()
             rs.append(rn)
             sts.append(st)
@@ -297,8 +336,14 @@ def main():
     total_frames, max_t = timed(runners, streams, args.steps)
 
     def launch_text(pipe_):
-        return 'eager' if args.no_graph else ('hipGraph replay of the steady-state frame' + (
-            ', software-pipelined (previous frame\'s memorize under this frame\'s key encoder)' if pipe_ else ''))
+        if args.no_graph:
+            return 'eager'
+        if args.lookahead > 0:
+            return ('hipGraph replay, %d frames per replay: one batched key-encoder pass for the next %d frames%s + the %d frame '
+                    'chains (match, segment, encode_value, memorize) of the current ones'
+                    % (args.lookahead, args.lookahead, ' on a side stream' if pipe_ else '', args.lookahead))
+        return 'hipGraph replay of the steady-state frame' + (
+            ', software-pipelined (previous frame\'s memorize under this frame\'s key encoder)' if pipe_ else '')
 
     out = None
     if rank == 0:
@@ -360,8 +405,17 @@ def main():
 
     if world == 1:
         # ---------------- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream
-        nprof = min(args.steps, 5)
-        runner.graph = None                     # per-launch timing needs eager launches (same kernels, same plans)
+        kla = args.lookahead if (args.lookahead > 0 and not args.no_graph) else 0
+        nprof = min(args.steps, 5) if not kla else kla * max(1, 4 // kla)       # frames traced eagerly
+        runner.graph = runner.look = None       # per-launch timing needs eager launches (same kernels, same plans)
+
+        def eager_frames(n):
+            if kla:
+                for _ in range(n // kla):
+                    runner.eager_group(kla)
+            else:
+                for _ in range(n):
+                    runner.step()
         ops.CONV_TRACE = []
         # (matching's readout GEMM also runs on a conv kernel, launched by the library itself: a marker keeps the launch list
         # aligned with a rocprofv3 kernel trace, tools/conv_by_layer.py; it is priced in `em_matching`, not here)
@@ -375,10 +429,11 @@ def main():
         # The launch stream must never run dry while the frames are traced: with an empty queue a launch's event interval is
         # the HOST's enqueue time (~10 us per Python call), not the kernel's.  A spin kernel holds the GPU back until the host
         # has enqueued all traced frames; the intervals then lie between back-to-back packets of one in-order queue.
+        eager_frames(max(kla, 1))                   # (the eager batched shapes: workspaces sized, planes hinted)
         torch.cuda.synchronize()
         t_host = time.perf_counter()
-        runner.step()
-        t_host = time.perf_counter() - t_host       # host time to enqueue one eager frame
+        eager_frames(max(kla, 1))
+        t_host = (time.perf_counter() - t_host) / max(kla, 1)      # host time to enqueue one eager frame
         torch.cuda.synchronize()
         ops.CONV_TRACE = []
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -388,8 +443,7 @@ def main():
         torch.cuda.synchronize()
         cyc_per_ms = 10_000_000 / c0.elapsed_time(c1)
         torch.cuda._sleep(int(cyc_per_ms * 1e3 * t_host * nprof * 1.2))
-        for _ in range(nprof):
-            runner.step()
+        eager_frames(nprof)
         torch.cuda.synchronize()
         ops.match_packed = real_mp
         tr_all, ops.CONV_TRACE = ops.CONV_TRACE, None

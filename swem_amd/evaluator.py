@@ -328,6 +328,160 @@ class PipelinedFrameGraph(FrameGraph):
             self.primed = False
 
 
+def frame_chain(model, keys, frame, out_size, memorize=True):
+    """The part of a frame that depends on the memory (swem_evaluator.py:77-97): match -> segment -> argmax / one-hot ->
+    [bilinear -> encode_value -> memorize], from the frame's key-encoder outputs `keys` = (qk16, qv16, s16, s8, s4)."""
+    h, w = frame.shape[-2:]
+    qk16, qv16, s16, s8, s4 = keys
+    context, n = model('match', qk16, qv16)
+    _, pred_mask = model('segment', n, context, s8, s4, None, out_size)
+    pred, hard = ops.argmax_onehot(pred_mask, want_onehot=memorize)
+    if memorize:
+        pm = ops.resize_planes(pred_mask, (h, w), 'bilinear')
+        model('memorize', qk16, model('encode_value', frame, pm, s16), hard, pm)
+    return pred
+
+
+def key_item(keys, j):
+    """Frame j's share of a batched encode_key result (NCHW-shaped views of NHWC maps), with the planes the batch carries."""
+    from .modules import as_nchw, to_pixel_major
+    return tuple(as_nchw(ops.batch_item(to_pixel_major(t), j)) for t in keys)
+
+
+class LookaheadGraph:
+    """k frames of ONE sequence per replay, with the key encoder batched over them.
+
+    `encode_key` does not read the memory (swem_evaluator.py:75 vs :77) and the whole sequence is device-resident inside the
+    timed region (basic_evaluator.py:157-176), so the key encoder of the NEXT k frames runs as one B = k pass -- a k-th of
+    the launches, k times the grid: the B = 1 layers of the ResNet-50 trunk are 10-25 us launches that leave most of the
+    chip idle -- while the k frames of the CURRENT group run their memory-dependent chains (match -> segment -> encode_value ->
+    memorize) one after the other.  Two HIP graphs per buffer parity: `keys[p]` (stage k frames, one batched pass; its
+    outputs live in that graph's pool) and `chain[p]` (the k frame chains reading keys[p]'s outputs); a replay runs
+    chain[p] on the lane's stream and keys[1-p] for the following group on a side stream (overlap=True, one lane) or behind
+    it on the same stream (several lanes: their streams already fill the hardware queues).  Every kernel sees the data of
+    the sequential order; with batch-invariant plans (ops.PlanBook.fallback without a K-split) index maps and memory are those
+    of the frame-by-frame loop bit for bit (tests/test_gpu_model.py)."""
+
+    def __init__(self, model, frame_shape, out_size, k, streams=None, side_stream=None, overlap=True):
+        self.model, self.k, self.out_size = model, int(k), (int(out_size[0]), int(out_size[1]))
+        self.streams, self.side, self.overlap = streams, side_stream, overlap
+        core = model.swem_core
+        upd = core.memories['update'].bases
+        if upd is None or core.memories['first'].bases is None:
+            raise RuntimeError('LookaheadGraph needs an initialised memory with both banks (run two frames eagerly first)')
+        dev = upd['kappa'].device
+        self.frame_shape = tuple(frame_shape)                 # (1, 3, H, W)
+        self.frames = [torch.empty((self.k,) + self.frame_shape[1:], dtype=torch.float32, device=dev) for _ in range(2)]
+        self.state = {key: v.clone() for key, v in upd.items()}
+        core.memories['update'].bases = self.state
+        self.first = core.memories['first'].bases
+        self.kg = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+        self.cg = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+        self.keys = [None, None]
+        self.preds = [None, None]
+        self.p = 0                   # parity of the group whose keys are ready (after prime() / run())
+        self.primed = False
+
+    def _chains(self, p):
+        core = self.model.swem_core
+        preds = []
+        for j in range(self.k):
+            preds.append(frame_chain(self.model, key_item(self.keys[p], j), self.frames[p][j:j + 1], self.out_size))
+            new = core.memories['update'].bases
+            for key in self.state:
+                self.state[key].copy_(new[key])
+            core.memories['update'].bases = self.state
+            core.restamp()
+        return preds
+
+    def capture(self, example_frames):
+        """example_frames (k,3,H,W): any frames of the sequence's shape (everything the warm-up touches is restored)."""
+        core = self.model.swem_core
+        with torch.no_grad():
+            if self.streams is None:
+                self.streams = (ops.new_stream(), ops.new_stream())
+            if self.side is None:
+                self.side = overlapping_streams(2)[1] if self.overlap else self.streams[1]
+            warm, cap = self.streams
+            saved = {key: v.clone() for key, v in self.state.items()}
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                for p in (0, 1):
+                    self.frames[p].copy_(example_frames)
+                # eager passes: size every workspace, let the batched layers' consumers report their split requests (the
+                # producers then write the planes themselves) and -- while ops.AUTOTUNE is on -- tune the B = k layer shapes
+                for _ in range(2):
+                    self.keys[0] = self.model('encode_key', self.frames[0])
+                    self._chains(0)
+            torch.cuda.current_stream().wait_stream(warm)
+            for p in (0, 1):
+                for key in self.state:
+                    self.state[key].copy_(saved[key])
+                core.memories['update'].bases = self.state
+                self.pack = core.repack()
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.graph(self.kg[p], stream=cap):
+                    self.keys[p] = self.model('encode_key', self.frames[p])
+                with torch.cuda.graph(self.cg[p], stream=cap):
+                    self.preds[p] = self._chains(p)
+                torch.cuda.current_stream().wait_stream(cap)
+            for key in self.state:
+                self.state[key].copy_(saved[key])
+            core.memories['update'].bases = self.state
+            core.restamp()
+        self.primed = False
+        return self
+
+    def rebind(self):
+        """Adopt the model's CURRENT memory (a new sequence of the same shapes) into the captured graphs' static buffers."""
+        core = self.model.swem_core
+        cur_first, cur_upd = core.memories['first'].bases, core.memories['update'].bases
+        if cur_first is None or cur_upd is None or cur_first['kappa'].shape != self.first['kappa'].shape:
+            return False
+        if core._pack is not self.pack:
+            return False
+        core.repack()
+        for key in self.first:
+            if cur_first[key] is not self.first[key]:
+                self.first[key].copy_(cur_first[key])
+            if cur_upd[key] is not self.state[key]:
+                self.state[key].copy_(cur_upd[key])
+        core.memories['first'].bases = self.first
+        core.memories['update'].bases = self.state
+        core.restamp()
+        self.primed = False
+        return True
+
+    def prime(self, frames_k):
+        """Key-encoder pass of the first group (k,3,H,W)."""
+        self.frames[self.p].copy_(frames_k)
+        self.kg[self.p].replay()
+        self.primed = True
+
+    def run(self, next_frames_k=None):
+        """The k frame chains of the group whose keys are ready; `next_frames_k` (k,3,H,W) = the following group, whose key
+        encoder runs next to them (None: the sequence ends).  Returns the k (static) int64 index maps."""
+        if not self.primed:
+            raise RuntimeError('LookaheadGraph.run before prime()')
+        p, main = self.p, torch.cuda.current_stream()
+        if next_frames_k is not None:
+            self.frames[1 - p].copy_(next_frames_k)
+            if self.overlap:
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    self.kg[1 - p].replay()
+        self.cg[p].replay()
+        if next_frames_k is not None:
+            if self.overlap:
+                main.wait_stream(self.side)
+            else:
+                self.kg[1 - p].replay()
+            self.p = 1 - p
+        else:
+            self.primed = False
+        return self.preds[p]
+
+
 def run_sequences(model, sequences, meter=None):
     """basic_evaluator.py:149-199 without the disk IO: sequences = iterable of (frames, init_mask, out_size)."""
     meter = meter or FrameSecondMeter()
@@ -406,14 +560,16 @@ def overlapping_streams(n, device=None, tries=12):
 
 class SequencePool:
     """Several sequences in flight on one GPU, each on its own stream with its own model instance (memory banks):
-    sequences are independent and one sequence alone leaves the GPU under-filled (102 blocks in the
+    sequences are independent and one sequence alone leaves the GPU under-filled (204 blocks in the
     EM kernels, ~300 short launches per frame), so a second one's kernels fill the gaps (+18..25 % frames/s, bench.py).
     The lanes' streams are probed for real concurrency (`overlapping_streams`): two streams can share a hardware queue.
-    After a sequence's first two frames (eager: they build the two banks) the steady-state frame is replayed from a HIP
-    graph that is captured once per lane and re-bound to each new sequence of the same shape.  A pool of ONE model runs the
-    software-pipelined graph (PipelinedFrameGraph)."""
+    After a sequence's first two frames (eager: they build the two banks) the steady state runs from HIP graphs captured once
+    per lane and re-bound to each new sequence of the same shape: `lookahead` frames per replay with the key encoder batched
+    over them (LookaheadGraph; with ONE lane the next group's key encoder runs on a side stream next to the current group's
+    frame chains), the last frames of a sequence that do not fill a group eagerly.  lookahead = 0: one frame per replay
+    (FrameGraph; a pool of one model then runs the software-pipelined PipelinedFrameGraph)."""
 
-    def __init__(self, models, use_graph=True):
+    def __init__(self, models, use_graph=True, lookahead=4):
         self.models = list(models)
         n = len(self.models)
         for m in self.models[1:]:            # the lanes run the same layers on the same shapes: one PlanBook for all of them
@@ -422,6 +578,32 @@ class SequencePool:
         self.graphs = [None] * n
         self.graph_streams = [None] * n      # per lane: (warm-up stream, capture stream), reused by every re-capture
         self.use_graph = use_graph
+        self.lookahead = int(lookahead)
+
+    def _graph_for(self, li, frames, i, out_size):
+        """The lane's graph for this sequence's steady state, (re-)captured if its shapes changed; None if it cannot be used."""
+        model, g, k = self.models[li], self.graphs[li], self.lookahead
+        shape = tuple(frames[:, i].shape)
+        if k > 0:
+            ok = isinstance(g, LookaheadGraph) and g.frame_shape == shape and g.out_size == out_size and g.k == k
+        else:
+            ok = g is not None and not isinstance(g, LookaheadGraph) and g.frame.shape == frames[:, i].shape and g.out_size == out_size
+        if ok and g.rebind():
+            return g
+        if model.swem_core.memories['update'].bases is None:
+            return None
+        self.graphs[li] = None                # the replaced graph (and its private pool) goes first
+        if k > 0:
+            g = LookaheadGraph(model, shape, out_size, k, streams=self.graph_streams[li], overlap=len(self.models) == 1)
+            g.capture(frames[0, i:i + k])
+        else:
+            # one lane: the frame software-pipelined (+12 % frames/s); several lanes already fill the hardware queues, a
+            # forked graph per lane costs ~10 % there (bench.py --pipeline)
+            cls = PipelinedFrameGraph if len(self.models) == 1 else FrameGraph
+            g = cls(model, shape, out_size, streams=self.graph_streams[li])
+            g.capture(frames[:, i])
+        self.graphs[li], self.graph_streams[li] = g, g.streams
+        return g
 
     def run(self, sequences, seeds=None):
         """sequences: list of (frames (1,T,3,H,W), init_mask (1,N+1,Ho,Wo), out_size); returns one list of (1,Ho,Wo)
@@ -429,10 +611,8 @@ class SequencePool:
         right before its memory is initialised (reproducible random bases whatever the interleaving)."""
         todo = list(enumerate(sequences))
         results = [None] * len(sequences)
-        for g in self.graphs:                # a graph is bound to ONE sequence of ONE run() call: never to an index that a
-            if g is not None:                # later call re-uses (it would replay on the previous sequence's banks)
-                g._bound_to = None
-        lanes = [None] * len(self.models)          # per lane: [seq index, frames, out_size, next frame, preds]
+        k = self.lookahead
+        lanes = [None] * len(self.models)          # per lane: [seq index, frames, out_size, next frame, preds, bound graph]
         main = torch.cuda.current_stream()
         for st in self.streams:
             st.wait_stream(main)
@@ -450,31 +630,28 @@ class SequencePool:
                             mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
                             m0 = ops.resize_planes(init_mask.float().contiguous(), (h, w), 'nearest')
                             model('init', mk16, model('encode_value', frames[:, 0], m0, s16), init_mask)
-                            lanes[li] = [si, frames, (int(out_size[0]), int(out_size[1])), 1, []]
+                            # (a graph is bound to ONE sequence of ONE run() call: the record below is unique per sequence)
+                            lanes[li] = [si, frames, (int(out_size[0]), int(out_size[1])), 1, [], None]
                             continue
-                        si, frames, out_size, i, preds = lanes[li]
-                        g = self.graphs[li]
-                        bound = False
-                        if self.use_graph and i >= 2:
-                            if g is not None and g.frame.shape == frames[:, i].shape and g.out_size == out_size:
-                                bound = getattr(g, '_bound_to', None) is lanes[li] or g.rebind()
-                            if not bound and model.swem_core.memories['update'].bases is not None:
-                                self.graphs[li] = None        # the replaced graph (and its private pool) goes first
-                                # one lane: the frame software-pipelined (+12 % frames/s); several lanes already fill the
-                                # hardware queues, a forked graph per lane costs ~10 % there (bench.py --pipeline)
-                                cls = PipelinedFrameGraph if len(self.models) == 1 else FrameGraph
-                                g = cls(model, frames[:, i].shape, out_size, streams=self.graph_streams[li])
-                                g.capture(frames[:, i])
-                                self.graphs[li], self.graph_streams[li] = g, g.streams
-                                bound = True
-                            if bound:
-                                g._bound_to = lanes[li]        # (the lane record of this sequence: unique per sequence)
-                        if bound:
-                            preds.append(g.run(frames[:, i]).clone())
+                        si, frames, out_size, i, preds, bound = lanes[li]
+                        t = frames.shape[1]
+                        step = 1
+                        if self.use_graph and i >= 2 and bound is None and t - i >= max(k, 1):
+                            bound = lanes[li][5] = self._graph_for(li, frames, i, out_size)
+                            if bound is not None and k > 0:
+                                bound.prime(frames[0, i:i + k])
+                        if bound is not None and k > 0 and t - i >= k:
+                            nxt = frames[0, i + k:i + 2 * k] if t - i >= 2 * k else None
+                            preds.extend(p_.clone() for p_ in bound.run(nxt))
+                            step = k
+                            if nxt is None:
+                                bound = lanes[li][5] = None        # the rest of the sequence (fewer than k frames) eagerly
+                        elif bound is not None and k == 0:
+                            preds.append(bound.run(frames[:, i]).clone())
                         else:
-                            preds.append(frame_step(model, frames[:, i], out_size, memorize=i < frames.shape[1] - 1))
-                        lanes[li][3] = i + 1
-                        if i + 1 >= frames.shape[1]:
+                            preds.append(frame_step(model, frames[:, i], out_size, memorize=i < t - 1))
+                        lanes[li][3] = i + step
+                        if i + step >= t:
                             results[si] = preds
                             lanes[li] = None
         for st in self.streams:

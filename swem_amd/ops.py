@@ -34,8 +34,13 @@ class PlanBook:
     property of the model under test, never of what ran earlier in the process.  Free-standing `ops.*` calls use the
     process-wide default book (`ops.reset_plans()` empties it)."""
 
-    def __init__(self):
+    def __init__(self, fallback=0):
         self.conv, self.match, self.hints = {}, {}, {}
+        # plan hint of a layer shape nobody tuned (0 = the library's heuristic, which picks tile and K-split from the GEMM's
+        # size).  A fixed hint without K-split, e.g. 0x111, makes a layer's arithmetic independent of the batch it is called
+        # with: every output element is then one k-ordered MFMA chain whatever the grid (tests compare batched and per-frame
+        # passes bit for bit under it).
+        self.fallback = fallback
 
     def clear(self):
         self.conv.clear()
@@ -336,6 +341,23 @@ def presplit(t, relu=False, nplanes=3):
     return ent[0]
 
 
+def batch_item(t, j):
+    """Item j of a batched NHWC activation as a (1, H, W, C) view that keeps what the batch carries: the bf16 planes a
+    producing kernel wrote (planes are [plane][C/8][pixel][8] over ALL pixels of the batch: item j is the pixel range
+    [j*H*W, (j+1)*H*W) of every channel group, i.e. the same planes from an offset base with the same strides) and the
+    producer's site, so that a consumer's split request is still reported to the producer."""
+    v = t[j:j + 1]
+    d = t.__dict__
+    sp = d.get('_swem_split')
+    if sp and d.get('_swem_split_ver', t._version) == t._version and t.is_contiguous():
+        off = j * t.shape[1] * t.shape[2] * 8
+        v.__dict__['_swem_split'] = {relu: (planes[:, off:], npl) for relu, (planes, npl) in sp.items()}
+        v.__dict__['_swem_split_ver'] = v._version
+    if '_swem_site' in d:
+        v.__dict__['_swem_site'] = d['_swem_site']
+    return v
+
+
 DGRAD, DGRAD_EH, DGRAD_EW, MASK_POS = 8, 16, 32, 64
 
 
@@ -425,7 +447,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
 
     sig = (cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags, B, H, W) + _PLAN_TAG
     explicit = plan is not None
-    plan = plan if explicit else BOOK.conv.get(sig, 0)
+    plan = plan if explicit else BOOK.conv.get(sig, BOOK.fallback)
     if plan == 0 and len(_PLAN_TAG) == 2 and not AUTOTUNE:
         plan = _PLAN_TAG[1] << 16                  # conv_math((m,)) without tuning: the heuristic tile in math mode m
     if AUTOTUNE and not explicit and plan == 0 and not torch.cuda.is_current_stream_capturing():

@@ -334,6 +334,53 @@ def test_pipelined_frame_graph_matches_eager(lib):
         assert torch.equal(be[k], bg[k]), k
 
 
+@pytest.mark.parametrize('overlap', [True, False], ids=['keys_on_side_stream', 'one_stream'])
+def test_lookahead_graph_matches_sequential_loop(lib, overlap):
+    """evaluator.LookaheadGraph: k = 3 frames per replay, the key encoder of the NEXT three frames as one B = 3 pass next to
+    (or behind) the current three frames' chains.  With plans that do not depend on the batch (PlanBook.fallback = a tile
+    without K-split: every output element is one k-ordered MFMA chain whatever the grid) the index maps AND the memory after
+    the last frame are those of the frame-by-frame loop BIT FOR BIT; the batched outputs carry the bf16 planes their consumers
+    asked for (no split launch inside the captured chains)."""
+    from swem_amd import synth
+    cfg = O.make_cfg(**CFG_A)
+    k, t = 3, 12
+    frames, m0 = synth.make_clip(t=t, h=128, w=192, n_obj=2, seed=9)
+    frames, m0 = frames.to(DEV), m0.to(DEV)
+
+    def run(lookahead, math):
+        model, _ = H.make_model_and_sd(cfg, wseed=4, device=DEV)
+        model.book.fallback = 0x111 | math << 16        # 64x64 tile, no K-split, fp32 MFMA or bf16x3
+        with torch.no_grad():
+            torch.manual_seed(11)
+            mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+            model('init', mk16, model('encode_value', frames[:, 0], m0, s16), m0)
+            preds = [evaluator.frame_step(model, frames[:, i], (128, 192)).clone() for i in (1, 2)]
+            if lookahead:
+                g = evaluator.LookaheadGraph(model, frames[:, 1].shape, (128, 192), k, overlap=overlap).capture(frames[0, 3:3 + k])
+                g.prime(frames[0, 3:3 + k])
+                for i in range(3, t, k):
+                    nxt = frames[0, i + k:i + 2 * k] if i + 2 * k <= t else None
+                    preds += [p.clone() for p in g.run(nxt)]
+                torch.cuda.synchronize()
+                # the captured chains find the planes on the batched key-encoder outputs
+                assert any('_swem_split' in ops.batch_item(x.__dict__['_swem_nhwc'], 1).__dict__ for x in g.keys[0]
+                           if '_swem_nhwc' in x.__dict__) or math == 0
+            else:
+                preds += [evaluator.frame_step(model, frames[:, i], (128, 192)).clone() for i in range(3, t)]
+            bases = {kk: v.clone() for kk, v in model.swem_core.memories['update'].bases.items()}
+        torch.cuda.synchronize()
+        return preds, bases
+
+    for math in (0, 3):
+        pe, be = run(False, math)
+        pg, bg = run(True, math)
+        assert len(pe) == len(pg) == t - 1
+        for i, (a, b) in enumerate(zip(pe, pg)):
+            assert torch.equal(a, b), 'math %d frame %d' % (math, i + 1)
+        for kk in be:
+            assert torch.equal(be[kk], bg[kk]), (math, kk)
+
+
 def test_persistent_pack_is_kept_across_frames(lib):
     """SWEMCore keeps ONE packed copy of the banks: after the first two frames no frame re-packs a bank or allocates a new
     pack (memorize writes the new bank's packed form itself, matching reads it)."""
@@ -539,13 +586,16 @@ def test_module_level_vectors_vs_reference(lib, golden):
     assert logits_close(lg2.cpu(), fx['dec_logits_novalid'])
 
 
-@pytest.mark.parametrize('lanes', [2, 1], ids=['two_lanes', 'one_lane_pipelined'])
-def test_sequence_pool_equals_sequential_evaluation(lib, lanes):
+@pytest.mark.parametrize('lanes,lookahead', [(2, 0), (1, 0), (2, 2), (1, 2)],
+                         ids=['two_lanes', 'one_lane_pipelined', 'two_lanes_lookahead2', 'one_lane_lookahead2'])
+def test_sequence_pool_equals_sequential_evaluation(lib, lanes, lookahead):
     """Two sequences in flight per GPU (two streams, HIP-graph replay re-bound from sequence to sequence) -- or one lane, whose
     graph is the software-pipelined PipelinedFrameGraph -- give the same index maps as evaluating the sequences one after
-    another with the plain loop."""
+    another with the plain loop; so do the look-ahead graphs (two frames per replay, the key encoder batched over them; the
+    plans are pinned to a batch-invariant tile so that the comparison is bit for bit)."""
     cfg = O.make_cfg(**CFG_A)
     models = [H.make_model_and_sd(cfg, 5, DEV)[0] for _ in range(lanes)]
+    models[0].book.fallback = 0x111
     seqs, seeds = [], [11, 12, 13, 14, 15]
     # same shape three times (the lane's graph is re-bound), then one object (re-captured), then another frame size
     for k, (t, hh, ww, n) in enumerate(((5, 240, 432, 2), (4, 240, 432, 2), (6, 240, 432, 2), (5, 240, 432, 1),
@@ -558,11 +608,14 @@ def test_sequence_pool_equals_sequential_evaluation(lib, lanes):
         with torch.no_grad():
             preds, _ = evaluator.evaluate_davis_seq(models[0], frames, [m0] + [None] * (frames.shape[1] - 1), out)
         ref.append([p.clone() for p in preds])
-    pool = evaluator.SequencePool(models, use_graph=True)
+    pool = evaluator.SequencePool(models, use_graph=True, lookahead=lookahead)
     got = pool.run(seqs, seeds=seeds)
     torch.cuda.synchronize()
     assert pool.graphs[0] is not None
-    assert isinstance(pool.graphs[0], evaluator.PipelinedFrameGraph) == (lanes == 1)
+    if lookahead:
+        assert isinstance(pool.graphs[0], evaluator.LookaheadGraph) and pool.graphs[0].overlap == (lanes == 1)
+    else:
+        assert isinstance(pool.graphs[0], evaluator.PipelinedFrameGraph) == (lanes == 1)
     for r, g_ in zip(ref, got):
         assert len(r) == len(g_)
         for a, b in zip(r, g_):
