@@ -58,6 +58,14 @@ struct ConvP {
   unsigned short *ysp[2];
   int ysp_npl[2];     // planes to write per variant: 2 (hi, mid: all consumers run bf16x3) or 3
   long long ysp_ps;   // elements between the planes (M * Cout)
+  // Stream-K (conv_igemm_bf3s_kernel, plan bits 24-27 == 1): sk_workers persistent blocks share the tiles x k-blocks
+  // iteration space in equal contiguous ranges; see the kernel
+  // n / HoWo and n / Wo for 0 <= n < 2^31 as umulhi(n, mul) >> sh (fast_div; a runtime integer division is ~40 dependent
+  // vector instructions, and the row set-up of every block does four of them)
+  unsigned fd_howo_mul, fd_howo_sh, fd_wo_mul, fd_wo_sh;
+  int sk_workers, sk_mtiles, sk_ntiles;
+  float *sk_ws;         // one block tile of fp32 partial sums per worker
+  unsigned *sk_flags;   // one word per worker, zero at launch: "my partial tile is in sk_ws"
 };
 
 // One v_max_f32 per element.  fmaxf() costs two (hipcc first canonicalises the operand with v_max x,x), and in the fp32
@@ -93,6 +101,22 @@ __device__ __forceinline__ float4 mask4(float4 v, bool keep) {
   const unsigned m = keep ? 0xffffffffu : 0u;
   return make_float4(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m),
                      __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
+}
+
+// floor(n / d) for 0 <= n < 2^31 by a host-made multiplier: mul = floor(2^(31+l) / d) + 1, sh = l - 1 with l = ceil(log2 d)
+// (checked exhaustively against // for d < 3000 and on random d < 2^22); d = 1 is mul = 0.
+static inline void fast_div_make(unsigned d, unsigned &mul, unsigned &sh) {
+  if (d <= 1) {
+    mul = 0; sh = 0;
+    return;
+  }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  mul = (unsigned)(((1ull << (31 + l)) / d) + 1);
+  sh = l - 1;
+}
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
+  return mul ? (int)(__umulhi((unsigned)n, mul) >> sh) : n;
 }
 
 // Source pixel coordinate of output coordinate o (carried as o0) under tap k.
@@ -160,11 +184,59 @@ __device__ __forceinline__ void planes_flush(const ConvP &p, const unsigned *lds
   __builtin_amdgcn_s_waitcnt(0xc07f);   // the reads are done before the next tile is staged
 }
 
+// One 32 x 32 tile of SCALED accumulators (acc * scale + shift), staged by the wave in its LDS slice in row order, goes
+// out in ROW layout: lane (row id / 8, channel group id % 8) holds four consecutive channels of one pixel, adds the residual
+// (or applies the mask) from a 16-byte load, applies the ReLU, stores 16 bytes of y -- an instruction covers 8 rows x 128
+// bytes, against 4 rows x 64 bytes (or 2 x 128) of a dword store from the accumulator layout: a quarter of the store
+// instructions (the epilogue was store-issue bound: 9.8k cycles of a 128x128 block, 4.6k of a 64x64 one) -- and writes the
+// bf16 planes of the final values (an even lane and its odd neighbour hold the 8 channels of one 16-byte run).
+__device__ __forceinline__ void out_tile32(const ConvP &p, const unsigned *lds, int m_base, int n_base) {
+  const int lane = threadIdx.x & 63;
+  const bool relu_out = p.flags & SWEM_CONV_RELU_OUT;
+  const int HoWo = p.Ho * p.Wo;
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's staging writes have landed
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int id = lane + 64 * c, row = id >> 3, cg = id & 7;
+    const int m = m_base + row, n = n_base + 4 * cg;
+    const uint4 raw = *reinterpret_cast<const uint4 *>(lds + row * PL_STRIDE + 4 * cg);
+    float4 v = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+    const bool in = m < p.M && n < p.Cout;
+    if (in && p.res) {
+      const int b = fast_div(m, p.fd_howo_mul, p.fd_howo_sh);
+      const float4 rv = *reinterpret_cast<const float4 *>(p.res + (long long)b * p.res_bs + (long long)(m - b * HoWo) * p.Cout + n);
+      if (p.flags & SWEM_CONV_MASK_POS) {
+        v = make_float4(rv.x > 0.f ? v.x : 0.f, rv.y > 0.f ? v.y : 0.f, rv.z > 0.f ? v.z : 0.f, rv.w > 0.f ? v.w : 0.f);
+      } else {
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      }
+    }
+    if (relu_out) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    if (in) *reinterpret_cast<float4 *>(p.y + (long long)m * p.Cout + n) = v;
+#pragma unroll
+    for (int var = 0; var < 2; ++var) {
+      if (!p.ysp[var]) continue;
+      const float4 q = var ? relu4(v) : v;
+      uint2 h, mm, l;
+      split3(q, h, mm, l);
+      const uint2 h2 = make_uint2(__shfl_down(h.x, 1), __shfl_down(h.y, 1));
+      const uint2 m2 = make_uint2(__shfl_down(mm.x, 1), __shfl_down(mm.y, 1));
+      const uint2 l2 = make_uint2(__shfl_down(l.x, 1), __shfl_down(l.y, 1));
+      if (in && (cg & 1) == 0) {
+        unsigned short *d = p.ysp[var] + ((long long)(n >> 3) * p.M + m) * 8;
+        *reinterpret_cast<uint4 *>(d) = make_uint4(h.x, h.y, h2.x, h2.y);
+        *reinterpret_cast<uint4 *>(d + p.ysp_ps) = make_uint4(mm.x, mm.y, m2.x, m2.y);
+        if (p.ysp_npl[var] == 3) *reinterpret_cast<uint4 *>(d + 2 * p.ysp_ps) = make_uint4(l.x, l.y, l2.x, l2.y);
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // the reads are done before the next tile is staged
+}
+
 // Epilogue shared by both kernels: raw split-K partials, or scale/shift (+residual, ReLU) / GLU gate, NHWC stores.
 template <int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][WN], int m0, int n0, int wm, int wn,
                                               int r, int h) {
-  const int HoWo = p.Ho * p.Wo;
   const int mrow0 = m0 + wm * 32 * WM;
   const int ncol0 = n0 + wn * 32 * WN;
   if (p.partial) {  // split-K: raw partial sums, [z][M][Ncols]
@@ -183,7 +255,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][
       }
     return;
   }
-  const bool relu_out = p.flags & SWEM_CONV_RELU_OUT;
   if constexpr (WN == 2) {
     if (p.flags & SWEM_CONV_GLU) {
       // packed columns [group][f|a][32]: this wave's two N tiles are the f and a banks of one group
@@ -205,12 +276,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][
       return;
     }
   }
-  const bool planes = p.ysp[0] || p.ysp[1];
-  unsigned *lds = nullptr;
-  if (planes) {
-    __syncthreads();   // every wave is done with the operand stages: the LDS is free for the plane staging
-    lds = planes_lds();
-  }
+  __syncthreads();   // every wave is done with the operand stages: the LDS is free for the output staging
+  unsigned *lds = planes_lds();
 #pragma unroll
   for (int jn = 0; jn < WN; ++jn) {
     const int n = ncol0 + 32 * jn + r;
@@ -219,39 +286,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int m = mrow0 + 32 * i + acc_row(e, h);
-        float v = acc[i][jn][e] * sc + sh;
-        if (m < p.M && nin) {
-          if (p.res) {
-            int b = m / HoWo;
-            const float rv = p.res[(long long)b * p.res_bs + (long long)(m - b * HoWo) * p.Cout + n];
-            v = (p.flags & SWEM_CONV_MASK_POS) ? (rv > 0.f ? v : 0.f) : v + rv;
-          }
-          if (relu_out) v = fmaxf(v, 0.f);
-          p.y[(long long)m * p.Cout + n] = v;
-        }
-        acc[i][jn][e] = v;     // the final value, kept for the planes below
-      }
-      if (planes) {
-#pragma unroll
-        for (int var = 0; var < 2; ++var) {
-          if (!p.ysp[var]) continue;
-          unsigned lo[16];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            unsigned hm;
-            split_bf16_3(var ? relu1(acc[i][jn][e]) : acc[i][jn][e], hm, lo[e]);
-            lds[acc_row(e, h) * PL_STRIDE + r] = hm;
-          }
-          planes_flush(p, lds, p.ysp[var], mrow0 + 32 * i, ncol0 + 32 * jn, 0);
-          if (p.ysp_npl[var] == 3) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) lds[acc_row(e, h) * PL_STRIDE + r] = lo[e];
-            planes_flush(p, lds, p.ysp[var], mrow0 + 32 * i, ncol0 + 32 * jn, 1);
-          }
-        }
-      }
+      for (int e = 0; e < 16; ++e) lds[acc_row(e, h) * PL_STRIDE + r] = __float_as_uint(acc[i][jn][e] * sc + sh);
+      out_tile32(p, lds, mrow0 + 32 * i, ncol0 + 32 * jn);
     }
   }
 }
@@ -831,7 +867,6 @@ __device__ __forceinline__ f32x4v mfma_bf16_16(uint4 a, uint4 b, f32x4v c) {
 // Same semantics as conv_epilogue; a wave owns TM2 x TN2 tiles = 16 TM2 rows x 16 TN2 columns.
 template <int TM2, int TN2>
 __device__ __forceinline__ void conv_epilogue16(const ConvP &p, f32x4v (&acc)[TM2][TN2], int mrow0, int ncol0, int lane) {
-  const int HoWo = p.Ho * p.Wo;
   const int col = lane & 15, rg = lane >> 4;
   if (p.partial) {
     float *dst = p.partial + (long long)blockIdx.z * (p.M - p.part_m0) * p.Ncols - (long long)p.part_m0 * p.Ncols;
@@ -849,7 +884,6 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP &p, f32x4v (&acc)[TM
       }
     return;
   }
-  const bool relu_out = p.flags & SWEM_CONV_RELU_OUT;
   if constexpr (TN2 == 4) {
     if (p.flags & SWEM_CONV_GLU) {
       // packed columns [group][f|a][32]: tiles 0,1 are f, tiles 2,3 the gates of the same 32 channels
@@ -870,65 +904,32 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP &p, f32x4v (&acc)[TM
       return;
     }
   }
-#pragma unroll
-  for (int j = 0; j < TN2; ++j) {
-    const int n = ncol0 + 16 * j + col;
-    const bool nin = n < p.Ncols;
-    const float sc = (nin && p.scale) ? p.scale[n] : 1.f, sh = (nin && p.shift) ? p.shift[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM2; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int m = mrow0 + 16 * i + 4 * rg + e;
-        float v = acc[i][j][e] * sc + sh;
-        if (m < p.M && nin) {
-          if (p.res) {
-            const int b = m / HoWo;
-            const float rv = p.res[(long long)b * p.res_bs + (long long)(m - b * HoWo) * p.Cout + n];
-            v = (p.flags & SWEM_CONV_MASK_POS) ? (rv > 0.f ? v : 0.f) : v + rv;
-          }
-          if (relu_out) v = fmaxf(v, 0.f);
-          p.y[(long long)m * p.Cout + n] = v;
-        }
-        acc[i][j][e] = v;
-      }
-  }
-  if (!(p.ysp[0] || p.ysp[1])) return;
-  // output planes: 32 x 32 sub-tiles (2 x 2 accumulator tiles) through the wave's LDS slice
-  static_assert(TM2 % 2 == 0 && TN2 % 2 == 0, "the plane staging works on 32 x 32 sub-tiles");
-  __syncthreads();
+  // 32 x 32 sub-tiles (2 x 2 accumulator tiles) through the wave's LDS slice, out in row layout (out_tile32)
+  static_assert(TM2 % 2 == 0 && TN2 % 2 == 0, "the output staging works on 32 x 32 sub-tiles");
+  __syncthreads();   // every wave is done with the operand stages
   unsigned *lds = planes_lds();
 #pragma unroll
-  for (int i0 = 0; i0 < TM2; i0 += 2)
+  for (int j0 = 0; j0 < TN2; j0 += 2) {
+    float sc[2], sh[2];
 #pragma unroll
-    for (int j0 = 0; j0 < TN2; j0 += 2)
+    for (int jj = 0; jj < 2; ++jj) {
+      const int n = ncol0 + 16 * (j0 + jj) + col;
+      const bool nin = n < p.Ncols;
+      sc[jj] = (nin && p.scale) ? p.scale[n] : 1.f;
+      sh[jj] = (nin && p.shift) ? p.shift[n] : 0.f;
+    }
 #pragma unroll
-      for (int var = 0; var < 2; ++var) {
-        if (!p.ysp[var]) continue;
-        unsigned lo[16];
+    for (int i0 = 0; i0 < TM2; i0 += 2) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float v = acc[i0 + ii][j0 + jj][e];
-              unsigned hm;
-              split_bf16_3(var ? relu1(v) : v, hm, lo[(ii * 2 + jj) * 4 + e]);
-              lds[(16 * ii + 4 * rg + e) * PL_STRIDE + 16 * jj + col] = hm;
-            }
-        planes_flush(p, lds, p.ysp[var], mrow0 + 16 * i0, ncol0 + 16 * j0, 0);
-        if (p.ysp_npl[var] == 3) {
-#pragma unroll
-          for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                lds[(16 * ii + 4 * rg + e) * PL_STRIDE + 16 * jj + col] = lo[(ii * 2 + jj) * 4 + e];
-          planes_flush(p, lds, p.ysp[var], mrow0 + 16 * i0, ncol0 + 16 * j0, 1);
-        }
-      }
+          for (int e = 0; e < 4; ++e)
+            lds[(16 * ii + 4 * rg + e) * PL_STRIDE + 16 * jj + col] = __float_as_uint(acc[i0 + ii][j0 + jj][e] * sc[jj] + sh[jj]);
+      out_tile32(p, lds, mrow0 + 16 * i0, ncol0 + 16 * j0);
+    }
+  }
 }
 
 // M16: the products run on v_mfma_f32_16x16x32_bf16 (one k-block = one MFMA k-step) instead of 32x32x16: the same cycles
@@ -937,12 +938,28 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP &p, f32x4v (&acc)[TM
 // the mixed-precision mode of the training step (config.AMP), never the default.
 // KG = k/8 groups per k-block: 4 (32 k, the default) or 2 (16 k: half the LDS per stage -- the 128x128 tile then fits three
 // blocks of four waves per CU instead of one block; a k-block is half of a (channel block, tap) cell of the K order).
+// Stream-K instantiations re-read the launch parameters in every segment from the kernel-argument segment through a pointer
+// the optimiser cannot see through: left alone it hoists ~60 invariant scalar loads (descriptors, strides, epilogue
+// pointers) out of the segment loop, keeps them all live across the k-loop and spills 70 of them -- 30 more vector registers
+// and one resident block per CU instead of two.  (ConvP is the kernel's first argument: offset 0 of the segment.)
+template <bool SK>
+__device__ __forceinline__ const ConvP &segment_params(const ConvP &p) {
+  if constexpr (SK) {
+    typedef const __attribute__((address_space(4))) ConvP CP;
+    CP *pp = (CP *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pp));
+    return *(const ConvP *)pp;
+  } else {
+    return p;
+  }
+}
+
 // PF ("prefetched fragments", round 3): the wave keeps the MFMA fragments of k-block kb in registers and reads those of
 // kb+1 from the LDS BETWEEN the MFMA groups of kb, into a second register set -- its matrix stream no longer stops for its
 // own transfer requests, fragment reads and the stage hand-over, and a stage is free for the next transfer one iteration
 // earlier (its fragments are in registers), so a ring of NST stages keeps NST-1 k-blocks in flight under the MFMAs instead of
 // NST-2 + a hand-over in front of them.  16x16x32 MFMA, one or two planes.
-template <int WM, int WN, int NST, int NW, bool M16, int NPL, int KG = 4, bool PF = false>
+template <int WM, int WN, int NST, int NW, bool M16, int NPL, int KG = 4, bool PF = false, bool SK = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kernel(ConvP p STAMP_ARG) {
   STAMP(0);
   static_assert(KG == 4 || (KG == 2 && !M16 && NW == 4), "16-k blocks: four waves, 32x32x16 MFMA");
@@ -968,9 +985,45 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  int tm, tn;
-  tile_coords(tm, tn, p.xpn);
-  tm += p.mt0;
+  // ---- Stream-K.  A grid of T tiles on S resident-block slots runs ceil(T / S) rounds however few tiles the last one holds
+  // (2x120x216x256 -> 256: 810 tiles of 128x128 on 512 slots = 1.58 -> 2 rounds; most other layers: ~410 blocks = one round
+  // with a fifth of the slots empty).  Here the launch is sk_workers PERSISTENT blocks (every slot one), and worker v takes the
+  // v-th equal share of the (tile, k-block) iterations, tiles in the XCD-aware order: the tail of a tile another worker began
+  // (-> its partial sums go to the workspace), whole tiles, and the head of a last tile (-> this worker adds the partial
+  // sums of the workers that follow, in their order: deterministic, and runs the epilogue).  The producer of a partial tile
+  // works on it FIRST and never waits for anyone; the owner needs it LAST -- no worker waits on a worker that could be
+  // waiting, and a worker that is not yet resident (other streams' kernels hold slots) is dispatched as earlier ones finish.
+  // Hand-over across CUs / XCDs (per-XCD L2s are not coherent): the partial sums are stored and loaded past the caches
+  // (sc0 sc1), the producer drains its stores (vmcnt(0) + block barrier) before its flag, flags are agent-scope atomics.
+  constexpr bool sk = SK;   // (its own instantiation: the segment loop costs the plain kernel ~30 registers)
+  long long sk_it = 0, sk_end = 0, sk_total = 0;
+  int sk_v = 0;
+  if (sk) {
+    const int W_ = p.sk_workers, q8 = W_ >> 3, r8 = W_ & 7, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    sk_v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;   // an XCD's workers share a tile range
+    sk_total = (long long)p.sk_mtiles * p.sk_ntiles * p.nkb;
+    sk_it = sk_total * sk_v / W_;
+    sk_end = sk_total * (sk_v + 1) / W_;
+  }
+  const ConvP &p_arg = p;
+  for (;;) {   // segments of this worker (without stream-K: the one tile of this block)
+  const ConvP &p = segment_params<SK>(p_arg);
+  int tm, tn, seg_k0 = 0, seg_k1 = p.nkb, sk_tile = 0;
+  if (sk) {
+    if (sk_it >= sk_end) break;
+    sk_tile = (int)(sk_it / p.nkb);
+    seg_k0 = (int)(sk_it - (long long)sk_tile * p.nkb);
+    seg_k1 = (int)min((long long)p.nkb, seg_k0 + (sk_end - sk_it));
+    sk_it += seg_k1 - seg_k0;
+    const int ng = p.sk_ntiles / p.xpn, G = p.sk_mtiles * ng;   // tile order of tile_coords
+    const int jn = sk_tile / G, rem = sk_tile - jn * G;
+    tm = rem / ng;
+    tn = jn * ng + rem - tm * ng;
+    __syncthreads();   // every wave has left the previous segment (its epilogue stages planes in the operand LDS)
+  } else {
+    tile_coords(tm, tn, p.xpn);
+    tm += p.mt0;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
   auto src_rsrc = [&](int sidx) __attribute__((always_inline)) {
@@ -990,9 +1043,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
 #pragma unroll
   for (int j = 0; j < WM; ++j) {
     int m = m0 + j * 64 + lane;
-    int b = m / HoWo;
+    int b = fast_div(m, p.fd_howo_mul, p.fd_howo_sh);
     int rem = m - b * HoWo;
-    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    int oy = fast_div(rem, p.fd_wo_mul, p.fd_wo_sh), ox = rem - oy * p.Wo;
     iy0[j] = tap_origin(p, oy);
     ix0[j] = tap_origin(p, ox);
     bidx[j] = m < p.M ? b : -1;
@@ -1003,6 +1056,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
     int n = n0 + j * 64 + lane;
     bvoff[j] = n < p.Ncols ? (unsigned)n * 16u : OOB;
   }
+#ifdef SWEM_PROLOGUE_STAMPS
+  STAMP(6);
+#endif
   // Each wave moves ONE k/8 group (g = wave & 3) of every plane: the slot -> (operand, plane, row run) map is then a
   // compile-time constant and the wave only adds its group's offsets, kept in scalars that advance by one add per k-block.
   // (With eight waves, waves 0-3 move the A image and 4-7 the B image.)  Scalar instructions share the wave's issue
@@ -1027,15 +1083,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
   unsigned long long tmask[WM];
 #pragma unroll
   for (int j = 0; j < WM; ++j) {
+    // bit (ky * KW + kx) = tap row ky valid AND tap column kx valid: KH + KW coordinate tests, not KH * KW
+    unsigned colv = 0;
+    for (int kx = 0; kx < p.KW; ++kx) {
+      int ix;
+      colv |= (tap_coord(p, ix0[j], kx, p.W, ix) ? 1u : 0u) << kx;
+    }
     unsigned long long mk = 0;
-    for (int ky = 0; ky < p.KH; ++ky)
-      for (int kx = 0; kx < p.KW; ++kx) {
-        int iy, ix;
-        const bool ok = bidx[j] >= 0 && tap_coord(p, iy0[j], ky, p.H, iy) && tap_coord(p, ix0[j], kx, p.W, ix);
-        mk |= (unsigned long long)(ok ? 1 : 0) << (ky * p.KW + kx);
-      }
-    tmask[j] = mk;
+    for (int ky = 0; ky < p.KH; ++ky) {
+      int iy;
+      if (tap_coord(p, iy0[j], ky, p.H, iy)) mk |= (unsigned long long)colv << (ky * p.KW);
+    }
+    tmask[j] = bidx[j] >= 0 ? mk : 0ull;
   }
+#ifdef SWEM_PROLOGUE_STAMPS
+  STAMP(7);
+#endif
   auto set_src = [&](const KPos &q) __attribute__((always_inline)) {
     const long long ps = q.src == 0 ? p.ps[0] : (q.src == 1 ? p.ps[1] : p.ps[2]);
     const int npx = q.src == 0 ? p.npx[0] : (q.src == 1 ? p.npx[1] : p.npx[2]);
@@ -1118,9 +1181,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   }
 
-  const int kb_begin32 = blockIdx.z * p.kb_per_split;
+  const int kb_begin32 = sk ? seg_k0 : blockIdx.z * p.kb_per_split;
   const int kb_begin = kb_begin32 * (4 / KG);                       // in this kernel's k-blocks (16 or 32 k)
-  const int kb_end = min(p.nkb, kb_begin32 + p.kb_per_split) * (4 / KG);
+  const int kb_end = (sk ? seg_k1 : min(p.nkb, kb_begin32 + p.kb_per_split)) * (4 / KG);
   // Ring of NST stages.  In iteration kb the transfers of block kb+NST-1 are issued into the stage that was read in
   // iteration kb-1, the MFMAs run on stage kb%NST, then a COUNTED wait (all but the newest (NST-2)*NDMA transfers of
   // this wave, i.e. everything up to block kb+1) and a raw s_barrier publish stage (kb+1)%NST.  __syncthreads() would
@@ -1251,8 +1314,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
       body(std::integral_constant<int, 0>{}, kb);
       if (kb + 1 < kb_end) body(std::integral_constant<int, 1>{}, kb + 1);
     }
+#ifndef SWEM_PROLOGUE_STAMPS
     STAMP_ACC_OUT(6, t_vm);
     STAMP_ACC_OUT(7, t_bar);
+#endif
   } else {
     constexpr int NPRO = SWEM_ISSUE_LATE ? NST : NST - 1;   // blocks issued before the loop
     issue(0);
@@ -1378,13 +1443,71 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
       }
       st = st == NST - 1 ? 0 : st + 1;
     }
+#ifndef SWEM_PROLOGUE_STAMPS
     STAMP_ACC_OUT(6, t_vm);
     STAMP_ACC_OUT(7, t_bar);
+#endif
   }
   STAMP(3);
+  if (sk && (seg_k0 > 0 || seg_k1 < p.nkb)) {
+    // the accumulators as 16-byte chunks per lane, chunk c of every lane contiguous (coalesced): the layout of a partial tile
+    // (chunk c = accumulator tile c of the 16x16 layout, or quarter c % 4 of 32x32 tile c / 4: compile-time register indices)
+    constexpr int NCH = 4 * TM * TN;   // float4 chunks per lane (16 accumulators per 32x32 of the wave tile)
+    constexpr unsigned TILE_BYTES = BM * BN * 4;
+    if (seg_k0 > 0) {   // a tile another worker began: hand the partial sums over, then go on
+      const __amdgpu_buffer_rsrc_t rp =
+          __builtin_amdgcn_make_buffer_rsrc(p.sk_ws + (long long)sk_v * (BM * BN), 0, TILE_BYTES, 0x00020000);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        u32x4 v;
+        if constexpr (M16) {
+          const f32x4v t = acc16[c / (2 * TN)][c % (2 * TN)];
+          v.x = __float_as_uint(t[0]); v.y = __float_as_uint(t[1]); v.z = __float_as_uint(t[2]); v.w = __float_as_uint(t[3]);
+        } else {
+          const f32x16 t = acc[(c / 4) / TN][(c / 4) % TN];
+          v.x = __float_as_uint(t[4 * (c % 4)]); v.y = __float_as_uint(t[4 * (c % 4) + 1]);
+          v.z = __float_as_uint(t[4 * (c % 4) + 2]); v.w = __float_as_uint(t[4 * (c % 4) + 3]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(v, rp, (unsigned)((c * 64 * NW + tid) * 16), 0, 0x11);   // sc0 sc1
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(p.sk_flags + sk_v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    // the head of a tile: add the partial sums of the workers that hold the rest of it, in their order
+    const long long tile_end = (long long)(sk_tile + 1) * p.nkb;
+    for (int u = sk_v + 1; u < p.sk_workers; ++u) {
+      if (sk_total * u / p.sk_workers >= tile_end) break;
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(p.sk_flags + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 24))
+          __builtin_amdgcn_s_sleep(16);
+      }
+      __syncthreads();
+      const __amdgpu_buffer_rsrc_t rp =
+          __builtin_amdgcn_make_buffer_rsrc(p.sk_ws + (long long)u * (BM * BN), 0, TILE_BYTES, 0x00020000);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rp, (unsigned)((c * 64 * NW + tid) * 16), 0, 0x11);
+        if constexpr (M16) {
+          f32x4v t = acc16[c / (2 * TN)][c % (2 * TN)];
+          t[0] += __uint_as_float(v.x); t[1] += __uint_as_float(v.y); t[2] += __uint_as_float(v.z); t[3] += __uint_as_float(v.w);
+          acc16[c / (2 * TN)][c % (2 * TN)] = t;
+        } else {
+          f32x16 t = acc[(c / 4) / TN][(c / 4) % TN];
+          t[4 * (c % 4)] += __uint_as_float(v.x); t[4 * (c % 4) + 1] += __uint_as_float(v.y);
+          t[4 * (c % 4) + 2] += __uint_as_float(v.z); t[4 * (c % 4) + 3] += __uint_as_float(v.w);
+          acc[(c / 4) / TN][(c / 4) % TN] = t;
+        }
+      }
+    }
+  }
   if constexpr (M16) conv_epilogue16<2 * TM, 2 * TN>(p, acc16, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
   else conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, r, h);
   STAMP(4);
+  if (!sk) break;
+  }   // segments
 #ifdef SWEM_EM_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   STAMP(5);
@@ -1467,6 +1590,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
 struct Plan {
   int wm, wn, nsplit, kb_per_split;
 };
+constexpr int SK_MAX_WORKERS = 1024;   // stream-K: resident-block slots of the chip (256 CUs x at most 4 blocks)
 
 // Tuning hook (tools/conv_bench.py): SWEM_CONV_PLAN="wm,wn,nsplit" forces one plan for every launch.
 bool forced_plan(Plan &pl, int nkb, bool glu) {
@@ -1531,30 +1655,69 @@ int launch_bf3(const ConvP &p, dim3 grid, hipStream_t st) {
 // dynamic LDS of a launch: the operand stages, or -- where a small tile's stages are smaller -- the plane staging of the
 // epilogue (one PL_BYTES slice per wave), when output planes are wanted
 static inline size_t lds_with_planes(const ConvP &p, size_t lds, int nwaves) {
-  const size_t need = (p.ysp[0] || p.ysp[1]) ? (size_t)nwaves * PL_BYTES : 0;
+  (void)p;
+  const size_t need = (size_t)nwaves * PL_BYTES;   // (round 3: every epilogue stages its outputs, planes wanted or not)
   return lds < need ? need : lds;
 }
 
-template <int WM, int WN, int NST, int NW, bool M16 = false, int KG = 4, bool PF = false>
-int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st) {
-  if (p.nplanes == 1) {   // plain bf16 (one plane, one product): a third of the LDS, the same tiles
-    constexpr size_t lds1 = NST * 1 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;
-    SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG, PF>), lds1);
-    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 1, KG, PF>), grid, dim3(64 * NW),
-                       lds_with_planes(p, lds1, NW), st, p STAMP_PASS);
+// resident blocks per CU of one instantiation at its dynamic-LDS size (stream-K sizes its persistent grid by it): the
+// runtime's occupancy figure, never more than the LDS allows (the API has been seen one block per CU high near SGPR-count
+// edges, MI355X_MICROARCH.md: an over-sized persistent grid only costs a second, short round here -- no worker ever waits
+// on a worker that has not produced its partial sums first -- but the balance is lost)
+template <typename K>
+int blocks_per_cu(K kernel, int threads, size_t lds) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kernel), threads, lds) != hipSuccess || nb < 1)
+    nb = 1;
+  const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
+  if (by_lds >= 1 && nb > by_lds) nb = by_lds;
+  const int by_waves = 32 / (threads / 64);
+  return nb > by_waves ? by_waves : nb;
+}
+
+// occ != nullptr: do not launch, report the resident blocks per CU of the instantiation the launch would use
+// (p.sk_workers != 0 selects the stream-K instantiation: a query passes -1)
+template <int WM, int WN, int NST, int NW, bool M16, int KG, bool PF, int NPL, bool SK>
+int launch_bf3s_one(const ConvP &p, dim3 grid, hipStream_t st, int *occ) {
+  constexpr size_t lds = NST * NPL * KG * (64 * WM + 1 + 64 * WN + 1) * 16;   // NST stages x NPL planes
+  const size_t dyn = lds_with_planes(p, lds, NW);
+  SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK>), lds);
+  if (occ) {
+    static int nb = blocks_per_cu(conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK>, 64 * NW, dyn);
+    *occ = nb;
     return SWEM_OK;
+  }
+  hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK>), grid, dim3(64 * NW), dyn, st, p STAMP_PASS);
+  return SWEM_OK;
+}
+template <int WM, int WN, int NST, int NW, bool M16 = false, int KG = 4, bool PF = false>
+int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st, int *occ = nullptr) {
+  const bool sk = p.sk_workers != 0;
+  // stream-K instantiations exist for the two-plane ("bf16x3") and one-plane kernels of the eight-wave 16x16x32 tile and of
+  // the prefetched-fragment tiles (what the tuner is offered); everything else runs the plain grid
+  constexpr bool SKOK = M16 && KG == 4 && NST == 2 && (NW == 8 || PF);
+  if (sk && !(SKOK && p.nplanes <= 2)) {
+    if (occ) {
+      *occ = 0;   // no stream-K form of this variant: the caller launches the plain grid
+      return SWEM_OK;
+    }
+    swem_set_error("conv2d_bf16x3: this kernel variant has no stream-K form");
+    return SWEM_E_ARG;
+  }
+  if (p.nplanes == 1) {   // plain bf16 (one plane, one product): a third of the LDS, the same tiles
+    if constexpr (SKOK) {
+      if (sk) return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 1, true>(p, grid, st, occ);
+    }
+    return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 1, false>(p, grid, st, occ);
   }
   if (p.nplanes == 2) {   // "bf16x3": hi and mid planes, three products (hi.hi + hi.mid + mid.hi): two thirds of the LDS
-    constexpr size_t lds2 = NST * 2 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;
-    SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 2, KG, PF>), lds2);
-    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 2, KG, PF>), grid, dim3(64 * NW), lds2, st, p STAMP_PASS);
-    return SWEM_OK;
+    if constexpr (SKOK) {
+      if (sk) return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 2, true>(p, grid, st, occ);
+    }
+    return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 2, false>(p, grid, st, occ);
   }
   if constexpr (NST <= 3 && !PF) {
-    constexpr size_t lds = NST * 3 * KG * (64 * WM + 1 + 64 * WN + 1) * 16;  // NST stages x 3 planes
-    SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 3, KG>), lds);
-    hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, 3, KG>), grid, dim3(64 * NW), lds, st, p STAMP_PASS);
-    return SWEM_OK;
+    return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 3, false>(p, grid, st, occ);
   } else {
     swem_set_error("conv2d_bf16x3: four-stage rings and prefetched fragments need at most two planes");
     return SWEM_E_ARG;
@@ -1565,37 +1728,37 @@ int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st) {
 // 2 = eight waves on the 128x128 tile (two stages), 3 = eight waves, three stages; 4 / 6 = variants 0 / 2 on the
 // 16x16x32 MFMA shape
 template <int WM, int WN>
-int launch_bf3s(const ConvP &p, dim3 grid, hipStream_t st, int variant) {
+int launch_bf3s(const ConvP &p, dim3 grid, hipStream_t st, int variant, int *occ = nullptr) {
   // deeper rings (round 2): with two planes a stage is 33 KB for the 128x128 tile, so FOUR stages fit; the k-loop of every
   // tile was bound by the L2 / Infinity-Cache -> LDS latency of the one or two k-blocks in flight (in-kernel stamps,
   // tools/conv_stamps.py: 2600 cycles per k-block against 768 of MFMA on the 128x128 tile, 830 against 192 on 64x64)
   if (p.nplanes <= 2) {
     if constexpr (WM == 2 && WN == 2) {
-      if (variant == 12) return launch_bf3s_n<2, 2, 4, 8>(p, grid, st);
-      if (variant == 13) return launch_bf3s_n<2, 2, 4, 8, true>(p, grid, st);
+      if (variant == 12) return launch_bf3s_n<2, 2, 4, 8>(p, grid, st, occ);
+      if (variant == 13) return launch_bf3s_n<2, 2, 4, 8, true>(p, grid, st, occ);
     }
     if constexpr (WM == 2 && WN == 2) {
       // prefetched fragments (PF): 5 = four waves of 64x64, two stages (two blocks per CU); 15 = four waves, three stages (one
       // block per CU, one wave per SIMD); 7 = eight waves of 32x64, four stages (one block per CU)
-      if (variant == 5) return launch_bf3s_n<2, 2, 2, 4, true, 4, true>(p, grid, st);
-      if (variant == 15) return launch_bf3s_n<2, 2, 3, 4, true, 4, true>(p, grid, st);
-      if (variant == 7) return launch_bf3s_n<2, 2, 4, 8, true, 4, true>(p, grid, st);
+      if (variant == 5) return launch_bf3s_n<2, 2, 2, 4, true, 4, true>(p, grid, st, occ);
+      if (variant == 15) return launch_bf3s_n<2, 2, 3, 4, true, 4, true>(p, grid, st, occ);
+      if (variant == 7) return launch_bf3s_n<2, 2, 4, 8, true, 4, true>(p, grid, st, occ);
     }
-    if (variant == 10) return launch_bf3s_n<WM, WN, 4, 4>(p, grid, st);
-    if (variant == 11) return launch_bf3s_n<WM, WN, 4, 4, true>(p, grid, st);
+    if (variant == 10) return launch_bf3s_n<WM, WN, 4, 4>(p, grid, st, occ);
+    if (variant == 11) return launch_bf3s_n<WM, WN, 4, 4, true>(p, grid, st, occ);
   }
   if constexpr (WM == 2 && WN == 2) {
-    if (variant == 14) return launch_bf3s_n<2, 2, 3, 8, true>(p, grid, st);
-    if (variant == 2) return launch_bf3s_n<2, 2, 2, 8>(p, grid, st);
-    if (variant == 3) return launch_bf3s_n<2, 2, 3, 8>(p, grid, st);
-    if (variant == 6) return launch_bf3s_n<2, 2, 2, 8, true>(p, grid, st);
-    if (variant == 8) return launch_bf3s_n<2, 2, 2, 4, false, 2>(p, grid, st);   // 16-k blocks: three blocks per CU
-    if (variant == 9) return launch_bf3s_n<2, 2, 3, 4, false, 2>(p, grid, st);   // ... three stages: two blocks per CU
+    if (variant == 14) return launch_bf3s_n<2, 2, 3, 8, true>(p, grid, st, occ);
+    if (variant == 2) return launch_bf3s_n<2, 2, 2, 8>(p, grid, st, occ);
+    if (variant == 3) return launch_bf3s_n<2, 2, 3, 8>(p, grid, st, occ);
+    if (variant == 6) return launch_bf3s_n<2, 2, 2, 8, true>(p, grid, st, occ);
+    if (variant == 8) return launch_bf3s_n<2, 2, 2, 4, false, 2>(p, grid, st, occ);   // 16-k blocks: three blocks per CU
+    if (variant == 9) return launch_bf3s_n<2, 2, 3, 4, false, 2>(p, grid, st, occ);   // ... three stages: two blocks per CU
   }
   if (variant == 4)
-    return (WM * WN == 1) ? launch_bf3s_n<WM, WN, 3, 4, true>(p, grid, st) : launch_bf3s_n<WM, WN, 2, 4, true>(p, grid, st);
+    return (WM * WN == 1) ? launch_bf3s_n<WM, WN, 3, 4, true>(p, grid, st, occ) : launch_bf3s_n<WM, WN, 2, 4, true>(p, grid, st, occ);
   const bool three = (WM * WN == 1) != (variant == 1);
-  return three ? launch_bf3s_n<WM, WN, 3, 4>(p, grid, st) : launch_bf3s_n<WM, WN, 2, 4>(p, grid, st);
+  return three ? launch_bf3s_n<WM, WN, 3, 4>(p, grid, st, occ) : launch_bf3s_n<WM, WN, 2, 4>(p, grid, st, occ);
 }
 
 template <int WM, int WN, bool DB>
@@ -1670,6 +1833,8 @@ extern "C" size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, 
   int Ncols = (flags & SWEM_CONV_GLU) ? 2 * Cout : Cout;
   int nkb = cdiv((long long)KH * KW * Cin, BK);
   Plan pl = resolve_plan(plan, (int)M, Ncols, nkb, flags & SWEM_CONV_GLU);
+  if (((plan >> 24) & 15) == 1)   // stream-K: a partial tile and a flag per worker (workers <= resident slots)
+    return (size_t)SK_MAX_WORKERS * ((size_t)64 * pl.wm * 64 * pl.wn * sizeof(float) + sizeof(unsigned));
   if (pl.nsplit <= 1) {
     TailSplit t = tail_split(plan, pl, (int)M, Ncols, nkb);
     return t.nsplit > 1 ? (size_t)t.nsplit * (M - (long long)t.main_mt * 64 * pl.wm) * Ncols * sizeof(float) : 0;
@@ -1740,6 +1905,7 @@ int conv2d_f32_impl(void *stream, const float *x0, int c0, long long bs0, const 
   const bool glu = flags & SWEM_CONV_GLU;
   SWEM_REQUIRE(!glu || (Cout % 32 == 0 && !res), SWEM_E_SHAPE, "conv2d: GLU needs Cout %% 32 == 0 and no residual");
   ConvP p;
+  p.sk_workers = 0; p.sk_mtiles = p.sk_ntiles = 0; p.sk_ws = nullptr; p.sk_flags = nullptr;
   p.x[0] = x0; p.x[1] = x1 ? x1 : x0; p.x[2] = x2 ? x2 : x0;
   p.c[0] = c0; p.c[1] = c1; p.c[2] = c2;
   p.bs[0] = bs0; p.bs[1] = bs1; p.bs[2] = bs2;
@@ -1759,6 +1925,8 @@ int conv2d_f32_impl(void *stream, const float *x0, int c0, long long bs0, const 
   p.Cout = Cout; p.Ncols = glu ? 2 * Cout : Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.flags = flags;
   p.nkb = cdiv(p.K, BK);
+  fast_div_make((unsigned)(p.Ho * p.Wo), p.fd_howo_mul, p.fd_howo_sh);
+  fast_div_make((unsigned)p.Wo, p.fd_wo_mul, p.fd_wo_sh);
   Plan pl = resolve_plan(plan, p.M, p.Ncols, p.nkb, glu);
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;
@@ -1902,6 +2070,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   const bool glu = flags & SWEM_CONV_GLU;
   SWEM_REQUIRE(!glu || (Cout % 32 == 0 && !res), SWEM_E_SHAPE, "conv2d_bf16x3: GLU needs Cout %% 32 == 0, no residual");
   ConvP p;
+  p.sk_workers = 0; p.sk_mtiles = p.sk_ntiles = 0; p.sk_ws = nullptr; p.sk_flags = nullptr;
   p.x[0] = p.x[1] = p.x[2] = nullptr;
   p.xs[0] = static_cast<const unsigned short *>(x0);
   p.xs[1] = static_cast<const unsigned short *>(x1 ? x1 : x0);
@@ -1930,6 +2099,8 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   p.Cout = Cout; p.Ncols = glu ? 2 * Cout : Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.flags = flags;
   p.nkb = cdiv(p.K, BK);
+  fast_div_make((unsigned)(p.Ho * p.Wo), p.fd_howo_mul, p.fd_howo_sh);
+  fast_div_make((unsigned)p.Wo, p.fd_wo_mul, p.fd_wo_sh);
   Plan pl = resolve_plan(plan, p.M, p.Ncols, p.nkb, glu);
   SWEM_REQUIRE(w_bs == 0 || (p.Ho * p.Wo) % 128 == 0, SWEM_E_SHAPE,
                "conv2d_bf16x3: per-batch filters need Ho*Wo (%d) to be a multiple of the 128-row tile", p.Ho * p.Wo);
@@ -1976,13 +2147,44 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   }
   if (p.xpn != 1 && p.xpn != 2 && p.xpn != 4 && p.xpn != 8) p.xpn = 1;
   if (ntiles % p.xpn) p.xpn = 1;
-  auto run = [&](const ConvP &q, dim3 grid) {
-    if (pl.wm == 2 && pl.wn == 2) return launch_bf3s<2, 2>(q, grid, st, variant);
-    if (pl.wm == 1 && pl.wn == 2) return launch_bf3s<1, 2>(q, grid, st, variant);
-    return launch_bf3s<1, 1>(q, grid, st, variant);
+  auto run = [&](const ConvP &q, dim3 grid, int *occ = nullptr) {
+    if (pl.wm == 2 && pl.wn == 2) return launch_bf3s<2, 2>(q, grid, st, variant, occ);
+    if (pl.wm == 1 && pl.wn == 2) return launch_bf3s<1, 2>(q, grid, st, variant, occ);
+    return launch_bf3s<1, 1>(q, grid, st, variant, occ);
   };
-  const TailSplit tl = tail_split(plan, pl, p.M, p.Ncols, p.nkb);
   int rc;
+  if (((plan >> 24) & 15) == 1 && w_bs == 0) {
+    // stream-K (see the kernel): persistent workers, one per resident-block slot, equal shares of the tiles x k-blocks
+    int nb = 1;
+    p.sk_workers = -1;                           // (query the stream-K instantiation)
+    if ((rc = run(p, dim3(1, 1, 1), &nb))) return rc;
+    p.sk_workers = 0;
+    const long long iters = (long long)mtiles * ntiles * p.nkb;
+    long long W = (long long)nb * swem_device_cus();
+    if (W > iters / 4) W = iters / 4;            // at least four k-blocks per worker
+    if (W > SK_MAX_WORKERS) W = SK_MAX_WORKERS;
+    if (W >= 2) {
+      const size_t tile = (size_t)64 * pl.wm * 64 * pl.wn * sizeof(float);
+      const size_t need = (size_t)W * tile + (size_t)W * sizeof(unsigned);
+      SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_bf16x3: workspace %zu < %zu bytes (stream-K)", ws_bytes, need);
+      p.kb_per_split = p.nkb;
+      p.partial = nullptr;
+      p.sk_workers = (int)W; p.sk_mtiles = mtiles; p.sk_ntiles = ntiles;
+      p.sk_ws = static_cast<float *>(ws);
+      p.sk_flags = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + (size_t)W * tile);
+      if (hipMemsetAsync(p.sk_flags, 0, (size_t)W * sizeof(unsigned), st) != hipSuccess) {
+        swem_set_error("conv2d_bf16x3: hipMemsetAsync of the stream-K flags failed");
+        return SWEM_E_HIP;
+      }
+      static int dbg = -1;
+      if (dbg < 0) dbg = getenv("SWEM_SK_DEBUG") ? 1 : 0;
+      if (dbg) fprintf(stderr, "stream-K: %d x %d tiles x %d k-blocks on %lld workers (%d blocks per CU)\n", mtiles, ntiles, p.nkb, W, nb);
+      if ((rc = run(p, dim3((unsigned)W, 1, 1)))) return rc;
+      SWEM_CHECK_LAUNCH("conv_igemm_bf3s_kernel");
+      return SWEM_OK;
+    }
+  }
+  const TailSplit tl = tail_split(plan, pl, p.M, p.Ncols, p.nkb);
   if (tl.nsplit > 1) {
     if ((rc = run(p, dim3(tl.main_mt, ntiles, 1)))) return rc;      // the whole rounds
     ConvP t = p;                                                    // the last round's tile rows, split over K

@@ -401,7 +401,9 @@ class LookaheadGraph:
             if self.streams is None:
                 self.streams = (ops.new_stream(), ops.new_stream())
             if self.side is None:
-                self.side = overlapping_streams(2)[1] if self.overlap else self.streams[1]
+                # (the chains and the side branch replay on a PROBED pair: two streams may share a hardware queue, and the
+                # stream the caller happens to be on was never probed against anything)
+                self.side = tuple(overlapping_streams(2)) if self.overlap else ()
             warm, cap = self.streams
             saved = {key: v.clone() for key, v in self.state.items()}
             warm.wait_stream(torch.cuda.current_stream())
@@ -466,16 +468,21 @@ class LookaheadGraph:
         p, main = self.p, torch.cuda.current_stream()
         if next_frames_k is not None:
             self.frames[1 - p].copy_(next_frames_k)
-            if self.overlap:
-                self.side.wait_stream(main)
-                with torch.cuda.stream(self.side):
-                    self.kg[1 - p].replay()
-        self.cg[p].replay()
-        if next_frames_k is not None:
-            if self.overlap:
-                main.wait_stream(self.side)
-            else:
+        if self.overlap and next_frames_k is not None:
+            s0, s1 = self.side
+            s0.wait_stream(main)
+            s1.wait_stream(main)
+            with torch.cuda.stream(s0):
+                self.cg[p].replay()
+            with torch.cuda.stream(s1):
                 self.kg[1 - p].replay()
+            main.wait_stream(s0)
+            main.wait_stream(s1)
+        else:
+            self.cg[p].replay()
+            if next_frames_k is not None:
+                self.kg[1 - p].replay()
+        if next_frames_k is not None:
             self.p = 1 - p
         else:
             self.primed = False

@@ -548,6 +548,9 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
                             cands.append(base | 5 << 20)      # prefetched fragments: four waves of 64x64, two stages
                             cands.append(base | 15 << 20)     # ... three stages (one block per CU)
                             cands.append(base | 7 << 20)      # ... eight waves of 32x64, four stages
+                            if ns == 1 and nkb >= 16:         # stream-K (plan bits 24-27 = 1): persistent workers, equal shares
+                                cands.append(base | 6 << 20 | 1 << 24)
+                                cands.append(base | 5 << 20 | 1 << 24)
                     if ns == 1 and blocks > 256 and nkb >= 16:   # tail split: the last, partly filled round over K
                         for ts in (4, 8):
                             cands.append(base | ts << 24)

@@ -247,7 +247,7 @@ def test_conv2d_plans_and_math_modes(lib, plan):
 
 
 @pytest.mark.parametrize('plan', [0x20011, 0x20021, 0x20022, 0x120021, 0x220022, 0x420011, 0x420021, 0x620022, 0x20221, 0x820022, 0x920022,
-                                  0x4020021, 0xa20011, 0xd20022, 0x520022, 0x720022, 0xf20022], ids=lambda p: '%#x' % p)
+                                  0x4020021, 0xa20011, 0xd20022, 0x520022, 0x720022, 0xf20022, 0x1620022, 0x1020011], ids=lambda p: '%#x' % p)
 def test_conv2d_plain_bf16_mode(lib, plan):
     """Math mode 2 (mixed-precision training, config.AMP): operands rounded to bf16 once, ONE MFMA product, fp32
     accumulate.  On bf16-representable operands it is the fp32 convolution up to summation order; on general ones it
@@ -273,7 +273,7 @@ def test_conv2d_plain_bf16_mode(lib, plan):
 
 @pytest.mark.parametrize('plan', [0x00011, 0x00022, 0x00211, 0x10021, 0x10022, 0x10321, 0x30011, 0x30021, 0x30022, 0x230022,
                                   0x430011, 0x430021, 0x630022, 0x30221, 0x830022, 0x4030021, 0x8030022, 0xb30011, 0xd30022, 0xe30022,
-                                  0x530022, 0x730022, 0xf30022],
+                                  0x530022, 0x730022, 0xf30022, 0x1630022, 0x1030011, 0x1530022],
                          ids=lambda p: '%#x' % p)
 def test_conv2d_fused_output_planes(lib, plan):
     """The conv epilogues (32x32 and 16x16 accumulator layouts, the split-K reduce kernel, the tail split; fp32, bf16x6 and
@@ -385,7 +385,8 @@ def test_upsample_add_fused_output_planes(lib):
 
 @pytest.mark.parametrize('plan', [0x30011, 0x30021, 0x30022, 0x130021, 0x230022, 0x430011, 0x430021, 0x630022, 0x30221, 0x830022,
                                   0x930022, 0x4030021, 0xa30011, 0xb30021, 0xa30022, 0xc30022, 0xd30022, 0xe30022, 0xa30211,
-                                  0x530022, 0x730022, 0xf30022, 0x530222, 0x4530022], ids=lambda p: '%#x' % p)
+                                  0x530022, 0x730022, 0xf30022, 0x530222, 0x4530022,
+                                  0x1630022, 0x1030011, 0x1530022, 0x1030021, 0x1230022, 0x1830022, 0x1430011], ids=lambda p: '%#x' % p)
 def test_conv2d_bf16x3_mode(lib, plan):
     """Math mode 3 ("bf16x3"): each operand is taken as hi + mid (two bf16 terms = 16 significant bits) and the product is
     hi.hi + hi.mid + mid.hi in fp32 -- half the matrix-core work of bf16x6.  On operands that HAVE only 16 significant bits it
@@ -449,3 +450,29 @@ def test_conv2d_tail_split(lib, plan):
     assert float((y - base).abs().max()) < 1e-4
     # the workspace query covers the tail's partial sums
     assert ops._lib.query('swem_conv2d_workspace', 2, 120, 216, 64, 128, 3, 3, 1, 1, 1, plan) > 0
+
+
+@pytest.mark.parametrize('shape', [(2, 120, 216, 256, 256, 3), (2, 60, 108, 512, 256, 3), (2, 30, 54, 1280, 512, 3), (1, 30, 54, 256, 1024, 1),
+                                   (1, 37, 53, 96, 160, 3)], ids=lambda v: 'x'.join(str(e) for e in v))
+@pytest.mark.parametrize('plan', [0x1630022, 0x1030011], ids=lambda p: '%#x' % p)
+def test_conv2d_stream_k(lib, shape, plan):
+    """Plan bits 24-27 == 1: stream-K.  Persistent workers share the tiles x k-blocks iteration space in equal ranges; a
+    tile that straddles workers is finished by the worker that holds its head, which adds the others' partial sums in a fixed
+    order.  The result equals the plain launch's up to fp32 summation order (a straddled tile's sum is cut at other k than
+    a K-split would cut it), is the SAME on every launch (deterministic: no atomics on the data), and the config-B layer
+    shapes -- one to five workers per tile, tiles that no worker shares -- all agree with the fp32 convolution."""
+    B, H, W, Cin, Cout, k = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (0.5 / (Cin * k * k) ** 0.5)
+    b = torch.randn(Cout, generator=g) * 0.1
+    pack = ops.pack_conv(w.to(DEV), b.to(DEV), None, 1, k // 2)
+    xs = nhwc(x)
+    base = ops.conv2d([xs], pack, relu_in=True, relu_out=True, plan=plan & 0xffffff)
+    y = ops.conv2d([xs], pack, relu_in=True, relu_out=True, plan=plan)
+    y2 = ops.conv2d([xs], pack, relu_in=True, relu_out=True, plan=plan)
+    assert torch.equal(y, y2), 'stream-K must be deterministic'
+    err = float((y - base).abs().max() / base.abs().max())
+    assert err < 1e-5, err
+    ref = F.relu(F.conv2d(F.relu(x), w, b, padding=k // 2))
+    close(back(y), ref, 2e-5, 'stream-K conv')

@@ -24,6 +24,7 @@ def build():
         o = '/tmp/%s_stamps.o' % name
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
                                '-DSWEM_EM_STAMPS', '-DSWEM_STAMP_BLOCK=%d' % int(os.environ.get('SWEM_STAMP_BLOCK', '0')),
+                               *(['-DSWEM_PROLOGUE_STAMPS'] if os.environ.get('SWEM_PROLOGUE_STAMPS') else []),
                                '-c', os.path.join(csrc, name + '.hip'), '-o', o])
         objs.append(o)
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
@@ -81,7 +82,8 @@ def main():
         if not kk:
             break
         acc = {j: int(row[j, 0]) for j in range(8) if int(row[j, 1]) == -1}      # accumulated regions (STAMP_ACC_OUT)
-        pts = [j for j in range(kk) if j not in acc]
+        pts = sorted((j for j in range(8) if int(row[j, 0]) != 0 and j not in acc), key=lambda j: int(row[j, 0]))
+        print('   stamp order:', pts)
         print('launch %d: cycles %s | ns %s | gap since previous launch\'s last stamp: %s ns | cycles inside the counted vmcnt '
               'waits %s, inside lgkmcnt(0) + s_barrier %s (wave 0 of the block, k-loop)'
               % (i, [int(row[j, 0] - row[0, 0]) for j in pts], [(int(row[j, 1]) - int(row[0, 1])) * 10 for j in pts],
