@@ -373,6 +373,9 @@ class LookaheadGraph:
         self.frame_shape = tuple(frame_shape)                 # (1, 3, H, W)
         self.frames = [torch.empty((self.k,) + self.frame_shape[1:], dtype=torch.float32, device=dev) for _ in range(2)]
         self.state = {key: v.clone() for key, v in upd.items()}
+        # the frames of a group write their new bases alternately into the second set and back into the first: no copy of
+        # the update bank per frame (an odd k pays one copy back per group)
+        self.state2 = {key: torch.empty_like(v) for key, v in self.state.items()}
         core.memories['update'].bases = self.state
         self.first = core.memories['first'].bases
         self.kg = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
@@ -385,11 +388,16 @@ class LookaheadGraph:
     def _chains(self, p):
         core = self.model.swem_core
         preds = []
+        sets = (self.state, self.state2)
         for j in range(self.k):
+            core._next_out = sets[(j + 1) % 2]
             preds.append(frame_chain(self.model, key_item(self.keys[p], j), self.frames[p][j:j + 1], self.out_size))
-            new = core.memories['update'].bases
+            core._next_out = None
+            core.memories['update'].bases = sets[(j + 1) % 2]       # (the tensors memorize wrote, under their own names)
+            core.restamp()
+        if self.k % 2:
             for key in self.state:
-                self.state[key].copy_(new[key])
+                self.state[key].copy_(self.state2[key])
             core.memories['update'].bases = self.state
             core.restamp()
         return preds

@@ -191,7 +191,7 @@ class SWEMCore(nn.Module):
         return kappa.view(B, N, 2, -1, L), zita.view(B, N, 2, 1, L)
 
     # ------------------------------------------------------------------ modules.py:129-168
-    def swem(self, x, v, masks, bases_=None, pack=None, prior_packed=False, bank=1):
+    def swem(self, x, v, masks, bases_=None, pack=None, prior_packed=False, bank=1, out=None):
         B, Ck, H, W = x.shape
         N = masks.shape[1]
         if bases_ is None:
@@ -217,7 +217,9 @@ class SWEMCore(nn.Module):
             outs.append(ops.memorize(xp[b], vp[b], mk[b], kappa_[b].reshape(N, 2, Ck, L).contiguous(),
                                      nu_[b].reshape(N, 2, -1, L).contiguous(), zita_[b].reshape(N, 2, L).contiguous(),
                                      self.n_iters, self.tau, pack=pack if B == 1 else None,
-                                     prior_packed=prior_packed and N_new <= 0 and B == 1, bank=bank))
+                                     prior_packed=prior_packed and N_new <= 0 and B == 1, bank=bank,
+                                     out=None if (out is None or B != 1) else (
+                                         out['kappa'].view(N, 2, Ck, L), out['nu'].view(N, 2, -1, L), out['zita'].view(N, 2, L))))
         if B == 1:
             kappa, nu, zita = outs[0]
             return {'kappa': kappa.view(B, N, 2, Ck, L), 'nu': nu.view(B, N, 2, -1, L), 'zita': zita.view(B, N, 2, 1, L)}
@@ -250,7 +252,12 @@ class SWEMCore(nn.Module):
         pack = None if (grown or qk.shape[0] != 1) else self._pack_for(N, qk.shape[1], qk.device)
         bank = 0 if frame0 else 1
         prior_packed = pack is not None and update.bases is not None and self._stamped(1, update.bases)
-        bases = self.swem(qk, qv, masks, prior, pack=pack, prior_packed=prior_packed, bank=bank)
+        # (a frame graph may name the tensors the new bases go to -- its two static state sets alternate, so no copy moves
+        # the update bank back into a fixed buffer: evaluator.LookaheadGraph; consumed by this one call)
+        out, self._next_out = getattr(self, '_next_out', None), None
+        if out is not None and (grown or frame0 or out['kappa'].shape != prior['kappa'].shape):
+            out = None
+        bases = self.swem(qk, qv, masks, prior, pack=pack, prior_packed=prior_packed, bank=bank, out=out)
         if frame0:
             first.update(bases)
         else:

@@ -878,15 +878,24 @@ def em_mstep(A, per_object, z, prev, zita_prev, P, want_kn=False):
     return out, zita, kn
 
 
-def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau, pack=None, prior_packed=False, bank=1):
+def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau, pack=None, prior_packed=False, bank=1, out=None):
     """x (P,C); v (N,P,V); masks (N,2,P); bases (N,2,C,L)/(N,2,V,L)/(N,2,L) -> new bases.
-    pack = (mkn, mvp): matching's packed banks, kept current by this call (swem_memorize_packed_f32)."""
+    pack = (mkn, mvp): matching's packed banks, kept current by this call (swem_memorize_packed_f32).
+    out = (kappa, nu, zita): write the new bases there (tensors of the priors' shapes that are NOT the priors: the prior is
+    read by every M step); default: fresh tensors."""
     for t in (x, v, masks, kappa_prev, nu_prev, zita_prev):
         _chk(t)
     P, Cc = x.shape
     N, _, V = v.shape
     L = kappa_prev.shape[-1]
-    kappa, nu, zita = torch.empty_like(kappa_prev), torch.empty_like(nu_prev), torch.empty_like(zita_prev)
+    if out is not None:
+        kappa, nu, zita = (_chk(t) for t in out)
+        if (kappa.shape != kappa_prev.shape or nu.shape != nu_prev.shape or zita.shape != zita_prev.shape
+                or kappa.data_ptr() == kappa_prev.data_ptr() or nu.data_ptr() == nu_prev.data_ptr()
+                or zita.data_ptr() == zita_prev.data_ptr()):
+            raise _lib.SwemHipError('memorize: out must have the priors\' shapes and must not alias them')
+    else:
+        kappa, nu, zita = torch.empty_like(kappa_prev), torch.empty_like(nu_prev), torch.empty_like(zita_prev)
     wsb = _lib.query('swem_memorize_workspace', N, Cc, V, P, L)
     ws = workspace(wsb, x.device)
     if pack is not None:

@@ -837,3 +837,165 @@ def test_two_ranks_one_clip_each_equal_one_rank_two_clips(lib, tmp_path, graph):
     assert torch.equal(one, got['param']), d
     for a, b in zip(got['hist'], hist):
         assert a == pytest.approx(b, rel=1e-6)
+
+
+AMP_LAYERS = ('key_encoder.res2.0.conv2', 'key_encoder.layer2.0.conv2', 'key_encoder.layer3.5.conv3', 'key_proj.key_proj',
+              'value_encoder.layer2.0.conv1', 'value_encoder.fuser.block1.conv1', 'value_encoder.fuser.block2.conv2',
+              'decoder.compress.conv1', 'decoder.up_16_8.out_conv.conv1', 'decoder.up_8_4.skip_conv',
+              'decoder.up_8_4.out_conv.conv2')
+
+
+@pytest.mark.parametrize('case_name', ['r50k256', 'r50k256n5'], ids=['two_objects', 'five_objects_one_invalid'])
+def test_amp_step_stage_by_stage_at_the_training_shapes(lib, case_name):
+    """BASELINE configs C / D at their STATED precision: one config.AMP training step at the reference's training shapes
+    (ResNet-50, K = 256, 3 x 384x384 frames, 2 objects / 5 objects with one invalid), checked where the rounding step function
+    cannot compound -- stage by stage, TEACHER-FORCED: for eleven layers that span every stage of the step (trunk 3x3 /
+    strided / 1x1, key projection, value encoder, the two-source fuser, decoder at 1/16, 1/8 and 1/4) the first call's inputs
+    (activation, filters, output gradient) are taken out of the running step, and the three GEMMs the step ran on them
+    (forward, data gradient, weight gradient) are compared with the fp32 convolution of the bf16-ROUNDED operands
+    (the arithmetic of oracle.ROUNDED_CONV / _ConvRounded): <= 1e-4.  The check discriminates: the same GEMMs on the
+    UNROUNDED operands are 1e-3 away, and every bf16-mode result must be at least 3e-4 from them."""
+    import torch.nn.functional as F
+    from swem_amd import autograd as A, ops
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    case = tc['cases'][case_name]
+    cfg = O.make_cfg(**case['cfg'])
+    frames, init_mask, label, valid = [t.to(DEV) for t in H.train_batch(case)]
+    model, _ = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+    names = {id(p): n[:-len('.weight')] for n, p in model.named_parameters() if n.endswith('.weight')}
+    want = set(AMP_LAYERS)
+    rec, seen = {}, set()
+    real_fwd, real_bwd = A._Conv.forward, A._Conv.backward
+
+    def fwd(ctx, weight, bias, residual, meta, *srcs):
+        y = real_fwd(ctx, weight, bias, residual, meta, *srcs)
+        name = names.get(id(weight))
+        if name in want and name not in seen:
+            seen.add(name)
+            ctx._amp_rec = name
+            rec[name] = dict(meta=meta, w=weight.detach().clone(), b=None if bias is None else bias.detach().clone(),
+                             res=None if residual is None else residual.detach().clone(), srcs=[s.detach().clone() for s in srcs],
+                             y=y.detach().clone(), fwd_math=(ops.MATH_RAN or {}).copy())
+        return y
+
+    def bwd(ctx, dy):
+        out = real_bwd(ctx, dy)
+        name = getattr(ctx, '_amp_rec', None)
+        if name is not None:
+            r = rec[name]
+            stride, pad, relu_in, batch, cin_pad = r['meta']
+            weight = ctx.saved_tensors[0]
+            srcs = list(ctx.saved_tensors[2:])
+            r['dy'] = dy.detach().clone()
+            r['dx'] = [None if g is None else g.detach().clone() for g in out[4:]]
+            buf = torch.zeros_like(weight)
+            saved = (A._LANE, A._LANE_GRADS)
+            A.use_lane(saved[0], {id(weight): buf})
+            try:
+                A._wgrad(dy.contiguous(), srcs, weight, stride, pad, relu_in)
+            finally:
+                A.use_lane(*saved)
+            r['dw'] = buf
+            cs = [s.shape[3] for s in srcs]
+            r['wgrad_math'] = A.wgrad_math(cs, weight.shape[0], weight.shape[2], weight.shape[3], dy.shape[0] * dy.shape[1] * dy.shape[2])
+        return out
+    A._Conv.forward, A._Conv.backward = staticmethod(fwd), staticmethod(bwd)
+    try:
+        tr = SWEMTrainer(dict(SOLVER=tc['solver_cfg'], LOSS=tc['loss_cfg'], AMP=True), model, use_graph=False, lanes=1)
+        torch.manual_seed(91)
+        losses, _ = tr.one_step(frames, init_mask, valid, label, 45)
+    finally:
+        A._Conv.forward, A._Conv.backward = real_fwd, real_bwd
+    torch.cuda.synchronize()
+    assert math.isfinite(float(losses['total_loss'])) and seen == want, sorted(want - seen)
+    r16 = lambda t: t.bfloat16().float()
+    nchw = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu()
+    rows = {}
+    for name in AMP_LAYERS:
+        r = rec[name]
+        stride, pad, relu_in, batch, cin_pad = r['meta']
+        w = r['w'].cpu()
+        B = r['y'].shape[0]
+        xs = [nchw(s) for s in r['srcs']]
+        x = torch.cat([t.expand(B, -1, -1, -1) if t.shape[0] == 1 and B > 1 else t for t in xs], 1)
+        xa = F.relu(x) if relu_in else x
+        dy = nchw(r['dy'])
+        presplit = all(s.shape[3] % 32 == 0 for s in r['srcs'])          # (ops.conv2d: the pre-split kernel's condition)
+        out = {'amp_forward': presplit, 'amp_dgrad': w.shape[0] % 32 == 0, 'amp_wgrad': r['wgrad_math'] == 2}
+
+        def refs(rounded_x, rounded_w, rounded_d):
+            xx, ww, dd = (r16(xa) if rounded_x else xa), (r16(w) if rounded_w else w), (r16(dy) if rounded_d else dy)
+            return xx, ww, dd
+        # forward
+        for tag, rd in (('rounded', True), ('fp32', False)):
+            xx, ww, _ = refs(rd, rd, False)
+            y = F.conv2d(xx, ww, None if r['b'] is None else r['b'].cpu(), stride=stride, padding=pad)
+            if r['res'] is not None:
+                y = y + nchw(r['res'])
+            out['fwd_vs_' + tag] = H.rel_err(nchw(r['y']), y)
+            # data gradient (towards the first source that asked for one), input-ReLU mask folded in
+            _, ww, dd = refs(False, rd, rd)
+            dx = torch.nn.grad.conv2d_input(x.shape, ww, dd, stride=stride, padding=pad)
+            if relu_in:
+                dx = dx * (x > 0)
+            off = 0
+            for s, g in zip(xs, r['dx']):
+                c = s.shape[1]
+                if g is not None and s.shape[0] == B:
+                    out['dgrad_vs_' + tag] = H.rel_err(nchw(g), dx[:, off:off + c])
+                    break
+                off += c
+            xx, _, dd = refs(rd, False, rd)
+            dw = torch.nn.grad.conv2d_weight(xx, w.shape, dd, stride=stride, padding=pad)
+            out['wgrad_vs_' + tag] = H.rel_err(r['dw'].cpu(), dw)
+        rows[name] = out
+        print(name, {k: ('%.2e' % v if isinstance(v, float) else v) for k, v in out.items()})
+        for gemm, flag in (('fwd', out['amp_forward']), ('dgrad', out['amp_dgrad']), ('wgrad', out['amp_wgrad'])):
+            if gemm + '_vs_rounded' not in out:
+                continue
+            good, other = ('rounded', 'fp32') if flag else ('fp32', 'rounded')
+            assert out['%s_vs_%s' % (gemm, good)] < 1e-4, (name, gemm, out)
+            if flag:
+                assert out['%s_vs_%s' % (gemm, other)] > 3e-4, (name, gemm, 'not the bf16-operand arithmetic', out)
+    H.record_parity('amp_stages_%s' % case_name, {'total_loss': float(losses['total_loss']), 'layers': rows})
+
+
+def test_amp_training_throughput_property_run(lib):
+    """Configs C / D, driver-visible: four clips of 3 x 384x384 frames, 2 objects, ResNet-50, K = 256 per step under config.AMP
+    (graph replay after the two eager tuning steps).  Properties: every loss finite, the loss falls over the run on this
+    fixed batch, the graph-replayed steps are deterministic in time order; the sustained clips/s go into the parity report."""
+    import time
+    from swem_amd import ops
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    case = dict(tc['cases']['r50k256'], b=4, valid=[[1, 1, 1]] * 4)
+    cfg = O.make_cfg(**case['cfg'])
+    frames, init_mask, label, valid = [t.to(DEV) for t in H.train_batch(case)]
+    model, _ = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+    tr = SWEMTrainer(dict(SOLVER=dict(tc['solver_cfg'], BASE_LR=1e-4, PRETRAIN_ITERS=[1000, 2000]), LOSS=tc['loss_cfg'], AMP=True),
+                     model, lanes=4)
+    torch.manual_seed(7)
+    hist = []
+    ops.AUTOTUNE = True
+    for it in range(2):
+        hist.append(float(tr.one_step(frames, init_mask, valid, label, 45 + it)[0]['total_loss']))
+    ops.AUTOTUNE = False
+    for it in range(2, 4):
+        hist.append(float(tr.one_step(frames, init_mask, valid, label, 45 + it)[0]['total_loss']))
+    assert tr._graph is not None
+    torch.cuda.synchronize()
+    n = 12
+    t0 = time.perf_counter()
+    last = None
+    for it in range(n):
+        last = tr.one_step(frames, init_mask, valid, label, 49 + it)[0]['total_loss']
+    ops.spin_sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    hist.append(float(last))
+    assert all(math.isfinite(v) for v in hist), hist
+    assert hist[-1] < hist[0], hist
+    H.record_parity('amp_training_throughput', {'clips_per_s': 4 * n / dt, 'ms_per_step': 1e3 * dt / n, 'clips_per_step': 4,
+                                                 'steps_timed': n, 'loss_first_last': [hist[0], hist[-1]],
+                                                 'config': 'ResNet-50, K = 256, 3 x 384x384 frames, 2 objects, config.AMP, 4 lanes, graph replay'})
