@@ -854,7 +854,7 @@ def test_amp_step_stage_by_stage_at_the_training_shapes(lib, case_name):
     (activation, filters, output gradient) are taken out of the running step, and the three GEMMs the step ran on them
     (forward, data gradient, weight gradient) are compared with the fp32 convolution of the bf16-ROUNDED operands
     (the arithmetic of oracle.ROUNDED_CONV / _ConvRounded): <= 1e-4.  The check discriminates: the same GEMMs on the
-    UNROUNDED operands are 1e-3 away, and every bf16-mode result must be at least 3e-4 from them."""
+    UNROUNDED operands are 6e-5 .. 3e-3 away, and every bf16-mode result must be at least 20 x its own error from them."""
     import torch.nn.functional as F
     from swem_amd import autograd as A, ops
     from swem_amd.train import SWEMTrainer
@@ -956,8 +956,10 @@ def test_amp_step_stage_by_stage_at_the_training_shapes(lib, case_name):
                 continue
             good, other = ('rounded', 'fp32') if flag else ('fp32', 'rounded')
             assert out['%s_vs_%s' % (gemm, good)] < 1e-4, (name, gemm, out)
-            if flag:
-                assert out['%s_vs_%s' % (gemm, other)] > 3e-4, (name, gemm, 'not the bf16-operand arithmetic', out)
+            if flag:     # ... and really that arithmetic: the unrounded operands' result is far (bf16 rounding: 3e-3 on
+                # activations and data gradients, 6e-5 .. 1e-3 on weight gradients, whose sums over the pixels average it out)
+                assert out['%s_vs_%s' % (gemm, other)] > 20 * out['%s_vs_%s' % (gemm, good)], (
+                    name, gemm, 'not the bf16-operand arithmetic', out)
     H.record_parity('amp_stages_%s' % case_name, {'total_loss': float(losses['total_loss']), 'layers': rows})
 
 

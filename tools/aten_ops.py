@@ -15,8 +15,10 @@ from swem_amd import evaluator, synth, weights  # noqa: E402
 from swem_amd.swem import SWEM  # noqa: E402
 from types import SimpleNamespace  # noqa: E402
 
-NO_KERNEL = ('empty', 'view', 'reshape', 'permute', 'slice', 'select', 'unsqueeze', 'squeeze', 'expand', 'as_strided', 'detach',
-             'alias', 'unflatten', '_unsafe_view', 't.', 'transpose', 'unbind', 'split', 'flatten', 'size', 'stride', 'is_', 'sym_')
+NO_KERNEL = ('aten.empty', 'aten.view', 'aten.reshape', 'aten.permute', 'aten.slice', 'aten.select', 'aten.unsqueeze',
+             'aten.squeeze', 'aten.expand', 'aten.as_strided', 'aten.detach', 'aten.alias', 'aten.unflatten', 'aten._unsafe_view',
+             'aten.t.', 'aten.transpose', 'aten.unbind', 'aten.split', 'aten.flatten', 'aten.sym_', 'aten.is_', 'aten.size',
+             'aten.stride', 'aten.lift_fresh', 'aten._local_scalar')
 
 
 class Log(TorchDispatchMode):
