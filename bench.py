@@ -221,6 +221,7 @@ def main():
                     help='independent sequences processed concurrently per GPU, each on its own HIP stream')
     ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
     ap.add_argument('--no-em', action='store_true', help='skip the EM/matching timing legs (profiler runs)')
+    ap.add_argument('--no-round3-forms', action='store_true', help='tuner without the prefetched-fragment / stream-K kernel forms')
     ap.add_argument('--no-legs', action='store_true', help='skip the single-sequence and fp32-level legs (profiler runs)')
     ap.add_argument('--trace-layers', default=None, help='write the per-launch conv list of the eager roofline frames (JSON)')
     ap.add_argument('--cpu-frames', type=int, default=20, help='timed frames of the CPU baseline (after 2 warm-up frames)')
@@ -267,6 +268,8 @@ def main():
     book = ops.PlanBook()            # ONE book for every model of this process: tuned on the first sequence, read by all
     if args.load_plans:
         book.load(args.load_plans)
+    if args.no_round3_forms:
+        ops.TUNE_ROUND3_FORMS = False
     if args.max_split:
         ops._TUNE_SPLITS = tuple(v for v in ops._TUNE_SPLITS if v <= args.max_split)
     tune = not args.no_autotune and not args.load_plans   # per-layer plan chosen by timing, during warm-up only

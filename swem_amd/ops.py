@@ -23,6 +23,10 @@ AUTOTUNE = False
 # conv epilogues write the bf16 planes of outputs that later convolutions consume pre-split (learned per layer on the first
 # frames: SPLIT_HINTS) instead of a separate split launch per consumer tensor
 FUSE_SPLIT = True
+# the tuner also offers the round-3 kernel forms (prefetched fragments, stream-K); the training step turns both off (measured
+# on 4 clips in flight, AMP: 102 clips/s without them, 71 with both, 76 / 89 with one of them: persistent and 256-register
+# blocks crowd out the other lanes' kernels, and epilogue-written planes cost the big kernels more than the split launches)
+TUNE_ROUND3_FORMS = True
 
 
 class PlanBook:
@@ -78,6 +82,21 @@ class PlanBook:
 
 BOOK = PlanBook()     # the current book (the default one until a model makes its own current: use_book)
 MATH_RAN = None       # tests / bench set this to a dict: plan math field of every conv LAUNCH (what really ran) -> count
+
+
+class flags:
+    """Context: set module switches (FUSE_SPLIT, TUNE_ROUND3_FORMS, ...) for the duration of a block."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        g = globals()
+        self.saved = {k: g[k] for k in self.kw}
+        g.update(self.kw)
+
+    def __exit__(self, *a):
+        globals().update(self.saved)
 
 
 class use_book:
@@ -542,7 +561,10 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
                         cands.append(base | 8 << 20)          # 16-k blocks: three blocks of four waves per CU
                         cands.append(base | 9 << 20)          # ... with three LDS stages (two blocks per CU)
                         cands.append(base | 14 << 20)         # eight waves, 16x16x32 MFMA, three stages
-                        if math != 1:
+                        if math != 1 and not TUNE_ROUND3_FORMS:
+                            cands.append(base | 12 << 20)
+                            cands.append(base | 13 << 20)
+                        elif math != 1:
                             cands.append(base | 12 << 20)     # eight waves, four stages
                             cands.append(base | 13 << 20)     # ... on the 16x16x32 MFMA
                             cands.append(base | 5 << 20)      # prefetched fragments: four waves of 64x64, two stages
@@ -557,7 +579,7 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
                             if wm == 2 and wn == 2:
                                 cands.append(base | 2 << 20 | ts << 24)
                                 cands.append(base | 8 << 20 | ts << 24)
-                                if math != 1:
+                                if math != 1 and TUNE_ROUND3_FORMS:
                                     cands.append(base | 5 << 20 | ts << 24)
     def timed(plan, n):
         launch(plan)                               # warm (also grows the workspace)

@@ -444,6 +444,9 @@ class SWEMTrainer:
         st = contextlib.ExitStack()
         st.enter_context(ops.use_book(self.book))
         st.enter_context(ops.conv_math((2,)) if self.amp else ops.conv_math((0, 1)))
+        # conv epilogues do not write operand planes here and the tuner keeps to the non-persistent kernel forms (ops.py,
+        # TUNE_ROUND3_FORMS: measured on the four-lane step); the frozen-BN stages' own planes (autograd._planes_for) stay
+        st.enter_context(ops.flags(FUSE_SPLIT=False, TUNE_ROUND3_FORMS=False))
         return st
 
     def _capture(self, cur_iter):
