@@ -524,11 +524,19 @@ def main():
                                     8: (2, 4, False, 2), 9: (3, 4, False, 2)}[var_]
             elif var_ == 4:
                 nst, m16 = (3 if one else 2), True
-            return 'conv_igemm_bf3s_kernel<%d, %d, %d, %d, %s, %d, %d>' % (wm_, wn_, nst, nw, 'true' if m16 else 'false',
-                                                                          2 if pipe_ == 'bf16x3' else 3, kg)
+            pf, sk = var_ in (5, 7, 15), False
+            if var_ == 5:
+                nst, nw, m16, kg = 2, 4, True, 4
+            elif var_ == 15:
+                nst, nw, m16, kg = 3, 4, True, 4
+            elif var_ == 7:
+                nst, nw, m16, kg = 4, 8, True, 4
+            return 'conv_igemm_bf3s_kernel<%d, %d, %d, %d, %s, %d, %d, %s, %s>' % (
+                wm_, wn_, nst, nw, 'true' if m16 else 'false', 2 if pipe_ == 'bf16x3' else 3, kg, 'true' if pf else 'false',
+                'true' if sk else 'false')
         dk_name = bf3s_name(*dk) if dk[0] != 'fp32' else 'conv_igemm_pipe_kernel<%d, %d>' % (dk[1], dk[2])
         traffic, tsrc = None, None
-        for name in ('r02_conv_traffic_by_kernel.json',):
+        for name in ('r03_conv_traffic_by_kernel.json', 'r02_conv_traffic_by_kernel.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', name)) as f:
                     byk = json.load(f)
@@ -538,15 +546,27 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         if traffic is None:
-            for name in ('r02_conv_traffic.json', 'r01_conv_traffic.json'):
+            for name in ('r03_conv_traffic.json', 'r02_conv_traffic.json', 'r01_conv_traffic.json'):
                 try:
                     with open(os.path.join(ROOT, 'profiles', name)) as f:
                         traffic, tsrc = json.load(f)['hbm_bytes_per_launch'], 'profiles/' + name + ' (average over ALL conv launches)'
                     break
                 except (OSError, KeyError, ValueError):
                     pass
+        mfma_busy, mfma_src = None, None
+        try:       # counter evidence of the same kernel from the committed rocprofv3 --pmc passes (tools/pmc_kernels.sh)
+            with open(os.path.join(ROOT, 'profiles', 'r03_conv_pmc.json')) as f:
+                pm = json.load(f)
+            hit = [v for k, v in pm.items() if k.replace(' ', '') == dk_name.replace(' ', '') and 'mfma_busy' in v]
+            if hit:
+                mfma_busy, mfma_src = round(hit[0]['mfma_busy'], 4), 'profiles/r03_conv_pmc.json'
+        except (OSError, KeyError, ValueError):
+            pass
         out['roofline'] = {
-            'bound': 'mfma',
+            'bound': 'mfma', 'mfma_busy': mfma_busy, 'mfma_busy_source': mfma_src,
+            'mfma_busy_note': 'SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles of the dominant kernel on its largest layer, from separate '
+                              'rocprofv3 --pmc passes (NOT re-measured by this run): the share of cycles the matrix pipe is busy AT '
+                              'THE CLOCK THE CHIP HOLDS (1.7-2.0 GHz under this load), where frac divides by the 2.4 GHz peak',
             'kernel': (dk_name + ' -- implicit-GEMM conv on pre-split bf16 planes moved by LDS-DMA, %s, fp32 accumulate; '
                        'its operand-split and split-K reduce launches are inside the timed intervals'
                        % ('bf16x6 arithmetic (three planes per operand, six v_mfma_f32_32x32x16_bf16 products)' if dom == 'bf16'

@@ -36,20 +36,46 @@ def launch_ranks(n, argv, env=None, timeout=None):
     (no HIP call, no torch.cuda query): the children are fresh interpreters started by torch.distributed.run, the
     parent only relays their output and exit code -- it never execs over a GPU-initialised process.
     Returns (exit code, captured stdout of the job)."""
-    import socket
+    import signal
     import subprocess
     import sys
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
+    import threading
     e = dict(os.environ if env is None else env)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         e.pop(k, None)
     e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(int(n)),
-           '--master-addr', '127.0.0.1', '--master-port', str(port)] + list(argv)
-    p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, timeout=timeout)
-    return p.returncode, p.stdout.decode(errors='replace')
+    # --standalone: torchrun picks a free rendezvous port itself (no bind / close / reuse race); --local-addr keeps the
+    # rendezvous on the loopback (the container's host name may not resolve)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(int(n))] + list(argv)
+    # its own session: on a timeout / Ctrl-C the WHOLE job (torchrun and the rank processes that hold the GPUs) is
+    # signalled through its process group, not only the torchrun parent
+    p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE, start_new_session=True)
+    chunks = []
+
+    def pump():                                          # stream the job's stdout as it comes (a hung job shows where)
+        for line in iter(p.stdout.readline, b''):
+            chunks.append(line)
+            if os.environ.get('SWEM_DIST_ECHO'):
+                sys.stderr.write(line.decode(errors='replace'))
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    try:
+        p.wait(timeout=timeout)
+    except (subprocess.TimeoutExpired, KeyboardInterrupt):
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(p.pid, sig)                    # exactly the session this call started
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        raise
+    th.join(timeout=10)
+    return p.returncode, b''.join(chunks).decode(errors='replace')
 
 
 def shard(items, rank, world):

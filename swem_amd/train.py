@@ -164,7 +164,7 @@ def random_init_host(B, N, Cc, Lb):
 class SWEMTrainer:
     """swem_trainer.py:19-108 without the dataset / logging plumbing: model, criterion, optimizer, scheduler, one_step."""
 
-    def __init__(self, config, model, num_gpu=None, use_graph=True, lanes=4):
+    def __init__(self, config, model, num_gpu=None, use_graph=True, lanes=4, overlap_allreduce=True):
         self.config = config
         self.model = model
         # config.AMP (configs/config.py:89, basic_trainer.py:83-86,222): the reference runs the forward under fp16
@@ -172,6 +172,10 @@ class SWEMTrainer:
         # bf16 and take ONE MFMA product with fp32 accumulation (conv math mode 2); activations, EM, matching, the loss,
         # the weight gradient and the optimizer stay fp32.  bf16 keeps fp32's exponent range, so no loss scaling.
         self.amp = bool(_get(config, 'AMP'))
+        # data parallel: True = the non-trunk gradient slice is all-reduced while the lanes back-propagate through the
+        # key-encoder trunk (collective kernels next to the lanes' graphs); False = ONE all-reduce of the whole gradient after
+        # the backward pass, nothing of RCCL in flight beside the lanes (the conservative form; same result bit for bit)
+        self.overlap_allreduce = bool(overlap_allreduce)
         dev = next(model.parameters()).device
         model.train()
         for mod in model.modules():                    # BasicTrainer.set_bn_eval (swem_trainer.py:37-39)
@@ -372,12 +376,13 @@ class SWEMTrainer:
     # ------------------------------------------------------------------ data-parallel reduction (RCCL over xGMI)
     def _reduce_rest(self):
         """Start the all-reduce of the gradient slice that phase A completed; waited for in `_reduce_finish`."""
-        self._works = sdist.allreduce_sum_async(self.optimizer.grad[self.trunk_end:])
+        self._works = sdist.allreduce_sum_async(self.optimizer.grad[self.trunk_end:]) if self.overlap_allreduce else []
 
     def _reduce_finish(self):
         """All-reduce the trunk's slice and the three loss scalars (ONE 3-float all-reduce instead of the reference's three,
         basic_trainer.py:105-110,240-243; no host synchronisation), then wait for everything in flight."""
-        works = self._works + sdist.allreduce_sum_async(self.optimizer.grad[:self.trunk_end])
+        works = self._works + sdist.allreduce_sum_async(self.optimizer.grad[:self.trunk_end] if self.overlap_allreduce
+                                                         else self.optimizer.grad)
         works += sdist.allreduce_sum_async(self.buf['sums'], mean=True)
         for w in works:
             w.wait()

@@ -16,17 +16,20 @@ from tests import helpers as H  # noqa: E402
 
 def main():
     out_path, steps = sys.argv[1], int(sys.argv[2])
-    rank, _, world = sdist.env_world()
-    torch.cuda.set_device(0)
-    sdist.init(backend='gloo')
+    opts = set(sys.argv[3:])
+    rank, local_rank, world = sdist.env_world()
+    rccl = 'nccl' in opts                    # one rank per GPU over RCCL; default: both ranks on device 0 over gloo
+    dev = 'cuda:%d' % (local_rank if rccl else 0)
+    torch.cuda.set_device(local_rank if rccl else 0)
+    sdist.init(backend='nccl' if rccl else 'gloo')
     tc = H.train_cases()
     case = dict(tc['cases']['r18'], hw=[128, 128])
     cfg = O.make_cfg(**case['cfg'])
     # rank-local initialisation differs on purpose: the trainer's start-up broadcast must make rank 1 train rank 0's model
-    model, _ = H.make_model_and_sd(cfg, case['wseed'] + 7 * rank, 'cuda:0', pred_scale=tc['pred_scale'])
-    frames, init_mask, label, valid = [t.to('cuda:0') for t in H.train_batch(case)]
+    model, _ = H.make_model_and_sd(cfg, case['wseed'] + 7 * rank, dev, pred_scale=tc['pred_scale'])
+    frames, init_mask, label, valid = [t.to(dev) for t in H.train_batch(case)]
     tr = train.SWEMTrainer(dict(SOLVER=dict(tc['solver_cfg'], BASE_LR=1e-4), LOSS=tc['loss_cfg'], AMP=False), model,
-                           use_graph=len(sys.argv) > 3 and sys.argv[3] == 'graph')
+                           use_graph='graph' in opts, overlap_allreduce='single_allreduce' not in opts)
     hist = []
     real_init = train.random_init_host
     for it in range(steps):
@@ -38,9 +41,13 @@ def main():
                                 5 + it)
         hist.append([float(losses[k]) for k in ('total_loss', 'main_loss', 'aux_loss')])
     torch.cuda.synchronize()
-    flat = tr.optimizer.param.detach().cpu()
+    flat = tr.optimizer.param.detach()
     gathered = [torch.empty_like(flat) for _ in range(world)]
+    if not rccl:
+        flat = flat.cpu()
+        gathered = [g.cpu() for g in gathered]
     dist.all_gather(gathered, flat)
+    flat, gathered = flat.cpu(), [g.cpu() for g in gathered]
     if rank == 0:
         torch.save({'param': flat, 'same_on_all_ranks': all(torch.equal(g, flat) for g in gathered), 'hist': hist,
                     'world': dist.get_world_size()}, out_path)

@@ -795,20 +795,26 @@ def test_inference_after_a_step_sees_the_updated_weights(lib):
     assert torch.equal(after, ref)
 
 
-@pytest.mark.parametrize('graph', [False, True], ids=['eager', 'graph'])
-def test_two_ranks_one_clip_each_equal_one_rank_two_clips(lib, tmp_path, graph):
+@pytest.mark.parametrize('graph,opts', [(False, ()), (True, ()), (True, ('single_allreduce',)), (True, ('nccl',)), (False, ('nccl',))],
+                         ids=['eager', 'graph', 'graph_single_allreduce', 'graph_rccl_two_gpus', 'eager_rccl_two_gpus'])
+def test_two_ranks_one_clip_each_equal_one_rank_two_clips(lib, tmp_path, graph, opts):
     """Data parallel (swem_trainer.py:41-43: DistributedDataParallel): two ranks that step one clip each -- parameters
     broadcast from rank 0 at start-up, gradient all-reduced in two overlapped slices, loss scalars in one 3-float message --
     end with the parameters of ONE rank stepping both clips, on every rank, and report the batch's mean losses.
-    Rehearsed on one GPU over gloo (the RCCL path is the same torch.distributed calls)."""
+    Rehearsed on one GPU over gloo (the RCCL path is the same torch.distributed calls); the `rccl_two_gpus` variants run the
+    same comparison with one rank per GPU over RCCL -- collective kernels beside the lanes' graph replays -- wherever the box
+    has two GPUs (skipped on the one-GPU boxes of this pool); `single_allreduce` = SWEMTrainer(overlap_allreduce=False)."""
     import os
     from swem_amd import dist as sdist, train
     from swem_amd.train import SWEMTrainer
+    if 'nccl' in opts and torch.cuda.device_count() < 2:
+        pytest.skip('one rank per GPU over RCCL needs two GPUs')
     steps = 4 if graph else 2                        # (the graph is captured after two eager steps)
     out = str(tmp_path / 'ranks.pt')
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_dist_train_probe.py')
-    env = dict(os.environ, SWEM_DIST_BACKEND='gloo')
-    rc, text = sdist.launch_ranks(2, [probe, out, str(steps)] + (['graph'] if graph else []), env=env, timeout=900)
+    env = dict(os.environ)
+    env.pop('SWEM_DIST_BACKEND', None)
+    rc, text = sdist.launch_ranks(2, [probe, out, str(steps)] + (['graph'] if graph else []) + list(opts), env=env, timeout=900)
     assert rc == 0, text
     got = torch.load(out)
     assert got['world'] == 2 and got['same_on_all_ranks']

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/pmc_traffic; rm -rf $OUT; mkdir -p $OUT
 python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --seqs 1 --save-plans $OUT/plans.json > $OUT/tune.log 2>&1   # tune outside the profiler
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-em --no-graph --load-plans $OUT/plans.json --seqs 1 > $OUT/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-em --no-graph --no-legs --load-plans $OUT/plans.json --seqs 1 > $OUT/$c.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections, json

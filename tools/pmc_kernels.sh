@@ -15,7 +15,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- "$@" > $OUT/g$i.log 2>&1
   i=$((i+1))
 done
-python3 - "$OUT" "$FILTER" "$*" > $OUTTXT <<'PY'
+python3 - "$OUT" "$FILTER" "$*" "${OUTTXT%.txt}.json" > $OUTTXT <<'PY'
 import csv, glob, collections, re, sys
 root, filt, cmd = sys.argv[1:4]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -27,11 +27,14 @@ for f in glob.glob(root + '/g*/*/*counter_collection.csv'):
         k = re.sub(r'^void ', '', re.sub(r'\((?!anonymous).*', '', k))
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         nlaunch[k][r['Counter_Name']] += 1
-for f in glob.glob(root + '/g0/*/*kernel_trace.csv'):
+waves = collections.Counter()
+for f in glob.glob(root + '/g1/*/*kernel_trace.csv'):
     for r in csv.DictReader(open(f)):
         k = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
         k = re.sub(r'^void ', '', re.sub(r'\((?!anonymous).*', '', k))
         dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        waves[k] += int(r['Grid_Size']) // 64
+derived = {}
 print('rocprofv3 --kernel-trace --pmc, one counter group per run (tools/pmc_kernels.sh); command: %s' % cmd)
 print('counter values are SUMS over the launches of the kernel in that run; derived figures below each kernel.\n')
 for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get('SQ_WAVE_CYCLES', 0)):
@@ -42,16 +45,26 @@ for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get('SQ_WAVE_CYCLES', 0)):
     for c, v in sorted(d.items()):
         print('   %-36s %.5g' % (c, v))
     g = d.get('GRBM_GUI_ACTIVE', 0) / max(nlaunch[k].get('GRBM_GUI_ACTIVE', 1), 1) * n / 8   # summed over 8 XCDs -> chip cycles
+    # the SQ counters of this rocprofv3 see only a part of the chip's waves (SQ_WAVES against the launches' grid sizes: one
+    # half on this pool): every SQ figure is scaled by that coverage before it is set against chip cycles
+    cov = d.get('SQ_WAVES', 0) / waves[k] if waves.get(k) and d.get('SQ_WAVES') else 1.0
     if g:
         simd_cyc = g * 1024
-        print('   -- derived (chip-busy cycles of these launches = GRBM_GUI_ACTIVE / 8 = %.4g; x 1024 SIMDs = %.4g SIMD cycles)' % (g, simd_cyc))
+        print('   -- derived (chip-busy cycles of these launches = GRBM_GUI_ACTIVE / 8 = %.4g; x 1024 SIMDs = %.4g SIMD cycles; '
+              'SQ counters cover %.3f of the launched waves; clock under the profiler %.2f GHz)'
+              % (g, simd_cyc, cov, g / n / max(sum(dur[k]) / max(len(dur[k]), 1), 1e-9) / 1e3))
+        dk = derived.setdefault(k, {'launches': n, 'avg_us_under_profiler': sum(dur[k]) / max(len(dur[k]), 1), 'sq_coverage': cov,
+                                    'clock_ghz_under_profiler': g / n / max(sum(dur[k]) / max(len(dur[k]), 1), 1e-9) / 1e3})
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in d:
-            print('   mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles                  = %.3f' % (d['SQ_VALU_MFMA_BUSY_CYCLES'] / simd_cyc))
+            dk['mfma_busy'] = d['SQ_VALU_MFMA_BUSY_CYCLES'] / cov / simd_cyc
+            print('   mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / coverage / SIMD cycles       = %.3f' % (d['SQ_VALU_MFMA_BUSY_CYCLES'] / cov / simd_cyc))
         if 'SQ_LDS_IDX_ACTIVE' in d:
-            print('   lds_array_active = SQ_LDS_IDX_ACTIVE / (chip cycles x 256 CUs)      = %.3f   bank-conflict cycles / active = %.3f'
-                  % (d['SQ_LDS_IDX_ACTIVE'] / (g * 256), d.get('SQ_LDS_BANK_CONFLICT', 0) / max(d['SQ_LDS_IDX_ACTIVE'], 1)))
+            print('   lds_array_active = SQ_LDS_IDX_ACTIVE / coverage / (chip cycles x 256 CUs) = %.3f   bank-conflict cycles / active = %.3f'
+                  % (d['SQ_LDS_IDX_ACTIVE'] / cov / (g * 256), d.get('SQ_LDS_BANK_CONFLICT', 0) / max(d['SQ_LDS_IDX_ACTIVE'], 1)))
     if 'SQ_WAVE_CYCLES' in d:
         w = d['SQ_WAVE_CYCLES']
+        derived.setdefault(k, {}).update(wave_parked=d.get('SQ_WAIT_ANY', 0) / w, wave_issue_stalled=d.get('SQ_WAIT_INST_ANY', 0) / w,
+                                         wave_issuing=d.get('SQ_ACTIVE_INST_ANY', 0) / w)
         print('   of the wave cycles: parked in s_waitcnt / s_barrier (SQ_WAIT_ANY) %.3f, issue-stalled (SQ_WAIT_INST_ANY) %.3f '
               '(of which LDS issue %.3f), issuing (SQ_ACTIVE_INST_ANY) %.3f' % (
                   d.get('SQ_WAIT_ANY', 0) / w, d.get('SQ_WAIT_INST_ANY', 0) / w, d.get('SQ_WAIT_INST_LDS', 0) / w, d.get('SQ_ACTIVE_INST_ANY', 0) / w))
@@ -64,6 +77,11 @@ for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get('SQ_WAVE_CYCLES', 0)):
         print('   fabric traffic per launch: (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) x 1024 B = %.2f MB (fetch %.2f MB x 2, write %.2f MB); '
               'L2 hit rate %.3f' % ((2 * fs + ws) * 1024 / n / 1e6, fs * 1024 / n / 1e6, ws * 1024 / n / 1e6,
                                     d.get('TCC_HIT_sum', 0) / max(d.get('TCC_HIT_sum', 0) + d.get('TCC_MISS_sum', 0), 1)))
+        derived.setdefault(k, {}).update(fabric_bytes_per_launch=(2 * fs + ws) * 1024 / n,
+                                         l2_hit_rate=d.get('TCC_HIT_sum', 0) / max(d.get('TCC_HIT_sum', 0) + d.get('TCC_MISS_sum', 0), 1))
     print()
+import json
+with open(sys.argv[4], 'w') as f:
+    json.dump(derived, f, indent=1, sort_keys=True)
 PY
 tail -40 $OUTTXT

@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
 python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --seqs 1 --save-plans $OUT/plans.json > $OUT/tune.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-em --no-graph --seqs 1 --load-plans $OUT/plans.json > $OUT/bench_eager.json 2> $OUT/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-em --no-graph --no-legs --seqs 1 --load-plans $OUT/plans.json > $OUT/bench_eager.json 2> $OUT/stats.log
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 head -25 $OUT/kernel_stats.csv
 tail -1 $OUT/bench_eager.json
