@@ -662,7 +662,80 @@ __global__ void cbam_bwd_dg_kernel(const float *__restrict__ du, const float *__
 }
 
 // ---------------------------------------------------------------- decoder heads
-// conv3x3(relu(x)) -> 1 channel: one wave per output pixel, lanes over channel groups
+// conv3x3(relu(x)) -> 1 channel (networks.py:213).  As a GEMM it is [pixels x C] . [C x 9 taps]: every INPUT pixel's nine
+// tap products d[p][tap] = relu(x[p]) . w[tap] are one row of a v_mfma_f32_16x16x4_f32 tile (A = 16 consecutive pixels of a
+// row, B = the nine tap filters padded to 16 columns; exact fp32 FMA chains), and an output pixel is the sum of nine of them
+// from its 3x3 neighbourhood.  Block = 6 x 30 output pixels: its 8 x 32 input pixels (halo included) are 16 segments of 16
+// pixels, four per wave; the tap products go through the LDS, then 180 threads add their nine neighbours.  Each input pixel
+// is read ONCE per block as 16-byte loads (round 2 read it nine times, one wave per output pixel with a 64-lane shuffle
+// reduction each: 42 us for 2x120x216x256, 68 us beside three other sequences -- 11 TB/s of L2 traffic).
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+constexpr int PH_TH = 6, PH_TW = 30;   // output tile; input tile (PH_TH + 2) x (PH_TW + 2) = 8 x 32
+template <int CQ>   // C / 16: channel groups of 16 (four k-steps of four channels each)
+__global__ __launch_bounds__(256) void pred_head_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, float *__restrict__ logit, int B,
+                                                              int H, int W, int tiles_x, int tiles_y) {
+  __shared__ float t[(PH_TH + 2) * (PH_TW + 2)][12];   // tap products of the input tile (9 used; 48-byte rows)
+  const int C = 16 * CQ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y, b = bid / tiles_y;
+  const int oy0 = ty * PH_TH, ox0 = tx * PH_TW;
+  // B operand: lane (column li = tap, k-slot g) holds w[tap][16 q + 4 g + e] for step (q, e); taps 9..15 are zero columns
+  float4 wf[CQ];
+#pragma unroll
+  for (int q = 0; q < CQ; ++q) wf[q] = li < 9 ? ld4(w + li * C + 16 * q + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // the next segment's 16 loads are in flight under the current segment's 64 dependent MFMAs (two register sets)
+  float4 xv[2][CQ];
+  auto load_seg = [&](int sidx, float4 (&dst)[CQ]) __attribute__((always_inline)) {
+    const int seg = wave * 4 + sidx;             // 16 segments: row seg / 2 of the input tile, half seg % 2
+    const int iy = oy0 - 1 + (seg >> 1), ix = ox0 - 1 + 16 * (seg & 1) + li;
+    const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const float *xp = x + (((long long)b * H + (in ? iy : 0)) * W + (in ? ix : 0)) * C + 4 * g;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) dst[q] = in ? ld4(xp + 16 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  load_seg(0, xv[0]);
+#pragma unroll
+  for (int sidx = 0; sidx < 4; ++sidx) {
+    const int seg = wave * 4 + sidx;
+    if (sidx + 1 < 4) load_seg(sidx + 1, xv[(sidx + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4p acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // two chains: the MFMA's 40-cycle dependent latency
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+      const float4 v = xv[sidx & 1][q];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(v.x, 0.f), wf[q].x, acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(v.y, 0.f), wf[q].y, acc1, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(v.z, 0.f), wf[q].z, acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(v.w, 0.f), wf[q].w, acc1, 0, 0, 0);
+    }
+    acc += acc1;
+    __builtin_amdgcn_sched_barrier(0);
+    // D[pixel i][tap j] lives in lane j + 16 (i >> 2), register i & 3
+    if (li < 9) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[(seg >> 1) * (PH_TW + 2) + 16 * (seg & 1) + 4 * g + e][li] = acc[e];
+    }
+  }
+  __syncthreads();
+  if (tid < PH_TH * PH_TW) {
+    const int r = tid / PH_TW, c = tid - r * PH_TW;
+    const int oy = oy0 + r, ox = ox0 + c;
+    if (oy < H && ox < W) {
+      float s = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) s += t[(r + ky) * (PH_TW + 2) + c + kx][ky * 3 + kx];
+      logit[((long long)b * H + oy) * W + ox] = s + bias[0];
+    }
+  }
+}
+
+// generic channel counts (C % 4 == 0): one wave per output pixel, lanes over channel groups
 __global__ void pred_head_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                  const float *__restrict__ bias, float *__restrict__ logit, int B, int H, int W,
                                  int C) {
@@ -1003,8 +1076,13 @@ extern "C" int swem_cbam_bwd_f32(void *stream, const float *x, const float *w1, 
 extern "C" int swem_pred_head_f32(void *stream, const float *x, const float *w, const float *bias, float *logit,
                                   int B, int H, int W, int C) {
   SWEM_REQUIRE(x && w && bias && logit && C % 4 == 0, SWEM_E_SHAPE, "pred_head: bad argument");
-  hipLaunchKernelGGL(pred_head_kernel, grid1((long long)B * H * W * 64), dim3(256), 0, ST, x, w, bias, logit, B, H, W,
-                     C);
+  if (C == 256) {   // the decoder's head (networks.py:206): the matrix-core form
+    const int tiles_x = (W + PH_TW - 1) / PH_TW, tiles_y = (H + PH_TH - 1) / PH_TH;
+    hipLaunchKernelGGL(pred_head_mfma_kernel<16>, dim3((unsigned)(tiles_x * tiles_y * B)), dim3(256), 0, ST, x, w, bias, logit,
+                       B, H, W, tiles_x, tiles_y);
+  } else {
+    hipLaunchKernelGGL(pred_head_kernel, grid1((long long)B * H * W * 64), dim3(256), 0, ST, x, w, bias, logit, B, H, W, C);
+  }
   SWEM_CHECK_LAUNCH("pred_head");
   return SWEM_OK;
 }
