@@ -616,6 +616,11 @@ def main():
             return
         # EM / matching: capture the arguments of one real memorize + match call, then time 20 back-to-back
         # repetitions of each with HIP events (queue kept full, so this is device time, not host launch time)
+        # (the calls below are made outside model(...): they must see the plans of the timed run -- matching's readout plan --
+        # so its book is made current for the whole leg; round 3's first bench lines ran this leg on the EMPTY default book,
+        # i.e. with the fp32 three-kernel readout, and read 0.35 where tools/em_bench.py read 0.39)
+        book_ctx = ops.use_book(book)
+        book_ctx.__enter__()
         orig_mem, orig_match = ops.memorize, ops.match_packed
         cap = {}
 
@@ -688,6 +693,7 @@ def main():
             return {'sequences': n_streams, 'us_per_round': round(1e6 * best / reps, 1), 'achieved': round(tf, 2),
                     'frac': round(tf / FP32_MATRIX_PEAK_TFLOPS, 4)}
         conc = [em_concurrent(n) for n in sorted({1, 2, nseq, 4})]
+        book_ctx.__exit__(None, None, None)
         em = out['em_matching']
         ex_ratio = em_flops_executed_per_frame(n_obj) / em_flops_per_frame(n_obj)
         em['concurrent'] = [c for c in conc if c['sequences'] > 1]

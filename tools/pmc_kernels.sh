@@ -33,21 +33,24 @@ for f in glob.glob(root + '/g1/*/*kernel_trace.csv'):
         k = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
         k = re.sub(r'^void ', '', re.sub(r'\((?!anonymous).*', '', k))
         dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-        waves[k] += int(r['Grid_Size']) // 64
+        waves[k] += int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']) // 64
 derived = {}
 print('rocprofv3 --kernel-trace --pmc, one counter group per run (tools/pmc_kernels.sh); command: %s' % cmd)
 print('counter values are SUMS over the launches of the kernel in that run; derived figures below each kernel.\n')
 for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get('SQ_WAVE_CYCLES', 0)):
     if not re.search(filt, k):
         continue
-    n = max(nlaunch[k].values())
+    n = len(dur[k]) or max(nlaunch[k].values())      # launches: the kernel trace's dispatch records (the counter CSV
+    # holds several rows per dispatch: the SQ / TCC rows are partial sums that add up to the dispatch's value, the GRBM rows
+    # each repeat it)
     print('%s   (%d launches per pass; kernel-trace duration under the profiler: avg %.1f us)' % (k, n, sum(dur[k]) / max(len(dur[k]), 1)))
     for c, v in sorted(d.items()):
         print('   %-36s %.5g' % (c, v))
     g = d.get('GRBM_GUI_ACTIVE', 0) / max(nlaunch[k].get('GRBM_GUI_ACTIVE', 1), 1) * n / 8   # summed over 8 XCDs -> chip cycles
     # the SQ counters of this rocprofv3 see only a part of the chip's waves (SQ_WAVES against the launches' grid sizes: one
-    # half on this pool): every SQ figure is scaled by that coverage before it is set against chip cycles
+    # checked here): every SQ figure is scaled by that coverage before it is set against chip cycles
     cov = d.get('SQ_WAVES', 0) / waves[k] if waves.get(k) and d.get('SQ_WAVES') else 1.0
+    cov = min(cov, 1.0)
     if g:
         simd_cyc = g * 1024
         print('   -- derived (chip-busy cycles of these launches = GRBM_GUI_ACTIVE / 8 = %.4g; x 1024 SIMDs = %.4g SIMD cycles; '
