@@ -651,7 +651,7 @@ def main():
                               'note': 'swem_memorize_f32 + swem_match_f32 on one frame\'s real arguments, 20 back-to-back '
                                       'repetitions each; algorithmic FLOPs 4PL(C(3T-1)+V) + 4LmP(C+V) per object'}
         # the same kernels when several independent sequences share the GPU, as the product runs them (--seqs): one HIP
-        # graph of memorize + match per stream, replayed together.  A single sequence exposes 102 blocks to 256 CUs and a
+        # graph of memorize + match per stream, replayed together.  A single sequence exposes 204 blocks to 256 CUs and a
         # chain of dependent launches; concurrent sequences fill the rest.
         def em_concurrent(n_streams, reps=20):
             a_mem, k_mem = cap['mem']

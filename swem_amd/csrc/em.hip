@@ -196,10 +196,7 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
     for (int t = 0; t < LT; ++t) acc[t] = mfma16(a[m][t].w, xf[m].w, acc[t]);
     __builtin_amdgcn_sched_barrier(0);
   }
-  // l2norm of the bases (modules.py:7-9, :95, :114) on the GEMM's output: s = (x . kappa) / (|kappa| + eps).  The rows
-  // arrive raw with their squared norms beside them (packed keys): the M step writes both and no kernel in between
-  // normalises.  Lane (li, g = 0) holds row li's norm; the accumulator registers hold bases 4 g + r: one 16-float exchange
-  // per tile inside the wave.
+  // (the accumulators now hold s = x . l2norm(kappa): the rows were scaled on the way in, above)
   // maxima of the raw logits over this wave's bases; the W step's cosine is s / (|x| + eps) with a positive per-pixel
   // factor, so its joint maximum is that factor times the larger class maximum (rounding is monotonic): one exchange
   float ml = -__builtin_huge_valf();
