@@ -166,3 +166,62 @@ def test_nchw_views_find_their_nhwc_tensor_again():
     assert '_swem_split' not in back.__dict__         # a tensor from elsewhere: plain view, nothing attached
     other = torch.randn(2, 8, 5, 7).contiguous(memory_format=torch.channels_last)
     assert torch.equal(to_pixel_major(other), other.permute(0, 2, 3, 1))
+
+
+def test_plan_book_scoping_roundtrip_and_flags(tmp_path):
+    """ops.PlanBook: what a model learns about its launches belongs to the model -- the current book is swapped for the
+    duration of a block and restored, two models never see each other's plans unless they share a book, the tables of the
+    default book are reachable under their old module names, save / load round-trips, the digest names the plans."""
+    from swem_amd import ops
+    a, b = ops.PlanBook(), ops.PlanBook()
+    default = ops.BOOK
+    with ops.use_book(a):
+        ops.BOOK.conv[(256, 256, 3, 3, 1, 1, 2, 2, 120, 216)] = 0x630122
+        ops.BOOK.match[(2, 128, 512, 1620, 256, 2)] = 0x130221
+        ops.BOOK.hints[('conv', ('engine', 7), 2, 120, 216, 2)] = {True: 2}
+        assert ops._CONV_PLANS is a.conv and ops.SPLIT_HINTS is a.hints
+        with ops.use_book(b):
+            assert not ops.BOOK.conv and ops.BOOK is b
+        assert ops.BOOK is a
+    assert ops.BOOK is default and not default.conv and not b.conv
+    assert a.math_histogram() == {'fp32': 0, 'bf16x6': 0, 'bf16': 0, 'bf16x3': 1}
+    path = str(tmp_path / 'plans.json')
+    a.save(path)
+    c = ops.PlanBook().load(path)
+    assert c.conv == a.conv and c.match == a.match and c.digest() == a.digest() != b.digest()
+    m1, m2 = SWEM(O.make_cfg(BACKBONE='resnet18', NUM_BASES=64)), SWEM(O.make_cfg(BACKBONE='resnet18', NUM_BASES=64))
+    assert m1.book is not m2.book and isinstance(m1.book, ops.PlanBook)
+    # module switches for a block
+    assert ops.FUSE_SPLIT and ops.TUNE_ROUND3_FORMS
+    with ops.flags(FUSE_SPLIT=False, TUNE_ROUND3_FORMS=False):
+        assert not ops.FUSE_SPLIT and not ops.TUNE_ROUND3_FORMS
+    assert ops.FUSE_SPLIT and ops.TUNE_ROUND3_FORMS
+    # layer names of the hints: stable under pack_keys, unique otherwise
+    with ops.pack_keys('engine'):
+        k1 = ops._next_pack_key()
+    with ops.pack_keys('engine'):
+        k2 = ops._next_pack_key()
+    assert k1 == k2 == ('engine', 1) and ops._next_pack_key() != ops._next_pack_key()
+
+
+def test_launch_ranks_timeout_takes_the_whole_job_down(tmp_path):
+    """dist.launch_ranks runs the job in a session of its own: when the timeout fires, the rank processes (which would hold
+    the GPUs) are signalled through the process group, not only the torchrun parent."""
+    import subprocess
+    import time
+    from swem_amd import dist as sdist
+    script = tmp_path / 'sleeper.py'
+    script.write_text('import os, sys, time\n'
+                      'open(sys.argv[1] + "." + os.environ["RANK"], "w").write(str(os.getpid()))\n'
+                      'print("rank", os.environ["RANK"], flush=True)\n'
+                      'time.sleep(120)\n')
+    stem = str(tmp_path / 'pid')
+    t0 = time.time()
+    with pytest.raises(subprocess.TimeoutExpired):
+        sdist.launch_ranks(2, [str(script), stem], timeout=20)
+    assert time.time() - t0 < 60
+    pids = [int(open('%s.%d' % (stem, r)).read()) for r in (0, 1)]
+    time.sleep(1.0)
+    for pid in pids:
+        alive = os.path.exists('/proc/%d' % pid) and 'Z' not in open('/proc/%d/stat' % pid).read().split()[2]
+        assert not alive, 'rank process %d survived the timeout' % pid
