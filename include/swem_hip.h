@@ -278,6 +278,20 @@ int swem_memorize_packed_f32(void *stream, const float *x, const float *v, const
                              float *zita_out, float *mkn, float *mvp, void *mvq, int prior_packed, int bank, int N, int C,
                              int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes);
 
+/* The packed memorize in two calls (round 3).  modules.py:129-168 reads the value map only in its last statement
+ * (:164-165, nu = (zita_ nu_ + mv z) / zita); everything before it -- every E, W and key M step, 2T - 1 of the 2T launches --
+ * needs the key, the masks and the prior only, so a caller can run it BESIDE the value encoder that produces the value map
+ * (swem_evaluator.py:91-93 runs encode_value and memorize one after the other).  `keys` leaves the last E step's
+ * responsibilities in z [N][swem_em_pad(P)][2L] (caller-owned, not the workspace: the two calls may run on different
+ * streams); `values` is the value update from them.  Same blocks on the same data as the one-call form: identical results. */
+int swem_memorize_packed_keys_f32(void *stream, const float *x, const float *masks, const float *kappa_prev,
+                                  const float *zita_prev, float *kappa_out, float *zita_out, float *mkn, float *z,
+                                  int prior_packed, int bank, int N, int C, int P, int L, int T, float tau, void *ws,
+                                  size_t ws_bytes);
+int swem_memorize_packed_values_f32(void *stream, const float *v, const float *z, const float *nu_prev,
+                                    const float *zita_prev, float *nu_out, float *mvp, void *mvq, int bank, int N, int V,
+                                    int P, int L);
+
 /* ------------------------------------------------------------------------------------
  * Matching (modules.py:198-208, 232-289): l2norm, affinity, joint {bg,fg} softmax, value
  * readout and the top-l prefix-sum features, for all objects of one frame.

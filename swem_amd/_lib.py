@@ -55,6 +55,8 @@ SIGNATURES = {
     'swem_memorize_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'swem_memorize_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _sz]),
     'swem_memorize_packed_f32': (_i, [_p] * 13 + [_i] * 8 + [_f, _p, _sz]),
+    'swem_memorize_packed_keys_f32': (_i, [_p] * 9 + [_i] * 7 + [_f, _p, _sz]),
+    'swem_memorize_packed_values_f32': (_i, [_p] * 8 + [_i] * 5),
     'swem_match_pad': (_i, [_i]),
     'swem_match_workspace': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'swem_match_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _sz]),

@@ -609,11 +609,14 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
                   const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out, int N,
                   int C, int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes, float *z_ext,
                   const float *kn_prior, int knp_rows, int knp_off, float *kn_out, int kno_rows, int kno_off,
-                  float *mvp_out, int mvp_lm, int mvp_off, unsigned short *mvq_out = nullptr) {
-  SWEM_REQUIRE(x && v && masks && kappa_prev && nu_prev && zita_prev && kappa_out && nu_out && zita_out, SWEM_E_ARG,
-               "memorize: null pointer");
+                  float *mvp_out, int mvp_lm, int mvp_off, unsigned short *mvq_out = nullptr, bool keys_only = false) {
+  // keys_only: everything that does not read the value map -- all T (E, W, key M) steps; the last E step's z stays in z_ext
+  // for the value update (swem_memorize_packed_values_f32), which is ONE more M-step launch over the value rows
+  SWEM_REQUIRE(x && (v || keys_only) && masks && kappa_prev && (nu_prev || keys_only) && zita_prev && kappa_out &&
+                   (nu_out || keys_only) && zita_out, SWEM_E_ARG, "memorize: null pointer");
+  SWEM_REQUIRE(!keys_only || z_ext, SWEM_E_ARG, "memorize (keys): the responsibilities need a buffer of their own");
   SWEM_REQUIRE(T >= 1, SWEM_E_ARG, "memorize: T < 1");
-  SWEM_REQUIRE(kappa_out != kappa_prev && nu_out != nu_prev && zita_out != zita_prev, SWEM_E_ARG,
+  SWEM_REQUIRE(kappa_out != kappa_prev && (keys_only || nu_out != nu_prev) && zita_out != zita_prev, SWEM_E_ARG,
                "memorize: outputs must not alias the prior bases (the prior is read by every iteration)");
   SWEM_REQUIRE(C == 64 || C == 128, SWEM_E_SHAPE, "memorize: the key dimension must be 64 or 128 (got %d)", C);
   SWEM_REQUIRE(L == 64 || L == 128 || L == 256, SWEM_E_SHAPE, "memorize: L must be 64, 128 or 256 (got %d)", L);
@@ -626,7 +629,7 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
   float *z = z_ext ? z_ext : (float *)(base + w.z);
   const int NK = 2 * N, Pz = swem_em_pad(P);
   int rc;
-  if (z_ext && hipMemsetAsync(z_ext, 0, (size_t)N * Pz * 2 * L * 4, ST) != hipSuccess) {
+  if (z_ext && !keys_only && hipMemsetAsync(z_ext, 0, (size_t)N * Pz * 2 * L * 4, ST) != hipSuccess) {
     swem_set_error("memorize: memset failed");   // (training keeps z: rows [P, Pz) must read as zeros in the backward GEMM)
     return SWEM_E_HIP;
   }
@@ -641,9 +644,10 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
     // W step of iteration it-1 (modules.py:161-162) and E step of iteration it share one GEMM
     if ((rc = ew_launch(stream, x, kcur, krows, koff, masks, masks, nullptr, z, N, C, P, L, tau, it > 0, 1))) return rc;
     // key bases every iteration; the value bases (modules.py:164-165) from the LAST z, in the same two launches
-    if ((rc = mstep_impl(stream, x, last ? v : nullptr, z, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out,
-                         last ? kn_out : kn, last ? kno_rows : L, last ? kno_off : 0, last ? mvp_out : nullptr, mvp_lm,
-                         mvp_off, NK, C, last ? V : 0, C, V, P, L, last ? mvq_out : nullptr)))
+    const bool vals = last && !keys_only;
+    if ((rc = mstep_impl(stream, x, vals ? v : nullptr, z, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out,
+                         last ? kn_out : kn, last ? kno_rows : L, last ? kno_off : 0, vals ? mvp_out : nullptr, mvp_lm,
+                         mvp_off, NK, C, vals ? V : 0, C, V, P, L, vals ? mvq_out : nullptr)))
       return rc;
     kcur = kn, krows = L, koff = 0;
   }
@@ -676,6 +680,31 @@ extern "C" int swem_memorize_packed_f32(void *stream, const float *x, const floa
   return memorize_impl(stream, x, v, masks, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out, N, C, V, P, L, T,
                        tau, ws, ws_bytes, nullptr, prior_packed ? mkn : nullptr, 2 * L, L, mkn, 2 * L, bank * L, mvp,
                        2 * L, bank * L, static_cast<unsigned short *>(mvq));
+}
+
+// The packed memorize in two calls, so that a caller can run the part that does not need the value map -- every E, W and key
+// M step: 2T - 1 of the 2T launches -- BESIDE the value encoder that produces it (evaluator.frame_chain on a side stream):
+// `keys` leaves the last E step's responsibilities in z [N][swem_em_pad(P)][2L]; `values` is the value update
+// nu = (zita_prev nu_prev + v . z) / zita (modules.py:164-165) from them, written to bank `bank` of the pack like the one-call
+// form does.  Together they launch the same blocks on the same data as swem_memorize_packed_f32: identical results.
+extern "C" int swem_memorize_packed_keys_f32(void *stream, const float *x, const float *masks, const float *kappa_prev,
+                                             const float *zita_prev, float *kappa_out, float *zita_out, float *mkn, float *z,
+                                             int prior_packed, int bank, int N, int C, int P, int L, int T, float tau,
+                                             void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(mkn && z, SWEM_E_ARG, "memorize_packed_keys: null pack / z");
+  SWEM_REQUIRE(bank == 0 || bank == 1, SWEM_E_ARG, "memorize_packed_keys: bank must be 0 or 1");
+  return memorize_impl(stream, x, nullptr, masks, kappa_prev, nullptr, zita_prev, kappa_out, nullptr, zita_out, N, C, 32, P, L,
+                       T, tau, ws, ws_bytes, z, prior_packed ? mkn : nullptr, 2 * L, L, mkn, 2 * L, bank * L, nullptr, 2 * L,
+                       bank * L, nullptr, true);
+}
+extern "C" int swem_memorize_packed_values_f32(void *stream, const float *v, const float *z, const float *nu_prev,
+                                               const float *zita_prev, float *nu_out, float *mvp, void *mvq, int bank, int N,
+                                               int V, int P, int L) {
+  SWEM_REQUIRE(v && z && nu_prev && zita_prev && nu_out && mvp, SWEM_E_ARG, "memorize_packed_values: null pointer");
+  SWEM_REQUIRE(bank == 0 || bank == 1, SWEM_E_ARG, "memorize_packed_values: bank must be 0 or 1");
+  SWEM_REQUIRE(V % 32 == 0 && (L == 64 || L == 128 || L == 256), SWEM_E_SHAPE, "memorize_packed_values: V %% 32, L in {64,128,256}");
+  return mstep_impl(stream, nullptr, v, z, nullptr, nu_prev, zita_prev, nullptr, nu_out, nullptr, nullptr, 0, 0, mvp, 2 * L,
+                    bank * L, 2 * N, 0, V, 0, V, P, L, static_cast<unsigned short *>(mvq));
 }
 
 // training: the same as swem_memorize_f32, and the last E step's responsibilities z [N][Pz][2L] (Pz = swem_em_pad(P), rows

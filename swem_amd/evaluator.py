@@ -328,9 +328,12 @@ class PipelinedFrameGraph(FrameGraph):
             self.primed = False
 
 
-def frame_chain(model, keys, frame, out_size, memorize=True):
+def frame_chain(model, keys, frame, out_size, memorize=True, em_stream=None):
     """The part of a frame that depends on the memory (swem_evaluator.py:77-97): match -> segment -> argmax / one-hot ->
-    [bilinear -> encode_value -> memorize], from the frame's key-encoder outputs `keys` = (qk16, qv16, s16, s8, s4)."""
+    [bilinear -> encode_value -> memorize], from the frame's key-encoder outputs `keys` = (qk16, qv16, s16, s8, s4).
+    em_stream: run the part of memorize that does not read the value map -- every E, W and key M step, 2T - 1 of its 2T
+    launches (modules.py:129-163 need the key, the masks and the prior only) -- on that stream BESIDE encode_value, and only
+    the value update behind it (SWEM.memorize_begin / memorize_end: the same blocks on the same data, identical results)."""
     h, w = frame.shape[-2:]
     qk16, qv16, s16, s8, s4 = keys
     context, n = model('match', qk16, qv16)
@@ -338,7 +341,22 @@ def frame_chain(model, keys, frame, out_size, memorize=True):
     pred, hard = ops.argmax_onehot(pred_mask, want_onehot=memorize)
     if memorize:
         pm = ops.resize_planes(pred_mask, (h, w), 'bilinear')
-        model('memorize', qk16, model('encode_value', frame, pm, s16), hard, pm)
+        tok = None
+        if em_stream is not None:
+            main = torch.cuda.current_stream()
+            em_stream.wait_stream(main)
+            with torch.cuda.stream(em_stream):
+                tok = model.memorize_begin(qk16, hard, pm)
+        mv16 = model('encode_value', frame, pm, s16)
+        if em_stream is not None:
+            main.wait_stream(em_stream)
+        if tok is None:
+            model('memorize', qk16, mv16, hard, pm)
+        else:
+            if not torch.cuda.is_current_stream_capturing():
+                for t_ in (tok['kappa'], tok['zita'], tok['z']):
+                    t_.record_stream(main)
+            model.memorize_end(tok, mv16)
     return pred
 
 
@@ -362,7 +380,7 @@ class LookaheadGraph:
     the sequential order; with batch-invariant plans (ops.PlanBook.fallback without a K-split) index maps and memory are those
     of the frame-by-frame loop bit for bit (tests/test_gpu_model.py)."""
 
-    def __init__(self, model, frame_shape, out_size, k, streams=None, side_stream=None, overlap=True):
+    def __init__(self, model, frame_shape, out_size, k, streams=None, side_stream=None, overlap=True, em_overlap=False):
         self.model, self.k, self.out_size = model, int(k), (int(out_size[0]), int(out_size[1]))
         self.streams, self.side, self.overlap = streams, side_stream, overlap
         core = model.swem_core
@@ -382,6 +400,10 @@ class LookaheadGraph:
         self.cg = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
         self.keys = [None, None]
         self.preds = [None, None]
+        # em_overlap: the key half of every memorize (9 of its 10 launches: SWEM.memorize_begin) on a side stream beside the
+        # frame's value encoder.  Identical results (tested); measured NEUTRAL on config B (chains 2.26 -> 2.23 ms per frame
+        # alone, 2.71 -> 2.72 with the next group's key encoder beside them: the frame is bound by the kernel sum), so off
+        self.em_stream = ops.new_stream() if em_overlap else None
         self.p = 0                   # parity of the group whose keys are ready (after prime() / run())
         self.primed = False
 
@@ -391,7 +413,8 @@ class LookaheadGraph:
         sets = (self.state, self.state2)
         for j in range(self.k):
             core._next_out = sets[(j + 1) % 2]
-            preds.append(frame_chain(self.model, key_item(self.keys[p], j), self.frames[p][j:j + 1], self.out_size))
+            preds.append(frame_chain(self.model, key_item(self.keys[p], j), self.frames[p][j:j + 1], self.out_size,
+                                     em_stream=self.em_stream))
             core._next_out = None
             core.memories['update'].bases = sets[(j + 1) % 2]       # (the tensors memorize wrote, under their own names)
             core.restamp()

@@ -268,6 +268,46 @@ class SWEMCore(nn.Module):
         else:
             self._stamp = [None, None]
 
+    # ------------------------------------------------------------------ memorize in two calls (round 3)
+    def memorize_begin(self, qk, masks):
+        """Everything of `memorize` that does not read the value map -- the T (E, W, key M) steps, modules.py:129-163 -- so
+        that a caller can run it beside the value encoder (evaluator.frame_chain).  Steady state only (both banks exist, one
+        clip, no new object ids): returns a token for `memorize_end`, or None if the plain `memorize` has to be used."""
+        first, update = self.memories['first'], self.memories['update']
+        if first.bases is None or qk.shape[0] != 1 or masks.shape[1] != first.bases['kappa'].shape[1]:
+            return None
+        prior = first.bases if update.bases is None else update.bases
+        B, Ck, H, W = qk.shape
+        N, L = masks.shape[1], self.n_bases
+        pack = self._pack_for(N, Ck, qk.device)
+        prior_packed = update.bases is not None and self._stamped(1, update.bases)
+        out, self._next_out = getattr(self, '_next_out', None), None
+        if out is not None and out['kappa'].shape != prior['kappa'].shape:
+            out = None
+        xp = to_pixel_major(qk).view(H * W, Ck)
+        mk = masks.reshape(N, 2, H * W).contiguous()
+        kappa, zita, z = ops.memorize_keys(
+            xp, mk, prior['kappa'].view(N, 2, Ck, L), prior['zita'].view(N, 2, L), self.n_iters, self.tau, pack,
+            prior_packed=prior_packed, bank=1,
+            out=None if out is None else (out['kappa'].view(N, 2, Ck, L), out['zita'].view(N, 2, L)))
+        return {'kappa': kappa, 'zita': zita, 'z': z, 'prior': prior, 'pack': pack, 'out': out, 'shape': (N, Ck, H, W)}
+
+    def memorize_end(self, token, qv):
+        """The value update (modules.py:164-165) from the token's responsibilities, then the bank bookkeeping of `memorize`."""
+        N, Ck, H, W = token['shape']
+        L, prior, out = self.n_bases, token['prior'], token['out']
+        if qv.dim() == 5:
+            vp = to_pixel_major(qv.flatten(0, 1)).view(N, H * W, -1)
+        else:
+            vp = qv.view(N, H * W, -1)
+        nu = ops.memorize_values(vp, token['z'], prior['nu'].view(N, 2, -1, L), prior['zita'].view(N, 2, L), token['pack'], bank=1,
+                                 out=None if out is None else out['nu'].view(N, 2, -1, L))
+        bases = {'kappa': token['kappa'].view(1, N, 2, Ck, L), 'nu': nu.view(1, N, 2, -1, L),
+                 'zita': token['zita'].view(1, N, 2, 1, L)}
+        self.memories['first'].update(bases)
+        self.memories['update'].update(bases)
+        self._stamp[1] = self._stamp_of(bases)
+
     # ------------------------------------------------------------------ modules.py:232-293
     def _affinity_readout(self, qk, first, update):
         """get_affinity + perm_inv_feat in one kernel.  qk (B,Ck,h,w) RAW (normalised in-kernel, modules.py:282-283) ->

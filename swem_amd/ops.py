@@ -932,6 +932,44 @@ def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau, pack=None, pri
     return kappa, nu, zita
 
 
+def memorize_keys(x, masks, kappa_prev, zita_prev, T, tau, pack, prior_packed=False, bank=1, out=None):
+    """The part of memorize that does not read the value map (include/swem_hip.h, swem_memorize_packed_keys_f32): every E, W
+    and key M step.  x (P,C); masks (N,2,P); kappa_prev (N,2,C,L); zita_prev (N,2,L) -> (kappa, zita, z); the pack's key half
+    of bank `bank` is written.  out = (kappa, zita) tensors to write (not the priors)."""
+    for t in (x, masks, kappa_prev, zita_prev):
+        _chk(t)
+    P, Cc = x.shape
+    N, L = kappa_prev.shape[0], kappa_prev.shape[-1]
+    if out is not None:
+        kappa, zita = (_chk(t) for t in out)
+        if kappa.data_ptr() == kappa_prev.data_ptr() or zita.data_ptr() == zita_prev.data_ptr():
+            raise _lib.SwemHipError('memorize_keys: out must not alias the priors')
+    else:
+        kappa, zita = torch.empty_like(kappa_prev), torch.empty_like(zita_prev)
+    z = torch.empty((N, em_pad(P), 2 * L), dtype=torch.float32, device=x.device)
+    wsb = _lib.query('swem_memorize_workspace', N, Cc, 32, P, L)
+    ws = workspace(wsb, x.device)
+    _lib.call('swem_memorize_packed_keys_f32', _stream(), x.data_ptr(), masks.data_ptr(), kappa_prev.data_ptr(),
+              zita_prev.data_ptr(), kappa.data_ptr(), zita.data_ptr(), _chk(pack[0]).data_ptr(), z.data_ptr(), int(prior_packed),
+              int(bank), N, Cc, P, L, int(T), float(tau), ws.data_ptr(), wsb)
+    return kappa, zita, z
+
+
+def memorize_values(v, z, nu_prev, zita_prev, pack, bank=1, out=None):
+    """The value update of memorize from the responsibilities `memorize_keys` left: v (N,P,V); nu_prev (N,2,V,L) -> nu; the
+    pack's value half (and planes) of bank `bank` is written."""
+    for t in (v, z, nu_prev, zita_prev):
+        _chk(t)
+    N, P, V = v.shape
+    L = nu_prev.shape[-1]
+    nu = _chk(out) if out is not None else torch.empty_like(nu_prev)
+    if nu.data_ptr() == nu_prev.data_ptr():
+        raise _lib.SwemHipError('memorize_values: out must not alias the prior')
+    _lib.call('swem_memorize_packed_values_f32', _stream(), v.data_ptr(), z.data_ptr(), nu_prev.data_ptr(), zita_prev.data_ptr(),
+              nu.data_ptr(), _chk(pack[1]).data_ptr(), _pack_planes(pack), int(bank), N, V, P, L)
+    return nu
+
+
 def _match_plan(key, launch, M, V, nkb):
     """Readout plan of matching: the book's, else under conv_math((m,)) the heuristic tile in math mode m, else tuned."""
     plan = BOOK.match.get(key + _PLAN_TAG, 0)

@@ -81,6 +81,17 @@ class SWEM(nn.Module):
         masks = ops.mask_prep(masks_hard.contiguous(), masks_soft.float().contiguous(), h_16, w_16)
         self.swem_core.memorize(qk16, mv16, masks.view(b, n, 2, h_16, w_16))
 
+    # `memorize` in two calls (not in the reference): the part that does not need the value map, and the value update.
+    # memorize_begin returns None where the one-call form has to be used (frame 0, new object ids, a batch of clips).
+    def memorize_begin(self, qk16, masks_hard, masks_soft):
+        b, _, h_16, w_16 = qk16.shape
+        n = masks_hard.shape[1] - 1
+        masks = ops.mask_prep(masks_hard.contiguous(), masks_soft.float().contiguous(), h_16, w_16)
+        return self.swem_core.memorize_begin(qk16, masks.view(b, n, 2, h_16, w_16))
+
+    def memorize_end(self, token, mv16):
+        self.swem_core.memorize_end(token, mv16)
+
     # ------------------------------------------------------------------ swem.py:88-90
     def match(self, qk16, qv16):
         return self.swem_core.matching(qk16, qv16)

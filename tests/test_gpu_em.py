@@ -240,3 +240,33 @@ def test_packed_banks_equal_the_per_frame_packing(lib, L):
     err = float((mem_q - mem_p).abs().max()) / float(mem_p.abs().max())
     print('bf16x3 readout vs fp32 readout: rel %.3g' % err)
     assert 0 < err < 3e-5
+
+
+def test_memorize_in_two_calls_equals_the_one_call_form(lib):
+    """swem_memorize_packed_keys_f32 + swem_memorize_packed_values_f32 (the part of memorize that does not read the value map,
+    run beside the value encoder by evaluator.frame_chain; then the value update) launch the same blocks on the same data as
+    swem_memorize_packed_f32: bases and pack are bit-identical, also with the value update on another stream."""
+    g = torch.Generator().manual_seed(31)
+    N, C, V, P, L, T = 2, 128, 512, 405, 64, 4
+    d = lambda t: t.to(DEV)
+    x = d(torch.randn(P, C, generator=g))
+    v = d(torch.randn(N, P, V, generator=g))
+    m = d(torch.rand(N, 2, P, generator=g))
+    kp = d(torch.nn.functional.normalize(torch.randn(N, 2, C, L, generator=g), dim=2))
+    nup = d(torch.randn(N, 2, V, L, generator=g))
+    zp = d(torch.rand(N, 2, L, generator=g) * 3 + 0.1)
+    pack_a, pack_b = ops.new_pack(N, C, V, L, DEV), ops.new_pack(N, C, V, L, DEV)
+    for pk in (pack_a, pack_b):
+        ops.pack_bank(kp, nup, pk, 0)
+        ops.pack_bank(kp, nup, pk, 1)
+    ref = ops.memorize(x, v, m, kp, nup, zp, T, 0.05, pack=pack_a, prior_packed=True, bank=1)
+    kappa, zita, z = ops.memorize_keys(x, m, kp, zp, T, 0.05, pack_b, prior_packed=True, bank=1)
+    side = ops.new_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        nu = ops.memorize_values(v, z, nup, zp, pack_b, bank=1)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(kappa, ref[0]) and torch.equal(nu, ref[1]) and torch.equal(zita, ref[2])
+    for a, b in zip(pack_a, pack_b):
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b)

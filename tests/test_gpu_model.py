@@ -340,7 +340,8 @@ def test_lookahead_graph_matches_sequential_loop(lib, overlap):
     (or behind) the current three frames' chains.  With plans that do not depend on the batch (PlanBook.fallback = a tile
     without K-split: every output element is one k-ordered MFMA chain whatever the grid) the index maps AND the memory after
     the last frame are those of the frame-by-frame loop BIT FOR BIT; the batched outputs carry the bf16 planes their consumers
-    asked for (no split launch inside the captured chains)."""
+    asked for (no split launch inside the captured chains).  The side-stream variant also runs the key half of every memorize
+    beside the value encoder (em_overlap: SWEM.memorize_begin / memorize_end)."""
     from swem_amd import synth
     cfg = O.make_cfg(**CFG_A)
     k, t = 3, 12
@@ -356,7 +357,8 @@ def test_lookahead_graph_matches_sequential_loop(lib, overlap):
             model('init', mk16, model('encode_value', frames[:, 0], m0, s16), m0)
             preds = [evaluator.frame_step(model, frames[:, i], (128, 192)).clone() for i in (1, 2)]
             if lookahead:
-                g = evaluator.LookaheadGraph(model, frames[:, 1].shape, (128, 192), k, overlap=overlap).capture(frames[0, 3:3 + k])
+                g = evaluator.LookaheadGraph(model, frames[:, 1].shape, (128, 192), k, overlap=overlap,
+                                             em_overlap=overlap).capture(frames[0, 3:3 + k])
                 g.prime(frames[0, 3:3 + k])
                 for i in range(3, t, k):
                     nxt = frames[0, i + k:i + 2 * k] if i + 2 * k <= t else None
