@@ -1485,6 +1485,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
           __builtin_amdgcn_s_sleep(16);
       }
       __syncthreads();
+      if (tid == 0) __hip_atomic_store(p.sk_flags + u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed once: leave it zero
       const __amdgpu_buffer_rsrc_t rp =
           __builtin_amdgcn_make_buffer_rsrc(p.sk_ws + (long long)u * (BM * BN), 0, TILE_BYTES, 0x00020000);
 #pragma unroll
@@ -1503,8 +1504,78 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
       }
     }
   }
-  if constexpr (M16) conv_epilogue16<2 * TM, 2 * TN>(p, acc16, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
-  else conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, r, h);
+  // ---- K-split without a reduce launch (round 3: p.sk_flags set, gridDim.z splits).  Every split stores its partial tile past
+  // the caches (the stream-K layout: 16-byte chunks per lane), drains, and counts itself on the tile's counter; the split that
+  // arrives LAST adds all of them in z order -- its own from memory too, so the sum's order does not depend on who is last:
+  // deterministic -- and runs the epilogue.  Replaces conv_splitk_epilogue_kernel (one more launch of 5-10 us per K-split
+  // layer, twelve per frame) for this kernel; nobody waits for anybody.
+  bool fused_last = false;
+  if constexpr (!SK) {
+    if (p.partial && p.sk_flags) {
+      constexpr int NCH = 4 * TM * TN;
+      constexpr unsigned TILE_BYTES = BM * BN * 4;
+      const int nsp = (int)gridDim.z, tile_lin = (tm - p.mt0) * (int)gridDim.y + tn;
+      float *slots = p.partial + (long long)tile_lin * nsp * (BM * BN);
+      {
+        const __amdgpu_buffer_rsrc_t rp =
+            __builtin_amdgcn_make_buffer_rsrc(slots + (long long)blockIdx.z * (BM * BN), 0, TILE_BYTES, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          u32x4 v;
+          if constexpr (M16) {
+            const f32x4v t = acc16[c / (2 * TN)][c % (2 * TN)];
+            v.x = __float_as_uint(t[0]); v.y = __float_as_uint(t[1]); v.z = __float_as_uint(t[2]); v.w = __float_as_uint(t[3]);
+          } else {
+            const f32x16 t = acc[(c / 4) / TN][(c / 4) % TN];
+            v.x = __float_as_uint(t[4 * (c % 4)]); v.y = __float_as_uint(t[4 * (c % 4) + 1]);
+            v.z = __float_as_uint(t[4 * (c % 4) + 2]); v.w = __float_as_uint(t[4 * (c % 4) + 3]);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(v, rp, (unsigned)((c * 64 * NW + tid) * 16), 0, 0x11);   // sc0 sc1
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __shared__ unsigned sk_arrived;
+      __syncthreads();
+      if (tid == 0) sk_arrived = __hip_atomic_fetch_add(p.sk_flags + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (sk_arrived != (unsigned)(nsp - 1)) break;   // not the last split of this tile: done
+      fused_last = true;
+      if (tid == 0) __hip_atomic_store(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave it zero
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if constexpr (M16) acc16[c / (2 * TN)][c % (2 * TN)] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[(c / 4) / TN][(c / 4) % TN][4 * (c % 4) + e] = 0.f;
+      }
+      for (int zz = 0; zz < nsp; ++zz) {
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(slots + (long long)zz * (BM * BN), 0, TILE_BYTES, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rp, (unsigned)((c * 64 * NW + tid) * 16), 0, 0x11);
+          if constexpr (M16) {
+            f32x4v t = acc16[c / (2 * TN)][c % (2 * TN)];
+            t[0] += __uint_as_float(v.x); t[1] += __uint_as_float(v.y); t[2] += __uint_as_float(v.z); t[3] += __uint_as_float(v.w);
+            acc16[c / (2 * TN)][c % (2 * TN)] = t;
+          } else {
+            f32x16 t = acc[(c / 4) / TN][(c / 4) % TN];
+            t[4 * (c % 4)] += __uint_as_float(v.x); t[4 * (c % 4) + 1] += __uint_as_float(v.y);
+            t[4 * (c % 4) + 2] += __uint_as_float(v.z); t[4 * (c % 4) + 3] += __uint_as_float(v.w);
+            acc[(c / 4) / TN][(c / 4) % TN] = t;
+          }
+        }
+      }
+    }
+  }
+  if (fused_last) {   // the epilogue proper (the parameters' `partial` field only selects the raw-partials path)
+    ConvP q = p;
+    q.partial = nullptr;
+    if constexpr (M16) conv_epilogue16<2 * TM, 2 * TN>(q, acc16, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
+    else conv_epilogue<TM, TN>(q, acc, m0, n0, wm, wn, r, h);
+  } else {
+    if constexpr (M16) conv_epilogue16<2 * TM, 2 * TN>(p, acc16, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
+    else conv_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, r, h);
+  }
   STAMP(4);
   if (!sk) break;
   }   // segments
@@ -1839,13 +1910,17 @@ extern "C" size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, 
     TailSplit t = tail_split(plan, pl, (int)M, Ncols, nkb);
     return t.nsplit > 1 ? (size_t)t.nsplit * (M - (long long)t.main_mt * 64 * pl.wm) * Ncols * sizeof(float) : 0;
   }
-  return (size_t)pl.nsplit * M * Ncols * sizeof(float);
+  // (the pre-split kernel keeps padded partial TILES and a counter per tile; the fp32 kernels [z][M][Ncols]: the larger)
+  const size_t mt = cdiv(M, 64 * pl.wm), nt = cdiv(Ncols, 64 * pl.wn), tile = (size_t)64 * pl.wm * 64 * pl.wn * sizeof(float);
+  return (size_t)pl.nsplit * mt * nt * tile + mt * nt * sizeof(unsigned);
 }
 
 namespace {
 struct PlaneOut {
   void *planes[2];
   int npl[2];
+  unsigned *counters = nullptr;   // optional: caller-owned tile counters, ALL ZERO between calls (swem_conv2d_nhwc_bf16x3_planes_ctr)
+  size_t ncounters = 0;
 };
 // validate the optional output planes and put them into the launch parameters (after p.M / p.Cout are set)
 int set_planes(ConvP &p, const PlaneOut *po, bool glu, const char *who) {
@@ -2045,6 +2120,20 @@ extern "C" int swem_conv2d_nhwc_bf16x3_planes(void *stream, const void *x0, int 
   return conv2d_bf16x3_impl(stream, x0, c0, bs0, ps0, x1, c1, bs1, ps1, x2, c2, bs2, ps2, B, H, W, w_bf16x3, scale, shift, res,
                             res_bs, y, Cout, KH, KW, stride, pad, flags, plan, ws, ws_bytes, &po);
 }
+// ... with caller-owned tile counters: `counters` (ncounters words) must be ALL ZERO when the call is enqueued and must not be
+// used by another stream at the same time; the kernels leave it all zero again.  K-split and stream-K launches then need no
+// memset launch for their counters / flags (4.7 us each on this chip, as many as K-split layers per frame).
+extern "C" int swem_conv2d_nhwc_bf16x3_planes_ctr(void *stream, const void *x0, int c0, long long bs0, long long ps0,
+                                                  const void *x1, int c1, long long bs1, long long ps1, const void *x2, int c2,
+                                                  long long bs2, long long ps2, int B, int H, int W, const void *w_bf16x3,
+                                                  const float *scale, const float *shift, const float *res, long long res_bs,
+                                                  float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan,
+                                                  void *ws, size_t ws_bytes, void *planes, int nplanes, void *planes_relu,
+                                                  int nplanes_relu, void *counters, size_t ncounters) {
+  PlaneOut po{{planes, planes_relu}, {nplanes, nplanes_relu}, static_cast<unsigned *>(counters), ncounters};
+  return conv2d_bf16x3_impl(stream, x0, c0, bs0, ps0, x1, c1, bs1, ps1, x2, c2, bs2, ps2, B, H, W, w_bf16x3, scale, shift, res,
+                            res_bs, y, Cout, KH, KW, stride, pad, flags, plan, ws, ws_bytes, &po);
+}
 // batched GEMM on pre-split planes (common.h): y[b] = x[b] . w[b]^T with per-batch filter planes, w_bs bf16 elements apart
 int swem_gemm_bf16x3_batched(void *stream, const void *x, int K, long long bs, long long ps, int B, int M, const void *w,
                              long long w_bs, float *y, int Ncols, int plan, void *ws, size_t ws_bytes) {
@@ -2171,10 +2260,14 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
       p.partial = nullptr;
       p.sk_workers = (int)W; p.sk_mtiles = mtiles; p.sk_ntiles = ntiles;
       p.sk_ws = static_cast<float *>(ws);
-      p.sk_flags = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + (size_t)W * tile);
-      if (hipMemsetAsync(p.sk_flags, 0, (size_t)W * sizeof(unsigned), st) != hipSuccess) {
-        swem_set_error("conv2d_bf16x3: hipMemsetAsync of the stream-K flags failed");
-        return SWEM_E_HIP;
+      if (po && po->counters && po->ncounters >= (size_t)W) {
+        p.sk_flags = po->counters;     // zero on entry, reset by the workers that consume them: no memset launch
+      } else {
+        p.sk_flags = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + (size_t)W * tile);
+        if (hipMemsetAsync(p.sk_flags, 0, (size_t)W * sizeof(unsigned), st) != hipSuccess) {
+          swem_set_error("conv2d_bf16x3: hipMemsetAsync of the stream-K flags failed");
+          return SWEM_E_HIP;
+        }
       }
       static int dbg = -1;
       if (dbg < 0) dbg = getenv("SWEM_SK_DEBUG") ? 1 : 0;
@@ -2199,6 +2292,26 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
     const long long work = (M - t.part_m0) * (Cout / 4);
     hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(cdiv(work, 256)), dim3(256), 0, st, t, tl.nsplit);
     SWEM_CHECK_LAUNCH("conv_splitk_epilogue_kernel");
+    return SWEM_OK;
+  }
+  if (pl.nsplit > 1) {
+    // K-split reduced by the last-arriving split of every tile (see the kernel): partial TILES (padded), one counter per tile
+    const size_t tile = (size_t)64 * pl.wm * 64 * pl.wn * sizeof(float);
+    const size_t ntile = (size_t)mtiles * ntiles;
+    const size_t need = (size_t)pl.nsplit * ntile * tile + ntile * sizeof(unsigned);
+    SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_bf16x3: workspace %zu < %zu bytes (fused K-split)", ws_bytes, need);
+    p.partial = static_cast<float *>(ws);
+    if (po && po->counters && po->ncounters >= ntile) {
+      p.sk_flags = po->counters;       // zero on entry; the last-arriving split of a tile resets its counter: no memset launch
+    } else {
+      p.sk_flags = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + (size_t)pl.nsplit * ntile * tile);
+      if (hipMemsetAsync(p.sk_flags, 0, ntile * sizeof(unsigned), st) != hipSuccess) {
+        swem_set_error("conv2d_bf16x3: hipMemsetAsync of the K-split counters failed");
+        return SWEM_E_HIP;
+      }
+    }
+    if ((rc = run(p, dim3(mtiles, ntiles, pl.nsplit)))) return rc;
+    SWEM_CHECK_LAUNCH("conv_igemm_bf3s_kernel");
     return SWEM_OK;
   }
   if ((rc = run(p, dim3(mtiles, ntiles, pl.nsplit)))) return rc;

@@ -261,6 +261,32 @@ def workspace(nbytes, device):
     return buf
 
 
+_ctr = {}
+_ctr_capture = {}
+N_COUNTERS = 16384
+
+
+def counters(device):
+    """Tile counters for the K-split / stream-K convolution launches of the current stream (include/swem_hip.h,
+    swem_conv2d_nhwc_bf16x3_planes_ctr): a zero-initialised buffer per (device, stream) that the kernels leave all zero, so no
+    memset launch precedes each of them.  Inside a graph capture the buffer belongs to that capture (like `workspace`): graphs
+    captured on one stream may be replayed on different streams at the same time and must not share counters; its zero fill is
+    one node at the head of the graph, replayed with it."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    st = torch.cuda.current_stream().cuda_stream
+    cid = _capture_id(st)
+    if cid is None:
+        cache, key = _ctr, (dev, st)
+    else:
+        cache, key = _ctr_capture, (cid, dev, st)
+        if _ctr_capture and next(iter(_ctr_capture))[0] != cid:
+            _ctr_capture.clear()               # a new capture: the previous one's buffer stays with its graph
+    buf = cache.get(key)
+    if buf is None:
+        buf = cache[key] = torch.zeros(N_COUNTERS, dtype=torch.int32, device=device)
+    return buf
+
+
 class ConvPack:
     """Weights of one conv in kernel layout: w [Cout'][KH][KW][Cin_pad] plus per-filter scale / shift."""
 
@@ -456,9 +482,11 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
                 sargs += [sp.data_ptr(), s_.shape[3], args[3 * i + 2], sp.stride(0)]
             for _ in range(3 - len(srcs)):
                 sargs += [0, 0, 0, 0]
-            _lib.call('swem_conv2d_nhwc_bf16x3_planes', _stream(), *sargs, B, H, W, pack.w3.data_ptr(), _ptr(pack.scale),
+            ctr = counters(x0.device)
+            _lib.call('swem_conv2d_nhwc_bf16x3_planes_ctr', _stream(), *sargs, B, H, W, pack.w3.data_ptr(), _ptr(pack.scale),
                       _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw,
-                      pack.stride, pack.pad, flags & ~RELU_IN, plan, _ptr(ws), wsb, *pargs)
+                      pack.stride, pack.pad, flags & ~RELU_IN, plan, _ptr(ws), wsb, *pargs, _ptr(ctr),
+                      0 if ctr is None else ctr.numel())
             return
         _lib.call('swem_conv2d_nhwc_f32_planes', _stream(), *args, B, H, W, pack.w.data_ptr(), 0, _ptr(pack.scale),
                   _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw, pack.stride,
