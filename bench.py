@@ -275,7 +275,7 @@ def main():
     tune = not args.no_autotune and not args.load_plans   # per-layer plan chosen by timing, during warm-up only
     sd_box, clip_box = [None], {}
 
-    def make_runners(n, pipelined, seed_base):
+    def make_runners(n, pipelined, seed_base, tune=tune):
         """n independent sequences, each its own model (memory banks) on its own probed stream, warmed up (the first one
         tunes the plans of the current conv_math mode into `book`) and captured into its frame graph."""
         rs, sts = [], []
@@ -398,7 +398,9 @@ def main():
                                           'plans_digest': book.digest()}
             del r1, s1
         with ops.conv_math((0, 1)):
-            r32, s32 = make_runners(nseq, pipelined, 3234)
+            # (a loaded plan file may hold only the default leg's plans: this leg then tunes its own)
+            have32 = any(k_[-3:] == ('math', 0, 1) for k_ in book.conv)
+            r32, s32 = make_runners(nseq, pipelined, 3234, tune=tune or (not args.no_autotune and not have32))
             f32_, t32 = timed(r32, s32, args.steps)
         if rank == 0:
             h32 = {'fp32': 0, 'bf16x6': 0}
@@ -411,6 +413,8 @@ def main():
                                          'operands split exactly into three bf16 terms: fp32-level error), ops.conv_math((0, 1))'}
         del r32, s32
         torch.cuda.empty_cache()
+        if args.save_plans and rank == 0:
+            book.save(args.save_plans)             # again: with the plans the extra legs tuned
 
     if world == 1:
         # ---------------- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream

@@ -125,7 +125,7 @@ int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0,
  * convolutions that consume y pre-split -- no split launch and no re-read of y per consumer.
  *   planes       : planes of y, or NULL;  nplanes = 2 (hi, mid: every consumer runs bf16x3 / plain bf16) or 3
  *   planes_relu  : planes of relu(y) (for a consumer that applies its input ReLU while splitting, networks.py:26-27), or NULL
- * Bit-identical to swem_split_bf16x3_f32 on y.  Needs Cout % 8 == 0, not available with SWEM_CONV_GLU. */
+ * Bit-identical to swem_split_bf16x3_f32 on y.  Needs Cout % 8 == 0 (with SWEM_CONV_GLU: the planes of the gated output). */
 int swem_conv2d_nhwc_f32_planes(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
                                 long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
                                 const float *w, long long w_bs, const float *scale, const float *shift, const float *res,
@@ -170,6 +170,10 @@ int swem_prep_input_s2d_f32(void *stream, const float *frame, const float *masks
                             float *out, void *planes, int nplanes, int B, int N, int H, int W, int single_obj);
 /* nn.MaxPool2d(3, 2, 1): mod_resnet.py:123.  NHWC, C % 4 == 0 */
 int swem_maxpool3x3s2_nhwc_f32(void *stream, const float *x, float *y, int B, int H, int W, int C);
+/* The same, and the result's bf16 planes for the pre-split convolutions that consume it (mod_resnet.py:123 -> layer1's
+ * first block: conv1 and the downsample branch); arguments as swem_upsample_add_nhwc_f32_planes.  C % 8 == 0. */
+int swem_maxpool3x3s2_nhwc_f32_planes(void *stream, const float *x, float *y, int B, int H, int W, int C, void *planes,
+                                      int nplanes, void *planes_relu, int nplanes_relu);
 /* y = skip + bilinear(low -> Ho x Wo, align_corners=False): networks.py:193-194.  skip_bs 0 = shared skip */
 int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long long skip_bs, const float *low, float *y,
                                int B, int Hl, int Wl, int Ho, int Wo, int C);
@@ -198,6 +202,11 @@ size_t swem_cbam_workspace(int B, int H, int W, int C);
 int swem_cbam_f32(void *stream, const float *x, const float *w1, const float *b1, const float *w2, const float *b2,
                   const float *w7, const float *b7, float *cscale, float *y, int B, int H, int W, int C, int hid,
                   void *ws, size_t ws_bytes);
+/* The same, and y's bf16 planes for the pre-split convolution that consumes it (networks.py:46-48: block2 = ResBlock reads
+ * relu(y) and y); plane arguments as swem_upsample_add_nhwc_f32_planes.  C % 8 == 0 when a plane pointer is given. */
+int swem_cbam_f32_planes(void *stream, const float *x, const float *w1, const float *b1, const float *w2, const float *b2,
+                         const float *w7, const float *b7, float *cscale, float *y, int B, int H, int W, int C, int hid,
+                         void *ws, size_t ws_bytes, void *planes, int nplanes, void *planes_relu, int nplanes_relu);
 
 /* decoder.pred: conv3x3(relu(x)) -> 1 channel (networks.py:213).  x NHWC, w [3][3][C], logit [B][H][W] */
 int swem_pred_head_f32(void *stream, const float *x, const float *w, const float *bias, float *logit, int B, int H,

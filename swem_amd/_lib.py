@@ -34,12 +34,14 @@ SIGNATURES = {
     'swem_prep_value_input_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i]),
     'swem_prep_input_s2d_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_maxpool3x3s2_nhwc_f32': (_i, [_p, _p, _p, _i, _i, _i, _i]),
+    'swem_maxpool3x3s2_nhwc_f32_planes': (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _i]),
     'swem_upsample_add_nhwc_f32': (_i, [_p, _p, _ll, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_upsample_add_nhwc_f32_planes': (_i, [_p, _p, _ll, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i]),
     'swem_resize_planes_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_mask_prep_f32': (_i, [_p, _p, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i]),
     'swem_cbam_workspace': (_sz, [_i, _i, _i, _i]),
     'swem_cbam_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz]),
+    'swem_cbam_f32_planes': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i]),
     'swem_pred_head_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i]),
     'swem_decode_head_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_argmax_onehot_i64': (_i, [_p, _p, _p, _p, _i, _i, _ll]),

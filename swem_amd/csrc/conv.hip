@@ -257,22 +257,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][
   }
   if constexpr (WN == 2) {
     if (p.flags & SWEM_CONV_GLU) {
-      // packed columns [group][f|a][32]: this wave's two N tiles are the f and a banks of one group
+      // packed columns [group][f|a][32]: this wave's two N tiles are the f and a banks of one group; the gated values go
+      // through the wave's LDS slice and out in row layout like every other output (16-byte stores, bf16 planes)
       const int nf = ncol0 + r, na = ncol0 + 32 + r;
-      if (na >= p.Ncols) return;
-      const int co = (ncol0 >> 1) + r;
-      const float scf = p.scale ? p.scale[nf] : 1.f, sca = p.scale ? p.scale[na] : 1.f;
-      const float shf = p.shift ? p.shift[nf] : 0.f, sha = p.shift ? p.shift[na] : 0.f;
+      const bool nin = na < p.Ncols;
+      const float scf = (nin && p.scale) ? p.scale[nf] : 1.f, sca = (nin && p.scale) ? p.scale[na] : 1.f;
+      const float shf = (nin && p.shift) ? p.shift[nf] : 0.f, sha = (nin && p.shift) ? p.shift[na] : 0.f;
+      __syncthreads();   // every wave is done with the operand stages
+      unsigned *lds = planes_lds();
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+      for (int i = 0; i < WM; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          int m = mrow0 + 32 * i + acc_row(e, h);
-          if (m < p.M) {
-            float f = acc[i][0][e] * scf + shf, a = acc[i][1][e] * sca + sha;
-            p.y[(long long)m * p.Cout + co] = f * sigmoidf_(a);
-          }
+          const float f = acc[i][0][e] * scf + shf, a = acc[i][1][e] * sca + sha;
+          lds[acc_row(e, h) * PL_STRIDE + r] = __float_as_uint(f * sigmoidf_(a));
         }
+        out_tile32(p, lds, mrow0 + 32 * i, nin ? (ncol0 >> 1) : p.Cout);
+      }
       return;
     }
   }
@@ -886,20 +887,30 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP &p, f32x4v (&acc)[TM
   }
   if constexpr (TN2 == 4) {
     if (p.flags & SWEM_CONV_GLU) {
-      // packed columns [group][f|a][32]: tiles 0,1 are f, tiles 2,3 the gates of the same 32 channels
-      if (ncol0 + 64 > p.Ncols) return;
+      // packed columns [group][f|a][32]: tiles 0,1 are f, tiles 2,3 the gates of the same 32 channels; the gated values go
+      // through the wave's LDS slice and out in row layout (16-byte stores, bf16 planes)
+      static_assert(TM2 % 2 == 0, "the output staging works on 32 x 32 sub-tiles");
+      const bool nin = ncol0 + 64 <= p.Ncols;
+      float scf[2], sca[2], shf[2], sha[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int nf = ncol0 + 16 * j + col, na = nf + 32, co = (ncol0 >> 1) + 16 * j + col;
-        const float scf = p.scale ? p.scale[nf] : 1.f, sca = p.scale ? p.scale[na] : 1.f;
-        const float shf = p.shift ? p.shift[nf] : 0.f, sha = p.shift ? p.shift[na] : 0.f;
+        const int nf = ncol0 + 16 * j + col, na = nf + 32;
+        scf[j] = (nin && p.scale) ? p.scale[nf] : 1.f; sca[j] = (nin && p.scale) ? p.scale[na] : 1.f;
+        shf[j] = (nin && p.shift) ? p.shift[nf] : 0.f; sha[j] = (nin && p.shift) ? p.shift[na] : 0.f;
+      }
+      __syncthreads();   // every wave is done with the operand stages
+      unsigned *lds = planes_lds();
 #pragma unroll
-        for (int i = 0; i < TM2; ++i)
+      for (int i0 = 0; i0 < TM2; i0 += 2) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int m = mrow0 + 16 * i + 4 * rg + e;
-            if (m < p.M) p.y[(long long)m * p.Cout + co] = (acc[i][j][e] * scf + shf) * sigmoidf_(acc[i][j + 2][e] * sca + sha);
-          }
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              lds[(16 * ii + 4 * rg + e) * PL_STRIDE + 16 * j + col] = __float_as_uint(
+                  (acc[i0 + ii][j][e] * scf[j] + shf[j]) * sigmoidf_(acc[i0 + ii][j + 2][e] * sca[j] + sha[j]));
+        out_tile32(p, lds, mrow0 + 16 * i0, nin ? (ncol0 >> 1) : p.Cout);
       }
       return;
     }
@@ -1637,7 +1648,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
     if (p.flags & SWEM_CONV_RELU_OUT) v = relu4(v);
   }
   *reinterpret_cast<float4 *>(p.y + (long long)m * p.Cout + co) = v;
-  if (!(p.ysp[0] || p.ysp[1]) || glu) return;
+  if (!(p.ysp[0] || p.ysp[1])) return;
   // output planes (fused operand split): an even lane and its odd neighbour hold the 8 channels of one 16-byte run
   // (Cout / 4 is even -- Cout % 8 == 0 is the planes' precondition -- so a pair never straddles two pixels)
 #pragma unroll
@@ -1928,7 +1939,8 @@ int set_planes(ConvP &p, const PlaneOut *po, bool glu, const char *who) {
   p.ysp_npl[0] = p.ysp_npl[1] = 3;
   p.ysp_ps = (long long)p.M * p.Cout;
   if (!po || (!po->planes[0] && !po->planes[1])) return SWEM_OK;
-  SWEM_REQUIRE(!glu && p.Cout % 8 == 0, SWEM_E_SHAPE, "%s: output planes need Cout %% 8 == 0 and no GLU", who);
+  (void)glu;   // the gated output goes through the same row-layout stores as any other
+  SWEM_REQUIRE(p.Cout % 8 == 0, SWEM_E_SHAPE, "%s: output planes need Cout %% 8 == 0", who);
   for (int v = 0; v < 2; ++v) {
     SWEM_REQUIRE(!po->planes[v] || po->npl[v] == 2 || po->npl[v] == 3, SWEM_E_ARG, "%s: 2 or 3 output planes", who);
     p.ysp[v] = static_cast<unsigned short *>(po->planes[v]);

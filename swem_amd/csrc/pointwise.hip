@@ -152,6 +152,57 @@ __global__ void maxpool_kernel(const float *__restrict__ x, float *__restrict__ 
   st4(y + i * 4, m);
 }
 
+// bf16 planes (hi, mid[, lo]) of 8 consecutive channels of one pixel, with and / or without a ReLU, in the operand-split
+// layout [plane][C/8][npix][8] (split_bf16x3_kernel, conv.hip): i = channel group * npix + pixel, plane = npix * C.
+__device__ __forceinline__ void planes8_out(const float4 (&v)[2], unsigned short *pl0, int npl0, unsigned short *pl1, int npl1,
+                                            long long plane, long long i) {
+#pragma unroll
+  for (int var = 0; var < 2; ++var) {
+    unsigned short *out = var ? pl1 : pl0;
+    const int npl = var ? npl1 : npl0;
+    if (!out) continue;
+    uint2 h0, m0, l0, h1, m1, l1;
+    split3(var ? make_float4(fmaxf(v[0].x, 0.f), fmaxf(v[0].y, 0.f), fmaxf(v[0].z, 0.f), fmaxf(v[0].w, 0.f)) : v[0], h0, m0, l0);
+    split3(var ? make_float4(fmaxf(v[1].x, 0.f), fmaxf(v[1].y, 0.f), fmaxf(v[1].z, 0.f), fmaxf(v[1].w, 0.f)) : v[1], h1, m1, l1);
+    *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+    if (npl > 2) *reinterpret_cast<uint4 *>(out + 2 * plane + i * 8) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+  }
+}
+
+// maxpool_kernel plus the result's bf16 planes for the convolution that consumes it (the first block of layer1 reads the
+// pooled stem twice: conv1 and the downsample branch).  Block = 32 pixels x 8 channel groups, thread = (pixel, 8 channels).
+__global__ __launch_bounds__(256) void maxpool_planes_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                             unsigned short *__restrict__ pl0, int npl0,
+                                                             unsigned short *__restrict__ pl1, int npl1, int B, int H, int W,
+                                                             int C, int Ho, int Wo) {
+  const long long npix = (long long)B * Ho * Wo;
+  const long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int cg = blockIdx.y * 8 + (threadIdx.x & 7);
+  if (pix >= npix || cg >= C / 8) return;
+  const int ox = (int)(pix % Wo);
+  long long t = pix / Wo;
+  const int oy = (int)(t % Ho), b = (int)(t / Ho);
+  const float ninf = -__builtin_huge_valf();
+  float4 v[2] = {make_float4(ninf, ninf, ninf, ninf), make_float4(ninf, ninf, ninf, ninf)};
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 - 1 + ky;
+    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * 2 - 1 + kx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const float *src = x + (((long long)b * H + iy) * W + ix) * C + cg * 8;
+      v[0] = f4max(v[0], ld4(src));
+      v[1] = f4max(v[1], ld4(src + 4));
+    }
+  }
+  st4(y + pix * C + cg * 8, v[0]);
+  st4(y + pix * C + cg * 8 + 4, v[1]);
+  planes8_out(v, pl0, npl0, pl1, npl1, npix * C, (long long)cg * npix + pix);
+}
+
 __global__ void upsample_add_kernel(const float *__restrict__ skip, long long skip_bs, const float *__restrict__ low,
                                     float *__restrict__ y, int B, int Hl, int Wl, int Ho, int Wo, int C) {
   const int cq = C / 4;
@@ -203,19 +254,7 @@ __global__ __launch_bounds__(256) void upsample_add_planes_kernel(const float *_
     v[h] = f4add(ld4(sk + 4 * h), f4lerp2(ly.l0, r0, ly.l1, r1));
     st4(y + pix * C + cg * 8 + 4 * h, v[h]);
   }
-  const long long plane = npix * C, i = (long long)cg * npix + pix;
-#pragma unroll
-  for (int var = 0; var < 2; ++var) {
-    unsigned short *out = var ? pl1 : pl0;
-    const int npl = var ? npl1 : npl0;
-    if (!out) continue;
-    uint2 h0, m0, l0, h1, m1, l1;
-    split3(var ? make_float4(fmaxf(v[0].x, 0.f), fmaxf(v[0].y, 0.f), fmaxf(v[0].z, 0.f), fmaxf(v[0].w, 0.f)) : v[0], h0, m0, l0);
-    split3(var ? make_float4(fmaxf(v[1].x, 0.f), fmaxf(v[1].y, 0.f), fmaxf(v[1].z, 0.f), fmaxf(v[1].w, 0.f)) : v[1], h1, m1, l1);
-    *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-    *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
-    if (npl > 2) *reinterpret_cast<uint4 *>(out + 2 * plane + i * 8) = make_uint4(l0.x, l0.y, l1.x, l1.y);
-  }
+  planes8_out(v, pl0, npl0, pl1, npl1, npix * C, (long long)cg * npix + pix);
 }
 
 __global__ void resize_planes_kernel(const float *__restrict__ x, float *__restrict__ y, int planes, int Hi, int Wi,
@@ -443,6 +482,27 @@ __global__ void cbam_apply_kernel(const float *__restrict__ x, const float *__re
   float4 v = ld4(x + i * 4), g = ld4(cscale + (long long)b * C + c4 * 4);
   float s = sg[pix];
   st4(y + i * 4, make_float4(v.x + v.x * g.x * s, v.y + v.y * g.y * s, v.z + v.z * g.z * s, v.w + v.w * g.w * s));
+}
+
+// cbam_apply_kernel plus the result's bf16 planes (the value encoder's output feeds the fuser's first convolution).
+__global__ __launch_bounds__(256) void cbam_apply_planes_kernel(const float *__restrict__ x, const float *__restrict__ cscale,
+                                                                const float *__restrict__ sg, float *__restrict__ y,
+                                                                unsigned short *__restrict__ pl0, int npl0,
+                                                                unsigned short *__restrict__ pl1, int npl1, int B, int P, int C) {
+  const long long npix = (long long)B * P;
+  const long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int cg = blockIdx.y * 8 + (threadIdx.x & 7);
+  if (pix >= npix || cg >= C / 8) return;
+  const int b = (int)(pix / P);
+  const float s = sg[pix];
+  float4 v[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float4 u = ld4(x + pix * C + cg * 8 + 4 * h), g = ld4(cscale + (long long)b * C + cg * 8 + 4 * h);
+    v[h] = make_float4(u.x + u.x * g.x * s, u.y + u.y * g.y * s, u.z + u.z * g.z * s, u.w + u.w * g.w * s);
+    st4(y + pix * C + cg * 8 + 4 * h, v[h]);
+  }
+  planes8_out(v, pl0, npl0, pl1, npl1, npix * C, (long long)cg * npix + pix);
 }
 
 // ---------------------------------------------------------------- CBAM backward (training; attentions.py:22-84)
@@ -936,6 +996,20 @@ extern "C" int swem_maxpool3x3s2_nhwc_f32(void *stream, const float *x, float *y
   return SWEM_OK;
 }
 
+extern "C" int swem_maxpool3x3s2_nhwc_f32_planes(void *stream, const float *x, float *y, int B, int H, int W, int C,
+                                                 void *planes, int nplanes, void *planes_relu, int nplanes_relu) {
+  SWEM_REQUIRE(x && y && C % 8 == 0, SWEM_E_SHAPE, "maxpool_planes: need C %% 8 == 0");
+  SWEM_REQUIRE((!planes || (nplanes >= 2 && nplanes <= 3)) && (!planes_relu || (nplanes_relu >= 2 && nplanes_relu <= 3)),
+               SWEM_E_ARG, "maxpool_planes: 2 or 3 planes per variant");
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long npix = (long long)B * Ho * Wo;
+  hipLaunchKernelGGL(maxpool_planes_kernel, dim3((unsigned)cdiv(npix, 32), (unsigned)cdiv(C / 8, 8)), dim3(256), 0, ST, x, y,
+                     static_cast<unsigned short *>(planes), nplanes, static_cast<unsigned short *>(planes_relu), nplanes_relu,
+                     B, H, W, C, Ho, Wo);
+  SWEM_CHECK_LAUNCH("maxpool_planes");
+  return SWEM_OK;
+}
+
 extern "C" int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long long skip_bs, const float *low,
                                           float *y, int B, int Hl, int Wl, int Ho, int Wo, int C) {
   SWEM_REQUIRE(skip && low && y && C % 4 == 0, SWEM_E_SHAPE, "upsample_add: bad argument");
@@ -994,9 +1068,9 @@ extern "C" size_t swem_cbam_workspace(int B, int H, int W, int C) {
   return ((size_t)B * CBAM_CHUNKS * 2 * C + (size_t)B * H * W * 3) * sizeof(float);
 }
 
-extern "C" int swem_cbam_f32(void *stream, const float *x, const float *w1, const float *b1, const float *w2,
-                             const float *b2, const float *w7, const float *b7, float *cscale, float *y, int B, int H,
-                             int W, int C, int hid, void *ws, size_t ws_bytes) {
+static int cbam_impl(void *stream, const float *x, const float *w1, const float *b1, const float *w2, const float *b2,
+                     const float *w7, const float *b7, float *cscale, float *y, int B, int H, int W, int C, int hid, void *ws,
+                     size_t ws_bytes, void *planes, int nplanes, void *planes_relu, int nplanes_relu) {
   SWEM_REQUIRE(x && w1 && b1 && w2 && b2 && w7 && b7 && cscale && y, SWEM_E_ARG, "cbam: null pointer");
   SWEM_REQUIRE(C % 4 == 0 && C <= 4096 && hid > 0 && hid <= 256, SWEM_E_SHAPE, "cbam: unsupported C/hid");
   SWEM_REQUIRE(ws && ws_bytes >= swem_cbam_workspace(B, H, W, C), SWEM_E_WORKSPACE, "cbam: workspace too small");
@@ -1015,10 +1089,32 @@ extern "C" int swem_cbam_f32(void *stream, const float *x, const float *w1, cons
   SWEM_CHECK_LAUNCH("cbam_spatial_pool");
   hipLaunchKernelGGL(cbam_sgate_kernel, grid1((long long)B * P), dim3(256), 0, ST, comp, w7, b7, sg, B, H, W);
   SWEM_CHECK_LAUNCH("cbam_sgate");
-  hipLaunchKernelGGL(cbam_apply_kernel, grid1((long long)B * P * (C / 4)), dim3(256), 0, ST, x, cscale, sg, y, B, P,
-                     C);
+  if (planes || planes_relu) {
+    SWEM_REQUIRE(C % 8 == 0, SWEM_E_SHAPE, "cbam_planes: need C %% 8 == 0");
+    SWEM_REQUIRE((!planes || (nplanes >= 2 && nplanes <= 3)) && (!planes_relu || (nplanes_relu >= 2 && nplanes_relu <= 3)),
+                 SWEM_E_ARG, "cbam_planes: 2 or 3 planes per variant");
+    hipLaunchKernelGGL(cbam_apply_planes_kernel, dim3((unsigned)cdiv((long long)B * P, 32), (unsigned)cdiv(C / 8, 8)),
+                       dim3(256), 0, ST, x, cscale, sg, y, static_cast<unsigned short *>(planes), nplanes,
+                       static_cast<unsigned short *>(planes_relu), nplanes_relu, B, P, C);
+  } else {
+    hipLaunchKernelGGL(cbam_apply_kernel, grid1((long long)B * P * (C / 4)), dim3(256), 0, ST, x, cscale, sg, y, B, P, C);
+  }
   SWEM_CHECK_LAUNCH("cbam_apply");
   return SWEM_OK;
+}
+
+extern "C" int swem_cbam_f32(void *stream, const float *x, const float *w1, const float *b1, const float *w2,
+                             const float *b2, const float *w7, const float *b7, float *cscale, float *y, int B, int H,
+                             int W, int C, int hid, void *ws, size_t ws_bytes) {
+  return cbam_impl(stream, x, w1, b1, w2, b2, w7, b7, cscale, y, B, H, W, C, hid, ws, ws_bytes, nullptr, 3, nullptr, 3);
+}
+
+extern "C" int swem_cbam_f32_planes(void *stream, const float *x, const float *w1, const float *b1, const float *w2,
+                                    const float *b2, const float *w7, const float *b7, float *cscale, float *y, int B, int H,
+                                    int W, int C, int hid, void *ws, size_t ws_bytes, void *planes, int nplanes,
+                                    void *planes_relu, int nplanes_relu) {
+  return cbam_impl(stream, x, w1, b1, w2, b2, w7, b7, cscale, y, B, H, W, C, hid, ws, ws_bytes, planes, nplanes, planes_relu,
+                   nplanes_relu);
 }
 
 // backward of y = x + CBAM(x) (swem_cbam_f32): dx; the six parameter gradients are ACCUMULATED.

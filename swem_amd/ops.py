@@ -454,7 +454,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     # the output's own bf16 planes, if the convolutions that consumed this layer's output on an earlier frame split it:
     # the epilogue writes them (fused operand split: no split launch, no re-read of y)
     site = ('conv', pack.site_key, B, H, W, flags)
-    want = BOOK.hints.get(site) if (FUSE_SPLIT and dgrad is None and not pack.glu and pack.cout % 8 == 0) else None
+    want = BOOK.hints.get(site) if (FUSE_SPLIT and dgrad is None and pack.cout % 8 == 0) else None
     planes = {}
 
     def launch(plan, fresh=False):
@@ -706,7 +706,15 @@ def maxpool(x):
     _chk(x)
     B, H, W, Cc = x.shape
     y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.float32, device=x.device)
-    _lib.call('swem_maxpool3x3s2_nhwc_f32', _stream(), x.data_ptr(), y.data_ptr(), B, H, W, Cc)
+    site = ('maxpool', B, H, W, Cc)
+    planes, pargs = _fused_planes(site, y.numel(), y.device) if Cc % 8 == 0 else ({}, None)
+    if planes:
+        _lib.call('swem_maxpool3x3s2_nhwc_f32_planes', _stream(), x.data_ptr(), y.data_ptr(), B, H, W, Cc, *pargs)
+        y.__dict__['_swem_split'] = planes
+        y.__dict__['_swem_split_ver'] = y._version
+    else:
+        _lib.call('swem_maxpool3x3s2_nhwc_f32', _stream(), x.data_ptr(), y.data_ptr(), B, H, W, Cc)
+    y.__dict__['_swem_site'] = site
     return y
 
 
@@ -806,8 +814,17 @@ def cbam_residual(x, w1, b1, w2, b2, w7, b7):
     cscale = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
     wsb = _lib.query('swem_cbam_workspace', B, H, W, Cc)
     ws = workspace(wsb, x.device)
-    _lib.call('swem_cbam_f32', _stream(), x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-              w7.data_ptr(), b7.data_ptr(), cscale.data_ptr(), y.data_ptr(), B, H, W, Cc, hid, ws.data_ptr(), wsb)
+    site = ('cbam', B, H, W, Cc)
+    planes, pargs = _fused_planes(site, y.numel(), y.device) if Cc % 8 == 0 else ({}, None)
+    args = (_stream(), x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w7.data_ptr(),
+            b7.data_ptr(), cscale.data_ptr(), y.data_ptr(), B, H, W, Cc, hid, ws.data_ptr(), wsb)
+    if planes:
+        _lib.call('swem_cbam_f32_planes', *args, *pargs)
+        y.__dict__['_swem_split'] = planes
+        y.__dict__['_swem_split_ver'] = y._version
+    else:
+        _lib.call('swem_cbam_f32', *args)
+    y.__dict__['_swem_site'] = site
     return y
 
 

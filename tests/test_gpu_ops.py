@@ -347,6 +347,62 @@ def test_space_to_depth_stem_equals_the_7x7_stem(lib, value):
     assert float((got3 - ref).abs().max()) < 3e-5 * scale
 
 
+def _split_of(t, M, C, relu):
+    sp = torch.empty((3, M * C), dtype=torch.bfloat16, device=DEV)
+    __import__('swem_amd')._lib.call('swem_split_bf16x3_f32', ops._stream(), t.data_ptr(), sp.data_ptr(), M, C, int(relu))
+    return sp
+
+
+def _check_fused_planes(make, want, M, C):
+    """make() runs a producer; with a consumer's request recorded under its site the same call returns the same y plus
+    planes bit-identical to swem_split_bf16x3_f32 on y."""
+    ops.SPLIT_HINTS.clear()
+    y0 = make()
+    assert '_swem_split' not in y0.__dict__
+    try:
+        ops.SPLIT_HINTS[y0._swem_site] = dict(want)
+        y1 = make()
+        assert torch.equal(y1, y0)
+        got = y1.__dict__['_swem_split']
+        for relu, n in want.items():
+            assert got[relu][1] == n
+            assert torch.equal(got[relu][0][:n].view(torch.int16), _split_of(y0, M, C, relu)[:n].view(torch.int16))
+            assert ops.presplit(y1, relu, n) is got[relu][0]
+    finally:
+        ops.SPLIT_HINTS.clear()
+
+
+@pytest.mark.parametrize('plan', [0x00022, 0x10022, 0x30022, 0x230022, 0x630022, 0x630122, 0x30222, 0x830022, 0x8030022,
+                                  0xd30022, 0x530022, 0x1630022], ids=lambda p: '%#x' % p)
+def test_conv2d_glu_fused_output_planes(lib, plan):
+    """modules.py:25-26 (f * sigmoid(a)) with the gated output's bf16 planes written by the conv's own epilogue (32x32 and
+    16x16 accumulator layouts, separate and fused K-split reduce): the decoder's first ResBlock consumes it pre-split."""
+    g = torch.Generator().manual_seed(83)
+    a, q, s = torch.randn(2, 64, 19, 23, generator=g), torch.randn(1, 64, 19, 23, generator=g), torch.rand(2, 32, 19, 23, generator=g)
+    wf, wa = torch.randn(96, 160, 3, 3, generator=g) * 0.05, torch.randn(96, 160, 3, 3, generator=g) * 0.05
+    bf, ba = torch.randn(96, generator=g) * 0.1, torch.randn(96, generator=g) * 0.1
+    xin = torch.cat([a, q.expand(2, -1, -1, -1), s], 1)
+    ref = F.conv2d(xin, wf, bf, padding=1) * torch.sigmoid(F.conv2d(xin, wa, ba, padding=1))
+    pack = ops.pack_glu(wf.to(DEV), bf.to(DEV), wa.to(DEV), ba.to(DEV))
+    srcs = [nhwc(a), nhwc(q), nhwc(s)]
+    close(back(ops.conv2d(srcs, pack, batch=2, plan=plan)), ref, 2e-5, 'glu plan %#x' % plan)
+    _check_fused_planes(lambda: ops.conv2d(srcs, pack, batch=2, plan=plan), {False: 3, True: 2}, 2 * 19 * 23, 96)
+
+
+def test_maxpool_and_cbam_fused_output_planes(lib):
+    """mod_resnet.py:123 and networks.py:46-47 with the result's bf16 planes written by the producing launch."""
+    g = torch.Generator().manual_seed(6)
+    x = nhwc(torch.randn(2, 72, 21, 37, generator=g))
+    _check_fused_planes(lambda: ops.maxpool(x), {False: 2, True: 3}, 2 * 11 * 19, 72)
+    B, Cc, H, W, hid = 2, 136, 15, 27, 16
+    x = nhwc(torch.randn(B, Cc, H, W, generator=g))
+    par = [t.to(DEV).contiguous() for t in (torch.randn(hid, Cc, generator=g) * 0.05, torch.randn(hid, generator=g) * 0.1,
+                                            torch.randn(Cc, hid, generator=g) * 0.2, torch.randn(Cc, generator=g) * 0.1,
+                                            torch.randn(1, 2, 7, 7, generator=g) * 0.1, torch.randn(1, generator=g) * 0.1)]
+    _check_fused_planes(lambda: ops.cbam_residual(x, *par), {True: 2}, B * H * W, Cc)
+    _check_fused_planes(lambda: ops.cbam_residual(x, *par), {False: 3, True: 3}, B * H * W, Cc)
+
+
 def test_upsample_add_fused_output_planes(lib):
     """networks.py:193-194 with the result's bf16 planes written by the same launch (the decoder's ResBlocks consume it
     pre-split, with and without their input ReLU): y bit-identical to the plain kernel, planes bit-identical to
