@@ -221,7 +221,9 @@ def main():
                     help='independent sequences processed concurrently per GPU, each on its own HIP stream')
     ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
     ap.add_argument('--no-em', action='store_true', help='skip the EM/matching timing legs (profiler runs)')
-    ap.add_argument('--no-round3-forms', action='store_true', help='tuner without the prefetched-fragment / stream-K kernel forms')
+    ap.add_argument('--tune', action='store_true', help='ignore the shipped plan file: tune every layer shape on the device')
+    ap.add_argument('--no-roofline', action='store_true', help='skip the per-launch roofline / EM legs (plan search tools)')
+    ap.add_argument('--round3-forms', action='store_true', help='tuner also offers the prefetched-fragment / stream-K kernel forms')
     ap.add_argument('--no-legs', action='store_true', help='skip the single-sequence and fp32-level legs (profiler runs)')
     ap.add_argument('--trace-layers', default=None, help='write the per-launch conv list of the eager roofline frames (JSON)')
     ap.add_argument('--cpu-frames', type=int, default=20, help='timed frames of the CPU baseline (after 2 warm-up frames)')
@@ -266,13 +268,21 @@ def main():
     nseq = max(1, args.seqs)
     from swem_amd import evaluator
     book = ops.PlanBook()            # ONE book for every model of this process: tuned on the first sequence, read by all
+    plans_src = None
     if args.load_plans:
         book.load(args.load_plans)
-    if args.no_round3_forms:
-        ops.TUNE_ROUND3_FORMS = False
+        plans_src = args.load_plans
+    elif not args.tune and not args.no_autotune and os.path.exists(ops.shipped_plans()):
+        # default: the plan file that ships with the library for this workload (per-layer tuner + whole-frame check of the near
+        # ties, tools/tune_in_context.py: the tuner times a layer ALONE, which loses 2-4 % of the frame rate to ties that go
+        # the other way when four sequences share the chip); shapes it does not hold are tuned on the device
+        book.load_shipped()
+        plans_src = 'swem_amd/plans/mi355x_480p_k256.json (shipped; shapes it does not hold are tuned during warm-up; --tune re-tunes all)'
+    if args.round3_forms:
+        ops.TUNE_ROUND3_FORMS = True
     if args.max_split:
         ops._TUNE_SPLITS = tuple(v for v in ops._TUNE_SPLITS if v <= args.max_split)
-    tune = not args.no_autotune and not args.load_plans   # per-layer plan chosen by timing, during warm-up only
+    tune = not args.no_autotune and not args.load_plans   # per-layer plan chosen by timing, during warm-up only (missing shapes)
     sd_box, clip_box = [None], {}
 
     def make_runners(n, pipelined, seed_base, tune=tune):
@@ -381,7 +391,7 @@ def main():
             'fps_per_gpu': round(fps / world, 3),
             'frame_algorithmic_tflops': round(algorithmic_flops_per_frame(n_obj) * fps / world / 1e12, 2),
             'plans': {'conv_layer_shapes_by_math': hist, 'digest': book.digest(),
-                      'source': args.load_plans or ('on-device tuner during warm-up' if tune else 'built-in heuristic (fp32 MFMA)'),
+                      'source': plans_src or ('on-device tuner during warm-up' if tune else 'built-in heuristic (fp32 MFMA)'),
                       'math_modes_allowed': list(ops.CONV_MATH_MODES)},
         }
 
@@ -416,7 +426,7 @@ def main():
         if args.save_plans and rank == 0:
             book.save(args.save_plans)             # again: with the plans the extra legs tuned
 
-    if world == 1:
+    if world == 1 and not args.no_roofline:
         # ---------------- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream
         kla = args.lookahead if (args.lookahead > 0 and not args.no_graph) else 0
         nprof = min(args.steps, 5) if not kla else kla * max(1, 4 // kla)       # frames traced eagerly
@@ -434,10 +444,10 @@ def main():
         # aligned with a rocprofv3 kernel trace, tools/conv_by_layer.py; it is priced in `em_matching`, not here)
         real_mp = ops.match_packed
 
-        def marked(qk_, pack_, L_, topl_, tau_):
+        def marked(qk_, pack_, L_, topl_, tau_, **kw_):
             ops.CONV_TRACE.append((None, None, 2.0 * pack_[1].shape[0] * qk_.shape[0] * pack_[1].shape[1] * pack_[1].shape[2],
                                    'matching readout GEMM', 0.0, 0, 'readout'))
-            return real_mp(qk_, pack_, L_, topl_, tau_)
+            return real_mp(qk_, pack_, L_, topl_, tau_, **kw_)
         ops.match_packed = marked
         # The launch stream must never run dry while the frames are traced: with an empty queue a launch's event interval is
         # the HOST's enqueue time (~10 us per Python call), not the kernel's.  A spin kernel holds the GPU back until the host

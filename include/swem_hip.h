@@ -341,6 +341,15 @@ size_t swem_match_packed_workspace(int N, int C, int V, int P, int L, int readou
 int swem_match_packed_f32(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq, float *mem_out,
                           float *S, int N, int C, int V, int P, int L, int topl, float tau, int readout_plan, void *ws,
                           size_t ws_bytes);
+/* The same, and the outputs' own bf16 planes for the pre-split convolution that consumes them (the fusion conv of
+ * modules.py:286-291 reads cat([mem_out, qv, S])): mem_planes = planes of mem_out, [V/8][N*Pm][8] (Pm = swem_match_pad(P): the
+ * padded rows are part of the pixel axis), N*Pm*V elements apart; s_planes = planes of S, [2 topl/8][N*P][8], N*P*2*topl apart;
+ * *_nplanes = 2 or 3 written; either pointer may be NULL.  Bit-identical to swem_split_bf16x3_f32 on the fp32 outputs.
+ * Only with the pre-split readout (mvq given and readout_plan's math field 3); V % 8 == 0, topl % 4 == 0. */
+int swem_match_packed_f32_planes(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq,
+                                 float *mem_out, float *S, int N, int C, int V, int P, int L, int topl, float tau,
+                                 int readout_plan, void *ws, size_t ws_bytes, void *mem_planes, int mem_nplanes, void *s_planes,
+                                 int s_nplanes);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,7 @@ SIGNATURES = {
     'swem_match_pack_bank_f32': (_i, [_p] * 6 + [_i] * 6),
     'swem_match_packed_workspace': (_sz, [_i] * 6),
     'swem_match_packed_f32': (_i, [_p] * 7 + [_i] * 6 + [_f, _i, _p, _sz]),
+    'swem_match_packed_f32_planes': (_i, [_p] * 7 + [_i] * 6 + [_f, _i, _p, _sz, _p, _i, _p, _i]),
     # ---- include/swem_hip_train.h
     'swem_vos_loss_workspace': (_sz, [_i, _i, _ll]),
     'swem_vos_loss_frame_fwd_f32': (_i, [_p, _p, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _ll, _ll, _p, _p, _sz]),

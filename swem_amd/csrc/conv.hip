@@ -2148,9 +2148,11 @@ extern "C" int swem_conv2d_nhwc_bf16x3_planes_ctr(void *stream, const void *x0, 
 }
 // batched GEMM on pre-split planes (common.h): y[b] = x[b] . w[b]^T with per-batch filter planes, w_bs bf16 elements apart
 int swem_gemm_bf16x3_batched(void *stream, const void *x, int K, long long bs, long long ps, int B, int M, const void *w,
-                             long long w_bs, float *y, int Ncols, int plan, void *ws, size_t ws_bytes) {
+                             long long w_bs, float *y, int Ncols, int plan, void *ws, size_t ws_bytes, void *y_planes,
+                             int y_nplanes) {
+  PlaneOut po{{y_planes, nullptr}, {y_nplanes, 3}};
   return conv2d_bf16x3_impl(stream, x, K, bs, ps, nullptr, 0, 0, 0, nullptr, 0, 0, 0, B, M, 1, w, nullptr, nullptr, nullptr, 0, y,
-                            Ncols, 1, 1, 1, 0, 0, plan, ws, ws_bytes, nullptr, w_bs);
+                            Ncols, 1, 1, 1, 0, 0, plan, ws, ws_bytes, y_planes ? &po : nullptr, w_bs);
 }
 namespace {
 int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1, int c1,

@@ -130,7 +130,8 @@ typedef float f32x4m __attribute__((ext_vector_type(4)));
 template <int TW, int CM>  // TW 16-base tiles per wave (Ltot = 128 * TW), C = 16 * CM
 __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__restrict__ qk, const float *__restrict__ mkn,
                                                                float *__restrict__ pT, unsigned short *__restrict__ pq,
-                                                               float *__restrict__ S, int topl, int P, int Pm, float tau) {
+                                                               float *__restrict__ S, unsigned short *__restrict__ sq, int sq_npl,
+                                                               int topl, int P, int Pm, float tau) {
   constexpr int C = 16 * CM, Ltot = 128 * TW, Lm = Ltot / 2;
   constexpr int TP = TW > 4 ? 4 : TW, NPASS = TW / TP;   // tiles per pass: at most 4 (32 x 16 bytes of base rows in flight)
   __shared__ float red[2][8][16];
@@ -285,6 +286,18 @@ __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__re
         float *dst = S + ((long long)n * P + pp) * (2 * topl);
         dst[lane] = f;
         dst[topl + lane] = 1.f - f;
+        if (sq) {
+          // S's own bf16 planes [2 topl / 8][N * P][8] for the pre-split convolution that consumes it (modules.py:288-289):
+          // channel c of pixel gp is element ((c / 8) * npix + gp) * 8 + c % 8 of a plane
+          uint2 h, m, lo;
+          split3(make_float4(f, 1.f - f, 0.f, 0.f), h, m, lo);
+          const long long npix = (long long)gridDim.y * P, gp = (long long)n * P + pp, plane = npix * 2 * topl;
+          const long long i0 = ((long long)(lane >> 3) * npix + gp) * 8 + (lane & 7);
+          const long long i1 = ((long long)((topl + lane) >> 3) * npix + gp) * 8 + ((topl + lane) & 7);
+          sq[i0] = (unsigned short)h.x, sq[i1] = (unsigned short)(h.x >> 16);
+          sq[plane + i0] = (unsigned short)m.x, sq[plane + i1] = (unsigned short)(m.x >> 16);
+          if (sq_npl > 2) sq[2 * plane + i0] = (unsigned short)lo.x, sq[2 * plane + i1] = (unsigned short)(lo.x >> 16);
+        }
       }
     }
   }
@@ -349,12 +362,12 @@ __global__ __launch_bounds__(256) void match_topl_kernel(const float *__restrict
 // (there are only Pm/32 x N blocks, so a block's latency is the kernel's time)
 // S != NULL: the top-l features come out of the same launch (pT may then be NULL: nothing else reads the probabilities)
 static int launch_affinity(hipStream_t st, const float *qk, const float *mkn, float *pT, unsigned short *pq, float *S,
-                           int topl, int N, int C, int P, int Pm, int Lm, float tau) {
+                           unsigned short *sq, int sq_npl, int topl, int N, int C, int P, int Pm, int Lm, float tau) {
   if (C == 128 || C == 64) {
     // the grid covers all Pm rows of pT: the readout GEMM's last row tile reads rows [P, Pm), which pad tiles write as zeros
     dim3 grid16(Pm / 16, N);
 #define AFF16(TW_, CM_)                                                                                              \
-  hipLaunchKernelGGL((match_affinity16_kernel<TW_, CM_>), grid16, dim3(512), 0, st, qk, mkn, pT, pq, S, topl, P, Pm, tau)
+  hipLaunchKernelGGL((match_affinity16_kernel<TW_, CM_>), grid16, dim3(512), 0, st, qk, mkn, pT, pq, S, sq, sq_npl, topl, P, Pm, tau)
     if (C == 128) {
       if (Lm == 64) AFF16(1, 8);
       else if (Lm == 128) AFF16(2, 8);
@@ -573,19 +586,22 @@ namespace {
 // affinity + top-l features + readout on PACKED banks: mkn [2N][C/4+1][Lm][4], mvp [N][V][2Lm]
 int match_core(void *stream, const float *qk, const float *mkn, const float *mvp, const unsigned short *mvq, float *pT,
                unsigned short *pq, float *mem_out, float *S, int N, int C, int V, int P, int Lm, int topl, float tau,
-               int readout_plan, void *conv_ws, size_t conv_bytes) {
+               int readout_plan, void *conv_ws, size_t conv_bytes, void *mem_planes = nullptr, int mem_npl = 3,
+               void *s_planes = nullptr, int s_npl = 3) {
   const int Pm = swem_match_pad(P), Ltot = 2 * Lm;
   int rc;
   dim3 gridt(cdiv((long long)N * P, 4));
   // readout on pre-split planes ("bf16x3": hi + mid planes, three bf16 products -- the arithmetic of the convolutions that
   // consume mem_out) when the plan asks for it and the caller keeps the value planes
   const bool presplit = mvq && pq && ((readout_plan >> 16) & 3) == 3;
+  SWEM_REQUIRE(presplit || (!mem_planes && !s_planes), SWEM_E_ARG,
+               "match: output planes come with the pre-split readout only (value planes + readout plan math 3)");
   if (presplit) {
     // one launch: affinity + softmax, the probabilities as bf16 planes for the readout, and the top-l features
-    if ((rc = launch_affinity(ST, qk, mkn, nullptr, pq, S, topl, N, C, P, Pm, Lm, tau))) return rc;
+    if ((rc = launch_affinity(ST, qk, mkn, nullptr, pq, S, static_cast<unsigned short *>(s_planes), s_npl, topl, N, C, P, Pm, Lm, tau))) return rc;
     SWEM_CHECK_LAUNCH("match_affinity (fused top-l)");
   } else {
-    if ((rc = launch_affinity(ST, qk, mkn, pT, nullptr, nullptr, 0, N, C, P, Pm, Lm, tau))) return rc;
+    if ((rc = launch_affinity(ST, qk, mkn, pT, nullptr, nullptr, nullptr, 3, 0, N, C, P, Pm, Lm, tau))) return rc;
 #define TOPL(J_) hipLaunchKernelGGL((match_topl_kernel<J_>), gridt, dim3(256), 0, ST, pT, S, N, P, Pm, topl)
     if (Lm == 64) TOPL(1);
     else if (Lm == 128) TOPL(2);
@@ -598,7 +614,7 @@ int match_core(void *stream, const float *qk, const float *mkn, const float *mvp
   // "image" of Pm x 1 pixels with Ltot channels, 1x1 filters = the V value rows of object n (w_bs = V*Ltot)
   if (presplit)
     return swem_gemm_bf16x3_batched(stream, pq, Ltot, (long long)Pm * Ltot, (long long)N * Pm * Ltot, N, Pm, mvq,
-                                    (long long)2 * V * Ltot, mem_out, V, readout_plan, conv_ws, conv_bytes);
+                                    (long long)2 * V * Ltot, mem_out, V, readout_plan, conv_ws, conv_bytes, mem_planes, mem_npl);
   return swem_conv2d_nhwc_f32(stream, pT, Ltot, (long long)Pm * Ltot, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, mvp,
                               (long long)V * Ltot, nullptr, nullptr, nullptr, 0, mem_out, V, 1, 1, 1, 0, 0,
                               readout_plan, conv_ws, conv_bytes);
@@ -663,19 +679,39 @@ extern "C" size_t swem_match_packed_workspace(int N, int C, int V, int P, int L,
   return w.total - w.pT;
 }
 
-extern "C" int swem_match_packed_f32(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq,
-                                     float *mem_out, float *S, int N, int C, int V, int P, int L, int topl, float tau,
-                                     int readout_plan, void *ws, size_t ws_bytes) {
+namespace {
+int match_packed_impl(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq, float *mem_out, float *S,
+                      int N, int C, int V, int P, int L, int topl, float tau, int readout_plan, void *ws, size_t ws_bytes,
+                      void *mem_planes, int mem_npl, void *s_planes, int s_npl) {
   SWEM_REQUIRE(qk && mkn && mvp && mem_out && S, SWEM_E_ARG, "match_packed: null pointer");
   int rc;
   if ((rc = match_check(C, V, L, 2 * L, topl, tau))) return rc;
+  SWEM_REQUIRE((!mem_planes || ((mem_npl == 2 || mem_npl == 3) && V % 8 == 0)) &&
+                   (!s_planes || ((s_npl == 2 || s_npl == 3) && topl % 4 == 0)),
+               SWEM_E_ARG, "match_packed: output planes: 2 or 3 per tensor, V %% 8 == 0, topl %% 4 == 0");
   MatchWs w = match_ws(N, C, V, P, L, 2, readout_plan);
   SWEM_REQUIRE(ws && ws_bytes >= w.total - w.pT, SWEM_E_WORKSPACE, "match_packed: workspace %zu < %zu", ws_bytes,
                w.total - w.pT);
   char *base = static_cast<char *>(ws) - w.pT;     // the workspace starts at the probability slot
   return match_core(stream, qk, mkn, mvp, static_cast<const unsigned short *>(mvq), (float *)(base + w.pT),
                     (unsigned short *)(base + w.pq), mem_out, S, N, C, V, P, 2 * L, topl, tau, readout_plan, base + w.conv,
-                    w.total - w.conv);
+                    w.total - w.conv, mem_planes, mem_npl, s_planes, s_npl);
+}
+}  // namespace
+
+extern "C" int swem_match_packed_f32(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq,
+                                     float *mem_out, float *S, int N, int C, int V, int P, int L, int topl, float tau,
+                                     int readout_plan, void *ws, size_t ws_bytes) {
+  return match_packed_impl(stream, qk, mkn, mvp, mvq, mem_out, S, N, C, V, P, L, topl, tau, readout_plan, ws, ws_bytes, nullptr, 3,
+                           nullptr, 3);
+}
+
+extern "C" int swem_match_packed_f32_planes(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq,
+                                            float *mem_out, float *S, int N, int C, int V, int P, int L, int topl, float tau,
+                                            int readout_plan, void *ws, size_t ws_bytes, void *mem_planes, int mem_nplanes,
+                                            void *s_planes, int s_nplanes) {
+  return match_packed_impl(stream, qk, mkn, mvp, mvq, mem_out, S, N, C, V, P, L, topl, tau, readout_plan, ws, ws_bytes, mem_planes,
+                           mem_nplanes, s_planes, s_nplanes);
 }
 
 // backward of swem_match_f32 for one clip: d mem_out [N][Pm][V] and dS [N][P][2*topl] (either may be NULL) ->
@@ -716,7 +752,7 @@ extern "C" int swem_match_bwd_f32(void *stream, const float *qk, const float *ka
   if (nbanks == 2)
     hipLaunchKernelGGL(pack_values_kernel, dim3(cdiv(work, 256)), dim3(256), 0, ST, nu_update, mvp, N, V, L, Lm, L);
   dim3 gridt(cdiv((long long)N * P, 4));
-  if ((rc = launch_affinity(ST, qk, mkn, pT, nullptr, nullptr, 0, N, C, P, Pm, Lm, tau))) return rc;
+  if ((rc = launch_affinity(ST, qk, mkn, pT, nullptr, nullptr, nullptr, 3, 0, N, C, P, Pm, Lm, tau))) return rc;
   SWEM_CHECK_LAUNCH("match_bwd (forward recompute)");
   // (1) dP[n] = dmem[n] . mvp[n]   (batched GEMM on the conv kernel; filters = mvp[n]^T [Ltot][V])
   if ((rc = swem_transpose_f32(stream, mvp, mvpT, N, V, Ltot, V))) return rc;

@@ -370,24 +370,46 @@ __global__ void mask_prep_kernel(const HT *__restrict__ hard, int Hh, int Wh, co
 
 // ---------------------------------------------------------------- CBAM
 constexpr int CBAM_CHUNKS = 32;
-// stage 1: per (b, chunk): partial sum and max over the chunk's pixels for every channel
-__global__ void cbam_pool_partial_kernel(const float *__restrict__ x, float *__restrict__ part, int P, int C) {
+// stage 1: per (b, chunk): partial sum and max over the chunk's pixels for every channel.  A work item = (4 channels,
+// one of nsub interleaved pixel subsets of the chunk): nsub x C/4 items per block, so a thread's chain of dependent loads is
+// per / nsub pixels long (6-7 at 1/16 of 480p: the kernel is latency, not bandwidth: 6.6 MB); the subsets are combined in
+// a fixed order through the LDS (deterministic sums).
+__global__ __launch_bounds__(1024) void cbam_pool_partial_kernel(const float *__restrict__ x, float *__restrict__ part, int P,
+                                                                 int C, int nsub) {
+  extern __shared__ float4 psm[];   // [nsub][2][C/4]
   const int cq = C / 4;
   const int b = blockIdx.y, ch = blockIdx.x;
   const int per = (P + CBAM_CHUNKS - 1) / CBAM_CHUNKS;
   const int p0 = ch * per, p1 = min(P, p0 + per);
   const float ninf = -__builtin_huge_valf();
-  for (int c4 = threadIdx.x; c4 < cq; c4 += blockDim.x) {
+  for (int it = threadIdx.x; it < cq * nsub; it += blockDim.x) {
+    const int c4 = it % cq, sub = it / cq;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), m = make_float4(ninf, ninf, ninf, ninf);
-    for (int p = p0; p < p1; ++p) {
+#pragma unroll 4
+    for (int p = p0 + sub; p < p1; p += nsub) {
       float4 v = ld4(x + ((long long)b * P + p) * C + c4 * 4);
       s = f4add(s, v);
       m = f4max(m, v);
+    }
+    psm[(sub * 2) * cq + c4] = s;
+    psm[(sub * 2 + 1) * cq + c4] = m;
+  }
+  __syncthreads();
+  for (int c4 = threadIdx.x; c4 < cq; c4 += blockDim.x) {
+    float4 s = psm[c4], m = psm[cq + c4];
+    for (int sub = 1; sub < nsub; ++sub) {
+      s = f4add(s, psm[(sub * 2) * cq + c4]);
+      m = f4max(m, psm[(sub * 2 + 1) * cq + c4]);
     }
     float *dst = part + (((long long)b * CBAM_CHUNKS + ch) * 2) * C + c4 * 4;
     st4(dst, s);
     st4(dst + C, m);
   }
+}
+static void launch_cbam_pool(hipStream_t st, const float *x, float *part, int B, int P, int C) {
+  const int nsub = C <= 1024 ? 8 : C <= 2048 ? 4 : 2;    // nsub x 2 x C floats of LDS: at most 64 KB (C <= 4096)
+  hipLaunchKernelGGL(cbam_pool_partial_kernel, dim3(CBAM_CHUNKS, B), dim3(1024), (size_t)nsub * 2 * C * sizeof(float), st, x,
+                     part, P, C, nsub);
 }
 // stage 2 + MLP (attentions.py:26-50): one block per batch item
 __global__ void cbam_mlp_kernel(const float *__restrict__ part, const float *__restrict__ w1,
@@ -396,15 +418,17 @@ __global__ void cbam_mlp_kernel(const float *__restrict__ part, const float *__r
   extern __shared__ float sm[];  // avg[C], max[C], hidden[2][hid]
   float *avg = sm, *mx = sm + C, *hd = sm + 2 * C;
   const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f, m = -__builtin_huge_valf();
+  for (int it = threadIdx.x; it < 2 * C; it += blockDim.x) {   // item = (channel, sum | max): independent loads, unrolled
+    const int c = it % C, kind = it / C;
+    const float *src = part + ((long long)b * CBAM_CHUNKS * 2 + kind) * C + c;
+    float r = kind ? -__builtin_huge_valf() : 0.f;
+#pragma unroll 8
     for (int ch = 0; ch < CBAM_CHUNKS; ++ch) {
-      const float *src = part + (((long long)b * CBAM_CHUNKS + ch) * 2) * C + c;
-      s += src[0];
-      m = fmaxf(m, src[C]);
+      const float v = src[(long long)ch * 2 * C];
+      r = kind ? fmaxf(r, v) : r + v;
     }
-    avg[c] = s / (float)P;
-    mx[c] = m;
+    if (kind) mx[c] = r;
+    else avg[c] = r / (float)P;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -419,12 +443,83 @@ __global__ void cbam_mlp_kernel(const float *__restrict__ part, const float *__r
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float sa = b2[c], sm_ = b2[c];
+#pragma unroll 8
     for (int j = 0; j < hid; ++j) {
       float wv = w2[(long long)c * hid + j];
       sa += wv * hd[j];
       sm_ += wv * hd[hid + j];
     }
     cscale[(long long)b * C + c] = sigmoidf_(sa + sm_);
+  }
+}
+// The same for C <= 512, hid <= 32 (hid % 4 == 0), 1024 threads: the kernel is three dependent rounds of global loads on one
+// block per image (17 us of pure latency at 1/16 of 480p); the weights do not depend on the data, so every load of all
+// three rounds is issued up front and the rounds run from registers.  Same summation order as cbam_mlp_kernel.
+__global__ __launch_bounds__(1024) void cbam_mlp_fast_kernel(const float *__restrict__ part, const float *__restrict__ w1,
+                                                             const float *__restrict__ b1, const float *__restrict__ w2,
+                                                             const float *__restrict__ b2, float *__restrict__ cscale, int P,
+                                                             int C, int hid) {
+  extern __shared__ float sm[];  // avg[C], max[C], hidden[2][hid]
+  float *avg = sm, *mx = sm + C, *hd = sm + 2 * C;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool pin = t < 2 * C;
+  const int pc = pin ? t % C : 0, kind = pin ? t / C : 0;
+  const float *src = part + ((long long)b * CBAM_CHUNKS * 2 + kind) * C + pc;
+  float pv[CBAM_CHUNKS];
+#pragma unroll
+  for (int ch = 0; ch < CBAM_CHUNKS; ++ch) pv[ch] = pin ? src[(long long)ch * 2 * C] : 0.f;
+  float w1r[4][8], b1r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = wave + 16 * r;
+    const bool jin = j < 2 * hid;
+    const float *wr = w1 + (long long)(jin ? j % hid : 0) * C;
+    b1r[r] = jin ? b1[j % hid] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w1r[r][k] = (jin && lane + 64 * k < C) ? wr[lane + 64 * k] : 0.f;
+  }
+  const bool cin = t < C;
+  float4 w2r[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    w2r[q] = (cin && 4 * q < hid) ? ld4(w2 + (long long)t * hid + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float b2r = cin ? b2[t] : 0.f;
+  if (pin) {
+    float r = kind ? -__builtin_huge_valf() : 0.f;
+#pragma unroll
+    for (int ch = 0; ch < CBAM_CHUNKS; ++ch) r = kind ? fmaxf(r, pv[ch]) : r + pv[ch];
+    if (kind) mx[pc] = r;
+    else avg[pc] = r / (float)P;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = wave + 16 * r;
+    if (j >= 2 * hid) continue;
+    const float *v = j < hid ? avg : mx;
+    float sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (lane + 64 * k < C) sacc += w1r[r][k] * v[lane + 64 * k];
+    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+    if (lane == 0) hd[j] = fmaxf(sacc + b1r[r], 0.f);
+  }
+  __syncthreads();
+  if (cin) {
+    float sa = b2r, sm_ = b2r;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float wv[4] = {w2r[q].x, w2r[q].y, w2r[q].z, w2r[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = 4 * q + e;
+        if (j < hid) {
+          sa += wv[e] * hd[j];
+          sm_ += wv[e] * hd[hid + j];
+        }
+      }
+    }
+    cscale[(long long)b * C + t] = sigmoidf_(sa + sm_);
   }
 }
 // channel max / mean of x*cscale per pixel: one wave per pixel (attentions.py:53-55)
@@ -1078,11 +1173,16 @@ static int cbam_impl(void *stream, const float *x, const float *w1, const float 
   float *part = static_cast<float *>(ws);
   float *comp = part + (size_t)B * CBAM_CHUNKS * 2 * C;
   float *sg = comp + (size_t)B * P * 2;
-  hipLaunchKernelGGL(cbam_pool_partial_kernel, dim3(CBAM_CHUNKS, B), dim3(256), 0, ST, x, part, P, C);
+  launch_cbam_pool(ST, x, part, B, P, C);
   SWEM_CHECK_LAUNCH("cbam_pool_partial");
   // one block per batch item, 16 waves: the 2*hid hidden units are a wave each (4 waves took 48 us for this tiny MLP)
-  hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(1024), (2 * C + 2 * hid) * sizeof(float), ST, part, w1, b1, w2, b2,
-                     cscale, P, C, hid);
+  if (C <= 512 && hid <= 32 && hid % 4 == 0) {
+    hipLaunchKernelGGL(cbam_mlp_fast_kernel, dim3(B), dim3(1024), (2 * C + 2 * hid) * sizeof(float), ST, part, w1, b1, w2, b2,
+                       cscale, P, C, hid);
+  } else {
+    hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(1024), (2 * C + 2 * hid) * sizeof(float), ST, part, w1, b1, w2, b2,
+                       cscale, P, C, hid);
+  }
   SWEM_CHECK_LAUNCH("cbam_mlp");
   hipLaunchKernelGGL(cbam_spatial_pool_kernel, grid1((long long)B * P * 64), dim3(256), 0, ST, x, cscale, comp, B, P,
                      C);
@@ -1145,7 +1245,7 @@ extern "C" int swem_cbam_bwd_f32(void *stream, const float *x, const float *w1, 
   float *du = reinterpret_cast<float *>(amax + (size_t)B * C);
   float *dxp = du + (size_t)B * P * C;
   // forward intermediates again (cheap next to keeping them alive across the whole clip)
-  hipLaunchKernelGGL(cbam_pool_partial_kernel, dim3(CBAM_CHUNKS, B), dim3(256), 0, ST, x, part, P, C);
+  launch_cbam_pool(ST, x, part, B, P, C);
   hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(256), (2 * C + 2 * hid) * sizeof(float), ST, part, w1, b1, w2, b2,
                      cscale, P, C, hid);
   hipLaunchKernelGGL(cbam_stats_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, ST, part, avg, mx, P, C);

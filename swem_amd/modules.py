@@ -316,9 +316,9 @@ class SWEMCore(nn.Module):
         xp = to_pixel_major(qk).view(B, H * W, Ck)
         N, L = first['kappa'].shape[1], first['kappa'].shape[-1]
         if B == 1 and update is not None:       # both banks: matching reads the persistent pack (kept current by memorize)
-            mem_out, S = ops.match_packed(xp[0], self.repack(), L, self.topl, self.tau)
             # mem_out keeps a row pitch per object (ops.match): NHWC images, free batch stride
-            return S.view(N, H, W, -1), mem_out.unflatten(1, (H, W))
+            mem_out, S = ops.match_packed(xp[0], self.repack(), L, self.topl, self.tau, hw=(H, W))
+            return S, mem_out
         mems, Ss = [], []
         for b in range(B):     # the first matched frame of a sequence (one bank) or a batch of clips: packed in the call
             kf = first['kappa'][b].reshape(N, 2, Ck, L).contiguous()

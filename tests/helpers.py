@@ -33,11 +33,11 @@ ARITH_MODES = ('fp32', 'bf16x3', 'tuned')
 
 
 def tuned_plans_path():
-    """The newest committed plan file of the bench configuration (profiles/rNN_tuned_plans.json)."""
-    import glob
+    """The plan file of the bench configuration that ships with the library (what `python bench.py` runs by default)."""
     import os
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'r[0-9][0-9]_tuned_plans.json')))
-    return files[-1] if files else None
+    from swem_amd import ops
+    path = ops.shipped_plans()
+    return path if os.path.exists(path) else None
 
 
 class arith:
@@ -62,7 +62,7 @@ class arith:
             self.cm.__enter__()
         elif self.mode == 'tuned':
             path = tuned_plans_path()
-            assert path, 'no profiles/rNN_tuned_plans.json'
+            assert path, 'no shipped plan file (swem_amd/plans/)'
             for m in self.models:              # models, or PlanBooks
                 getattr(m, 'book', m).load(path)
         ops.MATH_RAN = self.ran

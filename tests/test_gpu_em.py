@@ -234,8 +234,26 @@ def test_packed_banks_equal_the_per_frame_packing(lib, L):
     try:
         ops._MATCH_PLANS[key] = 2 | 2 << 4 | 1 << 8 | 3 << 16
         mem_q, S_q = ops.match_packed(d(qx), pack, L, 64, 0.05)
+        # ... and, as NHWC images, with their own bf16 planes once the fusion conv has asked for them (swem_match_packed_f32_planes):
+        # same outputs, planes bit-identical to swem_split_bf16x3_f32 (mem_out's pixel axis is the PADDED one)
+        mem_i, S_i = ops.match_packed(d(qx), pack, L, 64, 0.05, hw=(h, w))
+        assert torch.equal(mem_i.flatten(1, 2), mem_q) and torch.equal(S_i.flatten(1, 2), S_q)
+        assert '_swem_split' not in mem_i.__dict__ and '_swem_split' not in S_i.__dict__
+        ops.SPLIT_HINTS[mem_i._swem_site] = {False: 2}
+        ops.SPLIT_HINTS[S_i._swem_site] = {False: 3}
+        mem_j, S_j = ops.match_packed(d(qx), pack, L, 64, 0.05, hw=(h, w))
+        assert torch.equal(mem_j, mem_i) and torch.equal(S_j, S_i)
+        Pm = mem_j.stride(0) // V
+        full = torch.as_strided(mem_j, (N, Pm, V), (Pm * V, V, 1))
+        for img, flat, npix, Cc, npl in ((mem_j, full, N * Pm, V, 2), (S_j, S_j, N * P, 128, 3)):
+            planes, n_ = img.__dict__['_swem_split'][False]
+            assert n_ == npl and ops.presplit(img, False, npl) is planes
+            sp = torch.empty((3, npix * Cc), dtype=torch.bfloat16, device=DEV)
+            __import__('swem_amd')._lib.call('swem_split_bf16x3_f32', ops._stream(), flat.data_ptr(), sp.data_ptr(), npix, Cc, 0)
+            assert torch.equal(planes[:npl].view(torch.int16), sp[:npl].view(torch.int16))
     finally:
         ops._MATCH_PLANS.pop(key, None)
+        ops.SPLIT_HINTS.clear()
     assert torch.equal(S_q, S_p)
     err = float((mem_q - mem_p).abs().max()) / float(mem_p.abs().max())
     print('bf16x3 readout vs fp32 readout: rel %.3g' % err)

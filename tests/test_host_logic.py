@@ -192,10 +192,10 @@ def test_plan_book_scoping_roundtrip_and_flags(tmp_path):
     m1, m2 = SWEM(O.make_cfg(BACKBONE='resnet18', NUM_BASES=64)), SWEM(O.make_cfg(BACKBONE='resnet18', NUM_BASES=64))
     assert m1.book is not m2.book and isinstance(m1.book, ops.PlanBook)
     # module switches for a block
-    assert ops.FUSE_SPLIT and ops.TUNE_ROUND3_FORMS
-    with ops.flags(FUSE_SPLIT=False, TUNE_ROUND3_FORMS=False):
-        assert not ops.FUSE_SPLIT and not ops.TUNE_ROUND3_FORMS
-    assert ops.FUSE_SPLIT and ops.TUNE_ROUND3_FORMS
+    assert ops.FUSE_SPLIT and not ops.TUNE_ROUND3_FORMS
+    with ops.flags(FUSE_SPLIT=False, TUNE_ROUND3_FORMS=True):
+        assert not ops.FUSE_SPLIT and ops.TUNE_ROUND3_FORMS
+    assert ops.FUSE_SPLIT and not ops.TUNE_ROUND3_FORMS
     # layer names of the hints: stable under pack_keys, unique otherwise
     with ops.pack_keys('engine'):
         k1 = ops._next_pack_key()

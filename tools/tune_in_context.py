@@ -1,0 +1,71 @@
+"""Plan refinement IN CONTEXT: the per-layer tuner (ops._autotune) times a layer alone on an idle chip; in the frame the
+layers of four sequences and of the batched key encoder share the CUs, and some near ties go the other way.  Starting from
+a plan file, every layer shape on which alternative plan files disagree is flipped to the alternative, the default bench
+workload (four sequences, graph replay, no extra legs) is timed in a child process, and the flip is kept if the whole-job
+frames/s improves by more than the noise margin.
+
+    python tools/tune_in_context.py BASE.json OUT.json ALT1.json [ALT2.json ...] [--margin 0.004] [--steps 20]
+
+The parent never touches the GPU (children are plain `python bench.py ...` processes)."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def fps_of(plans, steps, extra):
+    with tempfile.NamedTemporaryFile('w', suffix='.json', delete=False, dir=ROOT) as f:
+        json.dump(plans, f)
+        path = f.name
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', str(steps), '--warmup', '3', '--no-legs',
+                              '--no-cpu-baseline', '--no-em', '--no-roofline', '--load-plans', path] + extra,
+                             capture_output=True, text=True, cwd=ROOT)
+        return json.loads(out.stdout.strip().splitlines()[-1])['value']
+    finally:
+        os.unlink(path)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('base')
+    ap.add_argument('out')
+    ap.add_argument('alts', nargs='+')
+    ap.add_argument('--margin', type=float, default=0.004)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--seqs', type=int, default=4)
+    a = ap.parse_args()
+    extra = ['--seqs', str(a.seqs)]
+    cur = json.load(open(a.base))
+    key = lambda k: json.dumps(k)
+    conv = {key(k): v for k, v in cur['conv']}
+    flips = []
+    for p in a.alts:
+        for k, v in json.load(open(p))['conv']:
+            if len(k) == 10 and key(k) in conv and conv[key(k)] != v and (key(k), v) not in flips:   # (untagged: the default leg's)
+                flips.append((key(k), v))
+    base = [fps_of(cur, a.steps, extra) for _ in range(3)]
+    best = sorted(base)[1]
+    print('base %s -> %.2f frames/s; %d flips to try' % (base, best, len(flips)), flush=True)
+    for k, v in flips:
+        trial = dict(cur, conv=[[json.loads(kk), (v if kk == k else vv)] for kk, vv in conv.items()])
+        f = fps_of(trial, a.steps, extra)
+        keep = f > best * (1 + a.margin)
+        if keep:                                   # confirm: a second run must agree
+            f2 = fps_of(trial, a.steps, extra)
+            keep = f2 > best * (1 + a.margin)
+            f = min(f, f2)
+        print('%s %#x -> %#x: %.2f %s' % (k, conv[k], v, f, 'KEEP' if keep else ''), flush=True)
+        if keep:
+            conv[k], best, cur = v, f, trial
+    cur = dict(cur, conv=[[json.loads(kk), vv] for kk, vv in conv.items()])
+    json.dump(cur, open(a.out, 'w'))
+    print('final %.2f frames/s (%s)' % (fps_of(cur, a.steps, extra), a.out))
+
+
+if __name__ == '__main__':
+    main()
