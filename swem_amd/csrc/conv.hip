@@ -1515,11 +1515,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
       }
     }
   }
-  // ---- K-split without a reduce launch (round 3: p.sk_flags set, gridDim.z splits).  Every split stores its partial tile past
-  // the caches (the stream-K layout: 16-byte chunks per lane), drains, and counts itself on the tile's counter; the split that
-  // arrives LAST adds all of them in z order -- its own from memory too, so the sum's order does not depend on who is last:
-  // deterministic -- and runs the epilogue.  Replaces conv_splitk_epilogue_kernel (one more launch of 5-10 us per K-split
-  // layer, twelve per frame) for this kernel; nobody waits for anybody.
+  // ---- K-split without a reduce launch (round 3: p.sk_flags set, gridDim.z splits).  The LAST split (z = gridDim.z - 1) of a
+  // tile is its reducer: the others store their partial tile past the caches (the stream-K layout: 16-byte chunks per lane),
+  // drain, and count themselves on the tile's counter; the reducer keeps its own sums in registers, waits until the counter
+  // says the others' tiles are in memory, adds them in z order (own + p0 + p1 + ...: a fixed order -- deterministic) and runs
+  // the epilogue.  The reducer only ever waits for blocks dispatched BEFORE it (z is the slowest grid dimension), which are
+  // resident or finished and wait for nobody: no deadlock whatever the grid size.  Against "the last arriver reduces"
+  // (this round's first form) a tile's own sums never travel: 2 (nsp - 1) instead of 2 nsp tile moves -- the splits of a
+  // layer finish together, so the stores and loads of the partials are a burst the matrix pipe cannot hide (13 of the 54 us
+  // of `2x30x54 k3 512->512` at nsp = 4).  Replaces conv_splitk_epilogue_kernel for this kernel.
   bool fused_last = false;
   if constexpr (!SK) {
     if (p.partial && p.sk_flags) {
@@ -1527,7 +1531,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
       constexpr unsigned TILE_BYTES = BM * BN * 4;
       const int nsp = (int)gridDim.z, tile_lin = (tm - p.mt0) * (int)gridDim.y + tn;
       float *slots = p.partial + (long long)tile_lin * nsp * (BM * BN);
-      {
+      if ((int)blockIdx.z != nsp - 1) {
         const __amdgpu_buffer_rsrc_t rp =
             __builtin_amdgcn_make_buffer_rsrc(slots + (long long)blockIdx.z * (BM * BN), 0, TILE_BYTES, 0x00020000);
 #pragma unroll
@@ -1543,23 +1547,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
           }
           __builtin_amdgcn_raw_buffer_store_b128(v, rp, (unsigned)((c * 64 * NW + tid) * 16), 0, 0x11);   // sc0 sc1
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.sk_flags + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;   // not the reducer: done
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __shared__ unsigned sk_arrived;
-      __syncthreads();
-      if (tid == 0) sk_arrived = __hip_atomic_fetch_add(p.sk_flags + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      if (sk_arrived != (unsigned)(nsp - 1)) break;   // not the last split of this tile: done
       fused_last = true;
-      if (tid == 0) __hip_atomic_store(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave it zero
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        if constexpr (M16) acc16[c / (2 * TN)][c % (2 * TN)] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        else
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[(c / 4) / TN][(c / 4) % TN][4 * (c % 4) + e] = 0.f;
+      if (tid == 0) {
+        // (a read-modify-write of zero: executed where the other splits' increments are, never served from a cache)
+        while (__hip_atomic_fetch_add(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(nsp - 1))
+          __builtin_amdgcn_s_sleep(8);
+        __hip_atomic_store(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave it zero
       }
-      for (int zz = 0; zz < nsp; ++zz) {
+      __syncthreads();
+      for (int zz = 0; zz < nsp - 1; ++zz) {
         const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(slots + (long long)zz * (BM * BN), 0, TILE_BYTES, 0x00020000);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
