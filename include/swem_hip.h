@@ -140,7 +140,7 @@ int swem_conv2d_nhwc_bf16x3_planes(void *stream, const void *x0, int c0, long lo
                                    void *planes, int nplanes, void *planes_relu, int nplanes_relu);
 /* ... with caller-owned tile counters (round 3): `counters` (ncounters 32-bit words) must be ALL ZERO when the call is
  * enqueued and must not be used by another stream at the same time; the kernels leave it all zero.  The K-split (reduced by
- * the last-arriving split of every tile, no reduce launch) and stream-K forms then need no memset launch per call. */
+ * the last split of every tile, no reduce launch) and stream-K forms then need no memset launch per call. */
 int swem_conv2d_nhwc_bf16x3_planes_ctr(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1,
                                    int c1, long long bs1, long long ps1, const void *x2, int c2, long long bs2,
                                    long long ps2, int B, int H, int W, const void *w_bf16x3, const float *scale,

@@ -1856,10 +1856,11 @@ int launch(const ConvP &p, dim3 grid, hipStream_t st) {
 
 // plan hint: 0 = heuristic; else wm | wn << 4 | nsplit << 8 | math << 16 | variant << 20 (swem_hip.h)
 Plan resolve_plan(int plan, int M, int Ncols, int nkb, bool glu) {
+  const bool presplit_math = ((plan >> 16) & 3) != 0;   // the 128x64 tile (wm 2, wn 1) exists for the pre-split kernels only
   plan &= 0xffff;
   if (plan > 0) {
     int wm = plan & 15, wn = (plan >> 4) & 15, ns = plan >> 8;
-    bool ok = (wm == 1 || wm == 2) && (wn == 1 || wn == 2) && !(wm == 2 && wn == 1) && !(glu && wn != 2);
+    bool ok = (wm == 1 || wm == 2) && (wn == 1 || wn == 2) && !(wm == 2 && wn == 1 && !presplit_math) && !(glu && wn != 2);
     if (ok) {
       ns = ns < 1 ? 1 : (ns > nkb ? nkb : ns);
       int per = cdiv(nkb, ns);
@@ -2016,6 +2017,7 @@ int conv2d_f32_impl(void *stream, const float *x0, int c0, long long bs0, const 
   fast_div_make((unsigned)(p.Ho * p.Wo), p.fd_howo_mul, p.fd_howo_sh);
   fast_div_make((unsigned)p.Wo, p.fd_wo_mul, p.fd_wo_sh);
   Plan pl = resolve_plan(plan, p.M, p.Ncols, p.nkb, glu);
+  if (pl.wm == 2 && pl.wn == 1) pl.wm = 1;   // (a 128x64 plan on inputs that are not pre-split: the kernels here have no such tile)
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;
   p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.xpn = 1;
@@ -2254,6 +2256,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   auto run = [&](const ConvP &q, dim3 grid, int *occ = nullptr) {
     if (pl.wm == 2 && pl.wn == 2) return launch_bf3s<2, 2>(q, grid, st, variant, occ);
     if (pl.wm == 1 && pl.wn == 2) return launch_bf3s<1, 2>(q, grid, st, variant, occ);
+    if (pl.wm == 2 && pl.wn == 1) return launch_bf3s<2, 1>(q, grid, st, variant, occ);   // 128x64: the 64-channel layers
     return launch_bf3s<1, 1>(q, grid, st, variant, occ);
   };
   int rc;
@@ -2310,14 +2313,14 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
     return SWEM_OK;
   }
   if (pl.nsplit > 1) {
-    // K-split reduced by the last-arriving split of every tile (see the kernel): partial TILES (padded), one counter per tile
+    // K-split reduced by the last split (z = nsplit - 1) of every tile (see the kernel): partial TILES (padded), one counter per tile
     const size_t tile = (size_t)64 * pl.wm * 64 * pl.wn * sizeof(float);
     const size_t ntile = (size_t)mtiles * ntiles;
     const size_t need = (size_t)pl.nsplit * ntile * tile + ntile * sizeof(unsigned);
     SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_bf16x3: workspace %zu < %zu bytes (fused K-split)", ws_bytes, need);
     p.partial = static_cast<float *>(ws);
     if (po && po->counters && po->ncounters >= ntile) {
-      p.sk_flags = po->counters;       // zero on entry; the last-arriving split of a tile resets its counter: no memset launch
+      p.sk_flags = po->counters;       // zero on entry; the reducing split of a tile resets its counter: no memset launch
     } else {
       p.sk_flags = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + (size_t)pl.nsplit * ntile * tile);
       if (hipMemsetAsync(p.sk_flags, 0, ntile * sizeof(unsigned), st) != hipSuccess) {

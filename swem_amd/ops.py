@@ -169,7 +169,7 @@ def _next_pack_key():
 # error), 3 = bf16x3 (hi + mid planes, the three products above 2^-16: 16 significant bits per operand, half the MFMA work
 # of bf16x6; the per-stage 1e-4 and per-frame 1e-3 parity bars are asserted with it enabled)
 CONV_MATH_MODES = (0, 1, 3)
-_TUNE_TILES = ((2, 2), (1, 2), (1, 1))
+_TUNE_TILES = ((2, 2), (1, 2), (2, 1), (1, 1))   # (2, 1) = 128x64: pre-split kernels only (64-channel layers)
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
 
 
@@ -586,6 +586,8 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
             if ns > 1 and (nkb // ns < 2 or blocks * ns > 4096):
                 continue
             for math in CONV_MATH_MODES:
+                if (wm, wn) == (2, 1) and (math == 0 or ncols > 64):
+                    continue                       # the 128x64 tile: where a 64-wide N leaves nothing else to widen
                 cands.append(wm | wn << 4 | ns << 8 | math << 16)
                 if math in (1, 2, 3):              # pre-split kernel variants: other stage count, 8-wave 128x128 tile
                     base = wm | wn << 4 | ns << 8 | math << 16

@@ -219,7 +219,8 @@ def test_bicubic_flip_lincomb_inject(lib):
 
 @pytest.mark.parametrize('plan', [0x00011, 0x00021, 0x00022, 0x00211, 0x10011, 0x10021, 0x10022, 0x10321,
                                   0x110011, 0x110021, 0x110022, 0x210022, 0x310022, 0x210222,
-                                  0x410011, 0x410021, 0x410022, 0x610022, 0x410221, 0x810022, 0x910022, 0x810222, 0x910322],
+                                  0x410011, 0x410021, 0x410022, 0x610022, 0x410221, 0x810022, 0x910022, 0x810222, 0x910322,
+                                  0x10012, 0x110012, 0x410012, 0x10212],
                          ids=lambda p: 'math%d_wm%d_wn%d_ns%d' % (p >> 16, p & 15, (p >> 4) & 15, (p >> 8) & 255))
 def test_conv2d_plans_and_math_modes(lib, plan):
     """Every tiling / K-split / math mode of the fast conv kernel gives the same convolution: fp32 MFMA and the
@@ -247,7 +248,7 @@ def test_conv2d_plans_and_math_modes(lib, plan):
 
 
 @pytest.mark.parametrize('plan', [0x20011, 0x20021, 0x20022, 0x120021, 0x220022, 0x420011, 0x420021, 0x620022, 0x20221, 0x820022, 0x920022,
-                                  0x4020021, 0xa20011, 0xd20022, 0x520022, 0x720022, 0xf20022, 0x1620022, 0x1020011], ids=lambda p: '%#x' % p)
+                                  0x4020021, 0xa20011, 0xd20022, 0x520022, 0x720022, 0xf20022, 0x1620022, 0x1020011, 0x20012, 0x420012], ids=lambda p: '%#x' % p)
 def test_conv2d_plain_bf16_mode(lib, plan):
     """Math mode 2 (mixed-precision training, config.AMP): operands rounded to bf16 once, ONE MFMA product, fp32
     accumulate.  On bf16-representable operands it is the fp32 convolution up to summation order; on general ones it
@@ -273,7 +274,7 @@ def test_conv2d_plain_bf16_mode(lib, plan):
 
 @pytest.mark.parametrize('plan', [0x00011, 0x00022, 0x00211, 0x10021, 0x10022, 0x10321, 0x30011, 0x30021, 0x30022, 0x230022,
                                   0x430011, 0x430021, 0x630022, 0x30221, 0x830022, 0x4030021, 0x8030022, 0xb30011, 0xd30022, 0xe30022,
-                                  0x530022, 0x730022, 0xf30022, 0x1630022, 0x1030011, 0x1530022],
+                                  0x530022, 0x730022, 0xf30022, 0x1630022, 0x1030011, 0x1530022, 0x30012, 0x430012, 0x30212],
                          ids=lambda p: '%#x' % p)
 def test_conv2d_fused_output_planes(lib, plan):
     """The conv epilogues (32x32 and 16x16 accumulator layouts, the split-K reduce kernel, the tail split; fp32, bf16x6 and
@@ -442,7 +443,8 @@ def test_upsample_add_fused_output_planes(lib):
 @pytest.mark.parametrize('plan', [0x30011, 0x30021, 0x30022, 0x130021, 0x230022, 0x430011, 0x430021, 0x630022, 0x30221, 0x830022,
                                   0x930022, 0x4030021, 0xa30011, 0xb30021, 0xa30022, 0xc30022, 0xd30022, 0xe30022, 0xa30211,
                                   0x530022, 0x730022, 0xf30022, 0x530222, 0x4530022,
-                                  0x1630022, 0x1030011, 0x1530022, 0x1030021, 0x1230022, 0x1830022, 0x1430011], ids=lambda p: '%#x' % p)
+                                  0x1630022, 0x1030011, 0x1530022, 0x1030021, 0x1230022, 0x1830022, 0x1430011,
+                                  0x30012, 0x130012, 0x430012, 0xa30012, 0xb30012, 0x30212, 0x4030012], ids=lambda p: '%#x' % p)
 def test_conv2d_bf16x3_mode(lib, plan):
     """Math mode 3 ("bf16x3"): each operand is taken as hi + mid (two bf16 terms = 16 significant bits) and the product is
     hi.hi + hi.mid + mid.hi in fp32 -- half the matrix-core work of bf16x6.  On operands that HAVE only 16 significant bits it
