@@ -1555,7 +1555,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
       fused_last = true;
       if (tid == 0) {
         // (a read-modify-write of zero: executed where the other splits' increments are, never served from a cache)
-        while (__hip_atomic_fetch_add(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(nsp - 1))
+        // (>= and a bounded spin: counters left non-zero by an aborted launch give a wrong tile, never a hung queue)
+        for (int spin = 0; spin < (1 << 24) &&
+                           __hip_atomic_fetch_add(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(nsp - 1);
+             ++spin)
           __builtin_amdgcn_s_sleep(8);
         __hip_atomic_store(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave it zero
       }
