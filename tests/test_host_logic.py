@@ -168,6 +168,29 @@ def test_nchw_views_find_their_nhwc_tensor_again():
     assert torch.equal(to_pixel_major(other), other.permute(0, 2, 3, 1))
 
 
+def test_shipped_plan_file_is_well_formed():
+    """swem_amd/plans/mi355x_480p_k256.json (what `python bench.py` loads by default, ops.PlanBook.load_shipped): every conv key
+    is a layer signature (10 fields, or 13 with the (math, ...) tag of the fp32-level mode), every value a plan hint whose
+    fields the C ABI accepts (include/swem_hip.h): tile in {64, 128}^2, math field 0..3, K-split <= 255; untagged entries never
+    use the tuner forms that are off by default (prefetched fragments 5 / 7 / 15) except where the whole-frame check kept one."""
+    from swem_amd import ops
+    book = ops.PlanBook().load_shipped()
+    assert len(book.conv) >= 58 and len(book.match) >= 2
+    untagged = {k: v for k, v in book.conv.items() if len(k) == 10}
+    tagged = {k: v for k, v in book.conv.items() if len(k) == 13}
+    assert len(untagged) + len(tagged) == len(book.conv) and all(k[10:] == ('math', 0, 1) for k in tagged)
+    for k, v in book.conv.items():
+        wm, wn, ns, math = v & 15, (v >> 4) & 15, (v >> 8) & 255, (v >> 16) & 3
+        assert wm in (1, 2) and wn in (1, 2) and 1 <= ns <= 255, (k, hex(v))
+        assert math in ((0, 1) if len(k) == 13 else (0, 1, 3)), (k, hex(v))
+        cin, cout, kh, kw, stride, pad, flags, B, H, W = k[:10]
+        assert cin > 0 and cout % 4 == 0 and kh == kw and stride in (1, 2) and B in (1, 2, 4)
+    hist = book.math_histogram()
+    assert hist['bf16x3'] >= 50 and hist['bf16'] == 0          # the default leg: bf16x3 nearly everywhere, never plain bf16
+    assert sum(1 for v in untagged.values() if (v >> 20) & 15 in (5, 7, 15)) <= 1
+    assert isinstance(book.digest(), str) and len(book.digest()) == 12
+
+
 def test_plan_book_scoping_roundtrip_and_flags(tmp_path):
     """ops.PlanBook: what a model learns about its launches belongs to the model -- the current book is swapped for the
     duration of a block and restored, two models never see each other's plans unless they share a book, the tables of the
