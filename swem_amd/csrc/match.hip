@@ -119,6 +119,49 @@ __device__ __forceinline__ float merge_top64(float a, float b, int lane) {
   return __uint_as_float(v);
 }
 
+// The same networks on G independent rows of TWc 64-lane chunks at once, STAGE BY STAGE over all chunks: a compare-exchange
+// reads the register the previous stage of the same chunk wrote through DPP, which costs two wait states when the two are
+// adjacent (574 s_nop in the affinity kernel's 6.2k instructions); with the other chunks' stage in between none is needed.
+// Result: the 64 largest of row g, descending across the wave, in v[g * TWc].  Bit-identical to sort64_desc / merge_top64.
+template <int K, int J, int N>
+__device__ __forceinline__ void cmpex_all(unsigned (&v)[N], int lane) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = cmpex<K, J>(v[i], lane);
+}
+template <int G, int TWc>
+__device__ __forceinline__ void top64_rows(float (&vf)[G * TWc], int lane) {
+  constexpr int N = G * TWc;
+  unsigned v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = __float_as_uint(vf[i]);
+  cmpex_all<2, 1>(v, lane);
+  cmpex_all<4, 2>(v, lane); cmpex_all<4, 1>(v, lane);
+  cmpex_all<8, 4>(v, lane); cmpex_all<8, 2>(v, lane); cmpex_all<8, 1>(v, lane);
+  cmpex_all<16, 8>(v, lane); cmpex_all<16, 4>(v, lane); cmpex_all<16, 2>(v, lane); cmpex_all<16, 1>(v, lane);
+  cmpex_all<32, 16>(v, lane); cmpex_all<32, 8>(v, lane); cmpex_all<32, 4>(v, lane); cmpex_all<32, 2>(v, lane);
+  cmpex_all<32, 1>(v, lane);
+  cmpex_all<64, 32>(v, lane); cmpex_all<64, 16>(v, lane); cmpex_all<64, 8>(v, lane); cmpex_all<64, 4>(v, lane);
+  cmpex_all<64, 2>(v, lane); cmpex_all<64, 1>(v, lane);
+#pragma unroll
+  for (int w = 1; w < TWc; w <<= 1) {
+    // the pairs (j, j + w) of every row: first the cross-over max of all pairs, then the six merge stages of all pairs
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int j = 0; j + w < TWc; j += 2 * w) {
+        const unsigned ub = (unsigned)__shfl((int)v[g * TWc + j + w], 63 - lane), ua = v[g * TWc + j];
+        v[g * TWc + j] = ua > ub ? ua : ub;
+      }
+#define SWEM_MERGE_STAGE(J_)                                                                     \
+    _Pragma("unroll") for (int g = 0; g < G; ++g)                                                \
+      _Pragma("unroll") for (int j = 0; j + w < TWc; j += 2 * w) v[g * TWc + j] = cmpex<64, J_>(v[g * TWc + j], lane)
+    SWEM_MERGE_STAGE(32); SWEM_MERGE_STAGE(16); SWEM_MERGE_STAGE(8); SWEM_MERGE_STAGE(4); SWEM_MERGE_STAGE(2); SWEM_MERGE_STAGE(1);
+#undef SWEM_MERGE_STAGE
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) vf[g * TWc] = __uint_as_float(v[g * TWc]);
+}
+
 // K1: affinity + joint softmax, pT[n][p][l] = exp((aff - max)/tau) / sum  (pixel-major, one row of Ltot probabilities per
 // pixel; rows >= P are 0).  16-pixel tiles (the shape of em.hip's E/W kernel): block = (object, 16-pixel tile), 8 waves; wave w owns the
 // 16*TW bases [w*16*TW, +16*TW) of the concatenated bank order (class w / 4).  v_mfma_f32_16x16x4_f32 with the base rows as
@@ -258,24 +301,23 @@ __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__re
         for (int t = 0; t < TW; ++t) *reinterpret_cast<float4 *>(d + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
       }
       __syncthreads();
+      {
+        float v[2 * TW];   // both pixels of the wave: 2 TW independent chunks through the networks together
 #pragma unroll
-      for (int sp = 0; sp < 2; ++sp) {
-        float v[TW];
+        for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-        for (int j = 0; j < TW; ++j) v[j] = pl[2 * wave + sp][lane + 64 * j];
+          for (int j = 0; j < TW; ++j) v[sp * TW + j] = pl[2 * wave + sp][lane + 64 * j];
+        top64_rows<2, TW>(v, lane);
 #pragma unroll
-        for (int j = 0; j < TW; ++j) v[j] = sort64_desc(v[j], lane);
+        for (int sp = 0; sp < 2; ++sp) {
+          float cs = v[sp * TW];
 #pragma unroll
-        for (int w = 1; w < TW; w <<= 1)
-#pragma unroll
-          for (int j = 0; j + w < TW; j += 2 * w) v[j] = merge_top64(v[j], v[j + w], lane);
-        float cs = v[0];
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-          const float tt = __shfl_up(cs, dd);
-          if (lane >= dd) cs += tt;
+          for (int dd = 1; dd < 64; dd <<= 1) {
+            const float tt = __shfl_up(cs, dd);
+            if (lane >= dd) cs += tt;
+          }
+          cum[sp][c] = cs;
         }
-        cum[sp][c] = cs;
       }
     }
 #pragma unroll
@@ -336,12 +378,7 @@ __global__ __launch_bounds__(256) void match_topl_kernel(const float *__restrict
     float v[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) v[j] = row[cls * Lm + lane + 64 * j];
-#pragma unroll
-    for (int j = 0; j < J; ++j) v[j] = sort64_desc(v[j], lane);
-#pragma unroll
-    for (int w = 1; w < J; w <<= 1)
-#pragma unroll
-      for (int j = 0; j + w < J; j += 2 * w) v[j] = merge_top64(v[j], v[j + w], lane);
+    top64_rows<1, J>(v, lane);
     float c = v[0];
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -455,12 +492,7 @@ __global__ __launch_bounds__(256) void match_bwd_pixel_kernel(const float *__res
     float v[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) pv[cls][j] = v[j] = row[cls * Lm + lane + 64 * j];
-#pragma unroll
-    for (int j = 0; j < J; ++j) v[j] = sort64_desc(v[j], lane);
-#pragma unroll
-    for (int ww = 1; ww < J; ww <<= 1)
-#pragma unroll
-      for (int j = 0; j + ww < J; j += 2 * ww) v[j] = merge_top64(v[j], v[j + ww], lane);
+    top64_rows<1, J>(v, lane);
     float c = v[0];
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
