@@ -212,7 +212,7 @@ __device__ __forceinline__ void out_tile32(const ConvP &p, const unsigned *lds, 
       }
     }
     if (relu_out) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-    if (in) *reinterpret_cast<float4 *>(p.y + (long long)m * p.Cout + n) = v;
+    if (in && p.y) *reinterpret_cast<float4 *>(p.y + (long long)m * p.Cout + n) = v;   // (y = NULL: planes-only output)
 #pragma unroll
     for (int var = 0; var < 2; ++var) {
       if (!p.ysp[var]) continue;
@@ -1651,7 +1651,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
     }
     if (p.flags & SWEM_CONV_RELU_OUT) v = relu4(v);
   }
-  *reinterpret_cast<float4 *>(p.y + (long long)m * p.Cout + co) = v;
+  if (p.y) *reinterpret_cast<float4 *>(p.y + (long long)m * p.Cout + co) = v;
   if (!(p.ysp[0] || p.ysp[1])) return;
   // output planes (fused operand split): an even lane and its odd neighbour hold the 8 channels of one 16-byte run
   // (Cout / 4 is even -- Cout % 8 == 0 is the planes' precondition -- so a pair never straddles two pixels)
@@ -1985,7 +1985,8 @@ int conv2d_f32_impl(void *stream, const float *x0, int c0, long long bs0, const 
                     const float *w, long long w_bs, const float *scale, const float *shift, const float *res,
                     long long res_bs, float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan, void *ws,
                     size_t ws_bytes, const PlaneOut *po) {
-  SWEM_REQUIRE(x0 && w && y, SWEM_E_ARG, "conv2d: null pointer");
+  SWEM_REQUIRE(x0 && w && (y || (po && (po->planes[0] || po->planes[1]))), SWEM_E_ARG,
+               "conv2d: null pointer (y may be NULL only when output planes are given)");
   if (!x1) c1 = 0;
   if (!x2) c2 = 0;
   SWEM_REQUIRE(!(x2 && !x1), SWEM_E_ARG, "conv2d: source 2 without source 1");
@@ -2166,7 +2167,8 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
                        const void *w_bf16x3, const float *scale, const float *shift, const float *res, long long res_bs,
                        float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
                        const PlaneOut *po, long long w_bs) {
-  SWEM_REQUIRE(x0 && w_bf16x3 && y, SWEM_E_ARG, "conv2d_bf16x3: null pointer");
+  SWEM_REQUIRE(x0 && w_bf16x3 && (y || (po && (po->planes[0] || po->planes[1]))), SWEM_E_ARG,
+               "conv2d_bf16x3: null pointer (y may be NULL only when output planes are given)");
   if (!x1) c1 = 0;
   if (!x2) c2 = 0;
   SWEM_REQUIRE(!(x2 && !x1), SWEM_E_ARG, "conv2d_bf16x3: source 2 without source 1");

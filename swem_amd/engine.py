@@ -38,11 +38,12 @@ class _Block:
 
     def __call__(self, x):
         res = x if self.down is None else ops.conv2d([x], self.down)
+        # (conv1's and conv2's outputs have exactly one consumer, the next convolution: planes-only once it reads planes)
         if self.bottleneck:
-            y = ops.conv2d([x], self.c1, relu_out=True)
-            y = ops.conv2d([y], self.c2, relu_out=True)
+            y = ops.conv2d([x], self.c1, relu_out=True, planes_only=True)
+            y = ops.conv2d([y], self.c2, relu_out=True, planes_only=True)
             return ops.conv2d([y], self.c3, relu_out=True, residual=res)
-        y = ops.conv2d([x], self.c1, relu_out=True)
+        y = ops.conv2d([x], self.c1, relu_out=True, planes_only=True)
         return ops.conv2d([y], self.c2, relu_out=True, residual=res)
 
 
@@ -55,7 +56,7 @@ class _ResBlock:
         self.down = None if rb.downsample is None else ops.pack_conv(rb.downsample.weight, rb.downsample.bias)
 
     def __call__(self, srcs, batch=None):
-        r = ops.conv2d(srcs, self.c1, relu_in=True, batch=batch)
+        r = ops.conv2d(srcs, self.c1, relu_in=True, batch=batch, planes_only=True)     # (only conv2 reads it)
         if self.down is None:
             # identity shortcut: with two sources the concatenated tensor itself is the residual
             res = srcs[0] if len(srcs) == 1 else ops.concat2(srcs[0], srcs[1], batch or srcs[0].shape[0])

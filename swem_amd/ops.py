@@ -23,12 +23,54 @@ AUTOTUNE = False
 # conv epilogues write the bf16 planes of outputs that later convolutions consume pre-split (learned per layer on the first
 # frames: SPLIT_HINTS) instead of a separate split launch per consumer tensor
 FUSE_SPLIT = True
+# conv2d(planes_only=True) may skip the fp32 map of an output whose only consumer reads the planes
+PLANES_ONLY = os.environ.get('SWEM_PLANES_ONLY', '1') != '0'
 # True: the tuner also offers the round-3 kernel forms (prefetched fragments, stream-K).  Off by default: timed ALONE they tie
 # with the plain forms (the tuner then picks them by noise), in the frame they lose -- persistent and 256-register blocks
 # crowd out the kernels of the other streams (inference, four sequences: 427 frames/s with a plan set holding two of them,
 # 446 without on the same box; training, 4 clips in flight, AMP: 102 clips/s without, 71-89 with).  The kernels stay
 # reachable through an explicit plan (tests/test_gpu_ops.py runs them).
 TUNE_ROUND3_FORMS = False
+
+
+_MODE_GEN = [0]       # bumped by conv_math / flags (process-wide switches that change which kernels a conv call reaches)
+
+
+class _Plans(dict):
+    """A plan table that counts its changes into its book's epoch."""
+
+    def __init__(self, gen):
+        super().__init__()
+        self._gen = gen
+
+    def _bump(self):
+        self._gen[0] += 1
+
+    def __setitem__(self, k, v):
+        if self.get(k, None) != v:
+            self._bump()
+        super().__setitem__(k, v)
+
+    def __delitem__(self, k):
+        self._bump()
+        super().__delitem__(k)
+
+    def pop(self, *a):
+        self._bump()
+        return super().pop(*a)
+
+    def clear(self):
+        self._bump()
+        super().clear()
+
+    def update(self, *a, **kw):
+        self._bump()
+        super().update(*a, **kw)
+
+    def setdefault(self, k, v=None):
+        if k not in self:
+            self._bump()
+        return super().setdefault(k, v)
 
 
 class PlanBook:
@@ -41,17 +83,34 @@ class PlanBook:
     process-wide default book (`ops.reset_plans()` empties it)."""
 
     def __init__(self, fallback=0):
-        self.conv, self.match, self.hints = {}, {}, {}
+        # `epoch`: bumped by every change of a plan (conv / match tables, fallback).  A planes-only output (conv2d) is allowed
+        # only while the consumer's request for planes is of the CURRENT epoch: after any change that could send that consumer
+        # down the fp32 path the producer writes the fp32 map again until the consumer has asked anew.
+        self._gen = [0]
+        self.conv, self.match, self.hints, self.hint_epoch = _Plans(self._gen), _Plans(self._gen), {}, {}
         # plan hint of a layer shape nobody tuned (0 = the library's heuristic, which picks tile and K-split from the GEMM's
         # size).  A fixed hint without K-split, e.g. 0x111, makes a layer's arithmetic independent of the batch it is called
         # with: every output element is then one k-ordered MFMA chain whatever the grid (tests compare batched and per-frame
         # passes bit for bit under it).
         self.fallback = fallback
 
+    @property
+    def fallback(self):
+        return self._fallback
+
+    @fallback.setter
+    def fallback(self, v):
+        self._fallback = v
+        self._gen[0] += 1
+
+    def epoch(self):
+        return (self._gen[0], _MODE_GEN[0])
+
     def clear(self):
         self.conv.clear()
         self.match.clear()
         self.hints.clear()
+        self.hint_epoch.clear()
 
     def math_histogram(self):
         """{'fp32': n, 'bf16x6': n, 'bf16': n, 'bf16x3': n} over the conv plans (a plan of 0 is the fp32 heuristic)."""
@@ -105,9 +164,11 @@ class flags:
         g = globals()
         self.saved = {k: g[k] for k in self.kw}
         g.update(self.kw)
+        _MODE_GEN[0] += 1
 
     def __exit__(self, *a):
         globals().update(self.saved)
+        _MODE_GEN[0] += 1
 
 
 class use_book:
@@ -213,6 +274,9 @@ def _ptr(t):
 
 
 def _chk(t, name='tensor'):
+    if t.__dict__.get('_swem_planes_only'):
+        raise _lib.SwemHipError('%s is a planes-only convolution output (ops.conv2d(planes_only=True)): its fp32 map was never '
+                                'written; only a pre-split convolution may consume it' % name)
     if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise _lib.SwemHipError('%s must be a contiguous fp32 device tensor (got %s %s contiguous=%s)'
                                 % (name, t.device, t.dtype, t.is_contiguous()))
@@ -386,7 +450,12 @@ def presplit(t, relu=False, nplanes=3):
         h = BOOK.hints.setdefault(site, {})
         if h.get(relu, 0) < nplanes:
             h[relu] = nplanes              # the producer of this tensor can write the planes itself next time
+        BOOK.hint_epoch[site] = BOOK.epoch()   # ... and, while no plan changes, leave the fp32 map out (conv2d planes_only)
     if ent is None or ent[1] < nplanes:
+        if t.__dict__.get('_swem_planes_only'):
+            raise _lib.SwemHipError('presplit: a planes-only convolution output is asked for planes its producer did not write '
+                                    '(relu=%s, %d planes): it has more than the one consumer conv2d(planes_only=True) promises'
+                                    % (relu, nplanes))
         B, H, W, Cc = t.shape
         if B > 1 and t.stride(0) % Cc:
             raise _lib.SwemHipError('presplit: batch stride must be a multiple of the channel count')
@@ -411,6 +480,8 @@ def batch_item(t, j):
         v.__dict__['_swem_split_ver'] = v._version
     if '_swem_site' in d:
         v.__dict__['_swem_site'] = d['_swem_site']
+    if d.get('_swem_planes_only'):
+        v.__dict__['_swem_planes_only'] = True
     return v
 
 
@@ -418,11 +489,15 @@ DGRAD, DGRAD_EH, DGRAD_EW, MASK_POS = 8, 16, 32, 64
 
 
 def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadcast=False, batch=None, out=None,
-           plan=None, dgrad=None, mask=None):
+           plan=None, dgrad=None, mask=None, planes_only=False):
     """srcs: list of up to three NHWC tensors concatenated on C; a source with batch 1 is broadcast over `batch`.
     plan: explicit plan hint (include/swem_hip.h); default = tuned plan of this layer shape, else the heuristic.
     dgrad=(H, W): data-gradient mode (SWEM_CONV_DGRAD): srcs = [dY], pack = the transposed filters, the result has the
-    forward input's size H x W.  mask: tensor of the output's shape; the result is zeroed where mask <= 0."""
+    forward input's size H x W.  mask: tensor of the output's shape; the result is zeroed where mask <= 0.
+    planes_only: the caller promises that the ONLY consumer of the result is one pre-split convolution (conv1 -> conv2 -> conv3
+    inside a ResNet block, conv1 -> conv2 of a ResBlock).  Once that consumer has asked for the planes (BOOK.hints, from the
+    second frame on) the fp32 map is not written at all -- half the output bytes of such a layer, which is what bounds the
+    64-channel and 1x1 layers -- and the returned tensor only carries the planes; any other use of it raises."""
     x0 = _chk_src(srcs[0])
     B = batch if batch is not None else max(s.shape[0] for s in srcs)
     _, H, W, _ = x0.shape
@@ -467,6 +542,8 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     site = ('conv', pack.site_key, B, H, W, flags)
     want = BOOK.hints.get(site) if (FUSE_SPLIT and dgrad is None and pack.cout % 8 == 0) else None
     planes = {}
+    skip_y = bool(planes_only and want and out is None and PLANES_ONLY and BOOK.hint_epoch.get(site) == BOOK.epoch())
+    y_ptr = 0 if skip_y else y.data_ptr()
 
     def launch(plan, fresh=False):
         wsb = _lib.query('swem_conv2d_workspace', B, H, W, cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad,
@@ -495,12 +572,14 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
                 sargs += [0, 0, 0, 0]
             ctr = counters(x0.device)
             _lib.call('swem_conv2d_nhwc_bf16x3_planes_ctr', _stream(), *sargs, B, H, W, pack.w3.data_ptr(), _ptr(pack.scale),
-                      _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw,
+                      _ptr(pack.shift), _ptr(residual), res_bs, y_ptr, pack.cout, pack.kh, pack.kw,
                       pack.stride, pack.pad, flags & ~RELU_IN, plan, _ptr(ws), wsb, *pargs, _ptr(ctr),
                       0 if ctr is None else ctr.numel())
             return
+        if any(s_.__dict__.get('_swem_planes_only') for s_ in srcs):
+            raise _lib.SwemHipError('conv2d: a planes-only source reached a convolution that reads the fp32 map (plan %#x)' % plan)
         _lib.call('swem_conv2d_nhwc_f32_planes', _stream(), *args, B, H, W, pack.w.data_ptr(), 0, _ptr(pack.scale),
-                  _ptr(pack.shift), _ptr(residual), res_bs, y.data_ptr(), pack.cout, pack.kh, pack.kw, pack.stride,
+                  _ptr(pack.shift), _ptr(residual), res_bs, y_ptr, pack.cout, pack.kh, pack.kw, pack.stride,
                   pack.pad, flags, plan, _ptr(ws), wsb, *pargs)
 
     sig = (cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags, B, H, W) + _PLAN_TAG
@@ -525,6 +604,8 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         if planes:
             y.__dict__['_swem_split'] = dict(planes)
             y.__dict__['_swem_split_ver'] = y._version
+        if skip_y:
+            y.__dict__['_swem_planes_only'] = True
     if CONV_TRACE is not None:
         e1.record()
         ncols = pack.cout * (2 if pack.glu else 1)
@@ -553,10 +634,12 @@ class conv_math:
         global CONV_MATH_MODES, _PLAN_TAG
         self.saved = (CONV_MATH_MODES, _PLAN_TAG)
         CONV_MATH_MODES, _PLAN_TAG = self.modes, ('math',) + self.modes
+        _MODE_GEN[0] += 1
 
     def __exit__(self, *a):
         global CONV_MATH_MODES, _PLAN_TAG
         CONV_MATH_MODES, _PLAN_TAG = self.saved
+        _MODE_GEN[0] += 1
 
 
 def AUTOTUNE_PENDING():

@@ -404,6 +404,51 @@ def test_maxpool_and_cbam_fused_output_planes(lib):
     _check_fused_planes(lambda: ops.cbam_residual(x, *par), {False: 3, True: 3}, B * H * W, Cc)
 
 
+def test_conv2d_planes_only_output(lib):
+    """ops.conv2d(planes_only=True) (the conv1 -> conv2 -> conv3 chains inside a block: mod_resnet.py:58-113, networks.py:22-32):
+    once the single consumer has asked for the planes the producer leaves the fp32 map out (y = NULL through the C ABI) and
+    the consumer's result is BIT-IDENTICAL to the one computed from a fully written producer; the promise is withdrawn by any
+    plan change until the consumer asks again; every other use of such a tensor raises."""
+    from swem_amd import _lib
+    g = torch.Generator().manual_seed(91)
+    B, Cin, H, W, Cmid, Cout = 2, 64, 21, 37, 64, 96
+    x = nhwc(torch.randn(B, Cin, H, W, generator=g) * 2)
+    p1 = ops.pack_conv((torch.randn(Cmid, Cin, 3, 3, generator=g) * 0.05).to(DEV), (torch.randn(Cmid, generator=g) * 0.1).to(DEV))
+    p2 = ops.pack_conv((torch.randn(Cout, Cmid, 3, 3, generator=g) * 0.05).to(DEV), (torch.randn(Cout, generator=g) * 0.1).to(DEV))
+    book = ops.PlanBook(fallback=0x30011)          # both layers on the pre-split kernel (bf16x3)
+
+    def chain(only):
+        y = ops.conv2d([x], p1, relu_out=True, planes_only=only)
+        return y, ops.conv2d([y], p2, relu_out=True)
+    with ops.use_book(book):
+        y_ref, z_ref = chain(False)                 # frame 1: nothing known yet, y written, the consumer splits it
+        y_a, z_a = chain(False)                     # frame 2, ordinary fused planes: y written AND planes
+        assert '_swem_split' in y_a.__dict__ and not y_a.__dict__.get('_swem_planes_only') and torch.equal(y_a, y_ref)
+        y_b, z_b = chain(True)                      # the same with the promise: planes only
+        assert y_b.__dict__.get('_swem_planes_only') and torch.equal(z_b, z_ref) and torch.equal(z_a, z_ref)
+        assert torch.equal(y_b.__dict__['_swem_split'][False][0][:2].view(torch.int16),
+                           y_a.__dict__['_swem_split'][False][0][:2].view(torch.int16))
+        with pytest.raises(_lib.SwemHipError):
+            ops.maxpool(y_b)                        # an fp32 consumer: loud
+        with pytest.raises(_lib.SwemHipError):
+            ops.conv2d([y_b], p2, relu_in=True)     # planes its producer did not write (the ReLU variant)
+        with pytest.raises(_lib.SwemHipError):
+            ops.conv2d([y_b], p2, relu_out=True, plan=0x00011)   # a convolution on the fp32 path
+        book.fallback = 0x30021                     # a plan change: the consumer might now take another path
+        y_c, z_c = chain(True)
+        assert not y_c.__dict__.get('_swem_planes_only') and torch.equal(y_c, y_ref)
+        y_d, z_d = chain(True)                      # ... it asked again: planes only
+        assert y_d.__dict__.get('_swem_planes_only') and torch.equal(z_d, z_c)
+        with ops.conv_math((3,)):                   # a mode change withdraws the promise too, for one frame
+            y_e, _ = chain(True)
+            assert not y_e.__dict__.get('_swem_planes_only')
+        book.fallback = 0x00011                     # the consumer on the fp32 kernels: it never asks, the map is always written
+        for _ in range(3):
+            y_f, z_f = chain(True)
+            assert not y_f.__dict__.get('_swem_planes_only')
+        close(z_f, z_ref, 2e-5, 'fp32 path after the planes-only frames')
+
+
 def test_upsample_add_fused_output_planes(lib):
     """networks.py:193-194 with the result's bf16 planes written by the same launch (the decoder's ResBlocks consume it
     pre-split, with and without their input ReLU): y bit-identical to the plain kernel, planes bit-identical to
