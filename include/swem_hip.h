@@ -125,7 +125,9 @@ int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0,
  * convolutions that consume y pre-split -- no split launch and no re-read of y per consumer.
  *   planes       : planes of y, or NULL;  nplanes = 2 (hi, mid: every consumer runs bf16x3 / plain bf16) or 3
  *   planes_relu  : planes of relu(y) (for a consumer that applies its input ReLU while splitting, networks.py:26-27), or NULL
- * Bit-identical to swem_split_bf16x3_f32 on y.  Needs Cout % 8 == 0 (with SWEM_CONV_GLU: the planes of the gated output). */
+ * Bit-identical to swem_split_bf16x3_f32 on y.  Needs Cout % 8 == 0 (with SWEM_CONV_GLU: the planes of the gated output).
+ * y may be NULL when at least one plane pointer is given: a PLANES-ONLY output, for a layer whose every consumer reads the
+ * planes (conv1 -> conv2 -> conv3 inside a block, mod_resnet.py:58-113, networks.py:22-32): the fp32 map is not written. */
 int swem_conv2d_nhwc_f32_planes(void *stream, const float *x0, int c0, long long bs0, const float *x1, int c1,
                                 long long bs1, const float *x2, int c2, long long bs2, int B, int H, int W,
                                 const float *w, long long w_bs, const float *scale, const float *shift, const float *res,
