@@ -446,7 +446,9 @@ def presplit(t, relu=False, nplanes=3):
     t.__dict__['_swem_split_ver'] = t._version
     ent = cache.get(relu)
     site = t.__dict__.get('_swem_site')
-    if site is not None:
+    if site is not None and not _IN_TUNER[0]:
+        # (the tuner's candidates do not count: a bf16x6 candidate that lost would leave the producer writing a third plane --
+        # a quarter more plane bytes -- for a consumer that reads two)
         h = BOOK.hints.setdefault(site, {})
         if h.get(relu, 0) < nplanes:
             h[relu] = nplanes              # the producer of this tensor can write the planes itself next time
@@ -717,6 +719,17 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
         e1.record()
         e1.synchronize()
         return e0.elapsed_time(e1) / n
+    _IN_TUNER[0] += 1
+    try:
+        return _autotune_pick(cands, timed, reps)
+    finally:
+        _IN_TUNER[0] -= 1
+
+
+_IN_TUNER = [0]
+
+
+def _autotune_pick(cands, timed, reps):
     first = sorted((timed(plan, reps), plan) for plan in cands)
     # the candidates within 15 % of the fastest (at most four) are timed again: three interleaved rounds, the best round of
     # each counts (a round disturbed by another stream's kernels or a clock step does not decide a near tie; a plan must be
