@@ -191,6 +191,52 @@ def test_shipped_plan_file_is_well_formed():
     assert isinstance(book.digest(), str) and len(book.digest()) == 12
 
 
+def test_plan_epochs_gate_planes_only_outputs(tmp_path):
+    """ops.PlanBook.epoch(): the count a planes-only convolution output depends on (ops.conv2d(planes_only=True) leaves the fp32
+    map out only while its consumer's request for planes carries the CURRENT count).  Every change that can send a consumer down
+    another path moves it: a new or changed plan (not a re-assignment of the same value), removing one, loading a file, the
+    fallback, clearing, a conv_math / flags block (on entry and on exit); reading does not."""
+    from swem_amd import ops
+    b = ops.PlanBook()
+    seen = [b.epoch()]
+
+    def moved():
+        seen.append(b.epoch())
+        return seen[-1] != seen[-2]
+    key = (64, 64, 3, 3, 1, 1, 2, 1, 120, 216)
+    b.conv[key] = 0x30011
+    assert moved()
+    b.conv[key] = 0x30011
+    assert not moved()                          # the same plan again: nothing changed
+    b.conv[key] = 0x630022
+    assert moved()
+    assert b.conv.get(key) == 0x630022 and key in b.conv and not moved()
+    b.match[(2, 128, 512, 1620, 256, 2)] = 0x30111
+    assert moved()
+    b.conv.pop(key)
+    assert moved()
+    b.fallback = 0x111
+    assert moved()
+    path = str(tmp_path / 'p.json')
+    b.save(path)
+    assert not moved()
+    b.load(path)
+    assert moved()
+    with ops.conv_math((3,)):
+        assert moved()
+    assert moved()
+    with ops.flags(FUSE_SPLIT=False):
+        assert moved()
+    assert moved()
+    b.clear()
+    assert moved()
+    other = ops.PlanBook()                      # books count on their own: another model's tuning does not disturb this one
+    e = b.epoch()
+    other.conv[key] = 1
+    assert b.epoch() == e
+    assert len(set(seen)) == len(seen) - 3      # three reads without a change in between
+
+
 def test_plan_book_scoping_roundtrip_and_flags(tmp_path):
     """ops.PlanBook: what a model learns about its launches belongs to the model -- the current book is swapped for the
     duration of a block and restored, two models never see each other's plans unless they share a book, the tables of the
