@@ -334,6 +334,47 @@ def test_pipelined_frame_graph_matches_eager(lib):
         assert torch.equal(be[k], bg[k]), k
 
 
+def test_planes_only_outputs_leave_the_frames_unchanged(lib):
+    """ops.PLANES_ONLY (conv1 / conv2 inside every block write only their bf16 planes once the next convolution reads planes,
+    engine.py) against the same frames with every fp32 map written: index maps, probabilities and the memory after the last
+    frame are BIT-IDENTICAL, and the switch really takes effect (planes-only tensors are produced from the second frame on)."""
+    from swem_amd import synth
+    cfg = O.make_cfg(**CFG_A)
+    frames, m0 = synth.make_clip(t=6, h=128, w=192, n_obj=2, seed=12)
+    frames, m0 = frames.to(DEV), m0.to(DEV)
+
+    def run(planes_only):
+        model, _ = H.make_model_and_sd(cfg, wseed=5, device=DEV)
+        model.book.fallback = 0x30011                   # every layer on the pre-split kernel (bf16x3), 64x64 tile
+        seen = []
+        real = ops.conv2d
+
+        def spy(*a, **kw):
+            y = real(*a, **kw)
+            seen.append(bool(y.__dict__.get('_swem_planes_only')))
+            return y
+        with torch.no_grad(), ops.flags(PLANES_ONLY=planes_only):
+            ops.conv2d = spy
+            try:
+                torch.manual_seed(3)
+                mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+                model('init', mk16, model('encode_value', frames[:, 0], m0, s16), m0)
+                preds = [evaluator.frame_step(model, frames[:, i], (128, 192)).clone() for i in range(1, 6)]
+            finally:
+                ops.conv2d = real
+            bases = {kk: v.clone() for kk, v in model.swem_core.memories['update'].bases.items()}
+        torch.cuda.synchronize()
+        return preds, bases, sum(seen), len(seen)
+
+    pa, ba, n_a, tot_a = run(True)
+    pb, bb, n_b, tot_b = run(False)
+    assert n_b == 0 and tot_a == tot_b and n_a > 0.25 * tot_a, (n_a, tot_a)    # (ResNet-18 encoders: one conv in three sits inside a block)
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
+    for kk in ba:
+        assert torch.equal(ba[kk], bb[kk]), kk
+
+
 @pytest.mark.parametrize('overlap', [True, False], ids=['keys_on_side_stream', 'one_stream'])
 def test_lookahead_graph_matches_sequential_loop(lib, overlap):
     """evaluator.LookaheadGraph: k = 3 frames per replay, the key encoder of the NEXT three frames as one B = 3 pass next to
