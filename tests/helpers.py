@@ -45,7 +45,7 @@ class arith:
       'fp32'   -- no plans, no forced math: every GEMM on the fp32 MFMA (plan 0).
       'bf16x3' -- ops.conv_math((3,)): every convolution the pre-split kernel can take AND matching's value readout run on
                   the hi + mid bf16 planes (16 significant bits per operand, three products), the heuristic tile.
-      'tuned'  -- the bench's plans (profiles/rNN_tuned_plans.json) loaded into the model's book: the mix of tiles, K-splits
+      'tuned'  -- the bench's plans (swem_amd/plans/mi355x_480p_k256.json, what ships) loaded into the model's book: the mix of tiles, K-splits
                   and math modes the tuner chose at config B (other shapes find no plan and run fp32).
     `ran` = {math field: conv launches} of what really ran; leaving the context asserts it matches the mode."""
 
