@@ -39,7 +39,8 @@ CFG = dict(BACKBONE='resnet50', NUM_BASES=256, NUM_EM_ITERS=5, SINGLE_OBJ=False,
            EM_TAU=0.05, TOPL=64)
 FP32_MATRIX_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 BF16X6_PEAK_TFLOPS = round(2500.0 / 6, 1)  # dense bf16 MFMA peak / six products per fp32 product (bf16x6 conv mode)
-BF16X3_PEAK_TFLOPS = round(2500.0 / 3, 1)  # ... / three products (bf16x3 mode: hi + mid planes)
+BF16X3_PEAK_TFLOPS = round(2500.0 / 3, 1)  # ... / three products (bf16x3 and f16x3 modes: hi + mid planes; the dense f16 MFMA peak
+                                           # equals the bf16 one, MI355X_MICROARCH.md)
 
 
 def algorithmic_flops_per_frame(n):
@@ -375,7 +376,9 @@ def main():
             'vs_baseline': None,
             # what the arithmetic IS (not a precision claim): storage and accumulation are fp32 everywhere, the convolutions'
             # operands are what the plans say -- the mode that holds most layer shapes names the line, `dtype_detail` has all
-            'dtype': ('f32 storage + accumulate; conv operands bf16x3 (hi+mid bf16 planes = 16 significant bits, 3 MFMA products)'
+            'dtype': ('f32 storage + accumulate; conv operands f16x3 (fp16 hi+mid planes = 22-23 significant bits, 3 MFMA products: '
+                      'fp32-level error)' if hist['f16x3'] >= max(hist['bf16x6'], hist['bf16x3'], 1) else
+                      'f32 storage + accumulate; conv operands bf16x3 (hi+mid bf16 planes = 16 significant bits, 3 MFMA products)'
                       if hist['bf16x3'] >= max(hist['bf16x6'], 1) else
                       'f32 storage + accumulate; conv operands bf16x6 (exact 3-way bf16 split = 24 significant bits, 6 MFMA products)'
                       if hist['bf16x6'] else 'f32 (fp32 MFMA)'),
@@ -498,7 +501,7 @@ def main():
             d['flops'] += t_[2]
             d['bytes'] += t_[4]
             d['n'] += 1
-        peaks = {'bf16': BF16X6_PEAK_TFLOPS, 'bf16x3': BF16X3_PEAK_TFLOPS, 'fp32': FP32_MATRIX_PEAK_TFLOPS}
+        peaks = {'bf16': BF16X6_PEAK_TFLOPS, 'bf16x3': BF16X3_PEAK_TFLOPS, 'f16x3': BF16X3_PEAK_TFLOPS, 'fp32': FP32_MATRIX_PEAK_TFLOPS}
         per_pipe = {}
         for k, d in pipes.items():
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
@@ -545,9 +548,9 @@ def main():
                 nst, nw, m16, kg = 3, 4, True, 4
             elif var_ == 7:
                 nst, nw, m16, kg = 4, 8, True, 4
-            return 'conv_igemm_bf3s_kernel<%d, %d, %d, %d, %s, %d, %d, %s, %s>' % (
-                wm_, wn_, nst, nw, 'true' if m16 else 'false', 2 if pipe_ == 'bf16x3' else 3, kg, 'true' if pf else 'false',
-                'true' if sk else 'false')
+            return 'conv_igemm_bf3s_kernel<%d, %d, %d, %d, %s, %d, %d, %s, %s, %s>' % (
+                wm_, wn_, nst, nw, 'true' if m16 else 'false', 2 if pipe_ in ('bf16x3', 'f16x3') else 3, kg, 'true' if pf else 'false',
+                'true' if sk else 'false', 'true' if pipe_ == 'f16x3' else 'false')
         dk_name = bf3s_name(*dk) if dk[0] != 'fp32' else 'conv_igemm_pipe_kernel<%d, %d>' % (dk[1], dk[2])
         traffic, tsrc = None, None
         for name in ('r03_conv_traffic_by_kernel.json', 'r02_conv_traffic_by_kernel.json'):
@@ -584,6 +587,7 @@ def main():
             'kernel': (dk_name + ' -- implicit-GEMM conv on pre-split bf16 planes moved by LDS-DMA, %s, fp32 accumulate; '
                        'its operand-split and split-K reduce launches are inside the timed intervals'
                        % ('bf16x6 arithmetic (three planes per operand, six v_mfma_f32_32x32x16_bf16 products)' if dom == 'bf16'
+                          else 'f16x3 arithmetic (fp16 hi + mid planes, three f16 MFMA products)' if dom == 'f16x3'
                           else 'bf16x3 arithmetic (hi + mid planes, three bf16 MFMA products)')) if dom != 'fp32' else
                       'conv_igemm_pipe_kernel: implicit-GEMM conv on v_mfma_f32_32x32x2_f32',
             'achieved': round(dk_ach, 2), 'peak': peaks[dk[0]], 'unit': 'TFLOP/s',
@@ -602,13 +606,15 @@ def main():
                                                                              FP32_MATRIX_PEAK_TFLOPS),
             'pipes': per_pipe,
             'frac_bf16_pipe': per_pipe.get('bf16', {}).get('frac'), 'frac_bf16x3_pipe': per_pipe.get('bf16x3', {}).get('frac'),
+            'frac_f16x3_pipe': per_pipe.get('f16x3', {}).get('frac'),
             'frac_fp32_pipe': per_pipe.get('fp32', {}).get('frac'),
             'conv_ms_per_frame_eager_one_stream': round(sum(d['ms'] for d in pipes.values()) / nprof, 3),
             'note': 'useful conv FLOPs (2*M*Cout*KH*KW*Cin, unpadded) of %d eager frames of ONE sequence / summed per-launch '
                     'HIP-event durations on the launch stream (the queue held full behind a spin kernel: the intervals are '
                     'GPU time between back-to-back packets, not host enqueue time); the timed region above is graph replay of %d sequence(s) on %d '
                     'stream(s), whose kernels overlap -- `whole_frame` prices THAT' % (nprof, nseq, nseq),
-            'plans_bf16x6': hist['bf16x6'], 'plans_bf16x3': hist['bf16x3'], 'plans_total': sum(hist.values())}
+            'plans_bf16x6': hist['bf16x6'], 'plans_bf16x3': hist['bf16x3'], 'plans_f16x3': hist['f16x3'],
+            'plans_total': sum(hist.values())}
         # whole frame of the TIMED configuration against the blended ceiling: every FLOP priced at its pipe's peak
         conv_fl = {k: d['flops'] / nprof for k, d in pipes.items()}
         em_fl = em_flops_per_frame(n_obj)
@@ -617,6 +623,7 @@ def main():
         out['whole_frame'] = {'executed_gflop_per_frame': round((sum(conv_fl.values()) + em_fl) / 1e9, 1),
                               'gflop_bf16_pipe': round(conv_fl.get('bf16', 0.0) / 1e9, 1),
                               'gflop_bf16x3_pipe': round(conv_fl.get('bf16x3', 0.0) / 1e9, 1),
+                              'gflop_f16x3_pipe': round(conv_fl.get('f16x3', 0.0) / 1e9, 1),
                               'gflop_fp32_pipe': round((conv_fl.get('fp32', 0.0) + em_fl) / 1e9, 1),
                               'ms_per_frame_timed': round(1e3 * t_frame, 3), 'ms_per_frame_at_pipe_peaks': round(1e3 * t_ideal, 3),
                               'frac_of_blended_mfma_ceiling': round(t_ideal / t_frame, 4),

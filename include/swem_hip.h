@@ -97,6 +97,24 @@ int swem_conv2d_nhwc_f32(void *stream, const float *x0, int c0, long long bs0, c
  * channel-group major [C/8][npix][8], with x = hi + mid + lo exactly (three round-to-nearest bf16 terms = 24
  * significant bits); relu != 0 splits relu(x) (the input ReLU of networks.py:26-27 then costs nothing in the conv). */
 int swem_split_bf16x3_f32(void *stream, const float *x, void *out, long long npix, int C, int relu);
+/* Operands for the "f16x3" arithmetic (round 4): x -> TWO fp16 planes in the same channel-group-major layout with
+ * x = hi + mid, round-to-nearest residual: 11 + 11 significant bits and the residual's sign, i.e. x to half an fp32 ulp
+ * wherever |x| >= 2^-2 (mid a normal fp16 number), to 2^-25 absolute below (mid subnormal; the converter and the f16 MFMA
+ * keep subnormals).  |x| must stay below 65520, the fp16 range -- the range the reference's own mixed-precision mode
+ * (fp16 autocast, basic_trainer.py:83-86) runs these activations in; beyond it the planes hold inf and the convolution
+ * returns NaN (loud), never a silently wrong number.
+ * Everywhere this header takes a plane count (`nplanes`: 2 or 3 bf16 planes) the value SWEM_PLANES_F16 asks for this fp16
+ * pair instead, bit-identical to this function on the fp32 values.
+ * A convolution reads such planes with plan bit 18 set (SWEM_PLAN_F16) and math 3: the three products hi.hi + hi.mid +
+ * mid.hi on v_mfma_f32_*_f16 -- the LDS image, MFMA count and kernel of "bf16x3", with 23-bit instead of 16-bit operands: the
+ * dropped mid.mid term is 2^-24 relative, so the result carries fp32-level error (the accumulation's own rounding dominates:
+ * tests/test_gpu_ops.py::test_conv2d_f16x3_mode measures it against float64 beside the fp32-MFMA and bf16x6 kernels).
+ * The FILTER planes of that mode are the fp16 pair of w[n][:] * 2^e[n], e[n] chosen per output column so that the column's
+ * largest weight lands in [2^13, 2^14) (small weights would otherwise leave `mid` subnormal); the caller passes
+ * scale[n] * 2^-e[n] as `scale` (exact: a power of two). */
+#define SWEM_PLANES_F16 4
+#define SWEM_PLAN_F16 (1 << 18)
+int swem_split_f16x2_f32(void *stream, const float *x, void *out, long long npix, int C, int relu);
 /* The same convolution as swem_conv2d_nhwc_f32 in bf16x6 math with PRE-SPLIT sources and filters: xK = plane 0 of
  * source K in the layout above (npix = all pixels of its storage; bsK = fp32-element batch stride as before, a
  * multiple of cK), psK = elements between its three planes (npix * cK), cK % 32 == 0;

@@ -23,3 +23,37 @@ __device__ __forceinline__ void split3(float4 v, uint2 &h, uint2 &m, uint2 &l) {
   l.x = pack_bf16(rx - lo_f32(m.x), ry - hi_f32(m.x));
   l.y = pack_bf16(rz - lo_f32(m.y), rw - hi_f32(m.y));
 }
+
+// ---- fp16 pair ("f16x3" conv arithmetic, round 4) ------------------------------------------------------------------
+// x = hi + mid with both terms fp16, round-to-nearest residual: 11 + 11 significant bits and the residual's sign, i.e. x to
+// within 2^-24 |x| -- half an fp32 ulp -- wherever mid is a NORMAL fp16 number (|x| >= 2^-2); below that mid is subnormal
+// (v_cvt_f16_f32 and the f16 MFMA both keep subnormals: tools/f16_probe.hip) and the absolute error is bounded by half the
+// fp16 subnormal spacing, 2^-25.  |x| must stay below 65520 (the fp16 range; the reference's own mixed-precision mode,
+// basic_trainer.py:83-86, runs these activations in fp16): beyond it hi is inf and the product is NaN -- loud, never a
+// silently wrong number.  Plane-count code of this format in the C ABI: SWEM_PLANES_F16 (= 4): two planes, hi then mid.
+#ifndef SWEM_PLANES_F16
+#define SWEM_PLANES_F16 4
+#endif
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));   // round to nearest even, a in the low half
+}
+__device__ __forceinline__ float lo_f16(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
+__device__ __forceinline__ float hi_f16(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
+__device__ __forceinline__ void split2h(float4 v, uint2 &h, uint2 &m) {
+  h.x = pack_f16(v.x, v.y);
+  h.y = pack_f16(v.z, v.w);
+  m.x = pack_f16(v.x - lo_f16(h.x), v.y - hi_f16(h.x));
+  m.y = pack_f16(v.z - lo_f16(h.y), v.w - hi_f16(h.y));
+}
+// the split a producer was asked for: npl = 2 / 3 bf16 planes (l valid for 3) or SWEM_PLANES_F16
+__device__ __forceinline__ void split_as(int npl, float4 v, uint2 &h, uint2 &m, uint2 &l) {
+  if (npl == SWEM_PLANES_F16) {
+    split2h(v, h, m);
+    l = make_uint2(0u, 0u);
+  } else {
+    split3(v, h, m, l);
+  }
+}

@@ -48,7 +48,8 @@ struct ConvP {
   int Cout, Ncols, KH, KW, stride, pad, flags;
   int nkb, kb_per_split;
   float *partial;
-  int nplanes;  // 3 = bf16x6 (hi/mid/lo planes, six products), 1 = plain bf16 (hi plane only)
+  int nplanes;  // 3 = bf16x6 (hi/mid/lo planes, six products), 2 = three products on (hi, mid), 1 = plain bf16 (hi plane only)
+  int f16;      // nplanes == 2 only: the operand planes are fp16 pairs (bf16_split.h, split2h) -- the "f16x3" arithmetic
   int xpn;      // XCD partition of the N tiles (1, 2, 4, 8): see tile_coords
   int mt0;      // first M tile of this launch (the tail launch of a tail-split layer starts further down)
   int part_m0;  // first output row held by `partial` (rows are stored relative to it)
@@ -218,7 +219,7 @@ __device__ __forceinline__ void out_tile32(const ConvP &p, const unsigned *lds, 
       if (!p.ysp[var]) continue;
       const float4 q = var ? relu4(v) : v;
       uint2 h, mm, l;
-      split3(q, h, mm, l);
+      split_as(p.ysp_npl[var], q, h, mm, l);
       const uint2 h2 = make_uint2(__shfl_down(h.x, 1), __shfl_down(h.y, 1));
       const uint2 m2 = make_uint2(__shfl_down(mm.x, 1), __shfl_down(mm.y, 1));
       const uint2 l2 = make_uint2(__shfl_down(l.x, 1), __shfl_down(l.y, 1));
@@ -864,6 +865,18 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma_bf16_16(uint4 a, uint4 b, f32x4v c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// F16: the planes hold fp16 pairs (bf16_split.h, split2h) and the products run on the f16 MFMA of the same shape -- the
+// "f16x3" arithmetic: three products on 23-bit operands, fp32-level error at the bf16x3 kernel's cost.
+template <bool F16>
+__device__ __forceinline__ f32x4v mm16(uint4 a, uint4 b, f32x4v c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return mfma_bf16_16(a, b, c);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mm32(uint4 a, uint4 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return mfma_bf16(a, b, c);
+}
 // Epilogue for 16x16 accumulator tiles (v_mfma_f32_16x16x32_bf16): lane l holds column l % 16 and rows 4 (l / 16) + e.
 // Same semantics as conv_epilogue; a wave owns TM2 x TN2 tiles = 16 TM2 rows x 16 TN2 columns.
 template <int TM2, int TN2>
@@ -970,9 +983,10 @@ __device__ __forceinline__ const ConvP &segment_params(const ConvP &p) {
 // own transfer requests, fragment reads and the stage hand-over, and a stage is free for the next transfer one iteration
 // earlier (its fragments are in registers), so a ring of NST stages keeps NST-1 k-blocks in flight under the MFMAs instead of
 // NST-2 + a hand-over in front of them.  16x16x32 MFMA, one or two planes.
-template <int WM, int WN, int NST, int NW, bool M16, int NPL, int KG = 4, bool PF = false, bool SK = false>
+template <int WM, int WN, int NST, int NW, bool M16, int NPL, int KG = 4, bool PF = false, bool SK = false, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kernel(ConvP p STAMP_ARG) {
   STAMP(0);
+  static_assert(!F16 || NPL == 2, "fp16 planes come as a (hi, mid) pair");
   static_assert(KG == 4 || (KG == 2 && !M16 && NW == 4), "16-k blocks: four waves, 32x32x16 MFMA");
   static_assert(!PF || (M16 && NPL <= 2 && KG == 4), "prefetched fragments: 16x16x32 MFMA, at most two planes");
   // block tile 64WM x 64WN, NW waves as an (NW/2) x 2 grid, each owning TM x TN 32x32 accumulator tiles
@@ -1297,10 +1311,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
         for (int jn = 0; jn < 2 * TN; ++jn) {
           f32x4v c = acc16[i][jn];
           if constexpr (NPL >= 2) {   // "bf16x3": the three products above 2^-16, smallest first
-            c = mfma_bf16_16(fa[cur][0][i], fb[cur][1][jn], c);
-            c = mfma_bf16_16(fa[cur][1][i], fb[cur][0][jn], c);
+            c = mm16<F16>(fa[cur][0][i], fb[cur][1][jn], c);
+            c = mm16<F16>(fa[cur][1][i], fb[cur][0][jn], c);
           }
-          c = mfma_bf16_16(fa[cur][0][i], fb[cur][0][jn], c);
+          c = mm16<F16>(fa[cur][0][i], fb[cur][0][jn], c);
           acc16[i][jn] = c;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1400,15 +1414,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
           for (int jn = 0; jn < 2 * TN; ++jn) {
             f32x4v c = acc16[i][jn];
             if constexpr (NPL == 3) {
-              c = mfma_bf16_16(a[0][i], b[2][jn], c);
-              c = mfma_bf16_16(a[2][i], b[0][jn], c);
-              c = mfma_bf16_16(a[1][i], b[1][jn], c);
+              c = mm16<F16>(a[0][i], b[2][jn], c);
+              c = mm16<F16>(a[2][i], b[0][jn], c);
+              c = mm16<F16>(a[1][i], b[1][jn], c);
             }
             if constexpr (NPL >= 2) {   // NPL == 2: "bf16x3", the three products above 2^-16
-              c = mfma_bf16_16(a[0][i], b[1][jn], c);
-              c = mfma_bf16_16(a[1][i], b[0][jn], c);
+              c = mm16<F16>(a[0][i], b[1][jn], c);
+              c = mm16<F16>(a[1][i], b[0][jn], c);
             }
-            c = mfma_bf16_16(a[0][i], b[0][jn], c);
+            c = mm16<F16>(a[0][i], b[0][jn], c);
             acc16[i][jn] = c;
           }
         }
@@ -1438,15 +1452,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
             for (int jn = 0; jn < TN; ++jn) {
               f32x16 c = acc[i][jn];
               if constexpr (NPL == 3) {
-                c = mfma_bf16(a[s2][0][i], b[s2][2][jn], c);
-                c = mfma_bf16(a[s2][2][i], b[s2][0][jn], c);
-                c = mfma_bf16(a[s2][1][i], b[s2][1][jn], c);
+                c = mm32<F16>(a[s2][0][i], b[s2][2][jn], c);
+                c = mm32<F16>(a[s2][2][i], b[s2][0][jn], c);
+                c = mm32<F16>(a[s2][1][i], b[s2][1][jn], c);
               }
               if constexpr (NPL >= 2) {
-                c = mfma_bf16(a[s2][0][i], b[s2][1][jn], c);
-                c = mfma_bf16(a[s2][1][i], b[s2][0][jn], c);
+                c = mm32<F16>(a[s2][0][i], b[s2][1][jn], c);
+                c = mm32<F16>(a[s2][1][i], b[s2][0][jn], c);
               }
-              c = mfma_bf16(a[s2][0][i], b[s2][0][jn], c);
+              c = mm32<F16>(a[s2][0][i], b[s2][0][jn], c);
               acc[i][jn] = c;
             }
         }
@@ -1660,7 +1674,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
     if (!p.ysp[var]) continue;
     const float4 q = var ? relu4(v) : v;
     uint2 h, mm, l;
-    split3(q, h, mm, l);
+    split_as(p.ysp_npl[var], q, h, mm, l);
     const uint2 h2 = make_uint2(__shfl_down(h.x, 1), __shfl_down(h.y, 1));
     const uint2 m2 = make_uint2(__shfl_down(mm.x, 1), __shfl_down(mm.y, 1));
     const uint2 l2 = make_uint2(__shfl_down(l.x, 1), __shfl_down(l.y, 1));
@@ -1763,17 +1777,27 @@ int blocks_per_cu(K kernel, int threads, size_t lds) {
 
 // occ != nullptr: do not launch, report the resident blocks per CU of the instantiation the launch would use
 // (p.sk_workers != 0 selects the stream-K instantiation: a query passes -1)
-template <int WM, int WN, int NST, int NW, bool M16, int KG, bool PF, int NPL, bool SK>
+template <int WM, int WN, int NST, int NW, bool M16, int KG, bool PF, int NPL, bool SK, bool F16 = false>
 int launch_bf3s_one(const ConvP &p, dim3 grid, hipStream_t st, int *occ) {
   constexpr size_t lds = NST * NPL * KG * (64 * WM + 1 + 64 * WN + 1) * 16;   // NST stages x NPL planes
   const size_t dyn = lds_with_planes(p, lds, NW);
-  SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK>), lds);
+  SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK, F16>), lds);
   if (occ) {
-    static int nb = blocks_per_cu(conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK>, 64 * NW, dyn);
+    // (the occupancy of an instantiation depends on its dynamic-LDS size and, in a multi-device process, on the device:
+    // asked again whenever either differs from the last query -- ADVICE r03: a function-local static froze the first answer)
+    static int nb = 0, nb_dev = -1;
+    static size_t nb_dyn = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (nb == 0 || dev != nb_dev || dyn != nb_dyn) {
+      nb = blocks_per_cu(conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK, F16>, 64 * NW, dyn);
+      nb_dev = dev;
+      nb_dyn = dyn;
+    }
     *occ = nb;
     return SWEM_OK;
   }
-  hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK>), grid, dim3(64 * NW), dyn, st, p STAMP_PASS);
+  hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK, F16>), grid, dim3(64 * NW), dyn, st, p STAMP_PASS);
   return SWEM_OK;
 }
 template <int WM, int WN, int NST, int NW, bool M16 = false, int KG = 4, bool PF = false>
@@ -1795,6 +1819,17 @@ int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st, int *occ = nullptr)
       if (sk) return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 1, true>(p, grid, st, occ);
     }
     return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 1, false>(p, grid, st, occ);
+  }
+  if (p.nplanes == 2 && p.f16) {   // "f16x3": the same kernel on fp16 (hi, mid) planes and the f16 MFMA
+    if (sk) {
+      if (occ) {
+        *occ = 0;
+        return SWEM_OK;
+      }
+      swem_set_error("conv2d_bf16x3: the f16x3 arithmetic has no stream-K form");
+      return SWEM_E_ARG;
+    }
+    return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 2, false, true>(p, grid, st, occ);
   }
   if (p.nplanes == 2) {   // "bf16x3": hi and mid planes, three products (hi.hi + hi.mid + mid.hi): two thirds of the LDS
     if constexpr (SKOK) {
@@ -1947,7 +1982,8 @@ int set_planes(ConvP &p, const PlaneOut *po, bool glu, const char *who) {
   (void)glu;   // the gated output goes through the same row-layout stores as any other
   SWEM_REQUIRE(p.Cout % 8 == 0, SWEM_E_SHAPE, "%s: output planes need Cout %% 8 == 0", who);
   for (int v = 0; v < 2; ++v) {
-    SWEM_REQUIRE(!po->planes[v] || po->npl[v] == 2 || po->npl[v] == 3, SWEM_E_ARG, "%s: 2 or 3 output planes", who);
+    SWEM_REQUIRE(!po->planes[v] || po->npl[v] == 2 || po->npl[v] == 3 || po->npl[v] == SWEM_PLANES_F16, SWEM_E_ARG,
+                 "%s: 2 or 3 bf16 output planes, or SWEM_PLANES_F16 (an fp16 pair)", who);
     p.ysp[v] = static_cast<unsigned short *>(po->planes[v]);
     p.ysp_npl[v] = po->npl[v];
   }
@@ -2024,7 +2060,7 @@ int conv2d_f32_impl(void *stream, const float *x0, int c0, long long bs0, const 
   if (pl.wm == 2 && pl.wn == 1) pl.wm = 1;   // (a 128x64 plan on inputs that are not pre-split: the kernels here have no such tile)
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;
-  p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.xpn = 1;
+  p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.f16 = 0; p.xpn = 1;
   if (int prc = set_planes(p, po, glu, "conv2d")) return prc;
   if (pl.nsplit > 1) {
     size_t need = (size_t)pl.nsplit * M * p.Ncols * sizeof(float);
@@ -2103,6 +2139,36 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restri
   *reinterpret_cast<uint4 *>(out + 2 * plane + i * 8) = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
 }  // namespace
+
+namespace {
+// ... -> two fp16 planes [C/8][npix][8] with x = hi + mid (bf16_split.h, split2h): the operand format of the f16x3 arithmetic
+__global__ __launch_bounds__(256) void split_f16x2_kernel(const float *__restrict__ x, unsigned short *__restrict__ out,
+                                                          long long npix, int C, int relu) {
+  const long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int cg = blockIdx.y * 8 + (threadIdx.x & 7);
+  if (pix >= npix || cg >= C / 8) return;
+  const float *src = x + pix * C + cg * 8;
+  float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 4);
+  if (relu) {
+    v0 = relu4(v0);
+    v1 = relu4(v1);
+  }
+  uint2 h0, m0, h1, m1;
+  split2h(v0, h0, m0);
+  split2h(v1, h1, m1);
+  const long long plane = npix * C, i = (long long)cg * npix + pix;
+  *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+}
+}  // namespace
+
+extern "C" int swem_split_f16x2_f32(void *stream, const float *x, void *out, long long npix, int C, int relu) {
+  SWEM_REQUIRE(x && out && npix > 0 && C > 0 && C % 8 == 0, SWEM_E_ARG, "split_f16x2: need C %% 8 == 0");
+  hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)cdiv(npix, 32), (unsigned)cdiv(C / 8, 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, static_cast<unsigned short *>(out), npix, C, relu);
+  SWEM_CHECK_LAUNCH("split_f16x2");
+  return SWEM_OK;
+}
 
 extern "C" int swem_split_bf16x3_f32(void *stream, const float *x, void *out, long long npix, int C, int relu) {
   SWEM_REQUIRE(x && out && npix > 0 && C > 0 && C % 8 == 0, SWEM_E_ARG, "split_bf16x3: need C %% 8 == 0");
@@ -2217,7 +2283,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
                "conv2d_bf16x3: per-batch filters need Ho*Wo (%d) to be a multiple of the 128-row tile", p.Ho * p.Wo);
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;
-  p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.xpn = 1;
+  p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.f16 = 0; p.xpn = 1;
   if (int prc = set_planes(p, po, glu, "conv2d_bf16x3")) return prc;
   if (pl.nsplit > 1) {
     size_t need = (size_t)pl.nsplit * M * p.Ncols * sizeof(float);
@@ -2230,6 +2296,10 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   // math 2 = plain bf16 (mixed-precision training), 3 = "bf16x3" (hi + mid planes, three products: 16 significant bits per
   // operand, ~2^-16 relative error per product), else bf16x6
   p.nplanes = ((plan >> 16) & 3) == 2 ? 1 : (((plan >> 16) & 3) == 3 ? 2 : 3);
+  // plan bit 18 (SWEM_PLAN_F16) with math 3: "f16x3" -- the planes of every source and of the filters are fp16 pairs
+  // (swem_split_f16x2_f32; the filters scaled per output column by a power of two that the caller folds into `scale`)
+  p.f16 = (p.nplanes == 2 && ((plan >> 18) & 1)) ? 1 : 0;
+  SWEM_REQUIRE(!((plan >> 18) & 1) || p.nplanes == 2, SWEM_E_ARG, "conv2d_bf16x3: plan bit 18 (fp16 planes) needs math mode 3");
   const int mtiles = cdiv(p.M, 64 * pl.wm), ntiles = cdiv(p.Ncols, 64 * pl.wn);
   // XCD partition of the N tiles: plan bits 28-29 force 2 / 4 / 8 groups; 0 = the cut with the least fetch traffic by
   // the model  groups * activations + (8 / groups) * filters  (each XCD reads its groups' filters and its share of the

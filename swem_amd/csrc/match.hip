@@ -332,13 +332,13 @@ __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__re
           // S's own bf16 planes [2 topl / 8][N * P][8] for the pre-split convolution that consumes it (modules.py:288-289):
           // channel c of pixel gp is element ((c / 8) * npix + gp) * 8 + c % 8 of a plane
           uint2 h, m, lo;
-          split3(make_float4(f, 1.f - f, 0.f, 0.f), h, m, lo);
+          split_as(sq_npl, make_float4(f, 1.f - f, 0.f, 0.f), h, m, lo);
           const long long npix = (long long)gridDim.y * P, gp = (long long)n * P + pp, plane = npix * 2 * topl;
           const long long i0 = ((long long)(lane >> 3) * npix + gp) * 8 + (lane & 7);
           const long long i1 = ((long long)((topl + lane) >> 3) * npix + gp) * 8 + ((topl + lane) & 7);
           sq[i0] = (unsigned short)h.x, sq[i1] = (unsigned short)(h.x >> 16);
           sq[plane + i0] = (unsigned short)m.x, sq[plane + i1] = (unsigned short)(m.x >> 16);
-          if (sq_npl > 2) sq[2 * plane + i0] = (unsigned short)lo.x, sq[2 * plane + i1] = (unsigned short)(lo.x >> 16);
+          if (sq_npl == 3) sq[2 * plane + i0] = (unsigned short)lo.x, sq[2 * plane + i1] = (unsigned short)(lo.x >> 16);
         }
       }
     }
@@ -644,9 +644,11 @@ int match_core(void *stream, const float *qk, const float *mkn, const float *mvp
   }
   // value readout (modules.py:272-273) = batched GEMM  mem_out[n] = pT[n] . mvp[n]^T  on the conv kernel:
   // "image" of Pm x 1 pixels with Ltot channels, 1x1 filters = the V value rows of object n (w_bs = V*Ltot)
+  // (the pack's value planes and the probability planes above are bf16: SWEM_PLAN_F16 does not apply to the readout)
   if (presplit)
     return swem_gemm_bf16x3_batched(stream, pq, Ltot, (long long)Pm * Ltot, (long long)N * Pm * Ltot, N, Pm, mvq,
-                                    (long long)2 * V * Ltot, mem_out, V, readout_plan, conv_ws, conv_bytes, mem_planes, mem_npl);
+                                    (long long)2 * V * Ltot, mem_out, V, readout_plan & ~SWEM_PLAN_F16, conv_ws, conv_bytes,
+                                    mem_planes, mem_npl);
   return swem_conv2d_nhwc_f32(stream, pT, Ltot, (long long)Pm * Ltot, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, mvp,
                               (long long)V * Ltot, nullptr, nullptr, nullptr, 0, mem_out, V, 1, 1, 1, 0, 0,
                               readout_plan, conv_ws, conv_bytes);
@@ -718,8 +720,8 @@ int match_packed_impl(void *stream, const float *qk, const float *mkn, const flo
   SWEM_REQUIRE(qk && mkn && mvp && mem_out && S, SWEM_E_ARG, "match_packed: null pointer");
   int rc;
   if ((rc = match_check(C, V, L, 2 * L, topl, tau))) return rc;
-  SWEM_REQUIRE((!mem_planes || ((mem_npl == 2 || mem_npl == 3) && V % 8 == 0)) &&
-                   (!s_planes || ((s_npl == 2 || s_npl == 3) && topl % 4 == 0)),
+  SWEM_REQUIRE((!mem_planes || ((mem_npl == 2 || mem_npl == 3 || mem_npl == SWEM_PLANES_F16) && V % 8 == 0)) &&
+                   (!s_planes || ((s_npl == 2 || s_npl == 3 || s_npl == SWEM_PLANES_F16) && topl % 4 == 0)),
                SWEM_E_ARG, "match_packed: output planes: 2 or 3 per tensor, V %% 8 == 0, topl %% 4 == 0");
   MatchWs w = match_ws(N, C, V, P, L, 2, readout_plan);
   SWEM_REQUIRE(ws && ws_bytes >= w.total - w.pT, SWEM_E_WORKSPACE, "match_packed: workspace %zu < %zu", ws_bytes,

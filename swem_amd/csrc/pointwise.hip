@@ -116,12 +116,12 @@ __global__ void prep_input_s2d_kernel(const float *__restrict__ f, const float *
   }
   if (planes) {
     uint2 h0, m0, l0, h1, m1, l1;
-    split3(v0, h0, m0, l0);
-    split3(v1, h1, m1, l1);
+    split_as(nplanes, v0, h0, m0, l0);
+    split_as(nplanes, v1, h1, m1, l1);
     const long long plane = npix * 32, o = ((long long)ph * npix + blk) * 8;
     *reinterpret_cast<uint4 *>(planes + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
     *reinterpret_cast<uint4 *>(planes + plane + o) = make_uint4(m0.x, m0.y, m1.x, m1.y);
-    if (nplanes > 2) *reinterpret_cast<uint4 *>(planes + 2 * plane + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    if (nplanes == 3) *reinterpret_cast<uint4 *>(planes + 2 * plane + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
   }
 }
 
@@ -162,11 +162,11 @@ __device__ __forceinline__ void planes8_out(const float4 (&v)[2], unsigned short
     const int npl = var ? npl1 : npl0;
     if (!out) continue;
     uint2 h0, m0, l0, h1, m1, l1;
-    split3(var ? make_float4(fmaxf(v[0].x, 0.f), fmaxf(v[0].y, 0.f), fmaxf(v[0].z, 0.f), fmaxf(v[0].w, 0.f)) : v[0], h0, m0, l0);
-    split3(var ? make_float4(fmaxf(v[1].x, 0.f), fmaxf(v[1].y, 0.f), fmaxf(v[1].z, 0.f), fmaxf(v[1].w, 0.f)) : v[1], h1, m1, l1);
+    split_as(npl, var ? make_float4(fmaxf(v[0].x, 0.f), fmaxf(v[0].y, 0.f), fmaxf(v[0].z, 0.f), fmaxf(v[0].w, 0.f)) : v[0], h0, m0, l0);
+    split_as(npl, var ? make_float4(fmaxf(v[1].x, 0.f), fmaxf(v[1].y, 0.f), fmaxf(v[1].z, 0.f), fmaxf(v[1].w, 0.f)) : v[1], h1, m1, l1);
     *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
     *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
-    if (npl > 2) *reinterpret_cast<uint4 *>(out + 2 * plane + i * 8) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    if (npl == 3) *reinterpret_cast<uint4 *>(out + 2 * plane + i * 8) = make_uint4(l0.x, l0.y, l1.x, l1.y);
   }
 }
 
@@ -1073,7 +1073,7 @@ extern "C" int swem_prep_input_s2d_f32(void *stream, const float *frame, const f
                                        int single_obj) {
   SWEM_REQUIRE(frame && mean3 && std3 && (out || planes) && B > 0 && N > 0, SWEM_E_ARG, "prep_input_s2d: bad argument");
   SWEM_REQUIRE(H % 2 == 0 && W % 2 == 0, SWEM_E_SHAPE, "prep_input_s2d: the frame size must be even (got %dx%d)", H, W);
-  SWEM_REQUIRE(!planes || nplanes == 2 || nplanes == 3, SWEM_E_ARG, "prep_input_s2d: 2 or 3 planes");
+  SWEM_REQUIRE(!planes || nplanes == 2 || nplanes == 3 || nplanes == SWEM_PLANES_F16, SWEM_E_ARG, "prep_input_s2d: 2 or 3 planes, or SWEM_PLANES_F16");
   float3 m = make_float3(mean3[0], mean3[1], mean3[2]), s = make_float3(std3[0], std3[1], std3[2]);
   const long long n = (long long)B * N * (H / 2 + 1) * (W / 2 + 1) * 4;
   hipLaunchKernelGGL(prep_input_s2d_kernel, grid1(n), dim3(256), 0, ST, frame, masks, m, s, out,
@@ -1094,7 +1094,7 @@ extern "C" int swem_maxpool3x3s2_nhwc_f32(void *stream, const float *x, float *y
 extern "C" int swem_maxpool3x3s2_nhwc_f32_planes(void *stream, const float *x, float *y, int B, int H, int W, int C,
                                                  void *planes, int nplanes, void *planes_relu, int nplanes_relu) {
   SWEM_REQUIRE(x && y && C % 8 == 0, SWEM_E_SHAPE, "maxpool_planes: need C %% 8 == 0");
-  SWEM_REQUIRE((!planes || (nplanes >= 2 && nplanes <= 3)) && (!planes_relu || (nplanes_relu >= 2 && nplanes_relu <= 3)),
+  SWEM_REQUIRE((!planes || (nplanes >= 2 && nplanes <= 4)) && (!planes_relu || (nplanes_relu >= 2 && nplanes_relu <= 4)),
                SWEM_E_ARG, "maxpool_planes: 2 or 3 planes per variant");
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long npix = (long long)B * Ho * Wo;
@@ -1118,7 +1118,7 @@ extern "C" int swem_upsample_add_nhwc_f32_planes(void *stream, const float *skip
                                                  float *y, int B, int Hl, int Wl, int Ho, int Wo, int C, void *planes,
                                                  int nplanes, void *planes_relu, int nplanes_relu) {
   SWEM_REQUIRE(skip && low && y && C % 8 == 0, SWEM_E_SHAPE, "upsample_add_planes: need C %% 8 == 0");
-  SWEM_REQUIRE((!planes || (nplanes >= 2 && nplanes <= 3)) && (!planes_relu || (nplanes_relu >= 2 && nplanes_relu <= 3)),
+  SWEM_REQUIRE((!planes || (nplanes >= 2 && nplanes <= 4)) && (!planes_relu || (nplanes_relu >= 2 && nplanes_relu <= 4)),
                SWEM_E_ARG, "upsample_add_planes: 2 or 3 planes per variant");
   const long long npix = (long long)B * Ho * Wo;
   hipLaunchKernelGGL(upsample_add_planes_kernel, dim3((unsigned)cdiv(npix, 32), (unsigned)cdiv(C / 8, 8)), dim3(256), 0, ST,
@@ -1191,7 +1191,7 @@ static int cbam_impl(void *stream, const float *x, const float *w1, const float 
   SWEM_CHECK_LAUNCH("cbam_sgate");
   if (planes || planes_relu) {
     SWEM_REQUIRE(C % 8 == 0, SWEM_E_SHAPE, "cbam_planes: need C %% 8 == 0");
-    SWEM_REQUIRE((!planes || (nplanes >= 2 && nplanes <= 3)) && (!planes_relu || (nplanes_relu >= 2 && nplanes_relu <= 3)),
+    SWEM_REQUIRE((!planes || (nplanes >= 2 && nplanes <= 4)) && (!planes_relu || (nplanes_relu >= 2 && nplanes_relu <= 4)),
                  SWEM_E_ARG, "cbam_planes: 2 or 3 planes per variant");
     hipLaunchKernelGGL(cbam_apply_planes_kernel, dim3((unsigned)cdiv((long long)B * P, 32), (unsigned)cdiv(C / 8, 8)),
                        dim3(256), 0, ST, x, cscale, sg, y, static_cast<unsigned short *>(planes), nplanes,

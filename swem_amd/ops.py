@@ -11,6 +11,10 @@ import torch
 from . import _lib
 
 RELU_IN, RELU_OUT, GLU = 1, 2, 4
+# plane-count code of the fp16 (hi, mid) pair (include/swem_hip.h, SWEM_PLANES_F16): the operand format of the f16x3 conv
+# arithmetic (plan math field 7 = math 3 + SWEM_PLAN_F16); 2 / 3 = bf16 planes
+PLANES_F16 = 4
+MATH_NAMES = {0: 'fp32', 1: 'bf16x6', 2: 'bf16', 3: 'bf16x3', 7: 'f16x3'}
 
 _ws = {}
 # bench.py sets this to a list to time every conv launch with HIP events on the launch stream:
@@ -112,12 +116,13 @@ class PlanBook:
         self.hints.clear()
         self.hint_epoch.clear()
 
-    def math_histogram(self):
-        """{'fp32': n, 'bf16x6': n, 'bf16': n, 'bf16x3': n} over the conv plans (a plan of 0 is the fp32 heuristic)."""
-        names = ('fp32', 'bf16x6', 'bf16', 'bf16x3')
-        out = {n: 0 for n in names}
-        for v in self.conv.values():
-            out[names[(v >> 16) & 3]] += 1
+    def math_histogram(self, tag=()):
+        """{'fp32': n, 'bf16x6': n, 'bf16': n, 'bf16x3': n, 'f16x3': n} over the conv plans tuned under the conv_math tag `tag`
+        (default: the untagged ones; a plan of 0 is the fp32 heuristic)."""
+        out = {n: 0 for n in MATH_NAMES.values()}
+        for k, v in self.conv.items():
+            if tuple(k[10:]) == tuple(tag):
+                out[MATH_NAMES.get((v >> 16) & 7, 'fp32')] += 1
         return out
 
     def digest(self):
@@ -229,7 +234,10 @@ def _next_pack_key():
 # math modes the conv tuner may choose from: 0 = fp32 MFMA, 1 = bf16x6 (exact 3-way bf16 split, six products: fp32-level
 # error), 3 = bf16x3 (hi + mid planes, the three products above 2^-16: 16 significant bits per operand, half the MFMA work
 # of bf16x6; the per-stage 1e-4 and per-frame 1e-3 parity bars are asserted with it enabled)
-CONV_MATH_MODES = (0, 1, 3)
+# 7 = f16x3 (round 4): the bf16x3 kernel on fp16 (hi, mid) planes -- 23 significant bits per operand, fp32-level error
+# (measured beside fp32 MFMA and bf16x6: tests/test_gpu_ops.py::test_conv2d_f16x3_mode) at the bf16x3 cost.  It replaces
+# bf16x3 in the default set: bf16x3 (16 bits) stays reachable through conv_math((3,)) or an explicit plan.
+CONV_MATH_MODES = (0, 1, 7)
 _TUNE_TILES = ((2, 2), (1, 2), (2, 1), (1, 1))   # (2, 1) = 128x64: pre-split kernels only (64-channel layers)
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
 
@@ -379,12 +387,39 @@ class ConvPack:
         # the planes' K axis runs (ci / 32, ky, kx, ci % 32), not (ky, kx, ci): swem_conv2d_nhwc_bf16x3 walks the taps of
         # one 32-channel block back to back, so a tile's activations are fetched once instead of once per tap
         self.w3 = None
+        self._w16 = None                  # (fp16 filter planes, scale with the planes' power-of-two column factors folded in)
         if kk % 8 == 0 and self.cin % 32 == 0 and kh * kw <= 64:
-            wk = w
-            if kh * kw > 1:
-                wk = w.reshape(co, kh * kw, self.cin // 32, 32).permute(0, 2, 1, 3).contiguous()
             self.w3 = torch.empty((3, co * kk), dtype=torch.bfloat16, device=w.device)
-            _lib.call('swem_split_bf16x3_f32', _stream(), wk.data_ptr(), self.w3.data_ptr(), co, kk, 0)
+            _lib.call('swem_split_bf16x3_f32', _stream(), self._k_ordered().data_ptr(), self.w3.data_ptr(), co, kk, 0)
+
+    def _k_ordered(self):
+        w = self.w
+        co, khw = w.shape[0], w.shape[1] * w.shape[2]
+        if khw > 1:
+            return w.reshape(co, khw, self.cin // 32, 32).permute(0, 2, 1, 3).contiguous()
+        return w
+
+    def planes16(self):
+        """(w16, scale16): the filters as the fp16 (hi, mid) pair of the f16x3 arithmetic (include/swem_hip.h,
+        swem_split_f16x2_f32) and the epilogue scale that goes with them.  Every output column n is multiplied by 2^e[n] so that
+        its largest weight lies in [2^13, 2^14) before the split -- conv weights are O(1e-2), and the `mid` term of a value below
+        2^-2 would be a subnormal fp16 number -- and scale16[n] = scale[n] * 2^-e[n] undoes it in the epilogue (exact: powers of
+        two).  Built on first use, once per pack."""
+        if self._w16 is None:
+            if self.w3 is None:
+                raise _lib.SwemHipError('this layer has no pre-split form (K %% 8, Cin %% 32, at most 64 taps)')
+            wk = self._k_ordered()
+            co, kk = wk.shape[0], wk[0].numel()
+            amax = wk.reshape(co, kk).abs().amax(dim=1)
+            e = torch.where(amax > 0, 13 - torch.floor(torch.log2(amax.clamp_min(1e-30))), torch.zeros_like(amax))
+            # (log2 of a float just below a power of two may round up: the column then peaks in [2^12, 2^13), equally fine)
+            f = torch.exp2(e.clamp(-100, 100))
+            w16 = torch.empty((2, co * kk), dtype=torch.float16, device=wk.device)
+            _lib.call('swem_split_f16x2_f32', _stream(), (wk.reshape(co, kk) * f[:, None]).contiguous().data_ptr(),
+                      w16.data_ptr(), co, kk, 0)
+            sc = (self.scale if self.scale is not None else torch.ones_like(f)) / f
+            self._w16 = (w16, sc.contiguous())
+        return self._w16
 
 
 def pack_conv(weight, bias=None, bn=None, stride=1, pad=None, cin_pad=None, eps=1e-5):
@@ -437,35 +472,64 @@ def presplit(t, relu=False, nplanes=3):
     """bf16 planes, each [C/8][npix][8], of an NHWC fp32 activation with t = hi + mid + lo (of relu(t) if asked), computed
     once per tensor and cached on it: conv inputs are never modified after they are produced.  npix covers the tensor's
     storage range (a batch stride larger than one image, as match's mem_out has, is kept).  nplanes: how many of the three
-    the caller reads (2 for a bf16x3 / plain-bf16 consumer).  A producer that knows its consumers writes the planes itself
+    the caller reads (2 for a bf16x3 / plain-bf16 consumer; PLANES_F16: the fp16 (hi, mid) pair of an f16x3 consumer, its
+    own cache entry -- a request for it outranks bf16 requests in the producer's hint, a tensor with consumers of both
+    formats pays a split launch for the bf16 ones).  A producer that knows its consumers writes the planes itself
     (conv2d's epilogue, the frozen-BN stages of the training step): the request is recorded under the producer's site so
     that it can do so from the next frame / step on."""
     cache = t.__dict__.setdefault('_swem_split', {})
     if cache and t.__dict__.get('_swem_split_ver', t._version) != t._version:
         cache.clear()                      # the tensor was modified in place after its planes were made
     t.__dict__['_swem_split_ver'] = t._version
-    ent = cache.get(relu)
+    f16 = nplanes == PLANES_F16
+    key = _pkey(relu, nplanes)
+    ent = cache.get(key)
     site = t.__dict__.get('_swem_site')
     if site is not None and not _IN_TUNER[0]:
         # (the tuner's candidates do not count: a bf16x6 candidate that lost would leave the producer writing a third plane --
         # a quarter more plane bytes -- for a consumer that reads two)
         h = BOOK.hints.setdefault(site, {})
-        if h.get(relu, 0) < nplanes:
-            h[relu] = nplanes              # the producer of this tensor can write the planes itself next time
+        cur = h.get(relu, 0)
+        if cur < nplanes or (cur == PLANES_F16) != f16:
+            # the producer of this tensor can write the planes itself next time: more bf16 planes than it writes now, or the
+            # other format (the latest request decides: a planes-only output has ONE consumer, and it must find its format)
+            h[relu] = nplanes
         BOOK.hint_epoch[site] = BOOK.epoch()   # ... and, while no plan changes, leave the fp32 map out (conv2d planes_only)
-    if ent is None or ent[1] < nplanes:
+    if ent is None or (not f16 and ent[1] < nplanes):
         if t.__dict__.get('_swem_planes_only'):
             raise _lib.SwemHipError('presplit: a planes-only convolution output is asked for planes its producer did not write '
-                                    '(relu=%s, %d planes): it has more than the one consumer conv2d(planes_only=True) promises'
+                                    '(relu=%s, plane code %d): it has more than the one consumer conv2d(planes_only=True) promises'
                                     % (relu, nplanes))
         B, H, W, Cc = t.shape
         if B > 1 and t.stride(0) % Cc:
             raise _lib.SwemHipError('presplit: batch stride must be a multiple of the channel count')
         npix = (B - 1) * (t.stride(0) // Cc) + H * W if B > 1 else H * W
-        sp = torch.empty((3, npix * Cc), dtype=torch.bfloat16, device=t.device)
-        _lib.call('swem_split_bf16x3_f32', _stream(), t.data_ptr(), sp.data_ptr(), npix, Cc, int(relu))
-        ent = cache[relu] = (sp, 3)
+        if f16:
+            sp = torch.empty((2, npix * Cc), dtype=torch.float16, device=t.device)
+            _lib.call('swem_split_f16x2_f32', _stream(), t.data_ptr(), sp.data_ptr(), npix, Cc, int(relu))
+            ent = cache[key] = (sp, PLANES_F16)
+        else:
+            sp = torch.empty((3, npix * Cc), dtype=torch.bfloat16, device=t.device)
+            _lib.call('swem_split_bf16x3_f32', _stream(), t.data_ptr(), sp.data_ptr(), npix, Cc, int(relu))
+            ent = cache[key] = (sp, 3)
     return ent[0]
+
+
+def _pkey(relu, npl):
+    """Key of a tensor's plane cache (`_swem_split`): relu (False / True = 0 / 1) for bf16 planes, 2 + relu for the fp16 pair."""
+    return int(bool(relu)) + (2 if npl == PLANES_F16 else 0)
+
+
+def _new_planes(npl, numel, device):
+    """Storage for a producer-written plane set: (3, numel) bf16, or (2, numel) fp16 for PLANES_F16."""
+    if npl == PLANES_F16:
+        return torch.empty((2, numel), dtype=torch.float16, device=device)
+    return torch.empty((3, numel), dtype=torch.bfloat16, device=device)
+
+
+def _keyed(planes):
+    """{relu: (tensor, npl)} as a producer collected it -> the `_swem_split` cache of its output."""
+    return {_pkey(r, e[1]): e for r, e in planes.items()}
 
 
 def batch_item(t, j):
@@ -556,12 +620,13 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
             for relu_v, npl in want.items():
                 sp = planes.get(relu_v)
                 if sp is None:
-                    sp = planes[relu_v] = (torch.empty((3, B * Ho * Wo * pack.cout), dtype=torch.bfloat16,
-                                                       device=x0.device), npl)
+                    sp = planes[relu_v] = (_new_planes(npl, B * Ho * Wo * pack.cout, x0.device), npl)
                 pargs[2 * int(relu_v)], pargs[2 * int(relu_v) + 1] = sp[0].data_ptr(), npl
         if (plan >> 16) & 3 and presplit_ok:
-            # bf16 math: sources split once per tensor (input ReLU folded into the split), filters split at pack time
-            need = 3 if (plan >> 16) & 3 == 1 else 2
+            # bf16 / fp16 math: sources split once per tensor (input ReLU folded into the split), filters split at pack time
+            f16 = (plan >> 16) & 7 == 7
+            need = 3 if (plan >> 16) & 3 == 1 else (PLANES_F16 if f16 else 2)
+            w3, scale = pack.planes16() if f16 else (pack.w3, pack.scale)
             sargs = []
             for i, s_ in enumerate(srcs):
                 # (tuning charges a candidate the split of its inputs -- except inputs a conv epilogue produces: those arrive
@@ -573,7 +638,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
             for _ in range(3 - len(srcs)):
                 sargs += [0, 0, 0, 0]
             ctr = counters(x0.device)
-            _lib.call('swem_conv2d_nhwc_bf16x3_planes_ctr', _stream(), *sargs, B, H, W, pack.w3.data_ptr(), _ptr(pack.scale),
+            _lib.call('swem_conv2d_nhwc_bf16x3_planes_ctr', _stream(), *sargs, B, H, W, w3.data_ptr(), _ptr(scale),
                       _ptr(pack.shift), _ptr(residual), res_bs, y_ptr, pack.cout, pack.kh, pack.kw,
                       pack.stride, pack.pad, flags & ~RELU_IN, plan, _ptr(ws), wsb, *pargs, _ptr(ctr),
                       0 if ctr is None else ctr.numel())
@@ -597,14 +662,15 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         e0.record()
     launch(plan)
     if MATH_RAN is not None:
-        m_ = (plan >> 16) & 3
+        m_ = (plan >> 16) & 7
+        m_ = m_ if m_ == 7 else m_ & 3
         if not presplit_ok:                # (what the library runs on the fp32 entry point: conv.hip, `emulate`)
             m_ = 1 if (m_ & 1 and pipe_ok) else 0
         MATH_RAN[m_] = MATH_RAN.get(m_, 0) + 1
     if out is None:
         y.__dict__['_swem_site'] = site
         if planes:
-            y.__dict__['_swem_split'] = dict(planes)
+            y.__dict__['_swem_split'] = _keyed(planes)
             y.__dict__['_swem_split_ver'] = y._version
         if skip_y:
             y.__dict__['_swem_planes_only'] = True
@@ -617,7 +683,8 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         CONV_TRACE.append((e0, e1, 2.0 * B * Ho * Wo * ncols * pack.kh * pack.kw * pack.cin_true,
                            '%dx%dx%d k%d s%d %d->%d' % (B, H, W, pack.kh, pack.stride, pack.cin_true, ncols),
                            in_bytes + 4.0 * ncols * pack.kh * pack.kw * pack.cin_true + 4.0 * B * Ho * Wo * pack.cout,
-                           plan, ('bf16x3' if (plan >> 16) & 3 == 3 and presplit_ok else
+                           plan, ('f16x3' if (plan >> 16) & 7 == 7 and presplit_ok else
+                                  'bf16x3' if (plan >> 16) & 3 == 3 and presplit_ok else
                                   'bf16' if ((plan >> 16) & 3 and (presplit_ok or ((plan >> 16) & 1 and pipe_ok))) else 'fp32')))
     return y
 
@@ -658,7 +725,7 @@ def load_plans(path, book=None):
     return (book or BOOK).load(path)
 
 
-def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
+def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False, modes=None):
     """Time candidate (wave tile, K-split, math mode) plans for one layer shape; return the fastest as a plan hint.
     fresh_kw: the launcher takes fresh=True to re-split its inputs every time (the split cost is then part of the
     bf16x6 candidates' time, as if no other layer shared the input)."""
@@ -670,11 +737,11 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
         for ns in _TUNE_SPLITS:
             if ns > 1 and (nkb // ns < 2 or blocks * ns > 4096):
                 continue
-            for math in CONV_MATH_MODES:
+            for math in (modes if modes is not None else CONV_MATH_MODES):
                 if (wm, wn) == (2, 1) and (math == 0 or ncols > 64):
                     continue                       # the 128x64 tile: where a 64-wide N leaves nothing else to widen
                 cands.append(wm | wn << 4 | ns << 8 | math << 16)
-                if math in (1, 2, 3):              # pre-split kernel variants: other stage count, 8-wave 128x128 tile
+                if math in (1, 2, 3, 7):           # pre-split kernel variants: other stage count, 8-wave 128x128 tile
                     base = wm | wn << 4 | ns << 8 | math << 16
                     cands.append(base | 1 << 20)
                     cands.append(base | 4 << 20)              # 16x16x32 MFMA shape
@@ -696,7 +763,7 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False):
                             cands.append(base | 5 << 20)      # prefetched fragments: four waves of 64x64, two stages
                             cands.append(base | 15 << 20)     # ... three stages (one block per CU)
                             cands.append(base | 7 << 20)      # ... eight waves of 32x64, four stages
-                            if ns == 1 and nkb >= 16:         # stream-K (plan bits 24-27 = 1): persistent workers, equal shares
+                            if ns == 1 and nkb >= 16 and math != 7:   # stream-K (plan bits 24-27 = 1): persistent workers, equal shares
                                 cands.append(base | 6 << 20 | 1 << 24)
                                 cands.append(base | 5 << 20 | 1 << 24)
                     if ns == 1 and blocks > 256 and nkb >= 16:   # tail split: the last, partly filled round over K
@@ -810,12 +877,15 @@ def prep_input_s2d(frame, masks, mean3, std3, single_obj=False):
         N = masks.shape[1] - 1
     Hb, Wb = H // 2 + 1, W // 2 + 1
     out = torch.empty((B * N, Hb, Wb, 32), dtype=torch.float32, device=frame.device)
-    sp = torch.empty((3, out.numel()), dtype=torch.bfloat16, device=frame.device)
+    site = ('prep_s2d', B * N, H, W)
+    # (three bf16 planes unless the stem that consumed this input on an earlier frame asked for the fp16 pair)
+    npl = PLANES_F16 if BOOK.hints.get(site, {}).get(False) == PLANES_F16 else 3
+    sp = _new_planes(npl, out.numel(), frame.device)
     _lib.call('swem_prep_input_s2d_f32', _stream(), frame.data_ptr(), _ptr(masks), C.addressof(mean3), C.addressof(std3),
-              out.data_ptr(), sp.data_ptr(), 3, B, N, H, W, int(single_obj))
-    out.__dict__['_swem_split'] = {False: (sp, 3)}
+              out.data_ptr(), sp.data_ptr(), npl, B, N, H, W, int(single_obj))
+    out.__dict__['_swem_split'] = {_pkey(False, npl): (sp, npl)}
     out.__dict__['_swem_split_ver'] = out._version
-    out.__dict__['_swem_site'] = ('prep_s2d', B * N, H, W)
+    out.__dict__['_swem_site'] = site
     return out
 
 
@@ -842,10 +912,10 @@ def _fused_planes(site, numel, device):
     planes, pargs = {}, [0, 3, 0, 3]
     if want:
         for relu_v, npl in want.items():
-            sp = torch.empty((3, numel), dtype=torch.bfloat16, device=device)
+            sp = _new_planes(npl, numel, device)
             planes[relu_v] = (sp, npl)
             pargs[2 * int(relu_v)], pargs[2 * int(relu_v) + 1] = sp.data_ptr(), npl
-    return planes, pargs
+    return _keyed(planes), pargs
 
 
 def upsample_add(skip, low, batch=None):
@@ -1138,8 +1208,11 @@ def _match_plan(key, launch, M, V, nkb):
     if plan == 0 and len(_PLAN_TAG) == 2 and not AUTOTUNE:
         plan = _PLAN_TAG[1] << 16
     if AUTOTUNE and plan == 0 and not torch.cuda.is_current_stream_capturing():
-        plan = BOOK.match[key + _PLAN_TAG] = _autotune(launch, M, V, nkb, False)
-    return plan
+        # (the value planes of a pack and the probability planes of the affinity kernel are bf16: where the convolutions may
+        # run f16x3 the readout is offered bf16x3)
+        modes = tuple(dict.fromkeys(3 if m == 7 else m for m in CONV_MATH_MODES))
+        plan = BOOK.match[key + _PLAN_TAG] = _autotune(launch, M, V, nkb, False, modes=modes)
+    return plan & ~(1 << 18)
 
 
 def match(qk, kappa_first, nu_first, kappa_update, nu_update, topl, tau):
@@ -1223,7 +1296,7 @@ def match_packed(qk, pack, L, topl, tau, hw=None):
             pargs = []
             for key, want, numel in (('m', want_m, mem_out.numel()), ('s', want_s, S.numel())):
                 if want and key not in planes:
-                    planes[key] = (torch.empty((3, numel), dtype=torch.bfloat16, device=qk.device), want)
+                    planes[key] = (_new_planes(want, numel, qk.device), want)
                 pargs += [planes[key][0].data_ptr(), planes[key][1]] if want else [0, 3]
             _lib.call('swem_match_packed_f32_planes', *args, *pargs)
         else:
@@ -1236,7 +1309,7 @@ def match_packed(qk, pack, L, topl, tau, hw=None):
     mem_img, s_img = mem_out[:, :P].unflatten(1, hw), S.view(N, hw[0], hw[1], -1)
     for img, key, site in ((mem_img, 'm', site_m), (s_img, 's', site_s)):
         if key in planes:
-            img.__dict__['_swem_split'] = {False: planes[key]}
+            img.__dict__['_swem_split'] = {_pkey(False, planes[key][1]): planes[key]}
             img.__dict__['_swem_split_ver'] = img._version
         img.__dict__['_swem_site'] = site
     return mem_img, s_img

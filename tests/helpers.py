@@ -28,8 +28,8 @@ def clip_from_fixture(fx):
     return frames, m0
 
 
-ROUND = 'r03'
-ARITH_MODES = ('fp32', 'bf16x3', 'tuned')
+ROUND = 'r04'
+ARITH_MODES = ('fp32', 'f16x3', 'bf16x3', 'tuned')
 
 
 def tuned_plans_path():
@@ -43,10 +43,13 @@ def tuned_plans_path():
 class arith:
     """Context: the conv arithmetic a parity test runs, selected EXPLICITLY and checked afterwards.
       'fp32'   -- no plans, no forced math: every GEMM on the fp32 MFMA (plan 0).
+      'f16x3'  -- ops.conv_math((7,)): every convolution the pre-split kernel can take runs on the fp16 (hi, mid) planes (22-23
+                  significant bits per operand, three products: fp32-level error), the heuristic tile; matching's value readout
+                  on its bf16 planes (the pack's format).
       'bf16x3' -- ops.conv_math((3,)): every convolution the pre-split kernel can take AND matching's value readout run on
                   the hi + mid bf16 planes (16 significant bits per operand, three products), the heuristic tile.
       'tuned'  -- the bench's plans (swem_amd/plans/mi355x_480p_k256.json, what ships) loaded into the model's book: the mix of tiles, K-splits
-                  and math modes the tuner chose at config B (other shapes find no plan and run fp32).
+                  and math modes the tuner chose at config B (f16x3 nearly everywhere; other shapes find no plan and run fp32).
     `ran` = {math field: conv launches} of what really ran; leaving the context asserts it matches the mode."""
 
     def __init__(self, mode, *models, need_bf16x3=True):
@@ -57,8 +60,8 @@ class arith:
     def __enter__(self):
         ops = self.ops
         assert self.mode in ARITH_MODES and ops.MATH_RAN is None
-        if self.mode == 'bf16x3':
-            self.cm = ops.conv_math((3,))
+        if self.mode in ('bf16x3', 'f16x3'):
+            self.cm = ops.conv_math((3,) if self.mode == 'bf16x3' else (7,))
             self.cm.__enter__()
         elif self.mode == 'tuned':
             path = tuned_plans_path()
@@ -77,15 +80,16 @@ class arith:
             assert total > 0, 'no conv launch was counted'
             if self.mode == 'fp32':
                 assert set(self.ran) == {0}, self.ran
-            elif self.mode == 'bf16x3':
+            elif self.mode in ('bf16x3', 'f16x3'):
                 # everything but the layers the pre-split kernel cannot take (7x7 stems on 4 / 8 channels, 1-channel heads)
-                assert self.ran.get(3, 0) >= 0.85 * total and not self.ran.get(1) and not self.ran.get(2), self.ran
+                m, other = (3, 7) if self.mode == 'bf16x3' else (7, 3)
+                assert self.ran.get(m, 0) >= 0.85 * total and not self.ran.get(1) and not self.ran.get(2) and not self.ran.get(other), self.ran
             elif self.need:
-                assert self.ran.get(3, 0) > 0, self.ran
+                assert self.ran.get(7, 0) > 0 and not self.ran.get(3), self.ran      # the shipped plans: f16x3, no 16-bit layer
         return False
 
     def summary(self):
-        names = {0: 'fp32', 1: 'bf16x6', 2: 'bf16', 3: 'bf16x3'}
+        names = {0: 'fp32', 1: 'bf16x6', 2: 'bf16', 3: 'bf16x3', 7: 'f16x3'}
         return {names[k]: v for k, v in sorted(self.ran.items())}
 
 

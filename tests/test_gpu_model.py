@@ -199,12 +199,12 @@ def test_stages_vs_oracle_with_autotuner(lib):
     hist = model.book.math_histogram()
     H.record_parity('stages_configB[autotuned]', {'plans_by_math': hist, 'plans_digest': model.book.digest(),
                                                   'conv_launches_by_math': {str(k): v for k, v in ran.items()}})
-    assert hist['bf16x3'] + hist['bf16x6'] > 0 and not ops.BOOK.conv, (hist, 'plans leaked into the default book')
+    assert hist['f16x3'] + hist['bf16x6'] > 0 and not hist['bf16x3'] and not ops.BOOK.conv, (hist, 'plans leaked into the default book')
 
 
-@pytest.mark.parametrize('mode', ('bf16x3', 'tuned'))
+@pytest.mark.parametrize('mode', ('f16x3', 'bf16x3', 'tuned'))
 def test_stages_vs_oracle_config_b_in_bench_arithmetic(lib, mode):
-    """Stage by stage at config B with bf16x3 FORCED on every layer / with the bench's committed plans: 1e-4 per stage."""
+    """Stage by stage at config B with f16x3 / bf16x3 FORCED on every layer / with the bench's committed plans: 1e-4 per stage."""
     book = ops.PlanBook()
     with H.arith(mode, book) as ar:
         _stages_vs_oracle(CFG_B, 480, 864, 2, book=book)
@@ -233,11 +233,12 @@ def _run_fixture(golden, name, kw, sub, mode='fp32'):
 
 
 @pytest.mark.parametrize('name,kw,sub,mode', [('g6_configA.npz', CFG_A_SO, 2, 'fp32'), ('g6_configA_mo.npz', CFG_A, 2, 'fp32'),
-                                              ('g6_configA_mo.npz', CFG_A, 2, 'bf16x3'),
+                                              ('g6_configA_mo.npz', CFG_A, 2, 'bf16x3'), ('g6_configA_mo.npz', CFG_A, 2, 'f16x3'),
                                               ('g7_configB.npz', CFG_B, 8, 'fp32'), ('g7_configB.npz', CFG_B, 8, 'bf16x3'),
-                                              ('g7_configB.npz', CFG_B, 8, 'tuned')],
+                                              ('g7_configB.npz', CFG_B, 8, 'f16x3'), ('g7_configB.npz', CFG_B, 8, 'tuned')],
                          ids=['configA_single_object', 'configA_multi_object', 'configA_multi_object_bf16x3',
-                              'configB_480p_r50_k256', 'configB_480p_r50_k256_bf16x3', 'configB_480p_r50_k256_tuned'])
+                              'configA_multi_object_f16x3', 'configB_480p_r50_k256', 'configB_480p_r50_k256_bf16x3',
+                              'configB_480p_r50_k256_f16x3', 'configB_480p_r50_k256_tuned'])
 def test_clip_vs_golden(lib, golden, name, kw, sub, mode):
     """Free-running clips against the reference's outputs (BASELINE configs[0] and configs[1]), the multi-object ones also
     with bf16x3 forced on every conv layer, config B also with the bench's committed plans (helpers.arith)."""
@@ -454,7 +455,7 @@ def test_persistent_pack_is_kept_across_frames(lib):
     assert len(calls) <= 2, calls
 
 
-@pytest.mark.parametrize('mode', ('fp32', 'bf16x3'))
+@pytest.mark.parametrize('mode', ('fp32', 'f16x3', 'bf16x3'))
 def test_ytvos_loop_and_tta_vs_golden(lib, golden, mode):
     """f1 rows: evaluate_ytvos_seq with an object that appears at frame 2 (exercises N_new > 0 in swem() and
     MemoryBank.add_new) and the multi-scale + flip TTA, against the reference's index maps."""

@@ -348,7 +348,11 @@ def test_space_to_depth_stem_equals_the_7x7_stem(lib, value):
     assert float((got3 - ref).abs().max()) < 3e-5 * scale
 
 
-def _split_of(t, M, C, relu):
+def _split_of(t, M, C, relu, npl=3):
+    if npl == ops.PLANES_F16:
+        sp = torch.empty((2, M * C), dtype=torch.float16, device=DEV)
+        __import__('swem_amd')._lib.call('swem_split_f16x2_f32', ops._stream(), t.data_ptr(), sp.data_ptr(), M, C, int(relu))
+        return sp
     sp = torch.empty((3, M * C), dtype=torch.bfloat16, device=DEV)
     __import__('swem_amd')._lib.call('swem_split_bf16x3_f32', ops._stream(), t.data_ptr(), sp.data_ptr(), M, C, int(relu))
     return sp
@@ -366,9 +370,10 @@ def _check_fused_planes(make, want, M, C):
         assert torch.equal(y1, y0)
         got = y1.__dict__['_swem_split']
         for relu, n in want.items():
-            assert got[relu][1] == n
-            assert torch.equal(got[relu][0][:n].view(torch.int16), _split_of(y0, M, C, relu)[:n].view(torch.int16))
-            assert ops.presplit(y1, relu, n) is got[relu][0]
+            key, rows = ops._pkey(relu, n), (2 if n == ops.PLANES_F16 else n)
+            assert got[key][1] == n
+            assert torch.equal(got[key][0][:rows].view(torch.int16), _split_of(y0, M, C, relu, n)[:rows].view(torch.int16))
+            assert ops.presplit(y1, relu, n) is got[key][0]
     finally:
         ops.SPLIT_HINTS.clear()
 
@@ -388,6 +393,7 @@ def test_conv2d_glu_fused_output_planes(lib, plan):
     srcs = [nhwc(a), nhwc(q), nhwc(s)]
     close(back(ops.conv2d(srcs, pack, batch=2, plan=plan)), ref, 2e-5, 'glu plan %#x' % plan)
     _check_fused_planes(lambda: ops.conv2d(srcs, pack, batch=2, plan=plan), {False: 3, True: 2}, 2 * 19 * 23, 96)
+    _check_fused_planes(lambda: ops.conv2d(srcs, pack, batch=2, plan=plan), {False: ops.PLANES_F16, True: 3}, 2 * 19 * 23, 96)
 
 
 def test_maxpool_and_cbam_fused_output_planes(lib):
@@ -395,6 +401,7 @@ def test_maxpool_and_cbam_fused_output_planes(lib):
     g = torch.Generator().manual_seed(6)
     x = nhwc(torch.randn(2, 72, 21, 37, generator=g))
     _check_fused_planes(lambda: ops.maxpool(x), {False: 2, True: 3}, 2 * 11 * 19, 72)
+    _check_fused_planes(lambda: ops.maxpool(x), {False: ops.PLANES_F16, True: ops.PLANES_F16}, 2 * 11 * 19, 72)
     B, Cc, H, W, hid = 2, 136, 15, 27, 16
     x = nhwc(torch.randn(B, Cc, H, W, generator=g))
     par = [t.to(DEV).contiguous() for t in (torch.randn(hid, Cc, generator=g) * 0.05, torch.randn(hid, generator=g) * 0.1,
@@ -402,6 +409,33 @@ def test_maxpool_and_cbam_fused_output_planes(lib):
                                             torch.randn(1, 2, 7, 7, generator=g) * 0.1, torch.randn(1, generator=g) * 0.1)]
     _check_fused_planes(lambda: ops.cbam_residual(x, *par), {True: 2}, B * H * W, Cc)
     _check_fused_planes(lambda: ops.cbam_residual(x, *par), {False: 3, True: 3}, B * H * W, Cc)
+    _check_fused_planes(lambda: ops.cbam_residual(x, *par), {False: ops.PLANES_F16}, B * H * W, Cc)
+
+
+@pytest.mark.parametrize('plan', [0x00011, 0x10022, 0x70011, 0x70022, 0x670022, 0x70221, 0x870022, 0x4070021, 0xa70211, 0x70012],
+                         ids=lambda p: '%#x' % p)
+def test_conv2d_fused_output_planes_f16(lib, plan):
+    """The fp16 (hi, mid) pair of a conv output from the conv's own epilogue (every kernel family, fused K-split, tail split,
+    residual + ReLU variants): bit-identical to swem_split_f16x2_f32 on y; mixed with a bf16 request for the other variant."""
+    g = torch.Generator().manual_seed(81)
+    B, Cin, H, W, Cout = 2, 160, 21, 37, 192
+    x = nhwc(torch.randn(B, Cin, H, W, generator=g) * 3)
+    res = nhwc(torch.randn(B, Cout, H, W, generator=g))
+    pack = ops.pack_conv((torch.randn(Cout, Cin, 3, 3, generator=g) * 0.03).to(DEV), (torch.randn(Cout, generator=g) * 0.1).to(DEV))
+    make = lambda: ops.conv2d([x], pack, relu_in=True, residual=res, plan=plan)
+    _check_fused_planes(make, {False: ops.PLANES_F16, True: ops.PLANES_F16}, B * H * W, Cout)
+    _check_fused_planes(make, {False: 3, True: ops.PLANES_F16}, B * H * W, Cout)
+    # a consumer of the other format does not find them: it splits for itself, into its own cache entry
+    ops.SPLIT_HINTS.clear()
+    y0 = make()
+    try:
+        ops.SPLIT_HINTS[y0._swem_site] = {False: ops.PLANES_F16}
+        y1 = make()
+        h = y1.__dict__['_swem_split'][ops._pkey(False, ops.PLANES_F16)][0]
+        b3 = ops.presplit(y1, False, 2)
+        assert b3.dtype == torch.bfloat16 and ops.presplit(y1, False, ops.PLANES_F16) is h and ops.presplit(y1, False, 3) is b3
+    finally:
+        ops.SPLIT_HINTS.clear()
 
 
 def test_conv2d_planes_only_output(lib):
@@ -516,6 +550,85 @@ def test_conv2d_bf16x3_mode(lib, plan):
     err6 = float((back(y6) - full).abs().max() / full.abs().max())
     print('plan %#x: bf16x3 error %.2e of the output range (bf16x6: %.2e)' % (plan, err, err6))
     assert err6 < 2e-6 < err < 2e-5, (err, err6)     # really the three-product mode, and within its error budget
+
+
+def _two_f16_terms(t, scale=None):
+    """hi + mid as the fp16 pair holds them (swem_split_f16x2_f32; filters: per output column scaled by a power of two)."""
+    s = 1.0 if scale is None else scale
+    ts = (t * s).float()
+    hi = ts.half().float()
+    return (hi + (ts - hi).half().float()) / s
+
+
+@pytest.mark.parametrize('plan', [0x70011, 0x70021, 0x70022, 0x170021, 0x270022, 0x470011, 0x470021, 0x670022, 0x70221, 0x870022,
+                                  0x970022, 0x4070021, 0xa70011, 0xb70021, 0xa70022, 0xc70022, 0xd70022, 0xe70022, 0xa70211,
+                                  0x570022, 0x770022, 0xf70022, 0x570222, 0x70012, 0x470012, 0x70212, 0x4070012],
+                         ids=lambda p: '%#x' % p)
+def test_conv2d_f16x3_mode(lib, plan):
+    """Math mode 7 ("f16x3", round 4): the bf16x3 kernel on fp16 (hi, mid) planes -- each operand carries 22-23 significant bits
+    and the product is hi.hi + hi.mid + mid.hi in fp32.  (1) It IS the convolution of those two-term operands (the dropped
+    mid.mid term is 2^-24 of a product).  (2) Against the float64 convolution of the fp32 operands its error is that of the
+    fp32 kernels -- measured beside the exact fp32 MFMA kernel and bf16x6 on the same inputs, and an order of magnitude below
+    bf16x3's."""
+    g = torch.Generator().manual_seed(79)
+    B, Cin, H, W, Cout = 2, 160, 21, 37, 192
+    x = torch.randn(B, Cin, H, W, generator=g) * 3
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.03
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(B, Cout, H, W, generator=g)
+    wscale = torch.exp2(13 - torch.floor(torch.log2(w.abs().amax(dim=(1, 2, 3), keepdim=True))))
+    x2, w2 = _two_f16_terms(F.relu(x)), _two_f16_terms(w, wscale)
+    ref2 = F.relu(F.conv2d(x2.double(), w2.double(), b.double(), padding=1) + res.double()).float()
+    full = F.relu(F.conv2d(F.relu(x).double(), w.double(), b.double(), padding=1) + res.double()).float()
+
+    def run(pl):
+        y = ops.conv2d([nhwc(x)], ops.pack_conv(w.to(DEV), b.to(DEV)), relu_in=True, relu_out=True, residual=nhwc(res), plan=pl)
+        return back(y), float((back(y) - full).abs().max() / full.abs().max())
+    y7, err7 = run(plan)
+    close(y7, ref2, 2e-6, 'f16x3 conv = conv of the two-term fp16 operands, plan %#x' % plan)
+    tile = plan & 0xffff if (plan & 0xff) != 0x12 else (plan & 0xff00) | 0x11     # (the 128x64 tile is a pre-split tile)
+    _, err32 = run(tile)
+    _, err6 = run((plan & ~0x70000) | 0x10000)
+    _, err3 = run((plan & ~0x70000) | 0x30000)
+    print('plan %#x: error against float64, of the output range: f16x3 %.2e, fp32 MFMA %.2e, bf16x6 %.2e, bf16x3 %.2e'
+          % (plan, err7, err32, err6, err3))
+    assert err7 < 1.5 * max(err32, err6) and err7 < 2e-6 and err3 > 3 * err7, (err7, err32, err6, err3)
+
+
+def test_f16x3_small_and_large_operands(lib):
+    """The fp16 pair across the range (include/swem_hip.h, swem_split_f16x2_f32).  Filters of any magnitude, columns decades
+    apart: scaled per output column, always full precision.  Activations: wherever most of a tensor's energy sits above 2^-2
+    (every conv operand of the bench configuration: rms 0.56-4.5, tools/act_ranges.py) the error against float64 is the fp32
+    kernel's; a tensor of TINY values degrades gracefully -- `mid` is subnormal, the absolute error per element is bounded by
+    2^-25, i.e. per output by 2^-25 * sum |w| -- and never overflows below 65520."""
+    g = torch.Generator().manual_seed(5)
+    B, Cin, H, W, Cout = 1, 64, 24, 40, 64
+    w0 = torch.randn(Cout, Cin, 3, 3, generator=g)
+    for xs, ws in ((1e-3, 1e-4), (0.02, 0.03), (0.5, 0.03), (1.0, 30.0), (2e3, 1e-2), (3e4, 1e-6)):
+        x = (torch.randn(B, Cin, H, W, generator=g).abs() * xs).clamp(max=6.0e4)
+        w = w0 * ws * torch.logspace(-3, 0, Cout).view(-1, 1, 1, 1)          # columns three decades apart
+        full = F.conv2d(x.double(), w.double(), None, padding=1)
+        col = full.abs().amax(dim=(0, 2, 3), keepdim=True)                   # per-column range: every filter on its own scale
+        errs = {}
+        for name, pl in (('f16x3', 0x70011), ('fp32', 0x11), ('bf16x3', 0x30011)):
+            y = back(ops.conv2d([nhwc(x)], ops.pack_conv(w.to(DEV)), plan=pl)).double()
+            assert torch.isfinite(y).all()
+            errs[name] = float(((y - full).abs() / col).max())
+        # the documented bound of the subnormal regime, per column, on that column's scale
+        sub = float((2.0 ** -25 * w.double().abs().sum(dim=(1, 2, 3)).view(1, -1, 1, 1) / col).max())
+        print('x ~ %.0e, w ~ %.0e: %s, subnormal-regime bound %.2e' % (xs, ws, errs, sub))
+        assert errs['f16x3'] < max(3 * errs['fp32'], 2e-6) + sub, (xs, ws, errs, sub)
+        if xs >= 0.5:
+            assert errs['f16x3'] < max(3 * errs['fp32'], 2e-6) and 3 * errs['f16x3'] < errs['bf16x3'], (xs, ws, errs)
+
+
+def test_f16x3_out_of_range_is_loud(lib):
+    """An activation beyond the fp16 range gives inf planes and a NaN / inf result -- never a finite wrong number."""
+    x = torch.ones(1, 32, 8, 8)
+    x[0, 3, 2, 2] = 1.0e5
+    w = torch.ones(32, 32, 1, 1) * 0.01
+    y = back(ops.conv2d([nhwc(x)], ops.pack_conv(w.to(DEV)), plan=0x70011))
+    assert not torch.isfinite(y[0, :, 2, 2]).any() and torch.isfinite(y[0, :, 0, 0]).all()
 
 
 @pytest.mark.parametrize('plan', [0x10010011, 0x20010011, 0x30010011, 0x10010021, 0x20010022, 0x30210022, 0x24010021, 0x20810022,

@@ -187,7 +187,7 @@ def test_teacher_forced_config_b_clip(lib, golden, mode):
 
 @pytest.mark.parametrize('n_obj,h,w,bases,topl', [(1, 96, 160, 64, 64), (5, 112, 176, 64, 32), (3, 80, 144, 128, 64)],
                          ids=['one_object', 'five_objects_topl32', 'three_objects_k128'])
-@pytest.mark.parametrize('mode', ('fp32', 'bf16x3'))
+@pytest.mark.parametrize('mode', ('fp32', 'f16x3', 'bf16x3'))
 def test_teacher_forced_edge_shapes(lib, n_obj, h, w, bases, topl, mode):
     """The edge cases of test_gpu_model.py::test_edge_shapes_free_running (one object; the reference's maximum of five
     with a top-l smaller than the bank; 1/16 grids that are no multiple of the pixel tile; an object with an EMPTY first

@@ -180,13 +180,15 @@ def test_shipped_plan_file_is_well_formed():
     tagged = {k: v for k, v in book.conv.items() if len(k) == 13}
     assert len(untagged) + len(tagged) == len(book.conv) and all(k[10:] == ('math', 0, 1) for k in tagged)
     for k, v in book.conv.items():
-        wm, wn, ns, math = v & 15, (v >> 4) & 15, (v >> 8) & 255, (v >> 16) & 3
+        wm, wn, ns, math = v & 15, (v >> 4) & 15, (v >> 8) & 255, (v >> 16) & 7
         assert wm in (1, 2) and wn in (1, 2) and 1 <= ns <= 255, (k, hex(v))
-        assert math in ((0, 1) if len(k) == 13 else (0, 1, 3)), (k, hex(v))
+        assert math in ((0, 1) if len(k) == 13 else (0, 1, 7)), (k, hex(v))     # (7 = f16x3: math 3 + SWEM_PLAN_F16)
         cin, cout, kh, kw, stride, pad, flags, B, H, W = k[:10]
         assert cin > 0 and cout % 4 == 0 and kh == kw and stride in (1, 2) and B in (1, 2, 4)
-    hist = book.math_histogram()
-    assert hist['bf16x3'] >= 50 and hist['bf16'] == 0          # the default leg: bf16x3 nearly everywhere, never plain bf16
+    hist, hist32 = book.math_histogram(), book.math_histogram(('math', 0, 1))
+    # the default leg: f16x3 nearly everywhere, never a 16-bit or 8-bit operand mode; the exact-split leg: fp32 MFMA / bf16x6
+    assert hist['f16x3'] >= 50 and hist['bf16'] == hist['bf16x3'] == 0 and sum(hist.values()) == len(untagged)
+    assert hist32['bf16x6'] + hist32['fp32'] == len(tagged)
     assert sum(1 for v in untagged.values() if (v >> 20) & 15 in (5, 7, 15)) <= 1
     assert isinstance(book.digest(), str) and len(book.digest()) == 12
 
@@ -253,7 +255,7 @@ def test_plan_book_scoping_roundtrip_and_flags(tmp_path):
             assert not ops.BOOK.conv and ops.BOOK is b
         assert ops.BOOK is a
     assert ops.BOOK is default and not default.conv and not b.conv
-    assert a.math_histogram() == {'fp32': 0, 'bf16x6': 0, 'bf16': 0, 'bf16x3': 1}
+    assert a.math_histogram() == {'fp32': 0, 'bf16x6': 0, 'bf16': 0, 'bf16x3': 1, 'f16x3': 0}
     path = str(tmp_path / 'plans.json')
     a.save(path)
     c = ops.PlanBook().load(path)
