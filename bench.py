@@ -340,6 +340,7 @@ def main():
         ops.spin_sync(sts)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        ops.check_faults()       # (outside the clock) a K-split / stream-K wait that expired inside the region raises here
         sdist.barrier()
         return sdist.reduce_counters(steps * len(rs), elapsed, device=dev)
 
@@ -366,11 +367,16 @@ def main():
             ', software-pipelined (previous frame\'s memorize under this frame\'s key encoder)' if pipe_ else '')
 
     out = None
+    # the key says which collective library the process group really runs on: 'rccl_ranks' only when torch's backend is nccl
+    # (= RCCL on ROCm); a gloo rehearsal on a smaller box reports 'gloo_ranks' (the old line said rccl_ranks = 2
+    # over gloo); a single process has no communicator at all
+    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
+    ranks_key = 'rccl_ranks' if backend == 'nccl' else ('%s_ranks' % backend if backend else 'ranks')
     if rank == 0:
         fps = total_frames / max_t
         out = {
             'metric': 'frames/sec (480p, K=256 bases, multi-object SWEM inference)', 'value': round(fps, 3),
-            'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': ranks, 'steps': args.steps, 'warmup': args.warmup,
+            'unit': 'frames/s', 'n_gpus': world, ranks_key: ranks, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * max_t / args.steps, 3), 'ms_per_frame': round(1e3 * max_t / total_frames * world, 3),
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,

@@ -159,8 +159,15 @@ int swem_conv2d_nhwc_bf16x3_planes(void *stream, const void *x0, int c0, long lo
                                    int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
                                    void *planes, int nplanes, void *planes_relu, int nplanes_relu);
 /* ... with caller-owned tile counters (round 3): `counters` (ncounters 32-bit words) must be ALL ZERO when the call is
- * enqueued and must not be used by another stream at the same time; the kernels leave it all zero.  The K-split (reduced by
- * the last split of every tile, no reduce launch) and stream-K forms then need no memset launch per call. */
+ * enqueued and must not be used by another stream at the same time; the kernels leave words [0, ncounters - 1) all zero.  The
+ * K-split (reduced by the last split of every tile, no reduce launch) and stream-K forms then need no memset launch per call.
+ * ASYNCHRONOUS FAULTS (round 4).  The return code of a call only covers what is known when it is enqueued.  The LAST word,
+ * counters[ncounters - 1], is a sticky fault word: a block whose bounded wait for another block's partial tile expires (a
+ * producer that was preempted or never dispatched: the reduced tile is then WRONG) ORs SWEM_FAULT_* into it, and nothing on
+ * the device clears it.  The caller reads it wherever it synchronises anyway (swem_amd.ops.check_faults); on a fault it must
+ * zero the whole buffer before the next call (a stale tile counter corrupts the next launch the same way). */
+#define SWEM_FAULT_KSPLIT_WAIT 1   /* the reducing split of a tile gave up waiting for the other splits' partial tiles */
+#define SWEM_FAULT_STREAMK_WAIT 2  /* a stream-K tile owner gave up waiting for a producer's partial tile */
 int swem_conv2d_nhwc_bf16x3_planes_ctr(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1,
                                    int c1, long long bs1, long long ps1, const void *x2, int c2, long long bs2,
                                    long long ps2, int B, int H, int W, const void *w_bf16x3, const float *scale,
@@ -306,9 +313,10 @@ int swem_memorize_f32(void *stream, const float *x, const float *v, const float 
  * (modules.py:295-306 `get_mem` concatenates the banks on every frame; here the caller owns one persistent pack):
  *   mkn [2N][C/4+1][2L][4] packed keys (see kp above) of both banks, rows [0,L) 'first', [L,2L) 'update'
  *   mvp [N][V][4L]        value bases, mvp[n][v][cls*2L + bank*L + l]
- *   mvq [N][2][4L/8][V][8] (optional, bf16) the same value bases pre-split for the readout GEMM: planes hi and mid
- *                         (x = hi + mid to 16 significant bits), k = cls*2L + bank*L + l in groups of 8 -- the filter layout
- *                         of swem_conv2d_nhwc_bf16x3.  NULL: not kept (the readout then runs from mvp).
+ *   mvq [N][2][4L/8][V][8] (optional, fp16) the same value bases pre-split for the readout GEMM: the fp16 pair hi, mid
+ *                         of swem_split_f16x2_f32 (x = hi + mid to 22-23 significant bits; round 3: bf16, 16 bits),
+ *                         k = cls*2L + bank*L + l in groups of 8 -- the filter layout of swem_conv2d_nhwc_bf16x3.
+ *                         NULL: not kept (the readout then runs from mvp).
  * prior_packed != 0: the prior's packed keys are READ from the pack's 'update' half (written there by the previous
  * frame's call: kappa_prev must be that frame's kappa_out); the new bases are WRITTEN to bank `bank` (0 'first', 1 'update'). */
 int swem_memorize_packed_f32(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
@@ -351,10 +359,10 @@ int swem_match_f32(void *stream, const float *qk, const float *kappa_first, cons
  * swem_match_pack_bank_f32 (re)builds one bank of a pack from the reference-layout bases (nbanks = 1: a pack of one bank;
  * mvq may be NULL).
  * Readout arithmetic (modules.py:272-273, mem_out = p . nu): readout_plan's math field 0 = fp32 matrix cores, 1 = bf16x6
- * (operands split in the kernel, fp32-level error), 3 = "bf16x3" on PRE-SPLIT planes -- the affinity kernel also writes
- * the probabilities as bf16 planes hi / mid, the filters are the pack's mvq (required for this mode; without it the call
- * falls back to the fp32 kernel), three bf16 products: ~2^-16 relative per product, the arithmetic of the convolutions that
- * consume mem_out. */
+ * (operands split in the kernel, fp32-level error), 3 (with or without SWEM_PLAN_F16) = the PRE-SPLIT readout in the f16x3
+ * arithmetic -- the affinity kernel also writes the probabilities, times 2^14, as the fp16 pair hi / mid (p <= 1: unscaled,
+ * most of a row would leave `mid` subnormal), the filters are the pack's mvq (required for this mode; without it the call
+ * falls back to the fp32 kernel), three f16 products, the epilogue multiplies by 2^-14: 1e-7 from the fp32 readout. */
 int swem_match_pack_bank_f32(void *stream, const float *kappa, const float *nu, float *mkn, float *mvp, void *mvq, int bank,
                              int nbanks, int N, int C, int V, int L);
 size_t swem_match_packed_workspace(int N, int C, int V, int P, int L, int readout_plan);

@@ -32,11 +32,15 @@ def new_step(prebuild=False):
             _PACKS[key] = _keyed(build(), key)
 
 
-def reset():
-    """Forget the recorded packs (a new trainer / model)."""
+def reset(book=None):
+    """Forget the recorded packs (a new trainer / model) and the fused-split hints of `book` (default: the current book) --
+    the hints of the training step are keyed by its packs' recipes, i.e. by parameter identity: a trainer passes ITS book
+    (SWEMTrainer.book), so that a model rebuilt at a recycled address never inherits a dead layer's hints."""
     _PACKS.clear()
     _RECIPES.clear()
-    ops.BOOK.hints.clear()
+    b = book if book is not None else ops.BOOK
+    b.hints.clear()
+    b.hint_epoch.clear()
 
 
 def ensure_grads(params):

@@ -14,11 +14,12 @@ int swem_norm_bases_into(void *stream, const float *kappa, float *kn, int NK, in
 // conv.hip: batched GEMM y[b] = x[b] . w[b]^T on pre-split bf16 planes (the pre-split convolution kernel as a 1x1 layer over
 // an M x 1 image per batch item): x = plane 0 of [K/8][B*M][8] planes `ps` elements apart (bs = M*K), w = plane 0 of batch
 // item 0's filter planes [K/8][Ncols][8], planes Ncols*K apart, batch items w_bs elements apart; M a multiple of 128.
-// plan / ws as swem_conv2d_nhwc_bf16x3 (math field 3 = two planes, 1 = three).  y_planes (may be NULL): y's own bf16 planes
-// [Ncols/8][B*M][8], y_nplanes (2 or 3) of them written, B*M*Ncols elements apart (Ncols % 8 == 0).
+// plan / ws as swem_conv2d_nhwc_bf16x3 (math field 3 = two planes, 1 = three; SWEM_PLAN_F16: x and w are fp16 pairs).
+// y_planes (may be NULL): y's own planes [Ncols/8][B*M][8], y_nplanes (2, 3 or SWEM_PLANES_F16) of them written, B*M*Ncols
+// elements apart (Ncols % 8 == 0).  out_scale multiplies every output (the caller's operand scaling, undone exactly).
 int swem_gemm_bf16x3_batched(void *stream, const void *x, int K, long long bs, long long ps, int B, int M, const void *w,
                              long long w_bs, float *y, int Ncols, int plan, void *ws, size_t ws_bytes, void *y_planes,
-                             int y_nplanes);
+                             int y_nplanes, float out_scale);
 // raise the dynamic-LDS limit of a kernel once (needed above 64 KiB)
 #define SWEM_ALLOW_LDS(kernel, bytes)                                                                   \
   do {                                                                                                  \

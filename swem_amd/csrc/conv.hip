@@ -39,6 +39,7 @@ struct ConvP {
   long long bs[3];
   int B, H, W, Ho, Wo, Cin, K, M;
   const float *w, *scale, *shift, *res;
+  float uscale;  // the scale of every output column where `scale` is NULL (1; matching's readout undoes its operand scaling here)
   long long res_bs, w_bs;  // w_bs: elements between the filter banks of consecutive batch items (0 = shared)
   const unsigned short *wsplit;  // optional [3][Ncols][K] bf16: the filters pre-split into hi/mid/lo planes
   const unsigned short *xs[3];   // pre-split activations (conv_igemm_bf3s_kernel): plane 0 of each source
@@ -67,6 +68,9 @@ struct ConvP {
   int sk_workers, sk_mtiles, sk_ntiles;
   float *sk_ws;         // one block tile of fp32 partial sums per worker
   unsigned *sk_flags;   // one word per worker, zero at launch: "my partial tile is in sk_ws"
+  int spin_limit;       // polls a block may spend waiting for another block's partial tile (2^24 ~ seconds; SWEM_SPIN_LIMIT)
+  unsigned *fault;      // optional sticky fault word (the last word of the caller's counter buffer): a bounded wait that expires
+                        // ORs SWEM_FAULT_* into it -- the tile is then wrong, and the host can know (never cleared on the device)
 };
 
 // One v_max_f32 per element.  fmaxf() costs two (hipcc first canonicalises the operand with v_max x,x), and in the fp32
@@ -262,7 +266,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][
       // through the wave's LDS slice and out in row layout like every other output (16-byte stores, bf16 planes)
       const int nf = ncol0 + r, na = ncol0 + 32 + r;
       const bool nin = na < p.Ncols;
-      const float scf = (nin && p.scale) ? p.scale[nf] : 1.f, sca = (nin && p.scale) ? p.scale[na] : 1.f;
+      const float scf = (nin && p.scale) ? p.scale[nf] : p.uscale, sca = (nin && p.scale) ? p.scale[na] : p.uscale;
       const float shf = (nin && p.shift) ? p.shift[nf] : 0.f, sha = (nin && p.shift) ? p.shift[na] : 0.f;
       __syncthreads();   // every wave is done with the operand stages
       unsigned *lds = planes_lds();
@@ -284,7 +288,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x16 (&acc)[WM][
   for (int jn = 0; jn < WN; ++jn) {
     const int n = ncol0 + 32 * jn + r;
     const bool nin = n < p.Ncols;
-    const float sc = (nin && p.scale) ? p.scale[n] : 1.f, sh = (nin && p.shift) ? p.shift[n] : 0.f;
+    const float sc = (nin && p.scale) ? p.scale[n] : p.uscale, sh = (nin && p.shift) ? p.shift[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -908,7 +912,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP &p, f32x4v (&acc)[TM
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int nf = ncol0 + 16 * j + col, na = nf + 32;
-        scf[j] = (nin && p.scale) ? p.scale[nf] : 1.f; sca[j] = (nin && p.scale) ? p.scale[na] : 1.f;
+        scf[j] = (nin && p.scale) ? p.scale[nf] : p.uscale; sca[j] = (nin && p.scale) ? p.scale[na] : p.uscale;
         shf[j] = (nin && p.shift) ? p.shift[nf] : 0.f; sha[j] = (nin && p.shift) ? p.shift[na] : 0.f;
       }
       __syncthreads();   // every wave is done with the operand stages
@@ -939,7 +943,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP &p, f32x4v (&acc)[TM
     for (int jj = 0; jj < 2; ++jj) {
       const int n = ncol0 + 16 * (j0 + jj) + col;
       const bool nin = n < p.Ncols;
-      sc[jj] = (nin && p.scale) ? p.scale[n] : 1.f;
+      sc[jj] = (nin && p.scale) ? p.scale[n] : p.uscale;
       sh[jj] = (nin && p.shift) ? p.shift[n] : 0.f;
     }
 #pragma unroll
@@ -1506,8 +1510,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
       if (sk_total * u / p.sk_workers >= tile_end) break;
       if (tid == 0) {
         int spins = 0;
-        while (__hip_atomic_load(p.sk_flags + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 24))
+        unsigned seen = __hip_atomic_load(p.sk_flags + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (seen == 0u && spins < p.spin_limit) {
           __builtin_amdgcn_s_sleep(16);
+          ++spins;
+          seen = __hip_atomic_load(p.sk_flags + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (seen == 0u && p.fault)   // the producer never arrived: what follows adds a tile that was not written
+          __hip_atomic_fetch_or(p.fault, (unsigned)SWEM_FAULT_STREAMK_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
       if (tid == 0) __hip_atomic_store(p.sk_flags + u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed once: leave it zero
@@ -1569,11 +1579,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
       fused_last = true;
       if (tid == 0) {
         // (a read-modify-write of zero: executed where the other splits' increments are, never served from a cache)
-        // (>= and a bounded spin: counters left non-zero by an aborted launch give a wrong tile, never a hung queue)
-        for (int spin = 0; spin < (1 << 24) &&
-                           __hip_atomic_fetch_add(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(nsp - 1);
-             ++spin)
+        // (>= and a bounded spin: a producer that is never dispatched -- XCDs advance their dispatch independently, so with
+        // other streams' grids in flight the "dispatched before me" order is not a guarantee -- or counters left
+        // non-zero by an aborted launch end in a wrong tile AND a set fault word, never in a hung queue)
+        int spin = 0;
+        unsigned seen = __hip_atomic_fetch_add(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (seen < (unsigned)(nsp - 1) && spin < p.spin_limit) {
           __builtin_amdgcn_s_sleep(8);
+          ++spin;
+          seen = __hip_atomic_fetch_add(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (seen < (unsigned)(nsp - 1) && p.fault)
+          __hip_atomic_fetch_or(p.fault, (unsigned)SWEM_FAULT_KSPLIT_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave it zero
       }
       __syncthreads();
@@ -1637,7 +1654,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
     return s;
   };
   auto affine4 = [&](float4 s, int col) {
-    float4 sc = p.scale ? *reinterpret_cast<const float4 *>(p.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 sc = p.scale ? *reinterpret_cast<const float4 *>(p.scale + col) : make_float4(p.uscale, p.uscale, p.uscale, p.uscale);
     float4 sh = p.shift ? *reinterpret_cast<const float4 *>(p.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     return make_float4(s.x * sc.x + sh.x, s.y * sc.y + sh.y, s.z * sc.z + sh.z, s.w * sc.w + sh.w);
   };
@@ -2034,7 +2051,7 @@ int conv2d_f32_impl(void *stream, const float *x0, int c0, long long bs0, const 
   const bool glu = flags & SWEM_CONV_GLU;
   SWEM_REQUIRE(!glu || (Cout % 32 == 0 && !res), SWEM_E_SHAPE, "conv2d: GLU needs Cout %% 32 == 0 and no residual");
   ConvP p;
-  p.sk_workers = 0; p.sk_mtiles = p.sk_ntiles = 0; p.sk_ws = nullptr; p.sk_flags = nullptr;
+  p.sk_workers = 0; p.sk_mtiles = p.sk_ntiles = 0; p.sk_ws = nullptr; p.sk_flags = nullptr; p.fault = nullptr; p.spin_limit = 1 << 24;
   p.x[0] = x0; p.x[1] = x1 ? x1 : x0; p.x[2] = x2 ? x2 : x0;
   p.c[0] = c0; p.c[1] = c1; p.c[2] = c2;
   p.bs[0] = bs0; p.bs[1] = bs1; p.bs[2] = bs2;
@@ -2049,7 +2066,7 @@ int conv2d_f32_impl(void *stream, const float *x0, int c0, long long bs0, const 
   long long M = (long long)B * p.Ho * p.Wo;
   SWEM_REQUIRE(M < (1ll << 31) && M * (glu ? 2 * Cout : Cout) < (1ll << 40), SWEM_E_SHAPE, "conv2d: too large");
   p.M = (int)M;
-  p.w = w; p.scale = scale; p.shift = shift; p.res = res; p.res_bs = res_bs; p.w_bs = w_bs; p.y = y;
+  p.w = w; p.scale = scale; p.uscale = 1.f; p.shift = shift; p.res = res; p.res_bs = res_bs; p.w_bs = w_bs; p.y = y;
   p.wsplit = nullptr;
   p.Cout = Cout; p.Ncols = glu ? 2 * Cout : Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.flags = flags;
@@ -2183,7 +2200,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
                        long long bs1, long long ps1, const void *x2, int c2, long long bs2, long long ps2, int B, int H, int W,
                        const void *w_bf16x3, const float *scale, const float *shift, const float *res, long long res_bs,
                        float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
-                       const PlaneOut *po, long long w_bs = 0);
+                       const PlaneOut *po, long long w_bs = 0, float uscale = 1.f);
 }
 extern "C" int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0, long long ps0,
                                        const void *x1, int c1, long long bs1, long long ps1, const void *x2, int c2,
@@ -2222,17 +2239,17 @@ extern "C" int swem_conv2d_nhwc_bf16x3_planes_ctr(void *stream, const void *x0, 
 // batched GEMM on pre-split planes (common.h): y[b] = x[b] . w[b]^T with per-batch filter planes, w_bs bf16 elements apart
 int swem_gemm_bf16x3_batched(void *stream, const void *x, int K, long long bs, long long ps, int B, int M, const void *w,
                              long long w_bs, float *y, int Ncols, int plan, void *ws, size_t ws_bytes, void *y_planes,
-                             int y_nplanes) {
+                             int y_nplanes, float out_scale) {
   PlaneOut po{{y_planes, nullptr}, {y_nplanes, 3}};
   return conv2d_bf16x3_impl(stream, x, K, bs, ps, nullptr, 0, 0, 0, nullptr, 0, 0, 0, B, M, 1, w, nullptr, nullptr, nullptr, 0, y,
-                            Ncols, 1, 1, 1, 0, 0, plan, ws, ws_bytes, y_planes ? &po : nullptr, w_bs);
+                            Ncols, 1, 1, 1, 0, 0, plan, ws, ws_bytes, y_planes ? &po : nullptr, w_bs, out_scale);
 }
 namespace {
 int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1, int c1,
                        long long bs1, long long ps1, const void *x2, int c2, long long bs2, long long ps2, int B, int H, int W,
                        const void *w_bf16x3, const float *scale, const float *shift, const float *res, long long res_bs,
                        float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
-                       const PlaneOut *po, long long w_bs) {
+                       const PlaneOut *po, long long w_bs, float uscale) {
   SWEM_REQUIRE(x0 && w_bf16x3 && (y || (po && (po->planes[0] || po->planes[1]))), SWEM_E_ARG,
                "conv2d_bf16x3: null pointer (y may be NULL only when output planes are given)");
   if (!x1) c1 = 0;
@@ -2247,7 +2264,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   const bool glu = flags & SWEM_CONV_GLU;
   SWEM_REQUIRE(!glu || (Cout % 32 == 0 && !res), SWEM_E_SHAPE, "conv2d_bf16x3: GLU needs Cout %% 32 == 0, no residual");
   ConvP p;
-  p.sk_workers = 0; p.sk_mtiles = p.sk_ntiles = 0; p.sk_ws = nullptr; p.sk_flags = nullptr;
+  p.sk_workers = 0; p.sk_mtiles = p.sk_ntiles = 0; p.sk_ws = nullptr; p.sk_flags = nullptr; p.fault = nullptr; p.spin_limit = 1 << 24;
   p.x[0] = p.x[1] = p.x[2] = nullptr;
   p.xs[0] = static_cast<const unsigned short *>(x0);
   p.xs[1] = static_cast<const unsigned short *>(x1 ? x1 : x0);
@@ -2272,7 +2289,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   SWEM_REQUIRE(M < (1ll << 31), SWEM_E_SHAPE, "conv2d_bf16x3: too large");
   p.M = (int)M;
   p.w = nullptr; p.wsplit = static_cast<const unsigned short *>(w_bf16x3);
-  p.scale = scale; p.shift = shift; p.res = res; p.res_bs = res_bs; p.w_bs = w_bs; p.y = y;
+  p.scale = scale; p.uscale = uscale; p.shift = shift; p.res = res; p.res_bs = res_bs; p.w_bs = w_bs; p.y = y;
   p.Cout = Cout; p.Ncols = glu ? 2 * Cout : Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.flags = flags;
   p.nkb = cdiv(p.K, BK);
@@ -2285,6 +2302,18 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   p.partial = nullptr;
   p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.f16 = 0; p.xpn = 1;
   if (int prc = set_planes(p, po, glu, "conv2d_bf16x3")) return prc;
+  // caller-owned counters: words [0, n - 1) are tile counters / stream-K flags, word n - 1 is the sticky fault word
+  const size_t nctr = (po && po->counters && po->ncounters >= 2) ? po->ncounters - 1 : 0;
+  if (nctr) p.fault = po->counters + nctr;
+  {
+    static int limit = -1;   // (tests shorten the wait to see the fault path: tests/test_gpu_ops.py)
+    if (limit < 0) {
+      const char *e = getenv("SWEM_SPIN_LIMIT");
+      limit = e ? atoi(e) : (1 << 24);
+      if (limit < 0) limit = 0;
+    }
+    p.spin_limit = limit;
+  }
   if (pl.nsplit > 1) {
     size_t need = (size_t)pl.nsplit * M * p.Ncols * sizeof(float);
     SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_bf16x3: workspace %zu < %zu bytes", ws_bytes, need);
@@ -2353,7 +2382,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
       p.partial = nullptr;
       p.sk_workers = (int)W; p.sk_mtiles = mtiles; p.sk_ntiles = ntiles;
       p.sk_ws = static_cast<float *>(ws);
-      if (po && po->counters && po->ncounters >= (size_t)W) {
+      if (nctr >= (size_t)W) {
         p.sk_flags = po->counters;     // zero on entry, reset by the workers that consume them: no memset launch
       } else {
         p.sk_flags = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + (size_t)W * tile);
@@ -2394,7 +2423,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
     const size_t need = (size_t)pl.nsplit * ntile * tile + ntile * sizeof(unsigned);
     SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_bf16x3: workspace %zu < %zu bytes (fused K-split)", ws_bytes, need);
     p.partial = static_cast<float *>(ws);
-    if (po && po->counters && po->ncounters >= ntile) {
+    if (nctr >= ntile) {
       p.sk_flags = po->counters;       // zero on entry; the reducing split of a tile resets its counter: no memset launch
     } else {
       p.sk_flags = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + (size_t)pl.nsplit * ntile * tile);

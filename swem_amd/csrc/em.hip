@@ -279,7 +279,7 @@ struct MStepP {
   float *kappa_out, *nu_out, *zita_out;
   float *kp_out;   // optional: the new key bases packed [NK][C/4][kp_rows][4] at row offset kp_off (what E/W / affinity read)
   float *mvp_out;  // optional: value bases packed for matching, mvp[n][v][cls*mvp_lm + mvp_off + l]
-  unsigned short *mvq_out;  // optional: the same as two bf16 planes (hi, mid) per object, [n][2][2*mvp_lm/8][V][8]
+  unsigned short *mvq_out;  // optional: the same as the fp16 pair (hi, mid: bf16_split.h, split2h) per object, [n][2][2*mvp_lm/8][V][8]
   int kp_rows, kp_off, mvp_lm, mvp_off;
   int Ck, C, V, P, Pz, L, NK, nrt, total;  // nrt = 32-row tiles of the row space, total = NK * (L/16) * nrt blocks
   int rpg;                                 // row tiles per group of the tile order (a divisor of nrt)
@@ -451,9 +451,9 @@ __global__ __launch_bounds__(512, WPE) void em_mstep_kernel(MStepP p STAMP_ARG) 
                                vt[(8 * grp + 3) * 33 + vr]);
         float4 b = make_float4(vt[(8 * grp + 4) * 33 + vr], vt[(8 * grp + 5) * 33 + vr], vt[(8 * grp + 6) * 33 + vr],
                                vt[(8 * grp + 7) * 33 + vr]);
-        uint2 h0, m0, lo0, h1, m1, lo1;
-        split3(a, h0, m0, lo0);
-        split3(b, h1, m1, lo1);
+        uint2 h0, m0, h1, m1;
+        split2h(a, h0, m0);
+        split2h(b, h1, m1);
         const int kg = (cls * p.mvp_lm + p.mvp_off + l0) / 8 + grp, ngrp = 2 * p.mvp_lm / 8;
         unsigned short *base = p.mvq_out + (long long)n * 2 * ngrp * p.V * 8;
         *reinterpret_cast<uint4 *>(base + ((long long)kg * p.V + col + vr) * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);

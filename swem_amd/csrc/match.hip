@@ -37,7 +37,8 @@ __global__ void pack_values_kernel(const float *__restrict__ nu, float *__restri
   *reinterpret_cast<float4 *>(mvp + ((long long)n * V + v) * (2 * Lm) + cls * Lm + off + l4 * 4) = val;
 }
 
-// the readout GEMM's pre-split filters: mvq[n][plane][(cls*Lm + off + l)/8][v][l%8] = bf16 hi / mid of nu[n][cls][v][l]
+constexpr float MATCH_P_SCALE = 16384.f;   // the readout's probability planes hold p * 2^14 (see match_core)
+// the readout GEMM's pre-split filters: mvq[n][plane][(cls*Lm + off + l)/8][v][l%8] = fp16 hi / mid of nu[n][cls][v][l]
 __global__ void pack_value_planes_kernel(const float *__restrict__ nu, unsigned short *__restrict__ mvq, int N, int V, int L,
                                          int Lm, int off) {
   const int l8n = L / 8;
@@ -49,9 +50,9 @@ __global__ void pack_value_planes_kernel(const float *__restrict__ nu, unsigned 
   t /= l8n;
   const int cls = (int)(t & 1), n = (int)(t >> 1);
   const float *src = nu + (((long long)n * 2 + cls) * V + v) * L + l8 * 8;
-  uint2 h0, m0, lo0, h1, m1, lo1;
-  split3(ld4(src), h0, m0, lo0);
-  split3(ld4(src + 4), h1, m1, lo1);
+  uint2 h0, m0, h1, m1;
+  split2h(ld4(src), h0, m0);
+  split2h(ld4(src + 4), h1, m1);
   const int ngrp = 2 * Lm / 8, kg = (cls * Lm + off) / 8 + l8;
   unsigned short *base = mvq + (long long)n * 2 * ngrp * V * 8;
   *reinterpret_cast<uint4 *>(base + ((long long)kg * V + v) * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__re
     }
   }
   if (pq) {
-    // the same probabilities as the readout GEMM's pre-split operand: bf16 planes hi / mid, [plane][Ltot/8][N*Pm][8]
+    // the same probabilities (times 2^14) as the readout GEMM's pre-split operand: fp16 planes hi / mid, [plane][Ltot/8][N*Pm][8]
     // (conv.hip's activation layout).  The lane's four bases are half of an 8-channel group: 8 bytes per plane and tile,
     // the 16 pixels x 2 halves of a group one contiguous 256-byte run.
     const long long npix = (long long)gridDim.y * Pm, gp = (long long)n * Pm + p;
@@ -352,8 +353,8 @@ __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__re
     const long long plane = npix * Ltot;
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
-      uint2 h, m, lo;
-      split3(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), h, m, lo);
+      uint2 h, m;
+      split2h(make_float4(acc[t][0] * MATCH_P_SCALE, acc[t][1] * MATCH_P_SCALE, acc[t][2] * MATCH_P_SCALE, acc[t][3] * MATCH_P_SCALE), h, m);
       *reinterpret_cast<uint2 *>(d0 + (long long)2 * t * npix * 8) = h;
       *reinterpret_cast<uint2 *>(d0 + plane + (long long)2 * t * npix * 8) = m;
     }
@@ -644,11 +645,14 @@ int match_core(void *stream, const float *qk, const float *mkn, const float *mvp
   }
   // value readout (modules.py:272-273) = batched GEMM  mem_out[n] = pT[n] . mvp[n]^T  on the conv kernel:
   // "image" of Pm x 1 pixels with Ltot channels, 1x1 filters = the V value rows of object n (w_bs = V*Ltot)
-  // (the pack's value planes and the probability planes above are bf16: SWEM_PLAN_F16 does not apply to the readout)
+  // The pre-split readout runs the f16x3 arithmetic whatever the plan's math field says beyond "pre-split" (round 4): the
+  // pack's value planes are fp16 pairs (em.hip, pack_value_planes_kernel) and the affinity kernel wrote the probabilities as
+  // the fp16 pair of p * 2^14 (p <= 1: most of a row is far below 2^-2, where an unscaled `mid` would be subnormal); the
+  // epilogue multiplies by 2^-14 (exact).  1e-7 from the fp32 readout, where the bf16 (hi, mid) planes of round 3 gave 3e-6.
   if (presplit)
     return swem_gemm_bf16x3_batched(stream, pq, Ltot, (long long)Pm * Ltot, (long long)N * Pm * Ltot, N, Pm, mvq,
-                                    (long long)2 * V * Ltot, mem_out, V, readout_plan & ~SWEM_PLAN_F16, conv_ws, conv_bytes,
-                                    mem_planes, mem_npl);
+                                    (long long)2 * V * Ltot, mem_out, V, (readout_plan & ~(3 << 16)) | (3 << 16) | SWEM_PLAN_F16,
+                                    conv_ws, conv_bytes, mem_planes, mem_npl, 1.f / MATCH_P_SCALE);
   return swem_conv2d_nhwc_f32(stream, pT, Ltot, (long long)Pm * Ltot, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, mvp,
                               (long long)V * Ltot, nullptr, nullptr, nullptr, 0, mem_out, V, 1, 1, 1, 0, 0,
                               readout_plan, conv_ws, conv_bytes);

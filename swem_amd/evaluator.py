@@ -60,6 +60,9 @@ def evaluate_davis_seq(model, frames, init_masks, out_size, trace=None):
             mv16 = model('encode_value', frames[:, i], pm, s16)
             model('memorize', qk16, mv16, hard_pred_mask, pm)
         preds.append(pred)
+    # the sequence boundary is where the host waits anyway (basic_evaluator.py:171-176 synchronises around every sequence):
+    # asynchronous faults of the sequence's launches surface here, not as a silently wrong mask
+    ops.check_faults()
     return preds, pred_scores
 
 
@@ -87,6 +90,7 @@ def evaluate_ytvos_seq(model, frames, init_masks, out_size):
             mv16 = model('encode_value', frames[:, i], pm, s16)
             model('memorize', qk16, mv16, hard_pred_mask, pm)
         preds.append(pred)
+    ops.check_faults()
     return preds
 
 
@@ -694,4 +698,5 @@ class SequencePool:
                             lanes[li] = None
         for st in self.streams:
             main.wait_stream(st)
+        ops.check_faults()       # (synchronises: the results are about to be read)
         return results

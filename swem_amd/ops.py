@@ -108,7 +108,9 @@ class PlanBook:
         self._gen[0] += 1
 
     def epoch(self):
-        return (self._gen[0], _MODE_GEN[0])
+        # (AUTOTUNE is part of it: with the tuner on, a consumer whose plan is still 0 times fp32 candidates on its source --
+        # a producer that skipped the fp32 map for it under the tuner-off heuristic must write it again)
+        return (self._gen[0], _MODE_GEN[0], bool(AUTOTUNE))
 
     def clear(self):
         self.conv.clear()
@@ -346,7 +348,10 @@ def workspace(nbytes, device):
 
 _ctr = {}
 _ctr_capture = {}
+_ctr_all = []            # weak references to every counter buffer handed out (check_faults reads their fault words)
 N_COUNTERS = 16384
+FAULT_BITS = {1: 'a K-split reducer gave up waiting for the other splits\' partial tiles',
+              2: 'a stream-K tile owner gave up waiting for a producer\'s partial tile'}
 
 
 def counters(device):
@@ -354,7 +359,11 @@ def counters(device):
     swem_conv2d_nhwc_bf16x3_planes_ctr): a zero-initialised buffer per (device, stream) that the kernels leave all zero, so no
     memset launch precedes each of them.  Inside a graph capture the buffer belongs to that capture (like `workspace`): graphs
     captured on one stream may be replayed on different streams at the same time and must not share counters; its zero fill is
-    one node at the head of the graph, replayed with it."""
+    one node at the head of the graph, replayed with it.
+    The LAST word of the buffer is the launches' sticky FAULT word: a kernel whose bounded wait for another block's partial
+    tile expires (a preempted or never-dispatched producer: the output tile is then wrong) ORs a bit into it and nothing on
+    the device ever clears it -- `check_faults` reads it on the host and raises."""
+    import weakref
     dev = device.index if device.index is not None else torch.cuda.current_device()
     st = torch.cuda.current_stream().cuda_stream
     cid = _capture_id(st)
@@ -367,7 +376,30 @@ def counters(device):
     buf = cache.get(key)
     if buf is None:
         buf = cache[key] = torch.zeros(N_COUNTERS, dtype=torch.int32, device=device)
+        _ctr_all[:] = [r for r in _ctr_all if r() is not None]
+        _ctr_all.append(weakref.ref(buf))
     return buf
+
+
+def check_faults():
+    """Asynchronous faults of the launches made so far (the C ABI's return codes only cover what is known at enqueue time):
+    reads the fault word of every counter buffer -- one small device-to-host copy, i.e. a synchronisation: call it where the
+    host waits anyway (the evaluator does at the end of every sequence, bench.py behind its timed regions).  On a fault every
+    counter buffer is zeroed (a stale tile counter would corrupt the next launch the same way) and SwemHipError is raised."""
+    bufs = [b for b in (r() for r in _ctr_all) if b is not None]
+    if not bufs:
+        return
+    words = [int(v) for v in torch.stack([b[-1] for b in bufs]).tolist()]
+    if any(words):
+        for b in bufs:
+            b.zero_()
+        torch.cuda.synchronize()
+        bits = 0
+        for w in words:
+            bits |= w
+        what = '; '.join(t for b, t in FAULT_BITS.items() if bits & b) or 'unknown fault bits %#x' % bits
+        raise _lib.SwemHipError('asynchronous fault in a convolution launch: %s -- the affected output tiles are wrong; the '
+                                'counters have been reset, re-run the sequence' % what)
 
 
 class ConvPack:
@@ -463,6 +495,8 @@ def pack_glu(wf, bf, wa, ba):
 def _chk_src(t):
     """A conv source: fp32 device tensor (B,H,W,C) whose images are contiguous; the batch stride is free
     (match's mem_out keeps a row pitch per object)."""
+    if t.__dict__.get('_swem_planes_only'):
+        return t                           # (no fp32 map behind it: only its planes are read, conv2d checks that)
     if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t[0].is_contiguous()):
         raise _lib.SwemHipError('conv input must be an fp32 device tensor (B,H,W,C) with contiguous images')
     return t
@@ -540,7 +574,7 @@ def batch_item(t, j):
     v = t[j:j + 1]
     d = t.__dict__
     sp = d.get('_swem_split')
-    if sp and d.get('_swem_split_ver', t._version) == t._version and t.is_contiguous():
+    if sp and d.get('_swem_split_ver', t._version) == t._version and (t.is_contiguous() or d.get('_swem_planes_only')):
         off = j * t.shape[1] * t.shape[2] * 8
         v.__dict__['_swem_split'] = {relu: (planes[:, off:], npl) for relu, (planes, npl) in sp.items()}
         v.__dict__['_swem_split_ver'] = v._version
@@ -552,6 +586,17 @@ def batch_item(t, j):
 
 
 DGRAD, DGRAD_EH, DGRAD_EW, MASK_POS = 8, 16, 32, 64
+_NAN = {}
+
+
+def _nan_cell(device):
+    """One NaN per device, made once outside any graph capture (a fill inside a capture would be a node of that graph and live
+    in its pool); None while the first request falls into a capture -- the caller then allocates an ordinary tensor."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    t = _NAN.get(dev)
+    if t is None and not torch.cuda.is_current_stream_capturing():
+        t = _NAN[dev] = torch.full((1,), float('nan'), dtype=torch.float32, device=device)
+    return t
 
 
 def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadcast=False, batch=None, out=None,
@@ -574,6 +619,8 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         if s.shape[1] != H or s.shape[2] != W:
             raise _lib.SwemHipError('conv2d: sources differ in spatial size')
         bs = 0 if (s.shape[0] == 1 and B > 1) else (s.stride(0) if s.shape[0] > 1 else H * W * s.shape[3])
+        if s.__dict__.get('_swem_planes_only') and s.shape[0] > 1:
+            bs = H * W * s.shape[3]        # (the stand-in tensor of a planes-only output has no strides of its own)
         args += [s.data_ptr(), s.shape[3], bs]
         cin += s.shape[3]
     for _ in range(3 - len(srcs)):
@@ -594,7 +641,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         if residual is not None:
             raise _lib.SwemHipError('conv2d: mask and residual share the res operand')
         residual, flags = mask, flags | MASK_POS
-    y = out if out is not None else torch.empty((B, Ho, Wo, pack.cout), dtype=torch.float32, device=x0.device)
+    y = out
     res_bs = 0
     if residual is not None:
         _chk(residual, 'conv residual')
@@ -609,6 +656,12 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     want = BOOK.hints.get(site) if (FUSE_SPLIT and dgrad is None and pack.cout % 8 == 0) else None
     planes = {}
     skip_y = bool(planes_only and want and out is None and PLANES_ONLY and BOOK.hint_epoch.get(site) == BOOK.epoch())
+    if y is None:
+        # a planes-only output has no fp32 map at all: the tensor that carries its planes is one NaN expanded to the shape
+        # (no allocation of the map; anything that reads it by accident sees NaN, _chk / _chk_src refuse it by its flag)
+        nan1 = _nan_cell(x0.device) if skip_y else None
+        y = (nan1.expand(B, Ho, Wo, pack.cout) if nan1 is not None
+             else torch.empty((B, Ho, Wo, pack.cout), dtype=torch.float32, device=x0.device))
     y_ptr = 0 if skip_y else y.data_ptr()
 
     def launch(plan, fresh=False):
@@ -1208,8 +1261,8 @@ def _match_plan(key, launch, M, V, nkb):
     if plan == 0 and len(_PLAN_TAG) == 2 and not AUTOTUNE:
         plan = _PLAN_TAG[1] << 16
     if AUTOTUNE and plan == 0 and not torch.cuda.is_current_stream_capturing():
-        # (the value planes of a pack and the probability planes of the affinity kernel are bf16: where the convolutions may
-        # run f16x3 the readout is offered bf16x3)
+        # (the pre-split readout has ONE arithmetic, f16x3 on the pack's fp16 value planes: math field 3 selects it whatever
+        # two-plane mode the convolutions run)
         modes = tuple(dict.fromkeys(3 if m == 7 else m for m in CONV_MATH_MODES))
         plan = BOOK.match[key + _PLAN_TAG] = _autotune(launch, M, V, nkb, False, modes=modes)
     return plan & ~(1 << 18)
@@ -1245,18 +1298,18 @@ def match(qk, kappa_first, nu_first, kappa_update, nu_update, topl, tau):
 
 def new_pack(N, Cc, V, L, device):
     """Matching's persistent packed banks for N objects (include/swem_hip.h, swem_memorize_packed_f32): packed keys,
-    packed values, and the values again as bf16 planes (hi, mid) for the pre-split readout GEMM."""
+    packed values, and the values again as the fp16 pair (hi, mid) for the pre-split readout GEMM (f16x3 arithmetic)."""
     return (torch.zeros((2 * N, Cc // 4 + 1, 2 * L, 4), dtype=torch.float32, device=device),
             torch.zeros((N, V, 4 * L), dtype=torch.float32, device=device),
-            torch.zeros((N, 2, 4 * L // 8, V, 8), dtype=torch.bfloat16, device=device))
+            torch.zeros((N, 2, 4 * L // 8, V, 8), dtype=torch.float16, device=device))
 
 
 def _pack_planes(pack):
     if len(pack) < 3 or pack[2] is None:
         return None
     q = pack[2]
-    if not (q.is_cuda and q.dtype == torch.bfloat16 and q.is_contiguous()):
-        raise _lib.SwemHipError('the value planes of a pack must be a contiguous bf16 device tensor')
+    if not (q.is_cuda and q.dtype == torch.float16 and q.is_contiguous()):
+        raise _lib.SwemHipError('the value planes of a pack must be a contiguous fp16 device tensor')
     return q.data_ptr()
 
 

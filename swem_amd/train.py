@@ -181,10 +181,10 @@ class SWEMTrainer:
         for mod in model.modules():                    # BasicTrainer.set_bn_eval (swem_trainer.py:37-39)
             if mod.__class__.__name__.find('BatchNorm') != -1:
                 mod.eval()
-        A.reset()
         # what the step learns about its launches (tuned conv plans, fused-split hints) is the trainer's own: the model's
         # inference book (validation between steps) and other trainers in the process never see it
         self.book = ops.PlanBook()
+        A.reset(self.book)
         self.optimizer = optim.make_optimizer(_get(config, 'SOLVER'), model, num_gpu)
         # DistributedDataParallel's constructor broadcasts rank 0's parameters AND buffers (swem_trainer.py:41-43;
         # broadcast_buffers=False only stops the per-iteration re-broadcast): without it rank-local initialisation

@@ -697,5 +697,6 @@ def test_bench_gpus_2_starts_two_ranks_by_itself(lib):
                          text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
-    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['scaling'] == 'weak'
+    # (the communicator of this rehearsal is gloo: the line must say so, and must NOT claim RCCL ranks)
+    assert line['n_gpus'] == 2 and line['gloo_ranks'] == 2 and 'rccl_ranks' not in line and line['scaling'] == 'weak'
     assert line['config']['frames_per_step'] == 1 and line['value'] > 0

@@ -462,6 +462,8 @@ def test_conv2d_planes_only_output(lib):
         assert y_b.__dict__.get('_swem_planes_only') and torch.equal(z_b, z_ref) and torch.equal(z_a, z_ref)
         assert torch.equal(y_b.__dict__['_swem_split'][False][0][:2].view(torch.int16),
                            y_a.__dict__['_swem_split'][False][0][:2].view(torch.int16))
+        # no fp32 map exists behind it: the tensor is ONE NaN expanded to the shape (nothing allocated, nothing uninitialised)
+        assert not y_b.is_contiguous() and y_b.untyped_storage().nbytes() == 4 and bool(torch.isnan(y_b).all())
         with pytest.raises(_lib.SwemHipError):
             ops.maxpool(y_b)                        # an fp32 consumer: loud
         with pytest.raises(_lib.SwemHipError):
@@ -476,6 +478,13 @@ def test_conv2d_planes_only_output(lib):
         with ops.conv_math((3,)):                   # a mode change withdraws the promise too, for one frame
             y_e, _ = chain(True)
             assert not y_e.__dict__.get('_swem_planes_only')
+        chain(True)
+        assert chain(True)[0].__dict__.get('_swem_planes_only')
+        try:                                        # ... and so does switching the tuner on (its candidates read the fp32 map)
+            ops.AUTOTUNE = True
+            assert not chain(True)[0].__dict__.get('_swem_planes_only')
+        finally:
+            ops.AUTOTUNE = False
         book.fallback = 0x00011                     # the consumer on the fp32 kernels: it never asks, the map is always written
         for _ in range(3):
             y_f, z_f = chain(True)
@@ -692,3 +701,49 @@ def test_conv2d_stream_k(lib, shape, plan):
     assert err < 1e-5, err
     ref = F.relu(F.conv2d(F.relu(x), w, b, padding=k // 2))
     close(back(y), ref, 2e-5, 'stream-K conv')
+
+
+def test_async_fault_word_reaches_the_host(lib):
+    """A K-split reducer whose bounded wait for the other splits' partial tiles expires sets the sticky fault word of the
+    caller's counter buffer (include/swem_hip.h, SWEM_FAULT_KSPLIT_WAIT) instead of silently reducing tiles that were never
+    written; ops.check_faults() raises on the host, zeroes the counters, and the next launch is clean.  The wait is shortened
+    to zero polls through SWEM_SPIN_LIMIT in a child process (the library reads it once): with every reducer arriving
+    together with its producers, some tile of a 4-way split always finds its partials missing."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    code = '''
+import torch
+from swem_amd import ops, _lib
+g = torch.Generator().manual_seed(1)
+x = torch.randn(2, 30, 54, 512, generator=g).cuda()
+pack = ops.pack_conv((torch.randn(512, 512, 3, 3, generator=g) * 0.02).cuda())
+ref = ops.conv2d([x], pack, plan=0x30122)                     # no K-split: no waiting
+ops.check_faults()
+y = ops.conv2d([x], pack, plan=0x30422)                       # four splits, the last one reduces
+torch.cuda.synchronize()
+ctr = ops.counters(x.device)
+word = int(ctr[-1])
+try:
+    ops.check_faults()
+    raised = False
+except _lib.SwemHipError as e:
+    raised = 'K-split' in str(e)
+print('FAULT_WORD', word, 'RAISED', raised, 'ZEROED', int(ctr.abs().sum()) == 0)
+ops.check_faults()                                            # reset: clean again
+'''
+    env = dict(os.environ, SWEM_SPIN_LIMIT='0', PYTHONPATH=root)
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('FAULT_WORD')][-1].split()
+    assert int(line[1]) & 1 and line[3] == 'True' and line[5] == 'True', out.stdout
+    # the same launches with the default wait: no fault, K-split result = unsplit result up to the summation order
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 30, 54, 512, generator=g).to(DEV)
+    pack = ops.pack_conv((torch.randn(512, 512, 3, 3, generator=g) * 0.02).to(DEV))
+    ref = ops.conv2d([x], pack, plan=0x30122)
+    y = ops.conv2d([x], pack, plan=0x30422)
+    ops.check_faults()
+    assert int(ops.counters(x.device).abs().sum()) == 0
+    close(y.cpu(), ref.cpu(), 1e-5, 'fused K-split')
