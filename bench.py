@@ -229,6 +229,8 @@ def main():
     ap.add_argument('--trace-layers', default=None, help='write the per-launch conv list of the eager roofline frames (JSON)')
     ap.add_argument('--cpu-frames', type=int, default=20, help='timed frames of the CPU baseline (after 2 warm-up frames)')
     ap.add_argument('--max-split', type=int, default=0, help='cap the K-split factors the conv tuner may choose (0 = all)')
+    ap.add_argument('--object-legs', type=int, nargs='*', default=[1, 3],
+                    help='extra single-sequence legs at these object counts, both arithmetics (default 1 3; empty: none)')
     args = ap.parse_args()
 
     from swem_amd import dist as sdist
@@ -268,7 +270,8 @@ def main():
     n_obj = args.objects
     nseq = max(1, args.seqs)
     from swem_amd import evaluator
-    book = ops.PlanBook()            # ONE book for every model of this process: tuned on the first sequence, read by all
+    # ONE book for every model of this process: tuned on the first sequence, read by all (untuned shapes: a model's default)
+    book = ops.PlanBook(fallback=ops.MODEL_FALLBACK)
     plans_src = None
     if args.load_plans:
         book.load(args.load_plans)
@@ -286,7 +289,7 @@ def main():
     tune = not args.no_autotune and not args.load_plans   # per-layer plan chosen by timing, during warm-up only (missing shapes)
     sd_box, clip_box = [None], {}
 
-    def make_runners(n, pipelined, seed_base, tune=tune):
+    def make_runners(n, pipelined, seed_base, tune=tune, n_obj=n_obj):
         """n independent sequences, each its own model (memory banks) on its own probed stream, warmed up (the first one
         tunes the plans of the current conv_math mode into `book`) and captured into its frame graph."""
         rs, sts = [], []
@@ -300,9 +303,9 @@ def main():
             model = model.eval().to(dev)
             model.book = book
             seed = 123 + rank * 16 + si
-            if seed not in clip_box:
-                clip_box[seed] = synth.make_clip(t=8, h=H, w=W, n_obj=n_obj, out_hw=OUT_HW, seed=seed)
-            frames_cpu, m0_cpu = clip_box[seed]
+            if (seed, n_obj) not in clip_box:
+                clip_box[(seed, n_obj)] = synth.make_clip(t=8, h=H, w=W, n_obj=n_obj, out_hw=OUT_HW, seed=seed)
+            frames_cpu, m0_cpu = clip_box[(seed, n_obj)]
             st = seq_streams[si]
             with torch.cuda.stream(st):
                 torch.manual_seed(seed_base + rank * 16 + si)
@@ -347,7 +350,7 @@ def main():
     pipelined = args.pipeline == 'on' or (args.pipeline == 'auto' and nseq == 1)
     runners, streams = make_runners(nseq, pipelined, 1234)
     runner = runners[0]
-    frames_cpu, m0_cpu = clip_box[123 + rank * 16]
+    frames_cpu, m0_cpu = clip_box[(123 + rank * 16, n_obj)]
     sd = sd_box[0]
     if args.save_plans and rank == 0:
         book.save(args.save_plans)
@@ -404,38 +407,9 @@ def main():
                       'math_modes_allowed': list(ops.CONV_MATH_MODES)},
         }
 
-    # ---------------- the same workload in the reference's own FPS semantics (one sequence at a time,
-    # basic_evaluator.py:171-176) and at fp32-level conv arithmetic (fp32 MFMA / bf16x6 only), same steps, same clock
-    if not args.no_legs and world == 1:
-        if nseq != 1 and not args.no_graph:
-            r1, s1 = make_runners(1, args.pipeline != 'off', 2234)
-            f1, t1 = timed(r1, s1, args.steps)
-            if rank == 0:
-                out['single_sequence_fps'] = round(f1 / t1, 3)
-                out['single_sequence'] = {'value': round(f1 / t1, 3), 'unit': 'frames/s', 'ms_per_frame': round(1e3 * t1 / f1 * world, 3),
-                                          'steps': args.steps, 'sequences_per_gpu': 1, 'launch': launch_text(args.pipeline != 'off'),
-                                          'plans_digest': book.digest()}
-            del r1, s1
-        with ops.conv_math((0, 1)):
-            # (a loaded plan file may hold only the default leg's plans: this leg then tunes its own)
-            have32 = any(k_[-3:] == ('math', 0, 1) for k_ in book.conv)
-            r32, s32 = make_runners(nseq, pipelined, 3234, tune=tune or (not args.no_autotune and not have32))
-            f32_, t32 = timed(r32, s32, args.steps)
-        if rank == 0:
-            h32 = {'fp32': 0, 'bf16x6': 0}
-            for k_, v_ in book.conv.items():
-                if k_[-3:] == ('math', 0, 1):
-                    h32['bf16x6' if (v_ >> 16) & 3 == 1 else 'fp32'] += 1
-            out['fp32_level'] = {'value': round(f32_ / t32, 3), 'unit': 'frames/s', 'ms_per_frame': round(1e3 * t32 / f32_ * world, 3),
-                                 'steps': args.steps, 'sequences_per_gpu': nseq, 'conv_layer_shapes_by_math': h32,
-                                 'note': 'the same workload with the conv tuner restricted to fp32 MFMA and bf16x6 (both '
-                                         'operands split exactly into three bf16 terms: fp32-level error), ops.conv_math((0, 1))'}
-        del r32, s32
-        torch.cuda.empty_cache()
-        if args.save_plans and rank == 0:
-            book.save(args.save_plans)             # again: with the plans the extra legs tuned
-
-    if world == 1 and not args.no_roofline:
+    def leg_roofline(runner, hist, pmc_tag):
+        """Roofline of one leg's dominant conv kernel: per-launch HIP-event timing of eager frames of ONE sequence (runner) in the
+        conv_math mode the caller has entered; pmc_tag names the committed counter files (profiles/r04_conv_*<tag>.json)."""
         # ---------------- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream
         kla = args.lookahead if (args.lookahead > 0 and not args.no_graph) else 0
         nprof = min(args.steps, 5) if not kla else kla * max(1, 4 // kla)       # frames traced eagerly
@@ -481,7 +455,7 @@ def main():
         tr_all, ops.CONV_TRACE = ops.CONV_TRACE, None
         tr = [t_ for t_ in tr_all if t_[0] is not None]
         if args.trace_layers:                   # per-launch list for tools/conv_by_layer.py (joined with rocprofv3 durations)
-            with open(args.trace_layers, 'w') as f:
+            with open(args.trace_layers + pmc_tag, 'w') as f:
                 json.dump({'frames': nprof, 'launches': [{'layer': t_[3], 'flops': t_[2], 'bytes': t_[4], 'plan': t_[5],
                                                           'pipe': t_[6], 'event_us': None if t_[0] is None else
                                                           1e3 * t_[0].elapsed_time(t_[1])} for t_ in tr_all]}, f)
@@ -559,7 +533,7 @@ def main():
                 'true' if sk else 'false', 'true' if pipe_ == 'f16x3' else 'false')
         dk_name = bf3s_name(*dk) if dk[0] != 'fp32' else 'conv_igemm_pipe_kernel<%d, %d>' % (dk[1], dk[2])
         traffic, tsrc = None, None
-        for name in ('r03_conv_traffic_by_kernel.json', 'r02_conv_traffic_by_kernel.json'):
+        for name in ('r04_conv_traffic_by_kernel%s.json' % pmc_tag, 'r03_conv_traffic_by_kernel.json', 'r02_conv_traffic_by_kernel.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', name)) as f:
                     byk = json.load(f)
@@ -578,14 +552,17 @@ def main():
                     pass
         mfma_busy, mfma_src = None, None
         try:       # counter evidence of the same kernel from the committed rocprofv3 --pmc passes (tools/pmc_kernels.sh)
-            with open(os.path.join(ROOT, 'profiles', 'r03_conv_pmc.json')) as f:
+            pmc_file = 'r04_conv_pmc%s.json' % pmc_tag
+            if not os.path.exists(os.path.join(ROOT, 'profiles', pmc_file)):
+                pmc_file = 'r03_conv_pmc.json'
+            with open(os.path.join(ROOT, 'profiles', pmc_file)) as f:
                 pm = json.load(f)
             hit = [v for k, v in pm.items() if k.replace(' ', '') == dk_name.replace(' ', '') and 'mfma_busy' in v]
             if hit:
-                mfma_busy, mfma_src = round(hit[0]['mfma_busy'], 4), 'profiles/r03_conv_pmc.json'
+                mfma_busy, mfma_src = round(hit[0]['mfma_busy'], 4), 'profiles/' + pmc_file
         except (OSError, KeyError, ValueError):
             pass
-        out['roofline'] = {
+        roof = {
             'bound': 'mfma', 'mfma_busy': mfma_busy, 'mfma_busy_source': mfma_src,
             'mfma_busy_note': 'SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles of the dominant kernel on its largest layer, from separate '
                               'rocprofv3 --pmc passes (NOT re-measured by this run): the share of cycles the matrix pipe is busy AT '
@@ -621,6 +598,75 @@ def main():
                     'stream(s), whose kernels overlap -- `whole_frame` prices THAT' % (nprof, nseq, nseq),
             'plans_bf16x6': hist['bf16x6'], 'plans_bf16x3': hist['bf16x3'], 'plans_f16x3': hist['f16x3'],
             'plans_total': sum(hist.values())}
+        return roof, pipes, per_pipe, peaks, nprof
+
+    # ---------------- the same workload in the reference's own FPS semantics (one sequence at a time,
+    # basic_evaluator.py:171-176) and in the EXACT-SPLIT arithmetic (fp32 MFMA / bf16x6 only: every operand bit of the fp32
+    # reference enters the products), same steps, same clock; the second leg with its own roofline and single-sequence figure
+    def single_leg(seed_base, n_objects=n_obj, tune_=tune):
+        r1, s1 = make_runners(1, args.pipeline != 'off', seed_base, tune=tune_, n_obj=n_objects)
+        f1, t1 = timed(r1, s1, args.steps)
+        d = {'value': round(f1 / t1, 3), 'unit': 'frames/s', 'ms_per_frame': round(1e3 * t1 / f1 * world, 3), 'steps': args.steps,
+             'sequences_per_gpu': 1, 'objects': n_objects, 'launch': launch_text(args.pipeline != 'off')}
+        del r1, s1
+        return d
+
+    if not args.no_legs and world == 1:
+        if nseq != 1 and not args.no_graph:
+            d1 = single_leg(2234)
+            if rank == 0:
+                out['single_sequence_fps'] = d1['value']
+                out['single_sequence'] = dict(d1, plans_digest=book.digest())
+        with ops.conv_math((0, 1)):
+            # (a loaded plan file may hold only the default leg's plans: this leg then tunes its own)
+            have32 = any(k_[-3:] == ('math', 0, 1) for k_ in book.conv)
+            tune32 = tune or (not args.no_autotune and not have32)
+            r32, s32 = make_runners(nseq, pipelined, 3234, tune=tune32)
+            f32_, t32 = timed(r32, s32, args.steps)
+            h32 = book.math_histogram(('math', 0, 1))
+            leg = {'value': round(f32_ / t32, 3), 'unit': 'frames/s', 'ms_per_frame': round(1e3 * t32 / f32_ * world, 3),
+                   'steps': args.steps, 'sequences_per_gpu': nseq, 'conv_layer_shapes_by_math': {k_: v_ for k_, v_ in h32.items() if v_},
+                   'dtype': 'f32 storage + accumulate; conv operands fp32 (v_mfma_f32_32x32x2_f32) or bf16x6 (exact 3-way bf16 split = '
+                            '24 significant bits, 6 MFMA products)',
+                   'note': 'the same workload with the conv tuner restricted to fp32 MFMA and bf16x6 (both operands split exactly '
+                           'into three bf16 terms), ops.conv_math((0, 1)): no operand bit of the fp32 reference is dropped'}
+            if not args.no_roofline:
+                roof32, _, _, _, _ = leg_roofline(r32[0], h32, '_exact')
+                leg['roofline'] = roof32
+            del r32, s32
+            torch.cuda.empty_cache()
+            if nseq != 1 and not args.no_graph:
+                leg['single_sequence'] = single_leg(4234, tune_=tune32)
+                leg['single_sequence_fps'] = leg['single_sequence']['value']
+        if rank == 0:
+            out['fp32_level'] = leg
+            # both arithmetics side by side at top level (a reader must not mistake one leg for the other)
+            out['value_by_arithmetic'] = {
+                'f16x3 (shipped plans; fp16 hi+mid operands, 22-23 significant bits; error against float64 = the fp32 kernels\', '
+                'tests/test_gpu_ops.py::test_conv2d_f16x3_mode)': {'frames_per_s': out['value'], 'single_sequence_fps': out.get('single_sequence_fps')},
+                'exact split (fp32 MFMA / bf16x6: all 24 operand bits)': {'frames_per_s': leg['value'],
+                                                                           'single_sequence_fps': leg.get('single_sequence_fps')}}
+        torch.cuda.empty_cache()
+        # ---------------- other object counts (DAVIS17-val sequences carry 1-5 objects, swem_evaluator.py:59-102; SURVEY 8d:
+        # N in {1, 2, 3}): one sequence at a time, both arithmetics, the shipped plans of those shapes
+        if args.object_legs and not args.no_graph:
+            legs_n = {}
+            for n_ in args.object_legs:
+                if n_ == n_obj:
+                    continue
+                d_ = {'f16x3': single_leg(5234 + n_, n_objects=n_)}
+                with ops.conv_math((0, 1)):
+                    d_['exact_split'] = single_leg(6234 + n_, n_objects=n_, tune_=tune or not args.no_autotune)
+                d_['algorithmic_gflop_per_frame'] = round(algorithmic_flops_per_frame(n_) / 1e9, 1)
+                legs_n[str(n_)] = d_
+            if rank == 0 and legs_n:
+                out['objects'] = legs_n
+        if args.save_plans and rank == 0:
+            book.save(args.save_plans)             # again: with the plans the extra legs tuned
+
+    if world == 1 and not args.no_roofline:
+        roof, pipes, per_pipe, peaks, nprof = leg_roofline(runner, hist, '')
+        out['roofline'] = roof
         # whole frame of the TIMED configuration against the blended ceiling: every FLOP priced at its pipe's peak
         conv_fl = {k: d['flops'] / nprof for k, d in pipes.items()}
         em_fl = em_flops_per_frame(n_obj)
@@ -733,6 +779,9 @@ def main():
                               'eager': {'ms_per_frame': em['ms_per_frame'], 'achieved': em['achieved'], 'frac': em['frac']}}
             em['achieved'], em['frac'] = mine[0]['achieved'], mine[0]['frac']
             em['frac_executed_flops'] = round(mine[0]['frac'] * ex_ratio, 4)
+            # the headline of this object: ONE sequence alone, on the FLOPs the kernels really issue
+            em['headline'] = {'frac_executed_flops_one_sequence': round(one['frac'] * ex_ratio, 4),
+                              'frac_algorithmic_flops_one_sequence': one['frac'], 'us_per_frame_one_sequence': one['us_per_round']}
             em['flops_note'] = ('frac = ALGORITHMIC FLOPs (the 3T - 1 key GEMMs of the reference + the value GEMM per memorize) / time / '
                                 'fp32 matrix peak; frac_executed_flops counts what the kernels issue (E and W steps share one '
                                 'GEMM: 2T key GEMMs), %.3f of the algorithmic figure' % ex_ratio)

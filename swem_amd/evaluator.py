@@ -611,11 +611,20 @@ class SequencePool:
     frame chains), the last frames of a sequence that do not fill a group eagerly.  lookahead = 0: one frame per replay
     (FrameGraph; a pool of one model then runs the software-pipelined PipelinedFrameGraph)."""
 
-    def __init__(self, models, use_graph=True, lookahead=4):
+    def __init__(self, models, use_graph=True, lookahead=4, plans='shipped'):
         self.models = list(models)
         n = len(self.models)
         for m in self.models[1:]:            # the lanes run the same layers on the same shapes: one PlanBook for all of them
             m.book = self.models[0].book
+        # plans='shipped' (default): a pool whose book holds no tuned conv plan yet loads the plan file that ships with the
+        # library (swem_amd/plans/: 480p, K = 256, 1 / 2 / 3 / 5 objects on MI355X) -- layer shapes it does not hold run the
+        # book's fallback (f16x3 on the heuristic tile).  plans=None: the book as it is; a path: that file.
+        book = self.models[0].book
+        if plans is not None and not book.conv:
+            import os
+            path = ops.shipped_plans() if plans == 'shipped' else plans
+            if os.path.exists(path):
+                book.load(path)
         self.streams = overlapping_streams(n) if n > 1 else [torch.cuda.current_stream()]
         self.graphs = [None] * n
         self.graph_streams = [None] * n      # per lane: (warm-up stream, capture stream), reused by every re-capture

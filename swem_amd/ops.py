@@ -157,6 +157,12 @@ def shipped_plans(name='mi355x_480p_k256'):
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'plans', name + '.json')
 
 
+# What a MODEL's book answers for a layer shape nobody tuned (SWEM.__init__): the library's heuristic tile / K-split in the
+# f16x3 arithmetic -- fp32-level error (tests/test_gpu_ops.py::test_conv2d_f16x3_mode) at 2-4 x the exact fp32 kernels' speed, so
+# that an object count or a frame size outside the shipped plan file is not a performance cliff.  Layers the
+# pre-split kernel cannot take (stems on 4 / 8 channels) run the fp32 kernels as before.  model.book.fallback = 0 gives the exact
+# fp32 MFMA kernels everywhere; the free-standing default book (plain ops.* calls) keeps 0.
+MODEL_FALLBACK = 7 << 16
 BOOK = PlanBook()     # the current book (the default one until a model makes its own current: use_book)
 MATH_RAN = None       # tests / bench set this to a dict: plan math field of every conv LAUNCH (what really ran) -> count
 
@@ -704,12 +710,18 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
 
     sig = (cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags, B, H, W) + _PLAN_TAG
     explicit = plan is not None
-    plan = plan if explicit else BOOK.conv.get(sig, BOOK.fallback)
-    if plan == 0 and len(_PLAN_TAG) == 2 and not AUTOTUNE:
-        plan = _PLAN_TAG[1] << 16                  # conv_math((m,)) without tuning: the heuristic tile in math mode m
-    if AUTOTUNE and not explicit and plan == 0 and not torch.cuda.is_current_stream_capturing():
-        plan = BOOK.conv[sig] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
-                                            -(-pack.kh * pack.kw * cin // 32), pack.glu, fresh_kw=True)
+    if not explicit:
+        plan = BOOK.conv.get(sig)
+        if plan is None:
+            # a shape nobody tuned: under conv_math((m,)) the heuristic tile in math mode m; else the book's fallback (a model's
+            # book: MODEL_FALLBACK, the heuristic tile in f16x3; the free-standing default book: 0, the exact fp32 kernels)
+            plan = _PLAN_TAG[1] << 16 if (len(_PLAN_TAG) == 2 and not AUTOTUNE) else BOOK.fallback
+            if _PLAN_TAG and (plan >> 16) & 7 not in CONV_MATH_MODES:
+                plan = (plan & 0xffff) | max(CONV_MATH_MODES) << 16    # (a restricted block: its most capable allowed mode)
+            if AUTOTUNE and plan & 0xffff == 0 and not torch.cuda.is_current_stream_capturing():
+                # (a fallback that names a tile is a decision -- batch-invariant plans -- and is not tuned over)
+                plan = BOOK.conv[sig] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
+                                                    -(-pack.kh * pack.kw * cin // 32), pack.glu, fresh_kw=True)
     if CONV_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -1260,6 +1272,8 @@ def _match_plan(key, launch, M, V, nkb):
     plan = BOOK.match.get(key + _PLAN_TAG, 0)
     if plan == 0 and len(_PLAN_TAG) == 2 and not AUTOTUNE:
         plan = _PLAN_TAG[1] << 16
+    elif plan == 0 and not AUTOTUNE and (BOOK.fallback >> 16) & 3 == 3:
+        plan = 3 << 16                             # a model's default: the pre-split (f16x3) readout on the heuristic tile
     if AUTOTUNE and plan == 0 and not torch.cuda.is_current_stream_capturing():
         # (the pre-split readout has ONE arithmetic, f16x3 on the pack's fp16 value planes: math field 3 selects it whatever
         # two-plane mode the convolutions run)

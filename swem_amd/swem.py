@@ -38,7 +38,9 @@ class SWEM(nn.Module):
         self.swem_core._engine = self.engine
         # tuned plans and fused-split hints of THIS model (ops.PlanBook); current for the duration of every forward() call.
         # Models that run the same layers on the same shapes may share one (evaluator.SequencePool does): m.book = other.book
-        self.book = ops.PlanBook()
+        # A fresh book holds no tuned plan: every layer then runs the heuristic tile in the f16x3 arithmetic (ops.MODEL_FALLBACK;
+        # book.fallback = 0: the exact fp32 kernels); book.load_shipped() / ops.AUTOTUNE add tuned plans.
+        self.book = ops.PlanBook(fallback=ops.MODEL_FALLBACK)
 
     # -- packed-weight cache: rebuilt after load_state_dict / .to() / .cuda()
     def engine(self):

@@ -652,7 +652,7 @@ def test_sequence_pool_equals_sequential_evaluation(lib, lanes, lookahead):
         with torch.no_grad():
             preds, _ = evaluator.evaluate_davis_seq(models[0], frames, [m0] + [None] * (frames.shape[1] - 1), out)
         ref.append([p.clone() for p in preds])
-    pool = evaluator.SequencePool(models, use_graph=True, lookahead=lookahead)
+    pool = evaluator.SequencePool(models, use_graph=True, lookahead=lookahead, plans=None)   # (the book as the reference runs used it)
     got = pool.run(seqs, seeds=seeds)
     torch.cuda.synchronize()
     assert pool.graphs[0] is not None

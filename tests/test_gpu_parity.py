@@ -185,6 +185,25 @@ def test_teacher_forced_config_b_clip(lib, golden, mode):
                                                               'plans_digest': model.book.digest(), 'frames': rows})
 
 
+@pytest.mark.parametrize('n_obj', (1, 3), ids=['one_object', 'three_objects'])
+def test_teacher_forced_config_b_other_object_counts(lib, n_obj):
+    """BASELINE configs[1] at the other object counts DAVIS17-val carries (swem_evaluator.py:59-102 runs whatever init_masks
+    holds; SURVEY 8d: N in {1, 2, 3}), in the arithmetic the product ships for them ('tuned': the plan file holds these shapes
+    too): the same bars as the two-object clip, against the oracle run here (a 3-frame clip: the oracle is the CPU reference)."""
+    from swem_amd import synth
+    cfg = O.make_cfg(**CFG_B)
+    model, sd = H.make_model_and_sd(cfg, 3, device=DEV)
+    out = (480, 854)
+    frames, m0 = synth.make_clip(t=3, h=480, w=864, n_obj=n_obj, out_hw=out, seed=60 + n_obj)
+    steps = oracle_trajectory(('cfgB', n_obj), O.Model(sd, cfg), frames, m0, out, seed=9)
+    with H.arith('tuned', model) as ar:
+        rows = teacher_forced_clip(model, steps, frames, out)
+    # the shipped file must really hold this object count's layer shapes: nothing fell to the untuned fallback but the stems
+    assert ar.ran.get(7, 0) >= 0.95 * sum(ar.ran.values()), ar.ran
+    H.record_parity('teacher_forced_configB_%dobj[tuned]' % n_obj, {'conv_launches_by_math': ar.summary(),
+                                                                    'plans_digest': model.book.digest(), 'frames': rows})
+
+
 @pytest.mark.parametrize('n_obj,h,w,bases,topl', [(1, 96, 160, 64, 64), (5, 112, 176, 64, 32), (3, 80, 144, 128, 64)],
                          ids=['one_object', 'five_objects_topl32', 'three_objects_k128'])
 @pytest.mark.parametrize('mode', ('fp32', 'f16x3', 'bf16x3'))

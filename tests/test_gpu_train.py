@@ -790,6 +790,7 @@ def test_inference_after_a_step_sees_the_updated_weights(lib):
     fresh = SWEM(cfg)
     fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
     fresh = fresh.eval().to(DEV)
+    fresh.book.fallback = model.book.fallback               # (the same arithmetic as the test model: helpers.make_model_and_sd)
     ref = infer(fresh)
     assert float((after - before).abs().max()) > 1e-3, 'the step did not move the outputs: the test is vacuous'
     assert torch.equal(after, ref)
