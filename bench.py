@@ -229,6 +229,9 @@ def main():
     ap.add_argument('--trace-layers', default=None, help='write the per-launch conv list of the eager roofline frames (JSON)')
     ap.add_argument('--cpu-frames', type=int, default=20, help='timed frames of the CPU baseline (after 2 warm-up frames)')
     ap.add_argument('--max-split', type=int, default=0, help='cap the K-split factors the conv tuner may choose (0 = all)')
+    ap.add_argument('--math-modes', type=int, nargs='*', default=None,
+                    help='run the WHOLE bench (main timed region, roofline) under ops.conv_math(modes), e.g. 0 1 = the exact-split '
+                         'arithmetic as the main leg (profiler runs of that leg); implies --no-legs')
     ap.add_argument('--object-legs', type=int, nargs='*', default=[1, 3],
                     help='extra single-sequence legs at these object counts, both arithmetics (default 1 3; empty: none)')
     args = ap.parse_args()
@@ -348,13 +351,20 @@ def main():
         return sdist.reduce_counters(steps * len(rs), elapsed, device=dev)
 
     pipelined = args.pipeline == 'on' or (args.pipeline == 'auto' and nseq == 1)
-    runners, streams = make_runners(nseq, pipelined, 1234)
+    main_tag, pmc_tag = (), ''
+    if args.math_modes:
+        mm_ctx = ops.conv_math(tuple(args.math_modes))
+        mm_ctx.__enter__()                   # (for the rest of the process)
+        args.no_legs = True
+        main_tag, pmc_tag = ('math',) + tuple(args.math_modes), '_exact' if tuple(args.math_modes) == (0, 1) else ''
+        tune = tune or (not args.no_autotune and not any(k_[10:] == main_tag for k_ in book.conv))
+    runners, streams = make_runners(nseq, pipelined, 1234, tune=tune)
     runner = runners[0]
     frames_cpu, m0_cpu = clip_box[(123 + rank * 16, n_obj)]
     sd = sd_box[0]
     if args.save_plans and rank == 0:
         book.save(args.save_plans)
-    hist = book.math_histogram()
+    hist = book.math_histogram(main_tag)
 
     # ---------------- timed region: exactly K steps between barrier + synchronize
     total_frames, max_t = timed(runners, streams, args.steps)
@@ -665,7 +675,7 @@ def main():
             book.save(args.save_plans)             # again: with the plans the extra legs tuned
 
     if world == 1 and not args.no_roofline:
-        roof, pipes, per_pipe, peaks, nprof = leg_roofline(runner, hist, '')
+        roof, pipes, per_pipe, peaks, nprof = leg_roofline(runner, hist, pmc_tag)
         out['roofline'] = roof
         # whole frame of the TIMED configuration against the blended ceiling: every FLOP priced at its pipe's peak
         conv_fl = {k: d['flops'] / nprof for k, d in pipes.items()}

@@ -13,7 +13,7 @@ import csv
 import json
 import sys
 
-PEAK = {'bf16': 2500.0 / 6, 'bf16x3': 2500.0 / 3, 'fp32': 157.3}
+PEAK = {'bf16': 2500.0 / 6, 'bf16x3': 2500.0 / 3, 'f16x3': 2500.0 / 3, 'fp32': 157.3}
 
 
 def peak_of(pipe, kname):
@@ -21,7 +21,7 @@ def peak_of(pipe, kname):
     if pipe != 'readout':
         return PEAK[pipe]
     if 'bf3s' in kname:
-        return PEAK['bf16x3'] if kname.rstrip('>').split()[-2] == '2' else PEAK['bf16']
+        return PEAK['bf16x3'] if kname[kname.index('<') + 1:].rstrip('>').split()[5] == '2' else PEAK['bf16']   # (template parameter NPL)
     return PEAK['bf16'] if 'bf3_kernel' in kname else PEAK['fp32']
 
 
@@ -37,7 +37,7 @@ def main(layers_json, trace_csv, out_csv):
     for li, (mi, la) in enumerate(zip(main_idx, launches)):
         t_main, t_split, t_red = dur(rows[mi]), 0.0, 0.0
         for j in range(max(prev + 1, mi - 6), mi):                # operand splits issued for this launch
-            if 'split_bf16x3' in rows[j]['Kernel_Name']:
+            if 'split_bf16x3' in rows[j]['Kernel_Name'] or 'split_f16x2' in rows[j]['Kernel_Name']:
                 t_split += dur(rows[j])
         if mi + 1 < len(rows) and 'conv_splitk_epilogue' in rows[mi + 1]['Kernel_Name']:
             t_red = dur(rows[mi + 1])

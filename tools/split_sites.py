@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Which tensors of a steady-state frame are still split by a separate swem_split_bf16x3_f32 launch (no producer wrote their
+"""Which tensors of a steady-state frame are still split by a separate swem_split_bf16x3_f32 / swem_split_f16x2_f32 launch (no producer wrote their
 planes), and every libswem_hip.so call of the frame by name.   python tools/split_sites.py [--lookahead 4]"""
 import argparse
 import collections
@@ -26,6 +26,8 @@ def main():
     model = model.eval().to(dev)
     if a.load_plans:
         model.book.load(a.load_plans)
+    else:
+        model.book.load_shipped()
     frames, m0 = synth.make_clip(t=8, h=bench.H, w=bench.W, n_obj=2, out_hw=bench.OUT_HW, seed=123)
     runner = bench.FrameRunner(model, frames.to(dev), m0.to(dev))
     for _ in range(3):
@@ -38,7 +40,7 @@ def main():
 
     def counting(name, *args):
         calls[name] += 1
-        if name == 'swem_split_bf16x3_f32':
+        if name in ('swem_split_bf16x3_f32', 'swem_split_f16x2_f32'):
             where = [f for f in traceback.extract_stack() if 'swem_amd' in f.filename and 'ops.py' not in f.filename]
             w = where[-1] if where else None
             splits['%s:%d %s  [npix %d x C %d]' % (os.path.basename(w.filename), w.lineno, w.line, args[3], args[4]) if w else '?'] += 1
