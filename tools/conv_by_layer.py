@@ -26,23 +26,40 @@ def peak_of(pipe, kname):
 
 
 def main(layers_json, trace_csv, out_csv):
+    import re
     launches = json.load(open(layers_json))['launches']
     rows = sorted(csv.DictReader(open(trace_csv)), key=lambda r: int(r['Start_Timestamp']))
-    main_idx = [i for i, r in enumerate(rows) if 'conv_igemm' in r['Kernel_Name']]
-    assert len(main_idx) >= len(launches), (len(main_idx), len(launches))
-    main_idx = main_idx[-len(launches):]
     dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    is_conv = lambda r: 'conv_igemm' in r['Kernel_Name']
+    is_red = lambda r: 'conv_splitk_epilogue' in r['Kernel_Name']
+    is_split = lambda r: 'split_bf16x3' in r['Kernel_Name'] or 'split_f16x2' in r['Kernel_Name']
+    # The traced frames are the LAST conv launches of the run: walk both lists backwards.  One traced launch = [operand-split
+    # kernels] + one implicit-GEMM kernel (TWO for a tail-split plan whose last round of tiles was split over K: the whole
+    # rounds, then the tail) + [split-K reduce kernel].
     agg = {}
-    prev = main_idx[0] - 8
-    for li, (mi, la) in enumerate(zip(main_idx, launches)):
-        t_main, t_split, t_red = dur(rows[mi]), 0.0, 0.0
-        for j in range(max(prev + 1, mi - 6), mi):                # operand splits issued for this launch
-            if 'split_bf16x3' in rows[j]['Kernel_Name'] or 'split_f16x2' in rows[j]['Kernel_Name']:
+    i = len(rows) - 1
+    for la in reversed(launches):
+        while i >= 0 and not (is_conv(rows[i]) or is_red(rows[i])):
+            i -= 1
+        assert i >= 0, 'kernel trace holds fewer conv launches than the layer list'
+        t_main, t_split, t_red = 0.0, 0.0, 0.0
+        if is_red(rows[i]):
+            t_red = dur(rows[i])
+            i -= 1
+            while not is_conv(rows[i]):
+                i -= 1
+            ts = (la['plan'] >> 24) & 15
+            if ts > 1 and i >= 1 and is_conv(rows[i - 1]) and rows[i - 1]['Kernel_Name'] == rows[i]['Kernel_Name'] and la['pipe'] != 'readout':
+                t_main += dur(rows[i])          # the tail launch of a tail-split layer; the whole rounds precede it
+                i -= 1
+        mi = i
+        t_main += dur(rows[mi])
+        i -= 1
+        j = i
+        while j >= 0 and not (is_conv(rows[j]) or is_red(rows[j])) and mi - j <= 6:   # operand splits issued for this launch
+            if is_split(rows[j]):
                 t_split += dur(rows[j])
-        if mi + 1 < len(rows) and 'conv_splitk_epilogue' in rows[mi + 1]['Kernel_Name']:
-            t_red = dur(rows[mi + 1])
-        prev = mi
-        import re
+            j -= 1
         kname = re.search(r'(conv_igemm\w*(<[^>]*>)?)', rows[mi]['Kernel_Name']).group(1).replace(', ', ' ')
         a = agg.setdefault((la['layer'], la['pipe'], '%#x' % la['plan'], kname), [0, 0.0, 0.0, 0.0, 0.0, 0.0])
         a[0] += 1
