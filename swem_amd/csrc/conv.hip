@@ -1212,7 +1212,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kern
 
   const int kb_begin32 = sk ? seg_k0 : blockIdx.z * p.kb_per_split;
   const int kb_begin = kb_begin32 * (4 / KG);                       // in this kernel's k-blocks (16 or 32 k)
-  const int kb_end = (sk ? seg_k1 : min(p.nkb, kb_begin32 + p.kb_per_split)) * (4 / KG);
+  // (the LAST split of a fused K-split tile -- its reducer -- takes whatever the others leave: the host may give them a
+  // smaller share each, so that their partial tiles are in memory before the reducer is done with its own k-blocks)
+  const int kb_end = (sk ? seg_k1 : ((int)blockIdx.z == (int)gridDim.z - 1 && p.sk_flags && p.partial)
+                                        ? p.nkb : min(p.nkb, kb_begin32 + p.kb_per_split)) * (4 / KG);
   // Ring of NST stages.  In iteration kb the transfers of block kb+NST-1 are issued into the stage that was read in
   // iteration kb-1, the MFMAs run on stage kb%NST, then a COUNTED wait (all but the newest (NST-2)*NDMA transfers of
   // this wave, i.e. everything up to block kb+1) and a raw s_barrier publish stage (kb+1)%NST.  __syncthreads() would
@@ -1707,6 +1710,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
 struct Plan {
   int wm, wn, nsplit, kb_per_split;
 };
+constexpr int SWEM_KSPLIT_SKEW_DEFAULT = 0;   // percent (see the fused K-split launch)
 constexpr int SK_MAX_WORKERS = 1024;   // stream-K: resident-block slots of the chip (256 CUs x at most 4 blocks)
 
 // Tuning hook (tools/conv_bench.py): SWEM_CONV_PLAN="wm,wn,nsplit" forces one plan for every launch.
@@ -2431,6 +2435,22 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
         swem_set_error("conv2d_bf16x3: hipMemsetAsync of the K-split counters failed");
         return SWEM_E_HIP;
       }
+    }
+    {
+      // Staggered shares (round 4): equal shares make all splits of a tile finish together -- the producers' stores and the
+      // reducer's loads are then a burst nothing hides (13 of 54 us on 2x30x54 k3 512->512 at nsp = 4, HISTORY.md).  The
+      // producers get `skew` percent less than an equal share each, the reducer the rest: their tiles land while it still
+      // multiplies.  SWEM_KSPLIT_SKEW overrides the default (0 = equal shares).
+      static int skew = -1;
+      if (skew < 0) {
+        const char *e = getenv("SWEM_KSPLIT_SKEW");
+        skew = e ? atoi(e) : SWEM_KSPLIT_SKEW_DEFAULT;
+        if (skew < 0 || skew > 50) skew = 0;
+      }
+      int per = (int)((long long)p.nkb * (100 - skew) / (100LL * pl.nsplit));
+      if (per < 1) per = 1;
+      if ((long long)per * (pl.nsplit - 1) >= p.nkb) per = pl.kb_per_split;   // (too few k-blocks to skew)
+      if (skew > 0 && per <= pl.kb_per_split) p.kb_per_split = per;
     }
     if ((rc = run(p, dim3(mtiles, ntiles, pl.nsplit)))) return rc;
     SWEM_CHECK_LAUNCH("conv_igemm_bf3s_kernel");
