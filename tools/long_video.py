@@ -39,12 +39,14 @@ def main():
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     cfg = SimpleNamespace(**bench.CFG)
-    ops.AUTOTUNE = not a.load_plans
+    ops.AUTOTUNE = False               # (the shipped plans, or --load-plans; shapes they do not hold: the book's f16x3 fallback)
     model = SWEM(cfg)
     model.load_state_dict(weights.fill_state_dict(model.state_dict(), seed=3, backbone='resnet50'))
     model = model.eval().to(dev)
     if a.load_plans:
         model.book.load(a.load_plans)
+    else:
+        model.book.load_shipped()
     frames, m0 = synth.make_clip(t=8, h=bench.H, w=bench.W, n_obj=a.objects, out_hw=bench.OUT_HW, seed=123)
     frames, m0 = frames.to(dev), m0.to(dev)
     torch.manual_seed(1234)
