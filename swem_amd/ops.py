@@ -251,7 +251,10 @@ _TUNE_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # (the raw handle of torch's current stream of the current device, straight from the C++ binding: the Python-level
+    # torch.cuda.current_stream() costs ~5 us per call -- device-index plumbing and a Stream object -- and an eager frame asks
+    # ~800 times: a quarter of the host time of the reference's loop as written, tools/host_profile.py)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 _hip = None
@@ -322,6 +325,8 @@ def _hip_runtime():
 
 def _capture_id(stream_ptr):
     """Id of the graph capture the stream is recording into, or None."""
+    if not torch._C._cuda_isCurrentStreamCapturing():      # (the common case, without a ctypes round trip)
+        return None
     status, cid = C.c_int(0), C.c_ulonglong(0)
     rc = _hip_runtime().hipStreamGetCaptureInfo(C.c_void_p(stream_ptr), C.byref(status), C.byref(cid))
     return cid.value if rc == 0 and status.value == 1 else None       # hipStreamCaptureStatusActive
@@ -337,7 +342,7 @@ def workspace(nbytes, device):
     pool and lives exactly as long as the graph.  A captured launch never sees a buffer of the eager cache (a later, larger
     eager request on that stream replaces and frees it) nor one of an earlier capture (its graph may be gone)."""
     dev = device.index if device.index is not None else torch.cuda.current_device()
-    st = torch.cuda.current_stream().cuda_stream
+    st = _stream()
     cid = _capture_id(st)
     if cid is None:
         cache, key = _ws, (dev, st)
@@ -371,7 +376,7 @@ def counters(device):
     the device ever clears it -- `check_faults` reads it on the host and raises."""
     import weakref
     dev = device.index if device.index is not None else torch.cuda.current_device()
-    st = torch.cuda.current_stream().cuda_stream
+    st = _stream()
     cid = _capture_id(st)
     if cid is None:
         cache, key = _ctr, (dev, st)
@@ -592,6 +597,7 @@ def batch_item(t, j):
 
 
 DGRAD, DGRAD_EH, DGRAD_EW, MASK_POS = 8, 16, 32, 64
+_WSB = {}      # conv workspace bytes by (shape, plan)
 _NAN = {}
 
 
@@ -671,8 +677,10 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     y_ptr = 0 if skip_y else y.data_ptr()
 
     def launch(plan, fresh=False):
-        wsb = _lib.query('swem_conv2d_workspace', B, H, W, cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad,
-                         flags, plan)
+        wkey = (B, H, W, cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags, plan)
+        wsb = _WSB.get(wkey)
+        if wsb is None:                    # (a pure function of the shape and the plan: asked once, not per launch)
+            wsb = _WSB[wkey] = _lib.query('swem_conv2d_workspace', *wkey)
         ws = workspace(wsb, x0.device) if wsb else None
         pargs = [0, 3, 0, 3]
         if want:
