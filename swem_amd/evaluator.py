@@ -687,17 +687,23 @@ class SequencePool:
                         si, frames, out_size, i, preds, bound = lanes[li]
                         t = frames.shape[1]
                         step = 1
-                        if self.use_graph and i >= 2 and bound is None and t - i >= max(k, 1):
+                        # A captured frame always memorizes; the reference's loop does not memorize a sequence's LAST frame
+                        # (swem_evaluator.py:89: `if i < t - 1`).  The graphs therefore never take the last frame: a group of k
+                        # frames runs from the graph only while MORE than k frames remain, the tail (at most k frames) eagerly --
+                        # no wasted encode_value + memorize per sequence, and the model's memory after run() is the eager
+                        # loop's.  (The software-pipelined one-frame graph defers every memorize by a frame and
+                        # simply never applies the last one.)
+                        if self.use_graph and i >= 2 and bound is None and t - i > max(k, 1):
                             bound = lanes[li][5] = self._graph_for(li, frames, i, out_size)
                             if bound is not None and k > 0:
                                 bound.prime(frames[0, i:i + k])
-                        if bound is not None and k > 0 and t - i >= k:
-                            nxt = frames[0, i + k:i + 2 * k] if t - i >= 2 * k else None
+                        if bound is not None and k > 0 and t - i > k:
+                            nxt = frames[0, i + k:i + 2 * k] if t - i > 2 * k else None
                             preds.extend(p_.clone() for p_ in bound.run(nxt))
                             step = k
                             if nxt is None:
-                                bound = lanes[li][5] = None        # the rest of the sequence (fewer than k frames) eagerly
-                        elif bound is not None and k == 0:
+                                bound = lanes[li][5] = None        # the rest of the sequence (at most k frames) eagerly
+                        elif bound is not None and k == 0 and (i < t - 1 or isinstance(bound, PipelinedFrameGraph)):
                             preds.append(bound.run(frames[:, i]).clone())
                         else:
                             preds.append(frame_step(model, frames[:, i], out_size, memorize=i < t - 1))
