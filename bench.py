@@ -15,11 +15,18 @@ HBM before the timed region (the reference also excludes the H2D copy, basic_eva
 Every rank runs its own clip (sequences are independent: weak scaling, no data-path collective);
 value = frames of all ranks / max-over-ranks time.
 
+Arithmetic of the line (`dtype`, `plans`): the shipped plans run the convolutions in f16x3 -- operands as fp16 hi + mid pairs
+(22-23 significant bits), three MFMA products, fp32 accumulation: the error of the exact fp32 kernels.
+
 Extra objects in the JSON line:
-  roofline     -- dominant kernel = the implicit-GEMM conv in bf16x6 mode: useful conv FLOPs / summed launch durations
-                  (HIP events on the launch stream) against ITS pipe's ceiling (dense bf16 MFMA peak / 6 products);
+  roofline     -- dominant conv kernel of the timed leg: useful conv FLOPs / summed launch durations (HIP events on the launch
+                  stream) against ITS pipe's ceiling (dense f16 / bf16 MFMA peak / products per fp32 product); mfma_busy and
+                  traffic from the committed rocprofv3 --pmc passes (profiles/r04_conv_pmc*.json, r04_conv_traffic_by_kernel*.json);
                   `pipes` has the fp32-MFMA layers against 157.3 TFLOP/s; `whole_frame` prices the timed configuration.
-  em_matching  -- the same for the EM/matching kernels (algorithmic FLOPs of SURVEY.md section 8d).
+  fp32_level   -- the same workload in the exact-split arithmetic (fp32 MFMA / bf16x6: all 24 operand bits), with its own
+                  `roofline` and single-sequence figure; `value_by_arithmetic` puts both legs side by side at top level.
+  single_sequence, objects -- one sequence at a time (the reference's FPS semantics); 1 and 3 objects, both arithmetics.
+  em_matching  -- the EM / matching kernels against the fp32 matrix peak (algorithmic and executed FLOPs).
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference's PyTorch path) on the same clip, bounded sample.
 """
 import argparse
@@ -402,8 +409,9 @@ def main():
                       'f32 storage + accumulate; conv operands bf16x6 (exact 3-way bf16 split = 24 significant bits, 6 MFMA products)'
                       if hist['bf16x6'] else 'f32 (fp32 MFMA)'),
             'dtype_detail': {'conv_layer_shapes_by_math': hist, 'em_and_affinity': 'fp32 MFMA',
-                             'matching_readout': 'bf16x3' if any((v >> 16) & 3 == 3 for v in book.match.values()) else 'fp32 MFMA',
-                             'fp32_level_leg': 'fp32_level (conv tuner restricted to fp32 MFMA / bf16x6)'},
+                             'matching_readout': ('f16x3 (probabilities x 2^14 and value bases as fp16 pairs)'
+                                                  if any((v >> 16) & 3 == 3 for v in book.match.values()) else 'fp32 MFMA'),
+                             'fp32_level_leg': 'fp32_level = the exact-split arithmetic (conv tuner restricted to fp32 MFMA / bf16x6)'},
             'data': 'synthetic',
             'config': {'workload': 'DAVIS17-val-shaped synthetic 480x864 clip (out 480x854), ResNet-50 key encoder, '
                                    'K=256, 5 EM iters, %d objects, memorise every frame, %d sequence(s) per GPU' % (n_obj, nseq),
