@@ -153,12 +153,30 @@ class TrainGraph:
         return {'kappa': kappa, 'nu': nu, 'zita': zita}
 
 
+class one_cpu_thread:
+    """Context: torch CPU ops inside run on ONE thread.  A torch CPU op of a few hundred KB wakes the whole intra-op pool -- one
+    OpenMP thread per logical CPU, 128-256 on the hosts of this pool, busy-waiting between ops -- and inside a container with a
+    CFS CPU quota (cpu.max = 16 CPUs per 100 ms here) that burns the period's budget in milliseconds: the kernel then stalls
+    EVERY thread of the process, the one feeding the GPU included, until the next period.  That was the "bimodal" training rate
+    of rounds 1-3 (70-76 vs 99-111 clips/s, step times of 38 / 62 / 100 / 200 ms on a 100 ms grid): with the step's host-side
+    draw on one thread every step takes 37.2-37.9 ms (tools/train_bench.py --per-step, profiles/r04_train_step_times.txt)."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.n)
+
+
 def random_init_host(B, N, Cc, Lb):
-    """kappa of modules.py:170-178 drawn from the global torch CPU generator (the reference draws one tensor for the whole
-    batch): N(0, sqrt(2/L)) l2-normalised over C.  (nu = 0 and zita = 1e-6 are constants.)"""
-    kappa = torch.zeros(B, N, 2, Cc, Lb)
-    kappa.normal_(0, math.sqrt(2.0 / Lb))
-    return kappa / (torch.linalg.norm(kappa, dim=-2, keepdim=True) + 1e-6)
+    """kappa of modules.py:170-178 drawn from the global torch CPU generator (the parity mode of the tests, SWEMCore.init_on_host:
+    the reference trainer's fixtures were recorded on the CPU): N(0, sqrt(2/L)) l2-normalised over C, one tensor for the whole
+    batch.  (nu = 0 and zita = 1e-6 are constants.)"""
+    with one_cpu_thread():
+        kappa = torch.zeros(B, N, 2, Cc, Lb)
+        kappa.normal_(0, math.sqrt(2.0 / Lb))
+        return kappa / (torch.linalg.norm(kappa, dim=-2, keepdim=True) + 1e-6)
 
 
 class SWEMTrainer:
@@ -401,20 +419,28 @@ class SWEMTrainer:
         bf['label'].copy_(label)
         if valid_obj is not None:
             bf['valid'].copy_(valid_obj)
-        # the random bases are drawn on the host (the global torch CPU generator, as the fixtures of the reference step) and
-        # reach the device through a ring of three pinned buffers: a pageable copy would block the host until the previous
-        # step has drained, i.e. serialise host and device every step
-        ring = self.__dict__.setdefault('_kappa_ring', {})
-        if ring.get('shape') != tuple(bf['kappa0'].shape):
-            ring.update(shape=tuple(bf['kappa0'].shape), i=0, ev=[None] * 3,
-                        pin=[torch.empty(bf['kappa0'].shape, dtype=torch.float32).pin_memory() for _ in range(3)])
-        i = ring['i'] = (ring['i'] + 1) % 3
-        if ring['ev'][i] is not None:
-            ring['ev'][i].synchronize()                 # the copy issued three steps ago has long finished
-        ring['pin'][i].copy_(random_init_host(B, N, bf['kappa0'].shape[3], core.n_bases))
-        bf['kappa0'].copy_(ring['pin'][i], non_blocking=True)
-        ring['ev'][i] = torch.cuda.Event()
-        ring['ev'][i].record()
+        if not core.init_on_host:
+            # the random bases as the reference draws them (modules.py:170-178: `normal_` on the DEVICE tensor, the device's
+            # generator), straight into the static buffer the captured step reads: no host work, no copy
+            k0 = bf['kappa0']
+            k0.normal_(0, math.sqrt(2.0 / k0.shape[-1]))
+            k0.div_(torch.linalg.norm(k0, dim=-2, keepdim=True).add_(1e-6))
+        else:
+            # parity mode: drawn on the host (the global torch CPU generator, as the fixtures of the reference step were) and
+            # sent through a ring of three pinned buffers -- a pageable copy would block the host until the previous step has
+            # drained, i.e. serialise host and device every step
+            ring = self.__dict__.setdefault('_kappa_ring', {})
+            if ring.get('shape') != tuple(bf['kappa0'].shape):
+                ring.update(shape=tuple(bf['kappa0'].shape), i=0, ev=[None] * 3,
+                            pin=[torch.empty(bf['kappa0'].shape, dtype=torch.float32).pin_memory() for _ in range(3)])
+            i = ring['i'] = (ring['i'] + 1) % 3
+            if ring['ev'][i] is not None:
+                ring['ev'][i].synchronize()                 # the copy issued three steps ago has long finished
+            with one_cpu_thread():
+                ring['pin'][i].copy_(random_init_host(B, N, bf['kappa0'].shape[3], core.n_bases))
+            bf['kappa0'].copy_(ring['pin'][i], non_blocking=True)
+            ring['ev'][i] = torch.cuda.Event()
+            ring['ev'][i].record()
         # mean over the clips of this rank and over the ranks (DistributedDataParallel averages, swem_trainer.py:41-43)
         world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         if getattr(self, '_gout_for', None) != (B, world, id(bf['gout'])):

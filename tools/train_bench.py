@@ -102,7 +102,8 @@ def main():
         print(json.dumps({'metric': 'training clips/s (3 x %dx%d frames, %d objects, %s, %s)' % (
         a.size, a.size, a.objects, a.backbone, 'AMP: bf16 conv operands' if a.amp else 'fp32-accurate'), 'value': a.clips / dt, 'ms_per_step': dt * 1e3, 'clips_per_step': a.clips,
         'total_loss': float(losses['total_loss']), 'graph': tr._graph is not None, 'lanes': a.lanes, 'n_gpus': world,
-        'rccl_ranks': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+        ('rccl_ranks' if (torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl') else 'ranks'):
+            torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
         'peak_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30}))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
