@@ -274,10 +274,13 @@ def new_stream():
 
 
 def spin_sync(streams=None):
-    """Wait for the work queued so far on `streams` (default: the current stream) by POLLING events.  A blocking wait
-    (hipDeviceSynchronize / hipEventSynchronize) sleeps on an interrupt; where interrupts are delivered late (virtualised
-    hosts: wake-ups quantised to 100 ms were measured) the caller loses up to a tick per wait -- and a benchmark's clock
-    with it.  Polling returns within microseconds of completion."""
+    """Wait for the work queued so far on `streams` (default: the current stream) by POLLING events, with a short sleep between
+    polls.  Rounds 1-3 saw blocking waits return up to 100 ms late and blamed interrupt delivery; the cause was the container's
+    CFS CPU quota (16 CPUs per 100 ms period on this pool): once a process has burnt the period's budget -- a torch CPU op waking
+    a 128-thread pool does it in milliseconds, train.one_cpu_thread -- EVERY thread of it stalls until the next period, a thread
+    blocked in hipEventSynchronize included.  The cure is not to burn the budget: this loop therefore yields the CPU between
+    polls (a busy loop per rank is itself 1 CPU of the quota; eight ranks share one container), at a resolution of ~50 us."""
+    import time
     evs = []
     for st in (streams or [torch.cuda.current_stream()]):
         e = torch.cuda.Event()
@@ -285,7 +288,7 @@ def spin_sync(streams=None):
         evs.append(e)
     for e in evs:
         while not e.query():
-            pass
+            time.sleep(2e-5)
 
 
 def _ptr(t):
