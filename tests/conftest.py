@@ -11,6 +11,18 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The CPU oracle runs beside the GPU tests.  torch sizes its intra-op pool by the HOST's logical CPUs (256 on the GPU boxes of
+    # this pool) while the container may use 16 of them per 100 ms (cgroup cpu.max): a 128-thread pool burns that budget in
+    # milliseconds and the kernel then stalls the whole process for the rest of every period (training row).
+    # One thread per CPU of the quota is all the oracle can use anyway.
+    try:
+        import torch
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, per = f.read().split()[:2]
+        if q != 'max':
+            torch.set_num_threads(max(1, min(torch.get_num_threads(), int(int(q) / int(per)))))
+    except (OSError, ValueError, ImportError):
+        pass
 
 
 @pytest.fixture(scope='session')

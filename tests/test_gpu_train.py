@@ -965,7 +965,9 @@ def test_amp_step_stage_by_stage_at_the_training_shapes(lib, case_name):
             assert out['%s_vs_%s' % (gemm, good)] < 1e-4, (name, gemm, out)
             if flag:     # ... and really that arithmetic: the unrounded operands' result is far (bf16 rounding: 3e-3 on
                 # activations and data gradients, 6e-5 .. 1e-3 on weight gradients, whose sums over the pixels average it out)
-                assert out['%s_vs_%s' % (gemm, other)] > 20 * out['%s_vs_%s' % (gemm, good)], (
+                # (weight gradients: an order of magnitude -- the decoder's last layer sums 5 x 147k pixels, which averages the
+                # rounding down to 4e-5 against 2.5e-6; activations and data gradients: 20 x)
+                assert out['%s_vs_%s' % (gemm, other)] > (10 if gemm == 'wgrad' else 20) * out['%s_vs_%s' % (gemm, good)], (
                     name, gemm, 'not the bf16-operand arithmetic', out)
     H.record_parity('amp_stages_%s' % case_name, {'total_loss': float(losses['total_loss']), 'layers': rows})
 
