@@ -20,6 +20,7 @@ convolutions' forward and data gradient take bf16 operands (one MFMA product, fp
 """
 import contextlib
 import math
+import os
 
 import torch
 
@@ -477,6 +478,8 @@ class SWEMTrainer:
         st.enter_context(ops.conv_math((2,)) if self.amp else ops.conv_math((0, 1)))
         # conv epilogues do not write operand planes here and the tuner keeps to the non-persistent kernel forms (ops.py,
         # TUNE_ROUND3_FORMS: measured on the four-lane step); the frozen-BN stages' own planes (autograd._planes_for) stay
+        # (re-measured in round 4 with the step's timing stable to +-0.3 %: FUSE_SPLIT on or off is the same 112 / 69 clips/s --
+        # round 3's "71 against 108" was the CPU-quota throttling of that round's processes, not the planes)
         st.enter_context(ops.flags(FUSE_SPLIT=False, TUNE_ROUND3_FORMS=False))
         return st
 
