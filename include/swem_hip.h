@@ -174,6 +174,21 @@ int swem_conv2d_nhwc_bf16x3_planes_ctr(void *stream, const void *x0, int c0, lon
                                    const float *shift, const float *res, long long res_bs, float *y, int Cout, int KH,
                                    int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
                                    void *planes, int nplanes, void *planes_relu, int nplanes_relu, void *counters, size_t ncounters);
+/* ... and with the RESIDUAL given as operand planes instead of an fp32 map (round 4).  A ResNet block's output that only
+ * convolutions and the NEXT block's residual add consume (mod_resnet.py:77-113: `out += identity`) need not exist as an fp32 map:
+ * its producer writes planes only (y = NULL above) and this entry point reads the addend back from them -- hi + mid of the fp16
+ * pair (exact in fp32: the value to 22-23 significant bits) or hi + mid + lo of three bf16 planes (exactly the value).
+ *   res_planes : plane 0 of the residual, layout [Cout/8][res_npx][8]; res_ps = elements between its planes
+ *   res_nplanes: SWEM_PLANES_F16 or 3 (two bf16 planes carry 16 bits only: refused)
+ *   res_bs     : as `res_bs` of the fp32 form (elements between the batch items of the residual, 0 = one image for the batch)
+ * No GLU, no SWEM_CONV_MASK_POS; everything else as swem_conv2d_nhwc_bf16x3_planes_ctr. */
+int swem_conv2d_nhwc_bf16x3_planes_res(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1,
+                                       int c1, long long bs1, long long ps1, const void *x2, int c2, long long bs2,
+                                       long long ps2, int B, int H, int W, const void *w_bf16x3, const float *scale,
+                                       const float *shift, const void *res_planes, long long res_ps, long long res_npx,
+                                       int res_nplanes, long long res_bs, float *y, int Cout, int KH, int KW, int stride,
+                                       int pad, int flags, int plan, void *ws, size_t ws_bytes, void *planes, int nplanes,
+                                       void *planes_relu, int nplanes_relu, void *counters, size_t ncounters);
 
 /* ------------------------------------------------------------------------------------
  * Pointwise / pooling / resampling kernels.

@@ -27,6 +27,8 @@ SIGNATURES = {
                                             _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i]),
     'swem_conv2d_nhwc_bf16x3_planes_ctr': (_i, [_p, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _i, _i, _i, _p, _p, _p, _p,
                                             _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i, _p, _sz]),
+    'swem_conv2d_nhwc_bf16x3_planes_res': (_i, [_p, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _i, _i, _i, _p, _p, _p, _p,
+                                            _ll, _ll, _i, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i, _p, _sz]),
     'swem_split_bf16x3_f32': (_i, [_p, _p, _p, _ll, _i, _i]),
     'swem_split_f16x2_f32': (_i, [_p, _p, _p, _ll, _i, _i]),
     'swem_conv2d_nhwc_bf16x3': (_i, [_p, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _i, _i, _i, _p, _p, _p, _p, _ll,

@@ -57,6 +57,12 @@ struct ConvP {
   // Optional: the output's bf16 planes, written by the epilogue itself for the convolutions that will consume this tensor
   // pre-split (the layout swem_split_bf16x3_f32 produces, [plane][Cout/8][M][8]): variant 0 = the planes of y, variant 1 =
   // the planes of relu(y) (a consumer that applies its input ReLU while splitting).  NULL = not wanted.
+  // Optional: the residual as operand PLANES instead of an fp32 map (round 4): a block output that only convolutions and the
+  // next block's residual add consume is written as planes only, and the add reads it back from them -- hi + mid of the fp16
+  // pair (exact in fp32: the value to 22-23 significant bits) or hi + mid + lo of three bf16 planes (exactly the value).
+  const unsigned short *res_pl;   // plane 0 of the residual, [C/8][res_npx][8]; NULL = the fp32 map `res`
+  long long res_ps;               // elements between its planes
+  int res_npx, res_npl;           // pixels per plane; SWEM_PLANES_F16 or 3
   unsigned short *ysp[2];
   int ysp_npl[2];     // planes to write per variant: 2 (hi, mid: all consumers run bf16x3) or 3
   long long ysp_ps;   // elements between the planes (M * Cout)
@@ -189,6 +195,17 @@ __device__ __forceinline__ void planes_flush(const ConvP &p, const unsigned *lds
   __builtin_amdgcn_s_waitcnt(0xc07f);   // the reads are done before the next tile is staged
 }
 
+// Four consecutive channels n..n+3 of residual pixel `pix` from its planes (see ConvP::res_pl): 8 bytes per plane.
+__device__ __forceinline__ float4 residual_from_planes(const ConvP &p, long long pix, int n) {
+  const unsigned short *q = p.res_pl + ((long long)(n >> 3) * p.res_npx + pix) * 8 + (n & 7);
+  const uint2 h = *reinterpret_cast<const uint2 *>(q), m = *reinterpret_cast<const uint2 *>(q + p.res_ps);
+  if (p.res_npl == SWEM_PLANES_F16)
+    return make_float4(lo_f16(h.x) + lo_f16(m.x), hi_f16(h.x) + hi_f16(m.x), lo_f16(h.y) + lo_f16(m.y), hi_f16(h.y) + hi_f16(m.y));
+  const uint2 l = *reinterpret_cast<const uint2 *>(q + 2 * p.res_ps);
+  return make_float4((lo_f32(h.x) + lo_f32(m.x)) + lo_f32(l.x), (hi_f32(h.x) + hi_f32(m.x)) + hi_f32(l.x),
+                     (lo_f32(h.y) + lo_f32(m.y)) + lo_f32(l.y), (hi_f32(h.y) + hi_f32(m.y)) + hi_f32(l.y));
+}
+
 // One 32 x 32 tile of SCALED accumulators (acc * scale + shift), staged by the wave in its LDS slice in row order, goes
 // out in ROW layout: lane (row id / 8, channel group id % 8) holds four consecutive channels of one pixel, adds the residual
 // (or applies the mask) from a 16-byte load, applies the ReLU, stores 16 bytes of y -- an instruction covers 8 rows x 128
@@ -207,9 +224,11 @@ __device__ __forceinline__ void out_tile32(const ConvP &p, const unsigned *lds, 
     const uint4 raw = *reinterpret_cast<const uint4 *>(lds + row * PL_STRIDE + 4 * cg);
     float4 v = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
     const bool in = m < p.M && n < p.Cout;
-    if (in && p.res) {
+    if (in && (p.res || p.res_pl)) {
       const int b = fast_div(m, p.fd_howo_mul, p.fd_howo_sh);
-      const float4 rv = *reinterpret_cast<const float4 *>(p.res + (long long)b * p.res_bs + (long long)(m - b * HoWo) * p.Cout + n);
+      // (res_bs: fp32 elements between batch items, 0 = one image for the whole batch; the planes' pixel index follows from it)
+      const float4 rv = p.res_pl ? residual_from_planes(p, (long long)b * (p.res_bs / p.Cout) + (m - b * HoWo), n)
+                                 : *reinterpret_cast<const float4 *>(p.res + (long long)b * p.res_bs + (long long)(m - b * HoWo) * p.Cout + n);
       if (p.flags & SWEM_CONV_MASK_POS) {
         v = make_float4(rv.x > 0.f ? v.x : 0.f, rv.y > 0.f ? v.y : 0.f, rv.z > 0.f ? v.z : 0.f, rv.w > 0.f ? v.w : 0.f);
       } else {
@@ -988,7 +1007,10 @@ __device__ __forceinline__ const ConvP &segment_params(const ConvP &p) {
 // earlier (its fragments are in registers), so a ring of NST stages keeps NST-1 k-blocks in flight under the MFMAs instead of
 // NST-2 + a hand-over in front of them.  16x16x32 MFMA, one or two planes.
 template <int WM, int WN, int NST, int NW, bool M16, int NPL, int KG = 4, bool PF = false, bool SK = false, bool F16 = false>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bf3s_kernel(ConvP p STAMP_ARG) {
+// (second launch bound = resident blocks per CU the register allocation must allow: the 16-k-block tiles (KG == 2) exist to run
+// THREE blocks of four waves per CU -- 168 registers; left at 2 the three-plane instantiation came out at 169 once the epilogue
+// grew by the plane-residual path, and the exact-split leg lost 4 %)
+__global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv_igemm_bf3s_kernel(ConvP p STAMP_ARG) {
   STAMP(0);
   static_assert(!F16 || NPL == 2, "fp16 planes come as a (hi, mid) pair");
   static_assert(KG == 4 || (KG == 2 && !M16 && NW == 4), "16-k blocks: four waves, 32x32x16 MFMA");
@@ -1669,11 +1691,12 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
     v = make_float4(f.x * sigmoidf_(a.x), f.y * sigmoidf_(a.y), f.z * sigmoidf_(a.z), f.w * sigmoidf_(a.w));
   } else {
     v = affine4(sum4(co), co);
-    if (p.res) {
+    if (p.res || p.res_pl) {
       const int HoWo = p.Ho * p.Wo;
       int b = m / HoWo;
-      float4 rv = *reinterpret_cast<const float4 *>(p.res + (long long)b * p.res_bs +
-                                                    (long long)(m - b * HoWo) * p.Cout + co);
+      float4 rv = p.res_pl ? residual_from_planes(p, (long long)b * (p.res_bs / p.Cout) + (m - b * HoWo), co)
+                           : *reinterpret_cast<const float4 *>(p.res + (long long)b * p.res_bs +
+                                                               (long long)(m - b * HoWo) * p.Cout + co);
       if (p.flags & SWEM_CONV_MASK_POS) {
         v = make_float4(rv.x > 0.f ? v.x : 0.f, rv.y > 0.f ? v.y : 0.f, rv.z > 0.f ? v.z : 0.f, rv.w > 0.f ? v.w : 0.f);
       } else {
@@ -1993,6 +2016,9 @@ struct PlaneOut {
   int npl[2];
   unsigned *counters = nullptr;   // optional: caller-owned tile counters, ALL ZERO between calls (swem_conv2d_nhwc_bf16x3_planes_ctr)
   size_t ncounters = 0;
+  const void *res_planes = nullptr;   // optional: the residual as planes (swem_conv2d_nhwc_bf16x3_planes_res)
+  long long res_ps = 0, res_npx = 0;
+  int res_npl = 0;
 };
 // validate the optional output planes and put them into the launch parameters (after p.M / p.Cout are set)
 int set_planes(ConvP &p, const PlaneOut *po, bool glu, const char *who) {
@@ -2055,7 +2081,7 @@ int conv2d_f32_impl(void *stream, const float *x0, int c0, long long bs0, const 
   const bool glu = flags & SWEM_CONV_GLU;
   SWEM_REQUIRE(!glu || (Cout % 32 == 0 && !res), SWEM_E_SHAPE, "conv2d: GLU needs Cout %% 32 == 0 and no residual");
   ConvP p;
-  p.sk_workers = 0; p.sk_mtiles = p.sk_ntiles = 0; p.sk_ws = nullptr; p.sk_flags = nullptr; p.fault = nullptr; p.spin_limit = 1 << 24;
+  p.sk_workers = 0; p.sk_mtiles = p.sk_ntiles = 0; p.sk_ws = nullptr; p.sk_flags = nullptr; p.fault = nullptr; p.spin_limit = 1 << 24; p.res_pl = nullptr; p.res_ps = 0; p.res_npx = 0; p.res_npl = 0;
   p.x[0] = x0; p.x[1] = x1 ? x1 : x0; p.x[2] = x2 ? x2 : x0;
   p.c[0] = c0; p.c[1] = c1; p.c[2] = c2;
   p.bs[0] = bs0; p.bs[1] = bs1; p.bs[2] = bs2;
@@ -2240,6 +2266,21 @@ extern "C" int swem_conv2d_nhwc_bf16x3_planes_ctr(void *stream, const void *x0, 
   return conv2d_bf16x3_impl(stream, x0, c0, bs0, ps0, x1, c1, bs1, ps1, x2, c2, bs2, ps2, B, H, W, w_bf16x3, scale, shift, res,
                             res_bs, y, Cout, KH, KW, stride, pad, flags, plan, ws, ws_bytes, &po);
 }
+// ... and with the RESIDUAL given as operand planes (see include/swem_hip.h)
+extern "C" int swem_conv2d_nhwc_bf16x3_planes_res(void *stream, const void *x0, int c0, long long bs0, long long ps0,
+                                                  const void *x1, int c1, long long bs1, long long ps1, const void *x2, int c2,
+                                                  long long bs2, long long ps2, int B, int H, int W, const void *w_bf16x3,
+                                                  const float *scale, const float *shift, const void *res_planes,
+                                                  long long res_ps, long long res_npx, int res_nplanes, long long res_bs,
+                                                  float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan,
+                                                  void *ws, size_t ws_bytes, void *planes, int nplanes, void *planes_relu,
+                                                  int nplanes_relu, void *counters, size_t ncounters) {
+  PlaneOut po{{planes, planes_relu}, {nplanes, nplanes_relu}, static_cast<unsigned *>(counters), ncounters};
+  po.res_planes = res_planes; po.res_ps = res_ps; po.res_npx = res_npx; po.res_npl = res_nplanes;
+  SWEM_REQUIRE(res_planes, SWEM_E_ARG, "conv2d_bf16x3_planes_res: null residual planes");
+  return conv2d_bf16x3_impl(stream, x0, c0, bs0, ps0, x1, c1, bs1, ps1, x2, c2, bs2, ps2, B, H, W, w_bf16x3, scale, shift, nullptr,
+                            res_bs, y, Cout, KH, KW, stride, pad, flags, plan, ws, ws_bytes, &po);
+}
 // batched GEMM on pre-split planes (common.h): y[b] = x[b] . w[b]^T with per-batch filter planes, w_bs bf16 elements apart
 int swem_gemm_bf16x3_batched(void *stream, const void *x, int K, long long bs, long long ps, int B, int M, const void *w,
                              long long w_bs, float *y, int Ncols, int plan, void *ws, size_t ws_bytes, void *y_planes,
@@ -2268,7 +2309,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   const bool glu = flags & SWEM_CONV_GLU;
   SWEM_REQUIRE(!glu || (Cout % 32 == 0 && !res), SWEM_E_SHAPE, "conv2d_bf16x3: GLU needs Cout %% 32 == 0, no residual");
   ConvP p;
-  p.sk_workers = 0; p.sk_mtiles = p.sk_ntiles = 0; p.sk_ws = nullptr; p.sk_flags = nullptr; p.fault = nullptr; p.spin_limit = 1 << 24;
+  p.sk_workers = 0; p.sk_mtiles = p.sk_ntiles = 0; p.sk_ws = nullptr; p.sk_flags = nullptr; p.fault = nullptr; p.spin_limit = 1 << 24; p.res_pl = nullptr; p.res_ps = 0; p.res_npx = 0; p.res_npl = 0;
   p.x[0] = p.x[1] = p.x[2] = nullptr;
   p.xs[0] = static_cast<const unsigned short *>(x0);
   p.xs[1] = static_cast<const unsigned short *>(x1 ? x1 : x0);
@@ -2307,6 +2348,16 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.f16 = 0; p.xpn = 1;
   if (int prc = set_planes(p, po, glu, "conv2d_bf16x3")) return prc;
   // caller-owned counters: words [0, n - 1) are tile counters / stream-K flags, word n - 1 is the sticky fault word
+  if (po && po->res_planes) {
+    SWEM_REQUIRE(!res && !glu && !(flags & SWEM_CONV_MASK_POS) && Cout % 8 == 0, SWEM_E_ARG,
+                 "conv2d_bf16x3: a plane residual replaces `res` (no GLU, no mask; Cout %% 8 == 0)");
+    SWEM_REQUIRE(po->res_npl == SWEM_PLANES_F16 || po->res_npl == 3, SWEM_E_ARG,
+                 "conv2d_bf16x3: a plane residual is an fp16 pair or three bf16 planes (two bf16 planes carry 16 bits only)");
+    SWEM_REQUIRE(po->res_npx > 0 && po->res_ps >= po->res_npx * (long long)Cout && res_bs % Cout == 0, SWEM_E_ARG,
+                 "conv2d_bf16x3: plane residual geometry");
+    p.res_pl = static_cast<const unsigned short *>(po->res_planes);
+    p.res_ps = po->res_ps; p.res_npx = (int)po->res_npx; p.res_npl = po->res_npl;
+  }
   const size_t nctr = (po && po->counters && po->ncounters >= 2) ? po->ncounters - 1 : 0;
   if (nctr) p.fault = po->counters + nctr;
   {

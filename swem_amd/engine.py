@@ -35,16 +35,21 @@ class _Block:
         if blk.downsample is not None:
             d = blk.downsample
             self.down = ops.pack_conv(d[0].weight, d[0].bias, _bn(d[1]), s, 0)
+        # set by the Engine for every block but the last of its stage: the output is consumed by the next block only -- its
+        # convolutions and its residual add (mod_resnet.py:77-113) -- and may be left as operand planes (ops.conv2d, 'block');
+        # a stage's LAST output is handed to the caller (s4 / s8 / s16) and keeps its fp32 map
+        self.inner = False
 
     def __call__(self, x):
         res = x if self.down is None else ops.conv2d([x], self.down)
+        only = 'block' if self.inner else False
         # (conv1's and conv2's outputs have exactly one consumer, the next convolution: planes-only once it reads planes)
         if self.bottleneck:
             y = ops.conv2d([x], self.c1, relu_out=True, planes_only=True)
             y = ops.conv2d([y], self.c2, relu_out=True, planes_only=True)
-            return ops.conv2d([y], self.c3, relu_out=True, residual=res)
+            return ops.conv2d([y], self.c3, relu_out=True, residual=res, planes_only=only)
         y = ops.conv2d([x], self.c1, relu_out=True, planes_only=True)
-        return ops.conv2d([y], self.c2, relu_out=True, residual=res)
+        return ops.conv2d([y], self.c2, relu_out=True, residual=res, planes_only=only)
 
 
 class _ResBlock:
@@ -90,6 +95,9 @@ class Engine:
         self.k_stem = ops.pack_conv(ke.conv1.weight, None, _bn(ke.bn1), 2, 3, cin_pad=4)
         self.k_stem_s2d = ops.pack_stem_s2d(ke.conv1.weight, None, _bn(ke.bn1))
         self.k_stages = [[_Block(b) for b in st] for st in (ke.res2, ke.layer2, ke.layer3)]
+        for st in self.k_stages:
+            for b_ in st[:-1]:
+                b_.inner = True
         self.key_proj = ops.pack_conv(model.key_proj.key_proj.weight, model.key_proj.key_proj.bias)
         self.key_comp = ops.pack_conv(model.key_comp.weight, model.key_comp.bias)
         # --- value encoder (networks.py:94-129)
@@ -97,6 +105,9 @@ class Engine:
         self.v_stem = ops.pack_conv(ve.conv1.weight, ve.conv1.bias, _bn(ve.bn1), 2, 3, cin_pad=8)
         self.v_stem_s2d = ops.pack_stem_s2d(ve.conv1.weight, ve.conv1.bias, _bn(ve.bn1))
         self.v_stages = [[_Block(b) for b in st] for st in (ve.layer1, ve.layer2, ve.layer3)]
+        for st in self.v_stages:
+            for b_ in st[:-1]:
+                b_.inner = True
         self.fuse1 = _ResBlock(ve.fuser.block1)
         self.fuse2 = _ResBlock(ve.fuser.block2)
         att = ve.fuser.attention

@@ -92,6 +92,9 @@ class PlanBook:
         # down the fp32 path the producer writes the fp32 map again until the consumer has asked anew.
         self._gen = [0]
         self.conv, self.match, self.hints, self.hint_epoch = _Plans(self._gen), _Plans(self._gen), {}, {}
+        # producer site -> epoch at which the convolution that ADDS this tensor as its residual last said it can read the addend
+        # from operand planes (None: it cannot -- an fp32 kernel).  conv2d(planes_only='block') needs it current.
+        self.res_epoch = {}
         # plan hint of a layer shape nobody tuned (0 = the library's heuristic, which picks tile and K-split from the GEMM's
         # size).  A fixed hint without K-split, e.g. 0x111, makes a layer's arithmetic independent of the batch it is called
         # with: every output element is then one k-ordered MFMA chain whatever the grid (tests compare batched and per-frame
@@ -117,6 +120,7 @@ class PlanBook:
         self.match.clear()
         self.hints.clear()
         self.hint_epoch.clear()
+        self.res_epoch.clear()
 
     def math_histogram(self, tag=()):
         """{'fp32': n, 'bf16x6': n, 'bf16': n, 'bf16x3': n, 'f16x3': n} over the conv plans tuned under the conv_math tag `tag`
@@ -623,7 +627,11 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     planes_only: the caller promises that the ONLY consumer of the result is one pre-split convolution (conv1 -> conv2 -> conv3
     inside a ResNet block, conv1 -> conv2 of a ResBlock).  Once that consumer has asked for the planes (BOOK.hints, from the
     second frame on) the fp32 map is not written at all -- half the output bytes of such a layer, which is what bounds the
-    64-channel and 1x1 layers -- and the returned tensor only carries the planes; any other use of it raises."""
+    64-channel and 1x1 layers -- and the returned tensor only carries the planes; any other use of it raises.
+    planes_only='block' (round 4): the result is a ResNet block's output inside a stage -- its consumers are the next block's
+    convolutions (planes, without an input ReLU) AND the next block's residual add (mod_resnet.py:77-113).  The map is left out
+    once the convolution that adds it has also said, for the current plans, that it reads the addend from the planes
+    (BOOK.res_epoch): a third of the bytes of the byte-bound 1x1 expansion layers.  `residual` may then be such a tensor."""
     x0 = _chk_src(srcs[0])
     B = batch if batch is not None else max(s.shape[0] for s in srcs)
     _, H, W, _ = x0.shape
@@ -658,8 +666,21 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         residual, flags = mask, flags | MASK_POS
     y = out
     res_bs = 0
+    res_planes = None          # (planes tensor, plane code) of a planes-only residual
     if residual is not None:
-        _chk(residual, 'conv residual')
+        if residual.__dict__.get('_swem_planes_only'):
+            ent = None
+            for npl_ in (PLANES_F16, 3):          # (two bf16 planes carry 16 bits: not an addend)
+                e_ = residual.__dict__.get('_swem_split', {}).get(_pkey(False, npl_))
+                if e_ is not None and (npl_ == PLANES_F16 or e_[1] == 3):
+                    ent = (e_[0], npl_)
+                    break
+            if ent is None or mask is not None or pack.glu:
+                raise _lib.SwemHipError('conv2d: the residual is a planes-only block output without planes an addend can be read '
+                                        'from (an fp16 pair or three bf16 planes), or this call cannot take a plane residual')
+            res_planes = ent
+        else:
+            _chk(residual, 'conv residual')
         res_bs = 0 if (res_broadcast or (residual.shape[0] == 1 and B > 1)) else Ho * Wo * pack.cout
 
     pipe_ok = all(s_.shape[3] % 32 == 0 for s_ in srcs)      # (the register-staged kernels' condition, conv.hip)
@@ -671,6 +692,12 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     want = BOOK.hints.get(site) if (FUSE_SPLIT and dgrad is None and pack.cout % 8 == 0) else None
     planes = {}
     skip_y = bool(planes_only and want and out is None and PLANES_ONLY and BOOK.hint_epoch.get(site) == BOOK.epoch())
+    if skip_y and planes_only == 'block':
+        # ... and the adding convolution reads planes, and planes of the values themselves (no input ReLU) in a format an
+        # addend can come from are among those this launch writes
+        # (fp16 pair only: from three bf16 planes the addend costs 6 bytes per element against the map's 4, and the exact-split
+        # leg measured 4 % SLOWER with it -- the C ABI takes them, this policy does not use them)
+        skip_y = BOOK.res_epoch.get(site) == BOOK.epoch() and want.get(False) == PLANES_F16
     if y is None:
         # a planes-only output has no fp32 map at all: the tensor that carries its planes is one NaN expanded to the shape
         # (no allocation of the map; anything that reads it by accident sees NaN, _chk / _chk_src refuse it by its flag)
@@ -708,13 +735,20 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
             for _ in range(3 - len(srcs)):
                 sargs += [0, 0, 0, 0]
             ctr = counters(x0.device)
+            if res_planes is not None:
+                rp, rnpl = res_planes
+                _lib.call('swem_conv2d_nhwc_bf16x3_planes_res', _stream(), *sargs, B, H, W, w3.data_ptr(), _ptr(scale),
+                          _ptr(pack.shift), rp.data_ptr(), rp.stride(0), rp.stride(0) // pack.cout, rnpl, res_bs, y_ptr,
+                          pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags & ~RELU_IN, plan, _ptr(ws), wsb, *pargs,
+                          _ptr(ctr), 0 if ctr is None else ctr.numel())
+                return
             _lib.call('swem_conv2d_nhwc_bf16x3_planes_ctr', _stream(), *sargs, B, H, W, w3.data_ptr(), _ptr(scale),
                       _ptr(pack.shift), _ptr(residual), res_bs, y_ptr, pack.cout, pack.kh, pack.kw,
                       pack.stride, pack.pad, flags & ~RELU_IN, plan, _ptr(ws), wsb, *pargs, _ptr(ctr),
                       0 if ctr is None else ctr.numel())
             return
-        if any(s_.__dict__.get('_swem_planes_only') for s_ in srcs):
-            raise _lib.SwemHipError('conv2d: a planes-only source reached a convolution that reads the fp32 map (plan %#x)' % plan)
+        if res_planes is not None or any(s_.__dict__.get('_swem_planes_only') for s_ in srcs):
+            raise _lib.SwemHipError('conv2d: a planes-only source or residual reached a convolution that reads the fp32 map (plan %#x)' % plan)
         _lib.call('swem_conv2d_nhwc_f32_planes', _stream(), *args, B, H, W, pack.w.data_ptr(), 0, _ptr(pack.scale),
                   _ptr(pack.shift), _ptr(residual), res_bs, y_ptr, pack.cout, pack.kh, pack.kw, pack.stride,
                   pack.pad, flags, plan, _ptr(ws), wsb, *pargs)
@@ -733,6 +767,12 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
                 # (a fallback that names a tile is a decision -- batch-invariant plans -- and is not tuned over)
                 plan = BOOK.conv[sig] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
                                                     -(-pack.kh * pack.kw * cin // 32), pack.glu, fresh_kw=True)
+    if residual is not None and mask is None and not _IN_TUNER[0]:
+        rsite = residual.__dict__.get('_swem_site')
+        if rsite is not None:
+            # (this convolution adds a tensor some producer made: tell that producer whether the addend may come from planes --
+            # it may when this launch runs the pre-split kernel, which is the only one with that path)
+            BOOK.res_epoch[rsite] = BOOK.epoch() if ((plan >> 16) & 3 and presplit_ok and not pack.glu) else None
     if CONV_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

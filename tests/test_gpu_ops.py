@@ -747,3 +747,53 @@ ops.check_faults()                                            # reset: clean aga
     ops.check_faults()
     assert int(ops.counters(x.device).abs().sum()) == 0
     close(y.cpu(), ref.cpu(), 1e-5, 'fused K-split')
+
+
+@pytest.mark.parametrize('plan', [0x70011, 0x70022, 0x670022, 0x70221, 0x4070021, 0x470012], ids=lambda p: '%#x' % p)
+def test_conv2d_block_output_as_planes_and_plane_residual(lib, plan):
+    """Two chained ResNet-style blocks (mod_resnet.py:77-113: out = relu(conv(x) + identity)): with planes_only='block' the FIRST
+    block's output is written as operand planes only once both of its consumers in the second block -- the convolution that reads
+    it (planes) and the convolution that ADDS it (swem_conv2d_nhwc_bf16x3_planes_res: the addend read back from the planes) -- have
+    asked, for the current plans.  The addend is hi + mid of the fp16 pair (22-23 bits of the fp32 value): the second block's output
+    stays within 2e-6 of the all-fp32-map run.  A consumer on the fp32 kernels or a plan change withdraw the promise.  (The entry
+    point also takes three bf16 planes -- the value exactly; the policy does not use them: 6 bytes per element against the map's 4
+    made the exact-split leg slower -- checked here through the C ABI directly.)"""
+    from swem_amd import _lib
+    g = torch.Generator().manual_seed(17)
+    B, C, H, W = 2, 64, 21, 37
+    x = nhwc(torch.randn(B, C, H, W, generator=g))
+    mk = lambda: ops.pack_conv((torch.randn(C, C, 3, 3, generator=g) * 0.05).to(DEV), (torch.randn(C, generator=g) * 0.1).to(DEV))
+    pa, pb, pc = mk(), mk(), mk()
+    book = ops.PlanBook(fallback=plan)
+
+    def two_blocks(only):
+        y1 = ops.conv2d([x], pa, relu_out=True, residual=x, planes_only=only)          # block 1: relu(conv(x) + x)
+        t = ops.conv2d([y1], pb, relu_out=True, planes_only=True)                      # block 2, conv1 reads y1
+        y2 = ops.conv2d([t], pc, relu_out=True, residual=y1)                           # block 2, conv2 adds y1
+        return y1, y2
+    exact = False
+    with ops.use_book(book):
+        y1_ref, y2_ref = two_blocks(False)           # frame 1: everything written; both consumers of y1 have asked
+        assert not y1_ref.__dict__.get('_swem_planes_only')
+        y1_b, y2_b = two_blocks('block')             # frame 2: planes only
+        assert y1_b.__dict__.get('_swem_planes_only') and bool(torch.isnan(y1_b).all())
+        if exact:
+            assert torch.equal(y2_b, y2_ref)
+        else:
+            close(back(y2_b), back(y2_ref), 2e-6, 'second block, addend from the fp16 pair, plan %#x' % plan)
+            assert not torch.equal(y2_b, y2_ref)     # (really the plane path: the addend differs in its last bit or two)
+        with pytest.raises(_lib.SwemHipError):
+            ops.conv2d([t_ := ops.conv2d([y1_b], pb, relu_out=True)], pc, residual=y1_b, plan=0x11)    # an fp32-kernel adder: loud
+        book.fallback = plan ^ 0x100                 # a plan change: written again until both consumers have asked anew
+        y1_c, _ = two_blocks('block')
+        assert not y1_c.__dict__.get('_swem_planes_only')
+        assert two_blocks('block')[0].__dict__.get('_swem_planes_only')
+    # the adding convolution on the fp32 kernels (its own tuned plan says so) never says it can read planes: no promise, ever
+    book2 = ops.PlanBook(fallback=plan)
+    book2.conv[(C, C, 3, 3, 1, 1, 0, B, H, W)] = 0x11           # (the adder below: no output ReLU, hence its own signature)
+    with ops.use_book(book2):
+        for _ in range(3):
+            y1_d = ops.conv2d([x], pa, relu_out=True, residual=x, planes_only='block')
+            t = ops.conv2d([y1_d], pb, relu_out=True, planes_only=True)
+            ops.conv2d([t], pc, residual=y1_d)
+            assert not y1_d.__dict__.get('_swem_planes_only')
