@@ -262,10 +262,9 @@ def main():
     torch.cuda.set_device(local_rank)        # before the RCCL communicator is created
     dev = torch.device('cuda', local_rank)
     sdist.init()
-    if world > 1:
-        # the ranks of a node share one container's CPU quota (16 CPUs per 100 ms on this pool): a rank's torch CPU ops (clip
-        # synthesis, weight fill) must not wake a 128-thread pool each -- a burnt quota stalls every thread of every rank
-        torch.set_num_threads(max(1, min(torch.get_num_threads(), 16 // world)))
+    # the ranks of a node share one container's CPU quota (16 CPUs per 100 ms on this pool): a rank's torch CPU ops (clip
+    # synthesis, weight fill) must not wake a 128-thread pool each -- a burnt quota stalls every thread of every rank
+    sdist.respect_cpu_quota(world)
     ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     if ranks != args.gpus:
         raise SystemExit('--gpus %d but the process group has %d ranks' % (args.gpus, ranks))

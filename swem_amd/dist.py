@@ -142,3 +142,25 @@ def allreduce_sum_async(t, bucket_bytes=64 << 20, mean=False):
         t.div_(dist.get_world_size())
     n = max(1, bucket_bytes // t.element_size())
     return [dist.all_reduce(t[i:i + n], op=dist.ReduceOp.SUM, async_op=True) for i in range(0, t.numel(), n)]
+
+
+def respect_cpu_quota(ranks=1):
+    """Size torch's intra-op CPU pool by what the CONTAINER may use, not by the host's logical CPUs.  torch starts one OpenMP
+    thread per logical CPU (128-256 on the GPU hosts of this pool) and the threads busy-wait between ops; under a cgroup CPU
+    quota (cpu.max, e.g. 16 CPUs per 100 ms period) a single torch CPU op of a few hundred KB then burns the period's budget and
+    the kernel stalls EVERY thread of the process until the next period -- the thread feeding the GPU included (the bimodal
+    training rate of rounds 1-3).  Call once at start-up of a driver script (bench.py, tools/train_bench.py,
+    tests/conftest.py do); `ranks` = processes sharing the container.  Returns the thread count now in force."""
+    import torch
+    n = torch.get_num_threads()
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, per = f.read().split()[:2]
+        if q != 'max':
+            n = max(1, min(n, int(int(q) / int(per)) // max(1, int(ranks))))
+    except (OSError, ValueError):
+        pass
+    if hasattr(os, 'sched_getaffinity'):
+        n = max(1, min(n, len(os.sched_getaffinity(0)) // max(1, int(ranks))))
+    torch.set_num_threads(n)
+    return n

@@ -15,14 +15,8 @@ def pytest_configure(config):
     # this pool) while the container may use 16 of them per 100 ms (cgroup cpu.max): a 128-thread pool burns that budget in
     # milliseconds and the kernel then stalls the whole process for the rest of every period (training row).
     # One thread per CPU of the quota is all the oracle can use anyway.
-    try:
-        import torch
-        with open('/sys/fs/cgroup/cpu.max') as f:
-            q, per = f.read().split()[:2]
-        if q != 'max':
-            torch.set_num_threads(max(1, min(torch.get_num_threads(), int(int(q) / int(per)))))
-    except (OSError, ValueError, ImportError):
-        pass
+    from swem_amd import dist as sdist
+    sdist.respect_cpu_quota()
 
 
 @pytest.fixture(scope='session')

@@ -46,6 +46,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     sdist.init()
+    sdist.respect_cpu_quota(world)
     cfg = SimpleNamespace(KEYDIM=128, VALDIM=512, NUM_BASES=256, NUM_EM_ITERS=4, EM_TAU=0.05, TOPL=64, SINGLE_OBJ=False,
                           BACKBONE=a.backbone)
     model = SWEM(cfg)
