@@ -617,7 +617,7 @@ class SequencePool:
         for m in self.models[1:]:            # the lanes run the same layers on the same shapes: one PlanBook for all of them
             m.book = self.models[0].book
         # plans='shipped' (default): a pool whose book holds no tuned conv plan yet loads the plan file that ships with the
-        # library (swem_amd/plans/: 480p, K = 256, 1 / 2 / 3 / 5 objects on MI355X) -- layer shapes it does not hold run the
+        # library (swem_amd/plans/: 480p, K = 256, 1-5 objects on MI355X) -- layer shapes it does not hold run the
         # book's fallback (f16x3 on the heuristic tile).  plans=None: the book as it is; a path: that file.
         book = self.models[0].book
         if plans is not None and not book.conv:

@@ -110,7 +110,7 @@ def test_reference_loop_throughput_at_480p(lib):
 def test_pool_defaults_on_a_three_object_sequence(lib):
     """A maintainer's first run (missing 5 / weak 12): `SWEM(cfg)` as constructed -- no plan loaded by hand, no
     tuner -- in a `SequencePool` with its defaults, on a 480p sequence with THREE objects.  The pool loads the shipped plan
-    file, which holds the 1 / 2 / 3 / 5-object shapes; what it does not hold runs the book's fallback (f16x3 on the heuristic
+    file, which holds the 1-5-object shapes; what it does not hold runs the book's fallback (f16x3 on the heuristic
     tile), never the exact-fp32 kernels: counted per launch.  The three-object rate is that of the two-object workload scaled
     by the frames' algorithmic FLOPs, within 15 %."""
     from swem_amd import evaluator, synth, weights

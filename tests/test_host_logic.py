@@ -184,7 +184,7 @@ def test_shipped_plan_file_is_well_formed():
         assert wm in (1, 2) and wn in (1, 2) and 1 <= ns <= 255, (k, hex(v))
         assert math in ((0, 1) if len(k) == 13 else (0, 1, 7)), (k, hex(v))     # (7 = f16x3: math 3 + SWEM_PLAN_F16)
         cin, cout, kh, kw, stride, pad, flags, B, H, W = k[:10]
-        assert cin > 0 and cout % 4 == 0 and kh == kw and stride in (1, 2) and B in (1, 2, 3, 4, 5)    # 1 / 2 / 3 / 5 objects, look-ahead 4
+        assert cin > 0 and cout % 4 == 0 and kh == kw and stride in (1, 2) and B in (1, 2, 3, 4, 5)    # 1-5 objects, look-ahead 4
     hist, hist32 = book.math_histogram(), book.math_histogram(('math', 0, 1))
     # the default leg: f16x3 nearly everywhere, never a 16-bit or 8-bit operand mode; the exact-split leg: fp32 MFMA / bf16x6
     assert hist['f16x3'] >= 50 and hist['bf16'] == hist['bf16x3'] == 0 and sum(hist.values()) == len(untagged)
@@ -296,3 +296,33 @@ def test_launch_ranks_timeout_takes_the_whole_job_down(tmp_path):
     for pid in pids:
         alive = os.path.exists('/proc/%d' % pid) and 'Z' not in open('/proc/%d/stat' % pid).read().split()[2]
         assert not alive, 'rank process %d survived the timeout' % pid
+
+
+def test_cpu_pool_is_sized_by_the_container_quota(tmp_path, monkeypatch):
+    """dist.respect_cpu_quota: torch's intra-op pool follows the cgroup quota (cpu.max) and the affinity mask, divided by the
+    ranks that share the container; train.one_cpu_thread restores the count it found."""
+    import builtins
+    import torch
+    from swem_amd import dist as sdist, train
+    before = torch.get_num_threads()
+    real_open = builtins.open
+    quota = tmp_path / 'cpu.max'
+    quota.write_text('400000 100000\n')          # 4 CPUs per 100 ms
+
+    def fake_open(path, *a, **k):
+        return real_open(str(quota) if path == '/sys/fs/cgroup/cpu.max' else path, *a, **k)
+    try:
+        monkeypatch.setattr(builtins, 'open', fake_open)
+        torch.set_num_threads(max(before, 4))
+        assert sdist.respect_cpu_quota() == min(4, torch.get_num_threads()) <= 4
+        assert sdist.respect_cpu_quota(ranks=2) <= 2 and sdist.respect_cpu_quota(ranks=64) == 1
+        quota.write_text('max 100000\n')
+        torch.set_num_threads(3)
+        assert sdist.respect_cpu_quota() <= 3        # no quota: never MORE threads than before
+        monkeypatch.undo()
+        torch.set_num_threads(before)
+        with train.one_cpu_thread():
+            assert torch.get_num_threads() == 1
+        assert torch.get_num_threads() == before
+    finally:
+        torch.set_num_threads(before)
