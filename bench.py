@@ -222,9 +222,10 @@ def main():
     ap.add_argument('--pipeline', choices=('auto', 'on', 'off'), default='auto',
                     help='software-pipelined frame graph (evaluator.PipelinedFrameGraph): +12 %% with one sequence, -10 %% with several '
                          '(their streams already fill the hardware queues); auto = on for --seqs 1 only')
-    ap.add_argument('--lookahead', type=int, default=4,
+    ap.add_argument('--lookahead', type=int, default=-1,
                     help='frames per graph replay with the key encoder batched over them (evaluator.LookaheadGraph); 0 = one frame '
-                         'per replay')
+                         'per replay; default: the divisor of --steps nearest to 8 (the timed region then holds exactly --steps '
+                         'frames per sequence: 10 for 20 or 100 steps, 8 for 24 / 40 / 48), else 4')
     ap.add_argument('--seqs', type=int, default=4,
                     help='independent sequences processed concurrently per GPU, each on its own HIP stream')
     ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
@@ -242,6 +243,10 @@ def main():
     ap.add_argument('--object-legs', type=int, nargs='*', default=[1, 3],
                     help='extra single-sequence legs at these object counts, both arithmetics (default 1 3; empty: none)')
     args = ap.parse_args()
+    if args.lookahead < 0:
+        # a longer look-ahead batches the key encoder further (8-10 frames: + 2-3 % over 4, profiles/r04_lookahead_sweep.txt); the
+        # replay granularity must divide the timed steps, or the region would hold up to k - 1 frames of work it does not count
+        args.lookahead = next((k for k in (8, 10, 6, 12, 5, 4) if args.steps % k == 0), 4)
 
     from swem_amd import dist as sdist
     rank, local_rank, world = sdist.env_world()

@@ -611,7 +611,7 @@ class SequencePool:
     frame chains), the last frames of a sequence that do not fill a group eagerly.  lookahead = 0: one frame per replay
     (FrameGraph; a pool of one model then runs the software-pipelined PipelinedFrameGraph)."""
 
-    def __init__(self, models, use_graph=True, lookahead=4, plans='shipped'):
+    def __init__(self, models, use_graph=True, lookahead=8, plans='shipped'):
         self.models = list(models)
         n = len(self.models)
         for m in self.models[1:]:            # the lanes run the same layers on the same shapes: one PlanBook for all of them
