@@ -1858,12 +1858,16 @@ int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st, int *occ = nullptr)
     swem_set_error("conv2d_bf16x3: this kernel variant has no stream-K form");
     return SWEM_E_ARG;
   }
+  // (SWEM_ISA_SUBSET: tests/test_abi.py compiles this file to assembly to check the LDS-DMA kernels' use of M0; a fifth of the
+  // instantiations -- every tile, the two-plane kernels of both operand formats, no stream-K -- keeps that check to a minute)
+#ifndef SWEM_ISA_SUBSET
   if (p.nplanes == 1) {   // plain bf16 (one plane, one product): a third of the LDS, the same tiles
     if constexpr (SKOK) {
       if (sk) return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 1, true>(p, grid, st, occ);
     }
     return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 1, false>(p, grid, st, occ);
   }
+#endif
   if (p.nplanes == 2 && p.f16) {   // "f16x3": the same kernel on fp16 (hi, mid) planes and the f16 MFMA
     if (sk) {
       if (occ) {
@@ -1876,17 +1880,20 @@ int launch_bf3s_n(const ConvP &p, dim3 grid, hipStream_t st, int *occ = nullptr)
     return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 2, false, true>(p, grid, st, occ);
   }
   if (p.nplanes == 2) {   // "bf16x3": hi and mid planes, three products (hi.hi + hi.mid + mid.hi): two thirds of the LDS
+#ifndef SWEM_ISA_SUBSET
     if constexpr (SKOK) {
       if (sk) return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 2, true>(p, grid, st, occ);
     }
+#endif
     return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 2, false>(p, grid, st, occ);
   }
+#ifndef SWEM_ISA_SUBSET
   if constexpr (NST <= 3 && !PF) {
     return launch_bf3s_one<WM, WN, NST, NW, M16, KG, PF, 3, false>(p, grid, st, occ);
-  } else {
-    swem_set_error("conv2d_bf16x3: four-stage rings and prefetched fragments need at most two planes");
-    return SWEM_E_ARG;
   }
+#endif
+  swem_set_error("conv2d_bf16x3: four-stage rings and prefetched fragments need at most two planes");
+  return SWEM_E_ARG;
 }
 
 // variant (plan bits 20-23): 0 = the tile's default; 1 = three LDS stages instead of two (or two instead of three);
@@ -1897,6 +1904,7 @@ int launch_bf3s(const ConvP &p, dim3 grid, hipStream_t st, int variant, int *occ
   // deeper rings (round 2): with two planes a stage is 33 KB for the 128x128 tile, so FOUR stages fit; the k-loop of every
   // tile was bound by the L2 / Infinity-Cache -> LDS latency of the one or two k-blocks in flight (in-kernel stamps,
   // tools/conv_stamps.py: 2600 cycles per k-block against 768 of MFMA on the 128x128 tile, 830 against 192 on 64x64)
+#ifndef SWEM_ISA_SUBSET
   if (p.nplanes <= 2) {
     if constexpr (WM == 2 && WN == 2) {
       if (variant == 12) return launch_bf3s_n<2, 2, 4, 8>(p, grid, st, occ);
@@ -1912,13 +1920,16 @@ int launch_bf3s(const ConvP &p, dim3 grid, hipStream_t st, int variant, int *occ
     if (variant == 10) return launch_bf3s_n<WM, WN, 4, 4>(p, grid, st, occ);
     if (variant == 11) return launch_bf3s_n<WM, WN, 4, 4, true>(p, grid, st, occ);
   }
+#endif
   if constexpr (WM == 2 && WN == 2) {
+#ifndef SWEM_ISA_SUBSET
     if (variant == 14) return launch_bf3s_n<2, 2, 3, 8, true>(p, grid, st, occ);
     if (variant == 2) return launch_bf3s_n<2, 2, 2, 8>(p, grid, st, occ);
     if (variant == 3) return launch_bf3s_n<2, 2, 3, 8>(p, grid, st, occ);
+    if (variant == 9) return launch_bf3s_n<2, 2, 3, 4, false, 2>(p, grid, st, occ);   // ... three stages: two blocks per CU
+#endif
     if (variant == 6) return launch_bf3s_n<2, 2, 2, 8, true>(p, grid, st, occ);
     if (variant == 8) return launch_bf3s_n<2, 2, 2, 4, false, 2>(p, grid, st, occ);   // 16-k blocks: three blocks per CU
-    if (variant == 9) return launch_bf3s_n<2, 2, 3, 4, false, 2>(p, grid, st, occ);   // ... three stages: two blocks per CU
   }
   if (variant == 4)
     return (WM * WN == 1) ? launch_bf3s_n<WM, WN, 3, 4, true>(p, grid, st, occ) : launch_bf3s_n<WM, WN, 2, 4, true>(p, grid, st, occ);
