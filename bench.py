@@ -65,6 +65,15 @@ def em_flops_executed_per_frame(n, P=1620, L=256, C=128, V=512, T=5, Lm=512):
     return n * (4.0 * P * L * (C * 2 * T + V) + 4.0 * Lm * P * (C + V))
 
 
+def em_ideal_seconds_executed(n, P=1620, L=256, C=128, V=512, T=5, Lm=512, readout_f16=True):
+    """Time of the EXECUTED EM + matching FLOPs of one frame at the peak of the pipe each GEMM runs on: the value readout
+    (4 Lm P V per object, 3.4 GFLOP at N = 2) runs as an f16x3 GEMM on the pre-split conv kernel -- ceiling 2500 / 3 TFLOP/s --
+    everything else on the fp32 matrix pipe (157.3).  VERDICT r04 item 3c: dividing the readout by the fp32 peak flattered it."""
+    readout = n * 4.0 * Lm * P * V
+    rest = em_flops_executed_per_frame(n, P, L, C, V, T, Lm) - readout
+    return rest / (FP32_MATRIX_PEAK_TFLOPS * 1e12) + readout / ((BF16X3_PEAK_TFLOPS if readout_f16 else FP32_MATRIX_PEAK_TFLOPS) * 1e12)
+
+
 class FrameRunner:
     """Steady-state frame loop over a pre-staged clip (frames cycle; the memory keeps evolving)."""
 
@@ -213,6 +222,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--regions', type=int, default=7,
+                    help='how many times the timed region of --steps steps is run back to back (each bracketed by barrier + '
+                         'synchronize, max over ranks): `value` is the MEDIAN region, value_min / value_max the spread (one region '
+                         'of 20 steps is 0.17 s: box-to-box and run-to-run noise of +-4 %% otherwise decides the line)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--objects', type=int, default=N_OBJ)
     ap.add_argument('--no-autotune', action='store_true')
@@ -365,6 +378,15 @@ def main():
         sdist.barrier()
         return sdist.reduce_counters(steps * len(rs), elapsed, device=dev)
 
+    def timed_median(rs, sts, steps):
+        """--regions timed regions back to back -> (frames of one region, the MEDIAN region's seconds, frames/s of every
+        region in run order).  Every region is the contract's: exactly `steps` steps between barrier + synchronize, max over
+        ranks; the median is taken over the regions' max-over-ranks times (every rank computes the same list)."""
+        regs = [timed(rs, sts, steps) for _ in range(max(1, args.regions))]
+        ts = sorted(t for _, t in regs)
+        med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+        return regs[0][0], med, [round(f / t, 3) for f, t in regs]
+
     pipelined = args.pipeline == 'on' or (args.pipeline == 'auto' and nseq == 1)
     main_tag, pmc_tag = (), ''
     if args.math_modes:
@@ -381,8 +403,8 @@ def main():
         book.save(args.save_plans)
     hist = book.math_histogram(main_tag)
 
-    # ---------------- timed region: exactly K steps between barrier + synchronize
-    total_frames, max_t = timed(runners, streams, args.steps)
+    # ---------------- timed region: exactly K steps between barrier + synchronize, --regions times; the median region counts
+    total_frames, max_t, region_fps = timed_median(runners, streams, args.steps)
 
     def launch_text(pipe_):
         if args.no_graph:
@@ -406,6 +428,10 @@ def main():
             'metric': 'frames/sec (480p, K=256 bases, multi-object SWEM inference)', 'value': round(fps, 3),
             'unit': 'frames/s', 'n_gpus': world, ranks_key: ranks, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * max_t / args.steps, 3), 'ms_per_frame': round(1e3 * max_t / total_frames * world, 3),
+            'timed_regions': len(region_fps), 'value_min': min(region_fps), 'value_max': max(region_fps),
+            'value_regions': region_fps,
+            'value_note': 'value = frames of one region of --steps steps / the MEDIAN region time over --regions back-to-back regions '
+                          '(each: barrier + synchronize on both sides, max over ranks); ms_per_step = that median / steps',
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
             # what the arithmetic IS (not a precision claim): storage and accumulation are fp32 everywhere, the convolutions'
@@ -631,8 +657,9 @@ def main():
     # reference enters the products), same steps, same clock; the second leg with its own roofline and single-sequence figure
     def single_leg(seed_base, n_objects=n_obj, tune_=tune):
         r1, s1 = make_runners(1, args.pipeline != 'off', seed_base, tune=tune_, n_obj=n_objects)
-        f1, t1 = timed(r1, s1, args.steps)
-        d = {'value': round(f1 / t1, 3), 'unit': 'frames/s', 'ms_per_frame': round(1e3 * t1 / f1 * world, 3), 'steps': args.steps,
+        f1, t1, reg1 = timed_median(r1, s1, args.steps)
+        d = {'value': round(f1 / t1, 3), 'value_min': min(reg1), 'value_max': max(reg1), 'timed_regions': len(reg1),
+             'unit': 'frames/s', 'ms_per_frame': round(1e3 * t1 / f1 * world, 3), 'steps': args.steps,
              'sequences_per_gpu': 1, 'objects': n_objects, 'launch': launch_text(args.pipeline != 'off')}
         del r1, s1
         return d
@@ -648,9 +675,10 @@ def main():
             have32 = any(k_[-3:] == ('math', 0, 1) for k_ in book.conv)
             tune32 = tune or (not args.no_autotune and not have32)
             r32, s32 = make_runners(nseq, pipelined, 3234, tune=tune32)
-            f32_, t32 = timed(r32, s32, args.steps)
+            f32_, t32, reg32 = timed_median(r32, s32, args.steps)
             h32 = book.math_histogram(('math', 0, 1))
-            leg = {'value': round(f32_ / t32, 3), 'unit': 'frames/s', 'ms_per_frame': round(1e3 * t32 / f32_ * world, 3),
+            leg = {'value': round(f32_ / t32, 3), 'value_min': min(reg32), 'value_max': max(reg32), 'timed_regions': len(reg32),
+                   'unit': 'frames/s', 'ms_per_frame': round(1e3 * t32 / f32_ * world, 3),
                    'steps': args.steps, 'sequences_per_gpu': nseq, 'conv_layer_shapes_by_math': {k_: v_ for k_, v_ in h32.items() if v_},
                    'dtype': 'f32 storage + accumulate; conv operands fp32 (v_mfma_f32_32x32x2_f32) or bf16x6 (exact 3-way bf16 split = '
                             '24 significant bits, 6 MFMA products)',
@@ -666,6 +694,9 @@ def main():
                 leg['single_sequence_fps'] = leg['single_sequence']['value']
         if rank == 0:
             out['fp32_level'] = leg
+            # (the headline runs on 22-23 operand bits; the figure at all 24 bits belongs next to it, at top level)
+            out['exact_split_fps'] = leg['value']
+            out['exact_split_single_sequence_fps'] = leg.get('single_sequence_fps')
             # both arithmetics side by side at top level (a reader must not mistake one leg for the other)
             out['value_by_arithmetic'] = {
                 'f16x3 (shipped plans; fp16 hi+mid operands, 22-23 significant bits; error against float64 = the fp32 kernels\', '
@@ -806,8 +837,17 @@ def main():
             em['achieved'], em['frac'] = mine[0]['achieved'], mine[0]['frac']
             em['frac_executed_flops'] = round(mine[0]['frac'] * ex_ratio, 4)
             # the headline of this object: ONE sequence alone, on the FLOPs the kernels really issue
+            f16_readout = any((v >> 16) & 3 == 3 for v in book.match.values()) or (book.fallback >> 16) & 3 == 3
+            ideal_us = 1e6 * em_ideal_seconds_executed(n_obj, readout_f16=f16_readout)
             em['headline'] = {'frac_executed_flops_one_sequence': round(one['frac'] * ex_ratio, 4),
-                              'frac_algorithmic_flops_one_sequence': one['frac'], 'us_per_frame_one_sequence': one['us_per_round']}
+                              'frac_algorithmic_flops_one_sequence': one['frac'], 'us_per_frame_one_sequence': one['us_per_round'],
+                              # every GEMM against the peak of the pipe it runs on (the readout: f16x3, 833 TFLOP/s)
+                              'frac_of_blended_ceiling_one_sequence': round(ideal_us / one['us_per_round'], 4),
+                              'us_per_frame_at_pipe_peaks': round(ideal_us, 1),
+                              'note': 'frac_executed_flops_one_sequence divides ALL executed FLOPs by the fp32 matrix peak (round 3-4 '
+                                      'definition, kept for continuity); the value readout (%.1f of the %.1f executed GFLOP) runs on the '
+                                      'f16 pipe: frac_of_blended_ceiling prices it there and is the honest figure'
+                                      % (n_obj * 4.0 * 512 * 1620 * 512 / 1e9, em_flops_executed_per_frame(n_obj) / 1e9)}
             em['flops_note'] = ('frac = ALGORITHMIC FLOPs (the 3T - 1 key GEMMs of the reference + the value GEMM per memorize) / time / '
                                 'fp32 matrix peak; frac_executed_flops counts what the kernels issue (E and W steps share one '
                                 'GEMM: 2T key GEMMs), %.3f of the algorithmic figure' % ex_ratio)

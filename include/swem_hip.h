@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SWEM_ABI_VERSION 1
+#define SWEM_ABI_VERSION 2   /* round 5: explicit fault-word arguments (see "Asynchronous faults") */
 
 enum {
   SWEM_OK = 0,
@@ -43,7 +43,9 @@ enum {
 /* conv flags */
 enum {
   SWEM_CONV_RELU_IN = 1,  /* relu applied to the input while loading (ResBlock, networks.py:26-27) */
-  SWEM_CONV_RELU_OUT = 2, /* relu after scale/shift/residual */
+  SWEM_CONV_RELU_OUT = 2, /* relu after scale/shift/residual.  Both ReLUs are `v_max_f32 0, x` (IEEE maxNum): a NaN maps to 0,
+                           * like ATen's clamp-based ReLU on finite activations -- a NaN that an out-of-range fp16 operand pair
+                           * produced is therefore NOT visible in the output; SWEM_FAULT_RANGE reports it at its source */
   SWEM_CONV_GLU = 4,      /* two filter banks f,a: y = f * sigmoid(a) (modules.py:25-26) */
   /* training (swem_hip_train.h): the same kernels compute the DATA GRADIENT of a convolution.  x = dY [B][H][W][c],
    * w = the filters transposed to [Cin][KH][KW][Cout], Cout(arg) = Cin; the output is dX with the forward input's size
@@ -101,8 +103,11 @@ int swem_split_bf16x3_f32(void *stream, const float *x, void *out, long long npi
  * x = hi + mid, round-to-nearest residual: 11 + 11 significant bits and the residual's sign, i.e. x to half an fp32 ulp
  * wherever |x| >= 2^-2 (mid a normal fp16 number), to 2^-25 absolute below (mid subnormal; the converter and the f16 MFMA
  * keep subnormals).  |x| must stay below 65520, the fp16 range -- the range the reference's own mixed-precision mode
- * (fp16 autocast, basic_trainer.py:83-86) runs these activations in; beyond it the planes hold inf and the convolution
- * returns NaN (loud), never a silently wrong number.
+ * (fp16 autocast, basic_trainer.py:83-86) runs these activations in, but NOT the reference's fp32 inference
+ * (networks.py:22-32 has no range limit).  Beyond it the planes hold inf / NaN, and a consumer's ReLU epilogue
+ * (v_max_f32 0, x) maps the resulting NaN accumulators to 0 -- a finite, wrong feature map.  Therefore EVERY producer of
+ * an fp16 pair takes a `fault` word and ORs SWEM_FAULT_RANGE into it when a value it splits has |x| >= 65520 (inf and NaN
+ * included; tested on the value that is split, i.e. behind an input / output ReLU): see "Asynchronous faults" below.
  * Everywhere this header takes a plane count (`nplanes`: 2 or 3 bf16 planes) the value SWEM_PLANES_F16 asks for this fp16
  * pair instead, bit-identical to this function on the fp32 values.
  * A convolution reads such planes with plan bit 18 set (SWEM_PLAN_F16) and math 3: the three products hi.hi + hi.mid +
@@ -114,7 +119,7 @@ int swem_split_bf16x3_f32(void *stream, const float *x, void *out, long long npi
  * scale[n] * 2^-e[n] as `scale` (exact: a power of two). */
 #define SWEM_PLANES_F16 4
 #define SWEM_PLAN_F16 (1 << 18)
-int swem_split_f16x2_f32(void *stream, const float *x, void *out, long long npix, int C, int relu);
+int swem_split_f16x2_f32(void *stream, const float *x, void *out, long long npix, int C, int relu, void *fault);
 /* The same convolution as swem_conv2d_nhwc_f32 in bf16x6 math with PRE-SPLIT sources and filters: xK = plane 0 of
  * source K in the layout above (npix = all pixels of its storage; bsK = fp32-element batch stride as before, a
  * multiple of cK), psK = elements between its three planes (npix * cK), cK % 32 == 0;
@@ -151,7 +156,7 @@ int swem_conv2d_nhwc_f32_planes(void *stream, const float *x0, int c0, long long
                                 const float *w, long long w_bs, const float *scale, const float *shift, const float *res,
                                 long long res_bs, float *y, int Cout, int KH, int KW, int stride, int pad, int flags,
                                 int plan, void *ws, size_t ws_bytes, void *planes, int nplanes, void *planes_relu,
-                                int nplanes_relu);
+                                int nplanes_relu, void *fault);
 int swem_conv2d_nhwc_bf16x3_planes(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1,
                                    int c1, long long bs1, long long ps1, const void *x2, int c2, long long bs2,
                                    long long ps2, int B, int H, int W, const void *w_bf16x3, const float *scale,
@@ -159,21 +164,32 @@ int swem_conv2d_nhwc_bf16x3_planes(void *stream, const void *x0, int c0, long lo
                                    int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
                                    void *planes, int nplanes, void *planes_relu, int nplanes_relu);
 /* ... with caller-owned tile counters (round 3): `counters` (ncounters 32-bit words) must be ALL ZERO when the call is
- * enqueued and must not be used by another stream at the same time; the kernels leave words [0, ncounters - 1) all zero.  The
- * K-split (reduced by the last split of every tile, no reduce launch) and stream-K forms then need no memset launch per call.
- * ASYNCHRONOUS FAULTS (round 4).  The return code of a call only covers what is known when it is enqueued.  The LAST word,
- * counters[ncounters - 1], is a sticky fault word: a block whose bounded wait for another block's partial tile expires (a
- * producer that was preempted or never dispatched: the reduced tile is then WRONG) ORs SWEM_FAULT_* into it, and nothing on
- * the device clears it.  The caller reads it wherever it synchronises anyway (swem_amd.ops.check_faults); on a fault it must
- * zero the whole buffer before the next call (a stale tile counter corrupts the next launch the same way). */
+ * enqueued and must not be used by another stream at the same time; the kernels leave every word zero again.  The K-split
+ * (reduced by the last split of every tile, no reduce launch) and stream-K forms then need no memset launch per call.
+ *
+ * ASYNCHRONOUS FAULTS (round 4; round 5: an argument of its own).  The return code of a call only covers what is known when
+ * it is enqueued.  `fault` (may be NULL: no reporting) points to ONE 32-bit word the CALLER owns, zero-initialised once and
+ * never written by anything else: a kernel that detects one of the conditions below ORs the bit into it (agent-scope atomic)
+ * and nothing on the device ever clears it -- it is deliberately NOT part of `counters`, which a caller may re-zero at the
+ * head of a replayed HIP graph (a fault of replay k must still be there after replay k+1).  The caller reads it wherever it
+ * synchronises anyway (swem_amd.ops.check_faults: every sequence boundary) and clears it itself.
+ *   SWEM_FAULT_KSPLIT_WAIT / SWEM_FAULT_STREAMK_WAIT: a block's bounded wait for another block's partial tile expired (a
+ *     producer that was preempted or never dispatched): the reduced tile is WRONG; the caller must also zero `counters`
+ *     before the next call (a stale tile counter corrupts the next launch the same way).
+ *   SWEM_FAULT_RANGE: a value written into an fp16 operand pair (SWEM_PLANES_F16) had |x| >= 65520: the planes hold inf / NaN
+ *     and whatever consumes them is WRONG (possibly finite: a ReLU epilogue maps NaN to 0).  Every entry point that can write
+ *     an fp16 pair takes `fault` for this; the caller re-runs the work in a bf16 / fp32 arithmetic (math 0 / 1), which has
+ *     the reference's fp32 range. */
 #define SWEM_FAULT_KSPLIT_WAIT 1   /* the reducing split of a tile gave up waiting for the other splits' partial tiles */
 #define SWEM_FAULT_STREAMK_WAIT 2  /* a stream-K tile owner gave up waiting for a producer's partial tile */
+#define SWEM_FAULT_RANGE 4         /* a value beyond the fp16 range went into an fp16 operand pair */
 int swem_conv2d_nhwc_bf16x3_planes_ctr(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1,
                                    int c1, long long bs1, long long ps1, const void *x2, int c2, long long bs2,
                                    long long ps2, int B, int H, int W, const void *w_bf16x3, const float *scale,
                                    const float *shift, const float *res, long long res_bs, float *y, int Cout, int KH,
                                    int KW, int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
-                                   void *planes, int nplanes, void *planes_relu, int nplanes_relu, void *counters, size_t ncounters);
+                                   void *planes, int nplanes, void *planes_relu, int nplanes_relu, void *counters, size_t ncounters,
+                                   void *fault);
 /* ... and with the RESIDUAL given as operand planes instead of an fp32 map (round 4).  A ResNet block's output that only
  * convolutions and the NEXT block's residual add consume (mod_resnet.py:77-113: `out += identity`) need not exist as an fp32 map:
  * its producer writes planes only (y = NULL above) and this entry point reads the addend back from them -- hi + mid of the fp16
@@ -188,7 +204,7 @@ int swem_conv2d_nhwc_bf16x3_planes_res(void *stream, const void *x0, int c0, lon
                                        const float *shift, const void *res_planes, long long res_ps, long long res_npx,
                                        int res_nplanes, long long res_bs, float *y, int Cout, int KH, int KW, int stride,
                                        int pad, int flags, int plan, void *ws, size_t ws_bytes, void *planes, int nplanes,
-                                       void *planes_relu, int nplanes_relu, void *counters, size_t ncounters);
+                                       void *planes_relu, int nplanes_relu, void *counters, size_t ncounters, void *fault);
 
 /* ------------------------------------------------------------------------------------
  * Pointwise / pooling / resampling kernels.
@@ -209,13 +225,13 @@ int swem_prep_value_input_f32(void *stream, const float *frame, const float *mas
  * (layout of swem_split_bf16x3_f32, nplanes = 2 or 3 written).  Filters: w'[co][dy][dx][(py*2+px)*8 + c] =
  * w[co][2dy+py-1][2dx+px-1][c] (zero where the index is -1): swem_amd.ops.pack_stem_s2d.  H and W even. */
 int swem_prep_input_s2d_f32(void *stream, const float *frame, const float *masks, const float *mean3, const float *std3,
-                            float *out, void *planes, int nplanes, int B, int N, int H, int W, int single_obj);
+                            float *out, void *planes, int nplanes, int B, int N, int H, int W, int single_obj, void *fault);
 /* nn.MaxPool2d(3, 2, 1): mod_resnet.py:123.  NHWC, C % 4 == 0 */
 int swem_maxpool3x3s2_nhwc_f32(void *stream, const float *x, float *y, int B, int H, int W, int C);
 /* The same, and the result's bf16 planes for the pre-split convolutions that consume it (mod_resnet.py:123 -> layer1's
  * first block: conv1 and the downsample branch); arguments as swem_upsample_add_nhwc_f32_planes.  C % 8 == 0. */
 int swem_maxpool3x3s2_nhwc_f32_planes(void *stream, const float *x, float *y, int B, int H, int W, int C, void *planes,
-                                      int nplanes, void *planes_relu, int nplanes_relu);
+                                      int nplanes, void *planes_relu, int nplanes_relu, void *fault);
 /* y = skip + bilinear(low -> Ho x Wo, align_corners=False): networks.py:193-194.  skip_bs 0 = shared skip */
 int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long long skip_bs, const float *low, float *y,
                                int B, int Hl, int Wl, int Ho, int Wo, int C);
@@ -224,7 +240,7 @@ int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long long skip_b
  * B*Ho*Wo*C elements; C % 8 == 0.  Replaces a split launch (and its re-read of y) per consumer variant. */
 int swem_upsample_add_nhwc_f32_planes(void *stream, const float *skip, long long skip_bs, const float *low, float *y,
                                       int B, int Hl, int Wl, int Ho, int Wo, int C, void *planes, int nplanes,
-                                      void *planes_relu, int nplanes_relu);
+                                      void *planes_relu, int nplanes_relu, void *fault);
 /* F.interpolate / flip on NCHW planes; mode 0 = nearest (legacy), 1 = bilinear align_corners=False
  * (swem_evaluator.py:67,91), 2 = bicubic align_corners=False (swem_evaluator.py:43, basic_evaluator.py:160),
  * 3 = horizontal flip, same size (torch.flip(dims=[-1]), swem_evaluator.py:46-49) */
@@ -248,7 +264,7 @@ int swem_cbam_f32(void *stream, const float *x, const float *w1, const float *b1
  * relu(y) and y); plane arguments as swem_upsample_add_nhwc_f32_planes.  C % 8 == 0 when a plane pointer is given. */
 int swem_cbam_f32_planes(void *stream, const float *x, const float *w1, const float *b1, const float *w2, const float *b2,
                          const float *w7, const float *b7, float *cscale, float *y, int B, int H, int W, int C, int hid,
-                         void *ws, size_t ws_bytes, void *planes, int nplanes, void *planes_relu, int nplanes_relu);
+                         void *ws, size_t ws_bytes, void *planes, int nplanes, void *planes_relu, int nplanes_relu, void *fault);
 
 /* decoder.pred: conv3x3(relu(x)) -> 1 channel (networks.py:213).  x NHWC, w [3][3][C], logit [B][H][W] */
 int swem_pred_head_f32(void *stream, const float *x, const float *w, const float *bias, float *logit, int B, int H,
@@ -331,13 +347,14 @@ int swem_memorize_f32(void *stream, const float *x, const float *v, const float 
  *   mvq [N][2][4L/8][V][8] (optional, fp16) the same value bases pre-split for the readout GEMM: the fp16 pair hi, mid
  *                         of swem_split_f16x2_f32 (x = hi + mid to 22-23 significant bits; round 3: bf16, 16 bits),
  *                         k = cls*2L + bank*L + l in groups of 8 -- the filter layout of swem_conv2d_nhwc_bf16x3.
- *                         NULL: not kept (the readout then runs from mvp).
+ *                         NULL: not kept (the readout then runs from mvp).  `fault`: SWEM_FAULT_RANGE when a value base
+ *                         leaves the fp16 range (NULL: not reported -- a caller whose readout does not read mvq).
  * prior_packed != 0: the prior's packed keys are READ from the pack's 'update' half (written there by the previous
  * frame's call: kappa_prev must be that frame's kappa_out); the new bases are WRITTEN to bank `bank` (0 'first', 1 'update'). */
 int swem_memorize_packed_f32(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
                              const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out,
                              float *zita_out, float *mkn, float *mvp, void *mvq, int prior_packed, int bank, int N, int C,
-                             int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes);
+                             int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes, void *fault);
 
 /* The packed memorize in two calls (round 3).  modules.py:129-168 reads the value map only in its last statement
  * (:164-165, nu = (zita_ nu_ + mv z) / zita); everything before it -- every E, W and key M step, 2T - 1 of the 2T launches --
@@ -351,7 +368,7 @@ int swem_memorize_packed_keys_f32(void *stream, const float *x, const float *mas
                                   size_t ws_bytes);
 int swem_memorize_packed_values_f32(void *stream, const float *v, const float *z, const float *nu_prev,
                                     const float *zita_prev, float *nu_out, float *mvp, void *mvq, int bank, int N, int V,
-                                    int P, int L);
+                                    int P, int L, void *fault);
 
 /* ------------------------------------------------------------------------------------
  * Matching (modules.py:198-208, 232-289): l2norm, affinity, joint {bg,fg} softmax, value
@@ -379,7 +396,7 @@ int swem_match_f32(void *stream, const float *qk, const float *kappa_first, cons
  * most of a row would leave `mid` subnormal), the filters are the pack's mvq (required for this mode; without it the call
  * falls back to the fp32 kernel), three f16 products, the epilogue multiplies by 2^-14: 1e-7 from the fp32 readout. */
 int swem_match_pack_bank_f32(void *stream, const float *kappa, const float *nu, float *mkn, float *mvp, void *mvq, int bank,
-                             int nbanks, int N, int C, int V, int L);
+                             int nbanks, int N, int C, int V, int L, void *fault);
 size_t swem_match_packed_workspace(int N, int C, int V, int P, int L, int readout_plan);
 int swem_match_packed_f32(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq, float *mem_out,
                           float *S, int N, int C, int V, int P, int L, int topl, float tau, int readout_plan, void *ws,
@@ -392,7 +409,7 @@ int swem_match_packed_f32(void *stream, const float *qk, const float *mkn, const
 int swem_match_packed_f32_planes(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq,
                                  float *mem_out, float *S, int N, int C, int V, int P, int L, int topl, float tau,
                                  int readout_plan, void *ws, size_t ws_bytes, void *mem_planes, int mem_nplanes, void *s_planes,
-                                 int s_nplanes);
+                                 int s_nplanes, void *fault);
 
 #ifdef __cplusplus
 }

@@ -22,29 +22,29 @@ SIGNATURES = {
     'swem_conv2d_nhwc_f32': (_i, [_p, _p, _i, _ll, _p, _i, _ll, _p, _i, _ll, _i, _i, _i, _p, _ll, _p, _p, _p, _ll, _p,
                                   _i, _i, _i, _i, _i, _i, _i, _p, _sz]),
     'swem_conv2d_nhwc_f32_planes': (_i, [_p, _p, _i, _ll, _p, _i, _ll, _p, _i, _ll, _i, _i, _i, _p, _ll, _p, _p, _p, _ll, _p,
-                                         _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i]),
+                                         _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i, _p]),
     'swem_conv2d_nhwc_bf16x3_planes': (_i, [_p, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _i, _i, _i, _p, _p, _p, _p,
                                             _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i]),
     'swem_conv2d_nhwc_bf16x3_planes_ctr': (_i, [_p, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _i, _i, _i, _p, _p, _p, _p,
-                                            _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i, _p, _sz]),
+                                            _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i, _p, _sz, _p]),
     'swem_conv2d_nhwc_bf16x3_planes_res': (_i, [_p, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _i, _i, _i, _p, _p, _p, _p,
-                                            _ll, _ll, _i, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i, _p, _sz]),
+                                            _ll, _ll, _i, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i, _p, _sz, _p]),
     'swem_split_bf16x3_f32': (_i, [_p, _p, _p, _ll, _i, _i]),
-    'swem_split_f16x2_f32': (_i, [_p, _p, _p, _ll, _i, _i]),
+    'swem_split_f16x2_f32': (_i, [_p, _p, _p, _ll, _i, _i, _p]),
     'swem_conv2d_nhwc_bf16x3': (_i, [_p, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _i, _i, _i, _p, _p, _p, _p, _ll,
                                      _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz]),
     'swem_prep_key_input_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i]),
     'swem_prep_value_input_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i]),
-    'swem_prep_input_s2d_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
+    'swem_prep_input_s2d_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'swem_maxpool3x3s2_nhwc_f32': (_i, [_p, _p, _p, _i, _i, _i, _i]),
-    'swem_maxpool3x3s2_nhwc_f32_planes': (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _i]),
+    'swem_maxpool3x3s2_nhwc_f32_planes': (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
     'swem_upsample_add_nhwc_f32': (_i, [_p, _p, _ll, _p, _p, _i, _i, _i, _i, _i, _i]),
-    'swem_upsample_add_nhwc_f32_planes': (_i, [_p, _p, _ll, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i]),
+    'swem_upsample_add_nhwc_f32_planes': (_i, [_p, _p, _ll, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
     'swem_resize_planes_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_mask_prep_f32': (_i, [_p, _p, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i]),
     'swem_cbam_workspace': (_sz, [_i, _i, _i, _i]),
     'swem_cbam_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz]),
-    'swem_cbam_f32_planes': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i]),
+    'swem_cbam_f32_planes': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _p, _i, _p]),
     'swem_pred_head_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i]),
     'swem_decode_head_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_argmax_onehot_i64': (_i, [_p, _p, _p, _p, _i, _i, _ll]),
@@ -61,16 +61,16 @@ SIGNATURES = {
     'swem_em_mstep_f32': (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz]),
     'swem_memorize_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'swem_memorize_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _sz]),
-    'swem_memorize_packed_f32': (_i, [_p] * 13 + [_i] * 8 + [_f, _p, _sz]),
+    'swem_memorize_packed_f32': (_i, [_p] * 13 + [_i] * 8 + [_f, _p, _sz, _p]),
     'swem_memorize_packed_keys_f32': (_i, [_p] * 9 + [_i] * 7 + [_f, _p, _sz]),
-    'swem_memorize_packed_values_f32': (_i, [_p] * 8 + [_i] * 5),
+    'swem_memorize_packed_values_f32': (_i, [_p] * 8 + [_i] * 5 + [_p]),
     'swem_match_pad': (_i, [_i]),
     'swem_match_workspace': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'swem_match_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _sz]),
-    'swem_match_pack_bank_f32': (_i, [_p] * 6 + [_i] * 6),
+    'swem_match_pack_bank_f32': (_i, [_p] * 6 + [_i] * 6 + [_p]),
     'swem_match_packed_workspace': (_sz, [_i] * 6),
     'swem_match_packed_f32': (_i, [_p] * 7 + [_i] * 6 + [_f, _i, _p, _sz]),
-    'swem_match_packed_f32_planes': (_i, [_p] * 7 + [_i] * 6 + [_f, _i, _p, _sz, _p, _i, _p, _i]),
+    'swem_match_packed_f32_planes': (_i, [_p] * 7 + [_i] * 6 + [_f, _i, _p, _sz, _p, _i, _p, _i, _p]),
     # ---- include/swem_hip_train.h
     'swem_vos_loss_workspace': (_sz, [_i, _i, _ll]),
     'swem_vos_loss_frame_fwd_f32': (_i, [_p, _p, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _ll, _ll, _p, _p, _sz]),
@@ -113,6 +113,12 @@ _lib = None
 
 class SwemHipError(RuntimeError):
     pass
+
+
+class SwemRangeError(SwemHipError):
+    """SWEM_FAULT_RANGE (include/swem_hip.h): a value beyond the fp16 range went into an fp16 operand pair of the f16x3
+    arithmetic.  Nothing else is wrong with the launches: the caller re-runs the work in a full-range arithmetic
+    (ops.PlanBook.to_full_range; the evaluator loops do)."""
 
 
 def load():

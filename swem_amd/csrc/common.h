@@ -17,9 +17,10 @@ int swem_norm_bases_into(void *stream, const float *kappa, float *kn, int NK, in
 // plan / ws as swem_conv2d_nhwc_bf16x3 (math field 3 = two planes, 1 = three; SWEM_PLAN_F16: x and w are fp16 pairs).
 // y_planes (may be NULL): y's own planes [Ncols/8][B*M][8], y_nplanes (2, 3 or SWEM_PLANES_F16) of them written, B*M*Ncols
 // elements apart (Ncols % 8 == 0).  out_scale multiplies every output (the caller's operand scaling, undone exactly).
+// fault: the caller's sticky fault word (SWEM_FAULT_RANGE when y does not fit an fp16 pair asked for), or NULL.
 int swem_gemm_bf16x3_batched(void *stream, const void *x, int K, long long bs, long long ps, int B, int M, const void *w,
                              long long w_bs, float *y, int Ncols, int plan, void *ws, size_t ws_bytes, void *y_planes,
-                             int y_nplanes, float out_scale);
+                             int y_nplanes, float out_scale, void *fault);
 // raise the dynamic-LDS limit of a kernel once (needed above 64 KiB)
 #define SWEM_ALLOW_LDS(kernel, bytes)                                                                   \
   do {                                                                                                  \

@@ -75,8 +75,9 @@ struct ConvP {
   float *sk_ws;         // one block tile of fp32 partial sums per worker
   unsigned *sk_flags;   // one word per worker, zero at launch: "my partial tile is in sk_ws"
   int spin_limit;       // polls a block may spend waiting for another block's partial tile (2^24 ~ seconds; SWEM_SPIN_LIMIT)
-  unsigned *fault;      // optional sticky fault word (the last word of the caller's counter buffer): a bounded wait that expires
-                        // ORs SWEM_FAULT_* into it -- the tile is then wrong, and the host can know (never cleared on the device)
+  unsigned *fault;      // optional sticky fault word (the caller's, one per device: include/swem_hip.h): a bounded wait that expires
+                        // or an output that does not fit the fp16 pair it is written as ORs SWEM_FAULT_* into it -- the tile is
+                        // then wrong, and the host can know (never cleared on the device)
 };
 
 // One v_max_f32 per element.  fmaxf() costs two (hipcc first canonicalises the operand with v_max x,x), and in the fp32
@@ -216,6 +217,7 @@ __device__ __forceinline__ void out_tile32(const ConvP &p, const unsigned *lds, 
   const int lane = threadIdx.x & 63;
   const bool relu_out = p.flags & SWEM_CONV_RELU_OUT;
   const int HoWo = p.Ho * p.Wo;
+  unsigned bad = 0;   // a value this lane wrote into an fp16 pair was beyond the fp16 range (SWEM_FAULT_RANGE)
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's staging writes have landed
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -242,7 +244,9 @@ __device__ __forceinline__ void out_tile32(const ConvP &p, const unsigned *lds, 
       if (!p.ysp[var]) continue;
       const float4 q = var ? relu4(v) : v;
       uint2 h, mm, l;
-      split_as(p.ysp_npl[var], q, h, mm, l);
+      unsigned oor = 0;
+      split_as(p.ysp_npl[var], q, h, mm, l, oor);
+      if (in) bad |= oor;
       const uint2 h2 = make_uint2(__shfl_down(h.x, 1), __shfl_down(h.y, 1));
       const uint2 m2 = make_uint2(__shfl_down(mm.x, 1), __shfl_down(mm.y, 1));
       const uint2 l2 = make_uint2(__shfl_down(l.x, 1), __shfl_down(l.y, 1));
@@ -254,6 +258,7 @@ __device__ __forceinline__ void out_tile32(const ConvP &p, const unsigned *lds, 
       }
     }
   }
+  if (p.ysp[0] || p.ysp[1]) range_fault(p.fault, bad);
   __builtin_amdgcn_s_waitcnt(0xc07f);   // the reads are done before the next tile is staged
 }
 
@@ -1712,12 +1717,13 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
   if (!(p.ysp[0] || p.ysp[1])) return;
   // output planes (fused operand split): an even lane and its odd neighbour hold the 8 channels of one 16-byte run
   // (Cout / 4 is even -- Cout % 8 == 0 is the planes' precondition -- so a pair never straddles two pixels)
+  unsigned bad = 0;
 #pragma unroll
   for (int var = 0; var < 2; ++var) {
     if (!p.ysp[var]) continue;
     const float4 q = var ? relu4(v) : v;
     uint2 h, mm, l;
-    split_as(p.ysp_npl[var], q, h, mm, l);
+    split_as(p.ysp_npl[var], q, h, mm, l, bad);
     const uint2 h2 = make_uint2(__shfl_down(h.x, 1), __shfl_down(h.y, 1));
     const uint2 m2 = make_uint2(__shfl_down(mm.x, 1), __shfl_down(mm.y, 1));
     const uint2 l2 = make_uint2(__shfl_down(l.x, 1), __shfl_down(l.y, 1));
@@ -1728,6 +1734,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
       if (p.ysp_npl[var] == 3) *reinterpret_cast<uint4 *>(d + 2 * p.ysp_ps) = make_uint4(l.x, l.y, l2.x, l2.y);
     }
   }
+  range_fault(p.fault, bad);
 }
 
 struct Plan {
@@ -2030,6 +2037,7 @@ struct PlaneOut {
   const void *res_planes = nullptr;   // optional: the residual as planes (swem_conv2d_nhwc_bf16x3_planes_res)
   long long res_ps = 0, res_npx = 0;
   int res_npl = 0;
+  unsigned *fault = nullptr;          // optional: the caller's sticky fault word (SWEM_FAULT_*)
 };
 // validate the optional output planes and put them into the launch parameters (after p.M / p.Cout are set)
 int set_planes(ConvP &p, const PlaneOut *po, bool glu, const char *who) {
@@ -2067,8 +2075,9 @@ extern "C" int swem_conv2d_nhwc_f32_planes(void *stream, const float *x0, int c0
                                            const float *w, long long w_bs, const float *scale, const float *shift,
                                            const float *res, long long res_bs, float *y, int Cout, int KH, int KW,
                                            int stride, int pad, int flags, int plan, void *ws, size_t ws_bytes,
-                                           void *planes, int nplanes, void *planes_relu, int nplanes_relu) {
+                                           void *planes, int nplanes, void *planes_relu, int nplanes_relu, void *fault) {
   PlaneOut po{{planes, planes_relu}, {nplanes, nplanes_relu}};
+  po.fault = static_cast<unsigned *>(fault);
   return conv2d_f32_impl(stream, x0, c0, bs0, x1, c1, bs1, x2, c2, bs2, B, H, W, w, w_bs, scale, shift, res, res_bs, y, Cout,
                          KH, KW, stride, pad, flags, plan, ws, ws_bytes, &po);
 }
@@ -2120,6 +2129,7 @@ int conv2d_f32_impl(void *stream, const float *x0, int c0, long long bs0, const 
   p.partial = nullptr;
   p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.f16 = 0; p.xpn = 1;
   if (int prc = set_planes(p, po, glu, "conv2d")) return prc;
+  p.fault = po ? po->fault : nullptr;
   if (pl.nsplit > 1) {
     size_t need = (size_t)pl.nsplit * M * p.Ncols * sizeof(float);
     SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d: workspace %zu < %zu bytes", ws_bytes, need);
@@ -2201,7 +2211,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restri
 namespace {
 // ... -> two fp16 planes [C/8][npix][8] with x = hi + mid (bf16_split.h, split2h): the operand format of the f16x3 arithmetic
 __global__ __launch_bounds__(256) void split_f16x2_kernel(const float *__restrict__ x, unsigned short *__restrict__ out,
-                                                          long long npix, int C, int relu) {
+                                                          long long npix, int C, int relu, unsigned *fault) {
   const long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
   const int cg = blockIdx.y * 8 + (threadIdx.x & 7);
   if (pix >= npix || cg >= C / 8) return;
@@ -2217,13 +2227,15 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float *__restric
   const long long plane = npix * C, i = (long long)cg * npix + pix;
   *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
   *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+  range_fault(fault, f16_oor(v0) | f16_oor(v1));   // (behind the input ReLU: a large NEGATIVE value under a ReLU is a plain 0)
 }
 }  // namespace
 
-extern "C" int swem_split_f16x2_f32(void *stream, const float *x, void *out, long long npix, int C, int relu) {
+extern "C" int swem_split_f16x2_f32(void *stream, const float *x, void *out, long long npix, int C, int relu, void *fault) {
   SWEM_REQUIRE(x && out && npix > 0 && C > 0 && C % 8 == 0, SWEM_E_ARG, "split_f16x2: need C %% 8 == 0");
   hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)cdiv(npix, 32), (unsigned)cdiv(C / 8, 8)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, static_cast<unsigned short *>(out), npix, C, relu);
+                     static_cast<hipStream_t>(stream), x, static_cast<unsigned short *>(out), npix, C, relu,
+                     static_cast<unsigned *>(fault));
   SWEM_CHECK_LAUNCH("split_f16x2");
   return SWEM_OK;
 }
@@ -2272,8 +2284,9 @@ extern "C" int swem_conv2d_nhwc_bf16x3_planes_ctr(void *stream, const void *x0, 
                                                   const float *scale, const float *shift, const float *res, long long res_bs,
                                                   float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan,
                                                   void *ws, size_t ws_bytes, void *planes, int nplanes, void *planes_relu,
-                                                  int nplanes_relu, void *counters, size_t ncounters) {
+                                                  int nplanes_relu, void *counters, size_t ncounters, void *fault) {
   PlaneOut po{{planes, planes_relu}, {nplanes, nplanes_relu}, static_cast<unsigned *>(counters), ncounters};
+  po.fault = static_cast<unsigned *>(fault);
   return conv2d_bf16x3_impl(stream, x0, c0, bs0, ps0, x1, c1, bs1, ps1, x2, c2, bs2, ps2, B, H, W, w_bf16x3, scale, shift, res,
                             res_bs, y, Cout, KH, KW, stride, pad, flags, plan, ws, ws_bytes, &po);
 }
@@ -2285,8 +2298,9 @@ extern "C" int swem_conv2d_nhwc_bf16x3_planes_res(void *stream, const void *x0, 
                                                   long long res_ps, long long res_npx, int res_nplanes, long long res_bs,
                                                   float *y, int Cout, int KH, int KW, int stride, int pad, int flags, int plan,
                                                   void *ws, size_t ws_bytes, void *planes, int nplanes, void *planes_relu,
-                                                  int nplanes_relu, void *counters, size_t ncounters) {
+                                                  int nplanes_relu, void *counters, size_t ncounters, void *fault) {
   PlaneOut po{{planes, planes_relu}, {nplanes, nplanes_relu}, static_cast<unsigned *>(counters), ncounters};
+  po.fault = static_cast<unsigned *>(fault);
   po.res_planes = res_planes; po.res_ps = res_ps; po.res_npx = res_npx; po.res_npl = res_nplanes;
   SWEM_REQUIRE(res_planes, SWEM_E_ARG, "conv2d_bf16x3_planes_res: null residual planes");
   return conv2d_bf16x3_impl(stream, x0, c0, bs0, ps0, x1, c1, bs1, ps1, x2, c2, bs2, ps2, B, H, W, w_bf16x3, scale, shift, nullptr,
@@ -2295,8 +2309,9 @@ extern "C" int swem_conv2d_nhwc_bf16x3_planes_res(void *stream, const void *x0, 
 // batched GEMM on pre-split planes (common.h): y[b] = x[b] . w[b]^T with per-batch filter planes, w_bs bf16 elements apart
 int swem_gemm_bf16x3_batched(void *stream, const void *x, int K, long long bs, long long ps, int B, int M, const void *w,
                              long long w_bs, float *y, int Ncols, int plan, void *ws, size_t ws_bytes, void *y_planes,
-                             int y_nplanes, float out_scale) {
+                             int y_nplanes, float out_scale, void *fault) {
   PlaneOut po{{y_planes, nullptr}, {y_nplanes, 3}};
+  po.fault = static_cast<unsigned *>(fault);
   return conv2d_bf16x3_impl(stream, x, K, bs, ps, nullptr, 0, 0, 0, nullptr, 0, 0, 0, B, M, 1, w, nullptr, nullptr, nullptr, 0, y,
                             Ncols, 1, 1, 1, 0, 0, plan, ws, ws_bytes, y_planes ? &po : nullptr, w_bs, out_scale);
 }
@@ -2358,7 +2373,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   p.partial = nullptr;
   p.mt0 = 0; p.part_m0 = 0; p.nplanes = 3; p.f16 = 0; p.xpn = 1;
   if (int prc = set_planes(p, po, glu, "conv2d_bf16x3")) return prc;
-  // caller-owned counters: words [0, n - 1) are tile counters / stream-K flags, word n - 1 is the sticky fault word
+  // caller-owned counters: tile counters / stream-K flags (all zero between calls); the sticky fault word is the caller's too
   if (po && po->res_planes) {
     SWEM_REQUIRE(!res && !glu && !(flags & SWEM_CONV_MASK_POS) && Cout % 8 == 0, SWEM_E_ARG,
                  "conv2d_bf16x3: a plane residual replaces `res` (no GLU, no mask; Cout %% 8 == 0)");
@@ -2369,8 +2384,8 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
     p.res_pl = static_cast<const unsigned short *>(po->res_planes);
     p.res_ps = po->res_ps; p.res_npx = (int)po->res_npx; p.res_npl = po->res_npl;
   }
-  const size_t nctr = (po && po->counters && po->ncounters >= 2) ? po->ncounters - 1 : 0;
-  if (nctr) p.fault = po->counters + nctr;
+  const size_t nctr = (po && po->counters) ? po->ncounters : 0;
+  p.fault = po ? po->fault : nullptr;
   {
     static int limit = -1;   // (tests shorten the wait to see the fault path: tests/test_gpu_ops.py)
     if (limit < 0) {

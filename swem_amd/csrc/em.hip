@@ -280,6 +280,7 @@ struct MStepP {
   float *kp_out;   // optional: the new key bases packed [NK][C/4][kp_rows][4] at row offset kp_off (what E/W / affinity read)
   float *mvp_out;  // optional: value bases packed for matching, mvp[n][v][cls*mvp_lm + mvp_off + l]
   unsigned short *mvq_out;  // optional: the same as the fp16 pair (hi, mid: bf16_split.h, split2h) per object, [n][2][2*mvp_lm/8][V][8]
+  unsigned *fault;          // optional: the caller's sticky fault word (SWEM_FAULT_RANGE: a value base beyond the fp16 range)
   int kp_rows, kp_off, mvp_lm, mvp_off;
   int Ck, C, V, P, Pz, L, NK, nrt, total;  // nrt = 32-row tiles of the row space, total = NK * (L/16) * nrt blocks
   int rpg;                                 // row tiles per group of the tile order (a divisor of nrt)
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(512, WPE) void em_mstep_kernel(MStepP p STAMP_ARG) 
         uint2 h0, m0, h1, m1;
         split2h(a, h0, m0);
         split2h(b, h1, m1);
+        range_fault(p.fault, f16_oor(a) | f16_oor(b));   // (tid < 64: wave 0, all lanes)
         const int kg = (cls * p.mvp_lm + p.mvp_off + l0) / 8 + grp, ngrp = 2 * p.mvp_lm / 8;
         unsigned short *base = p.mvq_out + (long long)n * 2 * ngrp * p.V * 8;
         *reinterpret_cast<uint4 *>(base + ((long long)kg * p.V + col + vr) * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
@@ -535,8 +537,9 @@ namespace {
 int mstep_impl(void *stream, const float *x, const float *v, const float *z, const float *kappa_prev,
                const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out,
                float *kp_out, int kp_rows, int kp_off, float *mvp_out, int mvp_lm, int mvp_off, int NK, int Ck, int Vv,
-               int C, int V, int P, int L, unsigned short *mvq_out = nullptr) {
+               int C, int V, int P, int L, unsigned short *mvq_out = nullptr, unsigned *fault = nullptr) {
   MStepP mp;
+  mp.fault = fault;
   mp.x = x, mp.v = v, mp.z = z;
   mp.kappa_prev = kappa_prev, mp.nu_prev = nu_prev, mp.zita_prev = zita_prev;
   mp.kappa_out = kappa_out, mp.nu_out = nu_out, mp.zita_out = zita_out;
@@ -609,7 +612,8 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
                   const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out, int N,
                   int C, int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes, float *z_ext,
                   const float *kn_prior, int knp_rows, int knp_off, float *kn_out, int kno_rows, int kno_off,
-                  float *mvp_out, int mvp_lm, int mvp_off, unsigned short *mvq_out = nullptr, bool keys_only = false) {
+                  float *mvp_out, int mvp_lm, int mvp_off, unsigned short *mvq_out = nullptr, bool keys_only = false,
+                  unsigned *fault = nullptr) {
   // keys_only: everything that does not read the value map -- all T (E, W, key M) steps; the last E step's z stays in z_ext
   // for the value update (swem_memorize_packed_values_f32), which is ONE more M-step launch over the value rows
   SWEM_REQUIRE(x && (v || keys_only) && masks && kappa_prev && (nu_prev || keys_only) && zita_prev && kappa_out &&
@@ -647,7 +651,7 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
     const bool vals = last && !keys_only;
     if ((rc = mstep_impl(stream, x, vals ? v : nullptr, z, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out,
                          last ? kn_out : kn, last ? kno_rows : L, last ? kno_off : 0, vals ? mvp_out : nullptr, mvp_lm,
-                         mvp_off, NK, C, vals ? V : 0, C, V, P, L, vals ? mvq_out : nullptr)))
+                         mvp_off, NK, C, vals ? V : 0, C, V, P, L, vals ? mvq_out : nullptr, fault)))
       return rc;
     kcur = kn, krows = L, koff = 0;
   }
@@ -674,12 +678,12 @@ extern "C" int swem_memorize_packed_f32(void *stream, const float *x, const floa
                                         const float *kappa_prev, const float *nu_prev, const float *zita_prev,
                                         float *kappa_out, float *nu_out, float *zita_out, float *mkn, float *mvp,
                                         void *mvq, int prior_packed, int bank, int N, int C, int V, int P, int L, int T,
-                                        float tau, void *ws, size_t ws_bytes) {
+                                        float tau, void *ws, size_t ws_bytes, void *fault) {
   SWEM_REQUIRE(mkn && mvp, SWEM_E_ARG, "memorize_packed: null pack");
   SWEM_REQUIRE(bank == 0 || bank == 1, SWEM_E_ARG, "memorize_packed: bank must be 0 or 1");
   return memorize_impl(stream, x, v, masks, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out, N, C, V, P, L, T,
                        tau, ws, ws_bytes, nullptr, prior_packed ? mkn : nullptr, 2 * L, L, mkn, 2 * L, bank * L, mvp,
-                       2 * L, bank * L, static_cast<unsigned short *>(mvq));
+                       2 * L, bank * L, static_cast<unsigned short *>(mvq), false, static_cast<unsigned *>(fault));
 }
 
 // The packed memorize in two calls, so that a caller can run the part that does not need the value map -- every E, W and key
@@ -699,12 +703,12 @@ extern "C" int swem_memorize_packed_keys_f32(void *stream, const float *x, const
 }
 extern "C" int swem_memorize_packed_values_f32(void *stream, const float *v, const float *z, const float *nu_prev,
                                                const float *zita_prev, float *nu_out, float *mvp, void *mvq, int bank, int N,
-                                               int V, int P, int L) {
+                                               int V, int P, int L, void *fault) {
   SWEM_REQUIRE(v && z && nu_prev && zita_prev && nu_out && mvp, SWEM_E_ARG, "memorize_packed_values: null pointer");
   SWEM_REQUIRE(bank == 0 || bank == 1, SWEM_E_ARG, "memorize_packed_values: bank must be 0 or 1");
   SWEM_REQUIRE(V % 32 == 0 && (L == 64 || L == 128 || L == 256), SWEM_E_SHAPE, "memorize_packed_values: V %% 32, L in {64,128,256}");
   return mstep_impl(stream, nullptr, v, z, nullptr, nu_prev, zita_prev, nullptr, nu_out, nullptr, nullptr, 0, 0, mvp, 2 * L,
-                    bank * L, 2 * N, 0, V, 0, V, P, L, static_cast<unsigned short *>(mvq));
+                    bank * L, 2 * N, 0, V, 0, V, P, L, static_cast<unsigned short *>(mvq), static_cast<unsigned *>(fault));
 }
 
 // training: the same as swem_memorize_f32, and the last E step's responsibilities z [N][Pz][2L] (Pz = swem_em_pad(P), rows

@@ -40,7 +40,7 @@ __global__ void pack_values_kernel(const float *__restrict__ nu, float *__restri
 constexpr float MATCH_P_SCALE = 16384.f;   // the readout's probability planes hold p * 2^14 (see match_core)
 // the readout GEMM's pre-split filters: mvq[n][plane][(cls*Lm + off + l)/8][v][l%8] = fp16 hi / mid of nu[n][cls][v][l]
 __global__ void pack_value_planes_kernel(const float *__restrict__ nu, unsigned short *__restrict__ mvq, int N, int V, int L,
-                                         int Lm, int off) {
+                                         int Lm, int off, unsigned *fault) {
   const int l8n = L / 8;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)N * 2 * V * l8n) return;
@@ -51,8 +51,10 @@ __global__ void pack_value_planes_kernel(const float *__restrict__ nu, unsigned 
   const int cls = (int)(t & 1), n = (int)(t >> 1);
   const float *src = nu + (((long long)n * 2 + cls) * V + v) * L + l8 * 8;
   uint2 h0, m0, h1, m1;
-  split2h(ld4(src), h0, m0);
-  split2h(ld4(src + 4), h1, m1);
+  const float4 s0 = ld4(src), s1 = ld4(src + 4);
+  split2h(s0, h0, m0);
+  split2h(s1, h1, m1);
+  range_fault(fault, f16_oor(s0) | f16_oor(s1));
   const int ngrp = 2 * Lm / 8, kg = (cls * Lm + off) / 8 + l8;
   unsigned short *base = mvq + (long long)n * 2 * ngrp * V * 8;
   *reinterpret_cast<uint4 *>(base + ((long long)kg * V + v) * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
@@ -620,7 +622,7 @@ namespace {
 int match_core(void *stream, const float *qk, const float *mkn, const float *mvp, const unsigned short *mvq, float *pT,
                unsigned short *pq, float *mem_out, float *S, int N, int C, int V, int P, int Lm, int topl, float tau,
                int readout_plan, void *conv_ws, size_t conv_bytes, void *mem_planes = nullptr, int mem_npl = 3,
-               void *s_planes = nullptr, int s_npl = 3) {
+               void *s_planes = nullptr, int s_npl = 3, void *fault = nullptr) {
   const int Pm = swem_match_pad(P), Ltot = 2 * Lm;
   int rc;
   dim3 gridt(cdiv((long long)N * P, 4));
@@ -649,10 +651,17 @@ int match_core(void *stream, const float *qk, const float *mkn, const float *mvp
   // pack's value planes are fp16 pairs (em.hip, pack_value_planes_kernel) and the affinity kernel wrote the probabilities as
   // the fp16 pair of p * 2^14 (p <= 1: most of a row is far below 2^-2, where an unscaled `mid` would be subnormal); the
   // epilogue multiplies by 2^-14 (exact).  1e-7 from the fp32 readout, where the bf16 (hi, mid) planes of round 3 gave 3e-6.
-  if (presplit)
+  if (presplit) {
+    // (the f16x3 kernels have no stream-K form: a plan tuned for the bf16x3 readout of round 3 with plan bits 24-27 == 1 runs
+    // the plain grid of its tile instead of failing at launch -- ADVICE r04; tail-split factors 2..15 stay)
+    int plan = (readout_plan & ~(3 << 16)) | (3 << 16) | SWEM_PLAN_F16;
+    if (((plan >> 24) & 15) == 1) plan &= ~(15 << 24);
+    // (the probability planes hold p * 2^14 <= 2^14 and the top-l features lie in [0, 1]: only mem_out's own planes -- the
+    // readout's epilogue -- can leave the fp16 range)
     return swem_gemm_bf16x3_batched(stream, pq, Ltot, (long long)Pm * Ltot, (long long)N * Pm * Ltot, N, Pm, mvq,
-                                    (long long)2 * V * Ltot, mem_out, V, (readout_plan & ~(3 << 16)) | (3 << 16) | SWEM_PLAN_F16,
-                                    conv_ws, conv_bytes, mem_planes, mem_npl, 1.f / MATCH_P_SCALE);
+                                    (long long)2 * V * Ltot, mem_out, V, plan, conv_ws, conv_bytes, mem_planes, mem_npl,
+                                    1.f / MATCH_P_SCALE, fault);
+  }
   return swem_conv2d_nhwc_f32(stream, pT, Ltot, (long long)Pm * Ltot, nullptr, 0, 0, nullptr, 0, 0, N, Pm, 1, mvp,
                               (long long)V * Ltot, nullptr, nullptr, nullptr, 0, mem_out, V, 1, 1, 1, 0, 0,
                               readout_plan, conv_ws, conv_bytes);
@@ -671,7 +680,7 @@ int match_check(int C, int V, int L, int Lm, int topl, float tau) {
 
 // one bank's bases into the packed form matching reads (modules.py:295-306 `get_mem` + the l2norm of :283)
 extern "C" int swem_match_pack_bank_f32(void *stream, const float *kappa, const float *nu, float *mkn, float *mvp,
-                                        void *mvq, int bank, int nbanks, int N, int C, int V, int L) {
+                                        void *mvq, int bank, int nbanks, int N, int C, int V, int L, void *fault) {
   SWEM_REQUIRE(kappa && nu && mkn && mvp, SWEM_E_ARG, "match_pack_bank: null pointer");
   SWEM_REQUIRE(nbanks >= 1 && nbanks <= 2 && bank >= 0 && bank < nbanks, SWEM_E_ARG, "match_pack_bank: bad bank index");
   const int Lm = nbanks * L;
@@ -682,7 +691,7 @@ extern "C" int swem_match_pack_bank_f32(void *stream, const float *kappa, const 
   if (mvq) {
     SWEM_REQUIRE(L % 8 == 0, SWEM_E_SHAPE, "match_pack_bank: value planes need L %% 8 == 0");
     hipLaunchKernelGGL(pack_value_planes_kernel, dim3(cdiv(work / 2, 256)), dim3(256), 0, ST, nu,
-                       static_cast<unsigned short *>(mvq), N, V, L, Lm, bank * L);
+                       static_cast<unsigned short *>(mvq), N, V, L, Lm, bank * L, static_cast<unsigned *>(fault));
   }
   SWEM_CHECK_LAUNCH("pack_values");
   return SWEM_OK;
@@ -702,9 +711,9 @@ extern "C" int swem_match_f32(void *stream, const float *qk, const float *kappa_
   SWEM_REQUIRE(ws && ws_bytes >= w.total, SWEM_E_WORKSPACE, "match: workspace %zu < %zu", ws_bytes, w.total);
   char *base = static_cast<char *>(ws);
   float *mkn = (float *)(base + w.mkn), *mvp = (float *)(base + w.mvp), *pT = (float *)(base + w.pT);
-  if ((rc = swem_match_pack_bank_f32(stream, kappa_first, nu_first, mkn, mvp, nullptr, 0, nbanks, N, C, V, L))) return rc;
+  if ((rc = swem_match_pack_bank_f32(stream, kappa_first, nu_first, mkn, mvp, nullptr, 0, nbanks, N, C, V, L, nullptr))) return rc;
   if (nbanks == 2 &&
-      (rc = swem_match_pack_bank_f32(stream, kappa_update, nu_update, mkn, mvp, nullptr, 1, nbanks, N, C, V, L)))
+      (rc = swem_match_pack_bank_f32(stream, kappa_update, nu_update, mkn, mvp, nullptr, 1, nbanks, N, C, V, L, nullptr)))
     return rc;
   return match_core(stream, qk, mkn, mvp, nullptr, pT, nullptr, mem_out, S, N, C, V, P, Lm, topl, tau, readout_plan,
                     base + w.conv, w.total - w.conv);
@@ -720,7 +729,7 @@ extern "C" size_t swem_match_packed_workspace(int N, int C, int V, int P, int L,
 namespace {
 int match_packed_impl(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq, float *mem_out, float *S,
                       int N, int C, int V, int P, int L, int topl, float tau, int readout_plan, void *ws, size_t ws_bytes,
-                      void *mem_planes, int mem_npl, void *s_planes, int s_npl) {
+                      void *mem_planes, int mem_npl, void *s_planes, int s_npl, void *fault) {
   SWEM_REQUIRE(qk && mkn && mvp && mem_out && S, SWEM_E_ARG, "match_packed: null pointer");
   int rc;
   if ((rc = match_check(C, V, L, 2 * L, topl, tau))) return rc;
@@ -733,7 +742,7 @@ int match_packed_impl(void *stream, const float *qk, const float *mkn, const flo
   char *base = static_cast<char *>(ws) - w.pT;     // the workspace starts at the probability slot
   return match_core(stream, qk, mkn, mvp, static_cast<const unsigned short *>(mvq), (float *)(base + w.pT),
                     (unsigned short *)(base + w.pq), mem_out, S, N, C, V, P, 2 * L, topl, tau, readout_plan, base + w.conv,
-                    w.total - w.conv, mem_planes, mem_npl, s_planes, s_npl);
+                    w.total - w.conv, mem_planes, mem_npl, s_planes, s_npl, fault);
 }
 }  // namespace
 
@@ -741,15 +750,15 @@ extern "C" int swem_match_packed_f32(void *stream, const float *qk, const float 
                                      float *mem_out, float *S, int N, int C, int V, int P, int L, int topl, float tau,
                                      int readout_plan, void *ws, size_t ws_bytes) {
   return match_packed_impl(stream, qk, mkn, mvp, mvq, mem_out, S, N, C, V, P, L, topl, tau, readout_plan, ws, ws_bytes, nullptr, 3,
-                           nullptr, 3);
+                           nullptr, 3, nullptr);
 }
 
 extern "C" int swem_match_packed_f32_planes(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq,
                                             float *mem_out, float *S, int N, int C, int V, int P, int L, int topl, float tau,
                                             int readout_plan, void *ws, size_t ws_bytes, void *mem_planes, int mem_nplanes,
-                                            void *s_planes, int s_nplanes) {
+                                            void *s_planes, int s_nplanes, void *fault) {
   return match_packed_impl(stream, qk, mkn, mvp, mvq, mem_out, S, N, C, V, P, L, topl, tau, readout_plan, ws, ws_bytes, mem_planes,
-                           mem_nplanes, s_planes, s_nplanes);
+                           mem_nplanes, s_planes, s_nplanes, fault);
 }
 
 // backward of swem_match_f32 for one clip: d mem_out [N][Pm][V] and dS [N][P][2*topl] (either may be NULL) ->

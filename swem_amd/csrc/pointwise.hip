@@ -85,7 +85,7 @@ __global__ void prep_value_input_kernel(const float *__restrict__ f, const float
 // (networks.py:161): (r, g, b, 0, ...); masks == NULL selects the key form.
 __global__ void prep_input_s2d_kernel(const float *__restrict__ f, const float *__restrict__ masks, float3 mean, float3 stdv,
                                       float *__restrict__ out, unsigned short *__restrict__ planes, int nplanes, int B,
-                                      int N, int H, int W, int single_obj) {
+                                      int N, int H, int W, int single_obj, unsigned *fault) {
   const int Hb = H / 2 + 1, Wb = W / 2 + 1;
   const long long npix = (long long)B * N * Hb * Wb;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (image, block row, block col, phase)
@@ -116,8 +116,10 @@ __global__ void prep_input_s2d_kernel(const float *__restrict__ f, const float *
   }
   if (planes) {
     uint2 h0, m0, l0, h1, m1, l1;
-    split_as(nplanes, v0, h0, m0, l0);
-    split_as(nplanes, v1, h1, m1, l1);
+    unsigned bad = 0;
+    split_as(nplanes, v0, h0, m0, l0, bad);
+    split_as(nplanes, v1, h1, m1, l1, bad);
+    range_fault(fault, bad);   // (a frame far outside [0, 1], or a NaN in it)
     const long long plane = npix * 32, o = ((long long)ph * npix + blk) * 8;
     *reinterpret_cast<uint4 *>(planes + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
     *reinterpret_cast<uint4 *>(planes + plane + o) = make_uint4(m0.x, m0.y, m1.x, m1.y);
@@ -155,19 +157,21 @@ __global__ void maxpool_kernel(const float *__restrict__ x, float *__restrict__ 
 // bf16 planes (hi, mid[, lo]) of 8 consecutive channels of one pixel, with and / or without a ReLU, in the operand-split
 // layout [plane][C/8][npix][8] (split_bf16x3_kernel, conv.hip): i = channel group * npix + pixel, plane = npix * C.
 __device__ __forceinline__ void planes8_out(const float4 (&v)[2], unsigned short *pl0, int npl0, unsigned short *pl1, int npl1,
-                                            long long plane, long long i) {
+                                            long long plane, long long i, unsigned *fault) {
+  unsigned bad = 0;   // a value that does not fit the fp16 pair it is written as (SWEM_FAULT_RANGE, include/swem_hip.h)
 #pragma unroll
   for (int var = 0; var < 2; ++var) {
     unsigned short *out = var ? pl1 : pl0;
     const int npl = var ? npl1 : npl0;
     if (!out) continue;
     uint2 h0, m0, l0, h1, m1, l1;
-    split_as(npl, var ? make_float4(fmaxf(v[0].x, 0.f), fmaxf(v[0].y, 0.f), fmaxf(v[0].z, 0.f), fmaxf(v[0].w, 0.f)) : v[0], h0, m0, l0);
-    split_as(npl, var ? make_float4(fmaxf(v[1].x, 0.f), fmaxf(v[1].y, 0.f), fmaxf(v[1].z, 0.f), fmaxf(v[1].w, 0.f)) : v[1], h1, m1, l1);
+    split_as(npl, var ? make_float4(fmaxf(v[0].x, 0.f), fmaxf(v[0].y, 0.f), fmaxf(v[0].z, 0.f), fmaxf(v[0].w, 0.f)) : v[0], h0, m0, l0, bad);
+    split_as(npl, var ? make_float4(fmaxf(v[1].x, 0.f), fmaxf(v[1].y, 0.f), fmaxf(v[1].z, 0.f), fmaxf(v[1].w, 0.f)) : v[1], h1, m1, l1, bad);
     *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
     *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
     if (npl == 3) *reinterpret_cast<uint4 *>(out + 2 * plane + i * 8) = make_uint4(l0.x, l0.y, l1.x, l1.y);
   }
+  range_fault(fault, bad);
 }
 
 // maxpool_kernel plus the result's bf16 planes for the convolution that consumes it (the first block of layer1 reads the
@@ -175,7 +179,7 @@ __device__ __forceinline__ void planes8_out(const float4 (&v)[2], unsigned short
 __global__ __launch_bounds__(256) void maxpool_planes_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                              unsigned short *__restrict__ pl0, int npl0,
                                                              unsigned short *__restrict__ pl1, int npl1, int B, int H, int W,
-                                                             int C, int Ho, int Wo) {
+                                                             int C, int Ho, int Wo, unsigned *fault) {
   const long long npix = (long long)B * Ho * Wo;
   const long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
   const int cg = blockIdx.y * 8 + (threadIdx.x & 7);
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void maxpool_planes_kernel(const float *__rest
   }
   st4(y + pix * C + cg * 8, v[0]);
   st4(y + pix * C + cg * 8 + 4, v[1]);
-  planes8_out(v, pl0, npl0, pl1, npl1, npix * C, (long long)cg * npix + pix);
+  planes8_out(v, pl0, npl0, pl1, npl1, npix * C, (long long)cg * npix + pix, fault);
 }
 
 __global__ void upsample_add_kernel(const float *__restrict__ skip, long long skip_bs, const float *__restrict__ low,
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void upsample_add_planes_kernel(const float *_
                                                                   const float *__restrict__ low, float *__restrict__ y,
                                                                   unsigned short *__restrict__ pl0, int npl0,
                                                                   unsigned short *__restrict__ pl1, int npl1, int B, int Hl,
-                                                                  int Wl, int Ho, int Wo, int C) {
+                                                                  int Wl, int Ho, int Wo, int C, unsigned *fault) {
   const long long npix = (long long)B * Ho * Wo;
   const long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
   const int cg = blockIdx.y * 8 + (threadIdx.x & 7);
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256) void upsample_add_planes_kernel(const float *_
     v[h] = f4add(ld4(sk + 4 * h), f4lerp2(ly.l0, r0, ly.l1, r1));
     st4(y + pix * C + cg * 8 + 4 * h, v[h]);
   }
-  planes8_out(v, pl0, npl0, pl1, npl1, npix * C, (long long)cg * npix + pix);
+  planes8_out(v, pl0, npl0, pl1, npl1, npix * C, (long long)cg * npix + pix, fault);
 }
 
 __global__ void resize_planes_kernel(const float *__restrict__ x, float *__restrict__ y, int planes, int Hi, int Wi,
@@ -583,7 +587,8 @@ __global__ void cbam_apply_kernel(const float *__restrict__ x, const float *__re
 __global__ __launch_bounds__(256) void cbam_apply_planes_kernel(const float *__restrict__ x, const float *__restrict__ cscale,
                                                                 const float *__restrict__ sg, float *__restrict__ y,
                                                                 unsigned short *__restrict__ pl0, int npl0,
-                                                                unsigned short *__restrict__ pl1, int npl1, int B, int P, int C) {
+                                                                unsigned short *__restrict__ pl1, int npl1, int B, int P, int C,
+                                                                unsigned *fault) {
   const long long npix = (long long)B * P;
   const long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
   const int cg = blockIdx.y * 8 + (threadIdx.x & 7);
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(256) void cbam_apply_planes_kernel(const float *__r
     v[h] = make_float4(u.x + u.x * g.x * s, u.y + u.y * g.y * s, u.z + u.z * g.z * s, u.w + u.w * g.w * s);
     st4(y + pix * C + cg * 8 + 4 * h, v[h]);
   }
-  planes8_out(v, pl0, npl0, pl1, npl1, npix * C, (long long)cg * npix + pix);
+  planes8_out(v, pl0, npl0, pl1, npl1, npix * C, (long long)cg * npix + pix, fault);
 }
 
 // ---------------------------------------------------------------- CBAM backward (training; attentions.py:22-84)
@@ -1070,14 +1075,14 @@ extern "C" int swem_prep_value_input_f32(void *stream, const float *frame, const
 
 extern "C" int swem_prep_input_s2d_f32(void *stream, const float *frame, const float *masks, const float *mean3,
                                        const float *std3, float *out, void *planes, int nplanes, int B, int N, int H, int W,
-                                       int single_obj) {
+                                       int single_obj, void *fault) {
   SWEM_REQUIRE(frame && mean3 && std3 && (out || planes) && B > 0 && N > 0, SWEM_E_ARG, "prep_input_s2d: bad argument");
   SWEM_REQUIRE(H % 2 == 0 && W % 2 == 0, SWEM_E_SHAPE, "prep_input_s2d: the frame size must be even (got %dx%d)", H, W);
   SWEM_REQUIRE(!planes || nplanes == 2 || nplanes == 3 || nplanes == SWEM_PLANES_F16, SWEM_E_ARG, "prep_input_s2d: 2 or 3 planes, or SWEM_PLANES_F16");
   float3 m = make_float3(mean3[0], mean3[1], mean3[2]), s = make_float3(std3[0], std3[1], std3[2]);
   const long long n = (long long)B * N * (H / 2 + 1) * (W / 2 + 1) * 4;
   hipLaunchKernelGGL(prep_input_s2d_kernel, grid1(n), dim3(256), 0, ST, frame, masks, m, s, out,
-                     static_cast<unsigned short *>(planes), nplanes, B, N, H, W, single_obj);
+                     static_cast<unsigned short *>(planes), nplanes, B, N, H, W, single_obj, static_cast<unsigned *>(fault));
   SWEM_CHECK_LAUNCH("prep_input_s2d");
   return SWEM_OK;
 }
@@ -1092,7 +1097,7 @@ extern "C" int swem_maxpool3x3s2_nhwc_f32(void *stream, const float *x, float *y
 }
 
 extern "C" int swem_maxpool3x3s2_nhwc_f32_planes(void *stream, const float *x, float *y, int B, int H, int W, int C,
-                                                 void *planes, int nplanes, void *planes_relu, int nplanes_relu) {
+                                                 void *planes, int nplanes, void *planes_relu, int nplanes_relu, void *fault) {
   SWEM_REQUIRE(x && y && C % 8 == 0, SWEM_E_SHAPE, "maxpool_planes: need C %% 8 == 0");
   SWEM_REQUIRE((!planes || (nplanes >= 2 && nplanes <= 4)) && (!planes_relu || (nplanes_relu >= 2 && nplanes_relu <= 4)),
                SWEM_E_ARG, "maxpool_planes: 2 or 3 planes per variant");
@@ -1100,7 +1105,7 @@ extern "C" int swem_maxpool3x3s2_nhwc_f32_planes(void *stream, const float *x, f
   const long long npix = (long long)B * Ho * Wo;
   hipLaunchKernelGGL(maxpool_planes_kernel, dim3((unsigned)cdiv(npix, 32), (unsigned)cdiv(C / 8, 8)), dim3(256), 0, ST, x, y,
                      static_cast<unsigned short *>(planes), nplanes, static_cast<unsigned short *>(planes_relu), nplanes_relu,
-                     B, H, W, C, Ho, Wo);
+                     B, H, W, C, Ho, Wo, static_cast<unsigned *>(fault));
   SWEM_CHECK_LAUNCH("maxpool_planes");
   return SWEM_OK;
 }
@@ -1116,14 +1121,14 @@ extern "C" int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long 
 
 extern "C" int swem_upsample_add_nhwc_f32_planes(void *stream, const float *skip, long long skip_bs, const float *low,
                                                  float *y, int B, int Hl, int Wl, int Ho, int Wo, int C, void *planes,
-                                                 int nplanes, void *planes_relu, int nplanes_relu) {
+                                                 int nplanes, void *planes_relu, int nplanes_relu, void *fault) {
   SWEM_REQUIRE(skip && low && y && C % 8 == 0, SWEM_E_SHAPE, "upsample_add_planes: need C %% 8 == 0");
   SWEM_REQUIRE((!planes || (nplanes >= 2 && nplanes <= 4)) && (!planes_relu || (nplanes_relu >= 2 && nplanes_relu <= 4)),
                SWEM_E_ARG, "upsample_add_planes: 2 or 3 planes per variant");
   const long long npix = (long long)B * Ho * Wo;
   hipLaunchKernelGGL(upsample_add_planes_kernel, dim3((unsigned)cdiv(npix, 32), (unsigned)cdiv(C / 8, 8)), dim3(256), 0, ST,
                      skip, skip_bs, low, y, static_cast<unsigned short *>(planes), nplanes,
-                     static_cast<unsigned short *>(planes_relu), nplanes_relu, B, Hl, Wl, Ho, Wo, C);
+                     static_cast<unsigned short *>(planes_relu), nplanes_relu, B, Hl, Wl, Ho, Wo, C, static_cast<unsigned *>(fault));
   SWEM_CHECK_LAUNCH("upsample_add_planes");
   return SWEM_OK;
 }
@@ -1165,7 +1170,7 @@ extern "C" size_t swem_cbam_workspace(int B, int H, int W, int C) {
 
 static int cbam_impl(void *stream, const float *x, const float *w1, const float *b1, const float *w2, const float *b2,
                      const float *w7, const float *b7, float *cscale, float *y, int B, int H, int W, int C, int hid, void *ws,
-                     size_t ws_bytes, void *planes, int nplanes, void *planes_relu, int nplanes_relu) {
+                     size_t ws_bytes, void *planes, int nplanes, void *planes_relu, int nplanes_relu, void *fault) {
   SWEM_REQUIRE(x && w1 && b1 && w2 && b2 && w7 && b7 && cscale && y, SWEM_E_ARG, "cbam: null pointer");
   SWEM_REQUIRE(C % 4 == 0 && C <= 4096 && hid > 0 && hid <= 256, SWEM_E_SHAPE, "cbam: unsupported C/hid");
   SWEM_REQUIRE(ws && ws_bytes >= swem_cbam_workspace(B, H, W, C), SWEM_E_WORKSPACE, "cbam: workspace too small");
@@ -1195,7 +1200,7 @@ static int cbam_impl(void *stream, const float *x, const float *w1, const float 
                  SWEM_E_ARG, "cbam_planes: 2 or 3 planes per variant");
     hipLaunchKernelGGL(cbam_apply_planes_kernel, dim3((unsigned)cdiv((long long)B * P, 32), (unsigned)cdiv(C / 8, 8)),
                        dim3(256), 0, ST, x, cscale, sg, y, static_cast<unsigned short *>(planes), nplanes,
-                       static_cast<unsigned short *>(planes_relu), nplanes_relu, B, P, C);
+                       static_cast<unsigned short *>(planes_relu), nplanes_relu, B, P, C, static_cast<unsigned *>(fault));
   } else {
     hipLaunchKernelGGL(cbam_apply_kernel, grid1((long long)B * P * (C / 4)), dim3(256), 0, ST, x, cscale, sg, y, B, P, C);
   }
@@ -1206,15 +1211,15 @@ static int cbam_impl(void *stream, const float *x, const float *w1, const float 
 extern "C" int swem_cbam_f32(void *stream, const float *x, const float *w1, const float *b1, const float *w2,
                              const float *b2, const float *w7, const float *b7, float *cscale, float *y, int B, int H,
                              int W, int C, int hid, void *ws, size_t ws_bytes) {
-  return cbam_impl(stream, x, w1, b1, w2, b2, w7, b7, cscale, y, B, H, W, C, hid, ws, ws_bytes, nullptr, 3, nullptr, 3);
+  return cbam_impl(stream, x, w1, b1, w2, b2, w7, b7, cscale, y, B, H, W, C, hid, ws, ws_bytes, nullptr, 3, nullptr, 3, nullptr);
 }
 
 extern "C" int swem_cbam_f32_planes(void *stream, const float *x, const float *w1, const float *b1, const float *w2,
                                     const float *b2, const float *w7, const float *b7, float *cscale, float *y, int B, int H,
                                     int W, int C, int hid, void *ws, size_t ws_bytes, void *planes, int nplanes,
-                                    void *planes_relu, int nplanes_relu) {
+                                    void *planes_relu, int nplanes_relu, void *fault) {
   return cbam_impl(stream, x, w1, b1, w2, b2, w7, b7, cscale, y, B, H, W, C, hid, ws, ws_bytes, planes, nplanes, planes_relu,
-                   nplanes_relu);
+                   nplanes_relu, fault);
 }
 
 // backward of y = x + CBAM(x) (swem_cbam_f32): dx; the six parameter gradients are ACCUMULATED.

@@ -36,9 +36,34 @@ class FrameSecondMeter:
         return self.frame_n / self.total_time
 
 
+def range_fallback(model, err, what):
+    """A sequence raised SwemRangeError: an activation of THIS model on THIS input left the fp16 range of the f16x3 arithmetic
+    (the reference's fp32 inference has no such limit, networks.py:22-32).  The model's book leaves f16x3 for the bf16x6 /
+    fp32 kernels (ops.PlanBook.to_full_range: all 24 operand bits, fp32 exponent range) and stays there -- a checkpoint that
+    overflows once will again -- and the caller re-runs the sequence, fresh work in this process.  Loud: a warning per model."""
+    import warnings
+    if model.book.full_range:
+        raise err            # (cannot happen: a full-range book produces no fp16 pair)
+    n = model.book.to_full_range()
+    warnings.warn('swem_amd: %s: %s -- this model now runs the full-range arithmetic (bf16x6 / fp32 kernels; %d tuned f16x3 '
+                  'plans converted): about 0.6x the f16x3 frame rate, the reference\'s fp32 range' % (what, err, n), RuntimeWarning)
+
+
 def evaluate_davis_seq(model, frames, init_masks, out_size, trace=None):
     """frames (1,T,3,H,W) in [0,1] on the device; init_masks list with a (1,N+1,Ho,Wo) float mask first;
-    returns (list of (1,Ho,Wo) int64 index maps, list of (1,N+1,Ho,Wo) probability maps)."""
+    returns (list of (1,Ho,Wo) int64 index maps, list of (1,N+1,Ho,Wo) probability maps).
+    A sequence whose activations leave the fp16 range of the default f16x3 arithmetic is re-run in the full-range one
+    (`range_fallback`): the result is then the fp32-range result, never a silently wrong mask."""
+    try:
+        return _davis_seq(model, frames, init_masks, out_size, trace)
+    except ops.SwemRangeError as err:
+        range_fallback(model, err, 'evaluate_davis_seq')
+        if trace is not None:
+            del trace[:]
+        return _davis_seq(model, frames, init_masks, out_size, trace)
+
+
+def _davis_seq(model, frames, init_masks, out_size, trace=None):
     preds, pred_scores = [], []
     b, t, c, h, w = frames.shape
     out_size = (int(out_size[0]), int(out_size[1]))
@@ -69,7 +94,16 @@ def evaluate_davis_seq(model, frames, init_masks, out_size, trace=None):
 def evaluate_ytvos_seq(model, frames, init_masks, out_size):
     """swem_evaluator.py:104-148: like the DAVIS loop, but objects may be annotated from a later frame on:
     ``init_masks[i]`` (1,N'+1,Ho,Wo) then zeroes the predicted scores where a new object sits and appends the new
-    masks as extra channels; the memory grows by random-initialised bases for the new ids (modules.py:140-146)."""
+    masks as extra channels; the memory grows by random-initialised bases for the new ids (modules.py:140-146).
+    Range faults of the f16x3 arithmetic: as evaluate_davis_seq."""
+    try:
+        return _ytvos_seq(model, frames, init_masks, out_size)
+    except ops.SwemRangeError as err:
+        range_fallback(model, err, 'evaluate_ytvos_seq')
+        return _ytvos_seq(model, frames, init_masks, out_size)
+
+
+def _ytvos_seq(model, frames, init_masks, out_size):
     preds = []
     b, t, c, h, w = frames.shape
     out_size = (int(out_size[0]), int(out_size[1]))
@@ -619,12 +653,17 @@ class SequencePool:
         # plans='shipped' (default): a pool whose book holds no tuned conv plan yet loads the plan file that ships with the
         # library (swem_amd/plans/: 480p, K = 256, 1-5 objects on MI355X) -- layer shapes it does not hold run the
         # book's fallback (f16x3 on the heuristic tile).  plans=None: the book as it is; a path: that file.
+        # The shipped file is f16x3 plans tuned on an MI355X: it is NOT loaded into a book whose owner chose another default
+        # arithmetic (book.fallback = 0: the exact fp32 kernels; a book that has left the fp16 range) nor on a device of
+        # another architecture -- those run the book as it is.
         book = self.models[0].book
-        if plans is not None and not book.conv:
+        dev = next(self.models[0].parameters()).device
+        if plans is not None and not book.conv and (plans != 'shipped' or
+                                                    ((book.fallback >> 16) & 7 == 7 and not book.full_range)):
             import os
             path = ops.shipped_plans() if plans == 'shipped' else plans
             if os.path.exists(path):
-                book.load(path)
+                book.load(path, device=dev if plans == 'shipped' else None)
         self.streams = overlapping_streams(n) if n > 1 else [torch.cuda.current_stream()]
         self.graphs = [None] * n
         self.graph_streams = [None] * n      # per lane: (warm-up stream, capture stream), reused by every re-capture
@@ -659,7 +698,17 @@ class SequencePool:
     def run(self, sequences, seeds=None):
         """sequences: list of (frames (1,T,3,H,W), init_mask (1,N+1,Ho,Wo), out_size); returns one list of (1,Ho,Wo)
         int64 index maps per sequence (frames 1..T-1), in input order.  seeds: optional torch seed per sequence, set
-        right before its memory is initialised (reproducible random bases whatever the interleaving)."""
+        right before its memory is initialised (reproducible random bases whatever the interleaving).
+        A range fault of the f16x3 arithmetic (ops.SwemRangeError at the final check) moves the lanes' shared book to the
+        full-range arithmetic, drops the captured graphs (they hold f16x3 launches) and runs the call's sequences again."""
+        try:
+            return self._run(sequences, seeds)
+        except ops.SwemRangeError as err:
+            range_fallback(self.models[0], err, 'SequencePool.run')
+            self.graphs = [None] * len(self.models)
+            return self._run(sequences, seeds)
+
+    def _run(self, sequences, seeds=None):
         todo = list(enumerate(sequences))
         results = [None] * len(sequences)
         k = self.lookahead

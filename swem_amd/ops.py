@@ -100,6 +100,9 @@ class PlanBook:
         # with: every output element is then one k-ordered MFMA chain whatever the grid (tests compare batched and per-frame
         # passes bit for bit under it).
         self.fallback = fallback
+        # True once the book has left the f16x3 arithmetic for good (to_full_range): no launch under it reads or writes an fp16
+        # operand pair any more, and nothing re-loads f16x3 plans into it
+        self.full_range = False
 
     @property
     def fallback(self):
@@ -122,6 +125,27 @@ class PlanBook:
         self.hint_epoch.clear()
         self.res_epoch.clear()
 
+    def to_full_range(self):
+        """Leave the f16x3 arithmetic (range |x| < 65520) for the full-range ones, in place: after a SWEM_FAULT_RANGE
+        (`check_faults` raised SwemRangeError) the work is re-run under this book and cannot fault again.  Every tuned conv plan
+        in math 7 keeps its block tile and K-split and becomes bf16x6 (math 1: three bf16 planes per operand = all 24 bits, the
+        fp32 exponent range; kernel variant and tail-split bits are dropped -- some f16x3 variants have no three-plane form);
+        matching's readout plans are dropped (-> the fp32 readout from `mvp`); untuned shapes run bf16x6 on the heuristic tile;
+        the fused-split hints are forgotten (their producers wrote fp16 pairs) and re-learned on the next frames.  This is the
+        reference's own range: its inference runs in fp32 (networks.py:22-32).  Returns the number of conv plans changed."""
+        n = 0
+        for k, v in list(self.conv.items()):
+            if (v >> 16) & 7 == 7:
+                self.conv[k] = (v & 0xffff) | (1 << 16)
+                n += 1
+        self.match.clear()
+        self.hints.clear()
+        self.hint_epoch.clear()
+        self.res_epoch.clear()
+        self.fallback = 1 << 16
+        self.full_range = True
+        return n
+
     def math_histogram(self, tag=()):
         """{'fp32': n, 'bf16x6': n, 'bf16': n, 'bf16x3': n, 'f16x3': n} over the conv plans tuned under the conv_math tag `tag`
         (default: the untagged ones; a plan of 0 is the fp32 heuristic)."""
@@ -140,21 +164,38 @@ class PlanBook:
     def save(self, path):
         import json
         with open(path, 'w') as f:
-            json.dump({'conv': [[list(k), v] for k, v in self.conv.items()],
+            json.dump({'device': device_arch(), 'conv': [[list(k), v] for k, v in self.conv.items()],
                        'match': [[list(k), v] for k, v in self.match.items()]}, f)
 
-    def load(self, path):
+    def load(self, path, device=None):
+        """Add the plans of a file.  device (a torch device): the plans are only taken if the file names that device's
+        architecture ('device': the gcnArchName prefix it was tuned on) -- tile choices tuned on an MI355X are not a default for
+        anything else; a mismatch loads nothing and returns False (no device given: loaded unconditionally)."""
         import json
         with open(path) as f:
             d = json.load(f)
-        self.conv.update({tuple(k): v for k, v in d.get('conv', [])})
-        self.match.update({tuple(k): v for k, v in d.get('match', [])})
+        if device is not None and d.get('device') and d['device'] != device_arch(device):
+            return False
+        conv = {tuple(k): v for k, v in d.get('conv', [])}
+        match = {tuple(k): v for k, v in d.get('match', [])}
+        if self.full_range:          # (a book that faulted out of the fp16 range stays out of it)
+            conv = {k: ((v & 0xffff) | (1 << 16)) if (v >> 16) & 7 == 7 else v for k, v in conv.items()}
+            match = {}
+        self.conv.update(conv)
+        self.match.update(match)
         return self
 
     def load_shipped(self, name='mi355x_480p_k256'):
         """The plan file that ships with the library for a named workload (swem_amd/plans/): the per-layer tuner's choices
         checked in the whole frame (tools/tune_in_context.py).  Opt-in: a fresh book is empty = the fp32 kernels."""
         return self.load(shipped_plans(name))
+
+
+def device_arch(device=None):
+    """'gfx950' for an MI355X: the architecture name plan files are keyed by."""
+    if not torch.cuda.is_available():
+        return None
+    return torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).gcnArchName.split(':')[0]
 
 
 def shipped_plans(name='mi355x_480p_k256'):
@@ -366,10 +407,17 @@ def workspace(nbytes, device):
 
 _ctr = {}
 _ctr_capture = {}
-_ctr_all = []            # weak references to every counter buffer handed out (check_faults reads their fault words)
+_ctr_all = []            # weak references to every counter buffer handed out (a wait fault zeroes them)
 N_COUNTERS = 16384
-FAULT_BITS = {1: 'a K-split reducer gave up waiting for the other splits\' partial tiles',
-              2: 'a stream-K tile owner gave up waiting for a producer\'s partial tile'}
+FAULT_KSPLIT, FAULT_STREAMK, FAULT_RANGE = 1, 2, 4      # include/swem_hip.h, SWEM_FAULT_*
+FAULT_BITS = {FAULT_KSPLIT: 'a K-split reducer gave up waiting for the other splits\' partial tiles (those output tiles are wrong; '
+                            'the tile counters have been reset)',
+              FAULT_STREAMK: 'a stream-K tile owner gave up waiting for a producer\'s partial tile (those output tiles are '
+                             'wrong; the tile counters have been reset)',
+              FAULT_RANGE: 'a value beyond the fp16 range (|x| >= 65520, inf or NaN) went into an fp16 operand pair of the f16x3 '
+                           'arithmetic: everything computed from those planes is wrong, possibly FINITE (a ReLU epilogue maps the '
+                           'resulting NaN to 0) -- re-run in a full-range arithmetic (PlanBook.to_full_range)'}
+SwemRangeError = _lib.SwemRangeError
 
 
 def counters(device):
@@ -377,10 +425,7 @@ def counters(device):
     swem_conv2d_nhwc_bf16x3_planes_ctr): a zero-initialised buffer per (device, stream) that the kernels leave all zero, so no
     memset launch precedes each of them.  Inside a graph capture the buffer belongs to that capture (like `workspace`): graphs
     captured on one stream may be replayed on different streams at the same time and must not share counters; its zero fill is
-    one node at the head of the graph, replayed with it.
-    The LAST word of the buffer is the launches' sticky FAULT word: a kernel whose bounded wait for another block's partial
-    tile expires (a preempted or never-dispatched producer: the output tile is then wrong) ORs a bit into it and nothing on
-    the device ever clears it -- `check_faults` reads it on the host and raises."""
+    one node at the head of the graph, replayed with it (which is why the fault word is NOT part of it: `fault_word`)."""
     import weakref
     dev = device.index if device.index is not None else torch.cuda.current_device()
     st = _stream()
@@ -399,25 +444,58 @@ def counters(device):
     return buf
 
 
+_fault = {}              # device index -> that device's sticky fault word (held for the life of the process)
+
+
+def fault_word(device=None):
+    """The device's sticky FAULT word (include/swem_hip.h, "Asynchronous faults"): ONE int32 per device, zero-initialised once,
+    allocated outside any graph capture and never touched by a graph's memset nodes, so a fault raised inside replay k of a
+    HIP graph is still there after replay k + 1 (as the last word of the per-capture counter buffer it was
+    re-zeroed at the head of every replay and unreachable once a newer capture existed).  Kernels only ever OR bits into it;
+    `check_faults` reads and clears it."""
+    if device is None or device.index is None:
+        dev = torch.cuda.current_device()
+    else:
+        dev = device.index
+    t = _fault.get(dev)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.SwemHipError('ops.fault_word: the first launch on device %d falls inside a graph capture; call '
+                                    'ops.fault_word(device) (or run one eager pass) before capturing' % dev)
+        t = _fault[dev] = torch.zeros(1, dtype=torch.int32, device=torch.device('cuda', dev))
+    return t
+
+
+def _fault_ptr(device):
+    return fault_word(device).data_ptr()
+
+
 def check_faults():
-    """Asynchronous faults of the launches made so far (the C ABI's return codes only cover what is known at enqueue time):
-    reads the fault word of every counter buffer -- one small device-to-host copy, i.e. a synchronisation: call it where the
-    host waits anyway (the evaluator does at the end of every sequence, bench.py behind its timed regions).  On a fault every
-    counter buffer is zeroed (a stale tile counter would corrupt the next launch the same way) and SwemHipError is raised."""
-    bufs = [b for b in (r() for r in _ctr_all) if b is not None]
-    if not bufs:
-        return
-    words = [int(v) for v in torch.stack([b[-1] for b in bufs]).tolist()]
-    if any(words):
-        for b in bufs:
-            b.zero_()
-        torch.cuda.synchronize()
-        bits = 0
-        for w in words:
-            bits |= w
-        what = '; '.join(t for b, t in FAULT_BITS.items() if bits & b) or 'unknown fault bits %#x' % bits
-        raise _lib.SwemHipError('asynchronous fault in a convolution launch: %s -- the affected output tiles are wrong; the '
-                                'counters have been reset, re-run the sequence' % what)
+    """Asynchronous faults of the launches made so far on every device this process used (the C ABI's return codes only cover
+    what is known at enqueue time).  Synchronises each device and reads its fault word: call it where the host waits anyway
+    (the evaluator does at the end of every sequence, bench.py behind its timed regions, the trainer where it reads the
+    loss).  On a fault the word is cleared, on a WAIT fault every tile-counter buffer of that device is zeroed too (a stale
+    counter would corrupt the next launch the same way), and an exception is raised: SwemRangeError when the only fault is
+    SWEM_FAULT_RANGE (the launches themselves were sound: re-run in a full-range arithmetic), else SwemHipError."""
+    bits = 0
+    for dev, t in _fault.items():
+        torch.cuda.synchronize(dev)            # (every stream: a lane of a SequencePool may still be running)
+        w = int(t.item())
+        if not w:
+            continue
+        bits |= w
+        t.zero_()
+        if w & (FAULT_KSPLIT | FAULT_STREAMK):
+            for b in (r() for r in _ctr_all):
+                if b is not None and b.device.index == dev:
+                    b.zero_()
+        torch.cuda.synchronize(dev)
+    if bits:
+        what = '; '.join(t for b, t in FAULT_BITS.items() if bits & b)
+        if bits & ~(FAULT_KSPLIT | FAULT_STREAMK | FAULT_RANGE):
+            what += '; unknown fault bits %#x' % bits
+        cls = SwemRangeError if bits == FAULT_RANGE else _lib.SwemHipError
+        raise cls('asynchronous fault (fault word %#x): %s' % (bits, what))
 
 
 class ConvPack:
@@ -466,7 +544,7 @@ class ConvPack:
             f = torch.exp2(e.clamp(-100, 100))
             w16 = torch.empty((2, co * kk), dtype=torch.float16, device=wk.device)
             _lib.call('swem_split_f16x2_f32', _stream(), (wk.reshape(co, kk) * f[:, None]).contiguous().data_ptr(),
-                      w16.data_ptr(), co, kk, 0)
+                      w16.data_ptr(), co, kk, 0, 0)      # (scaled into [2^13, 2^14): cannot leave the range)
             sc = (self.scale if self.scale is not None else torch.ones_like(f)) / f
             self._w16 = (w16, sc.contiguous())
         return self._w16
@@ -525,8 +603,10 @@ def presplit(t, relu=False, nplanes=3):
     once per tensor and cached on it: conv inputs are never modified after they are produced.  npix covers the tensor's
     storage range (a batch stride larger than one image, as match's mem_out has, is kept).  nplanes: how many of the three
     the caller reads (2 for a bf16x3 / plain-bf16 consumer; PLANES_F16: the fp16 (hi, mid) pair of an f16x3 consumer, its
-    own cache entry -- a request for it outranks bf16 requests in the producer's hint, a tensor with consumers of both
-    formats pays a split launch for the bf16 ones).  A producer that knows its consumers writes the planes itself
+    own cache entry.  In the producer's hint the LATEST request decides the format: a planes-only output has ONE consumer,
+    which must find its format; a tensor with consumers of BOTH formats -- mixed tuned plans -- therefore settles on
+    whichever asks last, and the other pays a split launch per frame: counted in `RESPLITS`, tools/split_sites.py lists the
+    sites).  A producer that knows its consumers writes the planes itself
     (conv2d's epilogue, the frozen-BN stages of the training step): the request is recorded under the producer's site so
     that it can do so from the next frame / step on."""
     cache = t.__dict__.setdefault('_swem_split', {})
@@ -555,16 +635,23 @@ def presplit(t, relu=False, nplanes=3):
         B, H, W, Cc = t.shape
         if B > 1 and t.stride(0) % Cc:
             raise _lib.SwemHipError('presplit: batch stride must be a multiple of the channel count')
+        if site is not None and cache and not _IN_TUNER[0]:
+            # the producer DID write planes for this tensor, only not these: a consumer of the other format (or of more planes)
+            # pays this launch every frame -- ADVICE r04: count it instead of paying it silently
+            RESPLITS[site] = RESPLITS.get(site, 0) + 1
         npix = (B - 1) * (t.stride(0) // Cc) + H * W if B > 1 else H * W
         if f16:
             sp = torch.empty((2, npix * Cc), dtype=torch.float16, device=t.device)
-            _lib.call('swem_split_f16x2_f32', _stream(), t.data_ptr(), sp.data_ptr(), npix, Cc, int(relu))
+            _lib.call('swem_split_f16x2_f32', _stream(), t.data_ptr(), sp.data_ptr(), npix, Cc, int(relu), _fault_ptr(t.device))
             ent = cache[key] = (sp, PLANES_F16)
         else:
             sp = torch.empty((3, npix * Cc), dtype=torch.bfloat16, device=t.device)
             _lib.call('swem_split_bf16x3_f32', _stream(), t.data_ptr(), sp.data_ptr(), npix, Cc, int(relu))
             ent = cache[key] = (sp, 3)
     return ent[0]
+
+
+RESPLITS = {}      # producer site -> split launches made for a tensor that already carried producer-written planes
 
 
 def _pkey(relu, npl):
@@ -740,18 +827,18 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
                 _lib.call('swem_conv2d_nhwc_bf16x3_planes_res', _stream(), *sargs, B, H, W, w3.data_ptr(), _ptr(scale),
                           _ptr(pack.shift), rp.data_ptr(), rp.stride(0), rp.stride(0) // pack.cout, rnpl, res_bs, y_ptr,
                           pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags & ~RELU_IN, plan, _ptr(ws), wsb, *pargs,
-                          _ptr(ctr), 0 if ctr is None else ctr.numel())
+                          _ptr(ctr), 0 if ctr is None else ctr.numel(), _fault_ptr(x0.device))
                 return
             _lib.call('swem_conv2d_nhwc_bf16x3_planes_ctr', _stream(), *sargs, B, H, W, w3.data_ptr(), _ptr(scale),
                       _ptr(pack.shift), _ptr(residual), res_bs, y_ptr, pack.cout, pack.kh, pack.kw,
                       pack.stride, pack.pad, flags & ~RELU_IN, plan, _ptr(ws), wsb, *pargs, _ptr(ctr),
-                      0 if ctr is None else ctr.numel())
+                      0 if ctr is None else ctr.numel(), _fault_ptr(x0.device))
             return
         if res_planes is not None or any(s_.__dict__.get('_swem_planes_only') for s_ in srcs):
             raise _lib.SwemHipError('conv2d: a planes-only source or residual reached a convolution that reads the fp32 map (plan %#x)' % plan)
         _lib.call('swem_conv2d_nhwc_f32_planes', _stream(), *args, B, H, W, pack.w.data_ptr(), 0, _ptr(pack.scale),
                   _ptr(pack.shift), _ptr(residual), res_bs, y_ptr, pack.cout, pack.kh, pack.kw, pack.stride,
-                  pack.pad, flags, plan, _ptr(ws), wsb, *pargs)
+                  pack.pad, flags, plan, _ptr(ws), wsb, *pargs, _fault_ptr(x0.device))
 
     sig = (cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags, B, H, W) + _PLAN_TAG
     explicit = plan is not None
@@ -998,7 +1085,7 @@ def prep_input_s2d(frame, masks, mean3, std3, single_obj=False):
     npl = PLANES_F16 if BOOK.hints.get(site, {}).get(False) == PLANES_F16 else 3
     sp = _new_planes(npl, out.numel(), frame.device)
     _lib.call('swem_prep_input_s2d_f32', _stream(), frame.data_ptr(), _ptr(masks), C.addressof(mean3), C.addressof(std3),
-              out.data_ptr(), sp.data_ptr(), npl, B, N, H, W, int(single_obj))
+              out.data_ptr(), sp.data_ptr(), npl, B, N, H, W, int(single_obj), _fault_ptr(frame.device))
     out.__dict__['_swem_split'] = {_pkey(False, npl): (sp, npl)}
     out.__dict__['_swem_split_ver'] = out._version
     out.__dict__['_swem_site'] = site
@@ -1012,7 +1099,8 @@ def maxpool(x):
     site = ('maxpool', B, H, W, Cc)
     planes, pargs = _fused_planes(site, y.numel(), y.device) if Cc % 8 == 0 else ({}, None)
     if planes:
-        _lib.call('swem_maxpool3x3s2_nhwc_f32_planes', _stream(), x.data_ptr(), y.data_ptr(), B, H, W, Cc, *pargs)
+        _lib.call('swem_maxpool3x3s2_nhwc_f32_planes', _stream(), x.data_ptr(), y.data_ptr(), B, H, W, Cc, *pargs,
+                  _fault_ptr(x.device))
         y.__dict__['_swem_split'] = planes
         y.__dict__['_swem_split_ver'] = y._version
     else:
@@ -1046,7 +1134,7 @@ def upsample_add(skip, low, batch=None):
     planes, pargs = _fused_planes(site, y.numel(), y.device) if Cc % 8 == 0 else ({}, None)
     if planes:
         _lib.call('swem_upsample_add_nhwc_f32_planes', _stream(), skip.data_ptr(), sbs, low.data_ptr(), y.data_ptr(), B,
-                  low.shape[1], low.shape[2], Ho, Wo, Cc, *pargs)
+                  low.shape[1], low.shape[2], Ho, Wo, Cc, *pargs, _fault_ptr(low.device))
         y.__dict__['_swem_split'] = planes
         y.__dict__['_swem_split_ver'] = y._version
     else:
@@ -1122,7 +1210,7 @@ def cbam_residual(x, w1, b1, w2, b2, w7, b7):
     args = (_stream(), x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w7.data_ptr(),
             b7.data_ptr(), cscale.data_ptr(), y.data_ptr(), B, H, W, Cc, hid, ws.data_ptr(), wsb)
     if planes:
-        _lib.call('swem_cbam_f32_planes', *args, *pargs)
+        _lib.call('swem_cbam_f32_planes', *args, *pargs, _fault_ptr(x.device))
         y.__dict__['_swem_split'] = planes
         y.__dict__['_swem_split_ver'] = y._version
     else:
@@ -1272,7 +1360,7 @@ def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau, pack=None, pri
         _lib.call('swem_memorize_packed_f32', _stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(),
                   kappa_prev.data_ptr(), nu_prev.data_ptr(), zita_prev.data_ptr(), kappa.data_ptr(), nu.data_ptr(),
                   zita.data_ptr(), _chk(pack[0]).data_ptr(), _chk(pack[1]).data_ptr(), _pack_planes(pack),
-                  int(prior_packed), int(bank), N, Cc, V, P, L, int(T), float(tau), ws.data_ptr(), wsb)
+                  int(prior_packed), int(bank), N, Cc, V, P, L, int(T), float(tau), ws.data_ptr(), wsb, _fault_ptr(x.device))
         return kappa, nu, zita
     _lib.call('swem_memorize_f32', _stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(), kappa_prev.data_ptr(),
               nu_prev.data_ptr(), zita_prev.data_ptr(), kappa.data_ptr(), nu.data_ptr(), zita.data_ptr(), N, Cc, V,
@@ -1314,7 +1402,7 @@ def memorize_values(v, z, nu_prev, zita_prev, pack, bank=1, out=None):
     if nu.data_ptr() == nu_prev.data_ptr():
         raise _lib.SwemHipError('memorize_values: out must not alias the prior')
     _lib.call('swem_memorize_packed_values_f32', _stream(), v.data_ptr(), z.data_ptr(), nu_prev.data_ptr(), zita_prev.data_ptr(),
-              nu.data_ptr(), _chk(pack[1]).data_ptr(), _pack_planes(pack), int(bank), N, V, P, L)
+              nu.data_ptr(), _chk(pack[1]).data_ptr(), _pack_planes(pack), int(bank), N, V, P, L, _fault_ptr(v.device))
     return nu
 
 
@@ -1370,7 +1458,9 @@ def new_pack(N, Cc, V, L, device):
 
 
 def _pack_planes(pack):
-    if len(pack) < 3 or pack[2] is None:
+    # (a book that left the f16x3 arithmetic -- PlanBook.to_full_range -- reads the fp32 value bases `mvp`: the fp16 pair is
+    # then neither written nor range-checked)
+    if len(pack) < 3 or pack[2] is None or BOOK.full_range:
         return None
     q = pack[2]
     if not (q.is_cuda and q.dtype == torch.float16 and q.is_contiguous()):
@@ -1384,7 +1474,7 @@ def pack_bank(kappa, nu, pack, bank):
     _chk(nu)
     N, _, Cc, L = kappa.shape
     _lib.call('swem_match_pack_bank_f32', _stream(), kappa.data_ptr(), nu.data_ptr(), pack[0].data_ptr(),
-              pack[1].data_ptr(), _pack_planes(pack), int(bank), 2, N, Cc, nu.shape[2], L)
+              pack[1].data_ptr(), _pack_planes(pack), int(bank), 2, N, Cc, nu.shape[2], L, _fault_ptr(kappa.device))
 
 
 def match_packed(qk, pack, L, topl, tau, hw=None):
@@ -1416,7 +1506,7 @@ def match_packed(qk, pack, L, topl, tau, hw=None):
                 if want and key not in planes:
                     planes[key] = (_new_planes(want, numel, qk.device), want)
                 pargs += [planes[key][0].data_ptr(), planes[key][1]] if want else [0, 3]
-            _lib.call('swem_match_packed_f32_planes', *args, *pargs)
+            _lib.call('swem_match_packed_f32_planes', *args, *pargs, _fault_ptr(qk.device))
         else:
             planes.clear()
             _lib.call('swem_match_packed_f32', *args)

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_version_and_error_channel(lib):
-    assert lib.swem_version() == 1
+    assert lib.swem_version() == 2      # round 5: explicit fault-word arguments
     # argument validation happens before any HIP call, so it can be exercised without a GPU
     rc = lib.swem_conv2d_nhwc_f32(None, None, 4, 0, None, 0, 0, None, 0, 0, 1, 8, 8, None, 0, None, None, None, 0, None,
                                   32, 3, 3, 1, 1, 0, 0, None, 0)
@@ -73,3 +73,21 @@ def test_lds_dma_kernels_are_the_only_m0_users():
         assert body.count('offen lds') == len(uses)            # one M0 write per transfer, nothing else
         checked += 1
     assert checked >= 6
+
+
+def test_integration_md_binding_matches_the_signature_table(lib):
+    """INTEGRATION.md section 2's ctypes stub (the reference-side binding of matching) is executed on the GPU by
+    tests/test_gpu_em.py::test_integration_md_ctypes_binding_runs_as_printed; here, without a GPU: the block compiles, loads the
+    library, and declares the argument types swem_amd/_lib.py holds for the same entry points."""
+    root = os.path.join(os.path.dirname(__file__), '..')
+    md = open(os.path.join(root, 'INTEGRATION.md')).read()
+    sec = md[md.index('## 2. Binding the C ABI directly'):md.index('## 3.')]
+    code = re.search(r'```python\n(.*?)```', sec, flags=re.S).group(1)
+    ns = {}
+    exec(compile(code.replace("'swem_amd/libswem_hip.so'", repr(os.path.join(root, 'swem_amd', 'libswem_hip.so'))),
+                 'INTEGRATION.md#2', 'exec'), ns)
+    for name in ('swem_match_workspace', 'swem_match_f32'):
+        fn = getattr(ns['lib'], name)
+        res, args = _lib.SIGNATURES[name]
+        assert fn.restype is res and list(fn.argtypes) == list(args), name
+    assert callable(ns['matching_features'])

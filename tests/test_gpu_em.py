@@ -105,6 +105,45 @@ def test_matching_vs_golden(lib, golden):
         assert e_S < 1e-4, '%s S abs err %.3g' % (tag, e_S)
 
 
+def test_integration_md_ctypes_binding_runs_as_printed(lib, golden):
+    """INTEGRATION.md section 2 shows the reference-side binding a maintainer would paste into methods/SWEM/modules.py
+    (`matching_features`, in place of get_affinity + perm_inv_feat, modules.py:198-208,232-276).  The code block is taken from
+    the document VERBATIM and executed -- only the library path is made absolute -- on a core holding the reference's banks
+    (fixtures g2 / g3), with one bank and with two, against the reference's recorded S / mem_out and against the oracle."""
+    import os
+    import re
+    import types
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    md = open(os.path.join(root, 'INTEGRATION.md')).read()
+    sec = md[md.index('## 2. Binding the C ABI directly'):md.index('## 3.')]
+    code = re.search(r'```python\n(.*?)```', sec, flags=re.S).group(1)
+    assert 'def matching_features(core, qk)' in code and "C.CDLL('swem_amd/libswem_hip.so')" in code
+    ns = {}
+    exec(compile(code.replace("'swem_amd/libswem_hip.so'", repr(os.path.join(root, 'swem_amd', 'libswem_hip.so'))),
+                 'INTEGRATION.md#2', 'exec'), ns)
+    g, m = golden('g2_memorize.npz'), golden('g3_matching.npz')
+    qk = d(m['qk'])                                                   # (1, C, h, w) as modules.py:278-283 passes it
+    h, w = qk.shape[-2:]
+    bank = lambda i: {'kappa': d(g['kappa%d' % i]), 'nu': d(g['nu%d' % i])}
+    for tag, upd, Sref, memref in (('Lm=64', None, m['S1'], m['mem1']), ('Lm=128', bank(1), m['S2'], m['mem2'])):
+        core = types.SimpleNamespace(memories={'first': types.SimpleNamespace(bases=bank(0)),
+                                               'update': types.SimpleNamespace(bases=upd)}, topl=64, tau=0.05)
+        S, mem = ns['matching_features'](core, qk)
+        torch.cuda.synchronize()
+        mem = mem.reshape(2, h, w, -1).permute(0, 3, 1, 2).cpu()
+        S = S.view(2, h, w, -1).permute(0, 3, 1, 2).cpu()
+        assert float((mem - memref[0]).abs().max()) < 1e-4 * max(1.0, float(memref.abs().max())), tag
+        assert float((S - Sref).abs().max()) < 1e-4, tag
+        # ... and the oracle's get_affinity on the same banks (oracle/swem_oracle.py, bit-identical to the reference)
+        oc = O.Core(g['kappa0'].shape[-1], g['nu0'].shape[-2], 4, 0.05, 64)
+        oc.first.update({'kappa': g['kappa0'], 'nu': g['nu0'], 'zita': g['zita0']})
+        if upd is not None:
+            oc.upd.update({'kappa': g['kappa1'], 'nu': g['nu1'], 'zita': g['zita1']})
+        omem, _, oS, _ = oc.match_features(m['qk'], torch.zeros(1, g['nu0'].shape[-2], h, w))
+        assert float((mem - omem).abs().max()) < 1e-4 * max(1.0, float(omem.abs().max())), tag
+        assert float((S - oS).abs().max()) < 1e-4, tag
+
+
 @pytest.mark.parametrize('L,T', [(64, 4), (128, 3), (256, 5)])
 def test_memorize_and_match_vs_oracle(lib, L, T):
     """Fresh seeded inputs, oracle computed on the CPU at test time; covers every template instance (L = 64/128/256)."""
@@ -253,7 +292,7 @@ def test_packed_banks_equal_the_per_frame_packing(lib, L):
                 assert n_ == npl and ops.presplit(img, False, npl) is planes
                 if npl == F16:
                     sp = torch.empty((2, npix * Cc), dtype=torch.float16, device=DEV)
-                    __import__('swem_amd')._lib.call('swem_split_f16x2_f32', ops._stream(), flat.data_ptr(), sp.data_ptr(), npix, Cc, 0)
+                    __import__('swem_amd')._lib.call('swem_split_f16x2_f32', ops._stream(), flat.data_ptr(), sp.data_ptr(), npix, Cc, 0, 0)
                     assert torch.equal(planes.view(torch.int16), sp.view(torch.int16))
                 else:
                     sp = torch.empty((3, npix * Cc), dtype=torch.bfloat16, device=DEV)

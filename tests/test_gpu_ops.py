@@ -351,7 +351,7 @@ def test_space_to_depth_stem_equals_the_7x7_stem(lib, value):
 def _split_of(t, M, C, relu, npl=3):
     if npl == ops.PLANES_F16:
         sp = torch.empty((2, M * C), dtype=torch.float16, device=DEV)
-        __import__('swem_amd')._lib.call('swem_split_f16x2_f32', ops._stream(), t.data_ptr(), sp.data_ptr(), M, C, int(relu))
+        __import__('swem_amd')._lib.call('swem_split_f16x2_f32', ops._stream(), t.data_ptr(), sp.data_ptr(), M, C, int(relu), 0)
         return sp
     sp = torch.empty((3, M * C), dtype=torch.bfloat16, device=DEV)
     __import__('swem_amd')._lib.call('swem_split_bf16x3_f32', ops._stream(), t.data_ptr(), sp.data_ptr(), M, C, int(relu))
@@ -631,13 +631,114 @@ def test_f16x3_small_and_large_operands(lib):
             assert errs['f16x3'] < max(3 * errs['fp32'], 2e-6) and 3 * errs['f16x3'] < errs['bf16x3'], (xs, ws, errs)
 
 
-def test_f16x3_out_of_range_is_loud(lib):
-    """An activation beyond the fp16 range gives inf planes and a NaN / inf result -- never a finite wrong number."""
+def _expect_range_fault():
+    with pytest.raises(ops.SwemRangeError, match='fp16 range'):
+        ops.check_faults()
+    ops.check_faults()                 # cleared by the raise: clean again
+
+
+def test_f16x3_out_of_range_raises_through_a_relu_epilogue(lib):
+    """An activation beyond the fp16 range gives inf / NaN planes; WITHOUT a ReLU the consumer's output is NaN, but a ReLU
+    epilogue (v_max_f32 0, x) maps that NaN to 0 -- a finite, wrong feature map.  What makes it loud is
+    the producer: whoever writes a value with |x| >= 65520 into an fp16 pair sets SWEM_FAULT_RANGE in the caller's sticky
+    fault word and ops.check_faults() raises SwemRangeError.  Every producer is exercised: the stand-alone split (with and
+    without its input ReLU), a conv epilogue (both plane variants, K-split reducer included), max-pool, upsample-add, CBAM,
+    the space-to-depth input, matching's value planes."""
+    ops.check_faults()
     x = torch.ones(1, 32, 8, 8)
     x[0, 3, 2, 2] = 1.0e5
     w = torch.ones(32, 32, 1, 1) * 0.01
-    y = back(ops.conv2d([nhwc(x)], ops.pack_conv(w.to(DEV)), plan=0x70011))
+    pack = ops.pack_conv(w.to(DEV))
+    # (1) the split launch of an fp32 map, consumer WITH a ReLU epilogue: the wrong pixel comes out as a clean 0
+    y = back(ops.conv2d([nhwc(x)], pack, relu_out=True, plan=0x70011))
+    assert torch.isfinite(y).all() and float(y[0, :, 2, 2].abs().max()) == 0.0 and float(y[0, 0, 0, 0]) > 0.3
+    _expect_range_fault()
+    # ... without the ReLU it is NaN (and faults all the same)
+    y = back(ops.conv2d([nhwc(x)], pack, plan=0x70011))
     assert not torch.isfinite(y[0, :, 2, 2]).any() and torch.isfinite(y[0, :, 0, 0]).all()
+    _expect_range_fault()
+    # a large NEGATIVE value under the consumer's input ReLU is a plain 0 in the reference too: no fault, right result
+    xn = torch.ones(1, 32, 8, 8)
+    xn[0, 3, 2, 2] = -1.0e5
+    y = back(ops.conv2d([nhwc(xn)], pack, relu_in=True, plan=0x70011))
+    ops.check_faults()
+    close(y, F.conv2d(F.relu(xn), w), 1e-6, 'negative under relu')
+    # the bf16 arithmetics have the fp32 range: no fault, finite right result
+    for pl in (0x10011, 0x30011, 0x11):
+        y = back(ops.conv2d([nhwc(x)], pack, relu_out=True, plan=pl))
+        ops.check_faults()
+        close(y, F.relu(F.conv2d(x, w)), 1e-2 if pl == 0x30011 else 1e-5, 'plan %#x' % pl)
+    # (2) a conv EPILOGUE that writes its output as an fp16 pair (the fused operand split): inputs in range, output not
+    big = ops.pack_conv((torch.ones(32, 32, 1, 1) * 100.0).to(DEV))
+    xin = nhwc(torch.ones(1, 32, 8, 8) * 30.0)            # y = 96000
+    site_flags = []
+    for relu_out, plan in ((True, 0x70011), (False, 0x70011), (False, 0x11), (True, 0x70211)):
+        with ops.use_book(ops.PlanBook()):
+            for it in range(2):                           # second pass: the producer writes the planes its consumer asked for
+                y1 = ops.conv2d([xin], big, relu_out=relu_out, plan=plan)
+                ops.conv2d([y1], pack, relu_out=True, plan=0x70011)
+                if it == 0:
+                    _expect_range_fault()                 # (first pass: the stand-alone split of y1 faults)
+            assert y1.__dict__.get('_swem_split'), 'the producer did not write planes'
+            _expect_range_fault()
+    # (3) the pointwise producers
+    with ops.use_book(ops.PlanBook()):
+        xb = nhwc(torch.ones(1, 32, 16, 16))
+        xb[0, 5, 5, 7] = 7.0e4
+        skip, low = nhwc(torch.zeros(1, 32, 16, 16)), nhwc(torch.ones(1, 32, 8, 8) * 7.0e4)
+        for it in range(2):
+            for prod in (lambda: ops.maxpool(xb), lambda: ops.upsample_add(skip, low)):
+                t = prod()
+                ops.conv2d([t], pack, relu_out=True, plan=0x70011)
+                if it:
+                    assert t.__dict__.get('_swem_split')
+                _expect_range_fault()
+    # the stand-alone split with relu: +1e5 faults, -1e5 does not
+    for val, want in ((1.0e5, True), (-1.0e5, False), (float('inf'), True), (float('nan'), True), (65519.0, False), (65520.0, True)):
+        t = torch.zeros(64, 32, device=DEV)
+        t[3, 9] = val
+        sp = torch.empty((2, 64 * 32), dtype=torch.float16, device=DEV)
+        __import__('swem_amd')._lib.call('swem_split_f16x2_f32', ops._stream(), t.data_ptr(), sp.data_ptr(), 64, 32, 1,
+                                         ops.fault_word(t.device).data_ptr())
+        if want:
+            _expect_range_fault()
+        else:
+            ops.check_faults()
+
+
+def test_fault_word_survives_graph_replays(lib):
+    """the fault word used to be the last word of the per-capture counter buffer, whose zero fill is a node at the
+    head of the captured graph -- a fault of replay k was erased by replay k + 1, and the words of every graph but the newest
+    were unreachable.  It is now one persistent word per device outside every graph: fault in one replay of an OLDER graph, run
+    clean replays of it and of a newer graph, and check_faults still raises."""
+    ops.check_faults()
+    w = torch.ones(32, 32, 1, 1) * 0.01
+    pack = ops.pack_conv(w.to(DEV))
+    xs = [nhwc(torch.ones(2, 32, 30, 54)) for _ in range(2)]
+    graphs = []
+    for x in xs:
+        st = ops.new_stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            ops.conv2d([x], pack, relu_out=True, plan=0x70211)       # eager warm-up (K-split: the launch uses the counters)
+            st.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                x.__dict__.pop('_swem_split', None)
+                y = ops.conv2d([x], pack, relu_out=True, plan=0x70211)
+        graphs.append((g, y))
+    torch.cuda.current_stream().wait_stream(st)
+    graphs[0][0].replay()
+    ops.check_faults()
+    xs[0][1, 7, 3, 4] = 1.0e5
+    graphs[0][0].replay()                     # faults
+    xs[0][1, 7, 3, 4] = 1.0
+    graphs[0][0].replay()                     # clean replay of the same graph: its memset node runs again
+    graphs[1][0].replay()                     # a newer graph's replay
+    _expect_range_fault()
+    graphs[0][0].replay()
+    ops.check_faults()
+    close(back(graphs[0][1]), F.relu(F.conv2d(torch.ones(2, 32, 30, 54), w)), 1e-5, 'replayed conv')
 
 
 @pytest.mark.parametrize('plan', [0x10010011, 0x20010011, 0x30010011, 0x10010021, 0x20010022, 0x30210022, 0x24010021, 0x20810022,
@@ -705,7 +806,7 @@ def test_conv2d_stream_k(lib, shape, plan):
 
 def test_async_fault_word_reaches_the_host(lib):
     """A K-split reducer whose bounded wait for the other splits' partial tiles expires sets the sticky fault word of the
-    caller's counter buffer (include/swem_hip.h, SWEM_FAULT_KSPLIT_WAIT) instead of silently reducing tiles that were never
+    device (include/swem_hip.h, SWEM_FAULT_KSPLIT_WAIT; ops.fault_word) instead of silently reducing tiles that were never
     written; ops.check_faults() raises on the host, zeroes the counters, and the next launch is clean.  The wait is shortened
     to zero polls through SWEM_SPIN_LIMIT in a child process (the library reads it once): with every reducer arriving
     together with its producers, some tile of a 4-way split always finds its partials missing."""
@@ -724,7 +825,10 @@ ops.check_faults()
 y = ops.conv2d([x], pack, plan=0x30422)                       # four splits, the last one reduces
 torch.cuda.synchronize()
 ctr = ops.counters(x.device)
-word = int(ctr[-1])
+word = int(ops.fault_word(x.device))
+y2 = ops.conv2d([x], pack, plan=0x30122)                      # later clean launches do not clear it
+torch.cuda.synchronize()
+assert int(ops.fault_word(x.device)) == word
 try:
     ops.check_faults()
     raised = False
