@@ -282,7 +282,7 @@ def main():
     sdist.init()
     # the ranks of a node share one container's CPU quota (16 CPUs per 100 ms on this pool): a rank's torch CPU ops (clip
     # synthesis, weight fill) must not wake a 128-thread pool each -- a burnt quota stalls every thread of every rank
-    sdist.respect_cpu_quota(world)
+    cpu_threads = sdist.respect_cpu_quota(world)
     ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     if ranks != args.gpus:
         raise SystemExit('--gpus %d but the process group has %d ranks' % (args.gpus, ranks))
@@ -451,6 +451,7 @@ def main():
                                    'K=256, 5 EM iters, %d objects, memorise every frame, %d sequence(s) per GPU' % (n_obj, nseq),
                        'objects': n_obj, 'frames_per_step': nseq, 'sequences_per_gpu': nseq, 'parallelism': 'seq-sharded x%d (no collective)' % world,
                        'weights': 'random init of the reference architecture (seeded)',
+                       'torch_cpu_threads_per_rank': cpu_threads,
                        'launch': launch_text(pipelined)},
             'fps_per_gpu': round(fps / world, 3),
             'frame_algorithmic_tflops': round(algorithmic_flops_per_frame(n_obj) * fps / world / 1e12, 2),

@@ -57,6 +57,11 @@ __device__ __forceinline__ unsigned f16_oor(float4 v) {
                          max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
   return a >= 0x477ff000u ? 1u : 0u;
 }
+__device__ __forceinline__ unsigned f32_nan(float4 v) {   // 1 if any of the four is a NaN
+  const unsigned a = max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
+                         max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
+  return a > 0x7f800000u ? 1u : 0u;
+}
 #ifndef SWEM_FAULT_RANGE
 #define SWEM_FAULT_RANGE 4
 #endif

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/swem_hip.h"
 
 void swem_set_error(const char *fmt, ...);
@@ -21,18 +23,22 @@ int swem_norm_bases_into(void *stream, const float *kappa, float *kn, int NK, in
 int swem_gemm_bf16x3_batched(void *stream, const void *x, int K, long long bs, long long ps, int B, int M, const void *w,
                              long long w_bs, float *y, int Ncols, int plan, void *ws, size_t ws_bytes, void *y_planes,
                              int y_nplanes, float out_scale, void *fault);
-// raise the dynamic-LDS limit of a kernel once (needed above 64 KiB)
+// raise the dynamic-LDS limit of a kernel once per device (needed above 64 KiB).  The "done" record is one atomic bit per
+// device ordinal: concurrent first launches from two host threads both set the attribute (idempotent) and OR their bit.
 #define SWEM_ALLOW_LDS(kernel, bytes)                                                                   \
   do {                                                                                                  \
-    static bool done_ = false;                                                                          \
-    if (!done_) {                                                                                       \
+    static std::atomic<unsigned long long> done_{0ull};                                                 \
+    int dev_ = 0;                                                                                       \
+    (void)hipGetDevice(&dev_);                                                                          \
+    const unsigned long long bit_ = 1ull << (dev_ & 63);                                                \
+    if (!(done_.load(std::memory_order_acquire) & bit_)) {                                              \
       hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),                       \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));    \
       if (e_ != hipSuccess) {                                                                           \
         swem_set_error("hipFuncSetAttribute(%s): %s", #kernel, hipGetErrorString(e_));                  \
         return SWEM_E_HIP;                                                                              \
       }                                                                                                 \
-      done_ = true;                                                                                     \
+      done_.fetch_or(bit_, std::memory_order_release);                                                  \
     }                                                                                                   \
   } while (0)
 

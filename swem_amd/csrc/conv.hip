@@ -1391,6 +1391,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
     wait_blocks(issued - 1);   // block 0 has landed; the younger ones may stay in flight
     __builtin_amdgcn_s_barrier();
     STAMP(2);
+#ifdef SWEM_SETPRIO
+    // (experiment, round 5; MI355X_MICROARCH.md "Two waves per SIMD", item 4: static priority for the second-dispatched half)
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(SWEM_SETPRIO);
+#endif
     int st = 0;
     STAMP_ACC_DECL(t_vm);
     STAMP_ACC_DECL(t_bar);
@@ -1441,9 +1445,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
           for (int i = 0; i < 2 * TN; ++i) b[pl][i] = Bb[pl * PB + 16 * i];
         }
         constexpr int FRONT = SWEM_MFMA_FRONT * TM < 2 * TM ? SWEM_MFMA_FRONT * TM : 2 * TM;
+        // SWEM_STAGGER (experiment, round 5; MI355X_MICROARCH.md "Two waves per SIMD", item 9): the two waves of an eight-wave
+        // block that share a SIMD (w and w + 4) run the same program in lockstep -- both reach their MFMAs, their LDS reads and
+        // the barrier together.  1: waves 4-7 run their MFMAs IN FRONT of the hand-over, waves 0-3 behind it (the default
+        // order): the pair's matrix phases alternate around the barrier.  2: the halves swapped.  3: by parity (w & 1).
+#ifndef SWEM_STAGGER
+#define SWEM_STAGGER 0
+#endif
+        const bool late = SWEM_STAGGER == 0 || NW != 8 ? false
+                          : (SWEM_STAGGER == 1 ? wave >= 4 : (SWEM_STAGGER == 2 ? wave < 4 : (wave & 1) != 0));
+        if (SWEM_STAGGER != 0 && NW == 8 && !late) hand_over();
 #pragma unroll
         for (int i = 0; i < 2 * TM; ++i) {
-          if (i == FRONT) hand_over();
+          if (SWEM_STAGGER == 0 || NW != 8) {
+            if (i == FRONT) hand_over();
+          }
 #pragma unroll
           for (int jn = 0; jn < 2 * TN; ++jn) {
             f32x4v c = acc16[i][jn];
@@ -1460,7 +1476,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
             acc16[i][jn] = c;
           }
         }
-        if (FRONT >= 2 * TM) hand_over();
+        if (SWEM_STAGGER == 0 || NW != 8) {
+          if (FRONT >= 2 * TM) hand_over();
+        } else if (late) {
+          hand_over();
+        }
       } else {
         const uint4 *Ab = As + st * NPL * PA + wm * 32 * TM + r;
         const uint4 *Bb = Bs + st * NPL * PB + wn * 32 * TN + r;
@@ -1834,18 +1854,10 @@ int launch_bf3s_one(const ConvP &p, dim3 grid, hipStream_t st, int *occ) {
   const size_t dyn = lds_with_planes(p, lds, NW);
   SWEM_ALLOW_LDS((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK, F16>), lds);
   if (occ) {
-    // (the occupancy of an instantiation depends on its dynamic-LDS size and, in a multi-device process, on the device:
-    // asked again whenever either differs from the last query -- ADVICE r03: a function-local static froze the first answer)
-    static int nb = 0, nb_dev = -1;
-    static size_t nb_dyn = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (nb == 0 || dev != nb_dev || dyn != nb_dyn) {
-      nb = blocks_per_cu(conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK, F16>, 64 * NW, dyn);
-      nb_dev = dev;
-      nb_dyn = dyn;
-    }
-    *occ = nb;
+    // (asked anew on every query: the answer depends on the instantiation, its dynamic-LDS size and the current device, and a
+    // cached copy would be unsynchronised mutable state in a library whose contract is "re-entrant across streams" -- the
+    // query costs microseconds and only stream-K launches make it)
+    *occ = blocks_per_cu(conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK, F16>, 64 * NW, dyn);
     return SWEM_OK;
   }
   hipLaunchKernelGGL((conv_igemm_bf3s_kernel<WM, WN, NST, NW, M16, NPL, KG, PF, SK, F16>), grid, dim3(64 * NW), dyn, st, p STAMP_PASS);
@@ -2217,6 +2229,8 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float *__restric
   if (pix >= npix || cg >= C / 8) return;
   const float *src = x + pix * C + cg * 8;
   float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 4);
+  // (a NaN in the map is a fault whatever follows: relu1 would turn it into a clean 0 before the range test sees it)
+  const unsigned nan_in = relu ? (f32_nan(v0) | f32_nan(v1)) : 0u;
   if (relu) {
     v0 = relu4(v0);
     v1 = relu4(v1);
@@ -2227,7 +2241,7 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float *__restric
   const long long plane = npix * C, i = (long long)cg * npix + pix;
   *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
   *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
-  range_fault(fault, f16_oor(v0) | f16_oor(v1));   // (behind the input ReLU: a large NEGATIVE value under a ReLU is a plain 0)
+  range_fault(fault, f16_oor(v0) | f16_oor(v1) | nan_in);   // (behind the input ReLU: a large NEGATIVE value under a ReLU is a plain 0)
 }
 }  // namespace
 

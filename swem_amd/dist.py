@@ -43,7 +43,12 @@ def launch_ranks(n, argv, env=None, timeout=None):
     e = dict(os.environ if env is None else env)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         e.pop(k, None)
-    e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
+    if int(n) > 1 and 'HSA_ENABLE_IPC_MODE_LEGACY' not in e:
+        # The image exports HSA_ENABLE_IPC_MODE_LEGACY=0 (the host driver supports dmabuf IPC only; without it RCCL's
+        # hipIpcGetMemHandle fails with "invalid argument").  Set it only where the caller's environment does not say anything,
+        # and say so: this build has never met RCCL with N > 1, the tweak is taken on the image's word.
+        e['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+        sys.stderr.write('[swem_amd.dist] HSA_ENABLE_IPC_MODE_LEGACY was unset: the %d ranks run with =0 (dmabuf IPC)\n' % int(n))
     # --standalone: torchrun picks a free rendezvous port itself (no bind / close / reuse race); --local-addr keeps the
     # rendezvous on the loopback (the container's host name may not resolve)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',

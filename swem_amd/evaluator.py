@@ -580,8 +580,11 @@ def overlapping_streams(n, device=None, tries=12):
     """n HIP streams that really run concurrently.  HIP multiplexes streams onto a few hardware queues, and two streams on
     one queue execute strictly one after the other (measured: two sequences on two such streams took exactly twice the time
     of one).  There is no query for the queue of a stream, so candidates are probed: a short chain of small kernels is
-    replayed on a pair, and a candidate is kept if the pair finishes in well under twice the single-stream time."""
-    import time
+    replayed on a pair, and a candidate is kept if the pair finishes in well under twice the single-stream time.
+    The probe is timed ON THE GPU (HIP events around the replays, which are held back behind a short spin kernel until the
+    host has enqueued all of them), not with the host clock: on an 8-GPU node eight ranks share one container's CPU quota,
+    and a host that is late by a replay's 0.2 ms would make every pair look serial.  Found streams are
+    cached per device for the life of the process."""
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
     have = _PROBED.setdefault(dev.index, [])       # streams found earlier in this process: probe only for the missing ones
     if len(have) >= n:
@@ -600,15 +603,22 @@ def overlapping_streams(n, device=None, tries=12):
         return g
 
     def run(pairs):
-        torch.cuda.synchronize()
+        """GPU time (ms) from the common start to the last stream's end, best of five."""
+        main = torch.cuda.current_stream()
         best = None
-        for _ in range(5):                           # best of five: the host may be busy (eight ranks share it)
-            t0 = time.perf_counter()
-            for st, g in pairs:
+        for _ in range(5):
+            torch.cuda.synchronize()
+            start = torch.cuda.Event(enable_timing=True)
+            ends = [torch.cuda.Event(enable_timing=True) for _ in pairs]
+            torch.cuda._sleep(2_000_000)                 # ~1 ms: the replays below are all enqueued before it ends
+            start.record(main)
+            for (st, g), e in zip(pairs, ends):
+                st.wait_event(start)
                 with torch.cuda.stream(st):
                     g.replay()
+                    e.record(st)
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            dt = max(start.elapsed_time(e) for e in ends)
             best = dt if best is None else min(best, dt)
         return best
     chosen = [(st, chain(st, i)) for i, st in enumerate(have)]

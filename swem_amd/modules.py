@@ -131,12 +131,14 @@ class SWEMCore(nn.Module):
 
     @staticmethod
     def _stamp_of(bases):
-        return (bases['kappa'], bases['kappa']._version, bases['nu'], bases['nu']._version)
+        # (the last field: whether the bank's fp16 value planes were written with it -- ops.value_planes_wanted at that time)
+        return (bases['kappa'], bases['kappa']._version, bases['nu'], bases['nu']._version, ops.value_planes_wanted())
 
     def _stamped(self, bank, bases):
         st = self._stamp[bank]
         return (st is not None and st[0] is bases['kappa'] and st[1] == bases['kappa']._version
-                and st[2] is bases['nu'] and st[3] == bases['nu']._version)
+                and st[2] is bases['nu'] and st[3] == bases['nu']._version
+                and (st[4] or not ops.value_planes_wanted()))     # planes left out then, wanted now: repack
 
     def restamp(self):
         """Declare the pack consistent with the banks as they stand (after a frame graph moved new bases into its static

@@ -1457,10 +1457,27 @@ def new_pack(N, Cc, V, L, device):
             torch.zeros((N, 2, 4 * L // 8, V, 8), dtype=torch.float16, device=device))
 
 
+def value_planes_wanted():
+    """Whether matching's readout may read the pack's fp16 value planes `mvq` under the CURRENT book / conv_math block (the
+    pre-split f16x3 readout: _match_plan).  Where it cannot -- a book on the exact fp32 kernels (fallback 0), one that left the
+    fp16 range (to_full_range), the exact-split block conv_math((0, 1)) with its tuned bf16x6 readout -- memorize neither
+    writes nor range-checks them: value bases beyond 65520 are then no fault, nothing reads them as fp16.  SWEMCore stamps
+    each bank of its pack with this flag and repacks a bank whose planes were left out once they are wanted again."""
+    if BOOK.full_range:
+        return False
+    if AUTOTUNE:
+        return True                        # (the tuner may choose the pre-split readout)
+    # (the same order as _match_plan: a tuned plan of the current tag, else conv_math((m,))'s mode, else the book's fallback;
+    # any shape's plan counts -- writing planes nobody reads costs a few microseconds, reading planes nobody wrote is wrong)
+    if any((v >> 16) & 3 == 3 for k, v in BOOK.match.items() if tuple(k[6:]) == tuple(_PLAN_TAG)):
+        return True
+    if len(_PLAN_TAG) == 2:
+        return _PLAN_TAG[1] & 3 == 3       # conv_math((m,)): the heuristic tile in math mode m (3 or 7: pre-split)
+    return (BOOK.fallback >> 16) & 3 == 3
+
+
 def _pack_planes(pack):
-    # (a book that left the f16x3 arithmetic -- PlanBook.to_full_range -- reads the fp32 value bases `mvp`: the fp16 pair is
-    # then neither written nor range-checked)
-    if len(pack) < 3 or pack[2] is None or BOOK.full_range:
+    if len(pack) < 3 or pack[2] is None or not value_planes_wanted():
         return None
     q = pack[2]
     if not (q.is_cuda and q.dtype == torch.float16 and q.is_contiguous()):

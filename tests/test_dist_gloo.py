@@ -80,3 +80,36 @@ def test_bench_self_launch_comes_before_any_gpu_call():
     src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'bench.py')).read()
     main = src[src.index('def main():'):]
     assert main.index('sdist.launch_ranks(') < main.index('torch.cuda.')
+
+
+def _worker8(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    r, lr, w = sdist.init(backend='gloo')
+    n = sdist.respect_cpu_quota(w)
+    mine = sdist.shard(list(range(30)), r, w)            # DAVIS17-val has 30 sequences
+    sdist.barrier()
+    frames, secs = sdist.reduce_counters(len(mine), 0.5 + 0.125 * r)
+    q.put((r, mine, frames, secs, n))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_partition_and_counter_reduction():
+    """The 8-GPU inference launch on CPU ranks: sequences i -> rank i mod 8 is a partition of the 30 DAVIS17-val sequences,
+    the (frames, seconds) reduction is SUM / MAX over all eight, and every rank sizes its torch pool to an eighth of the
+    container's CPU quota (never zero)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    seen = sorted(i for _, mine, _, _, _ in out for i in mine)
+    assert seen == list(range(30))
+    assert all(len(mine) in (3, 4) for _, mine, _, _, _ in out)
+    assert all(f == 30 and s == 0.5 + 0.125 * 7 for _, _, f, s, _ in out)
+    assert all(n >= 1 for *_, n in out) and len({n for *_, n in out}) == 1

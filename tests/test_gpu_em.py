@@ -249,9 +249,16 @@ def test_packed_banks_equal_the_per_frame_packing(lib, L):
     ref1 = ops.memorize(pm(x1), pv(v1), pk(m1), *ref0, T, 0.05)
     ref2 = ops.memorize(pm(x2), pv(v2), pk(m2), *ref1, T, 0.05)
     pack = ops.new_pack(N, C, V, L, DEV)
-    got0 = ops.memorize(pm(x0), pv(v0), pk(m0), kap, nu, zita, T, 0.05, pack=pack, prior_packed=False, bank=0)
-    got1 = ops.memorize(pm(x1), pv(v1), pk(m1), *got0, T, 0.05, pack=pack, prior_packed=False, bank=1)
-    got2 = ops.memorize(pm(x2), pv(v2), pk(m2), *got1, T, 0.05, pack=pack, prior_packed=True, bank=1)
+    # (the pack's fp16 value planes are kept only under a book whose readout may read them -- ops.value_planes_wanted: a
+    # model's default book does, the free-standing default book of plain ops.* calls, exact fp32 kernels, does not)
+    f16_book = ops.PlanBook(fallback=ops.MODEL_FALLBACK)
+    with ops.use_book(f16_book):
+        got0 = ops.memorize(pm(x0), pv(v0), pk(m0), kap, nu, zita, T, 0.05, pack=pack, prior_packed=False, bank=0)
+        got1 = ops.memorize(pm(x1), pv(v1), pk(m1), *got0, T, 0.05, pack=pack, prior_packed=False, bank=1)
+        got2 = ops.memorize(pm(x2), pv(v2), pk(m2), *got1, T, 0.05, pack=pack, prior_packed=True, bank=1)
+    pack_nop = ops.new_pack(N, C, V, L, DEV)
+    ops.memorize(pm(x0), pv(v0), pk(m0), kap, nu, zita, T, 0.05, pack=pack_nop, prior_packed=False, bank=0)
+    assert not pack_nop[2].any() and torch.equal(pack_nop[1][:, :, :L], pack[1][:, :, :L])     # planes left out, values kept
     for a, b in zip(ref0 + ref1 + ref2, got0 + got1 + got2):
         assert torch.equal(a, b)
     qx, _ = H.structured_keys(P, C, 6, g)
@@ -260,8 +267,9 @@ def test_packed_banks_equal_the_per_frame_packing(lib, L):
     assert torch.equal(mem_r, mem_p) and torch.equal(S_r, S_p)
     # a pack rebuilt from the bases (SWEMCore.repack) is the pack memorize kept
     pack2 = ops.new_pack(N, C, V, L, DEV)
-    ops.pack_bank(ref0[0], ref0[1], pack2, 0)
-    ops.pack_bank(ref2[0], ref2[1], pack2, 1)
+    with ops.use_book(f16_book):
+        ops.pack_bank(ref0[0], ref0[1], pack2, 0)
+        ops.pack_bank(ref2[0], ref2[1], pack2, 1)
     assert torch.equal(pack2[0], pack[0]) and torch.equal(pack2[1], pack[1])
     # ... including the values' fp16 pair (hi, mid) the pre-split readout GEMM reads: hi + mid = nu to 22 significant bits (or to
     # 2^-25 absolute where mid is subnormal)

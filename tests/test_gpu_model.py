@@ -765,3 +765,39 @@ def test_bench_gpus_2_starts_two_ranks_by_itself(lib):
     # (the communicator of this rehearsal is gloo: the line must say so, and must NOT claim RCCL ranks)
     assert line['n_gpus'] == 2 and line['gloo_ranks'] == 2 and 'rccl_ranks' not in line and line['scaling'] == 'weak'
     assert line['config']['frames_per_step'] == 1 and line['value'] > 0
+
+
+def test_bench_gpus_8_rehearsal_on_one_gpu(lib):
+    """The driver's 8-GPU launch, rehearsed on this one-GPU box (no multi-GPU box was ever available to
+    this build): `python bench.py --gpus 8` starts eight ranks itself, they wrap onto device 0 and reduce their counters over
+    gloo (SWEM_DIST_BACKEND).  Asserted: eight ranks in the process group, ONE JSON line (rank 0's), value = the frames of all
+    eight ranks / the max-over-ranks time, every rank's torch CPU pool sized to its share of the container's CPU quota, the
+    stream probe usable while eight processes load the host, and no RCCL claim on a gloo run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    env = dict(os.environ, SWEM_DIST_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '2',
+                          '--regions', '3', '--seqs', '2', '--lookahead', '2', '--no-autotune', '--no-cpu-baseline', '--no-em'],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, 'rank 0 alone prints the line (got %d)' % len(lines)
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and line['gloo_ranks'] == 8 and 'rccl_ranks' not in line and line['scaling'] == 'weak'
+    assert line['config']['frames_per_step'] == 2 and line['timed_regions'] == 3 and line['value'] > 0
+    assert line['value_min'] <= line['value'] <= line['value_max']
+    # eight ranks share the container: each rank's torch pool is at most an eighth of the quota and at least one thread
+    # (torchrun itself starts its ranks with OMP_NUM_THREADS=1: then it is one)
+    from swem_amd import dist as sdist
+    import torch as _t
+    before = _t.get_num_threads()
+    share = sdist.respect_cpu_quota(8)
+    _t.set_num_threads(before)
+    assert 1 <= line['config']['torch_cpu_threads_per_rank'] <= max(1, share)
+    # whole-job frames per region: 8 ranks x 2 sequences x 4 steps
+    assert abs(line['value'] * line['ms_per_step'] * 1e-3 * line['steps'] - 8 * 2 * 4) < 0.02 * 64

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build an experimental variant of conv.hip into its own library:  tools/conv_variant.sh NAME "-DSWEM_STAGGER=1 ..."
+# -> swem_amd/libswem_hip_NAME.so (conv.hip compiled with -DSWEM_ISA_SUBSET: a fifth of the instantiations, about a minute;
+# every other object as built).  Run with  SWEM_HIP_LIB=swem_amd/libswem_hip_NAME.so python tools/conv_bench.py --dominant
+set -e
+cd "$(dirname "$0")/.."
+name=$1; shift
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DSWEM_ISA_SUBSET $@ \
+  -c swem_amd/csrc/conv.hip -o /tmp/conv_$name.o
+objs=""
+for o in api pointwise em match train train_conv; do objs="$objs swem_amd/csrc/$o.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o swem_amd/libswem_hip_$name.so /tmp/conv_$name.o $objs
+echo swem_amd/libswem_hip_$name.so
