@@ -206,6 +206,22 @@ int swem_conv2d_nhwc_bf16x3_planes_res(void *stream, const void *x0, int c0, lon
                                        int pad, int flags, int plan, void *ws, size_t ws_bytes, void *planes, int nplanes,
                                        void *planes_relu, int nplanes_relu, void *counters, size_t ncounters, void *fault);
 
+/* A whole identity bottleneck block of the key encoder's ResNet-50 layer1 (mod_resnet.py:77-113 / torchvision v1.5
+ * Bottleneck, networks.py:139-144: conv1x1 C -> C/4, bn, relu, conv3x3 C/4 -> C/4, bn, relu, conv1x1 C/4 -> C, bn, + x, relu;
+ * stride 1, no down-sampling branch) in ONE launch, in the f16x3 arithmetic: the C/4-channel intermediates stay in the LDS.
+ * As three launches of the convolution above the block runs at 0.3x of a plain copy of its input planes to its output planes
+ * (profiles/r05_bottleneck_fusion_bound.json); csrc/bneck.hip.
+ *   x_planes : the input as the fp16 pair of swem_split_f16x2_f32, [2][C/8][B*H*W][8], x_ps elements between the planes;
+ *              also the identity (read back as hi + mid, like swem_conv2d_nhwc_bf16x3_planes_res)
+ *   w1/w2/w3 : filter planes as swem_conv2d_nhwc_bf16x3 takes them with SWEM_PLAN_F16 (fp16 pairs [2][K/8][Cout][8], K ordered
+ *              (ci / 32, ky, kx, ci % 32), columns scaled by powers of two that sK undo); sK / bK: folded BatchNorm scale / shift
+ *   y        : fp32 NHWC output or NULL;  y_planes: the output's own fp16 pair (same layout as x_planes, y_ps apart) or NULL
+ *   fault    : SWEM_FAULT_RANGE when an intermediate or the output leaves the fp16 range
+ * C must be 256 (the layer1 geometry).  Same k order and product order as the convolution kernel's 16x16x32 form. */
+int swem_bottleneck_f16x3(void *stream, const void *x_planes, long long x_ps, int B, int H, int W, int C, const void *w1,
+                          const float *s1, const float *b1, const void *w2, const float *s2, const float *b2, const void *w3,
+                          const float *s3, const float *b3, float *y, void *y_planes, long long y_ps, void *fault);
+
 /* ------------------------------------------------------------------------------------
  * Pointwise / pooling / resampling kernels.
  */

@@ -33,6 +33,7 @@ SIGNATURES = {
     'swem_split_f16x2_f32': (_i, [_p, _p, _p, _ll, _i, _i, _p]),
     'swem_conv2d_nhwc_bf16x3': (_i, [_p, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _p, _i, _ll, _ll, _i, _i, _i, _p, _p, _p, _p, _ll,
                                      _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz]),
+    'swem_bottleneck_f16x3': (_i, [_p, _p, _ll, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _p]),
     'swem_prep_key_input_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i]),
     'swem_prep_value_input_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i]),
     'swem_prep_input_s2d_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

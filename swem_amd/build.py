@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libswem_hip.so')
-SOURCES = ['api.hip', 'conv.hip', 'pointwise.hip', 'em.hip', 'match.hip', 'train.hip', 'train_conv.hip']
+SOURCES = ['api.hip', 'conv.hip', 'bneck.hip', 'pointwise.hip', 'em.hip', 'match.hip', 'train.hip', 'train_conv.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 

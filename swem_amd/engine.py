@@ -44,6 +44,8 @@ class _Block:
         res = x if self.down is None else ops.conv2d([x], self.down)
         only = 'block' if self.inner else False
         # (conv1's and conv2's outputs have exactly one consumer, the next convolution: planes-only once it reads planes)
+        if self.bottleneck and self.down is None and ops.bottleneck_ok(x, self.c1, self.c2, self.c3):
+            return ops.bottleneck(x, self.c1, self.c2, self.c3, planes_only=only)     # (layer1's identity blocks: one launch)
         if self.bottleneck:
             y = ops.conv2d([x], self.c1, relu_out=True, planes_only=True)
             y = ops.conv2d([y], self.c2, relu_out=True, planes_only=True)

@@ -894,6 +894,87 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
 
 _PLAN_TAG = ()
 
+# The identity bottleneck blocks of the key encoder's layer1 as ONE launch (include/swem_hip.h, swem_bottleneck_f16x3) wherever the
+# book runs all three of the block's convolutions in f16x3.  OFF by default (SWEM_FUSE_BOTTLENECK=1 / ops.flags(FUSE_BOTTLENECK=
+# True) turn it on): measured in round 5 (profiles/r05_bottleneck_fusion.txt) the fused block is 1.35 x the three launches for one
+# frame and 1.08 x for the ten-frame batch the look-ahead graphs run -- below the 1.4 x bar VERDICT r04 item 6 set for shipping it --
+# and the frame rate does not move (468 against 467 frames/s with four sequences, 387.7 against 387.6 with one): with the 64-channel
+# intermediates gone the block is bound by what is left, its 256-channel input (read once more as the identity, and 1.4 x for the
+# 3x3's halo) and output, at the memory system's ~5 TB/s.
+FUSE_BOTTLENECK = os.environ.get('SWEM_FUSE_BOTTLENECK', '0') == '1'
+
+
+def _plan_of(pack, flags, B, H, W):
+    """The plan conv2d would run this layer with under the current book / conv_math block (no tuning)."""
+    sig = (pack.cin, pack.cout, pack.kh, pack.kw, pack.stride, pack.pad, flags, B, H, W) + _PLAN_TAG
+    plan = BOOK.conv.get(sig)
+    if plan is None:
+        plan = _PLAN_TAG[1] << 16 if len(_PLAN_TAG) == 2 else BOOK.fallback
+        if _PLAN_TAG and (plan >> 16) & 7 not in CONV_MATH_MODES:
+            plan = (plan & 0xffff) | max(CONV_MATH_MODES) << 16
+    return plan
+
+
+def bottleneck_ok(x, c1, c2, c3):
+    """Whether `bottleneck` can stand in for conv1 -> conv2 -> conv3 (+ identity) of this block: the layer1 geometry
+    (256 -> 64 -> 64 -> 256, stride 1, folded BatchNorm on every convolution) and all three layers in f16x3 under the current
+    book (tuned plans or its fallback) -- a book on the exact / bf16 arithmetics keeps the three launches, as does the tuner."""
+    if not FUSE_BOTTLENECK or AUTOTUNE or _IN_TUNER[0] or x.dim() != 4 or x.shape[3] != 256:
+        return False
+    geo = ((c1, 256, 64, 1, 0), (c2, 64, 64, 3, 1), (c3, 64, 256, 1, 0))
+    for pk, ci, co, k, pad in geo:
+        if (pk.cin, pk.cout, pk.kh, pk.kw, pk.stride, pk.pad, pk.glu) != (ci, co, k, k, 1, pad, False) or pk.w3 is None \
+                or pk.scale is None or pk.shift is None:
+            return False
+    B, H, W, _ = x.shape
+    if B * H * W * 16 >= 1 << 32:
+        return False
+    return all((_plan_of(pk, RELU_OUT, B, H, W) >> 16) & 7 == 7 for pk, *_ in geo)
+
+
+def bottleneck(x, c1, c2, c3, planes_only=False):
+    """relu(bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x)))))))) + x) for an identity bottleneck block (mod_resnet.py:77-113)
+    in one launch; x NHWC (B,H,W,256), possibly a planes-only block output.  The result carries its site and -- once its consumers
+    have asked for the fp16 pair -- its planes; planes_only='block' as conv2d: inside a stage the fp32 map is left out when every
+    consumer reads the planes (the next block's convolutions and its identity, which this kernel reads from the planes too)."""
+    B, H, W, Cc = x.shape
+    xp = presplit(x, False, PLANES_F16)                 # (2, ...) fp16: the block's input AND its identity
+    xsite = x.__dict__.get('_swem_site')
+    if xsite is not None and not _IN_TUNER[0]:
+        BOOK.res_epoch[xsite] = BOOK.epoch()             # (this block reads its identity from the planes)
+    site = ('bneck', c3.site_key, B, H, W)
+    want = BOOK.hints.get(site) if FUSE_SPLIT else None
+    f16_only = bool(want) and set(want.items()) == {(False, PLANES_F16)}
+    skip_y = bool(planes_only and f16_only and PLANES_ONLY and BOOK.hint_epoch.get(site) == BOOK.epoch()
+                  and (planes_only != 'block' or BOOK.res_epoch.get(site) == BOOK.epoch()))
+    nan1 = _nan_cell(x.device) if skip_y else None
+    if skip_y and nan1 is None:
+        skip_y = False
+    y = nan1.expand(B, H, W, Cc) if skip_y else torch.empty((B, H, W, Cc), dtype=torch.float32, device=x.device)
+    yp = _new_planes(PLANES_F16, B * H * W * Cc, x.device) if (want and want.get(False) == PLANES_F16) else None
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    (w1, s1), (w2, s2), (w3, s3) = c1.planes16(), c2.planes16(), c3.planes16()
+    _lib.call('swem_bottleneck_f16x3', _stream(), xp.data_ptr(), xp.stride(0), B, H, W, Cc, w1.data_ptr(), s1.data_ptr(),
+              c1.shift.data_ptr(), w2.data_ptr(), s2.data_ptr(), c2.shift.data_ptr(), w3.data_ptr(), s3.data_ptr(),
+              c3.shift.data_ptr(), 0 if skip_y else y.data_ptr(), _ptr(yp), 0 if yp is None else yp.stride(0),
+              _fault_ptr(x.device))
+    if MATH_RAN is not None:
+        MATH_RAN[7] = MATH_RAN.get(7, 0) + 1
+    y.__dict__['_swem_site'] = site
+    if yp is not None:
+        y.__dict__['_swem_split'] = {_pkey(False, PLANES_F16): (yp, PLANES_F16)}
+        y.__dict__['_swem_split_ver'] = y._version
+    if skip_y:
+        y.__dict__['_swem_planes_only'] = True
+    if CONV_TRACE is not None:
+        e1.record()
+        CONV_TRACE.append((e0, e1, 2.0 * B * H * W * (256 * 64 + 9 * 64 * 64 + 64 * 256),
+                           'bneck %dx%dx%d 256->64->64->256' % (B, H, W), 8.0 * B * H * W * Cc + 4.0 * (2 * 256 * 64 + 9 * 64 * 64),
+                           7 << 16, 'f16x3'))
+    return y
+
 
 class conv_math:
     """Context: restrict the math modes the conv tuner may choose (0 fp32 MFMA, 1 bf16x6, 2 plain bf16) and keep the plans

@@ -467,6 +467,13 @@ class SWEMTrainer:
         self.model.invalidate()
         sums = bf['sums']
         losses = {'total_loss': sums[0], 'main_loss': sums[1], 'aux_loss': sums[2], 'p': p}
+        # asynchronous faults of the step's launches (a K-split wait that expired: ops.check_faults).  The check synchronises
+        # the device, so it runs every `fault_check_every` steps (default 20: the reference's trainer reads its losses -- a
+        # synchronisation -- every LOG_PERIOD steps anyway, basic_trainer.py:105-131), and always on the eager first steps
+        self._steps_seen = getattr(self, '_steps_seen', 0) + 1
+        every = getattr(self, 'fault_check_every', 20)
+        if every and (self._graph is None or self._steps_seen % every == 0):
+            ops.check_faults()
         return losses, results
 
     def _math(self):

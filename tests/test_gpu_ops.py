@@ -901,3 +901,77 @@ def test_conv2d_block_output_as_planes_and_plane_residual(lib, plan):
             t = ops.conv2d([y1_d], pb, relu_out=True, planes_only=True)
             ops.conv2d([t], pc, residual=y1_d)
             assert not y1_d.__dict__.get('_swem_planes_only')
+
+
+@pytest.mark.parametrize('B,H,W', [(1, 8, 16), (2, 21, 37), (1, 120, 216)], ids=lambda v: str(v))
+def test_fused_bottleneck_matches_three_launches(lib, B, H, W):
+    """swem_bottleneck_f16x3 (csrc/bneck.hip): an identity bottleneck block of the key encoder's layer1 (mod_resnet.py:77-113:
+    1x1 256 -> 64, 3x3 64 -> 64, 1x1 64 -> 256, frozen BN + ReLU after each, + identity) in ONE launch, against (a) the same block
+    as three launches of the f16x3 convolution kernel in its 16x16x32 form -- same operand pairs, same k order: agreement to a
+    few fp32 ulps of the accumulation -- and (b) torch fp32 on the CPU.  Ragged sizes (tiles of 8 x 16 pixels that hang over the
+    image on both axes), the output as the fp32 map, as map + fp16 pair, and as planes only; the pair bit-identical to
+    swem_split_f16x2_f32 of the map."""
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, 256, H, W, generator=g).abs()           # (a block's input is a ReLU output)
+
+    def conv_bn(co, ci, k):
+        w = torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5
+        bn = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1,
+              torch.rand(co, generator=g) + 0.5)
+        return w, bn, ops.pack_conv(w.to(DEV), None, [t.to(DEV) for t in bn], 1, k // 2)
+    (w1, bn1, c1), (w2, bn2, c2), (w3, bn3, c3) = conv_bn(64, 256, 1), conv_bn(64, 64, 3), conv_bn(256, 64, 1)
+
+    def bnf(t, bn):
+        return F.batch_norm(t, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    ref = F.relu(bnf(F.conv2d(x, w1), bn1))
+    ref = F.relu(bnf(F.conv2d(ref, w2, padding=1), bn2))
+    ref = F.relu(bnf(F.conv2d(ref, w3), bn3) + x)
+    xs = nhwc(x)
+    plan = 0x470111                                             # f16x3, 64 x 64 tile, 16x16x32 MFMA, no K-split
+    with ops.use_book(ops.PlanBook(fallback=ops.MODEL_FALLBACK)):
+        assert not ops.bottleneck_ok(xs, c1, c2, c3)            # off by default (profiles/r05_bottleneck_fusion.txt)
+    with ops.use_book(ops.PlanBook(fallback=ops.MODEL_FALLBACK)) as book, ops.flags(FUSE_BOTTLENECK=True):
+        assert ops.bottleneck_ok(xs, c1, c2, c3)
+        y1 = ops.conv2d([xs], c1, relu_out=True, plan=plan)
+        y2 = ops.conv2d([y1], c2, relu_out=True, plan=plan)
+        y3 = ops.conv2d([y2], c3, relu_out=True, residual=xs, plan=plan)
+        # (the unfused path adds the fp32 identity, the fused one hi + mid of its fp16 pair: 2^-23 |x| apart at most)
+        yf = ops.bottleneck(xs, c1, c2, c3)
+        ops.check_faults()
+        assert '_swem_split' not in yf.__dict__
+        close(back(yf), ref, 2e-5, 'fused bottleneck vs torch')
+        close(yf.cpu(), y3.cpu(), 2e-6, 'fused bottleneck vs three launches')
+        # a consumer asks for the fp16 pair: from the next call on the launch writes it, bit-identical to the split of the map
+        ops.presplit(yf, False, ops.PLANES_F16)
+        yg = ops.bottleneck(xs, c1, c2, c3)
+        assert torch.equal(yg, yf)
+        sp = yg.__dict__['_swem_split'][ops._pkey(False, ops.PLANES_F16)][0]
+        want = torch.empty_like(sp)
+        __import__('swem_amd')._lib.call('swem_split_f16x2_f32', ops._stream(), yg.data_ptr(), want.data_ptr(), B * H * W, 256, 0, 0)
+        assert torch.equal(sp.view(torch.int16), want.view(torch.int16))
+        # inside a stage: two blocks chained, the first one's output as planes only once both of its consumers -- the second block's
+        # convolutions and its identity -- read planes (the fused kernel does both)
+        for _ in range(3):
+            a = ops.bottleneck(xs, c1, c2, c3, planes_only='block')
+            bb = ops.bottleneck(a, c1, c2, c3)
+        assert a.__dict__.get('_swem_planes_only')
+        ref2 = F.relu(bnf(F.conv2d(ref, w1), bn1))
+        ref2 = F.relu(bnf(F.conv2d(ref2, w2, padding=1), bn2))
+        ref2 = F.relu(bnf(F.conv2d(ref2, w3), bn3) + ref)
+        close(back(bb), ref2, 3e-5, 'two fused blocks')
+        # ... and an unfused consumer of a planes-only fused output (the next stage's first block: a strided 3x3 elsewhere; here
+        # the plain 1x1) reads the same planes
+        z = ops.conv2d([a], c1, relu_out=True, plan=plan)
+        close(back(z), F.relu(bnf(F.conv2d(ref, w1), bn1)), 2e-5, 'unfused consumer of the planes')
+        ops.check_faults()
+    # a book on another arithmetic keeps the three launches
+    with ops.use_book(ops.PlanBook(fallback=0)), ops.flags(FUSE_BOTTLENECK=True):
+        assert not ops.bottleneck_ok(xs, c1, c2, c3)
+    with ops.use_book(ops.PlanBook(fallback=ops.MODEL_FALLBACK)), ops.conv_math((3,)), ops.flags(FUSE_BOTTLENECK=True):
+        assert not ops.bottleneck_ok(xs, c1, c2, c3)
+    # the range fault of the shipped arithmetic reaches through the fused kernel too (an intermediate beyond 65520)
+    big = ops.pack_conv((w1 * 3.0e4).to(DEV), None, [t.to(DEV) for t in bn1], 1, 0)
+    with ops.use_book(ops.PlanBook(fallback=ops.MODEL_FALLBACK)):
+        ops.bottleneck(xs, big, c2, c3)
+        with pytest.raises(ops.SwemRangeError):
+            ops.check_faults()

@@ -20,7 +20,7 @@ def build():
     objs = []
     for name in ('api', 'pointwise', 'train', 'train_conv', 'match'):
         objs.append(os.path.join(csrc, name + '.o'))
-    for name in ('em', 'conv'):
+    for name in ('em', 'conv', 'bneck'):
         o = '/tmp/%s_stamps.o' % name
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
                                '-DSWEM_EM_STAMPS', '-DSWEM_STAMP_BLOCK=%d' % int(os.environ.get('SWEM_STAMP_BLOCK', '0')),

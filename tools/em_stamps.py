@@ -20,7 +20,9 @@ def main():
     a = ap.parse_args()
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import conv_stamps
-    out = conv_stamps.build()
+    out = os.path.join(ROOT, 'swem_amd', 'libswem_hip_stamps.so')
+    if not os.path.exists(out):            # (built here when missing: cross-compile it in the build container, it travels)
+        out = conv_stamps.build()
     from swem_amd import _lib
     _lib.LIB_PATH = out
     import torch
