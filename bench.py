@@ -21,7 +21,7 @@ Arithmetic of the line (`dtype`, `plans`): the shipped plans run the convolution
 Extra objects in the JSON line:
   roofline     -- dominant conv kernel of the timed leg: useful conv FLOPs / summed launch durations (HIP events on the launch
                   stream) against ITS pipe's ceiling (dense f16 / bf16 MFMA peak / products per fp32 product); mfma_busy and
-                  traffic from the committed rocprofv3 --pmc passes (profiles/r04_conv_pmc*.json, r04_conv_traffic_by_kernel*.json);
+                  traffic from the committed rocprofv3 --pmc passes (profiles/r05_conv_pmc*.json, r05_conv_traffic_by_kernel*.json);
                   `pipes` has the fp32-MFMA layers against 157.3 TFLOP/s; `whole_frame` prices the timed configuration.
   fp32_level   -- the same workload in the exact-split arithmetic (fp32 MFMA / bf16x6: all 24 operand bits), with its own
                   `roofline` and single-sequence figure; `value_by_arithmetic` puts both legs side by side at top level.
@@ -462,7 +462,7 @@ def main():
 
     def leg_roofline(runner, hist, pmc_tag):
         """Roofline of one leg's dominant conv kernel: per-launch HIP-event timing of eager frames of ONE sequence (runner) in the
-        conv_math mode the caller has entered; pmc_tag names the committed counter files (profiles/r04_conv_*<tag>.json)."""
+        conv_math mode the caller has entered; pmc_tag names the committed counter files (profiles/r05_conv_*<tag>.json)."""
         # ---------------- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream
         kla = args.lookahead if (args.lookahead > 0 and not args.no_graph) else 0
         nprof = min(args.steps, 5) if not kla else kla * max(1, 4 // kla)       # frames traced eagerly
@@ -586,7 +586,10 @@ def main():
                 'true' if sk else 'false', 'true' if pipe_ == 'f16x3' else 'false')
         dk_name = bf3s_name(*dk) if dk[0] != 'fp32' else 'conv_igemm_pipe_kernel<%d, %d>' % (dk[1], dk[2])
         traffic, tsrc = None, None
-        for name in ('r04_conv_traffic_by_kernel%s.json' % pmc_tag, 'r03_conv_traffic_by_kernel.json', 'r02_conv_traffic_by_kernel.json'):
+        for name in ('r05_conv_traffic_by_kernel%s.json' % pmc_tag, 'r04_conv_traffic_by_kernel%s.json' % pmc_tag,
+                     'r03_conv_traffic_by_kernel.json', 'r02_conv_traffic_by_kernel.json'):
+            if traffic is not None:
+                break
             try:
                 with open(os.path.join(ROOT, 'profiles', name)) as f:
                     byk = json.load(f)
@@ -605,9 +608,8 @@ def main():
                     pass
         mfma_busy, mfma_src = None, None
         try:       # counter evidence of the same kernel from the committed rocprofv3 --pmc passes (tools/pmc_kernels.sh)
-            pmc_file = 'r04_conv_pmc%s.json' % pmc_tag
-            if not os.path.exists(os.path.join(ROOT, 'profiles', pmc_file)):
-                pmc_file = 'r03_conv_pmc.json'
+            pmc_file = next((f_ for f_ in ('r05_conv_pmc%s.json' % pmc_tag, 'r04_conv_pmc%s.json' % pmc_tag, 'r03_conv_pmc.json')
+                             if os.path.exists(os.path.join(ROOT, 'profiles', f_))), 'r03_conv_pmc.json')
             with open(os.path.join(ROOT, 'profiles', pmc_file)) as f:
                 pm = json.load(f)
             hit = [v for k, v in pm.items() if k.replace(' ', '') == dk_name.replace(' ', '') and 'mfma_busy' in v]
