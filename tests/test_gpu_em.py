@@ -343,3 +343,46 @@ def test_memorize_in_two_calls_equals_the_one_call_form(lib):
     assert torch.equal(kappa, ref[0]) and torch.equal(nu, ref[1]) and torch.equal(zita, ref[2])
     for a, b in zip(pack_a, pack_b):
         assert torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, b.view(torch.int16) if b.dtype == torch.float16 else b)
+
+
+def test_round3_stream_k_readout_plan_still_runs(lib):
+    """the pre-split readout now always runs f16x3, whose kernels have no stream-K form; a readout plan tuned or saved
+    in round 3 with bf16x3 + stream-K (plan bits 24-27 == 1: the r03 tuner offered them) must run the plain grid of its tile, not
+    fail at launch -- and give the fp32 readout's result to the f16x3 readout's 1e-6."""
+    g = torch.Generator().manual_seed(7)
+    h, w, C, V, N, L = 12, 20, 128, 128, 2, 64
+    P = h * w
+    kap = d(torch.nn.functional.normalize(torch.randn(N, 2, C, L, generator=g), dim=2))
+    nu = d(torch.randn(N, 2, V, L, generator=g))
+    qx, _ = H.structured_keys(P, C, 6, g)
+    key = (N, C, V, P, L, 2)
+    ref_mem, ref_S = ops.match(d(qx), kap, nu, kap, nu, 64, 0.05)          # default book: fp32 readout
+    with ops.use_book(ops.PlanBook(fallback=ops.MODEL_FALLBACK)) as book:
+        pack = ops.new_pack(N, C, V, L, DEV)
+        ops.pack_bank(kap, nu, pack, 0)
+        ops.pack_bank(kap, nu, pack, 1)
+        for plan in (2 | 2 << 4 | 1 << 8 | 3 << 16 | 6 << 20 | 1 << 24,      # r03: 128x128 tile, 8 waves, bf16x3, stream-K
+                     2 | 2 << 4 | 1 << 8 | 3 << 16 | 5 << 20 | 1 << 24):     # ... prefetched fragments + stream-K
+            book.match[key] = plan
+            mem, S = ops.match_packed(d(qx), pack, L, 64, 0.05)
+            ops.check_faults()
+            assert torch.equal(S, ref_S)
+            assert float((mem - ref_mem).abs().max()) <= 2e-6 * float(ref_mem.abs().max())
+
+
+def test_shipped_plans_are_keyed_by_device(lib):
+    """SequencePool loads the shipped plan file only on the architecture the file names: here, on the gfx950 box,
+    it loads; a copy that names another architecture does not."""
+    import json
+    import os
+    import tempfile
+    dev = torch.device(DEV)
+    assert ops.device_arch(dev) == 'gfx950'
+    b = ops.PlanBook(fallback=ops.MODEL_FALLBACK)
+    assert b.load(ops.shipped_plans(), device=dev) is b and b.conv
+    dd = json.load(open(ops.shipped_plans()))
+    with tempfile.TemporaryDirectory() as tmp:
+        other = os.path.join(tmp, 'other.json')
+        json.dump(dict(dd, device='gfx942'), open(other, 'w'))
+        b2 = ops.PlanBook(fallback=ops.MODEL_FALLBACK)
+        assert b2.load(other, device=dev) is False and not b2.conv

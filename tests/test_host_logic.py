@@ -327,3 +327,50 @@ def test_cpu_pool_is_sized_by_the_container_quota(tmp_path, monkeypatch):
         assert torch.get_num_threads() == before
     finally:
         torch.set_num_threads(before)
+
+
+def test_full_range_book_policy(tmp_path):
+    """The host side of the f16x3 range fault, no GPU needed: a book that leaves the fp16
+    range converts its tuned f16x3 conv plans to bf16x6 on the same tile (kernel-variant / tail-split bits dropped: some f16x3
+    variants have no three-plane form), drops matching's readout plans and every plane hint, falls back to bf16x6 for untuned
+    shapes, stops keeping matching's fp16 value planes, and stays there through later plan loads; the shipped file is keyed by
+    the architecture it was tuned on."""
+    import json
+    from swem_amd import ops
+    book = ops.PlanBook(fallback=ops.MODEL_FALLBACK).load_shipped()
+    n7 = book.math_histogram()['f16x3']
+    assert n7 > 100 and book.match and not book.full_range
+    with ops.use_book(book):
+        assert ops.value_planes_wanted()
+    some = next(k for k, v in book.conv.items() if (v >> 16) & 7 == 7 and (v >> 20))      # a plan with variant bits
+    tile = book.conv[some] & 0xffff
+    book.hints[('conv', ('x',), 1, 2, 3, 0)] = {False: ops.PLANES_F16}
+    e0 = book.epoch()
+    assert book.to_full_range() == n7
+    assert book.full_range and book.epoch() != e0 and not book.hints and not book.match
+    assert book.math_histogram()['f16x3'] == 0 and book.conv[some] == (tile | 1 << 16) and (book.fallback >> 16) & 7 == 1
+    with ops.use_book(book):
+        assert not ops.value_planes_wanted()
+        assert ops._pack_planes((None, None, torch.zeros(1, dtype=torch.float16))) is None
+    book.load_shipped()                                        # a later load cannot bring the fp16 range back
+    assert book.math_histogram()['f16x3'] == 0 and not book.match and book.full_range
+    # books on other arithmetics: the exact fp32 kernels never read the fp16 value planes; a tuned pre-split readout does
+    exact = ops.PlanBook(fallback=0)
+    with ops.use_book(exact):
+        assert not ops.value_planes_wanted()
+        exact.match[(2, 128, 512, 1620, 256, 2)] = 0x30111
+        assert ops.value_planes_wanted()
+        with ops.conv_math((0, 1)):                            # ... but not inside the exact-split block (its own tag)
+            assert not ops.value_planes_wanted()
+    with ops.use_book(ops.PlanBook(fallback=ops.MODEL_FALLBACK)), ops.conv_math((3,)):
+        assert ops.value_planes_wanted()
+    # the plan file names its device; a file tuned elsewhere is not taken as a default (device=...: only checked with a GPU)
+    d = json.load(open(ops.shipped_plans()))
+    assert d['device'] == 'gfx950'
+    other = tmp_path / 'other.json'
+    json.dump(dict(d, device='gfx942'), open(other, 'w'))
+    b2 = ops.PlanBook()
+    assert b2.load(str(other)) is b2 and b2.conv                # (no device given: loaded unconditionally)
+    # fault-word bookkeeping without a device: nothing to read, nothing raised
+    ops.check_faults()
+    assert ops.FAULT_BITS.keys() == {1, 2, 4} and issubclass(ops.SwemRangeError, __import__('swem_amd')._lib.SwemHipError)
