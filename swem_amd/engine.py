@@ -142,6 +142,10 @@ class Engine:
                 x = blk(x)
             feats.append(x)
         s4, s8, s16 = feats
+        if ops.SKIP_IN_KEY_PASS:
+            # the decoder's skip convolutions depend on the frame alone (ops.SKIP_IN_KEY_PASS): computed here, handed on with s8 / s4
+            for t_, pk in ((s8, self.skip8), (s4, self.skip4)):
+                t_.__dict__['_swem_skip'] = (ops.conv2d([t_], pk), t_._version, self)
         qk16 = ops.conv2d([s16], self.key_proj)
         qv16 = ops.conv2d([s16], self.key_comp)
         return qk16, qv16, s16, s8, s4
@@ -174,12 +178,19 @@ class Engine:
             qv16 = per_object(qv16, BN // qv16.shape[0])     # (B,...) -> (B*N,...): modules.py:287 .expand_as
         return ops.conv2d([mem_out, qv16, s_feat], self.glu, batch=BN)
 
+    def _skip(self, s, pack):
+        """skip_conv(s) (networks.py:190-196): what THIS engine's encode_key computed for exactly this tensor, else computed now."""
+        c = s.__dict__.get('_swem_skip')
+        if c is not None and c[1] == s._version and c[2] is self and c[0].shape[:3] == s.shape[:3]:
+            return c[0]
+        return ops.conv2d([s], pack)
+
     # networks.py:208-213 ; the skip convs see the same s8/s4 for every object (swem.py:94-95): computed once
     def decoder_logit(self, context, s8, s4):
         BN, B = context.shape[0], s8.shape[0]
         x = self.compress([context])
-        sk = ops.conv2d([s8], self.skip8)
+        sk = self._skip(s8, self.skip8)
         x = self.out8([ops.upsample_add(sk if B in (1, BN) else per_object(sk, BN // B), x)])
-        sk = ops.conv2d([s4], self.skip4)
+        sk = self._skip(s4, self.skip4)
         x = self.out4([ops.upsample_add(sk if B in (1, BN) else per_object(sk, BN // B), x)])
         return ops.pred_head(x, self.pred_w, self.pred_b)

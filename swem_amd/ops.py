@@ -652,6 +652,13 @@ def presplit(t, relu=False, nplanes=3):
 
 
 RESPLITS = {}      # producer site -> split launches made for a tensor that already carried producer-written planes
+# The decoder's two skip convolutions (networks.py:190-196: UpsampleBlock.skip_conv on s8 / s4) read the KEY encoder's features only:
+# the same for every object (round 2: computed once per frame) and independent of the memory.  With this switch (default on;
+# SWEM_SKIP_IN_KEY_PASS=0) Engine.encode_key computes them right behind the trunk and hands them on with s8 / s4 -- in the look-ahead
+# graphs that moves 0.2 ms per frame of B = 1 launches out of the memory-dependent frame chain into the batched key-encoder pass
+# (ten frames per launch, on the side stream); Engine.decoder_logit computes them itself whenever the s8 / s4 it is given do not carry
+# them (tensors that did not come from this engine's encode_key).  Same kernels on the same data: results unchanged.
+SKIP_IN_KEY_PASS = os.environ.get('SWEM_SKIP_IN_KEY_PASS', '1') != '0'
 
 
 def _pkey(relu, npl):
@@ -687,6 +694,9 @@ def batch_item(t, j):
         v.__dict__['_swem_site'] = d['_swem_site']
     if d.get('_swem_planes_only'):
         v.__dict__['_swem_planes_only'] = True
+    sk = d.get('_swem_skip')              # (the decoder's skip convolution of this feature map, computed in the key pass)
+    if sk is not None and sk[1] == t._version:
+        v.__dict__['_swem_skip'] = (batch_item(sk[0], j), v._version, sk[2])
     return v
 
 
