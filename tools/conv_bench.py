@@ -31,11 +31,14 @@ def main():
     ap.add_argument('--only', type=int, default=-1)
     ap.add_argument('--plan', type=lambda v: int(v, 0), default=None, help='explicit plan hint, e.g. 0x10021')
     ap.add_argument('--fresh', action='store_true', help='re-split the input every launch (bf16x6 plans)')
+    ap.add_argument('--small', action='store_true', help='like --dominant, for the small layers (64x64 tiles, 1x1 convolutions)')
     ap.add_argument('--dominant', action='store_true',
                     help='the layers of the dominant f16x3 instantiation (128x128 tile, eight waves, 16x16x32 MFMA) with their '
                          'shipped plans: the set the round-5 kernel experiments are judged on (SWEM_HIP_LIB picks the build)')
     a = ap.parse_args()
     dominant = {0: 0x670122, 1: 0x670422, 2: 0x670422, 3: 0x670222, 4: 0x670222, 5: 0x670122, 11: 0x670822}
+    if a.small:      # the small / byte-bound layers with their shipped f16x3 plans (kernel variants the subset builds hold)
+        a.dominant, dominant = True, {6: 0x170111, 7: 0x70411, 8: 0x70211, 9: 0x70111, 10: 0x670122}
     dev = 'cuda:0'
     print('plan=%s' % os.environ.get('SWEM_CONV_PLAN', 'auto'))
     for idx, (B, H, W, ci, co, k, s, relu) in enumerate(SHAPES):

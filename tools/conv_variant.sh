@@ -8,6 +8,6 @@ name=$1; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DSWEM_ISA_SUBSET $@ \
   -c swem_amd/csrc/conv.hip -o /tmp/conv_$name.o
 objs=""
-for o in api pointwise em match train train_conv; do objs="$objs swem_amd/csrc/$o.o"; done
+for o in api bneck pointwise em match train train_conv; do objs="$objs swem_amd/csrc/$o.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o swem_amd/libswem_hip_$name.so /tmp/conv_$name.o $objs
 echo swem_amd/libswem_hip_$name.so

@@ -14,8 +14,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--objects', type=int, default=2)
     ap.add_argument('--reps', type=int, default=50)
-    ap.add_argument('--plan', type=lambda t: int(t, 0), default=0x130221,
-                    help='readout GEMM plan (include/swem_hip.h); default: what the tuner picks at config B, 0 = heuristic fp32')
+    ap.add_argument('--plan', type=lambda t: int(t, 0), default=0x8030111,
+                    help='readout GEMM plan (include/swem_hip.h); default: the shipped plan file\'s entry for config B with two objects '
+                         '(pre-split f16x3 readout, 64x64 tile, tail split 8), 0 = heuristic fp32')
     a = ap.parse_args()
     dev = 'cuda:0'
     N, P, C, V, L, T, tau, topl = a.objects, 1620, 128, 512, 256, 5, 0.05, 64
