@@ -31,6 +31,7 @@ def main():
     ap.add_argument('--only', type=int, default=-1)
     ap.add_argument('--plan', type=lambda v: int(v, 0), default=None, help='explicit plan hint, e.g. 0x10021')
     ap.add_argument('--fresh', action='store_true', help='re-split the input every launch (bf16x6 plans)')
+    ap.add_argument('--graph', action='store_true', help='time a HIP-graph replay of the launches (device time, no host launch cost)')
     ap.add_argument('--small', action='store_true', help='like --dominant, for the small layers (64x64 tiles, 1x1 convolutions)')
     ap.add_argument('--dominant', action='store_true',
                     help='the layers of the dominant f16x3 instantiation (128x128 tile, eight waves, 16x16x32 MFMA) with their '
@@ -58,11 +59,26 @@ def main():
             y = run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.reps):
-            y = run()
-        e1.record()
-        torch.cuda.synchronize()
+        if a.graph:      # (small layers: an eager loop measures the host's ~16 us per Python launch, not the kernel)
+            st = ops.new_stream()
+            st.wait_stream(torch.cuda.current_stream())
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(st):
+                with torch.cuda.graph(gr, stream=st):
+                    for _ in range(a.reps):
+                        y = run()
+                gr.replay()
+                st.synchronize()
+                e0.record(st)
+                gr.replay()
+                e1.record(st)
+            torch.cuda.synchronize()
+        else:
+            e0.record()
+            for _ in range(a.reps):
+                y = run()
+            e1.record()
+            torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / a.reps
         fl = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * co * k * k * ci
         print('%dx%dx%d k%d s%d %4d->%4d  %8.1f us  %6.1f TFLOP/s%s' % (B, H, W, k, s, ci, co, us, fl / us / 1e6,
