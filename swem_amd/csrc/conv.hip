@@ -1219,7 +1219,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
   };
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   const unsigned lds_a = lds0 + (unsigned)g * (SA * 16), lds_b = lds0 + NST * NPL * PA * 16 + (unsigned)g * (SB * 16);
+  // SWEM_ABLATE (diagnosis builds only, tools/conv_variant.sh; results are garbage): 1 = no MFMAs in the k-loop (what the data
+  // movement alone costs), 2 = no transfers (what fragment reads + MFMAs + hand-overs alone cost)
+#ifndef SWEM_ABLATE
+#define SWEM_ABLATE 0
+#endif
   auto issue = [&](int stage) __attribute__((always_inline)) {
+    if (SWEM_ABLATE == 2) return;
     const unsigned sa = lds_a + (unsigned)stage * (NPL * PA * 16), sb = lds_b + (unsigned)stage * (NPL * PB * 16);
     if (NW == KG || half == 0) {
 #pragma unroll
@@ -1483,6 +1489,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
 #pragma unroll
           for (int jn = 0; jn < 2 * TN; ++jn) {
             f32x4v c = acc16[i][jn];
+            if (SWEM_ABLATE == 1) {   // (keep the fragments live: one cheap use per pair)
+              c[0] += __uint_as_float(a[0][i].x ^ b[0][jn].x ^ a[NPL - 1][i].y ^ b[NPL - 1][jn].y);
+              acc16[i][jn] = c;
+              continue;
+            }
             if constexpr (NPL == 3) {
               c = mm16<F16>(a[0][i], b[2][jn], c);
               c = mm16<F16>(a[2][i], b[0][jn], c);
