@@ -74,6 +74,34 @@ int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3, long long 
                              long long ps1, const unsigned short *x2, int c2, long long bs2, long long ps2, int B, int H,
                              int W, int Cout, int KH, int KW, int stride, int pad, int math, float *dw, int cin_store,
                              int accumulate, int plan, void *ws, size_t ws_bytes);
+/* ---- fp32-level training on the f16x3 arithmetic (round 5).  The reference back-propagates in fp32
+ * (swem_trainer.py:92-105, `loss.backward()` without autocast unless config.AMP); the six-product bf16 split reproduces that at six
+ * MFMA products per fp32 product, the fp16 (hi, mid) pair of the inference path at three -- but gradients span too many binades for
+ * an unscaled pair.  swem_split_f16x2_scaled_f32 writes the pair of  dY * 2^s  ([2][C/8][npix][8] fp16, as swem_split_f16x2_f32),
+ * s = 13 - floor(log2 max|dY|) chosen ON THE DEVICE from the map itself (two launches: SWEM_AMAX_PARTS block maxima, then the
+ * split; no host decision, so a captured graph replays it), and stores 2^-s in scratch[0] for the consumers:
+ *   - the data-gradient convolution (swem_conv2d_nhwc_bf16x3_planes_ctr on those planes, SWEM_PLAN_F16): its per-column epilogue
+ *     `scale` multiplied by scratch[0] -- swem_vec_scale_f32(in, scratch, out, n): out[i] = (in ? in[i] : 1) * scratch[0];
+ *   - swem_conv2d_wgrad_f16x3 (dy_inv_scale = scratch): three products hi.mid + mid.hi + hi.hi on the f16 MFMA, the partial sums
+ *     multiplied by 2^-s in the reduce.  x planes: swem_split_f16x2_f32 of the forward activations (unscaled: |x| < 65520, faulted).
+ * Powers of two: the scaling is exact.  The largest element lands in [2^13, 2^14); elements within 2^-15 of it keep >= 22 bits,
+ * smaller ones carry an absolute error <= 2^-39 of the maximum.  scratch: SWEM_AMAX_PARTS + 1 floats of device memory, contents
+ * irrelevant on entry (nothing to zero).  A non-finite element sets SWEM_FAULT_RANGE in `fault` (may be NULL) and leaves s = 0.
+ * plan / workspace of the weight gradient: as swem_conv2d_wgrad_bf16x3 (same workspace query). */
+#define SWEM_AMAX_PARTS 256
+int swem_split_f16x2_scaled_f32(void *stream, const float *x, void *out, long long npix, int C, float *scratch, void *fault);
+int swem_vec_scale_f32(void *stream, const float *in, const float *factor, float *out, int n);
+/* filters w [Cout][K] (K % 8 == 0, K in the pre-split kernel's order) -> the fp16 pair planes [2][K/8][Cout][8] of the f16x3
+ * arithmetic, each filter scaled by its own power of two (largest weight in [2^13, 2^14): swem_hip.h, "f16x3"), and
+ * scale_out[n] = (scale_in ? scale_in[n] : 1) * 2^-e[n], the epilogue scale that undoes it.  One launch: the training step
+ * re-packs every filter every step. */
+int swem_pack_filters_f16x2_f32(void *stream, const float *w, void *out, int Cout, int K, const float *scale_in,
+                                float *scale_out);
+int swem_conv2d_wgrad_f16x3(void *stream, const void *dy2, long long dy_ps, const void *x0, int c0, long long bs0,
+                            long long ps0, const void *x1, int c1, long long bs1, long long ps1, const void *x2, int c2,
+                            long long bs2, long long ps2, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                            const float *dy_inv_scale, float *dw, int cin_store, int accumulate, int plan, void *ws,
+                            size_t ws_bytes);
 /* column sums of a [M][C] matrix: out1[c] (+)= sum_m a[m][c], out2[c] (+)= sum_m a[m][c]*b[m][c]  (bias and frozen
  * BatchNorm parameter gradients); either output may be NULL */
 size_t swem_colsum_workspace(long long M, int C);

@@ -29,7 +29,13 @@ def new_step(prebuild=False):
     _PACKS.clear()
     if prebuild:
         for key, build in _RECIPES.items():
-            _PACKS[key] = _keyed(build(), key)
+            pk = _PACKS[key] = _keyed(build(), key)
+            if isinstance(pk, ops.ConvPack):
+                # (the planes the layer's plan read last step are built now, on the main stream -- not lazily inside one lane)
+                if pk.site_key in ops.F16_PACK_SITES:
+                    pk.planes16()
+                if pk.site_key in ops.BF16_PACK_SITES:
+                    pk.w3
 
 
 def reset(book=None):
@@ -38,6 +44,8 @@ def reset(book=None):
     (SWEMTrainer.book), so that a model rebuilt at a recycled address never inherits a dead layer's hints."""
     _PACKS.clear()
     _RECIPES.clear()
+    ops.F16_PACK_SITES.clear()
+    ops.BF16_PACK_SITES.clear()
     b = book if book is not None else ops.BOOK
     b.hints.clear()
     b.hint_epoch.clear()
@@ -114,8 +122,11 @@ def _shared_pack(key, build):
 
 
 def _fwd_pack(weight, bias, stride, pad, cin_pad):
-    return _shared_pack((id(weight), 'fwd', cin_pad),
-                        lambda: ops.pack_conv(weight, bias, None, stride, pad, cin_pad=cin_pad))
+    def build():
+        pk = ops.pack_conv(weight, bias, None, stride, pad, cin_pad=cin_pad, lazy_planes=True)
+        pk.fast16 = True           # (re-packed every step: the fp16 planes of an f16x3 plan in one launch)
+        return pk
+    return _shared_pack((id(weight), 'fwd', cin_pad), build)
 
 
 def _dgrad_pack(weight, off, c, stride, pad, cin_pad):
@@ -126,12 +137,14 @@ def _dgrad_pack(weight, off, c, stride, pad, cin_pad):
         if cin_pad is not None and cin_pad != ci:
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_pad - ci))
         wt = w[:, off:off + c].permute(1, 2, 3, 0).contiguous()        # [c][KH][KW][Cout]
-        return ops.ConvPack(wt, None, None, c, kh, kw, stride, pad)
+        pk = ops.ConvPack(wt, None, None, c, kh, kw, stride, pad, lazy_planes=True)
+        pk.fast16 = True
+        return pk
     return _shared_pack((id(weight), 'dgrad', off, c, cin_pad), build)
 
 
 def wgrad_math(cs, cout, kh, kw, M):
-    """Which kernel takes a layer's weight gradient: 0 = fp32 MFMA on the fp32 tensors, 1 = bf16x6 / 2 = plain bf16 on
+    """Which kernel takes a layer's weight gradient: 0 = fp32 MFMA on the fp32 tensors, 1 = bf16x6 / 2 = plain bf16 / 3 = f16x3 on
     the pre-split planes (include/swem_hip_train.h).  Under ops.conv_math((2,)) (config.AMP) every layer the bf16 kernel
     is not slower on takes plain bf16; otherwise the large 3x3 layers take bf16x6 (fp32-level error) -- measured with
     tools/wgrad_bench.py on the training shapes."""
@@ -140,6 +153,10 @@ def wgrad_math(cs, cout, kh, kw, M):
     big = cout >= 128 and all(c >= 128 for c in cs)
     if ops._PLAN_TAG == ('math', 2):
         return 2 if (kh * kw > 1 or (big and M >= 2048)) else 0
+    if 7 in ops.CONV_MATH_MODES and ops._PLAN_TAG:
+        # fp32-level training on the f16x3 arithmetic (round 5): the plane kernel with fp16 pairs, dY scaled (three products
+        # instead of bf16x6's six; the same layers the one-product kernel is not slower on)
+        return 3 if (kh * kw > 1 or (big and M >= 2048)) else 0
     return 1 if (big and kh * kw > 1 and 1 in ops.CONV_MATH_MODES) else 0
 
 
@@ -152,16 +169,25 @@ def _wgrad(dy, srcs, weight, stride, pad, relu_in):
     cs = [s.shape[3] for s in srcs]
     math = wgrad_math(cs, Cout, kh, kw, B * Ho * Wo)
     args = []
+    npl = ops.PLANES_F16 if math == 3 else 3
     for s in srcs:
         bs = 0 if (s.shape[0] == 1 and B > 1) else (s.stride(0) if s.shape[0] > 1 else H * W * s.shape[3])
         if math:
-            sp = ops.presplit(s, relu_in)
+            sp = ops.presplit(s, relu_in, npl)
             args += [sp.data_ptr(), s.shape[3], bs, sp.stride(0)]
         else:
             args += [s.data_ptr(), s.shape[3], bs]
     for _ in range(3 - len(srcs)):
         args += [0, 0, 0, 0] if math else [0, 0, 0]
     cs = cs + [0, 0]
+    if math == 3:
+        d2 = ops.presplit(dy, False, ops.PLANES_F16)             # (dy is marked a gradient map: the scaled pair)
+        wsb = _lib.query('swem_conv2d_wgrad_bf16x3_workspace', B, H, W, cs[0], cs[1], cs[2], Cout, kh, kw, stride, pad, 0)
+        ws = _ws(wsb, dev)
+        _lib.call('swem_conv2d_wgrad_f16x3', ops._stream(), d2.data_ptr(), d2.stride(0), *args, B, H, W, Cout, kh, kw,
+                  stride, pad, dy.__dict__['_swem_inv'].data_ptr(), _grad(weight).data_ptr(), weight.shape[1], 1, 0,
+                  ws.data_ptr(), wsb)
+        return
     if math:
         d3 = ops.presplit(dy, False)
         wsb = _lib.query('swem_conv2d_wgrad_bf16x3_workspace', B, H, W, cs[0], cs[1], cs[2], Cout, kh, kw, stride, pad, 0)
@@ -194,6 +220,7 @@ class _Conv(Function):
         stride, pad, relu_in, batch, cin_pad = ctx.meta
         weight, bias, *srcs = ctx.saved_tensors
         dy = dy.contiguous()
+        dy.__dict__['_swem_grad'] = True      # (an fp16-pair consumer of this map gets the SCALED pair: ops.presplit)
         B, Ho, Wo, Cout = dy.shape
         dev = dy.device
         if bias is not None and bias.requires_grad:
@@ -269,7 +296,7 @@ def _planes_for(site, t, M, Cc):
     """The bf16 planes of a stage's output, written by the stage itself when an earlier step saw a convolution split this
     output (ops.SPLIT_HINTS): attached to the tensor where ops.presplit looks for them.  Otherwise the tensor is tagged
     with its producer so that a later split records the hint."""
-    if Cc % 8 == 0 and ops.BOOK.hints.get(site, {}).get(False):
+    if Cc % 8 == 0 and ops.BOOK.hints.get(site, {}).get(False, 0) in (1, 2, 3):      # (bf16 planes; an fp16-pair consumer splits itself)
         planes = torch.empty((3, M * Cc), dtype=torch.bfloat16, device=t.device)
         t.__dict__['_swem_split'] = {False: (planes, 3)}
         return planes

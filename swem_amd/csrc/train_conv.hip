@@ -11,6 +11,7 @@
 #include "../../include/swem_hip_train.h"
 #include "common.h"
 #include "lds_dma.h"
+#include "bf16_split.h"
 
 namespace {
 
@@ -149,16 +150,26 @@ struct WgradBP {
 __device__ __forceinline__ wg_s16x4 lds_tr16(unsigned addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3))) *)(size_t)addr);
 }
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
 __device__ __forceinline__ f32x16 wg_mfma(wg_s16x8 a, wg_s16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, a), __builtin_bit_cast(wg_bf16x8, b), c, 0,
-                                                 0, 0);
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, a), __builtin_bit_cast(wg_f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, a), __builtin_bit_cast(wg_bf16x8, b), c, 0,
+                                                   0, 0);
 }
 
 // KS = pixels per slab: 32 (every wave fills rows 8w..8w+7 of all images) or 16 (waves 0,1 fill the dY images, waves 2,3
 // the x images; half the LDS per stage, so the six-product mode keeps three blocks per CU instead of one).
-template <int WT, int NPL, int KS>
+// F16 (round 5, NPL = 2): the planes are fp16 (hi, mid) pairs -- dY's scaled by a power of two (swem_split_f16x2_scaled_f32) --
+// three products hi.mid + mid.hi + hi.hi on the f16 MFMA: the f16x3 arithmetic of the forward pass (fp32-level error) at half
+// the matrix work of the six-product mode.
+template <int WT, int NPL, int KS, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
   static_assert(KS == 16 || KS == 32, "slab of 16 or 32 pixels");
+  static_assert(!F16 || NPL == 2, "fp16 planes come as a (hi, mid) pair");
+  constexpr int NPB = F16 ? 2 : 3;              // planes behind the base pointers
   constexpr int BT = 64 * WT;
   constexpr int IMG = KS * 128;                 // bytes of one KS-pixel x 64-channel image
   constexpr int OPB = WT * NPL * IMG;           // one operand of one stage: [image][plane]
@@ -192,8 +203,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
     dok[i] = n0 / 8 + 8 * i + ch < p.Cout / 8;
     xok[i] = ci0 / 8 + 8 * i + ch < p.cs / 8;
   }
-  const i32x4 rsd = raw_rsrc(p.dy3, (unsigned)(3 * p.dps * 2));
-  const i32x4 rsx = raw_rsrc(p.x3, (unsigned)(3 * p.xps * 2));
+  const i32x4 rsd = raw_rsrc(p.dy3, (unsigned)(NPB * p.dps * 2));
+  const i32x4 rsx = raw_rsrc(p.x3, (unsigned)(NPB * p.xps * 2));
   const unsigned dplane = (unsigned)(p.dps * 2), xplane = (unsigned)(p.xps * 2);
   const unsigned d_base = (unsigned)(n0 / 8) * dgroup, x_base = (unsigned)(ci0 / 8) * xgroup;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
@@ -284,13 +295,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
         for (int j = 0; j < WT; ++j) {
           f32x16 c = acc[i][j];
           if constexpr (NPL == 3) {
-            c = wg_mfma(a[0][i], bb[2][j], c);
-            c = wg_mfma(a[2][i], bb[0][j], c);
-            c = wg_mfma(a[1][i], bb[1][j], c);
-            c = wg_mfma(a[0][i], bb[1][j], c);
-            c = wg_mfma(a[1][i], bb[0][j], c);
+            c = wg_mfma<F16>(a[0][i], bb[2][j], c);
+            c = wg_mfma<F16>(a[2][i], bb[0][j], c);
+            c = wg_mfma<F16>(a[1][i], bb[1][j], c);
           }
-          c = wg_mfma(a[0][i], bb[0][j], c);
+          if constexpr (NPL >= 2) {
+            c = wg_mfma<F16>(a[0][i], bb[1][j], c);
+            c = wg_mfma<F16>(a[1][i], bb[0][j], c);
+          }
+          c = wg_mfma<F16>(a[0][i], bb[0][j], c);
           acc[i][j] = c;
         }
     }
@@ -319,7 +332,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
 // stored as one contiguous run of 64 * taps floats of dw.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial,
                                                                 float *__restrict__ dw, int Cout, int Cin, int taps,
-                                                                int Cin_store, int zsplit, int accumulate, int cpb) {
+                                                                int Cin_store, int zsplit, int accumulate, int cpb,
+                                                                const float *__restrict__ factor) {
+  // (factor: one float in device memory the sums are multiplied by -- the inverse of dY's power-of-two plane scale; NULL = 1)
+  const float fac = factor ? *factor : 1.f;
   extern __shared__ float red_s[];   // [cpb][taps]; cpb = 64 or 16 input channels per block (16: enough blocks for small layers)
   const int n = blockIdx.y, c0 = blockIdx.x * cpb;
   const int nc = min(cpb, Cin_store - c0);
@@ -330,17 +346,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
     float s = 0.f;
     if (cl < nc)
       for (int z = 0; z < zsplit; ++z) s += src[z * zs + (long long)tap * Cin + cl];
-    red_s[cl * taps + tap] = s;
+    red_s[cl * taps + tap] = s * fac;
   }
   __syncthreads();
   float *o = dw + ((long long)n * Cin_store + c0) * taps;
   for (int idx = threadIdx.x; idx < nc * taps; idx += 256) o[idx] = accumulate ? o[idx] + red_s[idx] : red_s[idx];
 }
 static inline void launch_wgrad_reduce(hipStream_t st, const float *partial, float *dw, int Cout, int Cin, int taps,
-                                       int cin_store, int zsplit, int accumulate) {
+                                       int cin_store, int zsplit, int accumulate, const float *factor = nullptr) {
   const int cpb = (long long)cdiv(cin_store, 64) * Cout < 1024 ? 16 : 64;
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(cin_store, cpb), Cout), dim3(256), cpb * taps * sizeof(float), st,
-                     partial, dw, Cout, Cin, taps, cin_store, zsplit, accumulate, cpb);
+                     partial, dw, Cout, Cin, taps, cin_store, zsplit, accumulate, cpb, factor);
 }
 
 // per-column sums of a [M][C] matrix (optionally of the product with a second one): stage 1 = one partial row per
@@ -523,11 +539,11 @@ static WgradPlan wgrad_bf_plan(long long M, int Cout, int KH, int KW, int c0, in
   return wgrad_pick(M, Cout, KH, KW, c0, c1, c2, plan, math == 1 ? 64 : 128);
 }
 
-template <int WT, int NPL, int KS>
+template <int WT, int NPL, int KS, bool F16 = false>
 static int launch_wgrad_bf(const WgradBP &p, dim3 grid, hipStream_t st) {
   constexpr size_t lds = 2 * 2 * WT * NPL * KS * 128;
-  SWEM_ALLOW_LDS((conv_wgrad_bf_kernel<WT, NPL, KS>), lds);
-  hipLaunchKernelGGL((conv_wgrad_bf_kernel<WT, NPL, KS>), grid, dim3(256), lds, st, p);
+  SWEM_ALLOW_LDS((conv_wgrad_bf_kernel<WT, NPL, KS, F16>), lds);
+  hipLaunchKernelGGL((conv_wgrad_bf_kernel<WT, NPL, KS, F16>), grid, dim3(256), lds, st, p);
   return SWEM_OK;
 }
 
@@ -541,19 +557,20 @@ extern "C" size_t swem_conv2d_wgrad_bf16x3_workspace(int B, int H, int W, int c0
   return (size_t)(z1 > z2 ? z1 : z2) * Cout * KH * KW * (c0 + c1 + c2) * sizeof(float);
 }
 
-extern "C" int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3, long long dy_ps,
-                                        const unsigned short *x0, int c0, long long bs0, long long ps0,
-                                        const unsigned short *x1, int c1, long long bs1, long long ps1,
-                                        const unsigned short *x2, int c2, long long bs2, long long ps2, int B, int H,
-                                        int W, int Cout, int KH, int KW, int stride, int pad, int math, float *dw,
-                                        int cin_store, int accumulate, int plan, void *ws, size_t ws_bytes) {
+// math: 1 = bf16x6, 2 = plain bf16, 3 = f16x3 (fp16 pairs; `factor` = device float the result is multiplied by, or NULL)
+static int wgrad_planes_impl(void *stream, const unsigned short *dy3, long long dy_ps,
+                             const unsigned short *x0, int c0, long long bs0, long long ps0,
+                             const unsigned short *x1, int c1, long long bs1, long long ps1,
+                             const unsigned short *x2, int c2, long long bs2, long long ps2, int B, int H,
+                             int W, int Cout, int KH, int KW, int stride, int pad, int math, float *dw,
+                             int cin_store, int accumulate, int plan, void *ws, size_t ws_bytes, const float *factor) {
   SWEM_REQUIRE(dy3 && x0 && dw, SWEM_E_ARG, "conv2d_wgrad_bf16x3: null pointer");
   SWEM_REQUIRE((c1 == 0 || x1) && (c2 == 0 || x2) && c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0 && c2 % 8 == 0 &&
                    Cout % 8 == 0 && Cout > 0,
                SWEM_E_SHAPE, "conv2d_wgrad_bf16x3: channel counts must be multiples of 8");
   SWEM_REQUIRE(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, SWEM_E_SHAPE,
                "conv2d_wgrad_bf16x3: bad geometry");
-  SWEM_REQUIRE(math == 1 || math == 2, SWEM_E_ARG, "conv2d_wgrad_bf16x3: math must be 1 (bf16x6) or 2 (bf16)");
+  SWEM_REQUIRE(math >= 1 && math <= 3, SWEM_E_ARG, "conv2d_wgrad_bf16x3: math must be 1 (bf16x6) or 2 (bf16)");
   const int Cin = c0 + c1 + c2;
   SWEM_REQUIRE(cin_store > 0 && cin_store <= Cin, SWEM_E_SHAPE, "conv2d_wgrad_bf16x3: cin_store out of range");
   WgradBP p;
@@ -594,7 +611,10 @@ extern "C" int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3,
     // slab: 16 pixels for the six-product 128x128 tile (48 KB of LDS instead of 96: three blocks per CU), else 32;
     // plan bit 12 flips the choice (tools/wgrad_bench.py)
     const bool ks16 = ((pl.wt == 2 && math == 1) != (((plan >> 12) & 1) != 0));
-    if (pl.wt == 2) {
+    if (math == 3) {
+      if (pl.wt == 2) rc = ks16 ? launch_wgrad_bf<2, 2, 16, true>(p, grid, st) : launch_wgrad_bf<2, 2, 32, true>(p, grid, st);
+      else rc = ks16 ? launch_wgrad_bf<1, 2, 16, true>(p, grid, st) : launch_wgrad_bf<1, 2, 32, true>(p, grid, st);
+    } else if (pl.wt == 2) {
       if (math == 1) rc = ks16 ? launch_wgrad_bf<2, 3, 16>(p, grid, st) : launch_wgrad_bf<2, 3, 32>(p, grid, st);
       else rc = ks16 ? launch_wgrad_bf<2, 1, 16>(p, grid, st) : launch_wgrad_bf<2, 1, 32>(p, grid, st);
     } else {
@@ -605,8 +625,166 @@ extern "C" int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3,
     SWEM_CHECK_LAUNCH("conv_wgrad_bf_kernel");
     off += cs[s];
   }
-  launch_wgrad_reduce(st, p.partial, dw, Cout, Cin, KH * KW, cin_store, pl.zsplit, accumulate);
+  launch_wgrad_reduce(st, p.partial, dw, Cout, Cin, KH * KW, cin_store, pl.zsplit, accumulate, factor);
   SWEM_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
+  return SWEM_OK;
+}
+
+extern "C" int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3, long long dy_ps,
+                                        const unsigned short *x0, int c0, long long bs0, long long ps0,
+                                        const unsigned short *x1, int c1, long long bs1, long long ps1,
+                                        const unsigned short *x2, int c2, long long bs2, long long ps2, int B, int H,
+                                        int W, int Cout, int KH, int KW, int stride, int pad, int math, float *dw,
+                                        int cin_store, int accumulate, int plan, void *ws, size_t ws_bytes) {
+  SWEM_REQUIRE(math == 1 || math == 2, SWEM_E_ARG, "conv2d_wgrad_bf16x3: math must be 1 (bf16x6) or 2 (bf16)");
+  return wgrad_planes_impl(stream, dy3, dy_ps, x0, c0, bs0, ps0, x1, c1, bs1, ps1, x2, c2, bs2, ps2, B, H, W, Cout, KH, KW, stride,
+                           pad, math, dw, cin_store, accumulate, plan, ws, ws_bytes, nullptr);
+}
+
+extern "C" int swem_conv2d_wgrad_f16x3(void *stream, const void *dy2, long long dy_ps, const void *x0, int c0, long long bs0,
+                                       long long ps0, const void *x1, int c1, long long bs1, long long ps1, const void *x2,
+                                       int c2, long long bs2, long long ps2, int B, int H, int W, int Cout, int KH, int KW,
+                                       int stride, int pad, const float *dy_inv_scale, float *dw, int cin_store,
+                                       int accumulate, int plan, void *ws, size_t ws_bytes) {
+  return wgrad_planes_impl(stream, static_cast<const unsigned short *>(dy2), dy_ps, static_cast<const unsigned short *>(x0), c0,
+                           bs0, ps0, static_cast<const unsigned short *>(x1), c1, bs1, ps1,
+                           static_cast<const unsigned short *>(x2), c2, bs2, ps2, B, H, W, Cout, KH, KW, stride, pad, 3, dw,
+                           cin_store, accumulate, plan, ws, ws_bytes, dy_inv_scale);
+}
+
+// ---- the fp16 (hi, mid) pair of a GRADIENT map, scaled by a power of two chosen from its largest magnitude
+// Gradients span too many binades for an unscaled fp16 pair (the pair carries 22-23 bits only where |x| >= 2^-2, and nothing above
+// 65504).  Pass 1: SWEM_AMAX_PARTS block maxima of |x| (no atomics, nothing to zero: the scratch may be uninitialised memory).
+// Pass 2: every block reduces the maxima itself, scales by 2^s with s = 13 - floor(log2 amax) -- the largest element lands in
+// [2^13, 2^14), every element within 2^-15 of it keeps >= 22 bits, smaller ones an absolute error <= 2^-39 of the maximum -- and
+// splits; block 0 stores 2^-s for the consumers (the data-gradient convolution's epilogue scale, the weight gradient's reduce).
+// Exact (powers of two), deterministic, graph-safe (no host decision).  A non-finite maximum sets SWEM_FAULT_RANGE (scale 1).
+namespace {
+__global__ __launch_bounds__(256) void amax_partials_kernel(const float4 *__restrict__ x, long long n4, float *__restrict__ part) {
+  unsigned m = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = x[i];
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu, __float_as_uint(v.z) & 0x7fffffffu));
+    m = max(m, __float_as_uint(v.w) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  __shared__ unsigned sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = __uint_as_float(max(max(sh[0], sh[1]), max(sh[2], sh[3])));
+}
+__device__ __forceinline__ int grad_scale_exp(const float *part, unsigned *fault) {
+  // (block-wide: every thread returns s; blockDim = 256 >= SWEM_AMAX_PARTS)
+  unsigned m = threadIdx.x < SWEM_AMAX_PARTS ? __float_as_uint(part[threadIdx.x]) : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  __shared__ unsigned sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+  if (m >= 0x7f800000u) {   // inf / NaN in the map: the planes carry it on (as the fp32 arithmetic would); reported
+    if (fault && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+      __hip_atomic_fetch_or(fault, (unsigned)SWEM_FAULT_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+  }
+  if (m == 0u) return 0;
+  const int s = 140 - (int)(m >> 23);   // 13 - (biased exponent - 127)
+  return s < -126 ? -126 : (s > 126 ? 126 : s);
+}
+__global__ __launch_bounds__(256) void split_f16x2_scaled_kernel(const float *__restrict__ x, unsigned short *__restrict__ out,
+                                                                 long long npix, int C, const float *__restrict__ part,
+                                                                 float *__restrict__ inv_out, unsigned *fault) {
+  const int s = grad_scale_exp(part, fault);
+  const float scale = __uint_as_float((unsigned)(s + 127) << 23);
+  if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) *inv_out = __uint_as_float((unsigned)(127 - s) << 23);
+  const long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int cg = blockIdx.y * 8 + (threadIdx.x & 7);
+  if (pix >= npix || cg >= C / 8) return;
+  const float *src = x + pix * C + cg * 8;
+  float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 4);
+  v0 = make_float4(v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale);
+  v1 = make_float4(v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale);
+  uint2 h0, m0, h1, m1;
+  split2h(v0, h0, m0);
+  split2h(v1, h1, m1);
+  const long long plane = npix * C, i = (long long)cg * npix + pix;
+  *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+}
+__global__ __launch_bounds__(256) void vec_scale_kernel(const float *__restrict__ in, const float *__restrict__ factor,
+                                                        float *__restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (in ? in[i] : 1.f) * *factor;
+}
+}  // namespace
+
+extern "C" int swem_split_f16x2_scaled_f32(void *stream, const float *x, void *out, long long npix, int C, float *scratch,
+                                           void *fault) {
+  SWEM_REQUIRE(x && out && scratch && npix > 0 && C > 0 && C % 8 == 0, SWEM_E_ARG, "split_f16x2_scaled: need C %% 8 == 0");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(amax_partials_kernel, dim3(SWEM_AMAX_PARTS), dim3(256), 0, st, reinterpret_cast<const float4 *>(x),
+                     npix * C / 4, scratch + 1);
+  SWEM_CHECK_LAUNCH("amax_partials_kernel");
+  hipLaunchKernelGGL(split_f16x2_scaled_kernel, dim3((unsigned)cdiv(npix, 32), (unsigned)cdiv(C / 8, 8)), dim3(256), 0, st, x,
+                     static_cast<unsigned short *>(out), npix, C, scratch + 1, scratch, static_cast<unsigned *>(fault));
+  SWEM_CHECK_LAUNCH("split_f16x2_scaled_kernel");
+  return SWEM_OK;
+}
+
+// filters [Cout][K] -> the fp16 pair planes [2][K/8][Cout][8] of the f16x3 arithmetic, every filter (output column) scaled by its
+// own power of two so that its largest weight lies in [2^13, 2^14) (swem_hip.h, "f16x3"), and the epilogue scale that undoes it:
+// scale_out[n] = (scale_in ? scale_in[n] : 1) * 2^-e[n].  One launch per pack (the training step re-packs every filter every step).
+namespace {
+__global__ __launch_bounds__(256) void pack_filters_f16x2_kernel(const float *__restrict__ w, unsigned short *__restrict__ out,
+                                                                 int Cout, int K, const float *__restrict__ scale_in,
+                                                                 float *__restrict__ scale_out) {
+  const int n = blockIdx.x;
+  const float *row = w + (long long)n * K;
+  unsigned m = 0;
+  for (int k = threadIdx.x * 4; k < K; k += 1024) {
+    const float4 v = *reinterpret_cast<const float4 *>(row + k);
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu, __float_as_uint(v.z) & 0x7fffffffu));
+    m = max(m, __float_as_uint(v.w) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  __shared__ unsigned sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+  int s = (m == 0u || m >= 0x7f800000u) ? 0 : 140 - (int)(m >> 23);
+  s = s < -100 ? -100 : (s > 100 ? 100 : s);
+  const float scale = __uint_as_float((unsigned)(s + 127) << 23);
+  if (threadIdx.x == 0) scale_out[n] = (scale_in ? scale_in[n] : 1.f) * __uint_as_float((unsigned)(127 - s) << 23);
+  const long long plane = (long long)Cout * K;
+  for (int k = threadIdx.x * 8; k < K; k += 2048) {
+    float4 v0 = *reinterpret_cast<const float4 *>(row + k), v1 = *reinterpret_cast<const float4 *>(row + k + 4);
+    v0 = make_float4(v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale);
+    v1 = make_float4(v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale);
+    uint2 h0, m0, h1, m1;
+    split2h(v0, h0, m0);
+    split2h(v1, h1, m1);
+    const long long i = (long long)(k >> 3) * Cout + n;
+    *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+  }
+}
+}  // namespace
+
+extern "C" int swem_pack_filters_f16x2_f32(void *stream, const float *w, void *out, int Cout, int K, const float *scale_in,
+                                           float *scale_out) {
+  SWEM_REQUIRE(w && out && scale_out && Cout > 0 && K > 0 && K % 8 == 0, SWEM_E_ARG, "pack_filters_f16x2: need K %% 8 == 0");
+  hipLaunchKernelGGL(pack_filters_f16x2_kernel, dim3(Cout), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                     static_cast<unsigned short *>(out), Cout, K, scale_in, scale_out);
+  SWEM_CHECK_LAUNCH("pack_filters_f16x2_kernel");
+  return SWEM_OK;
+}
+
+extern "C" int swem_vec_scale_f32(void *stream, const float *in, const float *factor, float *out, int n) {
+  SWEM_REQUIRE(factor && out && n > 0, SWEM_E_ARG, "vec_scale: bad argument");
+  hipLaunchKernelGGL(vec_scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), in, factor, out, n);
+  SWEM_CHECK_LAUNCH("vec_scale_kernel");
   return SWEM_OK;
 }
 

@@ -501,7 +501,7 @@ def check_faults():
 class ConvPack:
     """Weights of one conv in kernel layout: w [Cout'][KH][KW][Cin_pad] plus per-filter scale / shift."""
 
-    def __init__(self, w, scale, shift, cout, kh, kw, stride, pad, glu=False):
+    def __init__(self, w, scale, shift, cout, kh, kw, stride, pad, glu=False, lazy_planes=False):
         self.w, self.scale, self.shift = w, scale, shift
         self.cout, self.kh, self.kw, self.stride, self.pad, self.glu = cout, kh, kw, stride, pad, glu
         self.cin = w.shape[-1]
@@ -514,11 +514,29 @@ class ConvPack:
         # (the activation split kernel on the [Cout'][K] matrix: one launch; the training step re-packs every step)
         # the planes' K axis runs (ci / 32, ky, kx, ci % 32), not (ky, kx, ci): swem_conv2d_nhwc_bf16x3 walks the taps of
         # one 32-channel block back to back, so a tile's activations are fetched once instead of once per tap
-        self.w3 = None
+        self._w3 = None
         self._w16 = None                  # (fp16 filter planes, scale with the planes' power-of-two column factors folded in)
-        if kk % 8 == 0 and self.cin % 32 == 0 and kh * kw <= 64:
-            self.w3 = torch.empty((3, co * kk), dtype=torch.bfloat16, device=w.device)
-            _lib.call('swem_split_bf16x3_f32', _stream(), self._k_ordered().data_ptr(), self.w3.data_ptr(), co, kk, 0)
+        # the training step re-packs every filter every step: its packs make the fp16 planes in ONE launch
+        # (swem_pack_filters_f16x2_f32: exponent bits instead of log2, otherwise the arithmetic of planes16 below)
+        self.fast16 = False
+        self.presplit_form = kk % 8 == 0 and self.cin % 32 == 0 and kh * kw <= 64     # (the pre-split kernel can take this layer)
+        if self.presplit_form and not lazy_planes:
+            self._make_w3()
+
+    def _make_w3(self):
+        wk = self._k_ordered()
+        co, kk = wk.shape[0], wk[0].numel()
+        self._w3 = torch.empty((3, co * kk), dtype=torch.bfloat16, device=wk.device)
+        _lib.call('swem_split_bf16x3_f32', _stream(), wk.data_ptr(), self._w3.data_ptr(), co, kk, 0)
+
+    @property
+    def w3(self):
+        """The three bf16 filter planes (None where the layer has no pre-split form).  A per-step pack of the training step
+        (`lazy_planes`) builds them on first use: a layer whose plan is f16x3 never reads them."""
+        if self._w3 is None and self.presplit_form:
+            self._make_w3()
+        return self._w3
+
 
     def _k_ordered(self):
         w = self.w
@@ -534,10 +552,17 @@ class ConvPack:
         2^-2 would be a subnormal fp16 number -- and scale16[n] = scale[n] * 2^-e[n] undoes it in the epilogue (exact: powers of
         two).  Built on first use, once per pack."""
         if self._w16 is None:
-            if self.w3 is None:
+            if not self.presplit_form:
                 raise _lib.SwemHipError('this layer has no pre-split form (K %% 8, Cin %% 32, at most 64 taps)')
             wk = self._k_ordered()
             co, kk = wk.shape[0], wk[0].numel()
+            if self.fast16:
+                w16 = torch.empty((2, co * kk), dtype=torch.float16, device=wk.device)
+                sc = torch.empty(co, dtype=torch.float32, device=wk.device)
+                _lib.call('swem_pack_filters_f16x2_f32', _stream(), wk.data_ptr(), w16.data_ptr(), co, kk, _ptr(self.scale),
+                          sc.data_ptr())
+                self._w16 = (w16, sc)
+                return self._w16
             amax = wk.reshape(co, kk).abs().amax(dim=1)
             e = torch.where(amax > 0, 13 - torch.floor(torch.log2(amax.clamp_min(1e-30))), torch.zeros_like(amax))
             # (log2 of a float just below a power of two may round up: the column then peaks in [2^12, 2^13), equally fine)
@@ -550,7 +575,7 @@ class ConvPack:
         return self._w16
 
 
-def pack_conv(weight, bias=None, bn=None, stride=1, pad=None, cin_pad=None, eps=1e-5):
+def pack_conv(weight, bias=None, bn=None, stride=1, pad=None, cin_pad=None, eps=1e-5, lazy_planes=False):
     """OIHW weight (+bias, + frozen BatchNorm (gamma, beta, mean, var)) -> ConvPack.
     BN folding follows ATen's eval-mode batch_norm: alpha = gamma/sqrt(var+eps), y = x*alpha + (beta - mean*alpha)."""
     co, ci, kh, kw = weight.shape
@@ -571,7 +596,7 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=None, cin_pad=None, eps=
         shift = shift.contiguous()
     elif bias is not None:
         shift = bias.detach().float().contiguous()
-    pk = ConvPack(w.to(dev), scale, shift, co, kh, kw, stride, kh // 2 if pad is None else pad)
+    pk = ConvPack(w.to(dev), scale, shift, co, kh, kw, stride, kh // 2 if pad is None else pad, lazy_planes=lazy_planes)
     pk.cin_true = ci
     return pk
 
@@ -640,7 +665,18 @@ def presplit(t, relu=False, nplanes=3):
             # pays this launch every frame -- ADVICE r04: count it instead of paying it silently
             RESPLITS[site] = RESPLITS.get(site, 0) + 1
         npix = (B - 1) * (t.stride(0) // Cc) + H * W if B > 1 else H * W
-        if f16:
+        if f16 and t.__dict__.get('_swem_grad'):
+            # a GRADIENT map (autograd marks them): the pair of t * 2^s, s chosen on the device from max |t|; the consumers
+            # multiply by scratch[0] = 2^-s (include/swem_hip_train.h, swem_split_f16x2_scaled_f32)
+            if relu:
+                raise _lib.SwemHipError('presplit: a gradient map has no input ReLU')
+            sp = torch.empty((2, npix * Cc), dtype=torch.float16, device=t.device)
+            scratch = torch.empty(AMAX_PARTS + 1, dtype=torch.float32, device=t.device)
+            _lib.call('swem_split_f16x2_scaled_f32', _stream(), t.data_ptr(), sp.data_ptr(), npix, Cc, scratch.data_ptr(),
+                      _fault_ptr(t.device))
+            t.__dict__['_swem_inv'] = scratch
+            ent = cache[key] = (sp, PLANES_F16)
+        elif f16:
             sp = torch.empty((2, npix * Cc), dtype=torch.float16, device=t.device)
             _lib.call('swem_split_f16x2_f32', _stream(), t.data_ptr(), sp.data_ptr(), npix, Cc, int(relu), _fault_ptr(t.device))
             ent = cache[key] = (sp, PLANES_F16)
@@ -651,6 +687,12 @@ def presplit(t, relu=False, nplanes=3):
     return ent[0]
 
 
+AMAX_PARTS = 256   # include/swem_hip_train.h, SWEM_AMAX_PARTS
+# per-step packs (ConvPack.fast16: the training step's) that ran an f16x3 plan: their fp16 filter planes are built lazily, which
+# inside a step would happen on ONE lane's stream while the other lanes read the shared pack -- autograd.new_step(prebuild=True)
+# builds them with the pack, on the main stream, before the lanes fork
+F16_PACK_SITES = set()
+BF16_PACK_SITES = set()     # ... and the same for the bf16 planes (built lazily for those packs: ConvPack(lazy_planes=True))
 RESPLITS = {}      # producer site -> split launches made for a tensor that already carried producer-written planes
 # The decoder's two skip convolutions (networks.py:190-196: UpsampleBlock.skip_conv on s8 / s4) read the KEY encoder's features only:
 # the same for every object (round 2: computed once per frame) and independent of the memory.  With this switch (default on;
@@ -781,7 +823,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
         res_bs = 0 if (res_broadcast or (residual.shape[0] == 1 and B > 1)) else Ho * Wo * pack.cout
 
     pipe_ok = all(s_.shape[3] % 32 == 0 for s_ in srcs)      # (the register-staged kernels' condition, conv.hip)
-    presplit_ok = pack.w3 is not None and pipe_ok
+    presplit_ok = pack.presplit_form and pipe_ok
 
     # the output's own bf16 planes, if the convolutions that consumed this layer's output on an earlier frame split it:
     # the epilogue writes them (fused operand split: no split launch, no re-read of y)
@@ -821,6 +863,9 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
             f16 = (plan >> 16) & 7 == 7
             need = 3 if (plan >> 16) & 3 == 1 else (PLANES_F16 if f16 else 2)
             w3, scale = pack.planes16() if f16 else (pack.w3, pack.scale)
+            if pack.fast16 and not _IN_TUNER[0]:
+                # (the training step pre-builds the planes its packs' plans read: autograd.new_step)
+                (F16_PACK_SITES if f16 else BF16_PACK_SITES).add(pack.site_key)
             sargs = []
             for i, s_ in enumerate(srcs):
                 # (tuning charges a candidate the split of its inputs -- except inputs a conv epilogue produces: those arrive
@@ -829,6 +874,14 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
                     s_.__dict__.pop('_swem_split', None)
                 sp = presplit(s_, relu_in, need)
                 sargs += [sp.data_ptr(), s_.shape[3], args[3 * i + 2], sp.stride(0)]
+                if f16 and s_.__dict__.get('_swem_grad'):
+                    # the planes hold dY * 2^s (presplit): the epilogue scale takes the 2^-s (device side: graph-safe)
+                    if len(srcs) != 1:
+                        raise _lib.SwemHipError('conv2d: a scaled gradient map is the only source of its data-gradient convolution')
+                    ncol = pack.cout * (2 if pack.glu else 1)
+                    sc_ = torch.empty(ncol, dtype=torch.float32, device=x0.device)
+                    _lib.call('swem_vec_scale_f32', _stream(), _ptr(scale), s_.__dict__['_swem_inv'].data_ptr(), sc_.data_ptr(), ncol)
+                    scale = sc_
             for _ in range(3 - len(srcs)):
                 sargs += [0, 0, 0, 0]
             ctr = counters(x0.device)
@@ -933,7 +986,7 @@ def bottleneck_ok(x, c1, c2, c3):
         return False
     geo = ((c1, 256, 64, 1, 0), (c2, 64, 64, 3, 1), (c3, 64, 256, 1, 0))
     for pk, ci, co, k, pad in geo:
-        if (pk.cin, pk.cout, pk.kh, pk.kw, pk.stride, pk.pad, pk.glu) != (ci, co, k, k, 1, pad, False) or pk.w3 is None \
+        if (pk.cin, pk.cout, pk.kh, pk.kw, pk.stride, pk.pad, pk.glu) != (ci, co, k, k, 1, pad, False) or not pk.presplit_form \
                 or pk.scale is None or pk.shift is None:
             return False
     B, H, W, _ = x.shape

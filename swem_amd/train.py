@@ -191,6 +191,13 @@ class SWEMTrainer:
         # bf16 and take ONE MFMA product with fp32 accumulation (conv math mode 2); activations, EM, matching, the loss,
         # the weight gradient and the optimizer stay fp32.  bf16 keeps fp32's exponent range, so no loss scaling.
         self.amp = bool(_get(config, 'AMP'))
+        # fp32-level steps (no AMP) may run their convolutions -- forward, data and weight gradient -- in the f16x3 arithmetic of
+        # the inference path (three fp16 MFMA products, 22-23 operand bits) next to fp32 MFMA and bf16x6 (six products): the
+        # tuner picks per layer.  Gradient maps are scaled by a power of two chosen on the device (swem_split_f16x2_scaled_f32);
+        # activations beyond the fp16 range raise SwemRangeError at the fault check (then: SWEM_TRAIN_F16X3=0 / trainer.f16x3 = False
+        # before the first step).
+        self.f16x3 = os.environ.get('SWEM_TRAIN_F16X3', '1') != '0'
+        self.math_modes = None       # (tests: an explicit set of conv math modes for the step, e.g. (7,) = f16x3 wherever it applies)
         # data parallel: True = the non-trunk gradient slice is all-reduced while the lanes back-propagate through the
         # key-encoder trunk (collective kernels next to the lanes' graphs); False = ONE all-reduce of the whole gradient after
         # the backward pass, nothing of RCCL in flight beside the lanes (the conservative form; same result bit for bit)
@@ -477,12 +484,14 @@ class SWEMTrainer:
         return losses, results
 
     def _math(self):
-        """Conv math modes of the step: config.AMP = plain bf16 operands; otherwise the fp32-level modes only (fp32 MFMA and
-        bf16x6) -- the 16-bit-operand bf16x3 mode the inference tuner may pick is kept out of the gradient path."""
+        """Conv math modes of the step: config.AMP = plain bf16 operands; otherwise the fp32-level modes only (fp32 MFMA,
+        bf16x6 and -- round 5, `self.f16x3` -- the fp16-pair f16x3 with gradient maps scaled on the device, include/
+        swem_hip_train.h) -- the 16-bit-operand bf16x3 mode the inference tuner may pick is kept out of the gradient path."""
         import contextlib
         st = contextlib.ExitStack()
         st.enter_context(ops.use_book(self.book))
-        st.enter_context(ops.conv_math((2,)) if self.amp else ops.conv_math((0, 1)))
+        modes = self.math_modes or ((2,) if self.amp else ((0, 1, 7) if self.f16x3 else (0, 1)))
+        st.enter_context(ops.conv_math(modes))
         # conv epilogues do not write operand planes here and the tuner keeps to the non-persistent kernel forms (ops.py,
         # TUNE_ROUND3_FORMS: measured on the four-lane step); the frozen-BN stages' own planes (autograd._planes_for) stay
         # (re-measured in round 4 with the step's timing stable to +-0.3 %: FUSE_SPLIT on or off is the same 112 / 69 clips/s --

@@ -3,6 +3,7 @@ pinned to the reference trainer by tests/golden/g9_*).  Loss / optimizer first, 
 identical inputs, then the whole step."""
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -435,6 +436,23 @@ def test_memorize_backward(lib):
 def test_one_step_matches_reference_trainer(golden, lib, tag, it):
     """a18: SWEMTrainer.one_step on HIP against the losses, index maps, per-parameter gradient norms and the AdamW
     update recorded from the REFERENCE trainer (tests/golden/make_golden_train.py)."""
+    _one_step_vs_reference(golden, tag, it, None)
+
+
+@pytest.mark.parametrize('tag,it', [('r18', 45), ('r50', 45), ('r50k256', 45), ('r50k256n5', 45)])
+def test_one_step_f16x3_matches_reference_trainer(golden, lib, tag, it):
+    """The same step with EVERY convolution the pre-split kernel can take in the f16x3 arithmetic (round 5: forward, data gradient
+    on the device-scaled fp16 pair of dY, weight gradient swem_conv2d_wgrad_f16x3) -- held to the same bars against the reference
+    trainer's record as the fp32 / bf16x6 step above (the tuner mixes the three per layer; this is the all-f16x3 corner)."""
+    from swem_amd import ops
+    ran = {}
+    with ops.flags(MATH_RAN=ran):
+        _one_step_vs_reference(golden, tag, it, (7,))
+    assert ran.get(7, 0) > 50 and ran.get(7, 0) > 5 * ran.get(0, 0), ran        # (the stems and the heads stay on the fp32 kernels)
+    ops.check_faults()
+
+
+def _one_step_vs_reference(golden, tag, it, modes):
     from swem_amd.train import SWEMTrainer
     tc = H.train_cases()
     case = tc['cases'][tag]
@@ -442,6 +460,7 @@ def test_one_step_matches_reference_trainer(golden, lib, tag, it):
     cfg = O.make_cfg(**case['cfg'])
     model, sd = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
     trainer = SWEMTrainer(dict(SOLVER=tc['solver_cfg'], LOSS=tc['loss_cfg'], AMP=False), model)
+    trainer.math_modes = modes
     frames, init_mask, label, valid = H.train_batch(case)
     assert H.checksum(frames) == pytest.approx(float(fx['frames_sum']), rel=1e-12)
     torch.manual_seed(91)
@@ -472,7 +491,7 @@ def test_one_step_matches_reference_trainer(golden, lib, tag, it):
     fe = fx['floor64_elem'].tolist()
     print('   elementwise rel err: pred.weight %.2e (floor %.1e), key_proj.bias %.2e (%.1e), value conv1.weight %.2e (%.1e)'
           % (errs[0], fe[0], errs[1], fe[1], errs[2], fe[2]))
-    H.record_parity('train_step_%s_it%d' % (tag, it), {
+    H.record_parity('train_step_%s_it%d%s' % (tag, it, '' if modes is None else '_f16x3'), {
         'losses': got, 'reference_losses': {k: float(fx[k]) for k in got}, 'reference_fp32_vs_fp64_loss_floor': float(fx['floor64_loss']),
         'index_agreement': agree, 'reference_fp32_vs_fp64_agreement': float(fx['agree64']),
         'grad_norm_rel_err': {'median': srt[len(srt) // 2], 'p90': srt[int(len(srt) * 0.9)], 'worst': srt[-1]},
@@ -653,6 +672,130 @@ def test_conv_wgrad_bf16_pipe(lib, case, math):
             close(got, ref(lambda t: t.bfloat16().float())[:, :cin_store], 3e-5, 'dW bf16 (rounded operands) plan %#x' % plan)
             err = float((got - exact).abs().max() / exact.abs().max())
             assert 1e-5 < err < 2e-2, err
+
+
+@pytest.mark.parametrize('gscale', [1.0, 3.0e-7, 2.5e4], ids=['unit', 'tiny', 'huge'])
+@pytest.mark.parametrize('case', [
+    dict(cins=[(256, 2)], cout=256, k=3, s=1, hw=(24, 24), relu_in=True),
+    dict(cins=[(136, 2)], cout=200, k=3, s=2, hw=(21, 19), relu_in=False),
+    dict(cins=[(72, 3)], cout=40, k=3, s=1, hw=(25, 23), relu_in=False),
+    dict(cins=[(64, 1)], cout=128, k=1, s=2, hw=(16, 15), relu_in=True, pad=0),
+    dict(cins=[(128, 3), (256, 1), (128, 3)], cout=128, k=3, s=1, hw=(9, 11), relu_in=False),
+], ids=['whole128', 'ragged128_s2', 'ragged64', '1x1_s2', 'three_src_shared'])
+def test_conv_wgrad_f16x3_scaled(lib, case, gscale):
+    """swem_split_f16x2_scaled_f32 + swem_conv2d_wgrad_f16x3 (round 5): the weight gradient from fp16
+    (hi, mid) pairs -- dY scaled by a power of two chosen ON THE DEVICE from its largest magnitude, the activations unscaled --
+    carries fp32-level error against F.conv2d's autograd in fp64 whatever the gradient's magnitude: a dY of 3e-7 (its pair would
+    be all subnormal unscaled) or 2.5e4 x N(0,1) (beyond the fp16 range unscaled).  dY has a heavy tail on purpose (a few
+    elements 1e3 x the rest: the scale follows the maximum, the bulk sits ten binades below it)."""
+    from swem_amd import _lib, ops
+    ops.check_faults()
+    g = torch.Generator().manual_seed(13)
+    k, s = case['k'], case['s']
+    pad = case.get('pad', k // 2)
+    H_, W_ = case['hw']
+    B = max(b for _, b in case['cins'])
+    xs = [torch.randn(b, c, H_, W_, generator=g) for c, b in case['cins']]
+    cin = sum(c for c, _ in case['cins'])
+    cout = case['cout']
+    Ho, Wo = (H_ + 2 * pad - k) // s + 1, (W_ + 2 * pad - k) // s + 1
+    dy = torch.randn(B, cout, Ho, Wo, generator=g)
+    dy[torch.rand(dy.shape, generator=g) < 1e-3] *= 1.0e3
+    dy = dy * gscale
+    xcat = torch.cat([x.expand(B, -1, -1, -1) for x in xs], 1)
+    xcat = F.relu(xcat) if case['relu_in'] else xcat
+    w = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xcat.double(), w, stride=s, padding=pad).backward(dy.double())
+    exact = w.grad
+    srcs = [nhwc(x) for x in xs]
+    d = nhwc(dy)
+    d.__dict__['_swem_grad'] = True
+    d2 = ops.presplit(d, False, ops.PLANES_F16)
+    inv = d.__dict__['_swem_inv']
+    amax = float(dy.abs().max())
+    s_exp = 13 - int(np.floor(np.log2(amax)))
+    assert float(inv[0]) == 2.0 ** -s_exp, (float(inv[0]), s_exp)
+    # the planes ARE the pair of dy * 2^s: hi + mid reproduces it to 2^-22 of the element or 2^-25 absolute (scaled units)
+    rec = (d2[0].float() + d2[1].float()).view(cout // 8, B * Ho * Wo, 8).permute(1, 0, 2).reshape(B, Ho, Wo, cout)
+    want = d.float() * 2.0 ** s_exp
+    assert float(((rec - want).abs() - want.abs() * 2.0 ** -22).clamp_min(0).max()) <= 2.0 ** -25
+    args = []
+    for t in srcs:
+        sp = ops.presplit(t, case['relu_in'], ops.PLANES_F16)
+        args += [sp.data_ptr(), t.shape[3], 0 if (t.shape[0] == 1 and B > 1) else H_ * W_ * t.shape[3], sp.stride(0)]
+    cs = [t.shape[3] for t in srcs] + [0, 0]
+    for _ in range(3 - len(srcs)):
+        args += [0, 0, 0, 0]
+    for plan in (0, 1 | 3 << 4, 2 | 1 << 4, 2 | 2 << 4 | 1 << 12):
+        wsb = _lib.query('swem_conv2d_wgrad_bf16x3_workspace', B, H_, W_, cs[0], cs[1], cs[2], cout, k, k, s, pad, plan)
+        ws = ops.workspace(wsb, d.device)
+        dw = torch.full((cout, cin, k, k), 0.5 * gscale, device=DEV)
+        for acc in (0, 1):
+            _lib.call('swem_conv2d_wgrad_f16x3', ops._stream(), d2.data_ptr(), d2.stride(0), *args, B, H_, W_, cout, k, k, s, pad,
+                      inv.data_ptr(), dw.data_ptr(), cin, acc, plan, ws.data_ptr(), wsb)
+        close(dw.cpu().double() / 2, exact, 3e-5, 'dW f16x3 plan %#x' % plan)
+        err = float((dw.cpu().double() / 2 - exact).abs().max() / exact.abs().max())
+        assert err < 4e-6, err              # (fp32-level: bf16x6 measures 1-2e-6 on these shapes)
+    ops.check_faults()
+
+
+def test_scaled_gradient_planes_through_the_data_gradient_conv(lib):
+    """A gradient map marked by autograd (`_swem_grad`) that reaches an f16x3 data-gradient convolution is split into the SCALED
+    pair and the 2^-s goes into the epilogue scale on the device (ops.conv2d / swem_vec_scale_f32): dX against autograd in fp64
+    for gradients of 1e-7 and 1e4, with the input-ReLU mask, next to bf16x6 on the same data.  A non-finite gradient sets the
+    range fault."""
+    from swem_amd import autograd as A, ops
+    ops.check_faults()
+    A.new_step()
+    g = torch.Generator().manual_seed(17)
+    for gscale in (1.0, 1.0e-7, 1.0e4):
+        x = leaf(torch.randn(2, 64, 20, 28, generator=g))
+        w = leaf(torch.randn(96, 64, 3, 3, generator=g) * 0.05)
+        y = F.conv2d(F.relu(x.double()), w.double(), padding=1)
+        dy = torch.randn(*y.shape, generator=g) * gscale
+        gx_ref, gw_ref = torch.autograd.grad(y, (x, w), dy.double())
+        outs = {}
+        for modes in ((7,), (1,)):
+            with ops.use_book(ops.PlanBook()), ops.conv_math(modes):
+                A.new_step()
+                wp = param(w)
+                sx = nhwc(x.detach()).requires_grad_(True)
+                out = A.conv2d([sx], wp, None, stride=1, pad=1, relu_in=True)
+                out.backward(nhwc(dy))
+                outs[modes] = (back(sx.grad).double(), wp.grad.cpu().double())
+                ops.check_faults()
+        for modes, (gx, gw) in outs.items():
+            ex = float((gx - gx_ref).abs().max() / gx_ref.abs().max())
+            ew = float((gw - gw_ref).abs().max() / gw_ref.abs().max())
+            print('gradient scale %g, modes %s: dX rel err %.2e, dW %.2e' % (gscale, modes, ex, ew))
+            assert ex < 3e-6 and ew < 4e-6, (gscale, modes, ex, ew)
+    with ops.use_book(ops.PlanBook()), ops.conv_math((7,)):
+        A.new_step()
+        sx = nhwc(torch.randn(1, 64, 8, 8, generator=g)).requires_grad_(True)
+        out = A.conv2d([sx], param(torch.randn(64, 64, 3, 3, generator=g) * 0.05), None, stride=1, pad=1)
+        bad = torch.randn(*out.shape, generator=g)
+        bad[0, 3, 3, 3] = float('inf')
+        out.backward(bad.to(DEV))
+        with pytest.raises(ops.SwemRangeError):
+            ops.check_faults()
+
+
+def test_pack_filters_f16x2_kernel_equals_the_host_recipe(lib):
+    """swem_pack_filters_f16x2_f32 (the training step's per-step filter packs, one launch) against ConvPack.planes16's torch
+    recipe: the same planes and epilogue scales, bit for bit, wherever log2 does not round across a power of two."""
+    from swem_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for co, ci, k in ((64, 64, 3), (200, 96, 3), (128, 256, 1), (32, 32, 7)):
+        w = (torch.randn(co, ci, k, k, generator=g) * 0.03).to(DEV)
+        w[1] *= 1.0e-6
+        w[2] = 0.0
+        w[3] *= 300.0
+        bn = [t.to(DEV) for t in (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g), torch.randn(co, generator=g),
+                                  torch.rand(co, generator=g) + 0.5)]
+        a, b = ops.pack_conv(w, None, bn, 1, k // 2), ops.pack_conv(w, None, bn, 1, k // 2)
+        b.fast16 = True
+        (wa, sa), (wb, sb) = a.planes16(), b.planes16()
+        assert torch.equal(wa.view(torch.int16), wb.view(torch.int16)) and torch.equal(sa, sb), (co, ci, k)
 
 
 def test_amp_step_tracks_the_fp32_step(lib):
