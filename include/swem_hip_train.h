@@ -86,10 +86,13 @@ int swem_conv2d_wgrad_bf16x3(void *stream, const unsigned short *dy3, long long 
  *     multiplied by 2^-s in the reduce.  x planes: swem_split_f16x2_f32 of the forward activations (unscaled: |x| < 65520, faulted).
  * Powers of two: the scaling is exact.  The largest element lands in [2^13, 2^14); elements within 2^-15 of it keep >= 22 bits,
  * smaller ones carry an absolute error <= 2^-39 of the maximum.  scratch: SWEM_AMAX_PARTS + 1 floats of device memory, contents
- * irrelevant on entry (nothing to zero).  A non-finite element sets SWEM_FAULT_RANGE in `fault` (may be NULL) and leaves s = 0.
+ * irrelevant on entry (nothing to zero), nparts = 0.  nparts > 0: scratch[1 .. nparts] ALREADY hold block maxima of |x| that the
+ * map's producer wrote (swem_bn_act_bwd_amax_f32): the first pass is skipped, scratch is nparts + 1 floats.  A non-finite element
+ * sets SWEM_FAULT_RANGE in `fault` (may be NULL) and leaves s = 0.
  * plan / workspace of the weight gradient: as swem_conv2d_wgrad_bf16x3 (same workspace query). */
 #define SWEM_AMAX_PARTS 256
-int swem_split_f16x2_scaled_f32(void *stream, const float *x, void *out, long long npix, int C, float *scratch, void *fault);
+int swem_split_f16x2_scaled_f32(void *stream, const float *x, void *out, long long npix, int C, float *scratch, int nparts,
+                                void *fault);
 int swem_vec_scale_f32(void *stream, const float *in, const float *factor, float *out, int n);
 /* filters w [Cout][K] (K % 8 == 0, K in the pre-split kernel's order) -> the fp16 pair planes [2][K/8][Cout][8] of the f16x3
  * arithmetic, each filter scaled by its own power of two (largest weight in [2^13, 2^14): swem_hip.h, "f16x3"), and
@@ -125,6 +128,18 @@ size_t swem_bn_act_bwd_workspace(long long M, int C);
 int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y, const float *c, const float *alpha,
                         const float *mean, const float *invstd, float *dz, float *dc, float *dgamma, float *dbeta,
                         long long M, int C, int relu, void *planes, void *ws, size_t ws_bytes);
+/* ... for consumers on the f16x3 arithmetic (round 5).  swem_bn_act_planes_f32: the forward stage with the format of the planes
+ * given -- nplanes = 3 (bf16, as above) or SWEM_PLANES_F16 (the fp16 (hi, mid) pair [2][C/8][M][8], exactly swem_split_f16x2_f32's;
+ * `fault`: SWEM_FAULT_RANGE when an output leaves the fp16 range, may be NULL).  swem_bn_act_bwd_amax_f32: the backward stage, no
+ * planes, but one float per block -- the largest |dc| the block wrote -- into amax_parts[0 .. swem_bn_act_bwd_amax_parts(M, C)):
+ * the first pass of swem_split_f16x2_scaled_f32 for the gradient map dc (pass it scratch with scratch + 1 = amax_parts and
+ * nparts = that count). */
+int swem_bn_act_planes_f32(void *stream, const float *c, const float *alpha, const float *shift, const float *res, float *y,
+                           long long M, int C, int relu, void *planes, int nplanes, void *fault);
+int swem_bn_act_bwd_amax_parts(long long M, int C);
+int swem_bn_act_bwd_amax_f32(void *stream, const float *dy, const float *y, const float *c, const float *alpha,
+                             const float *mean, const float *invstd, float *dz, float *dc, float *dgamma, float *dbeta,
+                             long long M, int C, int relu, float *amax_parts, void *ws, size_t ws_bytes);
 /* backward of swem_cbam_f32 (y = x + CBAM(x), attentions.py:22-84): dx [B][H][W][C]; the gradients of the six
  * parameters (mlp.1 / mlp.3 weight+bias, spatial conv weight [1][2][7][7] + bias) are ACCUMULATED.  Ties of the two
  * max-pools send the gradient to the first maximum. */

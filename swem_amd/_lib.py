@@ -89,13 +89,16 @@ SIGNATURES = {
     'swem_conv2d_wgrad_bf16x3_workspace': (_sz, [_i] * 12),
     'swem_conv2d_wgrad_bf16x3': (_i, [_p, _p, _ll] + [_p, _i, _ll, _ll] * 3 + [_i] * 9 + [_p, _i, _i, _i, _p, _sz]),
     'swem_conv2d_wgrad_f16x3': (_i, [_p, _p, _ll] + [_p, _i, _ll, _ll] * 3 + [_i] * 8 + [_p, _p, _i, _i, _i, _p, _sz]),
-    'swem_split_f16x2_scaled_f32': (_i, [_p, _p, _p, _ll, _i, _p, _p]),
+    'swem_split_f16x2_scaled_f32': (_i, [_p, _p, _p, _ll, _i, _p, _i, _p]),
     'swem_vec_scale_f32': (_i, [_p, _p, _p, _p, _i]),
     'swem_pack_filters_f16x2_f32': (_i, [_p, _p, _p, _i, _i, _p, _p]),
     'swem_colsum_workspace': (_sz, [_ll, _i]),
     'swem_colsum_f32': (_i, [_p, _p, _p, _p, _p, _ll, _i, _i, _p, _sz]),
     'swem_sum_batch_f32': (_i, [_p, _p, _p, _i, _ll, _i]),
     'swem_bn_act_f32': (_i, [_p, _p, _p, _p, _p, _p, _ll, _i, _i, _p]),
+    'swem_bn_act_planes_f32': (_i, [_p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _i, _p]),
+    'swem_bn_act_bwd_amax_parts': (_i, [_ll, _i]),
+    'swem_bn_act_bwd_amax_f32': (_i, [_p] * 11 + [_ll, _i, _i, _p, _p, _sz]),
     'swem_bn_act_bwd_workspace': (_sz, [_ll, _i]),
     'swem_bn_act_bwd_f32': (_i, [_p] * 11 + [_ll, _i, _i, _p, _p, _sz]),
     'swem_cbam_bwd_workspace': (_sz, [_i, _i, _i, _i]),

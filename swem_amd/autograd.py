@@ -155,8 +155,8 @@ def wgrad_math(cs, cout, kh, kw, M):
         return 2 if (kh * kw > 1 or (big and M >= 2048)) else 0
     if 7 in ops.CONV_MATH_MODES and ops._PLAN_TAG:
         # fp32-level training on the f16x3 arithmetic (round 5): the plane kernel with fp16 pairs, dY scaled (three products
-        # instead of bf16x6's six; the same layers the one-product kernel is not slower on)
-        return 3 if (kh * kw > 1 or (big and M >= 2048)) else 0
+        # instead of bf16x6's six)
+        return 3                   # (every layer: faster than the fp32-MFMA kernel on all training shapes, tools/wgrad_bench.py)
     return 1 if (big and kh * kw > 1 and 1 in ops.CONV_MATH_MODES) else 0
 
 
@@ -266,8 +266,9 @@ class _BNAct(Function):
         fold = _shared_pack((id(gamma), 'bnfold', eps), build)     # once per step, shared by the frames and the lanes
         y = torch.empty_like(c)
         planes = _planes_for((id(gamma), 'y'), y, M, Cc)
-        _lib.call('swem_bn_act_f32', ops._stream(), c.data_ptr(), fold[0].data_ptr(), fold[1].data_ptr(), ops._ptr(res),
-                  y.data_ptr(), M, Cc, int(relu), ops._ptr(planes))
+        npl = ops.PLANES_F16 if (planes is not None and planes.dtype == torch.float16) else 3
+        _lib.call('swem_bn_act_planes_f32', ops._stream(), c.data_ptr(), fold[0].data_ptr(), fold[1].data_ptr(), ops._ptr(res),
+                  y.data_ptr(), M, Cc, int(relu), ops._ptr(planes), npl, ops._fault_ptr(c.device))
         ctx.save_for_backward(c, y, fold, gamma, beta, mean)     # (saved_tensors keeps the output without a cycle)
         ctx.flags = (relu, res is not None)
         return y
@@ -284,7 +285,20 @@ class _BNAct(Function):
         want = gamma.requires_grad or beta.requires_grad
         wsb = _lib.query('swem_bn_act_bwd_workspace', M, Cc) if want else 0
         ws = _ws(wsb, c.device) if want else None
-        planes = _planes_for((id(gamma), 'dc'), dc, M, Cc)
+        site = (id(gamma), 'dc')
+        if Cc % 8 == 0 and ops.BOOK.hints.get(site, {}).get(False, 0) == ops.PLANES_F16:
+            # the convolution behind this stage back-propagates in f16x3: it wants the SCALED fp16 pair of dc, whose first pass
+            # (the map's largest magnitude) this kernel delivers as block maxima (ops.presplit, `_swem_amax`)
+            nparts = _lib.query('swem_bn_act_bwd_amax_parts', M, Cc)
+            scratch = torch.empty(nparts + 1, dtype=torch.float32, device=c.device)
+            dc.__dict__['_swem_site'] = site
+            dc.__dict__['_swem_amax'] = (scratch, nparts)
+            _lib.call('swem_bn_act_bwd_amax_f32', ops._stream(), dy.data_ptr(), y.data_ptr(), c.data_ptr(), fold[0].data_ptr(),
+                      mean.data_ptr(), fold[2].data_ptr(), ops._ptr(dz), dc.data_ptr(),
+                      _grad(gamma).data_ptr() if gamma.requires_grad else 0, _grad(beta).data_ptr() if beta.requires_grad else 0,
+                      M, Cc, int(relu), scratch[1:].data_ptr(), ops._ptr(ws), wsb)
+            return dc, None, None, None, None, (dz if has_res else None), None, None
+        planes = _planes_for(site, dc, M, Cc)
         _lib.call('swem_bn_act_bwd_f32', ops._stream(), dy.data_ptr(), y.data_ptr(), c.data_ptr(), fold[0].data_ptr(),
                   mean.data_ptr(), fold[2].data_ptr(), ops._ptr(dz), dc.data_ptr(),
                   _grad(gamma).data_ptr() if gamma.requires_grad else 0, _grad(beta).data_ptr() if beta.requires_grad else 0,
@@ -296,7 +310,16 @@ def _planes_for(site, t, M, Cc):
     """The bf16 planes of a stage's output, written by the stage itself when an earlier step saw a convolution split this
     output (ops.SPLIT_HINTS): attached to the tensor where ops.presplit looks for them.  Otherwise the tensor is tagged
     with its producer so that a later split records the hint."""
-    if Cc % 8 == 0 and ops.BOOK.hints.get(site, {}).get(False, 0) in (1, 2, 3):      # (bf16 planes; an fp16-pair consumer splits itself)
+    want = ops.BOOK.hints.get(site, {}).get(False, 0) if Cc % 8 == 0 else 0
+    if want == ops.PLANES_F16 and site[1] == 'y':
+        # (forward maps only: the fp16 pair of a GRADIENT map is scaled by its maximum, which its producer cannot know while it
+        # writes -- _BNAct.backward hands the consumer the block maxima instead)
+        planes = torch.empty((2, M * Cc), dtype=torch.float16, device=t.device)
+        t.__dict__['_swem_split'] = {ops._pkey(False, ops.PLANES_F16): (planes, ops.PLANES_F16)}
+        t.__dict__['_swem_split_ver'] = t._version
+        t.__dict__['_swem_site'] = site
+        return planes
+    if want in (1, 2, 3):
         planes = torch.empty((3, M * Cc), dtype=torch.bfloat16, device=t.device)
         t.__dict__['_swem_split'] = {False: (planes, 3)}
         return planes

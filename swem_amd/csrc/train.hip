@@ -401,11 +401,18 @@ __device__ __forceinline__ void lerp_span(int s, float scale, int out, int &d0, 
 // backward: this layer's data / weight gradient -- finds its operand split already (one launch and one read of the
 // fp32 map less per BatchNorm call).  A thread owns 4 consecutive channels of one row = half a 16-byte cell.
 __device__ __forceinline__ void store_planes4(unsigned short *__restrict__ planes, long long M, int C, long long m, int c,
-                                              float4 v) {
-  uint2 h, md, l;
-  split3(v, h, md, l);
+                                              float4 v, bool f16 = false) {
   const long long cell = ((long long)(c >> 3) * M + m) * 8 + (c & 4);
   const long long plane = M * C;
+  if (f16) {   // the fp16 (hi, mid) pair of the f16x3 arithmetic (SWEM_PLANES_F16; the caller tests the range)
+    uint2 h, md;
+    split2h(v, h, md);
+    *reinterpret_cast<uint2 *>(planes + cell) = h;
+    *reinterpret_cast<uint2 *>(planes + plane + cell) = md;
+    return;
+  }
+  uint2 h, md, l;
+  split3(v, h, md, l);
   *reinterpret_cast<uint2 *>(planes + cell) = h;
   *reinterpret_cast<uint2 *>(planes + plane + cell) = md;
   *reinterpret_cast<uint2 *>(planes + 2 * plane + cell) = l;
@@ -413,10 +420,13 @@ __device__ __forceinline__ void store_planes4(unsigned short *__restrict__ plane
 __global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ c, const float *__restrict__ alpha,
                                                      const float *__restrict__ shift, const float *__restrict__ res,
                                                      float *__restrict__ y, long long M, int C, int relu,
-                                                     unsigned short *__restrict__ planes) {
+                                                     unsigned short *__restrict__ planes, int planes_f16, unsigned *fault) {
   const int cq = C / 4;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= M * cq) return;
+  if (i >= M * cq) {
+    if (planes && planes_f16) range_fault(fault, 0u);   // (the ballot inside wants the whole wave)
+    return;
+  }
   const int c4 = (int)(i % cq);
   const float4 v = ld4t(c + i * 4), a = ld4t(alpha + c4 * 4), s = ld4t(shift + c4 * 4);
   float4 o = make_float4(v.x * a.x + s.x, v.y * a.y + s.y, v.z * a.z + s.z, v.w * a.w + s.w);
@@ -426,7 +436,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ c
   }
   if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
   st4t(y + i * 4, o);
-  if (planes) store_planes4(planes, M, C, i / cq, c4 * 4, o);
+  if (planes) {
+    store_planes4(planes, M, C, i / cq, c4 * 4, o, planes_f16 != 0);
+    if (planes_f16) range_fault(fault, f16_oor(o));
+  }
 }
 // Backward of bn_act in one pass: dz = dy * (y > 0) (also the residual's gradient), dc = dz * alpha (the conv output's
 // gradient), and per block the column partials s1 = sum dz, s2 = sum dz * c for the BatchNorm parameters.
@@ -443,8 +456,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict
                                                          const float *__restrict__ c, const float *__restrict__ alpha,
                                                          float *__restrict__ dz, float *__restrict__ dc,
                                                          float *__restrict__ part, long long M, int C, int relu,
-                                                         int BN_ROWS, unsigned short *__restrict__ planes) {
+                                                         int BN_ROWS, unsigned short *__restrict__ planes,
+                                                         float *__restrict__ amax_parts) {
+  // amax_parts (optional): one float per block, the largest |dc| the block wrote -- the first pass of the scaled fp16 split of
+  // this gradient map (swem_split_f16x2_scaled_f32 with nparts = the block count), for free
   __shared__ float4 sh1[256], sh2[256];
+  unsigned amax = 0;
   const int cq = C / 4;
   const int c4 = blockIdx.x * 16 + (threadIdx.x & 15);
   const int rsub = threadIdx.x >> 4;
@@ -464,12 +481,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict
       const float4 gc = make_float4(g.x * a.x, g.y * a.y, g.z * a.z, g.w * a.w);
       st4t(dc + i, gc);
       if (planes) store_planes4(planes, M, C, m, c4 * 4, gc);
+      amax = max(max(amax, __float_as_uint(gc.x) & 0x7fffffffu), max(__float_as_uint(gc.y) & 0x7fffffffu, __float_as_uint(gc.z) & 0x7fffffffu));
+      amax = max(amax, __float_as_uint(gc.w) & 0x7fffffffu);
       if (part) {
         const float4 v = ld4t(c + i);
         s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
         s2.x += g.x * v.x; s2.y += g.y * v.y; s2.z += g.z * v.z; s2.w += g.w * v.w;
       }
     }
+  }
+  if (amax_parts) {   // (uniform branch: every thread of the block takes it)
+    __shared__ unsigned sha[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o));
+    if ((threadIdx.x & 63) == 0) sha[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      amax_parts[blockIdx.y * gridDim.x + blockIdx.x] = __uint_as_float(max(max(sha[0], sha[1]), max(sha[2], sha[3])));
   }
   if (!part) return;
   sh1[threadIdx.x] = s1;
@@ -813,23 +841,49 @@ __global__ __launch_bounds__(256) void prep_value_bwd_kernel(const float *__rest
 
 #define STT static_cast<hipStream_t>(stream)
 
-extern "C" int swem_bn_act_f32(void *stream, const float *c, const float *alpha, const float *shift, const float *res,
-                               float *y, long long M, int C, int relu, void *planes) {
+extern "C" int swem_bn_act_planes_f32(void *stream, const float *c, const float *alpha, const float *shift, const float *res,
+                                      float *y, long long M, int C, int relu, void *planes, int nplanes, void *fault) {
   SWEM_REQUIRE(c && alpha && shift && y && C % 4 == 0 && M > 0, SWEM_E_ARG, "bn_act: bad argument");
-  SWEM_REQUIRE(!planes || C % 8 == 0, SWEM_E_SHAPE, "bn_act: the bf16 planes need C %% 8 == 0");
+  SWEM_REQUIRE(!planes || C % 8 == 0, SWEM_E_SHAPE, "bn_act: the operand planes need C %% 8 == 0");
+  SWEM_REQUIRE(!planes || nplanes == 3 || nplanes == SWEM_PLANES_F16, SWEM_E_ARG, "bn_act: three bf16 planes or SWEM_PLANES_F16");
   hipLaunchKernelGGL(bn_act_kernel, grid1t(M * (C / 4)), dim3(256), 0, STT, c, alpha, shift, res, y, M, C, relu,
-                     static_cast<unsigned short *>(planes));
+                     static_cast<unsigned short *>(planes), nplanes == SWEM_PLANES_F16 ? 1 : 0, static_cast<unsigned *>(fault));
   SWEM_CHECK_LAUNCH("bn_act_kernel");
   return SWEM_OK;
+}
+extern "C" int swem_bn_act_f32(void *stream, const float *c, const float *alpha, const float *shift, const float *res,
+                               float *y, long long M, int C, int relu, void *planes) {
+  return swem_bn_act_planes_f32(stream, c, alpha, shift, res, y, M, C, relu, planes, 3, nullptr);
 }
 extern "C" size_t swem_bn_act_bwd_workspace(long long M, int C) {
   if (M <= 0 || C <= 0) return 0;
   return (size_t)cdiv(M, bn_rows(M, C)) * 2 * C * sizeof(float);
 }
+extern "C" int swem_bn_act_bwd_amax_parts(long long M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  return cdiv(C / 4, 16) * cdiv(M, bn_rows(M, C));
+}
+static int bn_act_bwd_impl(void *stream, const float *dy, const float *y, const float *c, const float *alpha,
+                           const float *mean, const float *invstd, float *dz, float *dc, float *dgamma,
+                           float *dbeta, long long M, int C, int relu, void *planes, void *ws,
+                           size_t ws_bytes, float *amax_parts);
 extern "C" int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y, const float *c, const float *alpha,
                                    const float *mean, const float *invstd, float *dz, float *dc, float *dgamma,
                                    float *dbeta, long long M, int C, int relu, void *planes, void *ws,
                                    size_t ws_bytes) {
+  return bn_act_bwd_impl(stream, dy, y, c, alpha, mean, invstd, dz, dc, dgamma, dbeta, M, C, relu, planes, ws, ws_bytes, nullptr);
+}
+extern "C" int swem_bn_act_bwd_amax_f32(void *stream, const float *dy, const float *y, const float *c, const float *alpha,
+                                        const float *mean, const float *invstd, float *dz, float *dc, float *dgamma,
+                                        float *dbeta, long long M, int C, int relu, float *amax_parts, void *ws,
+                                        size_t ws_bytes) {
+  SWEM_REQUIRE(amax_parts, SWEM_E_ARG, "bn_act_bwd_amax: null amax_parts");
+  return bn_act_bwd_impl(stream, dy, y, c, alpha, mean, invstd, dz, dc, dgamma, dbeta, M, C, relu, nullptr, ws, ws_bytes, amax_parts);
+}
+static int bn_act_bwd_impl(void *stream, const float *dy, const float *y, const float *c, const float *alpha,
+                           const float *mean, const float *invstd, float *dz, float *dc, float *dgamma,
+                           float *dbeta, long long M, int C, int relu, void *planes, void *ws,
+                           size_t ws_bytes, float *amax_parts) {
   SWEM_REQUIRE(dy && alpha && dc && (y || !relu) && C % 4 == 0 && M > 0, SWEM_E_ARG, "bn_act_bwd: bad argument");
   SWEM_REQUIRE(!planes || C % 8 == 0, SWEM_E_SHAPE, "bn_act_bwd: the bf16 planes need C %% 8 == 0");
   const bool params = dgamma || dbeta;
@@ -842,7 +896,7 @@ extern "C" int swem_bn_act_bwd_f32(void *stream, const float *dy, const float *y
     part = static_cast<float *>(ws);
   }
   hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(cdiv(C / 4, 16), nrow), dim3(256), 0, STT, dy, y, c, alpha, dz, dc, part, M,
-                     C, relu, rows, static_cast<unsigned short *>(planes));
+                     C, relu, rows, static_cast<unsigned short *>(planes), amax_parts);
   SWEM_CHECK_LAUNCH("bn_act_bwd_kernel");
   if (params) {
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 16)), dim3(256), 0, STT, part, nrow, mean, invstd, dgamma,

@@ -461,7 +461,12 @@ static WgradPlan wgrad_pick(long long M, int Cout, int KH, int KW, int c0, int c
   const int zforce = (plan >> 4) & 255;
   long long zs = zforce > 0 ? zforce : (512 + tiles - 1) / (tiles > 0 ? tiles : 1);
   const long long zmax = (M + 127) / 128;
-  if (zs > 16 && zforce == 0) zs = 16;
+  // pixel slices: enough blocks to fill the chip (~512); at most 16 -- or 64 where the partial sums stay small (<= 8 MB: the
+  // 64-channel and 1x1 layers, whose 4-36 tiles left three quarters of the CUs idle at 16 slices: tools/wgrad_bench.py --tune,
+  // round 5: 57.6 -> 33.9 us on 3x96x96 1x1 64->256)
+  const long long by_bytes = (long long)(8.0 * 1024 * 1024 / ((double)Cout * KH * KW * (c0 + c1 + c2) * 4.0));
+  const long long zcap = by_bytes > 64 ? 64 : (by_bytes < 16 ? 16 : by_bytes);
+  if (zs > zcap && zforce == 0) zs = zcap;
   if (zs > zmax) zs = zmax;
   if (zs < 1) zs = 1;
   long long per = ((M + zs - 1) / zs + 31) / 32 * 32;
@@ -610,7 +615,7 @@ static int wgrad_planes_impl(void *stream, const unsigned short *dy3, long long 
     int rc;
     // slab: 16 pixels for the six-product 128x128 tile (48 KB of LDS instead of 96: three blocks per CU), else 32;
     // plan bit 12 flips the choice (tools/wgrad_bench.py)
-    const bool ks16 = ((pl.wt == 2 && math == 1) != (((plan >> 12) & 1) != 0));
+    const bool ks16 = ((pl.wt == 2 && (math == 1 || math == 3)) != (((plan >> 12) & 1) != 0));   // (f16x3: measured like bf16x6)
     if (math == 3) {
       if (pl.wt == 2) rc = ks16 ? launch_wgrad_bf<2, 2, 16, true>(p, grid, st) : launch_wgrad_bf<2, 2, 32, true>(p, grid, st);
       else rc = ks16 ? launch_wgrad_bf<1, 2, 16, true>(p, grid, st) : launch_wgrad_bf<1, 2, 32, true>(p, grid, st);
@@ -674,9 +679,10 @@ __global__ __launch_bounds__(256) void amax_partials_kernel(const float4 *__rest
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = __uint_as_float(max(max(sh[0], sh[1]), max(sh[2], sh[3])));
 }
-__device__ __forceinline__ int grad_scale_exp(const float *part, unsigned *fault) {
-  // (block-wide: every thread returns s; blockDim = 256 >= SWEM_AMAX_PARTS)
-  unsigned m = threadIdx.x < SWEM_AMAX_PARTS ? __float_as_uint(part[threadIdx.x]) : 0u;
+__device__ __forceinline__ int grad_scale_exp(const float *part, int nparts, unsigned *fault) {
+  // (block-wide: every thread returns s)
+  unsigned m = 0u;
+  for (int i = threadIdx.x; i < nparts; i += 256) m = max(m, __float_as_uint(part[i]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
   __shared__ unsigned sh[4];
@@ -694,8 +700,8 @@ __device__ __forceinline__ int grad_scale_exp(const float *part, unsigned *fault
 }
 __global__ __launch_bounds__(256) void split_f16x2_scaled_kernel(const float *__restrict__ x, unsigned short *__restrict__ out,
                                                                  long long npix, int C, const float *__restrict__ part,
-                                                                 float *__restrict__ inv_out, unsigned *fault) {
-  const int s = grad_scale_exp(part, fault);
+                                                                 int nparts, float *__restrict__ inv_out, unsigned *fault) {
+  const int s = grad_scale_exp(part, nparts, fault);
   const float scale = __uint_as_float((unsigned)(s + 127) << 23);
   if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) *inv_out = __uint_as_float((unsigned)(127 - s) << 23);
   const long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
@@ -720,14 +726,18 @@ __global__ __launch_bounds__(256) void vec_scale_kernel(const float *__restrict_
 }  // namespace
 
 extern "C" int swem_split_f16x2_scaled_f32(void *stream, const float *x, void *out, long long npix, int C, float *scratch,
-                                           void *fault) {
-  SWEM_REQUIRE(x && out && scratch && npix > 0 && C > 0 && C % 8 == 0, SWEM_E_ARG, "split_f16x2_scaled: need C %% 8 == 0");
+                                           int nparts, void *fault) {
+  SWEM_REQUIRE(x && out && scratch && npix > 0 && C > 0 && C % 8 == 0 && nparts >= 0, SWEM_E_ARG,
+               "split_f16x2_scaled: need C %% 8 == 0");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(amax_partials_kernel, dim3(SWEM_AMAX_PARTS), dim3(256), 0, st, reinterpret_cast<const float4 *>(x),
-                     npix * C / 4, scratch + 1);
-  SWEM_CHECK_LAUNCH("amax_partials_kernel");
+  if (nparts == 0) {   // no producer-made maxima: the first pass here
+    nparts = SWEM_AMAX_PARTS;
+    hipLaunchKernelGGL(amax_partials_kernel, dim3(SWEM_AMAX_PARTS), dim3(256), 0, st, reinterpret_cast<const float4 *>(x),
+                       npix * C / 4, scratch + 1);
+    SWEM_CHECK_LAUNCH("amax_partials_kernel");
+  }
   hipLaunchKernelGGL(split_f16x2_scaled_kernel, dim3((unsigned)cdiv(npix, 32), (unsigned)cdiv(C / 8, 8)), dim3(256), 0, st, x,
-                     static_cast<unsigned short *>(out), npix, C, scratch + 1, scratch, static_cast<unsigned *>(fault));
+                     static_cast<unsigned short *>(out), npix, C, scratch + 1, nparts, scratch, static_cast<unsigned *>(fault));
   SWEM_CHECK_LAUNCH("split_f16x2_scaled_kernel");
   return SWEM_OK;
 }

@@ -671,8 +671,9 @@ def presplit(t, relu=False, nplanes=3):
             if relu:
                 raise _lib.SwemHipError('presplit: a gradient map has no input ReLU')
             sp = torch.empty((2, npix * Cc), dtype=torch.float16, device=t.device)
-            scratch = torch.empty(AMAX_PARTS + 1, dtype=torch.float32, device=t.device)
-            _lib.call('swem_split_f16x2_scaled_f32', _stream(), t.data_ptr(), sp.data_ptr(), npix, Cc, scratch.data_ptr(),
+            have = t.__dict__.get('_swem_amax')        # (scratch, nparts): block maxima the map's producer wrote (autograd._BNAct)
+            scratch, nparts = have if have is not None else (torch.empty(AMAX_PARTS + 1, dtype=torch.float32, device=t.device), 0)
+            _lib.call('swem_split_f16x2_scaled_f32', _stream(), t.data_ptr(), sp.data_ptr(), npix, Cc, scratch.data_ptr(), nparts,
                       _fault_ptr(t.device))
             t.__dict__['_swem_inv'] = scratch
             ent = cache[key] = (sp, PLANES_F16)

@@ -219,6 +219,46 @@ def test_bn_stages_write_the_operand_planes(lib):
     A.reset()
 
 
+def test_bn_stages_serve_an_f16x3_consumer(lib):
+    """The same for a consumer on the f16x3 arithmetic (round 5): the forward stage writes the fp16 (hi, mid) pair of y -- bit
+    for bit swem_split_f16x2_f32's -- and the backward stage hands the consumer of dc the block maxima of |dc|, from which the
+    scaled split (swem_split_f16x2_scaled_f32, first pass skipped) makes the SAME planes and the same 2^-s as with its own pass."""
+    from swem_amd import autograd as A, ops
+    A.reset()
+    g = torch.Generator().manual_seed(12)
+    B, Cc, H, W = 2, 64, 9, 13
+    mean, var = torch.randn(Cc, generator=g).to(DEV), (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+    gp, bp = param(torch.rand(Cc, generator=g) + 0.5), param(torch.randn(Cc, generator=g))
+    c = nhwc(torch.randn(B, Cc, H, W, generator=g))
+    dy = nhwc(torch.randn(B, Cc, H, W, generator=g) * 3.0e-5)
+
+    def run():
+        A.new_step()
+        cx = c.clone().requires_grad_(True)
+        y = A.bn_act(cx, (gp, bp, mean, var), relu=True)
+        hinted = '_swem_split' in y.__dict__
+        py = ops.presplit(y, False, ops.PLANES_F16).clone()
+        seen = {}
+
+        def hook(gr):
+            gr.__dict__['_swem_grad'] = True                       # (what _Conv.backward does with the gradient it is handed)
+            have = '_swem_amax' in gr.__dict__
+            pl = ops.presplit(gr, False, ops.PLANES_F16).clone()
+            seen['dc'] = (gr.clone(), have, pl, float(gr.__dict__['_swem_inv'][0]))
+        cx.register_hook(hook)
+        y.backward(dy)
+        return hinted, py, seen['dc']
+    h0, py0, (dc0, hd0, pd0, inv0) = run()
+    assert not h0 and not hd0
+    h1, py1, (dc1, hd1, pd1, inv1) = run()
+    assert h1 and hd1, 'the stages did not serve the fp16 consumer'
+    assert torch.equal(py0.view(torch.int16), py1.view(torch.int16)) and torch.equal(dc0, dc1)
+    assert inv0 == inv1 and 2.0 ** -14 < float(dc0.abs().max()) / inv0 <= 2.0 ** 14 and float(dc0.abs().max()) / inv0 >= 2.0 ** 13
+    assert torch.equal(pd0.view(torch.int16), pd1.view(torch.int16))
+    ops.check_faults()
+    A.reset()
+
+
 def test_maxpool_upsample_glu_backward(lib):
     from swem_amd import autograd as A
     g = torch.Generator().manual_seed(9)

@@ -11,11 +11,12 @@ SHAPES = [  # B, H, W, Cin, Cout, k, stride
     (2, 96, 96, 256, 256, 3, 1), (2, 48, 48, 512, 256, 3, 1), (2, 24, 24, 512, 512, 3, 1), (2, 24, 24, 1280, 512, 3, 1),
     (2, 24, 24, 1152, 512, 3, 1), (1, 24, 24, 1024, 256, 1, 1), (1, 24, 24, 256, 256, 3, 1), (1, 96, 96, 64, 64, 3, 1),
     (2, 96, 96, 64, 64, 3, 1), (1, 48, 48, 128, 128, 3, 1), (1, 96, 96, 64, 256, 1, 1), (2, 48, 48, 256, 512, 3, 2), (2, 25, 23, 72, 40, 3, 1),
-    (2, 96, 96, 256, 64, 1, 1), (1, 192, 192, 64, 64, 3, 1),
+    (2, 96, 96, 256, 64, 1, 1), (1, 192, 192, 64, 64, 3, 1), (3, 96, 96, 64, 256, 1, 1), (3, 96, 96, 256, 64, 1, 1),
+    (3, 48, 48, 128, 512, 1, 1), (3, 48, 48, 512, 128, 1, 1), (3, 24, 24, 256, 1024, 1, 1), (2, 24, 24, 1024, 256, 1, 1), (3, 96, 96, 64, 64, 1, 1),
 ]
 
 
-PLANS = ([0, 1 << 12] + [wt | z << 4 | f << 12 for wt in (1, 2) for z in (1, 2, 4, 8, 16) for f in (0, 1)]) if '--tune' in sys.argv else [0]
+PLANS = ([0, 1 << 12] + [wt | z << 4 | f << 12 for wt in (1, 2) for z in (1, 2, 4, 8, 16, 32, 64, 128) for f in (0, 1)]) if '--tune' in sys.argv else [0]
 
 
 def main():
@@ -65,6 +66,24 @@ def main():
                         best = (t, plan, err)
                 line += ' %s %7.1f us %6.1f TF plan %#x err %.1e |' % ('bf16x6' if math == 1 else 'bf16', best[0],
                                                                        fl / best[0] / 1e6, best[1], best[2])
+            # f16x3 (round 5): fp16 pairs, dY scaled on the device (swem_split_f16x2_scaled_f32), three products
+            dy.__dict__['_swem_grad'] = True
+            x2, d2 = ops.presplit(x, False, ops.PLANES_F16), ops.presplit(dy, False, ops.PLANES_F16)
+            inv = dy.__dict__['_swem_inv']
+            best = None
+            for plan in PLANS:
+                wsb2 = _lib.query('swem_conv2d_wgrad_bf16x3_workspace', B, H, W, ci, 0, 0, co, k, k, s, pad, plan)
+                ws2 = ops.workspace(wsb2, x.device)
+
+                def runh():
+                    _lib.call('swem_conv2d_wgrad_f16x3', ops._stream(), d2.data_ptr(), d2.stride(0), x2.data_ptr(), ci,
+                              H * W * ci, x2.stride(0), 0, 0, 0, 0, 0, 0, 0, 0, B, H, W, co, k, k, s, pad, inv.data_ptr(),
+                              dw.data_ptr(), ci, 0, plan, ws2.data_ptr(), wsb2)
+                t = timed(runh)
+                err = float((dw - ref).abs().max() / ref.abs().max())
+                if best is None or t < best[0]:
+                    best = (t, plan, err)
+            line += ' f16x3 %7.1f us %6.1f TF plan %#x err %.1e |' % (best[0], fl / best[0] / 1e6, best[1], best[2])
         print(line, flush=True)
 
 
