@@ -136,7 +136,13 @@ int swem_split_f16x2_f32(void *stream, const float *x, void *out, long long npix
  * v_mfma_f32_16x16x32_bf16 instead of 32x32x16, 8 / 9 = the 128x128 tile on four waves with 16-k blocks and two / three stages
  * (half the LDS per stage: three / two blocks per CU instead of one); bits 24-27 = K-split factor of the last, partly filled round of tiles; bits 28-29 = log2 of the XCD partition of the
  * N tiles (1-3: 2 / 4 / 8 groups of N tiles, 8/groups XCDs per group, each XCD reading only its group's filters; 0: chosen
- * by the traffic model groups * activations + (8 / groups) * filters; ignored where the N tiles do not divide). */
+ * by the traffic model groups * activations + (8 / groups) * filters; ignored where the N tiles do not divide).
+ * Plan tile wm = wn = 4 (f16x3 plans only: math 3 + SWEM_PLAN_F16; no per-batch filters, bits 24-27 = 0): the 256-COLUMN tiles of
+ * conv_t256_kernel (round 5) -- eight waves, ONE block per CU, 128 KB of LDS, the next k-block's transfers requested a whole
+ * k-block before anything waits for them, fragments read one step ahead of their MFMAs.  Bits 20-23 then give the tile HEIGHT:
+ * 0 = 256 rows (wave grid 2 x 4; the only form with SWEM_CONV_GLU), 4 / 5 / 6 / 7 = 128 / 160 / 192 / 224 rows (wave grid 1 x 8),
+ * chosen so that the tiles x K-split fill the chip's 256 CUs about once.  Same k order and products as the other tiles: without a
+ * K-split the result is bit-identical to theirs.  swem_conv2d_workspace sizes the K-split workspace for the height given. */
 int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1, int c1,
                             long long bs1, long long ps1, const void *x2, int c2, long long bs2, long long ps2, int B,
                             int H, int W, const void *w_bf16x3, const float *scale, const float *shift,

@@ -1712,6 +1712,364 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// "t256" (round 5): the f16x3 convolution on a 256 x 256 tile, eight waves, ONE block per CU.
+// The kernel above is the "128x128 tile, one hand-over per k-block" structure, whose ceiling on this chip is ~900 TFLOP/s of
+// MFMA work (cdna_hip_programming.md, "The step-3 structure's ~900 TF ceiling"; this library's f16x3 layers run at 3 x 290-370
+// = 870-1100): every k-block a wave requests the next transfers, reads 12 fragments, waits, meets the block at a barrier and
+// only then starts 24 MFMAs -- what hides that sequence is the CU's OTHER resident block.  The structure that gets past it keeps
+// ONE block per CU busy by itself: a wave tile of 128 x 64 (4 MFMAs per fragment read instead of 2), the transfers of k-block
+// kb + 1 requested a full k-block (96 MFMAs per wave, ~3k cycles per SIMD) before anything waits for them, and the fragments of
+// the next quarter of the wave tile read from the LDS while the MFMAs of the current quarter run (two fragment register sets).
+//   per k-block (32 k = one filter tap x 32 channels, hi + mid planes; stage = kb & 1, 64 KB per stage) eight steps over the
+//   eighths (32 rows x 32 columns) of the wave tile in snake order -- consecutive eighths share their A pair or their B pair:
+//     steps 0, 1: request the transfers of k-block kb + 1 into the other stage (eight 1 KB transfers per wave);
+//     every step: read the ONE new fragment pair of the next step (four ds_read_b128), then the twelve MFMAs of this step
+//                 on fragments read one step earlier (two A and two B register pairs, double-buffered: 64 registers);
+//     step 7:     vmcnt(0) (requested six steps ago), lgkmcnt(0), ONE s_barrier -- it publishes k-block kb + 1's stage and
+//                 releases this one for the transfers of kb + 2 -- read the first pairs of k-block kb + 1; MFMAs of step 7
+// Same k order, same three products per (A, B) fragment pair, same epilogue (conv_epilogue16) as the kernel above; the
+// accumulation order over k is the same, so the results are bit-identical to it.  LDS image per operand and stage:
+// [plane][k/8 group][256 rows][16 bytes] (fragment reads conflict-free as above: the group stride is a multiple of 16 slots).
+// Each wave transfers ONE 64-row run (run = wave & 3, plane = wave >> 2) of every k/8 group of both operands: one pixel decode
+// and one tap mask per lane.  128 accumulator + 64 fragment registers per lane, two waves per SIMD.
+// Preconditions (host): fp16 pairs (SWEM_PLAN_F16), no per-batch filters, plan tile 4 x 4, no tail split / stream-K.
+// TMW = 0: the layout above (wave grid 2 x 4, BM = 256).  TMW = 8, 10, 12, 14: wave grid 1 x 8 -- every wave owns ALL BM = 16 TMW
+// rows x 32 columns -- so that the tile HEIGHT can be chosen per layer: with one block per CU a launch is whole rounds of 256
+// tiles, and 203 tiles (2x120x216 rows / 256) leave a fifth of the chip idle where 232 tiles of 224 rows fill it (plan bits
+// 20-23 = TMW / 2).  Its k-block: the B pair once, then TMW / 2 steps of one A pair (read one step ahead) x twelve MFMAs.
+template <bool F16, int TMW = 0>
+__global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p) {
+  static_assert(TMW == 0 || (TMW >= 4 && TMW <= 14 && TMW % 2 == 0), "1 x 8 layout: an even number of 16-row tiles, below 256 rows");
+  constexpr int NPL = 2, KG = 4, BM = TMW ? 16 * TMW : 256, BN = 256, NW = 8;
+  constexpr int NTM = TMW ? TMW : 8, NTN = TMW ? 2 : 4;   // accumulator tiles of a wave
+  constexpr int PA = KG * 256;                 // 16-byte slots per plane of an operand image (256 rows, BM of them used)
+  constexpr unsigned OPB = NPL * PA * 16;      // bytes of one operand image (32 KB)
+  constexpr unsigned STAGE = 2 * OPB;          // A image, then B image (64 KB)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // wave tile: rows wr * 128 + [0, 128), columns wc * 64 + [0, 64)  (TMW: all rows, columns wave * 32 + [0, 32))
+  const int wr = TMW ? 0 : wave >> 2, wc = TMW ? wave : wave & 3;
+  const int r16 = lane & 15, kgl = lane >> 4;
+  int tm, tn;
+  tile_coords(tm, tn, p.xpn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int dj = wave & 3, dpl = wave >> 2;    // the 64-row run and the plane this wave transfers
+  const bool a_run = dj * 64 < BM;             // (a tile lower than 256 rows has fewer runs; rows past BM of the last one are
+                                               // the next tile's pixels: transferred, never read)
+
+  auto src_rsrc = [&](int sidx) __attribute__((always_inline)) {
+    const unsigned short *base = sidx == 0 ? p.xs[0] : (sidx == 1 ? p.xs[1] : p.xs[2]);
+    const long long ps = sidx == 0 ? p.ps[0] : (sidx == 1 ? p.ps[1] : p.ps[2]);
+    return raw_rsrc(base, (unsigned)(3 * ps * 2));
+  };
+  const i32x4 rsw = raw_rsrc(p.wsplit, (unsigned)((long long)3 * p.Ncols * p.K * 2));
+  const unsigned wplane = (unsigned)((long long)p.Ncols * p.K * 2);
+  const unsigned wgroup = (unsigned)p.Ncols * 16u;
+  // ---- the pixel this lane transfers (A image, row dj * 64 + lane) and its valid taps; the filter it transfers (B image)
+  int iy0, ix0, bidx;
+  {
+    const int m = m0 + dj * 64 + lane;
+    const int b = fast_div(m, p.fd_howo_mul, p.fd_howo_sh);
+    const int rem = m - b * (p.Ho * p.Wo);
+    const int oy = fast_div(rem, p.fd_wo_mul, p.fd_wo_sh), ox = rem - oy * p.Wo;
+    iy0 = tap_origin(p, oy);
+    ix0 = tap_origin(p, ox);
+    bidx = m < p.M ? b : -1;
+  }
+  unsigned bvoff;
+  {
+    const int n = n0 + dj * 64 + lane;
+    bvoff = n < p.Ncols ? (unsigned)n * 16u : OOB;
+  }
+  const int dsh = (p.flags & SWEM_CONV_DGRAD) ? p.stride - 1 : 0;
+  unsigned long long tmask = 0;
+  {
+    unsigned colv = 0;
+    for (int kx = 0; kx < p.KW; ++kx) {
+      int ix;
+      colv |= (tap_coord(p, ix0, kx, p.W, ix) ? 1u : 0u) << kx;
+    }
+    for (int ky = 0; ky < p.KH; ++ky) {
+      int iy;
+      if (tap_coord(p, iy0, ky, p.H, iy)) tmask |= (unsigned long long)colv << (ky * p.KW);
+    }
+    if (bidx < 0) tmask = 0ull;
+  }
+  unsigned avoff = OOB, aplane = 0, agroup = 0, a_base = 0, w_base = 0;
+  int pix0 = 0;
+  i32x4 rsa;
+  auto set_src = [&](const KPos &q) __attribute__((always_inline)) {
+    const long long ps = q.src == 0 ? p.ps[0] : (q.src == 1 ? p.ps[1] : p.ps[2]);
+    const int npx = q.src == 0 ? p.npx[0] : (q.src == 1 ? p.npx[1] : p.npx[2]);
+    const int bsp = q.src == 0 ? p.bsp[0] : (q.src == 1 ? p.bsp[1] : p.bsp[2]);
+    aplane = (unsigned)(ps * 2);
+    agroup = (unsigned)npx * 16u;
+    a_base = (unsigned)(q.ci0 / 8) * agroup + (unsigned)dpl * aplane;
+    rsa = src_rsrc(q.src);
+    pix0 = (bidx < 0 ? 0 : bidx) * bsp + (iy0 >> dsh) * p.W + (ix0 >> dsh);
+  };
+  auto set_tap = [&](const KPos &q) __attribute__((always_inline)) {
+    const int t = q.ky * p.KW + q.kx;
+    const int d = (q.ky >> dsh) * p.W + (q.kx >> dsh);
+    const int delta = (p.flags & SWEM_CONV_DGRAD) ? -d : d;
+    avoff = ((tmask >> t) & 1ull) ? (unsigned)(pix0 + delta) * 16u : OOB;
+  };
+  auto advance = [&](KPos &q) __attribute__((always_inline)) {
+    w_base += KG * wgroup;
+    if (++q.kx == p.KW) {
+      q.kx = 0;
+      if (++q.ky == p.KH) {
+        q.ky = 0;
+        q.ci0 += BK;
+        a_base += 4 * agroup;
+        const int cs = q.src == 0 ? p.c[0] : (q.src == 1 ? p.c[1] : p.c[2]);
+        if (q.ci0 >= cs) {
+          q.ci0 = 0;
+          ++q.src;
+          set_src(q);
+        }
+      }
+    }
+    set_tap(q);
+  };
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const unsigned lds_a = lds0 + (unsigned)(dpl * PA + dj * 64) * 16u, lds_b = lds_a + OPB;
+  auto issue_a = [&](int stage) __attribute__((always_inline)) {
+    const unsigned sa = lds_a + (unsigned)stage * STAGE;
+    if (a_run) {
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) dma16(rsa, sa + (unsigned)kg * (256 * 16), avoff, a_base + (unsigned)kg * agroup);
+    }
+  };
+  auto issue_b = [&](int stage) __attribute__((always_inline)) {
+    const unsigned sb = lds_b + (unsigned)stage * STAGE;
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) dma16(rsw, sb + (unsigned)kg * (BN * 16), bvoff, w_base + (unsigned)kg * wgroup);
+  };
+
+  f32x4v acc16[NTM][NTN];
+#pragma unroll
+  for (int i = 0; i < NTM; ++i)
+#pragma unroll
+    for (int j = 0; j < NTN; ++j) acc16[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  const int kb_begin = blockIdx.z * p.kb_per_split;
+  const int kb_end = ((int)blockIdx.z == (int)gridDim.z - 1 && p.sk_flags && p.partial) ? p.nkb : min(p.nkb, kb_begin + p.kb_per_split);
+  KPos q;
+  {
+    const int taps = p.KH * p.KW;
+    const int cb = kb_begin / taps, t = kb_begin - cb * taps;
+    q.ky = t / p.KW;
+    q.kx = t - q.ky * p.KW;
+    q.src = 0;
+    int ci = cb * BK;
+    if (ci >= p.c[0]) {
+      ci -= p.c[0];
+      q.src = 1;
+      if (ci >= p.c[1]) {
+        ci -= p.c[1];
+        q.src = 2;
+      }
+    }
+    q.ci0 = ci;
+    set_src(q);
+  }
+  w_base = (unsigned)(kb_begin * 4) * wgroup + (unsigned)dpl * wplane;
+  set_tap(q);
+
+  // fragment addresses: the lane's slot inside a plane of the A / B image (tile 0 of the wave, k/8 group kgl)
+  const uint4 *As = reinterpret_cast<const uint4 *>(smem) + kgl * 256 + wr * 128 + r16;
+  const uint4 *Bs = reinterpret_cast<const uint4 *>(smem + OPB) + kgl * BN + (TMW ? wc * 32 : wc * 64) + r16;
+  constexpr int SSL = STAGE / 16;              // slots per stage
+  // eighth (AM, BN) of the wave tile: rows AM * 32 + [0, 32) (two A tiles), columns BN * 32 + [0, 32) (two B tiles)
+  auto load_a = [&](int stage, int am, uint4 (&f)[NPL][2]) __attribute__((always_inline)) {
+    const uint4 *a = As + stage * SSL + am * 32;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) f[pl][i] = a[pl * PA + 16 * i];
+  };
+  auto load_b = [&](int stage, int bn, uint4 (&f)[NPL][2]) __attribute__((always_inline)) {
+    const uint4 *b = Bs + stage * SSL + bn * 32;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) f[pl][j] = b[pl * PA + 16 * j];
+  };
+#define T256_MFMA(AM, BNQ, FA, FB)                                                                          \
+  {                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)            \
+        acc16[AM * 2 + i][BNQ * 2 + j] = mm16<F16>(FA[0][i], FB[1][j], acc16[AM * 2 + i][BNQ * 2 + j]);     \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)            \
+        acc16[AM * 2 + i][BNQ * 2 + j] = mm16<F16>(FA[1][i], FB[0][j], acc16[AM * 2 + i][BNQ * 2 + j]);     \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)            \
+        acc16[AM * 2 + i][BNQ * 2 + j] = mm16<F16>(FA[0][i], FB[0][j], acc16[AM * 2 + i][BNQ * 2 + j]);     \
+    __builtin_amdgcn_s_setprio(0);                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+  }
+  // One k-block = eight steps over the wave tile's eighths in snake order, so that consecutive steps share the A pair or the B
+  // pair: every step reads ONE new pair (four ds_read_b128) for the next step while its twelve MFMAs run.  BX holds the B pair
+  // of eighth column 0 on entry; the next k-block's first B pair lands in BY (the roles swap from k-block to k-block).
+#define T256_KBLOCK(BX, BY)                                                                                 \
+  {                                                                                                         \
+    const bool more = kb + 1 < kb_end;                                                                      \
+    if (more) {                                                                                             \
+      advance(q);                                                                                           \
+      issue_a(st ^ 1);                                                                                      \
+    }                                                                                                       \
+    load_b(st, 1, BY);                                                                                      \
+    T256_MFMA(0, 0, a0, BX);                                                                                \
+    if (more) issue_b(st ^ 1);                                                                              \
+    load_a(st, 1, a1);                                                                                      \
+    T256_MFMA(0, 1, a0, BY);                                                                                \
+    load_b(st, 0, BX);                                                                                      \
+    T256_MFMA(1, 1, a1, BY);                                                                                \
+    load_a(st, 2, a0);                                                                                      \
+    T256_MFMA(1, 0, a1, BX);                                                                                \
+    load_b(st, 1, BY);                                                                                      \
+    T256_MFMA(2, 0, a0, BX);                                                                                \
+    load_a(st, 3, a1);                                                                                      \
+    T256_MFMA(2, 1, a0, BY);                                                                                \
+    load_b(st, 0, BX);                                                                                      \
+    T256_MFMA(3, 1, a1, BY);                                                                                \
+    /* hand-over: k-block kb + 1 has landed (requested seven steps ago), this wave's reads of stage st are done */ \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    __builtin_amdgcn_s_barrier();                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (more) {                                                                                             \
+      load_a(st ^ 1, 0, a0);                                                                                \
+      load_b(st ^ 1, 0, BY);                                                                                \
+    }                                                                                                       \
+    T256_MFMA(3, 0, a1, BX);                                                                                \
+    st ^= 1;                                                                                                \
+  }
+  issue_a(0);
+  issue_b(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int st = 0;
+  if constexpr (TMW == 0) {
+    uint4 a0[NPL][2], a1[NPL][2], b0[NPL][2], b1[NPL][2];
+    load_a(0, 0, a0);
+    load_b(0, 0, b0);
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+      T256_KBLOCK(b0, b1);
+      if (++kb >= kb_end) break;
+      T256_KBLOCK(b1, b0);
+    }
+  } else {
+    // 1 x 8 layout: fa[(c + PA_) & 1] holds the A pair of step c (rows 32 c + [0, 32)), fb[PB_] this k-block's B pair.  The
+    // buffer parities are compile-time constants (registers, not scratch): the k-loop is unrolled by two k-blocks.
+    constexpr int NCH = TMW / 2;
+    uint4 fa[2][NPL][2], fb[2][NPL][2];
+    load_a(0, 0, fa[0]);
+    load_b(0, 0, fb[0]);
+    int kb = kb_begin;
+    auto kblock = [&](auto pa_, auto pb_) __attribute__((always_inline)) {
+      constexpr int PA_ = decltype(pa_)::value, PB_ = decltype(pb_)::value;
+      const bool more = kb + 1 < kb_end;
+      if (more) {
+        advance(q);
+        issue_a(st ^ 1);
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c == 1 && more) issue_b(st ^ 1);
+        if (c + 1 < NCH) {
+          load_a(st, c + 1, fa[(c + 1 + PA_) & 1]);
+        } else {
+          // hand-over: k-block kb + 1 has landed (requested NCH - 1 steps ago), this wave's reads of stage st are done
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) {
+            load_a(st ^ 1, 0, fa[(NCH + PA_) & 1]);
+            load_b(st ^ 1, 0, fb[PB_ ^ 1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc16[2 * c + i][j] = mm16<F16>(fa[(c + PA_) & 1][prod == 1 ? 1 : 0][i], fb[PB_][prod == 0 ? 1 : 0][j], acc16[2 * c + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      st ^= 1;
+    };
+    for (; kb < kb_end; ++kb) {
+      kblock(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      if (++kb >= kb_end) break;
+      kblock(std::integral_constant<int, NCH & 1>{}, std::integral_constant<int, 1>{});
+    }
+  }
+#undef T256_KBLOCK
+#undef T256_MFMA
+  // ---- K-split reduced inside the launch: conv_igemm_bf3s_kernel's scheme (the last split of a tile is its reducer)
+  bool fused_last = false;
+  if (p.partial && p.sk_flags) {
+    constexpr int NCH = NTM * NTN;   // float4 chunks per lane: the wave's accumulator tiles
+    constexpr unsigned TILE_BYTES = BM * BN * 4;
+    const int nsp = (int)gridDim.z, tile_lin = tm * (int)gridDim.y + tn;
+    float *slots = p.partial + (long long)tile_lin * nsp * (BM * BN);
+    if ((int)blockIdx.z != nsp - 1) {
+      const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(slots + (long long)blockIdx.z * (BM * BN), 0, TILE_BYTES, 0x00020000);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const f32x4v t = acc16[c / NTN][c % NTN];
+        u32x4 v;
+        v.x = __float_as_uint(t[0]); v.y = __float_as_uint(t[1]); v.z = __float_as_uint(t[2]); v.w = __float_as_uint(t[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rp, (unsigned)((c * 64 * NW + tid) * 16), 0, 0x11);   // sc0 sc1
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(p.sk_flags + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    fused_last = true;
+    if (tid == 0) {
+      int spin = 0;
+      unsigned seen = __hip_atomic_fetch_add(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (seen < (unsigned)(nsp - 1) && spin < p.spin_limit) {
+        __builtin_amdgcn_s_sleep(8);
+        ++spin;
+        seen = __hip_atomic_fetch_add(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (seen < (unsigned)(nsp - 1) && p.fault)
+        __hip_atomic_fetch_or(p.fault, (unsigned)SWEM_FAULT_KSPLIT_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.sk_flags + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    for (int zz = 0; zz < nsp - 1; ++zz) {
+      const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(slots + (long long)zz * (BM * BN), 0, TILE_BYTES, 0x00020000);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rp, (unsigned)((c * 64 * NW + tid) * 16), 0, 0x11);
+        f32x4v t = acc16[c / NTN][c % NTN];
+        t[0] += __uint_as_float(v.x); t[1] += __uint_as_float(v.y); t[2] += __uint_as_float(v.z); t[3] += __uint_as_float(v.w);
+        acc16[c / NTN][c % NTN] = t;
+      }
+    }
+  }
+  if (fused_last) {
+    ConvP q2 = p;
+    q2.partial = nullptr;
+    conv_epilogue16<NTM, NTN>(q2, acc16, m0 + wr * 128, n0 + (TMW ? wc * 32 : wc * 64), lane);
+  } else {
+    conv_epilogue16<NTM, NTN>(p, acc16, m0 + wr * 128, n0 + (TMW ? wc * 32 : wc * 64), lane);
+  }
+}
+
 // Reduce split-K partials in z order and apply the same epilogue.  One thread per 4 output channels.
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int nsplit) {
   const bool glu = p.flags & SWEM_CONV_GLU;
@@ -2000,10 +2358,12 @@ int launch(const ConvP &p, dim3 grid, hipStream_t st) {
 // plan hint: 0 = heuristic; else wm | wn << 4 | nsplit << 8 | math << 16 | variant << 20 (swem_hip.h)
 Plan resolve_plan(int plan, int M, int Ncols, int nkb, bool glu) {
   const bool presplit_math = ((plan >> 16) & 3) != 0;   // the 128x64 tile (wm 2, wn 1) exists for the pre-split kernels only
+  const bool f16x3 = ((plan >> 16) & 7) == 7;           // ... and the 256x256 tile (wm 4, wn 4: conv_t256_kernel) for f16x3 only
   plan &= 0xffff;
   if (plan > 0) {
     int wm = plan & 15, wn = (plan >> 4) & 15, ns = plan >> 8;
     bool ok = (wm == 1 || wm == 2) && (wn == 1 || wn == 2) && !(wm == 2 && wn == 1 && !presplit_math) && !(glu && wn != 2);
+    ok = ok || (wm == 4 && wn == 4 && f16x3);
     if (ok) {
       ns = ns < 1 ? 1 : (ns > nkb ? nkb : ns);
       int per = cdiv(nkb, ns);
@@ -2020,6 +2380,12 @@ Plan resolve_plan(int plan, int M, int Ncols, int nkb, bool glu) {
 struct TailSplit {
   int main_mt, nsplit, kb_per_split;
 };
+// rows of a conv_t256_kernel tile (plan tile 4 x 4): plan bits 20-23 = TMW / 2 (the 1 x 8 wave layout, 16 TMW rows), 0 = 256
+static inline int t256_rows(int plan) {
+  const int v = (plan >> 20) & 15;
+  return (v >= 4 && v <= 7) ? 32 * v : 256;
+}
+static inline int tile_rows(int plan, const Plan &pl) { return pl.wm == 4 ? t256_rows(plan) : 64 * pl.wm; }
 static TailSplit tail_split(int plan, const Plan &pl, int M, int Ncols, int nkb) {
   TailSplit t{cdiv(M, 64 * pl.wm), 1, nkb};
   const int ts = (plan >> 24) & 15;
@@ -2067,7 +2433,7 @@ extern "C" size_t swem_conv2d_workspace(int B, int H, int W, int Cin, int Cout, 
     return t.nsplit > 1 ? (size_t)t.nsplit * (M - (long long)t.main_mt * 64 * pl.wm) * Ncols * sizeof(float) : 0;
   }
   // (the pre-split kernel keeps padded partial TILES and a counter per tile; the fp32 kernels [z][M][Ncols]: the larger)
-  const size_t mt = cdiv(M, 64 * pl.wm), nt = cdiv(Ncols, 64 * pl.wn), tile = (size_t)64 * pl.wm * 64 * pl.wn * sizeof(float);
+  const size_t mt = cdiv(M, tile_rows(plan, pl)), nt = cdiv(Ncols, 64 * pl.wn), tile = (size_t)tile_rows(plan, pl) * 64 * pl.wn * sizeof(float);
   return (size_t)pl.nsplit * mt * nt * tile + mt * nt * sizeof(unsigned);
 }
 
@@ -2455,7 +2821,12 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   // (swem_split_f16x2_f32; the filters scaled per output column by a power of two that the caller folds into `scale`)
   p.f16 = (p.nplanes == 2 && ((plan >> 18) & 1)) ? 1 : 0;
   SWEM_REQUIRE(!((plan >> 18) & 1) || p.nplanes == 2, SWEM_E_ARG, "conv2d_bf16x3: plan bit 18 (fp16 planes) needs math mode 3");
-  const int mtiles = cdiv(p.M, 64 * pl.wm), ntiles = cdiv(p.Ncols, 64 * pl.wn);
+  SWEM_REQUIRE(pl.wm != 4 || (p.f16 && w_bs == 0 && ((plan >> 24) & 15) == 0), SWEM_E_ARG,
+               "conv2d_bf16x3: the 256x256 tile runs f16x3 plans without per-batch filters, tail split or stream-K");
+  const int trows = tile_rows(plan, pl);
+  SWEM_REQUIRE(pl.wm != 4 || (trows == 256 && variant == 0) || (trows >= 128 && trows < 256 && trows % 32 == 0 && !glu), SWEM_E_ARG,
+               "conv2d_bf16x3: 256-column tile heights are 128, 160, 192, 224 (plan bits 20-23 = rows / 32; no GLU) or 256 (bits 0)");
+  const int mtiles = cdiv(p.M, trows), ntiles = cdiv(p.Ncols, 64 * pl.wn);
   // XCD partition of the N tiles: plan bits 28-29 force 2 / 4 / 8 groups; 0 = the cut with the least fetch traffic by
   // the model  groups * activations + (8 / groups) * filters  (each XCD reads its groups' filters and its share of the
   // M tiles' activations once: measured 533 -> 166 MB on 2x30x54x1280 -> 512 together with the channel-block K order)
@@ -2483,7 +2854,28 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   }
   if (p.xpn != 1 && p.xpn != 2 && p.xpn != 4 && p.xpn != 8) p.xpn = 1;
   if (ntiles % p.xpn) p.xpn = 1;
-  auto run = [&](const ConvP &q, dim3 grid, int *occ = nullptr) {
+  auto run = [&](const ConvP &q, dim3 grid, int *occ = nullptr) -> int {
+    if (pl.wm == 4) {   // the 256 x 256 tile: its own kernel (f16x3 only), one block per CU
+      constexpr size_t lds = 2 * 2 * 2 * 4 * 256 * 16;   // two stages x (A, B) x two planes x four k/8 groups x 256 rows
+      if (occ) {
+        *occ = 1;
+        return SWEM_OK;
+      }
+#define T256_LAUNCH(TMW_)                                                                         \
+  {                                                                                               \
+    SWEM_ALLOW_LDS((conv_t256_kernel<true, TMW_>), lds);                                          \
+    hipLaunchKernelGGL((conv_t256_kernel<true, TMW_>), grid, dim3(512), lds, st, q);              \
+  }
+      switch (trows) {
+        case 128: T256_LAUNCH(8); break;
+        case 160: T256_LAUNCH(10); break;
+        case 192: T256_LAUNCH(12); break;
+        case 224: T256_LAUNCH(14); break;
+        default: T256_LAUNCH(0)
+      }
+#undef T256_LAUNCH
+      return SWEM_OK;
+    }
     if (pl.wm == 2 && pl.wn == 2) return launch_bf3s<2, 2>(q, grid, st, variant, occ);
     if (pl.wm == 1 && pl.wn == 2) return launch_bf3s<1, 2>(q, grid, st, variant, occ);
     if (pl.wm == 2 && pl.wn == 1) return launch_bf3s<2, 1>(q, grid, st, variant, occ);   // 128x64: the 64-channel layers
@@ -2544,7 +2936,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   }
   if (pl.nsplit > 1) {
     // K-split reduced by the last split (z = nsplit - 1) of every tile (see the kernel): partial TILES (padded), one counter per tile
-    const size_t tile = (size_t)64 * pl.wm * 64 * pl.wn * sizeof(float);
+    const size_t tile = (size_t)trows * 64 * pl.wn * sizeof(float);
     const size_t ntile = (size_t)mtiles * ntiles;
     const size_t need = (size_t)pl.nsplit * ntile * tile + ntile * sizeof(unsigned);
     SWEM_REQUIRE(ws && ws_bytes >= need, SWEM_E_WORKSPACE, "conv2d_bf16x3: workspace %zu < %zu bytes (fused K-split)", ws_bytes, need);

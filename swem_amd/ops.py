@@ -136,6 +136,8 @@ class PlanBook:
         n = 0
         for k, v in list(self.conv.items()):
             if (v >> 16) & 7 == 7:
+                if v & 0xff == 0x44:                   # (the 256-column tiles exist in f16x3 only: the 128x128 tile, no K-split change)
+                    v = (v & 0xff00) | 0x22
                 self.conv[k] = (v & 0xffff) | (1 << 16)
                 n += 1
         self.match.clear()
@@ -293,6 +295,7 @@ def _next_pack_key():
 CONV_MATH_MODES = (0, 1, 7)
 _TUNE_TILES = ((2, 2), (1, 2), (2, 1), (1, 1))   # (2, 1) = 128x64: pre-split kernels only (64-channel layers)
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
+TUNE_T256 = True     # offer the tuner the 256-column tiles of conv_t256_kernel (round 5)
 
 
 def _stream():
@@ -1122,6 +1125,15 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False, modes=None):
                                 cands.append(base | 8 << 20 | ts << 24)
                                 if math != 1 and TUNE_ROUND3_FORMS:
                                     cands.append(base | 5 << 20 | ts << 24)
+    if 7 in (modes if modes is not None else CONV_MATH_MODES) and TUNE_T256 and ncols >= 192:
+        # the 256-column tile of conv_t256_kernel (f16x3 only; one block per CU): tile heights 128 .. 256 rows (plan bits
+        # 20-23 = rows / 32, 0 = 256: the only GLU form), K-split so that the tiles fill the 256 CUs about once
+        for v in ((0,) if glu else (0, 4, 5, 6, 7)):
+            rows = 32 * v if v else 256
+            tiles = -(-M // rows) * -(-ncols // 256)
+            for ns in sorted({1, max(1, min(nkb // 4, 256 // tiles)), max(1, min(nkb // 4, -(-256 // tiles)))}):
+                cands.append(4 | 4 << 4 | ns << 8 | 7 << 16 | v << 20)
+
     def timed(plan, n):
         launch(plan)                               # warm (also grows the workspace)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

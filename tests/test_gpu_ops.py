@@ -975,3 +975,81 @@ def test_fused_bottleneck_matches_three_launches(lib, B, H, W):
         ops.bottleneck(xs, big, c2, c3)
         with pytest.raises(ops.SwemRangeError):
             ops.check_faults()
+
+@pytest.mark.parametrize('case', [
+    dict(B=2, H=120, W=216, cs=[64], co=256, k=3, s=1, ns=1, relu=True, res=False),
+    dict(B=2, H=30, W=54, cs=[512], co=512, k=3, s=1, ns=4, relu=False, res=True),
+    dict(B=3, H=17, W=5, cs=[32, 64], co=96, k=3, s=1, ns=1, relu=True, res=True),
+    dict(B=5, H=11, W=13, cs=[64, 32, 32], co=200, k=3, s=1, ns=2, relu=False, res=False),
+    dict(B=2, H=33, W=41, cs=[128], co=256, k=3, s=2, ns=1, relu=False, res=False),
+    dict(B=1, H=64, W=64, cs=[1024], co=512, k=1, s=1, ns=8, relu=False, res=False),
+    dict(B=4, H=64, W=64, cs=[128], co=300, k=3, s=1, ns=1, relu=False, res=True),
+], ids=['big_relu', 'ksplit4_res', 'two_src', 'three_src_ksplit', 'stride2', '1x1_ksplit8', 'ragged_cols'])
+def test_conv2d_256_column_tiles_equal_the_128_tile(lib, case):
+    """conv_t256_kernel (plan tile 4 x 4; round 5): every tile height (256 rows on the 2 x 4 wave grid; 128 / 160 / 192 / 224 on
+    the 1 x 8 grid) against the 128x128 eight-wave kernel (variant 6) on the same planes -- the same k order and products, so
+    IDENTICAL bits without a K-split and 1e-6 of the range with one (another partition of the fp32 sums) -- and against fp64;
+    with output planes, residual, ReLU, several sources, stride 2, a ragged column tile."""
+    g = torch.Generator().manual_seed(11)
+    B, H_, W_, cs, co, k, s_, ns = (case[n] for n in ('B', 'H', 'W', 'cs', 'co', 'k', 's', 'ns'))
+    C = sum(cs)
+    w = (torch.randn(co, C, k, k, generator=g) * (2.0 / (C * k * k)) ** 0.5)
+    bias = torch.randn(co, generator=g)
+    xs = [torch.randn(B, c, H_, W_, generator=g) for c in cs]
+    pack = ops.pack_conv(w.to(DEV), bias.to(DEV), None, s_, k // 2)
+    ref = F.conv2d(torch.cat(xs, 1).double(), w.double(), bias.double(), stride=s_, padding=k // 2)
+    r = torch.randn(*ref.shape, generator=g) if case['res'] else None
+    if r is not None:
+        ref = ref + r.double()
+    if case['relu']:
+        ref = ref.relu()
+    srcs = [nhwc(x) for x in xs]
+    rs = nhwc(r) if r is not None else None
+    base = ops.conv2d(srcs, pack, relu_out=case['relu'], residual=rs, plan=0x670022 | ns << 8)
+    for v in (0, 4, 5, 6, 7):
+        plan = 0x70044 | ns << 8 | v << 20
+        y = ops.conv2d(srcs, pack, relu_out=case['relu'], residual=rs, plan=plan)
+        close(back(y), ref, 2e-6, 'plan %#x against fp64' % plan)
+        if ns == 1:
+            assert torch.equal(y, base), 'plan %#x differs from the 128x128 kernel' % plan
+        else:
+            assert float((y - base).abs().max()) <= 1e-6 * float(base.abs().max()), hex(plan)
+    ops.check_faults()
+
+
+def test_conv2d_256_column_tile_glu_and_planes(lib):
+    """The 256-row form is the only one that takes SWEM_CONV_GLU (the fusion layer, modules.py:13-26: packed f | gate columns);
+    its epilogue writes the output's operand planes like every other tile's: both against the 128x128 kernel, bit for bit.
+    A height below 256 with GLU or a tail-split field is refused."""
+    g = torch.Generator().manual_seed(5)
+    B, H_, W_, ci, co = 2, 30, 54, 256, 256
+    x = nhwc(torch.randn(B, ci, H_, W_, generator=g))
+    pk = ops.pack_glu(*(t.to(DEV) for t in (torch.randn(co, ci, 3, 3, generator=g) * 0.03, torch.randn(co, generator=g),
+                                            torch.randn(co, ci, 3, 3, generator=g) * 0.03, torch.randn(co, generator=g))))
+    y0 = ops.conv2d([x], pk, plan=0x670022)
+    y1 = ops.conv2d([x], pk, plan=0x70044)
+    y2 = ops.conv2d([x], pk, plan=0x70244)
+    assert torch.equal(y0, y1), 'GLU: the 256-row tile differs from the 128x128 kernel'
+    # (a K-split is another partition of the fp32 sums of BOTH factors of the gated product)
+    assert float((y2 - y0).abs().max()) <= 4e-6 * float(y0.abs().max()), float((y2 - y0).abs().max()) / float(y0.abs().max())
+    with pytest.raises(ops._lib.SwemHipError):
+        ops.conv2d([x], pk, plan=0x670044)          # 192 rows with GLU
+    pc = ops.pack_conv((torch.randn(co, ci, 3, 3, generator=g) * 0.03).to(DEV))
+    with pytest.raises(ops._lib.SwemHipError):
+        ops.conv2d([x], pc, plan=0x4070044)         # a tail-split field
+    # (a 4 x 4 tile under another arithmetic is no plan of this kernel: the library's own heuristic runs, as for any unknown tile)
+    close(back(ops.conv2d([x], pc, plan=0x10044)), back(ops.conv2d([x], pc, plan=0x10022)), 1e-6, 'bf16x6 with a 4 x 4 tile field')
+    # output planes from the epilogue (fused operand split): a consumer's request makes the producer write them
+    with ops.use_book(ops.PlanBook()), ops.flags(FUSE_SPLIT=True):
+        outs = {}
+        for plan in (0x670022, 0x770044, 0x70044):
+            for it in range(2):
+                y = ops.conv2d([x], pc, relu_out=True, plan=plan)
+                ops.conv2d([y], pc, plan=0x70011)
+            assert y.__dict__.get('_swem_split'), hex(plan)
+            outs[plan] = (y, {kk: vv[0].clone() for kk, vv in y.__dict__['_swem_split'].items()})
+        for plan in (0x770044, 0x70044):
+            assert torch.equal(outs[plan][0], outs[0x670022][0])
+            for kk, vv in outs[0x670022][1].items():
+                assert torch.equal(outs[plan][1][kk].view(torch.int16), vv.view(torch.int16)), (hex(plan), kk)
+    ops.check_faults()

@@ -36,6 +36,9 @@ def main():
     ap.add_argument('--dominant', action='store_true',
                     help='the layers of the dominant f16x3 instantiation (128x128 tile, eight waves, 16x16x32 MFMA) with their '
                          'shipped plans: the set the round-5 kernel experiments are judged on (SWEM_HIP_LIB picks the build)')
+    ap.add_argument('--t256', action='store_true', help='with --dominant: the 256x256-tile kernel (plan tile 4 x 4) with the K-split given by --ns')
+    ap.add_argument('--ns', type=int, default=0, help='K-split of the --t256 plans (0: as many as fill 256 CUs)')
+    ap.add_argument('--bmul', type=int, default=1, help='multiply every batch size (the look-ahead graphs run ten frames per launch)')
     a = ap.parse_args()
     dominant = {0: 0x670122, 1: 0x670422, 2: 0x670422, 3: 0x670222, 4: 0x670222, 5: 0x670122, 11: 0x670822}
     if a.small:      # the small / byte-bound layers with their shipped f16x3 plans (kernel variants the subset builds hold)
@@ -45,16 +48,42 @@ def main():
     for idx, (B, H, W, ci, co, k, s, relu) in enumerate(SHAPES):
         if a.only >= 0 and idx != a.only:
             continue
+        B *= a.bmul
         if a.dominant:
             if idx not in dominant:
                 continue
             a.plan = dominant[idx]
+            if a.t256:
+                a.plan = None            # (timed below over tile heights and K-splits: what the tuner would do)
         x = torch.randn(B, H, W, ci, device=dev)
         pack = ops.pack_conv(torch.randn(co, ci, k, k, device=dev) * 0.02, torch.zeros(co, device=dev), None, s, k // 2)
         def run():
             if a.fresh:
                 x.__dict__.pop('_swem_split', None)
             return ops.conv2d([x], pack, relu_in=relu, plan=a.plan)
+        if a.dominant and a.t256:
+            nkb = k * k * ci // 32
+            best = None
+            for v in (0, 4, 5, 6, 7):
+                rows = 32 * v if v else 256
+                tiles = -(-B * H * W // rows) * -(-co // 256)
+                cands = sorted({1, max(1, min(nkb // 4, 256 // tiles)), max(1, min(nkb // 4, -(-256 // tiles)))}) if not a.ns else [a.ns]
+                for ns in cands:
+                    a.plan = 0x70044 | ns << 8 | v << 20
+                    for _ in range(2):
+                        run()
+                    torch.cuda.synchronize()
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda._sleep(400_000)
+                    t0.record()
+                    for _ in range(8):
+                        run()
+                    t1.record()
+                    torch.cuda.synchronize()
+                    t = t0.elapsed_time(t1)
+                    if best is None or t < best[0]:
+                        best = (t, a.plan)
+            a.plan = best[1]
         for _ in range(3):
             y = run()
         torch.cuda.synchronize()
