@@ -1739,7 +1739,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
 // tiles, and 203 tiles (2x120x216 rows / 256) leave a fifth of the chip idle where 232 tiles of 224 rows fill it (plan bits
 // 20-23 = TMW / 2).  Its k-block: the B pair once, then TMW / 2 steps of one A pair (read one step ahead) x twelve MFMAs.
 template <bool F16, int TMW = 0>
-__global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p) {
+__global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
+  STAMP(0);
   static_assert(TMW == 0 || (TMW >= 4 && TMW <= 14 && TMW % 2 == 0), "1 x 8 layout: an even number of 16-row tiles, below 256 rows");
   constexpr int NPL = 2, KG = 4, BM = TMW ? 16 * TMW : 256, BN = 256, NW = 8;
   constexpr int NTM = TMW ? TMW : 8, NTN = TMW ? 2 : 4;   // accumulator tiles of a wave
@@ -1937,9 +1938,13 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p) {
     load_b(st, 0, BX);                                                                                      \
     T256_MFMA(3, 1, a1, BY);                                                                                \
     /* hand-over: k-block kb + 1 has landed (requested seven steps ago), this wave's reads of stage st are done */ \
+    STAMP_T0(t_vm);                                                                                         \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+    STAMP_ACC(t_vm);                                                                                        \
+    STAMP_T0(t_bar);                                                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
     __builtin_amdgcn_s_barrier();                                                                           \
+    STAMP_ACC(t_bar);                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (more) {                                                                                             \
       load_a(st ^ 1, 0, a0);                                                                                \
@@ -1948,10 +1953,14 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p) {
     T256_MFMA(3, 0, a1, BX);                                                                                \
     st ^= 1;                                                                                                \
   }
+  STAMP(1);
   issue_a(0);
   issue_b(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  STAMP(2);
+  STAMP_ACC_DECL(t_vm);
+  STAMP_ACC_DECL(t_bar);
   int st = 0;
   if constexpr (TMW == 0) {
     uint4 a0[NPL][2], a1[NPL][2], b0[NPL][2], b1[NPL][2];
@@ -1984,9 +1993,13 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p) {
           load_a(st, c + 1, fa[(c + 1 + PA_) & 1]);
         } else {
           // hand-over: k-block kb + 1 has landed (requested NCH - 1 steps ago), this wave's reads of stage st are done
+          STAMP_T0(t_vm);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          STAMP_ACC(t_vm);
+          STAMP_T0(t_bar);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
+          STAMP_ACC(t_bar);
           __builtin_amdgcn_sched_barrier(0);
           if (more) {
             load_a(st ^ 1, 0, fa[(NCH + PA_) & 1]);
@@ -2015,6 +2028,9 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p) {
   }
 #undef T256_KBLOCK
 #undef T256_MFMA
+  STAMP(3);
+  STAMP_ACC_OUT(6, t_vm);
+  STAMP_ACC_OUT(7, t_bar);
   // ---- K-split reduced inside the launch: conv_igemm_bf3s_kernel's scheme (the last split of a tile is its reducer)
   bool fused_last = false;
   if (p.partial && p.sk_flags) {
@@ -2068,6 +2084,7 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p) {
   } else {
     conv_epilogue16<NTM, NTN>(p, acc16, m0 + wr * 128, n0 + (TMW ? wc * 32 : wc * 64), lane);
   }
+  STAMP(4);
 }
 
 // Reduce split-K partials in z order and apply the same epilogue.  One thread per 4 output channels.
@@ -2864,7 +2881,7 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
 #define T256_LAUNCH(TMW_)                                                                         \
   {                                                                                               \
     SWEM_ALLOW_LDS((conv_t256_kernel<true, TMW_>), lds);                                          \
-    hipLaunchKernelGGL((conv_t256_kernel<true, TMW_>), grid, dim3(512), lds, st, q);              \
+    hipLaunchKernelGGL((conv_t256_kernel<true, TMW_>), grid, dim3(512), lds, st, q STAMP_PASS);   \
   }
       switch (trows) {
         case 128: T256_LAUNCH(8); break;

@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--shape', type=int, default=9)
     ap.add_argument('--plan', type=lambda v: int(v, 0), default=0x30011)
     ap.add_argument('--build-only', action='store_true')
+    ap.add_argument('--bmul', type=int, default=1, help='multiply the batch size of the shape')
     a = ap.parse_args()
     out = os.path.join(ROOT, 'swem_amd', 'libswem_hip_stamps.so')
     if a.build_only or not os.path.exists(out):
@@ -54,6 +55,7 @@ def main():
     lib.swem_debug_set_stamps.argtypes = [C.c_void_p]
     dev = 'cuda:0'
     B, H, W, ci, co, k, s, relu = conv_bench.SHAPES[a.shape]
+    B *= a.bmul
     x = torch.randn(B, H, W, ci, device=dev)
     pack = ops.pack_conv(torch.randn(co, ci, k, k, device=dev) * 0.02, torch.zeros(co, device=dev), None, s, k // 2)
     stamps = torch.zeros(64 * 16, dtype=torch.int64, device=dev)
