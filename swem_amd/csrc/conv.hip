@@ -2068,12 +2068,21 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
     __syncthreads();
     for (int zz = 0; zz < nsp - 1; ++zz) {
       const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(slots + (long long)zz * (BM * BN), 0, TILE_BYTES, 0x00020000);
+      // (eight 16-byte loads in flight per lane, not all NCH: beside 128 accumulator registers more would spill)
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rp, (unsigned)((c * 64 * NW + tid) * 16), 0, 0x11);
-        f32x4v t = acc16[c / NTN][c % NTN];
-        t[0] += __uint_as_float(v.x); t[1] += __uint_as_float(v.y); t[2] += __uint_as_float(v.z); t[3] += __uint_as_float(v.w);
-        acc16[c / NTN][c % NTN] = t;
+      for (int c0 = 0; c0 < NCH; c0 += 8) {
+        u32x4 v[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+          if (c0 + cc < NCH) v[cc] = __builtin_amdgcn_raw_buffer_load_b128(rp, (unsigned)(((c0 + cc) * 64 * NW + tid) * 16), 0, 0x11);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+          if (c0 + cc < NCH) {
+            f32x4v t = acc16[(c0 + cc) / NTN][(c0 + cc) % NTN];
+            t[0] += __uint_as_float(v[cc].x); t[1] += __uint_as_float(v[cc].y); t[2] += __uint_as_float(v[cc].z); t[3] += __uint_as_float(v[cc].w);
+            acc16[(c0 + cc) / NTN][(c0 + cc) % NTN] = t;
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
