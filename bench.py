@@ -638,6 +638,15 @@ def main():
                                 'gflop_per_launch': round(dkd['flops'] / dkd['n'] / 1e9, 3),
                                 'algorithmic_bytes_per_launch': int(dkd['bytes'] / dkd['n']),
                                 'whole_pipe': {'achieved': per_pipe[dom]['achieved'], 'frac': per_pipe[dom]['frac']}},
+            # every conv kernel instantiation that holds >= 3 % of the conv time, largest first (round 5: the f16x3 layers are
+            # shared between the 128x128 kernel and the 256-column tiles of conv_t256_kernel, one instantiation per tile height)
+            'conv_kernels': [{'rocprof_name': (bf3s_name(*k_) if k_[0] != 'fp32' else 'conv_igemm_pipe_kernel<%d, %d>' % (k_[1], k_[2])),
+                              'share_of_conv_time': round(d_['ms'] / sum(x_['ms'] for x_ in kern.values()), 3),
+                              'launches_per_frame': round(d_['n'] / nprof, 1), 'avg_launch_us': round(1e3 * d_['ms'] / d_['n'], 2),
+                              'achieved': round(d_['flops'] / (d_['ms'] * 1e-3) / 1e12, 2),
+                              'frac': round(d_['flops'] / (d_['ms'] * 1e-3) / 1e12 / peaks[k_[0]], 4)}
+                             for k_, d_ in sorted(kern.items(), key=lambda kv: -kv[1]['ms'])
+                             if d_['ms'] >= 0.03 * sum(x_['ms'] for x_ in kern.values())],
             'traffic_note': 'fabric-side bytes per launch of the dominant kernel, (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches, from '
                             'separate rocprofv3 --pmc passes (tools/pmc_bench_traffic.sh, tools/pmc_by_kernel.py); NOT re-measured by '
                             'this run',

@@ -1038,7 +1038,7 @@ def test_conv2d_256_column_tile_glu_and_planes(lib):
     with pytest.raises(ops._lib.SwemHipError):
         ops.conv2d([x], pc, plan=0x4070044)         # a tail-split field
     # (a 4 x 4 tile under another arithmetic is no plan of this kernel: the library's own heuristic runs, as for any unknown tile)
-    close(back(ops.conv2d([x], pc, plan=0x10044)), back(ops.conv2d([x], pc, plan=0x10022)), 1e-6, 'bf16x6 with a 4 x 4 tile field')
+    close(back(ops.conv2d([x], pc, plan=0x10044)), back(ops.conv2d([x], pc, plan=0x10022)), 4e-6, 'bf16x6 with a 4 x 4 tile field')
     # output planes from the epilogue (fused operand split): a consumer's request makes the producer write them
     with ops.use_book(ops.PlanBook()), ops.flags(FUSE_SPLIT=True):
         outs = {}

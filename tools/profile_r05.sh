@@ -33,11 +33,14 @@ if [[ $WHAT == *pmc* ]]; then
   # the dominant kernel of each leg on its largest layer (2x120x216 k3 256->256), the plans the shipped file holds for it
   bash tools/pmc_kernels.sh $OUT/conv_pmc.txt conv_igemm python3 tools/conv_bench.py --reps 8 --only 0 --plan 0x670122 > /dev/null
   bash tools/pmc_kernels.sh $OUT/conv_pmc_exact.txt conv_igemm python3 tools/conv_bench.py --reps 8 --only 0 --plan 0x8810122 > /dev/null
+  # the 256-column tile kernel (round 5) on the same layer: 224-row tiles, and the ten-frame batch on 256-row tiles
+  bash tools/pmc_kernels.sh $OUT/conv_pmc_t256.txt conv_t256 python3 tools/conv_bench.py --reps 8 --only 0 --plan 0x770144 > /dev/null
+  bash tools/pmc_kernels.sh $OUT/conv_pmc_t256_b10.txt conv_t256 python3 tools/conv_bench.py --reps 8 --only 0 --plan 0x70144 --bmul 5 > /dev/null
 fi
 if [[ $WHAT == *em* ]]; then
   bash tools/pmc_kernels.sh $OUT/em_pmc.txt 'em_|match_|conv_igemm' python3 tools/em_loop.py --reps 10 > /dev/null
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/emloop -- python3 tools/em_loop.py --reps 50 > $OUT/emloop.log 2>&1
   cp $(ls $OUT/emloop/*/*kernel_stats.csv | head -1) $OUT/em_loop_kernel_stats.csv; rm -rf $OUT/emloop
 fi
-rm -rf gpurun_out/pmc_conv_pmc gpurun_out/pmc_conv_pmc_exact gpurun_out/pmc_em_pmc
+rm -rf gpurun_out/pmc_conv_pmc gpurun_out/pmc_conv_pmc_exact gpurun_out/pmc_em_pmc gpurun_out/pmc_conv_pmc_t256 gpurun_out/pmc_conv_pmc_t256_b10
 ls -la $OUT | head -40
