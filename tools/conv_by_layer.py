@@ -30,7 +30,7 @@ def main(layers_json, trace_csv, out_csv):
     launches = json.load(open(layers_json))['launches']
     rows = sorted(csv.DictReader(open(trace_csv)), key=lambda r: int(r['Start_Timestamp']))
     dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    is_conv = lambda r: 'conv_igemm' in r['Kernel_Name']
+    is_conv = lambda r: 'conv_igemm' in r['Kernel_Name'] or 'conv_t256_kernel' in r['Kernel_Name']
     is_red = lambda r: 'conv_splitk_epilogue' in r['Kernel_Name']
     is_split = lambda r: 'split_bf16x3' in r['Kernel_Name'] or 'split_f16x2' in r['Kernel_Name']
     # The traced frames are the LAST conv launches of the run: walk both lists backwards.  One traced launch = [operand-split
@@ -60,7 +60,7 @@ def main(layers_json, trace_csv, out_csv):
             if is_split(rows[j]):
                 t_split += dur(rows[j])
             j -= 1
-        kname = re.search(r'(conv_igemm\w*(<[^>]*>)?)', rows[mi]['Kernel_Name']).group(1).replace(', ', ' ')
+        kname = re.search(r'(conv_(?:igemm|t256)\w*(<[^>]*>)?)', rows[mi]['Kernel_Name']).group(1).replace(', ', ' ')
         a = agg.setdefault((la['layer'], la['pipe'], '%#x' % la['plan'], kname), [0, 0.0, 0.0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += la['flops']
