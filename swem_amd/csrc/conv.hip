@@ -2068,15 +2068,17 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
     __syncthreads();
     for (int zz = 0; zz < nsp - 1; ++zz) {
       const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(slots + (long long)zz * (BM * BN), 0, TILE_BYTES, 0x00020000);
-      // (eight 16-byte loads in flight per lane, not all NCH: beside 128 accumulator registers more would spill)
+      // (sixteen 16-byte loads in flight per lane, not all NCH: beside 128 accumulator registers more would spill; fewer would
+      // make the reducer's tail a chain of load latencies)
+      constexpr int RCH = 16;
 #pragma unroll
-      for (int c0 = 0; c0 < NCH; c0 += 8) {
-        u32x4 v[8];
+      for (int c0 = 0; c0 < NCH; c0 += RCH) {
+        u32x4 v[RCH];
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc)
+        for (int cc = 0; cc < RCH; ++cc)
           if (c0 + cc < NCH) v[cc] = __builtin_amdgcn_raw_buffer_load_b128(rp, (unsigned)(((c0 + cc) * 64 * NW + tid) * 16), 0, 0x11);
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc)
+        for (int cc = 0; cc < RCH; ++cc)
           if (c0 + cc < NCH) {
             f32x4v t = acc16[(c0 + cc) / NTN][(c0 + cc) % NTN];
             t[0] += __uint_as_float(v[cc].x); t[1] += __uint_as_float(v[cc].y); t[2] += __uint_as_float(v[cc].z); t[3] += __uint_as_float(v[cc].w);
