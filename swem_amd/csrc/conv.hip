@@ -1975,20 +1975,52 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
     // 1 x 8 layout: fa[(c + PA_) & 1] holds the A pair of step c (rows 32 c + [0, 32)), fb[PB_] this k-block's B pair.  The
     // buffer parities are compile-time constants (registers, not scratch): the k-loop is unrolled by two k-blocks.
     constexpr int NCH = TMW / 2;
+    // SWEM_T256_STAGGER (experiment, round 5; default 0 -- measured 1-5 % SLOWER on every layer, profiles/r05_kernel_experiments.txt
+    // section 8: the ~750 cycles per k-block outside the MFMAs are not an idle SIMD at the hand-over, and the stagger halves the
+    // transfers' lead; bit-identical results, kept for the record): the two waves of a SIMD (w and w + 4) run HALF A K-BLOCK apart -- waves 4-7 start behind one
+    // extra barrier -- and the block meets twice per k-block: each barrier is the END of a k-block for one half (its hand-over:
+    // last reads done, next stage published) and the MIDDLE for the other, which is busy with MFMAs on both sides of it.  So a
+    // hand-over (barrier, first fragment reads of the new stage and their latency: ~700-780 cycles per k-block of whatever tile
+    // height, in-kernel stamps) runs under the other wave's MFMAs instead of idling the SIMD (cdna_hip_programming.md, the
+    // 8-phase template's staggered wave groups).  A stage is free for the transfers of k-block kb + 2 when the LATER half has
+    // finished kb: every wave requests its share right behind that barrier (the earlier half in the middle of its k-block kb + 1,
+    // the later half at the top of its own) and waits for it (vmcnt(0)) in front of the next barrier, half a k-block later.
+#ifndef SWEM_T256_STAGGER
+#define SWEM_T256_STAGGER 0
+#endif
+    constexpr bool STAG = SWEM_T256_STAGGER != 0;
+    constexpr int HMID = NCH / 2;
+    const int grp = STAG ? (wave >> 2) : 0;
     uint4 fa[2][NPL][2], fb[2][NPL][2];
     load_a(0, 0, fa[0]);
     load_b(0, 0, fb[0]);
+    if (STAG && grp == 1) __builtin_amdgcn_s_barrier();   // (pairs with the first middle barrier of waves 0-3)
     int kb = kb_begin;
     auto kblock = [&](auto pa_, auto pb_) __attribute__((always_inline)) {
       constexpr int PA_ = decltype(pa_)::value, PB_ = decltype(pb_)::value;
       const bool more = kb + 1 < kb_end;
-      if (more) {
+      if (more && (!STAG || grp == 1)) {
         advance(q);
         issue_a(st ^ 1);
+        if (STAG) issue_b(st ^ 1);
       }
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (c == 1 && more) issue_b(st ^ 1);
+        if (!STAG && c == 1 && more) issue_b(st ^ 1);
+        if (STAG && c == HMID) {
+          STAMP_T0(t_vm);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (waves 4-7: their share of k-block kb + 1, requested at the top)
+          STAMP_ACC(t_vm);
+          STAMP_T0(t_bar);
+          __builtin_amdgcn_s_barrier();
+          STAMP_ACC(t_bar);
+          if (more && grp == 0) {
+            advance(q);
+            issue_a(st ^ 1);
+            issue_b(st ^ 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (c + 1 < NCH) {
           load_a(st, c + 1, fa[(c + 1 + PA_) & 1]);
         } else {
@@ -2025,6 +2057,7 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
       if (++kb >= kb_end) break;
       kblock(std::integral_constant<int, NCH & 1>{}, std::integral_constant<int, 1>{});
     }
+    if (STAG && grp == 0) __builtin_amdgcn_s_barrier();   // (pairs with the last end-of-k-block barrier of waves 4-7)
   }
 #undef T256_KBLOCK
 #undef T256_MFMA
