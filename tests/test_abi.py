@@ -77,7 +77,8 @@ def _check_m0(subset, at_least):
                           *(['-DSWEM_ISA_SUBSET'] if subset else []), src, '-o', '-'], check=True, capture_output=True,
                          text=True, timeout=1800).stdout
     checked = 0
-    for m in re.finditer(r'^(_ZN\S*conv_igemm_bf3s_kernel\S*):', asm, flags=re.M):
+    t256 = 0
+    for m in re.finditer(r'^(_ZN\S*(?:conv_igemm_bf3s_kernel|conv_t256_kernel)\S*):', asm, flags=re.M):
         name = m.group(1)
         body = asm[m.end():asm.index('s_endpgm', m.end())]
         uses = [ln.strip() for ln in body.splitlines() if re.search(r'\bm0\b', ln) and not ln.strip().startswith(';')]
@@ -85,7 +86,8 @@ def _check_m0(subset, at_least):
         assert all(re.fullmatch(r's_mov_b32 m0, s\d+', u) for u in uses), (name, uses[:5])
         assert body.count('offen lds') == len(uses)            # one M0 write per transfer, nothing else
         checked += 1
-    assert checked >= at_least
+        t256 += 'conv_t256_kernel' in name
+    assert checked >= at_least and t256 == 5          # (conv_t256_kernel: the 256-row form and four tile heights)
 
 
 def test_integration_md_binding_matches_the_signature_table(lib):
