@@ -1053,3 +1053,19 @@ def test_conv2d_256_column_tile_glu_and_planes(lib):
             for kk, vv in outs[0x670022][1].items():
                 assert torch.equal(outs[plan][1][kk].view(torch.int16), vv.view(torch.int16)), (hex(plan), kk)
     ops.check_faults()
+
+def test_conv2d_256_column_tile_properties_at_config_b_size(lib):
+    """Size-independent properties of the 256-column tile kernel at the bench's largest layer (2 x 120 x 216, 256 -> 256, 3x3; 232
+    tiles of 224 rows) where an fp64 reference is not worth its time: scaling the input by a power of two scales every output bit-
+    exactly (fp16 pairs and fp32 accumulation are exact under it), swapping the two images swaps the outputs bit-exactly (a tile
+    straddles the image boundary: pixel 25,920 is row 160 of tile 115), and the result equals the 128x128 kernel's bit for bit."""
+    g = torch.Generator().manual_seed(23)
+    r = torch.randn(2, 120, 216, 256, generator=g)
+    x = (torch.sign(r) * (0.5 + r.abs())).to(DEV)      # (|x| >= 2^-2: the fp16 pair of x is exact to half an fp32 ulp, so 4x splits as 4 x the pair)
+    pk = ops.pack_conv((torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(DEV))
+    y = ops.conv2d([x], pk, relu_out=True, plan=0x770144)
+    assert torch.equal(y, ops.conv2d([x], pk, relu_out=True, plan=0x670122))
+    assert torch.equal(ops.conv2d([x * 4.0], pk, relu_out=True, plan=0x770144), y * 4.0)
+    assert torch.equal(ops.conv2d([x.flip(0).contiguous()], pk, relu_out=True, plan=0x770144), y.flip(0))
+    assert torch.isfinite(y).all() and float(y.max()) > 0
+    ops.check_faults()
