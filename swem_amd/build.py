@@ -7,6 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libswem_hip.so')
 SOURCES = ['api.hip', 'conv.hip', 'bneck.hip', 'pointwise.hip', 'em.hip', 'match.hip', 'train.hip', 'train_conv.hip']
+# (source, extra flags, object): conv.hip a second time for conv_t256_kernel alone (-DSWEM_CONV_T256_ONLY: csrc/conv.hip)
+EXTRA_UNITS = [('conv.hip', ['-DSWEM_CONV_T256_ONLY'], 'conv_t256.o')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
@@ -28,6 +30,12 @@ def build(force=False, verbose=False):
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         if force or _stale(o, [s] + hdrs):
             todo.append([HIPCC] + FLAGS + ['-c', s, '-o', o])
+        objs.append(o)
+    for src, extra, obj in EXTRA_UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, obj)
+        if force or _stale(o, [s] + hdrs):
+            todo.append([HIPCC] + FLAGS + extra + ['-c', s, '-o', o])
         objs.append(o)
 
     def run(cmd):

@@ -2131,6 +2131,36 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
   STAMP(4);
 }
 
+#ifdef SWEM_CONV_T256_ONLY
+// Second translation unit of this file (swem_amd/build.py compiles conv.hip twice, side by side: the instantiations of
+// conv_igemm_bf3s_kernel take five minutes, these five one): only conv_t256_kernel and its launcher.  ConvP lives in this file's
+// anonymous namespace, so it crosses the boundary as an opaque pointer (same source, same layout).
+}  // namespace
+int swem_conv_t256_launch(int trows, const void *convp, unsigned gx, unsigned gy, unsigned gz, void *stream) {
+  const ConvP &q = *static_cast<const ConvP *>(convp);
+  const dim3 grid(gx, gy, gz);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  constexpr size_t lds = 2 * 2 * 2 * 4 * 256 * 16;   // two stages x (A, B) x two planes x four k/8 groups x 256 rows
+#define T256_LAUNCH(TMW_)                                                                         \
+  {                                                                                               \
+    SWEM_ALLOW_LDS((conv_t256_kernel<true, TMW_>), lds);                                          \
+    hipLaunchKernelGGL((conv_t256_kernel<true, TMW_>), grid, dim3(512), lds, st, q STAMP_PASS);   \
+  }
+  switch (trows) {
+    case 128: T256_LAUNCH(8); break;
+    case 160: T256_LAUNCH(10); break;
+    case 192: T256_LAUNCH(12); break;
+    case 224: T256_LAUNCH(14); break;
+    default: T256_LAUNCH(0)
+  }
+#undef T256_LAUNCH
+  return SWEM_OK;
+}
+#else
+}  // namespace
+int swem_conv_t256_launch(int trows, const void *convp, unsigned gx, unsigned gy, unsigned gz, void *stream);   // (the other unit)
+namespace {
+
 // Reduce split-K partials in z order and apply the same epilogue.  One thread per 4 output channels.
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int nsplit) {
   const bool glu = p.flags & SWEM_CONV_GLU;
@@ -2917,25 +2947,11 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   if (ntiles % p.xpn) p.xpn = 1;
   auto run = [&](const ConvP &q, dim3 grid, int *occ = nullptr) -> int {
     if (pl.wm == 4) {   // the 256 x 256 tile: its own kernel (f16x3 only), one block per CU
-      constexpr size_t lds = 2 * 2 * 2 * 4 * 256 * 16;   // two stages x (A, B) x two planes x four k/8 groups x 256 rows
       if (occ) {
         *occ = 1;
         return SWEM_OK;
       }
-#define T256_LAUNCH(TMW_)                                                                         \
-  {                                                                                               \
-    SWEM_ALLOW_LDS((conv_t256_kernel<true, TMW_>), lds);                                          \
-    hipLaunchKernelGGL((conv_t256_kernel<true, TMW_>), grid, dim3(512), lds, st, q STAMP_PASS);   \
-  }
-      switch (trows) {
-        case 128: T256_LAUNCH(8); break;
-        case 160: T256_LAUNCH(10); break;
-        case 192: T256_LAUNCH(12); break;
-        case 224: T256_LAUNCH(14); break;
-        default: T256_LAUNCH(0)
-      }
-#undef T256_LAUNCH
-      return SWEM_OK;
+      return swem_conv_t256_launch(trows, &q, grid.x, grid.y, grid.z, st);
     }
     if (pl.wm == 2 && pl.wn == 2) return launch_bf3s<2, 2>(q, grid, st, variant, occ);
     if (pl.wm == 1 && pl.wn == 2) return launch_bf3s<1, 2>(q, grid, st, variant, occ);
@@ -3041,3 +3057,4 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   return SWEM_OK;
 }
 }  // namespace
+#endif   // SWEM_CONV_T256_ONLY

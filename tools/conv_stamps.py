@@ -30,6 +30,12 @@ def build():
                                *(['-DSWEM_ISA_SUBSET'] if name == 'conv' and os.environ.get('SWEM_STAMPS_SUBSET') else []),
                                '-c', os.path.join(csrc, name + '.hip'), '-o', o])
         objs.append(o)
+        if name == 'conv':          # (its second unit: conv_t256_kernel alone)
+            o2 = '/tmp/conv_t256_stamps.o'
+            subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-DSWEM_EM_STAMPS',
+                                   '-DSWEM_STAMP_BLOCK=%d' % int(os.environ.get('SWEM_STAMP_BLOCK', '0')), '-DSWEM_CONV_T256_ONLY',
+                                   '-c', os.path.join(csrc, 'conv.hip'), '-o', o2])
+            objs.append(o2)
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
     return out
 

@@ -7,7 +7,10 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DSWEM_ISA_SUBSET $@ \
   -c swem_amd/csrc/conv.hip -o /tmp/conv_$name.o
-objs=""
+# (the second unit of conv.hip: conv_t256_kernel alone, with the same flags)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DSWEM_CONV_T256_ONLY $@ \
+  -c swem_amd/csrc/conv.hip -o /tmp/conv_t256_$name.o
+objs="/tmp/conv_t256_$name.o"
 for o in api bneck pointwise em match train train_conv; do objs="$objs swem_amd/csrc/$o.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o swem_amd/libswem_hip_$name.so /tmp/conv_$name.o $objs
 echo swem_amd/libswem_hip_$name.so
