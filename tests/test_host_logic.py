@@ -344,13 +344,16 @@ def test_full_range_book_policy(tmp_path):
     assert n7 > 100 and book.match and not book.full_range
     with ops.use_book(book):
         assert ops.value_planes_wanted()
-    some = next(k for k, v in book.conv.items() if (v >> 16) & 7 == 7 and (v >> 20))      # a plan with variant bits
+    some = next(k for k, v in book.conv.items() if (v >> 16) & 7 == 7 and (v >> 20) and v & 0xff != 0x44)      # a plan with variant bits
+    t256 = next(k for k, v in book.conv.items() if v & 0xff == 0x44)                       # a 256-column tile plan (f16x3 only)
+    t256_ns = book.conv[t256] & 0xff00
     tile = book.conv[some] & 0xffff
     book.hints[('conv', ('x',), 1, 2, 3, 0)] = {False: ops.PLANES_F16}
     e0 = book.epoch()
     assert book.to_full_range() == n7
     assert book.full_range and book.epoch() != e0 and not book.hints and not book.match
     assert book.math_histogram()['f16x3'] == 0 and book.conv[some] == (tile | 1 << 16) and (book.fallback >> 16) & 7 == 1
+    assert book.conv[t256] == (t256_ns | 0x22 | 1 << 16)          # ... goes back to the 128x128 tile, K-split kept
     with ops.use_book(book):
         assert not ops.value_planes_wanted()
         assert ops._pack_planes((None, None, torch.zeros(1, dtype=torch.float16))) is None
