@@ -38,6 +38,7 @@ def main():
                          'shipped plans: the set the round-5 kernel experiments are judged on (SWEM_HIP_LIB picks the build)')
     ap.add_argument('--t256', action='store_true', help='with --dominant: the 256x256-tile kernel (plan tile 4 x 4) with the K-split given by --ns')
     ap.add_argument('--ns', type=int, default=0, help='K-split of the --t256 plans (0: as many as fill 256 CUs)')
+    ap.add_argument('--res', action='store_true', help='with a residual addend (a ResBlock / bottleneck closing convolution)')
     ap.add_argument('--bmul', type=int, default=1, help='multiply every batch size (the look-ahead graphs run ten frames per launch)')
     a = ap.parse_args()
     dominant = {0: 0x670122, 1: 0x670422, 2: 0x670422, 3: 0x670222, 4: 0x670222, 5: 0x670122, 11: 0x670822}
@@ -57,10 +58,12 @@ def main():
                 a.plan = None            # (timed below over tile heights and K-splits: what the tuner would do)
         x = torch.randn(B, H, W, ci, device=dev)
         pack = ops.pack_conv(torch.randn(co, ci, k, k, device=dev) * 0.02, torch.zeros(co, device=dev), None, s, k // 2)
+        resid = torch.randn(B, (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1, co, device=dev) if a.res else None
+
         def run():
             if a.fresh:
                 x.__dict__.pop('_swem_split', None)
-            return ops.conv2d([x], pack, relu_in=relu, plan=a.plan)
+            return ops.conv2d([x], pack, relu_in=relu, residual=resid, plan=a.plan)
         if a.dominant and a.t256:
             nkb = k * k * ci // 32
             best = None
