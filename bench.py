@@ -563,7 +563,7 @@ def main():
         # rocprofv3's name of that instantiation (conv.hip: variant -> stages / waves / MFMA shape), for the committed stats
         def bf3s_name(pipe_, wm_, wn_, var_):
             if wm_ == 4:                               # the 256-column tiles (conv_t256_kernel: height = 32 * variant rows, 0 = 256)
-                return 'conv_t256_kernel<true, %d>' % (2 * var_)
+                return 'conv_t256_kernel<%s, %d>' % ('true' if pipe_ == 'f16x3' else 'false', 2 * var_)
             one = (wm_, wn_) == (1, 1)
             big = (wm_, wn_) == (2, 2)
             nst, nw, m16, kg = (3 if one != (var_ == 1) else 2), 4, False, 4          # launch_bf3s (conv.hip), default / 1

@@ -142,7 +142,9 @@ int swem_split_f16x2_f32(void *stream, const float *x, void *out, long long npix
  * k-block before anything waits for them, fragments read one step ahead of their MFMAs.  Bits 20-23 then give the tile HEIGHT:
  * 0 = 256 rows (wave grid 2 x 4; the only form with SWEM_CONV_GLU), 4 / 5 / 6 / 7 = 128 / 160 / 192 / 224 rows (wave grid 1 x 8),
  * chosen so that the tiles x K-split fill the chip's 256 CUs about once.  Same k order and products as the other tiles: without a
- * K-split the result is bit-identical to theirs.  swem_conv2d_workspace sizes the K-split workspace for the height given. */
+ * K-split the result is bit-identical to theirs.  swem_conv2d_workspace sizes the K-split workspace for the height given.
+ * The same tile with math 1 (bf16x6, three planes, six products: all 24 operand bits) exists at ONE height: bits 20-23 = 4
+ * (128 rows; no GLU) -- (128 + 256) rows x 3 planes fill the LDS. */
 int swem_conv2d_nhwc_bf16x3(void *stream, const void *x0, int c0, long long bs0, long long ps0, const void *x1, int c1,
                             long long bs1, long long ps1, const void *x2, int c2, long long bs2, long long ps2, int B,
                             int H, int W, const void *w_bf16x3, const float *scale, const float *shift,

@@ -1742,11 +1742,15 @@ template <bool F16, int TMW = 0>
 __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
   STAMP(0);
   static_assert(TMW == 0 || (TMW >= 4 && TMW <= 14 && TMW % 2 == 0), "1 x 8 layout: an even number of 16-row tiles, below 256 rows");
-  constexpr int NPL = 2, KG = 4, BM = TMW ? 16 * TMW : 256, BN = 256, NW = 8;
+  // F16 = false: the bf16x6 arithmetic (three bf16 planes per operand, six products: all 24 operand bits) -- 128-row tiles only
+  // (TMW = 8): (128 + 256) rows x 64 bytes x 3 planes = 72 KB per stage.
+  static_assert(F16 || TMW == 8, "three planes fit the LDS with 128-row tiles only");
+  constexpr int NPL = F16 ? 2 : 3, KG = 4, BM = TMW ? 16 * TMW : 256, BN = 256, NW = 8;
   constexpr int NTM = TMW ? TMW : 8, NTN = TMW ? 2 : 4;   // accumulator tiles of a wave
-  constexpr int PA = KG * 256;                 // 16-byte slots per plane of an operand image (256 rows, BM of them used)
-  constexpr unsigned OPB = NPL * PA * 16;      // bytes of one operand image (32 KB)
-  constexpr unsigned STAGE = 2 * OPB;          // A image, then B image (64 KB)
+  constexpr int AROWS = F16 ? 256 : BM;        // rows of the A image (fp16 pairs: 256 allocated, BM of them used)
+  constexpr int PAA = KG * AROWS, PA = KG * 256;   // 16-byte slots per plane of the A / B image
+  constexpr unsigned OPA = NPL * PAA * 16, OPB = NPL * PA * 16;   // bytes of the A / B image of one stage
+  constexpr unsigned STAGE = OPA + OPB;        // A image, then B image (fp16 pairs: 64 KB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1807,7 +1811,7 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
     const int bsp = q.src == 0 ? p.bsp[0] : (q.src == 1 ? p.bsp[1] : p.bsp[2]);
     aplane = (unsigned)(ps * 2);
     agroup = (unsigned)npx * 16u;
-    a_base = (unsigned)(q.ci0 / 8) * agroup + (unsigned)dpl * aplane;
+    a_base = (unsigned)(q.ci0 / 8) * agroup + (F16 ? (unsigned)dpl * aplane : 0u);
     rsa = src_rsrc(q.src);
     pix0 = (bidx < 0 ? 0 : bidx) * bsp + (iy0 >> dsh) * p.W + (ix0 >> dsh);
   };
@@ -1836,18 +1840,37 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
     set_tap(q);
   };
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
-  const unsigned lds_a = lds0 + (unsigned)(dpl * PA + dj * 64) * 16u, lds_b = lds_a + OPB;
+  // fp16 pairs: wave (dj, dpl) moves the four k/8 groups of plane dpl of its run.  Three planes: the twelve (plane, group) cells of
+  // a run are shared by the two waves (dj, 0 / 1): cell index = 2 i + (wave >> 2), i < 6.
+  const unsigned lds_a = lds0 + (unsigned)((F16 ? dpl * PAA : 0) + dj * 64) * 16u;
+  const unsigned lds_b = lds0 + OPA + (unsigned)((F16 ? dpl * PA : 0) + dj * 64) * 16u;
   auto issue_a = [&](int stage) __attribute__((always_inline)) {
     const unsigned sa = lds_a + (unsigned)stage * STAGE;
     if (a_run) {
+      if constexpr (F16) {
 #pragma unroll
-      for (int kg = 0; kg < KG; ++kg) dma16(rsa, sa + (unsigned)kg * (256 * 16), avoff, a_base + (unsigned)kg * agroup);
+        for (int kg = 0; kg < KG; ++kg) dma16(rsa, sa + (unsigned)kg * (AROWS * 16), avoff, a_base + (unsigned)kg * agroup);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int cell = 2 * i + dpl, pl = cell >> 2, kg = cell & 3;
+          dma16(rsa, sa + (unsigned)(pl * PAA + kg * AROWS) * 16u, avoff, a_base + (unsigned)kg * agroup + (unsigned)pl * aplane);
+        }
+      }
     }
   };
   auto issue_b = [&](int stage) __attribute__((always_inline)) {
     const unsigned sb = lds_b + (unsigned)stage * STAGE;
+    if constexpr (F16) {
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg) dma16(rsw, sb + (unsigned)kg * (BN * 16), bvoff, w_base + (unsigned)kg * wgroup);
+      for (int kg = 0; kg < KG; ++kg) dma16(rsw, sb + (unsigned)kg * (BN * 16), bvoff, w_base + (unsigned)kg * wgroup);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int cell = 2 * i + dpl, pl = cell >> 2, kg = cell & 3;
+        dma16(rsw, sb + (unsigned)(pl * PA + kg * BN) * 16u, bvoff, w_base + (unsigned)kg * wgroup + (unsigned)pl * wplane);
+      }
+    }
   };
 
   f32x4v acc16[NTM][NTN];
@@ -1877,12 +1900,12 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
     q.ci0 = ci;
     set_src(q);
   }
-  w_base = (unsigned)(kb_begin * 4) * wgroup + (unsigned)dpl * wplane;
+  w_base = (unsigned)(kb_begin * 4) * wgroup + (F16 ? (unsigned)dpl * wplane : 0u);
   set_tap(q);
 
   // fragment addresses: the lane's slot inside a plane of the A / B image (tile 0 of the wave, k/8 group kgl)
-  const uint4 *As = reinterpret_cast<const uint4 *>(smem) + kgl * 256 + wr * 128 + r16;
-  const uint4 *Bs = reinterpret_cast<const uint4 *>(smem + OPB) + kgl * BN + (TMW ? wc * 32 : wc * 64) + r16;
+  const uint4 *As = reinterpret_cast<const uint4 *>(smem) + kgl * AROWS + wr * 128 + r16;
+  const uint4 *Bs = reinterpret_cast<const uint4 *>(smem + OPA) + kgl * BN + (TMW ? wc * 32 : wc * 64) + r16;
   constexpr int SSL = STAGE / 16;              // slots per stage
   // eighth (AM, BN) of the wave tile: rows AM * 32 + [0, 32) (two A tiles), columns BN * 32 + [0, 32) (two B tiles)
   auto load_a = [&](int stage, int am, uint4 (&f)[NPL][2]) __attribute__((always_inline)) {
@@ -1890,7 +1913,7 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) f[pl][i] = a[pl * PA + 16 * i];
+      for (int i = 0; i < 2; ++i) f[pl][i] = a[pl * PAA + 16 * i];
   };
   auto load_b = [&](int stage, int bn, uint4 (&f)[NPL][2]) __attribute__((always_inline)) {
     const uint4 *b = Bs + stage * SSL + bn * 32;
@@ -2040,13 +2063,18 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+        // products in the order of conv_igemm_bf3s_kernel (per accumulator): fp16 pairs a0 b1, a1 b0, a0 b0; three planes
+        // a0 b2, a2 b0, a1 b1, a0 b1, a1 b0, a0 b0
+        constexpr int NPROD = F16 ? 3 : 6;
+        constexpr int PAI[6] = {0, 2, 1, 0, 1, 0}, PBI[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-        for (int prod = 0; prod < 3; ++prod)
+        for (int prod = 0; prod < NPROD; ++prod)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc16[2 * c + i][j] = mm16<F16>(fa[(c + PA_) & 1][prod == 1 ? 1 : 0][i], fb[PB_][prod == 0 ? 1 : 0][j], acc16[2 * c + i][j]);
+              acc16[2 * c + i][j] = mm16<F16>(fa[(c + PA_) & 1][PAI[prod + 6 - NPROD]][i], fb[PB_][PBI[prod + 6 - NPROD]][j],
+                                              acc16[2 * c + i][j]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -2141,6 +2169,12 @@ int swem_conv_t256_launch(int trows, const void *convp, unsigned gx, unsigned gy
   const dim3 grid(gx, gy, gz);
   hipStream_t st = static_cast<hipStream_t>(stream);
   constexpr size_t lds = 2 * 2 * 2 * 4 * 256 * 16;   // two stages x (A, B) x two planes x four k/8 groups x 256 rows
+  if (!q.f16) {   // bf16x6 (three planes): 128-row tiles, (128 + 256) rows x 3 planes x 4 groups x 16 bytes per stage
+    constexpr size_t lds3 = 2 * 3 * 4 * (128 + 256) * 16;
+    SWEM_ALLOW_LDS((conv_t256_kernel<false, 8>), lds3);
+    hipLaunchKernelGGL((conv_t256_kernel<false, 8>), grid, dim3(512), lds3, st, q STAMP_PASS);
+    return SWEM_OK;
+  }
 #define T256_LAUNCH(TMW_)                                                                         \
   {                                                                                               \
     SWEM_ALLOW_LDS((conv_t256_kernel<true, TMW_>), lds);                                          \
@@ -2449,12 +2483,13 @@ int launch(const ConvP &p, dim3 grid, hipStream_t st) {
 // plan hint: 0 = heuristic; else wm | wn << 4 | nsplit << 8 | math << 16 | variant << 20 (swem_hip.h)
 Plan resolve_plan(int plan, int M, int Ncols, int nkb, bool glu) {
   const bool presplit_math = ((plan >> 16) & 3) != 0;   // the 128x64 tile (wm 2, wn 1) exists for the pre-split kernels only
-  const bool f16x3 = ((plan >> 16) & 7) == 7;           // ... and the 256x256 tile (wm 4, wn 4: conv_t256_kernel) for f16x3 only
+  const bool f16x3 = ((plan >> 16) & 7) == 7;           // ... and the 256-column tiles (wm 4, wn 4: conv_t256_kernel) for f16x3,
+  const bool bf16x6_128 = ((plan >> 16) & 7) == 1 && ((plan >> 20) & 15) == 4;   // or for bf16x6 with 128-row tiles (bits 20-23 = 4)
   plan &= 0xffff;
   if (plan > 0) {
     int wm = plan & 15, wn = (plan >> 4) & 15, ns = plan >> 8;
     bool ok = (wm == 1 || wm == 2) && (wn == 1 || wn == 2) && !(wm == 2 && wn == 1 && !presplit_math) && !(glu && wn != 2);
-    ok = ok || (wm == 4 && wn == 4 && f16x3);
+    ok = ok || (wm == 4 && wn == 4 && (f16x3 || bf16x6_128));
     if (ok) {
       ns = ns < 1 ? 1 : (ns > nkb ? nkb : ns);
       int per = cdiv(nkb, ns);
@@ -2912,8 +2947,8 @@ int conv2d_bf16x3_impl(void *stream, const void *x0, int c0, long long bs0, long
   // (swem_split_f16x2_f32; the filters scaled per output column by a power of two that the caller folds into `scale`)
   p.f16 = (p.nplanes == 2 && ((plan >> 18) & 1)) ? 1 : 0;
   SWEM_REQUIRE(!((plan >> 18) & 1) || p.nplanes == 2, SWEM_E_ARG, "conv2d_bf16x3: plan bit 18 (fp16 planes) needs math mode 3");
-  SWEM_REQUIRE(pl.wm != 4 || (p.f16 && w_bs == 0 && ((plan >> 24) & 15) == 0), SWEM_E_ARG,
-               "conv2d_bf16x3: the 256x256 tile runs f16x3 plans without per-batch filters, tail split or stream-K");
+  SWEM_REQUIRE(pl.wm != 4 || ((p.f16 || (p.nplanes == 3 && variant == 4 && !glu)) && w_bs == 0 && ((plan >> 24) & 15) == 0), SWEM_E_ARG,
+               "conv2d_bf16x3: the 256-column tiles run f16x3 plans (or bf16x6 with 128-row tiles, no GLU) without per-batch filters, tail split or stream-K");
   const int trows = tile_rows(plan, pl);
   SWEM_REQUIRE(pl.wm != 4 || (trows == 256 && variant == 0) || (trows >= 128 && trows < 256 && trows % 32 == 0 && !glu), SWEM_E_ARG,
                "conv2d_bf16x3: 256-column tile heights are 128, 160, 192, 224 (plan bits 20-23 = rows / 32; no GLU) or 256 (bits 0)");

@@ -1133,6 +1133,11 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False, modes=None):
             tiles = -(-M // rows) * -(-ncols // 256)
             for ns in sorted({1, max(1, min(nkb // 4, 256 // tiles)), max(1, min(nkb // 4, -(-256 // tiles)))}):
                 cands.append(4 | 4 << 4 | ns << 8 | 7 << 16 | v << 20)
+    if 1 in (modes if modes is not None else CONV_MATH_MODES) and TUNE_T256 and ncols >= 192 and not glu:
+        # ... and its bf16x6 form (three planes: 128-row tiles only, plan bits 20-23 = 4)
+        tiles = -(-M // 128) * -(-ncols // 256)
+        for ns in sorted({1, max(1, min(nkb // 4, 256 // tiles)), max(1, min(nkb // 4, -(-256 // tiles)))}):
+            cands.append(4 | 4 << 4 | ns << 8 | 1 << 16 | 4 << 20)
 
     def timed(plan, n):
         launch(plan)                               # warm (also grows the workspace)

@@ -1069,3 +1069,30 @@ def test_conv2d_256_column_tile_properties_at_config_b_size(lib):
     assert torch.equal(ops.conv2d([x.flip(0).contiguous()], pk, relu_out=True, plan=0x770144), y.flip(0))
     assert torch.isfinite(y).all() and float(y.max()) > 0
     ops.check_faults()
+
+@pytest.mark.parametrize('case', [
+    dict(B=2, H=60, W=108, cs=[256], co=256, k=3, s=1, ns=1, relu=True),
+    dict(B=2, H=30, W=54, cs=[512], co=512, k=3, s=1, ns=4, relu=False),
+    dict(B=3, H=17, W=5, cs=[32, 64], co=96, k=3, s=1, ns=1, relu=True),
+    dict(B=2, H=33, W=41, cs=[128], co=256, k=3, s=2, ns=2, relu=False),
+], ids=['mid', 'ksplit4', 'two_src', 'stride2_ksplit'])
+def test_conv2d_256_column_tile_bf16x6(lib, case):
+    """The three-plane (bf16x6: all 24 operand bits) form of conv_t256_kernel -- 128-row tiles, plan math 1, tile 4 x 4, bits 20-23
+    = 4 -- against fp64 and against the library's other bf16x6 kernels on the same planes (same products; the MFMA shape and the
+    partition of the sums may differ: 1e-6 of the range)."""
+    g = torch.Generator().manual_seed(29)
+    B, H_, W_, cs, co, k, s_, ns = (case[n] for n in ('B', 'H', 'W', 'cs', 'co', 'k', 's', 'ns'))
+    C = sum(cs)
+    w = (torch.randn(co, C, k, k, generator=g) * (2.0 / (C * k * k)) ** 0.5)
+    bias = torch.randn(co, generator=g)
+    xs = [torch.randn(B, c, H_, W_, generator=g) for c in cs]
+    pack = ops.pack_conv(w.to(DEV), bias.to(DEV), None, s_, k // 2)
+    ref = F.conv2d(torch.cat(xs, 1).double(), w.double(), bias.double(), stride=s_, padding=k // 2)
+    if case['relu']:
+        ref = ref.relu()
+    srcs = [nhwc(x) for x in xs]
+    y = ops.conv2d(srcs, pack, relu_out=case['relu'], plan=0x410044 | ns << 8)
+    base = ops.conv2d(srcs, pack, relu_out=case['relu'], plan=0x10022 | ns << 8)
+    close(back(y), ref, 2e-6, 'bf16x6 on 128-row tiles against fp64')
+    assert float((y - base).abs().max()) <= 1e-6 * float(base.abs().max())
+    ops.check_faults()

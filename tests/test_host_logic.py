@@ -182,8 +182,9 @@ def test_shipped_plan_file_is_well_formed():
     for k, v in book.conv.items():
         wm, wn, ns, math = v & 15, (v >> 4) & 15, (v >> 8) & 255, (v >> 16) & 7
         # (0 = the tuner found the library's own heuristic -- fp32 MFMA, its choice of tile -- fastest for that shape)
-        # (tile 4 x 4 = the 256-column tiles of conv_t256_kernel, round 5: f16x3 only, bits 20-23 = tile rows / 32 or 0 for 256)
-        t256 = wm == 4 and wn == 4 and math == 7 and (v >> 20) & 15 in (0, 4, 5, 6, 7) and (v >> 24) == 0
+        # (tile 4 x 4 = the 256-column tiles of conv_t256_kernel, round 5: f16x3 with bits 20-23 = tile rows / 32 or 0 for 256;
+        # bf16x6 -- the exact-split leg -- on 128-row tiles only)
+        t256 = wm == 4 and wn == 4 and (v >> 24) == 0 and ((math == 7 and (v >> 20) & 15 in (0, 4, 5, 6, 7)) or (math == 1 and (v >> 20) & 15 == 4))
         assert v == 0 or ((wm in (1, 2) and wn in (1, 2) or t256) and 1 <= ns <= 255), (k, hex(v))
         assert math in ((0, 1) if len(k) == 13 else (0, 1, 7)), (k, hex(v))     # (7 = f16x3: math 3 + SWEM_PLAN_F16)
         cin, cout, kh, kw, stride, pad, flags, B, H, W = k[:10]

@@ -50,13 +50,14 @@ def main():
     new = []
     with torch.no_grad():
         for k, v in d['conv']:
-            glu = bool(len(k) == 10 and k[6] & 4)
-            ok = (len(k) == 10 and (v & 0xff) == 0x22 and (v >> 16) & 7 == 7 and (v >> 24) & 15 == 0 and k[0] % 32 == 0
-                  and k[1] * (2 if glu else 1) >= 192 and not k[6] & 8)
+            glu = bool(k[6] & 4)
+            exact = len(k) == 13 and (v >> 16) & 7 == 1          # the exact-split leg's entries (tag ('math', 0, 1)): bf16x6
+            ok = ((len(k) == 10 and (v >> 16) & 7 == 7 or exact and not glu) and (v & 0xff) == 0x22 and (v >> 24) & 15 == 0
+                  and k[0] % 32 == 0 and k[1] * (2 if glu else 1) >= 192 and not k[6] & 8)
             if not ok:
                 new.append([k, v])
                 continue
-            cin, cout, kh, kw, stride, pad, flags, B, H, W = k
+            cin, cout, kh, kw, stride, pad, flags, B, H, W = k[:10]
             x = torch.randn(B, H, W, cin, device=dev)
             if glu:
                 pack = ops.pack_glu(torch.randn(cout, cin, kh, kw, device=dev) * 0.02, torch.zeros(cout, device=dev),
@@ -68,11 +69,11 @@ def main():
             Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
             M, ncols, nkb = B * Ho * Wo, cout * (2 if glu else 1), kh * kw * cin // 32
             best = None
-            for hv in ((0,) if glu else (0, 4, 5, 6, 7)):
+            for hv in ((4,) if exact else (0,) if glu else (0, 4, 5, 6, 7)):
                 rows = 32 * hv if hv else 256
                 tiles = -(-M // rows) * -(-ncols // 256)
                 for ns in sorted({1, max(1, min(nkb // 4, 256 // tiles)), max(1, min(nkb // 4, -(-256 // tiles)))}):
-                    plan = 4 | 4 << 4 | ns << 8 | 7 << 16 | hv << 20
+                    plan = 4 | 4 << 4 | ns << 8 | (1 if exact else 7) << 16 | hv << 20
                     t = timed(lambda: run(plan))
                     if best is None or t < best[0]:
                         best = (t, plan)

@@ -71,6 +71,28 @@ def main():
             bad += not ok
             print('dgrad %s: rel err vs fp64 %.2e; vs the 128x128 kernel %s %s' % ((B, H, W, c, co, k, s), err,
                                                                                   'IDENTICAL' if same else 'differs', '' if ok else 'FAILED'))
+        # bf16x6 (all 24 operand bits) on 128-row tiles: plan math 1, tile 4 x 4, bits 20-23 = 4 -- against the eight-wave 16x16x32
+        # three-plane kernel (variant 6: the same MFMA shape and order) and fp64
+        for ci, (B, H, W, cs, co, k, s, ns, relu, use_res) in enumerate(CASES):
+            C = sum(cs)
+            w = (torch.randn(co, C, k, k, generator=g) * (2.0 / (C * k * k)) ** 0.5).to(dev)
+            xs = [torch.randn(B, H, W, c, generator=g).to(dev) for c in cs]
+            pack = ops.pack_conv(w, None, None, s, k // 2)
+            y6 = ops.conv2d(xs, pack, relu_out=relu, plan=0x410044 | ns << 8)
+            try:
+                yb = ops.conv2d(xs, pack, relu_out=relu, plan=0x610022 | ns << 8)
+            except Exception:
+                yb = None
+            ref = F.conv2d(torch.cat(xs, 3).permute(0, 3, 1, 2).double(), w.double(), None, stride=s, padding=k // 2).permute(0, 2, 3, 1)
+            if relu:
+                ref = ref.relu()
+            err = float((y6.double() - ref).abs().max() / ref.abs().max())
+            same = yb is not None and torch.equal(y6, yb)
+            d = float((y6 - yb).abs().max() / yb.abs().max()) if yb is not None else float('nan')
+            ok = err < 2e-6 and (yb is None or same or (ns > 1 and d < 1e-6))
+            bad += not ok
+            print('bf16x6 case %d: rel err vs fp64 %.2e; vs the 128x128 three-plane kernel %s (%.1e) %s'
+                  % (ci, err, 'IDENTICAL' if same else ('differs' if yb is not None else 'n/a'), d, '' if ok else 'FAILED'), flush=True)
     print('t256_check: %s' % ('OK' if not bad else '%d cases FAILED' % bad))
     sys.exit(1 if bad else 0)
 
