@@ -89,7 +89,7 @@ def _check_m0(subset, at_least):
         assert body.count('offen lds') == len(uses)            # one M0 write per transfer, nothing else
         checked += 1
         t256 += 'conv_t256_kernel' in name
-    assert checked >= at_least and t256 == 5          # (conv_t256_kernel: the 256-row form and four tile heights)
+    assert checked >= at_least and t256 == 6          # (conv_t256_kernel: the 256-row form, four tile heights, the bf16x6 form)
 
 
 def test_integration_md_binding_matches_the_signature_table(lib):
