@@ -2659,6 +2659,7 @@ int conv2d_f32_impl(void *stream, const float *x0, int c0, long long bs0, const 
   fast_div_make((unsigned)(p.Ho * p.Wo), p.fd_howo_mul, p.fd_howo_sh);
   fast_div_make((unsigned)p.Wo, p.fd_wo_mul, p.fd_wo_sh);
   Plan pl = resolve_plan(plan, p.M, p.Ncols, p.nkb, glu);
+  if (pl.wm == 4) pl = make_plan(p.M, p.Ncols, p.nkb, glu);   // (the 256-column tiles belong to the pre-split kernel: heuristic tile here)
   if (pl.wm == 2 && pl.wn == 1) pl.wm = 1;   // (a 128x64 plan on inputs that are not pre-split: the kernels here have no such tile)
   p.kb_per_split = pl.kb_per_split;
   p.partial = nullptr;

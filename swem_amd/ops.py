@@ -920,7 +920,7 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
             if AUTOTUNE and plan & 0xffff == 0 and not torch.cuda.is_current_stream_capturing():
                 # (a fallback that names a tile is a decision -- batch-invariant plans -- and is not tuned over)
                 plan = BOOK.conv[sig] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
-                                                    -(-pack.kh * pack.kw * cin // 32), pack.glu, fresh_kw=True)
+                                                    -(-pack.kh * pack.kw * cin // 32), pack.glu, fresh_kw=True, t256=presplit_ok)
     if residual is not None and mask is None and not _IN_TUNER[0]:
         rsite = residual.__dict__.get('_swem_site')
         if rsite is not None:
@@ -1076,7 +1076,7 @@ def load_plans(path, book=None):
     return (book or BOOK).load(path)
 
 
-def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False, modes=None):
+def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False, modes=None, t256=True):
     """Time candidate (wave tile, K-split, math mode) plans for one layer shape; return the fastest as a plan hint.
     fresh_kw: the launcher takes fresh=True to re-split its inputs every time (the split cost is then part of the
     bf16x6 candidates' time, as if no other layer shared the input)."""
@@ -1125,7 +1125,7 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False, modes=None):
                                 cands.append(base | 8 << 20 | ts << 24)
                                 if math != 1 and TUNE_ROUND3_FORMS:
                                     cands.append(base | 5 << 20 | ts << 24)
-    if 7 in (modes if modes is not None else CONV_MATH_MODES) and TUNE_T256 and ncols >= 192:
+    if t256 and 7 in (modes if modes is not None else CONV_MATH_MODES) and TUNE_T256 and ncols >= 192:
         # the 256-column tile of conv_t256_kernel (f16x3 only; one block per CU): tile heights 128 .. 256 rows (plan bits
         # 20-23 = rows / 32, 0 = 256: the only GLU form), K-split so that the tiles fill the 256 CUs about once
         for v in ((0,) if glu else (0, 4, 5, 6, 7)):
@@ -1133,7 +1133,7 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False, modes=None):
             tiles = -(-M // rows) * -(-ncols // 256)
             for ns in sorted({1, max(1, min(nkb // 4, 256 // tiles)), max(1, min(nkb // 4, -(-256 // tiles)))}):
                 cands.append(4 | 4 << 4 | ns << 8 | 7 << 16 | v << 20)
-    if 1 in (modes if modes is not None else CONV_MATH_MODES) and TUNE_T256 and ncols >= 192 and not glu:
+    if t256 and 1 in (modes if modes is not None else CONV_MATH_MODES) and TUNE_T256 and ncols >= 192 and not glu:
         # ... and its bf16x6 form (three planes: 128-row tiles only, plan bits 20-23 = 4)
         tiles = -(-M // 128) * -(-ncols // 256)
         for ns in sorted({1, max(1, min(nkb // 4, 256 // tiles)), max(1, min(nkb // 4, -(-256 // tiles)))}):
@@ -1579,7 +1579,8 @@ def _match_plan(key, launch, M, V, nkb):
         # (the pre-split readout has ONE arithmetic, f16x3 on the pack's fp16 value planes: math field 3 selects it whatever
         # two-plane mode the convolutions run)
         modes = tuple(dict.fromkeys(3 if m == 7 else m for m in CONV_MATH_MODES))
-        plan = BOOK.match[key + _PLAN_TAG] = _autotune(launch, M, V, nkb, False, modes=modes)
+        # (the readout is a batched GEMM with per-object filters: no 256-column tiles)
+        plan = BOOK.match[key + _PLAN_TAG] = _autotune(launch, M, V, nkb, False, modes=modes, t256=False)
     return plan & ~(1 << 18)
 
 
