@@ -36,11 +36,12 @@ if [[ $WHAT == *pmc* ]]; then
   # the 256-column tile kernel (round 5) on the same layer: 224-row tiles, and the ten-frame batch on 256-row tiles
   bash tools/pmc_kernels.sh $OUT/conv_pmc_t256.txt conv_t256 python3 tools/conv_bench.py --reps 8 --only 0 --plan 0x770144 > /dev/null
   bash tools/pmc_kernels.sh $OUT/conv_pmc_t256_b10.txt conv_t256 python3 tools/conv_bench.py --reps 8 --only 0 --plan 0x70144 --bmul 5 > /dev/null
+  bash tools/pmc_kernels.sh $OUT/conv_pmc_t256_exact.txt conv_t256 python3 tools/conv_bench.py --reps 8 --only 0 --plan 0x410144 > /dev/null
 fi
 if [[ $WHAT == *em* ]]; then
   bash tools/pmc_kernels.sh $OUT/em_pmc.txt 'em_|match_|conv_igemm' python3 tools/em_loop.py --reps 10 > /dev/null
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/emloop -- python3 tools/em_loop.py --reps 50 > $OUT/emloop.log 2>&1
   cp $(ls $OUT/emloop/*/*kernel_stats.csv | head -1) $OUT/em_loop_kernel_stats.csv; rm -rf $OUT/emloop
 fi
-rm -rf gpurun_out/pmc_conv_pmc gpurun_out/pmc_conv_pmc_exact gpurun_out/pmc_em_pmc gpurun_out/pmc_conv_pmc_t256 gpurun_out/pmc_conv_pmc_t256_b10
+rm -rf gpurun_out/pmc_conv_pmc gpurun_out/pmc_conv_pmc_exact gpurun_out/pmc_em_pmc gpurun_out/pmc_conv_pmc_t256 gpurun_out/pmc_conv_pmc_t256_b10 gpurun_out/pmc_conv_pmc_t256_exact
 ls -la $OUT | head -40
