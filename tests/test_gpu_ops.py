@@ -1096,3 +1096,27 @@ def test_conv2d_256_column_tile_bf16x6(lib, case):
     close(back(y), ref, 2e-6, 'bf16x6 on 128-row tiles against fp64')
     assert float((y - base).abs().max()) <= 1e-6 * float(base.abs().max())
     ops.check_faults()
+
+def test_conv2d_256_column_tiles_reproduce_bitwise_on_concurrent_streams(lib):
+    """Race screen of conv_t256_kernel's hand-over (one barrier per k-block, the next stage's transfers awaited a k-block after they
+    were requested): launches of every form -- tile heights, K-splits (fixed reduction order), bf16x6 -- on two streams at once
+    reproduce, bit for bit, what the same plan gives alone (tools/t256_race_screen.py: the 80-round version)."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 60, 108, 256, generator=g).to(DEV)
+    x2 = torch.randn(2, 30, 54, 512, generator=g).to(DEV)
+    pk = ops.pack_conv((torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(DEV))
+    pk2 = ops.pack_conv((torch.randn(512, 512, 3, 3, generator=g) * 0.02).to(DEV))
+    p1, p2 = (0x770144, 0x70144, 0x570244, 0x470244, 0x410244), (0x570344, 0x70444, 0x470444, 0x410444)
+    r1 = [ops.conv2d([x], pk, plan=p).clone() for p in p1]
+    r2 = [ops.conv2d([x2], pk2, plan=p).clone() for p in p2]
+    torch.cuda.synchronize()
+    s1, s2 = ops.new_stream(), ops.new_stream()
+    for _ in range(12):
+        with torch.cuda.stream(s1):
+            ys = [ops.conv2d([x], pk, plan=p) for p in p1]
+        with torch.cuda.stream(s2):
+            zs = [ops.conv2d([x2], pk2, plan=p) for p in p2]
+        torch.cuda.synchronize()
+        for p, y, r in list(zip(p1, ys, r1)) + list(zip(p2, zs, r2)):
+            assert torch.equal(y, r), hex(p)
+    ops.check_faults()
