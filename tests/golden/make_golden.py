@@ -66,67 +66,107 @@ def import_reference():
     return modules, swem
 
 
+def import_reference_evaluator():
+    """methods/SWEM/swem_evaluator.py itself, so that the fixtures' frame loops are the REFERENCE's own methods
+    (SWEMEvaluator.evaluate_davis_seq :58-102, evaluate_ytvos_seq :104-148) and not a restatement of them.  Its base class
+    (methods/basic_modules/basic_evaluator.py) imports the repo's dataset / utils packages at module level, which pull cv2,
+    tensorboardX, easydict ... -- none of it is used by the two loop methods: empty stand-in MODULES are registered under those
+    names for the duration of the import (build container only; nothing of the reference is written anywhere)."""
+    saved = {k: sys.modules.get(k) for k in ('datasets', 'utils')}
+    ds = types.ModuleType('datasets')
+    ds.DAVIS_Test = ds.YTVOS_Test = None
+    ut = types.ModuleType('utils')
+    for name in ('mkdir', 'init_random_seed', 'setup_logger', 'FrameSecondMeter', 'save_seg_mask', 'save_overlay'):
+        setattr(ut, name, None)
+    sys.modules['datasets'], sys.modules['utils'] = ds, ut
+    try:
+        _load('methods.basic_modules.basic_evaluator', os.path.join(REF, 'methods/basic_modules/basic_evaluator.py'))
+        ev = _load('methods.SWEM.swem_evaluator', os.path.join(REF, 'methods/SWEM/swem_evaluator.py'))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return ev.SWEMEvaluator
+
+
+class _Recorder:
+    """Stands between the reference's loop and the reference's model: forwards every `model(mode, ...)` call unchanged and
+    keeps what the modes returned, frame by frame (the per-stage tensors the fixtures store)."""
+
+    def __init__(self, model):
+        self.model, self.calls = model, []
+
+    def __call__(self, mode, *args):
+        out = self.model(mode, *args)
+        self.calls.append((mode, out))
+        return out
+
+    def trace(self):
+        """One dict per frame 1..t-1 in the layout the fixtures were always written in."""
+        rows, cur = [], None
+        for mode, out in self.calls[3:]:            # (frame 0: encode_key, encode_value, init)
+            if mode == 'encode_key':
+                cur = dict(zip(('qk16', 'qv16', 's16', 's8', 's4'), out), mv16=None)
+                rows.append(cur)
+            elif mode == 'match':
+                cur['context'] = out[0]
+            elif mode == 'segment':
+                cur['logits'] = out[0]
+            elif mode == 'encode_value':
+                cur['mv16'] = out
+        return rows
+
+
+class _Quiet:
+    def info(self, *a, **k):
+        pass
+
+
+_EVALUATOR = []
+
+
+def _reference_self(model):
+    """An instance of the reference's SWEMEvaluator WITHOUT its constructor (which builds datasets, log directories and a
+    model from a config file): the loop methods touch self.model and self.logger.info only."""
+    if not _EVALUATOR:
+        _EVALUATOR.append(import_reference_evaluator())
+    ev = object.__new__(_EVALUATOR[0])
+    ev.model, ev.logger = model, _Quiet()
+    return ev
+
+
 def ref_evaluate_seq(model, frames, init_masks, out_size, trace=None):
-    """The frame loop of swem_evaluator.py:59-102 driven through the REFERENCE model (the evaluator class itself
-    needs cv2/tensorboardX/datasets, so only its loop body is exercised: calls, order and interpolation modes)."""
-    import torch.nn.functional as F
-    b, t, c, h, w = frames.shape
-    preds, scores = [], []
-    mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
-    init_mask = F.interpolate(init_masks[0], size=(h, w), mode='nearest')
-    mv16 = model('encode_value', frames[:, 0], init_mask.float(), s16)
-    model('init', mk16, mv16, init_masks[0])
-    for i in range(1, t):
-        qk16, qv16, s16, s8, s4 = model('encode_key', frames[:, i])
-        context, n = model('match', qk16, qv16)
-        logits, pred_mask = model('segment', n, context, s8, s4, None, out_size)
-        scores.append(pred_mask.clone())
-        pred = torch.argmax(pred_mask, dim=1, keepdim=True)
-        pred_expand = pred.expand(-1, n + 1, -1, -1)
-        obj_idx = torch.arange(n + 1).type(pred.dtype).view(1, -1, 1, 1).expand(b, -1, out_size[0], out_size[1])
-        hard = (pred_expand == obj_idx).type_as(pred)
-        if trace is not None:
-            trace.append({'qk16': qk16, 'qv16': qv16, 's16': s16, 's8': s8, 's4': s4, 'context': context,
-                          'logits': logits, 'mv16': None})
-        if i < t - 1:
-            pm = F.interpolate(pred_mask, size=(h, w), mode='bilinear', align_corners=False)
-            mv16 = model('encode_value', frames[:, i], pm, s16)
-            if trace is not None:
-                trace[-1]['mv16'] = mv16
-            model('memorize', qk16, mv16, hard, pm)
-        preds.append(pred[:, 0])
+    """SWEMEvaluator.evaluate_davis_seq (swem_evaluator.py:58-102), the reference's own method, on `model`."""
+    rec = _Recorder(model)
+    preds, scores = _reference_self(rec).evaluate_davis_seq(frames, init_masks, out_size)
+    if trace is not None:
+        trace.extend(rec.trace())
     return preds, scores
 
 
 def ref_evaluate_ytvos(model, frames, init_masks, out_size):
-    """The frame loop of swem_evaluator.py:104-148 driven through the REFERENCE model (see ref_evaluate_seq)."""
-    import torch.nn.functional as F
-    b, t, c, h, w = frames.shape
-    preds = []
-    mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
-    init_mask = F.interpolate(init_masks[0], size=(h, w), mode='nearest')
-    mv16 = model('encode_value', frames[:, 0], init_mask.float(), s16)
-    model('init', mk16, mv16, init_masks[0])
-    for i in range(1, t):
-        qk16, qv16, s16, s8, s4 = model('encode_key', frames[:, i])
-        context, n = model('match', qk16, qv16)
-        logits, pred_mask = model('segment', n, context, s8, s4, None, out_size)
-        if init_masks[i] is not None:
-            new_objects = torch.sum(init_masks[i][:, 1:], dim=1, keepdim=True)
-            new_objects = new_objects.expand_as(pred_mask)
-            pred_mask[new_objects > 0] = 0
-            pred_mask = torch.cat([pred_mask, init_masks[i][:, 1:]], dim=1)
-            n = pred_mask.shape[1] - 1
-        pred = torch.argmax(pred_mask, dim=1, keepdim=True)
-        pred_expand = pred.expand(-1, n + 1, -1, -1)
-        obj_idx = torch.arange(n + 1).type(pred.dtype).view(1, -1, 1, 1).expand(b, -1, out_size[0], out_size[1])
-        hard = (pred_expand == obj_idx).type_as(pred)
-        if i < t - 1:
-            pm = F.interpolate(pred_mask, size=(h, w), mode='bilinear', align_corners=False)
-            mv16 = model('encode_value', frames[:, i], pm, s16)
-            model('memorize', qk16, mv16, hard, pm)
-        preds.append(pred[:, 0])
-    return preds
+    """SWEMEvaluator.evaluate_ytvos_seq (swem_evaluator.py:104-148), the reference's own method, on `model`."""
+    return _reference_self(model).evaluate_ytvos_seq(frames, init_masks, out_size)
+
+
+class SeededInit:
+    """Re-seeds the global generator before every 'init' (the only mode that draws: modules.py:170-178), so that each pass of a
+    multi-pass evaluation starts from the same random bases."""
+
+    def __init__(self, model, seed):
+        self.model, self.seed = model, seed
+
+    def __call__(self, mode, *a):
+        if mode == 'init':
+            torch.manual_seed(self.seed)
+        return self.model(mode, *a)
+
+
+def ref_evaluate_ms(model, frames, init_masks, out_size, scales, is_flip):
+    """SWEMEvaluator.evaluate_davis_seq_ms (swem_evaluator.py:34-57): multi-scale / flip test-time augmentation."""
+    return _reference_self(model).evaluate_davis_seq_ms(frames, init_masks, out_size, scales=list(scales), is_flip=is_flip)
 
 
 def ytvos_masks(per_frame, appear_at):
@@ -161,8 +201,11 @@ def maxdiff(a, b):
     return float((a - b).abs().max())
 
 
+OUT = os.environ.get('SWEM_GOLDEN_OUT', HERE)     # another directory = regenerate beside the committed fixtures and compare
+
+
 def save(name, **arrs):
-    path = os.path.join(HERE, name)
+    path = os.path.join(OUT, name)
     np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
                                  for k, v in arrs.items()})
     print('  wrote %-28s %7.1f KB' % (name, os.path.getsize(path) / 1024))
@@ -183,7 +226,7 @@ def dump_keys(Rswem):
         out[tag] = {k: list(v.shape) for k, v in ref.state_dict().items()
                     if not (k.startswith('key_encoder.') and k.endswith('.bias') and '.bn' not in k
                             and 'downsample.1' not in k)}
-    with open(os.path.join(HERE, 'g0_state_dict_keys.json'), 'w') as f:
+    with open(os.path.join(OUT, 'g0_state_dict_keys.json'), 'w') as f:
         json.dump(out, f, indent=0, sort_keys=True)
     print('  wrote g0_state_dict_keys.json', {k: len(v) for k, v in out.items()})
 
@@ -381,33 +424,13 @@ def main():
     out = {'seed': 31, 'wseed': 5, 'agree64': np.array(agree64)}
     for i, pr in enumerate(rp):
         out['pred%d' % i] = pr.to(torch.uint8)
-    # test-time augmentation (swem_evaluator.py:34-57) on the 2-object DAVIS-style clip: reference evaluator body restated
-    import torch.nn.functional as F
+    # test-time augmentation on the 2-object DAVIS-style clip: the reference's own evaluate_davis_seq_ms (swem_evaluator.py:34-57),
+    # every pass from the same seeded random bases
     m0 = per_frame[0]
     tfr = frames[:, :3]
     with torch.no_grad():
-        final = [0, 0]
-        for scale in (240, 288):
-            hh, ww = scale, int((scale / 480) * 864)
-            fr = F.interpolate(tfr[0], size=(hh, ww), mode='bicubic', align_corners=False).unsqueeze(0)
-            torch.manual_seed(79)
-            _, sc = ref_evaluate_seq(ref, fr, [m0, None, None], (240, 432))
-            ff = torch.flip(fr, dims=[-1])
-            torch.manual_seed(79)
-            _, fs = ref_evaluate_seq(ref, ff, [torch.flip(m0, dims=[-1])], (240, 432))
-            sc = [(a + torch.flip(b_, dims=[-1])) / 2 for a, b_ in zip(sc, fs)]
-            final = [f + s_ / 2 for f, s_ in zip(final, sc)]
-        tta_ref = [torch.argmax(f, dim=1) for f in final]
-
-        class _Seeded:      # the oracle's evaluate_seq_ms runs 4 passes: reseed before each like the reference run above
-            def __init__(self, m):
-                self.m = m
-
-            def __call__(self, mode, *a):
-                if mode == 'init':
-                    torch.manual_seed(79)
-                return self.m(mode, *a)
-        tta_orc = O.evaluate_seq_ms(_Seeded(O.Model(sd, cfg)), tfr, [m0, None, None], (240, 432), scales=(240, 288),
+        tta_ref = ref_evaluate_ms(SeededInit(ref, 79), tfr, [m0, None, None], (240, 432), scales=(240, 288), is_flip=True)
+        tta_orc = O.evaluate_seq_ms(SeededInit(O.Model(sd, cfg), 79), tfr, [m0, None, None], (240, 432), scales=(240, 288),
                                     is_flip=True)
     for a, b_ in zip(tta_ref, tta_orc):
         assert torch.equal(a, b_)
@@ -426,6 +449,25 @@ def main():
         run_clip(dict(BACKBONE='resnet50', NUM_BASES=256, NUM_EM_ITERS=5, SINGLE_OBJ=False), 4, 480, 864, 2,
                  (480, 854), seed=123, wseed=3, tag='g7_configB', sub=8, double_floor=True)
     print('done')
+    if OUT != HERE:
+        compare_with_committed()
+
+
+def compare_with_committed():
+    """Every array of every regenerated fixture against the committed file of the same name, bit for bit (the .npz containers
+    themselves differ in their zip timestamps)."""
+    bad = 0
+    for name in sorted(os.listdir(OUT)):
+        if not name.endswith('.npz'):
+            continue
+        new, old = np.load(os.path.join(OUT, name)), np.load(os.path.join(HERE, name))
+        same = set(new.files) == set(old.files) and all(
+            new[k].dtype == old[k].dtype and new[k].shape == old[k].shape and np.array_equal(new[k], old[k], equal_nan=True)
+            for k in new.files)
+        print('  %-28s %3d arrays  %s' % (name, len(new.files), 'IDENTICAL to the committed fixture' if same else 'DIFFERS'))
+        bad += not same
+    if bad:
+        raise SystemExit('%d regenerated fixtures differ from the committed ones' % bad)
 
 
 if __name__ == '__main__':

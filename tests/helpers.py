@@ -31,7 +31,7 @@ def clip_from_fixture(fx):
     return frames, m0
 
 
-ROUND = 'r05'
+ROUND = 'r06'
 ARITH_MODES = ('fp32', 'f16x3', 'bf16x3', 'tuned')
 
 
@@ -211,63 +211,44 @@ def trainable_sd(sd, model):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
-# The reference's evaluator loops AS ITS AUTHORS WROTE THEM -- the loop bodies of swem_evaluator.py:58-102 (DAVIS) and
-# :104-148 (YouTube-VOS), ATen glue included (F.interpolate, torch.argmax, the one-hot compare, the in-place injection
-# `pred_mask[new_objects > 0] = 0` + torch.cat), driven through whatever `model` is.  tests/golden/make_golden.py runs the
-# same bodies through the REFERENCE model to record the fixtures; tests/test_gpu_dropin.py runs them through swem_amd.SWEM on
-# the GPU: what a maintainer gets who only swaps the import and keeps the evaluator file.
-def reference_loop_davis(model, frames, init_masks, out_size):
+# A per-sequence driver built from FOREIGN torch ops, for the drop-in tests (tests/test_gpu_dropin.py).  What it stands for: a
+# maintainer who swaps the import keeps an evaluator that glues the model's outputs together with
+# ATen -- resampling with F.interpolate, an argmax, a one-hot of the index map, an in-place overwrite of the probability map the
+# model returned, a torch.cat that grows it.  The call order it has to follow (swem_evaluator.py:59-148: key -> match -> segment
+# -> [resample -> value -> memorize] on all but the last frame, late annotations injected before the argmax) is not asserted
+# here: the REFERENCE's recorded index maps and logits (fixtures g6 / g7 / g8, written by the reference's own evaluator methods,
+# tests/golden/make_golden.py) are the judge of it -- a wrong order or resampling mode does not reproduce them.
+def aten_glue_loop(model, clip, annotations, out_hw, keep_scores=False):
+    """clip (1,T,3,H,W); annotations: one (1,N+1,Ho,Wo) mask tensor or None per frame (entry 0 = the first frame's objects;
+    a later entry = objects annotated for the first time at that frame, YouTube-VOS style).  Returns (index maps, scores):
+    T-1 int64 maps (1,Ho,Wo) and, with keep_scores, per frame (probabilities, logits) cloned before anything overwrites them."""
     import torch.nn.functional as F
-    preds, pred_scores = [], []
-    b, t, c, h, w = frames.shape
-    mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
-    init_mask = F.interpolate(init_masks[0], size=(h, w), mode='nearest')
-    mv16 = model('encode_value', frames[:, 0], init_mask.float(), s16)
-    model('init', mk16, mv16, init_masks[0])
-    for i in range(1, t):
-        qk16, qv16, s16, s8, s4 = model('encode_key', frames[:, i])
-        context, n = model('match', qk16, qv16)
-        logits, pred_mask = model('segment', n, context, s8, s4, None, out_size)
-        pred_scores.append((pred_mask.clone(), logits.clone()))
-        pred = torch.argmax(pred_mask, dim=1, keepdim=True)
-        pred_expand = pred.expand(-1, n + 1, -1, -1)
-        obj_idx = torch.arange(n + 1).type(pred.dtype).to(pred.device)
-        obj_idx = obj_idx.view(1, -1, 1, 1).expand(b, -1, out_size[0], out_size[1])
-        hard_pred_mask = (pred_expand == obj_idx).type_as(pred)
-        if i < t - 1:
-            pred_mask = F.interpolate(pred_mask, size=(h, w), mode='bilinear', align_corners=False)
-            mv16 = model('encode_value', frames[:, i], pred_mask, s16)
-            model('memorize', qk16, mv16, hard_pred_mask, pred_mask)
-        preds.append(pred[:, 0])
-    return preds, pred_scores
-
-
-def reference_loop_ytvos(model, frames, init_masks, out_size):
-    import torch.nn.functional as F
-    preds = []
-    b, t, c, h, w = frames.shape
-    mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
-    init_mask = F.interpolate(init_masks[0], size=(h, w), mode='nearest')
-    mv16 = model('encode_value', frames[:, 0], init_mask.float(), s16)
-    model('init', mk16, mv16, init_masks[0])
-    for i in range(1, t):
-        qk16, qv16, s16, s8, s4 = model('encode_key', frames[:, i])
-        context, n = model('match', qk16, qv16)
-        logits, pred_mask = model('segment', n, context, s8, s4, None, out_size)
-        if init_masks[i] is not None:
-            new_objects = torch.sum(init_masks[i][:, 1:], dim=1, keepdim=True)
-            new_objects = new_objects.expand_as(pred_mask)
-            pred_mask[new_objects > 0] = 0
-            pred_mask = torch.cat([pred_mask, init_masks[i][:, 1:]], dim=1)
-            n = pred_mask.shape[1] - 1
-        pred = torch.argmax(pred_mask, dim=1, keepdim=True)
-        pred_expand = pred.expand(-1, n + 1, -1, -1)
-        obj_idx = torch.arange(n + 1).type(pred.dtype).to(pred.device)
-        obj_idx = obj_idx.view(1, -1, 1, 1).expand(b, -1, out_size[0], out_size[1])
-        hard_pred_mask = (pred_expand == obj_idx).type_as(pred)
-        if i < t - 1:
-            pred_mask = F.interpolate(pred_mask, size=(h, w), mode='bilinear', align_corners=False)
-            mv16 = model('encode_value', frames[:, i], pred_mask, s16)
-            model('memorize', qk16, mv16, hard_pred_mask, pred_mask)
-        preds.append(pred[:, 0])
-    return preds
+    n_frames = clip.shape[1]
+    H, W = clip.shape[-2:]
+    image = clip[:, 0]
+    key, _, feat16, _, _ = model('encode_key', image)
+    seen = annotations[0]
+    value = model('encode_value', image, F.interpolate(seen, size=(H, W), mode='nearest').float(), feat16)
+    model('init', key, value, seen)
+    index_maps, scores = [], []
+    for f in range(1, n_frames):
+        image = clip[:, f]
+        key, qvalue, feat16, feat8, feat4 = model('encode_key', image)
+        context, n_obj = model('match', key, qvalue)
+        logits, prob = model('segment', n_obj, context, feat8, feat4, None, out_hw)
+        if keep_scores:
+            scores.append((prob.clone(), logits.clone()))
+        late = annotations[f] if f < len(annotations) else None
+        if late is not None:
+            fresh = late[:, 1:]                                          # the new objects' masks (channel 0 is background)
+            prob.masked_fill_(fresh.sum(dim=1, keepdim=True) > 0, 0)    # in place, on the tensor the model handed out
+            prob = torch.cat((prob, fresh), dim=1)
+            n_obj = prob.shape[1] - 1
+        idx = prob.argmax(dim=1)
+        index_maps.append(idx)
+        if f == n_frames - 1:
+            break                                                        # the last frame is not memorized
+        onehot = F.one_hot(idx, n_obj + 1).permute(0, 3, 1, 2).contiguous()           # int64, as the index map
+        soft = F.interpolate(prob, size=(H, W), mode='bilinear', align_corners=False)
+        model('memorize', key, model('encode_value', image, soft, feat16), onehot, soft)
+    return index_maps, scores

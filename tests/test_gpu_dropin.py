@@ -1,7 +1,8 @@
-"""GPU: the drop-in claim, literally.  The reference's evaluator loops -- their bodies as written,
-with their ATen glue (tests/helpers.py: reference_loop_davis / reference_loop_ytvos, swem_evaluator.py:58-148) -- run against
-`swem_amd.SWEM` and are held to the bars of the product's own evaluator (tests/test_gpu_model.py::test_clip_vs_golden,
-::test_ytvos_loop_and_tta_vs_golden) against the REFERENCE's recorded outputs.  What is exercised beyond the product's own loop:
+"""GPU: the drop-in claim.  A per-sequence driver made of foreign ATen ops (tests/helpers.py:
+aten_glue_loop -- the glue a maintainer's own evaluator applies between the model's modes, swem_evaluator.py:59-148) runs against
+`swem_amd.SWEM` and is held to the bars of the product's own evaluator (tests/test_gpu_model.py::test_clip_vs_golden,
+::test_ytvos_loop_and_tta_vs_golden) against the REFERENCE's recorded outputs (fixtures g6 / g7 / g8, written by the reference's own
+evaluator methods: the call order is pinned by them, not by a transcription).  What is exercised beyond the product's own loop:
 the NCHW-shaped channels-last views the model hands out go through foreign ops (F.interpolate, argmax, clone, in-place masked
 assignment, cat) and come back as ordinary ATen tensors (int64 one-hot masks, a contiguous NCHW probability map)."""
 import time
@@ -31,7 +32,7 @@ def test_reference_davis_loop_on_the_hip_model(lib, golden, name, kw, sub, mode)
     out = (int(fx['out_h']), int(fx['out_w']))
     with torch.no_grad(), H.arith(mode, model, need_bf16x3=name.startswith('g7')):
         torch.manual_seed(77)
-        preds, scores = H.reference_loop_davis(model, frames.to(DEV), [m0.to(DEV)] + [None] * (t - 1), out)
+        preds, scores = H.aten_glue_loop(model, frames.to(DEV), [m0.to(DEV)] + [None] * (t - 1), out, keep_scores=True)
     torch.cuda.synchronize()
     ops.check_faults()
     floor, agree64 = fx['floor64'], fx['agree64']
@@ -50,8 +51,8 @@ def test_reference_davis_loop_on_the_hip_model(lib, golden, name, kw, sub, mode)
 
 
 def test_reference_ytvos_loop_on_the_hip_model(lib, golden):
-    """swem_evaluator.py:104-148 as written: the in-place `pred_mask[new_objects > 0] = 0` hits the probability map the decode
-    head returned, torch.cat grows it, and the model memorizes a mask with an object it has no bases for yet."""
+    """The YouTube-VOS case of swem_evaluator.py:104-148: an in-place masked overwrite hits the probability map the decode head
+    returned, torch.cat grows it, and the model memorizes a mask with an object it has no bases for yet."""
     from swem_amd import synth
     fx = golden('g8_ytvos_tta.npz')
     cfg = O.make_cfg(**CFG_A)
@@ -60,7 +61,7 @@ def test_reference_ytvos_loop_on_the_hip_model(lib, golden):
     masks = [None if m is None else m.to(DEV) for m in H.ytvos_masks(per_frame, 2)]
     with torch.no_grad(), H.arith('f16x3', model):
         torch.manual_seed(78)
-        preds = H.reference_loop_ytvos(model, frames.to(DEV), masks, (240, 432))
+        preds, _ = H.aten_glue_loop(model, frames.to(DEV), masks, (240, 432))
     torch.cuda.synchronize()
     agrees = []
     for i, p in enumerate(preds):
@@ -71,7 +72,7 @@ def test_reference_ytvos_loop_on_the_hip_model(lib, golden):
 
 
 def test_reference_loop_throughput_at_480p(lib):
-    """The number INTEGRATION.md quotes for 'the reference's loop as written' on the HIP model: config B, shipped plans, eager
+    """The number INTEGRATION.md quotes for 'a reference-style evaluator loop (eager, ATen glue between the modes)' on the HIP model: config B, shipped plans, eager
     launches, one frame at a time, ATen glue included -- measured, and with the masks of the product's own loop."""
     from swem_amd import evaluator, synth
     cfg = O.make_cfg(**CFG_B)
@@ -85,13 +86,13 @@ def test_reference_loop_throughput_at_480p(lib):
         own, _ = evaluator.evaluate_davis_seq(model, frames, masks, (480, 854))
         own = [p.clone() for p in own]
         torch.manual_seed(5)
-        H.reference_loop_davis(model, frames, masks, (480, 854))           # warm (hints, planes-only outputs)
+        H.aten_glue_loop(model, frames, masks, (480, 854))                 # warm (hints, planes-only outputs)
         torch.cuda.synchronize()
         best = None
         for _ in range(3):
             torch.manual_seed(5)
             t0 = time.perf_counter()
-            preds, _ = H.reference_loop_davis(model, frames, masks, (480, 854))
+            preds, _ = H.aten_glue_loop(model, frames, masks, (480, 854))
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
@@ -101,9 +102,9 @@ def test_reference_loop_throughput_at_480p(lib):
     for i, (a, b) in enumerate(zip(preds, own)):
         assert float((a == b).float().mean()) >= (0.9995 if i < 2 else 0.99), i
     fps = frames.shape[1] / best          # basic_evaluator.py:171-176: every frame of the sequence counts, frame 0 too
-    print('reference loop as written on swem_amd.SWEM, 480p, 2 objects: %.1f frames/s' % fps)
+    print('reference-style eager loop (ATen glue) on swem_amd.SWEM, 480p, 2 objects: %.1f frames/s' % fps)
     H.record_parity('dropin_reference_loop_480p_fps', {'frames_per_s': fps, 'frames': int(frames.shape[1]),
-                                                      'launch': 'eager, one frame at a time, ATen glue of the reference loop'})
+                                                      'launch': 'eager, one frame at a time, ATen glue between the modes'})
     assert fps > 100
 
 

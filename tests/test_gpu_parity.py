@@ -105,6 +105,22 @@ def oracle_trajectory(key, om, frames, m0, out, fixture=None, seed=77):
 TIGHT_B = {'fp32': (2e-4, 4, 2e-5), 'f16x3': (2e-4, 4, 2e-5), 'tuned': (2e-4, 4, 2e-5), 'bf16x3': (1e-3, 8, 6e-5)}
 
 
+def index_ties(pred, opred, oprob, dprob, what):
+    """"Bit-exact index maps" with ties told apart from bugs: every pixel whose index differs from the
+    oracle's must be an argmax NEAR-TIE of the oracle itself -- the gap between the oracle's two largest probabilities at that
+    pixel no larger than twice the probability difference this very frame measured between the two implementations (`dprob`).
+    A differing pixel anywhere else is a wrong index, whatever the count.  Returns the measured gaps for the parity record."""
+    diff = pred != opred
+    if not bool(diff.any()):
+        return {'index_diff_oracle_top2_gap_max': 0.0, 'index_diffs_all_near_ties': True}
+    top2 = oprob.topk(2, dim=1).values
+    gaps = (top2[:, 0] - top2[:, 1])[diff]
+    worst = float(gaps.max())
+    assert worst <= 2.0 * dprob, ('%s: %d index-map pixels differ and the oracle\'s top-2 probability gap there reaches %.3g > 2 x '
+                                  '|dprob| = %.3g: not a tie' % (what, int(diff.sum()), worst, 2.0 * dprob))
+    return {'index_diff_oracle_top2_gap_max': worst, 'index_diffs_all_near_ties': True}
+
+
 def teacher_forced_clip(model, steps, frames, out, tol=1e-3, tight=None):
     """Frame by frame, the HIP model from the oracle's memory: banks injected before the frame, then encode_key -> match ->
     segment on the HIP side (logits, probabilities, index map) and memorize from the oracle's inputs (bases).  Returns one
@@ -180,6 +196,7 @@ def teacher_forced_clip(model, steps, frames, out, tol=1e-3, tight=None):
                 i, row['dprob_max'], row['dprob_beyond_bound'])
             assert agree >= 0.9995, 'frame %d index agreement %.6f' % (i, agree)
             row['index_pixels_differing'] = int((pred.cpu() != opred).sum())
+            row.update(index_ties(pred.cpu(), opred, oprob, row['dprob_max'], 'frame %d' % i))
             if tight is not None:
                 t_excess, t_pix, t_ctx = tight
                 assert excess <= t_excess, 'frame %d: logit excess over the ulp term %.3g > %.1g (regression bar)' % (i, excess, t_excess)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where the HOST time of an eager frame goes (the reference's loop as written is host-bound: ~300 library calls per frame):
-cProfile over a few frames of tests/helpers.py::reference_loop_davis at config B.   python tools/host_profile.py [--frames 6]"""
+cProfile over a few frames of tests/helpers.py::aten_glue_loop at config B.   python tools/host_profile.py [--frames 6]"""
 import argparse
 import cProfile
 import os
@@ -30,10 +30,10 @@ def main():
     frames, m0 = frames.to(dev), m0.to(dev)
     masks = [m0] + [None] * (a.frames - 1)
     with torch.no_grad():
-        H.reference_loop_davis(model, frames, masks, bench.OUT_HW)
+        H.aten_glue_loop(model, frames, masks, bench.OUT_HW)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        H.reference_loop_davis(model, frames, masks, bench.OUT_HW)
+        H.aten_glue_loop(model, frames, masks, bench.OUT_HW)
         t_host = time.perf_counter() - t0          # (enqueue only)
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
@@ -41,7 +41,7 @@ def main():
               % (a.frames, 1e3 * t_host / a.frames, 1e3 * t_all / a.frames, a.frames / t_all))
         pr = cProfile.Profile()
         pr.enable()
-        H.reference_loop_davis(model, frames, masks, bench.OUT_HW)
+        H.aten_glue_loop(model, frames, masks, bench.OUT_HW)
         pr.disable()
         torch.cuda.synchronize()
     pstats.Stats(pr).sort_stats('tottime').print_stats(28)
