@@ -47,6 +47,17 @@ int swem_vos_loss_frame_bwd_f32(void *stream, const float *prob, const float *ra
  *   p *= 1 - lr*wd;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps) */
 int swem_adamw_f32(void *stream, float *p, const float *g, float *m, float *v, long long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step);
+/* The same update behind a device-side GATE -- the counterpart of GradScaler's found_inf (basic_trainer.py:222-223 steps the
+ * optimizer through one): `gate` points at `ngate` device floats; if any is non-zero when the launch runs, p, m and v are left
+ * untouched.  applied (optional device int): incremented once by every launch that did update.  The trainer feeds the gate from
+ * swem_fault_flags_f32 below, all-reduced with the loss scalars, so every rank skips the same steps and no update is ever made
+ * from gradients a faulted launch produced -- without a host synchronisation per step. */
+int swem_adamw_gated_f32(void *stream, float *p, const float *g, float *m, float *v, long long n, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int step, const float *gate, int ngate, int *applied);
+/* The device's sticky fault word (swem_hip.h, "Asynchronous faults") as two floats, in stream order behind the step's launches:
+ * flags2[0] = 1 if SWEM_FAULT_RANGE is set, flags2[1] = 1 if any other fault bit is set (else 0).  Floats, so that they travel in
+ * the same SUM all-reduce as the loss scalars (swem_trainer.py:41-43, basic_trainer.py:105-110). */
+int swem_fault_flags_f32(void *stream, const unsigned *fault, float *flags2);
 
 /* ------------------------------------------------------------------------------------
  * Convolution backward.  The DATA gradient is swem_conv2d_nhwc_f32 / _bf16x3 themselves with SWEM_CONV_DGRAD
@@ -112,6 +123,10 @@ int swem_colsum_f32(void *stream, const float *a, const float *b, float *out1, f
                     int accumulate, void *ws, size_t ws_bytes);
 /* y[i] (+)= sum_b x[b][i], i < n: gradient of a map shared by the B objects of a frame */
 int swem_sum_batch_f32(void *stream, const float *x, float *y, int B, long long n, int accumulate);
+/* Clip-batched step (swem_trainer.py:60-90 runs the B clips of a GPU as one tensor): a map shared by the N objects of each of
+ * G clips, laid out once per object -- y[g N + j][i] = x[g][i], i < n -- and its gradient y[g][i] = sum_j x[g N + j][i] */
+int swem_expand_groups_f32(void *stream, const float *x, float *y, int G, int N, long long n);
+int swem_sum_groups_f32(void *stream, const float *x, float *y, int G, int N, long long n);
 
 /* ------------------------------------------------------------------------------------
  * Frozen BatchNorm (+ residual, ReLU) as a stage of its own: training keeps the raw convolution output c for the

@@ -78,6 +78,8 @@ SIGNATURES = {
     'swem_vos_loss_reduce_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _ll, _ll, _p, _f]),
     'swem_vos_loss_frame_bwd_f32': (_i, [_p, _p, _p, _p, _ll, _p, _p, _p, _p, _i, _i, _i, _ll, _ll, _p, _f, _p]),
     'swem_adamw_f32': (_i, [_p, _p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i]),
+    'swem_adamw_gated_f32': (_i, [_p, _p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _p, _i, _p]),
+    'swem_fault_flags_f32': (_i, [_p, _p, _p]),
     'swem_memorize_train_f32': (_i, [_p] * 11 + [_i] * 6 + [_f, _p, _sz]),
     'swem_nu_update_bwd_workspace': (_sz, [_i, _i, _i, _i]),
     'swem_nu_update_bwd_f32': (_i, [_p] * 7 + [_i] * 4 + [_p, _sz]),
@@ -95,6 +97,8 @@ SIGNATURES = {
     'swem_colsum_workspace': (_sz, [_ll, _i]),
     'swem_colsum_f32': (_i, [_p, _p, _p, _p, _p, _ll, _i, _i, _p, _sz]),
     'swem_sum_batch_f32': (_i, [_p, _p, _p, _i, _ll, _i]),
+    'swem_expand_groups_f32': (_i, [_p, _p, _p, _i, _i, _ll]),
+    'swem_sum_groups_f32': (_i, [_p, _p, _p, _i, _i, _ll]),
     'swem_bn_act_f32': (_i, [_p, _p, _p, _p, _p, _p, _ll, _i, _i, _p]),
     'swem_bn_act_planes_f32': (_i, [_p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _i, _p]),
     'swem_bn_act_bwd_amax_parts': (_i, [_ll, _i]),

@@ -168,6 +168,9 @@ def _wgrad(dy, srcs, weight, stride, pad, relu_in):
     kh, kw = weight.shape[2:]
     cs = [s.shape[3] for s in srcs]
     math = wgrad_math(cs, Cout, kh, kw, B * Ho * Wo)
+    if ops.FLOPS is not None:
+        ops.FLOPS['conv_wgrad'] = ops.FLOPS.get('conv_wgrad', 0.0) + 2.0 * B * Ho * Wo * Cout * kh * kw * sum(cs)
+        ops.FLOPS['wgrad_launches'] = ops.FLOPS.get('wgrad_launches', 0) + 1
     args = []
     npl = ops.PLANES_F16 if math == 3 else 3
     for s in srcs:
@@ -420,26 +423,60 @@ def concat2(x0, x1, batch):
 
 
 class _Unbatch(Function):
-    """(n, ...) -> n tensors (1, ...): the frames of a clip go through the key encoder in ONE pass (BatchNorm is frozen, so a
-    sample's result does not depend on its batch mates) and are handed to the frame loop one by one; the backward puts
-    the frames' gradients back side by side (zeros for a frame whose output was not used)."""
+    """(n * G, ...) -> n tensors (G, ...): the frames of a clip -- of the G clips a lane steps as one batch, frame-major -- go
+    through the key encoder in ONE pass (BatchNorm is frozen, so a sample's result does not depend on its batch mates) and are
+    handed to the frame loop one by one, as views (no copy: nothing modifies them in place); the backward puts the frames'
+    gradients back side by side (zeros for a frame whose output was not used)."""
 
     @staticmethod
     def forward(ctx, x, n):
-        ctx.meta = (x.shape, n)
-        return tuple(x[i:i + 1].clone() for i in range(n))
+        G = x.shape[0] // n
+        ctx.meta = (x.shape, n, G)
+        return tuple(x[i * G:(i + 1) * G] for i in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
-        shape, n = ctx.meta
+        shape, n, G = ctx.meta
         ref = next(g for g in grads if g is not None)
-        parts = [g if g is not None else torch.zeros((1,) + tuple(shape[1:]), dtype=ref.dtype, device=ref.device)
+        parts = [g if g is not None else torch.zeros((G,) + tuple(shape[1:]), dtype=ref.dtype, device=ref.device)
                  for g in grads]
         return torch.cat(parts, 0), None
 
 
 def unbatch(x, n):
     return _Unbatch.apply(x, n)
+
+
+class _ExpandObjects(Function):
+    """(G, ...) -> (G * N, ...), item g repeated for its N objects (train.py, clip-batched step): the reference broadcasts such
+    maps inside its ops (networks.py:119-121 `f16.unsqueeze(1).expand`, modules.py:287-289 `qv.unsqueeze(1).expand`); here the G
+    clips' objects form ONE convolution batch, so the shared map is laid out per object.  Backward: the N copies' gradients
+    summed in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, x, N):
+        G = x.shape[0]
+        n = x.numel() // G
+        ctx.meta = (x.shape, N)
+        y = torch.empty((G * N,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        _lib.call('swem_expand_groups_f32', ops._stream(), x.contiguous().data_ptr(), y.data_ptr(), G, N, n)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, N = ctx.meta
+        G = shape[0]
+        dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+        _lib.call('swem_sum_groups_f32', ops._stream(), dy.contiguous().data_ptr(), dx.data_ptr(), G, N, dx.numel() // G)
+        return dx, None
+
+
+def expand_objects(x, N):
+    """x (G, ...) shared by the N objects of each of its G items -> (G * N, ...); G == 1 or N == 1: x itself (conv2d / concat2 /
+    upsample_add broadcast a batch-1 source over their `batch` without a copy)."""
+    if x.shape[0] == 1 or N == 1:
+        return x
+    return _ExpandObjects.apply(x, N)
 
 
 class _GLU(Function):
@@ -571,41 +608,61 @@ def prep_value_input(frame, masks, mean3, std3, single_obj):
 
 # --------------------------------------------------------------------------------------------- EM value update, matching
 class _Memorize(Function):
-    """SWEMCore.swem (modules.py:129-168) for the N objects of one clip.  x (P,C) raw key (no gradient: the E/M/W steps
-    run under no_grad), v (N,P,V) value map, masks (N,2,P), prior bases.  Gradient flows v -> nu and nu_prev -> nu."""
+    """SWEMCore.swem (modules.py:129-168) for the N objects of each of G clips (the reference's `B` dimension; G = 1 when x is
+    (P,C)).  x (G,P,C) raw key (no gradient: the E/M/W steps run under no_grad), v (G*N,P,V) value map, masks (G*N,2,P), prior
+    bases (G*N, ...).  Gradient flows v -> nu and nu_prev -> nu.  Clips are independent problems: one library call per clip on
+    that clip's slices (EM + matching are 2 % of the step; the convolutions around them run the G clips as one batch)."""
 
     @staticmethod
     def forward(ctx, v, nu_prev, x, masks, kappa_prev, zita_prev, T, tau):
-        N, P, V = v.shape
-        Cc = x.shape[1]
+        GN, P, V = v.shape
+        G = 1 if x.dim() == 2 else x.shape[0]
+        N = GN // G
+        Cc = x.shape[-1]
         L = kappa_prev.shape[-1]
         dev = v.device
+        for t_, nm in ((v, 'v'), (nu_prev, 'nu_prev'), (x, 'x'), (masks, 'masks'), (kappa_prev, 'kappa_prev'), (zita_prev, 'zita_prev')):
+            if not t_.is_contiguous():
+                raise _lib.SwemHipError('memorize: %s must be contiguous' % nm)
         kappa = torch.empty_like(kappa_prev)
         nu = torch.empty_like(nu_prev)
         zita = torch.empty_like(zita_prev)
-        zT = torch.empty((N, _lib.query('swem_em_pad', P), 2 * L), dtype=torch.float32, device=dev)   # pixel-major z
+        Pz = _lib.query('swem_em_pad', P)
+        zT = torch.empty((GN, Pz, 2 * L), dtype=torch.float32, device=dev)   # pixel-major z
         wsb = _lib.query('swem_memorize_workspace', N, Cc, V, P, L)
         ws = _ws(wsb, dev)
-        _lib.call('swem_memorize_train_f32', ops._stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(),
-                  kappa_prev.data_ptr(), nu_prev.data_ptr(), zita_prev.data_ptr(), kappa.data_ptr(), nu.data_ptr(),
-                  zita.data_ptr(), zT.data_ptr(), N, Cc, V, P, L, T, tau, ws.data_ptr(), wsb)
+        st = ops._stream()
+        for g in range(G):
+            o = 4 * g * N                       # byte offset of clip g's first object, per element of an object's slice
+            _lib.call('swem_memorize_train_f32', st, x.data_ptr() + 4 * g * P * Cc, v.data_ptr() + o * P * V,
+                      masks.data_ptr() + o * 2 * P, kappa_prev.data_ptr() + o * 2 * Cc * L, nu_prev.data_ptr() + o * 2 * V * L,
+                      zita_prev.data_ptr() + o * 2 * L, kappa.data_ptr() + o * 2 * Cc * L, nu.data_ptr() + o * 2 * V * L,
+                      zita.data_ptr() + o * 2 * L, zT.data_ptr() + o * Pz * 2 * L, N, Cc, V, P, L, T, tau, ws.data_ptr(), wsb)
+        if ops.FLOPS is not None:     # SURVEY 8d: F_mem = 4 P L (C (3T - 1) + V) per object; the value update's backward: two GEMMs of 4 V P L
+            ops.FLOPS['em_match'] = ops.FLOPS.get('em_match', 0.0) + GN * 4.0 * P * L * (Cc * (3 * T - 1) + V) + GN * 8.0 * V * P * L
         ctx.save_for_backward(zT, zita_prev, zita)
-        ctx.dims = (N, P, V, L)
+        ctx.dims = (G, N, P, V, L)
         ctx.mark_non_differentiable(kappa, zita)
         return kappa, nu, zita
 
     @staticmethod
     def backward(ctx, dkappa, dnu, dzita):
         zT, zita_prev, zita = ctx.saved_tensors
-        N, P, V, L = ctx.dims
+        G, N, P, V, L = ctx.dims
         dev = zT.device
-        dv = torch.empty((N, P, V), dtype=torch.float32, device=dev)
+        dv = torch.empty((G * N, P, V), dtype=torch.float32, device=dev)
         want_prev = ctx.needs_input_grad[1]
+        dnu = dnu.contiguous()
         dnu_prev = torch.empty_like(dnu) if want_prev else None
         wsb = _lib.query('swem_nu_update_bwd_workspace', N, V, P, L)
         ws = _ws(wsb, dev)
-        _lib.call('swem_nu_update_bwd_f32', ops._stream(), zT.data_ptr(), zita_prev.data_ptr(), zita.data_ptr(),
-                  dnu.contiguous().data_ptr(), dv.data_ptr(), ops._ptr(dnu_prev), N, V, P, L, ws.data_ptr(), wsb)
+        st = ops._stream()
+        Pz = zT.shape[1]
+        for g in range(G):
+            o = 4 * g * N
+            _lib.call('swem_nu_update_bwd_f32', st, zT.data_ptr() + o * Pz * 2 * L, zita_prev.data_ptr() + o * 2 * L,
+                      zita.data_ptr() + o * 2 * L, dnu.data_ptr() + o * 2 * V * L, dv.data_ptr() + o * P * V,
+                      (dnu_prev.data_ptr() + o * 2 * V * L) if want_prev else 0, N, V, P, L, ws.data_ptr(), wsb)
         return dv, dnu_prev, None, None, None, None, None, None
 
 
@@ -614,46 +671,66 @@ def memorize(v, nu_prev, x, masks, kappa_prev, zita_prev, T, tau):
 
 
 class _Match(Function):
-    """get_affinity + perm_inv_feat (modules.py:198-208, 232-276) for the N objects of one clip.
-    qk (P,C) raw query key; banks: kappa (N,2,C,L) no gradient, nu (N,2,V,L) with gradient.
-    -> mem_out (N,Pm,V) (rows >= P zero), S (N,P,2*topl)."""
+    """get_affinity + perm_inv_feat (modules.py:198-208, 232-276) for the N objects of each of G clips (G = 1 when qk is (P,C)).
+    qk (G,P,C) raw query key; banks: kappa (G*N,2,C,L) no gradient, nu (G*N,2,V,L) with gradient.
+    -> mem_out (G*N,Pm,V) (rows >= P zero), S (G*N,P,2*topl).  One library call per clip (see _Memorize)."""
 
     @staticmethod
     def forward(ctx, qk, nu_first, nu_update, kappa_first, kappa_update, topl, tau):
-        P, Cc = qk.shape
-        N, _, V, L = nu_first.shape
+        G = 1 if qk.dim() == 2 else qk.shape[0]
+        P, Cc = qk.shape[-2:]
+        GN, _, V, L = nu_first.shape
+        N = GN // G
         dev = qk.device
+        for t_ in (qk, nu_first, nu_update, kappa_first, kappa_update):
+            if t_ is not None and not t_.is_contiguous():
+                raise _lib.SwemHipError('match: operands must be contiguous')
         nb = 1 if kappa_update is None else 2
         Pm = _lib.query('swem_match_pad', P)
-        mem = torch.empty((N, Pm, V), dtype=torch.float32, device=dev)
-        S = torch.empty((N, P, 2 * topl), dtype=torch.float32, device=dev)
+        mem = torch.empty((GN, Pm, V), dtype=torch.float32, device=dev)
+        S = torch.empty((GN, P, 2 * topl), dtype=torch.float32, device=dev)
         wsb = _lib.query('swem_match_workspace', N, Cc, V, P, L, nb, 0)
         ws = _ws(wsb, dev)
-        _lib.call('swem_match_f32', ops._stream(), qk.data_ptr(), kappa_first.data_ptr(), nu_first.data_ptr(),
-                  ops._ptr(kappa_update), ops._ptr(nu_update), mem.data_ptr(), S.data_ptr(), N, Cc, V, P, L, topl, tau, 0,
-                  ws.data_ptr(), wsb)
+        st = ops._stream()
+        for g in range(G):
+            o = 4 * g * N
+            _lib.call('swem_match_f32', st, qk.data_ptr() + 4 * g * P * Cc, kappa_first.data_ptr() + o * 2 * Cc * L,
+                      nu_first.data_ptr() + o * 2 * V * L, 0 if kappa_update is None else kappa_update.data_ptr() + o * 2 * Cc * L,
+                      0 if nu_update is None else nu_update.data_ptr() + o * 2 * V * L, mem.data_ptr() + o * Pm * V,
+                      S.data_ptr() + o * P * 2 * topl, N, Cc, V, P, L, topl, tau, 0, ws.data_ptr(), wsb)
+        if ops.FLOPS is not None:     # SURVEY 8d: F_match = 4 Lm P (C + V) per object, Lm = nb L; backward: twice that
+            ops.FLOPS['em_match'] = ops.FLOPS.get('em_match', 0.0) + 3.0 * GN * 4.0 * nb * L * P * (Cc + V)
         ctx.saved = (qk, nu_first, nu_update, kappa_first, kappa_update, topl, tau)
         return mem, S
 
     @staticmethod
     def backward(ctx, dmem, dS):
         qk, nu_first, nu_update, kappa_first, kappa_update, topl, tau = ctx.saved
-        P, Cc = qk.shape
-        N, _, V, L = nu_first.shape
+        G = 1 if qk.dim() == 2 else qk.shape[0]
+        P, Cc = qk.shape[-2:]
+        GN, _, V, L = nu_first.shape
+        N = GN // G
         dev = qk.device
         nb = 1 if kappa_update is None else 2
         Pm = _lib.query('swem_match_pad', P)
         if dmem is None:
-            dmem = torch.zeros((N, Pm, V), dtype=torch.float32, device=dev)
+            dmem = torch.zeros((GN, Pm, V), dtype=torch.float32, device=dev)
+        dmem = dmem.contiguous()
+        dS = None if dS is None else dS.contiguous()
         dqk = torch.empty_like(qk)
         dn1 = torch.empty_like(nu_first)
         dn2 = torch.empty_like(nu_update) if nu_update is not None else None
         wsb = _lib.query('swem_match_bwd_workspace', N, Cc, V, P, L, nb)
         ws = _ws(wsb, dev)
-        _lib.call('swem_match_bwd_f32', ops._stream(), qk.data_ptr(), kappa_first.data_ptr(), nu_first.data_ptr(),
-                  ops._ptr(kappa_update), ops._ptr(nu_update), dmem.contiguous().data_ptr(),
-                  ops._ptr(None if dS is None else dS.contiguous()), dqk.data_ptr(), dn1.data_ptr(), ops._ptr(dn2), N, Cc,
-                  V, P, L, topl, tau, ws.data_ptr(), wsb)
+        st = ops._stream()
+        for g in range(G):
+            o = 4 * g * N
+            _lib.call('swem_match_bwd_f32', st, qk.data_ptr() + 4 * g * P * Cc, kappa_first.data_ptr() + o * 2 * Cc * L,
+                      nu_first.data_ptr() + o * 2 * V * L, 0 if kappa_update is None else kappa_update.data_ptr() + o * 2 * Cc * L,
+                      0 if nu_update is None else nu_update.data_ptr() + o * 2 * V * L, dmem.data_ptr() + o * Pm * V,
+                      0 if dS is None else dS.data_ptr() + o * P * 2 * topl, dqk.data_ptr() + 4 * g * P * Cc,
+                      dn1.data_ptr() + o * 2 * V * L, 0 if dn2 is None else dn2.data_ptr() + o * 2 * V * L, N, Cc,
+                      V, P, L, topl, tau, ws.data_ptr(), wsb)
         return dqk, dn1, dn2, None, None, None, None
 
 

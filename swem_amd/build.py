@@ -20,21 +20,36 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _headers_of(path, seen=None):
+    """The repo headers a source includes, transitively (`#include "..."` lines only): a unit is rebuilt when ONE OF ITS OWN
+    headers is newer than its object -- conv.hip (five minutes) does not include the training header."""
+    import re
+    seen = set() if seen is None else seen
+    try:
+        text = open(path).read()
+    except OSError:
+        return seen
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        h = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+        if h not in seen and os.path.exists(h):
+            seen.add(h)
+            _headers_of(h, seen)
+    return seen
+
+
 def build(force=False, verbose=False):
-    import glob
     from concurrent.futures import ThreadPoolExecutor
-    hdrs = sorted(glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, '..', 'include', '*.h')))
     objs, todo = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
-        if force or _stale(o, [s] + hdrs):
+        if force or _stale(o, [s] + sorted(_headers_of(s))):
             todo.append([HIPCC] + FLAGS + ['-c', s, '-o', o])
         objs.append(o)
     for src, extra, obj in EXTRA_UNITS:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, obj)
-        if force or _stale(o, [s] + hdrs):
+        if force or _stale(o, [s] + sorted(_headers_of(s))):
             todo.append([HIPCC] + FLAGS + extra + ['-c', s, '-o', o])
         objs.append(o)
 

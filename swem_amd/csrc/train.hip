@@ -258,9 +258,19 @@ __global__ __launch_bounds__(256) void loss_pixel_bwd_kernel(const float *__rest
   }
 }
 
+// gate (optional): `ngate` device floats read at the top of every block; any non-zero one and the whole launch leaves p, m, v
+// untouched -- the found_inf gate of a loss scaler, fed by the step's fault flags (swem_fault_flags_f32) after their all-reduce,
+// so that every rank skips the same steps without a host round trip.  applied (optional): += 1 by one thread of a launch that
+// did update (the host reconciles its step count with it when it next looks).
 __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                     float *__restrict__ m, float *__restrict__ v, long long n, float decay,
-                                                    float b1, float b2, float eps, float step_size, float sqrt_bc2) {
+                                                    float b1, float b2, float eps, float step_size, float sqrt_bc2,
+                                                    const float *__restrict__ gate, int ngate, int *__restrict__ applied) {
+  if (gate) {
+    for (int i = 0; i < ngate; ++i)
+      if (gate[i] != 0.f) return;
+  }
+  if (applied && blockIdx.x == 0 && threadIdx.x == 0) *applied += 1;
   const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i0 >= n) return;
   if (i0 + 4 <= n) {
@@ -341,17 +351,39 @@ extern "C" int swem_vos_loss_frame_bwd_f32(void *stream, const float *prob, cons
   return SWEM_OK;
 }
 
-extern "C" int swem_adamw_f32(void *stream, float *p, const float *g, float *m, float *v, long long n, float lr,
-                              float beta1, float beta2, float eps, float weight_decay, int step) {
+extern "C" int swem_adamw_gated_f32(void *stream, float *p, const float *g, float *m, float *v, long long n, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, int step, const float *gate,
+                                    int ngate, int *applied) {
   SWEM_REQUIRE(p && g && m && v, SWEM_E_ARG, "adamw: null pointer");
   SWEM_REQUIRE(n > 0 && step >= 1, SWEM_E_SHAPE, "adamw: n=%lld step=%d", n, step);
   SWEM_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, SWEM_E_ARG,
                "adamw: buffers must be 16-byte aligned");
+  SWEM_REQUIRE(ngate >= 0 && (gate || ngate == 0), SWEM_E_ARG, "adamw: %d gate flags without a gate pointer", ngate);
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adamw_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g,
                      m, v, n, (float)(1.0 - (double)lr * weight_decay), beta1, beta2, eps, (float)(lr / bc1),
-                     (float)sqrt(bc2));
+                     (float)sqrt(bc2), ngate > 0 ? gate : nullptr, ngate, applied);
   SWEM_CHECK_LAUNCH("adamw_kernel");
+  return SWEM_OK;
+}
+
+extern "C" int swem_adamw_f32(void *stream, float *p, const float *g, float *m, float *v, long long n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int step) {
+  return swem_adamw_gated_f32(stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, nullptr, 0, nullptr);
+}
+
+namespace {
+__global__ void fault_flags_kernel(const unsigned *__restrict__ fault, float *__restrict__ out) {
+  const unsigned w = *fault;
+  out[0] = (w & SWEM_FAULT_RANGE) ? 1.f : 0.f;
+  out[1] = (w & ~(unsigned)SWEM_FAULT_RANGE) ? 1.f : 0.f;
+}
+}  // namespace
+
+extern "C" int swem_fault_flags_f32(void *stream, const unsigned *fault, float *flags2) {
+  SWEM_REQUIRE(fault && flags2, SWEM_E_ARG, "fault_flags: null pointer");
+  hipLaunchKernelGGL(fault_flags_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), fault, flags2);
+  SWEM_CHECK_LAUNCH("fault_flags_kernel");
   return SWEM_OK;
 }
 

@@ -442,6 +442,28 @@ __global__ __launch_bounds__(256) void sum_batch_kernel(const float *__restrict_
   *reinterpret_cast<float4 *>(y + i * 4) = s;
 }
 
+// Clip-batched training (train.py, round 6): a map that the N objects of EACH of G clips share -- the key encoder's 1/16 features
+// in the value encoder's fuser, the query values in the fusion layer, the decoder's skip features -- is laid out once per object
+// (y[(g N + j)][i] = x[g][i]) so that the clips' objects go through the convolutions as ONE batch; the gradient sums the N copies.
+__global__ __launch_bounds__(256) void expand_groups_kernel(const float *__restrict__ x, float *__restrict__ y, int N, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int g = blockIdx.y;
+  const float4 v = ld4g(x + ((long long)g * n4 + i) * 4);
+  for (int j = 0; j < N; ++j) *reinterpret_cast<float4 *>(y + (((long long)g * N + j) * n4 + i) * 4) = v;
+}
+__global__ __launch_bounds__(256) void sum_groups_kernel(const float *__restrict__ x, float *__restrict__ y, int N, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int g = blockIdx.y;
+  float4 s = ld4g(x + ((long long)g * N * n4 + i) * 4);
+  for (int j = 1; j < N; ++j) {               // (fixed order: deterministic, and the order sum_batch_kernel uses for one clip)
+    const float4 v = ld4g(x + (((long long)g * N + j) * n4 + i) * 4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4 *>(y + ((long long)g * n4 + i) * 4) = s;
+}
+
 struct WgradPlan {
   int wt, zsplit, m_per_split;
 };
@@ -816,6 +838,20 @@ extern "C" int swem_colsum_f32(void *stream, const float *a, const float *b, flo
   SWEM_CHECK_LAUNCH("colsum_partial_kernel");
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, part, out1, out2, nrow, C, accumulate);
   SWEM_CHECK_LAUNCH("colsum_final_kernel");
+  return SWEM_OK;
+}
+
+extern "C" int swem_expand_groups_f32(void *stream, const float *x, float *y, int G, int N, long long n) {
+  SWEM_REQUIRE(x && y && G > 0 && G < 65536 && N > 0 && n > 0 && n % 4 == 0, SWEM_E_ARG, "expand_groups: bad argument");
+  hipLaunchKernelGGL(expand_groups_kernel, dim3(cdiv(n / 4, 256), G), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, N, n / 4);
+  SWEM_CHECK_LAUNCH("expand_groups_kernel");
+  return SWEM_OK;
+}
+
+extern "C" int swem_sum_groups_f32(void *stream, const float *x, float *y, int G, int N, long long n) {
+  SWEM_REQUIRE(x && y && G > 0 && G < 65536 && N > 0 && n > 0 && n % 4 == 0, SWEM_E_ARG, "sum_groups: bad argument");
+  hipLaunchKernelGGL(sum_groups_kernel, dim3(cdiv(n / 4, 256), G), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, N, n / 4);
+  SWEM_CHECK_LAUNCH("sum_groups_kernel");
   return SWEM_OK;
 }
 

@@ -17,11 +17,30 @@ def env_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
 
+def single_rank_group():
+    """SWEM_DIST_SINGLE_RANK=1: a process group is created even for ONE process, and the collectives of this module are really
+    issued on it instead of being skipped (round 6: the only way a one-GPU box can put the RCCL code path -- communicator
+    creation, barrier(device_ids), the bucketed all-reduces, the all-reduce captured inside a HIP graph -- in front of librccl;
+    tests/test_gpu_train.py::test_rccl_single_rank_*).  With N = 1 a SUM all-reduce is the identity, so results are unchanged."""
+    return os.environ.get('SWEM_DIST_SINGLE_RANK', '0') == '1'
+
+
+def active():
+    """True when this module's collectives are to be issued: a process group of > 1 ranks, or the single-rank rehearsal."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_group())
+
+
 def init(backend=None):
-    """Initialise the default process group from the torchrun environment (no-op for a single process)."""
+    """Initialise the default process group from the torchrun environment (no-op for a single process, unless
+    SWEM_DIST_SINGLE_RANK=1 asks for a one-rank group: `single_rank_group`)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group()) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1 and 'MASTER_PORT' not in os.environ:
+            import socket                                 # (a one-rank group has nobody to agree a port with: any free one)
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
             backend = os.environ.get('SWEM_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
@@ -107,15 +126,20 @@ def reduce_counters(frames, seconds, device='cpu'):
     return int(round(f.item())), float(s.item())
 
 
-def allreduce_sum_(flat, bucket_bytes=64 << 20):
+def allreduce_sum_(flat, bucket_bytes=64 << 20, sync=False):
     """In-place SUM all-reduce of a flat gradient buffer in buckets (training: the reference wraps the model in
     DistributedDataParallel, swem_trainer.py:41-43; here the parameters' gradients already live in ONE buffer, so the
     'buckets' are plain slices).  All buckets are launched asynchronously and waited for together: on xGMI the ring is
     per-link bound, 64 MB slices keep every link busy without serialising the launch latency (58.6 M fp32 gradients =
     4 slices).  The mean over ranks is folded into the loss gradient by the caller (1 / (clips * world))."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return flat
     n = max(1, bucket_bytes // flat.element_size())
+    if sync:
+        # in stream order on the CURRENT stream's dependency chain (no work handles): the form a stream capture records
+        for i in range(0, flat.numel(), n):
+            dist.all_reduce(flat[i:i + n], op=dist.ReduceOp.SUM)
+        return flat
     works = [dist.all_reduce(flat[i:i + n], op=dist.ReduceOp.SUM, async_op=True) for i in range(0, flat.numel(), n)]
     for w in works:
         w.wait()
@@ -126,7 +150,7 @@ def broadcast_model_(flat_param, module=None, src=0):
     """Rank `src`'s parameters (one flat buffer, optim.flatten_parameters) and the module's buffers (BatchNorm running
     statistics, mean / std) to every rank: what DistributedDataParallel does once in its constructor
     (swem_trainer.py:41-43).  No-op for one process."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return flat_param
     dist.broadcast(flat_param, src=src)
     if module is not None:
@@ -141,7 +165,7 @@ def allreduce_sum_async(t, bucket_bytes=64 << 20, mean=False):
     process).  The collectives run on the process group's own stream behind what the CURRENT stream has queued so far; the
     caller overlaps them with later launches and calls ``.wait()`` on the handles before it consumes the result.
     mean: divide by the world size first (loss scalars: basic_trainer.py:105-110)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return []
     if mean:
         t.div_(dist.get_world_size())

@@ -64,6 +64,7 @@ def evaluate_davis_seq(model, frames, init_masks, out_size, trace=None):
 
 
 def _davis_seq(model, frames, init_masks, out_size, trace=None):
+    ops.drain_faults('evaluate_davis_seq')      # (a fault left by earlier work is not this sequence's: ops.FAULT_OWNERS)
     preds, pred_scores = [], []
     b, t, c, h, w = frames.shape
     out_size = (int(out_size[0]), int(out_size[1]))
@@ -104,6 +105,7 @@ def evaluate_ytvos_seq(model, frames, init_masks, out_size):
 
 
 def _ytvos_seq(model, frames, init_masks, out_size):
+    ops.drain_faults('evaluate_ytvos_seq')
     preds = []
     b, t, c, h, w = frames.shape
     out_size = (int(out_size[0]), int(out_size[1]))
@@ -719,6 +721,7 @@ class SequencePool:
             return self._run(sequences, seeds)
 
     def _run(self, sequences, seeds=None):
+        ops.drain_faults('SequencePool.run')
         todo = list(enumerate(sequences))
         results = [None] * len(sequences)
         k = self.lookahead

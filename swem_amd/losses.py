@@ -88,7 +88,9 @@ class VOSLoss:
         carries the gradient, the others are device scalars.  k_dev: int64 device scalar holding k (graph replay)."""
         H, W = logits_list[0].shape[-2:]
         p, k = self.top_k(it, H * W)
-        if target.dtype != torch.int64 or not target.is_contiguous():
+        # (the kernels take the clip's label frames through a batch stride: a (G,T,H,W) slice of a larger label tensor -- the
+        # clips of one lane, frames 1.. -- is read in place; only the frames themselves must be dense)
+        if target.dtype != torch.int64 or target.stride(-1) != 1 or target.stride(-2) != W:
             target = target.long().contiguous()
         out = _ClipLoss.apply(target, valid_obj, k, k_dev, self.aux_alpha, *logits_list)
         det = out.detach()

@@ -473,13 +473,9 @@ def _fault_ptr(device):
     return fault_word(device).data_ptr()
 
 
-def check_faults():
-    """Asynchronous faults of the launches made so far on every device this process used (the C ABI's return codes only cover
-    what is known at enqueue time).  Synchronises each device and reads its fault word: call it where the host waits anyway
-    (the evaluator does at the end of every sequence, bench.py behind its timed regions, the trainer where it reads the
-    loss).  On a fault the word is cleared, on a WAIT fault every tile-counter buffer of that device is zeroed too (a stale
-    counter would corrupt the next launch the same way), and an exception is raised: SwemRangeError when the only fault is
-    SWEM_FAULT_RANGE (the launches themselves were sound: re-run in a full-range arithmetic), else SwemHipError."""
+def _collect_faults():
+    """Synchronise every device this process used, read AND clear its fault word (on a WAIT fault also every tile-counter
+    buffer of that device: a stale counter would corrupt the next launch the same way); returns the OR of the words."""
     bits = 0
     for dev, t in _fault.items():
         torch.cuda.synchronize(dev)            # (every stream: a lane of a SequencePool may still be running)
@@ -493,12 +489,62 @@ def check_faults():
                 if b is not None and b.device.index == dev:
                     b.zero_()
         torch.cuda.synchronize(dev)
+    return bits
+
+
+def _fault_text(bits):
+    what = '; '.join(t for b, t in FAULT_BITS.items() if bits & b)
+    if bits & ~(FAULT_KSPLIT | FAULT_STREAMK | FAULT_RANGE):
+        what += '; unknown fault bits %#x' % bits
+    return what
+
+
+def check_faults():
+    """Asynchronous faults of the launches made so far on every device this process used (the C ABI's return codes only cover
+    what is known at enqueue time).  Synchronises each device and reads its fault word: call it where the host waits anyway
+    (the evaluator does at the end of every sequence, bench.py behind its timed regions, the trainer where it reads the
+    loss).  On a fault the word is cleared, on a WAIT fault every tile-counter buffer of that device is zeroed too (a stale
+    counter would corrupt the next launch the same way), and an exception is raised: SwemRangeError when the only fault is
+    SWEM_FAULT_RANGE (the launches themselves were sound: re-run in a full-range arithmetic), else SwemHipError."""
+    bits = _collect_faults()
     if bits:
-        what = '; '.join(t for b, t in FAULT_BITS.items() if bits & b)
-        if bits & ~(FAULT_KSPLIT | FAULT_STREAMK | FAULT_RANGE):
-            what += '; unknown fault bits %#x' % bits
         cls = SwemRangeError if bits == FAULT_RANGE else _lib.SwemHipError
-        raise cls('asynchronous fault (fault word %#x): %s' % (bits, what))
+        raise cls('asynchronous fault (fault word %#x): %s' % (bits, _fault_text(bits)))
+
+
+# Ownership of the fault word (ADVICE r05).  The word is one per DEVICE; whoever reads it next would otherwise be blamed for
+# whatever was left in it -- a validation sequence converting its model's book to the full-range arithmetic because a training
+# step faulted ten steps earlier, while the trainer never learns.  So: an owner of launches drains the word when it takes the
+# device over (`drain_faults` at the start of every evaluator loop / SequencePool.run) and collects its own faults where it ends
+# (`check_faults`).  What a drain finds belongs to EARLIER work: it is handed to the long-lived owners that registered
+# (`FAULT_OWNERS`: trainers, by weak reference -- `on_foreign_fault(bits)`), or, with nobody to take it, raised as what it is: a
+# stale fault, not this caller's.
+FAULT_OWNERS = []
+
+
+def register_fault_owner(obj):
+    import weakref
+    FAULT_OWNERS[:] = [r for r in FAULT_OWNERS if r() is not None]
+    FAULT_OWNERS.append(weakref.ref(obj))
+
+
+def drain_faults(what):
+    """Called by an owner BEFORE its first launch (synchronises): a set fault word is earlier work's -- see FAULT_OWNERS."""
+    if not _fault:
+        return
+    bits = _collect_faults()
+    if not bits:
+        return
+    owners = [o for o in (r() for r in FAULT_OWNERS) if o is not None]
+    if not owners:
+        raise _lib.SwemHipError('stale asynchronous fault (fault word %#x) found at the start of %s: it was raised by EARLIER work '
+                                'on this device that never called ops.check_faults() -- that work\'s results are suspect, not this '
+                                'call\'s: %s' % (bits, what, _fault_text(bits)))
+    import warnings
+    for o in owners:
+        o.on_foreign_fault(bits)
+    warnings.warn('swem_amd: %s found fault word %#x left by earlier work and handed it to %d registered owner(s) (trainers)'
+                  % (what, bits, len(owners)), RuntimeWarning)
 
 
 class ConvPack:
@@ -698,6 +744,7 @@ AMAX_PARTS = 256   # include/swem_hip_train.h, SWEM_AMAX_PARTS
 F16_PACK_SITES = set()
 BF16_PACK_SITES = set()     # ... and the same for the bf16 planes (built lazily for those packs: ConvPack(lazy_planes=True))
 RESPLITS = {}      # producer site -> split launches made for a tensor that already carried producer-written planes
+FLOPS = None        # a dict while somebody counts useful FLOPs (ops.flags(FLOPS={})): conv2d, autograd._wgrad / _Memorize / _Match add to it
 # The decoder's two skip convolutions (networks.py:190-196: UpsampleBlock.skip_conv on s8 / s4) read the KEY encoder's features only:
 # the same for every object (round 2: computed once per frame) and independent of the memory.  With this switch (default on;
 # SWEM_SKIP_IN_KEY_PASS=0) Engine.encode_key computes them right behind the trunk and hands them on with s8 / s4 -- in the look-ahead
@@ -930,6 +977,16 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
     if CONV_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    if FLOPS is not None and not _IN_TUNER[0]:
+        # useful multiply-adds x 2 of this launch (unpadded channels; a data gradient has the forward layer's count: every
+        # (output pixel, filter tap) pair once) -- tools/train_bench.py's roofline accounting
+        if dgrad is None:
+            fl = 2.0 * B * Ho * Wo * pack.cout * (2 if pack.glu else 1) * pack.kh * pack.kw * getattr(pack, 'cin_true', pack.cin)
+        else:
+            fl = 2.0 * B * H * W * pack.cin * pack.kh * pack.kw * pack.cout
+        k_ = 'conv_dgrad' if dgrad is not None else 'conv_fwd'
+        FLOPS[k_] = FLOPS.get(k_, 0.0) + fl
+        FLOPS['conv_launches'] = FLOPS.get('conv_launches', 0) + 1
     launch(plan)
     if MATH_RAN is not None:
         m_ = (plan >> 16) & 7
@@ -1183,11 +1240,14 @@ def _f3(t):
     return (C.c_float * 3)(*v)
 
 
-def prep_key_input(frames, mean3, std3):
-    """frames NCHW (B,3,H,W) -> normalised NHWC (B,H,W,4); mean3/std3 are ctypes float[3]."""
+def prep_key_input(frames, mean3, std3, out=None):
+    """frames NCHW (B,3,H,W) -> normalised NHWC (B,H,W,4); mean3/std3 are ctypes float[3].  out: a (B,H,W,4) slice to fill."""
     _chk(frames, 'frames')
     B, _, H, W = frames.shape
-    out = torch.empty((B, H, W, 4), dtype=torch.float32, device=frames.device)
+    if out is None:
+        out = torch.empty((B, H, W, 4), dtype=torch.float32, device=frames.device)
+    elif tuple(out.shape) != (B, H, W, 4) or not out.is_contiguous():
+        raise _lib.SwemHipError('prep_key_input: out must be a contiguous (B,H,W,4) tensor')
     _lib.call('swem_prep_key_input_f32', _stream(), frames.data_ptr(), C.addressof(mean3), C.addressof(std3),
               out.data_ptr(), B, H, W)
     return out

@@ -20,16 +20,37 @@ class FlatAdamW:
         self.v = torch.zeros_like(param)
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.step_count = 0
+        self.applied = None          # device int32: launches of `step(gate=...)` that updated
 
     def zero_grad(self, set_to_none=False):
         """The gradient buffer is one allocation shared by all parameter views: it is zeroed, never dropped."""
         self.grad.zero_()
 
-    def step(self):
+    def step(self, gate=None):
+        """gate: optional device float tensor; if any element is non-zero when the launch runs, the update is skipped ON THE
+        DEVICE (swem_adamw_gated_f32: the found_inf gate of the reference's GradScaler step, basic_trainer.py:222-223) --
+        `self.applied` counts the launches that did update, `reconcile()` brings the host's step count back in line."""
         self.step_count += 1
-        _lib.call('swem_adamw_f32', ops._stream(), self.param.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(),
+        if gate is None:
+            _lib.call('swem_adamw_f32', ops._stream(), self.param.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(),
+                      self.v.data_ptr(), self.param.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                      self.weight_decay, self.step_count)
+            return
+        if self.applied is None:
+            # (bias correction uses the HOST's step count: it equals the applied count for every launch that updates, because
+            # once the gate closes it stays closed until the host has looked -- the flags come from a sticky word)
+            self.applied = torch.full((1,), self.step_count - 1, dtype=torch.int32, device=self.param.device)
+        _lib.call('swem_adamw_gated_f32', ops._stream(), self.param.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(),
                   self.v.data_ptr(), self.param.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
-                  self.weight_decay, self.step_count)
+                  self.weight_decay, self.step_count, gate.data_ptr(), gate.numel(), self.applied.data_ptr())
+
+    def reconcile(self):
+        """After a closed gate was seen: the step count the device really applied (synchronises).  Returns the skipped steps."""
+        if self.applied is None:
+            return 0
+        done = int(self.applied.item())
+        skipped, self.step_count = self.step_count - done, done
+        return skipped
 
     def state_dict(self):
         return {'m': self.m, 'v': self.v, 'step': self.step_count, 'lr': self.lr}
@@ -38,6 +59,8 @@ class FlatAdamW:
         self.m.copy_(sd['m'])
         self.v.copy_(sd['v'])
         self.step_count, self.lr = int(sd['step']), float(sd['lr'])
+        if self.applied is not None:
+            self.applied.fill_(self.step_count)
 
 
 class MultiStepLR:
@@ -51,6 +74,12 @@ class MultiStepLR:
     def step(self):
         self.last_epoch += 1
         self.optimizer.lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if self.last_epoch >= m)
+
+    def rewind(self, n):
+        """n scheduler steps were taken for optimizer steps the device-side gate skipped (FlatAdamW.reconcile): undo them."""
+        if n > 0:
+            self.last_epoch -= n + 1
+            self.step()
 
     def state_dict(self):
         return {'last_epoch': self.last_epoch, 'base_lr': self.base_lr}

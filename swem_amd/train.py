@@ -37,7 +37,13 @@ def _get(cfg, k):
 
 
 class TrainGraph:
-    """The forward graphs of swem.py / networks.py on differentiable HIP stages, for ONE clip (batch 1, N objects)."""
+    """The forward graphs of swem.py / networks.py on differentiable HIP stages for G clips of N objects at once -- the reference
+    pushes the B clips of a GPU through the model as ONE tensor (swem_trainer.py:60-90: `frames[:, i]` is (B,3,H,W)); here G is
+    the share of the batch one lane (stream) steps: G = B with one lane, G = 1 with a lane per clip (rounds 1-5).  Layout: a
+    frame's tensors carry the clips on the batch axis (G, ...), per-object tensors the objects of clip 0, then clip 1, ...
+    (G*N, ...), as the reference's `.flatten(0, 1)` of (B, N, ...) does (swem.py:57,98); the key encoder takes all T frames of
+    the G clips in one pass, frame-major (T*G, ...).  EM and matching run clip by clip inside their stages (autograd._Memorize,
+    _Match); maps the N objects of a clip share are laid out per object for the convolutions (autograd.expand_objects)."""
 
     def __init__(self, model):
         dev = next(model.parameters()).device
@@ -78,9 +84,17 @@ class TrainGraph:
     # swem.py:39-43 + networks.py:160-182, in two parts: the ResNet trunk (every parameter of `key_encoder`, the FIRST slice of
     # the flat parameter buffer) and the two 3x3 projections on its 1/16 map.  The step back-propagates through the trunk in a
     # phase of its own (SWEMTrainer: the rest of the gradient is all-reduced meanwhile).
-    def key_trunk(self, frame):
+    def key_trunk(self, frames):
+        """frames: (T*G,3,H,W) frame-major, or a list of T tensors (G,3,H,W) (the frames of a lane's clips: slices of the step's
+        (T,B,3,H,W) input buffer)."""
         ke = self.m.key_encoder
-        x = ops.prep_key_input(frame, self.k_mean, self.k_std)
+        if isinstance(frames, (list, tuple)):
+            G, _, H, W = frames[0].shape
+            x = torch.empty((len(frames) * G, H, W, 4), dtype=torch.float32, device=frames[0].device)
+            for t, f in enumerate(frames):
+                ops.prep_key_input(f, self.k_mean, self.k_std, out=x[t * G:(t + 1) * G])
+        else:
+            x = ops.prep_key_input(frames, self.k_mean, self.k_std)
         x = A.maxpool(A.bn_act(A.conv2d([x], ke.conv1.weight, None, stride=2, pad=3, cin_pad=4), _bn(ke.bn1)))
         feats = []
         for st in (ke.res2, ke.layer2, ke.layer3):
@@ -103,53 +117,60 @@ class TrainGraph:
 
     # swem.py:45-62 + networks.py:113-129, 43-50
     def encode_value(self, frame, masks, s16):
+        """frame (G,3,H,W), masks (G,N+1,H,W), s16 (G,h,w,C) -> (G*N,h,w,V)."""
         ve = self.m.value_encoder
-        N = masks.shape[1] - 1
+        G, N = masks.shape[0], masks.shape[1] - 1
         x = A.prep_value_input(frame, masks, self.v_mean, self.v_std, self.single_obj)
         x = A.maxpool(A.bn_act(A.conv2d([x], ve.conv1.weight, ve.conv1.bias, stride=2, pad=3, cin_pad=8), _bn(ve.bn1)))
         for st in (ve.layer1, ve.layer2, ve.layer3):
             for blk in st:
                 x = self._block(blk, x)
-        x = self._res_block(ve.fuser.block1, [x, s16], batch=N)
+        x = self._res_block(ve.fuser.block1, [x, A.expand_objects(s16, N)], batch=G * N)
         att = ve.fuser.attention
         x = A.cbam_residual(x, att.ChannelGate.mlp[1].weight, att.ChannelGate.mlp[1].bias, att.ChannelGate.mlp[3].weight,
                             att.ChannelGate.mlp[3].bias, att.SpatialGate.spatial.conv.weight,
                             att.SpatialGate.spatial.conv.bias)
-        return self._res_block(ve.fuser.block2, [x])                      # (N, h, w, V)
+        return self._res_block(ve.fuser.block2, [x])                      # (G*N, h, w, V)
 
     # modules.py:278-293
     def match(self, qk16, qv16, first, update):
+        """qk16 (G,h,w,C), qv16 (G,h,w,V), banks (G*N, ...) -> context (G*N,h,w,V), N."""
         core = self.m.swem_core
-        _, h, w, Cc = qk16.shape
+        G, h, w, Cc = qk16.shape
         P = h * w
-        mem, S = A.match(qk16.view(P, Cc), first['nu'], None if update is None else update['nu'], first['kappa'],
+        mem, S = A.match(qk16.view(G, P, Cc), first['nu'], None if update is None else update['nu'], first['kappa'],
                          None if update is None else update['kappa'], core.topl, core.tau)
-        N = mem.shape[0]
-        mem = mem[:, :P].view(N, h, w, -1)
-        S = S.view(N, h, w, -1)
+        GN = mem.shape[0]
+        N = GN // G
+        mem = mem[:, :P].view(GN, h, w, -1)
+        S = S.view(GN, h, w, -1)
+        qv = A.expand_objects(qv16, N)
         fl = core.fusion_layer
-        f = A.conv2d([mem, qv16, S], fl.layer_f.weight, fl.layer_f.bias, batch=N)
-        a = A.conv2d([mem, qv16, S], fl.layer_a.weight, fl.layer_a.bias, batch=N)
+        f = A.conv2d([mem, qv, S], fl.layer_f.weight, fl.layer_f.bias, batch=GN)
+        a = A.conv2d([mem, qv, S], fl.layer_a.weight, fl.layer_a.bias, batch=GN)
         return A.glu(f, a), N
 
     # swem.py:92-116 + networks.py:199-216
     def segment(self, n, context, s8, s4, valid_obj, out_size):
+        """context (G*n,h,w,V), s8 / s4 (G, ...), valid_obj (G,n+1) or None -> logits, prob (G,n+1,Ho,Wo)."""
         dec = self.m.decoder
+        G = s8.shape[0]
         x = self._res_block(dec.compress, [context])
         sk = A.conv2d([s8], dec.up_16_8.skip_conv.weight, dec.up_16_8.skip_conv.bias)
-        x = self._res_block(dec.up_16_8.out_conv, [A.upsample_add(sk, x, batch=n)])
+        x = self._res_block(dec.up_16_8.out_conv, [A.upsample_add(A.expand_objects(sk, n), x, batch=G * n)])
         sk = A.conv2d([s4], dec.up_8_4.skip_conv.weight, dec.up_8_4.skip_conv.bias)
-        x = self._res_block(dec.up_8_4.out_conv, [A.upsample_add(sk, x, batch=n)])
+        x = self._res_block(dec.up_8_4.out_conv, [A.upsample_add(A.expand_objects(sk, n), x, batch=G * n)])
         logit4 = A.pred_head(x, dec.pred.weight, dec.pred.bias)
-        return A.decode_head(logit4, valid_obj, 1, n, out_size)
+        return A.decode_head(logit4, valid_obj, G, n, out_size)
 
     # swem.py:64-86 + modules.py:129-168, 183-193
     def memorize(self, qk16, mv16, masks_hard, masks_soft, prior):
+        """qk16 (G,h,w,C), mv16 (G*N,h,w,V), masks (G,N+1,H,W), prior bases (G*N, ...)."""
         core = self.m.swem_core
-        _, h, w, Cc = qk16.shape
-        N = mv16.shape[0]
-        masks = ops.mask_prep(masks_hard.contiguous(), masks_soft.detach().float().contiguous(), h, w)   # (N,2,P)
-        kappa, nu, zita = A.memorize(mv16.view(N, h * w, -1), prior['nu'], qk16.detach().view(h * w, Cc), masks,
+        G, h, w, Cc = qk16.shape
+        GN = mv16.shape[0]
+        masks = ops.mask_prep(masks_hard.contiguous(), masks_soft.detach().float().contiguous(), h, w)   # (G*N,2,P)
+        kappa, nu, zita = A.memorize(mv16.view(GN, h * w, -1), prior['nu'], qk16.detach().view(G, h * w, Cc), masks,
                                      prior['kappa'], prior['zita'], core.n_iters, core.tau)
         return {'kappa': kappa, 'nu': nu, 'zita': zita}
 
@@ -180,10 +201,13 @@ def random_init_host(B, N, Cc, Lb):
         return kappa / (torch.linalg.norm(kappa, dim=-2, keepdim=True) + 1e-6)
 
 
+DEFAULT_LANES = 2
+
+
 class SWEMTrainer:
     """swem_trainer.py:19-108 without the dataset / logging plumbing: model, criterion, optimizer, scheduler, one_step."""
 
-    def __init__(self, config, model, num_gpu=None, use_graph=True, lanes=4, overlap_allreduce=True):
+    def __init__(self, config, model, num_gpu=None, use_graph=True, lanes=None, overlap_allreduce=True, reduce_in_graph=False):
         self.config = config
         self.model = model
         # config.AMP (configs/config.py:89, basic_trainer.py:83-86,222): the reference runs the forward under fp16
@@ -202,6 +226,10 @@ class SWEMTrainer:
         # key-encoder trunk (collective kernels next to the lanes' graphs); False = ONE all-reduce of the whole gradient after
         # the backward pass, nothing of RCCL in flight beside the lanes (the conservative form; same result bit for bit)
         self.overlap_allreduce = bool(overlap_allreduce)
+        # reduce_in_graph: the all-reduce of the non-trunk slice is CAPTURED into the step's HIP graph (the node behind the lanes'
+        # gradient sum) instead of being issued between two graph replays -- one launch less on the host's critical path per step;
+        # needs a collective library that records into a stream capture (RCCL does: tests/_rccl_single_rank_probe.py)
+        self.reduce_in_graph = bool(reduce_in_graph)
         dev = next(model.parameters()).device
         model.train()
         for mod in model.modules():                    # BasicTrainer.set_bn_eval (swem_trainer.py:37-39)
@@ -229,25 +257,36 @@ class SWEMTrainer:
         self.graph = TrainGraph(model)
         self.device = dev
         self.use_graph = use_graph
-        self.lanes = max(1, int(lanes))      # clips of a batch in flight at once, each on its own stream
+        # The B clips of a step are cut into `lanes` contiguous shares; a share is stepped as ONE batch (TrainGraph: G clips
+        # through every convolution together, as the reference runs its batch, swem_trainer.py:60-90) on a stream of its own, with
+        # its own flat gradient buffer.  lanes = B: a clip per stream (rounds 1-5); lanes = 1: the whole batch in one pass.
+        # Default (SWEM_TRAIN_LANES overrides): DEFAULT_LANES, the faster on the reference's training shapes -- measured, profiles/
+        # r06_train_lanes_ab.txt.
+        self.lanes = max(1, int(lanes if lanes is not None else os.environ.get('SWEM_TRAIN_LANES', DEFAULT_LANES)))
         self._lane_state = None
+        self._foreign_fault = 0
+        ops.fault_word(dev)
+        ops.register_fault_owner(self)
 
     def clip_forward(self, frames, init_mask, valid_obj, prior0):
-        """swem_trainer.py:63-90 for one clip: frames (1,T,3,H,W), init_mask (1,N+1,H,W), valid_obj (1,N+1)."""
+        """swem_trainer.py:63-90 for G clips: frames = T tensors (G,3,H,W) (or one (T*G,3,H,W), frame-major), init_mask
+        (G,N+1,H,W), valid_obj (G,N+1) or None, prior0 = random bases (G*N, ...).  Returns T-1 logits (G,N+1,H,W) and index maps."""
         g = self.graph
-        t = frames.shape[1]
+        G = init_mask.shape[0]
+        t = len(frames) if isinstance(frames, (list, tuple)) else frames.shape[0] // G
+        frame = (lambda i: frames[i]) if isinstance(frames, (list, tuple)) else (lambda i: frames[i * G:(i + 1) * G])
         out_size = tuple(init_mask.shape[-2:])
-        # the key encoder does not depend on the memory: all t frames go through it in one pass (a third of its launches,
-        # three times larger kernels); frozen BatchNorm keeps every frame's result what a per-frame call gives
-        trunk = g.key_trunk(frames[0])                                       # (s16, s8, s4), all t frames
+        # the key encoder does not depend on the memory: all t frames of the G clips go through it in one pass (a third of its
+        # launches, t times larger kernels); frozen BatchNorm keeps every frame's result what a per-frame call gives
+        trunk = g.key_trunk(frames)                                          # (s16, s8, s4), all t frames, frame-major
         # the trunk's backward is a phase of its own (`trunk_backward`): everything downstream differentiates towards
         # detached copies, whose .grad the second phase feeds into the trunk
         cut = [o.detach().requires_grad_(True) for o in trunk]
         qk_all, qv_all = g.key_project(cut[0])
-        enc = [A.unbatch(e, t) for e in (qk_all, qv_all, cut[0], cut[1], cut[2])]   # [qk16, qv16, s16, s8, s4][frame]
+        enc = [A.unbatch(e, t) for e in (qk_all, qv_all, cut[0], cut[1], cut[2])]   # [qk16, qv16, s16, s8, s4][frame]: (G, ...)
         self._trunks.append((trunk, cut))
         mk16, s16 = enc[0][0], enc[2][0]
-        mv16 = g.encode_value(frames[:, 0], init_mask.float(), s16)
+        mv16 = g.encode_value(frame(0), init_mask.float(), s16)
         first = g.memorize(mk16, mv16, init_mask, init_mask.float(), prior0)
         update = None
         logits_list, results = [], []
@@ -259,7 +298,7 @@ class SWEMTrainer:
             pred, hard = ops.argmax_onehot(pred_mask.detach(), want_onehot=i < t - 1)
             results.append(pred)
             if i < t - 1:
-                mv16 = g.encode_value(frames[:, i], pred_mask, s16)
+                mv16 = g.encode_value(frame(i), pred_mask, s16)
                 update = g.memorize(qk16, mv16, hard, pred_mask, first if update is None else update)
         return logits_list, results
 
@@ -272,17 +311,20 @@ class SWEMTrainer:
             B, N = frames.shape[0], init_mask.shape[1] - 1
             Ck = self.model.key_proj.key_proj.weight.shape[0]
             dev = self.device
+            T = frames.shape[1]
             self.buf = {
-                'frames': torch.empty(frames.shape, dtype=torch.float32, device=dev),
+                # frame-major (T,B,3,H,W): frame t of a contiguous share of the clips is one dense (G,3,H,W) block
+                'frames': torch.empty((T, B) + tuple(frames.shape[2:]), dtype=torch.float32, device=dev),
                 'init_mask': torch.empty(init_mask.shape, dtype=torch.float32, device=dev),
                 'label': torch.empty(label.shape, dtype=torch.int64, device=dev),
                 'valid': None if valid_obj is None else torch.empty(valid_obj.shape, dtype=torch.float32, device=dev),
                 'kappa0': torch.empty((B, N, 2, Ck, core.n_bases), dtype=torch.float32, device=dev),
-                'nu0': torch.zeros((N, 2, core.valdim, core.n_bases), dtype=torch.float32, device=dev),
-                'zita0': torch.full((N, 2, core.n_bases), 1e-6, dtype=torch.float32, device=dev),
-                'gout': torch.zeros(3, dtype=torch.float32, device=dev),
+                'nu0': torch.zeros((B * N, 2, core.valdim, core.n_bases), dtype=torch.float32, device=dev),
+                'zita0': torch.full((B * N, 2, core.n_bases), 1e-6, dtype=torch.float32, device=dev),
+                'gout': torch.zeros((max(1, min(self.lanes, B)), 3), dtype=torch.float32, device=dev),   # per lane: its share / world
                 'k': torch.zeros(1, dtype=torch.int64, device=dev),
-                'sums': torch.zeros(3, dtype=torch.float32, device=dev),
+                # (total, main, aux) of the batch + the step's two fault flags (range, other: swem_fault_flags_f32) -- ONE message
+                'sums': torch.zeros(5, dtype=torch.float32, device=dev),
             }
             self._static_key, self._graph, self._eager_steps = key, None, 0
         return self.buf
@@ -305,40 +347,43 @@ class SWEMTrainer:
                 views.append(d)
             self._lane_state = {'streams': evaluator.overlapping_streams(n) if n > 1 else [None], 'flat': flat,
                                 'views': views, 'sums': torch.zeros((n, 3), dtype=torch.float32, device=self.device)}
+        # lane l steps the clips [chunks[l][0], chunks[l][1]) as one batch
+        self._lane_state['chunks'] = [((l * B) // n, ((l + 1) * B) // n) for l in range(n)]
         return self._lane_state
 
     # The step's clip work in three parts, so that it can run eagerly or as HIP graphs: `_pre` (main stream: re-pack the
     # filters once for all lanes, zero the lanes' gradient buffers), `_lane(l)` (lane l's clips: forward / loss / backward
     # on the lane's stream and gradient buffer), `_post` (main stream: lanes' gradients and losses summed).
     def _pre(self):
-        ls = self._lanes(self.buf['frames'].shape[0])
+        ls = self._lanes(self.buf['init_mask'].shape[0])
         A.new_step(prebuild=True)
         ls['flat'].zero_()
         ls['sums'].zero_()
-        self._results = [None] * self.buf['frames'].shape[0]
+        self._results = [None] * len(ls['streams'])
         self._lane_trunks = [[] for _ in ls['streams']]
 
     def _lane(self, l, cur_iter):
-        """Phase A of lane l: its clips' forward, loss and the backward of everything BUT the key-encoder trunk."""
+        """Phase A of lane l: its clips' forward (one batch), loss and the backward of everything BUT the key-encoder trunk."""
         bf = self.buf
-        B = bf['frames'].shape[0]
+        B = bf['init_mask'].shape[0]
         ls = self._lanes(B)
-        n = len(ls['streams'])
-        p = 1.0
+        b0, b1 = ls['chunks'][l]
+        G, N = b1 - b0, bf['init_mask'].shape[1] - 1
+        T = bf['frames'].shape[0]
         A.use_lane(l, ls['views'][l])
         self._trunks = self._lane_trunks[l]
-        for b in range(l, B, n):
-            vo = None if bf['valid'] is None else bf['valid'][b:b + 1]
-            prior = {'kappa': bf['kappa0'][b], 'nu': bf['nu0'], 'zita': bf['zita0']}
-            logits_list, res = self.clip_forward(bf['frames'][b:b + 1], bf['init_mask'][b:b + 1], vo, prior)
-            out = self.criterion.clip_loss(logits_list, bf['label'][b:b + 1, 1:], cur_iter, vo, k_dev=bf['k'])
-            vec = out['_vec']                                      # (total, main, aux) of this clip
-            vec.backward(bf['gout'])
-            ls['sums'][l].copy_(ops.lincomb(ls['sums'][l], 1.0, vec.detach(), 1.0 / B))
-            self._results[b] = torch.stack(res, dim=1)             # (1, T-1, H, W)
-            p = out['p']
+        vo = None if bf['valid'] is None else bf['valid'][b0:b1]
+        prior = {'kappa': bf['kappa0'][b0:b1].flatten(0, 1), 'nu': bf['nu0'][b0 * N:b1 * N], 'zita': bf['zita0'][b0 * N:b1 * N]}
+        # (the whole batch in one lane: the (T,B,...) buffer IS the key encoder's frame-major batch)
+        frames = bf['frames'].flatten(0, 1) if G == B else [bf['frames'][t, b0:b1] for t in range(T)]
+        logits_list, res = self.clip_forward(frames, bf['init_mask'][b0:b1], vo, prior)
+        out = self.criterion.clip_loss(logits_list, bf['label'][b0:b1, 1:], cur_iter, vo, k_dev=bf['k'])
+        vec = out['_vec']                                      # (total, main, aux): means over this lane's G clips
+        vec.backward(bf['gout'][l])
+        ls['sums'][l].copy_(ops.lincomb(vec.detach(), float(G) / B))
+        self._results[l] = torch.stack(res, dim=1)             # (G, T-1, H, W)
         A.use_lane(0, None)
-        return p
+        return out['p']
 
     def _lane_trunk(self, l):
         """Phase B of lane l: the key-encoder trunk's backward for the lane's clips (its parameters are the first slice of the
@@ -364,19 +409,19 @@ class SWEMTrainer:
 
     def _post(self):
         bf = self.buf
-        ls = self._lanes(bf['frames'].shape[0])
+        ls = self._lanes(bf['init_mask'].shape[0])
         self._sum_lanes(0, self.trunk_end)                                     # the trunk's slice
         tot = ls['sums'][0]
         for l in range(1, len(ls['streams'])):
             tot = ops.lincomb(tot, 1.0, ls['sums'][l], 1.0)
-        bf['sums'].copy_(tot)
+        bf['sums'][:3].copy_(tot)
         return torch.cat(self._results, dim=0)
 
     def _clips(self, cur_iter):
         """zero_grad + forward / loss / backward of every clip on the static buffers; returns (results, p).
         Data parallel: the all-reduce of the non-trunk gradient (6/7 of the parameters) is started as soon as every lane has
         finished phase A and runs while the lanes back-propagate through the key-encoder trunk."""
-        ls = self._lanes(self.buf['frames'].shape[0])
+        ls = self._lanes(self.buf['init_mask'].shape[0])
         main = torch.cuda.current_stream()
         self._pre()
         p = 1.0
@@ -400,8 +445,17 @@ class SWEMTrainer:
         return self._post(), p
 
     # ------------------------------------------------------------------ data-parallel reduction (RCCL over xGMI)
-    def _reduce_rest(self):
-        """Start the all-reduce of the gradient slice that phase A completed; waited for in `_reduce_finish`."""
+    def _reduce_rest(self, captured=False):
+        """Start the all-reduce of the gradient slice that phase A completed; waited for in `_reduce_finish`.
+        captured: called from inside the stream capture of the step (reduce_in_graph) -- the collective becomes a graph node, in
+        stream order, nothing to wait for; the replayed step then skips the eager call."""
+        if captured:
+            if self.overlap_allreduce and sdist.active():
+                sdist.allreduce_sum_(self.optimizer.grad[self.trunk_end:], sync=True)
+            return
+        if self.reduce_in_graph and self._graph is not None:
+            self._works = []
+            return
         self._works = sdist.allreduce_sum_async(self.optimizer.grad[self.trunk_end:]) if self.overlap_allreduce else []
 
     def _reduce_finish(self):
@@ -414,7 +468,7 @@ class SWEMTrainer:
             w.wait()
         self._works = []
 
-    def one_step(self, frames, init_mask, valid_obj, label, cur_iter):
+    def one_step(self, frames, init_mask, valid_obj, label, cur_iter, _redo=False):
         """swem_trainer.py:59-108.  With ``use_graph`` (default) the clips' forward/backward is captured into a HIP graph
         after two eager steps (which also tune the conv plans) and replayed afterwards: ~3000 launches per clip otherwise
         leave the GPU waiting for the host.  Everything that changes between steps enters through device buffers (inputs,
@@ -422,7 +476,7 @@ class SWEMTrainer:
         bf = self._static(frames, init_mask, valid_obj, label)
         B, N = frames.shape[0], init_mask.shape[1] - 1
         core = self.model.swem_core
-        bf['frames'].copy_(frames)
+        bf['frames'].copy_(frames.transpose(0, 1))             # (B,T,...) -> the frame-major buffer
         bf['init_mask'].copy_(init_mask)
         bf['label'].copy_(label)
         if valid_obj is not None:
@@ -452,7 +506,9 @@ class SWEMTrainer:
         # mean over the clips of this rank and over the ranks (DistributedDataParallel averages, swem_trainer.py:41-43)
         world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         if getattr(self, '_gout_for', None) != (B, world, id(bf['gout'])):
-            bf['gout'].copy_(torch.tensor([1.0 / (B * world), 0.0, 0.0]))
+            # a lane's loss vector is the mean over ITS clips: weight (its clips) / (clips of all lanes and ranks)
+            chunks = self._lanes(B)['chunks']
+            bf['gout'].copy_(torch.tensor([[float(b1 - b0) / (B * world), 0.0, 0.0] for b0, b1 in chunks]))
             self._gout_for = (B, world, id(bf['gout']))
         H, W = init_mask.shape[-2:]
         p, k = self.criterion.top_k(cur_iter, H * W)
@@ -466,22 +522,76 @@ class SWEMTrainer:
             with self._math():
                 results, p = self._clips(cur_iter)
             self._eager_steps += 1
+        # the step's fault flags, in stream order behind every launch of the step, into the message the loss scalars travel in:
+        # after the all-reduce every rank holds "some rank faulted" and gates its optimizer launch on it ON THE DEVICE (ADVICE
+        # r05: like GradScaler's found_inf -- no update is ever made from gradients a faulted launch produced, on any rank, and
+        # no rank steps alone into the next all-reduce)
+        _lib.call('swem_fault_flags_f32', ops._stream(), ops._fault_ptr(self.device), bf['sums'][3:].data_ptr())
+        if self._foreign_fault:
+            # bits another owner drained from the word (on_foreign_fault) are no longer on the device: they enter the flags here,
+            # every step until the host has looked -- through the all-reduce, so that every rank decides alike
+            ff = self._foreign_fault
+            bf['sums'][3:].add_(torch.tensor([float(bool(ff & ops.FAULT_RANGE)), float(bool(ff & ~ops.FAULT_RANGE))], device=self.device))
         self._reduce_finish()                                          # RCCL over xGMI; no-op for one process
-        self.optimizer.step()
+        self.optimizer.step(gate=bf['sums'][3:])
         self.lr_scheduler.step()
         # the parameters changed in place: inference through this model (validation, encode_key / segment modes) must not run
         # on the conv packs of the engine built before the step
         self.model.invalidate()
         sums = bf['sums']
         losses = {'total_loss': sums[0], 'main_loss': sums[1], 'aux_loss': sums[2], 'p': p}
-        # asynchronous faults of the step's launches (a K-split wait that expired: ops.check_faults).  The check synchronises
-        # the device, so it runs every `fault_check_every` steps (default 20: the reference's trainer reads its losses -- a
-        # synchronisation -- every LOG_PERIOD steps anyway, basic_trainer.py:105-131), and always on the eager first steps
+        # Looking at the flags synchronises the device, so the HOST looks every `fault_check_every` steps (default 20: the
+        # reference's trainer reads its losses -- a synchronisation -- every LOG_PERIOD steps anyway, basic_trainer.py:105-131), and
+        # always on the eager first steps.  Nothing is lost in between: the fault word is sticky, so from the faulting step on
+        # every optimizer launch finds the gate closed.
         self._steps_seen = getattr(self, '_steps_seen', 0) + 1
         every = getattr(self, 'fault_check_every', 20)
-        if every and (self._graph is None or self._steps_seen % every == 0):
-            ops.check_faults()
+        if every and (self._graph is None or self._steps_seen % every == 0 or (self._foreign_fault and not sdist.active())):
+            if self._look_at_faults() and not _redo:
+                return self.one_step(frames, init_mask, valid_obj, label, cur_iter, _redo=True)
         return losses, results
+
+    # ------------------------------------------------------------------ asynchronous faults of the step
+    def on_foreign_fault(self, bits):
+        """ops.drain_faults: another owner (a validation sequence about to start) found these bits in the device's fault word --
+        launches of THIS trainer's steps left them.  Remembered; the next step deals with them."""
+        self._foreign_fault |= int(bits)
+
+    def _look_at_faults(self):
+        """Read the all-reduced fault flags of the last step (synchronises).  Clean: False.  Otherwise the optimizer has not
+        moved since the faulting step (device-side gate, every rank alike); the host's step / scheduler counts are wound back to
+        what was applied, the local fault word is cleared, and
+          * a fault other than SWEM_FAULT_RANGE (a K-split / stream-K wait that expired) raises SwemHipError on EVERY rank;
+          * SWEM_FAULT_RANGE -- an activation or a scaled gradient left the fp16 range of the f16x3 arithmetic -- moves the
+            trainer to the reference's own range (fp32 MFMA / bf16x6: modes (0, 1)), warns, and returns True: the caller redoes
+            the step at hand (the batches of the skipped steps in between are lost, and counted in the warning);
+            a trainer that is on the full-range modes already raises SwemRangeError (cannot happen: no fp16 pair is produced)."""
+        import warnings
+        fl = self.buf['sums'][3:5].tolist()                 # (all-reduced: the same on every rank, and so is what follows)
+        rng, other = fl[0] != 0.0, fl[1] != 0.0
+        if not (rng or other):
+            return False
+        foreign, self._foreign_fault = self._foreign_fault, 0
+        bits = ops._collect_faults()                       # clear the local word (and, on a WAIT fault, the tile counters)
+        skipped = self.optimizer.reconcile()
+        self.lr_scheduler.rewind(skipped)
+        if other:
+            raise _lib.SwemHipError('asynchronous fault in the training step (flags range=%s other=%s, local word %#x): %s -- the '
+                                    'optimizer has not been stepped since the fault (%d steps skipped on every rank)'
+                                    % (rng, other, bits | foreign, ops._fault_text((bits | foreign) & ~ops.FAULT_RANGE) or
+                                       'raised on another rank', skipped))
+        modes = self.math_modes or ((2,) if self.amp else ((0, 1, 7) if self.f16x3 else (0, 1)))
+        if 7 not in modes:
+            raise ops.SwemRangeError('SWEM_FAULT_RANGE in a training step that runs no f16x3 launch (modes %s)' % (modes,))
+        self.f16x3, self.math_modes = False, None
+        self._graph, self._eager_steps = None, 0
+        self.book = ops.PlanBook()
+        A.reset(self.book)
+        warnings.warn('swem_amd: a training step left the fp16 range of the f16x3 arithmetic (SWEM_FAULT_RANGE on some rank): no '
+                      'optimizer update was applied from that step on (%d steps skipped); the trainer now runs the fp32-range '
+                      'arithmetic (fp32 MFMA / bf16x6, about 0.8x the step rate) and redoes the step at hand' % skipped,
+                      RuntimeWarning)
+        return True
 
     def _math(self):
         """Conv math modes of the step: config.AMP = plain bf16 operands; otherwise the fp32-level modes only (fp32 MFMA,
@@ -505,41 +615,48 @@ class SWEMTrainer:
         one hardware queue serialise (measured: 40 to 56 clips/s from run to run); separate graphs replay on the streams
         that `evaluator.overlapping_streams` found to overlap."""
         torch.cuda.synchronize()
-        ls = self._lanes(self.buf['frames'].shape[0])
+        ls = self._lanes(self.buf['init_mask'].shape[0])
         main = torch.cuda.current_stream()
         # (scratch buffers of the captured launches are allocated inside the captures, ops.workspace: the eager warm-up
         # steps left cached workspaces on these very streams, and a graph must not point into a cache entry that a later,
         # larger eager request -- e.g. 480p validation between steps -- replaces)
+        # With a collective library's process group alive its watchdog thread polls events of earlier collectives; under the default
+        # capture mode ("global") such a call from ANOTHER thread while this thread captures invalidates the capture (measured on
+        # the one-rank RCCL group of tests/_rccl_single_rank_probe.py: the process aborted in the first captured step).  The step's
+        # captures only concern this thread's launches: "thread_local".
+        cap = {'capture_error_mode': 'thread_local'} if sdist.active() else {}
         with self._math():
             g_pre = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_pre):
+            with torch.cuda.graph(g_pre, **cap):
                 self._pre()
             lanes_a, lanes_b = [], []
             for l, st in enumerate(ls['streams']):
                 g = torch.cuda.CUDAGraph()
                 if st is None:
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, **cap):
                         self._lane(l, cur_iter)
                 else:
                     st.wait_stream(main)
-                    with torch.cuda.graph(g, stream=st):
+                    with torch.cuda.graph(g, stream=st, **cap):
                         self._lane(l, cur_iter)
                 lanes_a.append(g)
             g_rest = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_rest):
+            with torch.cuda.graph(g_rest, **cap):
                 self._post_rest()
+                if self.reduce_in_graph:
+                    self._reduce_rest(captured=True)
             for l, st in enumerate(ls['streams']):
                 # phase B reads tensors phase A allocated (the trunk's activations, the cut's gradients): same memory pool
                 g = torch.cuda.CUDAGraph()
                 if st is None:
-                    with torch.cuda.graph(g, pool=lanes_a[l].pool()):
+                    with torch.cuda.graph(g, pool=lanes_a[l].pool(), **cap):
                         self._lane_trunk(l)
                 else:
-                    with torch.cuda.graph(g, stream=st, pool=lanes_a[l].pool()):
+                    with torch.cuda.graph(g, stream=st, pool=lanes_a[l].pool(), **cap):
                         self._lane_trunk(l)
                 lanes_b.append(g)
             g_post = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_post):
+            with torch.cuda.graph(g_post, **cap):
                 out = self._post()
         torch.cuda.synchronize()
         self._graph, self._graph_out = (g_pre, lanes_a, g_rest, lanes_b, g_post), out

@@ -740,6 +740,43 @@ def test_range_fault_falls_back_to_the_full_range_arithmetic(lib):
     assert agree >= 0.995, agree                             # (graph replay batches the key encoder: not bit for bit)
 
 
+def test_range_fault_fallback_against_the_oracle(lib):
+    """the one scenario in which the product changes its arithmetic BY ITSELF -- a range fault moves the book
+    to the full-range kernels -- held to the ORACLE (the reference's fp32 arithmetic on the same weights), not only to another HIP
+    run.  The model: the first block of the key encoder hands conv2 an activation 2^17 times larger (bn1's gamma and beta x 2^17,
+    conv2's filters x 2^-17): in fp32 that is the SAME function, exactly (powers of two), and as well conditioned as the
+    unscaled model -- but the activation (up to ~4e6) does not fit an fp16 pair.  The HIP model faults, falls back by itself, and
+    is then compared frame by frame, teacher-forced from the oracle's memory, at the north star's bars (teacher_forced_clip:
+    logits 1e-3 outside saturation, probabilities, index maps with every differing pixel a near-tie, memorize vs float64)."""
+    import warnings
+    from swem_amd import synth
+    from tests.test_gpu_parity import oracle_trajectory, teacher_forced_clip
+    cfg = O.make_cfg(**CFG_A)
+    model, sd = H.make_model_and_sd(cfg, 5, device=DEV)
+    sd = dict(sd)
+    for k, f in (('key_encoder.res2.0.bn1.weight', 2.0 ** 17), ('key_encoder.res2.0.bn1.bias', 2.0 ** 17),
+                 ('key_encoder.res2.0.conv2.weight', 2.0 ** -17)):
+        sd[k] = sd[k] * f
+    model.load_state_dict(sd, strict=True)
+    model.book.fallback = ops.MODEL_FALLBACK
+    frames, m0 = synth.make_clip(t=4, h=128, w=192, n_obj=2, seed=9)
+    out = (128, 192)
+    ops.check_faults()
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match='full-range arithmetic'):
+        evaluator.evaluate_davis_seq(H.SeededInit(model, 3), frames.to(DEV), [m0.to(DEV), None, None, None], out)
+    assert model.book.full_range                      # this model took the automatic way out; from here on: against the oracle
+    steps = oracle_trajectory(('range_fault', 5), O.Model(sd, cfg), frames, m0, out, seed=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        rows = teacher_forced_clip(model, steps, frames, out)
+    ops.check_faults()
+    H.record_parity('range_fault_fallback_vs_oracle', rows)
+    ran = {}
+    with torch.no_grad(), ops.flags(MATH_RAN=ran):
+        model('encode_key', frames[:, 1].to(DEV))
+    assert not ran.get(7) and not ran.get(3), ran       # (no fp16 / 16-bit operand layer is left on the fallen-back book)
+
+
 def synth_clip(t, h, w, n, seed):
     from swem_amd import synth
     return synth.make_clip(t=t, h=h, w=w, n_obj=n, out_hw=(h, w), seed=seed)

@@ -1029,6 +1029,182 @@ def test_two_ranks_one_clip_each_equal_one_rank_two_clips(lib, tmp_path, graph, 
         assert a == pytest.approx(b, rel=1e-6)
 
 
+def test_range_fault_in_a_training_step_never_reaches_the_weights(lib):
+    """fp32-level training runs f16x3 by default, and its asynchronous faults used to be read every 20 steps
+    AFTER optimizer.step().  Now the step's fault flags gate the AdamW launch on the device (swem_adamw_gated_f32, fed by
+    swem_fault_flags_f32 through the loss scalars' all-reduce): (a) an eager step that leaves the fp16 range -- the key encoder's
+    stem scaled by 3e4 -- moves nothing, the trainer switches to the reference's fp32 range (modes 0 / 1), warns and redoes the
+    step: parameters equal, bit for bit, to a trainer that never ran f16x3; (b) a fault inside REPLAYED steps that the host does
+    not look at is held back just the same: parameters and moments frozen from the faulting step until the host looks, step and
+    scheduler counts wound back, then the step at hand redone."""
+    from swem_amd import ops, train
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    case = dict(tc['cases']['r18'], hw=[128, 128])
+    cfg = O.make_cfg(**case['cfg'])
+    frames, init_mask, label, valid = [t.to(DEV) for t in H.train_batch(case)]
+    torch.manual_seed(4)
+    fixed = train.random_init_host(2, case['n'], 128, cfg.NUM_BASES)
+    real = train.random_init_host
+    train.random_init_host = lambda B, N, Cc, Lb: fixed.clone()
+
+    def make(scale):
+        model, sd = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+        if scale != 1.0:
+            sd = dict(sd)
+            sd['key_encoder.conv1.weight'] = sd['key_encoder.conv1.weight'] * scale
+            model.load_state_dict(sd, strict=True)
+        return model
+    conf = dict(SOLVER=dict(tc['solver_cfg'], BASE_LR=1e-4), LOSS=tc['loss_cfg'], AMP=False)
+    try:
+        # (a) a real range fault in the first, eager step
+        tr = SWEMTrainer(conf, make(3.0e4), use_graph=False)
+        assert tr.f16x3
+        tr.math_modes = (7,)                # (the tuner is off in the tests: every layer the pre-split kernel takes, in f16x3)
+        with pytest.warns(RuntimeWarning, match='fp32-range arithmetic'):
+            losses, _ = tr.one_step(frames, init_mask, valid, label, 45)
+        assert not tr.f16x3 and tr.optimizer.step_count == 1 and tr.lr_scheduler.last_epoch == 1
+        ref = SWEMTrainer(conf, make(3.0e4), use_graph=False)
+        ref.f16x3 = False
+        rl, _ = ref.one_step(frames, init_mask, valid, label, 45)
+        assert torch.equal(tr.optimizer.param, ref.optimizer.param)
+        assert float(losses['total_loss']) == float(rl['total_loss'])
+        ops.check_faults()
+        # (b) replayed steps, a fault the host does not look at for two steps
+        tr = SWEMTrainer(conf, make(1.0), use_graph=True)
+        tr.fault_check_every = 3
+        for it in range(3):
+            tr.one_step(frames, init_mask, valid, label, 45)
+        assert tr._graph is not None and tr.optimizer.step_count == 3
+        p3, m3 = tr.optimizer.param.clone(), tr.optimizer.m.clone()
+        ops.fault_word(torch.device(DEV)).fill_(ops.FAULT_RANGE)      # as a launch of step 4 would have
+        for it in range(2):
+            tr.one_step(frames, init_mask, valid, label, 45)          # steps 4, 5: not looked at
+        assert torch.equal(tr.optimizer.param, p3) and torch.equal(tr.optimizer.m, m3)
+        with pytest.warns(RuntimeWarning, match='3 steps skipped'):
+            tr.one_step(frames, init_mask, valid, label, 45)          # step 6: looked at, wound back, redone
+        assert tr.optimizer.step_count == 4 and tr.lr_scheduler.last_epoch == 4 and int(tr.optimizer.applied.item()) == 4
+        assert not torch.equal(tr.optimizer.param, p3)
+        ops.check_faults()
+    finally:
+        train.random_init_host = real
+
+
+def test_fault_word_ownership(lib):
+    """ONE sticky fault word per device, several owners of launches.  A fault a training step left must not
+    be read by the validation sequence that runs next and blamed on ITS model (book converted to the full-range arithmetic for
+    good): the evaluator drains the word before its first launch and hands what it finds to the registered trainer; with no
+    trainer alive the same drain raises a stale-fault error instead of blaming the sequence."""
+    import warnings
+    from swem_amd import evaluator, ops, synth
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    case = dict(tc['cases']['r18'], hw=[128, 128])
+    cfg = O.make_cfg(**case['cfg'])
+    model, _ = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+    tr = SWEMTrainer(dict(SOLVER=tc['solver_cfg'], LOSS=tc['loss_cfg'], AMP=False), model, use_graph=False)
+    val, _ = H.make_model_and_sd(cfg, 3, DEV)
+    val.book.fallback = ops.MODEL_FALLBACK
+    frames, m0 = synth.make_clip(t=3, h=128, w=192, n_obj=2, seed=9)
+    frames, m0 = frames.to(DEV), m0.to(DEV)
+    word = ops.fault_word(torch.device(DEV))
+    word.fill_(ops.FAULT_RANGE)                              # "a training step faulted and nobody has looked yet"
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match='handed it to 1 registered owner'):
+        evaluator.evaluate_davis_seq(H.SeededInit(val, 3), frames, [m0, None, None], (128, 192))
+    assert not val.book.full_range, 'the validation model was blamed for the trainer\'s fault'
+    assert tr._foreign_fault == ops.FAULT_RANGE and int(word.item()) == 0
+    # nobody to take it: loud, and named for what it is
+    del tr
+    ops.FAULT_OWNERS.clear()
+    word.fill_(ops.FAULT_KSPLIT)
+    with torch.no_grad(), pytest.raises(ops._lib.SwemHipError, match='stale asynchronous fault'):
+        evaluator.evaluate_davis_seq(H.SeededInit(val, 3), frames, [m0, None, None], (128, 192))
+    assert int(word.item()) == 0
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter('error')
+        evaluator.evaluate_davis_seq(H.SeededInit(val, 3), frames, [m0, None, None], (128, 192))
+
+
+@pytest.mark.parametrize('opts', [(), ('graph',), ('graph', 'reduce_in_graph')], ids=['eager', 'graph', 'graph_allreduce_captured'])
+def test_rccl_single_rank_training_step(lib, tmp_path, opts):
+    """RCCL met once on the hardware there is.  ONE rank with a real "nccl" (= RCCL) process group
+    (SWEM_DIST_SINGLE_RANK=1, swem_amd.dist.single_rank_group): communicator creation, barrier(device_ids), the (frames, seconds)
+    reduction, an all-reduce recorded into a HIP graph and replayed, and SWEMTrainer.one_step with its bucketed gradient
+    all-reduces + the 3-float loss all-reduce really issued (train.py: swem_trainer.py:41-43's DistributedDataParallel) -- eager,
+    between the replays of the step's graphs, and (`reduce_in_graph`) as a node INSIDE the captured step.  With one rank SUM is
+    the identity: the parameters after the steps equal those of a process without any process group, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from swem_amd import train
+    from swem_amd.train import SWEMTrainer
+    steps = 4 if 'graph' in opts else 2
+    out = str(tmp_path / 'rccl1.pt')
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_rccl_single_rank_probe.py')
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'SWEM_DIST_BACKEND'):
+        env.pop(k, None)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    run = subprocess.run([sys.executable, probe, out, str(steps)] + list(opts), env=env, capture_output=True, text=True, timeout=900)
+    if run.returncode != 0:                            # (the whole story, where the GPU box's run can be read afterwards)
+        log = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'rccl_single_rank_%s.err' % '_'.join(opts or ('eager',)))
+        os.makedirs(os.path.dirname(log), exist_ok=True)
+        with open(log, 'w') as f:
+            f.write(run.stdout + '\n---- stderr ----\n' + run.stderr)
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    got = torch.load(out)
+    rep = got['report']
+    print('RCCL single rank:', json.dumps(rep))
+    assert rep['backend'] == 'nccl' and rep['world'] == 1 and rep['active']
+    assert rep['counters'] == [10, 1.5]
+    assert rep['captured_allreduce'] == [[1.0, 1.0], [3.0, 3.0], [5.0, 5.0]]
+    assert rep['graph'] == ('graph' in opts)
+    # two gradient slices + the loss scalars per step, every step (the captured form records its slice once and replays it)
+    assert rep['all_reduce_calls'] >= (2 * steps if 'reduce_in_graph' in opts else 3 * steps), rep
+    tc = H.train_cases()
+    case = dict(tc['cases']['r18'], hw=[128, 128])
+    cfg = O.make_cfg(**case['cfg'])
+    model, _ = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+    frames, init_mask, label, valid = [t.to(DEV) for t in H.train_batch(case)]
+    tr = SWEMTrainer(dict(SOLVER=dict(tc['solver_cfg'], BASE_LR=1e-4), LOSS=tc['loss_cfg'], AMP=False), model,
+                     use_graph='graph' in opts)
+    real = train.random_init_host
+    hist = []
+    try:
+        for it in range(steps):
+            torch.manual_seed(1000 + it)
+            full = real(2, case['n'], 128, cfg.NUM_BASES)
+            train.random_init_host = lambda B, N, Cc, Lb, _f=full: _f.clone()
+            losses, _ = tr.one_step(frames, init_mask, valid, label, 5 + it)
+            hist.append([float(losses[k]) for k in ('total_loss', 'main_loss', 'aux_loss')])
+    finally:
+        train.random_init_host = real
+    assert torch.equal(tr.optimizer.param.detach().cpu(), got['param'])
+    assert hist == rep['hist']
+    H.record_parity('rccl_single_rank_training_step[%s]' % ('+'.join(opts) or 'eager'), rep)
+
+
+def test_bench_under_a_single_rank_rccl_group(lib):
+    """`bench.py` with a one-rank RCCL process group (SWEM_DIST_SINGLE_RANK=1): barrier(device_ids) and the counter all-reduce of
+    the timed regions go through librccl; the line says rccl_ranks = 1."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    env = dict(os.environ, SWEM_DIST_SINGLE_RANK='1', SWEM_DIST_BACKEND='nccl')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '4', '--warmup', '2', '--regions', '3',
+                          '--seqs', '2', '--lookahead', '2', '--no-autotune', '--no-cpu-baseline', '--no-em', '--no-legs'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1 and line['value'] > 0
+
+
 AMP_LAYERS = ('key_encoder.res2.0.conv2', 'key_encoder.layer2.0.conv2', 'key_encoder.layer3.5.conv3', 'key_proj.key_proj',
               'value_encoder.layer2.0.conv1', 'value_encoder.fuser.block1.conv1', 'value_encoder.fuser.block2.conv2',
               'decoder.compress.conv1', 'decoder.up_16_8.out_conv.conv1', 'decoder.up_8_4.skip_conv',

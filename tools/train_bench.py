@@ -29,7 +29,10 @@ def main():
     ap.add_argument('--objects', type=int, default=2)
     ap.add_argument('--backbone', default='resnet50')
     ap.add_argument('--no-autotune', action='store_true')
-    ap.add_argument('--lanes', type=int, default=4, help='clips in flight at once (streams)')
+    ap.add_argument('--lanes', type=int, default=None,
+                    help='streams the batch is cut over; each steps its share of the clips as ONE batch (default: train.DEFAULT_LANES)')
+    ap.add_argument('--cpu-baseline', action='store_true', help='time the oracle\'s training step (CPU) on one clip beside it')
+    ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--amp', action='store_true', help='config.AMP: bf16-operand convolutions')
     ap.add_argument('--per-step', action='store_true', help='synchronise and print every step time (stderr)')
     ap.add_argument('--save-plans', default=None)
@@ -99,13 +102,88 @@ def main():
     total, elapsed = sdist.reduce_counters(a.clips * a.steps, elapsed, device=dev)
     dt = elapsed / a.steps
     a.clips = total // a.steps
+    # ---- roofline: useful FLOPs of one step (counted from the step's own launch list, one eager pass: ops.FLOPS) / the replayed
+    # step's time, against the dense MFMA peak of the arithmetic the convolutions run in (MI355X_MICROARCH.md: 2500 TFLOP/s bf16 /
+    # fp16; f16x3 = three products per useful product: 833; bf16x6: 417; fp32 MFMA: 157.3)
+    roof = None
+    if not a.no_roofline:
+        fl, calls = {}, {'n': 0}
+        from swem_amd import _lib
+        real_call = _lib.call
+
+        def counting(name, *args_):
+            calls['n'] += 1
+            return real_call(name, *args_)
+        graph, tr._graph = tr._graph, None                     # one EAGER pass of the same step (same plans, same kernels)
+        use_graph, tr.use_graph = tr.use_graph, False
+        _lib.call = counting
+        try:
+            with ops.flags(FLOPS=fl):
+                tr.one_step(frames, init_mask, valid, label, 30000)
+        finally:
+            _lib.call = real_call
+            tr._graph, tr.use_graph = graph, use_graph
+        torch.cuda.synchronize()
+        per_rank_clips = a.clips // world
+        conv = fl.get('conv_fwd', 0.0) + fl.get('conv_dgrad', 0.0) + fl.get('conv_wgrad', 0.0)
+        modes = tr.math_modes or ((2,) if tr.amp else ((0, 1, 7) if tr.f16x3 else (0, 1)))
+        hist = tr.book.math_histogram(('math',) + tuple(modes))
+        peak, pipe = (2500.0, 'bf16 (config.AMP: one MFMA product per useful product)') if a.amp else \
+            ((2500.0 / 3, 'f16x3 (three fp16 MFMA products per useful product)') if hist.get('f16x3', 0) >= max(hist.get('bf16x6', 0), 1)
+             else (2500.0 / 6, 'bf16x6 (six bf16 MFMA products per useful product)'))
+        ach = (conv + fl.get('em_match', 0.0)) / per_rank_clips * (a.clips / dt) / world / 1e12
+        roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                'traffic': None, 'pipe': pipe,
+                'useful_gflop_per_clip': {k: round(v / per_rank_clips / 1e9, 2) for k, v in fl.items() if not k.endswith('launches')},
+                'useful_gflop_per_clip_total': round((conv + fl.get('em_match', 0.0)) / per_rank_clips / 1e9, 2),
+                'conv_layer_shapes_by_math': {k: v for k, v in hist.items() if v},
+                'library_calls_per_clip': round(calls['n'] / per_rank_clips, 1),
+                'conv_launches_per_clip': round((fl.get('conv_launches', 0) + fl.get('wgrad_launches', 0)) / per_rank_clips, 1),
+                'note': 'achieved = useful FLOPs of one step (2 x multiply-adds of every forward / data-gradient / weight-gradient '
+                        'convolution, unpadded, + the EM / matching GEMMs by SURVEY 8d\'s formulas; counted from the step\'s own launches '
+                        'in one eager pass) x steps/s of the replayed step, per GPU; peak = the dense matrix peak of the arithmetic '
+                        'most layers run in (the fp32-level step mixes fp32 MFMA / bf16x6 / f16x3 per layer: priced at the fastest '
+                        'of them, so frac is a lower bound); kernel-by-kernel times and launches per clip: tools/train_launches.sh '
+                        '-> profiles/r06_train_launches_*.csv'}
+    cpu = None
+    if a.cpu_baseline and rank == 0:
+        # the oracle's training step (the reference's autograd graph on torch CPU ops) on ONE clip of the same batch: forward,
+        # loss, backward -- what `one_step` does up to the optimizer launch
+        from oracle import swem_oracle as O
+        import bench
+        cpuinfo = bench.host_cpu()
+        threads = max(1, min(cpuinfo['physical_cores_available'] or torch.get_num_threads(), torch.get_num_threads()))
+        torch.set_num_threads(threads)
+        sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        names = {k for k, _ in model.named_parameters()}
+        for k, v in sd_cpu.items():
+            if k in names and v.dtype.is_floating_point:
+                v.requires_grad_(True)
+        ocfg = O.make_cfg(**vars(cfg))
+        loss_cfg = dict(NAME='boots_ce', BS_RATIO=0.3, BS_PERIOD=[20000, 70000], AUX='iou', AUX_RATIO=1.0, ONLY_VALID_OBJ=True)
+        t0c = time.time()
+        torch.manual_seed(0)
+        O.train_one_step(sd_cpu, ocfg, frames[:1].cpu(), init_mask[:1].cpu(), valid[:1].cpu(), label[:1].cpu(), 30000, loss_cfg)
+        dtc = time.time() - t0c
+        cpu = {'value': round(1.0 / dtc, 4), 'unit': 'clips/s', 'cores': threads, 'kind': 'port', 'cpu': cpuinfo,
+               'sample': 'oracle/swem_oracle.py::train_one_step (forward, loss, backward; no optimizer launch) on ONE clip of the '
+                         'same batch: %.1f s on %d torch CPU threads' % (dtc, threads)}
     if rank == 0:
-        print(json.dumps({'metric': 'training clips/s (3 x %dx%d frames, %d objects, %s, %s)' % (
-        a.size, a.size, a.objects, a.backbone, 'AMP: bf16 conv operands' if a.amp else 'fp32-accurate'), 'value': a.clips / dt, 'ms_per_step': dt * 1e3, 'clips_per_step': a.clips,
-        'total_loss': float(losses['total_loss']), 'graph': tr._graph is not None, 'lanes': a.lanes, 'n_gpus': world,
-        ('rccl_ranks' if (torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl') else 'ranks'):
-            torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
-        'peak_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30}))
+        line = {'metric': 'training clips/s (3 x %dx%d frames, %d objects, %s, %s)' % (
+            a.size, a.size, a.objects, a.backbone, 'AMP: bf16 conv operands' if a.amp else 'fp32-accurate'), 'value': a.clips / dt,
+            'unit': 'clips/s', 'ms_per_step': dt * 1e3, 'clips_per_step': a.clips,
+            'total_loss': float(losses['total_loss']), 'graph': tr._graph is not None, 'lanes': tr.lanes,
+            'clips_per_lane': [b1 - b0 for b0, b1 in tr._lane_state['chunks']], 'n_gpus': world,
+            ('rccl_ranks' if (torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl') else 'ranks'):
+                torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+            'optimizer_steps_applied': None if tr.optimizer.applied is None else int(tr.optimizer.applied.item()),
+            'optimizer_steps_issued': tr.optimizer.step_count,
+            'peak_mem_GB': torch.cuda.max_memory_allocated() / 2 ** 30}
+        if roof is not None:
+            line['roofline'] = roof
+        if cpu is not None:
+            line['cpu_baseline'] = cpu
+        print(json.dumps(line))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
