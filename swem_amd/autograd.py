@@ -61,11 +61,24 @@ _LANE = 0          # clips of a batch may run on several streams at once (train.
 _LANE_GRADS = None  # gradient buffer ({id(param): tensor view}), and packs its own copies of the filters
 
 
-def use_lane(lane, grads=None):
+_SIDE = None        # the lane's WEIGHT-GRADIENT stream (train.py, round 6), or None: everything on the lane's own stream
+_SIDE_KEEP = []     # tensors the side stream reads, kept alive until `join_side` (no reuse of their memory before it is done)
+
+
+def use_lane(lane, grads=None, side=None):
     """Route the in-kernel parameter-gradient accumulation of the following backward calls to `grads` ({id(param):
-    view of that lane's flat buffer}); None = the parameters' own .grad."""
-    global _LANE, _LANE_GRADS
-    _LANE, _LANE_GRADS = lane, grads
+    view of that lane's flat buffer}); None = the parameters' own .grad.  side: a second stream for the lane's weight gradients
+    (`_Conv.backward`): a layer's dW needs dY and the layer's input only -- nothing downstream of it waits for dW -- so it runs
+    beside the data-gradient chain (dY -> dX -> the previous layer), which is the backward pass's critical path."""
+    global _LANE, _LANE_GRADS, _SIDE
+    _LANE, _LANE_GRADS, _SIDE = lane, grads, side
+
+
+def join_side():
+    """The lane's stream waits for its weight-gradient stream; what that stream was reading may now be freed."""
+    if _SIDE is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE)
+    del _SIDE_KEEP[:]
 
 
 def _grad(p):
@@ -226,11 +239,29 @@ class _Conv(Function):
         dy.__dict__['_swem_grad'] = True      # (an fp16-pair consumer of this map gets the SCALED pair: ops.presplit)
         B, Ho, Wo, Cout = dy.shape
         dev = dy.device
-        if bias is not None and bias.requires_grad:
-            colsum(dy, out1=_grad(bias))
         H, W = srcs[0].shape[1:3]
-        if weight.requires_grad:
-            _wgrad(dy, srcs, weight, stride, pad, relu_in)
+        want_b = bias is not None and bias.requires_grad
+        if _SIDE is None:
+            if want_b:
+                colsum(dy, out1=_grad(bias))
+            if weight.requires_grad:
+                _wgrad(dy, srcs, weight, stride, pad, relu_in)
+        elif want_b or weight.requires_grad:
+            # dW and db on the lane's side stream.  dY's operand planes are shared with the data gradient below (and with whoever
+            # receives dY as a residual gradient): they are made HERE, on the lane's stream, before the fork -- a cache entry
+            # written on the side stream would be read by this stream without an order between the two.
+            if weight.requires_grad:
+                wm = wgrad_math([s_.shape[3] for s_ in srcs], Cout, weight.shape[2], weight.shape[3], B * Ho * Wo)
+                if wm:
+                    ops.presplit(dy, False, ops.PLANES_F16 if wm == 3 else 3)
+            cur = torch.cuda.current_stream()
+            _SIDE.wait_stream(cur)
+            _SIDE_KEEP.append((dy, srcs))
+            with torch.cuda.stream(_SIDE):
+                if want_b:
+                    colsum(dy, out1=_grad(bias))
+                if weight.requires_grad:
+                    _wgrad(dy, srcs, weight, stride, pad, relu_in)
         grads = []
         off = 0
         for i, s in enumerate(srcs):

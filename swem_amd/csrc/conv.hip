@@ -1137,13 +1137,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
   const int dsh = (p.flags & SWEM_CONV_DGRAD) ? p.stride - 1 : 0;
   int pix0[WM];
   unsigned long long tmask[WM];
-  // SWEM_FAST_PROLOGUE (round 5; 0 = the generic loops for every launch): the forward convolution's valid taps along an axis are
-  // the contiguous range  k in [max(0, -o0), min(K, lim - o0))  -- two bit ranges per row instead of KH + KW coordinate tests with
-  // their data-gradient branches (stamps: 2.8k of the 128x128 tile's 8.0k prologue cycles, 0.65k of the 64x64 tile's 4.0k)
-#ifndef SWEM_FAST_PROLOGUE
-#define SWEM_FAST_PROLOGUE 1
-#endif
-  const bool fwd_taps = SWEM_FAST_PROLOGUE && !(p.flags & SWEM_CONV_DGRAD) && p.KW < 32 && p.KH < 32;
+  // (round 5) the forward convolution's valid taps along an axis are the contiguous range  k in [max(0, -o0), min(K, lim - o0))
+  // -- two bit ranges per row instead of KH + KW coordinate tests with their data-gradient branches (stamps: 2.8k of the 128x128
+  // tile's 8.0k prologue cycles, 0.65k of the 64x64 tile's 4.0k); the generic loops serve the data gradient
+  const bool fwd_taps = !(p.flags & SWEM_CONV_DGRAD) && p.KW < 32 && p.KH < 32;
 #pragma unroll
   for (int j = 0; j < WM; ++j) {
     // bit (ky * KW + kx) = tap row ky valid AND tap column kx valid: KH + KW coordinate tests, not KH * KW
@@ -1219,13 +1216,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
   };
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   const unsigned lds_a = lds0 + (unsigned)g * (SA * 16), lds_b = lds0 + NST * NPL * PA * 16 + (unsigned)g * (SB * 16);
-  // SWEM_ABLATE (diagnosis builds only, tools/conv_variant.sh; results are garbage): 1 = no MFMAs in the k-loop (what the data
-  // movement alone costs), 2 = no transfers (what fragment reads + MFMAs + hand-overs alone cost)
-#ifndef SWEM_ABLATE
-#define SWEM_ABLATE 0
-#endif
   auto issue = [&](int stage) __attribute__((always_inline)) {
-    if (SWEM_ABLATE == 2) return;
     const unsigned sa = lds_a + (unsigned)stage * (NPL * PA * 16), sb = lds_b + (unsigned)stage * (NPL * PB * 16);
     if (NW == KG || half == 0) {
 #pragma unroll
@@ -1274,7 +1265,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
     const int taps = p.KH * p.KW;
     int cb = 0;
     q.ky = q.kx = 0;
-    if (!SWEM_FAST_PROLOGUE || kb_begin32 != 0) {   // (a launch without K-split starts at k-block 0: no divisions)
+    if (kb_begin32 != 0) {   // (a launch without K-split starts at k-block 0: no divisions)
       cb = kb_begin32 / taps;
       const int t = kb_begin32 - cb * taps;
       q.ky = t / p.KW;
@@ -1304,16 +1295,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
     else if (c == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");
   };
-  // SWEM_ISSUE_LATE = 1: the transfer of block kb+NST is issued right behind the hand-over of iteration kb, into the stage
-  // that barrier has just released, and flies under this iteration's MFMAs (all NST stages hold data in flight);
-  // 0 (default): it is issued at the top of the next iteration, behind those MFMAs (NST-1 stages in flight).
-  // Measured (tools/conv_bench.py, tuned plans): 1 is SLOWER -- 308 against 330 TFLOP/s on 2x120x216 256->256, 296 against
-  // 338 on 2x30x54 1280->512, and the 1x1 layers on 30x54 maps take 36 us instead of 20: the eight waves' address work and
-  // transfer requests right behind the barrier hold up all their MFMA chains at once; at the top of the next iteration they
-  // trickle in as the waves finish.
-#ifndef SWEM_ISSUE_LATE
-#define SWEM_ISSUE_LATE 0
-#endif
+  // The transfer of block kb+NST-1 is issued at the top of iteration kb, behind the previous iteration's MFMAs (NST-1 stages in
+  // flight).  (Issuing it right behind the hand-over instead -- all NST stages in flight -- measured SLOWER: 308 against 330
+  // TFLOP/s on 2x120x216 256->256, 296 against 338 on 2x30x54 1280->512: the eight waves' address work and transfer requests
+  // right behind the barrier hold up all their MFMA chains at once.  The experiment's diff: profiles/r06_experiments/.)
   if constexpr (PF) {
     // ---------------------------------------------------------------------------------------------------------------
     // Prologue: all NST stages requested; block 0's fragments into register set 0; block 1 landed and published.
@@ -1404,7 +1389,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
     STAMP_ACC_OUT(7, t_bar);
 #endif
   } else {
-    constexpr int NPRO = SWEM_ISSUE_LATE ? NST : NST - 1;   // blocks issued before the loop
+    constexpr int NPRO = NST - 1;   // blocks issued before the loop
     issue(0);
     int issued = 1;   // k-blocks handed to the DMA so far (relative to kb_begin)
 #pragma unroll
@@ -1417,15 +1402,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
     wait_blocks(issued - 1);   // block 0 has landed; the younger ones may stay in flight
     __builtin_amdgcn_s_barrier();
     STAMP(2);
-#ifdef SWEM_SETPRIO
-    // (experiment, round 5; MI355X_MICROARCH.md "Two waves per SIMD", item 4: static priority for the second-dispatched half)
-    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(SWEM_SETPRIO);
-#endif
     int st = 0;
     STAMP_ACC_DECL(t_vm);
     STAMP_ACC_DECL(t_bar);
     for (int kb = kb_begin; kb < kb_end; ++kb) {
-      if (!SWEM_ISSUE_LATE && kb + NST - 1 < kb_end) {
+      if (kb + NST - 1 < kb_end) {
         advance(q);
         issue(st == 0 ? NST - 1 : st - 1);  // stage (kb+NST-1) % NST
       }
@@ -1433,14 +1414,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
       // touch registers once the fragments are read, so any of them may run before or after it.  In front of it they would
       // hide the transfer this wave has just issued; behind it the waves of the block are decoupled while they compute (the
       // barrier does not wait for the slowest wave's MFMAs) and the next transfer starts earlier.  Measured on the config-B
-      // layers (tools/conv_bench.py, tuned plans; SWEM_MFMA_FRONT = 0 / 1 / 2 = none / half / all of the MFMAs in front):
-      // 330 / 334 / 310 TFLOP/s on 2x120x216 256->256, 338 / 317 / 302 on 2x30x54 1280->512, 329 / 314 / 296 on 2x60x108
-      // 512->256 -- everything BEHIND the hand-over wins: the other resident block's MFMAs hide the transfer, not this one's.
-      // (The compiler's own scheduling had arrived at nearly this order by sinking the MFMAs below the asm waits; it is now
-      // pinned by scheduling barriers.)
-#ifndef SWEM_MFMA_FRONT
-#define SWEM_MFMA_FRONT 0
-#endif
+      // layers (tools/conv_bench.py, tuned plans; none / half / all of the MFMAs in front): 330 / 334 / 310 TFLOP/s on
+      // 2x120x216 256->256, 338 / 317 / 302 on 2x30x54 1280->512, 329 / 314 / 296 on 2x60x108 512->256 -- everything BEHIND the
+      // hand-over wins: the other resident block's MFMAs hide the transfer, not this one's.  (The compiler's own scheduling had
+      // arrived at nearly this order by sinking the MFMAs below the asm waits; it is now pinned by scheduling barriers.  The
+      // two-waves-per-SIMD stagger and static-priority experiments of round 5 -- within +-1 % or 2-6 % slower -- are archived
+      // with this one: profiles/r06_experiments/.)
       auto hand_over = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         // block kb+1 must have landed (this wave's share); the blocks behind it (up to kb+NST-1) may stay in flight
@@ -1452,10 +1431,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of stage st are done
         __builtin_amdgcn_s_barrier();
         STAMP_ACC(t_bar);
-        if (SWEM_ISSUE_LATE && kb + NST < kb_end) {   // every wave has read stage st: refill it with block kb+NST
-          advance(q);
-          issue(st);
-        }
         __builtin_amdgcn_sched_barrier(0);
       };
       if constexpr (M16) {
@@ -1470,30 +1445,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
 #pragma unroll
           for (int i = 0; i < 2 * TN; ++i) b[pl][i] = Bb[pl * PB + 16 * i];
         }
-        constexpr int FRONT = SWEM_MFMA_FRONT * TM < 2 * TM ? SWEM_MFMA_FRONT * TM : 2 * TM;
-        // SWEM_STAGGER (experiment, round 5; MI355X_MICROARCH.md "Two waves per SIMD", item 9): the two waves of an eight-wave
-        // block that share a SIMD (w and w + 4) run the same program in lockstep -- both reach their MFMAs, their LDS reads and
-        // the barrier together.  1: waves 4-7 run their MFMAs IN FRONT of the hand-over, waves 0-3 behind it (the default
-        // order): the pair's matrix phases alternate around the barrier.  2: the halves swapped.  3: by parity (w & 1).
-#ifndef SWEM_STAGGER
-#define SWEM_STAGGER 0
-#endif
-        const bool late = SWEM_STAGGER == 0 || NW != 8 ? false
-                          : (SWEM_STAGGER == 1 ? wave >= 4 : (SWEM_STAGGER == 2 ? wave < 4 : (wave & 1) != 0));
-        if (SWEM_STAGGER != 0 && NW == 8 && !late) hand_over();
 #pragma unroll
         for (int i = 0; i < 2 * TM; ++i) {
-          if (SWEM_STAGGER == 0 || NW != 8) {
-            if (i == FRONT) hand_over();
-          }
+          if (i == 0) hand_over();
 #pragma unroll
           for (int jn = 0; jn < 2 * TN; ++jn) {
             f32x4v c = acc16[i][jn];
-            if (SWEM_ABLATE == 1) {   // (keep the fragments live: one cheap use per pair)
-              c[0] += __uint_as_float(a[0][i].x ^ b[0][jn].x ^ a[NPL - 1][i].y ^ b[NPL - 1][jn].y);
-              acc16[i][jn] = c;
-              continue;
-            }
             if constexpr (NPL == 3) {
               c = mm16<F16>(a[0][i], b[2][jn], c);
               c = mm16<F16>(a[2][i], b[0][jn], c);
@@ -1506,11 +1463,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
             c = mm16<F16>(a[0][i], b[0][jn], c);
             acc16[i][jn] = c;
           }
-        }
-        if (SWEM_STAGGER == 0 || NW != 8) {
-          if (FRONT >= 2 * TM) hand_over();
-        } else if (late) {
-          hand_over();
         }
       } else {
         const uint4 *Ab = As + st * NPL * PA + wm * 32 * TM + r;
@@ -1527,10 +1479,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
             for (int i = 0; i < TN; ++i) b[s2][pl][i] = Bb[pl * PB + k8 * SB + 32 * i];
           }
         }
-        constexpr int FRONT2 = SWEM_MFMA_FRONT >= 2 ? KG / 2 : (SWEM_MFMA_FRONT * (KG / 2)) / 2;   // k16 steps in front
 #pragma unroll
         for (int s2 = 0; s2 < KG / 2; ++s2) {
-          if (s2 == FRONT2) hand_over();
+          if (s2 == 0) hand_over();
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1549,7 +1500,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
               acc[i][jn] = c;
             }
         }
-        if (FRONT2 >= KG / 2) hand_over();
       }
       st = st == NST - 1 ? 0 : st + 1;
     }
@@ -1998,52 +1948,23 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
     // 1 x 8 layout: fa[(c + PA_) & 1] holds the A pair of step c (rows 32 c + [0, 32)), fb[PB_] this k-block's B pair.  The
     // buffer parities are compile-time constants (registers, not scratch): the k-loop is unrolled by two k-blocks.
     constexpr int NCH = TMW / 2;
-    // SWEM_T256_STAGGER (experiment, round 5; default 0 -- measured 1-5 % SLOWER on every layer, profiles/r05_kernel_experiments.txt
-    // section 8: the ~750 cycles per k-block outside the MFMAs are not an idle SIMD at the hand-over, and the stagger halves the
-    // transfers' lead; bit-identical results, kept for the record): the two waves of a SIMD (w and w + 4) run HALF A K-BLOCK apart -- waves 4-7 start behind one
-    // extra barrier -- and the block meets twice per k-block: each barrier is the END of a k-block for one half (its hand-over:
-    // last reads done, next stage published) and the MIDDLE for the other, which is busy with MFMAs on both sides of it.  So a
-    // hand-over (barrier, first fragment reads of the new stage and their latency: ~700-780 cycles per k-block of whatever tile
-    // height, in-kernel stamps) runs under the other wave's MFMAs instead of idling the SIMD (cdna_hip_programming.md, the
-    // 8-phase template's staggered wave groups).  A stage is free for the transfers of k-block kb + 2 when the LATER half has
-    // finished kb: every wave requests its share right behind that barrier (the earlier half in the middle of its k-block kb + 1,
-    // the later half at the top of its own) and waits for it (vmcnt(0)) in front of the next barrier, half a k-block later.
-#ifndef SWEM_T256_STAGGER
-#define SWEM_T256_STAGGER 0
-#endif
-    constexpr bool STAG = SWEM_T256_STAGGER != 0;
-    constexpr int HMID = NCH / 2;
-    const int grp = STAG ? (wave >> 2) : 0;
+    // (A half-k-block stagger of the two waves that share a SIMD -- waves 4-7 behind one extra barrier, two meetings per k-block
+    // -- measured 1-5 % SLOWER on every layer, profiles/r05_kernel_experiments.txt section 8: the ~750 cycles per k-block outside
+    // the MFMAs are not an idle SIMD at the hand-over, and the stagger halves the transfers' lead.  Diff: profiles/r06_experiments/.)
     uint4 fa[2][NPL][2], fb[2][NPL][2];
     load_a(0, 0, fa[0]);
     load_b(0, 0, fb[0]);
-    if (STAG && grp == 1) __builtin_amdgcn_s_barrier();   // (pairs with the first middle barrier of waves 0-3)
     int kb = kb_begin;
     auto kblock = [&](auto pa_, auto pb_) __attribute__((always_inline)) {
       constexpr int PA_ = decltype(pa_)::value, PB_ = decltype(pb_)::value;
       const bool more = kb + 1 < kb_end;
-      if (more && (!STAG || grp == 1)) {
+      if (more) {
         advance(q);
         issue_a(st ^ 1);
-        if (STAG) issue_b(st ^ 1);
       }
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (!STAG && c == 1 && more) issue_b(st ^ 1);
-        if (STAG && c == HMID) {
-          STAMP_T0(t_vm);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (waves 4-7: their share of k-block kb + 1, requested at the top)
-          STAMP_ACC(t_vm);
-          STAMP_T0(t_bar);
-          __builtin_amdgcn_s_barrier();
-          STAMP_ACC(t_bar);
-          if (more && grp == 0) {
-            advance(q);
-            issue_a(st ^ 1);
-            issue_b(st ^ 1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        if (c == 1 && more) issue_b(st ^ 1);
         if (c + 1 < NCH) {
           load_a(st, c + 1, fa[(c + 1 + PA_) & 1]);
         } else {
@@ -2085,7 +2006,6 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
       if (++kb >= kb_end) break;
       kblock(std::integral_constant<int, NCH & 1>{}, std::integral_constant<int, 1>{});
     }
-    if (STAG && grp == 0) __builtin_amdgcn_s_barrier();   // (pairs with the last end-of-k-block barrier of waves 4-7)
   }
 #undef T256_KBLOCK
 #undef T256_MFMA

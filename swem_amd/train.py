@@ -202,12 +202,14 @@ def random_init_host(B, N, Cc, Lb):
 
 
 DEFAULT_LANES = 2
+DEFAULT_WGRAD_STREAM = 1
 
 
 class SWEMTrainer:
     """swem_trainer.py:19-108 without the dataset / logging plumbing: model, criterion, optimizer, scheduler, one_step."""
 
-    def __init__(self, config, model, num_gpu=None, use_graph=True, lanes=None, overlap_allreduce=True, reduce_in_graph=False):
+    def __init__(self, config, model, num_gpu=None, use_graph=True, lanes=None, overlap_allreduce=True, reduce_in_graph=False,
+                 wgrad_stream=None):
         self.config = config
         self.model = model
         # config.AMP (configs/config.py:89, basic_trainer.py:83-86,222): the reference runs the forward under fp16
@@ -263,6 +265,11 @@ class SWEMTrainer:
         # Default (SWEM_TRAIN_LANES overrides): DEFAULT_LANES, the faster on the reference's training shapes -- measured, profiles/
         # r06_train_lanes_ab.txt.
         self.lanes = max(1, int(lanes if lanes is not None else os.environ.get('SWEM_TRAIN_LANES', DEFAULT_LANES)))
+        # every lane's weight gradients on a second stream beside its data-gradient chain (autograd.use_lane(side=...)): the
+        # backward pass's critical path is dY -> dX -> the previous layer; a third of its kernel time (dW) depends on nothing
+        # downstream.  Default (SWEM_TRAIN_WGRAD_STREAM overrides): on -- measured, profiles/r06_train_lanes_ab.txt.
+        self.wgrad_stream = bool(int(os.environ.get('SWEM_TRAIN_WGRAD_STREAM', DEFAULT_WGRAD_STREAM))) if wgrad_stream is None \
+            else bool(wgrad_stream)
         self._lane_state = None
         self._foreign_fault = 0
         ops.fault_word(dev)
@@ -345,7 +352,10 @@ class SWEMTrainer:
                     off = prm.grad.data_ptr() - opt.grad.data_ptr()
                     d[id(prm)] = flat[l, off // 4: off // 4 + prm.numel()].view(prm.shape)
                 views.append(d)
-            self._lane_state = {'streams': evaluator.overlapping_streams(n) if n > 1 else [None], 'flat': flat,
+            # (the lanes' streams and their weight-gradient streams: 2n streams probed to overlap one another)
+            sts = evaluator.overlapping_streams(2 * n if self.wgrad_stream else n) if (n > 1 or self.wgrad_stream) else [None]
+            self._lane_state = {'streams': (sts[:n] if n > 1 else [None]), 'flat': flat,
+                                'side': (sts[n:2 * n] if n > 1 else sts[:1]) if self.wgrad_stream else [None] * n,
                                 'views': views, 'sums': torch.zeros((n, 3), dtype=torch.float32, device=self.device)}
         # lane l steps the clips [chunks[l][0], chunks[l][1]) as one batch
         self._lane_state['chunks'] = [((l * B) // n, ((l + 1) * B) // n) for l in range(n)]
@@ -370,7 +380,7 @@ class SWEMTrainer:
         b0, b1 = ls['chunks'][l]
         G, N = b1 - b0, bf['init_mask'].shape[1] - 1
         T = bf['frames'].shape[0]
-        A.use_lane(l, ls['views'][l])
+        A.use_lane(l, ls['views'][l], ls['side'][l])
         self._trunks = self._lane_trunks[l]
         vo = None if bf['valid'] is None else bf['valid'][b0:b1]
         prior = {'kappa': bf['kappa0'][b0:b1].flatten(0, 1), 'nu': bf['nu0'][b0 * N:b1 * N], 'zita': bf['zita0'][b0 * N:b1 * N]}
@@ -382,6 +392,7 @@ class SWEMTrainer:
         vec.backward(bf['gout'][l])
         ls['sums'][l].copy_(ops.lincomb(vec.detach(), float(G) / B))
         self._results[l] = torch.stack(res, dim=1)             # (G, T-1, H, W)
+        A.join_side()
         A.use_lane(0, None)
         return out['p']
 
@@ -389,11 +400,12 @@ class SWEMTrainer:
         """Phase B of lane l: the key-encoder trunk's backward for the lane's clips (its parameters are the first slice of the
         flat buffer; meanwhile the rest of the gradient is summed over the lanes and all-reduced, `_post_rest`)."""
         ls = self._lane_state
-        A.use_lane(l, ls['views'][l])
+        A.use_lane(l, ls['views'][l], ls['side'][l])
         for trunk, cut in self._lane_trunks[l]:
             pairs = [(o, c.grad) for o, c in zip(trunk, cut) if c.grad is not None]
             torch.autograd.backward([o for o, _ in pairs], [g_ for _, g_ in pairs])
         self._lane_trunks[l] = []
+        A.join_side()
         A.use_lane(0, None)
 
     def _post_rest(self):

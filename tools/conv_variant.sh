@@ -1,5 +1,7 @@
 #!/bin/bash
-# Build an experimental variant of conv.hip into its own library:  tools/conv_variant.sh NAME "-DSWEM_STAGGER=1 ..."
+# Build an experimental variant of conv.hip into its own library:  tools/conv_variant.sh NAME "-DSOME_SWITCH=1 ..."
+# (the experiment switches of rounds 1-5 -- stagger, set-priority, MFMAs in front of the hand-over, late issue, ablations -- are no
+# longer in the shipped source: apply profiles/r06_experiments/conv_dead_switches.patch to get them back)
 # -> swem_amd/libswem_hip_NAME.so (conv.hip compiled with -DSWEM_ISA_SUBSET: a fifth of the instantiations, about a minute;
 # every other object as built).  Run with  SWEM_HIP_LIB=swem_amd/libswem_hip_NAME.so python tools/conv_bench.py --dominant
 set -e
