@@ -217,6 +217,39 @@ def cpu_baseline(frames, m0, sd, n_frames=20, warm=2):
                       '(one per physical core available; %s)' % (warm, n_frames, dt, threads, cpu['model'])}
 
 
+def training_leg(cpu=True, steps=10):
+    """BASELINE configs C / D (the training step, reference swem_trainer.py:59-108): a short leg of tools/train_bench.py -- 4 clips of
+    3 x 384x384, 2 objects, ResNet-50, K = 256, graph replay, the shipped training plans -- in a CHILD process (its own trainer,
+    plan book and HIP graphs; this process keeps its inference models), once per arithmetic: fp32-level (fp32 MFMA / bf16x6 / f16x3
+    per layer) and config.AMP (bf16 operands).  Each record carries clips/s, `roofline` (useful FLOPs of the step's convolutions and
+    EM / matching GEMMs / time, against the dense matrix peak of its arithmetic) and, for the fp32-level one, `cpu_baseline` (the
+    oracle's training step on one clip)."""
+    import subprocess
+    tool = os.path.join(ROOT, 'tools', 'train_bench.py')
+    out = {}
+    for key, extra in (('fp32_level', []), ('amp', ['--amp'])):
+        plans = os.path.join(ROOT, 'swem_amd', 'plans', 'mi355x_train_384_k256_%s.json' % key)
+        cmd = [sys.executable, tool, '--clips', '4', '--steps', str(steps), '--warmup', '1'] + extra
+        if os.path.exists(plans):
+            cmd += ['--load-plans', plans]
+        if cpu and key == 'fp32_level':
+            cmd += ['--cpu-baseline']
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            if r.returncode != 0 or not line:
+                out[key] = {'error': (r.stderr or r.stdout)[-600:]}
+                continue
+            d = json.loads(line[-1])
+            d['plans'] = os.path.relpath(plans, ROOT) if os.path.exists(plans) else 'tuned on the device in this run'
+            out[key] = d
+        except (subprocess.SubprocessError, OSError, ValueError) as e:
+            out[key] = {'error': repr(e)[:600]}
+    out['note'] = ('tools/train_bench.py in a child process per arithmetic, %d timed steps of 4 clips after the warm-up / capture steps; '
+                   'value = clips/s of the replayed step (forward, loss, backward, gradient sum over the lanes, gated AdamW)' % steps)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -247,6 +280,8 @@ def main():
     ap.add_argument('--no-roofline', action='store_true', help='skip the per-launch roofline / EM legs (plan search tools)')
     ap.add_argument('--round3-forms', action='store_true', help='tuner also offers the prefetched-fragment / stream-K kernel forms')
     ap.add_argument('--no-legs', action='store_true', help='skip the single-sequence and fp32-level legs (profiler runs)')
+    ap.add_argument('--no-training', action='store_true', help='skip the `training` sub-record (BASELINE configs C / D: a short leg '
+                                                              'of tools/train_bench.py in a child process, both arithmetics)')
     ap.add_argument('--trace-layers', default=None, help='write the per-launch conv list of the eager roofline frames (JSON)')
     ap.add_argument('--cpu-frames', type=int, default=20, help='timed frames of the CPU baseline (after 2 warm-up frames)')
     ap.add_argument('--max-split', type=int, default=0, help='cap the K-split factors the conv tuner may choose (0 = all)')
@@ -619,8 +654,25 @@ def main():
                 mfma_busy, mfma_src = round(hit[0]['mfma_busy'], 4), 'profiles/' + pmc_file
         except (OSError, KeyError, ValueError):
             pass
+        # counters copied from committed profile files are only as fresh as those files: older than the conv objects of the
+        # library this run loaded = measured on other code
+        def stale(src):
+            if not src:
+                return None
+            try:
+                f_ = os.path.join(ROOT, src.split(' ')[0])
+                objs = [os.path.join(ROOT, 'swem_amd', 'csrc', o_) for o_ in ('conv.o', 'conv_t256.o')]
+                newest = max(os.path.getmtime(o_) for o_ in objs if os.path.exists(o_))
+                return bool(os.path.getmtime(f_) < newest)
+            except (OSError, ValueError):
+                return None
+        tot_ms = sum(d_['ms'] for d_ in kern.values())
         roof = {
-            'bound': 'mfma', 'mfma_busy': mfma_busy, 'mfma_busy_source': mfma_src,
+            'bound': 'mfma', 'mfma_busy': mfma_busy, 'mfma_busy_source': mfma_src, 'mfma_busy_stale': stale(mfma_src),
+            'traffic_stale': stale(tsrc),
+            # every conv launch of the traced frames, each kernel weighted by the time it holds (what `frac` would be if the conv
+            # family were one kernel): the dominant kernel alone no longer speaks for the family -- its share is in dominant_kernel
+            'frac_time_weighted_all_conv_kernels': round(sum(d_['flops'] / 1e12 / peaks[k_[0]] for k_, d_ in kern.items()) / (tot_ms * 1e-3), 4),
             'mfma_busy_note': 'SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles of the dominant kernel on its largest layer, from separate '
                               'rocprofv3 --pmc passes (NOT re-measured by this run): the share of cycles the matrix pipe is busy AT '
                               'THE CLOCK THE CHIP HOLDS (1.7-2.0 GHz under this load), where frac divides by the 2.4 GHz peak',
@@ -738,6 +790,7 @@ def main():
     if world == 1 and not args.no_roofline:
         roof, pipes, per_pipe, peaks, nprof = leg_roofline(runner, hist, pmc_tag)
         out['roofline'] = roof
+        out['conv_frac_time_weighted'] = roof['frac_time_weighted_all_conv_kernels']    # (beside roofline.frac: VERDICT r05 item 8)
         # whole frame of the TIMED configuration against the blended ceiling: every FLOP priced at its pipe's peak
         conv_fl = {k: d['flops'] / nprof for k, d in pipes.items()}
         em_fl = em_flops_per_frame(n_obj)
@@ -872,6 +925,8 @@ def main():
                           '4PL(C(3T-1)+V) + 4LmP(C+V) per object' % nseq)
         if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only
             out['cpu_baseline'] = cpu_baseline(frames_cpu, m0_cpu, sd, n_frames=args.cpu_frames)
+    if rank == 0 and world == 1 and not args.no_training and not args.no_legs:
+        out['training'] = training_leg(cpu=not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(out))
     if torch.distributed.is_initialized():

@@ -424,12 +424,13 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckP p STAMP_ARG) {
         v.z += lo_f16(h.y) + lo_f16(mi.y);
         v.w += hi_f16(h.y) + hi_f16(mi.y);
       }
+      const unsigned nan_in = f32_nan(v);   // (before the ReLU turns a NaN into a clean 0: ADVICE r05)
       v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
       if (in && p.y) *reinterpret_cast<float4 *>(p.y + pix * C + n) = v;
       if (p.yp) {
         uint2 h, mi;
         split2h(v, h, mi);
-        if (in) bad |= f16_oor(v);
+        if (in) bad |= f16_oor(v) | nan_in;
         const uint2 h2 = make_uint2(__shfl_down(h.x, 1), __shfl_down(h.y, 1));
         const uint2 m2 = make_uint2(__shfl_down(mi.x, 1), __shfl_down(mi.y, 1));
         if (in && (cg & 1) == 0) {

@@ -237,6 +237,9 @@ __device__ __forceinline__ void out_tile32(const ConvP &p, const unsigned *lds, 
         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
       }
     }
+    // (a NaN must not leave through a ReLU as a clean 0 in an fp16 pair without a trace -- fmaxf(NaN, 0) = 0, and the planes of
+    // relu(y) may be the only output: the range test below looks at the value BEFORE any ReLU too)
+    const unsigned nan_in = f32_nan(v);
     if (relu_out) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
     if (in && p.y) *reinterpret_cast<float4 *>(p.y + (long long)m * p.Cout + n) = v;   // (y = NULL: planes-only output)
 #pragma unroll
@@ -246,6 +249,7 @@ __device__ __forceinline__ void out_tile32(const ConvP &p, const unsigned *lds, 
       uint2 h, mm, l;
       unsigned oor = 0;
       split_as(p.ysp_npl[var], q, h, mm, l, oor);
+      if (p.ysp_npl[var] == SWEM_PLANES_F16) oor |= nan_in;
       if (in) bad |= oor;
       const uint2 h2 = make_uint2(__shfl_down(h.x, 1), __shfl_down(h.y, 1));
       const uint2 m2 = make_uint2(__shfl_down(mm.x, 1), __shfl_down(mm.y, 1));
@@ -1662,6 +1666,99 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (KG == 2 ? 3 : 2) : 1) void conv
 #endif
 }
 
+// Epilogue of conv_t256_kernel (round 6).  conv_epilogue16 inlines one copy of out_tile32 -- residual / mask / ReLU / fp32 map / two
+// plane variants, all runtime flags -- per 32 x 32 sub-tile of the wave's accumulators, because the accumulators are registers and
+// a register array only takes compile-time indices: with this kernel's 128 accumulator registers that was 8 (+ 4 for the GLU form)
+// unrolled copies, 294 KB of code for conv_t256_kernel<true, 0>, 68 spilled registers and 72 scratch instructions in the epilogue
+// of the one-block-per-CU kernel whose measured weakness IS its epilogue.  Here the accumulators leave the
+// registers first: a pass stages up to four scaled sub-tiles (static register indices, ~70 instructions each) into the wave's
+// slice of the idle operand LDS (18 KB per wave), and ONE out_tile32 in a loop that is not unrolled takes them out -- the LDS
+// address is the only thing that depends on the loop counter.  Same values, same stores, same order per sub-tile.
+constexpr int T256_EPI_SUB = 4;                                  // sub-tiles staged per pass
+constexpr int T256_EPI_BYTES = T256_EPI_SUB * PL_BYTES;          // LDS bytes per wave (x 8 waves = 144 KB <= the block's 144 KB)
+template <int TM2, int TN2>
+__device__ __forceinline__ void t256_epilogue(const ConvP &p, f32x4v (&acc)[TM2][TN2], int mrow0, int ncol0, int lane, char *smem) {
+  static_assert(TM2 % 2 == 0 && TN2 % 2 == 0, "the output staging works on 32 x 32 sub-tiles");
+  const int col = lane & 15, rg = lane >> 4;
+  if (p.partial) {   // (a K-split launch whose partial tiles a separate kernel reduces: raw sums, as conv_epilogue16)
+    float *dst = p.partial + (long long)blockIdx.z * (p.M - p.part_m0) * p.Ncols - (long long)p.part_m0 * p.Ncols;
+#pragma unroll
+    for (int i = 0; i < TM2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN2; ++j) {
+        const int n = ncol0 + 16 * j + col;
+        if (n >= p.Ncols) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = mrow0 + 16 * i + 4 * rg + e;
+          if (m < p.M) dst[(long long)m * p.Ncols + n] = acc[i][j][e];
+        }
+      }
+    return;
+  }
+  constexpr int NI = TM2 / 2, NJ = TN2 / 2;
+  constexpr int SUBW = 32 * PL_STRIDE;                           // dwords per staged sub-tile
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned *lds = reinterpret_cast<unsigned *>(smem + wave * T256_EPI_BYTES);
+  const bool glu = TN2 == 4 && (p.flags & SWEM_CONV_GLU);
+  // per-column scale / shift of this lane's columns (GLU: tiles 0, 1 are f, tiles 2, 3 the gates of the same 32 channels)
+  float sc[TN2], sh[TN2];
+  const bool gin = ncol0 + 64 <= p.Ncols;
+#pragma unroll
+  for (int j = 0; j < TN2; ++j) {
+    const int n = ncol0 + 16 * j + col;
+    const bool nin = glu ? gin : n < p.Ncols;
+    sc[j] = (nin && p.scale) ? p.scale[n] : p.uscale;
+    sh[j] = (nin && p.shift) ? p.shift[n] : 0.f;
+  }
+  __syncthreads();   // every wave is done with the operand stages: the LDS is free for the output staging
+  const int nsub = glu ? NI : NI * NJ;                            // sub-tile s: rows 32 (s % NI), column pair s / NI
+  // The passes are spelled out (the accumulators a pass stages are dead after it: only the later passes' registers stay live
+  // across the output loop); the output loop inside a pass is NOT unrolled.
+  constexpr int NPASS = (NI * NJ + T256_EPI_SUB - 1) / T256_EPI_SUB;
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int s0 = pass * T256_EPI_SUB;
+    // ---- stage sub-tiles s0 .. s0 + 3 (compile-time register indices)
+#pragma unroll
+    for (int kk = 0; kk < T256_EPI_SUB; ++kk) {
+      const int s = s0 + kk;
+      if (s >= NI * NJ || s >= nsub) continue;
+      const int i0 = 2 * (s % NI), j0 = 2 * (s / NI);
+      unsigned *dst = lds + kk * SUBW;
+      if (glu) {
+        if constexpr (TN2 == 4) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                dst[(16 * ii + 4 * rg + e) * PL_STRIDE + 16 * j + col] = __float_as_uint(
+                    (acc[i0 + ii][j][e] * sc[j] + sh[j]) * sigmoidf_(acc[i0 + ii][j + 2][e] * sc[j + 2] + sh[j + 2]));
+        }
+      } else {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              dst[(16 * ii + 4 * rg + e) * PL_STRIDE + 16 * jj + col] =
+                  __float_as_uint(acc[i0 + ii][j0 + jj][e] * sc[j0 + jj] + sh[j0 + jj]);
+      }
+    }
+    // ---- ... and take them out: one out_tile32 per pass, the sub-tile is a runtime index
+    const int cnt = min(T256_EPI_SUB, nsub - s0);      // (<= 0 for the second pass of the GLU form: NI sub-tiles in all)
+#pragma nounroll
+    for (int k = 0; k < cnt; ++k) {
+      const int s = s0 + k;
+      const int si = s % NI, sj = s / NI;
+      out_tile32(p, lds + k * SUBW, mrow0 + 32 * si, glu ? (gin ? (ncol0 >> 1) : p.Cout) : ncol0 + 32 * sj);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // "t256" (round 5): the f16x3 convolution on a 256 x 256 tile, eight waves, ONE block per CU.
 // The kernel above is the "128x128 tile, one hand-over per k-block" structure, whose ceiling on this chip is ~900 TFLOP/s of
@@ -2072,9 +2169,9 @@ __global__ __launch_bounds__(512, 1) void conv_t256_kernel(ConvP p STAMP_ARG) {
   if (fused_last) {
     ConvP q2 = p;
     q2.partial = nullptr;
-    conv_epilogue16<NTM, NTN>(q2, acc16, m0 + wr * 128, n0 + (TMW ? wc * 32 : wc * 64), lane);
+    t256_epilogue<NTM, NTN>(q2, acc16, m0 + wr * 128, n0 + (TMW ? wc * 32 : wc * 64), lane, smem);
   } else {
-    conv_epilogue16<NTM, NTN>(p, acc16, m0 + wr * 128, n0 + (TMW ? wc * 32 : wc * 64), lane);
+    t256_epilogue<NTM, NTN>(p, acc16, m0 + wr * 128, n0 + (TMW ? wc * 32 : wc * 64), lane, smem);
   }
   STAMP(4);
 }
@@ -2088,9 +2185,13 @@ int swem_conv_t256_launch(int trows, const void *convp, unsigned gx, unsigned gy
   const ConvP &q = *static_cast<const ConvP *>(convp);
   const dim3 grid(gx, gy, gz);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  constexpr size_t lds = 2 * 2 * 2 * 4 * 256 * 16;   // two stages x (A, B) x two planes x four k/8 groups x 256 rows
+  // two stages x (A, B) x two planes x four k/8 groups x 256 rows = 128 KB for the k-loop; the epilogue stages four 32 x 32 sub-tiles
+  // per wave (t256_epilogue): 144 KB
+  constexpr size_t lds = 8 * T256_EPI_BYTES;
+  static_assert(lds >= 2 * 2 * 2 * 4 * 256 * 16 && lds <= 160 * 1024, "LDS of conv_t256_kernel");
   if (!q.f16) {   // bf16x6 (three planes): 128-row tiles, (128 + 256) rows x 3 planes x 4 groups x 16 bytes per stage
     constexpr size_t lds3 = 2 * 3 * 4 * (128 + 256) * 16;
+    static_assert(lds3 >= 8 * T256_EPI_BYTES, "the bf16x6 form's operand stages hold the epilogue's staging too");
     SWEM_ALLOW_LDS((conv_t256_kernel<false, 8>), lds3);
     hipLaunchKernelGGL((conv_t256_kernel<false, 8>), grid, dim3(512), lds3, st, q STAMP_PASS);
     return SWEM_OK;
@@ -2165,8 +2266,9 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
         v.w += rv.w;
       }
     }
-    if (p.flags & SWEM_CONV_RELU_OUT) v = relu4(v);
   }
+  const unsigned nan_in = f32_nan(v);   // (before any ReLU: out_tile32)
+  if (!glu && (p.flags & SWEM_CONV_RELU_OUT)) v = relu4(v);
   if (p.y) *reinterpret_cast<float4 *>(p.y + (long long)m * p.Cout + co) = v;
   if (!(p.ysp[0] || p.ysp[1])) return;
   // output planes (fused operand split): an even lane and its odd neighbour hold the 8 channels of one 16-byte run
@@ -2178,6 +2280,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvP p, int 
     const float4 q = var ? relu4(v) : v;
     uint2 h, mm, l;
     split_as(p.ysp_npl[var], q, h, mm, l, bad);
+    if (p.ysp_npl[var] == SWEM_PLANES_F16) bad |= nan_in;
     const uint2 h2 = make_uint2(__shfl_down(h.x, 1), __shfl_down(h.y, 1));
     const uint2 m2 = make_uint2(__shfl_down(mm.x, 1), __shfl_down(mm.y, 1));
     const uint2 l2 = make_uint2(__shfl_down(l.x, 1), __shfl_down(l.y, 1));

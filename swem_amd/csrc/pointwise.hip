@@ -167,6 +167,9 @@ __device__ __forceinline__ void planes8_out(const float4 (&v)[2], unsigned short
     uint2 h0, m0, l0, h1, m1, l1;
     split_as(npl, var ? make_float4(fmaxf(v[0].x, 0.f), fmaxf(v[0].y, 0.f), fmaxf(v[0].z, 0.f), fmaxf(v[0].w, 0.f)) : v[0], h0, m0, l0, bad);
     split_as(npl, var ? make_float4(fmaxf(v[1].x, 0.f), fmaxf(v[1].y, 0.f), fmaxf(v[1].z, 0.f), fmaxf(v[1].w, 0.f)) : v[1], h1, m1, l1, bad);
+    // (the ReLU variant: fmaxf(NaN, 0) = 0 would put a clean 0 into the fp16 pair -- the NaN is reported from the value before it,
+    // as split_f16x2_kernel does)
+    if (var && npl == SWEM_PLANES_F16) bad |= f32_nan(v[0]) | f32_nan(v[1]);
     *reinterpret_cast<uint4 *>(out + i * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
     *reinterpret_cast<uint4 *>(out + plane + i * 8) = make_uint4(m0.x, m0.y, m1.x, m1.y);
     if (npl == 3) *reinterpret_cast<uint4 *>(out + 2 * plane + i * 8) = make_uint4(l0.x, l0.y, l1.x, l1.y);

@@ -466,11 +466,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ c
     const float4 rv = ld4t(res + i * 4);
     o = make_float4(o.x + rv.x, o.y + rv.y, o.z + rv.z, o.w + rv.w);
   }
+  const unsigned nan_in = f32_nan(o);   // (before the ReLU turns a NaN into a clean 0: ADVICE r05)
   if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
   st4t(y + i * 4, o);
   if (planes) {
     store_planes4(planes, M, C, i / cq, c4 * 4, o, planes_f16 != 0);
-    if (planes_f16) range_fault(fault, f16_oor(o));
+    if (planes_f16) range_fault(fault, f16_oor(o) | nan_in);
   }
 }
 // Backward of bn_act in one pass: dz = dy * (y > 0) (also the residual's gradient), dc = dz * alpha (the conv output's

@@ -135,10 +135,9 @@ class PlanBook:
         reference's own range: its inference runs in fp32 (networks.py:22-32).  Returns the number of conv plans changed."""
         n = 0
         for k, v in list(self.conv.items()):
-            if (v >> 16) & 7 == 7:
-                if v & 0xff == 0x44:                   # (the 256-column tiles exist in f16x3 only: the 128x128 tile, no K-split change)
-                    v = (v & 0xff00) | 0x22
-                self.conv[k] = (v & 0xffff) | (1 << 16)
+            w = self._plan_full_range(v)
+            if w != v:
+                self.conv[k] = w
                 n += 1
         self.match.clear()
         self.hints.clear()
@@ -147,6 +146,19 @@ class PlanBook:
         self.fallback = 1 << 16
         self.full_range = True
         return n
+
+    @staticmethod
+    def _plan_full_range(v):
+        """A tuned plan as a full-range book may hold it: math 7 (f16x3) and math 3 (bf16x3: 16 operand bits -- not the reference's
+        arithmetic either) become bf16x6 (math 1) on the same block tile and K-split, kernel variant and tail-split bits dropped
+        (some two-plane variants have no three-plane form); the 256-column tile (0x44: the f16x3 kernel's; its bf16x6 form needs
+        its own tile height) becomes the 128x128 tile.  ONE conversion for `to_full_range` and `load` (`load` used to
+        keep 0x44 with math 1 and no variant, which resolve_plan rejects -> the heuristic tile without the tuned K-split)."""
+        if (v >> 16) & 7 in (7, 3):
+            if v & 0xff == 0x44:
+                v = (v & 0xff00) | 0x22
+            return (v & 0xffff) | (1 << 16)
+        return v
 
     def math_histogram(self, tag=()):
         """{'fp32': n, 'bf16x6': n, 'bf16': n, 'bf16x3': n, 'f16x3': n} over the conv plans tuned under the conv_math tag `tag`
@@ -181,7 +193,7 @@ class PlanBook:
         conv = {tuple(k): v for k, v in d.get('conv', [])}
         match = {tuple(k): v for k, v in d.get('match', [])}
         if self.full_range:          # (a book that faulted out of the fp16 range stays out of it)
-            conv = {k: ((v & 0xffff) | (1 << 16)) if (v >> 16) & 7 == 7 else v for k, v in conv.items()}
+            conv = {k: self._plan_full_range(v) for k, v in conv.items()}
             match = {}
         self.conv.update(conv)
         self.match.update(match)
@@ -690,6 +702,11 @@ def presplit(t, relu=False, nplanes=3):
     f16 = nplanes == PLANES_F16
     key = _pkey(relu, nplanes)
     ent = cache.get(key)
+    if ent is not None and f16 and t.__dict__.get('_swem_grad') and '_swem_inv' not in t.__dict__:
+        # a gradient map whose fp16 pair was cached UNSCALED (a producer epilogue, a caller that split it before autograd marked
+        # it): its consumers read the scale from `_swem_inv` -- make the scaled pair (this used to be a KeyError)
+        ent = None
+        cache.pop(key, None)
     site = t.__dict__.get('_swem_site')
     if site is not None and not _IN_TUNER[0]:
         # (the tuner's candidates do not count: a bf16x6 candidate that lost would leave the producer writing a third plane --
@@ -964,6 +981,8 @@ def conv2d(srcs, pack, relu_in=False, relu_out=False, residual=None, res_broadca
             plan = _PLAN_TAG[1] << 16 if (len(_PLAN_TAG) == 2 and not AUTOTUNE) else BOOK.fallback
             if _PLAN_TAG and (plan >> 16) & 7 not in CONV_MATH_MODES:
                 plan = (plan & 0xffff) | max(CONV_MATH_MODES) << 16    # (a restricted block: its most capable allowed mode)
+            if BOOK.full_range:
+                plan = PlanBook._plan_full_range(plan)                 # (whatever the block asks for: no fp16 / 16-bit operands)
             if AUTOTUNE and plan & 0xffff == 0 and not torch.cuda.is_current_stream_capturing():
                 # (a fallback that names a tile is a decision -- batch-invariant plans -- and is not tuned over)
                 plan = BOOK.conv[sig] = _autotune(launch, B * Ho * Wo, pack.cout * (2 if pack.glu else 1),
@@ -1137,6 +1156,12 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False, modes=None, t2
     """Time candidate (wave tile, K-split, math mode) plans for one layer shape; return the fastest as a plan hint.
     fresh_kw: the launcher takes fresh=True to re-split its inputs every time (the split cost is then part of the
     bf16x6 candidates' time, as if no other layer shared the input)."""
+    if modes is None:
+        modes = CONV_MATH_MODES
+    if BOOK.full_range:
+        # a book that left the fp16 range stays out of it: no f16x3 (7) and no 16-operand-bit bf16x3 (3) candidate (ADVICE r05:
+        # with the tuner on they were offered again, and a second range fault hits range_fallback's "cannot happen" re-raise)
+        modes = tuple(m_ for m_ in modes if m_ not in (7, 3)) or (1,)
     cands = [0]
     for wm, wn in _TUNE_TILES:
         if (glu and wn != 2) or (wn == 2 and ncols < 128):
@@ -1145,7 +1170,7 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False, modes=None, t2
         for ns in _TUNE_SPLITS:
             if ns > 1 and (nkb // ns < 2 or blocks * ns > 4096):
                 continue
-            for math in (modes if modes is not None else CONV_MATH_MODES):
+            for math in modes:
                 if (wm, wn) == (2, 1) and (math == 0 or ncols > 64):
                     continue                       # the 128x64 tile: where a 64-wide N leaves nothing else to widen
                 cands.append(wm | wn << 4 | ns << 8 | math << 16)
@@ -1182,7 +1207,7 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False, modes=None, t2
                                 cands.append(base | 8 << 20 | ts << 24)
                                 if math != 1 and TUNE_ROUND3_FORMS:
                                     cands.append(base | 5 << 20 | ts << 24)
-    if t256 and 7 in (modes if modes is not None else CONV_MATH_MODES) and TUNE_T256 and ncols >= 192:
+    if t256 and 7 in modes and TUNE_T256 and ncols >= 192:
         # the 256-column tile of conv_t256_kernel (f16x3 only; one block per CU): tile heights 128 .. 256 rows (plan bits
         # 20-23 = rows / 32, 0 = 256: the only GLU form), K-split so that the tiles fill the 256 CUs about once
         for v in ((0,) if glu else (0, 4, 5, 6, 7)):
@@ -1190,7 +1215,7 @@ def _autotune(launch, M, ncols, nkb, glu, reps=3, fresh_kw=False, modes=None, t2
             tiles = -(-M // rows) * -(-ncols // 256)
             for ns in sorted({1, max(1, min(nkb // 4, 256 // tiles)), max(1, min(nkb // 4, -(-256 // tiles)))}):
                 cands.append(4 | 4 << 4 | ns << 8 | 7 << 16 | v << 20)
-    if t256 and 1 in (modes if modes is not None else CONV_MATH_MODES) and TUNE_T256 and ncols >= 192 and not glu:
+    if t256 and 1 in modes and TUNE_T256 and ncols >= 192 and not glu:
         # ... and its bf16x6 form (three planes: 128-row tiles only, plan bits 20-23 = 4)
         tiles = -(-M // 128) * -(-ncols // 256)
         for ns in sorted({1, max(1, min(nkb // 4, 256 // tiles)), max(1, min(nkb // 4, -(-256 // tiles)))}):

@@ -201,8 +201,12 @@ def random_init_host(B, N, Cc, Lb):
         return kappa / (torch.linalg.norm(kappa, dim=-2, keepdim=True) + 1e-6)
 
 
-DEFAULT_LANES = 2
-DEFAULT_WGRAD_STREAM = 1
+# Measured on one box, 4 clips of 3 x 384x384, 2 objects, R50, graph replay (profiles/r06_train_lanes_ab.txt; fp32-level / AMP clips/s):
+#   4 lanes x 1 clip 89.4 / 114.8 -- 2 lanes x 2 clips 87.1 / 112.1 -- 1 lane x 4 clips 79.5 / 103.4 (82.4 / 107.9 with the weight
+#   gradients on a side stream).  Batching the clips cuts the kernel time per clip from 21.8 to 12.9 ms and the launches from 1,434
+#   to 502 (profiles/r06_train_launches_f16x3_lanes1.csv), but one stream of kernels that each fill a fraction of the chip (the
+#   1/16-scale layers: 36-72 tiles on 256 CUs) loses the 1.95x overlap four concurrent lanes get: the lanes keep the default.
+DEFAULT_LANES = 4
 
 
 class SWEMTrainer:
@@ -267,8 +271,10 @@ class SWEMTrainer:
         self.lanes = max(1, int(lanes if lanes is not None else os.environ.get('SWEM_TRAIN_LANES', DEFAULT_LANES)))
         # every lane's weight gradients on a second stream beside its data-gradient chain (autograd.use_lane(side=...)): the
         # backward pass's critical path is dY -> dX -> the previous layer; a third of its kernel time (dW) depends on nothing
-        # downstream.  Default (SWEM_TRAIN_WGRAD_STREAM overrides): on -- measured, profiles/r06_train_lanes_ab.txt.
-        self.wgrad_stream = bool(int(os.environ.get('SWEM_TRAIN_WGRAD_STREAM', DEFAULT_WGRAD_STREAM))) if wgrad_stream is None \
+        # downstream.  Measured (profiles/r06_train_lanes_ab.txt): + 3.5-4 % with ONE lane (79.5 -> 82.4 / 103.4 -> 107.9 clips/s).
+        # (beside OTHER lanes it loses: the forked branches of several lanes' graphs end up on shared hardware queues -- 89 -> 51
+        # clips/s with four lanes: the default is on for a single lane only)
+        self.wgrad_stream = bool(int(os.environ.get('SWEM_TRAIN_WGRAD_STREAM', 1 if self.lanes == 1 else 0))) if wgrad_stream is None \
             else bool(wgrad_stream)
         self._lane_state = None
         self._foreign_fault = 0

@@ -706,6 +706,42 @@ def test_f16x3_out_of_range_raises_through_a_relu_epilogue(lib):
             ops.check_faults()
 
 
+def test_nan_does_not_leave_through_a_relu_plane_without_a_fault(lib):
+    """fmaxf(NaN, 0) = 0 -- a producer that writes the fp16 pair of relu(y) tested the value AFTER the ReLU, so a NaN
+    (or -inf) in y left as a clean 0 without setting SWEM_FAULT_RANGE, and with a planes-only output nothing else carried it.
+    The producers now look at the value before the ReLU: a conv epilogue (ReLU output, and the ReLU plane variant its consumer
+    asks for), the pointwise plane writer (max-pool's consumer with an input ReLU) and the training step's frozen-BN stage."""
+    from swem_amd import _lib as L
+    ops.check_faults()
+    w = torch.ones(32, 32, 1, 1) * 0.01
+    pack = ops.pack_conv(w.to(DEV))
+    res = nhwc(torch.zeros(1, 32, 8, 8))
+    res[0, 2, 2, 5] = float('nan')                      # arrives through the fp32 residual: the operand planes are clean
+    xin = nhwc(torch.ones(1, 32, 8, 8))
+    for relu_out, relu_in in ((True, False), (False, True)):
+        with ops.use_book(ops.PlanBook()):
+            for it in range(2):                         # second pass: the producer writes the planes its consumer asked for
+                y1 = ops.conv2d([xin], pack, relu_out=relu_out, residual=res, plan=0x70011)
+                ops.conv2d([y1], pack, relu_in=relu_in, relu_out=True, plan=0x70011)
+                if it == 0:
+                    if relu_out:
+                        ops.check_faults()              # (the fp32 map holds a clean 0 already: the stand-alone split sees nothing)
+                    else:
+                        _expect_range_fault()           # (the stand-alone split tests before ITS input ReLU)
+            assert y1.__dict__.get('_swem_split'), 'the producer did not write planes'
+            _expect_range_fault()
+    # the training step's frozen-BN stage writing the fp16 pair of relu(bn(c))
+    c = torch.ones(64, 32, device=DEV)
+    c[5, 7] = float('nan')
+    one, zero = torch.ones(32, device=DEV), torch.zeros(32, device=DEV)
+    y = torch.empty_like(c)
+    planes = torch.empty((2, 64 * 32), dtype=torch.float16, device=DEV)
+    L.call('swem_bn_act_planes_f32', ops._stream(), c.data_ptr(), one.data_ptr(), zero.data_ptr(), 0, y.data_ptr(), 64, 32, 1,
+           planes.data_ptr(), ops.PLANES_F16, ops.fault_word(c.device).data_ptr())
+    assert float(y[5, 7]) == 0.0
+    _expect_range_fault()
+
+
 def test_fault_word_survives_graph_replays(lib):
     """the fault word used to be the last word of the per-capture counter buffer, whose zero fill is a node at the
     head of the captured graph -- a fault of replay k was erased by replay k + 1, and the words of every graph but the newest

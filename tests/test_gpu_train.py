@@ -492,14 +492,63 @@ def test_one_step_f16x3_matches_reference_trainer(golden, lib, tag, it):
     ops.check_faults()
 
 
-def _one_step_vs_reference(golden, tag, it, modes):
+@pytest.mark.parametrize('side', [False, True], ids=['one_stream', 'wgrad_side_stream'])
+@pytest.mark.parametrize('modes', [None, (7,)], ids=['fp32', 'f16x3'])
+def test_one_step_clip_batched_matches_reference_trainer(golden, lib, modes, side):
+    """Round 6: the clips of a lane go through the conv stack as ONE batch, as the reference's step does (swem_trainer.py:60-90:
+    `frames[:, i]` is (B,3,H,W)).  The two-clip fixture of the REFERENCE trainer (different valid_obj per clip) with one lane =
+    both clips in one pass -- key encoder on 6 frames, value encoder / decoder on 4 objects, EM and matching clip by clip inside
+    their stages, the shared maps laid out per object (autograd.expand_objects) -- held to the same bars as the lane-per-clip step;
+    `wgrad_side_stream`: the weight gradients on the lane's second stream beside the data-gradient chain."""
+    _one_step_vs_reference(golden, 'r18', 45, modes, lanes=1, wgrad_stream=side, record='_batched%s' % ('_side' if side else ''))
+
+
+def test_clip_batched_step_equals_lane_per_clip_step(lib):
+    """The same two clips stepped as one batch (one lane) and as a clip per lane: the forward is the same arithmetic image by image
+    (losses and index maps equal to rounding), the parameter gradients differ only by the order of their sums over the clips."""
+    from swem_amd import train
+    from swem_amd.train import SWEMTrainer
+    tc = H.train_cases()
+    case = dict(tc['cases']['r18'], hw=[128, 128])
+    cfg = O.make_cfg(**case['cfg'])
+    frames, init_mask, label, valid = [t.to(DEV) for t in H.train_batch(case)]
+    torch.manual_seed(4)
+    fixed = train.random_init_host(2, case['n'], 128, cfg.NUM_BASES)
+    real = train.random_init_host
+    train.random_init_host = lambda B, N, Cc, Lb: fixed.clone()
+    out = {}
+    try:
+        for lanes, side in ((2, False), (1, False), (1, True)):
+            model, _ = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
+            tr = SWEMTrainer(dict(SOLVER=tc['solver_cfg'], LOSS=tc['loss_cfg'], AMP=False), model, use_graph=False, lanes=lanes,
+                             wgrad_stream=side)
+            losses, results = tr.one_step(frames, init_mask, valid, label, 45)
+            assert [b1 - b0 for b0, b1 in tr._lane_state['chunks']] == ([1, 1] if lanes == 2 else [2])
+            out[(lanes, side)] = ([float(losses[k]) for k in ('total_loss', 'main_loss', 'aux_loss')], results.clone(),
+                                  tr.optimizer.grad.clone())
+    finally:
+        train.random_init_host = real
+    ref = out[(2, False)]
+    for key in ((1, False), (1, True)):
+        got = out[key]
+        assert got[0] == pytest.approx(ref[0], rel=1e-5), key
+        # (the fixtures' shrunken prediction head leaves the classes' probabilities close: the argmax of a few pixels is rounding)
+        assert float((got[1] == ref[1]).float().mean()) >= 0.999, key
+        rel = float((got[2] - ref[2]).norm() / ref[2].norm())
+        print('clip-batched %s vs lane-per-clip: losses %s vs %s, gradient rel diff %.3g' % (key, got[0], ref[0], rel))
+        assert rel < 2e-4, (key, rel)
+    # the side stream changes no arithmetic: bit for bit the one-stream batched step
+    assert torch.equal(out[(1, True)][2], out[(1, False)][2]) and out[(1, True)][0] == out[(1, False)][0]
+
+
+def _one_step_vs_reference(golden, tag, it, modes, lanes=None, wgrad_stream=None, record=''):
     from swem_amd.train import SWEMTrainer
     tc = H.train_cases()
     case = tc['cases'][tag]
     fx = golden('g9_train_%s_it%d.npz' % (tag, it))
     cfg = O.make_cfg(**case['cfg'])
     model, sd = H.make_model_and_sd(cfg, case['wseed'], DEV, pred_scale=tc['pred_scale'])
-    trainer = SWEMTrainer(dict(SOLVER=tc['solver_cfg'], LOSS=tc['loss_cfg'], AMP=False), model)
+    trainer = SWEMTrainer(dict(SOLVER=tc['solver_cfg'], LOSS=tc['loss_cfg'], AMP=False), model, lanes=lanes, wgrad_stream=wgrad_stream)
     trainer.math_modes = modes
     frames, init_mask, label, valid = H.train_batch(case)
     assert H.checksum(frames) == pytest.approx(float(fx['frames_sum']), rel=1e-12)
@@ -531,7 +580,7 @@ def _one_step_vs_reference(golden, tag, it, modes):
     fe = fx['floor64_elem'].tolist()
     print('   elementwise rel err: pred.weight %.2e (floor %.1e), key_proj.bias %.2e (%.1e), value conv1.weight %.2e (%.1e)'
           % (errs[0], fe[0], errs[1], fe[1], errs[2], fe[2]))
-    H.record_parity('train_step_%s_it%d%s' % (tag, it, '' if modes is None else '_f16x3'), {
+    H.record_parity('train_step_%s_it%d%s%s' % (tag, it, '' if modes is None else '_f16x3', record), {
         'losses': got, 'reference_losses': {k: float(fx[k]) for k in got}, 'reference_fp32_vs_fp64_loss_floor': float(fx['floor64_loss']),
         'index_agreement': agree, 'reference_fp32_vs_fp64_agreement': float(fx['agree64']),
         'grad_norm_rel_err': {'median': srt[len(srt) // 2], 'p90': srt[int(len(srt) * 0.9)], 'worst': srt[-1]},
@@ -714,7 +763,7 @@ def test_conv_wgrad_bf16_pipe(lib, case, math):
             assert 1e-5 < err < 2e-2, err
 
 
-@pytest.mark.parametrize('gscale', [1.0, 3.0e-7, 2.5e4], ids=['unit', 'tiny', 'huge'])
+@pytest.mark.parametrize('gscale,tail', [(1.0, 1e3), (3.0e-7, 1e3), (2.5e4, 1e3), (1.0, 1e6)], ids=['unit', 'tiny', 'huge', 'outliers_1e6'])
 @pytest.mark.parametrize('case', [
     dict(cins=[(256, 2)], cout=256, k=3, s=1, hw=(24, 24), relu_in=True),
     dict(cins=[(136, 2)], cout=200, k=3, s=2, hw=(21, 19), relu_in=False),
@@ -722,12 +771,14 @@ def test_conv_wgrad_bf16_pipe(lib, case, math):
     dict(cins=[(64, 1)], cout=128, k=1, s=2, hw=(16, 15), relu_in=True, pad=0),
     dict(cins=[(128, 3), (256, 1), (128, 3)], cout=128, k=3, s=1, hw=(9, 11), relu_in=False),
 ], ids=['whole128', 'ragged128_s2', 'ragged64', '1x1_s2', 'three_src_shared'])
-def test_conv_wgrad_f16x3_scaled(lib, case, gscale):
+def test_conv_wgrad_f16x3_scaled(lib, case, gscale, tail):
     """swem_split_f16x2_scaled_f32 + swem_conv2d_wgrad_f16x3 (round 5): the weight gradient from fp16
     (hi, mid) pairs -- dY scaled by a power of two chosen ON THE DEVICE from its largest magnitude, the activations unscaled --
     carries fp32-level error against F.conv2d's autograd in fp64 whatever the gradient's magnitude: a dY of 3e-7 (its pair would
     be all subnormal unscaled) or 2.5e4 x N(0,1) (beyond the fp16 range unscaled).  dY has a heavy tail on purpose (a few
-    elements 1e3 x the rest: the scale follows the maximum, the bulk sits ten binades below it)."""
+    elements `tail` = 1e3 x the rest: the scale follows the maximum, the bulk sits ten binades below it; `outliers_1e6` (ADVICE
+    r05): twenty binades -- the bulk's pairs keep ~17 bits there, an absolute error <= 2^-39 of the map's maximum, which is what
+    every sum the map enters is measured against: the same bar holds)."""
     from swem_amd import _lib, ops
     ops.check_faults()
     g = torch.Generator().manual_seed(13)
@@ -740,7 +791,7 @@ def test_conv_wgrad_f16x3_scaled(lib, case, gscale):
     cout = case['cout']
     Ho, Wo = (H_ + 2 * pad - k) // s + 1, (W_ + 2 * pad - k) // s + 1
     dy = torch.randn(B, cout, Ho, Wo, generator=g)
-    dy[torch.rand(dy.shape, generator=g) < 1e-3] *= 1.0e3
+    dy[torch.rand(dy.shape, generator=g) < 1e-3] *= tail
     dy = dy * gscale
     xcat = torch.cat([x.expand(B, -1, -1, -1) for x in xs], 1)
     xcat = F.relu(xcat) if case['relu_in'] else xcat
