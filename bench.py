@@ -623,7 +623,7 @@ def main():
                 'true' if sk else 'false', 'true' if pipe_ == 'f16x3' else 'false')
         dk_name = bf3s_name(*dk) if dk[0] != 'fp32' else 'conv_igemm_pipe_kernel<%d, %d>' % (dk[1], dk[2])
         traffic, tsrc = None, None
-        for name in ('r05_conv_traffic_by_kernel%s.json' % pmc_tag, 'r04_conv_traffic_by_kernel%s.json' % pmc_tag,
+        for name in ('r06_conv_traffic_by_kernel%s.json' % pmc_tag, 'r05_conv_traffic_by_kernel%s.json' % pmc_tag, 'r04_conv_traffic_by_kernel%s.json' % pmc_tag,
                      'r03_conv_traffic_by_kernel.json', 'r02_conv_traffic_by_kernel.json'):
             if traffic is not None:
                 break
@@ -645,7 +645,7 @@ def main():
                     pass
         mfma_busy, mfma_src = None, None
         try:       # counter evidence of the same kernel from the committed rocprofv3 --pmc passes (tools/pmc_kernels.sh)
-            pmc_file = next((f_ for f_ in ('r05_conv_pmc%s.json' % pmc_tag, 'r04_conv_pmc%s.json' % pmc_tag, 'r03_conv_pmc.json')
+            pmc_file = next((f_ for f_ in ('r06_conv_pmc%s.json' % pmc_tag, 'r05_conv_pmc%s.json' % pmc_tag, 'r04_conv_pmc%s.json' % pmc_tag, 'r03_conv_pmc.json')
                              if os.path.exists(os.path.join(ROOT, 'profiles', f_))), 'r03_conv_pmc.json')
             with open(os.path.join(ROOT, 'profiles', pmc_file)) as f:
                 pm = json.load(f)
@@ -657,15 +657,20 @@ def main():
         # counters copied from committed profile files are only as fresh as those files: older than the conv objects of the
         # library this run loaded = measured on other code
         def stale(src):
+            """True when the profile file `src` was measured on other convolution sources than this run's (the round's profile
+            set carries the hash of the sources it was taken on: tools/profile_stamp.py -> profiles/rNN_profile_stamp.json);
+            a profile of an earlier round, or one without a stamp, is stale by definition."""
             if not src:
                 return None
             try:
-                f_ = os.path.join(ROOT, src.split(' ')[0])
-                objs = [os.path.join(ROOT, 'swem_amd', 'csrc', o_) for o_ in ('conv.o', 'conv_t256.o')]
-                newest = max(os.path.getmtime(o_) for o_ in objs if os.path.exists(o_))
-                return bool(os.path.getmtime(f_) < newest)
-            except (OSError, ValueError):
-                return None
+                name = os.path.basename(src.split(' ')[0])
+                with open(os.path.join(ROOT, 'profiles', name[:3] + '_profile_stamp.json')) as f_:
+                    stamp = json.load(f_)['conv_sources_sha1']
+                sys.path.insert(0, os.path.join(ROOT, 'tools'))
+                import profile_stamp
+                return bool(stamp != profile_stamp.conv_sources_sha1())
+            except (OSError, KeyError, ValueError, ImportError):
+                return True
         tot_ms = sum(d_['ms'] for d_ in kern.values())
         roof = {
             'bound': 'mfma', 'mfma_busy': mfma_busy, 'mfma_busy_source': mfma_src, 'mfma_busy_stale': stale(mfma_src),
