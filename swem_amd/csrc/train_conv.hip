@@ -165,10 +165,18 @@ __device__ __forceinline__ f32x16 wg_mfma(wg_s16x8 a, wg_s16x8 b, f32x16 c) {
 // F16 (round 5, NPL = 2): the planes are fp16 (hi, mid) pairs -- dY's scaled by a power of two (swem_split_f16x2_scaled_f32) --
 // three products hi.mid + mid.hi + hi.hi on the f16 MFMA: the f16x3 arithmetic of the forward pass (fp32-level error) at half
 // the matrix work of the six-product mode.
-template <int WT, int NPL, int KS, bool F16 = false>
+// NST (round 6): stages of the slab ring.  Rounds 2-5 ran two stages with a full vmcnt(0) + barrier per slab: a slab is 12-24
+// MFMAs per wave (400-800 cycles), the L2 -> LDS round trip it must hide 2-4k -- only the CU's other resident blocks hid it.  With
+// NST stages the transfers of slab s + NST - 1 are requested at the top of slab s and the hand-over waits for slab s + 1 only
+// (counted vmcnt, as conv_igemm_bf3s_kernel does): NST - 2 slabs stay in flight across every barrier.  The slabs are consumed
+// in the same order, so the sums are bit-identical to the two-stage form.
+template <int WT, int NPL, int KS, bool F16 = false, int NST = 2>
 __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
   static_assert(KS == 16 || KS == 32, "slab of 16 or 32 pixels");
   static_assert(!F16 || NPL == 2, "fp16 planes come as a (hi, mid) pair");
+  static_assert(NST >= 2 && NST <= 4, "two to four stages");
+  constexpr int NDMA = (KS == 32 ? 2 : 1) * WT * NPL;   // 16-byte-per-lane transfers a wave requests per slab
+  static_assert(2 * NDMA <= 63, "vmcnt is a 6-bit counter");
   constexpr int NPB = F16 ? 2 : 3;              // planes behind the base pointers
   constexpr int BT = 64 * WT;
   constexpr int IMG = KS * 128;                 // bytes of one KS-pixel x 64-channel image
@@ -263,14 +271,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // wait until at most `c` of this wave's slabs (NDMA transfers each) are still in flight
+  auto wait_slabs = [&](int c) __attribute__((always_inline)) {
+    if (c <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (c == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+  };
+  const int nslab = (m_end - m_begin + KS - 1) / KS;
   issue(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int issued = 1;
+#pragma unroll
+  for (int d = 1; d < NST - 1; ++d)
+    if (d < nslab) {
+      advance();
+      issue(d);
+      ++issued;
+    }
+  wait_slabs(issued - 1);   // slab 0 has landed; the younger ones may stay in flight
   __builtin_amdgcn_s_barrier();
   int st = 0;
-  for (int mb = m_begin; mb < m_end; mb += KS) {
-    if (mb + KS < m_end) {
+  for (int sl = 0; sl < nslab; ++sl) {
+    if (sl + NST - 1 < nslab) {   // slab sl + NST - 1 into the stage the previous hand-over released
       advance();
-      issue(st ^ 1);
+      issue(st == 0 ? NST - 1 : st - 1);
     }
     const unsigned so = (unsigned)st * STAGE;
 #pragma unroll
@@ -307,10 +330,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf_kernel(WgradBP p) {
           acc[i][j] = c;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next slab has landed (this wave's share)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of stage st are done
+    // hand-over: slab sl + 1 has landed (this wave's share; the slabs behind it, up to sl + NST - 1, may stay in flight), this
+    // wave's fragment reads of stage st are done; the barrier publishes the one and frees the other
+    const int last = min(sl + NST - 1, nslab - 1);   // youngest slab requested so far
+    wait_slabs(last - (sl + 1));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    st ^= 1;
+    st = st == NST - 1 ? 0 : st + 1;
   }
   float *dst = p.partial + (long long)blockIdx.z * p.Cout * p.K + (long long)tap * p.Cin + p.c_off;
 #pragma unroll
@@ -560,18 +586,32 @@ extern "C" int swem_conv2d_wgrad_f32(void *stream, const float *dy, const float 
   return SWEM_OK;
 }
 
+// (three stages by default where they cost no resident block: 3 x stage <= 48 KB -> three blocks per CU as before)
+#define WGRAD_DEFAULT_NST(stage_bytes) ((3 * (stage_bytes) <= 48 * 1024) ? 3 : 2)
+
 // ---- bf16-pipe weight gradient (pre-split planes)
 // (the six-product mode takes the 128x128 tile from 64 tiles on: with the 16-pixel slab it keeps three blocks per CU)
 static WgradPlan wgrad_bf_plan(long long M, int Cout, int KH, int KW, int c0, int c1, int c2, int plan, int math) {
   return wgrad_pick(M, Cout, KH, KW, c0, c1, c2, plan, math == 1 ? 64 : 128);
 }
 
-template <int WT, int NPL, int KS, bool F16 = false>
-static int launch_wgrad_bf(const WgradBP &p, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = 2 * 2 * WT * NPL * KS * 128;
-  SWEM_ALLOW_LDS((conv_wgrad_bf_kernel<WT, NPL, KS, F16>), lds);
-  hipLaunchKernelGGL((conv_wgrad_bf_kernel<WT, NPL, KS, F16>), grid, dim3(256), lds, st, p);
+template <int WT, int NPL, int KS, bool F16, int NST>
+static int launch_wgrad_bf_n(const WgradBP &p, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = (size_t)NST * 2 * WT * NPL * KS * 128;
+  SWEM_ALLOW_LDS((conv_wgrad_bf_kernel<WT, NPL, KS, F16, NST>), lds);
+  hipLaunchKernelGGL((conv_wgrad_bf_kernel<WT, NPL, KS, F16, NST>), grid, dim3(256), lds, st, p);
   return SWEM_OK;
+}
+// nst: plan bits 13-14 (0 = the default below; 2, 3: forced -- tools/wgrad_bench.py --nst).  Default (round 6, measured on the
+// training shapes, profiles/r06_wgrad_nst.txt): three stages for the 64x64 tile -- the small layers, whose few blocks per CU hide
+// nothing: 33.4 -> 27.9 us on 3x96x96 1x1 64->256, 28.7 -> 23.4 on 3x48x48 1x1 128->512 -- and two for the 128x128 tile, whose three
+// resident blocks per CU already cover the round trip (three stages there: 1-4 % slower, the LDS is the co-limiter).
+template <int WT, int NPL, int KS, bool F16 = false>
+static int launch_wgrad_bf(const WgradBP &p, dim3 grid, hipStream_t st, int nst = 0) {
+  constexpr size_t stage = 2 * WT * NPL * KS * 128;
+  if (nst == 0) nst = WT == 1 ? WGRAD_DEFAULT_NST(stage) : 2;
+  if (nst >= 3 && 3 * stage <= 160 * 1024) return launch_wgrad_bf_n<WT, NPL, KS, F16, 3>(p, grid, st);
+  return launch_wgrad_bf_n<WT, NPL, KS, F16, 2>(p, grid, st);
 }
 
 extern "C" size_t swem_conv2d_wgrad_bf16x3_workspace(int B, int H, int W, int c0, int c1, int c2, int Cout, int KH,
@@ -638,15 +678,16 @@ static int wgrad_planes_impl(void *stream, const unsigned short *dy3, long long 
     // slab: 16 pixels for the six-product 128x128 tile (48 KB of LDS instead of 96: three blocks per CU), else 32;
     // plan bit 12 flips the choice (tools/wgrad_bench.py)
     const bool ks16 = ((pl.wt == 2 && (math == 1 || math == 3)) != (((plan >> 12) & 1) != 0));   // (f16x3: measured like bf16x6)
+    const int nst = (plan >> 13) & 3;
     if (math == 3) {
-      if (pl.wt == 2) rc = ks16 ? launch_wgrad_bf<2, 2, 16, true>(p, grid, st) : launch_wgrad_bf<2, 2, 32, true>(p, grid, st);
-      else rc = ks16 ? launch_wgrad_bf<1, 2, 16, true>(p, grid, st) : launch_wgrad_bf<1, 2, 32, true>(p, grid, st);
+      if (pl.wt == 2) rc = ks16 ? launch_wgrad_bf<2, 2, 16, true>(p, grid, st, nst) : launch_wgrad_bf<2, 2, 32, true>(p, grid, st, nst);
+      else rc = ks16 ? launch_wgrad_bf<1, 2, 16, true>(p, grid, st, nst) : launch_wgrad_bf<1, 2, 32, true>(p, grid, st, nst);
     } else if (pl.wt == 2) {
-      if (math == 1) rc = ks16 ? launch_wgrad_bf<2, 3, 16>(p, grid, st) : launch_wgrad_bf<2, 3, 32>(p, grid, st);
-      else rc = ks16 ? launch_wgrad_bf<2, 1, 16>(p, grid, st) : launch_wgrad_bf<2, 1, 32>(p, grid, st);
+      if (math == 1) rc = ks16 ? launch_wgrad_bf<2, 3, 16>(p, grid, st, nst) : launch_wgrad_bf<2, 3, 32>(p, grid, st, nst);
+      else rc = ks16 ? launch_wgrad_bf<2, 1, 16>(p, grid, st, nst) : launch_wgrad_bf<2, 1, 32>(p, grid, st, nst);
     } else {
-      if (math == 1) rc = ks16 ? launch_wgrad_bf<1, 3, 16>(p, grid, st) : launch_wgrad_bf<1, 3, 32>(p, grid, st);
-      else rc = ks16 ? launch_wgrad_bf<1, 1, 16>(p, grid, st) : launch_wgrad_bf<1, 1, 32>(p, grid, st);
+      if (math == 1) rc = ks16 ? launch_wgrad_bf<1, 3, 16>(p, grid, st, nst) : launch_wgrad_bf<1, 3, 32>(p, grid, st, nst);
+      else rc = ks16 ? launch_wgrad_bf<1, 1, 16>(p, grid, st, nst) : launch_wgrad_bf<1, 1, 32>(p, grid, st, nst);
     }
     if (rc != SWEM_OK) return rc;
     SWEM_CHECK_LAUNCH("conv_wgrad_bf_kernel");

@@ -16,7 +16,10 @@ SHAPES = [  # B, H, W, Cin, Cout, k, stride
 ]
 
 
+# plan: tile (bits 0-3) | pixel slices (4-11) | slab flip (12) | ring stages (13-14: 0 = the library's default, 2, 3)
 PLANS = ([0, 1 << 12] + [wt | z << 4 | f << 12 for wt in (1, 2) for z in (1, 2, 4, 8, 16, 32, 64, 128) for f in (0, 1)]) if '--tune' in sys.argv else [0]
+if '--nst' in sys.argv:      # A/B of the slab ring depth (round 6) on the default tile / slices: two stages, three, the default
+    PLANS = [2 << 13, 3 << 13, 0, 2 << 13 | 1 << 12, 3 << 13 | 1 << 12]
 
 
 def main():
@@ -70,6 +73,12 @@ def main():
             dy.__dict__['_swem_grad'] = True
             x2, d2 = ops.presplit(x, False, ops.PLANES_F16), ops.presplit(dy, False, ops.PLANES_F16)
             inv = dy.__dict__['_swem_inv']
+            def timed_plan(plan_):
+                wsb3 = _lib.query('swem_conv2d_wgrad_bf16x3_workspace', B, H, W, ci, 0, 0, co, k, k, s, pad, plan_)
+                ws3 = ops.workspace(wsb3, x.device)
+                return timed(lambda: _lib.call('swem_conv2d_wgrad_f16x3', ops._stream(), d2.data_ptr(), d2.stride(0), x2.data_ptr(), ci,
+                                               H * W * ci, x2.stride(0), 0, 0, 0, 0, 0, 0, 0, 0, B, H, W, co, k, k, s, pad, inv.data_ptr(),
+                                               dw.data_ptr(), ci, 0, plan_, ws3.data_ptr(), wsb3))
             best = None
             for plan in PLANS:
                 wsb2 = _lib.query('swem_conv2d_wgrad_bf16x3_workspace', B, H, W, ci, 0, 0, co, k, k, s, pad, plan)
@@ -84,6 +93,8 @@ def main():
                 if best is None or t < best[0]:
                     best = (t, plan, err)
             line += ' f16x3 %7.1f us %6.1f TF plan %#x err %.1e |' % (best[0], fl / best[0] / 1e6, best[1], best[2])
+            if '--nst' in sys.argv:
+                line += ' f16x3 by plan: ' + ' '.join('%#x=%.1f' % (pl_, timed_plan(pl_)) for pl_ in PLANS)
         print(line, flush=True)
 
 
