@@ -28,14 +28,24 @@ def new_step(prebuild=False):
     of packs (built lazily inside a lane they would be private to it: another lane's stream could not see them safely)."""
     _PACKS.clear()
     if prebuild:
-        for key, build in _RECIPES.items():
-            pk = _PACKS[key] = _keyed(build(), key)
-            if isinstance(pk, ops.ConvPack):
-                # (the planes the layer's plan read last step are built now, on the main stream -- not lazily inside one lane)
-                if pk.site_key in ops.F16_PACK_SITES:
-                    pk.planes16()
-                if pk.site_key in ops.BF16_PACK_SITES:
-                    pk.w3
+        prebuild_packs(0, 1)
+
+
+def prebuild_packs(part, nparts):
+    """Re-pack, on the CURRENT stream, every n-th recorded recipe (index % nparts == part): the step's filter packs, frozen-BN
+    folds and the operand planes their plans read last step.  The per-step re-pack is ~320 small dependent launches (2.6 ms of a
+    45 ms step when one stream does it alone, before anything else can start); the training step deals it out to its lanes'
+    streams and joins them before the first lane reads a pack (train.py, round 6)."""
+    for i, (key, build) in enumerate(list(_RECIPES.items())):
+        if i % nparts != part:
+            continue
+        pk = _PACKS[key] = _keyed(build(), key)
+        if isinstance(pk, ops.ConvPack):
+            # (the planes the layer's plan read last step are built now, before the lanes fork -- not lazily inside one lane)
+            if pk.site_key in ops.F16_PACK_SITES:
+                pk.planes16()
+            if pk.site_key in ops.BF16_PACK_SITES:
+                pk.w3
 
 
 def reset(book=None):

@@ -372,11 +372,16 @@ class SWEMTrainer:
     # on the lane's stream and gradient buffer), `_post` (main stream: lanes' gradients and losses summed).
     def _pre(self):
         ls = self._lanes(self.buf['init_mask'].shape[0])
-        A.new_step(prebuild=True)
+        A.new_step()                                 # (the packs themselves: `_packs`, dealt out to the lanes' streams)
         ls['flat'].zero_()
         ls['sums'].zero_()
         self._results = [None] * len(ls['streams'])
         self._lane_trunks = [[] for _ in ls['streams']]
+
+    def _packs(self, l):
+        """Lane l's share of the step's filter re-pack (autograd.prebuild_packs), on the lane's stream.  Every lane reads every
+        pack: the caller joins all lanes' streams between this and `_lane`."""
+        A.prebuild_packs(l, len(self._lane_state['streams']))
 
     def _lane(self, l, cur_iter):
         """Phase A of lane l: its clips' forward (one batch), loss and the backward of everything BUT the key-encoder trunk."""
@@ -445,7 +450,16 @@ class SWEMTrainer:
         p = 1.0
         for st in ls['streams']:
             if st is not None:
-                st.wait_stream(main)                                   # fork
+                st.wait_stream(main)                                   # fork: the re-pack, a share per lane
+        for l, st in enumerate(ls['streams']):
+            with torch.cuda.stream(st if st is not None else main):
+                self._packs(l)
+        for st in ls['streams']:
+            if st is not None:
+                main.wait_stream(st)                                   # every pack is there ...
+        for st in ls['streams']:
+            if st is not None:
+                st.wait_stream(main)                                   # ... before any lane reads one
         for l, st in enumerate(ls['streams']):
             with torch.cuda.stream(st if st is not None else main):
                 p = self._lane(l, cur_iter)
@@ -647,7 +661,20 @@ class SWEMTrainer:
             g_pre = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_pre, **cap):
                 self._pre()
-            lanes_a, lanes_b = [], []
+            packs, lanes_a, lanes_b = [], [], []
+            for l, st in enumerate(ls['streams']):
+                g = torch.cuda.CUDAGraph()
+                if st is None:
+                    with torch.cuda.graph(g, **cap):
+                        self._packs(l)
+                else:
+                    st.wait_stream(main)
+                    with torch.cuda.graph(g, stream=st, **cap):
+                        self._packs(l)
+                packs.append(g)
+            for st in ls['streams']:
+                if st is not None:
+                    main.wait_stream(st)
             for l, st in enumerate(ls['streams']):
                 g = torch.cuda.CUDAGraph()
                 if st is None:
@@ -677,13 +704,23 @@ class SWEMTrainer:
             with torch.cuda.graph(g_post, **cap):
                 out = self._post()
         torch.cuda.synchronize()
-        self._graph, self._graph_out = (g_pre, lanes_a, g_rest, lanes_b, g_post), out
+        self._graph, self._graph_out = (g_pre, packs, lanes_a, g_rest, lanes_b, g_post), out
 
     def _replay(self):
-        g_pre, lanes_a, g_rest, lanes_b, g_post = self._graph
+        g_pre, packs, lanes_a, g_rest, lanes_b, g_post = self._graph
         ls = self._lane_state
         main = torch.cuda.current_stream()
         g_pre.replay()
+        for st, g in zip(ls['streams'], packs):            # the re-pack, a share per lane's stream
+            if st is None:
+                g.replay()
+            else:
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    g.replay()
+        for st in ls['streams']:
+            if st is not None:
+                main.wait_stream(st)                       # every pack is there before any lane reads one
         for st, g in zip(ls['streams'], lanes_a):
             if st is None:
                 g.replay()
