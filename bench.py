@@ -875,7 +875,7 @@ def main():
                     fn()
                     st_.synchronize()
                     gr = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gr, stream=st_):
+                    with torch.cuda.graph(gr, stream=st_, **ops.graph_capture_kwargs()):
                         for _ in range(reps):
                             fn()
                 graphs.append(gr)

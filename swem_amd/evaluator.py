@@ -214,7 +214,7 @@ class FrameGraph:
             # replayed concurrently must not share one (torch's default capture stream is one object for all captures)
             # (scratch requested while capturing is allocated inside the capture and owned by the graph: ops.workspace)
             self.capture_stream = self.streams[1]
-            with torch.cuda.graph(self.graph, stream=self.capture_stream):
+            with torch.cuda.graph(self.graph, stream=self.capture_stream, **ops.graph_capture_kwargs()):
                 self.pred = frame_step(self.model, self.frame, self.out_size)
                 new = core.memories['update'].bases
                 for k in self.state:
@@ -332,7 +332,7 @@ class PipelinedFrameGraph(FrameGraph):
             self.pack = core.repack()
             self.capture_stream = cap
             cap.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.graph(self.graph, stream=cap):
+            with torch.cuda.graph(self.graph, stream=cap, **ops.graph_capture_kwargs()):
                 self.pred = self._body(cap, self.side)
             core.memories['update'].bases = self.state
             core.restamp()
@@ -493,9 +493,9 @@ class LookaheadGraph:
                 core.memories['update'].bases = self.state
                 self.pack = core.repack()
                 cap.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.graph(self.kg[p], stream=cap):
+                with torch.cuda.graph(self.kg[p], stream=cap, **ops.graph_capture_kwargs()):
                     self.keys[p] = self.model('encode_key', self.frames[p])
-                with torch.cuda.graph(self.cg[p], stream=cap):
+                with torch.cuda.graph(self.cg[p], stream=cap, **ops.graph_capture_kwargs()):
                     self.preds[p] = self._chains(p)
                 torch.cuda.current_stream().wait_stream(cap)
             for key in self.state:
@@ -599,7 +599,7 @@ def overlapping_streams(n, device=None, tries=12):
         with torch.cuda.stream(st):
             ops.lincomb(buf[k], 1.0)
             st.synchronize()
-            with torch.cuda.graph(g, stream=st):
+            with torch.cuda.graph(g, stream=st, **ops.graph_capture_kwargs()):
                 for _ in range(60):
                     ops.lincomb(buf[k], 1.0)
         return g

@@ -320,6 +320,16 @@ def _stream():
 _hip = None
 
 
+def graph_capture_kwargs():
+    """Keyword arguments for torch.cuda.graph(...) in this process: with a torch.distributed process group alive, the collective
+    library's watchdog thread polls events of earlier collectives, and under the default capture mode ("global") such a call from
+    ANOTHER thread while this thread captures invalidates the capture -- measured in round 6 on a one-rank RCCL group (the trainer's
+    first captured step aborted the process, tests/_rccl_single_rank_probe.py).  This package's captures only concern the capturing
+    thread's own launches: "thread_local".  Without a process group: the default."""
+    import torch.distributed as dist
+    return {'capture_error_mode': 'thread_local'} if (dist.is_available() and dist.is_initialized()) else {}
+
+
 def new_stream():
     """A HIP stream of its own.  torch.cuda.Stream() hands out 32 pooled streams round robin, so the 33rd request is the
     first stream again; scratch buffers are keyed by stream (workspace()) and captured graphs own theirs, so an aliased

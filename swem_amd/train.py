@@ -652,11 +652,7 @@ class SWEMTrainer:
         # (scratch buffers of the captured launches are allocated inside the captures, ops.workspace: the eager warm-up
         # steps left cached workspaces on these very streams, and a graph must not point into a cache entry that a later,
         # larger eager request -- e.g. 480p validation between steps -- replaces)
-        # With a collective library's process group alive its watchdog thread polls events of earlier collectives; under the default
-        # capture mode ("global") such a call from ANOTHER thread while this thread captures invalidates the capture (measured on
-        # the one-rank RCCL group of tests/_rccl_single_rank_probe.py: the process aborted in the first captured step).  The step's
-        # captures only concern this thread's launches: "thread_local".
-        cap = {'capture_error_mode': 'thread_local'} if sdist.active() else {}
+        cap = ops.graph_capture_kwargs()       # ("thread_local" while a process group's watchdog thread is alive: ops.py)
         with self._math():
             g_pre = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_pre, **cap):
