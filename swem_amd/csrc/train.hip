@@ -805,30 +805,51 @@ __global__ __launch_bounds__(256) void pred_head_bwd_x_kernel(const float *__res
   st4t(dx + i * 4, make_float4(v.x > 0.f ? acc.x : 0.f, v.y > 0.f ? acc.y : 0.f, v.z > 0.f ? acc.z : 0.f,
                                v.w > 0.f ? acc.w : 0.f));
 }
-// dw[tap][c] partial sums over a chunk of pixels; part [chunks][9][C]
-constexpr int PH_CHUNK = 256;
+// dw[tap][c] partial sums over a chunk of pixels; part [chunks][9][C].
+// Round 6: a block walks the INPUT pixels of its chunk -- thread = (pixel lane, channel quad), 256 / (C/4) pixel lanes -- reads each
+// relu(x) quad ONCE and feeds all nine taps from the nine neighbouring dlogit values (wave-uniform scalars); the lanes' partial sums
+// are added in lane order through the LDS.  (Rounds 1-5: thread = (tap, quad) walking all 256 OUTPUT pixels of a chunk with 64-bit
+// divisions per pixel: x read nine times, 72 blocks on the training shape, 288 us per launch -- the slowest launch of the step.)
+constexpr int PH_CHUNK = 64;
 __global__ __launch_bounds__(256) void pred_head_bwd_w_kernel(const float *__restrict__ x,
                                                               const float *__restrict__ dlogit,
                                                               float *__restrict__ part, int B, int H, int W, int C) {
+  extern __shared__ float phw_s[];   // [lanes][9][C]
   const int cq = C / 4;
-  const long long npix = (long long)B * H * W;
-  const long long p0 = (long long)blockIdx.x * PH_CHUNK, p1 = min(npix, p0 + PH_CHUNK);
-  for (int item = threadIdx.x; item < 9 * cq; item += 256) {
-    const int tap = item / cq, c4 = item - tap * cq;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long long pix = p0; pix < p1; ++pix) {
-      const int ox = (int)(pix % W);
-      long long t = pix / W;
-      const int oy = (int)(t % H);
-      const int b = (int)(t / H);
-      const int iy = oy - 1 + ky, ixx = ox - 1 + kx;
-      if ((unsigned)iy >= (unsigned)H || (unsigned)ixx >= (unsigned)W) continue;
-      const float d = dlogit[pix];
-      const float4 v = ld4t(x + (((long long)b * H + iy) * W + ixx) * C + c4 * 4);
-      acc.x += d * fmaxf(v.x, 0.f); acc.y += d * fmaxf(v.y, 0.f); acc.z += d * fmaxf(v.z, 0.f); acc.w += d * fmaxf(v.w, 0.f);
+  const int lanes = 256 / cq;        // (host: cq divides 256)
+  const int c4 = threadIdx.x % cq, pl = threadIdx.x / cq;
+  const int npix = B * H * W;
+  const int p0 = blockIdx.x * PH_CHUNK, p1 = min(npix, p0 + PH_CHUNK);
+  float4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int pix = p0 + pl; pix < p1; pix += lanes) {
+    const int ix = pix % W, t2 = pix / W;
+    const int iy = t2 % H, b = t2 / H;
+    float4 v = ld4t(x + (long long)pix * C + c4 * 4);
+    v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    const float *dl = dlogit + (long long)b * H * W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int oy = iy + 1 - ky;          // the output pixel whose tap (ky, kx) reads this input pixel
+      if ((unsigned)oy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ox = ix + 1 - kx;
+        if ((unsigned)ox >= (unsigned)W) continue;
+        const float d = dl[oy * W + ox];
+        float4 &a = acc[ky * 3 + kx];
+        a.x += d * v.x; a.y += d * v.y; a.z += d * v.z; a.w += d * v.w;
+      }
     }
-    st4t(part + ((long long)blockIdx.x * 9 + tap) * C + c4 * 4, acc);
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) st4t(phw_s + ((long long)pl * 9 + t) * C + c4 * 4, acc[t]);
+  __syncthreads();
+  for (int item = threadIdx.x; item < 9 * C; item += 256) {
+    float s = phw_s[item];
+    for (int l = 1; l < lanes; ++l) s += phw_s[(long long)l * 9 * C + item];
+    part[(long long)blockIdx.x * 9 * C + item] = s;
   }
 }
 // dw (OIHW [1][C][3][3]) += sum of the chunk partials; db += sum dlogit
@@ -1019,7 +1040,9 @@ extern "C" int swem_pred_head_bwd_f32(void *stream, const float *x, const float 
   float *part = static_cast<float *>(ws);
   hipLaunchKernelGGL(pred_head_bwd_x_kernel, grid1t(npix * (C / 4)), dim3(256), 0, STT, x, w, dlogit, dx, B, H, W, C);
   SWEM_CHECK_LAUNCH("pred_head_bwd_x_kernel");
-  hipLaunchKernelGGL(pred_head_bwd_w_kernel, dim3(nchunk), dim3(256), 0, STT, x, dlogit, part, B, H, W, C);
+  SWEM_REQUIRE(C / 4 <= 256 && 256 % (C / 4) == 0, SWEM_E_SHAPE, "pred_head_bwd: C / 4 must divide 256 (C = %d)", C);
+  hipLaunchKernelGGL(pred_head_bwd_w_kernel, dim3(nchunk), dim3(256), (size_t)(256 / (C / 4)) * 9 * C * sizeof(float), STT, x, dlogit,
+                     part, B, H, W, C);
   SWEM_CHECK_LAUNCH("pred_head_bwd_w_kernel");
   hipLaunchKernelGGL(pred_head_bwd_reduce_kernel, dim3(cdiv(9 * C, 256) + 1), dim3(256), 0, STT, part, dlogit, dw, db,
                      nchunk, npix, C);
