@@ -172,6 +172,10 @@ int swem_glu_bwd_f32(void *stream, const float *dy, const float *f, const float 
 int swem_add_f32(void *stream, const float *a, const float *b, float *y, long long n);
 /* backward of swem_maxpool3x3s2_nhwc_f32 (first maximum of a window takes the gradient, as ATen) */
 int swem_maxpool3x3s2_bwd_f32(void *stream, const float *x, const float *dy, float *dx, int B, int H, int W, int C);
+/* the same gradient with the forward output y = maxpool(x) at hand (a pixel wins a window iff it equals y there and no earlier
+ * position does): a quarter of the loads; bit-identical for finite inputs */
+int swem_maxpool3x3s2_bwd_y_f32(void *stream, const float *x, const float *y, const float *dy, float *dx, int B, int H, int W,
+                               int C);
 /* adjoint of the bilinear upsampling of swem_upsample_add_nhwc_f32 (the skip branch's gradient is dy itself) and of
  * swem_resize_planes_f32 mode 1 for upsampling (planes) */
 int swem_upsample_bwd_nhwc_f32(void *stream, const float *dy, float *dlow, int B, int Hl, int Wl, int Ho, int Wo,

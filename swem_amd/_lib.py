@@ -112,6 +112,7 @@ SIGNATURES = {
     'swem_glu_bwd_f32': (_i, [_p, _p, _p, _p, _p, _p, _ll]),
     'swem_add_f32': (_i, [_p, _p, _p, _p, _ll]),
     'swem_maxpool3x3s2_bwd_f32': (_i, [_p, _p, _p, _p, _i, _i, _i, _i]),
+    'swem_maxpool3x3s2_bwd_y_f32': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i]),
     'swem_upsample_bwd_nhwc_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_resize_bilinear_bwd_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _i]),
     'swem_decode_head_bwd_f32': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz]),

@@ -380,16 +380,17 @@ def bn_act(c, bn, res=None, relu=True, eps=1e-5):
 class _MaxPool(Function):
     @staticmethod
     def forward(ctx, x):
-        ctx.x = x
-        return ops.maxpool(x)
+        y = ops.maxpool(x)
+        ctx.save_for_backward(x, y)       # (y is kept alive by its consumer anyway; with it the backward needs a quarter of the loads)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x = ctx.x
+        x, y = ctx.saved_tensors
         B, H, W, Cc = x.shape
         dx = torch.empty_like(x)
-        _lib.call('swem_maxpool3x3s2_bwd_f32', ops._stream(), x.data_ptr(), dy.contiguous().data_ptr(), dx.data_ptr(), B,
-                  H, W, Cc)
+        _lib.call('swem_maxpool3x3s2_bwd_y_f32', ops._stream(), x.data_ptr(), y.data_ptr(), dy.contiguous().data_ptr(),
+                  dx.data_ptr(), B, H, W, Cc)
         return dx
 
 

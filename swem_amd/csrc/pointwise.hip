@@ -758,7 +758,7 @@ __global__ void cbam_bwd_pix2_kernel(const float *__restrict__ x, const float *_
   }
 }
 // channel-gate MLP backward, one block, batch items in sequence (the parameter gradients accumulate)
-__global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float *__restrict__ avg, const float *__restrict__ mx,
+__global__ __launch_bounds__(1024) void cbam_bwd_mlp_kernel(const float *__restrict__ avg, const float *__restrict__ mx,
                                                            const float *__restrict__ cscale,
                                                            const float *__restrict__ dg, const float *__restrict__ w1,
                                                            const float *__restrict__ b1, const float *__restrict__ w2,
@@ -766,8 +766,8 @@ __global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float *__restri
                                                            float *__restrict__ dw2, float *__restrict__ db2,
                                                            float *__restrict__ davg, float *__restrict__ dmx, int B,
                                                            int C, int hid) {
-  extern __shared__ float sm[];  // dA[C], h[2][hid], dh[2][hid]
-  float *dA = sm, *hd = sm + C, *dh = hd + 2 * hid;
+  extern __shared__ float sm[];  // dA[C], h[2][hid], dh[2][hid], partial davg / dmax [2][4][C]
+  float *dA = sm, *hd = sm + C, *dh = hd + 2 * hid, *pa = dh + 2 * hid;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int b = 0; b < B; ++b) {
     const float *av = avg + (long long)b * C, *mv = mx + (long long)b * C;
@@ -795,17 +795,27 @@ __global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float *__restri
       }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    // (round 6: work items (channel, j lane) over 1024 threads -- four lanes take every fourth hidden unit; rounds 1-5 walked all
+    // hid units per channel on 256 threads, a chain of dependent read-modify-writes: 132 us per launch)
+    for (int item = threadIdx.x; item < 4 * C; item += blockDim.x) {
+      const int c = item % C, jl = item / C;
       float da_ = 0.f, dm_ = 0.f;
-      for (int j = 0; j < hid; ++j) {
-        dw2[(long long)c * hid + j] += dA[c] * (hd[j] + hd[hid + j]);
-        dw1[(long long)j * C + c] += dh[j] * av[c] + dh[hid + j] * mv[c];
-        da_ += w1[(long long)j * C + c] * dh[j];
-        dm_ += w1[(long long)j * C + c] * dh[hid + j];
+      const float a_c = dA[c], av_c = av[c], mv_c = mv[c];
+      for (int j = jl; j < hid; j += 4) {
+        dw2[(long long)c * hid + j] += a_c * (hd[j] + hd[hid + j]);
+        dw1[(long long)j * C + c] += dh[j] * av_c + dh[hid + j] * mv_c;
+        const float wv = w1[(long long)j * C + c];
+        da_ += wv * dh[j];
+        dm_ += wv * dh[hid + j];
       }
+      pa[jl * C + c] = da_;
+      pa[(4 + jl) * C + c] = dm_;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
       db2[c] += 2.f * dA[c];
-      davg[(long long)b * C + c] = da_;
-      dmx[(long long)b * C + c] = dm_;
+      davg[(long long)b * C + c] = ((pa[c] + pa[C + c]) + pa[2 * C + c]) + pa[3 * C + c];
+      dmx[(long long)b * C + c] = ((pa[4 * C + c] + pa[5 * C + c]) + pa[6 * C + c]) + pa[7 * C + c];
     }
     __syncthreads();
   }
@@ -1294,7 +1304,8 @@ extern "C" int swem_cbam_bwd_f32(void *stream, const float *x, const float *w1, 
   hipLaunchKernelGGL(cbam_bwd_pix2_kernel, grid1((long long)B * P * 64), dim3(256), 0, ST, x, dy, cscale, sg, comp,
                      dcomp, du, dxp, B, P, C);
   hipLaunchKernelGGL(cbam_bwd_dg_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, ST, du, x, dg, P, C);
-  hipLaunchKernelGGL(cbam_bwd_mlp_kernel, dim3(1), dim3(256), (C + 4 * hid) * sizeof(float), ST, avg, mx, cscale, dg, w1,
+  SWEM_REQUIRE((size_t)(9 * C + 4 * hid) * sizeof(float) <= 64 * 1024, SWEM_E_SHAPE, "cbam_bwd: C = %d, hid = %d need more than 64 KB of LDS", C, hid);
+  hipLaunchKernelGGL(cbam_bwd_mlp_kernel, dim3(1), dim3(1024), (9 * C + 4 * hid) * sizeof(float), ST, avg, mx, cscale, dg, w1,
                      b1, w2, dw1, db1, dw2, db2, davg, dmx, B, C, hid);
   hipLaunchKernelGGL(cbam_bwd_pix3_kernel, grid1((long long)B * P * (C / 4)), dim3(256), 0, ST, dxp, davg, dmx, amax, dx,
                      B, P, C);

@@ -114,10 +114,24 @@ __global__ __launch_bounds__(1024) void loss_row_select_kernel(const float *__re
       if (tid < 256) hist[tid] = 0;
       __syncthreads();
       const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+      // (run-length merged: cross-entropy values share their sign / exponent byte almost everywhere, so the first passes would
+      // send a thousand threads' increments to two or three LDS words, one at a time -- 230 us for a 147k-pixel row, the step's
+      // slowest single-block launch; a thread counts a run of equal digits in a register and adds it once.  Counts are integers:
+      // the histogram is the same whatever the order.)
+      unsigned run_d = 256u, run_n = 0u;
       for (long long i = tid; i < HW; i += 1024) {
         const unsigned key = fkey(row[i]);
-        if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+        if ((key & himask) != prefix) continue;
+        const unsigned dgt = (key >> shift) & 255u;
+        if (dgt == run_d) {
+          ++run_n;
+        } else {
+          if (run_n) atomicAdd(&hist[run_d], run_n);
+          run_d = dgt;
+          run_n = 1u;
+        }
       }
+      if (run_n) atomicAdd(&hist[run_d], run_n);
       __syncthreads();
       if (tid == 0) {
         unsigned acc = 0;
@@ -662,6 +676,63 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restric
   st4t(dx + i * 4, make_float4(g[0], g[1], g[2], g[3]));
 }
 
+// The same gradient when the forward OUTPUT y is at hand (round 6): a pixel takes a window's gradient iff it equals the window's
+// maximum y and no EARLIER position of the window (ATen scan order ky, kx) does -- one 16-byte load of y and one of dy per window
+// (<= 4 windows per pixel), the earlier positions looked at only where the pixel itself attains the maximum (one position in nine).
+// maxpool_bwd_kernel above re-derives every window's maximum from its nine inputs: up to 36 loads per pixel, 126 us per launch on
+// the training shape.  Same result bit for bit (finite inputs).
+__global__ __launch_bounds__(256) void maxpool_bwd_y_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                            const float *__restrict__ dy, float *__restrict__ dx, int B, int H,
+                                                            int W, int C, int Ho, int Wo) {
+  const int cq = C / 4;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * H * W * cq) return;
+  const int c4 = (int)(i % cq);
+  long long t = i / cq;
+  const int ix = (int)(t % W);
+  t /= W;
+  const int iy = (int)(t % H);
+  const int b = (int)(t / H);
+  const float4 me = ld4t(x + i * 4);
+  const float mv[4] = {me.x, me.y, me.z, me.w};
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int oy = max(0, iy / 2); oy <= min(Ho - 1, (iy + 1) / 2); ++oy)
+    for (int ox = max(0, ix / 2); ox <= min(Wo - 1, (ix + 1) / 2); ++ox) {
+      const long long o = (((long long)b * Ho + oy) * Wo + ox) * C + c4 * 4;
+      const float4 m = ld4t(y + o);
+      const float mm[4] = {m.x, m.y, m.z, m.w};
+      bool win[4];
+      bool any = false;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        win[e] = mv[e] == mm[e];
+        any |= win[e];
+      }
+      if (!any) continue;
+      // an earlier position of this window that attains the maximum too takes the gradient instead
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = oy * 2 - 1 + ky;
+        if ((unsigned)yy >= (unsigned)H || yy > iy) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = ox * 2 - 1 + kx;
+          if ((unsigned)xx >= (unsigned)W) continue;
+          if (!(yy < iy || xx < ix)) continue;      // (scan order: rows first)
+          const float4 ov4 = ld4t(x + (((long long)b * H + yy) * W + xx) * C + c4 * 4);
+          const float ov[4] = {ov4.x, ov4.y, ov4.z, ov4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ov[e] == mm[e]) win[e] = false;
+        }
+      }
+      const float4 d = ld4t(dy + o);
+      const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (win[e]) g[e] += dv[e];
+    }
+  st4t(dx + i * 4, make_float4(g[0], g[1], g[2], g[3]));
+}
+
 // ---- adjoint of the bilinear upsampling inside upsample_add: dlow[b][ly][lx][c] = sum_o w(o->l) dy[b][oy][ox][c]
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dlow, int B,
                                                            int Hl, int Wl, int Ho, int Wo, int C) {
@@ -993,6 +1064,15 @@ extern "C" int swem_maxpool3x3s2_bwd_f32(void *stream, const float *x, const flo
   hipLaunchKernelGGL(maxpool_bwd_kernel, grid1t((long long)B * H * W * (C / 4)), dim3(256), 0, STT, x, dy, dx, B, H, W,
                      C, Ho, Wo);
   SWEM_CHECK_LAUNCH("maxpool_bwd_kernel");
+  return SWEM_OK;
+}
+extern "C" int swem_maxpool3x3s2_bwd_y_f32(void *stream, const float *x, const float *y, const float *dy, float *dx, int B, int H,
+                                           int W, int C) {
+  SWEM_REQUIRE(x && y && dy && dx && C % 4 == 0, SWEM_E_ARG, "maxpool_bwd_y: bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bwd_y_kernel, grid1t((long long)B * H * W * (C / 4)), dim3(256), 0, STT, x, y, dy, dx, B, H, W, C,
+                     Ho, Wo);
+  SWEM_CHECK_LAUNCH("maxpool_bwd_y_kernel");
   return SWEM_OK;
 }
 extern "C" int swem_upsample_bwd_nhwc_f32(void *stream, const float *dy, float *dlow, int B, int Hl, int Wl, int Ho,
