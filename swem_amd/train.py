@@ -202,7 +202,7 @@ def random_init_host(B, N, Cc, Lb):
 
 
 # Measured on one box, 4 clips of 3 x 384x384, 2 objects, R50, graph replay (profiles/r06_train_lanes_ab.txt; fp32-level / AMP clips/s):
-#   4 lanes x 1 clip 89.4 / 114.8 -- 2 lanes x 2 clips 87.1 / 112.1 -- 1 lane x 4 clips 79.5 / 103.4 (82.4 / 107.9 with the weight
+#   4 lanes x 1 clip 93.1 / 120.5 -- 2 lanes x 2 clips 89.4 / 118.0 -- 1 lane x 4 clips 81.2 / 106.9 (84.1 / 109.5 with the weight
 #   gradients on a side stream).  Batching the clips cuts the kernel time per clip from 21.8 to 12.9 ms and the launches from 1,434
 #   to 502 (profiles/r06_train_launches_f16x3_lanes1.csv), but one stream of kernels that each fill a fraction of the chip (the
 #   1/16-scale layers: 36-72 tiles on 256 CUs) loses the 1.95x overlap four concurrent lanes get: the lanes keep the default.
