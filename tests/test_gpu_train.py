@@ -277,6 +277,22 @@ def test_maxpool_upsample_glu_backward(lib):
     hc = nhwc(xc).requires_grad_(True)
     A.maxpool(hc).sum().backward()
     assert torch.equal(back(hc.grad), xc.grad)
+    # round 6: the product's backward reads the forward output (swem_maxpool3x3s2_bwd_y_f32); the window-scanning form of rounds 1-5
+    # stays in the ABI -- both give the same gradient bit for bit, also on a map FULL of ties (values quantised to four levels)
+    from swem_amd import _lib as L, ops
+    for quant in (False, True):
+        xt = torch.randn(3, 17, 22, 64, generator=g)
+        xt = (xt * 1.5).round().clamp(-2, 1) if quant else xt
+        xt = xt.to(DEV).contiguous()
+        yt = ops.maxpool(xt)
+        dyt = torch.randn(*yt.shape, generator=g).to(DEV)
+        d_old, d_new = torch.empty_like(xt), torch.empty_like(xt)
+        L.call('swem_maxpool3x3s2_bwd_f32', ops._stream(), xt.data_ptr(), dyt.data_ptr(), d_old.data_ptr(), 3, 17, 22, 64)
+        L.call('swem_maxpool3x3s2_bwd_y_f32', ops._stream(), xt.data_ptr(), yt.data_ptr(), dyt.data_ptr(), d_new.data_ptr(), 3, 17, 22, 64)
+        assert torch.equal(d_old, d_new), quant
+        xr = leaf(back(xt))
+        F.max_pool2d(xr, 3, 2, 1).backward(back(dyt))
+        close(back(d_new), xr.grad, 1e-6, 'maxpool dx vs ATen, ties %s' % quant)
     # skip (shared by the 3 objects) + bilinear x2 of the low map
     skip, low = leaf(torch.randn(1, 32, 12, 16, generator=g)), leaf(torch.randn(3, 32, 6, 8, generator=g))
     y = skip + F.interpolate(low, size=(12, 16), mode='bilinear', align_corners=False)
