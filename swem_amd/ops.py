@@ -320,6 +320,24 @@ def _stream():
 _hip = None
 
 
+# The key encoder of an eager model('encode_key', frame) call on a side stream (swem.SWEM._encode_key_side)
+ASYNC_KEY_ENCODER = os.environ.get('SWEM_ASYNC_KEY', '1') != '0'
+
+
+def record_stream_deep(t, stream):
+    """Tell the caching allocator that `t` -- and what this package hangs on it: producer-written operand planes, the decoder's
+    skip convolution computed in the key pass -- is used on `stream` although another stream allocated it."""
+    if not t.is_cuda:
+        return
+    t.record_stream(stream)
+    d = t.__dict__
+    for planes, _npl in (d.get('_swem_split') or {}).values():
+        planes.record_stream(stream)
+    sk = d.get('_swem_skip')
+    if sk is not None:
+        record_stream_deep(sk[0], stream)
+
+
 def graph_capture_kwargs():
     """Keyword arguments for torch.cuda.graph(...) in this process: with a torch.distributed process group alive, the collective
     library's watchdog thread polls events of earlier collectives, and under the default capture mode ("global") such a call from

@@ -61,8 +61,45 @@ class SWEM(nn.Module):
 
     # ------------------------------------------------------------------ swem.py:39-43
     def encode_key(self, frames):
-        qk16, qv16, s16, s8, s4 = self.engine().encode_key(frames.float().contiguous())
+        x = frames.float().contiguous()
+        if ops.ASYNC_KEY_ENCODER and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
+            outs = self._encode_key_side(x)
+        else:
+            outs = self.engine().encode_key(x)
+        qk16, qv16, s16, s8, s4 = outs
         return _nchw(qk16), _nchw(qv16), _nchw(s16), _nchw(s8), _nchw(s4)
+
+    def _encode_key_side(self, x):
+        """The key encoder on a SIDE stream (round 6, eager calls only).  It reads the frame and the weights -- never the memory
+        (swem_evaluator.py:75 vs :77) -- so in a loop that calls the modes one frame at a time (the reference's evaluator on this
+        model) frame i + 1's key encoder need not queue behind frame i's match -> segment -> encode_value -> memorize chain: the
+        host enqueues it while that chain is still running, and on its own stream the two overlap (the look-ahead graphs do the
+        same with a whole group of frames).  The caller's stream waits for the side stream before this returns, so every consumer
+        sees finished tensors; the side stream waits for the caller's stream up to the END OF THE PREVIOUS encode_key call when
+        this frame lives in the same storage as the previous one (a slice of a clip that was resident before the loop), and for
+        everything the caller has queued otherwise (a frame produced just now: no overlap, same result).  `ops.ASYNC_KEY_ENCODER
+        = False` / SWEM_ASYNC_KEY=0 turn it off (a caller that overwrites a resident clip buffer in place between calls must)."""
+        main = torch.cuda.current_stream()
+        st = self.__dict__.get('_key_stream')
+        if st is None or st[0] != x.device:
+            st = self.__dict__['_key_stream'] = (x.device, ops.new_stream())
+        side = st[1]
+        prev = self.__dict__.get('_key_prev')
+        stor = x.untyped_storage().data_ptr()
+        if prev is not None and prev[0] == stor and prev[2] == main.cuda_stream:
+            side.wait_event(prev[1])
+        else:
+            side.wait_stream(main)
+        x.record_stream(side)
+        with torch.cuda.stream(side):
+            outs = self.engine().encode_key(x)
+        for t in outs:
+            ops.record_stream_deep(t, main)        # (allocated on the side stream, consumed -- and released -- on the caller's)
+        main.wait_stream(side)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.__dict__['_key_prev'] = (stor, ev, main.cuda_stream)
+        return outs
 
     # ------------------------------------------------------------------ swem.py:45-62
     def encode_value(self, frame, masks, s16):
