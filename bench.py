@@ -504,12 +504,15 @@ def main():
         runner.graph = runner.look = None       # per-launch timing needs eager launches (same kernels, same plans)
 
         def eager_frames(n):
-            if kla:
-                for _ in range(n // kla):
-                    runner.eager_group(kla)
-            else:
-                for _ in range(n):
-                    runner.step()
+            # (per-launch durations are taken on ONE stream: the eager calls' side-stream key encoder, ops.ASYNC_KEY_ENCODER, would
+            # run some launches beside others and stretch both)
+            with ops.flags(ASYNC_KEY_ENCODER=False):
+                if kla:
+                    for _ in range(n // kla):
+                        runner.eager_group(kla)
+                else:
+                    for _ in range(n):
+                        runner.step()
         ops.CONV_TRACE = []
         # (matching's readout GEMM also runs on a conv kernel, launched by the library itself: a marker keeps the launch list
         # aligned with a rocprofv3 kernel trace, tools/conv_by_layer.py; it is priced in `em_matching`, not here)

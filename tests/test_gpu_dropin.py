@@ -71,6 +71,43 @@ def test_reference_ytvos_loop_on_the_hip_model(lib, golden):
     H.record_parity('dropin_reference_loop_g8_ytvos[f16x3]', {'index_agreement': agrees})
 
 
+def test_side_stream_key_encoder_changes_no_result(lib):
+    """Round 6: an eager model('encode_key', frame) call runs the key encoder on a side stream (swem.SWEM._encode_key_side: it never
+    reads the memory, so frame i + 1's key encoder overlaps frame i's match -> segment -> encode_value -> memorize chain; the
+    caller's stream waits for it before the call returns).  Same kernels on the same data: logits, probabilities and index maps of
+    a clip are bit-identical with the side stream and without it -- also when every frame is a freshly produced tensor (new storage
+    per call: the side stream then waits for everything the caller has queued)."""
+    from swem_amd import synth
+    cfg = O.make_cfg(**CFG_A)
+    frames, m0 = synth.make_clip(t=5, h=240, w=432, n_obj=2, out_hw=(240, 432), seed=124)
+    frames, m0 = frames.to(DEV), m0.to(DEV)
+    masks = [m0] + [None] * 4
+    runs = {}
+    for tag, flag, fresh in (('one stream', False, False), ('side stream', True, False), ('side stream, fresh frames', True, True)):
+        model, _ = H.make_model_and_sd(cfg, 2, device=DEV)
+        clip = frames
+        if fresh:
+            class Fresh:                      # (clip[:, i] makes a NEW tensor on the caller's stream right before the call)
+                shape = frames.shape
+
+                def __getitem__(self, idx):
+                    return (frames[idx] * 1.0).clone()
+            clip = Fresh()
+        with torch.no_grad(), ops.flags(ASYNC_KEY_ENCODER=flag), H.arith('f16x3', model):
+            torch.manual_seed(7)
+            preds, scores = H.aten_glue_loop(model, clip, masks, (240, 432), keep_scores=True)
+        torch.cuda.synchronize()
+        ops.check_faults()
+        runs[tag] = (preds, scores)
+    ref = runs['one stream']
+    for tag in ('side stream', 'side stream, fresh frames'):
+        got = runs[tag]
+        for a, b in zip(got[0], ref[0]):
+            assert torch.equal(a, b), tag
+        for (pa, la), (pb, lb) in zip(got[1], ref[1]):
+            assert torch.equal(pa, pb) and torch.equal(la, lb), tag
+
+
 def test_reference_loop_throughput_at_480p(lib):
     """The number INTEGRATION.md quotes for 'a reference-style evaluator loop (eager, ATen glue between the modes)' on the HIP model: config B, shipped plans, eager
     launches, one frame at a time, ATen glue included -- measured, and with the masks of the product's own loop."""
