@@ -506,13 +506,17 @@ def main():
         def eager_frames(n):
             # (per-launch durations are taken on ONE stream: the eager calls' side-stream key encoder, ops.ASYNC_KEY_ENCODER, would
             # run some launches beside others and stretch both)
-            with ops.flags(ASYNC_KEY_ENCODER=False):
+            # (set directly: ops.flags() starts a new plan / hint epoch, after which producers write their fp32 maps again for a frame)
+            saved, ops.ASYNC_KEY_ENCODER = ops.ASYNC_KEY_ENCODER, False
+            try:
                 if kla:
                     for _ in range(n // kla):
                         runner.eager_group(kla)
                 else:
                     for _ in range(n):
                         runner.step()
+            finally:
+                ops.ASYNC_KEY_ENCODER = saved
         ops.CONV_TRACE = []
         # (matching's readout GEMM also runs on a conv kernel, launched by the library itself: a marker keeps the launch list
         # aligned with a rocprofv3 kernel trace, tools/conv_by_layer.py; it is priced in `em_matching`, not here)
