@@ -380,3 +380,74 @@ def test_full_range_book_policy(tmp_path):
     # fault-word bookkeeping without a device: nothing to read, nothing raised
     ops.check_faults()
     assert ops.FAULT_BITS.keys() == {1, 2, 4} and issubclass(ops.SwemRangeError, __import__('swem_amd')._lib.SwemHipError)
+
+
+def test_round6_host_logic(tmp_path, monkeypatch):
+    """Host-side pieces of round 6 that need no GPU: ONE f16x3 -> bf16x6 plan conversion for `to_full_range` and `load` (ADVICE r05:
+    `load` used to keep the 256-column tile with math 1 and no variant, which the library rejects), no fp16 / 16-bit candidate for
+    the tuner on a full-range book, the scheduler wound back over gated optimizer steps, the fault word's owners, per-unit header
+    dependencies of the build, the one-rank process-group switch."""
+    import json
+    from swem_amd import build, dist as sdist, ops, optim
+    # --- one conversion
+    P = ops.PlanBook._plan_full_range
+    assert P(0x770144) == 0x10122 and P(0x670422) == 0x10422 and P(0x30211) == 0x10211      # f16x3 t256 / 128x128+variant, bf16x3
+    assert P(0x10422) == 0x10422 and P(0x8810122) == 0x8810122 and P(0) == 0 and P(0x22) == 0x22   # bf16x6 / fp32 stay
+    shipped = json.load(open(ops.shipped_plans()))
+    book = ops.PlanBook(fallback=ops.MODEL_FALLBACK)
+    book.to_full_range()
+    book.load(ops.shipped_plans())
+    a = ops.PlanBook(fallback=ops.MODEL_FALLBACK).load_shipped()
+    a.to_full_range()
+    assert book.conv == a.conv                                   # load-after == load-then-convert, entry for entry
+    assert not any((v >> 16) & 7 in (7, 3) for v in book.conv.values()) and not any(v & 0xff == 0x44 and (v >> 16) & 7 == 1 and
+                                                                                   (v >> 20) & 15 != 4 for v in book.conv.values())
+    assert len(book.conv) == len(shipped['conv'])
+    # --- the tuner's candidates on a full-range book
+    seen = []
+    monkeypatch.setattr(ops, '_autotune_pick', lambda cands, timed, reps: seen.append(list(cands)) or cands[0])
+    with ops.use_book(book):
+        ops._autotune(lambda plan, fresh=False: None, 4096, 512, 144, False, modes=(0, 1, 7, 3))
+    assert seen and not any((c >> 16) & 7 in (7, 3) for c in seen[0]) and any((c >> 16) & 7 == 1 for c in seen[0])
+    with ops.use_book(ops.PlanBook(fallback=ops.MODEL_FALLBACK)):
+        ops._autotune(lambda plan, fresh=False: None, 4096, 512, 144, False, modes=(0, 1, 7))
+    assert any((c >> 16) & 7 == 7 for c in seen[1])
+    # --- MultiStepLR.rewind: n scheduler steps taken for optimizer steps the device-side gate skipped
+    class Opt:
+        lr = 1.0
+    o = Opt()
+    sch = optim.MultiStepLR(o, [3, 6], 0.1)
+    for _ in range(7):
+        sch.step()
+    assert sch.last_epoch == 7 and o.lr == pytest.approx(0.01)
+    sch.rewind(3)
+    assert sch.last_epoch == 4 and o.lr == pytest.approx(0.1)
+    sch.rewind(0)
+    assert sch.last_epoch == 4
+    # --- owners of the fault word (no device: nothing to drain, nothing raised; registration is by weak reference)
+    class Owner:
+        got = 0
+
+        def on_foreign_fault(self, bits):
+            self.got |= bits
+    ops.FAULT_OWNERS.clear()
+    own = Owner()
+    ops.register_fault_owner(own)
+    assert len(ops.FAULT_OWNERS) == 1 and ops.FAULT_OWNERS[0]() is own
+    ops.drain_faults('a test')                 # (no fault word exists on a CPU-only host)
+    del own
+    ops.register_fault_owner(Owner())          # dead references are dropped on the next registration
+    assert len(ops.FAULT_OWNERS) == 1
+    ops.FAULT_OWNERS.clear()
+    txt = ops._fault_text(ops.FAULT_RANGE | ops.FAULT_KSPLIT)
+    assert 'K-split' in txt and 'fp16 range' in txt and 'unknown' not in txt and 'unknown fault bits' in ops._fault_text(64)
+    # --- build: a unit is rebuilt for ITS headers only (conv.hip does not include the training header)
+    conv_h = {p.split('/')[-1] for p in build._headers_of(build.CSRC + '/conv.hip')}
+    train_h = {p.split('/')[-1] for p in build._headers_of(build.CSRC + '/train.hip')}
+    assert 'swem_hip.h' in conv_h and 'swem_hip_train.h' not in conv_h and 'swem_hip_train.h' in train_h
+    # --- the one-rank process-group switch
+    monkeypatch.delenv('SWEM_DIST_SINGLE_RANK', raising=False)
+    assert not sdist.single_rank_group() and not sdist.active()
+    monkeypatch.setenv('SWEM_DIST_SINGLE_RANK', '1')
+    assert sdist.single_rank_group() and not sdist.active()     # (no process group initialised here)
+    assert ops.graph_capture_kwargs() == {}
