@@ -8,6 +8,8 @@ must live on a HIP device and fails loudly otherwise.
 
 Feature maps returned by the modes are NCHW-shaped views of channels-last (NHWC) memory.
 """
+import weakref
+
 import torch
 from torch import nn
 
@@ -18,6 +20,7 @@ from .networks import Decoder, KeyEncoder, KeyProjection, ValueEncoder, ValueEnc
 
 
 _nchw = as_nchw
+_KEY_STATE = weakref.WeakKeyDictionary()     # model -> side stream / last event of its eager encode_key calls
 
 
 class SWEM(nn.Module):
@@ -80,11 +83,12 @@ class SWEM(nn.Module):
         everything the caller has queued otherwise (a frame produced just now: no overlap, same result).  `ops.ASYNC_KEY_ENCODER
         = False` / SWEM_ASYNC_KEY=0 turn it off (a caller that overwrites a resident clip buffer in place between calls must)."""
         main = torch.cuda.current_stream()
-        st = self.__dict__.get('_key_stream')
+        state = _KEY_STATE.setdefault(self, {})       # (not in self.__dict__: streams and events do not deep-copy / pickle)
+        st = state.get('stream')
         if st is None or st[0] != x.device:
-            st = self.__dict__['_key_stream'] = (x.device, ops.new_stream())
+            st = state['stream'] = (x.device, ops.new_stream())
         side = st[1]
-        prev = self.__dict__.get('_key_prev')
+        prev = state.get('prev')
         stor = x.untyped_storage().data_ptr()
         if prev is not None and prev[0] == stor and prev[2] == main.cuda_stream:
             side.wait_event(prev[1])
@@ -98,7 +102,7 @@ class SWEM(nn.Module):
         main.wait_stream(side)
         ev = torch.cuda.Event()
         ev.record(main)
-        self.__dict__['_key_prev'] = (stor, ev, main.cuda_stream)
+        state['prev'] = (stor, ev, main.cuda_stream)
         return outs
 
     # ------------------------------------------------------------------ swem.py:45-62
