@@ -38,6 +38,7 @@ def main():
                          'shipped plans: the set the round-5 kernel experiments are judged on (SWEM_HIP_LIB picks the build)')
     ap.add_argument('--t256', action='store_true', help='with --dominant: the 256x256-tile kernel (plan tile 4 x 4) with the K-split given by --ns')
     ap.add_argument('--ns', type=int, default=0, help='K-split of the --t256 plans (0: as many as fill 256 CUs)')
+    ap.add_argument('--sk', action='store_true', help='with --dominant: the stream-K form of each plan (no K-split, plan bits 24-27 = 1); f16x3 plans need profiles/r06_experiments/streamk_f16.patch')
     ap.add_argument('--res', action='store_true', help='with a residual addend (a ResBlock / bottleneck closing convolution)')
     ap.add_argument('--bmul', type=int, default=1, help='multiply every batch size (the look-ahead graphs run ten frames per launch)')
     a = ap.parse_args()
@@ -54,6 +55,8 @@ def main():
             if idx not in dominant:
                 continue
             a.plan = dominant[idx]
+            if a.sk:
+                a.plan = (a.plan & ~0xf00) | 1 << 24
             if a.t256:
                 a.plan = None            # (timed below over tile heights and K-splits: what the tuner would do)
         x = torch.randn(B, H, W, ci, device=dev)
