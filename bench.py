@@ -145,6 +145,33 @@ class FrameRunner:
         self.graph = cls(self.model, self.frames[:, 1].shape, OUT_HW).capture(self.frames[:, 1])
 
 
+class LockstepRunner:
+    """S sequences in lock step on one stream (evaluator.LockstepGraph): a step = one frame of EACH of them.  Built from S warmed-up
+    FrameRunners (their models hold the sequences' memories; their staged clips give the frame groups)."""
+
+    def __init__(self, runners, k):
+        from swem_amd import evaluator
+        self.rs, self.nseq, self.k = list(runners), len(runners), k
+        self.model = self.rs[0].model
+        per_seq = []
+        for rn in self.rs:
+            cyc = [1 + (rn.i + j) % (rn.t - 1) for j in range(k * (rn.t - 1))]
+            per_seq.append([torch.cat([rn.frames[:, c] for c in cyc[g * k:(g + 1) * k]]) for g in range(rn.t - 1)])
+        self.groups = [torch.stack([per_seq[s][g] for s in range(self.nseq)], dim=1).contiguous() for g in range(len(per_seq[0]))]
+        self.look = evaluator.LockstepGraph([rn.model for rn in self.rs], self.rs[0].frames[:, 1].shape, OUT_HW, k,
+                                            overlap=False, forks='none').capture(self.groups[0])
+        self.look.prime(self.groups[0])
+        self.grp, self.left, self.preds = 0, 0, None
+
+    def step(self):
+        if self.left == 0:
+            self.grp = (self.grp + 1) % len(self.groups)
+            self.preds = self.look.run(self.groups[self.grp])
+            self.left = self.k
+        self.left -= 1
+        return self.preds[self.k - 1 - self.left]
+
+
 def host_cpu():
     """CPU model and core counts of this host (lscpu / /proc/cpuinfo; the affinity mask bounds what this process may use)."""
     import re
@@ -274,6 +301,10 @@ def main():
                          'frames per sequence: 10 for 20 or 100 steps, 8 for 24 / 40 / 48), else 4')
     ap.add_argument('--seqs', type=int, default=4,
                     help='independent sequences processed concurrently per GPU, each on its own HIP stream')
+    ap.add_argument('--lockstep', type=int, default=0,
+                    help='S > 1: the sequences run in lanes of S sequences in LOCK STEP (evaluator.LockstepGraph: decoder and value '
+                         'encoder batched over the objects of the S sequences, ONE key-encoder pass over S x lookahead frames), '
+                         '--seqs / S lanes side by side, each on its own stream; 0: every sequence its own pipeline')
     ap.add_argument('--conv-report', action='store_true', help='per-shape conv timing table on stderr')
     ap.add_argument('--no-em', action='store_true', help='skip the EM/matching timing legs (profiler runs)')
     ap.add_argument('--tune', action='store_true', help='ignore the shipped plan file: tune every layer shape on the device')
@@ -358,9 +389,13 @@ def main():
     def make_runners(n, pipelined, seed_base, tune=tune, n_obj=n_obj):
         """n independent sequences, each its own model (memory banks) on its own probed stream, warmed up (the first one
         tunes the plans of the current conv_math mode into `book`) and captured into its frame graph."""
-        rs, sts = [], []
+        rs, sts, pending = [], [], []
+        # lock-step lanes (--lockstep S): n / S lanes of S sequences each; a lane is ONE pipeline on one stream
+        S_ = args.lockstep if (args.lockstep > 1 and n >= args.lockstep and n % args.lockstep == 0 and args.lookahead > 0
+                               and not args.no_graph) else 0
+        nstreams = n // S_ if S_ else n
         # streams that really overlap (two HIP streams can share a hardware queue and then serialise: evaluator.overlapping_streams)
-        seq_streams = evaluator.overlapping_streams(n) if n > 1 else [torch.cuda.current_stream()]
+        seq_streams = evaluator.overlapping_streams(nstreams) if nstreams > 1 else [torch.cuda.current_stream()]
         for si in range(n):
             model = SWEM(cfg)
             if sd_box[0] is None:
@@ -372,13 +407,27 @@ def main():
             if (seed, n_obj) not in clip_box:
                 clip_box[(seed, n_obj)] = synth.make_clip(t=8, h=H, w=W, n_obj=n_obj, out_hw=OUT_HW, seed=seed)
             frames_cpu, m0_cpu = clip_box[(seed, n_obj)]
-            st = seq_streams[si]
+            st = seq_streams[si // S_ if S_ else si]
             with torch.cuda.stream(st):
                 torch.manual_seed(seed_base + rank * 16 + si)
                 rn = FrameRunner(model, frames_cpu.to(dev), m0_cpu.to(dev))
                 ops.AUTOTUNE = tune and si == 0
                 for _ in range(max(args.warmup, 2)):
                     rn.step()
+                if S_:
+                    ops.AUTOTUNE = False
+                    pending.append(rn)
+                    if len(pending) == S_:       # the lane is complete: capture its lock-step graphs (the first lane tunes the batched shapes)
+                        ops.AUTOTUNE = tune and si == S_ - 1
+                        lane = LockstepRunner(pending, args.lookahead)
+                        ops.AUTOTUNE = False
+                        for _ in range(2 * args.lookahead):
+                            lane.step()
+                        rs.append(lane)
+                        sts.append(st)
+                        pending = []
+                    torch.cuda.synchronize()
+                    continue
                 if not args.no_graph:
                     # (the look-ahead capture's eager passes tune the batched key-encoder shapes while the tuner is on)
                     rn.enable_graph(pipelined=pipelined, lookahead=args.lookahead)
@@ -411,7 +460,7 @@ def main():
         elapsed = time.perf_counter() - t0
         ops.check_faults()       # (outside the clock) a K-split / stream-K wait that expired inside the region raises here
         sdist.barrier()
-        return sdist.reduce_counters(steps * len(rs), elapsed, device=dev)
+        return sdist.reduce_counters(steps * sum(getattr(rn, 'nseq', 1) for rn in rs), elapsed, device=dev)
 
     def timed_median(rs, sts, steps):
         """--regions timed regions back to back -> (frames of one region, the MEDIAN region's seconds, frames/s of every
@@ -431,7 +480,8 @@ def main():
         main_tag, pmc_tag = ('math',) + tuple(args.math_modes), '_exact' if tuple(args.math_modes) == (0, 1) else ''
         tune = tune or (not args.no_autotune and not any(k_[10:] == main_tag for k_ in book.conv))
     runners, streams = make_runners(nseq, pipelined, 1234, tune=tune)
-    runner = runners[0]
+    lockstep = isinstance(runners[0], LockstepRunner)
+    runner = runners[0].rs[0] if lockstep else runners[0]      # (the per-launch roofline leg traces eager frames of ONE sequence)
     frames_cpu, m0_cpu = clip_box[(123 + rank * 16, n_obj)]
     sd = sd_box[0]
     if args.save_plans and rank == 0:
@@ -441,9 +491,14 @@ def main():
     # ---------------- timed region: exactly K steps between barrier + synchronize, --regions times; the median region counts
     total_frames, max_t, region_fps = timed_median(runners, streams, args.steps)
 
-    def launch_text(pipe_):
+    def launch_text(pipe_, lock_=False):
         if args.no_graph:
             return 'eager'
+        if lock_:
+            return ('hipGraph replay, %d lane(s) of %d sequences in lock step, %d frames of every sequence per replay: ONE key-encoder pass '
+                    'over the %d x %d frames of the next group + %d lock-step frames of the current one (match and memorize per sequence; '
+                    'decoder and value encoder batched over the objects of the %d sequences)'
+                    % (nseq // args.lockstep, args.lockstep, args.lookahead, args.lockstep, args.lookahead, args.lookahead, args.lockstep))
         if args.lookahead > 0:
             return ('hipGraph replay, %d frames per replay: one batched key-encoder pass for the next %d frames%s + the %d frame '
                     'chains (match, segment, encode_value, memorize) of the current ones'
@@ -487,7 +542,7 @@ def main():
                        'objects': n_obj, 'frames_per_step': nseq, 'sequences_per_gpu': nseq, 'parallelism': 'seq-sharded x%d (no collective)' % world,
                        'weights': 'random init of the reference architecture (seeded)',
                        'torch_cpu_threads_per_rank': cpu_threads,
-                       'launch': launch_text(pipelined)},
+                       'launch': launch_text(pipelined, lockstep), 'lockstep_lanes': (nseq // args.lockstep) if lockstep else 0},
             'fps_per_gpu': round(fps / world, 3),
             'frame_algorithmic_tflops': round(algorithmic_flops_per_frame(n_obj) * fps / world / 1e12, 2),
             'plans': {'conv_layer_shapes_by_math': hist, 'digest': book.digest(),
@@ -901,12 +956,14 @@ def main():
             tf = em_flops_per_frame(n_obj) * n_streams * reps / best / 1e12
             return {'sequences': n_streams, 'us_per_round': round(1e6 * best / reps, 1), 'achieved': round(tf, 2),
                     'frac': round(tf / FP32_MATRIX_PEAK_TFLOPS, 4)}
-        conc = [em_concurrent(n) for n in sorted({1, 2, nseq, 4})]
+        # (lock-step lanes run the per-sequence EM of their sequences one after the other: `lanes` of them are in flight at a time)
+        em_streams = (nseq // args.lockstep) if lockstep else nseq
+        conc = [em_concurrent(n) for n in sorted({1, 2, em_streams, 4})]
         book_ctx.__exit__(None, None, None)
         em = out['em_matching']
         ex_ratio = em_flops_executed_per_frame(n_obj) / em_flops_per_frame(n_obj)
         em['concurrent'] = [c for c in conc if c['sequences'] > 1]
-        mine = [c for c in conc if c['sequences'] == nseq]
+        mine = [c for c in conc if c['sequences'] == em_streams]
         if mine:       # the number for THIS run's configuration first; the single-sequence figures stay as `isolated`
             one = [c for c in conc if c['sequences'] == 1][0]
             em['isolated'] = {'ms_per_frame': round(one['us_per_round'] / 1e3, 3), 'achieved': one['achieved'],
@@ -930,11 +987,11 @@ def main():
             em['flops_note'] = ('frac = ALGORITHMIC FLOPs (the 3T - 1 key GEMMs of the reference + the value GEMM per memorize) / time / '
                                 'fp32 matrix peak; frac_executed_flops counts what the kernels issue (E and W steps share one '
                                 'GEMM: 2T key GEMMs), %.3f of the algorithmic figure' % ex_ratio)
-            em['ms_per_frame'] = round(mine[0]['us_per_round'] / nseq / 1e3, 3)
+            em['ms_per_frame'] = round(mine[0]['us_per_round'] / em_streams / 1e3, 3)
             em['note'] = ('memorize + match of the %d sequences this configuration keeps in flight per GPU, one HIP graph per '
                           'stream replayed together (device time per frame = round time / sequences); `isolated` = one '
                           'sequence alone (the same graph on one stream; `eager` = 20 back-to-back eager calls); algorithmic FLOPs '
-                          '4PL(C(3T-1)+V) + 4LmP(C+V) per object' % nseq)
+                          '4PL(C(3T-1)+V) + 4LmP(C+V) per object' % em_streams)
         if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only
             out['cpu_baseline'] = cpu_baseline(frames_cpu, m0_cpu, sd, n_frames=args.cpu_frames)
     if rank == 0 and world == 1 and not args.no_training and not args.no_legs:

@@ -560,6 +560,209 @@ class LookaheadGraph:
         return self.preds[p]
 
 
+def key_items(keys, j, n):
+    """Frames j .. j + n - 1 of a batched encode_key result (see key_item)."""
+    from .modules import as_nchw, to_pixel_major
+    return tuple(as_nchw(ops.batch_item(to_pixel_major(t), j, n)) for t in keys)
+
+
+def lockstep_chain(models, keys, keys_each, frames, out_size, forks, outs=None):
+    """frame_chain for ONE frame of each of S sequences in lock step (round 6): `models[s]` holds sequence s's memory,
+    `keys` = (qk16, qv16, s16, s8, s4) with batch S (models[0]'s key encoder over the S frames), keys_each[s] = sequence s's item of
+    them (key_item: with the planes the batch carries), `frames` (S,3,H,W).
+    What depends on one sequence's memory only -- match (affinity, top-l, readout, fusion conv) and memorize (EM) -- runs per
+    sequence on `forks[s]` (S streams that overlap: evaluator.overlapping_streams), exactly the launches of frame_chain; the
+    decoder and the value encoder, whose layers treat the objects as a batch (swem.py:52-53, 94-95), run ONCE for the S * N
+    objects of all sequences on the caller's stream through models[0]'s engine (the models are replicas: same weights, one
+    PlanBook) -- 4 x 3,240 rows per 1/16-scale layer instead of four launches of 3,240.  Needs the same N in every
+    sequence.  outs[s]: the tensors sequence s's new bases go to (LookaheadGraph's alternating state sets).
+    Returns the (S,Ho,Wo) int64 index maps."""
+    main = torch.cuda.current_stream()
+    h, w = frames.shape[-2:]
+    qk16, qv16, s16, s8, s4 = keys
+    S = len(models)
+    ctxs, n = [], None
+    forks = forks or [main] * S          # (no forks: the per-sequence parts one after the other on the caller's stream)
+    for s, (m, st) in enumerate(zip(models, forks)):
+        if st is not main:
+            st.wait_stream(main)
+        with torch.cuda.stream(st):
+            c, n_s = m('match', keys_each[s][0], keys_each[s][1])
+        if n is not None and n_s != n:
+            raise RuntimeError('lockstep_chain: the sequences hold %d and %d objects' % (n, n_s))
+        n = n_s
+        ctxs.append(c)
+    for st in forks:
+        if st is not main:
+            main.wait_stream(st)
+    m0 = models[0]
+    context = torch.cat([to_pixel_major_(c) for c in ctxs])
+    _, pred_mask = m0('segment', n, as_nchw_(context), s8, s4, None, out_size)
+    pred, hard = ops.argmax_onehot(pred_mask, want_onehot=True)
+    pm = ops.resize_planes(pred_mask, (h, w), 'bilinear')
+    mv16 = m0('encode_value', frames, pm, s16)                      # (S,N,V,h,w)
+    for s, (m, st) in enumerate(zip(models, forks)):
+        if st is not main:
+            st.wait_stream(main)
+        with torch.cuda.stream(st):
+            if outs is not None:
+                m.swem_core._next_out = outs[s]
+            m('memorize', keys_each[s][0], mv16[s:s + 1], hard[s:s + 1], pm[s:s + 1])
+            m.swem_core._next_out = None
+    for st in forks:
+        if st is not main:
+            main.wait_stream(st)
+    return pred
+
+
+def to_pixel_major_(t):
+    from .modules import to_pixel_major
+    return to_pixel_major(t)
+
+
+def as_nchw_(t):
+    from .modules import as_nchw
+    return as_nchw(t)
+
+
+class LockstepGraph:
+    """k frames of S sequences per replay, the sequences in lock step (round 6; VERDICT r05 item 2b taken to four sequences).
+
+    LookaheadGraph with a second batch axis: ONE key-encoder pass over the k x S frames of the next group (frame-major: the S
+    frames of step j are contiguous), and k lockstep_chain steps per replay -- per sequence: match and memorize on S forked
+    streams inside the graph; batched over the S * N objects: decoder and value encoder.  `models` are replicas (same
+    weights, one PlanBook), each holding one sequence's memory (both banks initialised, the same number of objects)."""
+
+    def __init__(self, models, frame_shape, out_size, k, streams=None, side_stream=None, overlap=True, forks=None):
+        self.models, self.k, self.out_size = list(models), int(k), (int(out_size[0]), int(out_size[1]))
+        self.S = len(self.models)
+        self.streams, self.side, self.overlap, self.forks = streams, side_stream, overlap, forks
+        cores = [m.swem_core for m in self.models]
+        for c in cores:
+            if c.memories['update'].bases is None or c.memories['first'].bases is None:
+                raise RuntimeError('LockstepGraph needs an initialised memory with both banks in every model')
+        shapes = {tuple(c.memories['first'].bases['kappa'].shape) for c in cores}
+        if len(shapes) != 1:
+            raise RuntimeError('LockstepGraph: the sequences must hold the same number of objects')
+        for m in self.models[1:]:
+            m.book = self.models[0].book
+        dev = cores[0].memories['update'].bases['kappa'].device
+        self.frame_shape = tuple(frame_shape)                 # (1, 3, H, W)
+        self.frames = [torch.empty((self.k, self.S) + self.frame_shape[1:], dtype=torch.float32, device=dev) for _ in range(2)]
+        self.state = [{key: v.clone() for key, v in c.memories['update'].bases.items()} for c in cores]
+        self.state2 = [{key: torch.empty_like(v) for key, v in st.items()} for st in self.state]
+        for c, st in zip(cores, self.state):
+            c.memories['update'].bases = st
+        self.first = [c.memories['first'].bases for c in cores]
+        self.kg = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+        self.cg = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+        self.keys = [None, None]
+        self.preds = [None, None]
+        self.packs = None
+        self.p = 0
+        self.primed = False
+
+    def _encode(self, p):
+        return self.models[0]('encode_key', self.frames[p].view((self.k * self.S,) + self.frame_shape[1:]))
+
+    def _chains(self, p):
+        cores = [m.swem_core for m in self.models]
+        preds = []
+        sets = (self.state, self.state2)
+        for j in range(self.k):
+            nxt = sets[(j + 1) % 2]
+            each = [key_item(self.keys[p], j * self.S + s) for s in range(self.S)]
+            preds.append(lockstep_chain(self.models, key_items(self.keys[p], j * self.S, self.S), each, self.frames[p][j],
+                                        self.out_size, self.forks, outs=nxt))
+            for c, st in zip(cores, nxt):
+                c.memories['update'].bases = st       # (the tensors memorize wrote, under their own names)
+                c.restamp()
+        if self.k % 2:
+            for c, a, b in zip(cores, self.state, self.state2):
+                for key in a:
+                    a[key].copy_(b[key])
+                c.memories['update'].bases = a
+                c.restamp()
+        return preds
+
+    def capture(self, example_frames):
+        """example_frames (k,S,3,H,W): any frames of the sequences' shape (everything the warm-up touches is restored)."""
+        cores = [m.swem_core for m in self.models]
+        with torch.no_grad():
+            if self.streams is None:
+                self.streams = (ops.new_stream(), ops.new_stream())
+            if self.forks is None:
+                self.forks = overlapping_streams(self.S)
+            elif self.forks == 'none':
+                self.forks = ()
+            if self.side is None:
+                self.side = tuple(overlapping_streams(2)) if self.overlap else ()
+            warm, cap = self.streams
+            saved = [{key: v.clone() for key, v in st.items()} for st in self.state]
+
+            def restore():
+                for c, st, sv in zip(cores, self.state, saved):
+                    for key in st:
+                        st[key].copy_(sv[key])
+                    c.memories['update'].bases = st
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                for p in (0, 1):
+                    self.frames[p].copy_(example_frames)
+                for _ in range(2):       # eager passes: workspaces, split requests, and -- while ops.AUTOTUNE is on -- the batched shapes' plans
+                    self.keys[0] = self._encode(0)
+                    self._chains(0)
+            torch.cuda.current_stream().wait_stream(warm)
+            for p in (0, 1):
+                restore()
+                self.packs = [c.repack() for c in cores]
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.graph(self.kg[p], stream=cap, **ops.graph_capture_kwargs()):
+                    self.keys[p] = self._encode(p)
+                with torch.cuda.graph(self.cg[p], stream=cap, **ops.graph_capture_kwargs()):
+                    self.preds[p] = self._chains(p)
+                torch.cuda.current_stream().wait_stream(cap)
+            restore()
+            for c in cores:
+                c.restamp()
+        self.primed = False
+        return self
+
+    def prime(self, frames_kS):
+        """Key-encoder pass of the first group (k,S,3,H,W)."""
+        self.frames[self.p].copy_(frames_kS)
+        self.kg[self.p].replay()
+        self.primed = True
+
+    def run(self, next_frames_kS=None):
+        """The k lock-step frames of the group whose keys are ready; `next_frames_kS` (k,S,3,H,W) = the following group, whose key
+        encoder runs next to them (None: the sequences end).  Returns k (static) (S,Ho,Wo) int64 index maps."""
+        if not self.primed:
+            raise RuntimeError('LockstepGraph.run before prime()')
+        p, main = self.p, torch.cuda.current_stream()
+        if next_frames_kS is not None:
+            self.frames[1 - p].copy_(next_frames_kS)
+        if self.overlap and next_frames_kS is not None:
+            s0, s1 = self.side
+            s0.wait_stream(main)
+            s1.wait_stream(main)
+            with torch.cuda.stream(s0):
+                self.cg[p].replay()
+            with torch.cuda.stream(s1):
+                self.kg[1 - p].replay()
+            main.wait_stream(s0)
+            main.wait_stream(s1)
+        else:
+            self.cg[p].replay()
+            if next_frames_kS is not None:
+                self.kg[1 - p].replay()
+        if next_frames_kS is not None:
+            self.p = 1 - p
+        else:
+            self.primed = False
+        return self.preds[p]
+
+
 def run_sequences(model, sequences, meter=None):
     """basic_evaluator.py:149-199 without the disk IO: sequences = iterable of (frames, init_mask, out_size)."""
     meter = meter or FrameSecondMeter()

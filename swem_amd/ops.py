@@ -816,12 +816,12 @@ def _keyed(planes):
     return {_pkey(r, e[1]): e for r, e in planes.items()}
 
 
-def batch_item(t, j):
-    """Item j of a batched NHWC activation as a (1, H, W, C) view that keeps what the batch carries: the bf16 planes a
-    producing kernel wrote (planes are [plane][C/8][pixel][8] over ALL pixels of the batch: item j is the pixel range
-    [j*H*W, (j+1)*H*W) of every channel group, i.e. the same planes from an offset base with the same strides) and the
+def batch_item(t, j, n=1):
+    """Items j .. j + n - 1 of a batched NHWC activation as an (n, H, W, C) view that keeps what the batch carries: the bf16
+    planes a producing kernel wrote (planes are [plane][C/8][pixel][8] over ALL pixels of the batch: the items are the pixel
+    range [j*H*W, (j+n)*H*W) of every channel group, i.e. the same planes from an offset base with the same strides) and the
     producer's site, so that a consumer's split request is still reported to the producer."""
-    v = t[j:j + 1]
+    v = t[j:j + n]
     d = t.__dict__
     sp = d.get('_swem_split')
     if sp and d.get('_swem_split_ver', t._version) == t._version and (t.is_contiguous() or d.get('_swem_planes_only')):
@@ -834,7 +834,7 @@ def batch_item(t, j):
         v.__dict__['_swem_planes_only'] = True
     sk = d.get('_swem_skip')              # (the decoder's skip convolution of this feature map, computed in the key pass)
     if sk is not None and sk[1] == t._version:
-        v.__dict__['_swem_skip'] = (batch_item(sk[0], j), v._version, sk[2])
+        v.__dict__['_swem_skip'] = (batch_item(sk[0], j, n), v._version, sk[2])
     return v
 
 

@@ -42,6 +42,7 @@ def graph_time(fn, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--clips', type=int, default=4)
+    ap.add_argument('--concurrent', action='store_true', help='also: the stages as concurrent pipelines of 1 / 2 / all clips per stream')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     model = SWEM(SimpleNamespace(**bench.CFG))
@@ -75,6 +76,50 @@ def main():
         ops.AUTOTUNE = False
         t_one = graph_time(lambda: [stages(i) for i in one])
         t_many = graph_time(lambda: stages(many))
+        if a.concurrent:
+            # the same work as CONCURRENT pipelines (what SequencePool does): `clips` streams of one clip each, clips / 2 streams
+            # of two-clip batches, one stream of all clips -- every stream replays its own graph, the host
+            # starts them back to back, time = start of the first to end of the last
+            def lanes_time(groups, reps=5):
+                graphs = []
+                for grp in groups:
+                    st = ops.new_stream()
+                    st.wait_stream(torch.cuda.current_stream())
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.stream(st):
+                        with torch.cuda.graph(g, stream=st, **ops.graph_capture_kwargs()):
+                            for _ in range(reps):
+                                stages(grp)
+                    graphs.append((st, g))
+                best = None
+                for _ in range(4):
+                    torch.cuda.synchronize()
+                    main = torch.cuda.current_stream()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(main)
+                    for st, g in graphs:
+                        st.wait_stream(main)
+                        with torch.cuda.stream(st):
+                            g.replay()
+                    for st, g in graphs:
+                        main.wait_stream(st)
+                    e1.record(main)
+                    torch.cuda.synchronize()
+                    t = e0.elapsed_time(e1) / reps
+                    best = t if best is None else min(best, t)
+                return best
+            pairs = [inputs(2) for _ in range(a.clips // 2)]
+            for _ in range(3):
+                ops.AUTOTUNE = True
+                for i in pairs:
+                    stages(i)
+                ops.AUTOTUNE = False
+            t_a = lanes_time(one)
+            t_b = lanes_time(pairs)
+            t_c = lanes_time([many])
+            print('the same stages of %d clips as concurrent pipelines: %d streams x 1 clip %.3f ms, %d streams x 2 clips %.3f ms (%+.1f %%), '
+                  '1 stream x %d clips %.3f ms (%+.1f %%)' % (a.clips, a.clips, t_a, a.clips // 2, t_b, 100 * (t_b / t_a - 1), a.clips, t_c,
+                                                             100 * (t_c / t_a - 1)))
     print('value encoder + decoder of %d clips (2 objects each, 480x864): %d single-clip passes %.3f ms, ONE batched pass %.3f ms '
           '(%.2f x); per clip %.3f -> %.3f ms' % (a.clips, a.clips, t_one, t_many, t_one / t_many, t_one / a.clips, t_many / a.clips))
 
