@@ -265,6 +265,14 @@ int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long long skip_b
 int swem_upsample_add_nhwc_f32_planes(void *stream, const float *skip, long long skip_bs, const float *low, float *y,
                                       int B, int Hl, int Wl, int Ho, int Wo, int C, void *planes, int nplanes,
                                       void *planes_relu, int nplanes_relu, void *fault);
+/* Both with `group` consecutive batch items sharing ONE skip image (item b adds skip image b / group; skip_bs = the stride between
+ * skip images): the N objects of a clip share the clip's skip feature (swem.py:94-95 .expand) -- with several clips in one batch
+ * (sequences in lock step, training clips) no per-object copy of the skip maps is materialised. */
+int swem_upsample_add_grouped_nhwc_f32(void *stream, const float *skip, long long skip_bs, int group, const float *low, float *y,
+                                       int B, int Hl, int Wl, int Ho, int Wo, int C);
+int swem_upsample_add_grouped_nhwc_f32_planes(void *stream, const float *skip, long long skip_bs, int group, const float *low,
+                                              float *y, int B, int Hl, int Wl, int Ho, int Wo, int C, void *planes, int nplanes,
+                                              void *planes_relu, int nplanes_relu, void *fault);
 /* F.interpolate / flip on NCHW planes; mode 0 = nearest (legacy), 1 = bilinear align_corners=False
  * (swem_evaluator.py:67,91), 2 = bicubic align_corners=False (swem_evaluator.py:43, basic_evaluator.py:160),
  * 3 = horizontal flip, same size (torch.flip(dims=[-1]), swem_evaluator.py:46-49) */

@@ -41,6 +41,8 @@ SIGNATURES = {
     'swem_maxpool3x3s2_nhwc_f32_planes': (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
     'swem_upsample_add_nhwc_f32': (_i, [_p, _p, _ll, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_upsample_add_nhwc_f32_planes': (_i, [_p, _p, _ll, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
+    'swem_upsample_add_grouped_nhwc_f32': (_i, [_p, _p, _ll, _i, _p, _p, _i, _i, _i, _i, _i, _i]),
+    'swem_upsample_add_grouped_nhwc_f32_planes': (_i, [_p, _p, _ll, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
     'swem_resize_planes_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i]),
     'swem_mask_prep_f32': (_i, [_p, _p, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i]),
     'swem_cbam_workspace': (_sz, [_i, _i, _i, _i]),

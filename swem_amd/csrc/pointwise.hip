@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void maxpool_planes_kernel(const float *__rest
 }
 
 __global__ void upsample_add_kernel(const float *__restrict__ skip, long long skip_bs, const float *__restrict__ low,
-                                    float *__restrict__ y, int B, int Hl, int Wl, int Ho, int Wo, int C) {
+                                    float *__restrict__ y, int B, int Hl, int Wl, int Ho, int Wo, int C, int group) {
   const int cq = C / 4;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)B * Ho * Wo * cq) return;
@@ -228,7 +228,7 @@ __global__ void upsample_add_kernel(const float *__restrict__ skip, long long sk
   float4 r1 = f4lerp2(lx.l0, ld4(base + ((long long)ly.i1 * Wl + lx.i0) * C), lx.l1,
                       ld4(base + ((long long)ly.i1 * Wl + lx.i1) * C));
   float4 up = f4lerp2(ly.l0, r0, ly.l1, r1);
-  float4 s = ld4(skip + (long long)b * skip_bs + ((long long)oy * Wo + ox) * C + c4 * 4);
+  float4 s = ld4(skip + (long long)(b / group) * skip_bs + ((long long)oy * Wo + ox) * C + c4 * 4);
   st4(y + i * 4, f4add(s, up));
 }
 
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void upsample_add_planes_kernel(const float *_
                                                                   const float *__restrict__ low, float *__restrict__ y,
                                                                   unsigned short *__restrict__ pl0, int npl0,
                                                                   unsigned short *__restrict__ pl1, int npl1, int B, int Hl,
-                                                                  int Wl, int Ho, int Wo, int C, unsigned *fault) {
+                                                                  int Wl, int Ho, int Wo, int C, unsigned *fault, int group) {
   const long long npix = (long long)B * Ho * Wo;
   const long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
   const int cg = blockIdx.y * 8 + (threadIdx.x & 7);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void upsample_add_planes_kernel(const float *_
   const int oy = (int)(t % Ho), b = (int)(t / Ho);
   Lerp ly = lerp_coord(oy, (float)Hl / (float)Ho, Hl), lx = lerp_coord(ox, (float)Wl / (float)Wo, Wl);
   const float *base = low + (long long)b * Hl * Wl * C + cg * 8;
-  const float *sk = skip + (long long)b * skip_bs + ((long long)oy * Wo + ox) * C + cg * 8;
+  const float *sk = skip + (long long)(b / group) * skip_bs + ((long long)oy * Wo + ox) * C + cg * 8;
   float4 v[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -1148,27 +1148,52 @@ extern "C" int swem_maxpool3x3s2_nhwc_f32_planes(void *stream, const float *x, f
   return SWEM_OK;
 }
 
-extern "C" int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long long skip_bs, const float *low,
-                                          float *y, int B, int Hl, int Wl, int Ho, int Wo, int C) {
-  SWEM_REQUIRE(skip && low && y && C % 4 == 0, SWEM_E_SHAPE, "upsample_add: bad argument");
+// group: `group` consecutive batch items share one skip image (item b reads skip image b / group: the N objects of a clip share
+// the clip's skip feature, swem.py:94-95, with several clips in the batch) -- no per-object copy of the skip maps
+static int upsample_add_launch(void *stream, const float *skip, long long skip_bs, int group, const float *low, float *y, int B, int Hl,
+                               int Wl, int Ho, int Wo, int C) {
+  SWEM_REQUIRE(skip && low && y && C % 4 == 0 && group >= 1, SWEM_E_SHAPE, "upsample_add: bad argument");
   hipLaunchKernelGGL(upsample_add_kernel, grid1((long long)B * Ho * Wo * (C / 4)), dim3(256), 0, ST, skip, skip_bs,
-                     low, y, B, Hl, Wl, Ho, Wo, C);
+                     low, y, B, Hl, Wl, Ho, Wo, C, group);
   SWEM_CHECK_LAUNCH("upsample_add");
   return SWEM_OK;
 }
-
-extern "C" int swem_upsample_add_nhwc_f32_planes(void *stream, const float *skip, long long skip_bs, const float *low,
-                                                 float *y, int B, int Hl, int Wl, int Ho, int Wo, int C, void *planes,
-                                                 int nplanes, void *planes_relu, int nplanes_relu, void *fault) {
-  SWEM_REQUIRE(skip && low && y && C % 8 == 0, SWEM_E_SHAPE, "upsample_add_planes: need C %% 8 == 0");
+static int upsample_add_planes_launch(void *stream, const float *skip, long long skip_bs, int group, const float *low, float *y, int B,
+                                      int Hl, int Wl, int Ho, int Wo, int C, void *planes, int nplanes, void *planes_relu,
+                                      int nplanes_relu, void *fault) {
+  SWEM_REQUIRE(skip && low && y && C % 8 == 0 && group >= 1, SWEM_E_SHAPE, "upsample_add_planes: need C %% 8 == 0");
   SWEM_REQUIRE((!planes || (nplanes >= 2 && nplanes <= 4)) && (!planes_relu || (nplanes_relu >= 2 && nplanes_relu <= 4)),
                SWEM_E_ARG, "upsample_add_planes: 2 or 3 planes per variant");
   const long long npix = (long long)B * Ho * Wo;
   hipLaunchKernelGGL(upsample_add_planes_kernel, dim3((unsigned)cdiv(npix, 32), (unsigned)cdiv(C / 8, 8)), dim3(256), 0, ST,
                      skip, skip_bs, low, y, static_cast<unsigned short *>(planes), nplanes,
-                     static_cast<unsigned short *>(planes_relu), nplanes_relu, B, Hl, Wl, Ho, Wo, C, static_cast<unsigned *>(fault));
+                     static_cast<unsigned short *>(planes_relu), nplanes_relu, B, Hl, Wl, Ho, Wo, C, static_cast<unsigned *>(fault), group);
   SWEM_CHECK_LAUNCH("upsample_add_planes");
   return SWEM_OK;
+}
+
+extern "C" int swem_upsample_add_nhwc_f32(void *stream, const float *skip, long long skip_bs, const float *low,
+                                          float *y, int B, int Hl, int Wl, int Ho, int Wo, int C) {
+  return upsample_add_launch(stream, skip, skip_bs, 1, low, y, B, Hl, Wl, Ho, Wo, C);
+}
+
+extern "C" int swem_upsample_add_nhwc_f32_planes(void *stream, const float *skip, long long skip_bs, const float *low,
+                                                 float *y, int B, int Hl, int Wl, int Ho, int Wo, int C, void *planes,
+                                                 int nplanes, void *planes_relu, int nplanes_relu, void *fault) {
+  return upsample_add_planes_launch(stream, skip, skip_bs, 1, low, y, B, Hl, Wl, Ho, Wo, C, planes, nplanes, planes_relu, nplanes_relu,
+                                    fault);
+}
+
+extern "C" int swem_upsample_add_grouped_nhwc_f32(void *stream, const float *skip, long long skip_bs, int group, const float *low,
+                                                  float *y, int B, int Hl, int Wl, int Ho, int Wo, int C) {
+  return upsample_add_launch(stream, skip, skip_bs, group, low, y, B, Hl, Wl, Ho, Wo, C);
+}
+
+extern "C" int swem_upsample_add_grouped_nhwc_f32_planes(void *stream, const float *skip, long long skip_bs, int group,
+                                                         const float *low, float *y, int B, int Hl, int Wl, int Ho, int Wo, int C,
+                                                         void *planes, int nplanes, void *planes_relu, int nplanes_relu, void *fault) {
+  return upsample_add_planes_launch(stream, skip, skip_bs, group, low, y, B, Hl, Wl, Ho, Wo, C, planes, nplanes, planes_relu,
+                                    nplanes_relu, fault);
 }
 
 extern "C" int swem_resize_planes_f32(void *stream, const float *x, float *y, int planes, int Hi, int Wi, int Ho,

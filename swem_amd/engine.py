@@ -190,7 +190,7 @@ class Engine:
         BN, B = context.shape[0], s8.shape[0]
         x = self.compress([context])
         sk = self._skip(s8, self.skip8)
-        x = self.out8([ops.upsample_add(sk if B in (1, BN) else per_object(sk, BN // B), x)])
+        x = self.out8([ops.upsample_add(sk, x)])          # (B skip images for B * N objects: image b // N, no per-object copy)
         sk = self._skip(s4, self.skip4)
-        x = self.out4([ops.upsample_add(sk if B in (1, BN) else per_object(sk, BN // B), x)])
+        x = self.out4([ops.upsample_add(sk, x)])
         return ops.pred_head(x, self.pred_w, self.pred_b)

@@ -566,7 +566,7 @@ def key_items(keys, j, n):
     return tuple(as_nchw(ops.batch_item(to_pixel_major(t), j, n)) for t in keys)
 
 
-def lockstep_chain(models, keys, keys_each, frames, out_size, forks, outs=None):
+def lockstep_chain(models, keys, keys_each, frames, out_size, forks, outs=None, fuse_batched=False):
     """frame_chain for ONE frame of each of S sequences in lock step (round 6): `models[s]` holds sequence s's memory,
     `keys` = (qk16, qv16, s16, s8, s4) with batch S (models[0]'s key encoder over the S frames), keys_each[s] = sequence s's item of
     them (key_item: with the planes the batch carries), `frames` (S,3,H,W).
@@ -587,7 +587,13 @@ def lockstep_chain(models, keys, keys_each, frames, out_size, forks, outs=None):
         if st is not main:
             st.wait_stream(main)
         with torch.cuda.stream(st):
-            c, n_s = m('match', keys_each[s][0], keys_each[s][1])
+            if fuse_batched:        # affinity / top-l / readout per sequence; the fusion conv (modules.py:286-291) below, batched
+                core = m.swem_core
+                with ops.use_book(m.book):
+                    c = core._affinity_readout(keys_each[s][0], core.memories['first'].bases, core.memories['update'].bases)
+                n_s = core.memories['first'].bases['kappa'].shape[1]
+            else:
+                c, n_s = m('match', keys_each[s][0], keys_each[s][1])
         if n is not None and n_s != n:
             raise RuntimeError('lockstep_chain: the sequences hold %d and %d objects' % (n, n_s))
         n = n_s
@@ -596,7 +602,12 @@ def lockstep_chain(models, keys, keys_each, frames, out_size, forks, outs=None):
         if st is not main:
             main.wait_stream(st)
     m0 = models[0]
-    context = torch.cat([to_pixel_major_(c) for c in ctxs])
+    if fuse_batched:
+        with ops.use_book(m0.book):
+            context = m0.engine().fuse_context(torch.cat([c[1].contiguous() for c in ctxs]), to_pixel_major_(qv16),
+                                               torch.cat([c[0] for c in ctxs]))
+    else:
+        context = torch.cat([to_pixel_major_(c) for c in ctxs])
     _, pred_mask = m0('segment', n, as_nchw_(context), s8, s4, None, out_size)
     pred, hard = ops.argmax_onehot(pred_mask, want_onehot=True)
     pm = ops.resize_planes(pred_mask, (h, w), 'bilinear')
@@ -633,9 +644,10 @@ class LockstepGraph:
     streams inside the graph; batched over the S * N objects: decoder and value encoder.  `models` are replicas (same
     weights, one PlanBook), each holding one sequence's memory (both banks initialised, the same number of objects)."""
 
-    def __init__(self, models, frame_shape, out_size, k, streams=None, side_stream=None, overlap=True, forks=None):
+    def __init__(self, models, frame_shape, out_size, k, streams=None, side_stream=None, overlap=True, forks=None, fuse_batched=False):
         self.models, self.k, self.out_size = list(models), int(k), (int(out_size[0]), int(out_size[1]))
         self.S = len(self.models)
+        self.fuse_batched = fuse_batched
         self.streams, self.side, self.overlap, self.forks = streams, side_stream, overlap, forks
         cores = [m.swem_core for m in self.models]
         for c in cores:
@@ -673,7 +685,7 @@ class LockstepGraph:
             nxt = sets[(j + 1) % 2]
             each = [key_item(self.keys[p], j * self.S + s) for s in range(self.S)]
             preds.append(lockstep_chain(self.models, key_items(self.keys[p], j * self.S, self.S), each, self.frames[p][j],
-                                        self.out_size, self.forks, outs=nxt))
+                                        self.out_size, self.forks, outs=nxt, fuse_batched=self.fuse_batched))
             for c, st in zip(cores, nxt):
                 c.memories['update'].bases = st       # (the tensors memorize wrote, under their own names)
                 c.restamp()
@@ -727,6 +739,27 @@ class LockstepGraph:
                 c.restamp()
         self.primed = False
         return self
+
+    def rebind(self):
+        """Adopt the models' CURRENT memories (new sequences of the same shapes) into the captured graphs' static buffers."""
+        cores = [m.swem_core for m in self.models]
+        for c, first, pack in zip(cores, self.first, self.packs or [None] * self.S):
+            cur_first, cur_upd = c.memories['first'].bases, c.memories['update'].bases
+            if cur_first is None or cur_upd is None or cur_first['kappa'].shape != first['kappa'].shape or c._pack is not pack:
+                return False
+        for c, first, state in zip(cores, self.first, self.state):
+            cur_first, cur_upd = c.memories['first'].bases, c.memories['update'].bases
+            c.repack()
+            for key in first:
+                if cur_first[key] is not first[key]:
+                    first[key].copy_(cur_first[key])
+                if cur_upd[key] is not state[key]:
+                    state[key].copy_(cur_upd[key])
+            c.memories['first'].bases = first
+            c.memories['update'].bases = state
+            c.restamp()
+        self.primed = False
+        return True
 
     def prime(self, frames_kS):
         """Key-encoder pass of the first group (k,S,3,H,W)."""
@@ -980,3 +1013,123 @@ class SequencePool:
             main.wait_stream(st)
         ops.check_faults()       # (synchronises: the results are about to be read)
         return results
+
+
+class LockstepPool:
+    """SequencePool for sequences that can march in LOCK STEP (round 6): len(models) / lockstep lanes, each a pipeline of `lockstep`
+    sequences of the same frame size, length, mask shape and output size (LockstepGraph: one key-encoder pass over
+    lockstep x lookahead frames, decoder and value encoder batched over the objects of all its sequences; match and memorize per
+    sequence).  run() cuts its sequences into such groups; what does not fill a group runs on a SequencePool over the first
+    models.  `models` are replicas (same weights); they share models[0]'s PlanBook.  Measured on config B (two lanes of four
+    sequences against four independent pipelines): bench.py, DESIGN.md section 5."""
+
+    def __init__(self, models, lockstep=4, use_graph=True, lookahead=10, plans='shipped'):
+        self.models, self.S = list(models), int(lockstep)
+        if self.S < 2 or len(self.models) % self.S:
+            raise ValueError('LockstepPool: %d models do not make lanes of %d sequences' % (len(self.models), self.S))
+        self.rest = SequencePool(self.models[:min(len(self.models), 4)], use_graph=use_graph, lookahead=lookahead, plans=plans)
+        for m in self.models[1:]:
+            m.book = self.models[0].book
+        self.lanes = [self.models[i:i + self.S] for i in range(0, len(self.models), self.S)]
+        self.streams = overlapping_streams(len(self.lanes)) if len(self.lanes) > 1 else [torch.cuda.current_stream()]
+        self.graphs = [None] * len(self.lanes)
+        self.graph_streams = [None] * len(self.lanes)
+        self.use_graph, self.lookahead = use_graph, int(lookahead)
+
+    def _graph_for(self, li, frames_list, i, out_size):
+        models, g, k = self.lanes[li], self.graphs[li], self.lookahead
+        shape = tuple(frames_list[0][:, i].shape)
+        if isinstance(g, LockstepGraph) and g.frame_shape == shape and g.out_size == out_size and g.k == k and g.rebind():
+            return g
+        if any(m.swem_core.memories['update'].bases is None for m in models):
+            return None
+        if len({tuple(m.swem_core.memories['first'].bases['kappa'].shape) for m in models}) != 1:
+            return None                       # (sequences with different numbers of objects: the lane runs them frame by frame)
+        self.graphs[li] = None
+        g = LockstepGraph(models, shape, out_size, k, streams=self.graph_streams[li], overlap=False, forks='none')
+        g.capture(torch.stack([f[0, i:i + k] for f in frames_list], dim=1))
+        self.graphs[li], self.graph_streams[li] = g, g.streams
+        return g
+
+    def run(self, sequences, seeds=None):
+        """As SequencePool.run (same arguments, same results layout, same range-fault fallback)."""
+        try:
+            return self._run(sequences, seeds)
+        except ops.SwemRangeError as err:
+            range_fallback(self.models[0], err, 'LockstepPool.run')
+            self.graphs = [None] * len(self.lanes)
+            self.rest.graphs = [None] * len(self.rest.models)
+            return self._run(sequences, seeds)
+
+    def _run(self, sequences, seeds=None):
+        ops.drain_faults('LockstepPool.run')
+        S, k = self.S, self.lookahead
+        buckets = {}
+        for si, (frames, init_mask, out_size) in enumerate(sequences):
+            key = (tuple(frames.shape), tuple(init_mask.shape), (int(out_size[0]), int(out_size[1])))
+            buckets.setdefault(key, []).append(si)
+        todo, rest = [], []
+        for idx in buckets.values():
+            while len(idx) >= S and k > 0 and self.use_graph:
+                todo.append(idx[:S])
+                idx = idx[S:]
+            rest += idx
+        results = [None] * len(sequences)
+        state = [None] * len(self.lanes)            # per lane: [sequence indices, next frame, preds per sequence, bound graph]
+        main = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(main)
+        with torch.no_grad():
+            while todo or any(l is not None for l in state):
+                for li, (models, st) in enumerate(zip(self.lanes, self.streams)):
+                    with torch.cuda.stream(st):
+                        if state[li] is None:
+                            if not todo:
+                                continue
+                            chunk = todo.pop(0)
+                            for m, si in zip(models, chunk):
+                                frames, init_mask, _ = sequences[si]
+                                if seeds is not None:
+                                    torch.manual_seed(seeds[si])
+                                h, w = frames.shape[-2:]
+                                mk16, _, s16, _, _ = m('encode_key', frames[:, 0])
+                                m0 = ops.resize_planes(init_mask.float().contiguous(), (h, w), 'nearest')
+                                m('init', mk16, m('encode_value', frames[:, 0], m0, s16), init_mask)
+                            state[li] = [chunk, 1, [[] for _ in chunk], None]
+                            continue
+                        chunk, i, preds, bound = state[li]
+                        fl = [sequences[si][0] for si in chunk]
+                        out_size = (int(sequences[chunk[0]][2][0]), int(sequences[chunk[0]][2][1]))
+                        t = fl[0].shape[1]
+                        step = 1
+                        # (as SequencePool: a captured frame always memorizes, the reference's loop does not memorize a sequence's
+                        # last frame -- a group runs from the graph only while MORE than k frames remain, the tail eagerly)
+                        if i >= 2 and bound is None and t - i > k:
+                            bound = state[li][3] = self._graph_for(li, fl, i, out_size)
+                            if bound is not None:
+                                bound.prime(torch.stack([f[0, i:i + k] for f in fl], dim=1))
+                        if bound is not None and t - i > k:
+                            nxt = torch.stack([f[0, i + k:i + 2 * k] for f in fl], dim=1) if t - i > 2 * k else None
+                            for p_ in bound.run(nxt):
+                                for s_ in range(S):
+                                    preds[s_].append(p_[s_:s_ + 1].clone())
+                            step = k
+                            if nxt is None:
+                                bound = state[li][3] = None
+                        else:
+                            for s_, m in enumerate(models):
+                                preds[s_].append(frame_step(m, fl[s_][:, i], out_size, memorize=i < t - 1))
+                        state[li][1] = i + step
+                        if i + step >= t:
+                            for s_, si in enumerate(chunk):
+                                results[si] = preds[s_]
+                            state[li] = None
+        for st in self.streams:
+            main.wait_stream(st)
+        ops.check_faults()       # (synchronises; a range fault of the lanes raises here, before the rest would drain it)
+        if rest:
+            sub = self.rest._run([sequences[si] for si in rest], None if seeds is None else [seeds[si] for si in rest])
+            for si, r in zip(rest, sub):
+                results[si] = r
+        return results
+

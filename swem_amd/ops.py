@@ -1398,22 +1398,26 @@ def _fused_planes(site, numel, device):
 
 
 def upsample_add(skip, low, batch=None):
-    """skip (B or 1, Ho, Wo, C) + bilinear(low (B, Hl, Wl, C))."""
+    """skip (B, 1 or B / n, Ho, Wo, C) + bilinear(low (B, Hl, Wl, C)); a skip batch of B / n: item b adds skip image b // n (the n
+    objects of a clip share the clip's skip feature -- no per-object copy)."""
     _chk(skip)
     _chk(low)
     B = low.shape[0]
-    _, Ho, Wo, Cc = skip.shape
+    Bs, Ho, Wo, Cc = skip.shape
+    if B % Bs:
+        raise _lib.SwemHipError('upsample_add: %d skip images for a batch of %d' % (Bs, B))
     y = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=low.device)
-    sbs = 0 if (skip.shape[0] == 1 and B > 1) else Ho * Wo * Cc
+    sbs = 0 if (Bs == 1 and B > 1) else Ho * Wo * Cc
+    group = B // Bs if Bs > 1 else 1
     site = ('upsample_add', B, Ho, Wo, Cc)
     planes, pargs = _fused_planes(site, y.numel(), y.device) if Cc % 8 == 0 else ({}, None)
     if planes:
-        _lib.call('swem_upsample_add_nhwc_f32_planes', _stream(), skip.data_ptr(), sbs, low.data_ptr(), y.data_ptr(), B,
+        _lib.call('swem_upsample_add_grouped_nhwc_f32_planes', _stream(), skip.data_ptr(), sbs, group, low.data_ptr(), y.data_ptr(), B,
                   low.shape[1], low.shape[2], Ho, Wo, Cc, *pargs, _fault_ptr(low.device))
         y.__dict__['_swem_split'] = planes
         y.__dict__['_swem_split_ver'] = y._version
     else:
-        _lib.call('swem_upsample_add_nhwc_f32', _stream(), skip.data_ptr(), sbs, low.data_ptr(), y.data_ptr(), B,
+        _lib.call('swem_upsample_add_grouped_nhwc_f32', _stream(), skip.data_ptr(), sbs, group, low.data_ptr(), y.data_ptr(), B,
                   low.shape[1], low.shape[2], Ho, Wo, Cc)
     y.__dict__['_swem_site'] = site
     return y

@@ -675,6 +675,110 @@ def test_sequence_pool_equals_sequential_evaluation(lib, lanes, lookahead):
     assert all(m.book is models[0].book for m in models)
 
 
+@pytest.mark.parametrize('forks,fused', [('none', False), (None, False), ('none', True)],
+                         ids=['linear_graph', 'forked_graph', 'fusion_conv_batched'])
+def test_lockstep_graph_matches_sequential_loops(lib, forks, fused):
+    """evaluator.LockstepGraph (round 6): THREE sequences in lock step, k = 3 frames of each per replay -- one key-encoder pass over
+    the 3 x 3 frames of the next group, decoder and value encoder batched over the objects of the three sequences, match and
+    memorize per sequence (one after the other, or on forked streams inside the graph; the fusion conv of matching per sequence or,
+    fuse_batched, once for all of them).  With plans that do not depend on the
+    batch (a tile without K-split) every sequence's index maps AND its memory after the last frame are those of its own
+    frame-by-frame loop BIT FOR BIT, in both arithmetics; a second set of sequences re-bound to the same graphs likewise."""
+    from swem_amd import synth
+    cfg = O.make_cfg(**CFG_A)
+    k, t, S = 3, 12, 3
+    clips = []
+    for s_ in range(2 * S):
+        frames, m0 = synth.make_clip(t=t, h=128, w=192, n_obj=2, seed=20 + s_)
+        clips.append((frames.to(DEV), m0.to(DEV)))
+
+    def start(model, frames, m0, seed):
+        torch.manual_seed(seed)
+        mk16, _, s16, _, _ = model('encode_key', frames[:, 0])
+        model('init', mk16, model('encode_value', frames[:, 0], m0, s16), m0)
+        return [evaluator.frame_step(model, frames[:, i], (128, 192)).clone() for i in (1, 2)]
+
+    def bases_of(model):
+        return {kk: v.clone() for kk, v in model.swem_core.memories['update'].bases.items()}
+
+    for math in (0, 3):
+        with torch.no_grad():
+            ref = []
+            model, _ = H.make_model_and_sd(cfg, wseed=4, device=DEV)
+            model.book.fallback = 0x111 | math << 16
+            for s_, (frames, m0) in enumerate(clips):
+                preds = start(model, frames, m0, 30 + s_)
+                preds += [evaluator.frame_step(model, frames[:, i], (128, 192)).clone() for i in range(3, t)]
+                ref.append((preds, bases_of(model)))
+            models = [H.make_model_and_sd(cfg, wseed=4, device=DEV)[0] for _ in range(S)]
+            for m in models:
+                m.book = models[0].book
+            models[0].book.fallback = 0x111 | math << 16
+            g = None
+            for half in (0, 1):
+                mine = clips[half * S:(half + 1) * S]
+                preds = [start(m, f, m0, 30 + half * S + s_) for s_, (m, (f, m0)) in enumerate(zip(models, mine))]
+                stack = lambda i: torch.stack([f[0, i:i + k] for f, _ in mine], dim=1)
+                if g is None:
+                    g = evaluator.LockstepGraph(models, mine[0][0][:, 1].shape, (128, 192), k, forks=forks, fuse_batched=fused).capture(stack(3))
+                else:
+                    assert g.rebind()
+                g.prime(stack(3))
+                for i in range(3, t, k):
+                    out = g.run(stack(i + k) if i + 2 * k <= t else None)
+                    for p_ in out:
+                        assert p_.shape == (S, 128, 192)
+                        for s_ in range(S):
+                            preds[s_].append(p_[s_:s_ + 1].clone())
+                torch.cuda.synchronize()
+                for s_ in range(S):
+                    rp, rb = ref[half * S + s_]
+                    assert len(rp) == len(preds[s_]) == t - 1
+                    for i, (a, b) in enumerate(zip(rp, preds[s_])):
+                        assert torch.equal(a, b), 'math %d sequence %d frame %d' % (math, half * S + s_, i + 1)
+                    got = bases_of(models[s_])
+                    for kk in rb:
+                        assert torch.equal(rb[kk], got[kk]), (math, half, s_, kk)
+
+
+def test_lockstep_pool_equals_sequential_evaluation(lib):
+    """evaluator.LockstepPool: two lanes of two sequences in lock step.  Seven sequences -- five of one shape (two lock-step groups
+    + one left over), one with another object count, one of another frame size and length -- come back in input order with the
+    index maps of evaluating them one after another with the plain loop (batch-invariant plans: bit for bit); the left-overs ran
+    on the inner SequencePool, and a second run() re-binds the lanes' graphs."""
+    cfg = O.make_cfg(**CFG_A)
+    models = [H.make_model_and_sd(cfg, 5, DEV)[0] for _ in range(4)]
+    models[0].book.fallback = 0x111
+    seqs, seeds = [], [11, 12, 13, 14, 15, 16, 17]
+    for k_, (t, hh, ww, n) in enumerate(((7, 240, 432, 2), (7, 240, 432, 2), (7, 240, 432, 1), (7, 240, 432, 2), (7, 240, 432, 2),
+                                         (5, 192, 320, 2), (7, 240, 432, 2))):
+        frames, m0 = synth_clip(t, hh, ww, n, 60 + k_)
+        seqs.append((frames.to(DEV), m0.to(DEV), (hh, ww)))
+    ref = []
+    for (frames, m0, out), sd_ in zip(seqs, seeds):
+        torch.manual_seed(sd_)
+        with torch.no_grad():
+            preds, _ = evaluator.evaluate_davis_seq(models[0], frames, [m0] + [None] * (frames.shape[1] - 1), out)
+        ref.append([p.clone() for p in preds])
+    pool = evaluator.LockstepPool(models, lockstep=2, lookahead=2, plans=None)
+    got = pool.run(seqs, seeds=seeds)
+    torch.cuda.synchronize()
+    assert all(isinstance(g_, evaluator.LockstepGraph) for g_ in pool.graphs)
+    assert any(g_ is not None for g_ in pool.rest.graphs)
+    for r, g_ in zip(ref, got):
+        assert len(r) == len(g_)
+        for a, b in zip(r, g_):
+            assert torch.equal(a, b)
+    got2 = pool.run(seqs[:5][::-1], seeds=seeds[:5][::-1])
+    torch.cuda.synchronize()
+    for r, g_ in zip(ref[:5][::-1], got2):
+        assert len(r) == len(g_)
+        for a, b in zip(r, g_):
+            assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        evaluator.LockstepPool(models[:3], lockstep=2)
+
+
 def test_range_fault_falls_back_to_the_full_range_arithmetic(lib):
     """VERDICT r04 item 1 / ADVICE r04: the shipped default arithmetic (f16x3) has the fp16 range, the reference's fp32
     inference (networks.py:22-32) has none.  A model whose activations leave it -- here: the key encoder's stem scaled by 3e4,

@@ -121,6 +121,23 @@ def test_resampling_matches_torch(lib):
     close(back(ops.upsample_add(nhwc(skip), nhwc(low))), ref, 1e-6, 'upsample_add')
     ref = skip[:1] + F.interpolate(low, size=(30, 54), mode='bilinear', align_corners=False)
     close(back(ops.upsample_add(nhwc(skip[:1]), nhwc(low))), ref, 1e-6, 'upsample_add shared skip')
+    # a skip image per GROUP of batch items (the objects of a clip share the clip's skip feature, several clips in the batch):
+    # bit-identical to the per-object copy of the skip maps, with and without the fused output planes
+    low6 = torch.randn(6, 32, 15, 27, generator=g)
+    rep = skip.repeat_interleave(3, dim=0)
+    full = ops.upsample_add(nhwc(rep), nhwc(low6))
+    assert torch.equal(ops.upsample_add(nhwc(skip), nhwc(low6)), full)
+    ops.SPLIT_HINTS.clear()
+    try:
+        ops.SPLIT_HINTS[full._swem_site] = {False: 2, True: 3}
+        a, b = ops.upsample_add(nhwc(skip), nhwc(low6)), ops.upsample_add(nhwc(rep), nhwc(low6))
+        assert torch.equal(a, full) and torch.equal(b, full)
+        for relu in (False, True):
+            assert torch.equal(a.__dict__['_swem_split'][relu][0].view(torch.int16), b.__dict__['_swem_split'][relu][0].view(torch.int16))
+    finally:
+        ops.SPLIT_HINTS.clear()
+    with pytest.raises(Exception):
+        ops.upsample_add(nhwc(skip), nhwc(low6[:5]))
     m = torch.rand(1, 3, 48, 85, generator=g)
     for size in ((48, 86), (30, 54), (96, 170), (48, 85)):
         assert torch.equal(ops.resize_planes(m.to(DEV), size, 'nearest').cpu(), F.interpolate(m, size=size, mode='nearest'))
