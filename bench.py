@@ -147,9 +147,10 @@ class FrameRunner:
 
 class LockstepRunner:
     """S sequences in lock step on one stream (evaluator.LockstepGraph): a step = one frame of EACH of them.  Built from S warmed-up
-    FrameRunners (their models hold the sequences' memories; their staged clips give the frame groups)."""
+    FrameRunners (their models hold the sequences' memories; their staged clips give the frame groups).  graph=False (or `look` set
+    to None later): the same groups eagerly (per-launch timing, profiler runs)."""
 
-    def __init__(self, runners, k):
+    def __init__(self, runners, k, graph=True):
         from swem_amd import evaluator
         self.rs, self.nseq, self.k = list(runners), len(runners), k
         self.model = self.rs[0].model
@@ -158,15 +159,35 @@ class LockstepRunner:
             cyc = [1 + (rn.i + j) % (rn.t - 1) for j in range(k * (rn.t - 1))]
             per_seq.append([torch.cat([rn.frames[:, c] for c in cyc[g * k:(g + 1) * k]]) for g in range(rn.t - 1)])
         self.groups = [torch.stack([per_seq[s][g] for s in range(self.nseq)], dim=1).contiguous() for g in range(len(per_seq[0]))]
-        self.look = evaluator.LockstepGraph([rn.model for rn in self.rs], self.rs[0].frames[:, 1].shape, OUT_HW, k,
-                                            overlap=False, forks='none').capture(self.groups[0])
-        self.look.prime(self.groups[0])
+        self.look = self.graph = None
         self.grp, self.left, self.preds = 0, 0, None
+        if graph:
+            self.look = evaluator.LockstepGraph([rn.model for rn in self.rs], self.rs[0].frames[:, 1].shape, OUT_HW, k,
+                                                overlap=False, forks='none').capture(self.groups[0])
+            self.look.prime(self.groups[0])
+
+    def eager_group(self, k):
+        """The next group of k lock-step frames eagerly: one key-encoder pass over the k x S frames, then the k lock-step chains."""
+        from swem_amd import evaluator
+        assert k == self.k
+        self.grp = (self.grp + 1) % len(self.groups)
+        grp = self.groups[self.grp]
+        models, S = [rn.model for rn in self.rs], self.nseq
+        preds = []
+        with torch.no_grad():
+            keys = self.model('encode_key', grp.view((k * S,) + tuple(grp.shape[2:])))
+            for j in range(k):
+                each = [evaluator.key_item(keys, j * S + s) for s in range(S)]
+                preds.append(evaluator.lockstep_chain(models, evaluator.key_items(keys, j * S, S), each, grp[j], OUT_HW, None))
+        return preds
 
     def step(self):
         if self.left == 0:
-            self.grp = (self.grp + 1) % len(self.groups)
-            self.preds = self.look.run(self.groups[self.grp])
+            if self.look is not None:
+                self.grp = (self.grp + 1) % len(self.groups)
+                self.preds = self.look.run(self.groups[self.grp])
+            else:
+                self.preds = self.eager_group(self.k)
             self.left = self.k
         self.left -= 1
         return self.preds[self.k - 1 - self.left]
@@ -299,9 +320,9 @@ def main():
                     help='frames per graph replay with the key encoder batched over them (evaluator.LookaheadGraph); 0 = one frame '
                          'per replay; default: the divisor of --steps nearest to 8 (the timed region then holds exactly --steps '
                          'frames per sequence: 10 for 20 or 100 steps, 8 for 24 / 40 / 48), else 4')
-    ap.add_argument('--seqs', type=int, default=4,
-                    help='independent sequences processed concurrently per GPU, each on its own HIP stream')
-    ap.add_argument('--lockstep', type=int, default=0,
+    ap.add_argument('--seqs', type=int, default=8,
+                    help='sequences in flight per GPU (default 8 = two lock-step lanes of four; round 5: --seqs 4 --lockstep 0)')
+    ap.add_argument('--lockstep', type=int, default=4,
                     help='S > 1: the sequences run in lanes of S sequences in LOCK STEP (evaluator.LockstepGraph: decoder and value '
                          'encoder batched over the objects of the S sequences, ONE key-encoder pass over S x lookahead frames), '
                          '--seqs / S lanes side by side, each on its own stream; 0: every sequence its own pipeline')
@@ -391,8 +412,7 @@ def main():
         tunes the plans of the current conv_math mode into `book`) and captured into its frame graph."""
         rs, sts, pending = [], [], []
         # lock-step lanes (--lockstep S): n / S lanes of S sequences each; a lane is ONE pipeline on one stream
-        S_ = args.lockstep if (args.lockstep > 1 and n >= args.lockstep and n % args.lockstep == 0 and args.lookahead > 0
-                               and not args.no_graph) else 0
+        S_ = args.lockstep if (args.lockstep > 1 and n >= args.lockstep and n % args.lockstep == 0 and args.lookahead > 0) else 0
         nstreams = n // S_ if S_ else n
         # streams that really overlap (two HIP streams can share a hardware queue and then serialise: evaluator.overlapping_streams)
         seq_streams = evaluator.overlapping_streams(nstreams) if nstreams > 1 else [torch.cuda.current_stream()]
@@ -419,10 +439,10 @@ def main():
                     pending.append(rn)
                     if len(pending) == S_:       # the lane is complete: capture its lock-step graphs (the first lane tunes the batched shapes)
                         ops.AUTOTUNE = tune and si == S_ - 1
-                        lane = LockstepRunner(pending, args.lookahead)
-                        ops.AUTOTUNE = False
+                        lane = LockstepRunner(pending, args.lookahead, graph=not args.no_graph)
                         for _ in range(2 * args.lookahead):
                             lane.step()
+                        ops.AUTOTUNE = False
                         rs.append(lane)
                         sts.append(st)
                         pending = []
@@ -555,7 +575,8 @@ def main():
         conv_math mode the caller has entered; pmc_tag names the committed counter files (profiles/r05_conv_*<tag>.json)."""
         # ---------------- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream
         kla = args.lookahead if (args.lookahead > 0 and not args.no_graph) else 0
-        nprof = min(args.steps, 5) if not kla else kla * max(1, 4 // kla)       # frames traced eagerly
+        per = getattr(runner, 'nseq', 1)        # (a lock-step lane: every eager group holds kla frames of EACH of its sequences)
+        nprof = min(args.steps, 5) if not kla else kla * max(1, 4 // kla) * per       # frames traced eagerly
         runner.graph = runner.look = None       # per-launch timing needs eager launches (same kernels, same plans)
 
         def eager_frames(n):
@@ -565,7 +586,7 @@ def main():
             saved, ops.ASYNC_KEY_ENCODER = ops.ASYNC_KEY_ENCODER, False
             try:
                 if kla:
-                    for _ in range(n // kla):
+                    for _ in range(n // (kla * per)):
                         runner.eager_group(kla)
                 else:
                     for _ in range(n):
@@ -585,11 +606,11 @@ def main():
         # The launch stream must never run dry while the frames are traced: with an empty queue a launch's event interval is
         # the HOST's enqueue time (~10 us per Python call), not the kernel's.  A spin kernel holds the GPU back until the host
         # has enqueued all traced frames; the intervals then lie between back-to-back packets of one in-order queue.
-        eager_frames(max(kla, 1))                   # (the eager batched shapes: workspaces sized, planes hinted)
+        eager_frames(max(kla, 1) * per)             # (the eager batched shapes: workspaces sized, planes hinted)
         torch.cuda.synchronize()
         t_host = time.perf_counter()
-        eager_frames(max(kla, 1))
-        t_host = (time.perf_counter() - t_host) / max(kla, 1)      # host time to enqueue one eager frame
+        eager_frames(max(kla, 1) * per)
+        t_host = (time.perf_counter() - t_host) / (max(kla, 1) * per)      # host time to enqueue one eager frame
         torch.cuda.synchronize()
         ops.CONV_TRACE = []
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -777,10 +798,12 @@ def main():
             'frac_f16x3_pipe': per_pipe.get('f16x3', {}).get('frac'),
             'frac_fp32_pipe': per_pipe.get('fp32', {}).get('frac'),
             'conv_ms_per_frame_eager_one_stream': round(sum(d['ms'] for d in pipes.values()) / nprof, 3),
-            'note': 'useful conv FLOPs (2*M*Cout*KH*KW*Cin, unpadded) of %d eager frames of ONE sequence / summed per-launch '
+            'note': 'useful conv FLOPs (2*M*Cout*KH*KW*Cin, unpadded) of %d eager frames of %s / summed per-launch '
                     'HIP-event durations on the launch stream (the queue held full behind a spin kernel: the intervals are '
                     'GPU time between back-to-back packets, not host enqueue time); the timed region above is graph replay of %d sequence(s) on %d '
-                    'stream(s), whose kernels overlap -- `whole_frame` prices THAT' % (nprof, nseq, nseq),
+                    'stream(s), whose kernels overlap -- `whole_frame` prices THAT'
+                    % (nprof, 'ONE sequence' if per == 1 else 'ONE lock-step lane of %d sequences (the launches the timed graphs replay)' % per,
+                       nseq, nseq // per),
             'plans_bf16x6': hist['bf16x6'], 'plans_bf16x3': hist['bf16x3'], 'plans_f16x3': hist['f16x3'],
             'plans_total': sum(hist.values())}
         return roof, pipes, per_pipe, peaks, nprof
@@ -818,7 +841,7 @@ def main():
                    'note': 'the same workload with the conv tuner restricted to fp32 MFMA and bf16x6 (both operands split exactly '
                            'into three bf16 terms), ops.conv_math((0, 1)): no operand bit of the fp32 reference is dropped'}
             if not args.no_roofline:
-                roof32, _, _, _, _ = leg_roofline(r32[0], h32, '_exact')
+                roof32, _, _, _, _ = leg_roofline(r32[0], h32, '_exact')      # (a lock-step lane traces its own eager groups)
                 leg['roofline'] = roof32
             del r32, s32
             torch.cuda.empty_cache()
@@ -855,7 +878,7 @@ def main():
             book.save(args.save_plans)             # again: with the plans the extra legs tuned
 
     if world == 1 and not args.no_roofline:
-        roof, pipes, per_pipe, peaks, nprof = leg_roofline(runner, hist, pmc_tag)
+        roof, pipes, per_pipe, peaks, nprof = leg_roofline(runners[0] if lockstep else runner, hist, pmc_tag)
         out['roofline'] = roof
         out['conv_frac_time_weighted'] = roof['frac_time_weighted_all_conv_kernels']    # (beside roofline.frac: VERDICT r05 item 8)
         # whole frame of the TIMED configuration against the blended ceiling: every FLOP priced at its pipe's peak

@@ -37,7 +37,7 @@ def main():
     ap.add_argument('alts', nargs='+')
     ap.add_argument('--margin', type=float, default=0.004)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--seqs', type=int, default=4)
+    ap.add_argument('--seqs', type=int, default=8)
     a = ap.parse_args()
     extra = ['--seqs', str(a.seqs)]
     cur = json.load(open(a.base))
