@@ -574,8 +574,8 @@ def main():
         """Roofline of one leg's dominant conv kernel: per-launch HIP-event timing of eager frames of ONE sequence (runner) in the
         conv_math mode the caller has entered; pmc_tag names the committed counter files (profiles/r05_conv_*<tag>.json)."""
         # ---------------- roofline of the dominant kernel: per-launch HIP-event timing on the launch stream
-        kla = args.lookahead if (args.lookahead > 0 and not args.no_graph) else 0
         per = getattr(runner, 'nseq', 1)        # (a lock-step lane: every eager group holds kla frames of EACH of its sequences)
+        kla = args.lookahead if (args.lookahead > 0 and (not args.no_graph or per > 1)) else 0      # (a lane runs whole groups, eagerly too)
         nprof = min(args.steps, 5) if not kla else kla * max(1, 4 // kla) * per       # frames traced eagerly
         runner.graph = runner.look = None       # per-launch timing needs eager launches (same kernels, same plans)
 

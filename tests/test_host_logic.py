@@ -451,3 +451,30 @@ def test_round6_host_logic(tmp_path, monkeypatch):
     monkeypatch.setenv('SWEM_DIST_SINGLE_RANK', '1')
     assert sdist.single_rank_group() and not sdist.active()     # (no process group initialised here)
     assert ops.graph_capture_kwargs() == {}
+
+
+def test_lockstep_host_logic():
+    """Round 6's lock-step lanes, the parts that need no GPU: the pool refuses a model count that does not make whole lanes (before it
+    touches a device), the shipped plan file holds the layer shapes of bench.py's default lanes (four sequences x two objects per
+    object layer, 4 x 10 frames per key-encoder pass) in both arithmetics, the bench's defaults are those lanes, and the C ABI
+    declares the grouped skip-add the batched decoder uses."""
+    import json
+    import os
+    import re
+    import sys
+    from swem_amd import evaluator, ops
+    with pytest.raises(ValueError):
+        evaluator.LockstepPool([object()] * 3, lockstep=2)
+    with pytest.raises(ValueError):
+        evaluator.LockstepPool([object()] * 4, lockstep=1)
+    shipped = json.load(open(ops.shipped_plans()))
+    keys = {tuple(k) for k, _ in shipped['conv']}
+    for tag in ((), ('math', 0, 1)):
+        assert (256, 256, 3, 3, 1, 1, 1, 8, 120, 216) + tag in keys         # decoder, 8 objects at 1/4 scale
+        assert (1280, 512, 3, 3, 1, 1, 1, 8, 30, 54) + tag in keys          # value encoder's fusion block, 8 objects at 1/16 scale
+        assert (256, 256, 3, 3, 1, 1, 0, 40, 120, 216) + tag in keys        # key encoder + decoder skip conv over 4 x 10 frames
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    src = open(os.path.join(root, 'bench.py')).read()
+    assert re.search(r"add_argument\('--seqs', type=int, default=8", src) and re.search(r"add_argument\('--lockstep', type=int, default=4", src)
+    hdr = open(os.path.join(root, 'include', 'swem_hip.h')).read()
+    assert 'swem_upsample_add_grouped_nhwc_f32(' in hdr and 'swem_upsample_add_grouped_nhwc_f32_planes(' in hdr
