@@ -683,7 +683,9 @@ def test_lockstep_graph_matches_sequential_loops(lib, forks, fused):
     memorize per sequence (one after the other, or on forked streams inside the graph; the fusion conv of matching per sequence or,
     fuse_batched, once for all of them).  With plans that do not depend on the
     batch (a tile without K-split) every sequence's index maps AND its memory after the last frame are those of its own
-    frame-by-frame loop BIT FOR BIT, in both arithmetics; a second set of sequences re-bound to the same graphs likewise."""
+    frame-by-frame loop BIT FOR BIT, in both arithmetics; a second set of sequences re-bound to the same graphs likewise.  (With the
+    fusion conv batched too, its GLU launch has another row count than the per-sequence one and the pinned plan does not bind a GLU
+    layer: fp32 summation order differs -- index maps agree on > 0.9995 of the pixels, memories to 1e-2 of their range.)"""
     from swem_amd import synth
     cfg = O.make_cfg(**CFG_A)
     k, t, S = 3, 12, 3
@@ -734,9 +736,15 @@ def test_lockstep_graph_matches_sequential_loops(lib, forks, fused):
                 for s_ in range(S):
                     rp, rb = ref[half * S + s_]
                     assert len(rp) == len(preds[s_]) == t - 1
+                    got = bases_of(models[s_])
+                    if fused:      # (the GLU conv of 3 x 2 objects runs the heuristic's tile for ITS row count: same products, other order)
+                        for i, (a, b) in enumerate(zip(rp, preds[s_])):
+                            assert float((a == b).float().mean()) > 0.9995, 'math %d sequence %d frame %d' % (math, half * S + s_, i + 1)
+                        for kk in rb:
+                            assert float((rb[kk] - got[kk]).abs().max()) <= 1e-2 * float(rb[kk].abs().max()), (math, half, s_, kk)
+                        continue
                     for i, (a, b) in enumerate(zip(rp, preds[s_])):
                         assert torch.equal(a, b), 'math %d sequence %d frame %d' % (math, half * S + s_, i + 1)
-                    got = bases_of(models[s_])
                     for kk in rb:
                         assert torch.equal(rb[kk], got[kk]), (math, half, s_, kk)
 

@@ -133,7 +133,9 @@ def test_resampling_matches_torch(lib):
         a, b = ops.upsample_add(nhwc(skip), nhwc(low6)), ops.upsample_add(nhwc(rep), nhwc(low6))
         assert torch.equal(a, full) and torch.equal(b, full)
         for relu in (False, True):
-            assert torch.equal(a.__dict__['_swem_split'][relu][0].view(torch.int16), b.__dict__['_swem_split'][relu][0].view(torch.int16))
+            n = a.__dict__['_swem_split'][relu][1]               # (planes written: 2 without the ReLU, 3 with it; the rest is not touched)
+            assert n == b.__dict__['_swem_split'][relu][1] == (3 if relu else 2)
+            assert torch.equal(a.__dict__['_swem_split'][relu][0][:n].view(torch.int16), b.__dict__['_swem_split'][relu][0][:n].view(torch.int16))
     finally:
         ops.SPLIT_HINTS.clear()
     with pytest.raises(Exception):

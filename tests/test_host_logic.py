@@ -188,7 +188,7 @@ def test_shipped_plan_file_is_well_formed():
         assert v == 0 or ((wm in (1, 2) and wn in (1, 2) or t256) and 1 <= ns <= 255), (k, hex(v))
         assert math in ((0, 1) if len(k) == 13 else (0, 1, 7)), (k, hex(v))     # (7 = f16x3: math 3 + SWEM_PLAN_F16)
         cin, cout, kh, kw, stride, pad, flags, B, H, W = k[:10]
-        assert cin > 0 and cout % 4 == 0 and kh == kw and stride in (1, 2) and B in (1, 2, 3, 4, 5, 8, 10, 40)    # 1-5 objects; key encoder batched over a look-ahead of 4, 8 or 10 frames; lock-step lanes (round 6): 4 sequences x 2 objects, 4 x 10 frames
+        assert cin > 0 and cout % 4 == 0 and kh == kw and stride in (1, 2) and B in (1, 2, 3, 4, 5, 8, 10, 12, 20, 40)    # 1-5 objects; key encoder batched over a look-ahead of 4, 8 or 10 frames; lock-step lanes (round 6): 4 sequences x 1, 2, 3, 5 objects, 4 x 10 frames
     hist, hist32 = book.math_histogram(), book.math_histogram(('math', 0, 1))
     # the default leg: f16x3 nearly everywhere, never a 16-bit or 8-bit operand mode; the exact-split leg: fp32 MFMA / bf16x6
     assert hist['f16x3'] >= 50 and hist['bf16'] == hist['bf16x3'] == 0 and sum(hist.values()) == len(untagged)
