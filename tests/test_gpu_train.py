@@ -1252,9 +1252,12 @@ def test_rccl_single_rank_training_step(lib, tmp_path, opts):
     H.record_parity('rccl_single_rank_training_step[%s]' % ('+'.join(opts) or 'eager'), rep)
 
 
-def test_bench_under_a_single_rank_rccl_group(lib):
+@pytest.mark.parametrize('lanes', [0, 2], ids=['independent_pipelines', 'lockstep_lanes'])
+def test_bench_under_a_single_rank_rccl_group(lib, lanes):
     """`bench.py` with a one-rank RCCL process group (SWEM_DIST_SINGLE_RANK=1): barrier(device_ids) and the counter all-reduce of
-    the timed regions go through librccl; the line says rccl_ranks = 1."""
+    the timed regions go through librccl; the line says rccl_ranks = 1.  Both launch forms: two independent pipelines, and the
+    default's form -- lock-step lanes (here two lanes of two sequences), whose graphs are captured while the process group's
+    watchdog thread is alive."""
     import json
     import os
     import subprocess
@@ -1265,11 +1268,13 @@ def test_bench_under_a_single_rank_rccl_group(lib):
         env.pop(k, None)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '4', '--warmup', '2', '--regions', '3',
-                          '--seqs', '2', '--lookahead', '2', '--no-autotune', '--no-cpu-baseline', '--no-em', '--no-legs'],
+                          '--lookahead', '2', '--no-autotune', '--no-cpu-baseline', '--no-em', '--no-legs']
+                         + (['--seqs', '4', '--lockstep', '2'] if lanes else ['--seqs', '2', '--lockstep', '0']),
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1 and line['value'] > 0
+    assert line['config']['lockstep_lanes'] == lanes and line['config']['frames_per_step'] == (4 if lanes else 2)
 
 
 AMP_LAYERS = ('key_encoder.res2.0.conv2', 'key_encoder.layer2.0.conv2', 'key_encoder.layer3.5.conv3', 'key_proj.key_proj',
