@@ -9,8 +9,11 @@ Workload (BASELINE.json configs[1]): synthetic structured 480x864 clip, ResNet-5
 encoder, K=256 bases, 5 EM iterations, 2 objects, output 480x854, random weights of the reference architecture.
 A "step" is one steady-state frame of the reference's per-sequence loop (swem_evaluator.py:72-97):
 encode_key -> match -> segment -> argmax/one-hot -> bilinear -> encode_value -> memorize, for each of the --seqs
-independent sequences a GPU works on concurrently (default 4, one HIP stream + one HIP graph each: the others'
-kernels fill the CUs one sequence leaves idle in small layers and kernel tails; --seqs 1 = strictly one at a time).  Frames are resident in
+independent sequences a GPU works on concurrently.  Default since round 6: 8 sequences as two LOCK-STEP lanes of four
+(--lockstep 4, evaluator.LockstepGraph: a lane encodes the keys of 4 x 10 frames in one pass, runs match and memorize per sequence
+and the decoder and value encoder once for the objects of its four sequences; the second lane's kernels fill what the first leaves
+idle).  --lockstep 0: every sequence its own pipeline, one HIP stream + one HIP graph each (round 5's default with --seqs 4);
+--seqs 1 = strictly one at a time.  Frames are resident in
 HBM before the timed region (the reference also excludes the H2D copy, basic_evaluator.py:157-176).
 Every rank runs its own clip (sequences are independent: weak scaling, no data-path collective);
 value = frames of all ranks / max-over-ranks time.
@@ -21,7 +24,7 @@ Arithmetic of the line (`dtype`, `plans`): the shipped plans run the convolution
 Extra objects in the JSON line:
   roofline     -- dominant conv kernel of the timed leg: useful conv FLOPs / summed launch durations (HIP events on the launch
                   stream) against ITS pipe's ceiling (dense f16 / bf16 MFMA peak / products per fp32 product); mfma_busy and
-                  traffic from the committed rocprofv3 --pmc passes (profiles/r05_conv_pmc*.json, r05_conv_traffic_by_kernel*.json);
+                  traffic from the committed rocprofv3 --pmc passes (profiles/r06_conv_pmc*.json, r06_conv_traffic_by_kernel*.json);
                   `pipes` has the fp32-MFMA layers against 157.3 TFLOP/s; `whole_frame` prices the timed configuration.
   fp32_level   -- the same workload in the exact-split arithmetic (fp32 MFMA / bf16x6: all 24 operand bits), with its own
                   `roofline` and single-sequence figure; `value_by_arithmetic` puts both legs side by side at top level.
