@@ -31,6 +31,7 @@ def main():
     ap.add_argument('--skip-independent', action='store_true')
     ap.add_argument('--no-forks', action='store_true', help='the per-sequence parts of a lock-step frame one after the other (a linear graph)')
     ap.add_argument('--no-overlap', action='store_true', help="a lane's key-encoder graph behind its chain graph on ONE stream instead of beside it")
+    ap.add_argument('--stagger-ms', type=float, default=0.0, help='hold lane i back by i x this many ms once, before the timed replays (phase of the lanes against each other)')
     ap.add_argument('--decompose', action='store_true', help='also: the chain graph and the key-encoder graph of each form replayed ALONE on the idle chip')
     ap.add_argument('--save-plans', default=None)
     ap.add_argument('--load-plans', default=None)
@@ -160,6 +161,16 @@ def main():
                 ln[0].run(ln[1][1])
         for _ in range(2):
             step_b()
+        if a.stagger_ms:
+            plain, calls = step_b, [0]
+
+            def step_b():          # (every timed region starts from a synchronize: the stagger is applied at its first replay, inside the clock)
+                if calls[0] % a.rounds == 0:
+                    for i, ln in enumerate(lanes):
+                        with torch.cuda.stream(ln[4]):
+                            torch.cuda._sleep(int(i * a.stagger_ms * 2.0e6))       # (~2 GHz: cycles per ms)
+                calls[0] += 1
+                plain()
         fps_b = median3(step_b) * a.lanes
         if a.decompose:
             lk = lanes[0][0]
