@@ -267,6 +267,53 @@ def test_teacher_forced_edge_shapes(lib, n_obj, h, w, bases, topl, mode):
                                                                                  'frames': rows})
 
 
+@pytest.mark.parametrize('mode', ('tuned', 'fp32'))
+def test_lockstep_lanes_against_the_reference_fixture_g7(lib, golden, mode):
+    """The lock-step lanes (evaluator.LockstepPool, round 6: bench.py's default launch form) at config-B size against the
+    REFERENCE's own index maps (fixture g7, recorded from lmm077/SWEM itself): four copies of the 4-frame clip run as two lanes of two
+    sequences with one frame per replay, so frame 2 of every sequence comes out of the captured lock-step graph -- the key encoder
+    over both sequences' frames in one pass, decoder and value encoder batched over their four objects -- with the shipped plans
+    ('tuned') and on the fp32 kernels.  Every sequence meets the free-running bar of the plain loop on every frame, agrees with the
+    plain loop of a replica to the same bar, and on the fp32 kernels equals it on the frame before the graph (frame 1)."""
+    fx = golden('g7_configB.npz')
+    cfg = O.make_cfg(**CFG_B)
+    out = (int(fx['out_h']), int(fx['out_w']))
+    frames, m0 = H.clip_from_fixture(fx)
+    frames, m0 = frames.to(DEV), m0.to(DEV)
+    models = [H.make_model_and_sd(cfg, int(fx['wseed']), device=DEV)[0] for _ in range(5)]
+    for m in models[1:4]:
+        m.book = models[0].book
+    with torch.no_grad(), H.arith(mode, models[0], models[4]) as ar:
+        torch.manual_seed(77)
+        plain, _ = evaluator.evaluate_davis_seq(models[4], frames, [m0, None, None, None], out)
+        plain = [p.clone() for p in plain]
+        pool = evaluator.LockstepPool(models[:4], lockstep=2, lookahead=1, plans=None)
+        got = pool.run([(frames, m0, out)] * 4, seeds=[77] * 4)
+        torch.cuda.synchronize()
+        assert all(isinstance(g_, evaluator.LockstepGraph) for g_ in pool.graphs)
+    agree = []
+    for preds in got:
+        assert len(preds) == 3
+        if mode == 'fp32':
+            assert torch.equal(preds[0], plain[0])                 # frame 1: the same eager launches
+        # ('tuned': which producers already write their consumers' fp16 planes -- and then leave the fp32 map out, so that a residual
+        # is read from the pair -- depends on what the book's hints have seen; four interleaved sequences and one plain loop differ there)
+        a_ = [float((p_.cpu().to(torch.uint8) == fx['pred%d' % i_]).float().mean()) for i_, p_ in enumerate(preds)]
+        for i_, v_ in enumerate(a_):
+            assert v_ >= min(0.9995, float(fx['agree64'][i_]) - 0.01), (i_, v_)
+        agree.append(a_)
+    # (against the plain loop of a replica the same free-running bar: the clip's EM amplifies a last-bit difference of frame 1 to
+    # the fp32-vs-float64 level of the fixture by frames 2-3)
+    vs_plain = [float((a == b).float().mean()) for preds in got for a, b in zip(preds, plain)]
+    for j_, v_ in enumerate(vs_plain):
+        assert v_ >= min(0.9995, float(fx['agree64'][j_ % 3]) - 0.01), (j_, v_)
+    H.record_parity('lockstep_lanes_g7[%s]' % mode, {'conv_launches_by_math': ar.summary(), 'plans_digest': models[0].book.digest(),
+                                                    'index_maps_agreement_with_reference_fixture_g7': agree,
+                                                    'index_maps_agreement_with_the_plain_loop_min': min(vs_plain),
+                                                    'note': 'two lanes of two sequences, one frame per replay: frame 2 of every sequence from '
+                                                            'the lock-step graph'})
+
+
 @pytest.mark.parametrize('mode', H.ARITH_MODES)
 def test_config_e_long_video(lib, golden, mode):
     """BASELINE config E: >= 1000 frames at 480x864, the memory re-estimated on EVERY frame (sequential base merging),
