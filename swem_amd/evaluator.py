@@ -981,6 +981,8 @@ class SequencePool:
                             model('init', mk16, model('encode_value', frames[:, 0], m0, s16), init_mask)
                             # (a graph is bound to ONE sequence of ONE run() call: the record below is unique per sequence)
                             lanes[li] = [si, frames, (int(out_size[0]), int(out_size[1])), 1, [], None]
+                            if frames.shape[1] <= 1:        # (a one-frame sequence: nothing to segment, swem_evaluator.py:72)
+                                results[si], lanes[li] = [], None
                             continue
                         si, frames, out_size, i, preds, bound = lanes[li]
                         t = frames.shape[1]
@@ -1096,6 +1098,10 @@ class LockstepPool:
                                 m0 = ops.resize_planes(init_mask.float().contiguous(), (h, w), 'nearest')
                                 m('init', mk16, m('encode_value', frames[:, 0], m0, s16), init_mask)
                             state[li] = [chunk, 1, [[] for _ in chunk], None]
+                            if sequences[chunk[0]][0].shape[1] <= 1:        # (one-frame sequences: nothing to segment)
+                                for si in chunk:
+                                    results[si] = []
+                                state[li] = None
                             continue
                         chunk, i, preds, bound = state[li]
                         fl = [sequences[si][0] for si in chunk]

@@ -750,16 +750,16 @@ def test_lockstep_graph_matches_sequential_loops(lib, forks, fused):
 
 
 def test_lockstep_pool_equals_sequential_evaluation(lib):
-    """evaluator.LockstepPool: two lanes of two sequences in lock step.  Seven sequences -- five of one shape (two lock-step groups
-    + one left over), one with another object count, one of another frame size and length -- come back in input order with the
+    """evaluator.LockstepPool: two lanes of two sequences in lock step.  Eight sequences -- five of one shape (two lock-step groups
+    + one left over), one with another object count, one of another frame size and length, one of a single frame -- come back in input order with the
     index maps of evaluating them one after another with the plain loop (batch-invariant plans: bit for bit); the left-overs ran
     on the inner SequencePool, and a second run() re-binds the lanes' graphs."""
     cfg = O.make_cfg(**CFG_A)
     models = [H.make_model_and_sd(cfg, 5, DEV)[0] for _ in range(4)]
     models[0].book.fallback = 0x111
-    seqs, seeds = [], [11, 12, 13, 14, 15, 16, 17]
+    seqs, seeds = [], [11, 12, 13, 14, 15, 16, 17, 18]
     for k_, (t, hh, ww, n) in enumerate(((7, 240, 432, 2), (7, 240, 432, 2), (7, 240, 432, 1), (7, 240, 432, 2), (7, 240, 432, 2),
-                                         (5, 192, 320, 2), (7, 240, 432, 2))):
+                                         (5, 192, 320, 2), (7, 240, 432, 2), (1, 240, 432, 2))):      # (the last: ONE frame, nothing to segment)
         frames, m0 = synth_clip(t, hh, ww, n, 60 + k_)
         seqs.append((frames.to(DEV), m0.to(DEV), (hh, ww)))
     ref = []
