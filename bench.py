@@ -162,26 +162,32 @@ class LockstepRunner:
             cyc = [1 + (rn.i + j) % (rn.t - 1) for j in range(k * (rn.t - 1))]
             per_seq.append([torch.cat([rn.frames[:, c] for c in cyc[g * k:(g + 1) * k]]) for g in range(rn.t - 1)])
         self.groups = [torch.stack([per_seq[s][g] for s in range(self.nseq)], dim=1).contiguous() for g in range(len(per_seq[0]))]
-        self.look = self.graph = None
+        self.look = self.graph = self.lane = None
         self.grp, self.left, self.preds = 0, 0, None
+        if not graph:      # (eager only: the lane object without captured graphs -- its lane-wide banks and packs serve the eager groups)
+            self.lane = evaluator.LockstepGraph([rn.model for rn in self.rs], self.rs[0].frames[:, 1].shape, OUT_HW, k, overlap=False,
+                                                forks='none', batched_em=True)
         if graph:
             self.look = evaluator.LockstepGraph([rn.model for rn in self.rs], self.rs[0].frames[:, 1].shape, OUT_HW, k,
-                                                overlap=False, forks='none').capture(self.groups[0])
+                                                overlap=False, forks='none', batched_em=True).capture(self.groups[0])
             self.look.prime(self.groups[0])
+            self.lane = self.look
 
     def eager_group(self, k):
-        """The next group of k lock-step frames eagerly: one key-encoder pass over the k x S frames, then the k lock-step chains."""
+        """The next group of k lock-step frames eagerly -- the launches the captured graphs replay: one key-encoder pass over the
+        k x S frames, then the k lock-step chains (EM and matching batched over the lane's sequences)."""
         from swem_amd import evaluator
         assert k == self.k
         self.grp = (self.grp + 1) % len(self.groups)
         grp = self.groups[self.grp]
-        models, S = [rn.model for rn in self.rs], self.nseq
+        lane, S = self.lane, self.nseq
+        sets = (lane.state, lane.state2)
         preds = []
         with torch.no_grad():
             keys = self.model('encode_key', grp.view((k * S,) + tuple(grp.shape[2:])))
             for j in range(k):
-                each = [evaluator.key_item(keys, j * S + s) for s in range(S)]
-                preds.append(evaluator.lockstep_chain(models, evaluator.key_items(keys, j * S, S), each, grp[j], OUT_HW, None))
+                preds.append(evaluator.lockstep_chain_batched(lane, evaluator.key_items(keys, j * S, S), grp[j], OUT_HW,
+                                                              sets[1 - lane.cur]))
         return preds
 
     def step(self):

@@ -388,6 +388,15 @@ int swem_memorize_packed_f32(void *stream, const float *x, const float *v, const
                              float *zita_out, float *mkn, float *mvp, void *mvq, int prior_packed, int bank, int N, int C,
                              int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes, void *fault);
 
+/* The same for the objects of SEVERAL clips in one call (round 6, sequences in lock step: evaluator.LockstepGraph): N objects in
+ * total, N / clips per clip -- the reference's batch dimension, modules.py:129-168 with B = clips, every clip with its own key map:
+ * x [clips][P][C].  v, masks, the bases and the pack are per object as above (the clips' objects back to back).  Per object the
+ * launches run the same blocks on the same data as `clips` single-clip calls: identical results. */
+int swem_memorize_packed_clips_f32(void *stream, const float *x, const float *v, const float *masks, const float *kappa_prev,
+                                   const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out,
+                                   float *zita_out, float *mkn, float *mvp, void *mvq, int prior_packed, int bank, int N,
+                                   int clips, int C, int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes, void *fault);
+
 /* The packed memorize in two calls (round 3).  modules.py:129-168 reads the value map only in its last statement
  * (:164-165, nu = (zita_ nu_ + mv z) / zita); everything before it -- every E, W and key M step, 2T - 1 of the 2T launches --
  * needs the key, the masks and the prior only, so a caller can run it BESIDE the value encoder that produces the value map
@@ -442,6 +451,12 @@ int swem_match_packed_f32_planes(void *stream, const float *qk, const float *mkn
                                  float *mem_out, float *S, int N, int C, int V, int P, int L, int topl, float tau,
                                  int readout_plan, void *ws, size_t ws_bytes, void *mem_planes, int mem_nplanes, void *s_planes,
                                  int s_nplanes, void *fault);
+/* Both for the objects of SEVERAL clips in one call (round 6): N objects in total, N / clips per clip, qk = one query key map per
+ * clip [clips][P][C] (modules.py:232-293 with B = clips); packs and outputs per object.  Plane pointers may be NULL. */
+int swem_match_packed_clips_f32(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq, float *mem_out,
+                                float *S, int N, int clips, int C, int V, int P, int L, int topl, float tau, int readout_plan,
+                                void *ws, size_t ws_bytes, void *mem_planes, int mem_nplanes, void *s_planes, int s_nplanes,
+                                void *fault);
 
 #ifdef __cplusplus
 }

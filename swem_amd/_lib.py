@@ -65,6 +65,7 @@ SIGNATURES = {
     'swem_memorize_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'swem_memorize_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _sz]),
     'swem_memorize_packed_f32': (_i, [_p] * 13 + [_i] * 8 + [_f, _p, _sz, _p]),
+    'swem_memorize_packed_clips_f32': (_i, [_p] * 13 + [_i] * 9 + [_f, _p, _sz, _p]),
     'swem_memorize_packed_keys_f32': (_i, [_p] * 9 + [_i] * 7 + [_f, _p, _sz]),
     'swem_memorize_packed_values_f32': (_i, [_p] * 8 + [_i] * 5 + [_p]),
     'swem_match_pad': (_i, [_i]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     'swem_match_packed_workspace': (_sz, [_i] * 6),
     'swem_match_packed_f32': (_i, [_p] * 7 + [_i] * 6 + [_f, _i, _p, _sz]),
     'swem_match_packed_f32_planes': (_i, [_p] * 7 + [_i] * 6 + [_f, _i, _p, _sz, _p, _i, _p, _i, _p]),
+    'swem_match_packed_clips_f32': (_i, [_p] * 7 + [_i] * 7 + [_f, _i, _p, _sz, _p, _i, _p, _i, _p]),
     # ---- include/swem_hip_train.h
     'swem_vos_loss_workspace': (_sz, [_i, _i, _ll]),
     'swem_vos_loss_frame_fwd_f32': (_i, [_p, _p, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _ll, _ll, _p, _p, _sz]),

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
                                                       int kn_rows, int kn_off, const float *__restrict__ masks,
                                                       const float *__restrict__ w_in, float *__restrict__ w_out,
                                                       float *__restrict__ z, int P, int Pz, float tau, int do_w,
-                                                      int do_e STAMP_ARG) {
+                                                      int do_e, int xg STAMP_ARG) {
   constexpr int C = 16 * CM, L = 64 * LT;
   STAMP(0);
   __shared__ float red[3][8][16];  // per-wave maxima / W exp-sums / E exp-sums per pixel
@@ -131,7 +131,9 @@ __global__ __launch_bounds__(512) void em_ew16_kernel(const float *__restrict__ 
   // issue order = arrival order (vmcnt counts in order): the pixel's key first, then the base rows chunk by chunk, so the
   // MFMAs of chunk m wait for chunk m only and the rest of the 256 KB streams in behind them
   // (buffer loads: pad pixels p >= P read as zeros by the range check -- no select in front of the MFMAs)
-  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, P * C * 4, 0x00020000);
+  // (xg objects share one key map: object n of a batch of clips reads clip n / xg's -- round 6, sequences in lock step)
+  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (long long)(n / xg) * P * C), 0, P * C * 4,
+                                                                  0x00020000);
   float4 xf[CM];
 #pragma unroll
   for (int m = 0; m < CM; ++m) {
@@ -284,6 +286,7 @@ struct MStepP {
   int kp_rows, kp_off, mvp_lm, mvp_off;
   int Ck, C, V, P, Pz, L, NK, nrt, total;  // nrt = 32-row tiles of the row space, total = NK * (L/16) * nrt blocks
   int rpg;                                 // row tiles per group of the tile order (a divisor of nrt)
+  int xg;                                  // objects per key map (x is [N / xg][P][C]: object n reads clip n / xg's keys)
 };
 
 // One launch = the whole M step (modules.py:122-127, 164-165), no partial sums in memory and no second kernel:
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(512, WPE) void em_mstep_kernel(MStepP p STAMP_ARG) 
   const int n = nk >> 1, cls = nk & 1;
   const int row0 = rt * 32;
   const bool key = row0 < p.Ck;
-  const float *src = key ? p.x : p.v + (long long)n * p.P * p.V;
+  const float *src = key ? p.x + (long long)(n / p.xg) * p.P * p.C : p.v + (long long)n * p.P * p.V;
   const int stride = key ? p.C : p.V;
   const int col = key ? row0 : row0 - p.Ck;
   __amdgpu_buffer_rsrc_t ra =
@@ -499,12 +502,13 @@ extern "C" int swem_em_pack_bases_f32(void *stream, const float *kappa, float *k
 
 namespace {
 int ew_launch(void *stream, const float *x, const float *kn, int kn_rows, int kn_off, const float *masks,
-              const float *w_in, float *w_out, float *z, int N, int C, int P, int L, float tau, int do_w, int do_e) {
+              const float *w_in, float *w_out, float *z, int N, int C, int P, int L, float tau, int do_w, int do_e,
+              int xg = 1 << 30) {
   const int Pz = swem_em_pad(P);
   dim3 grid(cdiv(P, 16), N);
 #define EW(LT_, CM_)                                                                                                  \
   hipLaunchKernelGGL((em_ew16_kernel<LT_, CM_>), grid, dim3(512), 0, ST, x, kn, kn_rows, kn_off, masks, w_in, w_out, z, \
-                     P, Pz, tau, do_w, do_e STAMP_PASS)
+                     P, Pz, tau, do_w, do_e, xg STAMP_PASS)
   if (C == 128) {
     if (L == 64) EW(1, 8);
     else if (L == 128) EW(2, 8);
@@ -537,9 +541,10 @@ namespace {
 int mstep_impl(void *stream, const float *x, const float *v, const float *z, const float *kappa_prev,
                const float *nu_prev, const float *zita_prev, float *kappa_out, float *nu_out, float *zita_out,
                float *kp_out, int kp_rows, int kp_off, float *mvp_out, int mvp_lm, int mvp_off, int NK, int Ck, int Vv,
-               int C, int V, int P, int L, unsigned short *mvq_out = nullptr, unsigned *fault = nullptr) {
+               int C, int V, int P, int L, unsigned short *mvq_out = nullptr, unsigned *fault = nullptr, int xg = 1 << 30) {
   MStepP mp;
   mp.fault = fault;
+  mp.xg = xg;
   mp.x = x, mp.v = v, mp.z = z;
   mp.kappa_prev = kappa_prev, mp.nu_prev = nu_prev, mp.zita_prev = zita_prev;
   mp.kappa_out = kappa_out, mp.nu_out = nu_out, mp.zita_out = zita_out;
@@ -613,13 +618,18 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
                   int C, int V, int P, int L, int T, float tau, void *ws, size_t ws_bytes, float *z_ext,
                   const float *kn_prior, int knp_rows, int knp_off, float *kn_out, int kno_rows, int kno_off,
                   float *mvp_out, int mvp_lm, int mvp_off, unsigned short *mvq_out = nullptr, bool keys_only = false,
-                  unsigned *fault = nullptr) {
+                  unsigned *fault = nullptr, int clips = 1) {
+  // clips > 1 (round 6): the N objects are those of `clips` clips, N / clips each, and x holds one key map per clip [clips][P][C];
+  // everything else is per object already.  The launches are the single-clip ones with `clips` times the objects: per object the
+  // same blocks on the same data.
   // keys_only: everything that does not read the value map -- all T (E, W, key M) steps; the last E step's z stays in z_ext
   // for the value update (swem_memorize_packed_values_f32), which is ONE more M-step launch over the value rows
   SWEM_REQUIRE(x && (v || keys_only) && masks && kappa_prev && (nu_prev || keys_only) && zita_prev && kappa_out &&
                    (nu_out || keys_only) && zita_out, SWEM_E_ARG, "memorize: null pointer");
   SWEM_REQUIRE(!keys_only || z_ext, SWEM_E_ARG, "memorize (keys): the responsibilities need a buffer of their own");
   SWEM_REQUIRE(T >= 1, SWEM_E_ARG, "memorize: T < 1");
+  SWEM_REQUIRE(clips >= 1 && N % clips == 0, SWEM_E_SHAPE, "memorize: %d objects do not divide into %d clips", N, clips);
+  const int xg = N / clips;
   SWEM_REQUIRE(kappa_out != kappa_prev && (keys_only || nu_out != nu_prev) && zita_out != zita_prev, SWEM_E_ARG,
                "memorize: outputs must not alias the prior bases (the prior is read by every iteration)");
   SWEM_REQUIRE(C == 64 || C == 128, SWEM_E_SHAPE, "memorize: the key dimension must be 64 or 128 (got %d)", C);
@@ -646,12 +656,12 @@ int memorize_impl(void *stream, const float *x, const float *v, const float *mas
   for (int it = 0; it < T; ++it) {
     const bool last = it == T - 1;
     // W step of iteration it-1 (modules.py:161-162) and E step of iteration it share one GEMM
-    if ((rc = ew_launch(stream, x, kcur, krows, koff, masks, masks, nullptr, z, N, C, P, L, tau, it > 0, 1))) return rc;
+    if ((rc = ew_launch(stream, x, kcur, krows, koff, masks, masks, nullptr, z, N, C, P, L, tau, it > 0, 1, xg))) return rc;
     // key bases every iteration; the value bases (modules.py:164-165) from the LAST z, in the same two launches
     const bool vals = last && !keys_only;
     if ((rc = mstep_impl(stream, x, vals ? v : nullptr, z, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out,
                          last ? kn_out : kn, last ? kno_rows : L, last ? kno_off : 0, vals ? mvp_out : nullptr, mvp_lm,
-                         mvp_off, NK, C, vals ? V : 0, C, V, P, L, vals ? mvq_out : nullptr, fault)))
+                         mvp_off, NK, C, vals ? V : 0, C, V, P, L, vals ? mvq_out : nullptr, fault, xg)))
       return rc;
     kcur = kn, krows = L, koff = 0;
   }
@@ -684,6 +694,21 @@ extern "C" int swem_memorize_packed_f32(void *stream, const float *x, const floa
   return memorize_impl(stream, x, v, masks, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out, N, C, V, P, L, T,
                        tau, ws, ws_bytes, nullptr, prior_packed ? mkn : nullptr, 2 * L, L, mkn, 2 * L, bank * L, mvp,
                        2 * L, bank * L, static_cast<unsigned short *>(mvq), false, static_cast<unsigned *>(fault));
+}
+
+// The same for the objects of SEVERAL clips in one call (round 6: sequences in lock step): N objects in total, N / clips per
+// clip, x = one key map per clip [clips][P][C]; v, masks, bases and the pack are per object as before (the clips' objects
+// back to back).  Per object the launches run the same blocks on the same data as `clips` single-clip calls: identical results.
+extern "C" int swem_memorize_packed_clips_f32(void *stream, const float *x, const float *v, const float *masks,
+                                              const float *kappa_prev, const float *nu_prev, const float *zita_prev,
+                                              float *kappa_out, float *nu_out, float *zita_out, float *mkn, float *mvp,
+                                              void *mvq, int prior_packed, int bank, int N, int clips, int C, int V, int P, int L,
+                                              int T, float tau, void *ws, size_t ws_bytes, void *fault) {
+  SWEM_REQUIRE(mkn && mvp, SWEM_E_ARG, "memorize_packed_clips: null pack");
+  SWEM_REQUIRE(bank == 0 || bank == 1, SWEM_E_ARG, "memorize_packed_clips: bank must be 0 or 1");
+  return memorize_impl(stream, x, v, masks, kappa_prev, nu_prev, zita_prev, kappa_out, nu_out, zita_out, N, C, V, P, L, T,
+                       tau, ws, ws_bytes, nullptr, prior_packed ? mkn : nullptr, 2 * L, L, mkn, 2 * L, bank * L, mvp,
+                       2 * L, bank * L, static_cast<unsigned short *>(mvq), false, static_cast<unsigned *>(fault), clips);
 }
 
 // The packed memorize in two calls, so that a caller can run the part that does not need the value map -- every E, W and key

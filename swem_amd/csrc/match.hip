@@ -177,7 +177,7 @@ template <int TW, int CM>  // TW 16-base tiles per wave (Ltot = 128 * TW), C = 1
 __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__restrict__ qk, const float *__restrict__ mkn,
                                                                float *__restrict__ pT, unsigned short *__restrict__ pq,
                                                                float *__restrict__ S, unsigned short *__restrict__ sq, int sq_npl,
-                                                               int topl, int P, int Pm, float tau) {
+                                                               int topl, int P, int Pm, float tau, int xg) {
   constexpr int C = 16 * CM, Ltot = 128 * TW, Lm = Ltot / 2;
   constexpr int TP = TW > 4 ? 4 : TW, NPASS = TW / TP;   // tiles per pass: at most 4 (32 x 16 bytes of base rows in flight)
   __shared__ float red[2][8][16];
@@ -185,7 +185,9 @@ __global__ __launch_bounds__(512) void match_affinity16_kernel(const float *__re
   const int li = lane & 15, g = lane >> 4;
   const int n = blockIdx.y, p = blockIdx.x * 16 + li;
   const int cls = wave >> 2, wq = wave & 3;
-  __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(qk), 0, P * C * 4, 0x00020000);
+  // (xg objects share one query key map: object n of a batch of clips reads clip n / xg's -- round 6)
+  __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(qk + (long long)(n / xg) * P * C), 0, P * C * 4,
+                                                                  0x00020000);
   float4 xf[CM];
 #pragma unroll
   for (int m = 0; m < CM; ++m) {
@@ -402,12 +404,12 @@ __global__ __launch_bounds__(256) void match_topl_kernel(const float *__restrict
 // (there are only Pm/32 x N blocks, so a block's latency is the kernel's time)
 // S != NULL: the top-l features come out of the same launch (pT may then be NULL: nothing else reads the probabilities)
 static int launch_affinity(hipStream_t st, const float *qk, const float *mkn, float *pT, unsigned short *pq, float *S,
-                           unsigned short *sq, int sq_npl, int topl, int N, int C, int P, int Pm, int Lm, float tau) {
+                           unsigned short *sq, int sq_npl, int topl, int N, int C, int P, int Pm, int Lm, float tau, int xg = 1 << 30) {
   if (C == 128 || C == 64) {
     // the grid covers all Pm rows of pT: the readout GEMM's last row tile reads rows [P, Pm), which pad tiles write as zeros
     dim3 grid16(Pm / 16, N);
 #define AFF16(TW_, CM_)                                                                                              \
-  hipLaunchKernelGGL((match_affinity16_kernel<TW_, CM_>), grid16, dim3(512), 0, st, qk, mkn, pT, pq, S, sq, sq_npl, topl, P, Pm, tau)
+  hipLaunchKernelGGL((match_affinity16_kernel<TW_, CM_>), grid16, dim3(512), 0, st, qk, mkn, pT, pq, S, sq, sq_npl, topl, P, Pm, tau, xg)
     if (C == 128) {
       if (Lm == 64) AFF16(1, 8);
       else if (Lm == 128) AFF16(2, 8);
@@ -622,7 +624,7 @@ namespace {
 int match_core(void *stream, const float *qk, const float *mkn, const float *mvp, const unsigned short *mvq, float *pT,
                unsigned short *pq, float *mem_out, float *S, int N, int C, int V, int P, int Lm, int topl, float tau,
                int readout_plan, void *conv_ws, size_t conv_bytes, void *mem_planes = nullptr, int mem_npl = 3,
-               void *s_planes = nullptr, int s_npl = 3, void *fault = nullptr) {
+               void *s_planes = nullptr, int s_npl = 3, void *fault = nullptr, int xg = 1 << 30) {
   const int Pm = swem_match_pad(P), Ltot = 2 * Lm;
   int rc;
   dim3 gridt(cdiv((long long)N * P, 4));
@@ -633,10 +635,10 @@ int match_core(void *stream, const float *qk, const float *mkn, const float *mvp
                "match: output planes come with the pre-split readout only (value planes + readout plan math 3)");
   if (presplit) {
     // one launch: affinity + softmax, the probabilities as bf16 planes for the readout, and the top-l features
-    if ((rc = launch_affinity(ST, qk, mkn, nullptr, pq, S, static_cast<unsigned short *>(s_planes), s_npl, topl, N, C, P, Pm, Lm, tau))) return rc;
+    if ((rc = launch_affinity(ST, qk, mkn, nullptr, pq, S, static_cast<unsigned short *>(s_planes), s_npl, topl, N, C, P, Pm, Lm, tau, xg))) return rc;
     SWEM_CHECK_LAUNCH("match_affinity (fused top-l)");
   } else {
-    if ((rc = launch_affinity(ST, qk, mkn, pT, nullptr, nullptr, nullptr, 3, 0, N, C, P, Pm, Lm, tau))) return rc;
+    if ((rc = launch_affinity(ST, qk, mkn, pT, nullptr, nullptr, nullptr, 3, 0, N, C, P, Pm, Lm, tau, xg))) return rc;
 #define TOPL(J_) hipLaunchKernelGGL((match_topl_kernel<J_>), gridt, dim3(256), 0, ST, pT, S, N, P, Pm, topl)
     if (Lm == 64) TOPL(1);
     else if (Lm == 128) TOPL(2);
@@ -729,8 +731,9 @@ extern "C" size_t swem_match_packed_workspace(int N, int C, int V, int P, int L,
 namespace {
 int match_packed_impl(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq, float *mem_out, float *S,
                       int N, int C, int V, int P, int L, int topl, float tau, int readout_plan, void *ws, size_t ws_bytes,
-                      void *mem_planes, int mem_npl, void *s_planes, int s_npl, void *fault) {
+                      void *mem_planes, int mem_npl, void *s_planes, int s_npl, void *fault, int clips = 1) {
   SWEM_REQUIRE(qk && mkn && mvp && mem_out && S, SWEM_E_ARG, "match_packed: null pointer");
+  SWEM_REQUIRE(clips >= 1 && N % clips == 0, SWEM_E_SHAPE, "match_packed: %d objects do not divide into %d clips", N, clips);
   int rc;
   if ((rc = match_check(C, V, L, 2 * L, topl, tau))) return rc;
   SWEM_REQUIRE((!mem_planes || ((mem_npl == 2 || mem_npl == 3 || mem_npl == SWEM_PLANES_F16) && V % 8 == 0)) &&
@@ -742,9 +745,20 @@ int match_packed_impl(void *stream, const float *qk, const float *mkn, const flo
   char *base = static_cast<char *>(ws) - w.pT;     // the workspace starts at the probability slot
   return match_core(stream, qk, mkn, mvp, static_cast<const unsigned short *>(mvq), (float *)(base + w.pT),
                     (unsigned short *)(base + w.pq), mem_out, S, N, C, V, P, 2 * L, topl, tau, readout_plan, base + w.conv,
-                    w.total - w.conv, mem_planes, mem_npl, s_planes, s_npl, fault);
+                    w.total - w.conv, mem_planes, mem_npl, s_planes, s_npl, fault, N / clips);
 }
 }  // namespace
+
+// The same for the objects of SEVERAL clips in one call (round 6: sequences in lock step): N objects in total, N / clips per
+// clip, qk = one query key map per clip [clips][P][C]; the packs and the outputs are per object as before.  Plane pointers may
+// be NULL (then as swem_match_packed_f32).  Per object the same blocks on the same data as `clips` single-clip calls.
+extern "C" int swem_match_packed_clips_f32(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq,
+                                           float *mem_out, float *S, int N, int clips, int C, int V, int P, int L, int topl, float tau,
+                                           int readout_plan, void *ws, size_t ws_bytes, void *mem_planes, int mem_nplanes,
+                                           void *s_planes, int s_nplanes, void *fault) {
+  return match_packed_impl(stream, qk, mkn, mvp, mvq, mem_out, S, N, C, V, P, L, topl, tau, readout_plan, ws, ws_bytes, mem_planes,
+                           mem_planes ? mem_nplanes : 3, s_planes, s_planes ? s_nplanes : 3, fault, clips);
+}
 
 extern "C" int swem_match_packed_f32(void *stream, const float *qk, const float *mkn, const float *mvp, const void *mvq,
                                      float *mem_out, float *S, int N, int C, int V, int P, int L, int topl, float tau,

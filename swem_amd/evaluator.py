@@ -626,6 +626,49 @@ def lockstep_chain(models, keys, keys_each, frames, out_size, forks, outs=None, 
     return pred
 
 
+def lockstep_chain_batched(lane, keys, frames, out_size, nxt):
+    """lockstep_chain with EM and matching batched over the lane's sequences as well (LockstepGraph(batched_em=True)): the lane keeps
+    the sequences' banks as slices of ONE tensor per bank and their packs as slices of ONE pack, so that affinity / top-l / readout
+    and the whole memorize run as single launches over the S * N objects with one key map per sequence
+    (swem_match_packed_clips_f32, swem_memorize_packed_clips_f32: per object the same blocks on the same data), and the fusion conv
+    takes the matching kernels' own output planes for all objects.  `nxt`: the per-sequence dicts of the state set the new bases go
+    to (views of the lane-wide tensors `lane.sets_all[...]`).  Steady state only (both banks, the packs current)."""
+    models, S = lane.models, lane.S
+    m0 = models[0]
+    cores = [m.swem_core for m in models]
+    core0 = cores[0]
+    h, w = frames.shape[-2:]
+    qk16, qv16, s16, s8, s4 = keys
+    Ck, h16, w16 = qk16.shape[1:]
+    P, L = h16 * w16, core0.n_bases
+    cur_all = lane.sets_all[lane.cur]
+    nxt_all = lane.sets_all[1 - lane.cur]
+    N = cur_all['kappa'].shape[1]
+    with ops.use_book(m0.book):
+        for c in cores:     # (under the lane's book: whether the packs carry the fp16 value planes depends on the book's readout)
+            if not (c._stamped(0, c.memories['first'].bases) and c._stamped(1, c.memories['update'].bases)):
+                c.repack()
+        xq = to_pixel_major_(qk16).view(S, P, Ck)
+        mem_img, s_img = ops.match_packed(xq, lane.pack_all, L, core0.topl, core0.tau, hw=(h16, w16), clips=S)
+        context = m0.engine().fuse_context(mem_img, to_pixel_major_(qv16), s_img)          # (S*N,h,w,V)
+    _, pred_mask = m0('segment', N, as_nchw_(context), s8, s4, None, out_size)
+    pred, hard = ops.argmax_onehot(pred_mask, want_onehot=True)
+    pm = ops.resize_planes(pred_mask, (h, w), 'bilinear')
+    mv16 = m0('encode_value', frames, pm, s16)                      # (S,N,V,h16,w16)
+    with ops.use_book(m0.book):
+        masks = ops.mask_prep(hard.contiguous(), pm.float().contiguous(), h16, w16)          # (S*N,2,P)
+        vp = to_pixel_major_(mv16.flatten(0, 1)).view(S * N, P, -1)
+        ops.memorize(xq, vp, masks, cur_all['kappa'].view(S * N, 2, Ck, L), cur_all['nu'].view(S * N, 2, -1, L),
+                     cur_all['zita'].view(S * N, 2, L), core0.n_iters, core0.tau, pack=lane.pack_all, prior_packed=True, bank=1,
+                     out=(nxt_all['kappa'].view(S * N, 2, Ck, L), nxt_all['nu'].view(S * N, 2, -1, L),
+                          nxt_all['zita'].view(S * N, 2, L)), clips=S)
+    for c, st in zip(cores, nxt):
+        c.memories['update'].bases = st       # (the lane-wide tensors memorize wrote, under the sequence's own views)
+        c.restamp()
+    lane.cur = 1 - lane.cur
+    return pred
+
+
 def to_pixel_major_(t):
     from .modules import to_pixel_major
     return to_pixel_major(t)
@@ -644,10 +687,12 @@ class LockstepGraph:
     streams inside the graph; batched over the S * N objects: decoder and value encoder.  `models` are replicas (same
     weights, one PlanBook), each holding one sequence's memory (both banks initialised, the same number of objects)."""
 
-    def __init__(self, models, frame_shape, out_size, k, streams=None, side_stream=None, overlap=True, forks=None, fuse_batched=False):
+    def __init__(self, models, frame_shape, out_size, k, streams=None, side_stream=None, overlap=True, forks=None, fuse_batched=False,
+                 batched_em=False):
         self.models, self.k, self.out_size = list(models), int(k), (int(out_size[0]), int(out_size[1]))
         self.S = len(self.models)
         self.fuse_batched = fuse_batched
+        self.batched_em = batched_em
         self.streams, self.side, self.overlap, self.forks = streams, side_stream, overlap, forks
         cores = [m.swem_core for m in self.models]
         for c in cores:
@@ -666,6 +711,8 @@ class LockstepGraph:
         for c, st in zip(cores, self.state):
             c.memories['update'].bases = st
         self.first = [c.memories['first'].bases for c in cores]
+        if batched_em:
+            self._share_state(cores, dev)
         self.kg = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
         self.cg = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
         self.keys = [None, None]
@@ -674,6 +721,26 @@ class LockstepGraph:
         self.p = 0
         self.primed = False
 
+    def _share_state(self, cores, dev):
+        """batched_em: the sequences' banks as slices of ONE tensor per bank (the reference's own layout with B = S:
+        kappa (S,N,2,C,L), modules.py:129-168) and their packs as slices of one pack -- every sequence's core keeps working on
+        its own views (eager frames, re-binding), the lane's batched launches on the whole."""
+        S = self.S
+        stack = lambda dicts: {key: torch.cat([d[key] for d in dicts]).contiguous() for key in dicts[0]}
+        first_all, state_all = stack(self.first), stack(self.state)
+        state2_all = {key: torch.empty_like(v) for key, v in state_all.items()}
+        views = lambda whole: [{key: v[s_:s_ + 1] for key, v in whole.items()} for s_ in range(S)]
+        self.first, self.state, self.state2 = views(first_all), views(state_all), views(state2_all)
+        self.sets_all, self.cur = (state_all, state2_all), 0
+        N, _, Ck, L = first_all['kappa'].shape[1:]
+        self.pack_all = ops.new_pack(S * N, Ck, cores[0].valdim, L, dev)
+        for s_, c in enumerate(cores):
+            c.memories['first'].bases = self.first[s_]
+            c.memories['update'].bases = self.state[s_]
+            c._pack = (self.pack_all[0][2 * N * s_:2 * N * (s_ + 1)], self.pack_all[1][N * s_:N * (s_ + 1)],
+                       self.pack_all[2][N * s_:N * (s_ + 1)])
+            c._stamp = [None, None]
+
     def _encode(self, p):
         return self.models[0]('encode_key', self.frames[p].view((self.k * self.S,) + self.frame_shape[1:]))
 
@@ -681,7 +748,12 @@ class LockstepGraph:
         cores = [m.swem_core for m in self.models]
         preds = []
         sets = (self.state, self.state2)
-        for j in range(self.k):
+        if self.batched_em:
+            self.cur = 0            # (a group starts from the first state set: `state`)
+            for j in range(self.k):
+                preds.append(lockstep_chain_batched(self, key_items(self.keys[p], j * self.S, self.S), self.frames[p][j],
+                                                    self.out_size, sets[(j + 1) % 2]))
+        for j in range(self.k if not self.batched_em else 0):
             nxt = sets[(j + 1) % 2]
             each = [key_item(self.keys[p], j * self.S + s) for s in range(self.S)]
             preds.append(lockstep_chain(self.models, key_items(self.keys[p], j * self.S, self.S), each, self.frames[p][j],
@@ -727,7 +799,8 @@ class LockstepGraph:
             torch.cuda.current_stream().wait_stream(warm)
             for p in (0, 1):
                 restore()
-                self.packs = [c.repack() for c in cores]
+                with ops.use_book(self.models[0].book):      # (the packs with the value planes THIS book's readout reads)
+                    self.packs = [c.repack() for c in cores]
                 cap.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.graph(self.kg[p], stream=cap, **ops.graph_capture_kwargs()):
                     self.keys[p] = self._encode(p)
@@ -749,7 +822,8 @@ class LockstepGraph:
                 return False
         for c, first, state in zip(cores, self.first, self.state):
             cur_first, cur_upd = c.memories['first'].bases, c.memories['update'].bases
-            c.repack()
+            with ops.use_book(self.models[0].book):
+                c.repack()
             for key in first:
                 if cur_first[key] is not first[key]:
                     first[key].copy_(cur_first[key])
@@ -1025,7 +1099,11 @@ class LockstepPool:
     models.  `models` are replicas (same weights); they share models[0]'s PlanBook.  Measured on config B (two lanes of four
     sequences against four independent pipelines): bench.py, DESIGN.md section 5."""
 
-    def __init__(self, models, lockstep=4, use_graph=True, lookahead=10, plans='shipped'):
+    def __init__(self, models, lockstep=4, use_graph=True, lookahead=10, plans='shipped', batched_em=True):
+        # batched_em (default): a lane runs EM and matching -- and with them the fusion conv -- once for the objects of all its
+        # sequences (LockstepGraph(batched_em=True)); False: per sequence (bit-identical to the per-sequence loops under
+        # batch-invariant plans; the batched fusion conv picks its tile by ITS row count)
+        self.batched_em = bool(batched_em)
         self.models, self.S = list(models), int(lockstep)
         if self.S < 2 or len(self.models) % self.S:
             raise ValueError('LockstepPool: %d models do not make lanes of %d sequences' % (len(self.models), self.S))
@@ -1048,7 +1126,8 @@ class LockstepPool:
         if len({tuple(m.swem_core.memories['first'].bases['kappa'].shape) for m in models}) != 1:
             return None                       # (sequences with different numbers of objects: the lane runs them frame by frame)
         self.graphs[li] = None
-        g = LockstepGraph(models, shape, out_size, k, streams=self.graph_streams[li], overlap=False, forks='none')
+        g = LockstepGraph(models, shape, out_size, k, streams=self.graph_streams[li], overlap=False, forks='none',
+                          batched_em=self.batched_em)
         g.capture(torch.stack([f[0, i:i + k] for f in frames_list], dim=1))
         self.graphs[li], self.graph_streams[li] = g, g.streams
         return g

@@ -1615,13 +1615,19 @@ def em_mstep(A, per_object, z, prev, zita_prev, P, want_kn=False):
     return out, zita, kn
 
 
-def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau, pack=None, prior_packed=False, bank=1, out=None):
+def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau, pack=None, prior_packed=False, bank=1, out=None, clips=1):
     """x (P,C); v (N,P,V); masks (N,2,P); bases (N,2,C,L)/(N,2,V,L)/(N,2,L) -> new bases.
     pack = (mkn, mvp): matching's packed banks, kept current by this call (swem_memorize_packed_f32).
     out = (kappa, nu, zita): write the new bases there (tensors of the priors' shapes that are NOT the priors: the prior is
-    read by every M step); default: fresh tensors."""
+    read by every M step); default: fresh tensors.
+    clips > 1 (packed form only): the N objects are those of `clips` clips, N / clips each, with one key map per clip -- x
+    (clips,P,C); per object the same launches as `clips` single-clip calls (swem_memorize_packed_clips_f32)."""
     for t in (x, v, masks, kappa_prev, nu_prev, zita_prev):
         _chk(t)
+    if clips > 1:
+        if pack is None or x.dim() != 3 or x.shape[0] != clips or v.shape[0] % clips:
+            raise _lib.SwemHipError('memorize: clips = %d needs a pack, x (clips,P,C) and a multiple of clips objects' % clips)
+        x = x.view(-1, x.shape[-1])[:x.shape[1]]          # (shape bookkeeping below: P, C of ONE clip; the pointer is the batch's)
     P, Cc = x.shape
     N, _, V = v.shape
     L = kappa_prev.shape[-1]
@@ -1635,6 +1641,13 @@ def memorize(x, v, masks, kappa_prev, nu_prev, zita_prev, T, tau, pack=None, pri
         kappa, nu, zita = torch.empty_like(kappa_prev), torch.empty_like(nu_prev), torch.empty_like(zita_prev)
     wsb = _lib.query('swem_memorize_workspace', N, Cc, V, P, L)
     ws = workspace(wsb, x.device)
+    if pack is not None and clips > 1:
+        _lib.call('swem_memorize_packed_clips_f32', _stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(),
+                  kappa_prev.data_ptr(), nu_prev.data_ptr(), zita_prev.data_ptr(), kappa.data_ptr(), nu.data_ptr(),
+                  zita.data_ptr(), _chk(pack[0]).data_ptr(), _chk(pack[1]).data_ptr(), _pack_planes(pack),
+                  int(prior_packed), int(bank), N, int(clips), Cc, V, P, L, int(T), float(tau), ws.data_ptr(), wsb,
+                  _fault_ptr(x.device))
+        return kappa, nu, zita
     if pack is not None:
         _lib.call('swem_memorize_packed_f32', _stream(), x.data_ptr(), v.data_ptr(), masks.data_ptr(),
                   kappa_prev.data_ptr(), nu_prev.data_ptr(), zita_prev.data_ptr(), kappa.data_ptr(), nu.data_ptr(),
@@ -1774,14 +1787,19 @@ def pack_bank(kappa, nu, pack, bank):
               pack[1].data_ptr(), _pack_planes(pack), int(bank), 2, N, Cc, nu.shape[2], L, _fault_ptr(kappa.device))
 
 
-def match_packed(qk, pack, L, topl, tau, hw=None):
+def match_packed(qk, pack, L, topl, tau, hw=None, clips=1):
     """qk (P,C); pack = (mkn (2N,C/4+1,2L,4), mvp (N,V,4L), mvq bf16 planes or None) -> mem_out (N,P,V) view, S (N,P,2*topl).
     hw = (H, W), H*W = P: the outputs come as the NHWC images (N,H,W,V) / (N,H,W,2*topl) the fusion conv consumes, and --
     once that conv has asked for their bf16 planes on an earlier frame (BOOK.hints) -- with the planes written by the
     matching kernels themselves (pre-split readout only)."""
     _chk(qk)
     mkn, mvp = _chk(pack[0]), _chk(pack[1])
-    P, Cc = qk.shape
+    if clips > 1:        # the objects of `clips` clips, one query key map per clip: qk (clips,P,C) (swem_match_packed_clips_f32)
+        if qk.dim() != 3 or qk.shape[0] != clips or mvp.shape[0] % clips:
+            raise _lib.SwemHipError('match_packed: clips = %d needs qk (clips,P,C) and a multiple of clips objects' % clips)
+        P, Cc = qk.shape[1:]
+    else:
+        P, Cc = qk.shape
     N, V = mvp.shape[0], mvp.shape[1]
     Pm = _lib.query('swem_match_pad', P)
     mem_out = torch.empty((N, Pm, V), dtype=torch.float32, device=qk.device)
@@ -1797,16 +1815,22 @@ def match_packed(qk, pack, L, topl, tau, hw=None):
                 int(topl), float(tau), plan, ws.data_ptr(), wsb)
         want_m = BOOK.hints.get(site_m, {}).get(False) if (FUSE_SPLIT and hw and V % 8 == 0) else None
         want_s = BOOK.hints.get(site_s, {}).get(False) if (FUSE_SPLIT and hw and topl % 4 == 0) else None
+        if clips > 1:
+            args = args[:8] + (int(clips),) + args[8:]
         if (want_m or want_s) and mvq and (plan >> 16) & 3 == 3:
             pargs = []
             for key, want, numel in (('m', want_m, mem_out.numel()), ('s', want_s, S.numel())):
                 if want and key not in planes:
                     planes[key] = (_new_planes(want, numel, qk.device), want)
                 pargs += [planes[key][0].data_ptr(), planes[key][1]] if want else [0, 3]
-            _lib.call('swem_match_packed_f32_planes', *args, *pargs, _fault_ptr(qk.device))
+            _lib.call('swem_match_packed_clips_f32' if clips > 1 else 'swem_match_packed_f32_planes', *args, *pargs,
+                      _fault_ptr(qk.device))
         else:
             planes.clear()
-            _lib.call('swem_match_packed_f32', *args)
+            if clips > 1:
+                _lib.call('swem_match_packed_clips_f32', *args, 0, 3, 0, 3, 0)
+            else:
+                _lib.call('swem_match_packed_f32', *args)
 
     launch(_match_plan((N, Cc, V, P, L, 2), launch, N * Pm, V, 4 * L // 32))
     if hw is None:

@@ -227,6 +227,72 @@ def test_config_b_size_properties(lib):
 
 
 @pytest.mark.parametrize('L', [64, 256])
+def test_clips_forms_equal_the_single_clip_calls(lib, L):
+    """swem_memorize_packed_clips_f32 / swem_match_packed_clips_f32 (round 6: the objects of several clips in ONE call, a key map per
+    clip -- modules.py:129-168 / 232-293 with B = clips; what a lock-step lane runs for its sequences): new bases, the pack they
+    keep current (keys, values, fp16 value planes) and matching's outputs are BIT-IDENTICAL to one packed call per clip, over two
+    frames with the second reading its prior's normalised keys from the pack; both readouts (fp32 and pre-split f16x3)."""
+    g = torch.Generator().manual_seed(500 + L)
+    h, w, C, V, N, T, S = 12, 20, 128, 128, 2, 3, 3
+    P = h * w
+    pm = lambda x: d(x[0].flatten(1).t())                                   # (P, C)
+    pv = lambda v: d(v[0].flatten(2).transpose(1, 2))                        # (N, P, V)
+    pk = lambda m: d(m[0].flatten(2))                                        # (N, 2, P)
+    frames = [[H.em_inputs(h, w, C, V, N, g) for _ in range(S)] for _ in range(2)]
+    torch.manual_seed(L)
+    prior = []
+    for _ in range(S):
+        kap, nu, zita = [d(t[0]) for t in O.random_init((1, N, 2, C, L), V)]
+        prior.append((kap, nu, zita[:, :, 0].contiguous()))
+    book = ops.PlanBook(fallback=ops.MODEL_FALLBACK)
+    qx = [d(H.structured_keys(P, C, 6, g)[0]) for _ in range(S)]
+    with ops.use_book(book):
+        # one call per clip
+        packs = [ops.new_pack(N, C, V, L, DEV) for _ in range(S)]
+        ref = []
+        for s_ in range(S):
+            x0, v0, m0 = frames[0][s_]
+            x1, v1, m1 = frames[1][s_]
+            b0 = ops.memorize(pm(x0), pv(v0), pk(m0), *prior[s_], T, 0.05, pack=packs[s_], prior_packed=False, bank=0)
+            ops.pack_bank(b0[0], b0[1], packs[s_], 1)
+            b1 = ops.memorize(pm(x1), pv(v1), pk(m1), *b0, T, 0.05, pack=packs[s_], prior_packed=True, bank=1)
+            ref.append((b0, b1))
+        # all clips in one call: the objects back to back, the packs as ONE pack
+        cat = lambda ts: torch.cat(list(ts)).contiguous()
+        pack_all = ops.new_pack(S * N, C, V, L, DEV)
+        xs = [torch.stack([pm(frames[f][s_][0]) for s_ in range(S)]).contiguous() for f in (0, 1)]
+        vs = [cat(pv(frames[f][s_][1]) for s_ in range(S)) for f in (0, 1)]
+        ms = [cat(pk(frames[f][s_][2]) for s_ in range(S)) for f in (0, 1)]
+        pr = [cat(prior[s_][i] for s_ in range(S)) for i in range(3)]
+        a0 = ops.memorize(xs[0], vs[0], ms[0], *pr, T, 0.05, pack=pack_all, prior_packed=False, bank=0, clips=S)
+        ops.pack_bank(a0[0], a0[1], pack_all, 1)
+        a1 = ops.memorize(xs[1], vs[1], ms[1], *a0, T, 0.05, pack=pack_all, prior_packed=True, bank=1, clips=S)
+        for s_ in range(S):
+            for i in range(3):
+                assert torch.equal(a0[i][s_ * N:(s_ + 1) * N], ref[s_][0][i]), (s_, i)
+                assert torch.equal(a1[i][s_ * N:(s_ + 1) * N], ref[s_][1][i]), (s_, i)
+            assert torch.equal(pack_all[0][2 * N * s_:2 * N * (s_ + 1)], packs[s_][0])
+            assert torch.equal(pack_all[1][N * s_:N * (s_ + 1)], packs[s_][1])
+            assert torch.equal(pack_all[2][N * s_:N * (s_ + 1)].view(torch.int16), packs[s_][2].view(torch.int16))
+        assert pack_all[2].any()
+        qall = torch.stack(qx).contiguous()
+        for plan in (0, 2 | 2 << 4 | 1 << 8 | 3 << 16):
+            try:
+                if plan:
+                    ops._MATCH_PLANS[(N, C, V, P, L, 2)] = plan
+                    ops._MATCH_PLANS[(S * N, C, V, P, L, 2)] = plan
+                mem_a, S_a = ops.match_packed(qall, pack_all, L, 64, 0.05, hw=(h, w), clips=S)
+                for s_ in range(S):
+                    mem_r, S_r = ops.match_packed(qx[s_], packs[s_], L, 64, 0.05, hw=(h, w))
+                    assert torch.equal(mem_a[s_ * N:(s_ + 1) * N], mem_r) and torch.equal(S_a[s_ * N:(s_ + 1) * N], S_r), (plan, s_)
+            finally:
+                ops._MATCH_PLANS.pop((N, C, V, P, L, 2), None)
+                ops._MATCH_PLANS.pop((S * N, C, V, P, L, 2), None)
+    with pytest.raises(Exception):
+        ops.memorize(xs[0][:2], vs[0], ms[0], *pr, T, 0.05, pack=pack_all, clips=S)
+
+
+@pytest.mark.parametrize('L', [64, 256])
 def test_packed_banks_equal_the_per_frame_packing(lib, L):
     """swem_memorize_packed_f32 / swem_match_packed_f32 (the persistent packed banks SWEMCore keeps: no per-frame `cat` +
     2 x `l2norm` of both banks, modules.py:282-283, 295-306) give BIT-IDENTICAL results to swem_memorize_f32 /

@@ -32,6 +32,9 @@ def main():
     ap.add_argument('--no-forks', action='store_true', help='the per-sequence parts of a lock-step frame one after the other (a linear graph)')
     ap.add_argument('--no-overlap', action='store_true', help="a lane's key-encoder graph behind its chain graph on ONE stream instead of beside it")
     ap.add_argument('--stagger-ms', type=float, default=0.0, help='hold lane i back by i x this many ms once, before the timed replays (phase of the lanes against each other)')
+    ap.add_argument('--drop-per-sequence', action='store_true',
+                    help='TIMING BOUND ONLY (wrong results): the lanes without their per-sequence parts -- match returns a cached context, '
+                         'memorize does nothing -- i.e. what batching EM and matching over a lane could gain at the very most')
     ap.add_argument('--decompose', action='store_true', help='also: the chain graph and the key-encoder graph of each form replayed ALONE on the idle chip')
     ap.add_argument('--save-plans', default=None)
     ap.add_argument('--load-plans', default=None)
@@ -134,6 +137,21 @@ def main():
             groups = [groups_of(rn) for rn in rs]
             ng = len(groups[0])
             both = [torch.stack([groups[s][g] for s in range(S)], dim=1).contiguous() for g in range(ng)]       # (k,S,3,H,W)
+            if a.drop_per_sequence:
+                for rn in rs:
+                    m = rn.model
+                    real = m._dispatch
+                    cache = {}
+
+                    def fake(mode, *args, _real=real, _cache=cache, **kw):
+                        if mode == 'match':
+                            if 'ctx' not in _cache:
+                                _cache['ctx'] = _real(mode, *args, **kw)
+                            return _cache['ctx']
+                        if mode == 'memorize':
+                            return None
+                        return _real(mode, *args, **kw)
+                    m._dispatch = fake
             ops.AUTOTUNE = ln == 0
             look = evaluator.LockstepGraph([rn.model for rn in rs], rs[0].frames[:, 1].shape, bench.OUT_HW, k,
                                            side_stream=tuple(sides[2 * ln:2 * ln + 2]), forks='none' if a.no_forks else sides[:S], overlap=not a.no_overlap).capture(both[0])
