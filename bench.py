@@ -608,7 +608,7 @@ def main():
         real_mp = ops.match_packed
 
         def marked(qk_, pack_, L_, topl_, tau_, **kw_):
-            ops.CONV_TRACE.append((None, None, 2.0 * pack_[1].shape[0] * qk_.shape[0] * pack_[1].shape[1] * pack_[1].shape[2],
+            ops.CONV_TRACE.append((None, None, 2.0 * pack_[1].shape[0] * qk_.shape[-2] * pack_[1].shape[1] * pack_[1].shape[2],      # (N objects x P pixels x V x 4L)
                                    'matching readout GEMM', 0.0, 0, 'readout'))
             return real_mp(qk_, pack_, L_, topl_, tau_, **kw_)
         ops.match_packed = marked
