@@ -859,6 +859,17 @@ def test_range_fault_falls_back_to_the_full_range_arithmetic(lib):
     m3.swem_core.init_on_host = True
     agree = min(float((a == b).float().mean()) for a, b in zip(got[0], rpreds))
     assert agree >= 0.995, agree                             # (graph replay batches the key encoder: not bit for bit)
+    # ... and the lock-step pool (round 6): two sequences in one lane fault inside the captured lock-step graph, the pool moves its
+    # shared book to the full-range arithmetic, drops the graphs and runs the call's sequences again
+    m4 = [make(ops.MODEL_FALLBACK) for _ in range(2)]
+    lpool = evaluator.LockstepPool(m4, lockstep=2, use_graph=True, lookahead=1, plans=None)
+    with pytest.warns(RuntimeWarning, match='full-range arithmetic'):
+        lgot = lpool.run([(frames, m0, (128, 192))] * 2, seeds=[3, 3])
+    assert m4[0].book.full_range and m4[1].book is m4[0].book and isinstance(lpool.graphs[0], evaluator.LockstepGraph)
+    for seq in lgot:
+        assert len(seq) == len(rpreds)
+        agree = min(float((a == b).float().mean()) for a, b in zip(seq, rpreds))
+        assert agree >= 0.995, agree
 
 
 def test_range_fault_fallback_against_the_oracle(lib):
