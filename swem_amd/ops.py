@@ -348,6 +348,11 @@ def graph_capture_kwargs():
     return {'capture_error_mode': 'thread_local'} if (dist.is_available() and dist.is_initialized()) else {}
 
 
+# engine.py, _SharedSourceSplit: the clip's key feature split off the value encoder's fusion block (computed once per clip, not per
+# object).  SWEM_SPLIT_SHARED=0 / False: the one-launch form of rounds 1-5.
+SPLIT_SHARED_SOURCE = os.environ.get('SWEM_SPLIT_SHARED', '1') != '0'
+
+
 def new_stream():
     """A HIP stream of its own.  torch.cuda.Stream() hands out 32 pooled streams round robin, so the 33rd request is the
     first stream again; scratch buffers are keyed by stream (workspace()) and captured graphs own theirs, so an aliased

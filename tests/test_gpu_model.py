@@ -675,6 +675,50 @@ def test_sequence_pool_equals_sequential_evaluation(lib, lanes, lookahead):
     assert all(m.book is models[0].book for m in models)
 
 
+@pytest.mark.parametrize('backbone', ['resnet18', 'resnet50'])
+def test_shared_source_split_of_the_fusion_block(lib, backbone):
+    """engine._SharedSourceSplit (round 6): the value encoder's ResBlock(cat[x, f16]) (networks.py:35-50, 113-129) with the clip's key
+    feature split off its two 1280-channel convolutions -- conv_s(f16) once per CLIP, conv_x(x_n) per object with conv_s's result as
+    the residual addend -- against the one-launch form on the same inputs: the same function up to fp32 summation order, for one
+    clip (the addend broadcast over the objects) and for two clips in one batch (repeated per object), two and three objects, in the
+    fp32 and the f16x3 arithmetic; one object keeps the one-launch form."""
+    from swem_amd import synth
+    cfg = O.make_cfg(BACKBONE=backbone, NUM_BASES=64)
+    model, _ = H.make_model_and_sd(cfg, wseed=6, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    for math in (0, 7):
+        model.book.fallback = 0x111 | math << 16
+        for B, N in ((1, 2), (2, 2), (1, 3), (1, 1)):
+            frames = torch.rand(B, 3, 96, 160, generator=g).to(DEV)
+            masks = torch.rand(B, N + 1, 96, 160, generator=g)
+            masks = (masks / masks.sum(1, keepdim=True)).to(DEV)
+            with torch.no_grad():
+                _, _, s16, _, _ = model('encode_key', frames)
+                seen = []
+                real = ops.conv2d
+
+                def spy(srcs, *a, **kw):
+                    seen.append(len(srcs))
+                    return real(srcs, *a, **kw)
+                ops.conv2d = spy
+                try:
+                    a = model('encode_value', frames, masks, s16)
+                finally:
+                    ops.conv2d = real
+                with ops.flags(SPLIT_SHARED_SOURCE=False):
+                    b = model('encode_value', frames, masks, s16)
+            # (ResNet-18: the block maps 256 + 256 -> 512 channels with an IDENTITY shortcut -- the concatenated tensor itself is the
+            # residual, networks.py:22-32 -- and keeps the one-launch form; ResNet-50: 256 + 1024 -> 512 with a downsample conv)
+            has_split = model.engine().fuse1_split is not None
+            assert has_split == (backbone == 'resnet50')
+            split_ran = has_split and N > 1
+            assert (2 in seen) == (not split_ran), (B, N, seen)   # the two-source (cat) launches are gone where objects share f16
+            assert a.shape == b.shape == (B, N, 512, 6, 10)
+            err = float((a - b).abs().max() / b.abs().max())
+            assert err < (1e-5 if split_ran else 1e-12), (math, B, N, err)
+            assert split_ran or torch.equal(a, b)
+
+
 @pytest.mark.parametrize('forks,fused', [('none', False), (None, False), ('none', True), ('none', 'em')],
                          ids=['linear_graph', 'forked_graph', 'fusion_conv_batched', 'em_and_matching_batched'])
 def test_lockstep_graph_matches_sequential_loops(lib, forks, fused):
