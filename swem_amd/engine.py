@@ -92,13 +92,26 @@ class _SharedSourceSplit:
         self.c1s = ops.pack_conv(w1[:, cx:], None)
         self.dx = ops.pack_conv(wd[:, :cx], rb.downsample.bias)
         self.ds = ops.pack_conv(wd[:, cx:], None)
+        # both shared halves as ONE convolution (conv1's filters, then the downsample's): valid where relu(f16) = f16
+        self.cs = ops.pack_conv(torch.cat([w1[:, cx:], wd[:, cx:]], dim=0), None)
+        self.cout = w1.shape[0]
 
     def __call__(self, x, shared, n, c2):
         """x (B*n,h,w,cx) per object, shared (B,h,w,cs) per clip, c2: the block's second conv pack."""
-        rs1 = ops.conv2d([shared], self.c1s, relu_in=True)
-        rs2 = ops.conv2d([shared], self.ds)
-        if shared.shape[0] > 1:
-            rs1, rs2 = per_object(rs1, n), per_object(rs2, n)
+        if ops.SPLIT_SHARED_MERGE and shared.__dict__.get('_swem_nonneg') == shared._version:
+            # f16 as THIS engine's key encoder wrote it ends in a ReLU (mod_resnet.py:108-113): relu(f16) = f16, so conv1's and the
+            # downsample's shared halves read the same input and run as one launch with twice the output columns
+            rs = ops.conv2d([shared], self.cs)
+            rs1, rs2 = rs[..., :self.cout], rs[..., self.cout:]
+            if shared.shape[0] > 1:
+                rs1, rs2 = per_object(rs1, n), per_object(rs2, n)
+            else:
+                rs1, rs2 = rs1.contiguous(), rs2.contiguous()
+        else:
+            rs1 = ops.conv2d([shared], self.c1s, relu_in=True)
+            rs2 = ops.conv2d([shared], self.ds)
+            if shared.shape[0] > 1:
+                rs1, rs2 = per_object(rs1, n), per_object(rs2, n)
         r = ops.conv2d([x], self.c1x, relu_in=True, residual=rs1, planes_only=True)     # (only conv2 reads it)
         res = ops.conv2d([x], self.dx, residual=rs2)
         return ops.conv2d([r], c2, relu_in=True, residual=res)
@@ -187,6 +200,7 @@ class Engine:
                 t_.__dict__['_swem_skip'] = (ops.conv2d([t_], pk), t_._version, self)
         qk16 = ops.conv2d([s16], self.key_proj)
         qv16 = ops.conv2d([s16], self.key_comp)
+        s16.__dict__['_swem_nonneg'] = s16._version       # (the trunk's last block ends in a ReLU: _SharedSourceSplit)
         return qk16, qv16, s16, s8, s4
 
     # swem.py:45-62 + networks.py:113-129, 43-50

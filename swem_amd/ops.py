@@ -351,6 +351,8 @@ def graph_capture_kwargs():
 # engine.py, _SharedSourceSplit: the clip's key feature split off the value encoder's fusion block (computed once per clip, not per
 # object).  SWEM_SPLIT_SHARED=0 / False: the one-launch form of rounds 1-5.
 SPLIT_SHARED_SOURCE = os.environ.get('SWEM_SPLIT_SHARED', '1') != '0'
+# ... and its two per-clip halves (conv1's, the downsample's) as ONE launch where the shared feature is known to be non-negative
+SPLIT_SHARED_MERGE = os.environ.get('SWEM_SPLIT_SHARED_MERGE', '1') != '0'
 
 
 def new_stream():
@@ -837,6 +839,8 @@ def batch_item(t, j, n=1):
         v.__dict__['_swem_site'] = d['_swem_site']
     if d.get('_swem_planes_only'):
         v.__dict__['_swem_planes_only'] = True
+    if d.get('_swem_nonneg', -1) == t._version:
+        v.__dict__['_swem_nonneg'] = v._version
     sk = d.get('_swem_skip')              # (the decoder's skip convolution of this feature map, computed in the key pass)
     if sk is not None and sk[1] == t._version:
         v.__dict__['_swem_skip'] = (batch_item(sk[0], j, n), v._version, sk[2])

@@ -707,6 +707,13 @@ def test_shared_source_split_of_the_fusion_block(lib, backbone):
                     ops.conv2d = real
                 with ops.flags(SPLIT_SHARED_SOURCE=False):
                     b = model('encode_value', frames, masks, s16)
+                # a key feature that does not come with the encoder's "ends in a ReLU" tag (a caller's own tensor: it may be
+                # negative) takes the two-launch form of the split, input ReLU on conv1's half only
+                neg = s16.clone() - 0.3
+                a2 = model('encode_value', frames, masks, neg)
+                with ops.flags(SPLIT_SHARED_SOURCE=False):
+                    b2 = model('encode_value', frames, masks, neg)
+            assert float((a2 - b2).abs().max() / b2.abs().max()) < 1e-5, (math, B, N)
             # (ResNet-18: the block maps 256 + 256 -> 512 channels with an IDENTITY shortcut -- the concatenated tensor itself is the
             # residual, networks.py:22-32 -- and keeps the one-launch form; ResNet-50: 256 + 1024 -> 512 with a downsample conv)
             has_split = model.engine().fuse1_split is not None
